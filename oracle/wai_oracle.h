@@ -1,0 +1,149 @@
+/* wai_oracle.h -- CPU restatement of Waiwera's Newton-step hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is imported, linked or executed by the
+ * product (waiwera_amd/, include/).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load liboracle.so, and there only as the checker / reported baseline.
+ *
+ * Parity pinning: every kernel-level function here is checked in tests/test_oracle_golden.py
+ * against the known-answer values the reference's own unit tests hold (the JSON files in tests/golden,
+ * transcribed from /root/reference/test/unit/src/{IAPWS,face,cell,eos_we,eos_w,
+ * relative_permeability,capillary_pressure,root_finder}_test.F90 and the 12-cell lhs.h5
+ * fixture).  The reference itself is NOT buildable in this image (it needs PETSc 3.22.5 headers
+ * and modules, fson, and a gfortran-class toolchain; writing stand-ins for those is not
+ * permitted), so there is no oracle/_ref.  The linear-algebra half (BAIJ SpMV, block ILU(0),
+ * BiCGStab/GMRES, SNES newtonls) lives in PETSc, which is not vendored under /root/reference:
+ * for those functions parity is UNPINNED at the iterate level; they restate PETSc's published
+ * algorithms and are cross-checked against scipy on the same operators (tests/).
+ *
+ * Layouts follow the reference exactly (AoS):
+ *   fluid record  : src/fluid.F90:36-52,212-267   [P,T,region,old_region,phases,perm_factor,
+ *                    Pp(nc)] + per phase [rho,mu,S,kr,Pc,h,u,X(nc)]
+ *   rock record   : src/rock.F90:56-65,97-112      [k1,k2,k3,wet_cond,dry_cond,phi,rho_r,c_r]
+ *   cell geometry : src/cell.F90:54-61,85-96       [centroid(3), volume]
+ *   face geometry : src/face.F90:67-76,119-135     [area,d1,d2,d12,n(3),g.n,centroid(3),dir]
+ */
+#ifndef WAI_ORACLE_H
+#define WAI_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- thermodynamics (src/IAPWS.F90) ---------------------------------------------------- */
+int wo_region1(double p, double t, double *rho, double *u);       /* :503-542 */
+int wo_region2(double p, double t, double *rho, double *u);       /* :596-639 */
+int wo_sat_pressure(double t, double *p);                          /* :762-789 */
+int wo_sat_temperature(double p, double *t);                       /* :793-818 */
+double wo_viscosity(double t, double rho);                         /* :412-443 */
+int wo_phase_composition(int region, double p, double t);          /* :317-365 */
+
+/* ---- curves (src/relative_permeability.F90, src/capillary_pressure.F90) ---------------- */
+enum { WO_RP_FULLY_MOBILE = 0, WO_RP_LINEAR = 1, WO_RP_PICKENS = 2, WO_RP_COREY = 3,
+       WO_RP_GRANT = 4, WO_RP_VAN_GENUCHTEN = 5 };
+enum { WO_CP_ZERO = 0, WO_CP_LINEAR = 1, WO_CP_VAN_GENUCHTEN = 2 };
+void wo_relperm(int type, const double *par, double sl, double rp[2]);
+double wo_capillary(int type, const double *par, double sl, double t);
+
+/* ---- root finder (src/root_finder.F90:127-248) ----------------------------------------- */
+typedef double (*wo_rootfn)(double x, void *ctx);
+int wo_brent(wo_rootfn f, void *ctx, double a, double b, double xtol, double ftol, int maxit,
+             double *root, int *iters);
+
+/* ---- EOS (src/eos.F90, src/eos_w.F90, src/eos_we.F90) ----------------------------------- */
+enum { WO_EOS_W = 0, WO_EOS_WE = 1 };
+typedef struct wo_eos {
+  int kind, np, nc, nph, nmob, df, isothermal;
+  double temperature;          /* eos_w only (eos_w.F90:97-98) */
+  double scale[5][4];          /* primary_scale(var, region), region 1..4 */
+  int rp_type, cp_type;
+  double rp_par[6], cp_par[6];
+} wo_eos;
+void wo_eos_init(wo_eos *e, int kind);
+void wo_eos_unscale(const wo_eos *e, const double *y, int region, double *primary);
+void wo_eos_scale(const wo_eos *e, const double *primary, int region, double *y);
+int wo_eos_bulk_properties(const wo_eos *e, const double *primary, double *fluid);
+int wo_eos_phase_properties(const wo_eos *e, const double *primary, double *fluid);
+int wo_eos_transition(const wo_eos *e, const double *old_primary, double *primary,
+                      const double *old_fluid, double *fluid, int *transition);
+int wo_eos_check_primary(const wo_eos *e, const double *fluid, const double *primary);
+
+/* ---- cell / face kernels (src/cell.F90:114-142, src/face.F90:443-515) ------------------ */
+void wo_cell_balance(const wo_eos *e, const double *fluid, const double *rock, double *bal);
+void wo_face_flux(const wo_eos *e, const double *fgeom, const double *fluid1,
+                  const double *rock1, const double *fluid2, const double *rock2,
+                  double *flux /* np + nmob */);
+double wo_face_phase_density(const wo_eos *e, const double *fluid1, const double *fluid2, int p);
+double wo_harmonic_average(const double *fgeom, double x1, double x2);
+double wo_conductivity(const double *rock, const double *fluid, const wo_eos *e);
+
+/* ---- block-sparse linear algebra (PETSc BAIJ / PCILU / KSP restated) -------------------- */
+void wo_bcsr_spmv(int n, int bs, const int *rowptr, const int *colidx, const double *val,
+                  const double *x, double *y);
+/* block-Jacobi ILU(0): subdomain s owns rows [sub_ptr[s], sub_ptr[s+1]); couplings leaving a
+ * subdomain are dropped from the factor.  fval has A's pattern, dinv holds inverted pivots. */
+int wo_bilu0_factor(int n, int bs, const int *rowptr, const int *colidx, const double *val,
+                    int nsub, const int *sub_ptr, double *fval, double *dinv);
+void wo_bilu0_apply(int n, int bs, const int *rowptr, const int *colidx, const double *fval,
+                    const double *dinv, int nsub, const int *sub_ptr, const double *r,
+                    double *z);
+
+/* communication hooks for the distributed (gloo) tests; all NULL on one rank */
+typedef void (*wo_halo_fn)(void *user, double *vec, int dof);
+typedef void (*wo_allreduce_fn)(void *user, double *vals, int n, int op /*0 sum,1 max,2 min*/);
+
+/* ---- simulation object ------------------------------------------------------------------ */
+typedef struct wo_sim wo_sim;
+wo_sim *wo_sim_create(int eos_kind, int n_owned, int n_halo, int n_bc, int n_faces,
+                      const int *face_cells, const double *face_geom, const double *cell_geom,
+                      const double *rock);
+void wo_sim_destroy(wo_sim *s);
+wo_eos *wo_sim_eos(wo_sim *s);
+void wo_sim_set_comm(wo_sim *s, wo_halo_fn halo, wo_allreduce_fn ar, void *user);
+void wo_sim_set_sources(wo_sim *s, int n, const int *cell, const double *rate,
+                        const double *enthalpy, const int *component);
+void wo_sim_set_subdomains(wo_sim *s, int nsub, const int *sub_ptr);
+void wo_sim_set_regions(wo_sim *s, const int *region /* n_owned+n_halo */);
+void wo_sim_get_regions(wo_sim *s, int *region);
+int wo_sim_init_bc(wo_sim *s, const double *primary /* unscaled, n_bc*np */, const int *region);
+double *wo_sim_fluid(wo_sim *s);      /* (n_owned+n_halo+n_bc) * df */
+int wo_sim_nnzb(wo_sim *s);
+void wo_sim_pattern(wo_sim *s, int *rowptr, int *colidx);
+
+/* ode_type surface (src/ode.F90:39-108, src/flow_simulation.F90) */
+void wo_pre_timestep(wo_sim *s);                                     /* :2022-2035 */
+void wo_pre_retry_timestep(wo_sim *s);                               /* :2093-2104 */
+void wo_pre_iteration(wo_sim *s);                                    /* :2108-2122 */
+int wo_pre_eval(wo_sim *s, double *y);                               /* :2126-2147, 2291-2415 */
+void wo_lhs(wo_sim *s, double *lhs);                                 /* :1242-1330 */
+void wo_rhs(wo_sim *s, double *rhs);                                 /* :1334-1485 */
+int wo_residual(wo_sim *s, double *y, double dt, const double *lhs_old, double *f);
+int wo_post_linesearch(wo_sim *s, const double *y_old, double *search, double *y,
+                       int *changed_search, int *changed_y);         /* :2419-2576 */
+/* FD Jacobian (timestepper.F90:1584-1611); mode 0 = per-row local differencing,
+ * mode 1 = literal coloured full-residual differencing (MatFDColoringApply, "ds" steps) */
+int wo_jacobian(wo_sim *s, double *y, double dt, const double *lhs_old, const double *f,
+                int mode, double *val);
+void wo_max_scaled(wo_sim *s, const double *v, const double *scale, double tol, double *maxval,
+                   int *maxloc);                                     /* dm_utils.F90:644-685 */
+
+/* KSP restated: 0 = bcgs (left PC, PETSc KSPBCGS), 1 = gmres(restart) left PC, CGS */
+int wo_ksp_solve(wo_sim *s, int ksp_type, int restart, const double *val, const double *b,
+                 double *x, double rtol, double atol, int maxits, int *its, double *rnorm,
+                 double *hist /* maxits+1 or NULL */);
+
+/* one Newton iteration of timestepper.F90:587-735 + 1898-1951.  Returns reason:
+ *  0 iterating, 1 converged (function), 2 converged (update), <0 diverged/domain error */
+typedef struct wo_newton_opts {
+  int ksp_type, restart, ksp_maxits, max_newton_its, jac_mode;
+  double ksp_rtol, ksp_atol, ftol_rel, ftol_abs, utol_rel, utol_abs, fd_eps, fd_umin;
+} wo_newton_opts;
+void wo_newton_opts_default(wo_newton_opts *o);
+int wo_newton_step(wo_sim *s, const wo_newton_opts *o, int iter, double dt, double *y,
+                   const double *lhs_old, double *f, int *ksp_its, double *max_residual);
+/* whole backward-Euler step: SNESSolve loop; y in/out.  Returns newton its (>0) or -reason */
+int wo_timestep(wo_sim *s, const wo_newton_opts *o, double dt, double *y, int *total_ksp_its);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

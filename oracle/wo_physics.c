@@ -1,0 +1,540 @@
+/* wo_physics.c -- CPU restatement of Waiwera's per-cell / per-face arithmetic.
+ *
+ * TEST INFRASTRUCTURE ONLY (see wai_oracle.h).  Plain C, fp64, written to be read next to the
+ * reference: every function cites the reference lines it follows.
+ */
+#include "wai_oracle.h"
+#include "if97_tables.h"
+#include <math.h>
+#include <string.h>
+
+#define TC_K 273.15            /* src/thermodynamics.F90:37 */
+#define RCONST 0.461526e3      /* src/thermodynamics.F90:36 */
+#define TCRITICALK 647.096     /* src/IAPWS.F90:273 */
+#define TCRITICAL (TCRITICALK - TC_K)
+#define PCRITICAL 22.064e6     /* src/IAPWS.F90:275 */
+#define DCRITICAL 322.0        /* src/IAPWS.F90:276 */
+
+/* integer power by repeated multiplication.  The reference evaluates the same powers through a
+ * precomputed addition chain (src/powertable.F90:261-278); both are products of the same
+ * factors and agree to a few ulp -- well inside the 1e-7 tolerance of IAPWS_test.F90:57. */
+static double ipow(double x, int n) {
+  if (n < 0) { x = 1.0 / x; n = -n; }
+  double r = 1.0;
+  while (n) {
+    if (n & 1) r *= x;
+    x *= x;
+    n >>= 1;
+  }
+  return r;
+}
+
+/* src/IAPWS.F90:503-542 */
+int wo_region1(double p, double t, double *rho, double *u) {
+  if (!((t <= 350.0) && (p <= 100.e6))) return 1;
+  const double pstar = 16.53e6, tstar = 1386.0;
+  double tk = t + TC_K, rt = RCONST * tk, pi = p / pstar, tau = tstar / tk;
+  double a = 7.1 - pi, b = tau - 1.222;
+  double gampi = 0.0, gamt = 0.0;
+  for (int i = 0; i < 34; i++) {
+    int I = WO_R1_I[i], J = WO_R1_J[i];
+    gampi += (WO_R1_N[i] * I) * ipow(a, I - 1) * ipow(b, J);
+    gamt += (WO_R1_N[i] * J) * ipow(a, I) * ipow(b, J - 1);
+  }
+  gampi = -gampi;
+  *rho = pstar / (rt * gampi);
+  *u = rt * (tau * gamt - pi * gampi);
+  return 0;
+}
+
+/* src/IAPWS.F90:596-639 */
+int wo_region2(double p, double t, double *rho, double *u) {
+  if (!((t <= 800.0) && (p <= 100.e6))) return 1;
+  const double pstar = 1.0e6, tstar = 540.0;
+  double tk = t + TC_K, rt = RCONST * tk, pi = p / pstar, tau = tstar / tk;
+  double b = tau - 0.5;
+  double gamt0 = 0.0, gampir = 0.0, gamtr = 0.0;
+  for (int i = 0; i < 9; i++)
+    gamt0 += (WO_R2_N0[i] * WO_R2_J0[i]) * ipow(tau, WO_R2_J0[i] - 1);
+  for (int i = 0; i < 43; i++) {
+    int I = WO_R2_I[i], J = WO_R2_J[i];
+    gampir += (WO_R2_N[i] * I) * ipow(pi, I - 1) * ipow(b, J);
+    gamtr += (WO_R2_N[i] * J) * ipow(pi, I) * ipow(b, J - 1);
+  }
+  double gampi = 1.0 / pi + gampir;
+  *rho = pstar / (rt * gampi);
+  *u = rt * (tau * (gamt0 + gamtr) - pi * gampi);
+  return 0;
+}
+
+/* src/IAPWS.F90:762-789 */
+int wo_sat_pressure(double t, double *p) {
+  if (!((t >= 0.0) && (t <= TCRITICAL))) return 1;
+  const double *n = WO_SAT_N - 1; /* 1-based like the formulation */
+  double tk = t + TC_K;
+  double theta = tk + n[9] / (tk - n[10]);
+  double theta2 = theta * theta;
+  double a = theta2 + n[1] * theta + n[2];
+  double b = n[3] * theta2 + n[4] * theta + n[5];
+  double c = n[6] * theta2 + n[7] * theta + n[8];
+  double x = 2.0 * c / (-b + sqrt(b * b - 4.0 * a * c));
+  x = x * x;
+  *p = 1.0e6 * x * x;
+  return 0;
+}
+
+/* src/IAPWS.F90:793-818 */
+int wo_sat_temperature(double p, double *t) {
+  if (!((p >= 611.213) && (p <= PCRITICAL))) return 1;
+  const double *n = WO_SAT_N - 1;
+  double beta2 = sqrt(p / 1.0e6);
+  double beta = sqrt(beta2);
+  double e = beta2 + n[3] * beta + n[6];
+  double f = n[1] * beta2 + n[4] * beta + n[7];
+  double g = n[2] * beta2 + n[5] * beta + n[8];
+  double d = 2.0 * g / (-f - sqrt(f * f - 4.0 * e * g));
+  double x = n[10] + d;
+  *t = 0.5 * (n[10] + d - sqrt(x * x - 4.0 * (n[9] + n[10] * d))) - TC_K;
+  return 0;
+}
+
+/* src/IAPWS.F90:412-443 */
+double wo_viscosity(double t, double rho) {
+  double tk = t + TC_K, tau = tk / TCRITICALK, del = rho / DCRITICAL;
+  double it = 1.0 / tau;
+  double s0 = 0.0;
+  for (int k = 0; k < 4; k++) s0 += WO_VISC_H0[k] * ipow(it, k);
+  double mu0 = 100.0 * sqrt(tau) / s0;
+  double a = it - 1.0, b = del - 1.0, s1 = 0.0;
+  for (int i = 0; i < 21; i++)
+    s1 += ipow(a, WO_VISC_I[i]) * WO_VISC_H1[i] * ipow(b, WO_VISC_J[i]);
+  double mu1 = exp(del * s1);
+  return 1.0e-6 * mu0 * mu1;
+}
+
+/* src/IAPWS.F90:317-365 */
+int wo_phase_composition(int region, double p, double t) {
+  if (region == 4) return 3;
+  if (t <= TCRITICAL) {
+    if (region == 1) return 1;
+    if (region == 2) return 2;
+    if (region == 3) {
+      double ps;
+      if (wo_sat_pressure(t, &ps) == 0) return (p >= ps) ? 1 : 2;
+      return -1;
+    }
+    return 0;
+  }
+  return (p <= PCRITICAL) ? 2 : 4;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* two-point table lookup with end clamping: interpolation_table "interpolate" on a 2-row table
+ * (src/interpolation.F90:202-222 index rule, :388-404 linear interpolant, :494-510 clamping) */
+static double lin2(double x, double x0, double x1, double y0, double y1) {
+  if (x <= x0) return y0;
+  if (x >= x1) return y1;
+  double xi = (x - x0) / (x1 - x0);
+  return (1.0 - xi) * y0 + xi * y1;
+}
+
+/* src/relative_permeability.F90:197-492.  par: linear [l0,l1,v0,v1]; pickens [power];
+ * corey/grant [slr,ssr]; van Genuchten [lambda,slr,sls,sum_unity,ssr] */
+void wo_relperm(int type, const double *par, double sl, double rp[2]) {
+  switch (type) {
+  case WO_RP_FULLY_MOBILE:
+    rp[0] = 1.0; rp[1] = 1.0; break;
+  case WO_RP_LINEAR:
+    rp[0] = lin2(sl, par[0], par[1], 0.0, 1.0);
+    rp[1] = lin2(1.0 - sl, par[2], par[3], 0.0, 1.0);
+    break;
+  case WO_RP_PICKENS:
+    rp[0] = pow(sl, par[0]); rp[1] = 1.0; break;
+  case WO_RP_COREY:
+  case WO_RP_GRANT: {
+    double slr = par[0], ssr = par[1], sv = 1.0 - sl;
+    if (sv < ssr) { rp[0] = 1.0; rp[1] = 0.0; }
+    else if (sv > 1.0 - slr) { rp[0] = 0.0; rp[1] = 1.0; }
+    else {
+      double ss = (sl - slr) / (1.0 - slr - ssr), ss2 = ss * ss;
+      rp[0] = ss2 * ss2;
+      if (type == WO_RP_COREY) rp[1] = (1.0 - 2.0 * ss + ss2) * (1.0 - ss2);
+      else rp[1] = 1.0 - rp[0];
+    }
+  } break;
+  case WO_RP_VAN_GENUCHTEN: {
+    double lambda = par[0], slr = par[1], sls = par[2];
+    int sum_unity = (par[3] != 0.0);
+    double ssr = par[4];
+    double ss = (sl - slr) / (sls - slr);
+    if (ss < 0.0) rp[0] = 0.0;
+    else if (ss < 1.0) {
+      double w = 1.0 - pow(1.0 - pow(ss, 1.0 / lambda), lambda);
+      rp[0] = sqrt(ss) * w * w;
+    } else rp[0] = 1.0;
+    if (sum_unity) rp[1] = 1.0 - rp[0];
+    else {
+      double sh = (sl - slr) / (1.0 - slr - ssr), sh2 = sh * sh;
+      rp[1] = (1.0 - 2.0 * sh + sh2) * (1.0 - sh2);
+      if (rp[1] > 1.0) rp[1] = 1.0;
+    }
+  } break;
+  default:
+    rp[0] = rp[1] = 0.0;
+  }
+}
+
+/* src/capillary_pressure.F90:159-305.  par: linear [s0,s1,pressure];
+ * van Genuchten [P0,lambda,slr,sls,Pmax,apply_Pmax] */
+double wo_capillary(int type, const double *par, double sl, double t) {
+  (void)t;
+  switch (type) {
+  case WO_CP_ZERO: return 0.0;
+  case WO_CP_LINEAR: return lin2(sl, par[0], par[1], -fabs(par[2]), 0.0);
+  case WO_CP_VAN_GENUCHTEN: {
+    const double eps = 1.e-3;
+    double P0 = fabs(par[0]), lambda = par[1], slr = par[2], sls = par[3];
+    double Pmax = fabs(par[4]);
+    int apply_Pmax = (par[5] != 0.0);
+    double cp;
+    if (sl < 1.0) {
+      double ss = (sl - slr) / (sls - slr);
+      if (ss < 0.0) cp = -Pmax;
+      else if (ss < 1.0) cp = -P0 * pow(pow(ss, -1.0 / lambda) - 1.0, 1.0 - lambda);
+      else cp = 0.0;
+      if (cp > 0.0) cp = 0.0;
+      if (apply_Pmax && cp < -Pmax) cp = -Pmax;
+      if (sl > 1.0 - eps) cp = cp * (1.0 - sl) / eps;
+    } else cp = 0.0;
+    return cp;
+  }
+  }
+  return 0.0;
+}
+
+/* Brent's method (Press et al., Numerical Recipes, zbrent), as the reference uses it:
+ * src/root_finder.F90:127-248.  Returns 0 ok, 1 not bracketed, 2 iterations exceeded. */
+int wo_brent(wo_rootfn f, void *ctx, double a, double b, double xtol, double ftol, int maxit,
+             double *root, int *iters) {
+  const double small = 1.e-16;
+  double fa = f(a, ctx), fb = f(b, ctx);
+  *root = 0.0;
+  if (iters) *iters = 0;
+  if (fa * fb > 0.0) return 1;
+  double c = b, fc = fb, d = 0.0, e = 0.0;
+  int found = 0, iter;
+  for (iter = 1; iter <= maxit; iter++) {
+    if (fb * fc > 0.0) { c = a; fc = fa; d = b - a; e = d; }
+    if (fabs(fc) < fabs(fb)) { a = b; b = c; c = a; fa = fb; fb = fc; fc = fa; }
+    double dx = 0.5 * (c - b);
+    if (fabs(dx) <= xtol || fabs(fb) <= ftol) { found = 1; break; }
+    if (fabs(e) >= xtol && fabs(fa) > fabs(fb)) {
+      double s = fb / fa, p, q;
+      if (fabs(a - c) <= small) { p = 2.0 * dx * s; q = 1.0 - s; }
+      else {
+        q = fa / fc;
+        double r = fb / fc;
+        p = s * (2.0 * dx * q * (q - r) - (b - a) * (r - 1.0));
+        q = (q - 1.0) * (r - 1.0) * (s - 1.0);
+      }
+      if (p > 0.0) q = -q; else p = -p;
+      double pc1 = 3.0 * dx * q - fabs(xtol * q), pc2 = fabs(e * q);
+      double pc = pc1 < pc2 ? pc1 : pc2;
+      if (2.0 * p < pc) { e = d; d = p / q; }
+      else { d = dx; e = d; }
+    } else { d = dx; e = d; }
+    a = b; fa = fb;
+    if (fabs(d) > xtol) b += d;
+    else b += (dx >= 0.0 ? fabs(xtol) : -fabs(xtol));
+    fb = f(b, ctx);
+  }
+  *root = b;
+  if (iters) *iters = iter;
+  return found ? 0 : 2;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* fluid record offsets (src/fluid.F90:212-267) */
+#define F_P 0
+#define F_T 1
+#define F_REGION 2
+#define F_OLD_REGION 3
+#define F_PHASES 4
+#define F_PERMFAC 5
+#define F_PP 6
+#define PH_RHO 0
+#define PH_MU 1
+#define PH_SAT 2
+#define PH_KR 3
+#define PH_PC 4
+#define PH_H 5
+#define PH_U 6
+#define PH_X 7
+static inline int phase_off(const wo_eos *e, int p) { return (7 + e->nc - 1) + p * (8 + e->nc - 1); }
+
+void wo_eos_init(wo_eos *e, int kind) {
+  memset(e, 0, sizeof(*e));
+  e->kind = kind;
+  e->nc = 1;
+  e->temperature = 20.0;
+  if (kind == WO_EOS_W) { /* src/eos_w.F90:50-99 */
+    e->np = 1; e->nph = 1; e->nmob = 1; e->isothermal = 1;
+    e->scale[1][0] = 1.e6; e->scale[2][0] = 1.e6;
+  } else {                /* src/eos_we.F90:56-126 */
+    e->np = 2; e->nph = 2; e->nmob = 2; e->isothermal = 0;
+    e->scale[1][0] = 1.e6; e->scale[1][1] = 1.e2;
+    e->scale[2][0] = 1.e6; e->scale[2][1] = 1.e2;
+    e->scale[4][0] = 1.e6; e->scale[4][1] = 1.0;
+  }
+  e->df = (7 + e->nc - 1) + e->nph * (8 + e->nc - 1);
+  /* reference defaults: linear [0,1]/[0,1] rel perm, zero Pc
+   * (relative_permeability.F90:225-226,591; capillary_pressure.F90:389) */
+  e->rp_type = WO_RP_LINEAR;
+  e->rp_par[0] = 0.0; e->rp_par[1] = 1.0; e->rp_par[2] = 0.0; e->rp_par[3] = 1.0;
+  e->cp_type = WO_CP_ZERO;
+}
+
+/* src/eos.F90:186-210 */
+void wo_eos_unscale(const wo_eos *e, const double *y, int region, double *primary) {
+  for (int k = 0; k < e->np; k++) primary[k] = y[k] * e->scale[region][k];
+}
+void wo_eos_scale(const wo_eos *e, const double *primary, int region, double *y) {
+  for (int k = 0; k < e->np; k++) y[k] = primary[k] / e->scale[region][k];
+}
+
+/* src/eos_we.F90:327-390 (we), src/eos_w.F90:126-147 (w); phase composition eos.F90:214-236 */
+int wo_eos_bulk_properties(const wo_eos *e, const double *primary, double *fl) {
+  int region = (int)lround(fl[F_REGION]);
+  int err = 0;
+  fl[F_P] = primary[0];
+  if (e->kind == WO_EOS_W) {
+    fl[F_T] = e->temperature;
+    fl[phase_off(e, 0) + PH_SAT] = 1.0;
+    int ph = wo_phase_composition(region, fl[F_P], fl[F_T]);
+    if (ph > 0) fl[F_PHASES] = (double)ph; else err = 1;
+    fl[F_PERMFAC] = 1.0;
+    fl[F_PP] = fl[F_P];
+    return err;
+  }
+  if (region == 4) {
+    double t;
+    err = wo_sat_temperature(fl[F_P], &t);
+    if (err == 0) fl[F_T] = t;
+  } else fl[F_T] = primary[1];
+  if (err) return err;
+  fl[F_PERMFAC] = 1.0;
+  int ph = wo_phase_composition(region, fl[F_P], fl[F_T]);
+  if (ph <= 0) return 1;
+  fl[F_PHASES] = (double)ph;
+  double *l = fl + phase_off(e, 0), *v = fl + phase_off(e, 1);
+  switch (region) {
+  case 1: l[PH_SAT] = 1.0; v[PH_SAT] = 0.0; break;
+  case 2: l[PH_SAT] = 0.0; v[PH_SAT] = 1.0; break;
+  case 4: l[PH_SAT] = 1.0 - primary[1]; v[PH_SAT] = primary[1]; break;
+  }
+  fl[F_PP] = fl[F_P];
+  return 0;
+}
+
+/* src/eos_we.F90:394-458 (we), src/eos_w.F90:168-213 (w) */
+int wo_eos_phase_properties(const wo_eos *e, const double *primary, double *fl) {
+  (void)primary;
+  double P = fl[F_P], T = fl[F_T];
+  if (e->kind == WO_EOS_W) {
+    int p = (int)lround(fl[F_REGION]); /* region 1 -> liquid, the only phase */
+    double *ph = fl + phase_off(e, 0);
+    double rho, u;
+    int err = (p == 1) ? wo_region1(P, T, &rho, &u) : wo_region2(P, T, &rho, &u);
+    if (err) return err;
+    ph[PH_RHO] = rho; ph[PH_U] = u; ph[PH_H] = u + P / rho;
+    ph[PH_KR] = 1.0; ph[PH_PC] = 0.0; ph[PH_X] = 1.0;
+    ph[PH_MU] = wo_viscosity(T, rho);
+    return 0;
+  }
+  int phases = (int)lround(fl[F_PHASES]);
+  double sl = fl[phase_off(e, 0) + PH_SAT];
+  double rp[2], cp[2];
+  wo_relperm(e->rp_type, e->rp_par, sl, rp);
+  cp[0] = wo_capillary(e->cp_type, e->cp_par, sl, T);
+  cp[1] = 0.0;
+  for (int p = 0; p < e->nph; p++) {
+    double *ph = fl + phase_off(e, p);
+    if (phases & (1 << p)) {
+      double rho, u;
+      int err = (p == 0) ? wo_region1(P, T, &rho, &u) : wo_region2(P, T, &rho, &u);
+      if (err) return err;
+      ph[PH_RHO] = rho; ph[PH_U] = u; ph[PH_H] = u + P / rho;
+      ph[PH_X] = 1.0; ph[PH_KR] = rp[p]; ph[PH_PC] = cp[p];
+      ph[PH_MU] = wo_viscosity(T, rho);
+    } else {
+      ph[PH_RHO] = 0.0; ph[PH_U] = 0.0; ph[PH_H] = 0.0; ph[PH_KR] = 0.0;
+      ph[PH_PC] = 0.0; ph[PH_MU] = 0.0; ph[PH_X] = 0.0;
+    }
+  }
+  return 0;
+}
+
+/* saturation-line difference along the old->new primary segment: src/eos_we.F90:530-553 */
+typedef struct { double p0, t0, p1, t1; } satline_ctx;
+static double satline_diff(double x, void *vc) {
+  satline_ctx *c = (satline_ctx *)vc;
+  double P = (1.0 - x) * c->p0 + x * c->p1, T = (1.0 - x) * c->t0 + x * c->t1, Ps = 0.0;
+  wo_sat_pressure(T, &Ps); /* error ignored, as the reference does */
+  return P - Ps;
+}
+
+/* src/eos_we.F90:149-323; eos_w has no transitions (eos_w.F90:103-122) */
+int wo_eos_transition(const wo_eos *e, const double *oldp, double *prim, const double *old_fluid,
+                      double *fluid, int *transition) {
+  *transition = 0;
+  if (e->kind == WO_EOS_W) return 0;
+  const double small = 1.e-6;
+  int old_region = (int)lround(old_fluid[F_REGION]);
+  int err = 0;
+  if (old_region == 4) {
+    double sv = prim[1];
+    int new_region = 0;
+    if (sv < 0.0) new_region = 1; else if (sv > 1.0) new_region = 2;
+    if (!new_region) return 0;
+    double bound = (new_region == 1) ? 0.0 : 1.0;
+    double pfac = (new_region == 1) ? 1.0 + small : 1.0 - small;
+    /* linear inverse interpolant on component 2: src/interpolation.F90:407-435 */
+    double v1 = oldp[1], v2 = prim[1];
+    double vmax = fmax(fabs(v1), fabs(v2));
+    int ierr = 0;
+    double xi = 0.0;
+    if (fabs(v2 - v1) >= 1.e-8 * vmax) {
+      double vs1 = v1 / vmax, vs2 = v2 / vmax, ys = bound / vmax;
+      xi = (ys - vs1) / (vs2 - vs1);
+      xi = (1.0 - xi) * 0.0 + xi * 1.0;
+    } else ierr = 1;
+    if (ierr == 0) {
+      /* interpolate(xi) clamps outside [0,1] (interpolation.F90:214-217,494-510) */
+      double ip;
+      if (xi <= 0.0) ip = oldp[0];
+      else if (xi >= 1.0) ip = prim[0];
+      else ip = (1.0 - xi) * oldp[0] + xi * prim[0];
+      prim[0] = pfac * ip;
+      double t;
+      err = wo_sat_temperature(ip, &t);
+      if (err == 0) { prim[1] = t; fluid[F_REGION] = (double)new_region; *transition = 1; }
+    } else {
+      double ps;
+      err = wo_sat_pressure(old_fluid[F_T], &ps);
+      if (err == 0) {
+        prim[0] = pfac * ps;
+        prim[1] = old_fluid[F_T];
+        fluid[F_REGION] = (double)new_region;
+        *transition = 1;
+      }
+    }
+    return err;
+  }
+  double ps;
+  err = wo_sat_pressure(prim[1], &ps);
+  if (err) return err;
+  if ((old_region == 1 && prim[0] < ps) || (old_region == 2 && prim[0] > ps)) {
+    satline_ctx c = {oldp[0], oldp[1], prim[0], prim[1]};
+    double root;
+    int it;
+    int rerr = wo_brent(satline_diff, &c, 0.0, 1.0, 1.e-8, 1.e-8, 100, &root, &it);
+    if (rerr == 0) {
+      double xi = root, ip;
+      if (xi <= 0.0) ip = oldp[0];
+      else if (xi >= 1.0) ip = prim[0];
+      else ip = (1.0 - xi) * oldp[0] + xi * prim[0];
+      prim[0] = ip;
+    } else prim[0] = ps;
+    prim[1] = (old_region == 1) ? small : 1.0 - small;
+    fluid[F_REGION] = 4.0;
+    *transition = 1;
+  }
+  return 0;
+}
+
+/* src/eos_we.F90:486-526, src/eos_w.F90:232-255 */
+int wo_eos_check_primary(const wo_eos *e, const double *fluid, const double *prim) {
+  double p = prim[0];
+  if (p < 0.0 || p > 100.e6) return 1;
+  if (e->kind == WO_EOS_W) return 0;
+  int region = (int)lround(fluid[F_REGION]);
+  if (region == 4) {
+    if (prim[1] < -1.0 || prim[1] > 2.0) return 1;
+  } else if (prim[1] < 0.0 || prim[1] > 800.0) return 1;
+  return 0;
+}
+
+/* src/cell.F90:114-142 with fluid.F90:295-315, :354-370 and rock.F90:142-150 */
+void wo_cell_balance(const wo_eos *e, const double *fl, const double *rock, double *bal) {
+  double phi = rock[5];
+  for (int c = 0; c < e->nc; c++) bal[c] = 0.0;
+  double ef = 0.0;
+  for (int p = 0; p < e->nph; p++) {
+    const double *ph = fl + phase_off(e, p);
+    double ds = ph[PH_RHO] * ph[PH_SAT];
+    for (int c = 0; c < e->nc; c++) bal[c] += ds * ph[PH_X + c];
+    ef += ds * ph[PH_U];
+  }
+  for (int c = 0; c < e->nc; c++) bal[c] = phi * bal[c];
+  if (!e->isothermal) {
+    double er = rock[6] * rock[7] * fl[F_T];
+    bal[e->np - 1] = phi * ef + (1.0 - phi) * er;
+  }
+}
+
+/* src/face.F90:358-377 */
+double wo_harmonic_average(const double *fg, double x1, double x2) {
+  double wx = (fg[1] * x2 + fg[2] * x1) / fg[3];
+  return (fabs(wx) > 1.e-30) ? x1 * x2 / wx : 0.0;
+}
+
+/* src/eos.F90:240-257 */
+double wo_conductivity(const double *rock, const double *fl, const wo_eos *e) {
+  double sl = fl[phase_off(e, 0) + PH_SAT];
+  return rock[4] + sqrt(sl) * (rock[3] - rock[4]);
+}
+
+/* src/face.F90:334-354 */
+double wo_face_phase_density(const wo_eos *e, const double *f1, const double *f2, int p) {
+  const double *a = f1 + phase_off(e, p), *b = f2 + phase_off(e, p);
+  double rho = a[PH_SAT] * a[PH_RHO] + b[PH_SAT] * b[PH_RHO];
+  double w = a[PH_SAT] + b[PH_SAT];
+  return rho / w;
+}
+
+/* src/face.F90:443-515 */
+void wo_face_flux(const wo_eos *e, const double *fg, const double *f1, const double *r1,
+                  const double *f2, const double *r2, double *flux) {
+  int np = e->np, nc = e->nc;
+  for (int i = 0; i < np + e->nmob; i++) flux[i] = 0.0;
+  int dir = (int)lround(fg[11]);
+  double k = wo_harmonic_average(fg, r1[dir - 1] * f1[F_PERMFAC], r2[dir - 1] * f2[F_PERMFAC]);
+  if (!e->isothermal) {
+    double cond = wo_harmonic_average(fg, wo_conductivity(r1, f1, e), wo_conductivity(r2, f2, e));
+    double dtdn = (f2[F_T] - f1[F_T]) / fg[3];
+    flux[np - 1] = -cond * dtdn;
+  }
+  int ph1 = (int)lround(f1[F_PHASES]), ph2 = (int)lround(f2[F_PHASES]);
+  int present = ph1 | ph2;
+  for (int p = 0; p < e->nmob; p++) {
+    if (!(present & (1 << p))) continue;
+    const double *a = f1 + phase_off(e, p), *b = f2 + phase_off(e, p);
+    double rho_f = wo_face_phase_density(e, f1, f2, p);
+    double dpdn = ((f2[F_P] + b[PH_PC]) - (f1[F_P] + a[PH_PC])) / fg[3];
+    double G = dpdn - rho_f * fg[7];
+    int up_is_1 = (G <= 0.0);
+    int phup = up_is_1 ? ph1 : ph2;
+    if (!(phup & (1 << p))) continue;
+    const double *u = up_is_1 ? a : b;
+    double mob = u[PH_KR] * u[PH_RHO] / u[PH_MU];
+    double F = -k * mob * G;
+    double sum = 0.0;
+    for (int c = 0; c < nc; c++) {
+      double fc = F * u[PH_X + c];
+      flux[c] += fc;
+      sum += fc;
+    }
+    if (!e->isothermal) flux[np - 1] += u[PH_H] * F;
+    flux[np + p] = sum;
+  }
+}

@@ -1,0 +1,958 @@
+/* wo_solver.c -- CPU restatement of Waiwera's residual / FD-Jacobian loops and of the PETSc
+ * pieces (BAIJ SpMV, block ILU(0), KSPBCGS, KSPGMRES, SNES newtonls protocol) they feed.
+ *
+ * TEST INFRASTRUCTURE ONLY (see wai_oracle.h).
+ *
+ * PETSc 3.22.5 is an un-vendored dependency of the reference (meson.build:12); the functions
+ * marked [PETSc] restate its published algorithms (Saad, "Iterative Methods for Sparse Linear
+ * Systems", alg. 7.7 BiCGStab / 6.9 GMRES / 10.4 ILU(0) in block form; PETSc manual KSPBCGS,
+ * KSPGMRES, PCBJACOBI, PCILU, SNESNEWTONLS, MatFDColoring "ds") and are anchored on the
+ * reference's call sites: src/timestepper.F90:1552-1641, :1645-1836, :587-735, :1898-1951.
+ */
+#include "wai_oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MAXBS 4
+
+struct wo_sim {
+  wo_eos eos;
+  int n_owned, n_halo, n_bc, n_local, n_prim;
+  int n_faces;
+  int *face_cells;
+  double *face_geom, *cell_geom, *rock;
+  double *fluid, *last_iteration_fluid, *last_timestep_fluid;
+  int *cf_ptr, *cf_face, *cf_side; /* owned cell -> faces, ascending face index */
+  int nnzb;
+  int *rowptr, *colidx;
+  int n_src;
+  int *src_cell, *src_comp;
+  double *src_rate, *src_enth;
+  int nsub;
+  int *sub_ptr;
+  wo_halo_fn halo;
+  wo_allreduce_fn ar;
+  void *user;
+  double *fval, *dinv;
+};
+
+static void *xmalloc(size_t n) {
+  void *p = calloc(n ? n : 1, 1);
+  if (!p) { fprintf(stderr, "oracle: out of memory\n"); abort(); }
+  return p;
+}
+
+static int cmp_int(const void *a, const void *b) {
+  int x = *(const int *)a, y = *(const int *)b;
+  return (x > y) - (x < y);
+}
+
+wo_sim *wo_sim_create(int eos_kind, int n_owned, int n_halo, int n_bc, int n_faces,
+                      const int *face_cells, const double *face_geom, const double *cell_geom,
+                      const double *rock) {
+  wo_sim *s = (wo_sim *)xmalloc(sizeof(*s));
+  wo_eos_init(&s->eos, eos_kind);
+  s->n_owned = n_owned; s->n_halo = n_halo; s->n_bc = n_bc;
+  s->n_prim = n_owned + n_halo;
+  s->n_local = s->n_prim + n_bc;
+  s->n_faces = n_faces;
+  s->face_cells = (int *)xmalloc(sizeof(int) * 2 * n_faces);
+  memcpy(s->face_cells, face_cells, sizeof(int) * 2 * n_faces);
+  s->face_geom = (double *)xmalloc(sizeof(double) * 12 * n_faces);
+  memcpy(s->face_geom, face_geom, sizeof(double) * 12 * n_faces);
+  s->cell_geom = (double *)xmalloc(sizeof(double) * 4 * s->n_local);
+  memcpy(s->cell_geom, cell_geom, sizeof(double) * 4 * s->n_local);
+  s->rock = (double *)xmalloc(sizeof(double) * 8 * s->n_local);
+  memcpy(s->rock, rock, sizeof(double) * 8 * s->n_local);
+  int df = s->eos.df;
+  s->fluid = (double *)xmalloc(sizeof(double) * df * s->n_local);
+  s->last_iteration_fluid = (double *)xmalloc(sizeof(double) * df * s->n_local);
+  s->last_timestep_fluid = (double *)xmalloc(sizeof(double) * df * s->n_local);
+  for (int c = 0; c < s->n_local; c++) {
+    s->fluid[c * df + 2] = 1.0; /* default region (eos_we.F90:91) */
+    s->fluid[c * df + 3] = 1.0;
+  }
+  /* cell -> face adjacency */
+  s->cf_ptr = (int *)xmalloc(sizeof(int) * (n_owned + 1));
+  for (int f = 0; f < n_faces; f++)
+    for (int k = 0; k < 2; k++) {
+      int c = face_cells[2 * f + k];
+      if (c < n_owned) s->cf_ptr[c + 1]++;
+    }
+  for (int c = 0; c < n_owned; c++) s->cf_ptr[c + 1] += s->cf_ptr[c];
+  int ncf = s->cf_ptr[n_owned];
+  s->cf_face = (int *)xmalloc(sizeof(int) * ncf);
+  s->cf_side = (int *)xmalloc(sizeof(int) * ncf);
+  int *fill = (int *)xmalloc(sizeof(int) * n_owned);
+  for (int f = 0; f < n_faces; f++)
+    for (int k = 0; k < 2; k++) {
+      int c = face_cells[2 * f + k];
+      if (c < n_owned) {
+        int q = s->cf_ptr[c] + fill[c]++;
+        s->cf_face[q] = f;
+        s->cf_side[q] = k;
+      }
+    }
+  free(fill);
+  /* block sparsity: FV cell-face-cell adjacency (dm_utils.F90:1041-1051), sorted columns */
+  s->rowptr = (int *)xmalloc(sizeof(int) * (n_owned + 1));
+  for (int c = 0; c < n_owned; c++) {
+    int cnt = 1;
+    for (int q = s->cf_ptr[c]; q < s->cf_ptr[c + 1]; q++) {
+      int f = s->cf_face[q], o = face_cells[2 * f + 1 - s->cf_side[q]];
+      if (o < s->n_prim) cnt++;
+    }
+    s->rowptr[c + 1] = s->rowptr[c] + cnt;
+  }
+  s->nnzb = s->rowptr[n_owned];
+  s->colidx = (int *)xmalloc(sizeof(int) * s->nnzb);
+  for (int c = 0; c < n_owned; c++) {
+    int *row = s->colidx + s->rowptr[c], cnt = 0;
+    row[cnt++] = c;
+    for (int q = s->cf_ptr[c]; q < s->cf_ptr[c + 1]; q++) {
+      int f = s->cf_face[q], o = face_cells[2 * f + 1 - s->cf_side[q]];
+      if (o < s->n_prim) row[cnt++] = o;
+    }
+    qsort(row, cnt, sizeof(int), cmp_int);
+  }
+  s->nsub = 1;
+  s->sub_ptr = (int *)xmalloc(sizeof(int) * 2);
+  s->sub_ptr[0] = 0; s->sub_ptr[1] = n_owned;
+  int bs = s->eos.np;
+  s->fval = (double *)xmalloc(sizeof(double) * s->nnzb * bs * bs);
+  s->dinv = (double *)xmalloc(sizeof(double) * n_owned * bs * bs);
+  return s;
+}
+
+void wo_sim_destroy(wo_sim *s) {
+  if (!s) return;
+  free(s->face_cells); free(s->face_geom); free(s->cell_geom); free(s->rock);
+  free(s->fluid); free(s->last_iteration_fluid); free(s->last_timestep_fluid);
+  free(s->cf_ptr); free(s->cf_face); free(s->cf_side); free(s->rowptr); free(s->colidx);
+  free(s->src_cell); free(s->src_comp); free(s->src_rate); free(s->src_enth);
+  free(s->sub_ptr); free(s->fval); free(s->dinv);
+  free(s);
+}
+
+wo_eos *wo_sim_eos(wo_sim *s) { return &s->eos; }
+void wo_sim_set_comm(wo_sim *s, wo_halo_fn halo, wo_allreduce_fn ar, void *user) {
+  s->halo = halo; s->ar = ar; s->user = user;
+}
+void wo_sim_set_sources(wo_sim *s, int n, const int *cell, const double *rate,
+                        const double *enthalpy, const int *component) {
+  free(s->src_cell); free(s->src_comp); free(s->src_rate); free(s->src_enth);
+  s->n_src = n;
+  s->src_cell = (int *)xmalloc(sizeof(int) * n);
+  s->src_comp = (int *)xmalloc(sizeof(int) * n);
+  s->src_rate = (double *)xmalloc(sizeof(double) * n);
+  s->src_enth = (double *)xmalloc(sizeof(double) * n);
+  memcpy(s->src_cell, cell, sizeof(int) * n);
+  memcpy(s->src_comp, component, sizeof(int) * n);
+  memcpy(s->src_rate, rate, sizeof(double) * n);
+  memcpy(s->src_enth, enthalpy, sizeof(double) * n);
+}
+void wo_sim_set_subdomains(wo_sim *s, int nsub, const int *sub_ptr) {
+  free(s->sub_ptr);
+  s->nsub = nsub;
+  s->sub_ptr = (int *)xmalloc(sizeof(int) * (nsub + 1));
+  memcpy(s->sub_ptr, sub_ptr, sizeof(int) * (nsub + 1));
+}
+void wo_sim_set_regions(wo_sim *s, const int *region) {
+  int df = s->eos.df;
+  for (int c = 0; c < s->n_prim; c++) {
+    s->fluid[c * df + 2] = (double)region[c];
+    s->fluid[c * df + 3] = (double)region[c];
+  }
+}
+void wo_sim_get_regions(wo_sim *s, int *region) {
+  int df = s->eos.df;
+  for (int c = 0; c < s->n_prim; c++) region[c] = (int)lround(s->fluid[c * df + 2]);
+}
+double *wo_sim_fluid(wo_sim *s) { return s->fluid; }
+int wo_sim_nnzb(wo_sim *s) { return s->nnzb; }
+void wo_sim_pattern(wo_sim *s, int *rowptr, int *colidx) {
+  memcpy(rowptr, s->rowptr, sizeof(int) * (s->n_owned + 1));
+  memcpy(colidx, s->colidx, sizeof(int) * s->nnzb);
+}
+
+/* Dirichlet boundary ghost cells: fluid record filled once from the BC primaries
+ * (src/mesh.F90:1199-1202 / flow_simulation fluid_init) */
+int wo_sim_init_bc(wo_sim *s, const double *primary, const int *region) {
+  int df = s->eos.df, np = s->eos.np, err = 0;
+  for (int b = 0; b < s->n_bc; b++) {
+    double *fl = s->fluid + (size_t)(s->n_prim + b) * df;
+    fl[2] = (double)region[b];
+    fl[3] = fl[2];
+    int e = wo_eos_bulk_properties(&s->eos, primary + b * np, fl);
+    if (!e) e = wo_eos_phase_properties(&s->eos, primary + b * np, fl);
+    if (e) err = 1;
+  }
+  return err;
+}
+
+static int collective_err(wo_sim *s, int err) { /* mpi_utils.F90:36-54 */
+  if (s->ar) {
+    double v = (double)err;
+    s->ar(s->user, &v, 1, 1);
+    err = (v > 0.0);
+  }
+  return err;
+}
+
+/* ---- ode_type hooks ---------------------------------------------------------------------- */
+void wo_pre_timestep(wo_sim *s) {
+  memcpy(s->last_timestep_fluid, s->fluid, sizeof(double) * s->eos.df * s->n_local);
+}
+void wo_pre_retry_timestep(wo_sim *s) {
+  memcpy(s->fluid, s->last_timestep_fluid, sizeof(double) * s->eos.df * s->n_local);
+}
+void wo_pre_iteration(wo_sim *s) {
+  memcpy(s->last_iteration_fluid, s->fluid, sizeof(double) * s->eos.df * s->n_local);
+}
+
+/* EOS for one cell with the region held in its record */
+static int eval_cell_fluid(const wo_eos *e, const double *yc, double *fl) {
+  double prim[MAXBS];
+  int region = (int)lround(fl[2]);
+  wo_eos_unscale(e, yc, region, prim);
+  int err = wo_eos_bulk_properties(e, prim, fl);
+  if (!err) err = wo_eos_phase_properties(e, prim, fl);
+  return err;
+}
+
+/* flow_simulation_fluid_properties (src/flow_simulation.F90:2291-2415), unperturbed form.  The
+ * overlap cells owned by other ranks get their primaries and regions through the halo exchange
+ * (the reference scatters the fluid vector instead, :1391-1400; same values either way). */
+int wo_pre_eval(wo_sim *s, double *y) {
+  int np = s->eos.np, df = s->eos.df, err = 0;
+  if (s->halo && s->n_halo) {
+    s->halo(s->user, y, np);
+    double *reg = (double *)xmalloc(sizeof(double) * s->n_prim);
+    for (int c = 0; c < s->n_prim; c++) reg[c] = s->fluid[c * df + 2];
+    s->halo(s->user, reg, 1);
+    for (int c = s->n_owned; c < s->n_prim; c++) s->fluid[c * df + 2] = reg[c];
+    free(reg);
+  }
+  for (int c = 0; c < s->n_prim; c++) {
+    if (eval_cell_fluid(&s->eos, y + c * np, s->fluid + (size_t)c * df)) { err = 1; break; }
+  }
+  return collective_err(s, err);
+}
+
+/* flow_simulation_cell_balances: src/flow_simulation.F90:1242-1330 */
+void wo_lhs(wo_sim *s, double *lhs) {
+  int np = s->eos.np, df = s->eos.df;
+  for (int c = 0; c < s->n_owned; c++)
+    wo_cell_balance(&s->eos, s->fluid + (size_t)c * df, s->rock + c * 8, lhs + c * np);
+}
+
+/* source term for one cell: src/source.F90:386-480, fluid.F90:377-453; flow[np] */
+static void source_flow(const wo_eos *e, const double *fl, double rate, double enth, int comp,
+                        double *flow) {
+  int np = e->np, nc = e->nc, nph = e->nph;
+  for (int k = 0; k < np; k++) flow[k] = 0.0;
+  double h = 0.0;
+  int component;
+  if (rate > 0.0) {
+    component = comp <= 0 ? 1 : comp; /* default injection component 1 */
+    h = enth;
+    flow[component - 1] = rate;
+  } else {
+    component = comp <= 0 ? 0 : comp; /* default production component 0 = all */
+    int phases = (int)lround(fl[4]);
+    double frac[4] = {0, 0, 0, 0}, sum = 0.0;
+    int boff = 7 + nc - 1, pdof = 8 + nc - 1;
+    if (component < np) {
+      for (int p = 0; p < nph; p++)
+        if (phases & (1 << p)) {
+          const double *ph = fl + boff + p * pdof;
+          frac[p] = ph[3] * ph[0] / ph[1];
+        }
+      for (int p = 0; p < nph; p++) sum += frac[p];
+      for (int p = 0; p < nph; p++) frac[p] /= sum;
+      if (!e->isothermal)
+        for (int p = 0; p < nph; p++)
+          if (phases & (1 << p)) h += frac[p] * fl[boff + p * pdof + 5];
+    }
+    if (component <= 0) {
+      double cf[4] = {0, 0, 0, 0}, cs = 0.0;
+      for (int c = 0; c < nc; c++) {
+        for (int p = 0; p < nph; p++)
+          if (phases & (1 << p)) cf[c] += frac[p] * fl[boff + p * pdof + 7 + c];
+        cs += cf[c];
+      }
+      for (int c = 0; c < nc; c++) flow[c] = rate * (cf[c] / cs);
+    } else flow[component - 1] = rate;
+  }
+  if (!e->isothermal && component < np) flow[np - 1] += h * rate;
+}
+
+/* flow_simulation_cell_inflows: src/flow_simulation.F90:1334-1485 */
+void wo_rhs(wo_sim *s, double *rhs) {
+  int np = s->eos.np, df = s->eos.df;
+  double flux[MAXBS + 4];
+  memset(rhs, 0, sizeof(double) * np * s->n_owned);
+  for (int f = 0; f < s->n_faces; f++) {
+    int c1 = s->face_cells[2 * f], c2 = s->face_cells[2 * f + 1];
+    const double *fg = s->face_geom + 12 * f;
+    wo_face_flux(&s->eos, fg, s->fluid + (size_t)c1 * df, s->rock + c1 * 8,
+                 s->fluid + (size_t)c2 * df, s->rock + c2 * 8, flux);
+    for (int k = 0; k < 2; k++) {
+      int c = k ? c2 : c1;
+      if (c < s->n_owned) {
+        double sign = k ? 1.0 : -1.0, vol = s->cell_geom[4 * c + 3];
+        for (int q = 0; q < np; q++) rhs[c * np + q] += sign * (flux[q] * fg[0]) / vol;
+      }
+    }
+  }
+  for (int i = 0; i < s->n_src; i++) {
+    int c = s->src_cell[i];
+    if (c < 0 || c >= s->n_owned) continue;
+    double flow[MAXBS];
+    source_flow(&s->eos, s->fluid + (size_t)c * df, s->src_rate[i], s->src_enth[i],
+                s->src_comp[i], flow);
+    for (int q = 0; q < np; q++) rhs[c * np + q] += flow[q] / s->cell_geom[4 * c + 3];
+  }
+}
+
+/* SNES_residual + backwards_Euler_residual: src/timestepper.F90:587-624, :345-374 */
+int wo_residual(wo_sim *s, double *y, double dt, const double *lhs_old, double *f) {
+  int n = s->eos.np * s->n_owned;
+  int err = wo_pre_eval(s, y);
+  if (err) return err;
+  double *L = (double *)xmalloc(sizeof(double) * n), *R = (double *)xmalloc(sizeof(double) * n);
+  wo_lhs(s, L);
+  wo_rhs(s, R);
+  for (int i = 0; i < n; i++) f[i] = (L[i] - lhs_old[i]) - dt * R[i];
+  free(L); free(R);
+  return 0;
+}
+
+/* MatFDColoring "ds" step [PETSc; doc/user/setup_time.rst:434-471] */
+static double fd_step(double yv, double eps, double umin) {
+  double dx = yv;
+  if (fabs(dx) < umin) dx = (dx >= 0.0) ? umin : -umin;
+  return dx * eps;
+}
+
+static int find_col(const wo_sim *s, int row, int col) {
+  for (int q = s->rowptr[row]; q < s->rowptr[row + 1]; q++)
+    if (s->colidx[q] == col) return q;
+  return -1;
+}
+
+/* residual of one owned cell given explicit fluid records for itself / its neighbours:
+ * which = -1: all base; which = -2: own record replaced by `alt`; which = q >= 0: neighbour
+ * across adjacency slot q replaced by `alt` */
+static void cell_residual(const wo_sim *s, int c, double dt, const double *lhs_old, int which,
+                          const double *alt, double *out) {
+  const wo_eos *e = &s->eos;
+  int np = e->np, df = e->df;
+  const double *own = (which == -2) ? alt : s->fluid + (size_t)c * df;
+  double L[MAXBS], R[MAXBS], flux[MAXBS + 4];
+  wo_cell_balance(e, own, s->rock + c * 8, L);
+  for (int k = 0; k < np; k++) R[k] = 0.0;
+  double vol = s->cell_geom[4 * c + 3];
+  for (int q = s->cf_ptr[c]; q < s->cf_ptr[c + 1]; q++) {
+    int f = s->cf_face[q], side = s->cf_side[q];
+    int o = s->face_cells[2 * f + 1 - side];
+    const double *of = (which == q) ? alt : s->fluid + (size_t)o * df;
+    const double *fg = s->face_geom + 12 * f;
+    if (side == 0) wo_face_flux(e, fg, own, s->rock + c * 8, of, s->rock + o * 8, flux);
+    else wo_face_flux(e, fg, of, s->rock + o * 8, own, s->rock + c * 8, flux);
+    double sign = side ? 1.0 : -1.0;
+    for (int k = 0; k < np; k++) R[k] += sign * (flux[k] * fg[0]) / vol;
+  }
+  for (int i = 0; i < s->n_src; i++)
+    if (s->src_cell[i] == c) {
+      double flow[MAXBS];
+      source_flow(e, own, s->src_rate[i], s->src_enth[i], s->src_comp[i], flow);
+      for (int k = 0; k < np; k++) R[k] += flow[k] / vol;
+    }
+  for (int k = 0; k < np; k++) out[k] = (L[k] - lhs_old[c * np + k]) - dt * R[k];
+}
+
+static int jacobian_local(wo_sim *s, double *y, double dt, const double *lhs_old, double eps,
+                          double umin, double *val) {
+  const wo_eos *e = &s->eos;
+  int np = e->np, df = e->df, bb = np * np, err = 0;
+  /* perturbed fluid records for every cell with primaries: pert[(c*np + k)*df] */
+  double *pert = (double *)xmalloc(sizeof(double) * (size_t)s->n_prim * np * df);
+  double *h = (double *)xmalloc(sizeof(double) * s->n_prim * np);
+  for (int c = 0; c < s->n_prim && !err; c++)
+    for (int k = 0; k < np; k++) {
+      double yp[MAXBS];
+      for (int q = 0; q < np; q++) yp[q] = y[c * np + q];
+      h[c * np + k] = fd_step(yp[k], eps, umin);
+      yp[k] += h[c * np + k];
+      double *fl = pert + ((size_t)c * np + k) * df;
+      memcpy(fl, s->fluid + (size_t)c * df, sizeof(double) * df);
+      if (eval_cell_fluid(e, yp, fl)) { err = 1; break; }
+    }
+  err = collective_err(s, err);
+  if (err) { free(pert); free(h); return err; }
+  memset(val, 0, sizeof(double) * (size_t)s->nnzb * bb);
+  for (int c = 0; c < s->n_owned; c++) {
+    double f0[MAXBS], f1[MAXBS];
+    cell_residual(s, c, dt, lhs_old, -1, NULL, f0);
+    int qd = find_col(s, c, c);
+    for (int k = 0; k < np; k++) {
+      cell_residual(s, c, dt, lhs_old, -2, pert + ((size_t)c * np + k) * df, f1);
+      for (int r = 0; r < np; r++) val[(size_t)qd * bb + r * np + k] = (f1[r] - f0[r]) / h[c * np + k];
+    }
+    for (int q = s->cf_ptr[c]; q < s->cf_ptr[c + 1]; q++) {
+      int f = s->cf_face[q], o = s->face_cells[2 * f + 1 - s->cf_side[q]];
+      if (o >= s->n_prim) continue;
+      int qo = find_col(s, c, o);
+      for (int k = 0; k < np; k++) {
+        cell_residual(s, c, dt, lhs_old, q, pert + ((size_t)o * np + k) * df, f1);
+        for (int r = 0; r < np; r++)
+          val[(size_t)qo * bb + r * np + k] += (f1[r] - f0[r]) / h[o * np + k];
+      }
+    }
+  }
+  free(pert); free(h);
+  return 0;
+}
+
+/* literal MatFDColoringApply: greedy distance-2 colouring, one full residual per colour x
+ * component (src/timestepper.F90:1584-1611, flow_simulation.F90:1102-1137).  One rank only. */
+static int jacobian_colored(wo_sim *s, double *y, double dt, const double *lhs_old,
+                            const double *f, double eps, double umin, double *val) {
+  int np = s->eos.np, n = s->n_owned, bb = np * np, df = s->eos.df;
+  int *color = (int *)xmalloc(sizeof(int) * n);
+  int ncolors = 0;
+  for (int c = 0; c < n; c++) color[c] = -1;
+  int *mark = (int *)xmalloc(sizeof(int) * (n + 1));
+  for (int c = 0; c < n; c++) {
+    for (int k = 0; k <= ncolors; k++) mark[k] = 0;
+    for (int q = s->rowptr[c]; q < s->rowptr[c + 1]; q++) {
+      int a = s->colidx[q];
+      if (a >= n) continue;
+      if (color[a] >= 0) mark[color[a]] = 1;
+      for (int r = s->rowptr[a]; r < s->rowptr[a + 1]; r++) {
+        int b = s->colidx[r];
+        if (b < n && color[b] >= 0) mark[color[b]] = 1;
+      }
+    }
+    int k = 0;
+    while (k < ncolors && mark[k]) k++;
+    color[c] = k;
+    if (k == ncolors) ncolors++;
+  }
+  double *saved = (double *)xmalloc(sizeof(double) * (size_t)df * s->n_local);
+  memcpy(saved, s->fluid, sizeof(double) * (size_t)df * s->n_local);
+  double *yp = (double *)xmalloc(sizeof(double) * np * s->n_prim);
+  double *fp = (double *)xmalloc(sizeof(double) * np * n);
+  memset(val, 0, sizeof(double) * (size_t)s->nnzb * bb);
+  int err = 0;
+  for (int col = 0; col < ncolors && !err; col++)
+    for (int k = 0; k < np && !err; k++) {
+      memcpy(yp, y, sizeof(double) * np * s->n_prim);
+      for (int c = 0; c < n; c++)
+        if (color[c] == col) yp[c * np + k] += fd_step(y[c * np + k], eps, umin);
+      memcpy(s->fluid, saved, sizeof(double) * (size_t)df * s->n_local);
+      err = wo_residual(s, yp, dt, lhs_old, fp);
+      if (err) break;
+      for (int j = 0; j < n; j++) {
+        if (color[j] != col) continue;
+        double hh = fd_step(y[j * np + k], eps, umin);
+        for (int q = s->rowptr[j]; q < s->rowptr[j + 1]; q++) {
+          int i = s->colidx[q];
+          if (i >= n) continue;
+          int qi = find_col(s, i, j);
+          for (int r = 0; r < np; r++)
+            val[(size_t)qi * bb + r * np + k] = (fp[i * np + r] - f[i * np + r]) / hh;
+        }
+      }
+    }
+  memcpy(s->fluid, saved, sizeof(double) * (size_t)df * s->n_local);
+  free(saved); free(yp); free(fp); free(color); free(mark);
+  return err;
+}
+
+static double g_fd_eps = 1.e-8, g_fd_umin = 1.e-2; /* timestepper.F90:1572-1573 */
+
+int wo_jacobian(wo_sim *s, double *y, double dt, const double *lhs_old, const double *f,
+                int mode, double *val) {
+  if (mode == 1) return jacobian_colored(s, y, dt, lhs_old, f, g_fd_eps, g_fd_umin, val);
+  return jacobian_local(s, y, dt, lhs_old, g_fd_eps, g_fd_umin, val);
+}
+
+/* vec_max_pointwise_abs_scale: src/dm_utils.F90:644-685 */
+void wo_max_scaled(wo_sim *s, const double *v, const double *scale, double tol, double *maxval,
+                   int *maxloc) {
+  int n = s->eos.np * s->n_owned;
+  double m = -1.0;
+  int loc = 0;
+  for (int i = 0; i < n; i++) {
+    double sc = fabs(scale[i]);
+    if (sc < tol) sc = tol;
+    double r = fabs(v[i]) / sc;
+    if (r > m || (isnan(r) && !isnan(m))) { m = r; loc = i; }
+  }
+  if (s->ar) s->ar(s->user, &m, 1, 1);
+  *maxval = m;
+  *maxloc = loc;
+}
+
+/* flow_simulation_fluid_transitions: src/flow_simulation.F90:2419-2576 */
+int wo_post_linesearch(wo_sim *s, const double *y_old, double *search, double *y,
+                       int *changed_search, int *changed_y) {
+  const wo_eos *e = &s->eos;
+  int np = e->np, df = e->df, err = 0;
+  *changed_search = 0;
+  *changed_y = 0;
+  for (int c = 0; c < s->n_owned; c++) {
+    double *fl = s->fluid + (size_t)c * df;
+    const double *ofl = s->last_iteration_fluid + (size_t)c * df;
+    double prim[MAXBS], oprim[MAXBS];
+    wo_eos_unscale(e, y + c * np, (int)lround(fl[2]), prim);
+    wo_eos_unscale(e, y_old + c * np, (int)lround(ofl[2]), oprim);
+    fl[3] = fl[2];
+    int transition = 0;
+    err = wo_eos_transition(e, oprim, prim, ofl, fl, &transition);
+    if (err) break;
+    *changed_y = 0; /* check_primary_variables resets the flag per cell (eos_we.F90:501) */
+    err = wo_eos_check_primary(e, fl, prim);
+    if (err) break;
+    if (transition) *changed_y = 1;
+    if (*changed_y) {
+      *changed_search = 1;
+      wo_eos_scale(e, prim, (int)lround(fl[2]), y + c * np);
+      for (int k = 0; k < np; k++) search[c * np + k] = y_old[c * np + k] - y[c * np + k];
+    }
+  }
+  err = collective_err(s, err);
+  if (s->ar) {
+    double v[2] = {(double)*changed_y, (double)*changed_search};
+    s->ar(s->user, v, 2, 1);
+    *changed_y = v[0] > 0;
+    *changed_search = v[1] > 0;
+  }
+  return err;
+}
+
+/* ---- block linear algebra [PETSc] -------------------------------------------------------- */
+void wo_bcsr_spmv(int n, int bs, const int *rowptr, const int *colidx, const double *val,
+                  const double *x, double *y) {
+  int bb = bs * bs;
+  for (int i = 0; i < n; i++) {
+    double acc[MAXBS] = {0, 0, 0, 0};
+    for (int q = rowptr[i]; q < rowptr[i + 1]; q++) {
+      const double *a = val + (size_t)q * bb, *xx = x + (size_t)colidx[q] * bs;
+      for (int r = 0; r < bs; r++)
+        for (int c = 0; c < bs; c++) acc[r] += a[r * bs + c] * xx[c];
+    }
+    for (int r = 0; r < bs; r++) y[(size_t)i * bs + r] = acc[r];
+  }
+}
+
+/* in-place inverse of a bs x bs block, Gauss-Jordan with partial pivoting; 0 ok, 1 singular */
+static int block_inverse(int bs, const double *a, double *inv) {
+  double m[MAXBS][2 * MAXBS];
+  for (int r = 0; r < bs; r++)
+    for (int c = 0; c < bs; c++) { m[r][c] = a[r * bs + c]; m[r][bs + c] = (r == c); }
+  for (int p = 0; p < bs; p++) {
+    int piv = p;
+    for (int r = p + 1; r < bs; r++)
+      if (fabs(m[r][p]) > fabs(m[piv][p])) piv = r;
+    if (m[piv][p] == 0.0) return 1;
+    if (piv != p)
+      for (int c = 0; c < 2 * bs; c++) { double t = m[p][c]; m[p][c] = m[piv][c]; m[piv][c] = t; }
+    double d = 1.0 / m[p][p];
+    for (int c = 0; c < 2 * bs; c++) m[p][c] *= d;
+    for (int r = 0; r < bs; r++)
+      if (r != p) {
+        double fct = m[r][p];
+        if (fct != 0.0)
+          for (int c = 0; c < 2 * bs; c++) m[r][c] -= fct * m[p][c];
+      }
+  }
+  for (int r = 0; r < bs; r++)
+    for (int c = 0; c < bs; c++) inv[r * bs + c] = m[r][bs + c];
+  return 0;
+}
+
+static void bmm(int bs, const double *a, const double *b, double *c) { /* c = a b */
+  for (int r = 0; r < bs; r++)
+    for (int q = 0; q < bs; q++) {
+      double t = 0.0;
+      for (int k = 0; k < bs; k++) t += a[r * bs + k] * b[k * bs + q];
+      c[r * bs + q] = t;
+    }
+}
+
+/* block ILU(0), IKJ form, restricted to each subdomain's diagonal block (PCBJACOBI + PCILU
+ * levels 0: src/timestepper.F90:1668-1669,1789-1834).  L carries the multipliers
+ * A_ik * inv(U_kk) (unit block diagonal), U's pivots are stored inverted in dinv. */
+int wo_bilu0_factor(int n, int bs, const int *rowptr, const int *colidx, const double *val,
+                    int nsub, const int *sub_ptr, double *fval, double *dinv) {
+  int bb = bs * bs, err = 0;
+  memcpy(fval, val, sizeof(double) * (size_t)rowptr[n] * bb);
+  for (int sd = 0; sd < nsub; sd++) {
+    int lo = sub_ptr[sd], hi = sub_ptr[sd + 1];
+    for (int i = lo; i < hi; i++) {
+      int qdiag = -1;
+      for (int q = rowptr[i]; q < rowptr[i + 1]; q++) {
+        int k = colidx[q];
+        if (k < lo || k >= hi) continue;
+        if (k == i) { qdiag = q; break; }
+        /* multiplier L_ik = w_k * inv(U_kk) */
+        double t[MAXBS * MAXBS];
+        bmm(bs, fval + (size_t)q * bb, dinv + (size_t)k * bb, t);
+        memcpy(fval + (size_t)q * bb, t, sizeof(double) * bb);
+        /* w_j -= L_ik U_kj for j > k in row k and in row i's pattern */
+        for (int r = rowptr[k]; r < rowptr[k + 1]; r++) {
+          int j = colidx[r];
+          if (j <= k || j < lo || j >= hi) continue;
+          for (int q2 = q + 1; q2 < rowptr[i + 1]; q2++)
+            if (colidx[q2] == j) {
+              double u[MAXBS * MAXBS];
+              bmm(bs, t, fval + (size_t)r * bb, u);
+              for (int z = 0; z < bb; z++) fval[(size_t)q2 * bb + z] -= u[z];
+              break;
+            }
+        }
+      }
+      if (qdiag < 0 || block_inverse(bs, fval + (size_t)qdiag * bb, dinv + (size_t)i * bb)) err = 1;
+    }
+  }
+  return err;
+}
+
+void wo_bilu0_apply(int n, int bs, const int *rowptr, const int *colidx, const double *fval,
+                    const double *dinv, int nsub, const int *sub_ptr, const double *r,
+                    double *z) {
+  int bb = bs * bs;
+  (void)n;
+  for (int sd = 0; sd < nsub; sd++) {
+    int lo = sub_ptr[sd], hi = sub_ptr[sd + 1];
+    for (int i = lo; i < hi; i++) { /* forward: L y = r */
+      double acc[MAXBS];
+      for (int a = 0; a < bs; a++) acc[a] = r[(size_t)i * bs + a];
+      for (int q = rowptr[i]; q < rowptr[i + 1]; q++) {
+        int k = colidx[q];
+        if (k < lo || k >= i) continue;
+        const double *m = fval + (size_t)q * bb, *yk = z + (size_t)k * bs;
+        for (int a = 0; a < bs; a++)
+          for (int c = 0; c < bs; c++) acc[a] -= m[a * bs + c] * yk[c];
+      }
+      for (int a = 0; a < bs; a++) z[(size_t)i * bs + a] = acc[a];
+    }
+    for (int i = hi - 1; i >= lo; i--) { /* backward: U x = y */
+      double acc[MAXBS], out[MAXBS];
+      for (int a = 0; a < bs; a++) acc[a] = z[(size_t)i * bs + a];
+      for (int q = rowptr[i]; q < rowptr[i + 1]; q++) {
+        int j = colidx[q];
+        if (j <= i || j >= hi) continue;
+        const double *m = fval + (size_t)q * bb, *xj = z + (size_t)j * bs;
+        for (int a = 0; a < bs; a++)
+          for (int c = 0; c < bs; c++) acc[a] -= m[a * bs + c] * xj[c];
+      }
+      const double *d = dinv + (size_t)i * bb;
+      for (int a = 0; a < bs; a++) {
+        out[a] = 0.0;
+        for (int c = 0; c < bs; c++) out[a] += d[a * bs + c] * acc[c];
+      }
+      for (int a = 0; a < bs; a++) z[(size_t)i * bs + a] = out[a];
+    }
+  }
+}
+
+/* ---- Krylov [PETSc KSPBCGS / KSPGMRES, left preconditioning, preconditioned norm] -------- */
+static double gdot(wo_sim *s, const double *a, const double *b, int n) {
+  double t = 0.0;
+  for (int i = 0; i < n; i++) t += a[i] * b[i];
+  if (s->ar) s->ar(s->user, &t, 1, 0);
+  return t;
+}
+
+/* z = B^-1 A x ; x must have room for halo entries */
+static void pc_amul(wo_sim *s, const double *val, double *x, double *tmp, double *z) {
+  int bs = s->eos.np;
+  if (s->halo && s->n_halo) s->halo(s->user, x, bs);
+  wo_bcsr_spmv(s->n_owned, bs, s->rowptr, s->colidx, val, x, tmp);
+  wo_bilu0_apply(s->n_owned, bs, s->rowptr, s->colidx, s->fval, s->dinv, s->nsub, s->sub_ptr,
+                 tmp, z);
+}
+
+static int ksp_bcgs(wo_sim *s, const double *val, const double *b, double *x, double rtol,
+                    double atol, int maxits, int *its, double *rnorm, double *hist) {
+  int bs = s->eos.np, n = bs * s->n_owned, nl = bs * s->n_prim;
+  double *R = xmalloc(sizeof(double) * n), *RP = xmalloc(sizeof(double) * n);
+  double *P = xmalloc(sizeof(double) * nl), *V = xmalloc(sizeof(double) * n);
+  double *S = xmalloc(sizeof(double) * nl), *T = xmalloc(sizeof(double) * n);
+  double *tmp = xmalloc(sizeof(double) * n);
+  int reason = 0, i;
+  memset(x, 0, sizeof(double) * n);
+  wo_bilu0_apply(s->n_owned, bs, s->rowptr, s->colidx, s->fval, s->dinv, s->nsub, s->sub_ptr,
+                 b, R);
+  double dp = sqrt(gdot(s, R, R, n));
+  double ttol = fmax(rtol * dp, atol), dp0 = dp;
+  if (hist) hist[0] = dp;
+  *its = 0;
+  if (dp <= ttol) reason = (dp <= atol) ? 3 : 2;
+  memcpy(RP, R, sizeof(double) * n);
+  double rhoold = 1.0, alphaold = 1.0, omegaold = 1.0;
+  for (i = 0; i < maxits && !reason; i++) {
+    double rho = gdot(s, R, RP, n);
+    if (rho == 0.0) { reason = -5; break; }
+    double beta = (rho / rhoold) * (alphaold / omegaold);
+    for (int q = 0; q < n; q++) P[q] = R[q] + (-omegaold * beta) * V[q] + beta * P[q];
+    pc_amul(s, val, P, tmp, V);
+    double d1 = gdot(s, V, RP, n);
+    if (d1 == 0.0) { reason = -5; break; }
+    double alpha = rho / d1;
+    for (int q = 0; q < n; q++) S[q] = R[q] - alpha * V[q];
+    pc_amul(s, val, S, tmp, T);
+    double d2;
+    d1 = gdot(s, S, T, n);
+    d2 = gdot(s, T, T, n);
+    if (d2 == 0.0) {
+      double ss = gdot(s, S, S, n);
+      if (ss != 0.0) { reason = -5; break; }
+      for (int q = 0; q < n; q++) x[q] += alpha * P[q];
+      *its = i + 1;
+      dp = 0.0;
+      if (hist) hist[i + 1] = dp;
+      reason = 3;
+      break;
+    }
+    double omega = d1 / d2;
+    for (int q = 0; q < n; q++) x[q] += alpha * P[q] + omega * S[q];
+    for (int q = 0; q < n; q++) R[q] = S[q] - omega * T[q];
+    dp = sqrt(gdot(s, R, R, n));
+    rhoold = rho; alphaold = alpha; omegaold = omega;
+    *its = i + 1;
+    if (hist) hist[i + 1] = dp;
+    if (isnan(dp)) reason = -9;
+    else if (dp <= ttol) reason = (dp <= atol) ? 3 : 2;
+    else if (dp >= 1.e4 * dp0) reason = -4;
+  }
+  if (!reason) reason = -3; /* KSP_DIVERGED_ITS */
+  *rnorm = dp;
+  free(R); free(RP); free(P); free(V); free(S); free(T); free(tmp);
+  return reason;
+}
+
+static int ksp_gmres(wo_sim *s, int m, const double *val, const double *b, double *x,
+                     double rtol, double atol, int maxits, int *its, double *rnorm,
+                     double *hist) {
+  int bs = s->eos.np, n = bs * s->n_owned, nl = bs * s->n_prim;
+  double *Vb = xmalloc(sizeof(double) * (size_t)nl * (m + 1));
+  double *H = xmalloc(sizeof(double) * (m + 1) * m), *cs = xmalloc(sizeof(double) * m);
+  double *sn = xmalloc(sizeof(double) * m), *g = xmalloc(sizeof(double) * (m + 1));
+  double *w = xmalloc(sizeof(double) * n), *tmp = xmalloc(sizeof(double) * n);
+  double *xl = xmalloc(sizeof(double) * nl), *yv = xmalloc(sizeof(double) * m);
+  int reason = 0, it = 0;
+  double ttol = 0.0, res = 0.0, res0 = 0.0;
+  memset(x, 0, sizeof(double) * n);
+  while (!reason) {
+    /* r = B^-1 (b - A x) */
+    double *v0 = Vb;
+    if (it == 0) {
+      wo_bilu0_apply(s->n_owned, bs, s->rowptr, s->colidx, s->fval, s->dinv, s->nsub,
+                     s->sub_ptr, b, v0);
+    } else {
+      memcpy(xl, x, sizeof(double) * n);
+      if (s->halo && s->n_halo) s->halo(s->user, xl, bs);
+      wo_bcsr_spmv(s->n_owned, bs, s->rowptr, s->colidx, val, xl, tmp);
+      for (int q = 0; q < n; q++) tmp[q] = b[q] - tmp[q];
+      wo_bilu0_apply(s->n_owned, bs, s->rowptr, s->colidx, s->fval, s->dinv, s->nsub,
+                     s->sub_ptr, tmp, v0);
+    }
+    res = sqrt(gdot(s, v0, v0, n));
+    if (it == 0) {
+      res0 = res;
+      ttol = fmax(rtol * res, atol);
+      if (hist) hist[0] = res;
+      if (res <= ttol) { reason = (res <= atol) ? 3 : 2; break; }
+    }
+    if (res == 0.0) { reason = 3; break; }
+    for (int q = 0; q < n; q++) v0[q] /= res;
+    memset(g, 0, sizeof(double) * (m + 1));
+    g[0] = res;
+    int j;
+    for (j = 0; j < m && !reason; j++) {
+      double *vj = Vb + (size_t)nl * j, *vn = Vb + (size_t)nl * (j + 1);
+      pc_amul(s, val, vj, tmp, w);
+      /* classical Gram-Schmidt, no refinement */
+      for (int i = 0; i <= j; i++) H[i * m + j] = 0.0;
+      {
+        double hh[64];
+        for (int i = 0; i <= j; i++) {
+          const double *vi = Vb + (size_t)nl * i;
+          double t = 0.0;
+          for (int q = 0; q < n; q++) t += w[q] * vi[q];
+          hh[i] = t;
+        }
+        if (s->ar) s->ar(s->user, hh, j + 1, 0);
+        for (int i = 0; i <= j; i++) {
+          const double *vi = Vb + (size_t)nl * i;
+          H[i * m + j] = hh[i];
+          for (int q = 0; q < n; q++) w[q] -= hh[i] * vi[q];
+        }
+      }
+      double hn = sqrt(gdot(s, w, w, n));
+      H[(j + 1) * m + j] = hn;
+      if (hn != 0.0)
+        for (int q = 0; q < n; q++) vn[q] = w[q] / hn;
+      for (int i = 0; i < j; i++) {
+        double a = H[i * m + j], bq = H[(i + 1) * m + j];
+        H[i * m + j] = cs[i] * a + sn[i] * bq;
+        H[(i + 1) * m + j] = -sn[i] * a + cs[i] * bq;
+      }
+      {
+        double a = H[j * m + j], bq = H[(j + 1) * m + j], d = sqrt(a * a + bq * bq);
+        cs[j] = a / d; sn[j] = bq / d;
+        H[j * m + j] = d; H[(j + 1) * m + j] = 0.0;
+        g[j + 1] = -sn[j] * g[j];
+        g[j] = cs[j] * g[j];
+      }
+      res = fabs(g[j + 1]);
+      it++;
+      if (hist) hist[it] = res;
+      if (isnan(res)) reason = -9;
+      else if (res <= ttol) reason = (res <= atol) ? 3 : 2;
+      else if (res >= 1.e4 * res0) reason = -4;
+      else if (it >= maxits) reason = -3;
+      else if (hn == 0.0) reason = 3;
+    }
+    int k = (reason && j < m) ? j : j; /* number of columns built */
+    if (k > m) k = m;
+    for (int i = k - 1; i >= 0; i--) {
+      double t = g[i];
+      for (int q = i + 1; q < k; q++) t -= H[i * m + q] * yv[q];
+      yv[i] = t / H[i * m + i];
+    }
+    for (int i = 0; i < k; i++) {
+      const double *vi = Vb + (size_t)nl * i;
+      for (int q = 0; q < n; q++) x[q] += yv[i] * vi[q];
+    }
+  }
+  *its = it;
+  *rnorm = res;
+  free(Vb); free(H); free(cs); free(sn); free(g); free(w); free(tmp); free(xl); free(yv);
+  return reason;
+}
+
+int wo_ksp_solve(wo_sim *s, int ksp_type, int restart, const double *val, const double *b,
+                 double *x, double rtol, double atol, int maxits, int *its, double *rnorm,
+                 double *hist) {
+  int bs = s->eos.np;
+  if (wo_bilu0_factor(s->n_owned, bs, s->rowptr, s->colidx, val, s->nsub, s->sub_ptr, s->fval,
+                      s->dinv))
+    return -11; /* KSP_DIVERGED_PC_FAILED */
+  if (ksp_type == 1) return ksp_gmres(s, restart > 0 ? restart : 30, val, b, x, rtol, atol,
+                                      maxits, its, rnorm, hist);
+  return ksp_bcgs(s, val, b, x, rtol, atol, maxits, its, rnorm, hist);
+}
+
+/* ---- Newton protocol --------------------------------------------------------------------- */
+void wo_newton_opts_default(wo_newton_opts *o) {
+  o->ksp_type = 0;            /* bcgs: timestepper.F90:2019-2020 */
+  o->restart = 30;
+  o->ksp_maxits = 10000;      /* PETSc default */
+  o->ksp_rtol = 1.e-5;        /* PETSc default */
+  o->ksp_atol = 1.e-50;
+  o->max_newton_its = 8;      /* timestepper.F90:1567 */
+  o->jac_mode = 0;
+  o->ftol_rel = 1.e-5; o->ftol_abs = 1.0;     /* timestepper.F90:1998-2001 */
+  o->utol_rel = 1.e-10; o->utol_abs = 1.0;
+  o->fd_eps = 1.e-8; o->fd_umin = 1.e-2;      /* timestepper.F90:1572-1573 */
+}
+
+static double norm2(wo_sim *s, const double *v, int n) { return sqrt(gdot(s, v, v, n)); }
+
+/* SNES_convergence: src/timestepper.F90:1898-1951, plus SNESConvergedDefault [PETSc] with the
+ * reference's settings (rtol 1e-8, atol 1e-50, stol 1e-99, dtol 1e8: :1570-1571,1618-1621) */
+static int snes_convergence(wo_sim *s, const wo_newton_opts *o, int it, const double *f,
+                            const double *lhs_old, const double *y, const double *update,
+                            double fnorm, double fnorm0, double *max_residual) {
+  int loc, reason = 0;
+  wo_max_scaled(s, f, lhs_old, o->ftol_abs, max_residual, &loc);
+  if (isnan(fnorm)) reason = -4;
+  else if (it == 0) { if (fnorm < 1.e-50) reason = 3; }
+  else if (fnorm <= 1.e-8 * fnorm0) reason = 4;
+  else if (fnorm > 1.e8 * fnorm0) reason = -9;
+  if (*max_residual < o->ftol_rel) reason = 1;
+  else if (it > 0) {
+    double mu;
+    wo_max_scaled(s, update, y, o->utol_abs, &mu, &loc);
+    if (mu <= o->utol_rel) reason = 2;
+  }
+  return reason;
+}
+
+int wo_newton_step(wo_sim *s, const wo_newton_opts *o, int iter, double dt, double *y,
+                   const double *lhs_old, double *f, int *ksp_its, double *max_residual) {
+  int np = s->eos.np, n = np * s->n_owned, nl = np * s->n_prim;
+  g_fd_eps = o->fd_eps; g_fd_umin = o->fd_umin;
+  double *val = xmalloc(sizeof(double) * (size_t)s->nnzb * np * np);
+  double *delta = xmalloc(sizeof(double) * n), *w = xmalloc(sizeof(double) * nl);
+  double *yold = xmalloc(sizeof(double) * nl);
+  int reason = 0;
+  static double fnorm0_keep = 0.0;
+  if (iter == 0) fnorm0_keep = norm2(s, f, n);
+  wo_pre_iteration(s); /* SNES_pre_iteration_update: timestepper.F90:628-645 */
+  if (wo_jacobian(s, y, dt, lhs_old, f, o->jac_mode, val)) { reason = -3; goto done; }
+  double rn;
+  int kreason = wo_ksp_solve(s, o->ksp_type, o->restart, val, f, delta, o->ksp_rtol,
+                             o->ksp_atol, o->ksp_maxits, ksp_its, &rn, NULL);
+  if (kreason < 0) { reason = -3; goto done; } /* SNES_DIVERGED_LINEAR_SOLVE */
+  /* SNES_linesearch: timestepper.F90:673-735, lambda = 1 */
+  memcpy(yold, y, sizeof(double) * nl);
+  for (int i = 0; i < n; i++) w[i] = y[i] - delta[i];
+  int cs, cy;
+  if (wo_post_linesearch(s, yold, delta, w, &cs, &cy)) { reason = -3; goto done; }
+  if (cy && !cs)
+    for (int i = 0; i < n; i++) w[i] = y[i] - delta[i];
+  memcpy(y, w, sizeof(double) * n);
+  if (iter < o->max_newton_its - 1) {
+    if (wo_residual(s, y, dt, lhs_old, f)) { reason = -3; goto done; }
+  }
+  {
+    double fnorm = norm2(s, f, n);
+    reason = snes_convergence(s, o, iter + 1, f, lhs_old, y, delta, fnorm, fnorm0_keep,
+                              max_residual);
+    if (!reason && iter + 1 >= o->max_newton_its) reason = -5; /* SNES_DIVERGED_MAX_IT */
+  }
+done:
+  free(val); free(delta); free(w); free(yold);
+  return reason;
+}
+
+int wo_timestep(wo_sim *s, const wo_newton_opts *o, double dt, double *y, int *total_ksp_its) {
+  int np = s->eos.np, n = np * s->n_owned, nl = np * s->n_prim;
+  double *lhs_old = xmalloc(sizeof(double) * n), *f = xmalloc(sizeof(double) * n);
+  double *ysave = xmalloc(sizeof(double) * nl);
+  int result;
+  *total_ksp_its = 0;
+  wo_pre_timestep(s);
+  memcpy(ysave, y, sizeof(double) * nl);
+  if (wo_pre_eval(s, y)) { result = -3; goto fail; }
+  wo_lhs(s, lhs_old);
+  if (wo_residual(s, y, dt, lhs_old, f)) { result = -3; goto fail; }
+  {
+    double mr, fnorm = norm2(s, f, n);
+    int reason = snes_convergence(s, o, 0, f, lhs_old, y, NULL, fnorm, fnorm, &mr);
+    int it = 0;
+    while (!reason) {
+      int kits = 0;
+      reason = wo_newton_step(s, o, it, dt, y, lhs_old, f, &kits, &mr);
+      *total_ksp_its += kits;
+      it++;
+    }
+    if (reason > 0) { result = it; goto ok; }
+    result = reason;
+  }
+fail:
+  memcpy(y, ysave, sizeof(double) * nl);
+  wo_pre_retry_timestep(s);
+ok:
+  free(lhs_old); free(f); free(ysave);
+  return result;
+}

@@ -1,0 +1,205 @@
+"""ctypes binding of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Nothing in waiwera_amd/ may import this module.
+"""
+import ctypes as C
+
+import numpy as np
+
+d = C.c_double
+i32 = C.c_int
+pd = C.POINTER(C.c_double)
+pi = C.POINTER(C.c_int)
+
+
+class Eos(C.Structure):
+    _fields_ = [("kind", i32), ("np", i32), ("nc", i32), ("nph", i32), ("nmob", i32),
+                ("df", i32), ("isothermal", i32), ("temperature", d),
+                ("scale", d * 4 * 5), ("rp_type", i32), ("cp_type", i32),
+                ("rp_par", d * 6), ("cp_par", d * 6)]
+
+
+class NewtonOpts(C.Structure):
+    _fields_ = [("ksp_type", i32), ("restart", i32), ("ksp_maxits", i32),
+                ("max_newton_its", i32), ("jac_mode", i32),
+                ("ksp_rtol", d), ("ksp_atol", d), ("ftol_rel", d), ("ftol_abs", d),
+                ("utol_rel", d), ("utol_abs", d), ("fd_eps", d), ("fd_umin", d)]
+
+
+ROOTFN = C.CFUNCTYPE(d, d, C.c_void_p)
+HALOFN = C.CFUNCTYPE(None, C.c_void_p, pd, i32)
+ARFN = C.CFUNCTYPE(None, C.c_void_p, pd, i32, i32)
+
+RP = {"fully_mobile": 0, "linear": 1, "pickens": 2, "corey": 3, "grant": 4, "van_genuchten": 5}
+CP = {"zero": 0, "linear": 1, "van_genuchten": 2}
+
+
+def dp(a):
+    return a.ctypes.data_as(pd)
+
+
+def ip(a):
+    return a.ctypes.data_as(pi)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32a(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def load(path):
+    L = C.CDLL(path)
+    sig = {
+        "wo_region1": (i32, [d, d, pd, pd]), "wo_region2": (i32, [d, d, pd, pd]),
+        "wo_sat_pressure": (i32, [d, pd]), "wo_sat_temperature": (i32, [d, pd]),
+        "wo_viscosity": (d, [d, d]), "wo_phase_composition": (i32, [i32, d, d]),
+        "wo_relperm": (None, [i32, pd, d, pd]), "wo_capillary": (d, [i32, pd, d, d]),
+        "wo_brent": (i32, [ROOTFN, C.c_void_p, d, d, d, d, i32, pd, pi]),
+        "wo_eos_init": (None, [C.POINTER(Eos), i32]),
+        "wo_eos_bulk_properties": (i32, [C.POINTER(Eos), pd, pd]),
+        "wo_eos_phase_properties": (i32, [C.POINTER(Eos), pd, pd]),
+        "wo_eos_transition": (i32, [C.POINTER(Eos), pd, pd, pd, pd, pi]),
+        "wo_eos_check_primary": (i32, [C.POINTER(Eos), pd, pd]),
+        "wo_cell_balance": (None, [C.POINTER(Eos), pd, pd, pd]),
+        "wo_face_flux": (None, [C.POINTER(Eos), pd, pd, pd, pd, pd, pd]),
+        "wo_face_phase_density": (d, [C.POINTER(Eos), pd, pd, i32]),
+        "wo_conductivity": (d, [pd, pd, C.POINTER(Eos)]),
+        "wo_bcsr_spmv": (None, [i32, i32, pi, pi, pd, pd, pd]),
+        "wo_bilu0_factor": (i32, [i32, i32, pi, pi, pd, i32, pi, pd, pd]),
+        "wo_bilu0_apply": (None, [i32, i32, pi, pi, pd, pd, i32, pi, pd, pd]),
+        "wo_sim_create": (C.c_void_p, [i32, i32, i32, i32, i32, pi, pd, pd, pd]),
+        "wo_sim_destroy": (None, [C.c_void_p]),
+        "wo_sim_eos": (C.POINTER(Eos), [C.c_void_p]),
+        "wo_sim_set_comm": (None, [C.c_void_p, HALOFN, ARFN, C.c_void_p]),
+        "wo_sim_set_sources": (None, [C.c_void_p, i32, pi, pd, pd, pi]),
+        "wo_sim_set_subdomains": (None, [C.c_void_p, i32, pi]),
+        "wo_sim_set_regions": (None, [C.c_void_p, pi]),
+        "wo_sim_get_regions": (None, [C.c_void_p, pi]),
+        "wo_sim_init_bc": (i32, [C.c_void_p, pd, pi]),
+        "wo_sim_fluid": (pd, [C.c_void_p]),
+        "wo_sim_nnzb": (i32, [C.c_void_p]),
+        "wo_sim_pattern": (None, [C.c_void_p, pi, pi]),
+        "wo_pre_timestep": (None, [C.c_void_p]), "wo_pre_retry_timestep": (None, [C.c_void_p]),
+        "wo_pre_iteration": (None, [C.c_void_p]),
+        "wo_pre_eval": (i32, [C.c_void_p, pd]),
+        "wo_lhs": (None, [C.c_void_p, pd]), "wo_rhs": (None, [C.c_void_p, pd]),
+        "wo_residual": (i32, [C.c_void_p, pd, d, pd, pd]),
+        "wo_post_linesearch": (i32, [C.c_void_p, pd, pd, pd, pi, pi]),
+        "wo_jacobian": (i32, [C.c_void_p, pd, d, pd, pd, i32, pd]),
+        "wo_max_scaled": (None, [C.c_void_p, pd, pd, d, pd, pi]),
+        "wo_ksp_solve": (i32, [C.c_void_p, i32, i32, pd, pd, pd, d, d, i32, pi, pd, pd]),
+        "wo_newton_opts_default": (None, [C.POINTER(NewtonOpts)]),
+        "wo_newton_step": (i32, [C.c_void_p, C.POINTER(NewtonOpts), i32, d, pd, pd, pd, pi, pd]),
+        "wo_timestep": (i32, [C.c_void_p, C.POINTER(NewtonOpts), d, pd, pi]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+class OracleSim:
+    """Thin object wrapper over the oracle's wo_sim for the tests / cpu baseline."""
+
+    def __init__(self, L, mesh, eos_kind):
+        self.L = L
+        self.mesh = mesh
+        self._keep = [f64(mesh.face_geom), f64(mesh.cell_geom), f64(mesh.rock), i32a(mesh.face_cells)]
+        fg, cg, rk, fc = self._keep
+        self.h = L.wo_sim_create(eos_kind, mesh.n_owned, mesh.n_halo, mesh.n_bc, mesh.n_faces,
+                                 ip(fc), dp(fg), dp(cg), dp(rk))
+        self.eos = L.wo_sim_eos(self.h).contents
+        self.np = self.eos.np
+        self.df = self.eos.df
+        self.n_owned, self.n_prim = mesh.n_owned, mesh.n_owned + mesh.n_halo
+        self.n_local = self.n_prim + mesh.n_bc
+        if mesh.n_bc:
+            bp, br = f64(mesh.bc_primary), i32a(mesh.bc_region)
+            assert L.wo_sim_init_bc(self.h, dp(bp), ip(br)) == 0
+        if getattr(mesh, "n_src", 0):
+            sc, sr, se, sk = i32a(mesh.src_cell), f64(mesh.src_rate), f64(mesh.src_enthalpy), i32a(mesh.src_component)
+            L.wo_sim_set_sources(self.h, len(sc), ip(sc), dp(sr), dp(se), ip(sk))
+        if getattr(mesh, "sub_ptr", None) is not None:
+            sp = i32a(mesh.sub_ptr)
+            L.wo_sim_set_subdomains(self.h, len(sp) - 1, ip(sp))
+        self._cb = None
+
+    def close(self):
+        if self.h:
+            self.L.wo_sim_destroy(self.h)
+            self.h = None
+
+    def set_regions(self, region):
+        r = i32a(region)
+        assert r.size == self.n_prim
+        self.L.wo_sim_set_regions(self.h, ip(r))
+
+    def regions(self):
+        r = np.zeros(self.n_prim, dtype=np.int32)
+        self.L.wo_sim_get_regions(self.h, ip(r))
+        return r
+
+    def fluid(self):
+        ptr = self.L.wo_sim_fluid(self.h)
+        return np.ctypeslib.as_array(ptr, shape=(self.n_local, self.df))
+
+    def pattern(self):
+        nnzb = self.L.wo_sim_nnzb(self.h)
+        rp = np.zeros(self.n_owned + 1, dtype=np.int32)
+        ci = np.zeros(nnzb, dtype=np.int32)
+        self.L.wo_sim_pattern(self.h, ip(rp), ip(ci))
+        return rp, ci
+
+    def yvec(self, y):
+        out = np.zeros(self.n_prim * self.np)
+        y = np.asarray(y, dtype=np.float64).ravel()
+        out[: y.size] = y
+        return out
+
+    def pre_eval(self, y):
+        return self.L.wo_pre_eval(self.h, dp(y))
+
+    def lhs(self):
+        out = np.zeros(self.n_owned * self.np)
+        self.L.wo_lhs(self.h, dp(out))
+        return out
+
+    def rhs(self):
+        out = np.zeros(self.n_owned * self.np)
+        self.L.wo_rhs(self.h, dp(out))
+        return out
+
+    def residual(self, y, dt, lhs_old):
+        f = np.zeros(self.n_owned * self.np)
+        err = self.L.wo_residual(self.h, dp(y), dt, dp(f64(lhs_old)), dp(f))
+        return err, f
+
+    def jacobian(self, y, dt, lhs_old, f, mode=0):
+        nnzb = self.L.wo_sim_nnzb(self.h)
+        val = np.zeros(nnzb * self.np * self.np)
+        err = self.L.wo_jacobian(self.h, dp(y), dt, dp(f64(lhs_old)), dp(f64(f)), mode, dp(val))
+        return err, val
+
+    def ksp_solve(self, val, b, ksp_type=0, restart=30, rtol=1e-5, atol=1e-50, maxits=10000):
+        x = np.zeros(self.n_prim * self.np)
+        its = C.c_int(0)
+        rn = C.c_double(0)
+        hist = np.zeros(maxits + 2)
+        reason = self.L.wo_ksp_solve(self.h, ksp_type, restart, dp(f64(val)), dp(f64(b)), dp(x),
+                                     rtol, atol, maxits, C.byref(its), C.byref(rn), dp(hist))
+        return reason, x[: self.n_owned * self.np], its.value, hist[: its.value + 1]
+
+    def opts(self):
+        o = NewtonOpts()
+        self.L.wo_newton_opts_default(C.byref(o))
+        return o
+
+    def timestep(self, y, dt, opts=None):
+        o = opts or self.opts()
+        k = C.c_int(0)
+        r = self.L.wo_timestep(self.h, C.byref(o), dt, dp(y), C.byref(k))
+        return r, k.value

@@ -1,0 +1,270 @@
+"""Pins the CPU oracle against the known-answer values the reference's own unit tests hold.
+
+The numbers in tests/golden/reference_unit_values.json are transcribed from
+/root/reference/test/unit/src/*_test.F90 (file:line in each block's "source").
+"""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as ol
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = json.load(open(os.path.join(HERE, "golden", "reference_unit_values.json")))
+TC_K = 273.15
+
+
+def rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-300)
+
+
+def test_region1(oracle):
+    g = G["iapws_region1"]
+    rho, u = C.c_double(), C.c_double()
+    for c in g["cases"]:
+        assert oracle.wo_region1(c["p"], c["tk"] - TC_K, rho, u) == 0
+        assert rel(rho.value, 1.0 / c["nu"]) < g["tol"]
+        assert rel(u.value, c["u"]) < g["tol"]
+    for c in g["errors"]:
+        assert oracle.wo_region1(c["p"], c["t"], rho, u) == 1
+
+
+def test_region2(oracle):
+    g = G["iapws_region2"]
+    rho, u = C.c_double(), C.c_double()
+    for c in g["cases"]:
+        assert oracle.wo_region2(c["p"], c["tk"] - TC_K, rho, u) == 0
+        assert rel(rho.value, 1.0 / c["nu"]) < g["tol"]
+        assert rel(u.value, c["u"]) < g["tol"]
+    for c in g["errors"]:
+        assert oracle.wo_region2(c["p"], c["t"], rho, u) == 1
+
+
+def test_saturation(oracle):
+    g = G["iapws_saturation"]
+    p, t = C.c_double(), C.c_double()
+    for c in g["cases"]:
+        assert oracle.wo_sat_pressure(c["tk"] - TC_K, p) == 0
+        assert rel(p.value, c["p"]) < g["tol"]
+        assert oracle.wo_sat_temperature(p.value, t) == 0
+        assert rel(t.value, c["tk"] - TC_K) < g["tol"]
+    assert oracle.wo_sat_pressure(g["t_error"], p) == 1
+    assert oracle.wo_sat_temperature(g["p_error"], t) == 1
+
+
+def test_viscosity(oracle):
+    g = G["iapws_viscosity"]
+    for tk, dd, v in zip(g["tk"], g["d"], g["visc_micro"]):
+        assert rel(oracle.wo_viscosity(tk - TC_K, dd), v * 1e-6) < g["tol"]
+
+
+def _eos(oracle, kind):
+    e = ol.Eos()
+    oracle.wo_eos_init(C.byref(e), kind)
+    return e
+
+
+def test_eos_w_fluid_properties(oracle):
+    g = G["eos_w_fluid_properties"]
+    e = _eos(oracle, 0)
+    e.temperature = g["temperature"]
+    assert e.df == 15
+    fl = np.zeros(e.df)
+    fl[2] = g["region"]
+    prim = np.array([g["pressure"]])
+    assert oracle.wo_eos_bulk_properties(C.byref(e), ol.dp(prim), ol.dp(fl)) == 0
+    assert oracle.wo_eos_phase_properties(C.byref(e), ol.dp(prim), ol.dp(fl)) == 0
+    assert fl[0] == g["pressure"] and fl[1] == g["temperature"] and int(fl[4]) == g["phases"]
+    ph = fl[7:15]
+    assert rel(ph[0], g["density"]) < g["tol"]
+    assert rel(ph[6], g["internal_energy"]) < g["tol"]
+    assert rel(ph[5], g["specific_enthalpy"]) < g["tol"]
+    assert rel(ph[1], g["viscosity"]) < g["tol"]
+    assert ph[2] == 1.0 and ph[3] == 1.0 and ph[7] == 1.0
+
+
+def test_eos_we_fluid_properties(oracle):
+    g = G["eos_we_fluid_properties"]
+    e = _eos(oracle, 1)
+    assert e.df == 23 and e.np == 2
+    e.rp_type = ol.RP["linear"]
+    for k, v in enumerate(g["relperm_linear"]):
+        e.rp_par[k] = v
+    fl = np.zeros(e.df)
+    fl[2] = g["region"]
+    prim = np.array([g["pressure"], g["vapour_saturation"]])
+    assert oracle.wo_eos_bulk_properties(C.byref(e), ol.dp(prim), ol.dp(fl)) == 0
+    assert oracle.wo_eos_phase_properties(C.byref(e), ol.dp(prim), ol.dp(fl)) == 0
+    assert rel(fl[1], g["temperature"]) < g["tol"]
+    assert int(fl[4]) == g["phases"]
+    for off, name, sat in ((7, "liquid", 1 - g["vapour_saturation"]), (15, "vapour", g["vapour_saturation"])):
+        ph, ex = fl[off:off + 8], g[name]
+        assert rel(ph[0], ex["density"]) < g["tol"]
+        assert rel(ph[1], ex["viscosity"]) < g["tol"]
+        assert ph[2] == sat
+        assert rel(ph[3], ex["relative_permeability"]) < g["tol"]
+        assert ph[4] == ex["capillary_pressure"]
+        assert rel(ph[5], ex["specific_enthalpy"]) < g["tol"]
+        assert rel(ph[6], ex["internal_energy"]) < g["tol"]
+        assert ph[7] == 1.0
+
+
+def test_eos_we_transition(oracle):
+    g = G["eos_we_transition"]
+    e = _eos(oracle, 1)
+    for c in g["cases"]:
+        ofl, fl = np.zeros(e.df), np.zeros(e.df)
+        ofl[2] = fl[2] = c["old_region"]
+        ofl[1] = c.get("old_temperature", 0.0)
+        oldp, prim = np.array(c["old_primary"]), np.array(c["primary"])
+        tr = C.c_int(0)
+        err = oracle.wo_eos_transition(C.byref(e), ol.dp(oldp), ol.dp(prim), ol.dp(ofl), ol.dp(fl), C.byref(tr))
+        assert err == 0, c["title"]
+        assert bool(tr.value) == c["transition"], c["title"]
+        assert int(fl[2]) == c["expected_region"], c["title"]
+        for a, b in zip(prim, c["expected_primary"]):
+            assert rel(a, b) < g["tol"], c["title"]
+
+
+def test_eos_we_errors(oracle):
+    e = _eos(oracle, 1)
+    for c in G["eos_we_errors"]["cases"]:
+        fl = np.zeros(e.df)
+        fl[2] = c["region"]
+        prim = np.array(c["primary"])
+        err = oracle.wo_eos_bulk_properties(C.byref(e), ol.dp(prim), ol.dp(fl))
+        if err == 0:
+            err = oracle.wo_eos_phase_properties(C.byref(e), ol.dp(prim), ol.dp(fl))
+        assert err == 1
+
+
+def test_eos_we_check_primary(oracle):
+    # bounds of eos_we_check_primary_variables (src/eos_we.F90:486-526)
+    e = _eos(oracle, 1)
+    fl = np.zeros(e.df)
+    for region, prim, want in ((1, [1e5, 20.0], 0), (1, [-1.0, 20.0], 1), (1, [1.01e8, 20.0], 1),
+                               (1, [1e5, 801.0], 1), (2, [1e5, -0.5], 1), (4, [1e5, 1.5], 0),
+                               (4, [1e5, 2.5], 1), (4, [1e5, -1.5], 1)):
+        fl[2] = region
+        p = np.array(prim)
+        assert oracle.wo_eos_check_primary(C.byref(e), ol.dp(fl), ol.dp(p)) == want
+
+
+def test_conductivity(oracle):
+    g = G["eos_we_conductivity"]
+    e = _eos(oracle, 1)
+    rock = np.zeros(8)
+    rock[3], rock[4] = g["wet"], g["dry"]
+    for sl, ex in zip(g["sl"], g["cond"]):
+        fl = np.zeros(e.df)
+        fl[9] = sl
+        assert abs(oracle.wo_conductivity(ol.dp(rock), ol.dp(fl), C.byref(e)) - ex) < g["tol"]
+
+
+def test_cell_balance(oracle):
+    g = G["cell_balance"]
+    e = _eos(oracle, 1)
+    # the reference test uses a 2-component, 3-primary layout with generic fluid data
+    e.nc, e.np, e.nph = 2, 3, 2
+    e.df = (7 + e.nc - 1) + e.nph * (8 + e.nc - 1)
+    fl, rock = np.array(g["fluid"]), np.array(g["rock"])
+    assert fl.size == e.df
+    bal = np.zeros(3)
+    oracle.wo_cell_balance(C.byref(e), ol.dp(fl), ol.dp(rock), ol.dp(bal))
+    for a, b in zip(bal, g["expected"]):
+        assert rel(a, b) < g["tol"]
+
+
+def test_face_flux(oracle):
+    g = G["face_flux"]
+    e = _eos(oracle, 1)
+    for c in g["cases"]:
+        arrs = [np.array(c[k], dtype=np.float64) for k in ("face", "fluid1", "rock1", "fluid2", "rock2")]
+        flux = np.zeros(4)
+        oracle.wo_face_flux(C.byref(e), *[ol.dp(a) for a in arrs], ol.dp(flux))
+        if "expected_liquid_density" in c:
+            assert rel(oracle.wo_face_phase_density(C.byref(e), ol.dp(arrs[1]), ol.dp(arrs[3]), 0),
+                       c["expected_liquid_density"]) < g["tol"]
+            assert rel(oracle.wo_face_phase_density(C.byref(e), ol.dp(arrs[1]), ol.dp(arrs[3]), 1),
+                       c["expected_vapour_density"]) < g["tol"]
+        for k, (a, b) in enumerate(zip(flux, c["expected"])):
+            if b == 0.0:
+                atol = c.get("abs_tol", [0.0] * 4)[k]
+                assert abs(a) <= atol, (c["title"], k, a)
+            else:
+                assert rel(a, b) < g["tol"], (c["title"], k, a, b)
+
+
+def test_relative_permeability(oracle):
+    g = G["relative_permeability"]
+    for c in g["cases"]:
+        par = np.zeros(6)
+        par[: len(c["par"])] = c["par"]
+        for sl, ex in zip(c["sl"], c["rp"]):
+            rp = np.zeros(2)
+            oracle.wo_relperm(ol.RP[c["type"]], ol.dp(par), sl, ol.dp(rp))
+            assert abs(rp[0] - ex[0]) < g["tol"] and abs(rp[1] - ex[1]) < g["tol"], (c["type"], sl, rp)
+
+
+def test_capillary_pressure(oracle):
+    g = G["capillary_pressure"]
+    for c in g["cases"]:
+        par = np.zeros(6)
+        par[: len(c["par"])] = c["par"]
+        for sl, ex in zip(c["sl"], c["cp"]):
+            v = oracle.wo_capillary(ol.CP[c["type"]], ol.dp(par), sl, 20.0)
+            assert abs(v - ex) <= g["tol"] * max(abs(ex), 1.0), (c["type"], sl, v)
+
+
+def test_root_finder(oracle):
+    g = G["root_finder"]
+    fns = {
+        "linear": lambda x: 0.5 - x,
+        "quadratic": lambda x: (x - 0.75) ** 2 - 0.5,
+        "zhang": lambda x: math.cos(x) - x ** 3,
+        "invquad": lambda x: (-1.0 if x - 2.0 / 3.0 > 0 else 1.0) * math.sqrt(abs(x - 2.0 / 3.0)),
+    }
+    for c in g["cases"]:
+        cb = ol.ROOTFN(lambda x, ctx, f=fns[c["fn"]]: f(x))
+        root, its = C.c_double(), C.c_int()
+        err = oracle.wo_brent(cb, None, c["interval"][0], c["interval"][1], 1e-8, 1e-8, 100, root, its)
+        assert err == 0
+        assert abs(root.value - c["root"]) < g["tol"]
+        assert its.value <= c["max_iterations"] + 1
+    # non-bracketing interval -> error 1 (root_finder_test.F90:74-80)
+    cb = ol.ROOTFN(lambda x, ctx: 0.5 - x)
+    root, its = C.c_double(), C.c_int()
+    assert oracle.wo_brent(cb, None, 0.6, 1.0, 1e-8, 1e-8, 100, root, its) == 1
+    # saturation line crossing: the same function eos_we_transition_to_two_phase solves
+    s = g["saturation_line"]
+
+    def satdiff(x, ctx):
+        P = (1 - x) * s["p"][0] + x * s["p"][1]
+        T = (1 - x) * s["t"][0] + x * s["t"][1]
+        ps = C.c_double()
+        oracle.wo_sat_pressure(T, ps)
+        return ps.value - P
+    cb = ol.ROOTFN(satdiff)
+    assert oracle.wo_brent(cb, None, 0.0, 1.0, 1e-8, 1e-8, 100, root, its) == 0
+    T = (1 - root.value) * s["t"][0] + root.value * s["t"][1]
+    assert rel(T, s["expected_temperature"]) < g["tol"]
+
+
+def test_flow_simulation_lhs_fixture(oracle):
+    """12-cell eos w LHS vector of test/unit/data/flow_simulation/lhs/lhs.h5."""
+    g = G["flow_simulation_lhs"]
+    e = _eos(oracle, 0)
+    e.temperature = g["temperature"]
+    fl = np.zeros(e.df)
+    fl[2] = 1
+    prim = np.array([g["pressure"]])
+    assert oracle.wo_eos_bulk_properties(C.byref(e), ol.dp(prim), ol.dp(fl)) == 0
+    assert oracle.wo_eos_phase_properties(C.byref(e), ol.dp(prim), ol.dp(fl)) == 0
+    rock = np.array([1e-14, 2e-14, 3e-14, 1.5, 1.5, g["porosity"], 2600.0, 900.0])
+    bal = np.zeros(1)
+    oracle.wo_cell_balance(C.byref(e), ol.dp(fl), ol.dp(rock), ol.dp(bal))
+    assert rel(bal[0], g["lhs"]) < g["tol"]
