@@ -1,0 +1,176 @@
+/* waiwera_hip.h -- C ABI of the MI355X-native Newton-step hot path (libwaiwera_hip.so).
+ *
+ * Drop-in boundary.  In the reference the hot path sits behind the abstract ode_type
+ * (src/ode.F90:39-108) as consumed by the timestepper through PETSc SNES callbacks
+ * (src/timestepper.F90:587-735, 1552-1641, 1898-1951).  Each entry point below names the
+ * reference interface it replaces; a Fortran 2003 host binds them with iso_c_binding
+ * (waiwera_amd/fortran/waiwera_hip_module.F90), a Python host with ctypes
+ * (waiwera_amd/lib.py).  Plain pointers and sizes only -- no torch, PETSc or HIP types.
+ *
+ * Conventions
+ *   - fp64 throughout, 0-based int32 indices.
+ *   - every call returns int: 0 ok; >0 recoverable numerical failure (EOS out of range,
+ *     transition failed, linear solve diverged -- the reference's `err` out-argument, which
+ *     makes the timestepper retry with a smaller step, src/timestepper.F90:616-622,1353-1375);
+ *     <0 fatal (HIP / RCCL error, bad argument); wai_last_error() gives the text.
+ *   - vector arguments (y, lhs, rhs, f, x ...) may be HOST or DEVICE pointers; the library
+ *     detects which (hipPointerGetAttributes).  Device pointers are used in place, host
+ *     arrays are staged.  Vectors are interleaved [cell][component] like PETSc block Vecs and
+ *     hold bs*n_owned entries (inputs that need ghost values are haloed internally).
+ *   - local cell order: [owned | halo (other ranks' cells) | Dirichlet boundary ghosts].
+ *   - collective calls (everything that evaluates residuals or solves) must be entered by all
+ *     ranks, like the reference's callbacks (src/flow_simulation.F90:1120,2411,2570-2572).
+ */
+#ifndef WAIWERA_HIP_H
+#define WAIWERA_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wai_ctx wai_ctx;
+
+enum { WAI_EOS_W = 0, WAI_EOS_WE = 1 };
+enum { WAI_RP_FULLY_MOBILE = 0, WAI_RP_LINEAR = 1, WAI_RP_PICKENS = 2, WAI_RP_COREY = 3,
+       WAI_RP_GRANT = 4, WAI_RP_VAN_GENUCHTEN = 5 };
+enum { WAI_CP_ZERO = 0, WAI_CP_LINEAR = 1, WAI_CP_VAN_GENUCHTEN = 2 };
+enum { WAI_KSP_BCGS = 0, WAI_KSP_GMRES = 1 };
+
+/* DMPlex-local arrays in the reference's own record layouts (AoS), host memory:
+ *   face_geom 12/face  src/face.F90:67-76,119-135   cell_geom 4/cell  src/cell.F90:54-61
+ *   rock 8/cell        src/rock.F90:56-65,97-112     face_cells 2/face (DMPlexGetSupport order,
+ *                                                    normal from cell 1 to cell 2)
+ * sub_ptr[n_sub+1]: block-Jacobi subdomains of the preconditioner as contiguous owned-row
+ * ranges (PCBJACOBI blocks, src/timestepper.F90:1668-1669); NULL = one block per rank. */
+typedef struct wai_mesh_desc {
+  int n_owned, n_halo, n_bc, n_faces;
+  const int *face_cells;
+  const double *face_geom;
+  const double *cell_geom;
+  const double *rock;
+  int n_sub;
+  const int *sub_ptr;
+} wai_mesh_desc;
+
+/* EOS + curve parameters: src/eos_setup.F90:75-92, eos_w.F90:50-99, eos_we.F90:56-126,
+ * relative_permeability.F90:197-492, capillary_pressure.F90:159-305.
+ * rp_par: linear [l0,l1,v0,v1]; pickens [power]; corey/grant [slr,ssr];
+ *         van Genuchten [lambda,slr,sls,sum_unity,ssr].
+ * cp_par: linear [s0,s1,pressure]; van Genuchten [P0,lambda,slr,sls,Pmax,apply_Pmax]. */
+typedef struct wai_eos_desc {
+  int kind;
+  double temperature;        /* eos w: "eos.temperature" */
+  double pressure_scale;     /* "eos.primary.scale.pressure"     default 1e6 */
+  double temperature_scale;  /* "eos.primary.scale.temperature"  default 1e2 */
+  int rp_type;
+  double rp_par[6];
+  int cp_type;
+  double cp_par[6];
+} wai_eos_desc;
+
+/* "time.step.solver.*" keys: src/timestepper.F90:1567-1573,1645-1720,1998-2020 */
+typedef struct wai_solver_opts {
+  int ksp_type;            /* linear.type: bcgs (default) | gmres */
+  int gmres_restart;       /* linear.options.gmres.restart, PETSc default 30 */
+  int ksp_max_its;         /* linear.maximum.iterations, PETSc default 10000 */
+  double ksp_rtol;         /* linear.tolerance.relative, PETSc default 1e-5 */
+  double ksp_atol;         /* PETSc default 1e-50 */
+  int max_newton_its;      /* nonlinear.maximum.iterations, default 8 */
+  double ftol_rel, ftol_abs;   /* nonlinear.tolerance.function.{relative 1e-5, absolute 1} */
+  double utol_rel, utol_abs;   /* nonlinear.tolerance.update.{relative 1e-10, absolute 1} */
+  double fd_eps, fd_umin;      /* nonlinear.jacobian.differencing.{increment 1e-8, tolerance 1e-2} */
+} wai_solver_opts;
+
+void wai_default_eos(wai_eos_desc *e, int kind);
+void wai_default_opts(wai_solver_opts *o);
+
+/* flow_simulation_init (src/flow_simulation.F90:882-1045) for the parts the path needs */
+int wai_ctx_create(const wai_mesh_desc *mesh, const wai_eos_desc *eos,
+                   const wai_solver_opts *opts, int device, wai_ctx **out);
+int wai_ctx_destroy(wai_ctx *ctx);
+const char *wai_last_error(wai_ctx *ctx);
+int wai_set_opts(wai_ctx *ctx, const wai_solver_opts *opts);
+
+/* boundary-condition ghost cells: unscaled primaries + region per bc cell
+ * (mesh_set_boundary_conditions, src/mesh.F90:1069-1264; fluid filled once :1199-1202) */
+int wai_set_bc(wai_ctx *ctx, const double *primary, const int *region);
+/* constant-rate sources (src/source.F90:386-480, source_network.F90:296-355) */
+int wai_set_sources(wai_ctx *ctx, int n, const int *cell, const double *rate,
+                    const double *enthalpy, const int *component);
+/* thermodynamic region of every owned+halo cell (fluid%region, src/fluid.F90:77-80) */
+int wai_set_regions(wai_ctx *ctx, const int *region);
+int wai_get_regions(wai_ctx *ctx, int *region);
+/* fluid vector in the reference's AoS layout, df doubles per local cell; which: 0 fluid,
+ * 1 last_iteration_fluid, 2 last_timestep_fluid (src/flow_simulation.F90:53-56) */
+int wai_get_fluid(wai_ctx *ctx, int which, double *out);
+int wai_num_fluid_dof(wai_ctx *ctx);
+int wai_block_size(wai_ctx *ctx);
+
+/* partition ghost exchange (DMGlobalToLocal, src/dm_utils.F90:480-498) over RCCL.
+ * nbr_rank[n_nbr]; send_idx[send_ptr[q]..send_ptr[q+1]) = owned cells sent to neighbour q;
+ * halo cells n_owned+recv_ptr[q] .. n_owned+recv_ptr[q+1] are received from neighbour q. */
+int wai_set_halo(wai_ctx *ctx, int n_nbr, const int *nbr_rank, const int *send_ptr,
+                 const int *send_idx, const int *recv_ptr);
+int wai_comm_unique_id(char id[128]);                       /* rank 0, then broadcast by host */
+int wai_comm_init(wai_ctx *ctx, int rank, int nranks, const char id[128]);
+int wai_halo_exchange(wai_ctx *ctx, double *vec, int dof);  /* vec has dof*(n_owned+n_halo) */
+
+/* ---- ode_type surface (src/ode.F90:39-108 as overridden by src/flow_simulation.F90) ------ */
+int wai_pre_timestep(wai_ctx *ctx);                 /* flow_simulation.F90:2022-2035 */
+int wai_pre_retry_timestep(wai_ctx *ctx);           /* :2093-2104 */
+int wai_pre_iteration(wai_ctx *ctx);                /* :2108-2122 */
+int wai_pre_eval(wai_ctx *ctx, double t, const double *y);                 /* :2126-2147 */
+int wai_lhs(wai_ctx *ctx, double t, const double *y, double *lhs);         /* :1242-1330 */
+int wai_rhs(wai_ctx *ctx, double t, const double *y, double *rhs);         /* :1334-1485 */
+int wai_post_linesearch(wai_ctx *ctx, const double *y_old, double *search, double *y,
+                        int *changed_search, int *changed_y);              /* :2419-2576 */
+
+/* ---- SNES / KSP slots (src/timestepper.F90) ----------------------------------------------- */
+/* SNES_residual + backwards_Euler_residual (:587-624, :345-374): f = L(y) - lhs_old - dt R(y) */
+int wai_residual(wai_ctx *ctx, double t, double dt, const double *y, const double *lhs_old,
+                 double *f);
+/* SNESComputeJacobianDefaultColor slot (:1584-1611): forward-difference BCSR Jacobian at y
+ * (pre_eval/residual at y must have been called: base fluid state and f are reused) */
+int wai_jacobian(wai_ctx *ctx, double t, double dt, const double *y, const double *lhs_old);
+int wai_jacobian_nnzb(wai_ctx *ctx);
+int wai_jacobian_pattern(wai_ctx *ctx, int *rowptr, int *colidx);  /* ode_setup_jacobian, ode.F90:266-287 */
+int wai_jacobian_get_values(wai_ctx *ctx, double *val);            /* bs*bs row-major blocks */
+int wai_jacobian_set_values(wai_ctx *ctx, const double *val);
+/* MatMult_SeqBAIJ / MPIBAIJ: y = J x (x haloed internally) */
+int wai_spmv(wai_ctx *ctx, const double *x, double *y);
+/* PCSetUp / PCApply of bjacobi + ilu(0) (:1668-1669,1789-1834) */
+int wai_pc_setup(wai_ctx *ctx);
+int wai_pc_apply(wai_ctx *ctx, const double *r, double *z);
+/* KSPSolve (:1645-1836): left-preconditioned BiCGStab / GMRES(m), zero initial guess.
+ * reason follows KSPConvergedReason: 2 rtol, 3 atol, -3 its, -4 dtol, -5 breakdown, -9 nan */
+int wai_ksp_solve(wai_ctx *ctx, const double *b, double *x, int *its, int *reason,
+                  double *rnorm);
+/* vec_max_pointwise_abs_scale (src/dm_utils.F90:644-685) */
+int wai_max_scaled(wai_ctx *ctx, const double *v, const double *scale, double tol, double *val,
+                   int *idx);
+/* one Newton iteration, device-resident (timestepper.F90:628-735,1898-1951 + PETSc newtonls):
+ * pre_iteration, Jacobian, KSP solve, full-step line search with transitions, new residual,
+ * convergence test.  reason: 0 iterating, 1 converged (function), 2 converged (update),
+ * 3/4 PETSc default tests, <0 diverged (-3 linear solve / domain error, -5 max its, -9 dtol) */
+int wai_newton_step(wai_ctx *ctx, double t, double dt, int iter, double *y,
+                    const double *lhs_old, double *f, int *ksp_its, int *reason,
+                    double *max_residual);
+/* SNESSolve for one backward-Euler step (timestepper_step without the retry loop, :2316-2376):
+ * on failure y and the fluid regions are restored (pre_retry_timestep) and reason < 0 */
+int wai_timestep(wai_ctx *ctx, double t, double dt, double *y, int *newton_its, int *ksp_its,
+                 int *reason);
+
+/* ---- measurement helpers ------------------------------------------------------------------- */
+int wai_timer_start(wai_ctx *ctx);             /* hipEvent on the library's stream */
+int wai_timer_stop(wai_ctx *ctx, float *ms);
+int wai_synchronize(wai_ctx *ctx);
+/* accumulated HIP-event time (ms) and launch counts per kernel class since the last reset;
+ * classes: 0 eos, 1 residual, 2 jacobian, 3 spmv, 4 pc_apply, 5 pc_setup, 6 vector, 7 transitions */
+int wai_profile_enable(wai_ctx *ctx, int on);
+int wai_profile_get(wai_ctx *ctx, int kclass, double *ms, long long *launches);
+int wai_profile_reset(wai_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

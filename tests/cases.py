@@ -1,0 +1,26 @@
+"""Shared seeded test problems (small enough for the oracle to finish in seconds)."""
+import numpy as np
+
+from waiwera_amd import mesh as M
+
+
+def make_case(dims=(8, 8, 8), brick=(4, 4, 4), eos="we", lens=False, sources=True, part=(1, 1, 1),
+              rank=0, hetero=True, top_bc=True):
+    g = M.StructuredGrid(dims, brick=brick, part=part)
+    srcs = M.benchmark_sources(g) if sources else None
+    bc = None
+    if top_bc:
+        bc = (([1.0e5, 20.0], 1) if eos == "we" else ([1.0e5], 1))
+    rock = M.heterogeneous_rock(g.n_global) if hetero else None
+    lm = g.local_mesh(rank, rock_fn=rock, top_bc=bc, sources=srcs)
+    prim, region = M.benchmark_initial_state(g, lm.extras["prim_ijk"], eos=eos, lens=lens)
+    return g, lm, prim, region
+
+
+def scaled(prim, region, eos="we"):
+    sc = np.ones((5, prim.shape[1]))
+    for r in (1, 2, 4):
+        sc[r, 0] = 1.0e6
+        if prim.shape[1] > 1:
+            sc[r, 1] = 1.0e2 if r != 4 else 1.0
+    return prim / sc[region]

@@ -1,0 +1,225 @@
+"""GPU parity tests: every HIP kernel / solver stage against the CPU oracle on the same seeded
+inputs, through the C ABI (waiwera_amd.lib -> libwaiwera_hip.so).
+
+Tolerances (fp64): the device code evaluates the same formulas with FMA contraction and a
+different (compile-time) power evaluation order, so kernel outputs agree to ~1e-13 relative;
+finite-difference Jacobian entries amplify that by 1/h ~ 1e8 relative to the residual terms,
+hence 1e-5 of the block-row scale; Krylov/Newton results are compared at the tolerance the
+solves are run to.
+"""
+import numpy as np
+import pytest
+
+from tests import oracle_lib as ol
+from tests.cases import make_case, scaled
+
+pytestmark = pytest.mark.gpu
+
+KIND = {"w": 0, "we": 1}
+
+
+def relmax(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def FS():
+    from waiwera_amd.flow_simulation import FlowSimulation
+    return FlowSimulation
+
+
+def build(FS, oracle, eos="we", dims=(8, 8, 8), brick=(4, 4, 4), lens=False, **kw):
+    g, lm, prim, region = make_case(dims=dims, brick=brick, eos=eos, lens=lens, **kw)
+    sim = FS(lm, eos=eos)
+    osim = ol.OracleSim(oracle, lm, KIND[eos])
+    sim.set_regions(region)
+    osim.set_regions(region)
+    y = scaled(prim, region, eos).ravel().copy()
+    return g, lm, sim, osim, y, region
+
+
+@pytest.mark.parametrize("eos,lens", [("we", False), ("we", True), ("w", False)])
+def test_fluid_properties_and_residual(FS, oracle, eos, lens):
+    g, lm, sim, osim, y, region = build(FS, oracle, eos=eos, lens=lens, dims=(10, 9, 8), brick=(4, 4, 4))
+    n = sim.n_owned * sim.num_primary_variables
+    assert sim.pre_eval(0.0, y) == 0
+    yo = osim.yvec(y)
+    assert osim.pre_eval(yo) == 0
+    fg, fo = sim.fluid(), osim.fluid()
+    assert fg.shape == fo.shape
+    scale = np.maximum(np.abs(fo).max(axis=0), 1e-300)
+    assert (np.abs(fg - fo) / scale).max() < 1e-12
+    L, R = np.zeros(n), np.zeros(n)
+    assert sim.lhs(0.0, (0.0, 0.0), y, L) == 0
+    assert sim.rhs(0.0, (0.0, 0.0), y, R) == 0
+    assert relmax(L, osim.lhs()) < 1e-13
+    Ro = osim.rhs()
+    assert np.abs(R - Ro).max() <= 1e-11 * np.abs(Ro).max()
+    dt = 1.0e4
+    f = np.zeros(n)
+    assert sim.residual(0.0, dt, y, L, f) == 0
+    err, fo_ = osim.residual(yo, dt, L)
+    assert err == 0
+    assert np.abs(f - fo_).max() <= 1e-11 * np.abs(fo_).max()
+    sim.destroy(); osim.close()
+
+
+@pytest.mark.parametrize("eos,lens", [("we", False), ("we", True), ("w", False)])
+def test_jacobian(FS, oracle, eos, lens):
+    g, lm, sim, osim, y, region = build(FS, oracle, eos=eos, lens=lens)
+    bs = sim.num_primary_variables
+    n = sim.n_owned * bs
+    dt = 2.0e4
+    yo = osim.yvec(y)
+    assert sim.pre_eval(0.0, y) == 0 and osim.pre_eval(yo) == 0
+    L = osim.lhs()
+    f = np.zeros(n)
+    assert sim.residual(0.0, dt, y, L, f) == 0
+    err, fo = osim.residual(yo, dt, L)
+    assert sim.jacobian(0.0, dt, y, L) == 0
+    err, Jo = osim.jacobian(yo, dt, L, fo, mode=0)
+    assert err == 0
+    rp, ci = sim.setup_jacobian()
+    orp, oci = osim.pattern()
+    assert np.array_equal(rp, orp) and np.array_equal(ci, oci)
+    Jg = sim.jacobian_values().reshape(-1, bs, bs)
+    Jo = Jo.reshape(-1, bs, bs)
+    # compare each entry against the scale of its block row and component row
+    for r in range(bs):
+        rowscale = np.zeros(sim.n_owned)
+        np.maximum.at(rowscale, np.repeat(np.arange(sim.n_owned), np.diff(rp)), np.abs(Jo[:, r, :]).max(axis=1))
+        sc = np.repeat(rowscale, np.diff(rp))[:, None]
+        assert (np.abs(Jg[:, r, :] - Jo[:, r, :]) / np.maximum(sc, 1e-300)).max() < 1e-5
+    sim.destroy(); osim.close()
+
+
+@pytest.mark.parametrize("eos", ["we", "w"])
+def test_spmv_ilu_krylov(FS, oracle, eos):
+    g, lm, sim, osim, y, region = build(FS, oracle, eos=eos, dims=(12, 10, 9), brick=(4, 4, 4))
+    bs = sim.num_primary_variables
+    n = sim.n_owned * bs
+    dt = 5.0e4
+    yo = osim.yvec(y)
+    assert osim.pre_eval(yo) == 0
+    L = osim.lhs()
+    err, fo = osim.residual(yo, dt, L)
+    err, Jo = osim.jacobian(yo, dt, L, fo, mode=0)
+    sim.set_jacobian_values(Jo)
+    rp, ci = osim.pattern()
+    rng = np.random.default_rng(7)
+    x = rng.uniform(-1, 1, n)
+    yg, yref = np.zeros(n), np.zeros(n)
+    assert sim.spmv(x, yg) == 0
+    oracle.wo_bcsr_spmv(sim.n_owned, bs, ol.ip(rp), ol.ip(ci), ol.dp(Jo), ol.dp(x), ol.dp(yref))
+    assert relmax(yg, yref) < 1e-14
+    # block-Jacobi ILU(0) apply
+    sp = ol.i32a(lm.sub_ptr)
+    fval, dinv = np.zeros_like(Jo), np.zeros(sim.n_owned * bs * bs)
+    assert oracle.wo_bilu0_factor(sim.n_owned, bs, ol.ip(rp), ol.ip(ci), ol.dp(Jo), sp.size - 1, ol.ip(sp),
+                                  ol.dp(fval), ol.dp(dinv)) == 0
+    zref, zg = np.zeros(n), np.zeros(n)
+    oracle.wo_bilu0_apply(sim.n_owned, bs, ol.ip(rp), ol.ip(ci), ol.dp(fval), ol.dp(dinv), sp.size - 1,
+                          ol.ip(sp), ol.dp(yref), ol.dp(zref))
+    assert sim.pc_setup() == 0
+    assert sim.pc_apply(yref, zg) == 0
+    assert relmax(zg, zref) < 1e-11
+    # Krylov solves to a tight tolerance: the solutions must agree
+    for ksp, kt in (("bcgs", 0), ("gmres", 1)):
+        sim.set_opts(ksp_type=ksp, ksp_rtol=1e-12)
+        xg = np.zeros(n)
+        its, reason, rn = sim.ksp_solve(fo, xg)
+        oreason, xo, oits, hist = osim.ksp_solve(Jo, fo, ksp_type=kt, rtol=1e-12)
+        assert reason > 0 and oreason > 0
+        assert relmax(xg, xo) < 1e-8
+        assert abs(its - oits) <= max(2, oits // 10)
+        r = np.zeros(n)
+        sim.spmv(xg, r)
+        assert np.linalg.norm(r - fo) / np.linalg.norm(fo) < 1e-9
+    sim.destroy(); osim.close()
+
+
+def test_max_scaled(FS, oracle):
+    g, lm, sim, osim, y, region = build(FS, oracle)
+    n = sim.n_owned * sim.num_primary_variables
+    rng = np.random.default_rng(3)
+    v, s = rng.normal(size=n), rng.normal(size=n) * 3
+    val, idx = sim.max_scaled(v, s, 1.0)
+    ref = np.abs(v) / np.maximum(np.abs(s), 1.0)
+    assert idx == int(np.argmax(ref)) and abs(val - ref.max()) < 1e-15
+    sim.destroy(); osim.close()
+
+
+def test_transitions(FS, oracle):
+    """Post-linesearch region switching (flow_simulation.F90:2419-2576) on crafted states
+    covering 1->4, 2->4, 4->1, 4->2 and null transitions."""
+    g, lm, sim, osim, y, region = build(FS, oracle, sources=False)
+    no = sim.n_owned
+    region = np.ones(sim.n_prim, dtype=np.int32)
+    yold = np.zeros((no, 2))
+    ynew = np.zeros((no, 2))
+    cases = [
+        (1, [20.0e5, 210.0], [15.0e5, 200.0]), (2, [84.0e5, 302.0], [86.0e5, 299.27215502281706]),
+        (4, [85.0e5, 0.1], [86.0e5, -0.01]), (4, [20.0e5, 0.9], [20.1e5, 1.02]),
+        (1, [1.0e5, 20.0], [1.1e5, 21.0]), (4, [1.0e5, 0.5], [1.0e5, 0.6]), (2, [1.0e5, 120.0], [1.0e5, 121.0]),
+    ]
+    sc = {1: (1e6, 1e2), 2: (1e6, 1e2), 4: (1e6, 1.0)}
+    for c in range(no):
+        rg, po, pn = cases[c % len(cases)]
+        region[c] = rg
+        yold[c] = [po[0] / sc[rg][0], po[1] / sc[rg][1]]
+        ynew[c] = [pn[0] / sc[rg][0], pn[1] / sc[rg][1]]
+    sim.set_regions(region); osim.set_regions(region)
+    yo_old = osim.yvec(yold.ravel())
+    assert sim.pre_eval(0.0, yold.ravel().copy()) == 0 and osim.pre_eval(yo_old) == 0
+    sim.pre_iteration(); oracle.wo_pre_iteration(osim.h)
+    search = (yold - ynew).ravel().copy()
+    yg, sg = ynew.ravel().copy(), search.copy()
+    cs, cy, err = sim.post_linesearch(yold.ravel().copy(), sg, yg)
+    yo, so = osim.yvec(ynew.ravel()), search.copy()
+    import ctypes as C
+    ocs, ocy = C.c_int(), C.c_int()
+    oerr = oracle.wo_post_linesearch(osim.h, ol.dp(yo_old), ol.dp(so), ol.dp(yo), C.byref(ocs), C.byref(ocy))
+    assert err == 0 and oerr == 0 and cs and ocs.value
+    assert np.array_equal(sim.regions(), osim.regions())
+    assert relmax(yg, yo[: yg.size]) < 1e-12
+    assert np.abs(sg - so).max() < 1e-12
+    assert set(np.unique(sim.regions())) == {1, 2, 4}
+    # out-of-bounds primary -> recoverable error (eos_we.F90:486-526)
+    bad = ynew.copy(); bad[0, 0] = 200.0
+    cs, cy, err = sim.post_linesearch(yold.ravel().copy(), search.copy(), bad.ravel().copy())
+    assert err == 1
+    sim.destroy(); osim.close()
+
+
+@pytest.mark.parametrize("eos,lens", [("we", False), ("we", True), ("w", False)])
+def test_timesteps(FS, oracle, eos, lens):
+    """Backward-Euler steps (SNESSolve): Newton / Krylov iteration counts and the step solution
+    against the oracle, with both paths solved tightly (KSP rtol 1e-10, function tol 1e-9)."""
+    g, lm, sim, osim, y, region = build(FS, oracle, eos=eos, lens=lens, dims=(8, 8, 10), brick=(4, 4, 5))
+    sim.set_opts(ksp_rtol=1e-10, ftol_rel=1e-9)
+    o = osim.opts()
+    o.ksp_rtol, o.ftol_rel = 1e-10, 1e-9
+    yg, yo = y.copy(), osim.yvec(y)
+    dt = 1.0e4
+    for step in range(4):
+        reason, nits, kits = sim.timestep(0.0, dt, yg)
+        r, ok = osim.timestep(yo, dt, o)
+        assert (reason > 0) == (r > 0)
+        if reason > 0:
+            assert nits == r
+            assert np.array_equal(sim.regions(), osim.regions())
+            assert relmax(yg, yo[: yg.size]) < 1e-7
+        dt *= 2
+    sim.destroy(); osim.close()
+
+
+def test_domain_error_is_recoverable(FS, oracle):
+    """EOS out of range -> err > 0 from pre_eval, exactly like the reference's err flag."""
+    g, lm, sim, osim, y, region = build(FS, oracle)
+    yb = y.copy()
+    yb[1] = 9.0  # 900 degC
+    assert sim.pre_eval(0.0, yb) == 1
+    assert osim.pre_eval(osim.yvec(yb)) == 1
+    assert sim.pre_eval(0.0, y) == 0
+    sim.destroy(); osim.close()

@@ -1,0 +1,1141 @@
+// C ABI of libwaiwera_hip.so (include/waiwera_hip.h): context set-up, the ode_type hooks, the
+// device-resident Krylov solvers (PETSc KSPBCGS / KSPGMRES restated, left preconditioning) and
+// the Newton iteration of the reference's SNES callbacks (src/timestepper.F90:587-735,
+// 1898-1951).  Host code here only orders kernel launches and RCCL calls on one HIP stream and
+// reads back a handful of scalars per Krylov iteration; all vectors and matrices stay in HBM.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include "comm.hpp"
+#include "context.hpp"
+
+using namespace wai;
+
+#define HIPCHK(c, call)                                                                 \
+  do {                                                                                  \
+    hipError_t e_ = (call);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      (c)->err = std::string(#call) + ": " + hipGetErrorString(e_);                     \
+      return -1;                                                                        \
+    }                                                                                   \
+  } while (0)
+
+namespace {
+
+enum { S_RHO = 0, S_RHOOLD = 1, S_ALPHA = 2, S_OMEGA = 3, S_BETA = 4, S_D1 = 5, S_D2 = 6,
+       S_DP2 = 7, S_W2 = 8, S_RHONEW = 9, S_BREAK = 15, S_H = 16 };
+constexpr int NB_MAX = 1024;
+constexpr int NSLOTS = 64;
+constexpr int NSCAL = 128;
+
+template <typename T>
+int dev_alloc(wai_ctx* c, T** p, size_t n) {
+  *p = nullptr;
+  if (n == 0) n = 1;
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+  return 0;
+}
+template <typename T>
+int dev_upload(wai_ctx* c, T** p, const std::vector<T>& v) {
+  if (dev_alloc(c, p, v.size())) return -1;
+  if (!v.empty()) HIPCHK(c, hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+bool is_device_ptr(const void* p) {
+  hipPointerAttribute_t a;
+  hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+// vector argument handling: device pointers pass through, host arrays are staged
+struct VecArg {
+  wai_ctx* c; double* dev = nullptr; double* host = nullptr; size_t n = 0; bool staged = false;
+  int in(const double* p, size_t n_, int slot) {
+    n = n_;
+    if (!p) { dev = nullptr; return 0; }
+    if (is_device_ptr(p)) { dev = const_cast<double*>(p); return 0; }
+    if (n > c->stage_len) { c->err = "vector longer than staging buffer"; return -1; }
+    host = const_cast<double*>(p); dev = c->stage[slot]; staged = true;
+    HIPCHK(c, hipMemcpyAsync(dev, p, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return 0;
+  }
+  int out_only(double* p, size_t n_, int slot) {
+    n = n_;
+    if (!p) { dev = nullptr; return 0; }
+    if (is_device_ptr(p)) { dev = p; return 0; }
+    if (n > c->stage_len) { c->err = "vector longer than staging buffer"; return -1; }
+    host = p; dev = c->stage[slot]; staged = true;
+    return 0;
+  }
+  int back() {
+    if (staged && host) {
+      HIPCHK(c, hipMemcpyAsync(host, dev, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+  }
+};
+
+struct Prof {
+  wai_ctx* c; int k;
+  Prof(wai_ctx* c_, int k_) : c(c_), k(k_) {
+    if (c->prof_on) (void)hipEventRecord(c->pev0, c->stream);
+  }
+  ~Prof() {
+    if (c->prof_on) {
+      (void)hipEventRecord(c->pev1, c->stream);
+      (void)hipEventSynchronize(c->pev1);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, c->pev0, c->pev1);
+      c->prof_ms[k] += ms;
+      c->prof_n[k] += 1;
+    }
+  }
+};
+
+// read and clear the device flags; collective over ranks
+int fetch_flags(wai_ctx* c, int out[4]) {
+  if (c->comm && c->comm->nranks > 1) {
+    // flags -> doubles -> allreduce max (flag 1 is a min: send its negation)
+    HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double v[4] = {(double)c->h_flags[0], -(double)c->h_flags[1], (double)c->h_flags[2], (double)c->h_flags[3]};
+    HIPCHK(c, hipMemcpyAsync(c->d_red + 2048, v, sizeof(v), hipMemcpyHostToDevice, c->stream));
+    if (comm_allreduce(c->comm, c->d_red + 2048, 4, 1, c->stream, c->err)) return -1;
+    HIPCHK(c, hipMemcpyAsync(c->h_red + 8, c->d_red + 2048, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out[0] = (int)c->h_red[8]; out[1] = c->h_flags[1]; out[2] = (int)c->h_red[10]; out[3] = (int)c->h_red[11];
+  } else {
+    HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 4; i++) out[i] = c->h_flags[i];
+  }
+  const int reset[4] = {0, 0x7fffffff, 0, 0};
+  HIPCHK(c, hipMemcpyAsync(c->d_flags, reset, sizeof(reset), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+int halo_exchange(wai_ctx* c, double* vec, int dof) {
+  if (!c->comm || c->mesh.n_halo == 0) return 0;
+  if (dof > c->max_dof_buf) { c->err = "halo dof too large"; return -1; }
+  pack_halo(c, vec, dof);
+  if (comm_exchange(c->comm, c->n_nbr, c->nbr_rank.data(), c->send_ptr.data(), c->recv_ptr.data(),
+                    dof, c->d_sendbuf, c->d_recvbuf, c->stream, c->err))
+    return -1;
+  return unpack_halo(c, vec, dof);
+}
+
+int allreduce_scal(wai_ctx* c, int slot, int count) {
+  if (!c->comm || c->comm->nranks == 1) return 0;
+  return comm_allreduce(c->comm, c->ks.scal + slot, count, 0, c->stream, c->err);
+}
+
+int read_scal(wai_ctx* c, int first, int count) {
+  HIPCHK(c, hipMemcpyAsync(c->ks.h_scal + first, c->ks.scal + first, count * sizeof(double),
+                           hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---- fluid_properties / pre_eval on device vectors -------------------------------------------
+int do_pre_eval(wai_ctx* c, double* y /* nl, device */) {
+  if (c->comm && c->mesh.n_halo) {
+    if (halo_exchange(c, y, c->np)) return -1;
+    launch_region_get(c, c->w_c);
+    if (halo_exchange(c, c->w_c, 1)) return -1;
+    launch_region_set(c, c->w_c, c->mesh.n_owned, c->mesh.n_halo);
+  }
+  {
+    Prof p(c, KC_EOS);
+    launch_eos(c, y, 0, c->mesh.n_prim, false);
+  }
+  int fl[4];
+  if (fetch_flags(c, fl)) return -1;
+  return fl[0] ? 1 : 0;
+}
+
+int do_residual(wai_ctx* c, double dt, double* y, const double* lhs_old, double* f) {
+  int e = do_pre_eval(c, y);
+  if (e) return e;
+  Prof p(c, KC_RESIDUAL);
+  launch_residual(c, dt, lhs_old, f, nullptr, nullptr);
+  return 0;
+}
+
+int do_jacobian(wai_ctx* c, double dt, const double* y, const double* lhs_old) {
+  {
+    Prof p(c, KC_EOS);
+    launch_eos(c, y, 0, c->mesh.n_prim, true);
+  }
+  int fl[4];
+  if (fetch_flags(c, fl)) return -1;
+  if (fl[0]) return 1;
+  Prof p(c, KC_JACOBIAN);
+  if (launch_jacobian(c, dt, lhs_old)) return -1;
+  c->ilu.factored = false;
+  return 0;
+}
+
+int do_pc_setup(wai_ctx* c) {
+  {
+    Prof p(c, KC_PC_SETUP);
+    if (launch_ilu_factor(c)) return -1;
+  }
+  int fl[4];
+  if (fetch_flags(c, fl)) return -1;
+  return fl[0] ? 1 : 0;
+}
+
+// z = B^-1 A x  (x has halo room)
+int pc_amul(wai_ctx* c, double* x, double* z) {
+  if (halo_exchange(c, x, c->np)) return -1;
+  {
+    Prof p(c, KC_SPMV);
+    launch_spmv(c, x, c->ks.tmp);
+  }
+  Prof p(c, KC_PC_APPLY);
+  launch_ilu_apply(c, c->ks.tmp, z);
+  return 0;
+}
+
+// KSPBCGS [PETSc], left preconditioning, preconditioned residual norm, zero initial guess
+int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
+  Krylov& k = c->ks;
+  const int n = k.n;
+  const double rtol = c->opts.ksp_rtol, atol = c->opts.ksp_atol;
+  const int maxits = c->opts.ksp_max_its;
+  vec_zero(c, x, n);
+  vec_zero(c, k.P, k.nl);
+  vec_zero(c, k.V, n);
+  {
+    Prof p(c, KC_PC_APPLY);
+    launch_ilu_apply(c, b, k.R);
+  }
+  {
+    Prof p(c, KC_VECTOR);
+    vec_dot(c, k.R, k.R, n, S_DP2);
+    if (allreduce_scal(c, S_DP2, 1)) return -1;
+    bcgs_scalars(c, 0);
+    vec_copy(c, k.RP, k.R, n);
+  }
+  if (read_scal(c, S_DP2, 1)) return -1;
+  double dp = std::sqrt(k.h_scal[S_DP2]);
+  const double dp0 = dp, ttol = std::max(rtol * dp, atol);
+  *its = 0;
+  *reason = 0;
+  if (std::isnan(dp)) *reason = -9;
+  else if (dp <= ttol) *reason = (dp <= atol) ? 3 : 2;
+  // X aliases the caller's x during the iteration
+  double* Xsave = k.X;
+  k.X = x;
+  for (int i = 0; i < maxits && !*reason; i++) {
+    {
+      Prof p(c, KC_VECTOR);
+      bcgs_scalars(c, 1);
+      bcgs_update_p(c);
+    }
+    if (pc_amul(c, k.P, k.V)) { k.X = Xsave; return -1; }
+    {
+      Prof p(c, KC_VECTOR);
+      vec_dot(c, k.V, k.RP, n, S_D1);
+      if (allreduce_scal(c, S_D1, 1)) { k.X = Xsave; return -1; }
+      bcgs_scalars(c, 2);
+      bcgs_update_s(c);
+    }
+    if (pc_amul(c, k.S, k.T)) { k.X = Xsave; return -1; }
+    {
+      Prof p(c, KC_VECTOR);
+      vec_dot2(c, k.S, k.T, k.T, k.T, n, S_D1);
+      if (allreduce_scal(c, S_D1, 2)) { k.X = Xsave; return -1; }
+      bcgs_scalars(c, 3);
+      bcgs_update_xr(c);
+      if (allreduce_scal(c, S_DP2, 1) || allreduce_scal(c, S_RHONEW, 1)) { k.X = Xsave; return -1; }
+      bcgs_scalars(c, 4);
+    }
+    if (read_scal(c, 0, 16)) { k.X = Xsave; return -1; }
+    dp = std::sqrt(k.h_scal[S_DP2]);
+    *its = i + 1;
+    if (k.h_scal[S_BREAK] != 0.0) *reason = -5;
+    else if (std::isnan(dp)) *reason = -9;
+    else if (dp <= ttol) *reason = (dp <= atol) ? 3 : 2;
+    else if (dp >= 1.e4 * dp0) *reason = -4;
+  }
+  k.X = Xsave;
+  if (!*reason) *reason = -3;
+  *rnorm = dp;
+  return 0;
+}
+
+// KSPGMRES [PETSc]: restarted, left preconditioning, classical Gram-Schmidt without refinement
+int ksp_gmres(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
+  Krylov& k = c->ks;
+  const int n = k.n, m = std::min(std::max(c->opts.gmres_restart, 1), k.basis_m);
+  const size_t ld = (size_t)k.nl;
+  const double rtol = c->opts.ksp_rtol, atol = c->opts.ksp_atol;
+  const int maxits = c->opts.ksp_max_its;
+  std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), yv(m);
+  vec_zero(c, x, n);
+  int it = 0;
+  double res = 0.0, res0 = 0.0, ttol = 0.0;
+  *reason = 0;
+  while (!*reason) {
+    double* v0 = k.basis;
+    if (it == 0) {
+      Prof p(c, KC_PC_APPLY);
+      launch_ilu_apply(c, b, v0);
+    } else {
+      vec_copy(c, k.P, x, n);
+      if (halo_exchange(c, k.P, c->np)) return -1;
+      { Prof p(c, KC_SPMV); launch_spmv(c, k.P, k.tmp); }
+      vec_waxpy(c, k.tmp, -1.0, k.tmp, b, n);
+      Prof p(c, KC_PC_APPLY);
+      launch_ilu_apply(c, k.tmp, v0);
+    }
+    {
+      Prof p(c, KC_VECTOR);
+      vec_dot(c, v0, v0, n, S_W2);
+      if (allreduce_scal(c, S_W2, 1)) return -1;
+    }
+    if (read_scal(c, S_W2, 1)) return -1;
+    res = std::sqrt(k.h_scal[S_W2]);
+    if (it == 0) {
+      res0 = res;
+      ttol = std::max(rtol * res, atol);
+      if (std::isnan(res)) { *reason = -9; break; }
+      if (res <= ttol) { *reason = (res <= atol) ? 3 : 2; break; }
+    }
+    if (res == 0.0) { *reason = 3; break; }
+    gmres_scale_to(c, v0, v0, S_W2, n);
+    std::fill(g.begin(), g.end(), 0.0);
+    g[0] = res;
+    int j = 0;
+    for (; j < m && !*reason; j++) {
+      double* vj = k.basis + ld * j;
+      double* vn = k.basis + ld * (j + 1);
+      double* w = k.T;
+      if (pc_amul(c, vj, w)) return -1;
+      {
+        Prof p(c, KC_VECTOR);
+        gmres_mdot(c, w, j + 1);
+        if (allreduce_scal(c, S_H, j + 1)) return -1;
+        gmres_maxpy_norm(c, w, j + 1);
+        if (allreduce_scal(c, S_W2, 1)) return -1;
+        gmres_scale_to(c, vn, w, S_W2, n);
+      }
+      if (read_scal(c, S_W2, S_H + j + 1 - S_W2)) return -1;
+      for (int i = 0; i <= j; i++) H[(size_t)i * m + j] = k.h_scal[S_H + i];
+      const double hn = std::sqrt(k.h_scal[S_W2]);
+      H[(size_t)(j + 1) * m + j] = hn;
+      for (int i = 0; i < j; i++) {
+        const double a = H[(size_t)i * m + j], bq = H[(size_t)(i + 1) * m + j];
+        H[(size_t)i * m + j] = cs[i] * a + sn[i] * bq;
+        H[(size_t)(i + 1) * m + j] = -sn[i] * a + cs[i] * bq;
+      }
+      const double a = H[(size_t)j * m + j], bq = H[(size_t)(j + 1) * m + j], d = std::sqrt(a * a + bq * bq);
+      cs[j] = a / d; sn[j] = bq / d;
+      H[(size_t)j * m + j] = d; H[(size_t)(j + 1) * m + j] = 0.0;
+      g[j + 1] = -sn[j] * g[j];
+      g[j] = cs[j] * g[j];
+      res = std::fabs(g[j + 1]);
+      it++;
+      if (std::isnan(res)) *reason = -9;
+      else if (res <= ttol) *reason = (res <= atol) ? 3 : 2;
+      else if (res >= 1.e4 * res0) *reason = -4;
+      else if (it >= maxits) *reason = -3;
+      else if (hn == 0.0) *reason = 3;
+    }
+    const int kk = j;
+    for (int i = kk - 1; i >= 0; i--) {
+      double t = g[i];
+      for (int q = i + 1; q < kk; q++) t -= H[(size_t)i * m + q] * yv[q];
+      yv[i] = t / H[(size_t)i * m + i];
+    }
+    {
+      Prof p(c, KC_VECTOR);
+      gmres_update_x(c, x, yv.data(), kk);
+      HIPCHK(c, hipStreamSynchronize(c->stream));  // yv is reused by the next cycle
+    }
+  }
+  *its = it;
+  *rnorm = res;
+  return 0;
+}
+
+int do_ksp(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
+  if (!c->ilu.factored) {
+    const int e = do_pc_setup(c);
+    if (e < 0) return -1;
+    if (e > 0) { *reason = -11; *its = 0; *rnorm = 0.0; return 0; }
+  }
+  if (c->opts.ksp_type == WAI_KSP_GMRES) return ksp_gmres(c, b, x, its, reason, rnorm);
+  return ksp_bcgs(c, b, x, its, reason, rnorm);
+}
+
+int do_norm2(wai_ctx* c, const double* v, double* out) {
+  vec_dot(c, v, v, c->ks.n, S_W2);
+  if (allreduce_scal(c, S_W2, 1)) return -1;
+  if (read_scal(c, S_W2, 1)) return -1;
+  *out = std::sqrt(c->ks.h_scal[S_W2]);
+  return 0;
+}
+
+int do_max_scaled(wai_ctx* c, const double* v, const double* scale, double tol, double* val, int* idx) {
+  if (launch_max_scaled(c, v, scale, tol, val, idx)) return -1;
+  if (c->comm && c->comm->nranks > 1) {
+    HIPCHK(c, hipMemcpyAsync(c->d_red + 2048, val, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (comm_allreduce(c->comm, c->d_red + 2048, 1, 1, c->stream, c->err)) return -1;
+    HIPCHK(c, hipMemcpyAsync(val, c->d_red + 2048, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return 0;
+}
+
+// SNES_convergence (timestepper.F90:1898-1951) + SNESConvergedDefault [PETSc]
+int snes_convergence(wai_ctx* c, int it, const double* f, const double* lhs_old, const double* y,
+                     const double* update, double fnorm, double* max_residual, int* reason) {
+  int loc;
+  if (do_max_scaled(c, f, lhs_old, c->opts.ftol_abs, max_residual, &loc)) return -1;
+  int r = 0;
+  if (std::isnan(fnorm)) r = -4;
+  else if (it == 0) { if (fnorm < 1.e-50) r = 3; }
+  else if (fnorm <= 1.e-8 * c->fnorm0) r = 4;
+  else if (fnorm > 1.e8 * c->fnorm0) r = -9;
+  if (*max_residual < c->opts.ftol_rel) r = 1;
+  else if (it > 0) {
+    double mu;
+    if (do_max_scaled(c, update, y, c->opts.utol_abs, &mu, &loc)) return -1;
+    if (mu <= c->opts.utol_rel) r = 2;
+  }
+  *reason = r;
+  return 0;
+}
+
+// one Newton iteration on device vectors y (nl), lhs_old (n), f (n)
+int do_newton_step(wai_ctx* c, double dt, int iter, double* y, const double* lhs_old, double* f,
+                   int* ksp_its, int* reason, double* max_residual) {
+  const int n = c->ks.n;
+  *ksp_its = 0;
+  if (iter == 0 && do_norm2(c, f, &c->fnorm0)) return -1;
+  // SNES_pre_iteration_update
+  HIPCHK(c, hipMemcpyAsync(c->flu_last_iter, c->flu, sizeof(double) * (size_t)c->df * c->mesh.n_local,
+                           hipMemcpyDeviceToDevice, c->stream));
+  int e = do_jacobian(c, dt, y, lhs_old);
+  if (e < 0) return -1;
+  if (e > 0) { *reason = -3; return 0; }
+  int kreason = 0;
+  double rn = 0.0;
+  if (do_ksp(c, f, c->w_delta, ksp_its, &kreason, &rn)) return -1;
+  if (kreason < 0) { *reason = -3; return 0; }
+  // SNES_linesearch, lambda = 1
+  vec_copy(c, c->w_yold, y, c->ks.nl);
+  vec_waxpy(c, y, -1.0, c->w_delta, c->w_yold, n);
+  {
+    Prof p(c, KC_TRANSITIONS);
+    launch_transitions(c, c->w_yold, c->w_delta, y);
+  }
+  int fl[4];
+  if (fetch_flags(c, fl)) return -1;
+  if (fl[0]) { *reason = -3; return 0; }
+  if (iter < c->opts.max_newton_its - 1) {
+    e = do_residual(c, dt, y, lhs_old, f);
+    if (e < 0) return -1;
+    if (e > 0) { *reason = -3; return 0; }
+  }
+  double fnorm;
+  if (do_norm2(c, f, &fnorm)) return -1;
+  if (snes_convergence(c, iter + 1, f, lhs_old, y, c->w_delta, fnorm, max_residual, reason)) return -1;
+  if (!*reason && iter + 1 >= c->opts.max_newton_its) *reason = -5;
+  return 0;
+}
+
+int snapshot_step(wai_ctx* c) {
+  HIPCHK(c, hipMemcpyAsync(c->flu_last_step, c->flu, sizeof(double) * (size_t)c->df * c->mesh.n_local,
+                           hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+int restore_step(wai_ctx* c) {
+  HIPCHK(c, hipMemcpyAsync(c->flu, c->flu_last_step, sizeof(double) * (size_t)c->df * c->mesh.n_local,
+                           hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+void free_all(wai_ctx* c) {
+  auto F = [](void* p) { if (p) (void)hipFree(p); };
+  DeviceMesh& m = c->mesh;
+  F(m.rock); F(m.vol); F(m.fgeom); F(m.fdir); F(m.adj_face); F(m.adj_other); F(m.adj_blk);
+  F(m.diag_blk); F(m.cell_src);
+  F(c->src.cell); F(c->src.comp); F(c->src.next); F(c->src.rate); F(c->src.enth);
+  F(c->J.rowptr); F(c->J.colidx); F(c->J.val);
+  IluSchedule& s = c->ilu;
+  F(s.sub_ptr); F(s.fwd_rows); F(s.fwd_lev_ptr); F(s.fwd_sub_lev); F(s.bwd_rows); F(s.bwd_lev_ptr);
+  F(s.bwd_sub_lev); F(s.lstart); F(s.uend); F(s.fval); F(s.dinv);
+  Krylov& k = c->ks;
+  F(k.R); F(k.RP); F(k.P); F(k.V); F(k.S); F(k.T); F(k.tmp); F(k.X); F(k.basis); F(k.partials); F(k.scal);
+  if (k.h_scal) (void)hipHostFree(k.h_scal);
+  F(c->flu); F(c->flu_last_iter); F(c->flu_last_step); F(c->flu_pert); F(c->hstep);
+  F(c->w_y); F(c->w_yold); F(c->w_delta); F(c->w_f); F(c->w_lhs); F(c->w_a); F(c->w_b); F(c->w_c);
+  F(c->d_flags); F(c->d_red);
+  if (c->h_flags) (void)hipHostFree(c->h_flags);
+  if (c->h_red) (void)hipHostFree(c->h_red);
+  for (auto& p : c->stage) F(p);
+  F(c->d_send_idx); F(c->d_sendbuf); F(c->d_recvbuf);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->pev0) (void)hipEventDestroy(c->pev0);
+  if (c->pev1) (void)hipEventDestroy(c->pev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  comm_destroy(c->comm);
+}
+
+}  // namespace
+
+extern "C" {
+
+void wai_default_eos(wai_eos_desc* e, int kind) {
+  std::memset(e, 0, sizeof(*e));
+  e->kind = kind;
+  e->temperature = 20.0;
+  e->pressure_scale = 1.e6;
+  e->temperature_scale = 1.e2;
+  e->rp_type = WAI_RP_LINEAR;
+  e->rp_par[0] = 0.0; e->rp_par[1] = 1.0; e->rp_par[2] = 0.0; e->rp_par[3] = 1.0;
+  e->cp_type = WAI_CP_ZERO;
+}
+
+void wai_default_opts(wai_solver_opts* o) {
+  o->ksp_type = WAI_KSP_BCGS;
+  o->gmres_restart = 30;
+  o->ksp_max_its = 10000;
+  o->ksp_rtol = 1.e-5;
+  o->ksp_atol = 1.e-50;
+  o->max_newton_its = 8;
+  o->ftol_rel = 1.e-5; o->ftol_abs = 1.0;
+  o->utol_rel = 1.e-10; o->utol_abs = 1.0;
+  o->fd_eps = 1.e-8; o->fd_umin = 1.e-2;
+}
+
+int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_solver_opts* od,
+                   int device, wai_ctx** out) {
+  if (!md || !ed || !out) return -2;
+  wai_ctx* c = new wai_ctx;
+  *out = c;
+  c->device = device;
+  HIPCHK(c, hipSetDevice(device));
+  HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCHK(c, hipEventCreate(&c->ev0)); HIPCHK(c, hipEventCreate(&c->ev1));
+  HIPCHK(c, hipEventCreate(&c->pev0)); HIPCHK(c, hipEventCreate(&c->pev1));
+  if (od) c->opts = *od; else wai_default_opts(&c->opts);
+  c->kind = ed->kind;
+  if (c->kind == WAI_EOS_W) { c->np = 1; c->df = 15; }
+  else if (c->kind == WAI_EOS_WE) { c->np = 2; c->df = 23; }
+  else { c->err = "unsupported eos kind"; return -2; }
+  std::memset(&c->ep, 0, sizeof(c->ep));
+  c->ep.temperature = ed->temperature;
+  const double ps = ed->pressure_scale > 0 ? ed->pressure_scale : 1.e6;
+  const double ts = ed->temperature_scale > 0 ? ed->temperature_scale : 1.e2;
+  c->ep.scale[1][0] = ps; c->ep.scale[1][1] = ts;
+  c->ep.scale[2][0] = ps; c->ep.scale[2][1] = ts;
+  c->ep.scale[4][0] = ps; c->ep.scale[4][1] = 1.0;
+  c->ep.rp_type = ed->rp_type; c->ep.cp_type = ed->cp_type;
+  for (int i = 0; i < 6; i++) { c->ep.rp_par[i] = ed->rp_par[i]; c->ep.cp_par[i] = ed->cp_par[i]; }
+
+  DeviceMesh& m = c->mesh;
+  m.n_owned = md->n_owned; m.n_halo = md->n_halo; m.n_bc = md->n_bc;
+  m.n_prim = m.n_owned + m.n_halo; m.n_local = m.n_prim + m.n_bc; m.n_faces = md->n_faces;
+  const int N = m.n_owned, NL = m.n_local, NF = m.n_faces, np = c->np;
+  if (N <= 0) { c->err = "no owned cells"; return -2; }
+  // SoA rock / volume / face geometry
+  {
+    std::vector<double> rock((size_t)8 * NL), vol(NL), fg((size_t)5 * NF);
+    std::vector<int> fdir(NF);
+    for (int i = 0; i < NL; i++) {
+      for (int k = 0; k < 8; k++) rock[(size_t)k * NL + i] = md->rock[(size_t)i * 8 + k];
+      vol[i] = md->cell_geom[(size_t)i * 4 + 3];
+    }
+    for (int f = 0; f < NF; f++) {
+      const double* g = md->face_geom + (size_t)f * 12;
+      fg[f] = g[0]; fg[(size_t)NF + f] = g[1]; fg[(size_t)2 * NF + f] = g[2];
+      fg[(size_t)3 * NF + f] = g[3]; fg[(size_t)4 * NF + f] = g[7];
+      fdir[f] = (int)std::lround(g[11]);
+      if (fdir[f] < 1 || fdir[f] > 3) { c->err = "bad permeability direction"; return -2; }
+    }
+    if (dev_upload(c, &m.rock, rock) || dev_upload(c, &m.vol, vol) || dev_upload(c, &m.fgeom, fg) ||
+        dev_upload(c, &m.fdir, fdir))
+      return -1;
+  }
+  // cell -> face adjacency (ascending face index per cell) and BCSR pattern
+  std::vector<int> deg(N, 0);
+  for (int f = 0; f < NF; f++)
+    for (int s = 0; s < 2; s++) {
+      const int cc = md->face_cells[2 * f + s];
+      if (cc < 0 || cc >= NL) { c->err = "face cell index out of range"; return -2; }
+      if (cc < N) deg[cc]++;
+    }
+  m.max_deg = *std::max_element(deg.begin(), deg.end());
+  std::vector<int> adj_face((size_t)m.max_deg * N, -1), adj_other((size_t)m.max_deg * N, 0),
+      adj_blk((size_t)m.max_deg * N, -1), fill(N, 0);
+  for (int f = 0; f < NF; f++)
+    for (int s = 0; s < 2; s++) {
+      const int cc = md->face_cells[2 * f + s];
+      if (cc >= N) continue;
+      const int slot = fill[cc]++;
+      adj_face[(size_t)slot * N + cc] = f * 2 + s;
+      adj_other[(size_t)slot * N + cc] = md->face_cells[2 * f + 1 - s];
+    }
+  Bcsr& J = c->J;
+  J.n = N; J.ncols = m.n_prim; J.bs = np;
+  J.h_rowptr.assign(N + 1, 0);
+  for (int i = 0; i < N; i++) {
+    int cnt = 1;
+    for (int s = 0; s < deg[i]; s++)
+      if (adj_other[(size_t)s * N + i] < m.n_prim) cnt++;
+    J.h_rowptr[i + 1] = J.h_rowptr[i] + cnt;
+  }
+  J.nnzb = J.h_rowptr[N];
+  J.h_colidx.resize(J.nnzb);
+  std::vector<int> diag(N);
+  for (int i = 0; i < N; i++) {
+    int* row = J.h_colidx.data() + J.h_rowptr[i];
+    int cnt = 0;
+    row[cnt++] = i;
+    for (int s = 0; s < deg[i]; s++) {
+      const int o = adj_other[(size_t)s * N + i];
+      if (o < m.n_prim) row[cnt++] = o;
+    }
+    std::sort(row, row + cnt);
+    for (int q = 0; q < cnt; q++) {
+      if (row[q] == i) diag[i] = J.h_rowptr[i] + q;
+      if (q > 0 && row[q] == row[q - 1]) { c->err = "duplicate connection between two cells"; return -2; }
+    }
+    for (int s = 0; s < deg[i]; s++) {
+      const int o = adj_other[(size_t)s * N + i];
+      if (o >= m.n_prim) continue;
+      const int* p = std::lower_bound(row, row + cnt, o);
+      adj_blk[(size_t)s * N + i] = J.h_rowptr[i] + (int)(p - row);
+    }
+  }
+  {
+    const int rpc = 256 / np;
+    int mx = 1;
+    for (int r0 = 0; r0 < N; r0 += rpc) {
+      const int r1 = std::min(N, r0 + rpc);
+      mx = std::max(mx, J.h_rowptr[r1] - J.h_rowptr[r0]);
+    }
+    J.max_chunk_blocks = mx;
+  }
+  if (dev_upload(c, &m.adj_face, adj_face) || dev_upload(c, &m.adj_other, adj_other) ||
+      dev_upload(c, &m.adj_blk, adj_blk) || dev_upload(c, &m.diag_blk, diag) ||
+      dev_upload(c, &J.rowptr, J.h_rowptr) || dev_upload(c, &J.colidx, J.h_colidx) ||
+      dev_alloc(c, &J.val, (size_t)J.nnzb * np * np))
+    return -1;
+  {
+    std::vector<int> cs(N, -1);
+    if (dev_upload(c, &m.cell_src, cs)) return -1;
+  }
+  // block-Jacobi subdomains + level schedules of the ILU(0) factors
+  {
+    IluSchedule& s = c->ilu;
+    std::vector<int> sub;
+    if (md->sub_ptr && md->n_sub > 0) sub.assign(md->sub_ptr, md->sub_ptr + md->n_sub + 1);
+    else sub = {0, N};
+    s.nsub = (int)sub.size() - 1;
+    if (sub.front() != 0 || sub.back() != N) { c->err = "sub_ptr must cover [0, n_owned]"; return -2; }
+    std::vector<int> lstart(N), uend(N), levf(N), levb(N);
+    std::vector<int> frows(N), brows(N), flev, blev, fsub(s.nsub + 1), bsub(s.nsub + 1);
+    flev.push_back(0); blev.push_back(0);
+    s.max_rows = 0;
+    for (int sd = 0; sd < s.nsub; sd++) {
+      const int lo = sub[sd], hi = sub[sd + 1];
+      if (hi < lo) { c->err = "sub_ptr not monotone"; return -2; }
+      s.max_rows = std::max(s.max_rows, hi - lo);
+      int nlf = 0, nlb = 0;
+      for (int i = lo; i < hi; i++) {
+        const int a = J.h_rowptr[i], b = J.h_rowptr[i + 1];
+        int ls = a;
+        while (ls < b && J.h_colidx[ls] < lo) ls++;
+        int ue = b;
+        while (ue > a && J.h_colidx[ue - 1] >= hi) ue--;
+        lstart[i] = ls; uend[i] = ue;
+        int lv = 0;
+        for (int q = ls; q < diag[i]; q++) lv = std::max(lv, levf[J.h_colidx[q]] + 1);
+        levf[i] = lv;
+        nlf = std::max(nlf, lv + 1);
+      }
+      for (int i = hi - 1; i >= lo; i--) {
+        int lv = 0;
+        for (int q = diag[i] + 1; q < uend[i]; q++) lv = std::max(lv, levb[J.h_colidx[q]] + 1);
+        levb[i] = lv;
+        nlb = std::max(nlb, lv + 1);
+      }
+      // counting sort rows by level
+      auto emit = [&](const std::vector<int>& lev, int nl, std::vector<int>& rows, std::vector<int>& lp,
+                      bool descending) {
+        std::vector<int> cnt(nl + 1, 0);
+        for (int i = lo; i < hi; i++) cnt[lev[i] + 1]++;
+        for (int l = 0; l < nl; l++) cnt[l + 1] += cnt[l];
+        std::vector<int> pos(cnt.begin(), cnt.end() - 1);
+        if (!descending) for (int i = lo; i < hi; i++) rows[lo + pos[lev[i]]++] = i;
+        else for (int i = hi - 1; i >= lo; i--) rows[lo + pos[lev[i]]++] = i;
+        for (int l = 0; l < nl; l++) lp.push_back(lo + cnt[l + 1]);
+      };
+      fsub[sd] = (int)flev.size() - 1;
+      bsub[sd] = (int)blev.size() - 1;
+      if (hi > lo) {
+        emit(levf, nlf, frows, flev, false);
+        emit(levb, nlb, brows, blev, true);
+      }
+    }
+    fsub[s.nsub] = (int)flev.size() - 1;
+    bsub[s.nsub] = (int)blev.size() - 1;
+    if ((size_t)s.max_rows * np * sizeof(double) > 64 * 1024) {
+      c->err = "preconditioner subdomain too large for the LDS-resident ILU(0) apply "
+               "(max 64 KiB of solution vector per subdomain); use smaller bricks";
+      return -2;
+    }
+    if (dev_upload(c, &s.sub_ptr, sub) || dev_upload(c, &s.fwd_rows, frows) ||
+        dev_upload(c, &s.fwd_lev_ptr, flev) || dev_upload(c, &s.fwd_sub_lev, fsub) ||
+        dev_upload(c, &s.bwd_rows, brows) || dev_upload(c, &s.bwd_lev_ptr, blev) ||
+        dev_upload(c, &s.bwd_sub_lev, bsub) || dev_upload(c, &s.lstart, lstart) ||
+        dev_upload(c, &s.uend, uend) || dev_alloc(c, &s.fval, (size_t)J.nnzb * np * np) ||
+        dev_alloc(c, &s.dinv, (size_t)N * np * np))
+      return -1;
+  }
+  // state and work vectors
+  const size_t nl = (size_t)np * m.n_prim, n = (size_t)np * N;
+  const size_t fsz = (size_t)c->df * NL;
+  if (dev_alloc(c, &c->flu, fsz) || dev_alloc(c, &c->flu_last_iter, fsz) ||
+      dev_alloc(c, &c->flu_last_step, fsz) || dev_alloc(c, &c->flu_pert, (size_t)np * c->df * m.n_prim) ||
+      dev_alloc(c, &c->hstep, nl))
+    return -1;
+  HIPCHK(c, hipMemset(c->flu, 0, fsz * sizeof(double)));
+  {
+    std::vector<double> ones(NL, 1.0);  // default region 1 (eos_we.F90:91)
+    HIPCHK(c, hipMemcpy(c->flu + (size_t)F_REGION * NL, ones.data(), NL * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->flu + (size_t)F_OLD_REGION * NL, ones.data(), NL * sizeof(double), hipMemcpyHostToDevice));
+  }
+  double** wv[] = {&c->w_y, &c->w_yold, &c->w_delta, &c->w_f, &c->w_lhs, &c->w_a, &c->w_b, &c->w_c};
+  for (auto p : wv) {
+    if (dev_alloc(c, p, nl + 16)) return -1;
+    HIPCHK(c, hipMemset(*p, 0, (nl + 16) * sizeof(double)));
+  }
+  Krylov& k = c->ks;
+  k.n = (int)n; k.nl = (int)nl;
+  double** kv[] = {&k.R, &k.RP, &k.P, &k.V, &k.S, &k.T, &k.tmp, &k.X};
+  for (auto p : kv) {
+    if (dev_alloc(c, p, nl + 16)) return -1;
+    HIPCHK(c, hipMemset(*p, 0, (nl + 16) * sizeof(double)));
+  }
+  k.basis_m = std::max(1, std::min(c->opts.gmres_restart > 0 ? c->opts.gmres_restart : 30, 40));
+  if (c->opts.ksp_type == WAI_KSP_GMRES) {
+    if (dev_alloc(c, &k.basis, (size_t)(k.basis_m + 1) * nl)) return -1;
+    HIPCHK(c, hipMemset(k.basis, 0, (size_t)(k.basis_m + 1) * nl * sizeof(double)));
+  }
+  if (dev_alloc(c, &k.partials, (size_t)NSLOTS * NB_MAX) || dev_alloc(c, &k.scal, (size_t)NSCAL)) return -1;
+  HIPCHK(c, hipMemset(k.scal, 0, NSCAL * sizeof(double)));
+  HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&k.h_scal), NSCAL * sizeof(double)));
+  if (dev_alloc(c, &c->d_flags, (size_t)4) || dev_alloc(c, &c->d_red, (size_t)4096)) return -1;
+  HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_flags), 4 * sizeof(int)));
+  HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_red), 64 * sizeof(double)));
+  {
+    const int reset[4] = {0, 0x7fffffff, 0, 0};
+    HIPCHK(c, hipMemcpy(c->d_flags, reset, sizeof(reset), hipMemcpyHostToDevice));
+  }
+  c->stage_len = std::max(nl, fsz) + 16;
+  for (auto& p : c->stage)
+    if (dev_alloc(c, &p, c->stage_len)) return -1;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int wai_ctx_destroy(wai_ctx* c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  free_all(c);
+  delete c;
+  return 0;
+}
+
+const char* wai_last_error(wai_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int wai_set_opts(wai_ctx* c, const wai_solver_opts* o) {
+  if (!c || !o) return -2;
+  const int old_type = c->opts.ksp_type;
+  c->opts = *o;
+  if (o->ksp_type == WAI_KSP_GMRES && (old_type != WAI_KSP_GMRES || !c->ks.basis)) {
+    if (c->ks.basis) (void)hipFree(c->ks.basis);
+    c->ks.basis_m = std::max(1, std::min(o->gmres_restart > 0 ? o->gmres_restart : 30, 40));
+    if (dev_alloc(c, &c->ks.basis, (size_t)(c->ks.basis_m + 1) * c->ks.nl)) return -1;
+  }
+  return 0;
+}
+
+int wai_num_fluid_dof(wai_ctx* c) { return c ? c->df : -2; }
+int wai_block_size(wai_ctx* c) { return c ? c->np : -2; }
+
+int wai_set_regions(wai_ctx* c, const int* region) {
+  if (!c || !region) return -2;
+  const int n = c->mesh.n_prim;
+  std::vector<double> r(n);
+  for (int i = 0; i < n; i++) r[i] = (double)region[i];
+  const size_t NL = c->mesh.n_local;
+  HIPCHK(c, hipMemcpy(c->flu + (size_t)F_REGION * NL, r.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->flu + (size_t)F_OLD_REGION * NL, r.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int wai_get_regions(wai_ctx* c, int* region) {
+  if (!c || !region) return -2;
+  const int n = c->mesh.n_prim;
+  std::vector<double> r(n);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(r.data(), c->flu + (size_t)F_REGION * c->mesh.n_local, n * sizeof(double), hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) region[i] = (int)std::lround(r[i]);
+  return 0;
+}
+
+int wai_set_bc(wai_ctx* c, const double* primary, const int* region) {
+  if (!c) return -2;
+  const int nb = c->mesh.n_bc, np = c->np;
+  if (nb == 0) return 0;
+  if (!primary || !region) return -2;
+  const size_t NL = c->mesh.n_local;
+  const int first = c->mesh.n_prim;
+  std::vector<double> reg(nb), ys((size_t)(first + nb) * np, 0.0);
+  for (int b = 0; b < nb; b++) {
+    const int rg = region[b];
+    if (rg < 1 || rg > 4 || rg == 3) { c->err = "bad bc region"; return -2; }
+    reg[b] = (double)rg;
+    for (int k = 0; k < np; k++) ys[(size_t)(first + b) * np + k] = primary[(size_t)b * np + k] / c->ep.scale[rg][k];
+  }
+  HIPCHK(c, hipMemcpy(c->flu + (size_t)F_REGION * NL + first, reg.data(), nb * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->flu + (size_t)F_OLD_REGION * NL + first, reg.data(), nb * sizeof(double), hipMemcpyHostToDevice));
+  double* tmp = nullptr;
+  if (dev_upload(c, &tmp, ys)) return -1;
+  launch_eos(c, tmp, first, nb, false);
+  int fl[4];
+  const int e = fetch_flags(c, fl);
+  (void)hipFree(tmp);
+  if (e) return -1;
+  c->bc_set = true;
+  return fl[0] ? 1 : 0;
+}
+
+int wai_set_sources(wai_ctx* c, int n, const int* cell, const double* rate, const double* enthalpy,
+                    const int* component) {
+  if (!c || n < 0) return -2;
+  Sources& s = c->src;
+  auto F = [](void* p) { if (p) (void)hipFree(p); };
+  F(s.cell); F(s.comp); F(s.next); F(s.rate); F(s.enth);
+  s = Sources();
+  s.n = n;
+  const int N = c->mesh.n_owned;
+  std::vector<int> head(N, -1), next(std::max(n, 1), -1), vc(std::max(n, 1), 0), vk(std::max(n, 1), 0);
+  std::vector<double> vr(std::max(n, 1), 0.0), ve(std::max(n, 1), 0.0);
+  // chain sources of a cell in input order
+  for (int i = n - 1; i >= 0; i--) {
+    if (cell[i] < 0 || cell[i] >= N) { c->err = "source cell not owned"; return -2; }
+    next[i] = head[cell[i]];
+    head[cell[i]] = i;
+    vc[i] = cell[i]; vk[i] = component ? component[i] : 0; vr[i] = rate[i]; ve[i] = enthalpy ? enthalpy[i] : 0.0;
+  }
+  HIPCHK(c, hipMemcpy(c->mesh.cell_src, head.data(), N * sizeof(int), hipMemcpyHostToDevice));
+  if (dev_upload(c, &s.cell, vc) || dev_upload(c, &s.comp, vk) || dev_upload(c, &s.next, next) ||
+      dev_upload(c, &s.rate, vr) || dev_upload(c, &s.enth, ve))
+    return -1;
+  return 0;
+}
+
+int wai_get_fluid(wai_ctx* c, int which, double* out) {
+  if (!c || !out) return -2;
+  const double* src = which == 0 ? c->flu : (which == 1 ? c->flu_last_iter : c->flu_last_step);
+  const size_t tot = (size_t)c->df * c->mesh.n_local;
+  launch_fluid_aos(c, src, c->stage[0]);
+  if (is_device_ptr(out)) HIPCHK(c, hipMemcpyAsync(out, c->stage[0], tot * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  else HIPCHK(c, hipMemcpyAsync(out, c->stage[0], tot * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int wai_set_halo(wai_ctx* c, int n_nbr, const int* nbr_rank, const int* send_ptr, const int* send_idx,
+                 const int* recv_ptr) {
+  if (!c || n_nbr < 0) return -2;
+  c->n_nbr = n_nbr;
+  c->nbr_rank.assign(nbr_rank, nbr_rank + n_nbr);
+  c->send_ptr.assign(send_ptr, send_ptr + n_nbr + 1);
+  c->recv_ptr.assign(recv_ptr, recv_ptr + n_nbr + 1);
+  c->send_total = n_nbr ? send_ptr[n_nbr] : 0;
+  if (n_nbr && recv_ptr[n_nbr] != c->mesh.n_halo) { c->err = "recv_ptr does not cover the halo cells"; return -2; }
+  std::vector<int> idx(send_idx, send_idx + c->send_total);
+  for (int v : idx) if (v < 0 || v >= c->mesh.n_owned) { c->err = "send_idx not an owned cell"; return -2; }
+  if (c->d_send_idx) (void)hipFree(c->d_send_idx);
+  if (c->d_sendbuf) (void)hipFree(c->d_sendbuf);
+  if (c->d_recvbuf) (void)hipFree(c->d_recvbuf);
+  c->max_dof_buf = std::max(c->np, 1);
+  if (dev_upload(c, &c->d_send_idx, idx) || dev_alloc(c, &c->d_sendbuf, (size_t)c->send_total * c->max_dof_buf) ||
+      dev_alloc(c, &c->d_recvbuf, (size_t)c->mesh.n_halo * c->max_dof_buf))
+    return -1;
+  return 0;
+}
+
+int wai_comm_unique_id(char id[128]) {
+  std::string err;
+  return comm_unique_id(id, err);
+}
+
+int wai_comm_init(wai_ctx* c, int rank, int nranks, const char id[128]) {
+  if (!c) return -2;
+  HIPCHK(c, hipSetDevice(c->device));
+  comm_destroy(c->comm);
+  c->comm = comm_create(rank, nranks, id, c->err);
+  return c->comm ? 0 : -1;
+}
+
+int wai_halo_exchange(wai_ctx* c, double* vec, int dof) {
+  if (!c || !vec) return -2;
+  VecArg v{c};
+  const size_t n = (size_t)dof * c->mesh.n_prim;
+  if (v.in(vec, n, 0)) return -1;
+  if (halo_exchange(c, v.dev, dof)) return -1;
+  return v.back();
+}
+
+int wai_pre_timestep(wai_ctx* c) { return c ? snapshot_step(c) : -2; }
+int wai_pre_retry_timestep(wai_ctx* c) { return c ? restore_step(c) : -2; }
+int wai_pre_iteration(wai_ctx* c) {
+  if (!c) return -2;
+  HIPCHK(c, hipMemcpyAsync(c->flu_last_iter, c->flu, sizeof(double) * (size_t)c->df * c->mesh.n_local,
+                           hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+// copy the owned part of a caller vector into an nl-sized work vector (halo room)
+static int to_work(wai_ctx* c, const double* y, double* work) {
+  const size_t n = c->ks.n;
+  if (is_device_ptr(y)) HIPCHK(c, hipMemcpyAsync(work, y, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  else HIPCHK(c, hipMemcpyAsync(work, y, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+static int from_work(wai_ctx* c, const double* work, double* y) {
+  const size_t n = c->ks.n;
+  if (is_device_ptr(y)) HIPCHK(c, hipMemcpyAsync(y, work, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  else HIPCHK(c, hipMemcpyAsync(y, work, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int wai_pre_eval(wai_ctx* c, double t, const double* y) {
+  (void)t;
+  if (!c || !y) return -2;
+  if (to_work(c, y, c->w_y)) return -1;
+  return do_pre_eval(c, c->w_y);
+}
+
+int wai_lhs(wai_ctx* c, double t, const double* y, double* lhs) {
+  (void)t; (void)y;
+  if (!c || !lhs) return -2;
+  VecArg o{c};
+  if (o.out_only(lhs, c->ks.n, 0)) return -1;
+  {
+    Prof p(c, KC_RESIDUAL);
+    launch_residual(c, 0.0, nullptr, nullptr, o.dev, nullptr);
+  }
+  return o.back();
+}
+
+int wai_rhs(wai_ctx* c, double t, const double* y, double* rhs) {
+  (void)t; (void)y;
+  if (!c || !rhs) return -2;
+  VecArg o{c};
+  if (o.out_only(rhs, c->ks.n, 0)) return -1;
+  {
+    Prof p(c, KC_RESIDUAL);
+    launch_residual(c, 0.0, nullptr, nullptr, nullptr, o.dev);
+  }
+  return o.back();
+}
+
+int wai_residual(wai_ctx* c, double t, double dt, const double* y, const double* lhs_old, double* f) {
+  (void)t;
+  if (!c || !y || !lhs_old || !f) return -2;
+  VecArg lo{c}, fo{c};
+  if (to_work(c, y, c->w_y) || lo.in(lhs_old, c->ks.n, 1) || fo.out_only(f, c->ks.n, 2)) return -1;
+  const int e = do_residual(c, dt, c->w_y, lo.dev, fo.dev);
+  if (e) return e;
+  return fo.back();
+}
+
+int wai_jacobian(wai_ctx* c, double t, double dt, const double* y, const double* lhs_old) {
+  (void)t;
+  if (!c || !y || !lhs_old) return -2;
+  VecArg lo{c};
+  if (to_work(c, y, c->w_y) || lo.in(lhs_old, c->ks.n, 1)) return -1;
+  if (c->comm && c->mesh.n_halo && halo_exchange(c, c->w_y, c->np)) return -1;
+  return do_jacobian(c, dt, c->w_y, lo.dev);
+}
+
+int wai_jacobian_nnzb(wai_ctx* c) { return c ? c->J.nnzb : -2; }
+
+int wai_jacobian_pattern(wai_ctx* c, int* rowptr, int* colidx) {
+  if (!c || !rowptr || !colidx) return -2;
+  std::memcpy(rowptr, c->J.h_rowptr.data(), sizeof(int) * (c->J.n + 1));
+  std::memcpy(colidx, c->J.h_colidx.data(), sizeof(int) * c->J.nnzb);
+  return 0;
+}
+
+int wai_jacobian_get_values(wai_ctx* c, double* val) {
+  if (!c || !val) return -2;
+  const size_t n = (size_t)c->J.nnzb * c->np * c->np;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(val, c->J.val, n * sizeof(double), is_device_ptr(val) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int wai_jacobian_set_values(wai_ctx* c, const double* val) {
+  if (!c || !val) return -2;
+  const size_t n = (size_t)c->J.nnzb * c->np * c->np;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->J.val, val, n * sizeof(double), is_device_ptr(val) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  c->ilu.factored = false;
+  return 0;
+}
+
+int wai_spmv(wai_ctx* c, const double* x, double* y) {
+  if (!c || !x || !y) return -2;
+  VecArg yo{c};
+  double* xd;
+  if (is_device_ptr(x) && (!c->comm || c->mesh.n_halo == 0)) xd = const_cast<double*>(x);
+  else { if (to_work(c, x, c->w_a)) return -1; xd = c->w_a; if (halo_exchange(c, xd, c->np)) return -1; }
+  if (yo.out_only(y, c->ks.n, 1)) return -1;
+  {
+    Prof p(c, KC_SPMV);
+    launch_spmv(c, xd, yo.dev);
+  }
+  return yo.back();
+}
+
+int wai_pc_setup(wai_ctx* c) { return c ? do_pc_setup(c) : -2; }
+
+int wai_pc_apply(wai_ctx* c, const double* r, double* z) {
+  if (!c || !r || !z) return -2;
+  if (!c->ilu.factored) { const int e = do_pc_setup(c); if (e) return e; }
+  VecArg ri{c}, zo{c};
+  if (ri.in(r, c->ks.n, 0) || zo.out_only(z, c->ks.n, 1)) return -1;
+  {
+    Prof p(c, KC_PC_APPLY);
+    launch_ilu_apply(c, ri.dev, zo.dev);
+  }
+  return zo.back();
+}
+
+int wai_ksp_solve(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
+  if (!c || !b || !x || !its || !reason || !rnorm) return -2;
+  VecArg bi{c}, xo{c};
+  if (bi.in(b, c->ks.n, 0) || xo.out_only(x, c->ks.n, 1)) return -1;
+  if (do_ksp(c, bi.dev, xo.dev, its, reason, rnorm)) return -1;
+  return xo.back();
+}
+
+int wai_max_scaled(wai_ctx* c, const double* v, const double* scale, double tol, double* val, int* idx) {
+  if (!c || !v || !scale || !val || !idx) return -2;
+  VecArg a{c}, b{c};
+  if (a.in(v, c->ks.n, 0) || b.in(scale, c->ks.n, 1)) return -1;
+  return do_max_scaled(c, a.dev, b.dev, tol, val, idx);
+}
+
+int wai_post_linesearch(wai_ctx* c, const double* y_old, double* search, double* y, int* changed_search,
+                        int* changed_y) {
+  if (!c || !y_old || !search || !y) return -2;
+  VecArg a{c}, s{c}, yy{c};
+  if (a.in(y_old, c->ks.n, 0) || s.in(search, c->ks.n, 1) || yy.in(y, c->ks.n, 2)) return -1;
+  {
+    Prof p(c, KC_TRANSITIONS);
+    launch_transitions(c, a.dev, s.dev, yy.dev);
+  }
+  int fl[4];
+  if (fetch_flags(c, fl)) return -1;
+  if (changed_y) *changed_y = fl[2];
+  if (changed_search) *changed_search = fl[3];
+  if (s.back() || yy.back()) return -1;
+  return fl[0] ? 1 : 0;
+}
+
+int wai_newton_step(wai_ctx* c, double t, double dt, int iter, double* y, const double* lhs_old, double* f,
+                    int* ksp_its, int* reason, double* max_residual) {
+  (void)t;
+  if (!c || !y || !lhs_old || !f || !ksp_its || !reason || !max_residual) return -2;
+  VecArg lo{c}, ff{c};
+  if (to_work(c, y, c->w_y) || lo.in(lhs_old, c->ks.n, 1) || ff.in(f, c->ks.n, 2)) return -1;
+  if (c->comm && c->mesh.n_halo && halo_exchange(c, c->w_y, c->np)) return -1;
+  if (do_newton_step(c, dt, iter, c->w_y, lo.dev, ff.dev, ksp_its, reason, max_residual)) return -1;
+  if (from_work(c, c->w_y, y)) return -1;
+  return ff.back();
+}
+
+int wai_timestep(wai_ctx* c, double t, double dt, double* y, int* newton_its, int* ksp_its, int* reason) {
+  (void)t;
+  if (!c || !y || !newton_its || !ksp_its || !reason) return -2;
+  const int n = c->ks.n;
+  *newton_its = 0; *ksp_its = 0; *reason = 0;
+  if (to_work(c, y, c->w_y)) return -1;
+  if (snapshot_step(c)) return -1;
+  vec_copy(c, c->w_b, c->w_y, n);  // saved solution for a failed step
+  int e = do_pre_eval(c, c->w_y);
+  if (e < 0) return -1;
+  int r = 0;
+  if (e > 0) r = -3;
+  if (!r) {
+    launch_residual(c, 0.0, nullptr, nullptr, c->w_lhs, nullptr);  // L(y_old)
+    e = do_residual(c, dt, c->w_y, c->w_lhs, c->w_f);
+    if (e < 0) return -1;
+    if (e > 0) r = -3;
+  }
+  if (!r) {
+    double fnorm, mr;
+    if (do_norm2(c, c->w_f, &fnorm)) return -1;
+    c->fnorm0 = fnorm;
+    if (snes_convergence(c, 0, c->w_f, c->w_lhs, c->w_y, nullptr, fnorm, &mr, &r)) return -1;
+    int it = 0;
+    while (!r) {
+      int kits = 0;
+      if (do_newton_step(c, dt, it, c->w_y, c->w_lhs, c->w_f, &kits, &r, &mr)) return -1;
+      *ksp_its += kits;
+      it++;
+    }
+    *newton_its = it;
+  }
+  *reason = r;
+  if (r < 0) {
+    vec_copy(c, c->w_y, c->w_b, n);
+    if (restore_step(c)) return -1;
+  }
+  return from_work(c, c->w_y, y);
+}
+
+int wai_timer_start(wai_ctx* c) { if (!c) return -2; HIPCHK(c, hipEventRecord(c->ev0, c->stream)); return 0; }
+int wai_timer_stop(wai_ctx* c, float* ms) {
+  if (!c || !ms) return -2;
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  HIPCHK(c, hipEventSynchronize(c->ev1));
+  HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return 0;
+}
+int wai_synchronize(wai_ctx* c) { if (!c) return -2; HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+int wai_profile_enable(wai_ctx* c, int on) { if (!c) return -2; c->prof_on = on != 0; return 0; }
+int wai_profile_get(wai_ctx* c, int kclass, double* ms, long long* launches) {
+  if (!c || kclass < 0 || kclass >= KC_COUNT) return -2;
+  if (ms) *ms = c->prof_ms[kclass];
+  if (launches) *launches = c->prof_n[kclass];
+  return 0;
+}
+int wai_profile_reset(wai_ctx* c) {
+  if (!c) return -2;
+  for (int i = 0; i < KC_COUNT; i++) { c->prof_ms[i] = 0.0; c->prof_n[i] = 0; }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,510 @@
+// Cell/face assembly sweeps for gfx950: EOS evaluation (K1), accumulation + cell-centric flux
+// gather + backward-Euler residual (K2-K4), finite-difference BCSR Jacobian (K5), phase
+// transitions (K11) and the scaled max-norm (K10).
+//
+// Reference loops replaced (under /root/reference/src):
+//   flow_simulation.F90:2291-2415 fluid_properties     -> k_eos / k_eos_pert
+//   flow_simulation.F90:1242-1330 cell_balances,
+//   flow_simulation.F90:1334-1485 cell_inflows,
+//   timestepper.F90:345-374 backwards_Euler_residual   -> k_residual (one fused sweep)
+//   timestepper.F90:1584-1611 MatFDColoring + flow_simulation.F90:1102-1137 update masks
+//                                                      -> k_jacobian (per-row differencing,
+//                                                         no colouring, no update_cell vector)
+//   flow_simulation.F90:2419-2576 fluid_transitions    -> k_transitions
+//   dm_utils.F90:644-685 vec_max_pointwise_abs_scale   -> k_max_scaled
+//
+// All kernels are HBM-bound fp64 streaming sweeps: one thread per cell, struct-of-arrays
+// state so every wave instruction reads 64 consecutive doubles, neighbour gathers served by
+// L2 (brick-major numbering keeps a cell's 6 neighbours within a few KB).  Roofline and
+// algorithmic bytes per cell: DESIGN.md section 4.
+#include "context.hpp"
+
+namespace wai {
+
+constexpr int MAXDEG = 8;   // faces per cell held in registers (structured: 6, MINC: 7)
+constexpr int TPB = 256;
+
+__device__ __forceinline__ double fd_step(double yv, double eps, double umin) {
+  // MatFDColoring "ds" increment (doc/user/setup_time.rst:434-471)
+  double dx = yv;
+  if (fabs(dx) < umin) dx = (dx >= 0.0) ? umin : -umin;
+  return dx * eps;
+}
+
+__device__ __forceinline__ void flag_error(int* flags, int cell) {
+  atomicMax(&flags[0], 1);
+  atomicMin(&flags[1], cell);
+}
+
+// ---- K1: EOS ---------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(TPB) void k_eos(EosParams ep, const double* __restrict__ y,
+                                             double* __restrict__ flu, size_t stride, int first,
+                                             int count, int* flags) {
+  using E = EosT<KIND>;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  const size_t c = (size_t)first + t;
+  double yc[E::np];
+#pragma unroll
+  for (int k = 0; k < E::np; k++) yc[k] = y[c * E::np + k];
+  const int region = (int)flu[F_REGION * stride + c];
+  CellState<KIND> s;
+  if (eos_eval<KIND>(ep, yc, region, s)) { flag_error(flags, (int)c); return; }
+  store_state<KIND>(flu, stride, c, s);
+}
+
+// perturbed states for the FD Jacobian: thread (k, cell); state k of cell c has primary k
+// incremented by h = fd_step(y_ck); region held fixed
+template <int KIND>
+__global__ __launch_bounds__(TPB) void k_eos_pert(EosParams ep, const double* __restrict__ y,
+                                                  const double* __restrict__ flu, size_t stride,
+                                                  double* __restrict__ flu_pert,
+                                                  double* __restrict__ hstep, int n_prim,
+                                                  double eps, double umin, int* flags) {
+  using E = EosT<KIND>;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)n_prim * E::np) return;
+  const int k = (int)(t / n_prim);
+  const size_t c = t - (size_t)k * n_prim;
+  double yc[E::np];
+#pragma unroll
+  for (int q = 0; q < E::np; q++) yc[q] = y[c * E::np + q];
+  double h = 0.0;
+#pragma unroll
+  for (int q = 0; q < E::np; q++)
+    if (q == k) { h = fd_step(yc[q], eps, umin); yc[q] += h; }
+  hstep[c * E::np + k] = h;
+  const int region = (int)flu[F_REGION * stride + c];
+  CellState<KIND> s;
+  if (eos_eval<KIND>(ep, yc, region, s)) { flag_error(flags, (int)c); return; }
+  store_state<KIND>(flu_pert + (size_t)k * E::df * n_prim, (size_t)n_prim, c, s);
+}
+
+// ---- shared pieces of the cell-centric sweeps ------------------------------------------------
+struct MeshView {
+  const double* rock; const double* vol; const double* fgeom; const int* fdir;
+  const int* adj_face; const int* adj_other; const int* adj_blk; const int* diag_blk;
+  const int* cell_src;
+  const int* src_next; const int* src_comp; const double* src_rate; const double* src_enth;
+  int n_owned, n_local, n_faces, max_deg;
+};
+
+__device__ __forceinline__ void load_face(const MeshView& m, int f, FaceGeom& g) {
+  const size_t nf = m.n_faces;
+  g.area = m.fgeom[f]; g.d1 = m.fgeom[nf + f]; g.d2 = m.fgeom[2 * nf + f];
+  g.d12 = m.fgeom[3 * nf + f]; g.gn = m.fgeom[4 * nf + f]; g.dir = m.fdir[f];
+}
+
+// sign * (flux * area) / vol for the face in adjacency slot, evaluated with states (own, other)
+template <int KIND>
+__device__ __forceinline__ void slot_term(const FaceGeom& g, int side, const CellState<KIND>& own,
+                                          const RockState& rown, const CellState<KIND>& oth,
+                                          const RockState& roth, double vol, double* term) {
+  using E = EosT<KIND>;
+  double flux[E::np];
+  if (side == 0) face_flux<KIND>(g, own, rown, oth, roth, flux);
+  else face_flux<KIND>(g, oth, roth, own, rown, flux);
+  const double sign = side ? 1.0 : -1.0;
+#pragma unroll
+  for (int k = 0; k < E::np; k++) term[k] = sign * (flux[k] * g.area) / vol;
+}
+
+template <int KIND>
+__device__ __forceinline__ void source_terms(const MeshView& m, int c, const CellState<KIND>& s,
+                                             double vol, double* R) {
+  using E = EosT<KIND>;
+  for (int si = m.cell_src[c]; si >= 0; si = m.src_next[si]) {
+    double flow[E::np];
+    source_flow<KIND>(s, m.src_rate[si], m.src_enth[si], m.src_comp[si], flow);
+#pragma unroll
+    for (int k = 0; k < E::np; k++) R[k] += flow[k] / vol;
+  }
+}
+
+// ---- K2-K4: residual -------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(TPB) void k_residual(MeshView m, const double* __restrict__ flu,
+                                                  size_t stride, double dt,
+                                                  const double* __restrict__ lhs_old,
+                                                  double* __restrict__ f, double* __restrict__ lhs_out,
+                                                  double* __restrict__ rhs_out) {
+  using E = EosT<KIND>;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= m.n_owned) return;
+  CellState<KIND> own;
+  RockState rown;
+  load_state<KIND>(flu, stride, c, own);
+  load_rock(m.rock, m.n_local, c, rown);
+  const double vol = m.vol[c];
+  double L[E::np], R[E::np];
+  cell_balance<KIND>(own, rown, L);
+#pragma unroll
+  for (int k = 0; k < E::np; k++) R[k] = 0.0;
+  for (int s = 0; s < m.max_deg; s++) {
+    const int fs = m.adj_face[(size_t)s * m.n_owned + c];
+    if (fs < 0) continue;
+    const int o = m.adj_other[(size_t)s * m.n_owned + c];
+    FaceGeom g;
+    load_face(m, fs >> 1, g);
+    CellState<KIND> oth;
+    RockState roth;
+    load_state<KIND>(flu, stride, o, oth);
+    load_rock(m.rock, m.n_local, o, roth);
+    double term[E::np];
+    slot_term<KIND>(g, fs & 1, own, rown, oth, roth, vol, term);
+#pragma unroll
+    for (int k = 0; k < E::np; k++) R[k] += term[k];
+  }
+  source_terms<KIND>(m, c, own, vol, R);
+#pragma unroll
+  for (int k = 0; k < E::np; k++) {
+    if (lhs_out) lhs_out[(size_t)c * E::np + k] = L[k];
+    if (rhs_out) rhs_out[(size_t)c * E::np + k] = R[k];
+    if (f) f[(size_t)c * E::np + k] = (L[k] - lhs_old[(size_t)c * E::np + k]) - dt * R[k];
+  }
+}
+
+// ---- K5: FD Jacobian, one block row per thread -----------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __restrict__ flu,
+                                                  size_t stride, const double* __restrict__ flu_pert,
+                                                  const double* __restrict__ hstep, int n_prim,
+                                                  double dt, const double* __restrict__ lhs_old,
+                                                  double* __restrict__ val) {
+  using E = EosT<KIND>;
+  constexpr int np = E::np, bb = E::np * E::np;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= m.n_owned) return;
+  CellState<KIND> own0;
+  RockState rown;
+  load_state<KIND>(flu, stride, c, own0);
+  load_rock(m.rock, m.n_local, c, rown);
+  const double vol = m.vol[c];
+  double lold[np];
+#pragma unroll
+  for (int k = 0; k < np; k++) lold[k] = lhs_old[(size_t)c * np + k];
+
+  // base residual, keeping every slot's contribution
+  double L0[np], terms0[MAXDEG][np], src0[np], f0[np];
+  cell_balance<KIND>(own0, rown, L0);
+#pragma unroll
+  for (int s = 0; s < MAXDEG; s++) {
+#pragma unroll
+    for (int k = 0; k < np; k++) terms0[s][k] = 0.0;
+    if (s < m.max_deg) {
+      const int fs = m.adj_face[(size_t)s * m.n_owned + c];
+      if (fs >= 0) {
+        const int o = m.adj_other[(size_t)s * m.n_owned + c];
+        FaceGeom g;
+        load_face(m, fs >> 1, g);
+        CellState<KIND> oth;
+        RockState roth;
+        load_state<KIND>(flu, stride, o, oth);
+        load_rock(m.rock, m.n_local, o, roth);
+        slot_term<KIND>(g, fs & 1, own0, rown, oth, roth, vol, terms0[s]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < np; k++) src0[k] = 0.0;
+  source_terms<KIND>(m, c, own0, vol, src0);
+  {
+    double R[np];
+#pragma unroll
+    for (int k = 0; k < np; k++) R[k] = 0.0;
+#pragma unroll
+    for (int s = 0; s < MAXDEG; s++) {
+      if (s < m.max_deg && m.adj_face[(size_t)s * m.n_owned + c] >= 0) {
+#pragma unroll
+        for (int k = 0; k < np; k++) R[k] += terms0[s][k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < np; k++) { R[k] += src0[k]; f0[k] = (L0[k] - lold[k]) - dt * R[k]; }
+  }
+
+  // diagonal block: own state perturbed in component k
+  double* dblk = val + (size_t)m.diag_blk[c] * bb;
+#pragma unroll
+  for (int k = 0; k < np; k++) {
+    CellState<KIND> ownk;
+    load_state<KIND>(flu_pert + (size_t)k * E::df * n_prim, (size_t)n_prim, c, ownk);
+    double Lk[np], R[np];
+    cell_balance<KIND>(ownk, rown, Lk);
+#pragma unroll
+    for (int q = 0; q < np; q++) R[q] = 0.0;
+    for (int s = 0; s < m.max_deg; s++) {
+      const int fs = m.adj_face[(size_t)s * m.n_owned + c];
+      if (fs < 0) continue;
+      const int o = m.adj_other[(size_t)s * m.n_owned + c];
+      FaceGeom g;
+      load_face(m, fs >> 1, g);
+      CellState<KIND> oth;
+      RockState roth;
+      load_state<KIND>(flu, stride, o, oth);
+      load_rock(m.rock, m.n_local, o, roth);
+      double term[np];
+      slot_term<KIND>(g, fs & 1, ownk, rown, oth, roth, vol, term);
+#pragma unroll
+      for (int q = 0; q < np; q++) R[q] += term[q];
+    }
+    source_terms<KIND>(m, c, ownk, vol, R);
+    const double h = hstep[(size_t)c * np + k];
+#pragma unroll
+    for (int r = 0; r < np; r++) {
+      const double f1 = (Lk[r] - lold[r]) - dt * R[r];
+      dblk[r * np + k] = (f1 - f0[r]) / h;
+    }
+  }
+
+  // off-diagonal blocks: neighbour across slot s perturbed in component k
+#pragma unroll
+  for (int s = 0; s < MAXDEG; s++) {
+    if (s >= m.max_deg) continue;
+    const int fs = m.adj_face[(size_t)s * m.n_owned + c];
+    if (fs < 0) continue;
+    const int blk = m.adj_blk[(size_t)s * m.n_owned + c];
+    if (blk < 0) continue;  // Dirichlet ghost: no column
+    const int o = m.adj_other[(size_t)s * m.n_owned + c];
+    FaceGeom g;
+    load_face(m, fs >> 1, g);
+    RockState roth;
+    load_rock(m.rock, m.n_local, o, roth);
+    double* oblk = val + (size_t)blk * bb;
+#pragma unroll
+    for (int k = 0; k < np; k++) {
+      CellState<KIND> othk;
+      load_state<KIND>(flu_pert + (size_t)k * E::df * n_prim, (size_t)n_prim, o, othk);
+      double term[np], R[np];
+      slot_term<KIND>(g, fs & 1, own0, rown, othk, roth, vol, term);
+#pragma unroll
+      for (int q = 0; q < np; q++) R[q] = 0.0;
+#pragma unroll
+      for (int s2 = 0; s2 < MAXDEG; s2++) {
+        if (s2 < m.max_deg && m.adj_face[(size_t)s2 * m.n_owned + c] >= 0) {
+#pragma unroll
+          for (int q = 0; q < np; q++) R[q] += (s2 == s) ? term[q] : terms0[s2][q];
+        }
+      }
+      const double h = hstep[(size_t)o * np + k];
+#pragma unroll
+      for (int r = 0; r < np; r++) {
+        const double f1 = (L0[r] - lold[r]) - dt * (R[r] + src0[r]);
+        oblk[r * np + k] += (f1 - f0[r]) / h;
+      }
+    }
+  }
+}
+
+// ---- K11: transitions ------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(TPB) void k_transitions(EosParams ep, int n_owned,
+                                                     double* __restrict__ flu, size_t stride,
+                                                     const double* __restrict__ flu_old,
+                                                     const double* __restrict__ y_old,
+                                                     double* __restrict__ search,
+                                                     double* __restrict__ y, int* flags) {
+  using E = EosT<KIND>;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_owned) return;
+  int region = (int)flu[F_REGION * stride + c];
+  const int old_region = (int)flu_old[F_REGION * stride + c];
+  const double old_t = flu_old[F_T * stride + c];
+  double prim[E::np], oldp[E::np], yo[E::np];
+#pragma unroll
+  for (int k = 0; k < E::np; k++) {
+    yo[k] = y_old[(size_t)c * E::np + k];
+    prim[k] = y[(size_t)c * E::np + k] * ep.scale[region][k];
+    oldp[k] = yo[k] * ep.scale[old_region][k];
+  }
+  flu[F_OLD_REGION * stride + c] = (double)region;
+  bool transition = false;
+  int err = eos_transition<KIND>(oldp, prim, old_region, old_t, region, transition);
+  if (!err) err = eos_check_primary<KIND>(prim, region);
+  if (err) { flag_error(flags, c); return; }
+  if (transition) {
+    flu[F_REGION * stride + c] = (double)region;
+#pragma unroll
+    for (int k = 0; k < E::np; k++) {
+      const double ys = prim[k] / ep.scale[region][k];
+      y[(size_t)c * E::np + k] = ys;
+      search[(size_t)c * E::np + k] = yo[k] - ys;
+    }
+    flags[2] = 1;
+    flags[3] = 1;
+  }
+}
+
+// ---- K10: max_i |v_i| / max(|s_i|, tol) with first-index argmax ------------------------------
+__global__ __launch_bounds__(TPB) void k_max_scaled(const double* __restrict__ v,
+                                                    const double* __restrict__ scale, double tol,
+                                                    int n, double* __restrict__ pval,
+                                                    int* __restrict__ pidx) {
+  double best = -1.0;
+  int bi = 0x7fffffff;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double sc = fmax(fabs(scale[i]), tol);
+    double r = fabs(v[i]) / sc;
+    if (r != r) r = __builtin_huge_val();  // NaN counts as the maximum
+    if (r > best) { best = r; bi = i; }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ob = __shfl_down(best, off);
+    const int oi = __shfl_down(bi, off);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  __shared__ double sb[TPB / 64];
+  __shared__ int si[TPB / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { sb[w] = best; si[w] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int q = 1; q < TPB / 64; q++)
+      if (sb[q] > best || (sb[q] == best && si[q] < bi)) { best = sb[q]; bi = si[q]; }
+    pval[blockIdx.x] = best;
+    pidx[blockIdx.x] = bi;
+  }
+}
+
+__global__ void k_max_scaled_final(int nb, double* pval, int* pidx) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double best = pval[0];
+    int bi = pidx[0];
+    for (int q = 1; q < nb; q++)
+      if (pval[q] > best || (pval[q] == best && pidx[q] < bi)) { best = pval[q]; bi = pidx[q]; }
+    pval[0] = best;
+    pidx[0] = bi;
+  }
+}
+
+// ---- layout helpers --------------------------------------------------------------------------
+__global__ void k_soa_to_aos(const double* __restrict__ soa, double* __restrict__ aos, int n, int df) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)n * df) return;
+  const int f = (int)(t / n);
+  const size_t c = t - (size_t)f * n;
+  aos[c * df + f] = soa[t];
+}
+__global__ void k_copy_strided(const double* __restrict__ src, double* __restrict__ dst, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) dst[t] = src[t];
+}
+
+// ---- launchers -------------------------------------------------------------------------------
+static MeshView view(wai_ctx* c) {
+  MeshView m;
+  m.rock = c->mesh.rock; m.vol = c->mesh.vol; m.fgeom = c->mesh.fgeom; m.fdir = c->mesh.fdir;
+  m.adj_face = c->mesh.adj_face; m.adj_other = c->mesh.adj_other; m.adj_blk = c->mesh.adj_blk;
+  m.diag_blk = c->mesh.diag_blk; m.cell_src = c->mesh.cell_src;
+  m.src_next = c->src.next; m.src_comp = c->src.comp; m.src_rate = c->src.rate;
+  m.src_enth = c->src.enth;
+  m.n_owned = c->mesh.n_owned; m.n_local = c->mesh.n_local; m.n_faces = c->mesh.n_faces;
+  m.max_deg = c->mesh.max_deg;
+  return m;
+}
+
+static inline int grid_for(size_t n) { return (int)((n + TPB - 1) / TPB); }
+
+int launch_eos(wai_ctx* c, const double* y, int first, int count, bool perturbed) {
+  if (count <= 0) return 0;
+  const size_t stride = c->mesh.n_local;
+  if (!perturbed) {
+    if (c->kind == EOS_W)
+      hipLaunchKernelGGL(k_eos<EOS_W>, grid_for(count), TPB, 0, c->stream, c->ep, y, c->flu,
+                         stride, first, count, c->d_flags);
+    else
+      hipLaunchKernelGGL(k_eos<EOS_WE>, grid_for(count), TPB, 0, c->stream, c->ep, y, c->flu,
+                         stride, first, count, c->d_flags);
+  } else {
+    const int n_prim = c->mesh.n_prim;
+    const size_t tot = (size_t)n_prim * c->np;
+    if (c->kind == EOS_W)
+      hipLaunchKernelGGL(k_eos_pert<EOS_W>, grid_for(tot), TPB, 0, c->stream, c->ep, y, c->flu,
+                         stride, c->flu_pert, c->hstep, n_prim, c->opts.fd_eps, c->opts.fd_umin,
+                         c->d_flags);
+    else
+      hipLaunchKernelGGL(k_eos_pert<EOS_WE>, grid_for(tot), TPB, 0, c->stream, c->ep, y, c->flu,
+                         stride, c->flu_pert, c->hstep, n_prim, c->opts.fd_eps, c->opts.fd_umin,
+                         c->d_flags);
+  }
+  return 0;
+}
+
+int launch_residual(wai_ctx* c, double dt, const double* lhs_old, double* f, double* lhs_out,
+                    double* rhs_out) {
+  const MeshView m = view(c);
+  const size_t stride = c->mesh.n_local;
+  if (c->kind == EOS_W)
+    hipLaunchKernelGGL(k_residual<EOS_W>, grid_for(m.n_owned), TPB, 0, c->stream, m, c->flu, stride,
+                       dt, lhs_old, f, lhs_out, rhs_out);
+  else
+    hipLaunchKernelGGL(k_residual<EOS_WE>, grid_for(m.n_owned), TPB, 0, c->stream, m, c->flu, stride,
+                       dt, lhs_old, f, lhs_out, rhs_out);
+  return 0;
+}
+
+int launch_jacobian(wai_ctx* c, double dt, const double* lhs_old) {
+  const MeshView m = view(c);
+  if (m.max_deg > MAXDEG) { c->err = "cell with more than 8 faces not supported"; return -1; }
+  const size_t stride = c->mesh.n_local;
+  hipMemsetAsync(c->J.val, 0, sizeof(double) * (size_t)c->J.nnzb * c->np * c->np, c->stream);
+  if (c->kind == EOS_W)
+    hipLaunchKernelGGL(k_jacobian<EOS_W>, grid_for(m.n_owned), TPB, 0, c->stream, m, c->flu, stride,
+                       c->flu_pert, c->hstep, c->mesh.n_prim, dt, lhs_old, c->J.val);
+  else
+    hipLaunchKernelGGL(k_jacobian<EOS_WE>, grid_for(m.n_owned), TPB, 0, c->stream, m, c->flu, stride,
+                       c->flu_pert, c->hstep, c->mesh.n_prim, dt, lhs_old, c->J.val);
+  return 0;
+}
+
+int launch_transitions(wai_ctx* c, const double* y_old, double* search, double* y) {
+  const int n = c->mesh.n_owned;
+  const size_t stride = c->mesh.n_local;
+  if (c->kind == EOS_W)
+    hipLaunchKernelGGL(k_transitions<EOS_W>, grid_for(n), TPB, 0, c->stream, c->ep, n, c->flu, stride,
+                       c->flu_last_iter, y_old, search, y, c->d_flags);
+  else
+    hipLaunchKernelGGL(k_transitions<EOS_WE>, grid_for(n), TPB, 0, c->stream, c->ep, n, c->flu, stride,
+                       c->flu_last_iter, y_old, search, y, c->d_flags);
+  return 0;
+}
+
+int launch_max_scaled(wai_ctx* c, const double* v, const double* scale, double tol, double* val,
+                      int* idx) {
+  const int n = c->np * c->mesh.n_owned;
+  int nb = grid_for(n);
+  if (nb > 1024) nb = 1024;
+  double* pval = c->d_red;
+  int* pidx = reinterpret_cast<int*>(c->d_red + 1024);
+  hipLaunchKernelGGL(k_max_scaled, nb, TPB, 0, c->stream, v, scale, tol, n, pval, pidx);
+  hipLaunchKernelGGL(k_max_scaled_final, 1, 64, 0, c->stream, nb, pval, pidx);
+  hipMemcpyAsync(c->h_red, pval, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  hipMemcpyAsync(c->h_red + 1, pidx, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+  *val = c->h_red[0];
+  *idx = *reinterpret_cast<int*>(c->h_red + 1);
+  return 0;
+}
+
+int launch_fluid_aos(wai_ctx* c, const double* flu_soa, double* out_aos) {
+  const size_t tot = (size_t)c->mesh.n_local * c->df;
+  hipLaunchKernelGGL(k_soa_to_aos, grid_for(tot), TPB, 0, c->stream, flu_soa, out_aos,
+                     c->mesh.n_local, c->df);
+  return 0;
+}
+
+int launch_region_get(wai_ctx* c, double* out) {
+  hipLaunchKernelGGL(k_copy_strided, grid_for(c->mesh.n_prim), TPB, 0, c->stream,
+                     c->flu + (size_t)F_REGION * c->mesh.n_local, out, c->mesh.n_prim);
+  return 0;
+}
+
+int launch_region_set(wai_ctx* c, const double* in, int first, int count) {
+  if (count <= 0) return 0;
+  double* reg = c->flu + (size_t)F_REGION * c->mesh.n_local;
+  hipLaunchKernelGGL(k_copy_strided, grid_for(count), TPB, 0, c->stream, in + first, reg + first, count);
+  return 0;
+}
+
+}  // namespace wai

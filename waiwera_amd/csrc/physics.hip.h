@@ -1,0 +1,472 @@
+// Per-cell / per-face physics as gfx950 device functions: EOS w / we, rel-perm and capillary
+// curves, accumulation terms, two-point flux, source terms, phase transitions.
+//
+// Reference arithmetic replaced (file:line under /root/reference/src):
+//   eos.F90:186-257, eos_w.F90:126-255, eos_we.F90:149-526, relative_permeability.F90:197-492,
+//   capillary_pressure.F90:159-305, cell.F90:114-142, face.F90:282-515, fluid.F90:197-453,
+//   rock.F90:142-150, source.F90:386-480, root_finder.F90:127-248, interpolation.F90:388-435.
+//
+// Data layout in HBM: the fluid state is struct-of-arrays, flu[field * stride + cell], with the
+// reference's 23 (we) / 15 (w) fields in the reference's order (fluid.F90:212-267) so that
+// field f of cell c of the reference's AoS record is flu[f*stride + c].  One thread owns one
+// cell; consecutive lanes read consecutive doubles of one field (512 B per wave instruction).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "if97.hip.h"
+
+namespace wai {
+
+enum { EOS_W = 0, EOS_WE = 1 };
+enum { RP_FULLY_MOBILE = 0, RP_LINEAR = 1, RP_PICKENS = 2, RP_COREY = 3, RP_GRANT = 4,
+       RP_VAN_GENUCHTEN = 5 };
+enum { CP_ZERO = 0, CP_LINEAR = 1, CP_VAN_GENUCHTEN = 2 };
+
+// fluid record field indices (nc = 1)
+enum { F_P = 0, F_T = 1, F_REGION = 2, F_OLD_REGION = 3, F_PHASES = 4, F_PERMFAC = 5, F_PP = 6,
+       F_PHASE0 = 7 };
+enum { PH_RHO = 0, PH_MU = 1, PH_SAT = 2, PH_KR = 3, PH_PC = 4, PH_H = 5, PH_U = 6, PH_X = 7,
+       PH_DOF = 8 };
+// rock record (rock.F90:97-112)
+enum { R_K1 = 0, R_K2 = 1, R_K3 = 2, R_WET = 3, R_DRY = 4, R_PHI = 5, R_RHO = 6, R_CP = 7 };
+
+template <int KIND> struct EosT;
+template <> struct EosT<EOS_W> {
+  static constexpr int np = 1, nc = 1, nph = 1, nmob = 1, df = 15;
+  static constexpr bool isothermal = true;
+};
+template <> struct EosT<EOS_WE> {
+  static constexpr int np = 2, nc = 1, nph = 2, nmob = 2, df = 23;
+  static constexpr bool isothermal = false;
+};
+
+// run-time EOS parameters (kernel argument, lives in SGPRs / constant cache)
+struct EosParams {
+  double temperature;     // eos_w
+  double scale[5][2];     // primary_scale(var, region)  (eos_we.F90:104-109)
+  int rp_type, cp_type;
+  double rp_par[6], cp_par[6];
+};
+
+// two-row table lookup with end clamping (interpolation.F90:202-222,388-404,494-510)
+__device__ __forceinline__ double lin2(double x, double x0, double x1, double y0, double y1) {
+  if (x <= x0) return y0;
+  if (x >= x1) return y1;
+  const double xi = (x - x0) / (x1 - x0);
+  return (1.0 - xi) * y0 + xi * y1;
+}
+
+__device__ __forceinline__ void relperm(const EosParams& e, double sl, double& kl, double& kv) {
+  const double* par = e.rp_par;
+  switch (e.rp_type) {
+    case RP_FULLY_MOBILE: kl = 1.0; kv = 1.0; break;
+    case RP_LINEAR:
+      kl = lin2(sl, par[0], par[1], 0.0, 1.0);
+      kv = lin2(1.0 - sl, par[2], par[3], 0.0, 1.0);
+      break;
+    case RP_PICKENS: kl = pow(sl, par[0]); kv = 1.0; break;
+    case RP_COREY:
+    case RP_GRANT: {
+      const double slr = par[0], ssr = par[1], sv = 1.0 - sl;
+      if (sv < ssr) { kl = 1.0; kv = 0.0; }
+      else if (sv > 1.0 - slr) { kl = 0.0; kv = 1.0; }
+      else {
+        const double ss = (sl - slr) / (1.0 - slr - ssr), ss2 = ss * ss;
+        kl = ss2 * ss2;
+        kv = (e.rp_type == RP_COREY) ? (1.0 - 2.0 * ss + ss2) * (1.0 - ss2) : 1.0 - kl;
+      }
+    } break;
+    case RP_VAN_GENUCHTEN: {
+      const double lambda = par[0], slr = par[1], sls = par[2], ssr = par[4];
+      const double ss = (sl - slr) / (sls - slr);
+      if (ss < 0.0) kl = 0.0;
+      else if (ss < 1.0) {
+        const double w = 1.0 - pow(1.0 - pow(ss, 1.0 / lambda), lambda);
+        kl = sqrt(ss) * w * w;
+      } else kl = 1.0;
+      if (par[3] != 0.0) kv = 1.0 - kl;
+      else {
+        const double sh = (sl - slr) / (1.0 - slr - ssr), sh2 = sh * sh;
+        kv = fmin(1.0, (1.0 - 2.0 * sh + sh2) * (1.0 - sh2));
+      }
+    } break;
+    default: kl = 0.0; kv = 0.0;
+  }
+}
+
+__device__ __forceinline__ double capillary(const EosParams& e, double sl) {
+  const double* par = e.cp_par;
+  switch (e.cp_type) {
+    case CP_LINEAR: return lin2(sl, par[0], par[1], -fabs(par[2]), 0.0);
+    case CP_VAN_GENUCHTEN: {
+      const double eps = 1.e-3;
+      const double P0 = fabs(par[0]), lambda = par[1], slr = par[2], sls = par[3];
+      const double Pmax = fabs(par[4]);
+      double cp = 0.0;
+      if (sl < 1.0) {
+        const double ss = (sl - slr) / (sls - slr);
+        if (ss < 0.0) cp = -Pmax;
+        else if (ss < 1.0) cp = -P0 * pow(pow(ss, -1.0 / lambda) - 1.0, 1.0 - lambda);
+        else cp = 0.0;
+        cp = fmin(0.0, cp);
+        if (par[5] != 0.0) cp = fmax(-Pmax, cp);
+        if (sl > 1.0 - eps) cp = cp * (1.0 - sl) / eps;
+      }
+      return cp;
+    }
+    default: return 0.0;
+  }
+}
+
+// ---- cell state in registers ---------------------------------------------------------------
+template <int KIND> struct CellState {
+  using E = EosT<KIND>;
+  double P, T, region, phases, permfac;
+  double rho[E::nph], mu[E::nph], sat[E::nph], kr[E::nph], pc[E::nph], h[E::nph], u[E::nph];
+};
+
+// full EOS evaluation: scaled primaries + region -> state (fluid_properties loop body,
+// flow_simulation.F90:2347-2403).  Returns the reference's err flag.
+template <int KIND>
+__device__ __forceinline__ int eos_eval(const EosParams& e, const double* y, int region,
+                                        CellState<KIND>& s) {
+  using E = EosT<KIND>;
+  s.region = (double)region;
+  s.permfac = 1.0;
+  if constexpr (KIND == EOS_W) {
+    s.P = y[0] * e.scale[region][0];
+    s.T = e.temperature;
+    s.sat[0] = 1.0;
+    const int ph = if97::phase_composition(region, s.P, s.T);
+    if (ph <= 0) return 1;
+    s.phases = (double)ph;
+    double rho, u;
+    const int err = (region == 1) ? if97::region1(s.P, s.T, rho, u) : if97::region2(s.P, s.T, rho, u);
+    if (err) return err;
+    s.rho[0] = rho; s.u[0] = u; s.h[0] = u + s.P / rho;
+    s.kr[0] = 1.0; s.pc[0] = 0.0;
+    s.mu[0] = if97::viscosity(s.T, rho);
+    return 0;
+  } else {
+    const double p0 = y[0] * e.scale[region][0], p1 = y[1] * e.scale[region][1];
+    s.P = p0;
+    if (region == 4) {
+      double t;
+      if (if97::sat_temperature(s.P, t)) return 1;
+      s.T = t;
+    } else s.T = p1;
+    const int ph = if97::phase_composition(region, s.P, s.T);
+    if (ph <= 0) return 1;
+    s.phases = (double)ph;
+    if (region == 1) { s.sat[0] = 1.0; s.sat[1] = 0.0; }
+    else if (region == 2) { s.sat[0] = 0.0; s.sat[1] = 1.0; }
+    else { s.sat[0] = 1.0 - p1; s.sat[1] = p1; }
+    double kl, kv;
+    relperm(e, s.sat[0], kl, kv);
+    const double pcl = capillary(e, s.sat[0]);
+#pragma unroll
+    for (int p = 0; p < E::nph; p++) {
+      if (ph & (1 << p)) {
+        double rho, u;
+        const int err = (p == 0) ? if97::region1(s.P, s.T, rho, u) : if97::region2(s.P, s.T, rho, u);
+        if (err) return err;
+        s.rho[p] = rho; s.u[p] = u; s.h[p] = u + s.P / rho;
+        s.kr[p] = (p == 0) ? kl : kv;
+        s.pc[p] = (p == 0) ? pcl : 0.0;
+        s.mu[p] = if97::viscosity(s.T, rho);
+      } else {
+        s.rho[p] = 0.0; s.u[p] = 0.0; s.h[p] = 0.0; s.kr[p] = 0.0; s.pc[p] = 0.0; s.mu[p] = 0.0;
+      }
+    }
+    return 0;
+  }
+}
+
+// store / load a state to the SoA fluid array (only the fields the EOS rewrites; region and
+// old_region are owned by the transition kernel)
+template <int KIND>
+__device__ __forceinline__ void store_state(double* flu, size_t stride, size_t c,
+                                            const CellState<KIND>& s) {
+  using E = EosT<KIND>;
+  flu[F_P * stride + c] = s.P;
+  flu[F_T * stride + c] = s.T;
+  flu[F_PHASES * stride + c] = s.phases;
+  flu[F_PERMFAC * stride + c] = s.permfac;
+  flu[F_PP * stride + c] = s.P;
+#pragma unroll
+  for (int p = 0; p < E::nph; p++) {
+    const size_t b = (size_t)(F_PHASE0 + p * PH_DOF) * stride + c;
+    const bool on = ((int)s.phases >> p) & 1;
+    flu[b + PH_RHO * stride] = s.rho[p];
+    flu[b + PH_MU * stride] = s.mu[p];
+    flu[b + PH_SAT * stride] = s.sat[p];
+    flu[b + PH_KR * stride] = s.kr[p];
+    flu[b + PH_PC * stride] = s.pc[p];
+    flu[b + PH_H * stride] = s.h[p];
+    flu[b + PH_U * stride] = s.u[p];
+    flu[b + PH_X * stride] = on ? 1.0 : 0.0;
+  }
+}
+
+template <int KIND>
+__device__ __forceinline__ void load_state(const double* __restrict__ flu, size_t stride, size_t c,
+                                           CellState<KIND>& s) {
+  using E = EosT<KIND>;
+  s.P = flu[F_P * stride + c];
+  s.T = flu[F_T * stride + c];
+  s.phases = flu[F_PHASES * stride + c];
+  s.permfac = flu[F_PERMFAC * stride + c];
+  s.region = 0.0;
+#pragma unroll
+  for (int p = 0; p < E::nph; p++) {
+    const size_t b = (size_t)(F_PHASE0 + p * PH_DOF) * stride + c;
+    s.rho[p] = flu[b + PH_RHO * stride];
+    s.mu[p] = flu[b + PH_MU * stride];
+    s.sat[p] = flu[b + PH_SAT * stride];
+    s.kr[p] = flu[b + PH_KR * stride];
+    s.pc[p] = flu[b + PH_PC * stride];
+    s.h[p] = flu[b + PH_H * stride];
+    s.u[p] = flu[b + PH_U * stride];
+  }
+}
+
+struct RockState { double k[3], wet, dry, phi, rho, cp; };
+__device__ __forceinline__ void load_rock(const double* __restrict__ rock, size_t stride, size_t c,
+                                          RockState& r) {
+  r.k[0] = rock[R_K1 * stride + c]; r.k[1] = rock[R_K2 * stride + c]; r.k[2] = rock[R_K3 * stride + c];
+  r.wet = rock[R_WET * stride + c]; r.dry = rock[R_DRY * stride + c];
+  r.phi = rock[R_PHI * stride + c]; r.rho = rock[R_RHO * stride + c]; r.cp = rock[R_CP * stride + c];
+}
+
+// cell%balance (cell.F90:114-142)
+template <int KIND>
+__device__ __forceinline__ void cell_balance(const CellState<KIND>& s, const RockState& r, double* bal) {
+  using E = EosT<KIND>;
+  double m = 0.0, ef = 0.0;
+#pragma unroll
+  for (int p = 0; p < E::nph; p++) {
+    const double ds = s.rho[p] * s.sat[p];
+    const double x = (((int)s.phases >> p) & 1) ? 1.0 : 0.0;  // mass_fraction(1)
+    m += ds * x;
+    ef += ds * s.u[p];
+  }
+  bal[0] = r.phi * m;
+  if constexpr (!E::isothermal) {
+    const double er = r.rho * r.cp * s.T;
+    bal[E::np - 1] = r.phi * ef + (1.0 - r.phi) * er;
+  }
+}
+
+struct FaceGeom { double area, d1, d2, d12, gn; int dir; };
+
+__device__ __forceinline__ double harmonic(const FaceGeom& g, double x1, double x2) {
+  const double wx = (g.d1 * x2 + g.d2 * x1) / g.d12;
+  return (fabs(wx) > 1.e-30) ? x1 * x2 / wx : 0.0;
+}
+
+// face%flux (face.F90:443-515): flux[np] from cell 1 to cell 2
+template <int KIND>
+__device__ __forceinline__ void face_flux(const FaceGeom& g, const CellState<KIND>& a,
+                                          const RockState& ra, const CellState<KIND>& b,
+                                          const RockState& rb, double* flux) {
+  using E = EosT<KIND>;
+#pragma unroll
+  for (int i = 0; i < E::np; i++) flux[i] = 0.0;
+  const int d = g.dir - 1;
+  const double ka = (d == 0) ? ra.k[0] : (d == 1 ? ra.k[1] : ra.k[2]);
+  const double kb = (d == 0) ? rb.k[0] : (d == 1 ? rb.k[1] : rb.k[2]);
+  const double k = harmonic(g, ka * a.permfac, kb * b.permfac);
+  if constexpr (!E::isothermal) {
+    const double ca = ra.dry + sqrt(a.sat[0]) * (ra.wet - ra.dry);
+    const double cb = rb.dry + sqrt(b.sat[0]) * (rb.wet - rb.dry);
+    const double cond = harmonic(g, ca, cb);
+    const double dtdn = (b.T - a.T) / g.d12;
+    flux[E::np - 1] = -cond * dtdn;
+  }
+  const int pa = (int)a.phases, pb = (int)b.phases, present = pa | pb;
+#pragma unroll
+  for (int p = 0; p < E::nmob; p++) {
+    if (!(present & (1 << p))) continue;
+    const double rho_f = (a.sat[p] * a.rho[p] + b.sat[p] * b.rho[p]) / (a.sat[p] + b.sat[p]);
+    const double dpdn = ((b.P + b.pc[p]) - (a.P + a.pc[p])) / g.d12;
+    const double G = dpdn - rho_f * g.gn;
+    const bool up1 = (G <= 0.0);
+    const int phup = up1 ? pa : pb;
+    if (!(phup & (1 << p))) continue;
+    const double kr = up1 ? a.kr[p] : b.kr[p], rho = up1 ? a.rho[p] : b.rho[p];
+    const double mu = up1 ? a.mu[p] : b.mu[p], h = up1 ? a.h[p] : b.h[p];
+    const double mob = kr * rho / mu;
+    const double F = -k * mob * G;
+    flux[0] += F * 1.0;  // mass_fraction(1) of a present phase is 1
+    if constexpr (!E::isothermal) flux[E::np - 1] += h * F;
+  }
+}
+
+// source term (source.F90:386-480, fluid.F90:377-453): flow[np] for one source
+template <int KIND>
+__device__ __forceinline__ void source_flow(const CellState<KIND>& s, double rate, double enth,
+                                            int comp, double* flow) {
+  using E = EosT<KIND>;
+#pragma unroll
+  for (int k = 0; k < E::np; k++) flow[k] = 0.0;
+  double h = 0.0;
+  int component;
+  if (rate > 0.0) {
+    component = comp <= 0 ? 1 : comp;
+    h = enth;
+    if (component - 1 < E::np) {
+#pragma unroll
+      for (int k = 0; k < E::np; k++) if (k == component - 1) flow[k] = rate;
+    }
+  } else {
+    component = comp <= 0 ? 0 : comp;
+    const int phases = (int)s.phases;
+    double frac[E::nph], sum = 0.0;
+    if (component < E::np) {
+#pragma unroll
+      for (int p = 0; p < E::nph; p++) {
+        frac[p] = (phases & (1 << p)) ? s.kr[p] * s.rho[p] / s.mu[p] : 0.0;
+        sum += frac[p];
+      }
+#pragma unroll
+      for (int p = 0; p < E::nph; p++) frac[p] /= sum;
+      if constexpr (!E::isothermal) {
+#pragma unroll
+        for (int p = 0; p < E::nph; p++) if (phases & (1 << p)) h += frac[p] * s.h[p];
+      }
+    }
+    if (component <= 0) {
+      double cf = 0.0;
+#pragma unroll
+      for (int p = 0; p < E::nph; p++) if (phases & (1 << p)) cf += frac[p] * 1.0;
+      flow[0] = rate * (cf / cf);
+    } else {
+#pragma unroll
+      for (int k = 0; k < E::np; k++) if (k == component - 1) flow[k] = rate;
+    }
+  }
+  if constexpr (!E::isothermal) {
+    if (component < E::np) flow[E::np - 1] += h * rate;
+  }
+}
+
+// ---- Brent on the saturation line (root_finder.F90:127-248 / eos_we.F90:530-553) -----------
+__device__ inline double satline_diff(double x, double p0, double t0, double p1, double t1) {
+  const double P = (1.0 - x) * p0 + x * p1, T = (1.0 - x) * t0 + x * t1;
+  double ps = 0.0;
+  if97::sat_pressure(T, ps);
+  return P - ps;
+}
+
+__device__ inline int brent_satline(double p0, double t0, double p1, double t1, double& root) {
+  const double xtol = 1.e-8, ftol = 1.e-8, small = 1.e-16;
+  double a = 0.0, b = 1.0;
+  double fa = satline_diff(a, p0, t0, p1, t1), fb = satline_diff(b, p0, t0, p1, t1);
+  root = 0.0;
+  if (fa * fb > 0.0) return 1;
+  double c = b, fc = fb, d = 0.0, e = 0.0;
+  bool found = false;
+  for (int iter = 1; iter <= 100; iter++) {
+    if (fb * fc > 0.0) { c = a; fc = fa; d = b - a; e = d; }
+    if (fabs(fc) < fabs(fb)) { a = b; b = c; c = a; fa = fb; fb = fc; fc = fa; }
+    const double dx = 0.5 * (c - b);
+    if (fabs(dx) <= xtol || fabs(fb) <= ftol) { found = true; break; }
+    if (fabs(e) >= xtol && fabs(fa) > fabs(fb)) {
+      const double s = fb / fa;
+      double p, q;
+      if (fabs(a - c) <= small) { p = 2.0 * dx * s; q = 1.0 - s; }
+      else {
+        q = fa / fc;
+        const double r = fb / fc;
+        p = s * (2.0 * dx * q * (q - r) - (b - a) * (r - 1.0));
+        q = (q - 1.0) * (r - 1.0) * (s - 1.0);
+      }
+      if (p > 0.0) q = -q; else p = -p;
+      const double pc = fmin(3.0 * dx * q - fabs(xtol * q), fabs(e * q));
+      if (2.0 * p < pc) { e = d; d = p / q; }
+      else { d = dx; e = d; }
+    } else { d = dx; e = d; }
+    a = b; fa = fb;
+    if (fabs(d) > xtol) b += d;
+    else b += (dx >= 0.0 ? xtol : -xtol);
+    fb = satline_diff(b, p0, t0, p1, t1);
+  }
+  root = b;
+  return found ? 0 : 2;
+}
+
+// eos%transition + check_primary_variables (eos_we.F90:149-323,486-526; eos_w.F90:103-122,232-255)
+// prim/oldp are unscaled primaries; region is updated in place.  Returns err.
+template <int KIND>
+__device__ inline int eos_transition(const double* oldp, double* prim, int old_region,
+                                     double old_temperature, int& region, bool& transition) {
+  transition = false;
+  if constexpr (KIND == EOS_W) {
+    (void)oldp; (void)old_region; (void)old_temperature; (void)region;
+    return 0;
+  } else {
+    const double small = 1.e-6;
+    if (old_region == 4) {
+      const double sv = prim[1];
+      int new_region = 0;
+      if (sv < 0.0) new_region = 1; else if (sv > 1.0) new_region = 2;
+      if (!new_region) return 0;
+      const double bound = (new_region == 1) ? 0.0 : 1.0;
+      const double pfac = (new_region == 1) ? 1.0 + small : 1.0 - small;
+      const double v1 = oldp[1], v2 = prim[1], vmax = fmax(fabs(v1), fabs(v2));
+      if (fabs(v2 - v1) >= 1.e-8 * vmax) {
+        const double vs1 = v1 / vmax, vs2 = v2 / vmax, ys = bound / vmax;
+        double xi = (ys - vs1) / (vs2 - vs1);
+        xi = (1.0 - xi) * 0.0 + xi * 1.0;
+        double ip;
+        if (xi <= 0.0) ip = oldp[0];
+        else if (xi >= 1.0) ip = prim[0];
+        else ip = (1.0 - xi) * oldp[0] + xi * prim[0];
+        prim[0] = pfac * ip;
+        double t;
+        const int err = if97::sat_temperature(ip, t);
+        if (err == 0) { prim[1] = t; region = new_region; transition = true; }
+        return err;
+      }
+      double ps;
+      const int err = if97::sat_pressure(old_temperature, ps);
+      if (err == 0) {
+        prim[0] = pfac * ps;
+        prim[1] = old_temperature;
+        region = new_region;
+        transition = true;
+      }
+      return err;
+    }
+    double ps;
+    const int err = if97::sat_pressure(prim[1], ps);
+    if (err) return err;
+    if ((old_region == 1 && prim[0] < ps) || (old_region == 2 && prim[0] > ps)) {
+      double root;
+      if (brent_satline(oldp[0], oldp[1], prim[0], prim[1], root) == 0) {
+        const double xi = root;
+        double ip;
+        if (xi <= 0.0) ip = oldp[0];
+        else if (xi >= 1.0) ip = prim[0];
+        else ip = (1.0 - xi) * oldp[0] + xi * prim[0];
+        prim[0] = ip;
+      } else prim[0] = ps;
+      prim[1] = (old_region == 1) ? small : 1.0 - small;
+      region = 4;
+      transition = true;
+    }
+    return 0;
+  }
+}
+
+template <int KIND>
+__device__ __forceinline__ int eos_check_primary(const double* prim, int region) {
+  const double p = prim[0];
+  if (p < 0.0 || p > 100.e6) return 1;
+  if constexpr (KIND == EOS_WE) {
+    if (region == 4) { if (prim[1] < -1.0 || prim[1] > 2.0) return 1; }
+    else if (prim[1] < 0.0 || prim[1] > 800.0) return 1;
+  }
+  return 0;
+}
+
+}  // namespace wai

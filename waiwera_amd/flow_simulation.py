@@ -1,0 +1,230 @@
+"""Host-side mirror of the reference's flow_simulation_type (src/flow_simulation.F90), i.e. the
+concrete ode_type (src/ode.F90:39-108) whose hot loops now run as HIP kernels.
+
+Method names, argument order and the `err` convention follow the reference's type-bound
+procedures (lhs, rhs, pre_eval, pre_iteration, pre_timestep, pre_retry_timestep,
+post_linesearch, setup_jacobian); the SNES/KSP slots the reference fills with PETSc objects
+(src/timestepper.F90:1552-1836) are the residual / jacobian / ksp_solve / newton_step methods.
+Vectors are numpy arrays (host) or torch tensors (device): both are passed by address.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from .lib import LIB, WaiError
+
+
+class FlowSimulation:
+    def __init__(self, mesh, eos="we", opts=None, device=0, temperature=20.0,
+                 relperm=("linear", [0.0, 1.0, 0.0, 1.0]), capillary=("zero", [])):
+        self.mesh = mesh
+        self.eos_name = eos
+        self._keep = dict(
+            face_cells=_lib._i32(mesh.face_cells), face_geom=_lib._f64(mesh.face_geom),
+            cell_geom=_lib._f64(mesh.cell_geom), rock=_lib._f64(mesh.rock),
+            sub_ptr=_lib._i32(mesh.sub_ptr) if mesh.sub_ptr is not None else None)
+        k = self._keep
+        md = _lib.MeshDesc()
+        md.n_owned, md.n_halo, md.n_bc, md.n_faces = mesh.n_owned, mesh.n_halo, mesh.n_bc, mesh.n_faces
+        md.face_cells = k["face_cells"].ctypes.data_as(_lib.pi)
+        md.face_geom = k["face_geom"].ctypes.data_as(_lib.pd)
+        md.cell_geom = k["cell_geom"].ctypes.data_as(_lib.pd)
+        md.rock = k["rock"].ctypes.data_as(_lib.pd)
+        if k["sub_ptr"] is not None:
+            md.n_sub = k["sub_ptr"].size - 1
+            md.sub_ptr = k["sub_ptr"].ctypes.data_as(_lib.pi)
+        self.eos_desc = _lib.eos_desc(eos, temperature, relperm, capillary)
+        self.opts = opts or _lib.default_opts()
+        h = C.c_void_p()
+        rc = LIB.wai_ctx_create(C.byref(md), C.byref(self.eos_desc), C.byref(self.opts), device, C.byref(h))
+        self.h = h
+        if rc != 0:
+            msg = LIB.wai_last_error(h).decode() if h else "?"
+            raise WaiError("wai_ctx_create failed (%d): %s" % (rc, msg))
+        self.num_primary_variables = LIB.wai_block_size(h)
+        self.fluid_dof = LIB.wai_num_fluid_dof(h)
+        self.n_owned, self.n_prim, self.n_local = mesh.n_owned, mesh.n_prim, mesh.n_local
+        self.time = 0.0
+        if mesh.n_bc:
+            bp, br = _lib._f64(mesh.bc_primary), _lib._i32(mesh.bc_region)
+            self._chk(LIB.wai_set_bc(h, bp.ctypes.data_as(_lib.pd), br.ctypes.data_as(_lib.pi)), "set_bc")
+        if mesh.n_src:
+            sc, sr = _lib._i32(mesh.src_cell), _lib._f64(mesh.src_rate)
+            se, sk = _lib._f64(mesh.src_enthalpy), _lib._i32(mesh.src_component)
+            self._chk(LIB.wai_set_sources(h, sc.size, sc.ctypes.data_as(_lib.pi), sr.ctypes.data_as(_lib.pd),
+                                          se.ctypes.data_as(_lib.pd), sk.ctypes.data_as(_lib.pi)), "set_sources")
+        if mesh.nbr_ranks is not None and len(mesh.nbr_ranks):
+            nr, sp = _lib._i32(mesh.nbr_ranks), _lib._i32(mesh.send_ptr)
+            si, rp = _lib._i32(mesh.send_idx), _lib._i32(mesh.recv_ptr)
+            self._chk(LIB.wai_set_halo(h, nr.size, nr.ctypes.data_as(_lib.pi), sp.ctypes.data_as(_lib.pi),
+                                       si.ctypes.data_as(_lib.pi), rp.ctypes.data_as(_lib.pi)), "set_halo")
+
+    # ------------------------------------------------------------------------------------------
+    def _chk(self, rc, what):
+        if rc < 0:
+            raise WaiError("%s failed (%d): %s" % (what, rc, LIB.wai_last_error(self.h).decode()))
+        return rc
+
+    def destroy(self):
+        if self.h:
+            LIB.wai_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def set_opts(self, **kw):
+        for k, v in kw.items():
+            if k == "ksp_type" and isinstance(v, str):
+                v = _lib.KSP[v]
+            setattr(self.opts, k, v)
+        self._chk(LIB.wai_set_opts(self.h, C.byref(self.opts)), "set_opts")
+
+    def comm_init(self, rank, nranks, unique_id):
+        self._chk(LIB.wai_comm_init(self.h, rank, nranks, unique_id), "comm_init")
+
+    def set_regions(self, region):
+        r = _lib._i32(region)
+        assert r.size == self.n_prim
+        self._chk(LIB.wai_set_regions(self.h, r.ctypes.data_as(_lib.pi)), "set_regions")
+
+    def regions(self):
+        r = np.zeros(self.n_prim, dtype=np.int32)
+        self._chk(LIB.wai_get_regions(self.h, r.ctypes.data_as(_lib.pi)), "get_regions")
+        return r
+
+    def fluid(self, which=0):
+        """Fluid vector in the reference's AoS layout (n_local, fluid_dof)."""
+        out = np.zeros((self.n_local, self.fluid_dof))
+        self._chk(LIB.wai_get_fluid(self.h, which, out.ctypes.data), "get_fluid")
+        return out
+
+    def scale(self, primary, region):
+        """eos%scale (src/eos.F90:186-197): unscaled primaries (n, np) -> scaled y."""
+        sc = np.ones((5, self.num_primary_variables))
+        ps, ts = self.eos_desc.pressure_scale, self.eos_desc.temperature_scale
+        for r in (1, 2, 4):
+            sc[r, 0] = ps
+            if self.num_primary_variables > 1:
+                sc[r, 1] = ts if r != 4 else 1.0
+        return np.asarray(primary, dtype=np.float64) / sc[np.asarray(region)]
+
+    # ---- ode_type hooks ------------------------------------------------------------------------
+    def pre_timestep(self):
+        return self._chk(LIB.wai_pre_timestep(self.h), "pre_timestep")
+
+    def pre_try_timestep(self, t):
+        return 0  # rock controls (flow_simulation.F90:2039-2089) are out of scope
+
+    def pre_retry_timestep(self):
+        return self._chk(LIB.wai_pre_retry_timestep(self.h), "pre_retry_timestep")
+
+    def post_timestep(self):
+        return 0
+
+    def pre_iteration(self, y=None):
+        return self._chk(LIB.wai_pre_iteration(self.h), "pre_iteration")
+
+    def pre_eval(self, t, y, perturbed_columns=None):
+        if perturbed_columns is not None and len(perturbed_columns):
+            raise WaiError("coloured perturbation is replaced by wai_jacobian")
+        return self._chk(LIB.wai_pre_eval(self.h, t, _lib.ptr(y)), "pre_eval")
+
+    pre_solve = pre_eval
+
+    def lhs(self, t, interval, y, lhs):
+        return self._chk(LIB.wai_lhs(self.h, t, _lib.ptr(y), _lib.ptr(lhs)), "lhs")
+
+    def rhs(self, t, interval, y, rhs):
+        return self._chk(LIB.wai_rhs(self.h, t, _lib.ptr(y), _lib.ptr(rhs)), "rhs")
+
+    def post_linesearch(self, y_old, search, y):
+        cs, cy = C.c_int(0), C.c_int(0)
+        err = self._chk(LIB.wai_post_linesearch(self.h, _lib.ptr(y_old), _lib.ptr(search), _lib.ptr(y),
+                                                C.byref(cs), C.byref(cy)), "post_linesearch")
+        return bool(cs.value), bool(cy.value), err
+
+    def setup_jacobian(self):
+        nnzb = LIB.wai_jacobian_nnzb(self.h)
+        rp = np.zeros(self.n_owned + 1, dtype=np.int32)
+        ci = np.zeros(nnzb, dtype=np.int32)
+        self._chk(LIB.wai_jacobian_pattern(self.h, rp.ctypes.data_as(_lib.pi), ci.ctypes.data_as(_lib.pi)),
+                  "jacobian_pattern")
+        return rp, ci
+
+    # ---- SNES / KSP slots ------------------------------------------------------------------------
+    def residual(self, t, dt, y, lhs_old, f):
+        return self._chk(LIB.wai_residual(self.h, t, dt, _lib.ptr(y), _lib.ptr(lhs_old), _lib.ptr(f)), "residual")
+
+    def jacobian(self, t, dt, y, lhs_old):
+        return self._chk(LIB.wai_jacobian(self.h, t, dt, _lib.ptr(y), _lib.ptr(lhs_old)), "jacobian")
+
+    def jacobian_values(self):
+        nnzb, bs = LIB.wai_jacobian_nnzb(self.h), self.num_primary_variables
+        v = np.zeros(nnzb * bs * bs)
+        self._chk(LIB.wai_jacobian_get_values(self.h, v.ctypes.data), "jacobian_get_values")
+        return v
+
+    def set_jacobian_values(self, val):
+        v = _lib._f64(val) if isinstance(val, np.ndarray) else val
+        self._chk(LIB.wai_jacobian_set_values(self.h, _lib.ptr(v)), "jacobian_set_values")
+
+    def spmv(self, x, y):
+        return self._chk(LIB.wai_spmv(self.h, _lib.ptr(x), _lib.ptr(y)), "spmv")
+
+    def pc_setup(self):
+        return self._chk(LIB.wai_pc_setup(self.h), "pc_setup")
+
+    def pc_apply(self, r, z):
+        return self._chk(LIB.wai_pc_apply(self.h, _lib.ptr(r), _lib.ptr(z)), "pc_apply")
+
+    def ksp_solve(self, b, x):
+        its, reason, rn = C.c_int(0), C.c_int(0), C.c_double(0)
+        self._chk(LIB.wai_ksp_solve(self.h, _lib.ptr(b), _lib.ptr(x), C.byref(its), C.byref(reason),
+                                    C.byref(rn)), "ksp_solve")
+        return its.value, reason.value, rn.value
+
+    def max_scaled(self, v, scale, tol):
+        val, idx = C.c_double(0), C.c_int(0)
+        self._chk(LIB.wai_max_scaled(self.h, _lib.ptr(v), _lib.ptr(scale), tol, C.byref(val), C.byref(idx)),
+                  "max_scaled")
+        return val.value, idx.value
+
+    def newton_step(self, t, dt, it, y, lhs_old, f):
+        k, r, m = C.c_int(0), C.c_int(0), C.c_double(0)
+        self._chk(LIB.wai_newton_step(self.h, t, dt, it, _lib.ptr(y), _lib.ptr(lhs_old), _lib.ptr(f),
+                                      C.byref(k), C.byref(r), C.byref(m)), "newton_step")
+        return r.value, k.value, m.value
+
+    def timestep(self, t, dt, y):
+        n, k, r = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._chk(LIB.wai_timestep(self.h, t, dt, _lib.ptr(y), C.byref(n), C.byref(k), C.byref(r)), "timestep")
+        return r.value, n.value, k.value
+
+    # ---- measurement ---------------------------------------------------------------------------
+    def timer_start(self):
+        self._chk(LIB.wai_timer_start(self.h), "timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float(0)
+        self._chk(LIB.wai_timer_stop(self.h, C.byref(ms)), "timer_stop")
+        return ms.value
+
+    def synchronize(self):
+        self._chk(LIB.wai_synchronize(self.h), "synchronize")
+
+    def profile(self, on=True):
+        LIB.wai_profile_enable(self.h, 1 if on else 0)
+        LIB.wai_profile_reset(self.h)
+
+    def profile_get(self):
+        out = {}
+        for k, name in enumerate(_lib.KCLASS):
+            ms, n = C.c_double(0), C.c_longlong(0)
+            LIB.wai_profile_get(self.h, k, C.byref(ms), C.byref(n))
+            out[name] = (ms.value, n.value)
+        return out

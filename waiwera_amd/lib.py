@@ -1,0 +1,161 @@
+"""ctypes binding of libwaiwera_hip.so (C ABI: include/waiwera_hip.h).
+
+There is no CPU fallback: if the HIP library has not been built, importing this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libwaiwera_hip.so")
+
+EOS_W, EOS_WE = 0, 1
+EOS_KIND = {"w": EOS_W, "we": EOS_WE}
+RP = {"fully_mobile": 0, "fully mobile": 0, "linear": 1, "pickens": 2, "corey": 3, "grant": 4,
+      "van_genuchten": 5, "van genuchten": 5}
+CP = {"zero": 0, "linear": 1, "van_genuchten": 2, "van genuchten": 2}
+KSP = {"bcgs": 0, "gmres": 1}
+KCLASS = ["eos", "residual", "jacobian", "spmv", "pc_apply", "pc_setup", "vector", "transitions"]
+
+d, i32 = C.c_double, C.c_int
+pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int)
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [("n_owned", i32), ("n_halo", i32), ("n_bc", i32), ("n_faces", i32),
+                ("face_cells", pi), ("face_geom", pd), ("cell_geom", pd), ("rock", pd),
+                ("n_sub", i32), ("sub_ptr", pi)]
+
+
+class EosDesc(C.Structure):
+    _fields_ = [("kind", i32), ("temperature", d), ("pressure_scale", d), ("temperature_scale", d),
+                ("rp_type", i32), ("rp_par", d * 6), ("cp_type", i32), ("cp_par", d * 6)]
+
+
+class SolverOpts(C.Structure):
+    _fields_ = [("ksp_type", i32), ("gmres_restart", i32), ("ksp_max_its", i32),
+                ("ksp_rtol", d), ("ksp_atol", d), ("max_newton_its", i32),
+                ("ftol_rel", d), ("ftol_abs", d), ("utol_rel", d), ("utol_abs", d),
+                ("fd_eps", d), ("fd_umin", d)]
+
+
+class WaiError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libwaiwera_hip.so is not built (python -m waiwera_amd.build); the Newton-step hot "
+            "path has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    sig = {
+        "wai_default_eos": (None, [C.POINTER(EosDesc), i32]),
+        "wai_default_opts": (None, [C.POINTER(SolverOpts)]),
+        "wai_ctx_create": (i32, [C.POINTER(MeshDesc), C.POINTER(EosDesc), C.POINTER(SolverOpts), i32,
+                                 C.POINTER(vp)]),
+        "wai_ctx_destroy": (i32, [vp]),
+        "wai_last_error": (C.c_char_p, [vp]),
+        "wai_set_opts": (i32, [vp, C.POINTER(SolverOpts)]),
+        "wai_set_bc": (i32, [vp, pd, pi]),
+        "wai_set_sources": (i32, [vp, i32, pi, pd, pd, pi]),
+        "wai_set_regions": (i32, [vp, pi]),
+        "wai_get_regions": (i32, [vp, pi]),
+        "wai_get_fluid": (i32, [vp, i32, vp]),
+        "wai_num_fluid_dof": (i32, [vp]),
+        "wai_block_size": (i32, [vp]),
+        "wai_set_halo": (i32, [vp, i32, pi, pi, pi, pi]),
+        "wai_comm_unique_id": (i32, [C.c_char_p]),
+        "wai_comm_init": (i32, [vp, i32, i32, C.c_char_p]),
+        "wai_halo_exchange": (i32, [vp, vp, i32]),
+        "wai_pre_timestep": (i32, [vp]),
+        "wai_pre_retry_timestep": (i32, [vp]),
+        "wai_pre_iteration": (i32, [vp]),
+        "wai_pre_eval": (i32, [vp, d, vp]),
+        "wai_lhs": (i32, [vp, d, vp, vp]),
+        "wai_rhs": (i32, [vp, d, vp, vp]),
+        "wai_post_linesearch": (i32, [vp, vp, vp, vp, pi, pi]),
+        "wai_residual": (i32, [vp, d, d, vp, vp, vp]),
+        "wai_jacobian": (i32, [vp, d, d, vp, vp]),
+        "wai_jacobian_nnzb": (i32, [vp]),
+        "wai_jacobian_pattern": (i32, [vp, pi, pi]),
+        "wai_jacobian_get_values": (i32, [vp, vp]),
+        "wai_jacobian_set_values": (i32, [vp, vp]),
+        "wai_spmv": (i32, [vp, vp, vp]),
+        "wai_pc_setup": (i32, [vp]),
+        "wai_pc_apply": (i32, [vp, vp, vp]),
+        "wai_ksp_solve": (i32, [vp, vp, vp, pi, pi, pd]),
+        "wai_max_scaled": (i32, [vp, vp, vp, d, pd, pi]),
+        "wai_newton_step": (i32, [vp, d, d, i32, vp, vp, vp, pi, pi, pd]),
+        "wai_timestep": (i32, [vp, d, d, vp, pi, pi, pi]),
+        "wai_timer_start": (i32, [vp]),
+        "wai_timer_stop": (i32, [vp, C.POINTER(C.c_float)]),
+        "wai_synchronize": (i32, [vp]),
+        "wai_profile_enable": (i32, [vp, i32]),
+        "wai_profile_get": (i32, [vp, i32, pd, C.POINTER(C.c_longlong)]),
+        "wai_profile_reset": (i32, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L, sorted(sig)
+
+
+LIB, EXPORTED = _load()
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def ptr(a):
+    """Raw address of a numpy array (host) or a torch tensor (device or host)."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):
+        assert a.is_contiguous()
+        return a.data_ptr()
+    return int(a)
+
+
+def default_opts(**kw):
+    o = SolverOpts()
+    LIB.wai_default_opts(C.byref(o))
+    for k, v in kw.items():
+        if k == "ksp_type" and isinstance(v, str):
+            v = KSP[v]
+        setattr(o, k, v)
+    return o
+
+
+def eos_desc(kind="we", temperature=20.0, relperm=("linear", [0.0, 1.0, 0.0, 1.0]),
+             capillary=("zero", []), pressure_scale=1.0e6, temperature_scale=1.0e2):
+    e = EosDesc()
+    LIB.wai_default_eos(C.byref(e), EOS_KIND[kind] if isinstance(kind, str) else kind)
+    e.temperature = temperature
+    e.pressure_scale = pressure_scale
+    e.temperature_scale = temperature_scale
+    e.rp_type = RP[relperm[0]]
+    for k, v in enumerate(relperm[1]):
+        e.rp_par[k] = v
+    e.cp_type = CP[capillary[0]]
+    for k, v in enumerate(capillary[1]):
+        e.cp_par[k] = v
+    return e
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    if LIB.wai_comm_unique_id(buf) != 0:
+        raise WaiError("cannot create an RCCL unique id")
+    return buf.raw

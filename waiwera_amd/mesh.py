@@ -1,0 +1,418 @@
+"""Synthetic structured finite-volume meshes in the flat-array form the hot path consumes.
+
+This replaces, for synthetic inputs, what the reference builds with PETSc DMPlex in
+src/mesh.F90 (out of scope as code): what matters to the Newton-step path
+are its *outputs* -- the DMPlex-local arrays
+
+* cell geometry  [centroid(3), volume]                       (src/cell.F90:54-61,85-96)
+* face geometry  [area, d1, d2, d12, n(3), g.n, centroid(3), dir]  (src/face.F90:67-76,119-135)
+* rock           [k1,k2,k3, wet, dry, porosity, density, cp]  (src/rock.F90:56-65,97-112)
+* face -> (cell1, cell2) support, normal pointing 1 -> 2     (src/mesh.F90:462-579)
+* Dirichlet boundary ghost cells appended after the interior cells, zero volume,
+  d = (d1, 0), d12 = d1, rock copied from the interior cell    (src/mesh.F90:583-664,1189-1202)
+* one-cell overlap between partitions                          (src/mesh.F90:40,160)
+
+Cell numbering is *brick-major*: the owned block of a rank is tiled by bricks (bx,by,bz) and
+cells are numbered brick after brick, x-fastest inside a brick.  A brick is one block-Jacobi /
+ILU(0) subdomain of the preconditioner (the reference's PCBJACOBI/PCASM with one block per MPI
+rank, src/timestepper.F90:1668-1669; here one block per brick so a subdomain fits a CU's LDS).
+
+Local cell order on a rank:  [owned | halo (other ranks' cells, grouped by neighbour) | bc].
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+GRAVITY = 9.8  # default 3-D gravity (0,0,-9.8): src/flow_simulation.F90:833-846
+
+
+def _splits(n, parts):
+    """Balanced contiguous split of range(n) into `parts` pieces: boundaries array."""
+    base, extra = divmod(n, parts)
+    sizes = np.full(parts, base, dtype=np.int64)
+    sizes[:extra] += 1
+    return np.concatenate([[0], np.cumsum(sizes)])
+
+
+class _Axis:
+    """Per-axis decomposition: ranks own whole bricks; bricks may be ragged at the end."""
+
+    def __init__(self, n, parts, brick):
+        self.n, self.parts = n, parts
+        nb = -(-n // brick)
+        edges = np.minimum(np.arange(nb + 1) * brick, n)  # brick boundaries
+        bsplit = _splits(nb, parts)  # bricks per rank
+        self.rank_lo = edges[bsplit[:-1]]
+        self.rank_hi = edges[bsplit[1:]]
+        c = np.arange(n)
+        self.brick_of = np.minimum(c // brick, nb - 1)
+        self.rank_of = np.searchsorted(bsplit, self.brick_of, side="right") - 1
+        self.brick_in_rank = self.brick_of - bsplit[self.rank_of]
+        self.off = c - edges[self.brick_of]
+        self.bsize = (edges[1:] - edges[:-1])[self.brick_of]
+        self.nbricks_rank = bsplit[1:] - bsplit[:-1]
+        self.bsplit = bsplit
+        self.edges = edges
+
+
+@dataclass
+class LocalMesh:
+    dims: tuple
+    spacing: tuple
+    part: tuple
+    rank: int
+    brick: tuple
+    n_owned: int = 0
+    n_halo: int = 0
+    n_bc: int = 0
+    n_faces: int = 0
+    face_cells: np.ndarray = None
+    face_geom: np.ndarray = None
+    cell_geom: np.ndarray = None
+    rock: np.ndarray = None
+    bc_primary: np.ndarray = None
+    bc_region: np.ndarray = None
+    sub_ptr: np.ndarray = None
+    owned_gid: np.ndarray = None      # natural global index (k*ny + j)*nx + i of each owned cell
+    owned_ijk: np.ndarray = None
+    nbr_ranks: np.ndarray = None      # halo description: neighbour ranks,
+    send_ptr: np.ndarray = None       # send_idx[send_ptr[q]:send_ptr[q+1]] = owned cells sent to q
+    send_idx: np.ndarray = None
+    recv_ptr: np.ndarray = None       # halo cells n_owned+recv_ptr[q] .. received from q
+    n_src: int = 0
+    src_cell: np.ndarray = None
+    src_rate: np.ndarray = None
+    src_enthalpy: np.ndarray = None
+    src_component: np.ndarray = None
+    n_global: int = 0
+    extras: dict = field(default_factory=dict)
+
+    @property
+    def n_prim(self):
+        return self.n_owned + self.n_halo
+
+    @property
+    def n_local(self):
+        return self.n_owned + self.n_halo + self.n_bc
+
+
+class StructuredGrid:
+    """Global description of an nx*ny*nz box split over px*py*pz ranks."""
+
+    def __init__(self, dims, spacing=(10.0, 10.0, 10.0), part=(1, 1, 1), brick=(8, 8, 8)):
+        self.dims = tuple(int(v) for v in dims)
+        self.spacing = tuple(float(v) for v in spacing)
+        self.part = tuple(int(v) for v in part)
+        self.brick = tuple(int(v) for v in brick)
+        self.ax = [_Axis(self.dims[a], self.part[a], self.brick[a]) for a in range(3)]
+        self.nranks = self.part[0] * self.part[1] * self.part[2]
+        self.n_global = self.dims[0] * self.dims[1] * self.dims[2]
+
+    def rank_coords(self, rank):
+        px, py, _ = self.part
+        return rank % px, (rank // px) % py, rank // (px * py)
+
+    def rank_id(self, rx, ry, rz):
+        px, py, _ = self.part
+        return (rz * py + ry) * px + rx
+
+    def owner(self, i, j, k):
+        return self.rank_id(self.ax[0].rank_of[i], self.ax[1].rank_of[j], self.ax[2].rank_of[k])
+
+    def _brick_starts(self, rc):
+        """Start offset of every brick of rank `rc` (brick-natural order, x fastest)."""
+        sizes = []
+        for a in range(3):
+            ax = self.ax[a]
+            b0, b1 = ax.bsplit[rc[a]], ax.bsplit[rc[a] + 1]
+            sizes.append((ax.edges[b0 + 1:b1 + 1] - ax.edges[b0:b1]))
+        vol = sizes[2][:, None, None] * sizes[1][None, :, None] * sizes[0][None, None, :]
+        starts = np.concatenate([[0], np.cumsum(vol.ravel())])
+        return starts, vol.shape
+
+    def local_id(self, rank, i, j, k):
+        """Local (owned) index on `rank` of global cells (i,j,k) that rank owns."""
+        rc = self.rank_coords(rank)
+        starts, shape = self._brick_starts(rc)
+        ax, ay, az = self.ax
+        b = (az.brick_in_rank[k] * shape[1] + ay.brick_in_rank[j]) * shape[2] + ax.brick_in_rank[i]
+        within = (az.off[k] * ay.bsize[j] + ay.off[j]) * ax.bsize[i] + ax.off[i]
+        return (starts[b] + within).astype(np.int64)
+
+    def natural_id(self, i, j, k):
+        nx, ny, _ = self.dims
+        return (np.asarray(k, dtype=np.int64) * ny + j) * nx + i
+
+    # -------------------------------------------------------------------------------------
+    def local_mesh(self, rank=0, rock_fn=None, top_bc=None, sources=None):
+        """Build the flat arrays of one rank.
+
+        rock_fn(gid) -> (n, 8) rock records for natural cell ids; top_bc = (primary, region)
+        puts Dirichlet ghost cells on the top (k = 0) faces; sources = list of dicts
+        {ijk, rate, enthalpy, component} in global coordinates.
+        """
+        nx, ny, nz = self.dims
+        dx, dy, dz = self.spacing
+        rc = self.rank_coords(rank)
+        lo = [self.ax[a].rank_lo[rc[a]] for a in range(3)]
+        hi = [self.ax[a].rank_hi[rc[a]] for a in range(3)]
+        m = LocalMesh(dims=self.dims, spacing=self.spacing, part=self.part, rank=rank,
+                      brick=self.brick, n_global=self.n_global)
+        # owned cells, in local order
+        I, J, K = np.meshgrid(np.arange(lo[0], hi[0]), np.arange(lo[1], hi[1]),
+                              np.arange(lo[2], hi[2]), indexing="ij")
+        I, J, K = I.ravel(), J.ravel(), K.ravel()
+        lid = self.local_id(rank, I, J, K)
+        n_owned = lid.size
+        order = np.empty(n_owned, dtype=np.int64)
+        order[lid] = np.arange(n_owned)
+        oi, oj, ok = I[order], J[order], K[order]
+        m.n_owned = n_owned
+        m.owned_ijk = np.stack([oi, oj, ok], axis=1).astype(np.int32)
+        m.owned_gid = self.natural_id(oi, oj, ok)
+        starts, _ = self._brick_starts(rc)
+        m.sub_ptr = starts.astype(np.int32)
+        # lookup: (i,j,k) in padded owned block -> local index (owned or halo), -1 elsewhere
+        shp = (hi[0] - lo[0] + 2, hi[1] - lo[1] + 2, hi[2] - lo[2] + 2)
+        lut = np.full(shp, -1, dtype=np.int64)
+        lut[oi - lo[0] + 1, oj - lo[1] + 1, ok - lo[2] + 1] = np.arange(n_owned)
+        # halo slabs, neighbour order -x,+x,-y,+y,-z,+z
+        nbr_ranks, send_idx, send_ptr, recv_ptr = [], [], [0], [0]
+        halo_ijk = []
+        for a in range(3):
+            for sgn in (-1, 1):
+                nrc = list(rc)
+                nrc[a] += sgn
+                if nrc[a] < 0 or nrc[a] >= self.part[a]:
+                    continue
+                nrank = self.rank_id(*nrc)
+                rng = [np.arange(lo[b], hi[b]) for b in range(3)]
+                mine = [r.copy() for r in rng]
+                theirs = [r.copy() for r in rng]
+                mine[a] = np.array([lo[a] if sgn < 0 else hi[a] - 1])
+                theirs[a] = np.array([lo[a] - 1 if sgn < 0 else hi[a]])
+                # slab cells in natural order (x fastest)
+                TK, TJ, TI = np.meshgrid(theirs[2], theirs[1], theirs[0], indexing="ij")
+                MK, MJ, MI = np.meshgrid(mine[2], mine[1], mine[0], indexing="ij")
+                ti, tj, tk = TI.ravel(), TJ.ravel(), TK.ravel()
+                nh = ti.size
+                base = n_owned + recv_ptr[-1]
+                lut[ti - lo[0] + 1, tj - lo[1] + 1, tk - lo[2] + 1] = base + np.arange(nh)
+                halo_ijk.append(np.stack([ti, tj, tk], axis=1))
+                nbr_ranks.append(nrank)
+                recv_ptr.append(recv_ptr[-1] + nh)
+                send_idx.append(lut[MI.ravel() - lo[0] + 1, MJ.ravel() - lo[1] + 1,
+                                    MK.ravel() - lo[2] + 1])
+                send_ptr.append(send_ptr[-1] + nh)
+        m.n_halo = recv_ptr[-1]
+        m.nbr_ranks = np.array(nbr_ranks, dtype=np.int32)
+        m.send_ptr = np.array(send_ptr, dtype=np.int32)
+        m.recv_ptr = np.array(recv_ptr, dtype=np.int32)
+        m.send_idx = (np.concatenate(send_idx) if send_idx else np.zeros(0)).astype(np.int32)
+        hijk = np.concatenate(halo_ijk) if halo_ijk else np.zeros((0, 3), dtype=np.int64)
+        n_prim = n_owned + m.n_halo
+        pi = np.concatenate([oi, hijk[:, 0]]).astype(np.int64)
+        pj = np.concatenate([oj, hijk[:, 1]]).astype(np.int64)
+        pk = np.concatenate([ok, hijk[:, 2]]).astype(np.int64)
+        m.extras["prim_ijk"] = np.stack([pi, pj, pk], axis=1)
+        m.extras["prim_gid"] = self.natural_id(pi, pj, pk)
+
+        # interior faces: every face with at least one owned cell; c1 = lower index along the
+        # axis, normal = +axis for x,y; for z the cell with smaller k is the *upper* one
+        # (k = 0 is the top layer), normal = (0,0,-1), g.n = +9.8
+        fc, fg = [], []
+        area = (dy * dz, dx * dz, dx * dy)
+        dist = (dx, dy, dz)
+        for a in range(3):
+            rng_lo = [lo[b] for b in range(3)]
+            rng_hi = [hi[b] for b in range(3)]
+            rng_lo[a] = max(lo[a] - 1, 0)
+            rng_hi[a] = min(hi[a], self.dims[a] - 1)  # first cell index of the pair
+            if rng_hi[a] <= rng_lo[a] and not (rng_hi[a] > rng_lo[a]):
+                pass
+            ck, cj, ci = np.meshgrid(np.arange(rng_lo[2], rng_hi[2]), np.arange(rng_lo[1], rng_hi[1]),
+                                     np.arange(rng_lo[0], rng_hi[0]), indexing="ij")
+            ci, cj, ck = ci.ravel(), cj.ravel(), ck.ravel()
+            if ci.size == 0:
+                continue
+            d = [0, 0, 0]
+            d[a] = 1
+            c1 = lut[ci - lo[0] + 1, cj - lo[1] + 1, ck - lo[2] + 1]
+            c2 = lut[ci + d[0] - lo[0] + 1, cj + d[1] - lo[1] + 1, ck + d[2] - lo[2] + 1]
+            keep = (c1 >= 0) & (c2 >= 0) & ((c1 < n_owned) | (c2 < n_owned))
+            c1, c2, ci, cj, ck = c1[keep], c2[keep], ci[keep], cj[keep], ck[keep]
+            g = np.zeros((c1.size, 12))
+            g[:, 0] = area[a]
+            g[:, 1] = 0.5 * dist[a]
+            g[:, 2] = 0.5 * dist[a]
+            g[:, 3] = dist[a]
+            nsign = 1.0 if a < 2 else -1.0
+            g[:, 4 + a] = nsign
+            g[:, 7] = GRAVITY if a == 2 else 0.0   # g = (0,0,-9.8), n = (0,0,-1)
+            cen = np.stack([(ci + 0.5) * dx, (cj + 0.5) * dy, -(ck + 0.5) * dz], axis=1)
+            cen[:, a] += 0.5 * dist[a] * nsign
+            g[:, 8:11] = cen
+            g[:, 11] = a + 1
+            fc.append(np.stack([c1, c2], axis=1))
+            fg.append(g)
+        # Dirichlet boundary ghost cells on the top faces of owned k = 0 cells
+        bc_cells = np.zeros(0, dtype=np.int64)
+        if top_bc is not None and lo[2] == 0:
+            top = np.nonzero(ok == 0)[0]
+            bc_cells = top
+            nb = top.size
+            ghost = n_prim + np.arange(nb)
+            g = np.zeros((nb, 12))
+            g[:, 0] = area[2]
+            g[:, 1] = 0.5 * dz
+            g[:, 2] = 0.0
+            g[:, 3] = 0.5 * dz
+            g[:, 6] = 1.0
+            g[:, 7] = -GRAVITY
+            g[:, 8] = (oi[top] + 0.5) * dx
+            g[:, 9] = (oj[top] + 0.5) * dy
+            g[:, 10] = 0.0
+            g[:, 11] = 3
+            fc.append(np.stack([top, ghost], axis=1))
+            fg.append(g)
+            prim, region = top_bc
+            m.bc_primary = np.tile(np.asarray(prim, dtype=np.float64), (nb, 1))
+            m.bc_region = np.full(nb, int(region), dtype=np.int32)
+        m.n_bc = bc_cells.size
+        m.face_cells = np.concatenate(fc).astype(np.int32)
+        m.face_geom = np.concatenate(fg)
+        m.n_faces = m.face_cells.shape[0]
+        # cell geometry
+        n_local = n_prim + m.n_bc
+        cg = np.zeros((n_local, 4))
+        cg[:n_prim, 0] = (pi + 0.5) * dx
+        cg[:n_prim, 1] = (pj + 0.5) * dy
+        cg[:n_prim, 2] = -(pk + 0.5) * dz
+        cg[:n_prim, 3] = dx * dy * dz
+        if m.n_bc:
+            cg[n_prim:, 0:3] = m.face_geom[-m.n_bc:, 8:11]
+            cg[n_prim:, 3] = 0.0
+        m.cell_geom = cg
+        # rock
+        rock = np.zeros((n_local, 8))
+        gids = m.extras["prim_gid"]
+        if rock_fn is None:
+            rock[:n_prim] = default_rock(gids.size)
+        else:
+            rock[:n_prim] = rock_fn(gids)
+        if m.n_bc:
+            rock[n_prim:] = rock[bc_cells]
+        m.rock = rock
+        # sources owned by this rank
+        if sources:
+            sc, sr, se, sk = [], [], [], []
+            for s in sources:
+                i, j, k = s["ijk"]
+                if self.owner(i, j, k) == rank:
+                    sc.append(int(self.local_id(rank, np.array([i]), np.array([j]), np.array([k]))[0]))
+                    sr.append(s["rate"])
+                    se.append(s.get("enthalpy", 0.0))
+                    sk.append(s.get("component", 0))
+            m.n_src = len(sc)
+            m.src_cell = np.array(sc, dtype=np.int32)
+            m.src_rate = np.array(sr, dtype=np.float64)
+            m.src_enthalpy = np.array(se, dtype=np.float64)
+            m.src_component = np.array(sk, dtype=np.int32)
+        return m
+
+
+def default_rock(n):
+    """Reference default rock (src/rock.F90:69-76): k 1e-13, cond 2.5, phi 0.1, 2200, 1000."""
+    r = np.zeros((n, 8))
+    r[:, 0:3] = 1.0e-13
+    r[:, 3:5] = 2.5
+    r[:, 5] = 0.1
+    r[:, 6] = 2200.0
+    r[:, 7] = 1000.0
+    return r
+
+
+def heterogeneous_rock(n_global, seed=20250418):
+    """SURVEY.md section 8d rock: k_x = k_y = 10^(-13 + 0.5 xi), k_z = 0.1 k_x, xi ~ N(0,1)."""
+    xi = np.random.default_rng(seed).standard_normal(n_global)
+
+    def fn(gid):
+        r = default_rock(gid.size)
+        kx = 10.0 ** (-13.0 + 0.5 * xi[gid])
+        r[:, 0] = kx
+        r[:, 1] = kx
+        r[:, 2] = 0.1 * kx
+        return r
+    return fn
+
+
+def liquid_density_estimate(t):
+    """Rough liquid-water density (kg/m3) for building hydrostatic initial columns only."""
+    return 1001.1 - 0.0867 * t - 0.0035 * t * t
+
+
+def benchmark_initial_state(grid, ijk, eos="we", lens=True):
+    """SURVEY.md section 8d initial state for natural cells ijk (n,3): returns primaries
+    (unscaled, (n, np)) and regions.  P hydrostatic from 1e5 Pa at z = 0, T = 20 + 0.08*depth;
+    optional two-phase lens (region 4, S_v 0.1..0.5) at depth 400..500 m, r < 200 m."""
+    nx, ny, nz = grid.dims
+    dx, dy, dz = grid.spacing
+    depth_c = (np.arange(nz) + 0.5) * dz
+    t_c = 20.0 + 0.08 * depth_c
+    rho_c = liquid_density_estimate(t_c)
+    p_c = np.empty(nz)
+    p = 1.0e5
+    for k in range(nz):
+        p_c[k] = p + 0.5 * dz * GRAVITY * rho_c[k]
+        p = p + dz * GRAVITY * rho_c[k]
+    i, j, k = ijk[:, 0], ijk[:, 1], ijk[:, 2]
+    P = p_c[k]
+    T = t_c[k]
+    region = np.ones(ijk.shape[0], dtype=np.int32)
+    if eos == "w":
+        return P[:, None].copy(), region
+    second = T.copy()
+    if lens:
+        x = (i + 0.5) * dx - 0.5 * nx * dx
+        y = (j + 0.5) * dy - 0.5 * ny * dy
+        r = np.sqrt(x * x + y * y)
+        depth = depth_c[k]
+        inl = (depth >= 400.0) & (depth <= 500.0) & (r < 200.0)
+        region[inl] = 4
+        second[inl] = 0.1 + 0.4 * r[inl] / 200.0
+    return np.stack([P, second], axis=1), region
+
+
+def benchmark_sources(grid):
+    """4 injectors (10 kg/s, 1.0e6 J/kg) and 4 producers (-5 kg/s) at fixed box fractions."""
+    nx, ny, nz = grid.dims
+    out = []
+    fr = [(0.25, 0.25), (0.75, 0.25), (0.25, 0.75), (0.75, 0.75)]
+    for fx, fy in fr:
+        out.append({"ijk": (int(fx * nx), int(fy * ny), int(0.7 * nz)), "rate": 10.0,
+                    "enthalpy": 1.0e6, "component": 1})
+    fr2 = [(0.5, 0.25), (0.25, 0.5), (0.75, 0.5), (0.5, 0.75)]
+    for fx, fy in fr2:
+        out.append({"ijk": (int(fx * nx), int(fy * ny), int(0.4 * nz)), "rate": -5.0,
+                    "enthalpy": 0.0, "component": 0})
+    return out
+
+
+def partition_shape(n):
+    """Rank grid for n GPUs: 8 -> 2x2x2, 4 -> 2x2x1, 2 -> 2x1x1."""
+    shapes = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2), 16: (4, 2, 2)}
+    if n in shapes:
+        return shapes[n]
+    p = [1, 1, 1]
+    a = 0
+    while n > 1:
+        for q in (2, 3, 5, 7):
+            if n % q == 0:
+                p[a % 3] *= q
+                n //= q
+                a += 1
+                break
+        else:
+            p[a % 3] *= n
+            n = 1
+    return tuple(p)
