@@ -164,6 +164,10 @@ int wai_timestep(wai_ctx *ctx, double t, double dt, double *y, int *newton_its, 
 int wai_timer_start(wai_ctx *ctx);             /* hipEvent on the library's stream */
 int wai_timer_stop(wai_ctx *ctx, float *ms);
 int wai_synchronize(wai_ctx *ctx);
+/* HIP-event timed repetitions of one kernel on the library's stream (needs an assembled
+ * Jacobian): which 0 block SpMV, 1 ILU(0) apply, 2 fused SpMV + ILU(0) apply + dot,
+ * 3/4 timing probes of 1/2 without the substitution sweeps */
+int wai_bench_kernel(wai_ctx *ctx, int which, int reps, float *ms_per_launch);
 /* accumulated HIP-event time (ms) and launch counts per kernel class since the last reset;
  * classes: 0 eos, 1 residual, 2 jacobian, 3 spmv, 4 pc_apply, 5 pc_setup, 6 vector, 7 transitions */
 int wai_profile_enable(wai_ctx *ctx, int on);

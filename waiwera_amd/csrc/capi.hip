@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include "comm.hpp"
@@ -26,7 +27,6 @@ namespace {
 
 enum { S_RHO = 0, S_RHOOLD = 1, S_ALPHA = 2, S_OMEGA = 3, S_BETA = 4, S_D1 = 5, S_D2 = 6,
        S_DP2 = 7, S_W2 = 8, S_RHONEW = 9, S_BREAK = 15, S_H = 16 };
-constexpr int NB_MAX = 1024;
 constexpr int NSLOTS = 64;
 constexpr int NSCAL = 128;
 
@@ -190,22 +190,19 @@ int do_pc_setup(wai_ctx* c) {
   return fl[0] ? 1 : 0;
 }
 
-// z = B^-1 A x  (x has halo room)
-int pc_amul(wai_ctx* c, double* x, double* z) {
+// z = B^-1 A x  (x has halo room); optional fused dot products of the result
+int pc_amul(wai_ctx* c, double* x, double* z, int dot_mode = 0, const double* aux = nullptr) {
   if (halo_exchange(c, x, c->np)) return -1;
-  {
-    Prof p(c, KC_SPMV);
-    launch_spmv(c, x, c->ks.tmp);
-  }
   Prof p(c, KC_PC_APPLY);
-  launch_ilu_apply(c, c->ks.tmp, z);
-  return 0;
+  return launch_pc(c, true, x, z, dot_mode, aux);
 }
 
-// KSPBCGS [PETSc], left preconditioning, preconditioned residual norm, zero initial guess
+// KSPBCGS [PETSc], left preconditioning, preconditioned residual norm, zero initial guess.
+// Launches per iteration: P update, fused A*P + ILU solve + (V,RP), alpha, S update, fused
+// A*S + ILU solve + (S,T),(T,T), omega, fused X/R update + (R,R),(R,RP), rho/beta.
 int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
   Krylov& k = c->ks;
-  const int n = k.n;
+  const int n = k.n, nsub = c->ilu.nsub;
   const double rtol = c->opts.ksp_rtol, atol = c->opts.ksp_atol;
   const int maxits = c->opts.ksp_max_its;
   vec_zero(c, x, n);
@@ -213,13 +210,12 @@ int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, doub
   vec_zero(c, k.V, n);
   {
     Prof p(c, KC_PC_APPLY);
-    launch_ilu_apply(c, b, k.R);
+    launch_pc(c, false, b, k.R, 3, nullptr);  // R = B^-1 b, partial (R,R)
   }
   {
     Prof p(c, KC_VECTOR);
-    vec_dot(c, k.R, k.R, n, S_DP2);
-    if (allreduce_scal(c, S_DP2, 1)) return -1;
-    bcgs_scalars(c, 0);
+    vec_finalize(c, nsub, S_DP2, 1, (c->comm && c->comm->nranks > 1) ? -1 : 0);
+    if (c->comm && c->comm->nranks > 1) { if (allreduce_scal(c, S_DP2, 1)) return -1; bcgs_scalars(c, 0); }
     vec_copy(c, k.RP, k.R, n);
   }
   if (read_scal(c, S_DP2, 1)) return -1;
@@ -229,34 +225,32 @@ int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, doub
   *reason = 0;
   if (std::isnan(dp)) *reason = -9;
   else if (dp <= ttol) *reason = (dp <= atol) ? 3 : 2;
-  // X aliases the caller's x during the iteration
+  const bool multi = c->comm && c->comm->nranks > 1;
   double* Xsave = k.X;
-  k.X = x;
-  for (int i = 0; i < maxits && !*reason; i++) {
+  k.X = x;  // X aliases the caller's x during the iteration
+  int rc = 0;
+  for (int i = 0; i < maxits && !*reason && !rc; i++) {
+    { Prof p(c, KC_VECTOR); bcgs_update_p(c); }
+    if ((rc = pc_amul(c, k.P, k.V, 1, k.RP))) break;
     {
       Prof p(c, KC_VECTOR);
-      bcgs_scalars(c, 1);
-      bcgs_update_p(c);
-    }
-    if (pc_amul(c, k.P, k.V)) { k.X = Xsave; return -1; }
-    {
-      Prof p(c, KC_VECTOR);
-      vec_dot(c, k.V, k.RP, n, S_D1);
-      if (allreduce_scal(c, S_D1, 1)) { k.X = Xsave; return -1; }
-      bcgs_scalars(c, 2);
+      vec_finalize(c, nsub, S_D1, 1, multi ? -1 : 2);
+      if (multi) { if ((rc = allreduce_scal(c, S_D1, 1))) break; bcgs_scalars(c, 2); }
       bcgs_update_s(c);
     }
-    if (pc_amul(c, k.S, k.T)) { k.X = Xsave; return -1; }
+    if ((rc = pc_amul(c, k.S, k.T, 2, nullptr))) break;
     {
       Prof p(c, KC_VECTOR);
-      vec_dot2(c, k.S, k.T, k.T, k.T, n, S_D1);
-      if (allreduce_scal(c, S_D1, 2)) { k.X = Xsave; return -1; }
-      bcgs_scalars(c, 3);
+      vec_finalize(c, nsub, S_D1, 2, multi ? -1 : 3);
+      if (multi) { if ((rc = allreduce_scal(c, S_D1, 2))) break; bcgs_scalars(c, 3); }
       bcgs_update_xr(c);
-      if (allreduce_scal(c, S_DP2, 1) || allreduce_scal(c, S_RHONEW, 1)) { k.X = Xsave; return -1; }
-      bcgs_scalars(c, 4);
+      vec_finalize(c, k.nblocks, S_DP2, 2, multi ? -1 : 4);
+      if (multi) {
+        if ((rc = allreduce_scal(c, S_DP2, 1)) || (rc = allreduce_scal(c, S_RHONEW, 1))) break;
+        bcgs_scalars(c, 4);
+      }
     }
-    if (read_scal(c, 0, 16)) { k.X = Xsave; return -1; }
+    if ((rc = read_scal(c, 0, 16))) break;
     dp = std::sqrt(k.h_scal[S_DP2]);
     *its = i + 1;
     if (k.h_scal[S_BREAK] != 0.0) *reason = -5;
@@ -265,6 +259,7 @@ int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, doub
     else if (dp >= 1.e4 * dp0) *reason = -4;
   }
   k.X = Xsave;
+  if (rc) return -1;
   if (!*reason) *reason = -3;
   *rnorm = dp;
   return 0;
@@ -286,14 +281,14 @@ int ksp_gmres(wai_ctx* c, const double* b, double* x, int* its, int* reason, dou
     double* v0 = k.basis;
     if (it == 0) {
       Prof p(c, KC_PC_APPLY);
-      launch_ilu_apply(c, b, v0);
+      launch_pc(c, false, b, v0, 0, nullptr);
     } else {
       vec_copy(c, k.P, x, n);
       if (halo_exchange(c, k.P, c->np)) return -1;
       { Prof p(c, KC_SPMV); launch_spmv(c, k.P, k.tmp); }
       vec_waxpy(c, k.tmp, -1.0, k.tmp, b, n);
       Prof p(c, KC_PC_APPLY);
-      launch_ilu_apply(c, k.tmp, v0);
+      launch_pc(c, false, k.tmp, v0, 0, nullptr);
     }
     {
       Prof p(c, KC_VECTOR);
@@ -469,10 +464,9 @@ void free_all(wai_ctx* c) {
   F(m.rock); F(m.vol); F(m.fgeom); F(m.fdir); F(m.adj_face); F(m.adj_other); F(m.adj_blk);
   F(m.diag_blk); F(m.cell_src);
   F(c->src.cell); F(c->src.comp); F(c->src.next); F(c->src.rate); F(c->src.enth);
-  F(c->J.rowptr); F(c->J.colidx); F(c->J.val);
+  F(c->J.rowptr); F(c->J.col); F(c->J.val);
   IluSchedule& s = c->ilu;
-  F(s.sub_ptr); F(s.fwd_rows); F(s.fwd_lev_ptr); F(s.fwd_sub_lev); F(s.bwd_rows); F(s.bwd_lev_ptr);
-  F(s.bwd_sub_lev); F(s.lstart); F(s.uend); F(s.fval); F(s.dinv);
+  F(s.sub_ptr); F(s.sub_nlev); F(s.row_info); F(s.fval); F(s.dinv);
   Krylov& k = c->ks;
   F(k.R); F(k.RP); F(k.P); F(k.V); F(k.S); F(k.T); F(k.tmp); F(k.X); F(k.basis); F(k.partials); F(k.scal);
   if (k.h_scal) (void)hipHostFree(k.h_scal);
@@ -594,10 +588,12 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
     for (int s = 0; s < deg[i]; s++)
       if (adj_other[(size_t)s * N + i] < m.n_prim) cnt++;
     J.h_rowptr[i + 1] = J.h_rowptr[i] + cnt;
+    J.W = std::max(J.W, cnt);
   }
+  if (J.W > 8) { c->err = "more than 8 blocks in a matrix row not supported"; return -2; }
   J.nnzb = J.h_rowptr[N];
   J.h_colidx.resize(J.nnzb);
-  std::vector<int> diag(N);
+  std::vector<int> diag(N), ell_col((size_t)J.W * N);
   for (int i = 0; i < N; i++) {
     int* row = J.h_colidx.data() + J.h_rowptr[i];
     int cnt = 0;
@@ -608,35 +604,29 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
     }
     std::sort(row, row + cnt);
     for (int q = 0; q < cnt; q++) {
-      if (row[q] == i) diag[i] = J.h_rowptr[i] + q;
+      if (row[q] == i) diag[i] = q;
       if (q > 0 && row[q] == row[q - 1]) { c->err = "duplicate connection between two cells"; return -2; }
+      ell_col[(size_t)q * N + i] = row[q];
     }
+    for (int q = cnt; q < J.W; q++) ell_col[(size_t)q * N + i] = i;  // padding: zero block on the diagonal column
     for (int s = 0; s < deg[i]; s++) {
       const int o = adj_other[(size_t)s * N + i];
       if (o >= m.n_prim) continue;
       const int* p = std::lower_bound(row, row + cnt, o);
-      adj_blk[(size_t)s * N + i] = J.h_rowptr[i] + (int)(p - row);
+      adj_blk[(size_t)s * N + i] = (int)(p - row);
     }
-  }
-  {
-    const int rpc = 256 / np;
-    int mx = 1;
-    for (int r0 = 0; r0 < N; r0 += rpc) {
-      const int r1 = std::min(N, r0 + rpc);
-      mx = std::max(mx, J.h_rowptr[r1] - J.h_rowptr[r0]);
-    }
-    J.max_chunk_blocks = mx;
   }
   if (dev_upload(c, &m.adj_face, adj_face) || dev_upload(c, &m.adj_other, adj_other) ||
       dev_upload(c, &m.adj_blk, adj_blk) || dev_upload(c, &m.diag_blk, diag) ||
-      dev_upload(c, &J.rowptr, J.h_rowptr) || dev_upload(c, &J.colidx, J.h_colidx) ||
-      dev_alloc(c, &J.val, (size_t)J.nnzb * np * np))
+      dev_upload(c, &J.rowptr, J.h_rowptr) || dev_upload(c, &J.col, ell_col) ||
+      dev_alloc(c, &J.val, (size_t)J.W * np * np * N))
     return -1;
+  HIPCHK(c, hipMemset(J.val, 0, sizeof(double) * (size_t)J.W * np * np * N));
   {
     std::vector<int> cs(N, -1);
     if (dev_upload(c, &m.cell_src, cs)) return -1;
   }
-  // block-Jacobi subdomains + level schedules of the ILU(0) factors
+  // block-Jacobi subdomains + dependency levels of the ILU(0) factors (symbolic phase, once)
   {
     IluSchedule& s = c->ilu;
     std::vector<int> sub;
@@ -644,65 +634,63 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
     else sub = {0, N};
     s.nsub = (int)sub.size() - 1;
     if (sub.front() != 0 || sub.back() != N) { c->err = "sub_ptr must cover [0, n_owned]"; return -2; }
-    std::vector<int> lstart(N), uend(N), levf(N), levb(N);
-    std::vector<int> frows(N), brows(N), flev, blev, fsub(s.nsub + 1), bsub(s.nsub + 1);
-    flev.push_back(0); blev.push_back(0);
-    s.max_rows = 0;
+    std::vector<int> info(N), levf(N), levb(N), nlev(s.nsub, 0);
+    s.max_rows = 0; s.max_lev = 0;
+    bool offdiag_fill = false;
     for (int sd = 0; sd < s.nsub; sd++) {
       const int lo = sub[sd], hi = sub[sd + 1];
       if (hi < lo) { c->err = "sub_ptr not monotone"; return -2; }
       s.max_rows = std::max(s.max_rows, hi - lo);
       int nlf = 0, nlb = 0;
+      std::vector<int> lfirst(hi - lo), ulast(hi - lo);
       for (int i = lo; i < hi; i++) {
-        const int a = J.h_rowptr[i], b = J.h_rowptr[i + 1];
-        int ls = a;
-        while (ls < b && J.h_colidx[ls] < lo) ls++;
-        int ue = b;
-        while (ue > a && J.h_colidx[ue - 1] >= hi) ue--;
-        lstart[i] = ls; uend[i] = ue;
+        const int* row = J.h_colidx.data() + J.h_rowptr[i];
+        const int cnt = J.h_rowptr[i + 1] - J.h_rowptr[i];
+        int ls = 0;
+        while (ls < cnt && row[ls] < lo) ls++;
+        int ue = cnt;
+        while (ue > 0 && row[ue - 1] >= hi) ue--;
+        lfirst[i - lo] = ls; ulast[i - lo] = ue;
         int lv = 0;
-        for (int q = ls; q < diag[i]; q++) lv = std::max(lv, levf[J.h_colidx[q]] + 1);
+        for (int q = ls; q < diag[i]; q++) lv = std::max(lv, levf[row[q]] + 1);
         levf[i] = lv;
         nlf = std::max(nlf, lv + 1);
       }
       for (int i = hi - 1; i >= lo; i--) {
+        const int* row = J.h_colidx.data() + J.h_rowptr[i];
         int lv = 0;
-        for (int q = diag[i] + 1; q < uend[i]; q++) lv = std::max(lv, levb[J.h_colidx[q]] + 1);
+        for (int q = diag[i] + 1; q < ulast[i - lo]; q++) lv = std::max(lv, levb[row[q]] + 1);
         levb[i] = lv;
         nlb = std::max(nlb, lv + 1);
       }
-      // counting sort rows by level
-      auto emit = [&](const std::vector<int>& lev, int nl, std::vector<int>& rows, std::vector<int>& lp,
-                      bool descending) {
-        std::vector<int> cnt(nl + 1, 0);
-        for (int i = lo; i < hi; i++) cnt[lev[i] + 1]++;
-        for (int l = 0; l < nl; l++) cnt[l + 1] += cnt[l];
-        std::vector<int> pos(cnt.begin(), cnt.end() - 1);
-        if (!descending) for (int i = lo; i < hi; i++) rows[lo + pos[lev[i]]++] = i;
-        else for (int i = hi - 1; i >= lo; i--) rows[lo + pos[lev[i]]++] = i;
-        for (int l = 0; l < nl; l++) lp.push_back(lo + cnt[l + 1]);
-      };
-      fsub[sd] = (int)flev.size() - 1;
-      bsub[sd] = (int)blev.size() - 1;
-      if (hi > lo) {
-        emit(levf, nlf, frows, flev, false);
-        emit(levb, nlb, brows, blev, true);
+      // does the IKJ elimination ever update an off-diagonal block of a row in this subdomain?
+      for (int i = lo; i < hi && !offdiag_fill; i++) {
+        const int* row = J.h_colidx.data() + J.h_rowptr[i];
+        for (int q = lfirst[i - lo]; q < diag[i] && !offdiag_fill; q++) {
+          const int k = row[q];
+          const int* rk = J.h_colidx.data() + J.h_rowptr[k];
+          for (int r2 = diag[k] + 1; r2 < ulast[k - lo]; r2++) {
+            const int j = rk[r2];
+            if (j == i) continue;
+            if (std::binary_search(row + q + 1, row + ulast[i - lo], j)) { offdiag_fill = true; break; }
+          }
+        }
       }
+      if (nlf > 1023 || nlb > 1023) { c->err = "more than 1023 dependency levels in a subdomain"; return -2; }
+      for (int i = lo; i < hi; i++)
+        info[i] = lfirst[i - lo] | (diag[i] << 4) | (ulast[i - lo] << 8) | (levf[i] << 12) | (levb[i] << 22);
+      nlev[sd] = nlf | (nlb << 16);
+      s.max_lev = std::max(s.max_lev, std::max(nlf, nlb));
     }
-    fsub[s.nsub] = (int)flev.size() - 1;
-    bsub[s.nsub] = (int)blev.size() - 1;
-    if ((size_t)s.max_rows * np * sizeof(double) > 64 * 1024) {
-      c->err = "preconditioner subdomain too large for the LDS-resident ILU(0) apply "
-               "(max 64 KiB of solution vector per subdomain); use smaller bricks";
+    if (s.max_rows > 1024) {
+      c->err = "preconditioner subdomain larger than 1024 rows (one thread per row, one workgroup "
+               "per subdomain); use smaller bricks";
       return -2;
     }
-    if (dev_upload(c, &s.sub_ptr, sub) || dev_upload(c, &s.fwd_rows, frows) ||
-        dev_upload(c, &s.fwd_lev_ptr, flev) || dev_upload(c, &s.fwd_sub_lev, fsub) ||
-        dev_upload(c, &s.bwd_rows, brows) || dev_upload(c, &s.bwd_lev_ptr, blev) ||
-        dev_upload(c, &s.bwd_sub_lev, bsub) || dev_upload(c, &s.lstart, lstart) ||
-        dev_upload(c, &s.uend, uend) || dev_alloc(c, &s.fval, (size_t)J.nnzb * np * np) ||
-        dev_alloc(c, &s.dinv, (size_t)N * np * np))
+    if (dev_upload(c, &s.sub_ptr, sub) || dev_upload(c, &s.sub_nlev, nlev) || dev_upload(c, &s.row_info, info) ||
+        dev_alloc(c, &s.fval, (size_t)J.W * np * np * N) || dev_alloc(c, &s.dinv, (size_t)np * np * N))
       return -1;
+    s.diag_only = !offdiag_fill && !getenv("WAI_ILU_GENERAL");
   }
   // state and work vectors
   const size_t nl = (size_t)np * m.n_prim, n = (size_t)np * N;
@@ -734,7 +722,9 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
     if (dev_alloc(c, &k.basis, (size_t)(k.basis_m + 1) * nl)) return -1;
     HIPCHK(c, hipMemset(k.basis, 0, (size_t)(k.basis_m + 1) * nl * sizeof(double)));
   }
-  if (dev_alloc(c, &k.partials, (size_t)NSLOTS * NB_MAX) || dev_alloc(c, &k.scal, (size_t)NSCAL)) return -1;
+  k.nb_max = std::max(1024, c->ilu.nsub);
+  if (dev_alloc(c, &k.partials, (size_t)NSLOTS * k.nb_max) || dev_alloc(c, &k.scal, (size_t)NSCAL)) return -1;
+  HIPCHK(c, hipMemset(k.partials, 0, (size_t)NSLOTS * k.nb_max * sizeof(double)));
   HIPCHK(c, hipMemset(k.scal, 0, NSCAL * sizeof(double)));
   HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&k.h_scal), NSCAL * sizeof(double)));
   if (dev_alloc(c, &c->d_flags, (size_t)4) || dev_alloc(c, &c->d_red, (size_t)4096)) return -1;
@@ -990,16 +980,27 @@ int wai_jacobian_pattern(wai_ctx* c, int* rowptr, int* colidx) {
 int wai_jacobian_get_values(wai_ctx* c, double* val) {
   if (!c || !val) return -2;
   const size_t n = (size_t)c->J.nnzb * c->np * c->np;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(val, c->J.val, n * sizeof(double), is_device_ptr(val) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+  double* tmp = nullptr;
+  if (dev_alloc(c, &tmp, n)) return -1;
+  launch_ell_to_bcsr(c, c->J.val, tmp);
+  hipError_t e = hipMemcpyAsync(val, tmp, n * sizeof(double),
+                                is_device_ptr(val) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(tmp);
+  HIPCHK(c, e);
   return 0;
 }
 
 int wai_jacobian_set_values(wai_ctx* c, const double* val) {
   if (!c || !val) return -2;
   const size_t n = (size_t)c->J.nnzb * c->np * c->np;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(c->J.val, val, n * sizeof(double), is_device_ptr(val) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  double* tmp = nullptr;
+  if (dev_alloc(c, &tmp, n)) return -1;
+  hipError_t e = hipMemcpyAsync(tmp, val, n * sizeof(double),
+                                is_device_ptr(val) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) { launch_bcsr_to_ell(c, tmp, c->J.val); e = hipStreamSynchronize(c->stream); }
+  (void)hipFree(tmp);
+  HIPCHK(c, e);
   c->ilu.factored = false;
   return 0;
 }
@@ -1027,7 +1028,7 @@ int wai_pc_apply(wai_ctx* c, const double* r, double* z) {
   if (ri.in(r, c->ks.n, 0) || zo.out_only(z, c->ks.n, 1)) return -1;
   {
     Prof p(c, KC_PC_APPLY);
-    launch_ilu_apply(c, ri.dev, zo.dev);
+    launch_pc(c, false, ri.dev, zo.dev, 0, nullptr);
   }
   return zo.back();
 }
@@ -1114,6 +1115,33 @@ int wai_timestep(wai_ctx* c, double t, double dt, double* y, int* newton_its, in
     if (restore_step(c)) return -1;
   }
   return from_work(c, c->w_y, y);
+}
+
+// Micro-benchmark of one kernel on the library's stream, HIP-event timed: which 0 = block SpMV,
+// 1 = ILU(0) apply z = B^-1 r, 2 = fused z = B^-1 (A x) with the (z, aux) reduction,
+// 3/4 = probes of 1/2 with the substitution sweeps skipped (load/compute phase split).
+int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
+  if (!c || !ms_per_launch || reps <= 0) return -2;
+  if (which > 0 && !c->ilu.factored) { const int e = do_pc_setup(c); if (e) return e < 0 ? -1 : e; }
+  Krylov& k = c->ks;
+  auto run = [&]() {
+    switch (which) {
+      case 0: launch_spmv(c, k.P, k.tmp); break;
+      case 1: case 3: launch_pc(c, false, k.P, k.V, 0, nullptr); break;
+      default: launch_pc(c, true, k.P, k.V, 1, k.RP); break;
+    }
+  };
+  c->dbg = (which >= 3) ? 1 : 0;
+  for (int i = 0; i < 5; i++) run();
+  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  for (int i = 0; i < reps; i++) run();
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  HIPCHK(c, hipEventSynchronize(c->ev1));
+  c->dbg = 0;
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *ms_per_launch = ms / reps;
+  return 0;
 }
 
 int wai_timer_start(wai_ctx* c) { if (!c) return -2; HIPCHK(c, hipEventRecord(c->ev0, c->stream)); return 0; }

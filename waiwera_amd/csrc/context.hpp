@@ -23,8 +23,8 @@ struct DeviceMesh {
   // ELL cell->face adjacency of owned cells, slot-major: [slot * n_owned + cell]
   int* adj_face = nullptr;   // face*2 + side (side 0: cell is cell 1 of the face), -1 = empty
   int* adj_other = nullptr;  // local index of the cell across the face
-  int* adj_blk = nullptr;    // BCSR block index of (cell, other), -1 when other is a bc cell
-  int* diag_blk = nullptr;   // BCSR block index of (cell, cell)
+  int* adj_blk = nullptr;    // matrix slot of (cell, other) in the cell's block row, -1 for a bc cell
+  int* diag_blk = nullptr;   // matrix slot of (cell, cell)
   int* cell_src = nullptr;   // first source in the cell or -1
 };
 
@@ -34,25 +34,32 @@ struct Sources {
   double* rate = nullptr; double* enth = nullptr;
 };
 
+// Block matrix in HBM: block-ELL, slot-major struct-of-arrays ("SELL" with one slice):
+//   col[s*n + i]            column of slot s of block row i (padding slots: col = i, values 0)
+//   val[(s*bb + e)*n + i]   entry e (row-major inside the bs x bs block) of that block
+// Slots of a row are in ascending column order, i.e. slot s of row i is BCSR block
+// rowptr[i] + s: the BCSR arrays (rowptr / colidx on the host) remain the exchange format of
+// the C ABI, the device layout is what lets one-thread-per-row kernels read and write fully
+// coalesced (64 consecutive doubles per wave instruction).
 struct Bcsr {
-  int n = 0, ncols = 0, nnzb = 0, bs = 0;
-  int* rowptr = nullptr; int* colidx = nullptr;
+  int n = 0, ncols = 0, nnzb = 0, bs = 0, W = 0;
+  int* col = nullptr;
   double* val = nullptr;
-  int max_chunk_blocks = 0;  // most blocks in any SpMV chunk of TPB/bs rows (sizes the LDS)
+  int* rowptr = nullptr;  // device copy of the BCSR row pointer (layout conversion kernels)
   std::vector<int> h_rowptr, h_colidx;
 };
 
+// Block-Jacobi ILU(0): one workgroup per subdomain, one thread per block row.
 struct IluSchedule {
-  int nsub = 0, max_rows = 0;
-  int* sub_ptr = nullptr;      // nsub+1 row ranges
-  int* fwd_rows = nullptr;     // rows of each subdomain sorted by forward level
-  int* fwd_lev_ptr = nullptr;  // per subdomain: offsets into fwd_rows (CSR over levels)
-  int* fwd_sub_lev = nullptr;  // nsub+1: offsets into fwd_lev_ptr
-  int* bwd_rows = nullptr; int* bwd_lev_ptr = nullptr; int* bwd_sub_lev = nullptr;
-  int* lstart = nullptr;       // per row: first block with column inside the subdomain
-  int* uend = nullptr;         // per row: one past the last block inside the subdomain
-  double* fval = nullptr;      // factor, same pattern as the matrix
-  double* dinv = nullptr;      // inverted pivot blocks
+  int nsub = 0, max_rows = 0, max_lev = 0;
+  int* sub_ptr = nullptr;   // nsub+1 row ranges
+  int* sub_nlev = nullptr;  // per subdomain: forward levels | backward levels << 16
+  int* row_info = nullptr;  // per row: lfirst | dslot<<4 | ulast<<8 | lev_f<<12 | lev_b<<22
+  double* fval = nullptr;   // factor in the matrix' block-ELL layout; the diagonal slot holds
+                            // the inverted pivot block
+  double* dinv = nullptr;   // inverted pivot blocks, SoA [bb][n]
+  bool diag_only = false;   // ILU(0) touches no off-diagonal block in any subdomain (== DILU)
+  bool force_general = false;
   bool factored = false;
 };
 
@@ -62,7 +69,8 @@ struct Krylov {
          *tmp = nullptr, *X = nullptr;
   double* basis = nullptr;     // GMRES: (m+1) vectors of nl
   int basis_m = 0;
-  double* partials = nullptr;  // [slots][nblocks]
+  double* partials = nullptr;  // [slots][nb_max]
+  int nb_max = 0;
   double* scal = nullptr;      // device scalars
   double* h_scal = nullptr;    // pinned host mirror
   int nblocks = 0;
@@ -109,6 +117,7 @@ struct wai_ctx {
   hipEvent_t pev0 = nullptr, pev1 = nullptr;
   std::string err;
   bool bc_set = false;
+  int dbg = 0;                  // timing probes (wai_bench_kernel)
 };
 
 // ---- kernel launchers (kernels_assembly.hip / kernels_linalg.hip) --------------------------
@@ -126,18 +135,23 @@ int launch_region_set(wai_ctx* c, const double* in, int first, int count);
 
 int launch_spmv(wai_ctx* c, const double* x, double* y);
 int launch_ilu_factor(wai_ctx* c);
-int launch_ilu_apply(wai_ctx* c, const double* r, double* z);
-// fused vector kernels; results of reductions land in c->ks.scal[slot...]
+// z = B^-1 r (spmv = false) or z = B^-1 (A x) (spmv = true: x is `in`, haloed by the caller).
+// dot_mode 0: none; 1: scal-partials S_D1 += (z, aux); 2: S_D1 += (in, z), S_D2 += (z, z);
+// 3: S_DP2 += (z, z)
+int launch_pc(wai_ctx* c, bool spmv, const double* in, double* z, int dot_mode, const double* aux);
+int launch_ell_to_bcsr(wai_ctx* c, const double* ell, double* bcsr);
+int launch_bcsr_to_ell(wai_ctx* c, const double* bcsr, double* ell);
+// reductions: partial sums live in ks.partials[slot][block]; finalize sums nb partials of
+// nslots consecutive slots into ks.scal and (phase >= 0) derives the BiCGStab scalars
+int vec_finalize(wai_ctx* c, int nb, int slot0, int nslots, int phase);
 int vec_dot(wai_ctx* c, const double* a, const double* b, int n, int slot);
-int vec_dot2(wai_ctx* c, const double* a, const double* b, const double* cc, const double* d,
-             int n, int slot);
 int vec_copy(wai_ctx* c, double* dst, const double* src, size_t n);
 int vec_zero(wai_ctx* c, double* dst, size_t n);
 int vec_waxpy(wai_ctx* c, double* w, double alpha, const double* x, const double* y, int n);
 int bcgs_scalars(wai_ctx* c, int phase);
 int bcgs_update_p(wai_ctx* c);
 int bcgs_update_s(wai_ctx* c);
-int bcgs_update_xr(wai_ctx* c);
+int bcgs_update_xr(wai_ctx* c);   // leaves partials in S_DP2, S_RHONEW; returns #blocks via ks.nblocks
 int gmres_mdot(wai_ctx* c, const double* w, int k);          // scal[16+i] = (w, v_i), i<k
 int gmres_maxpy_norm(wai_ctx* c, double* w, int k);          // w -= sum h_i v_i ; scal[8] = |w|^2
 int gmres_scale_to(wai_ctx* c, double* dst, const double* src, int slot_norm2, int n);

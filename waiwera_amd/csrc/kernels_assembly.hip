@@ -225,7 +225,9 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
   }
 
   // diagonal block: own state perturbed in component k
-  double* dblk = val + (size_t)m.diag_blk[c] * bb;
+  // block-ELL, slot-major SoA: entry e of slot q of row c lives at val[(q*bb + e)*n_owned + c]
+  const size_t nrow = m.n_owned;
+  double* dblk = val + (size_t)m.diag_blk[c] * bb * nrow + c;
 #pragma unroll
   for (int k = 0; k < np; k++) {
     CellState<KIND> ownk;
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
 #pragma unroll
     for (int r = 0; r < np; r++) {
       const double f1 = (Lk[r] - lold[r]) - dt * R[r];
-      dblk[r * np + k] = (f1 - f0[r]) / h;
+      dblk[(size_t)(r * np + k) * nrow] = (f1 - f0[r]) / h;
     }
   }
 
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
     load_face(m, fs >> 1, g);
     RockState roth;
     load_rock(m.rock, m.n_local, o, roth);
-    double* oblk = val + (size_t)blk * bb;
+    double* oblk = val + (size_t)blk * bb * nrow + c;
 #pragma unroll
     for (int k = 0; k < np; k++) {
       CellState<KIND> othk;
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
 #pragma unroll
       for (int r = 0; r < np; r++) {
         const double f1 = (L0[r] - lold[r]) - dt * (R[r] + src0[r]);
-        oblk[r * np + k] += (f1 - f0[r]) / h;
+        oblk[(size_t)(r * np + k) * nrow] += (f1 - f0[r]) / h;
       }
     }
   }
@@ -448,7 +450,7 @@ int launch_jacobian(wai_ctx* c, double dt, const double* lhs_old) {
   const MeshView m = view(c);
   if (m.max_deg > MAXDEG) { c->err = "cell with more than 8 faces not supported"; return -1; }
   const size_t stride = c->mesh.n_local;
-  hipMemsetAsync(c->J.val, 0, sizeof(double) * (size_t)c->J.nnzb * c->np * c->np, c->stream);
+  hipMemsetAsync(c->J.val, 0, sizeof(double) * (size_t)c->J.W * c->np * c->np * c->J.n, c->stream);
   if (c->kind == EOS_W)
     hipLaunchKernelGGL(k_jacobian<EOS_W>, grid_for(m.n_owned), TPB, 0, c->stream, m, c->flu, stride,
                        c->flu_pert, c->hstep, c->mesh.n_prim, dt, lhs_old, c->J.val);

@@ -1,79 +1,87 @@
-// Block-sparse linear algebra for gfx950: BCSR SpMV (K6), block-Jacobi ILU(0) factor / apply
+// Block-sparse linear algebra for gfx950: block SpMV (K6), block-Jacobi ILU(0) factor / apply
 // (K7/K8), fused Krylov vector kernels and reductions (K9), halo pack/unpack.
 //
 // These replace what the reference gets from PETSc 3.22.5 (not vendored): MatMult_SeqBAIJ_N /
 // MPIBAIJ, PCBJACOBI+PCILU(0) MatSolve_SeqBAIJ_N, and the VecDot/VecAXPY family inside KSPBCGS
 // / KSPGMRES -- configured at src/timestepper.F90:1645-1836.  fp64, HBM-bound, no MFMA.
 //
-// SpMV: "CSR-stream" on standard BCSR (row-major bs x bs blocks, int32 columns).  A workgroup
-// owns a fixed chunk of block rows; lanes first sweep the chunk's blocks in storage order
-// (fully coalesced 32-byte block loads, x gathered through L2) and park the bs partial
-// products per block in LDS; then one lane per scalar row sums its row's products from LDS.
-// Workgroup -> chunk mapping is XCD-aware (block b runs on XCD b % 8, so each XCD sweeps one
-// contiguous eighth of the matrix and its L2 only ever holds that eighth's x entries).
+// Layout: block-ELL, slot-major struct-of-arrays (context.hpp).  Every kernel here is
+// one-thread-per-block-row; thread i of a wave reads element i of a slot/entry plane, so each
+// wave instruction moves 64 consecutive doubles (512 B) -- the matrix streams through at HBM
+// rate with no LDS staging, and x is gathered through L2 (brick-major numbering keeps a row's
+// neighbours within a few KB).  Workgroup -> row-range mapping is XCD-aware: block b runs on
+// XCD b % 8, so XCD j is handed the j-th contiguous eighth of the rows / subdomains and its L2
+// only ever holds that eighth's x entries.
 //
-// ILU(0): one workgroup per block-Jacobi subdomain (a brick of the mesh); the subdomain's
-// solution vector lives in LDS and rows are processed level by level (dependency levels of
-// the triangular factors computed once on the host) with workgroup barriers -- no
-// inter-workgroup synchronisation, no per-level launches.
+// Preconditioner: one workgroup per block-Jacobi subdomain (a brick of the mesh, <= 1024
+// rows), one thread per row.  The fused kernel k_pc computes t = A x for the subdomain's rows
+// (optional), parks t in LDS, pulls the thread's factor row into registers, then runs the
+// forward and backward substitutions level by level out of LDS with workgroup barriers only
+// (levels = dependency depth inside the brick, computed once on the host).  The dot products
+// BiCGStab needs of the result are reduced in the same kernel.
 #include "context.hpp"
 
 namespace wai {
 
 constexpr int TPB = 256;
-constexpr int NB_MAX = 1024;  // partial-sum blocks per reduction slot
+constexpr int WMAX = 8;  // block-ELL width handled in registers (7-point stencil: 7, MINC: 8)
+
+enum { S_RHO = 0, S_RHOOLD = 1, S_ALPHA = 2, S_OMEGA = 3, S_BETA = 4, S_D1 = 5, S_D2 = 6,
+       S_DP2 = 7, S_W2 = 8, S_RHONEW = 9, S_BREAK = 15, S_H = 16 };
 
 __device__ __forceinline__ int xcd_remap(int b, int n) {
   // dispatch places block b on XCD b % 8: give XCD j the contiguous range j*per .. (j+1)*per
   const int per = (n + 7) >> 3;
-  const int id = (b & 7) * per + (b >> 3);
-  return id;
+  return (b & 7) * per + (b >> 3);
 }
 
-// ---- K6: BCSR SpMV ---------------------------------------------------------------------------
 template <int BS>
-__global__ __launch_bounds__(TPB) void k_spmv(int n, int rows_per_chunk, int nchunks,
-                                              const int* __restrict__ rowptr,
-                                              const int* __restrict__ colidx,
-                                              const double* __restrict__ val,
-                                              const double* __restrict__ x, double* __restrict__ y) {
-  extern __shared__ double prod[];  // [blocks in chunk][BS]
-  const int chunk = xcd_remap(blockIdx.x, nchunks);
-  if (chunk >= nchunks) return;
-  const int r0 = chunk * rows_per_chunk;
-  const int r1 = min(n, r0 + rows_per_chunk);
-  const int q0 = rowptr[r0], q1 = rowptr[r1];
-  for (int q = q0 + threadIdx.x; q < q1; q += TPB) {
-    const int col = colidx[q];
-    double xv[BS], a[BS * BS];
-    if constexpr (BS == 2) {
-      const double2 xx = *reinterpret_cast<const double2*>(x + (size_t)col * 2);
-      xv[0] = xx.x; xv[1] = xx.y;
-      const double2 a0 = *reinterpret_cast<const double2*>(val + (size_t)q * 4);
-      const double2 a1 = *reinterpret_cast<const double2*>(val + (size_t)q * 4 + 2);
-      a[0] = a0.x; a[1] = a0.y; a[2] = a1.x; a[3] = a1.y;
-    } else {
+__device__ __forceinline__ void load_x(const double* __restrict__ x, int col, double* xv) {
+  if constexpr (BS == 2) {
+    const double2 t = *reinterpret_cast<const double2*>(x + (size_t)col * 2);
+    xv[0] = t.x; xv[1] = t.y;
+  } else {
 #pragma unroll
-      for (int k = 0; k < BS; k++) xv[k] = x[(size_t)col * BS + k];
+    for (int k = 0; k < BS; k++) xv[k] = x[(size_t)col * BS + k];
+  }
+}
+
+// acc += A_row(i) * x over the W slots of block row i
+template <int BS>
+__device__ __forceinline__ void ell_row_mult(int n, int W, int i, const int* __restrict__ col,
+                                             const double* __restrict__ val,
+                                             const double* __restrict__ x, double* acc) {
+  constexpr int BB = BS * BS;
 #pragma unroll
-      for (int k = 0; k < BS * BS; k++) a[k] = val[(size_t)q * BS * BS + k];
-    }
+  for (int s = 0; s < WMAX; s++) {
+    if (s < W) {
+      const int c = col[(size_t)s * n + i];
+      double xv[BS];
+      load_x<BS>(x, c, xv);
 #pragma unroll
-    for (int r = 0; r < BS; r++) {
-      double t = 0.0;
+      for (int r = 0; r < BS; r++)
 #pragma unroll
-      for (int k = 0; k < BS; k++) t += a[r * BS + k] * xv[k];
-      prod[(size_t)(q - q0) * BS + r] = t;
+        for (int k = 0; k < BS; k++) acc[r] += val[((size_t)s * BB + r * BS + k) * n + i] * xv[k];
     }
   }
-  __syncthreads();
-  const int nscal = (r1 - r0) * BS;
-  for (int t = threadIdx.x; t < nscal; t += TPB) {
-    const int row = r0 + t / BS, r = t % BS;
-    const int a = rowptr[row] - q0, b = rowptr[row + 1] - q0;
-    double acc = 0.0;
-    for (int q = a; q < b; q++) acc += prod[(size_t)q * BS + r];
-    y[(size_t)row * BS + r] = acc;
+}
+
+// ---- K6: block SpMV --------------------------------------------------------------------------
+template <int BS>
+__global__ __launch_bounds__(TPB) void k_spmv(int n, int W, int nblk, const int* __restrict__ col,
+                                              const double* __restrict__ val,
+                                              const double* __restrict__ x, double* __restrict__ y) {
+  const int b = xcd_remap(blockIdx.x, nblk);
+  const int i = b * TPB + threadIdx.x;
+  if (b >= nblk || i >= n) return;
+  double acc[BS];
+#pragma unroll
+  for (int r = 0; r < BS; r++) acc[r] = 0.0;
+  ell_row_mult<BS>(n, W, i, col, val, x, acc);
+  if constexpr (BS == 2) *reinterpret_cast<double2*>(y + (size_t)i * 2) = make_double2(acc[0], acc[1]);
+  else {
+#pragma unroll
+    for (int r = 0; r < BS; r++) y[(size_t)i * BS + r] = acc[r];
   }
 }
 
@@ -118,31 +126,41 @@ __device__ __forceinline__ bool block_inverse(const double* a, double* inv) {
   return ok;
 }
 
-struct IluView {
-  const int* sub_ptr; const int* rows; const int* lev_ptr; const int* sub_lev;
-  const int* lstart; const int* uend; const int* diag;
-  const int* rowptr; const int* colidx;
-  int nsub;
-};
+__device__ __forceinline__ void unpack_info(int info, int& lfirst, int& dslot, int& ulast, int& lf,
+                                            int& lb) {
+  lfirst = info & 15; dslot = (info >> 4) & 15; ulast = (info >> 8) & 15;
+  lf = (info >> 12) & 1023; lb = (info >> 22) & 1023;
+}
 
-// ---- K7: block ILU(0) numeric factorisation (IKJ, per subdomain, level by level) --------------
+// ---- K7: block ILU(0) numeric factorisation (IKJ), one workgroup per subdomain ----------------
+// Works in place on fval (a copy of the matrix); rows of one dependency level are independent.
+// On exit the diagonal slot of every row holds the inverted pivot block.
 template <int BS>
-__global__ __launch_bounds__(TPB) void k_ilu_factor(IluView v, double* __restrict__ fval,
-                                                    double* __restrict__ dinv, int* flags) {
+__global__ void k_ilu_factor(int n, int nsub, const int* __restrict__ sub_ptr,
+                             const int* __restrict__ sub_nlev, const int* __restrict__ row_info,
+                             const int* __restrict__ col, double* fval, double* __restrict__ dinv,
+                             int* flags) {
   constexpr int BB = BS * BS;
-  const int s = xcd_remap(blockIdx.x, v.nsub);
-  if (s >= v.nsub) return;
-  const int l0 = v.sub_lev[s], l1 = v.sub_lev[s + 1];
-  for (int lev = l0; lev < l1; lev++) {
-    const int p0 = v.lev_ptr[lev], p1 = v.lev_ptr[lev + 1];
-    for (int p = p0 + threadIdx.x; p < p1; p += TPB) {
-      const int i = v.rows[p];
-      const int qd = v.diag[i], qe = v.uend[i];
-      for (int q = v.lstart[i]; q < qd; q++) {
-        const int k = v.colidx[q];
+  const int s = xcd_remap(blockIdx.x, nsub);
+  if (s >= nsub) return;
+  const int lo = sub_ptr[s], R = sub_ptr[s + 1] - lo;
+  const int nlf = sub_nlev[s] & 0xffff;
+  const int i = lo + threadIdx.x;
+  const bool active = (int)threadIdx.x < R;
+  int lfirst = 0, dslot = 0, ulast = 0, lf = -1, lb = 0;
+  if (active) unpack_info(row_info[i], lfirst, dslot, ulast, lf, lb);
+  for (int lev = 0; lev < nlf; lev++) {
+    if (active && lf == lev) {
+      for (int q = lfirst; q < dslot; q++) {
+        const int k = col[(size_t)q * n + i];
+        int kl, kd, ku, kf, kb;
+        unpack_info(row_info[k], kl, kd, ku, kf, kb);
         double w[BB], d[BB], t[BB];
 #pragma unroll
-        for (int z = 0; z < BB; z++) { w[z] = fval[(size_t)q * BB + z]; d[z] = dinv[(size_t)k * BB + z]; }
+        for (int z = 0; z < BB; z++) {
+          w[z] = fval[((size_t)q * BB + z) * n + i];
+          d[z] = fval[((size_t)kd * BB + z) * n + k];
+        }
 #pragma unroll
         for (int r = 0; r < BS; r++)
 #pragma unroll
@@ -153,14 +171,14 @@ __global__ __launch_bounds__(TPB) void k_ilu_factor(IluView v, double* __restric
             t[r * BS + c] = acc;
           }
 #pragma unroll
-        for (int z = 0; z < BB; z++) fval[(size_t)q * BB + z] = t[z];
-        for (int r2 = v.diag[k] + 1; r2 < v.uend[k]; r2++) {
-          const int j = v.colidx[r2];
-          for (int q2 = q + 1; q2 < qe; q2++) {
-            if (v.colidx[q2] != j) continue;
+        for (int z = 0; z < BB; z++) fval[((size_t)q * BB + z) * n + i] = t[z];
+        for (int r2 = kd + 1; r2 < ku; r2++) {
+          const int j = col[(size_t)r2 * n + k];
+          for (int q2 = q + 1; q2 < ulast; q2++) {
+            if (col[(size_t)q2 * n + i] != j) continue;
             double u[BB];
 #pragma unroll
-            for (int z = 0; z < BB; z++) u[z] = fval[(size_t)r2 * BB + z];
+            for (int z = 0; z < BB; z++) u[z] = fval[((size_t)r2 * BB + z) * n + k];
 #pragma unroll
             for (int r = 0; r < BS; r++)
 #pragma unroll
@@ -168,7 +186,7 @@ __global__ __launch_bounds__(TPB) void k_ilu_factor(IluView v, double* __restric
                 double acc = 0.0;
 #pragma unroll
                 for (int e = 0; e < BS; e++) acc += t[r * BS + e] * u[e * BS + c];
-                fval[(size_t)q2 * BB + r * BS + c] -= acc;
+                fval[((size_t)q2 * BB + r * BS + c) * n + i] -= acc;
               }
             break;
           }
@@ -176,94 +194,293 @@ __global__ __launch_bounds__(TPB) void k_ilu_factor(IluView v, double* __restric
       }
       double piv[BB], inv[BB];
 #pragma unroll
-      for (int z = 0; z < BB; z++) piv[z] = fval[(size_t)qd * BB + z];
+      for (int z = 0; z < BB; z++) piv[z] = fval[((size_t)dslot * BB + z) * n + i];
       if (!block_inverse<BS>(piv, inv)) atomicMax(&flags[0], 1);
 #pragma unroll
-      for (int z = 0; z < BB; z++) dinv[(size_t)i * BB + z] = inv[z];
+      for (int z = 0; z < BB; z++) {
+        fval[((size_t)dslot * BB + z) * n + i] = inv[z];
+        dinv[(size_t)z * n + i] = inv[z];
+      }
     }
     __threadfence_block();
     __syncthreads();
   }
 }
 
-// ---- K8: z = U^-1 L^-1 r per subdomain, solution vector in LDS --------------------------------
-template <int BS>
-__global__ __launch_bounds__(TPB) void k_ilu_apply(IluView fw, IluView bw,
-                                                   const double* __restrict__ fval,
-                                                   const double* __restrict__ dinv,
-                                                   const double* __restrict__ r,
-                                                   double* __restrict__ z) {
-  constexpr int BB = BS * BS;
-  extern __shared__ double ys[];  // [rows in subdomain][BS]
-  const int s = xcd_remap(blockIdx.x, fw.nsub);
-  if (s >= fw.nsub) return;
-  const int lo = fw.sub_ptr[s];
-  // forward: L y = r (unit block diagonal)
-  for (int lev = fw.sub_lev[s]; lev < fw.sub_lev[s + 1]; lev++) {
-    const int p0 = fw.lev_ptr[lev], p1 = fw.lev_ptr[lev + 1];
-    for (int p = p0 + threadIdx.x; p < p1; p += TPB) {
-      const int i = fw.rows[p];
-      double acc[BS];
+// ---- K6+K8 fused: z = U^-1 L^-1 (A x)  or  z = U^-1 L^-1 r ------------------------------------
+template <int NS>
+__device__ __forceinline__ void wg_reduce_store(double (&v)[NS], double* red, double* partials,
+                                                int nb_max, const int* slots, int blk) {
+  // red: LDS scratch of NS * 16 doubles (up to 16 waves per workgroup)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
 #pragma unroll
-      for (int a = 0; a < BS; a++) acc[a] = r[(size_t)i * BS + a];
-      const int qd = fw.diag[i];
-      for (int q = fw.lstart[i]; q < qd; q++) {
-        const int k = fw.colidx[q] - lo;
-        double m[BB];
-#pragma unroll
-        for (int e = 0; e < BB; e++) m[e] = fval[(size_t)q * BB + e];
-#pragma unroll
-        for (int a = 0; a < BS; a++)
-#pragma unroll
-          for (int c = 0; c < BS; c++) acc[a] -= m[a * BS + c] * ys[k * BS + c];
-      }
-#pragma unroll
-      for (int a = 0; a < BS; a++) ys[(i - lo) * BS + a] = acc[a];
-    }
-    __syncthreads();
+  for (int s = 0; s < NS; s++) {
+    double t = v[s];
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+    if (lane == 0) red[s * 16 + w] = t;
   }
-  // backward: U x = y
-  for (int lev = bw.sub_lev[s]; lev < bw.sub_lev[s + 1]; lev++) {
-    const int p0 = bw.lev_ptr[lev], p1 = bw.lev_ptr[lev + 1];
-    for (int p = p0 + threadIdx.x; p < p1; p += TPB) {
-      const int i = bw.rows[p];
-      double acc[BS], out[BS];
+  __syncthreads();
+  if (threadIdx.x == 0) {
 #pragma unroll
-      for (int a = 0; a < BS; a++) acc[a] = ys[(i - lo) * BS + a];
-      const int qe = bw.uend[i];
-      for (int q = bw.diag[i] + 1; q < qe; q++) {
-        const int k = bw.colidx[q] - lo;
-        double m[BB];
-#pragma unroll
-        for (int e = 0; e < BB; e++) m[e] = fval[(size_t)q * BB + e];
-#pragma unroll
-        for (int a = 0; a < BS; a++)
-#pragma unroll
-          for (int c = 0; c < BS; c++) acc[a] -= m[a * BS + c] * ys[k * BS + c];
-      }
-      double d[BB];
-#pragma unroll
-      for (int e = 0; e < BB; e++) d[e] = dinv[(size_t)i * BB + e];
-#pragma unroll
-      for (int a = 0; a < BS; a++) {
-        out[a] = 0.0;
-#pragma unroll
-        for (int c = 0; c < BS; c++) out[a] += d[a * BS + c] * acc[c];
-      }
-#pragma unroll
-      for (int a = 0; a < BS; a++) { ys[(i - lo) * BS + a] = out[a]; z[(size_t)i * BS + a] = out[a]; }
+    for (int s = 0; s < NS; s++) {
+      double t = 0.0;
+      for (int q = 0; q < nw; q++) t += red[s * 16 + q];
+      partials[(size_t)slots[s] * nb_max + blk] = t;
     }
-    __syncthreads();
   }
 }
 
-// ---- K9: fused vector kernels -----------------------------------------------------------------
-// scalars (device, ks.scal): BiCGStab state of PETSc's KSPBCGS
-enum { S_RHO = 0, S_RHOOLD = 1, S_ALPHA = 2, S_OMEGA = 3, S_BETA = 4, S_D1 = 5, S_D2 = 6,
-       S_DP2 = 7, S_W2 = 8, S_RHONEW = 9, S_BREAK = 15, S_H = 16 };
+// DILU = true: the symbolic phase found that ILU(0) never updates an off-diagonal block inside
+// any subdomain (true for hexahedral / MINC connectivity: no triangles in the cell graph), so
+// L_ik = A_ik inv(D_k) and U_ij = A_ij exactly and the factor is just the modified pivots.  The
+// matrix row a thread pulled in for the SpMV is then reused for both substitutions and only the
+// inverted pivot block is read from the factor: ~300 instead of ~520 bytes per block row.
+template <int BS, bool SPMV, int DOT, bool DILU>
+__global__ void k_pc(int n, int W, int nsub, const int* __restrict__ sub_ptr,
+                     const int* __restrict__ sub_nlev, const int* __restrict__ row_info,
+                     const int* __restrict__ col, const double* __restrict__ aval,
+                     const double* __restrict__ fval, const double* __restrict__ dinv,
+                     const double* __restrict__ in,
+                     double* __restrict__ z, const double* __restrict__ aux, double* partials,
+                     int nb_max, int dbg) {
+  constexpr int BB = BS * BS;
+  extern __shared__ double lds[];  // [T * BS] solution vector, then 32 doubles reduction scratch
+  const int s = xcd_remap(blockIdx.x, nsub);
+  if (s >= nsub) return;
+  const int lo = sub_ptr[s], R = sub_ptr[s + 1] - lo;
+  const int nl = sub_nlev[s];
+  const int nlf = (dbg & 1) ? 0 : (nl & 0xffff), nlb = (dbg & 1) ? 1 : (nl >> 16);  // dbg: timing probe
+  const int tid = threadIdx.x, i = lo + tid;
+  const bool active = tid < R;
+  double* ys = lds;
+  double f[WMAX][BB];
+  int fc[WMAX];
+  int lfirst = 0, dslot = 0, ulast = 0, lf = -1, lb = -1;
+  double xin[BS];
+#pragma unroll
+  for (int r = 0; r < BS; r++) xin[r] = 0.0;
+#pragma unroll
+  for (int q = 0; q < WMAX; q++) {
+    fc[q] = 0;
+#pragma unroll
+    for (int e = 0; e < BB; e++) f[q][e] = 0.0;
+  }
+  double dv[BB];
+#pragma unroll
+  for (int e = 0; e < BB; e++) dv[e] = 0.0;
+  if (active) {
+    unpack_info(row_info[i], lfirst, dslot, ulast, lf, lb);
+    double acc[BS];
+    if constexpr (DILU) {
+      // one pass over the matrix row: keep it in registers for the substitutions
+#pragma unroll
+      for (int q = 0; q < WMAX; q++) {
+        if (q < W) {
+          const int cg = col[(size_t)q * n + i];
+          fc[q] = cg - lo;
+#pragma unroll
+          for (int e = 0; e < BB; e++) f[q][e] = aval[((size_t)q * BB + e) * n + i];
+          if constexpr (SPMV) {
+            double xv[BS];
+            load_x<BS>(in, cg, xv);
+            if (q == 0) {
+#pragma unroll
+              for (int r = 0; r < BS; r++) acc[r] = 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < BS; r++)
+#pragma unroll
+              for (int k = 0; k < BS; k++) acc[r] += f[q][r * BS + k] * xv[k];
+          }
+        }
+      }
+      if constexpr (!SPMV) load_x<BS>(in, i, acc);
+      if constexpr (SPMV && DOT == 2) load_x<BS>(in, i, xin);
+#pragma unroll
+      for (int e = 0; e < BB; e++) dv[e] = dinv[(size_t)e * n + i];
+    } else {
+      if constexpr (SPMV) {
+#pragma unroll
+        for (int r = 0; r < BS; r++) acc[r] = 0.0;
+        ell_row_mult<BS>(n, W, i, col, aval, in, acc);
+        if constexpr (DOT == 2) load_x<BS>(in, i, xin);
+      } else {
+        load_x<BS>(in, i, acc);
+      }
+      // factor row -> registers (independent loads, all in flight before the first barrier)
+#pragma unroll
+      for (int q = 0; q < WMAX; q++) {
+        if (q < W) {
+          fc[q] = col[(size_t)q * n + i] - lo;
+#pragma unroll
+          for (int e = 0; e < BB; e++) f[q][e] = fval[((size_t)q * BB + e) * n + i];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < WMAX; q++)
+        if (q == dslot) {
+#pragma unroll
+          for (int e = 0; e < BB; e++) dv[e] = f[q][e];
+        }
+    }
+    if constexpr (DILU) {
+      if (lf == 0) {  // level-0 rows: w = inv(D) t straight away
+        double w0[BS];
+#pragma unroll
+        for (int r = 0; r < BS; r++) {
+          w0[r] = 0.0;
+#pragma unroll
+          for (int k = 0; k < BS; k++) w0[r] += dv[r * BS + k] * acc[k];
+        }
+#pragma unroll
+        for (int r = 0; r < BS; r++) acc[r] = w0[r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < BS; r++) ys[tid * BS + r] = acc[r];
+  }
+  __syncthreads();
+  // forward substitution.  General: L y = t (unit block diagonal), LDS holds y.
+  // DILU: y_i = t_i - sum A_ik w_k with w_k = inv(D_k) y_k; LDS holds w.
+  for (int lev = 1; lev < nlf; lev++) {  // level-0 rows have no lower couplings
+    if (lf == lev) {
+      double a[BS];
+#pragma unroll
+      for (int r = 0; r < BS; r++) a[r] = ys[tid * BS + r];
+#pragma unroll
+      for (int q = 0; q < WMAX; q++) {
+        if (q >= lfirst && q < dslot) {
+          double yk[BS];
+#pragma unroll
+          for (int c = 0; c < BS; c++) yk[c] = ys[fc[q] * BS + c];
+#pragma unroll
+          for (int r = 0; r < BS; r++)
+#pragma unroll
+            for (int c = 0; c < BS; c++) a[r] -= f[q][r * BS + c] * yk[c];
+        }
+      }
+      if constexpr (DILU) {
+        double w1[BS];
+#pragma unroll
+        for (int r = 0; r < BS; r++) {
+          w1[r] = 0.0;
+#pragma unroll
+          for (int k = 0; k < BS; k++) w1[r] += dv[r * BS + k] * a[k];
+        }
+#pragma unroll
+        for (int r = 0; r < BS; r++) a[r] = w1[r];
+      }
+#pragma unroll
+      for (int r = 0; r < BS; r++) ys[tid * BS + r] = a[r];
+    }
+    __syncthreads();
+  }
+  // backward substitution.  General: x_i = inv(D_i) (y_i - sum U_ij x_j).
+  // DILU: x_i = w_i - inv(D_i) sum A_ij x_j.
+  double out[BS];
+#pragma unroll
+  for (int r = 0; r < BS; r++) out[r] = 0.0;
+  for (int lev = 0; lev < nlb; lev++) {
+    if (lb == lev) {
+      double a[BS], sum[BS];
+#pragma unroll
+      for (int r = 0; r < BS; r++) { a[r] = ys[tid * BS + r]; sum[r] = 0.0; }
+#pragma unroll
+      for (int q = 0; q < WMAX; q++) {
+        if (q > dslot && q < ulast) {
+          double xk[BS];
+#pragma unroll
+          for (int c = 0; c < BS; c++) xk[c] = ys[fc[q] * BS + c];
+#pragma unroll
+          for (int r = 0; r < BS; r++)
+#pragma unroll
+            for (int c = 0; c < BS; c++) sum[r] += f[q][r * BS + c] * xk[c];
+        }
+      }
+      if constexpr (DILU) {
+#pragma unroll
+        for (int r = 0; r < BS; r++) {
+          double t = 0.0;
+#pragma unroll
+          for (int c = 0; c < BS; c++) t += dv[r * BS + c] * sum[c];
+          out[r] = a[r] - t;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < BS; r++) {
+          double t = 0.0;
+#pragma unroll
+          for (int c = 0; c < BS; c++) t += dv[r * BS + c] * (a[c] - sum[c]);
+          out[r] = t;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < BS; r++) ys[tid * BS + r] = out[r];
+    }
+    if (lev + 1 < nlb) __syncthreads();
+  }
+  if (active) {
+    if constexpr (BS == 2) *reinterpret_cast<double2*>(z + (size_t)i * 2) = make_double2(out[0], out[1]);
+    else {
+#pragma unroll
+      for (int r = 0; r < BS; r++) z[(size_t)i * BS + r] = out[r];
+    }
+  }
+  if constexpr (DOT != 0) {
+    double* red = lds + (size_t)blockDim.x * BS;
+    if constexpr (DOT == 1) {  // (z, aux)
+      double v[1] = {0.0};
+      if (active) {
+        double av[BS];
+        load_x<BS>(aux, i, av);
+#pragma unroll
+        for (int r = 0; r < BS; r++) v[0] += out[r] * av[r];
+      }
+      const int slots[1] = {S_D1};
+      __syncthreads();
+      wg_reduce_store<1>(v, red, partials, nb_max, slots, s);
+    } else if constexpr (DOT == 2) {  // (in, z), (z, z)
+      double v[2] = {0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < BS; r++) { v[0] += xin[r] * out[r]; v[1] += out[r] * out[r]; }
+      const int slots[2] = {S_D1, S_D2};
+      __syncthreads();
+      wg_reduce_store<2>(v, red, partials, nb_max, slots, s);
+    } else {  // (z, z)
+      double v[1] = {0.0};
+#pragma unroll
+      for (int r = 0; r < BS; r++) v[0] += out[r] * out[r];
+      const int slots[1] = {S_DP2};
+      __syncthreads();
+      wg_reduce_store<1>(v, red, partials, nb_max, slots, s);
+    }
+  }
+}
 
+// ---- layout conversion (C ABI exchanges BCSR) -------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_ell_to_bcsr(int n, int W, int bb, const int* __restrict__ rowptr,
+                                                     const double* __restrict__ ell, double* __restrict__ bcsr) {
+  const size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (t >= (size_t)n * W) return;
+  const int s = (int)(t / n), i = (int)(t - (size_t)s * n);
+  const int a = rowptr[i], cnt = rowptr[i + 1] - a;
+  if (s >= cnt) return;
+  for (int e = 0; e < bb; e++) bcsr[(size_t)(a + s) * bb + e] = ell[((size_t)s * bb + e) * n + i];
+}
+__global__ __launch_bounds__(TPB) void k_bcsr_to_ell(int n, int W, int bb, const int* __restrict__ rowptr,
+                                                     const double* __restrict__ bcsr, double* __restrict__ ell) {
+  const size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (t >= (size_t)n * W) return;
+  const int s = (int)(t / n), i = (int)(t - (size_t)s * n);
+  const int a = rowptr[i], cnt = rowptr[i + 1] - a;
+  for (int e = 0; e < bb; e++)
+    ell[((size_t)s * bb + e) * n + i] = (s < cnt) ? bcsr[(size_t)(a + s) * bb + e] : 0.0;
+}
+
+// ---- K9: fused vector kernels -----------------------------------------------------------------
 template <int NS>
-__device__ __forceinline__ void block_reduce_store(double (&v)[NS], double* partials, int slot0) {
+__device__ __forceinline__ void block_reduce_store(double (&v)[NS], double* partials, int nb_max,
+                                                   const int* slots) {
   __shared__ double sm[NS][TPB / 64];
 #pragma unroll
   for (int s = 0; s < NS; s++) {
@@ -278,58 +495,25 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[NS], double* part
       double t = 0.0;
 #pragma unroll
       for (int w = 0; w < TPB / 64; w++) t += sm[s][w];
-      partials[(size_t)(slot0 + s) * NB_MAX + blockIdx.x] = t;
+      partials[(size_t)slots[s] * nb_max + blockIdx.x] = t;
     }
   }
 }
 
 __global__ __launch_bounds__(TPB) void k_dot(const double* __restrict__ a, const double* __restrict__ b,
-                                             int n, double* partials, int slot) {
+                                             int n, double* partials, int nb_max, int slot) {
   double v[1] = {0.0};
   for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) v[0] += a[i] * b[i];
-  block_reduce_store<1>(v, partials, slot);
+  const int slots[1] = {slot};
+  block_reduce_store<1>(v, partials, nb_max, slots);
 }
 
-__global__ __launch_bounds__(TPB) void k_dot2(const double* __restrict__ a, const double* __restrict__ b,
-                                              const double* __restrict__ c, const double* __restrict__ d,
-                                              int n, double* partials, int slot) {
-  double v[2] = {0.0, 0.0};
-  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
-    v[0] += a[i] * b[i];
-    v[1] += c[i] * d[i];
-  }
-  block_reduce_store<2>(v, partials, slot);
-}
-
-// sum the per-block partials of nslots reduction slots into scal[slot0..]
-__global__ __launch_bounds__(TPB) void k_finalize(const double* __restrict__ partials, int nb,
-                                                  int slot0, int nslots, double* scal) {
-  __shared__ double sm[TPB / 64];
-  for (int s = 0; s < nslots; s++) {
-    double t = 0.0;
-    for (int i = threadIdx.x; i < nb; i += TPB) t += partials[(size_t)(slot0 + s) * NB_MAX + i];
-    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double tot = 0.0;
-      for (int w = 0; w < TPB / 64; w++) tot += sm[w];
-      scal[slot0 + s] = tot;
-    }
-    __syncthreads();
-  }
-}
-
-// derived BiCGStab scalars (PETSc KSPSolve_BCGS order of operations)
-__global__ void k_bcgs_scalars(double* s, int phase) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  switch (phase) {
+__device__ __forceinline__ void derive_scalars(double* s, int phase) {
+  switch (phase) {  // PETSc KSPSolve_BCGS order of operations
     case 0:  // after R = B^-1 b: DP2 = (R,R); rho = (R,RP) with RP = R
       s[S_RHO] = s[S_DP2]; s[S_RHOOLD] = 1.0; s[S_ALPHA] = 1.0; s[S_OMEGA] = 1.0; s[S_BREAK] = 0.0;
-      break;
-    case 1:  // beta = (rho/rhoold)*(alphaold/omegaold)
-      if (s[S_RHO] == 0.0) s[S_BREAK] = 1.0;
       s[S_BETA] = (s[S_RHO] / s[S_RHOOLD]) * (s[S_ALPHA] / s[S_OMEGA]);
+      if (s[S_RHO] == 0.0) s[S_BREAK] = 1.0;
       break;
     case 2:  // alpha = rho / (V,RP)
       if (s[S_D1] == 0.0) s[S_BREAK] = 1.0;
@@ -339,10 +523,38 @@ __global__ void k_bcgs_scalars(double* s, int phase) {
       if (s[S_D2] == 0.0) s[S_BREAK] = 2.0;
       s[S_OMEGA] = s[S_D1] / s[S_D2];
       break;
-    case 4:  // end of iteration: rotate rho
+    case 4:  // end of iteration: rotate rho, next beta = (rho/rhoold)*(alpha/omega)
       s[S_RHOOLD] = s[S_RHO]; s[S_RHO] = s[S_RHONEW];
+      if (s[S_RHO] == 0.0) s[S_BREAK] = 1.0;
+      s[S_BETA] = (s[S_RHO] / s[S_RHOOLD]) * (s[S_ALPHA] / s[S_OMEGA]);
       break;
+    default: break;
   }
+}
+
+// sum the per-block partials of up to 4 reduction slots into scal[...], then derive
+__global__ __launch_bounds__(1024) void k_finalize(const double* __restrict__ partials, int nb_max, int nb,
+                                                   int4 slots, int nslots, double* scal, int phase) {
+  __shared__ double sm[16];
+  const int sl[4] = {slots.x, slots.y, slots.z, slots.w};
+  for (int s = 0; s < nslots; s++) {
+    double t = 0.0;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) t += partials[(size_t)sl[s] * nb_max + i];
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tot = 0.0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); w++) tot += sm[w];
+      scal[sl[s]] = tot;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && phase >= 0) derive_scalars(scal, phase);
+}
+
+__global__ void k_bcgs_scalars(double* s, int phase) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) derive_scalars(s, phase);
 }
 
 // P = R + beta*(P - omega_old*V)   [VecAXPBYPCZ(P, 1, -omega*beta, beta, R, V)]
@@ -364,7 +576,8 @@ __global__ __launch_bounds__(TPB) void k_bcgs_s(double* __restrict__ S, const do
 __global__ __launch_bounds__(TPB) void k_bcgs_xr(double* __restrict__ X, double* __restrict__ R,
                                                  const double* __restrict__ P, const double* __restrict__ S,
                                                  const double* __restrict__ T, const double* __restrict__ RP,
-                                                 int n, const double* __restrict__ s, double* partials) {
+                                                 int n, const double* __restrict__ s, double* partials,
+                                                 int nb_max) {
   const double alpha = s[S_ALPHA], omega = s[S_OMEGA];
   double v[2] = {0.0, 0.0};
   for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
@@ -375,11 +588,8 @@ __global__ __launch_bounds__(TPB) void k_bcgs_xr(double* __restrict__ X, double*
     v[0] += r * r;
     v[1] += r * RP[i];
   }
-  // slots S_DP2 (7) and S_RHONEW (9) are not adjacent: store separately
-  double a[1] = {v[0]}, b[1] = {v[1]};
-  block_reduce_store<1>(a, partials, S_DP2);
-  __syncthreads();
-  block_reduce_store<1>(b, partials, S_RHONEW);
+  const int slots[2] = {S_DP2, S_RHONEW};
+  block_reduce_store<2>(v, partials, nb_max, slots);
 }
 
 __global__ __launch_bounds__(TPB) void k_waxpy(double* w, double alpha, const double* x, const double* y, int n) {
@@ -388,7 +598,7 @@ __global__ __launch_bounds__(TPB) void k_waxpy(double* w, double alpha, const do
 
 // GMRES: up to 8 dots (w, v_j) per pass
 __global__ __launch_bounds__(TPB) void k_mdot8(const double* __restrict__ w, const double* __restrict__ basis,
-                                               size_t ld, int j0, int cnt, int n, double* partials) {
+                                               size_t ld, int j0, int cnt, int n, double* partials, int nb_max) {
   double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
     const double wi = w[i];
@@ -396,12 +606,14 @@ __global__ __launch_bounds__(TPB) void k_mdot8(const double* __restrict__ w, con
     for (int q = 0; q < 8; q++)
       if (q < cnt) v[q] += wi * basis[(size_t)(j0 + q) * ld + i];
   }
-  block_reduce_store<8>(v, partials, S_H + j0);
+  const int slots[8] = {S_H + j0, S_H + j0 + 1, S_H + j0 + 2, S_H + j0 + 3,
+                        S_H + j0 + 4, S_H + j0 + 5, S_H + j0 + 6, S_H + j0 + 7};
+  block_reduce_store<8>(v, partials, nb_max, slots);
 }
 // w -= sum_j h_j v_j ; partial |w|^2
 __global__ __launch_bounds__(TPB) void k_maxpy_norm(double* __restrict__ w, const double* __restrict__ basis,
                                                     size_t ld, int k, int n, const double* __restrict__ s,
-                                                    double* partials) {
+                                                    double* partials, int nb_max) {
   double v[1] = {0.0};
   for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
     double wi = w[i];
@@ -409,7 +621,8 @@ __global__ __launch_bounds__(TPB) void k_maxpy_norm(double* __restrict__ w, cons
     w[i] = wi;
     v[0] += wi * wi;
   }
-  block_reduce_store<1>(v, partials, S_W2);
+  const int slots[1] = {S_W2};
+  block_reduce_store<1>(v, partials, nb_max, slots);
 }
 __global__ __launch_bounds__(TPB) void k_scale_to(double* dst, const double* src, const double* __restrict__ s,
                                                   int slot, int n) {
@@ -425,7 +638,7 @@ __global__ __launch_bounds__(TPB) void k_update_x(double* __restrict__ x, const 
   }
 }
 
-// halo pack / unpack: sendbuf[p*dof + k] = vec[send_idx[p]*dof + k]
+// halo pack: sendbuf[p*dof + k] = vec[send_idx[p]*dof + k]
 __global__ __launch_bounds__(TPB) void k_pack(const double* __restrict__ vec, const int* __restrict__ idx,
                                               int n, int dof, double* __restrict__ buf) {
   const int t = blockIdx.x * TPB + threadIdx.x;
@@ -437,87 +650,99 @@ __global__ __launch_bounds__(TPB) void k_pack(const double* __restrict__ vec, co
 // ---- launchers -------------------------------------------------------------------------------
 static inline int vgrid(int n) {
   int g = (n + TPB - 1) / TPB;
-  return g > NB_MAX ? NB_MAX : (g < 1 ? 1 : g);
+  return g > 1024 ? 1024 : (g < 1 ? 1 : g);
 }
 
 int launch_spmv(wai_ctx* c, const double* x, double* y) {
   const Bcsr& J = c->J;
-  const int bs = J.bs;
-  const int rpc = TPB / bs;
-  const int nchunks = (J.n + rpc - 1) / rpc;
-  const int grid = ((nchunks + 7) / 8) * 8;
-  const size_t lds = (size_t)J.max_chunk_blocks * bs * sizeof(double);
-  switch (bs) {
-    case 1: hipLaunchKernelGGL(k_spmv<1>, grid, TPB, lds, c->stream, J.n, rpc, nchunks, J.rowptr, J.colidx, J.val, x, y); break;
-    case 2: hipLaunchKernelGGL(k_spmv<2>, grid, TPB, lds, c->stream, J.n, rpc, nchunks, J.rowptr, J.colidx, J.val, x, y); break;
-    case 3: hipLaunchKernelGGL(k_spmv<3>, grid, TPB, lds, c->stream, J.n, rpc, nchunks, J.rowptr, J.colidx, J.val, x, y); break;
-    case 4: hipLaunchKernelGGL(k_spmv<4>, grid, TPB, lds, c->stream, J.n, rpc, nchunks, J.rowptr, J.colidx, J.val, x, y); break;
+  const int nblk = (J.n + TPB - 1) / TPB;
+  const int grid = ((nblk + 7) / 8) * 8;
+  switch (J.bs) {
+    case 1: hipLaunchKernelGGL(k_spmv<1>, grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, x, y); break;
+    case 2: hipLaunchKernelGGL(k_spmv<2>, grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, x, y); break;
+    case 3: hipLaunchKernelGGL(k_spmv<3>, grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, x, y); break;
     default: return -1;
   }
   return 0;
 }
 
-static IluView fview(wai_ctx* c) {
-  IluView v;
-  v.sub_ptr = c->ilu.sub_ptr; v.rows = c->ilu.fwd_rows; v.lev_ptr = c->ilu.fwd_lev_ptr;
-  v.sub_lev = c->ilu.fwd_sub_lev; v.lstart = c->ilu.lstart; v.uend = c->ilu.uend;
-  v.diag = c->mesh.diag_blk; v.rowptr = c->J.rowptr; v.colidx = c->J.colidx; v.nsub = c->ilu.nsub;
-  return v;
-}
-static IluView bview(wai_ctx* c) {
-  IluView v = fview(c);
-  v.rows = c->ilu.bwd_rows; v.lev_ptr = c->ilu.bwd_lev_ptr; v.sub_lev = c->ilu.bwd_sub_lev;
-  return v;
-}
+static inline int pc_threads(wai_ctx* c) { return ((c->ilu.max_rows + 63) / 64) * 64; }
 
 int launch_ilu_factor(wai_ctx* c) {
-  const int bs = c->J.bs;
-  hipMemcpyAsync(c->ilu.fval, c->J.val, sizeof(double) * (size_t)c->J.nnzb * bs * bs,
-                 hipMemcpyDeviceToDevice, c->stream);
-  const IluView v = fview(c);
-  const int grid = ((v.nsub + 7) / 8) * 8;
-  switch (bs) {
-    case 1: hipLaunchKernelGGL(k_ilu_factor<1>, grid, TPB, 0, c->stream, v, c->ilu.fval, c->ilu.dinv, c->d_flags); break;
-    case 2: hipLaunchKernelGGL(k_ilu_factor<2>, grid, TPB, 0, c->stream, v, c->ilu.fval, c->ilu.dinv, c->d_flags); break;
-    case 3: hipLaunchKernelGGL(k_ilu_factor<3>, grid, TPB, 0, c->stream, v, c->ilu.fval, c->ilu.dinv, c->d_flags); break;
-    case 4: hipLaunchKernelGGL(k_ilu_factor<4>, grid, TPB, 0, c->stream, v, c->ilu.fval, c->ilu.dinv, c->d_flags); break;
+  const Bcsr& J = c->J;
+  const IluSchedule& s = c->ilu;
+  hipMemcpyAsync(s.fval, J.val, sizeof(double) * (size_t)J.W * J.bs * J.bs * J.n, hipMemcpyDeviceToDevice, c->stream);
+  const int grid = ((s.nsub + 7) / 8) * 8, T = pc_threads(c);
+  switch (J.bs) {
+    case 1: hipLaunchKernelGGL(k_ilu_factor<1>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
+    case 2: hipLaunchKernelGGL(k_ilu_factor<2>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
+    case 3: hipLaunchKernelGGL(k_ilu_factor<3>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
     default: return -1;
   }
   c->ilu.factored = true;
   return 0;
 }
 
-int launch_ilu_apply(wai_ctx* c, const double* r, double* z) {
-  const int bs = c->J.bs;
-  const IluView fw = fview(c), bw = bview(c);
-  const int grid = ((fw.nsub + 7) / 8) * 8;
-  const size_t lds = (size_t)c->ilu.max_rows * bs * sizeof(double);
-  switch (bs) {
-    case 1: hipLaunchKernelGGL(k_ilu_apply<1>, grid, TPB, lds, c->stream, fw, bw, c->ilu.fval, c->ilu.dinv, r, z); break;
-    case 2: hipLaunchKernelGGL(k_ilu_apply<2>, grid, TPB, lds, c->stream, fw, bw, c->ilu.fval, c->ilu.dinv, r, z); break;
-    case 3: hipLaunchKernelGGL(k_ilu_apply<3>, grid, TPB, lds, c->stream, fw, bw, c->ilu.fval, c->ilu.dinv, r, z); break;
-    case 4: hipLaunchKernelGGL(k_ilu_apply<4>, grid, TPB, lds, c->stream, fw, bw, c->ilu.fval, c->ilu.dinv, r, z); break;
+template <int BS>
+static void launch_pc_bs(wai_ctx* c, bool spmv, const double* in, double* z, int dot_mode, const double* aux) {
+  const Bcsr& J = c->J;
+  const IluSchedule& s = c->ilu;
+  const int grid = ((s.nsub + 7) / 8) * 8, T = pc_threads(c);
+  const size_t lds = ((size_t)T * BS + 32) * sizeof(double);
+#define PCL(SP, DT)                                                                              \
+  do {                                                                                           \
+    if (s.diag_only)                                                                             \
+      hipLaunchKernelGGL((k_pc<BS, SP, DT, true>), grid, T, lds, c->stream, J.n, J.W, s.nsub,    \
+                         s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.fval, s.dinv, in, z, \
+                         aux, c->ks.partials, c->ks.nb_max, c->dbg);                             \
+    else                                                                                         \
+      hipLaunchKernelGGL((k_pc<BS, SP, DT, false>), grid, T, lds, c->stream, J.n, J.W, s.nsub,   \
+                         s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.fval, s.dinv, in, z, \
+                         aux, c->ks.partials, c->ks.nb_max, c->dbg);                             \
+  } while (0)
+  if (spmv) {
+    if (dot_mode == 1) PCL(true, 1); else if (dot_mode == 2) PCL(true, 2); else if (dot_mode == 3) PCL(true, 3); else PCL(true, 0);
+  } else {
+    if (dot_mode == 1) PCL(false, 1); else if (dot_mode == 3) PCL(false, 3); else PCL(false, 0);
+  }
+#undef PCL
+}
+
+int launch_pc(wai_ctx* c, bool spmv, const double* in, double* z, int dot_mode, const double* aux) {
+  switch (c->J.bs) {
+    case 1: launch_pc_bs<1>(c, spmv, in, z, dot_mode, aux); break;
+    case 2: launch_pc_bs<2>(c, spmv, in, z, dot_mode, aux); break;
+    case 3: launch_pc_bs<3>(c, spmv, in, z, dot_mode, aux); break;
     default: return -1;
   }
   return 0;
 }
 
-static void finalize(wai_ctx* c, int nb, int slot0, int nslots) {
-  hipLaunchKernelGGL(k_finalize, 1, TPB, 0, c->stream, c->ks.partials, nb, slot0, nslots, c->ks.scal);
+int launch_ell_to_bcsr(wai_ctx* c, const double* ell, double* bcsr) {
+  const Bcsr& J = c->J;
+  const size_t tot = (size_t)J.n * J.W;
+  hipLaunchKernelGGL(k_ell_to_bcsr, (int)((tot + TPB - 1) / TPB), TPB, 0, c->stream, J.n, J.W, J.bs * J.bs, J.rowptr, ell, bcsr);
+  return 0;
+}
+int launch_bcsr_to_ell(wai_ctx* c, const double* bcsr, double* ell) {
+  const Bcsr& J = c->J;
+  const size_t tot = (size_t)J.n * J.W;
+  hipLaunchKernelGGL(k_bcsr_to_ell, (int)((tot + TPB - 1) / TPB), TPB, 0, c->stream, J.n, J.W, J.bs * J.bs, J.rowptr, bcsr, ell);
+  return 0;
+}
+
+int vec_finalize(wai_ctx* c, int nb, int slot0, int nslots, int phase) {
+  int4 sl = make_int4(slot0, slot0 + 1, slot0 + 2, slot0 + 3);
+  if (slot0 == S_DP2 && nslots == 2) sl = make_int4(S_DP2, S_RHONEW, 0, 0);
+  const int T = nb > 256 ? 1024 : 256;
+  hipLaunchKernelGGL(k_finalize, 1, T, 0, c->stream, c->ks.partials, c->ks.nb_max, nb, sl, nslots, c->ks.scal, phase);
+  return 0;
 }
 
 int vec_dot(wai_ctx* c, const double* a, const double* b, int n, int slot) {
   const int g = vgrid(n);
-  hipLaunchKernelGGL(k_dot, g, TPB, 0, c->stream, a, b, n, c->ks.partials, slot);
-  finalize(c, g, slot, 1);
-  return 0;
-}
-int vec_dot2(wai_ctx* c, const double* a, const double* b, const double* cc, const double* d,
-             int n, int slot) {
-  const int g = vgrid(n);
-  hipLaunchKernelGGL(k_dot2, g, TPB, 0, c->stream, a, b, cc, d, n, c->ks.partials, slot);
-  finalize(c, g, slot, 2);
-  return 0;
+  hipLaunchKernelGGL(k_dot, g, TPB, 0, c->stream, a, b, n, c->ks.partials, c->ks.nb_max, slot);
+  return vec_finalize(c, g, slot, 1, -1);
 }
 int vec_copy(wai_ctx* c, double* dst, const double* src, size_t n) {
   return hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream) == hipSuccess ? 0 : -1;
@@ -544,9 +769,8 @@ int bcgs_update_s(wai_ctx* c) {
 int bcgs_update_xr(wai_ctx* c) {
   const int g = vgrid(c->ks.n);
   hipLaunchKernelGGL(k_bcgs_xr, g, TPB, 0, c->stream, c->ks.X, c->ks.R, c->ks.P, c->ks.S, c->ks.T,
-                     c->ks.RP, c->ks.n, c->ks.scal, c->ks.partials);
-  finalize(c, g, S_DP2, 1);
-  finalize(c, g, S_RHONEW, 1);
+                     c->ks.RP, c->ks.n, c->ks.scal, c->ks.partials, c->ks.nb_max);
+  c->ks.nblocks = g;
   return 0;
 }
 int gmres_mdot(wai_ctx* c, const double* w, int k) {
@@ -554,25 +778,23 @@ int gmres_mdot(wai_ctx* c, const double* w, int k) {
   for (int j0 = 0; j0 < k; j0 += 8) {
     const int cnt = (k - j0) < 8 ? (k - j0) : 8;
     hipLaunchKernelGGL(k_mdot8, g, TPB, 0, c->stream, w, c->ks.basis, (size_t)c->ks.nl, j0, cnt, c->ks.n,
-                       c->ks.partials);
-    finalize(c, g, S_H + j0, cnt);
+                       c->ks.partials, c->ks.nb_max);
+    for (int q = 0; q < cnt; q += 4) vec_finalize(c, g, S_H + j0 + q, (cnt - q) < 4 ? (cnt - q) : 4, -1);
   }
   return 0;
 }
 int gmres_maxpy_norm(wai_ctx* c, double* w, int k) {
   const int g = vgrid(c->ks.n);
   hipLaunchKernelGGL(k_maxpy_norm, g, TPB, 0, c->stream, w, c->ks.basis, (size_t)c->ks.nl, k, c->ks.n,
-                     c->ks.scal, c->ks.partials);
-  finalize(c, g, S_W2, 1);
-  return 0;
+                     c->ks.scal, c->ks.partials, c->ks.nb_max);
+  return vec_finalize(c, g, S_W2, 1, -1);
 }
 int gmres_scale_to(wai_ctx* c, double* dst, const double* src, int slot_norm2, int n) {
   hipLaunchKernelGGL(k_scale_to, vgrid(n), TPB, 0, c->stream, dst, src, c->ks.scal, slot_norm2, n);
   return 0;
 }
 int gmres_update_x(wai_ctx* c, double* x, const double* ycoef_host, int k) {
-  // coefficients travel through the tail of the scalar buffer
-  double* dcoef = c->ks.scal + 64;
+  double* dcoef = c->ks.scal + 64;  // coefficients travel through the tail of the scalar buffer
   hipMemcpyAsync(dcoef, ycoef_host, sizeof(double) * k, hipMemcpyHostToDevice, c->stream);
   hipLaunchKernelGGL(k_update_x, vgrid(c->ks.n), TPB, 0, c->stream, x, c->ks.basis, (size_t)c->ks.nl, k,
                      c->ks.n, dcoef);

@@ -214,6 +214,11 @@ class FlowSimulation:
         self._chk(LIB.wai_timer_stop(self.h, C.byref(ms)), "timer_stop")
         return ms.value
 
+    def bench_kernel(self, which, reps=100):
+        ms = C.c_float(0)
+        self._chk(LIB.wai_bench_kernel(self.h, which, reps, C.byref(ms)), "bench_kernel")
+        return ms.value
+
     def synchronize(self):
         self._chk(LIB.wai_synchronize(self.h), "synchronize")
 

@@ -158,25 +158,33 @@ class StructuredGrid:
         hi = [self.ax[a].rank_hi[rc[a]] for a in range(3)]
         m = LocalMesh(dims=self.dims, spacing=self.spacing, part=self.part, rank=rank,
                       brick=self.brick, n_global=self.n_global)
-        # owned cells, in local order
-        I, J, K = np.meshgrid(np.arange(lo[0], hi[0]), np.arange(lo[1], hi[1]),
-                              np.arange(lo[2], hi[2]), indexing="ij")
-        I, J, K = I.ravel(), J.ravel(), K.ravel()
-        lid = self.local_id(rank, I, J, K)
-        n_owned = lid.size
-        order = np.empty(n_owned, dtype=np.int64)
-        order[lid] = np.arange(n_owned)
-        oi, oj, ok = I[order], J[order], K[order]
+        # natural-order (k,j,i) table of local ids over the owned block, padded by one cell for
+        # the halo slabs; everything below is slicing / broadcasting (no per-cell gathers)
+        ax, ay, az = self.ax
+        ri = np.arange(lo[0], hi[0]); rj = np.arange(lo[1], hi[1]); rk = np.arange(lo[2], hi[2])
+        starts, bshape = self._brick_starts(rc)
+        bidx = ((az.brick_in_rank[rk][:, None, None] * bshape[1] + ay.brick_in_rank[rj][None, :, None])
+                * bshape[2] + ax.brick_in_rank[ri][None, None, :])
+        within = ((az.off[rk][:, None, None] * ay.bsize[rj][None, :, None] + ay.off[rj][None, :, None])
+                  * ax.bsize[ri][None, None, :] + ax.off[ri][None, None, :])
+        lid3 = (starts[bidx] + within).astype(np.int64)
+        del bidx, within
+        nzl, nyl, nxl = lid3.shape
+        n_owned = lid3.size
+        nat_local = np.empty(n_owned, dtype=np.int64)   # local id -> natural index inside the block
+        nat_local[lid3.ravel()] = np.arange(n_owned)
+        ok, rem = np.divmod(nat_local, nyl * nxl)
+        oj, oi = np.divmod(rem, nxl)
+        del rem, nat_local
+        oi += lo[0]; oj += lo[1]; ok += lo[2]
         m.n_owned = n_owned
         m.owned_ijk = np.stack([oi, oj, ok], axis=1).astype(np.int32)
         m.owned_gid = self.natural_id(oi, oj, ok)
-        starts, _ = self._brick_starts(rc)
         m.sub_ptr = starts.astype(np.int32)
-        # lookup: (i,j,k) in padded owned block -> local index (owned or halo), -1 elsewhere
-        shp = (hi[0] - lo[0] + 2, hi[1] - lo[1] + 2, hi[2] - lo[2] + 2)
-        lut = np.full(shp, -1, dtype=np.int64)
-        lut[oi - lo[0] + 1, oj - lo[1] + 1, ok - lo[2] + 1] = np.arange(n_owned)
-        # halo slabs, neighbour order -x,+x,-y,+y,-z,+z
+        lut = np.full((nzl + 2, nyl + 2, nxl + 2), -1, dtype=np.int64)
+        lut[1:-1, 1:-1, 1:-1] = lid3
+        del lid3
+        # halo slabs, neighbour order -x,+x,-y,+y,-z,+z; slab cells in natural order
         nbr_ranks, send_idx, send_ptr, recv_ptr = [], [], [0], [0]
         halo_ijk = []
         for a in range(3):
@@ -187,22 +195,24 @@ class StructuredGrid:
                     continue
                 nrank = self.rank_id(*nrc)
                 rng = [np.arange(lo[b], hi[b]) for b in range(3)]
-                mine = [r.copy() for r in rng]
                 theirs = [r.copy() for r in rng]
-                mine[a] = np.array([lo[a] if sgn < 0 else hi[a] - 1])
                 theirs[a] = np.array([lo[a] - 1 if sgn < 0 else hi[a]])
-                # slab cells in natural order (x fastest)
                 TK, TJ, TI = np.meshgrid(theirs[2], theirs[1], theirs[0], indexing="ij")
-                MK, MJ, MI = np.meshgrid(mine[2], mine[1], mine[0], indexing="ij")
                 ti, tj, tk = TI.ravel(), TJ.ravel(), TK.ravel()
                 nh = ti.size
                 base = n_owned + recv_ptr[-1]
-                lut[ti - lo[0] + 1, tj - lo[1] + 1, tk - lo[2] + 1] = base + np.arange(nh)
+                # slices of the padded table: the slab itself and my boundary layer next to it
+                sl_t = [slice(1, -1), slice(1, -1), slice(1, -1)]   # (k, j, i)
+                sl_m = [slice(1, -1), slice(1, -1), slice(1, -1)]
+                pos_t = 0 if sgn < 0 else (hi[a] - lo[a] + 1)
+                pos_m = 1 if sgn < 0 else (hi[a] - lo[a])
+                sl_t[2 - a] = slice(pos_t, pos_t + 1)
+                sl_m[2 - a] = slice(pos_m, pos_m + 1)
+                lut[tuple(sl_t)] = (base + np.arange(nh)).reshape(lut[tuple(sl_t)].shape)
                 halo_ijk.append(np.stack([ti, tj, tk], axis=1))
                 nbr_ranks.append(nrank)
                 recv_ptr.append(recv_ptr[-1] + nh)
-                send_idx.append(lut[MI.ravel() - lo[0] + 1, MJ.ravel() - lo[1] + 1,
-                                    MK.ravel() - lo[2] + 1])
+                send_idx.append(lut[tuple(sl_m)].ravel().copy())
                 send_ptr.append(send_ptr[-1] + nh)
         m.n_halo = recv_ptr[-1]
         m.nbr_ranks = np.array(nbr_ranks, dtype=np.int32)
@@ -217,31 +227,32 @@ class StructuredGrid:
         m.extras["prim_ijk"] = np.stack([pi, pj, pk], axis=1)
         m.extras["prim_gid"] = self.natural_id(pi, pj, pk)
 
-        # interior faces: every face with at least one owned cell; c1 = lower index along the
-        # axis, normal = +axis for x,y; for z the cell with smaller k is the *upper* one
-        # (k = 0 is the top layer), normal = (0,0,-1), g.n = +9.8
+        # interior faces: every face with at least one owned cell, in natural order of the first
+        # cell; c1 = lower index along the axis, normal = +axis for x,y; for z the cell with
+        # smaller k is the *upper* one (k = 0 is the top layer), normal = (0,0,-1), g.n = +9.8
         fc, fg = [], []
         area = (dy * dz, dx * dz, dx * dy)
         dist = (dx, dy, dz)
         for a in range(3):
-            rng_lo = [lo[b] for b in range(3)]
-            rng_hi = [hi[b] for b in range(3)]
-            rng_lo[a] = max(lo[a] - 1, 0)
-            rng_hi[a] = min(hi[a], self.dims[a] - 1)  # first cell index of the pair
-            if rng_hi[a] <= rng_lo[a] and not (rng_hi[a] > rng_lo[a]):
-                pass
-            ck, cj, ci = np.meshgrid(np.arange(rng_lo[2], rng_hi[2]), np.arange(rng_lo[1], rng_hi[1]),
-                                     np.arange(rng_lo[0], rng_hi[0]), indexing="ij")
-            ci, cj, ck = ci.ravel(), cj.ravel(), ck.ravel()
-            if ci.size == 0:
+            # padded-table range of the first cell of each pair along axis a
+            first_lo = 0 if lo[a] > 0 else 1
+            first_hi = (hi[a] - lo[a] + 1) if hi[a] < self.dims[a] else (hi[a] - lo[a])
+            if first_hi <= first_lo:
                 continue
-            d = [0, 0, 0]
-            d[a] = 1
-            c1 = lut[ci - lo[0] + 1, cj - lo[1] + 1, ck - lo[2] + 1]
-            c2 = lut[ci + d[0] - lo[0] + 1, cj + d[1] - lo[1] + 1, ck + d[2] - lo[2] + 1]
-            keep = (c1 >= 0) & (c2 >= 0) & ((c1 < n_owned) | (c2 < n_owned))
-            c1, c2, ci, cj, ck = c1[keep], c2[keep], ci[keep], cj[keep], ck[keep]
-            g = np.zeros((c1.size, 12))
+            s1 = [slice(1, -1), slice(1, -1), slice(1, -1)]
+            s2 = [slice(1, -1), slice(1, -1), slice(1, -1)]
+            s1[2 - a] = slice(first_lo, first_hi)
+            s2[2 - a] = slice(first_lo + 1, first_hi + 1)
+            c1 = lut[tuple(s1)]
+            c2 = lut[tuple(s2)]
+            shp3 = c1.shape
+            c1 = c1.ravel(); c2 = c2.ravel()
+            # coordinates of the first cell
+            kk = np.arange(shp3[0]) + (lo[2] if a != 2 else lo[2] + first_lo - 1)
+            jj = np.arange(shp3[1]) + (lo[1] if a != 1 else lo[1] + first_lo - 1)
+            ii = np.arange(shp3[2]) + (lo[0] if a != 0 else lo[0] + first_lo - 1)
+            nfa = c1.size
+            g = np.zeros((nfa, 12))
             g[:, 0] = area[a]
             g[:, 1] = 0.5 * dist[a]
             g[:, 2] = 0.5 * dist[a]
@@ -249,9 +260,11 @@ class StructuredGrid:
             nsign = 1.0 if a < 2 else -1.0
             g[:, 4 + a] = nsign
             g[:, 7] = GRAVITY if a == 2 else 0.0   # g = (0,0,-9.8), n = (0,0,-1)
-            cen = np.stack([(ci + 0.5) * dx, (cj + 0.5) * dy, -(ck + 0.5) * dz], axis=1)
-            cen[:, a] += 0.5 * dist[a] * nsign
-            g[:, 8:11] = cen
+            g3 = g.reshape(shp3 + (12,))
+            g3[..., 8] = ((ii + 0.5) * dx)[None, None, :]
+            g3[..., 9] = ((jj + 0.5) * dy)[None, :, None]
+            g3[..., 10] = (-(kk + 0.5) * dz)[:, None, None]
+            g3[..., 8 + a] += 0.5 * dist[a] * nsign
             g[:, 11] = a + 1
             fc.append(np.stack([c1, c2], axis=1))
             fg.append(g)
