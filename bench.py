@@ -227,7 +227,7 @@ def main():
     b_spmv = spmv_bytes(nnzb, lm.n_owned, bs)
     achieved = b_spmv / (ms * 1e-3) / 1e9
     log("spmv: %.3f ms/launch, %.1f GB/s algorithmic (%.1f%% of %.0f)" % (ms, achieved, 100 * achieved / HBM_PEAK_GBS, HBM_PEAK_GBS))
-    kb = {name: sim.bench_kernel(w, 50) for w, name in enumerate(["spmv", "ilu_apply", "fused_pc_amul", "probe_ilu_nosweep", "probe_fused_nosweep"])}
+    kb = {name: sim.bench_kernel(w, 50) for w, name in enumerate(["spmv", "ilu_apply", "fused_pc_amul", "probe_ilu_nosweep", "probe_fused_nosweep", "ilu_apply_barrier_path", "fused_barrier_path"])}
     log("kernel microbench (ms/launch): " + json.dumps(kb))
     if prof:
         log("kernel-class time inside the timed region (ms, launches): " + json.dumps(prof))

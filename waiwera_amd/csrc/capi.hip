@@ -636,7 +636,7 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
     if (sub.front() != 0 || sub.back() != N) { c->err = "sub_ptr must cover [0, n_owned]"; return -2; }
     std::vector<int> info(N), levf(N), levb(N), nlev(s.nsub, 0);
     s.max_rows = 0; s.max_lev = 0;
-    bool offdiag_fill = false;
+    bool offdiag_fill = false, level_sorted = true, fast3 = true;
     for (int sd = 0; sd < s.nsub; sd++) {
       const int lo = sub[sd], hi = sub[sd + 1];
       if (hi < lo) { c->err = "sub_ptr not monotone"; return -2; }
@@ -676,6 +676,12 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
           }
         }
       }
+      for (int i = lo; i + 1 < hi; i++)
+        if (levf[i] > levf[i + 1] || levb[i] < levb[i + 1]) level_sorted = false;
+      for (int i = lo; i < hi; i++) {
+        const int nL = diag[i] - lfirst[i - lo], nU = ulast[i - lo] - diag[i] - 1;
+        if (nL > 3 || nU > 3 || lfirst[i - lo] > 3 || diag[i] > 3) fast3 = false;
+      }
       if (nlf > 1023 || nlb > 1023) { c->err = "more than 1023 dependency levels in a subdomain"; return -2; }
       for (int i = lo; i < hi; i++)
         info[i] = lfirst[i - lo] | (diag[i] << 4) | (ulast[i - lo] << 8) | (levf[i] << 12) | (levb[i] << 22);
@@ -691,6 +697,10 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
         dev_alloc(c, &s.fval, (size_t)J.W * np * np * N) || dev_alloc(c, &s.dinv, (size_t)np * np * N))
       return -1;
     s.diag_only = !offdiag_fill && !getenv("WAI_ILU_GENERAL");
+    // wave-pipelined sweeps (one wave at a time, no per-level barrier) measured slower than the
+    // barrier-per-level form on MI355X (0.373 vs 0.346 ms at 4.1 M rows): opt-in only
+    s.level_sorted = level_sorted && getenv("WAI_ILU_WAVEPIPE");
+    s.fast3 = fast3 && !getenv("WAI_ILU_NOFAST");
   }
   // state and work vectors
   const size_t nl = (size_t)np * m.n_prim, n = (size_t)np * N;
@@ -1127,11 +1137,11 @@ int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
   auto run = [&]() {
     switch (which) {
       case 0: launch_spmv(c, k.P, k.tmp); break;
-      case 1: case 3: launch_pc(c, false, k.P, k.V, 0, nullptr); break;
+      case 1: case 3: case 5: launch_pc(c, false, k.P, k.V, 0, nullptr); break;
       default: launch_pc(c, true, k.P, k.V, 1, k.RP); break;
     }
   };
-  c->dbg = (which >= 3) ? 1 : 0;
+  c->dbg = (which == 3 || which == 4) ? 1 : (which >= 5 ? 2 : 0);
   for (int i = 0; i < 5; i++) run();
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   for (int i = 0; i < reps; i++) run();

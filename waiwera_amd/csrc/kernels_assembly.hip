@@ -225,9 +225,10 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
   }
 
   // diagonal block: own state perturbed in component k
-  // block-ELL, slot-major SoA: entry e of slot q of row c lives at val[(q*bb + e)*n_owned + c]
+  // block-ELL planes: row r of the block in slot q of block-row c is the np-vector at
+  // val[((q*np + r)*n_owned + c)*np + k]  (kernels_linalg.hip, vix)
   const size_t nrow = m.n_owned;
-  double* dblk = val + (size_t)m.diag_blk[c] * bb * nrow + c;
+  double* dblk = val + ((size_t)m.diag_blk[c] * np * nrow + c) * np;
 #pragma unroll
   for (int k = 0; k < np; k++) {
     CellState<KIND> ownk;
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
 #pragma unroll
     for (int r = 0; r < np; r++) {
       const double f1 = (Lk[r] - lold[r]) - dt * R[r];
-      dblk[(size_t)(r * np + k) * nrow] = (f1 - f0[r]) / h;
+      dblk[(size_t)r * nrow * np + k] = (f1 - f0[r]) / h;
     }
   }
 
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
     load_face(m, fs >> 1, g);
     RockState roth;
     load_rock(m.rock, m.n_local, o, roth);
-    double* oblk = val + (size_t)blk * bb * nrow + c;
+    double* oblk = val + ((size_t)blk * np * nrow + c) * np;
 #pragma unroll
     for (int k = 0; k < np; k++) {
       CellState<KIND> othk;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
 #pragma unroll
       for (int r = 0; r < np; r++) {
         const double f1 = (L0[r] - lold[r]) - dt * (R[r] + src0[r]);
-        oblk[(size_t)(r * np + k) * nrow] += (f1 - f0[r]) / h;
+        oblk[(size_t)r * nrow * np + k] += (f1 - f0[r]) / h;
       }
     }
   }

@@ -35,6 +35,26 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
   return (b & 7) * per + (b >> 3);
 }
 
+// Matrix entry addressing.  Planes are indexed by (slot, row-in-block); element i of a plane is
+// the BS-vector holding that block row of block-row i:  val[((s*BS + r)*n + i)*BS + k].  For
+// BS = 2 a lane's access is one 16-byte double2 and a wave instruction moves 1 KiB.
+template <int BS>
+__device__ __forceinline__ size_t vix(int n, int s, int e, int i) {
+  return ((size_t)(s * BS + e / BS) * n + i) * BS + (e % BS);
+}
+// load the BS x BS block (slot s, block row i) into b[]
+template <int BS>
+__device__ __forceinline__ void load_block(const double* __restrict__ val, int n, int s, int i, double* b) {
+  if constexpr (BS == 2) {
+    const double2 r0 = *reinterpret_cast<const double2*>(val + ((size_t)(s * 2) * n + i) * 2);
+    const double2 r1 = *reinterpret_cast<const double2*>(val + ((size_t)(s * 2 + 1) * n + i) * 2);
+    b[0] = r0.x; b[1] = r0.y; b[2] = r1.x; b[3] = r1.y;
+  } else {
+#pragma unroll
+    for (int e = 0; e < BS * BS; e++) b[e] = val[vix<BS>(n, s, e, i)];
+  }
+}
+
 template <int BS>
 __device__ __forceinline__ void load_x(const double* __restrict__ x, int col, double* xv) {
   if constexpr (BS == 2) {
@@ -56,12 +76,13 @@ __device__ __forceinline__ void ell_row_mult(int n, int W, int i, const int* __r
   for (int s = 0; s < WMAX; s++) {
     if (s < W) {
       const int c = col[(size_t)s * n + i];
-      double xv[BS];
+      double xv[BS], a[BS * BS];
       load_x<BS>(x, c, xv);
+      load_block<BS>(val, n, s, i, a);
 #pragma unroll
       for (int r = 0; r < BS; r++)
 #pragma unroll
-        for (int k = 0; k < BS; k++) acc[r] += val[((size_t)s * BB + r * BS + k) * n + i] * xv[k];
+        for (int k = 0; k < BS; k++) acc[r] += a[r * BS + k] * xv[k];
     }
   }
 }
@@ -158,8 +179,8 @@ __global__ void k_ilu_factor(int n, int nsub, const int* __restrict__ sub_ptr,
         double w[BB], d[BB], t[BB];
 #pragma unroll
         for (int z = 0; z < BB; z++) {
-          w[z] = fval[((size_t)q * BB + z) * n + i];
-          d[z] = fval[((size_t)kd * BB + z) * n + k];
+          w[z] = fval[vix<BS>(n, q, z, i)];
+          d[z] = fval[vix<BS>(n, kd, z, k)];
         }
 #pragma unroll
         for (int r = 0; r < BS; r++)
@@ -171,14 +192,14 @@ __global__ void k_ilu_factor(int n, int nsub, const int* __restrict__ sub_ptr,
             t[r * BS + c] = acc;
           }
 #pragma unroll
-        for (int z = 0; z < BB; z++) fval[((size_t)q * BB + z) * n + i] = t[z];
+        for (int z = 0; z < BB; z++) fval[vix<BS>(n, q, z, i)] = t[z];
         for (int r2 = kd + 1; r2 < ku; r2++) {
           const int j = col[(size_t)r2 * n + k];
           for (int q2 = q + 1; q2 < ulast; q2++) {
             if (col[(size_t)q2 * n + i] != j) continue;
             double u[BB];
 #pragma unroll
-            for (int z = 0; z < BB; z++) u[z] = fval[((size_t)r2 * BB + z) * n + k];
+            for (int z = 0; z < BB; z++) u[z] = fval[vix<BS>(n, r2, z, k)];
 #pragma unroll
             for (int r = 0; r < BS; r++)
 #pragma unroll
@@ -186,7 +207,7 @@ __global__ void k_ilu_factor(int n, int nsub, const int* __restrict__ sub_ptr,
                 double acc = 0.0;
 #pragma unroll
                 for (int e = 0; e < BS; e++) acc += t[r * BS + e] * u[e * BS + c];
-                fval[((size_t)q2 * BB + r * BS + c) * n + i] -= acc;
+                fval[vix<BS>(n, q2, r * BS + c, i)] -= acc;
               }
             break;
           }
@@ -194,12 +215,12 @@ __global__ void k_ilu_factor(int n, int nsub, const int* __restrict__ sub_ptr,
       }
       double piv[BB], inv[BB];
 #pragma unroll
-      for (int z = 0; z < BB; z++) piv[z] = fval[((size_t)dslot * BB + z) * n + i];
+      for (int z = 0; z < BB; z++) piv[z] = fval[vix<BS>(n, dslot, z, i)];
       if (!block_inverse<BS>(piv, inv)) atomicMax(&flags[0], 1);
 #pragma unroll
       for (int z = 0; z < BB; z++) {
-        fval[((size_t)dslot * BB + z) * n + i] = inv[z];
-        dinv[(size_t)z * n + i] = inv[z];
+        fval[vix<BS>(n, dslot, z, i)] = inv[z];
+        dinv[vix<BS>(n, 0, z, i)] = inv[z];
       }
     }
     __threadfence_block();
@@ -235,14 +256,14 @@ __device__ __forceinline__ void wg_reduce_store(double (&v)[NS], double* red, do
 // L_ik = A_ik inv(D_k) and U_ij = A_ij exactly and the factor is just the modified pivots.  The
 // matrix row a thread pulled in for the SpMV is then reused for both substitutions and only the
 // inverted pivot block is read from the factor: ~300 instead of ~520 bytes per block row.
-template <int BS, bool SPMV, int DOT, bool DILU>
+template <int BS, bool SPMV, bool DILU, bool WP, bool FAST>
 __global__ void k_pc(int n, int W, int nsub, const int* __restrict__ sub_ptr,
                      const int* __restrict__ sub_nlev, const int* __restrict__ row_info,
                      const int* __restrict__ col, const double* __restrict__ aval,
                      const double* __restrict__ fval, const double* __restrict__ dinv,
                      const double* __restrict__ in,
                      double* __restrict__ z, const double* __restrict__ aux, double* partials,
-                     int nb_max, int dbg) {
+                     int nb_max, int dot, int dbg) {
   constexpr int BB = BS * BS;
   extern __shared__ double lds[];  // [T * BS] solution vector, then 32 doubles reduction scratch
   const int s = xcd_remap(blockIdx.x, nsub);
@@ -278,8 +299,7 @@ __global__ void k_pc(int n, int W, int nsub, const int* __restrict__ sub_ptr,
         if (q < W) {
           const int cg = col[(size_t)q * n + i];
           fc[q] = cg - lo;
-#pragma unroll
-          for (int e = 0; e < BB; e++) f[q][e] = aval[((size_t)q * BB + e) * n + i];
+          load_block<BS>(aval, n, q, i, f[q]);
           if constexpr (SPMV) {
             double xv[BS];
             load_x<BS>(in, cg, xv);
@@ -295,15 +315,14 @@ __global__ void k_pc(int n, int W, int nsub, const int* __restrict__ sub_ptr,
         }
       }
       if constexpr (!SPMV) load_x<BS>(in, i, acc);
-      if constexpr (SPMV && DOT == 2) load_x<BS>(in, i, xin);
-#pragma unroll
-      for (int e = 0; e < BB; e++) dv[e] = dinv[(size_t)e * n + i];
+      if (SPMV && dot == 2) load_x<BS>(in, i, xin);
+      load_block<BS>(dinv, n, 0, i, dv);
     } else {
       if constexpr (SPMV) {
 #pragma unroll
         for (int r = 0; r < BS; r++) acc[r] = 0.0;
         ell_row_mult<BS>(n, W, i, col, aval, in, acc);
-        if constexpr (DOT == 2) load_x<BS>(in, i, xin);
+        if (dot == 2) load_x<BS>(in, i, xin);
       } else {
         load_x<BS>(in, i, acc);
       }
@@ -312,8 +331,7 @@ __global__ void k_pc(int n, int W, int nsub, const int* __restrict__ sub_ptr,
       for (int q = 0; q < WMAX; q++) {
         if (q < W) {
           fc[q] = col[(size_t)q * n + i] - lo;
-#pragma unroll
-          for (int e = 0; e < BB; e++) f[q][e] = fval[((size_t)q * BB + e) * n + i];
+          load_block<BS>(fval, n, q, i, f[q]);
         }
       }
 #pragma unroll
@@ -339,14 +357,80 @@ __global__ void k_pc(int n, int W, int nsub, const int* __restrict__ sub_ptr,
 #pragma unroll
     for (int r = 0; r < BS; r++) ys[tid * BS + r] = acc[r];
   }
-  __syncthreads();
-  // forward substitution.  General: L y = t (unit block diagonal), LDS holds y.
-  // DILU: y_i = t_i - sum A_ik w_k with w_k = inv(D_k) y_k; LDS holds w.
-  for (int lev = 1; lev < nlf; lev++) {  // level-0 rows have no lower couplings
-    if (lf == lev) {
-      double a[BS];
+  // FAST: every row has at most 3 lower and 3 upper couplings inside its subdomain and the
+  // first in-subdomain slot / the diagonal slot are < 4 (7-point stencils, MINC chains).  The
+  // lower / upper blocks are compacted once into fixed positions with register selects, so a
+  // level update is 3 unconditional LDS reads + straight-line FMAs instead of one divergent
+  // branch and LDS wait per matrix slot.
+  constexpr int MLU = 3;
+  double Lf[MLU][BB], Uf[MLU][BB];
+  int Lc[MLU], Uc[MLU];
+  if constexpr (FAST) {
+    const int nL = dslot - lfirst, nU = ulast - dslot - 1;
 #pragma unroll
-      for (int r = 0; r < BS; r++) a[r] = ys[tid * BS + r];
+    for (int p = 0; p < MLU; p++) {
+      Lc[p] = tid; Uc[p] = tid;
+#pragma unroll
+      for (int e = 0; e < BB; e++) { Lf[p][e] = 0.0; Uf[p][e] = 0.0; }
+#pragma unroll
+      for (int o = 0; o < 4; o++) {  // candidate source slots p + o (lower), p + 1 + o (upper)
+        const bool tl = active && (lfirst == o) && (p < nL);
+        const bool tu = active && (dslot == o) && (p < nU);
+        if (p + o < WMAX) {
+          Lc[p] = tl ? fc[p + o] : Lc[p];
+#pragma unroll
+          for (int e = 0; e < BB; e++) Lf[p][e] = tl ? f[p + o][e] : Lf[p][e];
+        }
+        if (p + 1 + o < WMAX) {
+          Uc[p] = tu ? fc[p + 1 + o] : Uc[p];
+#pragma unroll
+          for (int e = 0; e < BB; e++) Uf[p][e] = tu ? f[p + 1 + o][e] : Uf[p][e];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // One forward-level / backward-level update of this thread's row, out of LDS.
+  // General: L y = t (unit block diagonal), then x_i = inv(D_i) (y_i - sum U_ij x_j).
+  // DILU:    y_i = t_i - sum A_ik w_k with w_k = inv(D_k) y_k (LDS holds w), then
+  //          x_i = w_i - inv(D_i) sum A_ij x_j.
+  double out[BS];
+#pragma unroll
+  for (int r = 0; r < BS; r++) out[r] = 0.0;
+  auto gather3 = [&](const int (&cc)[MLU], const double (&ff)[MLU][BB], double* sum) {
+    double yk[MLU][BS];
+#pragma unroll
+    for (int p = 0; p < MLU; p++) {
+      if constexpr (BS == 2) {
+        const double2 t = *reinterpret_cast<const double2*>(ys + cc[p] * 2);
+        yk[p][0] = t.x; yk[p][1] = t.y;
+      } else {
+#pragma unroll
+        for (int c = 0; c < BS; c++) yk[p][c] = ys[cc[p] * BS + c];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < BS; r++) {
+      double part[MLU];
+#pragma unroll
+      for (int p = 0; p < MLU; p++) {
+        part[p] = 0.0;
+#pragma unroll
+        for (int c = 0; c < BS; c++) part[p] += ff[p][r * BS + c] * yk[p][c];
+      }
+      sum[r] = (part[0] + part[1]) + part[2];
+    }
+  };
+  auto fwd_row = [&]() {
+    double a[BS];
+#pragma unroll
+    for (int r = 0; r < BS; r++) a[r] = ys[tid * BS + r];
+    if constexpr (FAST) {
+      double sum[BS];
+      gather3(Lc, Lf, sum);
+#pragma unroll
+      for (int r = 0; r < BS; r++) a[r] -= sum[r];
+    } else {
 #pragma unroll
       for (int q = 0; q < WMAX; q++) {
         if (q >= lfirst && q < dslot) {
@@ -359,32 +443,28 @@ __global__ void k_pc(int n, int W, int nsub, const int* __restrict__ sub_ptr,
             for (int c = 0; c < BS; c++) a[r] -= f[q][r * BS + c] * yk[c];
         }
       }
-      if constexpr (DILU) {
-        double w1[BS];
+    }
+    if constexpr (DILU) {
+      double w1[BS];
 #pragma unroll
-        for (int r = 0; r < BS; r++) {
-          w1[r] = 0.0;
+      for (int r = 0; r < BS; r++) {
+        w1[r] = 0.0;
 #pragma unroll
-          for (int k = 0; k < BS; k++) w1[r] += dv[r * BS + k] * a[k];
-        }
-#pragma unroll
-        for (int r = 0; r < BS; r++) a[r] = w1[r];
+        for (int k = 0; k < BS; k++) w1[r] += dv[r * BS + k] * a[k];
       }
 #pragma unroll
-      for (int r = 0; r < BS; r++) ys[tid * BS + r] = a[r];
+      for (int r = 0; r < BS; r++) a[r] = w1[r];
     }
-    __syncthreads();
-  }
-  // backward substitution.  General: x_i = inv(D_i) (y_i - sum U_ij x_j).
-  // DILU: x_i = w_i - inv(D_i) sum A_ij x_j.
-  double out[BS];
 #pragma unroll
-  for (int r = 0; r < BS; r++) out[r] = 0.0;
-  for (int lev = 0; lev < nlb; lev++) {
-    if (lb == lev) {
-      double a[BS], sum[BS];
+    for (int r = 0; r < BS; r++) ys[tid * BS + r] = a[r];
+  };
+  auto bwd_row = [&]() {
+    double a[BS], sum[BS];
 #pragma unroll
-      for (int r = 0; r < BS; r++) { a[r] = ys[tid * BS + r]; sum[r] = 0.0; }
+    for (int r = 0; r < BS; r++) { a[r] = ys[tid * BS + r]; sum[r] = 0.0; }
+    if constexpr (FAST) {
+      gather3(Uc, Uf, sum);
+    } else {
 #pragma unroll
       for (int q = 0; q < WMAX; q++) {
         if (q > dslot && q < ulast) {
@@ -397,27 +477,61 @@ __global__ void k_pc(int n, int W, int nsub, const int* __restrict__ sub_ptr,
             for (int c = 0; c < BS; c++) sum[r] += f[q][r * BS + c] * xk[c];
         }
       }
+    }
+#pragma unroll
+    for (int r = 0; r < BS; r++) {
+      double t = 0.0;
       if constexpr (DILU) {
 #pragma unroll
-        for (int r = 0; r < BS; r++) {
-          double t = 0.0;
-#pragma unroll
-          for (int c = 0; c < BS; c++) t += dv[r * BS + c] * sum[c];
-          out[r] = a[r] - t;
-        }
+        for (int c = 0; c < BS; c++) t += dv[r * BS + c] * sum[c];
+        out[r] = a[r] - t;
       } else {
 #pragma unroll
-        for (int r = 0; r < BS; r++) {
-          double t = 0.0;
+        for (int c = 0; c < BS; c++) t += dv[r * BS + c] * (a[c] - sum[c]);
+        out[r] = t;
+      }
+    }
 #pragma unroll
-          for (int c = 0; c < BS; c++) t += dv[r * BS + c] * (a[c] - sum[c]);
-          out[r] = t;
+    for (int r = 0; r < BS; r++) ys[tid * BS + r] = out[r];
+  };
+  if constexpr (WP) {
+    // Rows are stored in level order (forward levels ascending, backward levels descending along
+    // the subdomain), so wave w owns a contiguous run of levels.  Waves take turns: inside its
+    // turn a wave walks its levels with no barrier at all (LDS traffic of one wave is in order),
+    // and only the hand-over to the next wave is a workgroup barrier: 2 x (#waves) barriers
+    // instead of one per level.
+    const int wave = tid >> 6, nw = (int)(blockDim.x >> 6);
+    const int nact = min(64, max(0, R - wave * 64));  // active lanes form a prefix of the wave
+    const int lf_first = __shfl(lf, 0), lf_last = __shfl(lf, nact > 0 ? nact - 1 : 0);
+    const int lb_first = __shfl(lb, 0), lb_last = __shfl(lb, nact > 0 ? nact - 1 : 0);
+    for (int ph = 0; ph < ((dbg & 1) ? 0 : nw); ph++) {
+      if (wave == ph && nact > 0) {
+        for (int lev = max(lf_first, DILU ? 1 : 1); lev <= lf_last; lev++) {
+          if (lf == lev) fwd_row();
+          __builtin_amdgcn_wave_barrier();
         }
       }
-#pragma unroll
-      for (int r = 0; r < BS; r++) ys[tid * BS + r] = out[r];
+      __syncthreads();
     }
-    if (lev + 1 < nlb) __syncthreads();
+    if (dbg & 1) bwd_row();
+    for (int ph = ((dbg & 1) ? -1 : nw - 1); ph >= 0; ph--) {
+      if (wave == ph && nact > 0) {
+        for (int lev = lb_last; lev <= lb_first; lev++) {
+          if (lb == lev) bwd_row();
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      if (ph > 0) __syncthreads();
+    }
+  } else {
+    for (int lev = 1; lev < nlf; lev++) {  // level-0 rows have no lower couplings
+      if (lf == lev) fwd_row();
+      __syncthreads();
+    }
+    for (int lev = 0; lev < nlb; lev++) {
+      if (lb == lev) bwd_row();
+      if (lev + 1 < nlb) __syncthreads();
+    }
   }
   if (active) {
     if constexpr (BS == 2) *reinterpret_cast<double2*>(z + (size_t)i * 2) = make_double2(out[0], out[1]);
@@ -426,55 +540,49 @@ __global__ void k_pc(int n, int W, int nsub, const int* __restrict__ sub_ptr,
       for (int r = 0; r < BS; r++) z[(size_t)i * BS + r] = out[r];
     }
   }
-  if constexpr (DOT != 0) {
+  if (dot != 0) {
     double* red = lds + (size_t)blockDim.x * BS;
-    if constexpr (DOT == 1) {  // (z, aux)
-      double v[1] = {0.0};
+    double v[2] = {0.0, 0.0};
+    int slots[2] = {S_D1, S_D2};
+    if (dot == 1) {  // (z, aux)
       if (active) {
         double av[BS];
         load_x<BS>(aux, i, av);
 #pragma unroll
         for (int r = 0; r < BS; r++) v[0] += out[r] * av[r];
       }
-      const int slots[1] = {S_D1};
-      __syncthreads();
-      wg_reduce_store<1>(v, red, partials, nb_max, slots, s);
-    } else if constexpr (DOT == 2) {  // (in, z), (z, z)
-      double v[2] = {0.0, 0.0};
+    } else if (dot == 2) {  // (in, z), (z, z)
 #pragma unroll
       for (int r = 0; r < BS; r++) { v[0] += xin[r] * out[r]; v[1] += out[r] * out[r]; }
-      const int slots[2] = {S_D1, S_D2};
-      __syncthreads();
-      wg_reduce_store<2>(v, red, partials, nb_max, slots, s);
     } else {  // (z, z)
-      double v[1] = {0.0};
 #pragma unroll
       for (int r = 0; r < BS; r++) v[0] += out[r] * out[r];
-      const int slots[1] = {S_DP2};
-      __syncthreads();
-      wg_reduce_store<1>(v, red, partials, nb_max, slots, s);
+      slots[0] = S_DP2;
     }
+    __syncthreads();
+    if (dot == 2) wg_reduce_store<2>(v, red, partials, nb_max, slots, s);
+    else { double v1[1] = {v[0]}; wg_reduce_store<1>(v1, red, partials, nb_max, slots, s); }
   }
 }
 
 // ---- layout conversion (C ABI exchanges BCSR) -------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_ell_to_bcsr(int n, int W, int bb, const int* __restrict__ rowptr,
+__global__ __launch_bounds__(TPB) void k_ell_to_bcsr(int n, int W, int bs, const int* __restrict__ rowptr,
                                                      const double* __restrict__ ell, double* __restrict__ bcsr) {
   const size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;
   if (t >= (size_t)n * W) return;
   const int s = (int)(t / n), i = (int)(t - (size_t)s * n);
-  const int a = rowptr[i], cnt = rowptr[i + 1] - a;
+  const int a = rowptr[i], cnt = rowptr[i + 1] - a, bb = bs * bs;
   if (s >= cnt) return;
-  for (int e = 0; e < bb; e++) bcsr[(size_t)(a + s) * bb + e] = ell[((size_t)s * bb + e) * n + i];
+  for (int e = 0; e < bb; e++) bcsr[(size_t)(a + s) * bb + e] = ell[((size_t)(s * bs + e / bs) * n + i) * bs + (e % bs)];
 }
-__global__ __launch_bounds__(TPB) void k_bcsr_to_ell(int n, int W, int bb, const int* __restrict__ rowptr,
+__global__ __launch_bounds__(TPB) void k_bcsr_to_ell(int n, int W, int bs, const int* __restrict__ rowptr,
                                                      const double* __restrict__ bcsr, double* __restrict__ ell) {
   const size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;
   if (t >= (size_t)n * W) return;
   const int s = (int)(t / n), i = (int)(t - (size_t)s * n);
-  const int a = rowptr[i], cnt = rowptr[i + 1] - a;
+  const int a = rowptr[i], cnt = rowptr[i + 1] - a, bb = bs * bs;
   for (int e = 0; e < bb; e++)
-    ell[((size_t)s * bb + e) * n + i] = (s < cnt) ? bcsr[(size_t)(a + s) * bb + e] : 0.0;
+    ell[((size_t)(s * bs + e / bs) * n + i) * bs + (e % bs)] = (s < cnt) ? bcsr[(size_t)(a + s) * bb + e] : 0.0;
 }
 
 // ---- K9: fused vector kernels -----------------------------------------------------------------
@@ -689,21 +797,24 @@ static void launch_pc_bs(wai_ctx* c, bool spmv, const double* in, double* z, int
   const IluSchedule& s = c->ilu;
   const int grid = ((s.nsub + 7) / 8) * 8, T = pc_threads(c);
   const size_t lds = ((size_t)T * BS + 32) * sizeof(double);
-#define PCL(SP, DT)                                                                              \
+#define PCL(SP, DI, WPP)                                                                        \
   do {                                                                                           \
-    if (s.diag_only)                                                                             \
-      hipLaunchKernelGGL((k_pc<BS, SP, DT, true>), grid, T, lds, c->stream, J.n, J.W, s.nsub,    \
-                         s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.fval, s.dinv, in, z, \
-                         aux, c->ks.partials, c->ks.nb_max, c->dbg);                             \
+    if (s.fast3)                                                                                 \
+      hipLaunchKernelGGL((k_pc<BS, SP, DI, WPP, true>), grid, T, lds, c->stream, J.n, J.W,       \
+                         s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.fval,        \
+                         s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, c->dbg);    \
     else                                                                                         \
-      hipLaunchKernelGGL((k_pc<BS, SP, DT, false>), grid, T, lds, c->stream, J.n, J.W, s.nsub,   \
-                         s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.fval, s.dinv, in, z, \
-                         aux, c->ks.partials, c->ks.nb_max, c->dbg);                             \
+      hipLaunchKernelGGL((k_pc<BS, SP, DI, WPP, false>), grid, T, lds, c->stream, J.n, J.W,      \
+                         s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.fval,        \
+                         s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, c->dbg);    \
   } while (0)
+  const bool wp = s.level_sorted && !(c->dbg & 2);
   if (spmv) {
-    if (dot_mode == 1) PCL(true, 1); else if (dot_mode == 2) PCL(true, 2); else if (dot_mode == 3) PCL(true, 3); else PCL(true, 0);
+    if (s.diag_only) { if (wp) PCL(true, true, true); else PCL(true, true, false); }
+    else { if (wp) PCL(true, false, true); else PCL(true, false, false); }
   } else {
-    if (dot_mode == 1) PCL(false, 1); else if (dot_mode == 3) PCL(false, 3); else PCL(false, 0);
+    if (s.diag_only) { if (wp) PCL(false, true, true); else PCL(false, true, false); }
+    else { if (wp) PCL(false, false, true); else PCL(false, false, false); }
   }
 #undef PCL
 }
@@ -721,13 +832,13 @@ int launch_pc(wai_ctx* c, bool spmv, const double* in, double* z, int dot_mode, 
 int launch_ell_to_bcsr(wai_ctx* c, const double* ell, double* bcsr) {
   const Bcsr& J = c->J;
   const size_t tot = (size_t)J.n * J.W;
-  hipLaunchKernelGGL(k_ell_to_bcsr, (int)((tot + TPB - 1) / TPB), TPB, 0, c->stream, J.n, J.W, J.bs * J.bs, J.rowptr, ell, bcsr);
+  hipLaunchKernelGGL(k_ell_to_bcsr, (int)((tot + TPB - 1) / TPB), TPB, 0, c->stream, J.n, J.W, J.bs, J.rowptr, ell, bcsr);
   return 0;
 }
 int launch_bcsr_to_ell(wai_ctx* c, const double* bcsr, double* ell) {
   const Bcsr& J = c->J;
   const size_t tot = (size_t)J.n * J.W;
-  hipLaunchKernelGGL(k_bcsr_to_ell, (int)((tot + TPB - 1) / TPB), TPB, 0, c->stream, J.n, J.W, J.bs * J.bs, J.rowptr, bcsr, ell);
+  hipLaunchKernelGGL(k_bcsr_to_ell, (int)((tot + TPB - 1) / TPB), TPB, 0, c->stream, J.n, J.W, J.bs, J.rowptr, bcsr, ell);
   return 0;
 }
 

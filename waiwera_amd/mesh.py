@@ -99,7 +99,12 @@ class LocalMesh:
 class StructuredGrid:
     """Global description of an nx*ny*nz box split over px*py*pz ranks."""
 
-    def __init__(self, dims, spacing=(10.0, 10.0, 10.0), part=(1, 1, 1), brick=(8, 8, 8)):
+    def __init__(self, dims, spacing=(10.0, 10.0, 10.0), part=(1, 1, 1), brick=(8, 8, 8),
+                 order="hyperplane"):
+        # order: numbering of the cells inside a brick.  "hyperplane" sorts them by i+j+k (ties in
+        # natural order) = by dependency level of the brick's ILU(0) factors, so storage order is
+        # level order and a wavefront owns whole consecutive levels; "natural" is x-fastest.
+        self.order = order
         self.dims = tuple(int(v) for v in dims)
         self.spacing = tuple(float(v) for v in spacing)
         self.part = tuple(int(v) for v in part)
@@ -167,6 +172,24 @@ class StructuredGrid:
                 * bshape[2] + ax.brick_in_rank[ri][None, None, :])
         within = ((az.off[rk][:, None, None] * ay.bsize[rj][None, :, None] + ay.off[rj][None, :, None])
                   * ax.bsize[ri][None, None, :] + ax.off[ri][None, None, :])
+        if self.order == "hyperplane":
+            ux, ix_id = np.unique(ax.bsize[ri], return_inverse=True)
+            uy, iy_id = np.unique(ay.bsize[rj], return_inverse=True)
+            uz, iz_id = np.unique(az.bsize[rk], return_inverse=True)
+            maxvol = int(ux.max() * uy.max() * uz.max())
+            tables = np.zeros((len(uz) * len(uy) * len(ux), maxvol), dtype=np.int64)
+            for a_, sz_ in enumerate(uz):
+                for b_, sy_ in enumerate(uy):
+                    for c_, sx_ in enumerate(ux):
+                        oz_, oy_, ox_ = np.meshgrid(np.arange(sz_), np.arange(sy_), np.arange(sx_), indexing="ij")
+                        nat = ((oz_ * sy_ + oy_) * sx_ + ox_).ravel()
+                        key = (oz_ + oy_ + ox_).ravel() * nat.size + nat
+                        hrank = np.empty(nat.size, dtype=np.int64)
+                        hrank[np.argsort(key, kind="stable")] = np.arange(nat.size)
+                        tables[(a_ * len(uy) + b_) * len(ux) + c_, nat] = hrank
+            sid3 = ((iz_id[:, None, None] * len(uy) + iy_id[None, :, None]) * len(ux) + ix_id[None, None, :])
+            within = tables[sid3, within]
+            del sid3
         lid3 = (starts[bidx] + within).astype(np.int64)
         del bidx, within
         nzl, nyl, nxl = lid3.shape
