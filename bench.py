@@ -92,6 +92,24 @@ def spmv_bytes(nnzb, n, bs):
     return nnzb * (8 * bs * bs + 4) + 4 * (n + 1) + 2 * 8 * bs * n
 
 
+def pc_bytes(nnzb, n, bs):
+    """Algorithmic bytes of one fused preconditioned-operator launch: the
+    matrix once (blocks + int32 columns), the inverted pivot blocks, the packed row descriptor,
+    and three vectors (x read, z written, aux read for the fused dot)."""
+    return nnzb * (8 * bs * bs + 4) + n * (8 * bs * bs + 4 + 3 * 8 * bs)
+
+
+def traffic_from_env():
+    """HBM bytes per k_pc launch from the rocprofv3 PMC passes (profiles/), when recorded."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic_r1.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get("k_pc_hbm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
 def cpu_baseline(dims_full, seconds=15.0):
     """Oracle (CPU restatement of the reference path) on a bounded sample of the same workload:
     whole Newton steps on a smaller box of the same synthetic problem, one core."""
@@ -210,25 +228,23 @@ def main():
     for rec in drv.log:
         log("  step %d dt %.3g newton %d krylov %d reason %d maxres %.3e" % rec)
 
-    # BCSR SpMV on the last assembled Jacobian: HIP events on the library's stream
+    # Kernel roofline, measured live with HIP events on the library's stream on the last
+    # assembled Jacobian.  Dominant kernel of a Newton step: the fused preconditioned operator
+    # k_pc (block SpMV t = A x, block-Jacobi ILU(0) solve z = U^-1 L^-1 t, dot (z, aux)), run
+    # twice per BiCGStab iteration.  Plain block SpMV is reported beside it.
     n = lm.n_owned * bs
     nnzb = wl.LIB.wai_jacobian_nnzb(sim.h)
-    xv = torch.zeros(sim.n_prim * bs, dtype=torch.float64, device="cuda")
-    xv[:n].copy_(torch.from_numpy(np.random.default_rng(7).uniform(-1, 1, n)))
-    yv = torch.zeros(n, dtype=torch.float64, device="cuda")
-    torch.cuda.synchronize()
-    for _ in range(20):
-        sim.spmv(xv, yv)
-    sim.synchronize()
-    sim.timer_start()
-    for _ in range(a.spmv_reps):
-        sim.spmv(xv, yv)
-    ms = sim.timer_stop() / a.spmv_reps
-    b_spmv = spmv_bytes(nnzb, lm.n_owned, bs)
-    achieved = b_spmv / (ms * 1e-3) / 1e9
-    log("spmv: %.3f ms/launch, %.1f GB/s algorithmic (%.1f%% of %.0f)" % (ms, achieved, 100 * achieved / HBM_PEAK_GBS, HBM_PEAK_GBS))
-    kb = {name: sim.bench_kernel(w, 50) for w, name in enumerate(["spmv", "ilu_apply", "fused_pc_amul", "probe_ilu_nosweep", "probe_fused_nosweep", "ilu_apply_barrier_path", "fused_barrier_path"])}
+    names = ["spmv", "ilu_apply", "fused_pc_amul", "probe_ilu_nosweep", "probe_fused_nosweep",
+             "ilu_apply_barrier_path", "fused_barrier_path"]
+    kb = {name: sim.bench_kernel(w, a.spmv_reps if w in (0, 2) else 20) for w, name in enumerate(names)}
     log("kernel microbench (ms/launch): " + json.dumps(kb))
+    b_spmv = spmv_bytes(nnzb, lm.n_owned, bs)
+    b_pc = pc_bytes(nnzb, lm.n_owned, bs)
+    ms, ms_pc = kb["spmv"], kb["fused_pc_amul"]
+    achieved = b_spmv / (ms * 1e-3) / 1e9
+    achieved_pc = b_pc / (ms_pc * 1e-3) / 1e9
+    log("spmv: %.3f ms/launch, %.1f GB/s algorithmic (%.1f%% of %.0f); fused pc: %.3f ms, %.1f GB/s (%.1f%%)"
+        % (ms, achieved, 100 * achieved / HBM_PEAK_GBS, HBM_PEAK_GBS, ms_pc, achieved_pc, 100 * achieved_pc / HBM_PEAK_GBS))
     if prof:
         log("kernel-class time inside the timed region (ms, launches): " + json.dumps(prof))
 
@@ -243,9 +259,12 @@ def main():
                                    % (dims + (grid.n_global,) + tuple(a.brick)),
                        "krylov_iterations_per_newton_step": kits / max(a.steps, 1),
                        "partition": "x".join(str(p) for p in grid.part), "ksp": a.ksp},
-            "roofline": {"bound": "hbm", "kernel": "k_spmv<2> (BCSR SpMV)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": b_spmv, "ms_per_launch": ms},
+            "roofline": {"bound": "hbm", "kernel": "k_pc<2,spmv,dilu> (fused BCSR SpMV + block ILU(0) apply + dot)",
+                         "achieved": achieved_pc, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_pc / HBM_PEAK_GBS, "traffic": traffic_from_env(),
+                         "algorithmic_bytes_per_launch": b_pc, "ms_per_launch": ms_pc,
+                         "spmv": {"kernel": "k_spmv<2> (BCSR SpMV)", "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+                                  "algorithmic_bytes_per_launch": b_spmv, "ms_per_launch": ms}},
         }
         if not a.no_cpu:
             cb = cpu_baseline(dims)
