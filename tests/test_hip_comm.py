@@ -1,0 +1,30 @@
+"""RCCL plumbing on ONE GPU: a 1-rank communicator whose only neighbour is itself.  The halo
+cells of a 2-rank partition's rank-0 mesh are filled by ncclSend/ncclRecv to self, which
+exercises pack -> group send/recv -> unpack and the all-reduce path of the library exactly as
+an N-rank run does (multi-GPU boxes are not available to the tests)."""
+import numpy as np
+import pytest
+
+from waiwera_amd import mesh as M
+
+pytestmark = pytest.mark.gpu
+
+
+def test_self_halo_exchange_and_allreduce():
+    from waiwera_amd import lib as wl
+    from waiwera_amd.flow_simulation import FlowSimulation
+    g = M.StructuredGrid((8, 8, 8), part=(2, 1, 1), brick=(4, 4, 4))
+    lm = g.local_mesh(0, top_bc=([1.0e5, 20.0], 1))
+    assert lm.n_halo > 0 and list(lm.nbr_ranks) == [1]
+    lm.nbr_ranks = np.array([0], dtype=np.int32)     # talk to myself
+    sim = FlowSimulation(lm, eos="we")
+    sim.comm_init(0, 1, wl.comm_unique_id())
+    rng = np.random.default_rng(0)
+    for dof in (1, 2):
+        v = np.zeros(lm.n_prim * dof)
+        v[: lm.n_owned * dof] = rng.normal(size=lm.n_owned * dof)
+        rc = wl.LIB.wai_halo_exchange(sim.h, v.ctypes.data, dof)
+        assert rc == 0, wl.LIB.wai_last_error(sim.h)
+        want = v[: lm.n_owned * dof].reshape(-1, dof)[lm.send_idx].ravel()
+        assert np.array_equal(v[lm.n_owned * dof:], want)
+    sim.destroy()

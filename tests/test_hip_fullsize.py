@@ -1,0 +1,91 @@
+"""Full-size (BASELINE configs[1]: 100^3 = 1 M cells, eos we) checks through size-independent
+properties -- the oracle would need minutes here, so no element-wise comparison:
+linearity of the block SpMV, SpMV against the BCSR values fetched through the ABI, the Krylov
+solution verified by an independent residual, mass conservation of the flux sweep, and
+Newton-step residual reduction."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from tests.cases import scaled
+from waiwera_amd import mesh as M
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big():
+    from waiwera_amd.flow_simulation import FlowSimulation
+    g = M.StructuredGrid((100, 100, 100), brick=(8, 8, 8))
+    lm = g.local_mesh(0, rock_fn=M.heterogeneous_rock(g.n_global), top_bc=None, sources=M.benchmark_sources(g))
+    prim, region = M.benchmark_initial_state(g, lm.extras["prim_ijk"], lens=True)
+    sim = FlowSimulation(lm, eos="we")
+    sim.set_regions(region)
+    y = scaled(prim, region).ravel().copy()
+    yield g, lm, sim, y
+    sim.destroy()
+
+
+def test_mass_conservation_of_the_flux_sweep(big):
+    """Closed box: interior fluxes cancel, so sum_i V_i R_i(mass) equals the net source rate."""
+    g, lm, sim, y = big
+    n = sim.n_owned * 2
+    assert sim.pre_eval(0.0, y) == 0
+    R = np.zeros(n)
+    sim.rhs(0.0, (0.0, 0.0), y, R)
+    vol = lm.cell_geom[: lm.n_owned, 3]
+    net = float(np.sum(vol * R[0::2]))
+    assert abs(net - lm.src_rate.sum()) <= 1e-9 * np.abs(lm.src_rate).sum()
+
+
+def test_spmv_linearity_and_values(big):
+    g, lm, sim, y = big
+    n = sim.n_owned * 2
+    L = np.zeros(n)
+    sim.lhs(0.0, (0.0, 0.0), y, L)
+    f = np.zeros(n)
+    dt = 1.0e4
+    assert sim.residual(dt, dt, y, L, f) == 0
+    assert sim.jacobian(dt, dt, y, L) == 0
+    rng = np.random.default_rng(7)
+    x1, x2 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    a, b = 0.37, -1.9
+    y1, y2, y12 = np.zeros(n), np.zeros(n), np.zeros(n)
+    sim.spmv(x1, y1); sim.spmv(x2, y2); sim.spmv(a * x1 + b * x2, y12)
+    assert np.abs(y12 - (a * y1 + b * y2)).max() <= 1e-12 * np.abs(y12).max()
+    rp, ci = sim.setup_jacobian()
+    val = sim.jacobian_values().reshape(-1, 2, 2)
+    A = sp.bsr_matrix((val, ci, rp), shape=(n, n))
+    ref = A @ x1
+    assert np.abs(y1 - ref).max() <= 1e-12 * np.abs(ref).max()
+    # Krylov solve checked with the independent scipy operator
+    sim.set_opts(ksp_rtol=1e-8)
+    x = np.zeros(n)
+    its, reason, rn = sim.ksp_solve(f, x)
+    assert reason > 0
+    z, zb = np.zeros(n), np.zeros(n)
+    sim.pc_apply(A @ x - f, z); sim.pc_apply(f, zb)   # preconditioned residual norm is what KSP tests
+    assert np.linalg.norm(z) <= 2e-8 * np.linalg.norm(zb)
+    sim.set_opts(ksp_rtol=1e-5)
+
+
+def test_newton_steps_reduce_the_residual(big):
+    g, lm, sim, y = big
+    n = sim.n_owned * 2
+    yy = y.copy()
+    dt = 2.0e3
+    sim.pre_timestep()
+    assert sim.pre_eval(0.0, yy) == 0
+    L, f = np.zeros(n), np.zeros(n)
+    sim.lhs(0.0, (0.0, 0.0), yy, L)
+    assert sim.residual(dt, dt, yy, L, f) == 0
+    r0, _ = sim.max_scaled(f, L, 1.0)
+    hist = [r0]
+    for it in range(4):
+        reason, kits, maxres = sim.newton_step(dt, dt, it, yy, L, f)
+        assert reason >= 0
+        hist.append(maxres)
+        if reason > 0:
+            break
+    assert hist[-1] < 1e-2 * hist[0]
+    assert set(np.unique(sim.regions())) <= {1, 2, 4}

@@ -1,0 +1,155 @@
+"""Cross-checks of the oracle's PETSc-restated half (parity unpinned at iterate level) against
+scipy / dense numpy on the same operators, and of the FD Jacobian against directional
+derivatives of the residual."""
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from tests import oracle_lib as ol
+from tests.cases import make_case, scaled
+
+
+def setup(oracle, dims=(6, 5, 4), brick=(3, 3, 2), eos="we", lens=False, dt=2.0e4):
+    g, lm, prim, region = make_case(dims=dims, brick=brick, eos=eos, lens=lens)
+    sim = ol.OracleSim(oracle, lm, 1 if eos == "we" else 0)
+    sim.set_regions(region)
+    y = sim.yvec(scaled(prim, region, eos).ravel())
+    assert sim.pre_eval(y) == 0
+    L = sim.lhs()
+    err, f = sim.residual(y, dt, L)
+    assert err == 0
+    err, J = sim.jacobian(y, dt, L, f, mode=0)
+    assert err == 0
+    return lm, sim, y, L, f, J, dt
+
+
+def to_bsr(sim, J):
+    rp, ci = sim.pattern()
+    bs = sim.np
+    return sp.bsr_matrix((J.reshape(-1, bs, bs), ci, rp), shape=(sim.n_owned * bs, sim.n_prim * bs)).tocsr()
+
+
+def test_spmv_matches_scipy_bsr(oracle):
+    lm, sim, y, L, f, J, dt = setup(oracle)
+    A = to_bsr(sim, J)
+    rp, ci = sim.pattern()
+    x = np.random.default_rng(1).normal(size=sim.n_owned * sim.np)
+    out = np.zeros_like(x)
+    oracle.wo_bcsr_spmv(sim.n_owned, sim.np, ol.ip(rp), ol.ip(ci), ol.dp(J), ol.dp(x), ol.dp(out))
+    assert np.allclose(out, A @ x, rtol=1e-13, atol=1e-13 * np.abs(out).max())
+    sim.close()
+
+
+def test_local_and_coloured_fd_jacobians_agree_and_match_directional_derivative(oracle):
+    lm, sim, y, L, f, J, dt = setup(oracle, lens=True)
+    err, Jc = sim.jacobian(y, dt, L, f, mode=1)
+    assert err == 0
+    assert np.abs(J - Jc).max() <= 1e-9 * np.abs(J).max()
+    A = to_bsr(sim, J)
+    v = np.random.default_rng(2).normal(size=y.size)
+    eps = 1e-7
+    err, f2 = sim.residual(y + eps * v, dt, L)
+    assert err == 0
+    lhs, rhs = (f2 - f) / eps, A @ v
+    assert np.abs(lhs - rhs).max() <= 2e-5 * np.abs(rhs).max()
+    sim.close()
+
+
+def test_bilu0_is_exact_lu_on_a_chain(oracle):
+    """On a 1-D chain the block tridiagonal Jacobian has no fill: ILU(0) with one subdomain must
+    solve the system exactly."""
+    lm, sim, y, L, f, J, dt = setup(oracle, dims=(12, 1, 1), brick=(12, 1, 1))
+    rp, ci = sim.pattern()
+    bs, n = sim.np, sim.n_owned
+    fval, dinv = np.zeros_like(J), np.zeros(n * bs * bs)
+    sub = ol.i32a([0, n])
+    assert oracle.wo_bilu0_factor(n, bs, ol.ip(rp), ol.ip(ci), ol.dp(J), 1, ol.ip(sub), ol.dp(fval), ol.dp(dinv)) == 0
+    b = np.random.default_rng(3).normal(size=n * bs)
+    z = np.zeros_like(b)
+    oracle.wo_bilu0_apply(n, bs, ol.ip(rp), ol.ip(ci), ol.dp(fval), ol.dp(dinv), 1, ol.ip(sub), ol.dp(b), ol.dp(z))
+    A = to_bsr(sim, J).toarray()
+    assert np.allclose(A @ z, b, rtol=1e-9, atol=1e-9 * np.abs(b).max())
+    sim.close()
+
+
+def test_block_jacobi_ilu0_equals_per_subdomain_factorisation(oracle):
+    lm, sim, y, L, f, J, dt = setup(oracle)
+    rp, ci = sim.pattern()
+    bs, n = sim.np, sim.n_owned
+    subp = ol.i32a(lm.sub_ptr)
+    fval, dinv = np.zeros_like(J), np.zeros(n * bs * bs)
+    assert oracle.wo_bilu0_factor(n, bs, ol.ip(rp), ol.ip(ci), ol.dp(J), subp.size - 1, ol.ip(subp), ol.dp(fval), ol.dp(dinv)) == 0
+    r = np.random.default_rng(4).normal(size=n * bs)
+    z = np.zeros_like(r)
+    oracle.wo_bilu0_apply(n, bs, ol.ip(rp), ol.ip(ci), ol.dp(fval), ol.dp(dinv), subp.size - 1, ol.ip(subp), ol.dp(r), ol.dp(z))
+    # reference: scipy's spilu cannot do ILU(0) with a fixed pattern, so check the defining
+    # property instead: (L U)_ij = A_ij on the pattern of each diagonal sub-block
+    A = to_bsr(sim, J).toarray()[:, : n * bs]
+    for s in range(subp.size - 1):
+        lo, hi = subp[s] * bs, subp[s + 1] * bs
+        Ass = A[lo:hi, lo:hi]
+        # rebuild L and U of the subdomain from the oracle's factor storage
+        Lm, Um = np.eye(hi - lo), np.zeros((hi - lo, hi - lo))
+        for i in range(subp[s], subp[s + 1]):
+            for q in range(rp[i], rp[i + 1]):
+                j = ci[q]
+                if j < subp[s] or j >= subp[s + 1]:
+                    continue
+                blk = fval[q * bs * bs:(q + 1) * bs * bs].reshape(bs, bs)
+                if j < i:
+                    Lm[(i - subp[s]) * bs:(i - subp[s] + 1) * bs, (j - subp[s]) * bs:(j - subp[s] + 1) * bs] = blk
+                elif j > i:
+                    Um[(i - subp[s]) * bs:(i - subp[s] + 1) * bs, (j - subp[s]) * bs:(j - subp[s] + 1) * bs] = blk
+                else:
+                    Um[(i - subp[s]) * bs:(i - subp[s] + 1) * bs, (j - subp[s]) * bs:(j - subp[s] + 1) * bs] = \
+                        np.linalg.inv(dinv[i * bs * bs:(i + 1) * bs * bs].reshape(bs, bs))
+        P = Lm @ Um
+        mask = Ass != 0
+        assert np.abs((P - Ass)[mask]).max() <= 1e-9 * np.abs(Ass).max()
+        zz = np.linalg.solve(P, r[lo:hi])
+        assert np.allclose(zz, z[lo:hi], rtol=1e-8, atol=1e-10 * np.abs(zz).max())
+    sim.close()
+
+
+def test_krylov_solvers_converge_to_the_dense_solution(oracle):
+    lm, sim, y, L, f, J, dt = setup(oracle)
+    A = to_bsr(sim, J).toarray()[:, : sim.n_owned * sim.np]
+    xref = np.linalg.solve(A, f)
+    for kt in (0, 1):
+        reason, x, its, hist = sim.ksp_solve(J, f, ksp_type=kt, rtol=1e-12)
+        assert reason > 0 and its > 0
+        assert np.abs(x - xref).max() <= 1e-7 * np.abs(xref).max()
+        assert np.all(np.isfinite(hist)) and hist[-1] <= 1e-12 * hist[0] * 1.0001
+    # GMRES residual history of the left-preconditioned operator against scipy's GMRES on the
+    # same operator (same Krylov space => same minimal residual norms)
+    rp, ci = sim.pattern()
+    n, bs = sim.n_owned, sim.np
+    subp = ol.i32a(lm.sub_ptr)
+    fval, dinv = np.zeros_like(J), np.zeros(n * bs * bs)
+    oracle.wo_bilu0_factor(n, bs, ol.ip(rp), ol.ip(ci), ol.dp(J), subp.size - 1, ol.ip(subp), ol.dp(fval), ol.dp(dinv))
+
+    def pc(r):
+        z = np.zeros(n * bs)
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        oracle.wo_bilu0_apply(n, bs, ol.ip(rp), ol.ip(ci), ol.dp(fval), ol.dp(dinv), subp.size - 1, ol.ip(subp), ol.dp(r), ol.dp(z))
+        return z
+    M = np.column_stack([pc(A[:, j].copy()) for j in range(n * bs)])
+    bp = pc(f)
+    res = []
+    spla.gmres(M, bp, rtol=1e-10, restart=30, maxiter=1, callback=lambda r: res.append(r), callback_type="pr_norm")
+    reason, x, its, hist = sim.ksp_solve(J, f, ksp_type=1, rtol=1e-10)
+    k = min(len(res), 25, its)
+    mine = hist[1:k + 1] / hist[0]
+    assert np.allclose(mine, np.array(res[:k]), rtol=2e-3)
+    sim.close()
+
+
+def test_newton_protocol_converges_quadratically(oracle):
+    lm, sim, y, L, f, J, dt = setup(oracle, dims=(6, 6, 6), brick=(3, 3, 3))
+    o = sim.opts()
+    o.ksp_rtol, o.ftol_rel = 1e-12, 1e-12
+    r, k = sim.timestep(y, dt, o)
+    assert 0 < r <= 6
+    sim.close()

@@ -1,0 +1,386 @@
+!> Fortran 2003 host binding of the MI355X-native Newton-step hot path (libwaiwera_hip.so).
+!!
+!! `hip_flow_simulation_type` presents the same type-bound procedure names and argument order as
+!! the reference's abstract `ode_type` (src/ode.F90:39-108) as overridden by
+!! `flow_simulation_type` (src/flow_simulation.F90): lhs, rhs, pre_eval, pre_iteration,
+!! pre_timestep, pre_try_timestep, pre_retry_timestep, post_timestep, post_linesearch,
+!! setup_jacobian -- with plain real(8) arrays where the reference passes PETSc Vecs, so the
+!! reference's timestepper logic (SNES callbacks, src/timestepper.F90:587-735) can drive it.
+!! The SNES Jacobian / KSP slots (src/timestepper.F90:1584-1611, 1645-1836) are the
+!! jacobian / ksp_solve / newton_step / timestep procedures.  `err` follows the reference:
+!! 0 ok, > 0 recoverable numerical failure (retry the step), < 0 fatal.
+module waiwera_hip_module
+
+  use, intrinsic :: iso_c_binding
+  implicit none
+  private
+
+  integer, parameter, public :: dp = c_double
+  integer(c_int), parameter, public :: WAI_EOS_W = 0, WAI_EOS_WE = 1
+  integer(c_int), parameter, public :: WAI_KSP_BCGS = 0, WAI_KSP_GMRES = 1
+
+  type, bind(c), public :: wai_mesh_desc
+     integer(c_int) :: n_owned, n_halo, n_bc, n_faces
+     type(c_ptr) :: face_cells, face_geom, cell_geom, rock
+     integer(c_int) :: n_sub
+     type(c_ptr) :: sub_ptr
+  end type wai_mesh_desc
+
+  type, bind(c), public :: wai_eos_desc
+     integer(c_int) :: kind
+     real(c_double) :: temperature, pressure_scale, temperature_scale
+     integer(c_int) :: rp_type
+     real(c_double) :: rp_par(6)
+     integer(c_int) :: cp_type
+     real(c_double) :: cp_par(6)
+  end type wai_eos_desc
+
+  type, bind(c), public :: wai_solver_opts
+     integer(c_int) :: ksp_type, gmres_restart, ksp_max_its
+     real(c_double) :: ksp_rtol, ksp_atol
+     integer(c_int) :: max_newton_its
+     real(c_double) :: ftol_rel, ftol_abs, utol_rel, utol_abs, fd_eps, fd_umin
+  end type wai_solver_opts
+
+  interface
+     subroutine wai_default_eos(e, kind) bind(c, name = "wai_default_eos")
+       import :: wai_eos_desc, c_int
+       type(wai_eos_desc), intent(out) :: e
+       integer(c_int), value :: kind
+     end subroutine wai_default_eos
+     subroutine wai_default_opts(o) bind(c, name = "wai_default_opts")
+       import :: wai_solver_opts
+       type(wai_solver_opts), intent(out) :: o
+     end subroutine wai_default_opts
+     integer(c_int) function wai_ctx_create(mesh, eos, opts, device, ctx) bind(c, name = "wai_ctx_create")
+       import :: wai_mesh_desc, wai_eos_desc, wai_solver_opts, c_int, c_ptr
+       type(wai_mesh_desc), intent(in) :: mesh
+       type(wai_eos_desc), intent(in) :: eos
+       type(wai_solver_opts), intent(in) :: opts
+       integer(c_int), value :: device
+       type(c_ptr), intent(out) :: ctx
+     end function wai_ctx_create
+     integer(c_int) function wai_ctx_destroy(ctx) bind(c, name = "wai_ctx_destroy")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function wai_ctx_destroy
+     integer(c_int) function wai_set_bc(ctx, primary, region) bind(c, name = "wai_set_bc")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: primary(*)
+       integer(c_int), intent(in) :: region(*)
+     end function wai_set_bc
+     integer(c_int) function wai_set_sources(ctx, n, cell, rate, enthalpy, component) bind(c, name = "wai_set_sources")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n
+       integer(c_int), intent(in) :: cell(*), component(*)
+       real(c_double), intent(in) :: rate(*), enthalpy(*)
+     end function wai_set_sources
+     integer(c_int) function wai_set_regions(ctx, region) bind(c, name = "wai_set_regions")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), intent(in) :: region(*)
+     end function wai_set_regions
+     integer(c_int) function wai_get_regions(ctx, region) bind(c, name = "wai_get_regions")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), intent(out) :: region(*)
+     end function wai_get_regions
+     integer(c_int) function wai_pre_timestep(ctx) bind(c, name = "wai_pre_timestep")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function wai_pre_timestep
+     integer(c_int) function wai_pre_retry_timestep(ctx) bind(c, name = "wai_pre_retry_timestep")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function wai_pre_retry_timestep
+     integer(c_int) function wai_pre_iteration(ctx) bind(c, name = "wai_pre_iteration")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function wai_pre_iteration
+     integer(c_int) function wai_pre_eval(ctx, t, y) bind(c, name = "wai_pre_eval")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: t
+       real(c_double), intent(in) :: y(*)
+     end function wai_pre_eval
+     integer(c_int) function wai_lhs(ctx, t, y, lhs) bind(c, name = "wai_lhs")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: t
+       real(c_double), intent(in) :: y(*)
+       real(c_double), intent(out) :: lhs(*)
+     end function wai_lhs
+     integer(c_int) function wai_rhs(ctx, t, y, rhs) bind(c, name = "wai_rhs")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: t
+       real(c_double), intent(in) :: y(*)
+       real(c_double), intent(out) :: rhs(*)
+     end function wai_rhs
+     integer(c_int) function wai_post_linesearch(ctx, y_old, search, y, changed_search, changed_y) &
+          bind(c, name = "wai_post_linesearch")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: y_old(*)
+       real(c_double), intent(in out) :: search(*), y(*)
+       integer(c_int), intent(out) :: changed_search, changed_y
+     end function wai_post_linesearch
+     integer(c_int) function wai_residual(ctx, t, dt, y, lhs_old, f) bind(c, name = "wai_residual")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: t, dt
+       real(c_double), intent(in) :: y(*), lhs_old(*)
+       real(c_double), intent(out) :: f(*)
+     end function wai_residual
+     integer(c_int) function wai_jacobian(ctx, t, dt, y, lhs_old) bind(c, name = "wai_jacobian")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: t, dt
+       real(c_double), intent(in) :: y(*), lhs_old(*)
+     end function wai_jacobian
+     integer(c_int) function wai_jacobian_nnzb(ctx) bind(c, name = "wai_jacobian_nnzb")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function wai_jacobian_nnzb
+     integer(c_int) function wai_jacobian_pattern(ctx, rowptr, colidx) bind(c, name = "wai_jacobian_pattern")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), intent(out) :: rowptr(*), colidx(*)
+     end function wai_jacobian_pattern
+     integer(c_int) function wai_jacobian_get_values(ctx, val) bind(c, name = "wai_jacobian_get_values")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: val(*)
+     end function wai_jacobian_get_values
+     integer(c_int) function wai_ksp_solve(ctx, b, x, its, reason, rnorm) bind(c, name = "wai_ksp_solve")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: b(*)
+       real(c_double), intent(out) :: x(*)
+       integer(c_int), intent(out) :: its, reason
+       real(c_double), intent(out) :: rnorm
+     end function wai_ksp_solve
+     integer(c_int) function wai_newton_step(ctx, t, dt, iter, y, lhs_old, f, ksp_its, reason, max_residual) &
+          bind(c, name = "wai_newton_step")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: t, dt
+       integer(c_int), value :: iter
+       real(c_double), intent(in out) :: y(*), f(*)
+       real(c_double), intent(in) :: lhs_old(*)
+       integer(c_int), intent(out) :: ksp_its, reason
+       real(c_double), intent(out) :: max_residual
+     end function wai_newton_step
+     integer(c_int) function wai_timestep(ctx, t, dt, y, newton_its, ksp_its, reason) bind(c, name = "wai_timestep")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: t, dt
+       real(c_double), intent(in out) :: y(*)
+       integer(c_int), intent(out) :: newton_its, ksp_its, reason
+     end function wai_timestep
+  end interface
+
+  type, public :: hip_flow_simulation_type
+     !! Concrete ode_type whose hot loops run on the GPU.
+     type(c_ptr) :: ctx = c_null_ptr
+     real(dp), public :: time = 0._dp
+     integer, public :: num_primary_variables = 0, num_cells = 0
+   contains
+     procedure, public :: init => hip_sim_init
+     procedure, public :: destroy => hip_sim_destroy
+     procedure, public :: lhs => hip_sim_lhs
+     procedure, public :: rhs => hip_sim_rhs
+     procedure, public :: pre_solve => hip_sim_pre_eval
+     procedure, public :: pre_eval => hip_sim_pre_eval
+     procedure, public :: pre_iteration => hip_sim_pre_iteration
+     procedure, public :: pre_timestep => hip_sim_pre_timestep
+     procedure, public :: pre_try_timestep => hip_sim_pre_try_timestep
+     procedure, public :: pre_retry_timestep => hip_sim_pre_retry_timestep
+     procedure, public :: post_timestep => hip_sim_post_timestep
+     procedure, public :: post_linesearch => hip_sim_post_linesearch
+     procedure, public :: setup_jacobian => hip_sim_setup_jacobian
+     procedure, public :: residual => hip_sim_residual
+     procedure, public :: jacobian => hip_sim_jacobian
+     procedure, public :: ksp_solve => hip_sim_ksp_solve
+     procedure, public :: newton_step => hip_sim_newton_step
+     procedure, public :: timestep => hip_sim_timestep
+  end type hip_flow_simulation_type
+
+  public :: wai_default_eos, wai_default_opts, wai_set_bc, wai_set_sources, wai_set_regions, &
+       wai_get_regions, wai_jacobian_nnzb, wai_jacobian_pattern, wai_jacobian_get_values
+
+contains
+
+  subroutine hip_sim_init(self, mesh, eos, opts, device, err)
+    class(hip_flow_simulation_type), intent(in out) :: self
+    type(wai_mesh_desc), intent(in) :: mesh
+    type(wai_eos_desc), intent(in) :: eos
+    type(wai_solver_opts), intent(in) :: opts
+    integer, intent(in) :: device
+    integer, intent(out) :: err
+    err = wai_ctx_create(mesh, eos, opts, int(device, c_int), self%ctx)
+    self%num_cells = mesh%n_owned
+    if (eos%kind == WAI_EOS_W) then
+       self%num_primary_variables = 1
+    else
+       self%num_primary_variables = 2
+    end if
+  end subroutine hip_sim_init
+
+  subroutine hip_sim_destroy(self)
+    class(hip_flow_simulation_type), intent(in out) :: self
+    integer(c_int) :: ierr
+    if (c_associated(self%ctx)) ierr = wai_ctx_destroy(self%ctx)
+    self%ctx = c_null_ptr
+  end subroutine hip_sim_destroy
+
+  subroutine hip_sim_lhs(self, t, interval, y, lhs, err)
+    !! ode_type lhs (src/ode.F90:78-87): lhs = L(t, y)
+    class(hip_flow_simulation_type), intent(in out) :: self
+    real(dp), intent(in) :: t, interval(2)
+    real(dp), intent(in) :: y(:)
+    real(dp), intent(in out) :: lhs(:)
+    integer, intent(out) :: err
+    err = wai_lhs(self%ctx, t, y, lhs)
+  end subroutine hip_sim_lhs
+
+  subroutine hip_sim_rhs(self, t, interval, y, rhs, err)
+    !! ode_type rhs (src/ode.F90:89-98): rhs = R(t, y)
+    class(hip_flow_simulation_type), intent(in out) :: self
+    real(dp), intent(in) :: t, interval(2)
+    real(dp), intent(in) :: y(:)
+    real(dp), intent(in out) :: rhs(:)
+    integer, intent(out) :: err
+    err = wai_rhs(self%ctx, t, y, rhs)
+  end subroutine hip_sim_rhs
+
+  subroutine hip_sim_pre_eval(self, t, y, perturbed_columns, err)
+    !! ode_type pre_eval (src/ode.F90:134-147, flow_simulation.F90:2126-2147).  Coloured
+    !! perturbations are not used: the Jacobian slot assembles all columns itself.
+    class(hip_flow_simulation_type), intent(in out) :: self
+    real(dp), intent(in) :: t
+    real(dp), intent(in) :: y(:)
+    integer, intent(in), optional :: perturbed_columns(:)
+    integer, intent(out) :: err
+    err = 0
+    if (present(perturbed_columns)) then
+       if (size(perturbed_columns) > 0) then
+          err = -2
+          return
+       end if
+    end if
+    err = wai_pre_eval(self%ctx, t, y)
+  end subroutine hip_sim_pre_eval
+
+  subroutine hip_sim_pre_iteration(self, y, err)
+    class(hip_flow_simulation_type), intent(in out) :: self
+    real(dp), intent(in out) :: y(:)
+    integer, intent(out) :: err
+    err = wai_pre_iteration(self%ctx)
+  end subroutine hip_sim_pre_iteration
+
+  subroutine hip_sim_pre_timestep(self)
+    class(hip_flow_simulation_type), intent(in out) :: self
+    integer(c_int) :: ierr
+    ierr = wai_pre_timestep(self%ctx)
+  end subroutine hip_sim_pre_timestep
+
+  subroutine hip_sim_pre_try_timestep(self, t)
+    class(hip_flow_simulation_type), intent(in out) :: self
+    real(dp), intent(in) :: t
+  end subroutine hip_sim_pre_try_timestep
+
+  subroutine hip_sim_pre_retry_timestep(self)
+    class(hip_flow_simulation_type), intent(in out) :: self
+    integer(c_int) :: ierr
+    ierr = wai_pre_retry_timestep(self%ctx)
+  end subroutine hip_sim_pre_retry_timestep
+
+  subroutine hip_sim_post_timestep(self)
+    class(hip_flow_simulation_type), intent(in out) :: self
+  end subroutine hip_sim_post_timestep
+
+  subroutine hip_sim_post_linesearch(self, y_old, search, y, changed_search, changed_y, err)
+    !! ode_type post_linesearch (src/ode.F90:198-212, flow_simulation.F90:2419-2576)
+    class(hip_flow_simulation_type), intent(in out) :: self
+    real(dp), intent(in) :: y_old(:)
+    real(dp), intent(in out) :: search(:), y(:)
+    logical, intent(out) :: changed_search, changed_y
+    integer, intent(out) :: err
+    integer(c_int) :: cs, cy
+    err = wai_post_linesearch(self%ctx, y_old, search, y, cs, cy)
+    changed_search = (cs /= 0)
+    changed_y = (cy /= 0)
+  end subroutine hip_sim_post_linesearch
+
+  subroutine hip_sim_setup_jacobian(self, rowptr, colidx, err)
+    !! ode_setup_jacobian (src/ode.F90:266-287): block sparsity (BAIJ) of the Jacobian
+    class(hip_flow_simulation_type), intent(in out) :: self
+    integer(c_int), allocatable, intent(out) :: rowptr(:), colidx(:)
+    integer, intent(out) :: err
+    allocate(rowptr(self%num_cells + 1), colidx(wai_jacobian_nnzb(self%ctx)))
+    err = wai_jacobian_pattern(self%ctx, rowptr, colidx)
+  end subroutine hip_sim_setup_jacobian
+
+  subroutine hip_sim_residual(self, t, dt, y, lhs_old, f, err)
+    !! SNES_residual + backwards_Euler_residual (src/timestepper.F90:587-624, 345-374)
+    class(hip_flow_simulation_type), intent(in out) :: self
+    real(dp), intent(in) :: t, dt
+    real(dp), intent(in) :: y(:), lhs_old(:)
+    real(dp), intent(in out) :: f(:)
+    integer, intent(out) :: err
+    err = wai_residual(self%ctx, t, dt, y, lhs_old, f)
+  end subroutine hip_sim_residual
+
+  subroutine hip_sim_jacobian(self, t, dt, y, lhs_old, err)
+    !! SNESComputeJacobianDefaultColor slot (src/timestepper.F90:1609-1611)
+    class(hip_flow_simulation_type), intent(in out) :: self
+    real(dp), intent(in) :: t, dt
+    real(dp), intent(in) :: y(:), lhs_old(:)
+    integer, intent(out) :: err
+    err = wai_jacobian(self%ctx, t, dt, y, lhs_old)
+  end subroutine hip_sim_jacobian
+
+  subroutine hip_sim_ksp_solve(self, b, x, its, reason, rnorm, err)
+    !! KSPSolve slot (src/timestepper.F90:1645-1836)
+    class(hip_flow_simulation_type), intent(in out) :: self
+    real(dp), intent(in) :: b(:)
+    real(dp), intent(in out) :: x(:)
+    integer, intent(out) :: its, reason, err
+    real(dp), intent(out) :: rnorm
+    integer(c_int) :: i, r
+    err = wai_ksp_solve(self%ctx, b, x, i, r, rnorm)
+    its = i
+    reason = r
+  end subroutine hip_sim_ksp_solve
+
+  subroutine hip_sim_newton_step(self, t, dt, iter, y, lhs_old, f, ksp_its, reason, max_residual, err)
+    class(hip_flow_simulation_type), intent(in out) :: self
+    real(dp), intent(in) :: t, dt
+    integer, intent(in) :: iter
+    real(dp), intent(in out) :: y(:), f(:)
+    real(dp), intent(in) :: lhs_old(:)
+    integer, intent(out) :: ksp_its, reason, err
+    real(dp), intent(out) :: max_residual
+    integer(c_int) :: k, r
+    err = wai_newton_step(self%ctx, t, dt, int(iter, c_int), y, lhs_old, f, k, r, max_residual)
+    ksp_its = k
+    reason = r
+  end subroutine hip_sim_newton_step
+
+  subroutine hip_sim_timestep(self, t, dt, y, newton_its, ksp_its, reason, err)
+    !! SNESSolve for one backward-Euler step (timestepper_step without the retry loop)
+    class(hip_flow_simulation_type), intent(in out) :: self
+    real(dp), intent(in) :: t, dt
+    real(dp), intent(in out) :: y(:)
+    integer, intent(out) :: newton_its, ksp_its, reason, err
+    integer(c_int) :: n, k, r
+    err = wai_timestep(self%ctx, t, dt, y, n, k, r)
+    newton_its = n
+    ksp_its = k
+    reason = r
+  end subroutine hip_sim_timestep
+
+end module waiwera_hip_module

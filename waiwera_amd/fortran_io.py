@@ -1,0 +1,37 @@
+"""Raw binary exchange with the Fortran driver (waiwera_amd/fortran/newton_driver.F90)."""
+import numpy as np
+
+from .lib import EOS_KIND
+
+
+def write_case(path, mesh, eos, y, region):
+    """Header of 10 int32, then the flat arrays in the order the driver reads them."""
+    np_ = 1 if eos == "w" else 2
+    nsub = mesh.sub_ptr.size - 1
+    hdr = np.array([EOS_KIND[eos], mesh.n_owned, mesh.n_halo, mesh.n_bc, mesh.n_faces, nsub,
+                    mesh.n_src, np_, 0, 0], dtype=np.int32)
+    with open(path, "wb") as f:
+        hdr.tofile(f)
+        np.ascontiguousarray(mesh.face_cells, dtype=np.int32).tofile(f)
+        np.ascontiguousarray(mesh.face_geom, dtype=np.float64).tofile(f)
+        np.ascontiguousarray(mesh.cell_geom, dtype=np.float64).tofile(f)
+        np.ascontiguousarray(mesh.rock, dtype=np.float64).tofile(f)
+        np.ascontiguousarray(mesh.sub_ptr, dtype=np.int32).tofile(f)
+        np.ascontiguousarray(region, dtype=np.int32).tofile(f)
+        np.ascontiguousarray(y, dtype=np.float64)[: mesh.n_owned * np_].tofile(f)
+        if mesh.n_bc:
+            np.ascontiguousarray(mesh.bc_primary, dtype=np.float64).tofile(f)
+            np.ascontiguousarray(mesh.bc_region, dtype=np.int32).tofile(f)
+        if mesh.n_src:
+            np.ascontiguousarray(mesh.src_cell, dtype=np.int32).tofile(f)
+            np.ascontiguousarray(mesh.src_rate, dtype=np.float64).tofile(f)
+            np.ascontiguousarray(mesh.src_enthalpy, dtype=np.float64).tofile(f)
+            np.ascontiguousarray(mesh.src_component, dtype=np.int32).tofile(f)
+
+
+def read_result(path, n_owned, n_prim, np_):
+    with open(path, "rb") as f:
+        tot = np.fromfile(f, dtype=np.int32, count=2)
+        y = np.fromfile(f, dtype=np.float64, count=n_owned * np_)
+        region = np.fromfile(f, dtype=np.int32, count=n_prim)
+    return int(tot[0]), int(tot[1]), y, region
