@@ -150,8 +150,8 @@ def cpu_baseline(dims_full, seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dims", type=int, nargs=3, default=[216, 216, 216])
     ap.add_argument("--brick", type=int, nargs=3, default=[8, 8, 8])
     ap.add_argument("--dt0", type=float, default=1.0e4)
