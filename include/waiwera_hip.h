@@ -30,7 +30,7 @@ extern "C" {
 
 typedef struct wai_ctx wai_ctx;
 
-enum { WAI_EOS_W = 0, WAI_EOS_WE = 1 };
+enum { WAI_EOS_W = 0, WAI_EOS_WE = 1, WAI_EOS_WCE = 2 };
 enum { WAI_RP_FULLY_MOBILE = 0, WAI_RP_LINEAR = 1, WAI_RP_PICKENS = 2, WAI_RP_COREY = 3,
        WAI_RP_GRANT = 4, WAI_RP_VAN_GENUCHTEN = 5 };
 enum { WAI_CP_ZERO = 0, WAI_CP_LINEAR = 1, WAI_CP_VAN_GENUCHTEN = 2 };
@@ -66,6 +66,8 @@ typedef struct wai_eos_desc {
   double rp_par[6];
   int cp_type;
   double cp_par[6];
+  double partial_pressure_scale; /* eos wce: "eos.primary.scale.partial_pressure"; 0 = adaptive
+                                    Pg / P (the reference default, src/eos_wge.F90:95-104) */
 } wai_eos_desc;
 
 /* "time.step.solver.*" keys: src/timestepper.F90:1567-1573,1645-1720,1998-2020 */

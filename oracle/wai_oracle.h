@@ -37,6 +37,13 @@ int wo_sat_temperature(double p, double *t);                       /* :793-818 *
 double wo_viscosity(double t, double rho);                         /* :412-443 */
 int wo_phase_composition(int region, double p, double t);          /* :317-365 */
 
+/* ---- CO2 as non-condensible gas (src/ncg_co2_thermodynamics.F90, src/ncg_thermodynamics.F90) -- */
+int wo_co2_properties(double pp, double t, double *rho, double *h);        /* :83-112 */
+double wo_co2_henrys_constant(double t);                                    /* :116-135 */
+double wo_co2_energy_solution(double t);             /* ncg_thermodynamics.F90:207-231 */
+int wo_co2_viscosity(double pp, double t, double *visc);                    /* :236-260 */
+double wo_ncg_mole_to_mass(double xmole, double mw);  /* ncg_thermodynamics.F90:155-167 */
+
 /* ---- curves (src/relative_permeability.F90, src/capillary_pressure.F90) ---------------- */
 enum { WO_RP_FULLY_MOBILE = 0, WO_RP_LINEAR = 1, WO_RP_PICKENS = 2, WO_RP_COREY = 3,
        WO_RP_GRANT = 4, WO_RP_VAN_GENUCHTEN = 5 };
@@ -50,11 +57,12 @@ int wo_brent(wo_rootfn f, void *ctx, double a, double b, double xtol, double fto
              double *root, int *iters);
 
 /* ---- EOS (src/eos.F90, src/eos_w.F90, src/eos_we.F90) ----------------------------------- */
-enum { WO_EOS_W = 0, WO_EOS_WE = 1 };
+enum { WO_EOS_W = 0, WO_EOS_WE = 1, WO_EOS_WCE = 2 };
 typedef struct wo_eos {
   int kind, np, nc, nph, nmob, df, isothermal;
   double temperature;          /* eos_w only (eos_w.F90:97-98) */
-  double scale[5][4];          /* primary_scale(var, region), region 1..4 */
+  double scale[5][4];          /* primary_scale(var, region), region 1..4; a zero partial-
+                                * pressure scale means adaptive scaling Pg/P (eos_wge.F90:639-674) */
   int rp_type, cp_type;
   double rp_par[6], cp_par[6];
 } wo_eos;
@@ -65,7 +73,8 @@ int wo_eos_bulk_properties(const wo_eos *e, const double *primary, double *fluid
 int wo_eos_phase_properties(const wo_eos *e, const double *primary, double *fluid);
 int wo_eos_transition(const wo_eos *e, const double *old_primary, double *primary,
                       const double *old_fluid, double *fluid, int *transition);
-int wo_eos_check_primary(const wo_eos *e, const double *fluid, const double *primary);
+/* returns err; *changed set when a primary was clamped (eos_wge.F90:573-635) */
+int wo_eos_check_primary(const wo_eos *e, const double *fluid, double *primary, int *changed);
 
 /* ---- cell / face kernels (src/cell.F90:114-142, src/face.F90:443-515) ------------------ */
 void wo_cell_balance(const wo_eos *e, const double *fluid, const double *rock, double *bal);

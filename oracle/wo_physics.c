@@ -128,6 +128,74 @@ int wo_phase_composition(int region, double p, double t) {
   return (p <= PCRITICAL) ? 2 : 4;
 }
 
+/* ---- CO2 NCG thermodynamics -------------------------------------------------------------- */
+#define CO2_MW 44.01             /* src/ncg_co2_thermodynamics.F90:14 */
+#define WATER_MW 18.01528        /* src/thermodynamics.F90:38 */
+#define GAS_CONSTANT 8.3144598   /* src/thermodynamics.F90:39 */
+/* published correlation data (Battistelli et al. 1997 / TOUGH2 EWASG), as held at
+ * src/ncg_co2_thermodynamics.F90:15-29 */
+static const double CO2_HENRY[6] = {0.783666, 1.96025, 8.20574, -7.40674, 2.18380, -0.220999};
+static const double CO2_VISC_P[5] = {0.0, 10.0, 15.0, 20.0, 30.0}; /* MPa */
+static const double CO2_VISC_C[5][5] = { /* [coefficient][pressure node] */
+    {1.3578, 3.9189, 9.6607, 13.1566, 14.7968},
+    {4.9227e-3, -35.984e-3, -135.479e-3, -179.352e-3, -160.731e-3},
+    {-2.9661e-6, 0.25825e-3, 0.90087e-3, 1.12474e-3, 0.850257e-3},
+    {2.8529e-9, -7.1178e-7, -2.4727e-6, -2.98864e-6, -1.99076e-6},
+    {-2.1829e-12, 6.9578e-10, 2.4156e-9, 2.85911e-9, 1.73423e-9}};
+
+static double horner(const double *a, int n, double x) { /* src/utils.F90:224-241 */
+  double p = a[n - 1];
+  for (int i = n - 2; i >= 0; i--) p = a[i] + x * p;
+  return p;
+}
+
+/* src/ncg_co2_thermodynamics.F90:83-112 */
+int wo_co2_properties(double partial_pressure, double t, double *rho, double *h) {
+  double tk = t + TC_K;
+  double pp = partial_pressure * 1.0e-6;
+  double tc = pow(0.01 * tk, 3.3333333333);
+  double hci = 1.667 + 0.001542 * tk - 0.7948 * log10(tk) - 41.35 / tk;
+  *h = 1.e6 * (hci - 0.3571 * pp * (1.0 + 0.07576 * pp) / tc);
+  double vc = 0.00018882 * tk - pp * (0.0824 + 0.01249 * pp) / tc;
+  *rho = pp / vc;
+  return 0;
+}
+
+/* src/ncg_co2_thermodynamics.F90:116-135 */
+double wo_co2_henrys_constant(double t) { return 1.e8 * horner(CO2_HENRY, 6, t / 100.0); }
+
+/* d(ln H)/dT (:183-205) and heat of solution (ncg_thermodynamics.F90:186-231) */
+double wo_co2_energy_solution(double t) {
+  double d[5];
+  for (int i = 0; i < 5; i++) d[i] = (i + 1) * CO2_HENRY[i + 1]; /* polynomial_derivative */
+  double H = wo_co2_henrys_constant(t);
+  double hd = 1.e8 * horner(d, 5, t / 100.0) / (H * 100.0);
+  double tk = t + TC_K;
+  return -1.e3 * GAS_CONSTANT * tk * tk * hd / CO2_MW;
+}
+
+/* src/ncg_co2_thermodynamics.F90:236-260: coefficients linearly interpolated in pressure */
+int wo_co2_viscosity(double partial_pressure, double t, double *visc) {
+  if (!(partial_pressure <= 300.e5)) return 1;
+  double p = partial_pressure / 1.e6, coefs[5];
+  int i = 0;
+  if (p <= CO2_VISC_P[0]) { for (int k = 0; k < 5; k++) coefs[k] = CO2_VISC_C[k][0]; }
+  else if (p >= CO2_VISC_P[4]) { for (int k = 0; k < 5; k++) coefs[k] = CO2_VISC_C[k][4]; }
+  else {
+    while (i < 3 && p >= CO2_VISC_P[i + 1]) i++;
+    double xi = (p - CO2_VISC_P[i]) / (CO2_VISC_P[i + 1] - CO2_VISC_P[i]);
+    for (int k = 0; k < 5; k++) coefs[k] = (1.0 - xi) * CO2_VISC_C[k][i] + xi * CO2_VISC_C[k][i + 1];
+  }
+  *visc = 1.e-5 * horner(coefs, 5, t);
+  return 0;
+}
+
+/* src/ncg_thermodynamics.F90:155-167 */
+double wo_ncg_mole_to_mass(double xmole, double mw) {
+  double w = xmole * mw;
+  return w / (w + (1.0 - xmole) * WATER_MW);
+}
+
 /* ---------------------------------------------------------------------------------------- */
 /* two-point table lookup with end clamping: interpolation_table "interpolate" on a 2-row table
  * (src/interpolation.F90:202-222 index rule, :388-404 linear interpolant, :494-510 clamping) */
@@ -280,11 +348,12 @@ void wo_eos_init(wo_eos *e, int kind) {
   if (kind == WO_EOS_W) { /* src/eos_w.F90:50-99 */
     e->np = 1; e->nph = 1; e->nmob = 1; e->isothermal = 1;
     e->scale[1][0] = 1.e6; e->scale[2][0] = 1.e6;
-  } else {                /* src/eos_we.F90:56-126 */
+  } else {                /* src/eos_we.F90:56-126; src/eos_wge.F90:44-128 + eos_wce.F90:24-47 */
     e->np = 2; e->nph = 2; e->nmob = 2; e->isothermal = 0;
     e->scale[1][0] = 1.e6; e->scale[1][1] = 1.e2;
     e->scale[2][0] = 1.e6; e->scale[2][1] = 1.e2;
     e->scale[4][0] = 1.e6; e->scale[4][1] = 1.0;
+    if (kind == WO_EOS_WCE) { e->np = 3; e->nc = 2; } /* scale[.][2] = 0: adaptive Pg/P */
   }
   e->df = (7 + e->nc - 1) + e->nph * (8 + e->nc - 1);
   /* reference defaults: linear [0,1]/[0,1] rel perm, zero Pc
@@ -297,9 +366,11 @@ void wo_eos_init(wo_eos *e, int kind) {
 /* src/eos.F90:186-210 */
 void wo_eos_unscale(const wo_eos *e, const double *y, int region, double *primary) {
   for (int k = 0; k < e->np; k++) primary[k] = y[k] * e->scale[region][k];
+  if (e->kind == WO_EOS_WCE && e->scale[region][2] == 0.0) primary[2] = y[2] * primary[0]; /* eos_wge.F90:659-674 */
 }
 void wo_eos_scale(const wo_eos *e, const double *primary, int region, double *y) {
   for (int k = 0; k < e->np; k++) y[k] = primary[k] / e->scale[region][k];
+  if (e->kind == WO_EOS_WCE && e->scale[region][2] == 0.0) y[2] = primary[2] / primary[0];   /* eos_wge.F90:639-655 */
 }
 
 /* src/eos_we.F90:327-390 (we), src/eos_w.F90:126-147 (w); phase composition eos.F90:214-236 */
@@ -316,9 +387,13 @@ int wo_eos_bulk_properties(const wo_eos *e, const double *primary, double *fl) {
     fl[F_PP] = fl[F_P];
     return err;
   }
+  if (e->kind == WO_EOS_WCE) { /* src/eos_wge.F90:350-389 */
+    fl[F_PP] = fl[F_P] - primary[2];
+    fl[F_PP + 1] = primary[2];
+  }
   if (region == 4) {
     double t;
-    err = wo_sat_temperature(fl[F_P], &t);
+    err = wo_sat_temperature(e->kind == WO_EOS_WCE ? fl[F_PP] : fl[F_P], &t);
     if (err == 0) fl[F_T] = t;
   } else fl[F_T] = primary[1];
   if (err) return err;
@@ -332,7 +407,62 @@ int wo_eos_bulk_properties(const wo_eos *e, const double *primary, double *fl) {
   case 2: l[PH_SAT] = 0.0; v[PH_SAT] = 1.0; break;
   case 4: l[PH_SAT] = 1.0 - primary[1]; v[PH_SAT] = primary[1]; break;
   }
-  fl[F_PP] = fl[F_P];
+  if (e->kind != WO_EOS_WCE) fl[F_PP] = fl[F_P];
+  return 0;
+}
+
+/* src/eos_wge.F90:421-543 with CO2 as the gas (eos_wce.F90) */
+static int wce_phase_properties(const wo_eos *e, double *fl) {
+  double P = fl[F_P], T = fl[F_T], Pw = fl[F_PP], Pg = fl[F_PP + 1];
+  int phases = (int)lround(fl[F_PHASES]);
+  double sl = fl[phase_off(e, 0) + PH_SAT];
+  double rp[2];
+  wo_relperm(e->rp_type, e->rp_par, sl, rp);
+  double gas_rho, gas_h;
+  int err = wo_co2_properties(Pg, T, &gas_rho, &gas_h);
+  if (err) return err;
+  for (int p = 0; p < e->nph; p++) {
+    double *ph = fl + phase_off(e, p);
+    if (phases & (1 << p)) {
+      double water_pressure, cap, henry, esol;
+      if (p == 0) {
+        water_pressure = P;
+        cap = wo_capillary(e->cp_type, e->cp_par, sl, T);
+        henry = wo_co2_henrys_constant(T);
+        esol = wo_co2_energy_solution(T);
+      } else {
+        water_pressure = Pw; cap = 0.0; henry = 0.0; esol = 0.0;
+      }
+      double wrho, wu;
+      err = (p == 0) ? wo_region1(water_pressure, T, &wrho, &wu) : wo_region2(water_pressure, T, &wrho, &wu);
+      if (err) return err;
+      double grho = (p == 0) ? 0.0 : gas_rho; /* effective_properties: no free gas in liquid */
+      double xg;
+      if (p == 0) xg = wo_ncg_mole_to_mass(Pg / henry, CO2_MW);
+      else {
+        double tot = grho + wrho;
+        xg = (tot < 1.e-30) ? 0.0 : grho / tot;
+      }
+      double wmu = wo_viscosity(T, wrho), mu;
+      if (p == 0) mu = wmu;
+      else {
+        double gmu;
+        err = wo_co2_viscosity(Pg, T, &gmu);
+        if (err) return err;
+        mu = wmu * (1.0 - xg) + gmu * xg;
+      }
+      ph[PH_MU] = mu;
+      ph[PH_RHO] = wrho + grho;
+      ph[PH_X] = 1.0 - xg; ph[PH_X + 1] = xg;
+      ph[PH_KR] = rp[p]; ph[PH_PC] = cap;
+      double wh = wu + water_pressure / wrho;
+      ph[PH_H] = wh * (1.0 - xg) + (gas_h + esol) * xg;
+      ph[PH_U] = ph[PH_H] - P / ph[PH_RHO];
+    } else {
+      ph[PH_RHO] = 0.0; ph[PH_U] = 0.0; ph[PH_H] = 0.0; ph[PH_KR] = 0.0;
+      ph[PH_PC] = 0.0; ph[PH_MU] = 0.0; ph[PH_X] = 0.0; ph[PH_X + 1] = 0.0;
+    }
+  }
   return 0;
 }
 
@@ -351,6 +481,7 @@ int wo_eos_phase_properties(const wo_eos *e, const double *primary, double *fl) 
     ph[PH_MU] = wo_viscosity(T, rho);
     return 0;
   }
+  if (e->kind == WO_EOS_WCE) return wce_phase_properties(e, fl);
   int phases = (int)lround(fl[F_PHASES]);
   double sl = fl[phase_off(e, 0) + PH_SAT];
   double rp[2], cp[2];
@@ -375,20 +506,28 @@ int wo_eos_phase_properties(const wo_eos *e, const double *primary, double *fl) 
 }
 
 /* saturation-line difference along the old->new primary segment: src/eos_we.F90:530-553 */
-typedef struct { double p0, t0, p1, t1; } satline_ctx;
+typedef struct { double p0, t0, p1, t1, g0, g1; } satline_ctx; /* g: gas partial pressure (eos_wge.F90:678-701) */
 static double satline_diff(double x, void *vc) {
   satline_ctx *c = (satline_ctx *)vc;
   double P = (1.0 - x) * c->p0 + x * c->p1, T = (1.0 - x) * c->t0 + x * c->t1, Ps = 0.0;
+  double Pg = (1.0 - x) * c->g0 + x * c->g1;
   wo_sat_pressure(T, &Ps); /* error ignored, as the reference does */
-  return P - Ps;
+  return P - Pg - Ps;
 }
 
-/* src/eos_we.F90:149-323; eos_w has no transitions (eos_w.F90:103-122) */
+/* src/eos_we.F90:149-323 and src/eos_wge.F90:154-346 (wce: water pressure = P - Pg on the
+ * saturation line, Pg clipped to [0, P] and interpolated); eos_w has no transitions */
+static double lerp_clamped(double xi, double a, double b) { /* interpolate(xi), interpolation.F90:494-543 */
+  if (xi <= 0.0) return a;
+  if (xi >= 1.0) return b;
+  return (1.0 - xi) * a + xi * b;
+}
 int wo_eos_transition(const wo_eos *e, const double *oldp, double *prim, const double *old_fluid,
                       double *fluid, int *transition) {
   *transition = 0;
   if (e->kind == WO_EOS_W) return 0;
   const double small = 1.e-6;
+  const int wce = (e->kind == WO_EOS_WCE);
   int old_region = (int)lround(old_fluid[F_REGION]);
   int err = 0;
   if (old_region == 4) {
@@ -398,31 +537,27 @@ int wo_eos_transition(const wo_eos *e, const double *oldp, double *prim, const d
     if (!new_region) return 0;
     double bound = (new_region == 1) ? 0.0 : 1.0;
     double pfac = (new_region == 1) ? 1.0 + small : 1.0 - small;
+    if (wce) prim[2] = fmax(0.0, fmin(prim[2], prim[0]));
     /* linear inverse interpolant on component 2: src/interpolation.F90:407-435 */
     double v1 = oldp[1], v2 = prim[1];
     double vmax = fmax(fabs(v1), fabs(v2));
-    int ierr = 0;
-    double xi = 0.0;
     if (fabs(v2 - v1) >= 1.e-8 * vmax) {
       double vs1 = v1 / vmax, vs2 = v2 / vmax, ys = bound / vmax;
-      xi = (ys - vs1) / (vs2 - vs1);
+      double xi = (ys - vs1) / (vs2 - vs1);
       xi = (1.0 - xi) * 0.0 + xi * 1.0;
-    } else ierr = 1;
-    if (ierr == 0) {
-      /* interpolate(xi) clamps outside [0,1] (interpolation.F90:214-217,494-510) */
-      double ip;
-      if (xi <= 0.0) ip = oldp[0];
-      else if (xi >= 1.0) ip = prim[0];
-      else ip = (1.0 - xi) * oldp[0] + xi * prim[0];
-      prim[0] = pfac * ip;
+      double ip = lerp_clamped(xi, oldp[0], prim[0]);
+      double ig = wce ? lerp_clamped(xi, oldp[2], prim[2]) : 0.0;
+      double iw = ip - ig; /* interpolated water pressure */
+      prim[0] = pfac * iw + ig;
+      if (wce) prim[2] = ig;
       double t;
-      err = wo_sat_temperature(ip, &t);
+      err = wo_sat_temperature(iw, &t);
       if (err == 0) { prim[1] = t; fluid[F_REGION] = (double)new_region; *transition = 1; }
     } else {
       double ps;
       err = wo_sat_pressure(old_fluid[F_T], &ps);
       if (err == 0) {
-        prim[0] = pfac * ps;
+        prim[0] = pfac * ps + (wce ? prim[2] : 0.0);
         prim[1] = old_fluid[F_T];
         fluid[F_REGION] = (double)new_region;
         *transition = 1;
@@ -433,18 +568,18 @@ int wo_eos_transition(const wo_eos *e, const double *oldp, double *prim, const d
   double ps;
   err = wo_sat_pressure(prim[1], &ps);
   if (err) return err;
-  if ((old_region == 1 && prim[0] < ps) || (old_region == 2 && prim[0] > ps)) {
-    satline_ctx c = {oldp[0], oldp[1], prim[0], prim[1]};
+  double pw = prim[0] - (wce ? prim[2] : 0.0);
+  if ((old_region == 1 && pw < ps) || (old_region == 2 && pw > ps)) {
+    if (wce) prim[2] = fmax(0.0, fmin(prim[2], prim[0]));
+    satline_ctx c = {oldp[0], oldp[1], prim[0], prim[1], wce ? oldp[2] : 0.0, wce ? prim[2] : 0.0};
     double root;
     int it;
     int rerr = wo_brent(satline_diff, &c, 0.0, 1.0, 1.e-8, 1.e-8, 100, &root, &it);
     if (rerr == 0) {
-      double xi = root, ip;
-      if (xi <= 0.0) ip = oldp[0];
-      else if (xi >= 1.0) ip = prim[0];
-      else ip = (1.0 - xi) * oldp[0] + xi * prim[0];
-      prim[0] = ip;
-    } else prim[0] = ps;
+      double ig = wce ? lerp_clamped(root, oldp[2], prim[2]) : 0.0;
+      prim[0] = lerp_clamped(root, oldp[0], prim[0]);
+      if (wce) prim[2] = ig;
+    } else prim[0] = ps + (wce ? prim[2] : 0.0);
     prim[1] = (old_region == 1) ? small : 1.0 - small;
     fluid[F_REGION] = 4.0;
     *transition = 1;
@@ -452,11 +587,21 @@ int wo_eos_transition(const wo_eos *e, const double *oldp, double *prim, const d
   return 0;
 }
 
-/* src/eos_we.F90:486-526, src/eos_w.F90:232-255 */
-int wo_eos_check_primary(const wo_eos *e, const double *fluid, const double *prim) {
-  double p = prim[0];
-  if (p < 0.0 || p > 100.e6) return 1;
-  if (e->kind == WO_EOS_W) return 0;
+/* src/eos_we.F90:486-526, src/eos_w.F90:232-255, src/eos_wge.F90:573-635 */
+int wo_eos_check_primary(const wo_eos *e, const double *fluid, double *prim, int *changed) {
+  *changed = 0;
+  if (e->kind == WO_EOS_WCE) {
+    const double small = 1.e-6;
+    if (!(prim[0] > 0.0)) return 1;
+    double maxpp = (1.0 - small) * prim[0];
+    if (prim[2] > maxpp) { prim[2] = maxpp; *changed = 1; }
+    else if (prim[2] < 0.0) { prim[2] = 0.0; *changed = 1; }
+    if (prim[0] - prim[2] > 100.e6) return 1;
+  } else {
+    double p = prim[0];
+    if (p < 0.0 || p > 100.e6) return 1;
+    if (e->kind == WO_EOS_W) return 0;
+  }
   int region = (int)lround(fluid[F_REGION]);
   if (region == 4) {
     if (prim[1] < -1.0 || prim[1] > 2.0) return 1;

@@ -515,8 +515,8 @@ int wo_post_linesearch(wo_sim *s, const double *y_old, double *search, double *y
     int transition = 0;
     err = wo_eos_transition(e, oprim, prim, ofl, fl, &transition);
     if (err) break;
-    *changed_y = 0; /* check_primary_variables resets the flag per cell (eos_we.F90:501) */
-    err = wo_eos_check_primary(e, fl, prim);
+    /* check_primary_variables resets the flag per cell (eos_we.F90:501, eos_wge.F90:591) */
+    err = wo_eos_check_primary(e, fl, prim, changed_y);
     if (err) break;
     if (transition) *changed_y = 1;
     if (*changed_y) {

@@ -7,10 +7,10 @@ from waiwera_amd import mesh as M
 def make_case(dims=(8, 8, 8), brick=(4, 4, 4), eos="we", lens=False, sources=True, part=(1, 1, 1),
               rank=0, hetero=True, top_bc=True):
     g = M.StructuredGrid(dims, brick=brick, part=part)
-    srcs = M.benchmark_sources(g) if sources else None
+    srcs = M.benchmark_sources(g, co2_fraction=0.05 if eos == "wce" else 0.0) if sources else None
     bc = None
     if top_bc:
-        bc = (([1.0e5, 20.0], 1) if eos == "we" else ([1.0e5], 1))
+        bc = {"we": ([1.0e5, 20.0], 1), "w": ([1.0e5], 1), "wce": ([1.0e5, 20.0, 0.02e5], 1)}[eos]
     rock = M.heterogeneous_rock(g.n_global) if hetero else None
     lm = g.local_mesh(rank, rock_fn=rock, top_bc=bc, sources=srcs)
     prim, region = M.benchmark_initial_state(g, lm.extras["prim_ijk"], eos=eos, lens=lens)
@@ -23,4 +23,7 @@ def scaled(prim, region, eos="we"):
         sc[r, 0] = 1.0e6
         if prim.shape[1] > 1:
             sc[r, 1] = 1.0e2 if r != 4 else 1.0
-    return prim / sc[region]
+    out = prim / sc[region]
+    if eos == "wce":  # adaptive partial-pressure scaling Pg / P (src/eos_wge.F90:639-655)
+        out[:, 2] = prim[:, 2] / prim[:, 0]
+    return out

@@ -62,7 +62,12 @@ def load(path):
         "wo_eos_bulk_properties": (i32, [C.POINTER(Eos), pd, pd]),
         "wo_eos_phase_properties": (i32, [C.POINTER(Eos), pd, pd]),
         "wo_eos_transition": (i32, [C.POINTER(Eos), pd, pd, pd, pd, pi]),
-        "wo_eos_check_primary": (i32, [C.POINTER(Eos), pd, pd]),
+        "wo_eos_check_primary": (i32, [C.POINTER(Eos), pd, pd, pi]),
+        "wo_co2_properties": (i32, [d, d, pd, pd]), "wo_co2_henrys_constant": (d, [d]),
+        "wo_co2_energy_solution": (d, [d]), "wo_co2_viscosity": (i32, [d, d, pd]),
+        "wo_ncg_mole_to_mass": (d, [d, d]),
+        "wo_eos_scale": (None, [C.POINTER(Eos), pd, i32, pd]),
+        "wo_eos_unscale": (None, [C.POINTER(Eos), pd, i32, pd]),
         "wo_cell_balance": (None, [C.POINTER(Eos), pd, pd, pd]),
         "wo_face_flux": (None, [C.POINTER(Eos), pd, pd, pd, pd, pd, pd]),
         "wo_face_phase_density": (d, [C.POINTER(Eos), pd, pd, i32]),

@@ -151,7 +151,8 @@ def test_eos_we_check_primary(oracle):
                                (4, [1e5, 2.5], 1), (4, [1e5, -1.5], 1)):
         fl[2] = region
         p = np.array(prim)
-        assert oracle.wo_eos_check_primary(C.byref(e), ol.dp(fl), ol.dp(p)) == want
+        ch = C.c_int()
+        assert oracle.wo_eos_check_primary(C.byref(e), ol.dp(fl), ol.dp(p), C.byref(ch)) == want
 
 
 def test_conductivity(oracle):

@@ -498,6 +498,7 @@ void wai_default_eos(wai_eos_desc* e, int kind) {
   e->rp_type = WAI_RP_LINEAR;
   e->rp_par[0] = 0.0; e->rp_par[1] = 1.0; e->rp_par[2] = 0.0; e->rp_par[3] = 1.0;
   e->cp_type = WAI_CP_ZERO;
+  e->partial_pressure_scale = 0.0;
 }
 
 void wai_default_opts(wai_solver_opts* o) {
@@ -526,6 +527,7 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
   c->kind = ed->kind;
   if (c->kind == WAI_EOS_W) { c->np = 1; c->df = 15; }
   else if (c->kind == WAI_EOS_WE) { c->np = 2; c->df = 23; }
+  else if (c->kind == WAI_EOS_WCE) { c->np = 3; c->df = 26; }
   else { c->err = "unsupported eos kind"; return -2; }
   std::memset(&c->ep, 0, sizeof(c->ep));
   c->ep.temperature = ed->temperature;
@@ -534,6 +536,9 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
   c->ep.scale[1][0] = ps; c->ep.scale[1][1] = ts;
   c->ep.scale[2][0] = ps; c->ep.scale[2][1] = ts;
   c->ep.scale[4][0] = ps; c->ep.scale[4][1] = 1.0;
+  // eos.primary.scale.partial_pressure: absent/<= 0 = adaptive Pg/P (eos_wge.F90:95-104)
+  const double gs = ed->partial_pressure_scale > 0 ? ed->partial_pressure_scale : 0.0;
+  c->ep.scale[1][2] = gs; c->ep.scale[2][2] = gs; c->ep.scale[4][2] = gs;
   c->ep.rp_type = ed->rp_type; c->ep.cp_type = ed->cp_type;
   for (int i = 0; i < 6; i++) { c->ep.rp_par[i] = ed->rp_par[i]; c->ep.cp_par[i] = ed->cp_par[i]; }
 
@@ -810,7 +815,11 @@ int wai_set_bc(wai_ctx* c, const double* primary, const int* region) {
     const int rg = region[b];
     if (rg < 1 || rg > 4 || rg == 3) { c->err = "bad bc region"; return -2; }
     reg[b] = (double)rg;
-    for (int k = 0; k < np; k++) ys[(size_t)(first + b) * np + k] = primary[(size_t)b * np + k] / c->ep.scale[rg][k];
+    for (int k = 0; k < np; k++) {
+      const double sc = c->ep.scale[rg][k];
+      ys[(size_t)(first + b) * np + k] = (sc == 0.0) ? primary[(size_t)b * np + k] / primary[(size_t)b * np]
+                                                     : primary[(size_t)b * np + k] / sc;
+    }
   }
   HIPCHK(c, hipMemcpy(c->flu + (size_t)F_REGION * NL + first, reg.data(), nb * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->flu + (size_t)F_OLD_REGION * NL + first, reg.data(), nb * sizeof(double), hipMemcpyHostToDevice));

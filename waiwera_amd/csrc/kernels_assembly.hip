@@ -314,25 +314,26 @@ __global__ __launch_bounds__(TPB) void k_transitions(EosParams ep, int n_owned,
   int region = (int)flu[F_REGION * stride + c];
   const int old_region = (int)flu_old[F_REGION * stride + c];
   const double old_t = flu_old[F_T * stride + c];
-  double prim[E::np], oldp[E::np], yo[E::np];
+  double prim[E::np], oldp[E::np], yo[E::np], yn[E::np];
 #pragma unroll
   for (int k = 0; k < E::np; k++) {
     yo[k] = y_old[(size_t)c * E::np + k];
-    prim[k] = y[(size_t)c * E::np + k] * ep.scale[region][k];
-    oldp[k] = yo[k] * ep.scale[old_region][k];
+    yn[k] = y[(size_t)c * E::np + k];
   }
+  eos_unscale<KIND>(ep, yn, region, prim);
+  eos_unscale<KIND>(ep, yo, old_region, oldp);
   flu[F_OLD_REGION * stride + c] = (double)region;
-  bool transition = false;
+  bool transition = false, changed = false;
   int err = eos_transition<KIND>(oldp, prim, old_region, old_t, region, transition);
-  if (!err) err = eos_check_primary<KIND>(prim, region);
+  if (!err) err = eos_check_primary<KIND>(prim, region, changed);
   if (err) { flag_error(flags, c); return; }
-  if (transition) {
-    flu[F_REGION * stride + c] = (double)region;
+  if (transition || changed) {
+    if (transition) flu[F_REGION * stride + c] = (double)region;
+    eos_scale<KIND>(ep, prim, region, yn);
 #pragma unroll
     for (int k = 0; k < E::np; k++) {
-      const double ys = prim[k] / ep.scale[region][k];
-      y[(size_t)c * E::np + k] = ys;
-      search[(size_t)c * E::np + k] = yo[k] - ys;
+      y[(size_t)c * E::np + k] = yn[k];
+      search[(size_t)c * E::np + k] = yo[k] - yn[k];
     }
     flags[2] = 1;
     flags[3] = 1;
@@ -409,27 +410,24 @@ static MeshView view(wai_ctx* c) {
 
 static inline int grid_for(size_t n) { return (int)((n + TPB - 1) / TPB); }
 
+// launch KERNEL<kind>(...) for the context's EOS
+#define WAI_BY_EOS(c, KERNEL, grid, ...)                                                          \
+  do {                                                                                           \
+    if ((c)->kind == EOS_W) hipLaunchKernelGGL(KERNEL<EOS_W>, grid, TPB, 0, (c)->stream, __VA_ARGS__);        \
+    else if ((c)->kind == EOS_WE) hipLaunchKernelGGL(KERNEL<EOS_WE>, grid, TPB, 0, (c)->stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL<EOS_WCE>, grid, TPB, 0, (c)->stream, __VA_ARGS__);                         \
+  } while (0)
+
 int launch_eos(wai_ctx* c, const double* y, int first, int count, bool perturbed) {
   if (count <= 0) return 0;
   const size_t stride = c->mesh.n_local;
   if (!perturbed) {
-    if (c->kind == EOS_W)
-      hipLaunchKernelGGL(k_eos<EOS_W>, grid_for(count), TPB, 0, c->stream, c->ep, y, c->flu,
-                         stride, first, count, c->d_flags);
-    else
-      hipLaunchKernelGGL(k_eos<EOS_WE>, grid_for(count), TPB, 0, c->stream, c->ep, y, c->flu,
-                         stride, first, count, c->d_flags);
+    WAI_BY_EOS(c, k_eos, grid_for(count), c->ep, y, c->flu, stride, first, count, c->d_flags);
   } else {
     const int n_prim = c->mesh.n_prim;
     const size_t tot = (size_t)n_prim * c->np;
-    if (c->kind == EOS_W)
-      hipLaunchKernelGGL(k_eos_pert<EOS_W>, grid_for(tot), TPB, 0, c->stream, c->ep, y, c->flu,
-                         stride, c->flu_pert, c->hstep, n_prim, c->opts.fd_eps, c->opts.fd_umin,
-                         c->d_flags);
-    else
-      hipLaunchKernelGGL(k_eos_pert<EOS_WE>, grid_for(tot), TPB, 0, c->stream, c->ep, y, c->flu,
-                         stride, c->flu_pert, c->hstep, n_prim, c->opts.fd_eps, c->opts.fd_umin,
-                         c->d_flags);
+    WAI_BY_EOS(c, k_eos_pert, grid_for(tot), c->ep, y, c->flu, stride, c->flu_pert, c->hstep, n_prim,
+               c->opts.fd_eps, c->opts.fd_umin, c->d_flags);
   }
   return 0;
 }
@@ -438,12 +436,7 @@ int launch_residual(wai_ctx* c, double dt, const double* lhs_old, double* f, dou
                     double* rhs_out) {
   const MeshView m = view(c);
   const size_t stride = c->mesh.n_local;
-  if (c->kind == EOS_W)
-    hipLaunchKernelGGL(k_residual<EOS_W>, grid_for(m.n_owned), TPB, 0, c->stream, m, c->flu, stride,
-                       dt, lhs_old, f, lhs_out, rhs_out);
-  else
-    hipLaunchKernelGGL(k_residual<EOS_WE>, grid_for(m.n_owned), TPB, 0, c->stream, m, c->flu, stride,
-                       dt, lhs_old, f, lhs_out, rhs_out);
+  WAI_BY_EOS(c, k_residual, grid_for(m.n_owned), m, c->flu, stride, dt, lhs_old, f, lhs_out, rhs_out);
   return 0;
 }
 
@@ -452,24 +445,16 @@ int launch_jacobian(wai_ctx* c, double dt, const double* lhs_old) {
   if (m.max_deg > MAXDEG) { c->err = "cell with more than 8 faces not supported"; return -1; }
   const size_t stride = c->mesh.n_local;
   hipMemsetAsync(c->J.val, 0, sizeof(double) * (size_t)c->J.W * c->np * c->np * c->J.n, c->stream);
-  if (c->kind == EOS_W)
-    hipLaunchKernelGGL(k_jacobian<EOS_W>, grid_for(m.n_owned), TPB, 0, c->stream, m, c->flu, stride,
-                       c->flu_pert, c->hstep, c->mesh.n_prim, dt, lhs_old, c->J.val);
-  else
-    hipLaunchKernelGGL(k_jacobian<EOS_WE>, grid_for(m.n_owned), TPB, 0, c->stream, m, c->flu, stride,
-                       c->flu_pert, c->hstep, c->mesh.n_prim, dt, lhs_old, c->J.val);
+  WAI_BY_EOS(c, k_jacobian, grid_for(m.n_owned), m, c->flu, stride, c->flu_pert, c->hstep, c->mesh.n_prim,
+             dt, lhs_old, c->J.val);
   return 0;
 }
 
 int launch_transitions(wai_ctx* c, const double* y_old, double* search, double* y) {
   const int n = c->mesh.n_owned;
   const size_t stride = c->mesh.n_local;
-  if (c->kind == EOS_W)
-    hipLaunchKernelGGL(k_transitions<EOS_W>, grid_for(n), TPB, 0, c->stream, c->ep, n, c->flu, stride,
-                       c->flu_last_iter, y_old, search, y, c->d_flags);
-  else
-    hipLaunchKernelGGL(k_transitions<EOS_WE>, grid_for(n), TPB, 0, c->stream, c->ep, n, c->flu, stride,
-                       c->flu_last_iter, y_old, search, y, c->d_flags);
+  WAI_BY_EOS(c, k_transitions, grid_for(n), c->ep, n, c->flu, stride, c->flu_last_iter, y_old, search, y,
+             c->d_flags);
   return 0;
 }
 

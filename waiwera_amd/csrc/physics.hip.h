@@ -16,33 +16,37 @@
 
 namespace wai {
 
-enum { EOS_W = 0, EOS_WE = 1 };
+enum { EOS_W = 0, EOS_WE = 1, EOS_WCE = 2 };
 enum { RP_FULLY_MOBILE = 0, RP_LINEAR = 1, RP_PICKENS = 2, RP_COREY = 3, RP_GRANT = 4,
        RP_VAN_GENUCHTEN = 5 };
 enum { CP_ZERO = 0, CP_LINEAR = 1, CP_VAN_GENUCHTEN = 2 };
 
-// fluid record field indices (nc = 1)
-enum { F_P = 0, F_T = 1, F_REGION = 2, F_OLD_REGION = 3, F_PHASES = 4, F_PERMFAC = 5, F_PP = 6,
-       F_PHASE0 = 7 };
-enum { PH_RHO = 0, PH_MU = 1, PH_SAT = 2, PH_KR = 3, PH_PC = 4, PH_H = 5, PH_U = 6, PH_X = 7,
-       PH_DOF = 8 };
+// fluid record field indices (fluid.F90:212-267): 6 bulk fields, nc partial pressures, then per
+// phase 7 scalars + nc mass fractions
+enum { F_P = 0, F_T = 1, F_REGION = 2, F_OLD_REGION = 3, F_PHASES = 4, F_PERMFAC = 5, F_PP = 6 };
+enum { PH_RHO = 0, PH_MU = 1, PH_SAT = 2, PH_KR = 3, PH_PC = 4, PH_H = 5, PH_U = 6, PH_X = 7 };
 // rock record (rock.F90:97-112)
 enum { R_K1 = 0, R_K2 = 1, R_K3 = 2, R_WET = 3, R_DRY = 4, R_PHI = 5, R_RHO = 6, R_CP = 7 };
 
 template <int KIND> struct EosT;
 template <> struct EosT<EOS_W> {
-  static constexpr int np = 1, nc = 1, nph = 1, nmob = 1, df = 15;
+  static constexpr int np = 1, nc = 1, nph = 1, nmob = 1, df = 15, f_phase0 = 7, ph_dof = 8;
   static constexpr bool isothermal = true;
 };
 template <> struct EosT<EOS_WE> {
-  static constexpr int np = 2, nc = 1, nph = 2, nmob = 2, df = 23;
+  static constexpr int np = 2, nc = 1, nph = 2, nmob = 2, df = 23, f_phase0 = 7, ph_dof = 8;
+  static constexpr bool isothermal = false;
+};
+template <> struct EosT<EOS_WCE> {  // water + CO2 + energy (eos_wge.F90 + eos_wce.F90)
+  static constexpr int np = 3, nc = 2, nph = 2, nmob = 2, df = 26, f_phase0 = 8, ph_dof = 9;
   static constexpr bool isothermal = false;
 };
 
 // run-time EOS parameters (kernel argument, lives in SGPRs / constant cache)
 struct EosParams {
   double temperature;     // eos_w
-  double scale[5][2];     // primary_scale(var, region)  (eos_we.F90:104-109)
+  double scale[5][3];     // primary_scale(var, region)  (eos_we.F90:104-109); a zero partial-
+                          // pressure scale selects adaptive scaling Pg/P (eos_wge.F90:639-674)
   int rp_type, cp_type;
   double rp_par[6], cp_par[6];
 };
@@ -117,11 +121,83 @@ __device__ __forceinline__ double capillary(const EosParams& e, double sl) {
   }
 }
 
+// ---- CO2 as non-condensible gas (ncg_co2_thermodynamics.F90:83-292, ncg_thermodynamics.F90) ---
+namespace co2 {
+constexpr double MW = 44.01, WATER_MW = 18.01528, GAS_CONSTANT = 8.3144598;
+__device__ __forceinline__ void properties(double partial_pressure, double t, double& rho, double& h) {
+  const double tk = t + if97::TC_K, pp = partial_pressure * 1.0e-6;
+  const double tc = pow(0.01 * tk, 3.3333333333);
+  const double hci = 1.667 + 0.001542 * tk - 0.7948 * log10(tk) - 41.35 / tk;
+  h = 1.e6 * (hci - 0.3571 * pp * (1.0 + 0.07576 * pp) / tc);
+  const double vc = 0.00018882 * tk - pp * (0.0824 + 0.01249 * pp) / tc;
+  rho = pp / vc;
+}
+__device__ __forceinline__ double henry_poly(double x) {
+  return 0.783666 + x * (1.96025 + x * (8.20574 + x * (-7.40674 + x * (2.18380 + x * -0.220999))));
+}
+__device__ __forceinline__ double henrys_constant(double t) { return 1.e8 * henry_poly(t / 100.0); }
+__device__ __forceinline__ double energy_solution(double t) {
+  const double x = t / 100.0;
+  const double dpoly = 1.96025 + x * (2.0 * 8.20574 + x * (3.0 * -7.40674 + x * (4.0 * 2.18380 + x * (5.0 * -0.220999))));
+  const double hd = 1.e8 * dpoly / (henrys_constant(t) * 100.0);
+  const double tk = t + if97::TC_K;
+  return -1.e3 * GAS_CONSTANT * tk * tk * hd / MW;
+}
+__device__ __forceinline__ int viscosity(double partial_pressure, double t, double& visc) {
+  if (!(partial_pressure <= 300.e5)) return 1;
+  const double P[5] = {0.0, 10.0, 15.0, 20.0, 30.0};
+  const double Cf[5][5] = {{1.3578, 3.9189, 9.6607, 13.1566, 14.7968},
+                           {4.9227e-3, -35.984e-3, -135.479e-3, -179.352e-3, -160.731e-3},
+                           {-2.9661e-6, 0.25825e-3, 0.90087e-3, 1.12474e-3, 0.850257e-3},
+                           {2.8529e-9, -7.1178e-7, -2.4727e-6, -2.98864e-6, -1.99076e-6},
+                           {-2.1829e-12, 6.9578e-10, 2.4156e-9, 2.85911e-9, 1.73423e-9}};
+  const double p = partial_pressure / 1.e6;
+  double c[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    // piecewise-linear in pressure with end clamping, written branch-light
+    double v = Cf[k][0];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const double xi = (p - P[i]) / (P[i + 1] - P[i]);
+      const double seg = (1.0 - xi) * Cf[k][i] + xi * Cf[k][i + 1];
+      v = (p > P[i] && p < P[i + 1]) ? seg : v;
+      v = (p >= P[i + 1]) ? Cf[k][i + 1] : v;
+    }
+    c[k] = v;
+  }
+  visc = 1.e-5 * (c[0] + t * (c[1] + t * (c[2] + t * (c[3] + t * c[4]))));
+  return 0;
+}
+__device__ __forceinline__ double mole_to_mass(double xmole) {
+  const double w = xmole * MW;
+  return w / (w + (1.0 - xmole) * WATER_MW);
+}
+}  // namespace co2
+
+// eos%unscale / eos%scale (eos.F90:186-210; adaptive third variable eos_wge.F90:639-674)
+template <int KIND>
+__device__ __forceinline__ void eos_unscale(const EosParams& e, const double* y, int region, double* prim) {
+  using E = EosT<KIND>;
+#pragma unroll
+  for (int k = 0; k < E::np; k++) prim[k] = y[k] * e.scale[region][k];
+  if constexpr (KIND == EOS_WCE) { if (e.scale[region][2] == 0.0) prim[2] = y[2] * prim[0]; }
+}
+template <int KIND>
+__device__ __forceinline__ void eos_scale(const EosParams& e, const double* prim, int region, double* y) {
+  using E = EosT<KIND>;
+#pragma unroll
+  for (int k = 0; k < E::np; k++) y[k] = prim[k] / e.scale[region][k];
+  if constexpr (KIND == EOS_WCE) { if (e.scale[region][2] == 0.0) y[2] = prim[2] / prim[0]; }
+}
+
 // ---- cell state in registers ---------------------------------------------------------------
 template <int KIND> struct CellState {
   using E = EosT<KIND>;
   double P, T, region, phases, permfac;
+  double pp[E::nc];
   double rho[E::nph], mu[E::nph], sat[E::nph], kr[E::nph], pc[E::nph], h[E::nph], u[E::nph];
+  double x[E::nph][E::nc];
 };
 
 // full EOS evaluation: scaled primaries + region -> state (fluid_properties loop body,
@@ -145,10 +221,71 @@ __device__ __forceinline__ int eos_eval(const EosParams& e, const double* y, int
     s.rho[0] = rho; s.u[0] = u; s.h[0] = u + s.P / rho;
     s.kr[0] = 1.0; s.pc[0] = 0.0;
     s.mu[0] = if97::viscosity(s.T, rho);
+    s.x[0][0] = 1.0; s.pp[0] = s.P;
+    return 0;
+  } else if constexpr (KIND == EOS_WCE) {
+    // eos_wge_bulk_properties / phase_properties (eos_wge.F90:350-543) with CO2 (eos_wce.F90)
+    double prim[3];
+    eos_unscale<KIND>(e, y, region, prim);
+    s.P = prim[0];
+    const double Pg = prim[2], Pw = s.P - Pg;
+    s.pp[0] = Pw; s.pp[1] = Pg;
+    if (region == 4) {
+      double t;
+      if (if97::sat_temperature(Pw, t)) return 1;
+      s.T = t;
+    } else s.T = prim[1];
+    const int ph = if97::phase_composition(region, s.P, s.T);
+    if (ph <= 0) return 1;
+    s.phases = (double)ph;
+    if (region == 1) { s.sat[0] = 1.0; s.sat[1] = 0.0; }
+    else if (region == 2) { s.sat[0] = 0.0; s.sat[1] = 1.0; }
+    else { s.sat[0] = 1.0 - prim[1]; s.sat[1] = prim[1]; }
+    double kl, kv;
+    relperm(e, s.sat[0], kl, kv);
+    double gas_rho, gas_h;
+    co2::properties(Pg, s.T, gas_rho, gas_h);
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      if (ph & (1 << p)) {
+        const double wpres = (p == 0) ? s.P : Pw;
+        double wrho, wu;
+        const int err = (p == 0) ? if97::region1(wpres, s.T, wrho, wu) : if97::region2(wpres, s.T, wrho, wu);
+        if (err) return err;
+        const double grho = (p == 0) ? 0.0 : gas_rho;
+        double xg, esol = 0.0;
+        if (p == 0) {
+          xg = co2::mole_to_mass(Pg / co2::henrys_constant(s.T));
+          esol = co2::energy_solution(s.T);
+        } else {
+          const double tot = grho + wrho;
+          xg = (tot < 1.e-30) ? 0.0 : grho / tot;
+        }
+        const double wmu = if97::viscosity(s.T, wrho);
+        double mu = wmu;
+        if (p == 1) {
+          double gmu;
+          if (co2::viscosity(Pg, s.T, gmu)) return 1;
+          mu = wmu * (1.0 - xg) + gmu * xg;
+        }
+        s.mu[p] = mu;
+        s.rho[p] = wrho + grho;
+        s.x[p][0] = 1.0 - xg; s.x[p][1] = xg;
+        s.kr[p] = (p == 0) ? kl : kv;
+        s.pc[p] = (p == 0) ? capillary(e, s.sat[0]) : 0.0;
+        const double wh = wu + wpres / wrho;
+        s.h[p] = wh * (1.0 - xg) + (gas_h + esol) * xg;
+        s.u[p] = s.h[p] - s.P / s.rho[p];
+      } else {
+        s.rho[p] = 0.0; s.u[p] = 0.0; s.h[p] = 0.0; s.kr[p] = 0.0; s.pc[p] = 0.0; s.mu[p] = 0.0;
+        s.x[p][0] = 0.0; s.x[p][1] = 0.0;
+      }
+    }
     return 0;
   } else {
     const double p0 = y[0] * e.scale[region][0], p1 = y[1] * e.scale[region][1];
     s.P = p0;
+    s.pp[0] = p0;
     if (region == 4) {
       double t;
       if (if97::sat_temperature(s.P, t)) return 1;
@@ -173,8 +310,10 @@ __device__ __forceinline__ int eos_eval(const EosParams& e, const double* y, int
         s.kr[p] = (p == 0) ? kl : kv;
         s.pc[p] = (p == 0) ? pcl : 0.0;
         s.mu[p] = if97::viscosity(s.T, rho);
+        s.x[p][0] = 1.0;
       } else {
         s.rho[p] = 0.0; s.u[p] = 0.0; s.h[p] = 0.0; s.kr[p] = 0.0; s.pc[p] = 0.0; s.mu[p] = 0.0;
+        s.x[p][0] = 0.0;
       }
     }
     return 0;
@@ -191,11 +330,11 @@ __device__ __forceinline__ void store_state(double* flu, size_t stride, size_t c
   flu[F_T * stride + c] = s.T;
   flu[F_PHASES * stride + c] = s.phases;
   flu[F_PERMFAC * stride + c] = s.permfac;
-  flu[F_PP * stride + c] = s.P;
+#pragma unroll
+  for (int q = 0; q < E::nc; q++) flu[(F_PP + q) * stride + c] = s.pp[q];
 #pragma unroll
   for (int p = 0; p < E::nph; p++) {
-    const size_t b = (size_t)(F_PHASE0 + p * PH_DOF) * stride + c;
-    const bool on = ((int)s.phases >> p) & 1;
+    const size_t b = (size_t)(E::f_phase0 + p * E::ph_dof) * stride + c;
     flu[b + PH_RHO * stride] = s.rho[p];
     flu[b + PH_MU * stride] = s.mu[p];
     flu[b + PH_SAT * stride] = s.sat[p];
@@ -203,7 +342,8 @@ __device__ __forceinline__ void store_state(double* flu, size_t stride, size_t c
     flu[b + PH_PC * stride] = s.pc[p];
     flu[b + PH_H * stride] = s.h[p];
     flu[b + PH_U * stride] = s.u[p];
-    flu[b + PH_X * stride] = on ? 1.0 : 0.0;
+#pragma unroll
+    for (int q = 0; q < E::nc; q++) flu[b + (PH_X + q) * stride] = s.x[p][q];
   }
 }
 
@@ -217,8 +357,10 @@ __device__ __forceinline__ void load_state(const double* __restrict__ flu, size_
   s.permfac = flu[F_PERMFAC * stride + c];
   s.region = 0.0;
 #pragma unroll
+  for (int q = 0; q < E::nc; q++) s.pp[q] = 0.0;  // not needed by the sweeps
+#pragma unroll
   for (int p = 0; p < E::nph; p++) {
-    const size_t b = (size_t)(F_PHASE0 + p * PH_DOF) * stride + c;
+    const size_t b = (size_t)(E::f_phase0 + p * E::ph_dof) * stride + c;
     s.rho[p] = flu[b + PH_RHO * stride];
     s.mu[p] = flu[b + PH_MU * stride];
     s.sat[p] = flu[b + PH_SAT * stride];
@@ -226,6 +368,12 @@ __device__ __forceinline__ void load_state(const double* __restrict__ flu, size_
     s.pc[p] = flu[b + PH_PC * stride];
     s.h[p] = flu[b + PH_H * stride];
     s.u[p] = flu[b + PH_U * stride];
+    if constexpr (E::nc == 1) {
+      s.x[p][0] = (((int)s.phases >> p) & 1) ? 1.0 : 0.0;  // mass_fraction(1) of a present phase
+    } else {
+#pragma unroll
+      for (int q = 0; q < E::nc; q++) s.x[p][q] = flu[b + (PH_X + q) * stride];
+    }
   }
 }
 
@@ -241,15 +389,18 @@ __device__ __forceinline__ void load_rock(const double* __restrict__ rock, size_
 template <int KIND>
 __device__ __forceinline__ void cell_balance(const CellState<KIND>& s, const RockState& r, double* bal) {
   using E = EosT<KIND>;
-  double m = 0.0, ef = 0.0;
+  double m[E::nc], ef = 0.0;
+#pragma unroll
+  for (int q = 0; q < E::nc; q++) m[q] = 0.0;
 #pragma unroll
   for (int p = 0; p < E::nph; p++) {
     const double ds = s.rho[p] * s.sat[p];
-    const double x = (((int)s.phases >> p) & 1) ? 1.0 : 0.0;  // mass_fraction(1)
-    m += ds * x;
+#pragma unroll
+    for (int q = 0; q < E::nc; q++) m[q] += ds * s.x[p][q];
     ef += ds * s.u[p];
   }
-  bal[0] = r.phi * m;
+#pragma unroll
+  for (int q = 0; q < E::nc; q++) bal[q] = r.phi * m[q];
   if constexpr (!E::isothermal) {
     const double er = r.rho * r.cp * s.T;
     bal[E::np - 1] = r.phi * ef + (1.0 - r.phi) * er;
@@ -296,7 +447,8 @@ __device__ __forceinline__ void face_flux(const FaceGeom& g, const CellState<KIN
     const double mu = up1 ? a.mu[p] : b.mu[p], h = up1 ? a.h[p] : b.h[p];
     const double mob = kr * rho / mu;
     const double F = -k * mob * G;
-    flux[0] += F * 1.0;  // mass_fraction(1) of a present phase is 1
+#pragma unroll
+    for (int q = 0; q < E::nc; q++) flux[q] += F * (up1 ? a.x[p][q] : b.x[p][q]);
     if constexpr (!E::isothermal) flux[E::np - 1] += h * F;
   }
 }
@@ -320,7 +472,7 @@ __device__ __forceinline__ void source_flow(const CellState<KIND>& s, double rat
   } else {
     component = comp <= 0 ? 0 : comp;
     const int phases = (int)s.phases;
-    double frac[E::nph], sum = 0.0;
+    double frac[E::nph] = {}, sum = 0.0;
     if (component < E::np) {
 #pragma unroll
       for (int p = 0; p < E::nph; p++) {
@@ -335,10 +487,16 @@ __device__ __forceinline__ void source_flow(const CellState<KIND>& s, double rat
       }
     }
     if (component <= 0) {
-      double cf = 0.0;
+      double cf[E::nc], cs = 0.0;
 #pragma unroll
-      for (int p = 0; p < E::nph; p++) if (phases & (1 << p)) cf += frac[p] * 1.0;
-      flow[0] = rate * (cf / cf);
+      for (int q = 0; q < E::nc; q++) {
+        cf[q] = 0.0;
+#pragma unroll
+        for (int p = 0; p < E::nph; p++) if (phases & (1 << p)) cf[q] += frac[p] * s.x[p][q];
+        cs += cf[q];
+      }
+#pragma unroll
+      for (int q = 0; q < E::nc; q++) flow[q] = rate * (cf[q] / cs);
     } else {
 #pragma unroll
       for (int k = 0; k < E::np; k++) if (k == component - 1) flow[k] = rate;
@@ -350,17 +508,19 @@ __device__ __forceinline__ void source_flow(const CellState<KIND>& s, double rat
 }
 
 // ---- Brent on the saturation line (root_finder.F90:127-248 / eos_we.F90:530-553) -----------
-__device__ inline double satline_diff(double x, double p0, double t0, double p1, double t1) {
-  const double P = (1.0 - x) * p0 + x * p1, T = (1.0 - x) * t0 + x * t1;
+struct SatLine { double p0, t0, p1, t1, g0, g1; };  // g: gas partial pressure (eos_wge.F90:678-701)
+__device__ inline double satline_diff(double x, const SatLine& c) {
+  const double P = (1.0 - x) * c.p0 + x * c.p1, T = (1.0 - x) * c.t0 + x * c.t1;
+  const double Pg = (1.0 - x) * c.g0 + x * c.g1;
   double ps = 0.0;
   if97::sat_pressure(T, ps);
-  return P - ps;
+  return P - Pg - ps;
 }
 
-__device__ inline int brent_satline(double p0, double t0, double p1, double t1, double& root) {
+__device__ inline int brent_satline(const SatLine& sl, double& root) {
   const double xtol = 1.e-8, ftol = 1.e-8, small = 1.e-16;
   double a = 0.0, b = 1.0;
-  double fa = satline_diff(a, p0, t0, p1, t1), fb = satline_diff(b, p0, t0, p1, t1);
+  double fa = satline_diff(a, sl), fb = satline_diff(b, sl);
   root = 0.0;
   if (fa * fb > 0.0) return 1;
   double c = b, fc = fb, d = 0.0, e = 0.0;
@@ -388,14 +548,20 @@ __device__ inline int brent_satline(double p0, double t0, double p1, double t1, 
     a = b; fa = fb;
     if (fabs(d) > xtol) b += d;
     else b += (dx >= 0.0 ? xtol : -xtol);
-    fb = satline_diff(b, p0, t0, p1, t1);
+    fb = satline_diff(b, sl);
   }
   root = b;
   return found ? 0 : 2;
 }
 
-// eos%transition + check_primary_variables (eos_we.F90:149-323,486-526; eos_w.F90:103-122,232-255)
+// eos%transition (eos_we.F90:149-323; eos_wge.F90:154-346; eos_w.F90:103-122).
 // prim/oldp are unscaled primaries; region is updated in place.  Returns err.
+__device__ __forceinline__ double lerp_clamped(double xi, double a, double b) {
+  if (xi <= 0.0) return a;
+  if (xi >= 1.0) return b;
+  return (1.0 - xi) * a + xi * b;
+}
+
 template <int KIND>
 __device__ inline int eos_transition(const double* oldp, double* prim, int old_region,
                                      double old_temperature, int& region, bool& transition) {
@@ -404,6 +570,8 @@ __device__ inline int eos_transition(const double* oldp, double* prim, int old_r
     (void)oldp; (void)old_region; (void)old_temperature; (void)region;
     return 0;
   } else {
+    constexpr bool wce = (KIND == EOS_WCE);
+    constexpr int ig_ = wce ? 2 : 0;
     const double small = 1.e-6;
     if (old_region == 4) {
       const double sv = prim[1];
@@ -412,25 +580,26 @@ __device__ inline int eos_transition(const double* oldp, double* prim, int old_r
       if (!new_region) return 0;
       const double bound = (new_region == 1) ? 0.0 : 1.0;
       const double pfac = (new_region == 1) ? 1.0 + small : 1.0 - small;
+      if constexpr (wce) prim[2] = fmax(0.0, fmin(prim[2], prim[0]));
       const double v1 = oldp[1], v2 = prim[1], vmax = fmax(fabs(v1), fabs(v2));
       if (fabs(v2 - v1) >= 1.e-8 * vmax) {
         const double vs1 = v1 / vmax, vs2 = v2 / vmax, ys = bound / vmax;
         double xi = (ys - vs1) / (vs2 - vs1);
         xi = (1.0 - xi) * 0.0 + xi * 1.0;
-        double ip;
-        if (xi <= 0.0) ip = oldp[0];
-        else if (xi >= 1.0) ip = prim[0];
-        else ip = (1.0 - xi) * oldp[0] + xi * prim[0];
-        prim[0] = pfac * ip;
+        const double ip = lerp_clamped(xi, oldp[0], prim[0]);
+        const double ig = wce ? lerp_clamped(xi, oldp[ig_], prim[ig_]) : 0.0;
+        const double iw = ip - ig;
+        prim[0] = pfac * iw + ig;
+        if constexpr (wce) prim[2] = ig;
         double t;
-        const int err = if97::sat_temperature(ip, t);
+        const int err = if97::sat_temperature(iw, t);
         if (err == 0) { prim[1] = t; region = new_region; transition = true; }
         return err;
       }
       double ps;
       const int err = if97::sat_pressure(old_temperature, ps);
       if (err == 0) {
-        prim[0] = pfac * ps;
+        prim[0] = pfac * ps + (wce ? prim[ig_] : 0.0);
         prim[1] = old_temperature;
         region = new_region;
         transition = true;
@@ -440,16 +609,16 @@ __device__ inline int eos_transition(const double* oldp, double* prim, int old_r
     double ps;
     const int err = if97::sat_pressure(prim[1], ps);
     if (err) return err;
-    if ((old_region == 1 && prim[0] < ps) || (old_region == 2 && prim[0] > ps)) {
+    const double pw = prim[0] - (wce ? prim[ig_] : 0.0);
+    if ((old_region == 1 && pw < ps) || (old_region == 2 && pw > ps)) {
+      if constexpr (wce) prim[2] = fmax(0.0, fmin(prim[2], prim[0]));
+      SatLine sl{oldp[0], oldp[1], prim[0], prim[1], wce ? oldp[ig_] : 0.0, wce ? prim[ig_] : 0.0};
       double root;
-      if (brent_satline(oldp[0], oldp[1], prim[0], prim[1], root) == 0) {
-        const double xi = root;
-        double ip;
-        if (xi <= 0.0) ip = oldp[0];
-        else if (xi >= 1.0) ip = prim[0];
-        else ip = (1.0 - xi) * oldp[0] + xi * prim[0];
-        prim[0] = ip;
-      } else prim[0] = ps;
+      if (brent_satline(sl, root) == 0) {
+        const double ig = wce ? lerp_clamped(root, oldp[ig_], prim[ig_]) : 0.0;
+        prim[0] = lerp_clamped(root, oldp[0], prim[0]);
+        if constexpr (wce) prim[2] = ig;
+      } else prim[0] = ps + (wce ? prim[ig_] : 0.0);
       prim[1] = (old_region == 1) ? small : 1.0 - small;
       region = 4;
       transition = true;
@@ -458,11 +627,23 @@ __device__ inline int eos_transition(const double* oldp, double* prim, int old_r
   }
 }
 
+// eos%check_primary_variables (eos_we.F90:486-526; eos_w.F90:232-255; eos_wge.F90:573-635:
+// the gas partial pressure is clamped to [0, (1-1e-6) P] and reported as `changed`)
 template <int KIND>
-__device__ __forceinline__ int eos_check_primary(const double* prim, int region) {
-  const double p = prim[0];
-  if (p < 0.0 || p > 100.e6) return 1;
-  if constexpr (KIND == EOS_WE) {
+__device__ __forceinline__ int eos_check_primary(double* prim, int region, bool& changed) {
+  changed = false;
+  if constexpr (KIND == EOS_WCE) {
+    const double small = 1.e-6;
+    if (!(prim[0] > 0.0)) return 1;
+    const double maxpp = (1.0 - small) * prim[0];
+    if (prim[2] > maxpp) { prim[2] = maxpp; changed = true; }
+    else if (prim[2] < 0.0) { prim[2] = 0.0; changed = true; }
+    if (prim[0] - prim[2] > 100.e6) return 1;
+  } else {
+    const double p = prim[0];
+    if (p < 0.0 || p > 100.e6) return 1;
+  }
+  if constexpr (KIND != EOS_W) {
     if (region == 4) { if (prim[1] < -1.0 || prim[1] > 2.0) return 1; }
     else if (prim[1] < 0.0 || prim[1] > 800.0) return 1;
   }

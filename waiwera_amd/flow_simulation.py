@@ -111,7 +111,11 @@ class FlowSimulation:
             sc[r, 0] = ps
             if self.num_primary_variables > 1:
                 sc[r, 1] = ts if r != 4 else 1.0
-        return np.asarray(primary, dtype=np.float64) / sc[np.asarray(region)]
+        prim = np.asarray(primary, dtype=np.float64)
+        out = prim / sc[np.asarray(region)]
+        if self.eos_name == "wce" and self.eos_desc.partial_pressure_scale <= 0:
+            out[..., 2] = prim[..., 2] / prim[..., 0]  # adaptive Pg / P (eos_wge.F90:639-655)
+        return out
 
     # ---- ode_type hooks ------------------------------------------------------------------------
     def pre_timestep(self):

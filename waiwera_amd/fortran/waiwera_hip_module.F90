@@ -16,7 +16,7 @@ module waiwera_hip_module
   private
 
   integer, parameter, public :: dp = c_double
-  integer(c_int), parameter, public :: WAI_EOS_W = 0, WAI_EOS_WE = 1
+  integer(c_int), parameter, public :: WAI_EOS_W = 0, WAI_EOS_WE = 1, WAI_EOS_WCE = 2
   integer(c_int), parameter, public :: WAI_KSP_BCGS = 0, WAI_KSP_GMRES = 1
 
   type, bind(c), public :: wai_mesh_desc
@@ -33,6 +33,7 @@ module waiwera_hip_module
      real(c_double) :: rp_par(6)
      integer(c_int) :: cp_type
      real(c_double) :: cp_par(6)
+     real(c_double) :: partial_pressure_scale
   end type wai_eos_desc
 
   type, bind(c), public :: wai_solver_opts
@@ -222,11 +223,14 @@ contains
     integer, intent(out) :: err
     err = wai_ctx_create(mesh, eos, opts, int(device, c_int), self%ctx)
     self%num_cells = mesh%n_owned
-    if (eos%kind == WAI_EOS_W) then
+    select case (eos%kind)
+    case (WAI_EOS_W)
        self%num_primary_variables = 1
-    else
+    case (WAI_EOS_WE)
        self%num_primary_variables = 2
-    end if
+    case default
+       self%num_primary_variables = 3
+    end select
   end subroutine hip_sim_init
 
   subroutine hip_sim_destroy(self)

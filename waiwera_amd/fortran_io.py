@@ -6,7 +6,7 @@ from .lib import EOS_KIND
 
 def write_case(path, mesh, eos, y, region):
     """Header of 10 int32, then the flat arrays in the order the driver reads them."""
-    np_ = 1 if eos == "w" else 2
+    np_ = {"w": 1, "we": 2, "wce": 3}[eos]
     nsub = mesh.sub_ptr.size - 1
     hdr = np.array([EOS_KIND[eos], mesh.n_owned, mesh.n_halo, mesh.n_bc, mesh.n_faces, nsub,
                     mesh.n_src, np_, 0, 0], dtype=np.int32)

@@ -408,6 +408,9 @@ def benchmark_initial_state(grid, ijk, eos="we", lens=True):
     if eos == "w":
         return P[:, None].copy(), region
     second = T.copy()
+    if eos == "wce":
+        # CO2 partial pressure 2 % of the total pressure
+        return np.stack([P, second, 0.02 * P], axis=1), region
     if lens:
         x = (i + 0.5) * dx - 0.5 * nx * dx
         y = (j + 0.5) * dy - 0.5 * ny * dy
@@ -419,7 +422,7 @@ def benchmark_initial_state(grid, ijk, eos="we", lens=True):
     return np.stack([P, second], axis=1), region
 
 
-def benchmark_sources(grid):
+def benchmark_sources(grid, co2_fraction=0.0):
     """4 injectors (10 kg/s, 1.0e6 J/kg) and 4 producers (-5 kg/s) at fixed box fractions."""
     nx, ny, nz = grid.dims
     out = []
@@ -427,6 +430,9 @@ def benchmark_sources(grid):
     for fx, fy in fr:
         out.append({"ijk": (int(fx * nx), int(fy * ny), int(0.7 * nz)), "rate": 10.0,
                     "enthalpy": 1.0e6, "component": 1})
+        if co2_fraction > 0.0:  # injectors carry 5 % CO2 (component 2) in configs 4/5
+            out[-1]["rate"] = 10.0 * (1.0 - co2_fraction)
+            out.append({"ijk": out[-1]["ijk"], "rate": 10.0 * co2_fraction, "enthalpy": 1.0e6, "component": 2})
     fr2 = [(0.5, 0.25), (0.25, 0.5), (0.75, 0.5), (0.5, 0.75)]
     for fx, fy in fr2:
         out.append({"ijk": (int(fx * nx), int(fy * ny), int(0.4 * nz)), "rate": -5.0,
