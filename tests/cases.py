@@ -5,14 +5,19 @@ from waiwera_amd import mesh as M
 
 
 def make_case(dims=(8, 8, 8), brick=(4, 4, 4), eos="we", lens=False, sources=True, part=(1, 1, 1),
-              rank=0, hetero=True, top_bc=True):
+              rank=0, hetero=True, top_bc=True, minc=False):
     g = M.StructuredGrid(dims, brick=brick, part=part)
     srcs = M.benchmark_sources(g, co2_fraction=0.05 if eos == "wce" else 0.0) if sources else None
     bc = None
     if top_bc:
         bc = {"we": ([1.0e5, 20.0], 1), "w": ([1.0e5], 1), "wce": ([1.0e5, 20.0, 0.02e5], 1)}[eos]
     rock = M.heterogeneous_rock(g.n_global) if hetero else None
-    lm = g.local_mesh(rank, rock_fn=rock, top_bc=bc, sources=srcs)
+    mspec = None
+    if minc:  # fracture fraction 0.1, one matrix level, 3 planes, 50 m
+        mrock = M.default_rock(1)[0]
+        mrock[0:3] = 1.0e-16
+        mspec = dict(geometry=M.MincGeometry([0.1, 0.9], [50.0, 50.0, 50.0]), matrix_rock=mrock)
+    lm = g.local_mesh(rank, rock_fn=rock, top_bc=bc, sources=srcs, minc=mspec)
     prim, region = M.benchmark_initial_state(g, lm.extras["prim_ijk"], eos=eos, lens=lens)
     return g, lm, prim, region
 

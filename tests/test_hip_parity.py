@@ -214,6 +214,41 @@ def test_timesteps(FS, oracle, eos, lens):
     sim.destroy(); osim.close()
 
 
+@pytest.mark.parametrize("eos", ["we", "wce"])
+def test_minc_dual_porosity(FS, oracle, eos):
+    """MINC matrix cells (BASELINE config 5 shape: one matrix level, nested cubes, 3 fracture
+    planes): irregular rows (8 blocks), chain faces with zero gravity term, generic sweep path."""
+    g, lm, sim, osim, y, region = build(FS, oracle, eos=eos, dims=(8, 6, 6), brick=(4, 3, 3), minc=True)
+    bs = sim.num_primary_variables
+    n = sim.n_owned * bs
+    assert lm.n_owned == 2 * 8 * 6 * 6
+    yo = osim.yvec(y)
+    assert sim.pre_eval(0.0, y) == 0 and osim.pre_eval(yo) == 0
+    L = osim.lhs()
+    dt = 5.0e2
+    f = np.zeros(n)
+    assert sim.residual(0.0, dt, y, L, f) == 0
+    err, fo = osim.residual(yo, dt, L)
+    assert np.abs(f - fo).max() <= 1e-11 * np.abs(fo).max()
+    assert sim.jacobian(0.0, dt, y, L) == 0
+    err, Jo = osim.jacobian(yo, dt, L, fo, mode=0)
+    Jg = sim.jacobian_values()
+    assert np.abs(Jg - Jo).max() <= 1e-5 * np.abs(Jo).max()
+    sim.set_opts(ksp_rtol=1e-10, ftol_rel=1e-9)
+    o = osim.opts()
+    o.ksp_rtol, o.ftol_rel = 1e-10, 1e-9
+    yg = y.copy()
+    for step in range(3):
+        reason, nits, kits = sim.timestep(0.0, dt, yg)
+        r, ok = osim.timestep(yo, dt, o)
+        assert (reason > 0) == (r > 0)
+        if reason > 0:
+            assert nits == r and np.array_equal(sim.regions(), osim.regions())
+            assert relmax(yg, yo[: yg.size]) < 1e-7
+        dt *= 2
+    sim.destroy(); osim.close()
+
+
 def test_domain_error_is_recoverable(FS, oracle):
     """EOS out of range -> err > 0 from pre_eval, exactly like the reference's err flag."""
     g, lm, sim, osim, y, region = build(FS, oracle)

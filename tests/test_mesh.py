@@ -70,3 +70,48 @@ def test_partition_shape():
     assert M.partition_shape(8) == (2, 2, 2) and M.partition_shape(4) == (2, 2, 1)
     assert M.partition_shape(2) == (2, 1, 1) and M.partition_shape(1) == (1, 1, 1)
     assert np.prod(M.partition_shape(6)) == 6
+
+
+def test_minc_geometry_matches_reference_unit_values():
+    """Known answers of test/unit/src/minc_test.F90:59-394 (proximity, derivative, inner
+    connection distance, setup_geometry areas / distances)."""
+    g1 = M.MincGeometry([0.1, 0.9], [50.0])
+    assert [g1.proximity(d) for d in (0.0, 10.0, 20.0, 25.0, 30.0)] == pytest.approx([0.0, 0.4, 0.8, 1.0, 1.0])
+    g3 = M.MincGeometry([0.1, 0.9], [50.0, 80.0, 60.0])
+    assert [g3.proximity(d) for d in (0.0, 10.0, 20.0, 25.0)] == pytest.approx([0.0, 0.7, 29.0 / 30.0, 1.0])
+    assert [g3.proximity_derivative(d) for d in (0.0, 10.0, 20.0)] == pytest.approx([0.0983333333, 0.045, 0.0116666667], rel=1e-8)
+    assert [g3.inner_connection_distance(d) for d in (0.0, 10.0, 20.0)] == pytest.approx([360.0 / 59.0, 4.0, 12.0 / 7.0])
+    g2 = M.MincGeometry([0.1, 0.9], [50.0, 80.0])
+    assert [g2.inner_connection_distance(d) for d in (0.0, 10.0, 20.0)] == pytest.approx([100.0 / 13.0, 5.0, 2.0])
+    a = M.MincGeometry([10, 90], [50.0])
+    assert a.connection_area == pytest.approx([0.036]) and a.connection_distance == pytest.approx([0.0, 25.0 / 3.0])
+    b = M.MincGeometry([10, 20, 30, 40], [100.0])
+    assert b.connection_area == pytest.approx([0.018, 0.018, 0.018])
+    assert b.connection_distance == pytest.approx([0.0, 50.0 / 9.0, 25.0 / 3.0, 7400.0 / 999.0], rel=1e-8)
+    c = M.MincGeometry([10, 30, 60], [100.0, 80.0, 90.0])
+    assert c.connection_area == pytest.approx([0.0605, 0.046229920797811137], rel=1e-7)
+    assert c.connection_distance == pytest.approx([0.0, 2.8192309717077664, 7.7871646178561607], rel=1e-7)
+
+
+def test_minc_mesh_structure():
+    g = M.StructuredGrid((8, 8, 4), part=(2, 1, 1), brick=(4, 4, 4))
+    geo = M.MincGeometry([0.1, 0.9], [50.0, 50.0, 50.0])
+    mrock = M.default_rock(1)[0]
+    mrock[0:3] = 1.0e-16
+    for r in range(2):
+        base = g.local_mesh(r, top_bc=([1e5, 20.0], 1), sources=M.benchmark_sources(g))
+        m = g.local_mesh(r, top_bc=([1e5, 20.0], 1), sources=M.benchmark_sources(g), minc=dict(geometry=geo, matrix_rock=mrock))
+        assert m.n_owned == 2 * base.n_owned and m.n_faces == base.n_faces + base.n_owned
+        assert m.sub_ptr[-1] == m.n_owned and np.all(np.diff(m.sub_ptr) == 2 * np.diff(base.sub_ptr))
+        vol = m.cell_geom[: m.n_owned, 3]
+        lev = m.extras["minc_level"]
+        assert np.allclose(vol[lev == 0], 100.0) and np.allclose(vol[lev == 1], 900.0)
+        mf = m.face_geom[base.n_faces:]
+        assert np.allclose(mf[:, 0], 1000.0 * geo.connection_area[0]) and np.all(mf[:, 7] == 0.0)
+        assert np.allclose(mf[:, 1], 0.0) and np.allclose(mf[:, 2], 5.0) and np.allclose(mf[:, 3], 5.0)
+        c1, c2 = m.face_cells[base.n_faces:, 0], m.face_cells[base.n_faces:, 1]
+        assert np.all(lev[c1] == 0) and np.all(lev[c2] == 1) and np.array_equal(m.owned_ijk[c1], m.owned_ijk[c2])
+        # every matrix cell sits in the same brick as its fracture cell
+        sub = np.searchsorted(m.sub_ptr, np.arange(m.n_owned), side="right") - 1
+        assert np.array_equal(sub[c1], sub[c2])
+        assert np.all(m.send_idx < m.n_owned) and np.all(lev[m.send_idx] == 0)

@@ -148,14 +148,24 @@ class StructuredGrid:
         nx, ny, _ = self.dims
         return (np.asarray(k, dtype=np.int64) * ny + j) * nx + i
 
+    def _local_mesh_minc(self, rank, rock_fn, top_bc, sources, minc):
+        base = self.local_mesh(rank, rock_fn=rock_fn, top_bc=top_bc, sources=sources)
+        return _add_minc(self, base, minc)
+
     # -------------------------------------------------------------------------------------
-    def local_mesh(self, rank=0, rock_fn=None, top_bc=None, sources=None):
+    def local_mesh(self, rank=0, rock_fn=None, top_bc=None, sources=None, minc=None):
         """Build the flat arrays of one rank.
 
         rock_fn(gid) -> (n, 8) rock records for natural cell ids; top_bc = (primary, region)
         puts Dirichlet ghost cells on the top (k = 0) faces; sources = list of dicts
-        {ijk, rate, enthalpy, component} in global coordinates.
+        {ijk, rate, enthalpy, component} in global coordinates.  minc = dict(geometry=MincGeometry,
+        matrix_rock=(8,) record) adds the MINC matrix cells of every owned fracture cell
+        (src/mesh.F90:3026-3186): inside a brick the fracture cells come first, then level 1, ...;
+        matrix cell of level m is connected to level m-1 by a face with area V*connection_area(m),
+        distances (cd(m), cd(m+1)), zero normal and gravity term, permeability direction 1.
         """
+        if minc is not None:
+            return self._local_mesh_minc(rank, rock_fn, top_bc, sources, minc)
         nx, ny, nz = self.dims
         dx, dy, dz = self.spacing
         rc = self.rank_coords(rank)
@@ -355,6 +365,143 @@ class StructuredGrid:
             m.src_enthalpy = np.array(se, dtype=np.float64)
             m.src_component = np.array(sk, dtype=np.int32)
         return m
+
+
+class MincGeometry:
+    """MINC 'nested cube' geometry (src/minc.F90:393-548): proximity function, its derivative,
+    innermost connection distance and the per-level connection areas / distances of
+    minc_setup_geometry.  volumes = [fracture, matrix level 1, ...] volume fractions."""
+
+    def __init__(self, volumes, spacing, fracture_connection_distance=0.0):
+        self.volume = np.asarray(volumes, dtype=np.float64)
+        self.volume = self.volume / self.volume.sum()
+        self.spacing = np.atleast_1d(np.asarray(spacing, dtype=np.float64))
+        self.num_planes = self.spacing.size
+        self.num_levels = self.volume.size - 1
+        self.fracture_connection_distance = fracture_connection_distance
+        self._setup()
+
+    def proximity(self, d):                       # minc.F90:393-411
+        fout = 1.0 - 2.0 * d / self.spacing
+        return 1.0 if np.any(fout < 0.0) else 1.0 - float(np.prod(fout))
+
+    def proximity_derivative(self, d):            # minc.F90:415-434
+        fout = 1.0 - 2.0 * d / self.spacing
+        if np.any(fout < 0.0):
+            return 0.0
+        excl = np.array([np.prod(np.delete(fout, i)) for i in range(fout.size)])
+        return 2.0 * float(np.sum(excl / self.spacing))
+
+    def inner_connection_distance(self, x):       # minc.F90:438-461 (Pruess 1983, GMINC)
+        u = self.spacing - 2.0 * x
+        if self.num_planes == 1:
+            return u[0] / 6.0
+        if self.num_planes == 2:
+            return 0.25 * np.prod(u) / np.sum(u)
+        pair = sum(u[i] * u[(i + 1) % 3] for i in range(3))
+        return 0.3 * np.prod(u) / pair
+
+    def _setup(self):                             # minc.F90:465-525
+        from scipy.optimize import brentq
+        vmatrix = 1.0 - self.volume[0]
+        volsum = np.cumsum(self.volume[1:]) / vmatrix
+        nl = self.num_levels
+        self.connection_distance = np.zeros(nl + 1)
+        self.connection_area = np.zeros(nl)
+        x = 0.0
+        self.connection_distance[0] = self.fracture_connection_distance
+        self.connection_area[0] = vmatrix * self.proximity_derivative(x)
+        xr = self.volume[1] / self.connection_area[0]
+        for i in range(nl - 1):
+            xl = x
+            f = lambda xx, v=volsum[i]: self.proximity(xx) - v
+            while f(xr) < 0.0:
+                xr *= 2.0
+            x = brentq(f, xl, xr, xtol=1e-12, rtol=1e-14)
+            self.connection_distance[i + 1] = 0.5 * (x - xl)
+            self.connection_area[i + 1] = vmatrix * self.proximity_derivative(x)
+        self.connection_distance[nl] = self.inner_connection_distance(x)
+
+
+def _add_minc(grid, base, minc):
+    """Rebuild a fracture-only LocalMesh with MINC matrix cells inserted brick by brick."""
+    geo, mrock = minc["geometry"], np.asarray(minc["matrix_rock"], dtype=np.float64)
+    nl = geo.num_levels
+    no = base.n_owned
+    sp = base.sub_ptr.astype(np.int64)
+    nsub = sp.size - 1
+    bsize = np.diff(sp)
+    # new index of fracture cell i and of its level-m matrix cell
+    sub_of = np.repeat(np.arange(nsub), bsize)
+    new_start = sp * (nl + 1)
+    within = np.arange(no) - sp[sub_of]
+    frac_new = new_start[sub_of] + within
+    level_new = [new_start[sub_of] + bsize[sub_of] * m + within for m in range(1, nl + 1)]
+    n_owned_new = no * (nl + 1)
+
+    def remap(idx):
+        idx = np.asarray(idx, dtype=np.int64)
+        out = np.where(idx < no, 0, idx + no * nl)
+        own = idx < no
+        out[own] = frac_new[idx[own]]
+        return out
+    m = LocalMesh(dims=base.dims, spacing=base.spacing, part=base.part, rank=base.rank, brick=base.brick,
+                  n_global=base.n_global)
+    m.n_owned, m.n_halo, m.n_bc = n_owned_new, base.n_halo, base.n_bc
+    n_local = m.n_local
+    # cells
+    cg = np.zeros((n_local, 4))
+    rock = np.zeros((n_local, 8))
+    cg[remap(np.arange(base.n_local))] = base.cell_geom
+    rock[remap(np.arange(base.n_local))] = base.rock
+    vol0 = base.cell_geom[:no, 3]
+    cg[frac_new, 3] = vol0 * geo.volume[0]
+    for mlev in range(1, nl + 1):
+        cg[level_new[mlev - 1], 0:3] = base.cell_geom[:no, 0:3]
+        cg[level_new[mlev - 1], 3] = vol0 * geo.volume[mlev]
+        rock[level_new[mlev - 1]] = mrock
+    # halo fracture cells keep the reduced fracture volume too (only used through faces of owned cells)
+    cg[n_owned_new:n_owned_new + base.n_halo, 3] *= geo.volume[0]
+    m.cell_geom, m.rock = cg, rock
+    # faces: original ones remapped, then MINC faces level by level
+    fc = [remap(base.face_cells.ravel()).reshape(-1, 2)]
+    fg = [base.face_geom]
+    for mlev in range(1, nl + 1):
+        c1 = frac_new if mlev == 1 else level_new[mlev - 2]
+        c2 = level_new[mlev - 1]
+        g = np.zeros((no, 12))
+        g[:, 0] = vol0 * geo.connection_area[mlev - 1]
+        g[:, 1] = geo.connection_distance[mlev - 1]
+        g[:, 2] = geo.connection_distance[mlev]
+        g[:, 3] = g[:, 1] + g[:, 2]
+        g[:, 8:11] = base.cell_geom[:no, 0:3]
+        g[:, 11] = 1.0
+        fc.append(np.stack([c1, c2], axis=1))
+        fg.append(g)
+    m.face_cells = np.concatenate(fc).astype(np.int32)
+    m.face_geom = np.concatenate(fg)
+    m.n_faces = m.face_cells.shape[0]
+    m.sub_ptr = (sp * (nl + 1)).astype(np.int32)
+    m.bc_primary, m.bc_region = base.bc_primary, base.bc_region
+    m.owned_gid = np.full(n_owned_new, -1, dtype=np.int64)
+    m.owned_gid[frac_new] = base.owned_gid
+    m.owned_ijk = np.zeros((n_owned_new, 3), dtype=np.int32)
+    m.owned_ijk[frac_new] = base.owned_ijk
+    for mlev in range(1, nl + 1):
+        m.owned_ijk[level_new[mlev - 1]] = base.owned_ijk
+    m.extras["minc_level"] = np.zeros(n_owned_new, dtype=np.int32)
+    for mlev in range(1, nl + 1):
+        m.extras["minc_level"][level_new[mlev - 1]] = mlev
+    m.extras["fracture_index"] = frac_new
+    pijk = np.concatenate([m.owned_ijk.astype(np.int64), base.extras["prim_ijk"][no:]])
+    m.extras["prim_ijk"] = pijk
+    m.nbr_ranks, m.send_ptr, m.recv_ptr = base.nbr_ranks, base.send_ptr, base.recv_ptr
+    m.send_idx = frac_new[base.send_idx].astype(np.int32) if base.send_idx is not None and base.send_idx.size else base.send_idx
+    m.n_src = base.n_src
+    if base.n_src:
+        m.src_cell = frac_new[base.src_cell].astype(np.int32)
+        m.src_rate, m.src_enthalpy, m.src_component = base.src_rate, base.src_enthalpy, base.src_component
+    return m
 
 
 def default_rock(n):
