@@ -225,7 +225,7 @@ def test_minc_dual_porosity(FS, oracle, eos):
     yo = osim.yvec(y)
     assert sim.pre_eval(0.0, y) == 0 and osim.pre_eval(yo) == 0
     L = osim.lhs()
-    dt = 5.0e2
+    dt = 1.0e2   # the fracture cells hold 10 % of the volume: injection needs small first steps
     f = np.zeros(n)
     assert sim.residual(0.0, dt, y, L, f) == 0
     err, fo = osim.residual(yo, dt, L)
@@ -238,14 +238,17 @@ def test_minc_dual_porosity(FS, oracle, eos):
     o = osim.opts()
     o.ksp_rtol, o.ftol_rel = 1e-10, 1e-9
     yg = y.copy()
+    converged = 0
     for step in range(3):
         reason, nits, kits = sim.timestep(0.0, dt, yg)
         r, ok = osim.timestep(yo, dt, o)
         assert (reason > 0) == (r > 0)
         if reason > 0:
+            converged += 1
             assert nits == r and np.array_equal(sim.regions(), osim.regions())
             assert relmax(yg, yo[: yg.size]) < 1e-7
         dt *= 2
+    assert converged == 3
     sim.destroy(); osim.close()
 
 
