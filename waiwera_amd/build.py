@@ -14,7 +14,7 @@ SOURCES = ["capi.hip", "kernels_assembly.hip", "kernels_linalg.hip", "comm.cpp"]
 HEADERS = ["context.hpp", "comm.hpp", "physics.hip.h", "if97.hip.h", "if97_tables.hip.h",
            os.path.join("..", "..", "include", "waiwera_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
-         "-Wno-unused-value"]
+         "-Wno-unused-value"] + os.environ.get("WAI_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _stale(target, deps):

@@ -24,6 +24,9 @@
 namespace wai {
 
 constexpr int TPB = 256;
+#ifndef PC_MIN_WAVES
+#define PC_MIN_WAVES 4   // waves per SIMD k_pc is compiled for; 5 or 6 force spills and measured 1.2x / 3x slower (tools/ab_pc_waves.sh)
+#endif
 constexpr int WMAX = 8;  // block-ELL width handled in registers (7-point stencil: 7, MINC: 8)
 
 enum { S_RHO = 0, S_RHOOLD = 1, S_ALPHA = 2, S_OMEGA = 3, S_BETA = 4, S_D1 = 5, S_D2 = 6,
@@ -257,7 +260,7 @@ __device__ __forceinline__ void wg_reduce_store(double (&v)[NS], double* red, do
 // matrix row a thread pulled in for the SpMV is then reused for both substitutions and only the
 // inverted pivot block is read from the factor: ~300 instead of ~520 bytes per block row.
 template <int BS, bool SPMV, bool DILU, bool WP, bool FAST>
-__global__ void k_pc(int n, int W, int nsub, const int* __restrict__ sub_ptr,
+__global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n, int W, int nsub, const int* __restrict__ sub_ptr,
                      const int* __restrict__ sub_nlev, const int* __restrict__ row_info,
                      const int* __restrict__ col, const double* __restrict__ aval,
                      const double* __restrict__ fval, const double* __restrict__ dinv,
@@ -289,6 +292,21 @@ __global__ void k_pc(int n, int W, int nsub, const int* __restrict__ sub_ptr,
   double dv[BB];
 #pragma unroll
   for (int e = 0; e < BB; e++) dv[e] = 0.0;
+  // FAST: every row has at most 3 lower and 3 upper couplings inside its subdomain and the
+  // first in-subdomain slot / the diagonal slot are < 4 (7-point stencils).  The lower / upper
+  // blocks are compacted into fixed positions with register selects, so a level update is 3
+  // unconditional LDS reads + straight-line FMAs instead of one divergent branch and LDS wait
+  // per matrix slot.  In the DILU case the compaction happens slot by slot as the blocks are
+  // consumed by the SpMV, which keeps the live register set (and so the occupancy) small.
+  constexpr int MLU = 3;
+  double Lf[MLU][BB], Uf[MLU][BB];
+  int Lc[MLU], Uc[MLU];
+#pragma unroll
+  for (int p = 0; p < MLU; p++) {
+    Lc[p] = tid; Uc[p] = tid;
+#pragma unroll
+    for (int e = 0; e < BB; e++) { Lf[p][e] = 0.0; Uf[p][e] = 0.0; }
+  }
   if (active) {
     unpack_info(row_info[i], lfirst, dslot, ulast, lf, lb);
     double acc[BS];
@@ -298,8 +316,8 @@ __global__ void k_pc(int n, int W, int nsub, const int* __restrict__ sub_ptr,
       for (int q = 0; q < WMAX; q++) {
         if (q < W) {
           const int cg = col[(size_t)q * n + i];
-          fc[q] = cg - lo;
-          load_block<BS>(aval, n, q, i, f[q]);
+          double blk[BB];
+          load_block<BS>(aval, n, q, i, blk);
           if constexpr (SPMV) {
             double xv[BS];
             load_x<BS>(in, cg, xv);
@@ -310,7 +328,25 @@ __global__ void k_pc(int n, int W, int nsub, const int* __restrict__ sub_ptr,
 #pragma unroll
             for (int r = 0; r < BS; r++)
 #pragma unroll
-              for (int k = 0; k < BS; k++) acc[r] += f[q][r * BS + k] * xv[k];
+              for (int k = 0; k < BS; k++) acc[r] += blk[r * BS + k] * xv[k];
+          }
+          if constexpr (FAST) {
+            const bool isl = (q >= lfirst) && (q < dslot), isu = (q > dslot) && (q < ulast);
+#pragma unroll
+            for (int p = 0; p < MLU; p++) {
+              const bool tl = isl && (q - lfirst == p), tu = isu && (q - dslot - 1 == p);
+              Lc[p] = tl ? cg - lo : Lc[p];
+              Uc[p] = tu ? cg - lo : Uc[p];
+#pragma unroll
+              for (int e = 0; e < BB; e++) {
+                Lf[p][e] = tl ? blk[e] : Lf[p][e];
+                Uf[p][e] = tu ? blk[e] : Uf[p][e];
+              }
+            }
+          } else {
+            fc[q] = cg - lo;
+#pragma unroll
+            for (int e = 0; e < BB; e++) f[q][e] = blk[e];
           }
         }
       }
@@ -357,21 +393,10 @@ __global__ void k_pc(int n, int W, int nsub, const int* __restrict__ sub_ptr,
 #pragma unroll
     for (int r = 0; r < BS; r++) ys[tid * BS + r] = acc[r];
   }
-  // FAST: every row has at most 3 lower and 3 upper couplings inside its subdomain and the
-  // first in-subdomain slot / the diagonal slot are < 4 (7-point stencils, MINC chains).  The
-  // lower / upper blocks are compacted once into fixed positions with register selects, so a
-  // level update is 3 unconditional LDS reads + straight-line FMAs instead of one divergent
-  // branch and LDS wait per matrix slot.
-  constexpr int MLU = 3;
-  double Lf[MLU][BB], Uf[MLU][BB];
-  int Lc[MLU], Uc[MLU];
-  if constexpr (FAST) {
+  if constexpr (FAST && !DILU) {  // stored-factor path: compact from the loaded factor row
     const int nL = dslot - lfirst, nU = ulast - dslot - 1;
 #pragma unroll
     for (int p = 0; p < MLU; p++) {
-      Lc[p] = tid; Uc[p] = tid;
-#pragma unroll
-      for (int e = 0; e < BB; e++) { Lf[p][e] = 0.0; Uf[p][e] = 0.0; }
 #pragma unroll
       for (int o = 0; o < 4; o++) {  // candidate source slots p + o (lower), p + 1 + o (upper)
         const bool tl = active && (lfirst == o) && (p < nL);
