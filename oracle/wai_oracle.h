@@ -15,6 +15,10 @@
  * for those functions parity is UNPINNED at the iterate level; they restate PETSc's published
  * algorithms and are cross-checked against scipy on the same operators (tests/).
  *
+ * The hot loops carry OpenMP pragmas so that bench.py's cpu_baseline can use every host core
+ * (block-Jacobi subdomains, rows and cells are independent); with OMP_NUM_THREADS=1 (the
+ * test default) everything is sequential and deterministic.
+ *
  * Layouts follow the reference exactly (AoS):
  *   fluid record  : src/fluid.F90:36-52,212-267   [P,T,region,old_region,phases,perm_factor,
  *                    Pp(nc)] + per phase [rho,mu,S,kr,Pc,h,u,X(nc)]

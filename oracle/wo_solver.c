@@ -14,6 +14,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define MAXBS 4
 
@@ -37,6 +40,9 @@ struct wo_sim {
   void *user;
   double *fval, *dinv;
 };
+
+static void cell_residual(const wo_sim *s, int c, double dt, const double *lhs_old, int which,
+                          const double *alt, double *out);
 
 static void *xmalloc(size_t n) {
   void *p = calloc(n ? n : 1, 1);
@@ -235,8 +241,9 @@ int wo_pre_eval(wo_sim *s, double *y) {
     for (int c = s->n_owned; c < s->n_prim; c++) s->fluid[c * df + 2] = reg[c];
     free(reg);
   }
+#pragma omp parallel for reduction(| : err) schedule(static)
   for (int c = 0; c < s->n_prim; c++) {
-    if (eval_cell_fluid(&s->eos, y + c * np, s->fluid + (size_t)c * df)) { err = 1; break; }
+    if (eval_cell_fluid(&s->eos, y + c * np, s->fluid + (size_t)c * df)) err |= 1;
   }
   return collective_err(s, err);
 }
@@ -244,6 +251,7 @@ int wo_pre_eval(wo_sim *s, double *y) {
 /* flow_simulation_cell_balances: src/flow_simulation.F90:1242-1330 */
 void wo_lhs(wo_sim *s, double *lhs) {
   int np = s->eos.np, df = s->eos.df;
+#pragma omp parallel for schedule(static)
   for (int c = 0; c < s->n_owned; c++)
     wo_cell_balance(&s->eos, s->fluid + (size_t)c * df, s->rock + c * 8, lhs + c * np);
 }
@@ -322,6 +330,16 @@ int wo_residual(wo_sim *s, double *y, double dt, const double *lhs_old, double *
   int n = s->eos.np * s->n_owned;
   int err = wo_pre_eval(s, y);
   if (err) return err;
+#ifdef _OPENMP
+  if (omp_get_max_threads() > 1) {
+    /* multi-core baseline: every cell gathers its own faces (cell_residual, the form the FD
+     * Jacobian uses; identical sums in identical order), so no scatter races */
+    int np = s->eos.np;
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < s->n_owned; c++) cell_residual(s, c, dt, lhs_old, -1, NULL, f + c * np);
+    return 0;
+  }
+#endif
   double *L = (double *)xmalloc(sizeof(double) * n), *R = (double *)xmalloc(sizeof(double) * n);
   wo_lhs(s, L);
   wo_rhs(s, R);
@@ -381,7 +399,8 @@ static int jacobian_local(wo_sim *s, double *y, double dt, const double *lhs_old
   /* perturbed fluid records for every cell with primaries: pert[(c*np + k)*df] */
   double *pert = (double *)xmalloc(sizeof(double) * (size_t)s->n_prim * np * df);
   double *h = (double *)xmalloc(sizeof(double) * s->n_prim * np);
-  for (int c = 0; c < s->n_prim && !err; c++)
+#pragma omp parallel for reduction(| : err) schedule(static)
+  for (int c = 0; c < s->n_prim; c++)
     for (int k = 0; k < np; k++) {
       double yp[MAXBS];
       for (int q = 0; q < np; q++) yp[q] = y[c * np + q];
@@ -389,11 +408,12 @@ static int jacobian_local(wo_sim *s, double *y, double dt, const double *lhs_old
       yp[k] += h[c * np + k];
       double *fl = pert + ((size_t)c * np + k) * df;
       memcpy(fl, s->fluid + (size_t)c * df, sizeof(double) * df);
-      if (eval_cell_fluid(e, yp, fl)) { err = 1; break; }
+      if (eval_cell_fluid(e, yp, fl)) err |= 1;
     }
   err = collective_err(s, err);
   if (err) { free(pert); free(h); return err; }
   memset(val, 0, sizeof(double) * (size_t)s->nnzb * bb);
+#pragma omp parallel for schedule(static)
   for (int c = 0; c < s->n_owned; c++) {
     double f0[MAXBS], f1[MAXBS];
     cell_residual(s, c, dt, lhs_old, -1, NULL, f0);
@@ -539,6 +559,7 @@ int wo_post_linesearch(wo_sim *s, const double *y_old, double *search, double *y
 void wo_bcsr_spmv(int n, int bs, const int *rowptr, const int *colidx, const double *val,
                   const double *x, double *y) {
   int bb = bs * bs;
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < n; i++) {
     double acc[MAXBS] = {0, 0, 0, 0};
     for (int q = rowptr[i]; q < rowptr[i + 1]; q++) {
@@ -592,6 +613,7 @@ int wo_bilu0_factor(int n, int bs, const int *rowptr, const int *colidx, const d
                     int nsub, const int *sub_ptr, double *fval, double *dinv) {
   int bb = bs * bs, err = 0;
   memcpy(fval, val, sizeof(double) * (size_t)rowptr[n] * bb);
+#pragma omp parallel for reduction(| : err) schedule(dynamic, 8)
   for (int sd = 0; sd < nsub; sd++) {
     int lo = sub_ptr[sd], hi = sub_ptr[sd + 1];
     for (int i = lo; i < hi; i++) {
@@ -617,7 +639,7 @@ int wo_bilu0_factor(int n, int bs, const int *rowptr, const int *colidx, const d
             }
         }
       }
-      if (qdiag < 0 || block_inverse(bs, fval + (size_t)qdiag * bb, dinv + (size_t)i * bb)) err = 1;
+      if (qdiag < 0 || block_inverse(bs, fval + (size_t)qdiag * bb, dinv + (size_t)i * bb)) err |= 1;
     }
   }
   return err;
@@ -628,6 +650,7 @@ void wo_bilu0_apply(int n, int bs, const int *rowptr, const int *colidx, const d
                     double *z) {
   int bb = bs * bs;
   (void)n;
+#pragma omp parallel for schedule(dynamic, 8)
   for (int sd = 0; sd < nsub; sd++) {
     int lo = sub_ptr[sd], hi = sub_ptr[sd + 1];
     for (int i = lo; i < hi; i++) { /* forward: L y = r */
@@ -665,6 +688,7 @@ void wo_bilu0_apply(int n, int bs, const int *rowptr, const int *colidx, const d
 /* ---- Krylov [PETSc KSPBCGS / KSPGMRES, left preconditioning, preconditioned norm] -------- */
 static double gdot(wo_sim *s, const double *a, const double *b, int n) {
   double t = 0.0;
+#pragma omp parallel for reduction(+ : t) schedule(static)
   for (int i = 0; i < n; i++) t += a[i] * b[i];
   if (s->ar) s->ar(s->user, &t, 1, 0);
   return t;
@@ -701,11 +725,13 @@ static int ksp_bcgs(wo_sim *s, const double *val, const double *b, double *x, do
     double rho = gdot(s, R, RP, n);
     if (rho == 0.0) { reason = -5; break; }
     double beta = (rho / rhoold) * (alphaold / omegaold);
+#pragma omp parallel for schedule(static)
     for (int q = 0; q < n; q++) P[q] = R[q] + (-omegaold * beta) * V[q] + beta * P[q];
     pc_amul(s, val, P, tmp, V);
     double d1 = gdot(s, V, RP, n);
     if (d1 == 0.0) { reason = -5; break; }
     double alpha = rho / d1;
+#pragma omp parallel for schedule(static)
     for (int q = 0; q < n; q++) S[q] = R[q] - alpha * V[q];
     pc_amul(s, val, S, tmp, T);
     double d2;
@@ -722,7 +748,9 @@ static int ksp_bcgs(wo_sim *s, const double *val, const double *b, double *x, do
       break;
     }
     double omega = d1 / d2;
+#pragma omp parallel for schedule(static)
     for (int q = 0; q < n; q++) x[q] += alpha * P[q] + omega * S[q];
+#pragma omp parallel for schedule(static)
     for (int q = 0; q < n; q++) R[q] = S[q] - omega * T[q];
     dp = sqrt(gdot(s, R, R, n));
     rhoold = rho; alphaold = alpha; omegaold = omega;

@@ -4,6 +4,8 @@ import sys
 
 import pytest
 
+os.environ.setdefault("OMP_NUM_THREADS", "1")  # the oracle is the checker: keep it deterministic
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
