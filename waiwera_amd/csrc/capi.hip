@@ -26,7 +26,7 @@ using namespace wai;
 namespace {
 
 enum { S_RHO = 0, S_RHOOLD = 1, S_ALPHA = 2, S_OMEGA = 3, S_BETA = 4, S_D1 = 5, S_D2 = 6,
-       S_DP2 = 7, S_W2 = 8, S_RHONEW = 9, S_BREAK = 15, S_H = 16 };
+       S_DP2 = 7, S_RHONEW = 8, S_W2 = 9, S_BREAK = 15, S_H = 16 };
 constexpr int NSLOTS = 64;
 constexpr int NSCAL = 128;
 
@@ -245,8 +245,8 @@ int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, doub
       if (multi) { if ((rc = allreduce_scal(c, S_D1, 2))) break; bcgs_scalars(c, 3); }
       bcgs_update_xr(c);
       vec_finalize(c, k.nblocks, S_DP2, 2, multi ? -1 : 4);
-      if (multi) {
-        if ((rc = allreduce_scal(c, S_DP2, 1)) || (rc = allreduce_scal(c, S_RHONEW, 1))) break;
+      if (multi) {  // (R,R) and (R,RP) sit in adjacent slots: one 16-byte all-reduce
+        if ((rc = allreduce_scal(c, S_DP2, 2))) break;
         bcgs_scalars(c, 4);
       }
     }
@@ -321,7 +321,7 @@ int ksp_gmres(wai_ctx* c, const double* b, double* x, int* its, int* reason, dou
         if (allreduce_scal(c, S_W2, 1)) return -1;
         gmres_scale_to(c, vn, w, S_W2, n);
       }
-      if (read_scal(c, S_W2, S_H + j + 1 - S_W2)) return -1;
+      if (read_scal(c, S_W2, S_H + j + 1 - S_W2)) return -1;  // |w|^2 and h_0..h_j
       for (int i = 0; i <= j; i++) H[(size_t)i * m + j] = k.h_scal[S_H + i];
       const double hn = std::sqrt(k.h_scal[S_W2]);
       H[(size_t)(j + 1) * m + j] = hn;

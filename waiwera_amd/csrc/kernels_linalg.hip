@@ -30,7 +30,7 @@ constexpr int TPB = 256;
 constexpr int WMAX = 8;  // block-ELL width handled in registers (7-point stencil: 7, MINC: 8)
 
 enum { S_RHO = 0, S_RHOOLD = 1, S_ALPHA = 2, S_OMEGA = 3, S_BETA = 4, S_D1 = 5, S_D2 = 6,
-       S_DP2 = 7, S_W2 = 8, S_RHONEW = 9, S_BREAK = 15, S_H = 16 };
+       S_DP2 = 7, S_RHONEW = 8, S_W2 = 9, S_BREAK = 15, S_H = 16 };
 
 __device__ __forceinline__ int xcd_remap(int b, int n) {
   // dispatch places block b on XCD b % 8: give XCD j the contiguous range j*per .. (j+1)*per
@@ -869,7 +869,6 @@ int launch_bcsr_to_ell(wai_ctx* c, const double* bcsr, double* ell) {
 
 int vec_finalize(wai_ctx* c, int nb, int slot0, int nslots, int phase) {
   int4 sl = make_int4(slot0, slot0 + 1, slot0 + 2, slot0 + 3);
-  if (slot0 == S_DP2 && nslots == 2) sl = make_int4(S_DP2, S_RHONEW, 0, 0);
   const int T = nb > 256 ? 1024 : 256;
   hipLaunchKernelGGL(k_finalize, 1, T, 0, c->stream, c->ks.partials, c->ks.nb_max, nb, sl, nslots, c->ks.scal, phase);
   return 0;
