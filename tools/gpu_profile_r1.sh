@@ -1,10 +1,14 @@
+# Round-1 evidence run on one MI355X: default bench line, rocprofv3 kernel-trace stats of the
+# same command, and separate PMC passes (FETCH_SIZE / WRITE_SIZE) for HBM traffic at 216^3.
 set -x
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python bench.py --steps 6 --warmup 2 > gpurun_out/bench_r1.json 2> gpurun_out/bench_r1.log
-tail -3 gpurun_out/bench_r1.log
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_kt -o r1 -- python bench.py --steps 3 --warmup 1 --no-cpu > gpurun_out/prof_kt.log 2>&1
-ls -R gpurun_out/prof_kt | head -20
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/prof_fetch -o r1 -- python bench.py --dims 160 160 160 --steps 1 --warmup 0 --no-cpu --spmv-reps 5 > gpurun_out/prof_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/prof_write -o r1 -- python bench.py --dims 160 160 160 --steps 1 --warmup 0 --no-cpu --spmv-reps 5 > gpurun_out/prof_write.log 2>&1
-ls -R gpurun_out/prof_fetch | head; du -sh gpurun_out/*
+python bench.py > gpurun_out/bench_r1.json 2> gpurun_out/bench_r1.log
+tail -2 gpurun_out/bench_r1.log | cut -c1-400
+rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o r1 -- python bench.py --no-cpu > gpurun_out/prof_kt.log 2>&1
+python tools/rocprof_summary.py /tmp/prof_kt/r1_results.db gpurun_out/rocprof_kernel_stats_r1.txt
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_fetch -o r1 -- python bench.py --steps 1 --warmup 0 --no-cpu --spmv-reps 10 > gpurun_out/prof_fetch.log 2>&1
+python tools/rocprof_summary.py /tmp/prof_fetch/r1_results.db gpurun_out/rocprof_pmc_fetch_r1.txt --pmc
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/prof_write -o r1 -- python bench.py --steps 1 --warmup 0 --no-cpu --spmv-reps 10 > gpurun_out/prof_write.log 2>&1
+python tools/rocprof_summary.py /tmp/prof_write/r1_results.db gpurun_out/rocprof_pmc_write_r1.txt --pmc
+du -sh /tmp/prof_kt /tmp/prof_fetch /tmp/prof_write

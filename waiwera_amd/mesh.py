@@ -35,18 +35,27 @@ def _splits(n, parts):
 
 
 class _Axis:
-    """Per-axis decomposition: ranks own whole bricks; bricks may be ragged at the end."""
+    """Per-axis decomposition.  Ranks get a balanced contiguous range of cells; every rank's range
+    is tiled with bricks starting at its lower end (the last brick of a rank may be ragged), so
+    preconditioner bricks never straddle ranks and the load stays balanced whatever the brick."""
 
     def __init__(self, n, parts, brick):
         self.n, self.parts = n, parts
-        nb = -(-n // brick)
-        edges = np.minimum(np.arange(nb + 1) * brick, n)  # brick boundaries
-        bsplit = _splits(nb, parts)  # bricks per rank
-        self.rank_lo = edges[bsplit[:-1]]
-        self.rank_hi = edges[bsplit[1:]]
+        csplit = _splits(n, parts)                      # balanced cell ranges
+        self.rank_lo = csplit[:-1].copy()
+        self.rank_hi = csplit[1:].copy()
+        edges, bsplit = [], [0]
+        for r in range(parts):
+            lo, hi = int(csplit[r]), int(csplit[r + 1])
+            e = list(range(lo, hi, brick))
+            edges += e
+            bsplit.append(len(edges))
+        edges.append(n)
+        edges = np.array(edges, dtype=np.int64)
+        bsplit = np.array(bsplit, dtype=np.int64)
         c = np.arange(n)
-        self.brick_of = np.minimum(c // brick, nb - 1)
-        self.rank_of = np.searchsorted(bsplit, self.brick_of, side="right") - 1
+        self.brick_of = np.searchsorted(edges, c, side="right") - 1
+        self.rank_of = np.searchsorted(csplit, c, side="right") - 1
         self.brick_in_rank = self.brick_of - bsplit[self.rank_of]
         self.off = c - edges[self.brick_of]
         self.bsize = (edges[1:] - edges[:-1])[self.brick_of]
