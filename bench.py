@@ -113,49 +113,57 @@ def traffic_from_profiles(dims):
     return None
 
 
-def cpu_baseline(dims_full, seconds=15.0):
-    """Oracle (CPU restatement of the reference path, OpenMP over the host cores the process may
-    use) on a bounded sample of the same workload: whole Newton steps of the same synthetic
-    problem on a smaller box for ~15 s, scaled by cell count to the full mesh."""
+def cpu_baseline(dims_full):
+    """Oracle (CPU restatement of the reference path, OpenMP) on a bounded sample of the same
+    workload: the first backward-Euler step (dt = 2e3 s, 4 Newton iterations) of the same
+    synthetic problem on a 96^3 box, run at several thread counts; the best rate is reported
+    (cores = the thread count that achieved it) and scaled by cell count to the full mesh."""
+    import ctypes
     so = os.path.join(ROOT, "oracle", "liboracle.so")
     if not os.path.exists(so):
         return None
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    os.environ["OMP_NUM_THREADS"] = str(cores)   # read by libgomp when the oracle is first loaded
+        avail = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(avail))
     from tests import oracle_lib as ol
     from tests.cases import scaled
     from waiwera_amd import mesh as M
     L = ol.load(so)
-    dims = (64, 64, 64) if cores >= 8 else (40, 40, 40)
+    try:
+        gomp = ctypes.CDLL("libgomp.so.1")
+    except OSError:
+        gomp = None
+    dims = (96, 96, 96) if avail >= 16 else (40, 40, 40)
     g = M.StructuredGrid(dims, brick=(8, 8, 8))
     lm = g.local_mesh(0, rock_fn=M.heterogeneous_rock(g.n_global), top_bc=([1.0e5, 20.0], 1),
                       sources=M.benchmark_sources(g))
     prim, region = M.benchmark_initial_state(g, lm.extras["prim_ijk"], lens=True)
-    osim = ol.OracleSim(L, lm, 1)
-    osim.set_regions(region)
-    y = osim.yvec(scaled(prim, region).ravel())
-    o = osim.opts()
-    dt, steps, kits, t0 = 1.0e4, 0, 0, time.time()
-    while time.time() - t0 < seconds:
-        r, k = osim.timestep(y, dt, o)
-        kits += k
-        if r > 0:
-            steps += r
-            dt *= 2.0
-        else:
-            dt *= 0.2
-            steps += o.max_newton_its
-    el = time.time() - t0
-    osim.close()
+    trials = sorted({t for t in (16, 32, 64, 128) if t <= avail} or {avail}) if gomp else [avail]
+    best = None
+    for t in trials:
+        if gomp:
+            gomp.omp_set_num_threads(t)
+        osim = ol.OracleSim(L, lm, 1)
+        osim.set_regions(region)
+        y = osim.yvec(scaled(prim, region).ravel())
+        t0 = time.time()
+        r, k = osim.timestep(y, 2.0e3, osim.opts())
+        el = time.time() - t0
+        osim.close()
+        steps = r if r > 0 else osim.opts().max_newton_its
+        log("  cpu baseline: %d threads: %d Newton steps, %d Krylov its in %.2f s" % (t, steps, k, el))
+        if best is None or steps / el > best[0]:
+            best = (steps / el, t, steps, k, el)
+    rate, t, steps, k, el = best
     n_s, n_f = dims[0] * dims[1] * dims[2], dims_full[0] * dims_full[1] * dims_full[2]
-    return {"value": steps / el * n_s / n_f, "unit": "Newton steps/s", "cores": cores, "kind": "port",
-            "sample": "%d Newton steps (%d Krylov iterations) of the same synthetic eos_we problem on a %dx%dx%d box "
-                      "in %.1f s with %d OpenMP threads, scaled by cell count (%d / %d) to the %dx%dx%d mesh"
-                      % (steps, kits, dims[0], dims[1], dims[2], el, cores, n_s, n_f, dims_full[0], dims_full[1],
-                         dims_full[2])}
+    return {"value": rate * n_s / n_f, "unit": "Newton steps/s", "cores": t, "kind": "port",
+            "sample": "first BE step (dt 2e3 s): %d Newton steps, %d Krylov iterations of the same synthetic eos_we "
+                      "problem on a %dx%dx%d box in %.1f s with %d OpenMP threads (best of %s threads on a %d-thread "
+                      "host), scaled by cell count (%d / %d) to the %dx%dx%d mesh"
+                      % (steps, k, dims[0], dims[1], dims[2], el, t, "/".join(str(x) for x in trials), avail, n_s, n_f,
+                         dims_full[0], dims_full[1], dims_full[2])}
 
 
 def main():
