@@ -31,6 +31,8 @@ extern "C" {
 typedef struct wai_ctx wai_ctx;
 
 enum { WAI_EOS_W = 0, WAI_EOS_WE = 1, WAI_EOS_WCE = 2 };
+/* time stepping methods (src/timestepper.F90:2262-2275 "beuler" | "bdf2" | "directss") */
+enum { WAI_METHOD_BEULER = 0, WAI_METHOD_BDF2 = 1, WAI_METHOD_DIRECTSS = 2 };
 enum { WAI_RP_FULLY_MOBILE = 0, WAI_RP_LINEAR = 1, WAI_RP_PICKENS = 2, WAI_RP_COREY = 3,
        WAI_RP_GRANT = 4, WAI_RP_VAN_GENUCHTEN = 5 };
 enum { WAI_CP_ZERO = 0, WAI_CP_LINEAR = 1, WAI_CP_VAN_GENUCHTEN = 2 };
@@ -128,7 +130,20 @@ int wai_post_linesearch(wai_ctx *ctx, const double *y_old, double *search, doubl
                         int *changed_search, int *changed_y);              /* :2419-2576 */
 
 /* ---- SNES / KSP slots (src/timestepper.F90) ----------------------------------------------- */
-/* SNES_residual + backwards_Euler_residual (:587-624, :345-374): f = L(y) - lhs_old - dt R(y) */
+/* Residual form every call below evaluates and differences (the method's `residual` procedure
+ * pointer, :1484-1500), for a caller that owns the step history as the reference's timestepper
+ * does:
+ *   WAI_METHOD_BEULER   backwards_Euler_residual :345-374  f = (L - lhs_old) - dt R
+ *   WAI_METHOD_BDF2     BDF2_residual :378-428  f = (1+2r) L - (r+1)^2 lhs_old + r^2 lhs_last2
+ *                       - dt (r+1) R, r = ratio = dt / last dt, lhs_last2 = lhs two steps back
+ *                       (n_owned*bs doubles, host or device, copied)
+ *   WAI_METHOD_DIRECTSS direct_ss_residual :431-452  f = R
+ * lhs_old stays the convergence scale (steps%last%lhs, :1917-1920) in every form. */
+int wai_set_residual_form(wai_ctx *ctx, int method, double ratio, const double *lhs_last2);
+/* Method wai_timestep integrates with; it then keeps the BDF2 history (lhs two steps back, last
+ * step size) itself and starts with a backward Euler step (:391-394).  Clears that history. */
+int wai_set_timestep_method(wai_ctx *ctx, int method);
+/* SNES_residual (:587-624) + the residual form in force (default backward Euler) */
 int wai_residual(wai_ctx *ctx, double t, double dt, const double *y, const double *lhs_old,
                  double *f);
 /* SNESComputeJacobianDefaultColor slot (:1584-1611): forward-difference BCSR Jacobian at y
@@ -157,7 +172,8 @@ int wai_max_scaled(wai_ctx *ctx, const double *v, const double *scale, double to
 int wai_newton_step(wai_ctx *ctx, double t, double dt, int iter, double *y,
                     const double *lhs_old, double *f, int *ksp_its, int *reason,
                     double *max_residual);
-/* SNESSolve for one backward-Euler step (timestepper_step without the retry loop, :2316-2376):
+/* SNESSolve for one step of the wai_set_timestep_method method (default backward Euler;
+ * timestepper_step without the retry loop, :2316-2376):
  * on failure y and the fluid regions are restored (pre_retry_timestep) and reason < 0 */
 int wai_timestep(wai_ctx *ctx, double t, double dt, double *y, int *newton_its, int *ksp_its,
                  int *reason);

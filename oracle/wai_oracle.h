@@ -129,6 +129,11 @@ void wo_pre_iteration(wo_sim *s);                                    /* :2108-21
 int wo_pre_eval(wo_sim *s, double *y);                               /* :2126-2147, 2291-2415 */
 void wo_lhs(wo_sim *s, double *lhs);                                 /* :1242-1330 */
 void wo_rhs(wo_sim *s, double *rhs);                                 /* :1334-1485 */
+/* residual form: 0 backward Euler (timestepper.F90:345-374), 1 variable-step BDF2 (:378-428,
+ * ratio = dt / last dt, lhs_last2 = lhs two steps back), 2 direct steady state (:431-452) */
+int wo_sim_set_residual_form(wo_sim *s, int method, double ratio, const double *lhs_last2);
+/* method wo_timestep integrates with; it then keeps the BDF2 history itself */
+int wo_sim_set_timestep_method(wo_sim *s, int method);
 int wo_residual(wo_sim *s, double *y, double dt, const double *lhs_old, double *f);
 int wo_post_linesearch(wo_sim *s, const double *y_old, double *search, double *y,
                        int *changed_search, int *changed_y);         /* :2419-2576 */

@@ -39,10 +39,36 @@ struct wo_sim {
   wo_allreduce_fn ar;
   void *user;
   double *fval, *dinv;
+  /* residual form of the time stepping method (see res_form) */
+  int method;           /* 0 backward Euler, 1 BDF2, 2 direct steady state */
+  double ratio;         /* BDF2: dt / last dt */
+  double *lhs_last2;    /* BDF2: L two steps back */
+  int scheme, taken;    /* wo_timestep's own history: method asked for, accepted steps */
+  double dt_last, dt_last_prev;
+  double *hist, *hist_prev;
+  int can_reject;
 };
 
 static void cell_residual(const wo_sim *s, int c, double dt, const double *lhs_old, int which,
                           const double *alt, double *out);
+
+/* The three residual forms of src/timestepper.F90, in the reference's order of operations:
+ *   backwards_Euler_residual :345-374   f = (L - L0) - dt R
+ *   BDF2_residual            :378-428   f = (((1+2r) L - (r+1)^2 L0) + r^2 L(-1)) - dt (r+1) R
+ *   direct_ss_residual       :431-452   f = R
+ * i = flat index into the owned lhs vectors. */
+static inline double res_form(const wo_sim *s, double dt, double L, double R, const double *lhs_old,
+                              int i) {
+  if (s->method == 1) {
+    double r = s->ratio, r1 = r + 1.0;
+    double v = L * (1.0 + 2.0 * r);
+    v = v + (-r1 * r1) * lhs_old[i];
+    v = v + (r * r) * s->lhs_last2[i];
+    return v + (-dt * r1) * R;
+  }
+  if (s->method == 2) return R;
+  return (L - lhs_old[i]) - dt * R;
+}
 
 static void *xmalloc(size_t n) {
   void *p = calloc(n ? n : 1, 1);
@@ -138,11 +164,38 @@ void wo_sim_destroy(wo_sim *s) {
   free(s->fluid); free(s->last_iteration_fluid); free(s->last_timestep_fluid);
   free(s->cf_ptr); free(s->cf_face); free(s->cf_side); free(s->rowptr); free(s->colidx);
   free(s->src_cell); free(s->src_comp); free(s->src_rate); free(s->src_enth);
-  free(s->sub_ptr); free(s->fval); free(s->dinv);
+  free(s->sub_ptr); free(s->fval); free(s->dinv); free(s->lhs_last2); free(s->hist); free(s->hist_prev);
   free(s);
 }
 
 wo_eos *wo_sim_eos(wo_sim *s) { return &s->eos; }
+
+/* residual form used by wo_residual / wo_jacobian / wo_newton_step from now on; lhs_last2 (owned
+ * lhs vector two steps back) is copied and only needed for method 1 */
+int wo_sim_set_residual_form(wo_sim *s, int method, double ratio, const double *lhs_last2) {
+  int n = s->eos.np * s->n_owned;
+  if (method < 0 || method > 2) return -1;
+  if (method == 1) {
+    if (!lhs_last2 || !(ratio > 0.0)) return -1;
+    if (!s->lhs_last2) s->lhs_last2 = (double *)xmalloc(sizeof(double) * n);
+    if (lhs_last2 != s->lhs_last2) memcpy(s->lhs_last2, lhs_last2, sizeof(double) * n);
+  }
+  s->method = method;
+  s->ratio = ratio;
+  return 0;
+}
+
+/* method wo_timestep integrates with (timestepper.F90:2262-2275 "beuler" | "bdf2" | "directss");
+ * clears the step history, so BDF2 starts with a backward Euler step (:391-394) */
+int wo_sim_set_timestep_method(wo_sim *s, int method) {
+  if (method < 0 || method > 2) return -1;
+  s->scheme = method;
+  s->taken = 0;
+  s->dt_last = 0.0;
+  s->can_reject = 0;
+  s->method = method == 2 ? 2 : 0;
+  return 0;
+}
 void wo_sim_set_comm(wo_sim *s, wo_halo_fn halo, wo_allreduce_fn ar, void *user) {
   s->halo = halo; s->ar = ar; s->user = user;
 }
@@ -212,6 +265,12 @@ void wo_pre_timestep(wo_sim *s) {
   memcpy(s->last_timestep_fluid, s->fluid, sizeof(double) * s->eos.df * s->n_local);
 }
 void wo_pre_retry_timestep(wo_sim *s) {
+  if (s->can_reject) { /* converged step turned down by the adaptor: timestepper.F90:1339,1468-1470 */
+    double *t = s->hist; s->hist = s->hist_prev; s->hist_prev = t;
+    s->dt_last = s->dt_last_prev;
+    s->taken--;
+    s->can_reject = 0;
+  }
   memcpy(s->fluid, s->last_timestep_fluid, sizeof(double) * s->eos.df * s->n_local);
 }
 void wo_pre_iteration(wo_sim *s) {
@@ -343,7 +402,7 @@ int wo_residual(wo_sim *s, double *y, double dt, const double *lhs_old, double *
   double *L = (double *)xmalloc(sizeof(double) * n), *R = (double *)xmalloc(sizeof(double) * n);
   wo_lhs(s, L);
   wo_rhs(s, R);
-  for (int i = 0; i < n; i++) f[i] = (L[i] - lhs_old[i]) - dt * R[i];
+  for (int i = 0; i < n; i++) f[i] = res_form(s, dt, L[i], R[i], lhs_old, i);
   free(L); free(R);
   return 0;
 }
@@ -389,7 +448,7 @@ static void cell_residual(const wo_sim *s, int c, double dt, const double *lhs_o
       source_flow(e, own, s->src_rate[i], s->src_enth[i], s->src_comp[i], flow);
       for (int k = 0; k < np; k++) R[k] += flow[k] / vol;
     }
-  for (int k = 0; k < np; k++) out[k] = (L[k] - lhs_old[c * np + k]) - dt * R[k];
+  for (int k = 0; k < np; k++) out[k] = res_form(s, dt, L[k], R[k], lhs_old, c * np + k);
 }
 
 static int jacobian_local(wo_sim *s, double *y, double dt, const double *lhs_old, double eps,
@@ -963,6 +1022,8 @@ int wo_timestep(wo_sim *s, const wo_newton_opts *o, double dt, double *y, int *t
   memcpy(ysave, y, sizeof(double) * nl);
   if (wo_pre_eval(s, y)) { result = -3; goto fail; }
   wo_lhs(s, lhs_old);
+  if (s->scheme == 1 && s->taken > 0) wo_sim_set_residual_form(s, 1, dt / s->dt_last, s->hist);
+  else wo_sim_set_residual_form(s, s->scheme == 2 ? 2 : 0, 0.0, NULL);
   if (wo_residual(s, y, dt, lhs_old, f)) { result = -3; goto fail; }
   {
     double mr, fnorm = norm2(s, f, n);
@@ -979,8 +1040,19 @@ int wo_timestep(wo_sim *s, const wo_newton_opts *o, double dt, double *y, int *t
   }
 fail:
   memcpy(y, ysave, sizeof(double) * nl);
+  s->can_reject = 0;
   wo_pre_retry_timestep(s);
+  goto out;
 ok:
+  /* accepted: this step's starting lhs becomes the two-steps-back vector of the next one */
+  { double *t = s->hist; s->hist = s->hist_prev; s->hist_prev = t; }
+  if (!s->hist) s->hist = (double *)xmalloc(sizeof(double) * n);
+  memcpy(s->hist, lhs_old, sizeof(double) * n);
+  s->dt_last_prev = s->dt_last;
+  s->dt_last = dt;
+  s->taken++;
+  s->can_reject = 1;
+out:
   free(lhs_old); free(f); free(ysave);
   return result;
 }

@@ -91,6 +91,8 @@ def load(path):
         "wo_pre_iteration": (None, [C.c_void_p]),
         "wo_pre_eval": (i32, [C.c_void_p, pd]),
         "wo_lhs": (None, [C.c_void_p, pd]), "wo_rhs": (None, [C.c_void_p, pd]),
+        "wo_sim_set_residual_form": (i32, [C.c_void_p, i32, d, pd]),
+        "wo_sim_set_timestep_method": (i32, [C.c_void_p, i32]),
         "wo_residual": (i32, [C.c_void_p, pd, d, pd, pd]),
         "wo_post_linesearch": (i32, [C.c_void_p, pd, pd, pd, pi, pi]),
         "wo_jacobian": (i32, [C.c_void_p, pd, d, pd, pd, i32, pd]),
@@ -177,6 +179,13 @@ class OracleSim:
         out = np.zeros(self.n_owned * self.np)
         self.L.wo_rhs(self.h, dp(out))
         return out
+
+    def set_residual_form(self, method=0, ratio=0.0, lhs_last2=None):
+        p = dp(f64(lhs_last2)) if lhs_last2 is not None else None
+        assert self.L.wo_sim_set_residual_form(self.h, method, ratio, p) == 0
+
+    def set_timestep_method(self, method=0):
+        assert self.L.wo_sim_set_timestep_method(self.h, method) == 0
 
     def residual(self, y, dt, lhs_old):
         f = np.zeros(self.n_owned * self.np)

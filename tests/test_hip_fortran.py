@@ -29,7 +29,8 @@ def test_fortran_driver_matches_python_host(tmp_path):
     sim = FlowSimulation(lm, eos="we")
     sim.set_regions(region)
     y = y0.copy()
-    ts = Timestepper(sim, y, stepsize=1.0e4)
+    # the driver doubles dt after every accepted step: an adaptor that always finds the step too small
+    ts = Timestepper(sim, y, stepsize=1.0e4, adapt=True, adapt_min=float("inf"), adapt_max=float("inf"))
     ts.run(4)
     assert tn == sum(h[2] for h in ts.history)
     assert np.array_equal(rf, sim.regions())

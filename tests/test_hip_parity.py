@@ -261,3 +261,128 @@ def test_domain_error_is_recoverable(FS, oracle):
     assert osim.pre_eval(osim.yvec(yb)) == 1
     assert sim.pre_eval(0.0, y) == 0
     sim.destroy(); osim.close()
+
+
+@pytest.mark.parametrize("eos", ["we", "wce"])
+@pytest.mark.parametrize("method", ["bdf2", "directss"])
+def test_residual_forms(FS, oracle, eos, method):
+    """BDF2 and direct steady state residuals (src/timestepper.F90:378-452) and their FD Jacobians
+    against the oracle; lhs two steps back is a perturbed copy of the current lhs."""
+    g, lm, sim, osim, y, region = build(FS, oracle, eos=eos, lens=(eos == "we"))
+    bs = sim.num_primary_variables
+    n = sim.n_owned * bs
+    dt, ratio = 2.0e4, 1.7
+    yo = osim.yvec(y)
+    assert sim.pre_eval(0.0, y) == 0 and osim.pre_eval(yo) == 0
+    L = osim.lhs()
+    rng = np.random.default_rng(5)
+    L2 = L * (1.0 + 1e-3 * rng.standard_normal(n))
+    sim.set_residual_form(method, ratio, L2)
+    osim.set_residual_form({"bdf2": 1, "directss": 2}[method], ratio, L2)
+    f = np.zeros(n)
+    assert sim.residual(0.0, dt, y, L, f) == 0
+    err, fo = osim.residual(yo, dt, L)
+    assert err == 0
+    assert np.abs(f - fo).max() <= 1e-11 * np.abs(fo).max()
+    if method == "directss":
+        R = np.zeros(n)
+        sim.rhs(0.0, (0.0, 0.0), y, R)
+        assert np.array_equal(f, R)
+    assert sim.jacobian(0.0, dt, y, L) == 0
+    err, Jo = osim.jacobian(yo, dt, L, fo, mode=0)
+    assert err == 0
+    rp, ci = sim.setup_jacobian()
+    Jg = sim.jacobian_values().reshape(-1, bs, bs)
+    Jo = Jo.reshape(-1, bs, bs)
+    # the BDF2 residual is a difference of lhs terms weighted (1+2r), (r+1)^2, r^2 (sum 14.6 for
+    # r = 1.7 against 2 for backward Euler): its rounding noise, divided by the FD step, is that
+    # much larger relative to the block row than in test_jacobian
+    jtol = 1e-4 if method == "bdf2" else 1e-5
+    for r in range(bs):
+        rowscale = np.zeros(sim.n_owned)
+        np.maximum.at(rowscale, np.repeat(np.arange(sim.n_owned), np.diff(rp)), np.abs(Jo[:, r, :]).max(axis=1))
+        sc = np.repeat(rowscale, np.diff(rp))[:, None]
+        assert (np.abs(Jg[:, r, :] - Jo[:, r, :]) / np.maximum(sc, 1e-300)).max() < jtol
+    # back to backward Euler: the default form is untouched by the excursion
+    sim.set_residual_form("beuler")
+    osim.set_residual_form(0)
+    assert sim.residual(0.0, dt, y, L, f) == 0
+    err, fo = osim.residual(yo, dt, L)
+    assert np.abs(f - fo).max() <= 1e-11 * np.abs(fo).max()
+    sim.destroy(); osim.close()
+
+
+@pytest.mark.parametrize("eos,lens", [("we", True), ("wce", False)])
+def test_bdf2_timesteps(FS, oracle, eos, lens):
+    """Variable-step BDF2 through wai_timestep (start-up backward Euler step, then the history the
+    library keeps) against the oracle doing the same, including a failed try in between."""
+    g, lm, sim, osim, y, region = build(FS, oracle, eos=eos, lens=lens, dims=(8, 8, 10), brick=(4, 4, 5))
+    sim.set_opts(ksp_rtol=1e-10, ftol_rel=1e-9)
+    sim.set_timestep_method("bdf2")
+    osim.set_timestep_method(1)
+    o = osim.opts()
+    o.ksp_rtol, o.ftol_rel = 1e-10, 1e-9
+    yg, yo = y.copy(), osim.yvec(y)
+    base = 5.0e2 if eos == "wce" else 5.0e3
+    accepted = 0
+    for fac in (1.0, 2.0, 1.0e6, 3.0, 1.5):   # 1e6: far too big, must fail in both and leave no trace
+        dt = base * fac
+        reason, nits, kits = sim.timestep(0.0, dt, yg)
+        r, ok = osim.timestep(yo, dt, o)
+        assert (reason > 0) == (r > 0)
+        if reason > 0:
+            accepted += 1
+            assert nits == r
+            assert np.array_equal(sim.regions(), osim.regions())
+            assert relmax(yg, yo[: yg.size]) < 1e-7
+    assert accepted >= 4
+    sim.destroy(); osim.close()
+
+
+def test_bdf2_rejected_step_restores_history(FS, oracle):
+    """pre_retry_timestep after a converged wai_timestep (adaptor says too big) undoes it: the
+    retried sequence equals one that never took the rejected step"""
+    g, lm, sim, osim, y, region = build(FS, oracle, eos="we", lens=True)
+    sim.set_timestep_method("bdf2")
+    ya = y.copy()
+    sim.timestep(0.0, 5e3, ya)
+    y1 = ya.copy()
+    assert sim.timestep(0.0, 2e4, ya)[0] > 0
+    sim.pre_retry_timestep()       # reject it
+    ya[:] = y1
+    assert sim.timestep(0.0, 1e4, ya)[0] > 0
+    assert sim.timestep(0.0, 1e4, ya)[0] > 0
+    sim2 = FS(lm, eos="we")
+    sim2.set_regions(region)
+    sim2.set_timestep_method("bdf2")
+    yb = y.copy()
+    for dt in (5e3, 1e4, 1e4):
+        assert sim2.timestep(0.0, dt, yb)[0] > 0
+    assert np.array_equal(ya, yb)
+    sim.destroy(); sim2.destroy(); osim.close()
+
+
+def test_direct_steady_state(FS, oracle):
+    """directss: one Newton solve of R(y) = 0 (timestepper.F90:431-452); same iterates as the
+    oracle, and the answer is a fixed point of a long backward Euler step."""
+    g, lm, sim, osim, y, region = build(FS, oracle, eos="we", dims=(6, 6, 6), brick=(3, 3, 3), sources=False)
+    # R is a rate, so the reference's relative function test is loose for it: run both solves on to
+    # PETSc's 1e-8 reduction of |R| (or the update test) instead
+    sim.set_opts(ksp_rtol=1e-10, ftol_rel=1e-20, max_newton_its=30)
+    sim.set_timestep_method("directss")
+    osim.set_timestep_method(2)
+    o = osim.opts()
+    o.ksp_rtol, o.ftol_rel, o.max_newton_its = 1e-10, 1e-20, 30
+    yg, yo = y.copy(), osim.yvec(y)
+    n = sim.num_dof
+    R0 = np.zeros(n)
+    sim.rhs(0.0, (0.0, 0.0), yg, R0)
+    reason, nits, kits = sim.timestep(0.0, 0.0, yg)
+    r, ok = osim.timestep(yo, 0.0, o)
+    assert (reason > 0) == (r > 0)
+    assert reason > 0 and nits == r
+    assert relmax(yg, yo[: yg.size]) < 1e-7
+    R = np.zeros(n)
+    sim.rhs(0.0, (0.0, 0.0), yg, R)
+    assert np.linalg.norm(R) < 1e-6 * np.linalg.norm(R0)
+    sim.destroy(); osim.close()

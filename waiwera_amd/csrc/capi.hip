@@ -471,7 +471,7 @@ void free_all(wai_ctx* c) {
   F(k.R); F(k.RP); F(k.P); F(k.V); F(k.S); F(k.T); F(k.tmp); F(k.X); F(k.basis); F(k.partials); F(k.scal);
   if (k.h_scal) (void)hipHostFree(k.h_scal);
   F(c->flu); F(c->flu_last_iter); F(c->flu_last_step); F(c->flu_pert); F(c->hstep);
-  F(c->w_y); F(c->w_yold); F(c->w_delta); F(c->w_f); F(c->w_lhs); F(c->w_a); F(c->w_b); F(c->w_c);
+  F(c->w_y); F(c->w_yold); F(c->w_delta); F(c->w_f); F(c->w_lhs); F(c->w_lhs2); F(c->w_hist); F(c->w_hist_prev); F(c->w_a); F(c->w_b); F(c->w_c);
   F(c->d_flags); F(c->d_red);
   if (c->h_flags) (void)hipHostFree(c->h_flags);
   if (c->h_red) (void)hipHostFree(c->h_red);
@@ -720,7 +720,8 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
     HIPCHK(c, hipMemcpy(c->flu + (size_t)F_REGION * NL, ones.data(), NL * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->flu + (size_t)F_OLD_REGION * NL, ones.data(), NL * sizeof(double), hipMemcpyHostToDevice));
   }
-  double** wv[] = {&c->w_y, &c->w_yold, &c->w_delta, &c->w_f, &c->w_lhs, &c->w_a, &c->w_b, &c->w_c};
+  double** wv[] = {&c->w_y, &c->w_yold, &c->w_delta, &c->w_f, &c->w_lhs, &c->w_a, &c->w_b, &c->w_c,
+                   &c->w_lhs2, &c->w_hist, &c->w_hist_prev};
   for (auto p : wv) {
     if (dev_alloc(c, p, nl + 16)) return -1;
     HIPCHK(c, hipMemset(*p, 0, (nl + 16) * sizeof(double)));
@@ -914,7 +915,16 @@ int wai_halo_exchange(wai_ctx* c, double* vec, int dof) {
 }
 
 int wai_pre_timestep(wai_ctx* c) { return c ? snapshot_step(c) : -2; }
-int wai_pre_retry_timestep(wai_ctx* c) { return c ? restore_step(c) : -2; }
+int wai_pre_retry_timestep(wai_ctx* c) {
+  if (!c) return -2;
+  if (c->can_reject) {  // a converged step the adaptor turned down (TIMESTEP_TOO_BIG, :1339,1468-1470)
+    std::swap(c->w_hist, c->w_hist_prev);
+    c->dt_last = c->dt_last_prev;
+    c->taken--;
+    c->can_reject = false;
+  }
+  return restore_step(c);
+}
 int wai_pre_iteration(wai_ctx* c) {
   if (!c) return -2;
   HIPCHK(c, hipMemcpyAsync(c->flu_last_iter, c->flu, sizeof(double) * (size_t)c->df * c->mesh.n_local,
@@ -966,6 +976,32 @@ int wai_rhs(wai_ctx* c, double t, const double* y, double* rhs) {
     launch_residual(c, 0.0, nullptr, nullptr, nullptr, o.dev);
   }
   return o.back();
+}
+
+int wai_set_residual_form(wai_ctx* c, int method, double ratio, const double* lhs_last2) {
+  if (!c) return -2;
+  if (method < WAI_METHOD_BEULER || method > WAI_METHOD_DIRECTSS) { c->err = "unknown time stepping method"; return -1; }
+  if (method == WAI_METHOD_BDF2) {
+    if (!lhs_last2 || !(ratio > 0.0)) { c->err = "BDF2 needs a step size ratio > 0 and the lhs two steps back"; return -1; }
+    if (lhs_last2 != c->w_lhs2) {
+      HIPCHK(c, hipMemcpyAsync(c->w_lhs2, lhs_last2, sizeof(double) * c->ks.n, hipMemcpyDefault, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+  }
+  c->method = method;
+  c->ratio = ratio;
+  return 0;
+}
+
+int wai_set_timestep_method(wai_ctx* c, int method) {
+  if (!c) return -2;
+  if (method < WAI_METHOD_BEULER || method > WAI_METHOD_DIRECTSS) { c->err = "unknown time stepping method"; return -1; }
+  c->scheme = method;
+  c->taken = 0;
+  c->dt_last = 0.0;
+  c->can_reject = false;
+  c->method = method == WAI_METHOD_DIRECTSS ? WAI_METHOD_DIRECTSS : WAI_METHOD_BEULER;
+  return 0;
 }
 
 int wai_residual(wai_ctx* c, double t, double dt, const double* y, const double* lhs_old, double* f) {
@@ -1110,6 +1146,13 @@ int wai_timestep(wai_ctx* c, double t, double dt, double* y, int* newton_its, in
   if (e > 0) r = -3;
   if (!r) {
     launch_residual(c, 0.0, nullptr, nullptr, c->w_lhs, nullptr);  // L(y_old)
+    if (c->scheme == WAI_METHOD_BDF2 && c->taken > 0) {
+      c->method = WAI_METHOD_BDF2;
+      c->ratio = dt / c->dt_last;
+      vec_copy(c, c->w_lhs2, c->w_hist, n);
+    } else {
+      c->method = c->scheme == WAI_METHOD_DIRECTSS ? WAI_METHOD_DIRECTSS : WAI_METHOD_BEULER;
+    }
     e = do_residual(c, dt, c->w_y, c->w_lhs, c->w_f);
     if (e < 0) return -1;
     if (e > 0) r = -3;
@@ -1132,6 +1175,15 @@ int wai_timestep(wai_ctx* c, double t, double dt, double* y, int* newton_its, in
   if (r < 0) {
     vec_copy(c, c->w_y, c->w_b, n);
     if (restore_step(c)) return -1;
+    c->can_reject = false;
+  } else {
+    // accepted: this step's starting lhs is the next step's two-steps-back vector
+    std::swap(c->w_hist, c->w_hist_prev);
+    vec_copy(c, c->w_hist, c->w_lhs, n);
+    c->dt_last_prev = c->dt_last;
+    c->dt_last = dt;
+    c->taken++;
+    c->can_reject = true;
   }
   return from_work(c, c->w_y, y);
 }

@@ -64,6 +64,14 @@ struct IluSchedule {
   bool factored = false;
 };
 
+// Residual form of the time stepping method (src/timestepper.F90:345-452), by value to kernels
+struct ResForm {
+  int method = 0;             // WAI_METHOD_BEULER | BDF2 | DIRECTSS
+  double dt = 0.0, ratio = 0.0;
+  const double* last = nullptr;   // lhs at the start of the step
+  const double* last2 = nullptr;  // BDF2: lhs one step further back
+};
+
 struct Krylov {
   int n = 0, nl = 0;           // bs*n_owned, bs*n_prim
   double *R = nullptr, *RP = nullptr, *P = nullptr, *V = nullptr, *S = nullptr, *T = nullptr,
@@ -110,6 +118,16 @@ struct wai_ctx {
   int send_total = 0, max_dof_buf = 0;
   // Newton bookkeeping
   double fnorm0 = 0.0;
+  // time stepping method: residual form in force, and wai_timestep's own BDF2 history
+  int method = 0;               // residual form (wai_set_residual_form)
+  double ratio = 0.0;
+  double* w_lhs2 = nullptr;     // lhs two steps back, as handed to wai_set_residual_form
+  int scheme = 0, taken = 0;    // wai_set_timestep_method, accepted wai_timestep calls since
+  double dt_last = 0.0;
+  double* w_hist = nullptr;     // lhs at the start of the last accepted wai_timestep
+  double* w_hist_prev = nullptr;  // ... and of the one before, to undo an acceptance
+  double dt_last_prev = 0.0;
+  bool can_reject = false;      // the last wai_timestep converged and has not been rejected
   // measurement
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool prof_on = false;

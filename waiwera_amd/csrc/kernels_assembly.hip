@@ -122,11 +122,24 @@ __device__ __forceinline__ void source_terms(const MeshView& m, int c, const Cel
   }
 }
 
+// backwards_Euler_residual / BDF2_residual / direct_ss_residual (src/timestepper.F90:345-452) in
+// the reference's order of operations; l1, l2 = lhs one and two steps back for this equation
+__device__ __forceinline__ double res_form(const ResForm& rf, double L, double R, double l1, double l2) {
+  if (rf.method == WAI_METHOD_BDF2) {
+    const double r = rf.ratio, r1 = r + 1.0;
+    double v = L * (1.0 + 2.0 * r);
+    v = v + (-r1 * r1) * l1;
+    v = v + (r * r) * l2;
+    return v + (-rf.dt * r1) * R;
+  }
+  if (rf.method == WAI_METHOD_DIRECTSS) return R;
+  return (L - l1) - rf.dt * R;
+}
+
 // ---- K2-K4: residual -------------------------------------------------------------------------
 template <int KIND>
 __global__ __launch_bounds__(TPB) void k_residual(MeshView m, const double* __restrict__ flu,
-                                                  size_t stride, double dt,
-                                                  const double* __restrict__ lhs_old,
+                                                  size_t stride, ResForm rf,
                                                   double* __restrict__ f, double* __restrict__ lhs_out,
                                                   double* __restrict__ rhs_out) {
   using E = EosT<KIND>;
@@ -161,7 +174,10 @@ __global__ __launch_bounds__(TPB) void k_residual(MeshView m, const double* __re
   for (int k = 0; k < E::np; k++) {
     if (lhs_out) lhs_out[(size_t)c * E::np + k] = L[k];
     if (rhs_out) rhs_out[(size_t)c * E::np + k] = R[k];
-    if (f) f[(size_t)c * E::np + k] = (L[k] - lhs_old[(size_t)c * E::np + k]) - dt * R[k];
+    if (f) {
+      const size_t i = (size_t)c * E::np + k;
+      f[i] = res_form(rf, L[k], R[k], rf.last[i], rf.method == WAI_METHOD_BDF2 ? rf.last2[i] : 0.0);
+    }
   }
 }
 
@@ -170,8 +186,7 @@ template <int KIND>
 __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __restrict__ flu,
                                                   size_t stride, const double* __restrict__ flu_pert,
                                                   const double* __restrict__ hstep, int n_prim,
-                                                  double dt, const double* __restrict__ lhs_old,
-                                                  double* __restrict__ val) {
+                                                  ResForm rf, double* __restrict__ val) {
   using E = EosT<KIND>;
   constexpr int np = E::np, bb = E::np * E::np;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -181,9 +196,12 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
   load_state<KIND>(flu, stride, c, own0);
   load_rock(m.rock, m.n_local, c, rown);
   const double vol = m.vol[c];
-  double lold[np];
+  double lold[np], lold2[np];
 #pragma unroll
-  for (int k = 0; k < np; k++) lold[k] = lhs_old[(size_t)c * np + k];
+  for (int k = 0; k < np; k++) {
+    lold[k] = rf.method == WAI_METHOD_DIRECTSS ? 0.0 : rf.last[(size_t)c * np + k];
+    lold2[k] = rf.method == WAI_METHOD_BDF2 ? rf.last2[(size_t)c * np + k] : 0.0;
+  }
 
   // base residual, keeping every slot's contribution
   double L0[np], terms0[MAXDEG][np], src0[np], f0[np];
@@ -221,7 +239,7 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
       }
     }
 #pragma unroll
-    for (int k = 0; k < np; k++) { R[k] += src0[k]; f0[k] = (L0[k] - lold[k]) - dt * R[k]; }
+    for (int k = 0; k < np; k++) { R[k] += src0[k]; f0[k] = res_form(rf, L0[k], R[k], lold[k], lold2[k]); }
   }
 
   // diagonal block: own state perturbed in component k
@@ -256,7 +274,7 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
     const double h = hstep[(size_t)c * np + k];
 #pragma unroll
     for (int r = 0; r < np; r++) {
-      const double f1 = (Lk[r] - lold[r]) - dt * R[r];
+      const double f1 = res_form(rf, Lk[r], R[r], lold[r], lold2[r]);
       dblk[(size_t)r * nrow * np + k] = (f1 - f0[r]) / h;
     }
   }
@@ -293,7 +311,7 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
       const double h = hstep[(size_t)o * np + k];
 #pragma unroll
       for (int r = 0; r < np; r++) {
-        const double f1 = (L0[r] - lold[r]) - dt * (R[r] + src0[r]);
+        const double f1 = res_form(rf, L0[r], R[r] + src0[r], lold[r], lold2[r]);
         oblk[(size_t)r * nrow * np + k] += (f1 - f0[r]) / h;
       }
     }
@@ -432,11 +450,22 @@ int launch_eos(wai_ctx* c, const double* y, int first, int count, bool perturbed
   return 0;
 }
 
+static ResForm res_form_of(const wai_ctx* c, double dt, const double* lhs_old) {
+  ResForm rf;
+  rf.method = c->method;
+  rf.dt = dt;
+  rf.ratio = c->ratio;
+  rf.last = lhs_old;
+  rf.last2 = c->w_lhs2;
+  return rf;
+}
+
 int launch_residual(wai_ctx* c, double dt, const double* lhs_old, double* f, double* lhs_out,
                     double* rhs_out) {
   const MeshView m = view(c);
   const size_t stride = c->mesh.n_local;
-  WAI_BY_EOS(c, k_residual, grid_for(m.n_owned), m, c->flu, stride, dt, lhs_old, f, lhs_out, rhs_out);
+  WAI_BY_EOS(c, k_residual, grid_for(m.n_owned), m, c->flu, stride, res_form_of(c, dt, lhs_old), f,
+             lhs_out, rhs_out);
   return 0;
 }
 
@@ -446,7 +475,7 @@ int launch_jacobian(wai_ctx* c, double dt, const double* lhs_old) {
   const size_t stride = c->mesh.n_local;
   hipMemsetAsync(c->J.val, 0, sizeof(double) * (size_t)c->J.W * c->np * c->np * c->J.n, c->stream);
   WAI_BY_EOS(c, k_jacobian, grid_for(m.n_owned), m, c->flu, stride, c->flu_pert, c->hstep, c->mesh.n_prim,
-             dt, lhs_old, c->J.val);
+             res_form_of(c, dt, lhs_old), c->J.val);
   return 0;
 }
 

@@ -45,6 +45,7 @@ class FlowSimulation:
         self.num_primary_variables = LIB.wai_block_size(h)
         self.fluid_dof = LIB.wai_num_fluid_dof(h)
         self.n_owned, self.n_prim, self.n_local = mesh.n_owned, mesh.n_prim, mesh.n_local
+        self.num_dof = self.n_owned * self.num_primary_variables
         self.time = 0.0
         if mesh.n_bc:
             bp, br = _lib._f64(mesh.bc_primary), _lib._i32(mesh.bc_region)
@@ -161,6 +162,18 @@ class FlowSimulation:
         return rp, ci
 
     # ---- SNES / KSP slots ------------------------------------------------------------------------
+    def set_residual_form(self, method="beuler", ratio=0.0, lhs_last2=None):
+        """Residual the SNES slots evaluate: the method's `residual` pointer
+        (src/timestepper.F90:1484-1500); bdf2 needs ratio = dt / last dt and the lhs two steps back."""
+        p = _lib.ptr(lhs_last2) if lhs_last2 is not None else None
+        return self._chk(LIB.wai_set_residual_form(self.h, _lib.METHOD_KIND[method], ratio, p),
+                         "set_residual_form")
+
+    def set_timestep_method(self, method="beuler"):
+        """Method `timestep` integrates with; the library then keeps the BDF2 history."""
+        return self._chk(LIB.wai_set_timestep_method(self.h, _lib.METHOD_KIND[method]),
+                         "set_timestep_method")
+
     def residual(self, t, dt, y, lhs_old, f):
         return self._chk(LIB.wai_residual(self.h, t, dt, _lib.ptr(y), _lib.ptr(lhs_old), _lib.ptr(f)), "residual")
 

@@ -128,6 +128,19 @@ module waiwera_hip_module
        real(c_double), intent(in out) :: search(*), y(*)
        integer(c_int), intent(out) :: changed_search, changed_y
      end function wai_post_linesearch
+     integer(c_int) function wai_set_residual_form(ctx, method, ratio, lhs_last2) &
+          bind(c, name = "wai_set_residual_form")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: method
+       real(c_double), value :: ratio
+       real(c_double), intent(in) :: lhs_last2(*)
+     end function wai_set_residual_form
+     integer(c_int) function wai_set_timestep_method(ctx, method) bind(c, name = "wai_set_timestep_method")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: method
+     end function wai_set_timestep_method
      integer(c_int) function wai_residual(ctx, t, dt, y, lhs_old, f) bind(c, name = "wai_residual")
        import :: c_int, c_ptr, c_double
        type(c_ptr), value :: ctx
@@ -183,6 +196,8 @@ module waiwera_hip_module
      end function wai_timestep
   end interface
 
+  integer, parameter, public :: WAI_METHOD_BEULER = 0, WAI_METHOD_BDF2 = 1, WAI_METHOD_DIRECTSS = 2
+
   type, public :: hip_flow_simulation_type
      !! Concrete ode_type whose hot loops run on the GPU.
      type(c_ptr) :: ctx = c_null_ptr
@@ -202,6 +217,8 @@ module waiwera_hip_module
      procedure, public :: post_timestep => hip_sim_post_timestep
      procedure, public :: post_linesearch => hip_sim_post_linesearch
      procedure, public :: setup_jacobian => hip_sim_setup_jacobian
+     procedure, public :: set_residual_form => hip_sim_set_residual_form
+     procedure, public :: set_timestep_method => hip_sim_set_timestep_method
      procedure, public :: residual => hip_sim_residual
      procedure, public :: jacobian => hip_sim_jacobian
      procedure, public :: ksp_solve => hip_sim_ksp_solve
@@ -386,5 +403,25 @@ contains
     ksp_its = k
     reason = r
   end subroutine hip_sim_timestep
+
+  subroutine hip_sim_set_residual_form(self, method, ratio, lhs_last2, err)
+    !! Residual form of the time stepping method (the `residual` pointer of
+    !! timestepper_method_type, src/timestepper.F90:1484-1500): WAI_METHOD_BEULER | BDF2 | DIRECTSS.
+    !! For BDF2 ratio = dt / last dt and lhs_last2 = steps%pstore(3)%p%lhs (:409).
+    class(hip_flow_simulation_type), intent(in out) :: self
+    integer, intent(in) :: method
+    real(dp), intent(in) :: ratio
+    real(dp), intent(in) :: lhs_last2(:)
+    integer, intent(out) :: err
+    err = wai_set_residual_form(self%ctx, int(method, c_int), ratio, lhs_last2)
+  end subroutine hip_sim_set_residual_form
+
+  subroutine hip_sim_set_timestep_method(self, method, err)
+    !! Method hip_sim_timestep integrates with (the library keeps the BDF2 history).
+    class(hip_flow_simulation_type), intent(in out) :: self
+    integer, intent(in) :: method
+    integer, intent(out) :: err
+    err = wai_set_timestep_method(self%ctx, int(method, c_int))
+  end subroutine hip_sim_set_timestep_method
 
 end module waiwera_hip_module

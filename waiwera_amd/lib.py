@@ -22,6 +22,9 @@ d, i32 = C.c_double, C.c_int
 pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int)
 
 
+METHOD_KIND = {"beuler": 0, "bdf2": 1, "directss": 2}  # src/timestepper.F90:2262-2275
+
+
 class MeshDesc(C.Structure):
     _fields_ = [("n_owned", i32), ("n_halo", i32), ("n_bc", i32), ("n_faces", i32),
                 ("face_cells", pi), ("face_geom", pd), ("cell_geom", pd), ("rock", pd),
@@ -78,6 +81,8 @@ def _load():
         "wai_lhs": (i32, [vp, d, vp, vp]),
         "wai_rhs": (i32, [vp, d, vp, vp]),
         "wai_post_linesearch": (i32, [vp, vp, vp, vp, pi, pi]),
+        "wai_set_residual_form": (i32, [vp, i32, d, vp]),
+        "wai_set_timestep_method": (i32, [vp, i32]),
         "wai_residual": (i32, [vp, d, d, vp, vp, vp]),
         "wai_jacobian": (i32, [vp, d, d, vp, vp]),
         "wai_jacobian_nnzb": (i32, [vp]),

@@ -1,51 +1,239 @@
-"""Minimal PETSc-free restatement of the reference's time-step loop around the Newton hot path.
+"""PETSc-free restatement of the reference's time-step controller around the Newton hot path.
 
-Only what the hot path needs to be driven the way the reference drives it
-(src/timestepper.F90:2316-2376 `timestepper_step`): pre_timestep, the try/retry loop with the
-step-size reduction on non-convergence (reduction 0.2, at most 10 tries, :1353-1375,1995-2007)
-and fluid restore (pre_retry_timestep).  The adaptor, checkpoints, BDF2 and output are out of
-scope.
+What drives the hot path the way the reference drives it (src/timestepper.F90):
+
+* `timestepper_step` (:2316-2376): pre_timestep, then tries until one is accepted -- pre_try /
+  pre_retry hooks, the nonlinear solve, status, next step size;
+* the step status and size logic of `timestepper_steps_type`: `set_current_status` (:1304-1375),
+  `set_next_stepsize` / `get_next_fixed_stepsize` / `adapt` (:1380-1476), `check_finished`
+  (:1234-1275) with its stop-time clip;
+* the adaptor (:772-858) with the "iteration" and "change" monitors (:277-310) and the reference's
+  defaults (:1971-2007): fixed sizes first, adaptor off, monitor band 5..8 iterations, reduction
+  0.2, amplification 2, at most 10 tries, default method backward Euler;
+* the methods "beuler" | "bdf2" | "directss" (:2262-2275): the residual form lives in the HIP
+  kernels (`FlowSimulation.set_timestep_method`), the history is kept by `wai_timestep`.
+
+Checkpoints, output and the auxiliary (tracer) linear solve stay out of scope.
 """
+
+# step status, timestepper.F90:40-42
+OK, NOT_CONVERGED, TOO_SMALL, TOO_BIG, ABORTED, FINAL = 0, 1, 2, 3, 4, 5
+STATUS_STR = {OK: "OK", NOT_CONVERGED: "not converged", TOO_SMALL: "increase", TOO_BIG: "reduce",
+              ABORTED: "aborted", FINAL: "final"}
 
 
 class StepFailed(RuntimeError):
     pass
 
 
+class Adaptor:
+    """timestep_adaptor_type (timestepper.F90:76-97, :772-858)."""
+
+    def __init__(self, on=False, method="iteration", minimum=5.0, maximum=8.0, reduction=0.2,
+                 amplification=2.0, max_stepsize=0.0):
+        if method not in ("iteration", "change"):
+            raise ValueError("unknown adapt method %r" % method)
+        self.on = on
+        self.method = method
+        self.monitor_min = minimum
+        self.monitor_max = maximum
+        self.reduction = reduction
+        self.amplification = amplification
+        self.max_stepsize = max_stepsize
+
+    def reduce(self, stepsize):
+        return stepsize * self.reduction
+
+    def increase(self, stepsize):
+        s = stepsize * self.amplification
+        if self.max_stepsize > 0.0:
+            s = min(s, self.max_stepsize)
+        return s
+
+
 class Timestepper:
-    def __init__(self, ode, y, time=0.0, stepsize=1.0e4, reduction=0.2, max_num_tries=10,
-                 growth=2.0):
+    """Drives `ode` (a FlowSimulation, or anything with its hooks) through accepted time steps."""
+
+    def __init__(self, ode, y, time=0.0, stepsize=0.1, method="beuler", adapt=False,
+                 adapt_method="iteration", adapt_min=5.0, adapt_max=8.0, reduction=0.2,
+                 amplification=2.0, max_stepsize=0.0, max_num_tries=10, stop_time=None,
+                 max_num_steps=100, stop_min_stepsize=-1.0, stop_max_stepsize=-1.0):
         self.ode = ode
         self.y = y              # numpy array or torch tensor, scaled primaries, in/out
         self.time = time
-        self.stepsize = stepsize
-        self.reduction = reduction
+        self.method = method
+        self.steady_state = method == "directss"
+        self.sizes = [float(s) for s in (stepsize if hasattr(stepsize, "__len__") else [stepsize])]
+        self.fixed_step_index = 1
+        self.next_stepsize = self.sizes[0]
+        self.fixed = not adapt
+        self.adaptor = Adaptor(False, adapt_method, adapt_min, adapt_max, reduction, amplification,
+                               max_stepsize)
         self.max_num_tries = max_num_tries
-        self.growth = growth
+        self.stop_time = stop_time
+        self.max_num_steps = max_num_steps
+        self.stop_min_stepsize = stop_min_stepsize
+        self.stop_max_stepsize = stop_max_stepsize
+        self.termination_tol = 1.0e-3
+        self.taken = 0
+        self.finished = False
+        self.status = OK
         self.history = []       # (time, stepsize, newton its, krylov its, tries)
+        self._last_lhs = None
+        if hasattr(ode, "set_timestep_method"):
+            ode.set_timestep_method(method)
+        elif method != "beuler":
+            raise ValueError("ode has no set_timestep_method; only backward Euler is possible")
 
+    @property
+    def stepsize(self):
+        return self.next_stepsize
+
+    @stepsize.setter
+    def stepsize(self, v):
+        self.next_stepsize = float(v)
+
+    # ---- timestepper_steps_type ---------------------------------------------------------------
+    def _check_finished(self, stepsize):
+        """check_finished (:1234-1275); returns the possibly clipped step size."""
+        self.finished = False
+        if self.steady_state:
+            self.finished = self.taken == 1
+            return stepsize
+        if self.stop_time is not None and self.time + stepsize + self.termination_tol * stepsize > self.stop_time:
+            stepsize = self.stop_time - self.time
+            self.finished = True
+        elif self.stop_min_stepsize > 0.0 and stepsize <= self.stop_min_stepsize:
+            stepsize = self.stop_min_stepsize
+            self.finished = True
+        elif self.stop_max_stepsize > 0.0 and stepsize >= self.stop_max_stepsize:
+            stepsize = self.stop_max_stepsize
+            self.finished = True
+        if self.max_num_steps >= 0 and self.taken + 1 >= self.max_num_steps:
+            self.finished = True
+        return stepsize
+
+    def _monitor(self, nits):
+        if self.adaptor.method == "iteration":
+            return float(nits)           # iteration_monitor :277-284
+        return self._relative_change()   # relative_change_monitor :288-310
+
+    def _relative_change(self):
+        import numpy as np
+        lhs = self._lhs_now()
+        eps = 1.0e-3
+        d = np.abs(lhs - self._last_lhs) / np.maximum(np.abs(self._last_lhs), eps)
+        return float(d.max())
+
+    def _lhs_now(self):
+        import numpy as np
+        n = self.ode.num_dof
+        out = np.zeros(n)
+        self.ode.lhs(self.time, None, self.y, out)
+        return out
+
+    def _set_status(self, converged, nits, tries):
+        """set_current_status (:1304-1375)."""
+        if self.steady_state:
+            self.status = FINAL if converged else ABORTED
+            self.finished = True
+            return
+        if converged:
+            if self.finished and self.status != ABORTED:
+                self.status = FINAL
+                return
+            if self.adaptor.on or (self.fixed_step_index == len(self.sizes) and not self.fixed):
+                eta = self._monitor(nits)
+                if eta < self.adaptor.monitor_min:
+                    self.status = TOO_SMALL
+                elif eta > self.adaptor.monitor_max:
+                    self.status = TOO_BIG
+                else:
+                    self.status = OK
+            else:
+                self.status = OK
+        elif tries >= self.max_num_tries:
+            self.status = ABORTED
+            self.finished = True
+        else:
+            self.status = NOT_CONVERGED
+            self.finished = False
+
+    def _adapt(self, stepsize):
+        """adapt (:1457-1476): (accepted, next step size)."""
+        if self.status == TOO_SMALL:
+            return True, self.adaptor.increase(stepsize)
+        if self.status in (TOO_BIG, NOT_CONVERGED):
+            return False, self.adaptor.reduce(stepsize)
+        return True, stepsize
+
+    def _next_fixed(self, stepsize):
+        """get_next_fixed_stepsize (:1380-1408)."""
+        self.fixed_step_index += 1
+        if self.fixed_step_index <= len(self.sizes):
+            return True, self.sizes[self.fixed_step_index - 1]
+        self.fixed_step_index = len(self.sizes)
+        if self.fixed:
+            return True, self.sizes[-1]
+        self.adaptor.on = True
+        return self._adapt(stepsize)
+
+    def _set_next_stepsize(self, stepsize):
+        """set_next_stepsize (:1412-1453)."""
+        if self.steady_state:
+            return True
+        if self.adaptor.on:
+            accepted, nxt = self._adapt(stepsize)
+            n = len(self.sizes)
+            if self.fixed_step_index < n or (self.fixed_step_index >= n and self.fixed):
+                if nxt >= self.sizes[self.fixed_step_index - 1]:
+                    self.adaptor.on = False  # back to the fixed sizes
+                    nxt = self.sizes[self.fixed_step_index - 1]
+        elif self.status in (TOO_BIG, NOT_CONVERGED):
+            self.adaptor.on = True           # temporarily adaptive
+            accepted, nxt = self._adapt(stepsize)
+        else:
+            accepted, nxt = self._next_fixed(stepsize)
+        self.next_stepsize = nxt
+        return accepted
+
+    # ---- timestepper_step ----------------------------------------------------------------------
     def step(self):
-        """One accepted backward-Euler step (timestepper_step)."""
+        """One accepted step (timestepper_step :2316-2376)."""
         ode = self.ode
+        ode.pre_timestep()
+        need_lhs = self.adaptor.method == "change" and not self.steady_state
+        if need_lhs:
+            self._last_lhs = self._lhs_now()
         tries = 0
-        while True:
-            tries += 1
+        accepted = False
+        y_start = self.y.clone() if hasattr(self.y, "clone") else self.y.copy()
+        self.status = OK
+        while not (accepted or (self.finished and tries > 0)):
             ode.pre_try_timestep(self.time)
-            reason, nits, kits = ode.timestep(self.time + self.stepsize, self.stepsize, self.y)
-            if reason > 0:
-                break
-            # TIMESTEP_NOT_CONVERGED: wai_timestep already restored y and the fluid regions
-            if tries >= self.max_num_tries:
-                raise StepFailed("time step not converged after %d tries" % tries)
-            self.stepsize *= self.reduction
-        self.time += self.stepsize
-        self.history.append((self.time, self.stepsize, nits, kits, tries))
+            if tries > 0:
+                ode.pre_retry_timestep()
+                self.y[...] = y_start
+            stepsize = self._check_finished(self.next_stepsize)
+            reason, nits, kits = ode.timestep(self.time + stepsize, stepsize, self.y)
+            tries += 1
+            self._set_status(reason > 0, nits, tries)
+            accepted = self._set_next_stepsize(stepsize)
+        if self.status == ABORTED:
+            raise StepFailed("time step aborted after %d tries" % tries)
+        self.taken += 1
+        if not self.steady_state:
+            self.time += stepsize
+        self.history.append((self.time, stepsize, nits, kits, tries))
         ode.time = self.time
         ode.post_timestep()
-        self.stepsize *= self.growth
         return nits, kits
 
-    def run(self, num_steps):
-        for _ in range(num_steps):
+    def run(self, num_steps=None):
+        """timestepper_run (:2380-2410): until finished, or `num_steps` accepted steps."""
+        n = 0
+        self.finished = False
+        while not self.finished and (num_steps is None or n < num_steps):
             self.step()
+            n += 1
         return self.history
