@@ -255,6 +255,8 @@ def main():
     nnzb = wl.LIB.wai_jacobian_nnzb(sim.h)
     names = ["spmv", "ilu_apply", "fused_pc_amul", "probe_ilu_nosweep", "probe_fused_nosweep",
              "ilu_apply_barrier_path", "fused_barrier_path"]
+    if os.environ.get("WAI_PC_PIPE") == "1":  # opt-in pipelined kernel: then 2 is that kernel, plus its probes
+        names += ["probe_pipe_nosweep", "probe_pipe_noloads"]
     kb = {name: sim.bench_kernel(w, a.spmv_reps if w in (0, 2) else 20) for w, name in enumerate(names)}
     log("kernel microbench (ms/launch): " + json.dumps(kb))
     b_spmv = spmv_bytes(nnzb, lm.n_owned, bs)

@@ -184,7 +184,8 @@ int wai_timer_stop(wai_ctx *ctx, float *ms);
 int wai_synchronize(wai_ctx *ctx);
 /* HIP-event timed repetitions of one kernel on the library's stream (needs an assembled
  * Jacobian): which 0 block SpMV, 1 ILU(0) apply, 2 fused SpMV + ILU(0) apply + dot,
- * 3/4 timing probes of 1/2 without the substitution sweeps */
+ * 3/4 timing probes of 1/2 without the substitution sweeps, 5/6 = 1/2 on the per-level barrier
+ * path, 7/8 probes of the opt-in pipelined kernel (WAI_PC_PIPE=1: sweeps / prefetch skipped) */
 int wai_bench_kernel(wai_ctx *ctx, int which, int reps, float *ms_per_launch);
 /* accumulated HIP-event time (ms) and launch counts per kernel class since the last reset;
  * classes: 0 eos, 1 residual, 2 jacobian, 3 spmv, 4 pc_apply, 5 pc_setup, 6 vector, 7 transitions */

@@ -706,6 +706,14 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
     // barrier-per-level form on MI355X (0.373 vs 0.346 ms at 4.1 M rows): opt-in only
     s.level_sorted = level_sorted && getenv("WAI_ILU_WAVEPIPE");
     s.fast3 = fast3 && !getenv("WAI_ILU_NOFAST");
+    {
+      const char* e = getenv("WAI_PC_PIPE");
+      s.pipe = e && e[0] == '1';  // opt-in: measured slower than k_pc
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
+        s.pipe_grid = ((prop.multiProcessorCount + 7) / 8) * 8;
+      if (const char* g = getenv("WAI_PC_PIPE_GRID")) s.pipe_grid = std::max(8, (atoi(g) / 8) * 8);
+    }
   }
   // state and work vectors
   const size_t nl = (size_t)np * m.n_prim, n = (size_t)np * N;
@@ -1202,7 +1210,8 @@ int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
       default: launch_pc(c, true, k.P, k.V, 1, k.RP); break;
     }
   };
-  c->dbg = (which == 3 || which == 4) ? 1 : (which >= 5 ? 2 : 0);
+  // 7/8: probes of the pipelined kernel (sweeps skipped / next-brick loads skipped)
+  c->dbg = (which == 3 || which == 4) ? 1 : (which == 7 ? 4 : which == 8 ? 8 : which >= 5 ? 2 : 0);
   for (int i = 0; i < 5; i++) run();
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   for (int i = 0; i < reps; i++) run();

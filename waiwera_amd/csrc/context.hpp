@@ -62,6 +62,8 @@ struct IluSchedule {
   bool fast3 = false;         // <= 3 lower and <= 3 upper in-subdomain couplings per row, offsets < 4
   bool level_sorted = false;  // every subdomain's rows are stored in dependency-level order
   bool factored = false;
+  bool pipe = false;          // software-pipelined persistent k_pc_pipe where it applies (WAI_PC_PIPE=1: on)
+  int pipe_grid = 256;        // its workgroups: one per CU
 };
 
 // Residual form of the time stepping method (src/timestepper.F90:345-452), by value to kernels

@@ -590,6 +590,213 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
   }
 }
 
+// ---- K6+K8 fused, software-pipelined over bricks (bs = 2, DILU, <= 3+3 couplings) --------------
+// k_pc alternates a load phase (matrix row, x gather: HBM/L2 latency) and the substitution
+// sweeps (LDS latency, ~2 x 22 barrier-separated levels for an 8x8x8 brick), and with ~100 VGPRs
+// only two workgroups fit a CU, so the sweeps (15-20 % of the kernel) are not hidden behind other
+// workgroups' loads.  Here a persistent workgroup walks its share of the bricks and issues the
+// next brick's loads before it starts the current brick's sweeps: the sweeps only touch LDS
+// (lgkmcnt), the global loads stay in flight across the level barriers (vmcnt is not waited on:
+// the barrier below is `s_waitcnt lgkmcnt(0); s_barrier`, not __syncthreads, whose fence would
+// drain vmcnt), and the x gather -- which needs the column indices -- is issued between the
+// forward and the backward sweep.  ~200 VGPRs, 2 waves/SIMD, one workgroup per CU.  Block-ELL
+// width 7 (3-D 7-point stencils) is compiled in; other widths take k_pc.
+// MEASURED (216^3, MI355X): 0.895 ms against k_pc's 0.776 ms, so it is opt-in (WAI_PC_PIPE=1).
+// Probes: loads only 0.68 ms, sweeps only 0.64 ms -- with one workgroup per CU a brick's 43
+// levels cost 8.3 us (~460 cycles per level: LDS round trip + dependent FMAs + barrier), longer
+// than the brick's 7.7 us share of HBM time, so the sweeps become the critical path; k_pc's two
+// resident workgroups per CU hide them better than prefetching does.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__global__ __launch_bounds__(512, 2) void k_pc_pipe(
+    int n, int nsub, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev,
+    const int* __restrict__ row_info, const int* __restrict__ col, const double* __restrict__ aval,
+    const double* __restrict__ dinv, const double* __restrict__ in, double* __restrict__ z,
+    const double* __restrict__ aux, double* partials, int nb_max, int dot, int dbg) {
+  constexpr int BS = 2, BB = 4, MLU = 3, WW = 7;
+  extern __shared__ double lds[];
+  double* ys = lds;
+  const int tid = threadIdx.x;
+  // XCD-aware brick schedule: workgroup (xcd, k) of the gx workgroups on its XCD takes bricks
+  // xcd*per + k, + gx, + 2 gx ... of the XCD's contiguous eighth
+  const int xcd = blockIdx.x & 7, k0 = blockIdx.x >> 3, gx = gridDim.x >> 3, per = (nsub + 7) >> 3;
+  auto brick = [&](int m) {
+    const int k = k0 + gx * m;
+    const int s = xcd * per + k;
+    return (k < per && s < nsub) ? s : -1;
+  };
+  // in-flight row of the next brick
+  double nb[WW][BB], ndv[BB], nx[WW][BS];
+  double2 nex = make_double2(0.0, 0.0);  // in[i] (dot 2) or aux[i] (dot 1) of the row
+  const double* exv = dot == 1 ? aux : in;  // always read: no conditional register merge around the load
+  int ncg[WW], ninfo = 0, nlo = 0, nR = 0, nnl = 0;
+#pragma unroll
+  for (int q = 0; q < WW; q++) {
+    ncg[q] = 0;
+#pragma unroll
+    for (int e = 0; e < BB; e++) nb[q][e] = 0.0;
+#pragma unroll
+    for (int r = 0; r < BS; r++) nx[q][r] = 0.0;
+  }
+#pragma unroll
+  for (int e = 0; e < BB; e++) ndv[e] = 0.0;
+  auto issue_main = [&](int s) {
+    nlo = sub_ptr[s]; nR = sub_ptr[s + 1] - nlo; nnl = sub_nlev[s];
+    if (tid < nR) {
+      const int i = nlo + tid;
+#pragma unroll
+      for (int q = 0; q < WW; q++)
+        ncg[q] = col[(size_t)q * n + i];
+      ninfo = row_info[i];
+      load_block<BS>(dinv, n, 0, i, ndv);
+#pragma unroll
+      for (int q = 0; q < WW; q++)
+        load_block<BS>(aval, n, q, i, nb[q]);
+    }
+  };
+  auto issue_x = [&]() {
+    nex = make_double2(0.0, 0.0);
+    if (tid < nR) {
+      const int i = nlo + tid;
+#pragma unroll
+      for (int q = 0; q < WW; q++)
+        load_x<BS>(in, ncg[q], nx[q]);
+      nex = *reinterpret_cast<const double2*>(exv + (size_t)i * 2);
+    }
+  };
+  double v0 = 0.0, v1 = 0.0;  // dot accumulators over this workgroup's bricks
+  int s = brick(0);
+  if (s >= 0) { issue_main(s); issue_x(); }
+  for (int m = 0; s >= 0; m++) {
+    // ---- consume the landed row: SpMV, compaction of the lower / upper blocks ----------------
+    // everything in flight has to land before the row is consumed; said once, outside the
+    // `active` branch, so the compiler's wait-count tracking starts every iteration from "nothing
+    // pending" instead of merging the skipped branch's state into conservative waits further down
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
+    const int lo = nlo, R = nR;
+    const int nlf = (dbg & 1) ? 0 : (nnl & 0xffff), nlb = (dbg & 1) ? 1 : (nnl >> 16);  // dbg: timing probes
+    const bool active = tid < R;
+    const int i = lo + tid;
+    double Lf[MLU][BB], Uf[MLU][BB], dv[BB];
+    const double2 ex = nex;
+    int Lc[MLU], Uc[MLU], lf = -1, lb = -1;
+#pragma unroll
+    for (int p = 0; p < MLU; p++) {
+      Lc[p] = tid; Uc[p] = tid;
+#pragma unroll
+      for (int e = 0; e < BB; e++) { Lf[p][e] = 0.0; Uf[p][e] = 0.0; }
+    }
+#pragma unroll
+    for (int e = 0; e < BB; e++) dv[e] = ndv[e];
+    if (active) {
+      int lfirst, dslot, ulast;
+      unpack_info(ninfo, lfirst, dslot, ulast, lf, lb);
+      double acc[BS] = {0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < WW; q++) {
+        {
+#pragma unroll
+          for (int r = 0; r < BS; r++)
+#pragma unroll
+            for (int k = 0; k < BS; k++) acc[r] += nb[q][r * BS + k] * nx[q][k];
+          const bool isl = (q >= lfirst) && (q < dslot), isu = (q > dslot) && (q < ulast);
+#pragma unroll
+          for (int p = 0; p < MLU; p++) {
+            const bool tl = isl && (q - lfirst == p), tu = isu && (q - dslot - 1 == p);
+            Lc[p] = tl ? ncg[q] - lo : Lc[p];
+            Uc[p] = tu ? ncg[q] - lo : Uc[p];
+#pragma unroll
+            for (int e = 0; e < BB; e++) {
+              Lf[p][e] = tl ? nb[q][e] : Lf[p][e];
+              Uf[p][e] = tu ? nb[q][e] : Uf[p][e];
+            }
+          }
+        }
+      }
+      if (lf == 0) {  // level-0 rows: w = inv(D) t straight away
+        const double w0 = dv[0] * acc[0] + dv[1] * acc[1], w1 = dv[2] * acc[0] + dv[3] * acc[1];
+        acc[0] = w0; acc[1] = w1;
+      }
+      *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(acc[0], acc[1]);
+    }
+    lds_barrier();
+    // ---- next brick's matrix row goes in flight now ---------------------------------------------
+    const int snext = brick(m + 1);
+    if (snext >= 0 && !(dbg & 2)) issue_main(snext);
+    auto gather3 = [&](const int (&cc)[MLU], const double (&ff)[MLU][BB], double* sum) {
+      double2 yk[MLU];
+#pragma unroll
+      for (int p = 0; p < MLU; p++) yk[p] = *reinterpret_cast<const double2*>(ys + cc[p] * 2);
+#pragma unroll
+      for (int r = 0; r < BS; r++) {
+        double part[MLU];
+#pragma unroll
+        for (int p = 0; p < MLU; p++) part[p] = ff[p][r * BS] * yk[p].x + ff[p][r * BS + 1] * yk[p].y;
+        sum[r] = (part[0] + part[1]) + part[2];
+      }
+    };
+    // forward: y_i = t_i - sum A_ik w_k, w_i = inv(D_i) y_i (LDS holds w)
+    for (int lev = 1; lev < nlf; lev++) {
+      if (lf == lev) {
+        const double2 a = *reinterpret_cast<const double2*>(ys + tid * 2);
+        double sum[BS];
+        gather3(Lc, Lf, sum);
+        const double a0 = a.x - sum[0], a1 = a.y - sum[1];
+        *reinterpret_cast<double2*>(ys + tid * 2) =
+            make_double2(dv[0] * a0 + dv[1] * a1, dv[2] * a0 + dv[3] * a1);
+      }
+      lds_barrier();
+    }
+    // the column indices of the next row have landed by now: x gather in flight under the
+    // backward sweep
+    if (snext >= 0 && !(dbg & 2)) issue_x();
+    // backward: x_i = w_i - inv(D_i) sum A_ij x_j
+    double out[BS] = {0.0, 0.0};
+    for (int lev = 0; lev < nlb; lev++) {
+      if (lb == lev) {
+        const double2 a = *reinterpret_cast<const double2*>(ys + tid * 2);
+        double sum[BS];
+        gather3(Uc, Uf, sum);
+        out[0] = a.x - (dv[0] * sum[0] + dv[1] * sum[1]);
+        out[1] = a.y - (dv[2] * sum[0] + dv[3] * sum[1]);
+        *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(out[0], out[1]);
+      }
+      lds_barrier();  // also fences this brick's last LDS reads from the next brick's writes
+    }
+    if (active) {
+      *reinterpret_cast<double2*>(z + (size_t)i * 2) = make_double2(out[0], out[1]);
+      if (dot == 1) v0 += out[0] * ex.x + out[1] * ex.y;
+      else if (dot == 2) { v0 += ex.x * out[0] + ex.y * out[1]; v1 += out[0] * out[0] + out[1] * out[1]; }
+      else if (dot == 3) v0 += out[0] * out[0] + out[1] * out[1];
+    }
+    s = snext;
+  }
+  if (dot != 0) {
+    // one partial per workgroup; the reduction kernel sums nsub entries per slot, so the
+    // remaining entries of this workgroup's stride are zeroed
+    double* red = lds + (size_t)blockDim.x * BS;
+    const int G = gridDim.x;
+    __syncthreads();
+    if (dot == 2) {
+      double v[2] = {v0, v1};
+      const int slots[2] = {S_D1, S_D2};
+      wg_reduce_store<2>(v, red, partials, nb_max, slots, blockIdx.x);
+      for (int j = blockIdx.x + G + tid * G; j < nsub; j += G * blockDim.x) {
+        partials[(size_t)S_D1 * nb_max + j] = 0.0;
+        partials[(size_t)S_D2 * nb_max + j] = 0.0;
+      }
+    } else {
+      double v[1] = {v0};
+      const int slots[1] = {dot == 1 ? S_D1 : S_DP2};
+      wg_reduce_store<1>(v, red, partials, nb_max, slots, blockIdx.x);
+      for (int j = blockIdx.x + G + tid * G; j < nsub; j += G * blockDim.x)
+        partials[(size_t)slots[0] * nb_max + j] = 0.0;
+    }
+  }
+}
+
 // ---- layout conversion (C ABI exchanges BCSR) -------------------------------------------------
 __global__ __launch_bounds__(TPB) void k_ell_to_bcsr(int n, int W, int bs, const int* __restrict__ rowptr,
                                                      const double* __restrict__ ell, double* __restrict__ bcsr) {
@@ -834,6 +1041,16 @@ static void launch_pc_bs(wai_ctx* c, bool spmv, const double* in, double* z, int
                          s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, c->dbg);    \
   } while (0)
   const bool wp = s.level_sorted && !(c->dbg & 2);
+  if constexpr (BS == 2) {
+    // software-pipelined persistent variant: needs a workgroup index below nsub for every
+    // workgroup's partial, i.e. at least as many bricks as workgroups
+    if (spmv && s.pipe && s.diag_only && s.fast3 && J.W == 7 && T <= 512 && !(c->dbg & 3) && s.nsub >= s.pipe_grid) {
+      hipLaunchKernelGGL(k_pc_pipe, s.pipe_grid, T, lds, c->stream, J.n, s.nsub, s.sub_ptr,
+                         s.sub_nlev, s.row_info, J.col, J.val, s.dinv, in, z, aux, c->ks.partials,
+                         c->ks.nb_max, dot_mode, c->dbg >> 2);
+      return;
+    }
+  }
   if (spmv) {
     if (s.diag_only) { if (wp) PCL(true, true, true); else PCL(true, true, false); }
     else { if (wp) PCL(true, false, true); else PCL(true, false, false); }
