@@ -178,6 +178,37 @@ int wai_newton_step(wai_ctx *ctx, double t, double dt, int iter, double *y,
 int wai_timestep(wai_ctx *ctx, double t, double dt, double *y, int *newton_its, int *ksp_its,
                  int *reason);
 
+/* ---- passive tracers: the auxiliary linear problem ------------------------------------------
+ * (src/tracer.F90:30-61; ode_type aux_lhs / aux_rhs / aux_pre_solve as overridden at
+ * src/flow_simulation.F90:107-109,1489-1959; timestepper setup_linear src/timestepper.F90:458-581
+ * and the auxiliary KSPSolve :2345-2355).  Tracer mass fractions are nt doubles per owned cell,
+ * interleaved [cell][tracer] like the reference's aux_solution Vec.  Tracers do not couple, so
+ * each is a scalar system on the flow Jacobian's sparsity, solved with the same SpMV / ILU(0) /
+ * Krylov kernels at block size 1.  Call after a converged wai_timestep (the phase fluxes are
+ * those of the converged fluid state). */
+/* phase: 0-based mobile phase the tracer lives in; decay constant (1/s), activation energy
+ * (J/mol), diffusion coefficient (m2/s); at most 8 tracers */
+int wai_set_tracers(wai_ctx *ctx, int n, const int *phase, const double *decay,
+                    const double *activation, const double *diffusion);
+int wai_set_tracer_bc(wai_ctx *ctx, const double *x_bc);         /* [n_bc][n] Dirichlet values */
+int wai_set_tracer_injection(wai_ctx *ctx, const double *rate);  /* [n_sources][n] kg/s, after wai_set_sources */
+/* auxiliary KSP (defaults gmres(30), rtol 1e-5, atol 1e-50, 10000 its: timestepper.F90:2021-2022) */
+int wai_set_aux_solver(wai_ctx *ctx, int ksp_type, int gmres_restart, double rtol, double atol,
+                       int max_its);
+/* aux_lhs: Al = porosity * saturation * density of the tracer's phase, [cell][tracer] */
+int wai_tracer_lhs(wai_ctx *ctx, double *Al);
+/* the system wai_tracer_solve would solve for one tracer, after aux_pre_solve: scalar CSR values
+ * on wai_jacobian_pattern's rowptr/colidx (nnzb doubles) and the right-hand side (n_owned) */
+int wai_tracer_system(wai_ctx *ctx, int tracer, int method, double dt, double ratio,
+                      const double *alx_last, const double *alx_last2, double *val, double *b);
+/* one auxiliary solve: setup_linear of `method` (WAI_METHOD_*; ratio = dt / last dt for BDF2),
+ * aux_pre_solve, KSPSolve from a zero initial guess.  alx_last / alx_last2 = Al o X one / two
+ * steps back (the caller owns the history like the reference's timestepper_steps), X in/out,
+ * alx_new = Al o X of the new state.  reason = smallest KSPConvergedReason over the tracers,
+ * its = summed iterations. */
+int wai_tracer_solve(wai_ctx *ctx, int method, double dt, double ratio, const double *alx_last,
+                     const double *alx_last2, double *X, double *alx_new, int *its, int *reason);
+
 /* ---- measurement helpers ------------------------------------------------------------------- */
 int wai_timer_start(wai_ctx *ctx);             /* hipEvent on the library's stream */
 int wai_timer_stop(wai_ctx *ctx, float *ms);

@@ -161,6 +161,20 @@ int wo_newton_step(wo_sim *s, const wo_newton_opts *o, int iter, double dt, doub
 /* whole backward-Euler step: SNESSolve loop; y in/out.  Returns newton its (>0) or -reason */
 int wo_timestep(wo_sim *s, const wo_newton_opts *o, double dt, double *y, int *total_ksp_its);
 
+/* ---- passive tracers: auxiliary linear problem (src/tracer.F90, flow_simulation.F90:1489-1959,
+ * timestepper.F90:458-581) ------------------------------------------------------------------- */
+int wo_sim_set_tracers(wo_sim *s, int nt, const int *phase, const double *decay,
+                       const double *activation, const double *diffusion);
+void wo_sim_set_tracer_bc(wo_sim *s, const double *x_bc);
+void wo_sim_set_tracer_injection(wo_sim *s, const double *rate);
+void wo_tracer_lhs(wo_sim *s, double *Al);
+void wo_tracer_system(wo_sim *s, int it, int method, double dt, double ratio,
+                      const double *alx_last, const double *alx_last2, double *A, double *b);
+int wo_tracer_solve(wo_sim *s, int method, double dt, double ratio, const double *alx_last,
+                    const double *alx_last2, double *X, double *alx_new, int ksp_type, int restart,
+                    double rtol, double atol, int maxits, int *its);
+
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,13 @@ struct wo_sim {
   double dt_last, dt_last_prev;
   double *hist, *hist_prev;
   int can_reject;
+  int ksp_bs;           /* block size of the system the Krylov code is solving (np, or 1: tracers) */
+  /* passive tracers (src/tracer.F90:30-40) */
+  int nt;
+  int *tr_phase;        /* 0-based phase index */
+  double *tr_decay, *tr_act, *tr_diff;
+  double *tr_bc;        /* [n_bc][nt] Dirichlet mass fractions */
+  double *tr_inj;       /* [n_src][nt] injection rates (kg/s) */
 };
 
 static void cell_residual(const wo_sim *s, int c, double dt, const double *lhs_old, int which,
@@ -165,6 +172,7 @@ void wo_sim_destroy(wo_sim *s) {
   free(s->cf_ptr); free(s->cf_face); free(s->cf_side); free(s->rowptr); free(s->colidx);
   free(s->src_cell); free(s->src_comp); free(s->src_rate); free(s->src_enth);
   free(s->sub_ptr); free(s->fval); free(s->dinv); free(s->lhs_last2); free(s->hist); free(s->hist_prev);
+  free(s->tr_phase); free(s->tr_decay); free(s->tr_act); free(s->tr_diff); free(s->tr_bc); free(s->tr_inj);
   free(s);
 }
 
@@ -754,8 +762,10 @@ static double gdot(wo_sim *s, const double *a, const double *b, int n) {
 }
 
 /* z = B^-1 A x ; x must have room for halo entries */
+static int ksp_bs(const wo_sim *s) { return s->ksp_bs > 0 ? s->ksp_bs : s->eos.np; }
+
 static void pc_amul(wo_sim *s, const double *val, double *x, double *tmp, double *z) {
-  int bs = s->eos.np;
+  int bs = ksp_bs(s);
   if (s->halo && s->n_halo) s->halo(s->user, x, bs);
   wo_bcsr_spmv(s->n_owned, bs, s->rowptr, s->colidx, val, x, tmp);
   wo_bilu0_apply(s->n_owned, bs, s->rowptr, s->colidx, s->fval, s->dinv, s->nsub, s->sub_ptr,
@@ -764,7 +774,7 @@ static void pc_amul(wo_sim *s, const double *val, double *x, double *tmp, double
 
 static int ksp_bcgs(wo_sim *s, const double *val, const double *b, double *x, double rtol,
                     double atol, int maxits, int *its, double *rnorm, double *hist) {
-  int bs = s->eos.np, n = bs * s->n_owned, nl = bs * s->n_prim;
+  int bs = ksp_bs(s), n = bs * s->n_owned, nl = bs * s->n_prim;
   double *R = xmalloc(sizeof(double) * n), *RP = xmalloc(sizeof(double) * n);
   double *P = xmalloc(sizeof(double) * nl), *V = xmalloc(sizeof(double) * n);
   double *S = xmalloc(sizeof(double) * nl), *T = xmalloc(sizeof(double) * n);
@@ -828,7 +838,7 @@ static int ksp_bcgs(wo_sim *s, const double *val, const double *b, double *x, do
 static int ksp_gmres(wo_sim *s, int m, const double *val, const double *b, double *x,
                      double rtol, double atol, int maxits, int *its, double *rnorm,
                      double *hist) {
-  int bs = s->eos.np, n = bs * s->n_owned, nl = bs * s->n_prim;
+  int bs = ksp_bs(s), n = bs * s->n_owned, nl = bs * s->n_prim;
   double *Vb = xmalloc(sizeof(double) * (size_t)nl * (m + 1));
   double *H = xmalloc(sizeof(double) * (m + 1) * m), *cs = xmalloc(sizeof(double) * m);
   double *sn = xmalloc(sizeof(double) * m), *g = xmalloc(sizeof(double) * (m + 1));
@@ -929,13 +939,197 @@ static int ksp_gmres(wo_sim *s, int m, const double *val, const double *b, doubl
 int wo_ksp_solve(wo_sim *s, int ksp_type, int restart, const double *val, const double *b,
                  double *x, double rtol, double atol, int maxits, int *its, double *rnorm,
                  double *hist) {
-  int bs = s->eos.np;
+  int bs = ksp_bs(s);
   if (wo_bilu0_factor(s->n_owned, bs, s->rowptr, s->colidx, val, s->nsub, s->sub_ptr, s->fval,
                       s->dinv))
     return -11; /* KSP_DIVERGED_PC_FAILED */
   if (ksp_type == 1) return ksp_gmres(s, restart > 0 ? restart : 30, val, b, x, rtol, atol,
                                       maxits, its, rnorm, hist);
   return ksp_bcgs(s, val, b, x, rtol, atol, maxits, its, rnorm, hist);
+}
+
+/* ---- passive tracers: the auxiliary linear problem --------------------------------------- */
+/* src/tracer.F90:30-61, flow_simulation.F90:1489-1959, timestepper.F90:458-581,2345-2355.
+ * Unknowns are tracer mass fractions, nt per owned cell, interleaved [cell][tracer] at the
+ * interface.  Tracers do not couple, so each one is a scalar system on the flow Jacobian's
+ * sparsity; Dirichlet boundary cells (identity rows in the reference's matrix, :1912-1937) are
+ * eliminated into the right-hand side. */
+int wo_sim_set_tracers(wo_sim *s, int nt, const int *phase, const double *decay,
+                       const double *activation, const double *diffusion) {
+  free(s->tr_phase); free(s->tr_decay); free(s->tr_act); free(s->tr_diff); free(s->tr_bc); free(s->tr_inj);
+  s->nt = nt;
+  s->tr_phase = (int *)xmalloc(sizeof(int) * nt);
+  s->tr_decay = (double *)xmalloc(sizeof(double) * nt);
+  s->tr_act = (double *)xmalloc(sizeof(double) * nt);
+  s->tr_diff = (double *)xmalloc(sizeof(double) * nt);
+  s->tr_bc = (double *)xmalloc(sizeof(double) * nt * (s->n_bc ? s->n_bc : 1));
+  s->tr_inj = (double *)xmalloc(sizeof(double) * nt * (s->n_src ? s->n_src : 1));
+  for (int i = 0; i < nt; i++) {
+    if (phase[i] < 0 || phase[i] >= s->eos.nmob) return -1;
+    s->tr_phase[i] = phase[i]; s->tr_decay[i] = decay[i]; s->tr_act[i] = activation[i];
+    s->tr_diff[i] = diffusion[i];
+  }
+  return 0;
+}
+void wo_sim_set_tracer_bc(wo_sim *s, const double *x_bc) {
+  memcpy(s->tr_bc, x_bc, sizeof(double) * s->nt * s->n_bc);
+}
+/* call after wo_sim_set_sources */
+void wo_sim_set_tracer_injection(wo_sim *s, const double *rate) {
+  free(s->tr_inj);
+  s->tr_inj = (double *)xmalloc(sizeof(double) * s->nt * (s->n_src ? s->n_src : 1));
+  memcpy(s->tr_inj, rate, sizeof(double) * s->nt * s->n_src);
+}
+
+/* cell_tracer_balance_coefs: src/cell.F90:146-164 */
+static double tracer_coef(const wo_sim *s, const double *fl, const double *rock, int p) {
+  const double *ph = fl + (7 + s->eos.nc - 1) + p * (8 + s->eos.nc - 1);
+  return rock[5] * ph[2] * ph[0]; /* porosity * saturation * density */
+}
+/* aux_lhs = flow_simulation_tracer_cell_balances: :1489-1556 */
+void wo_tracer_lhs(wo_sim *s, double *Al) {
+  for (int c = 0; c < s->n_owned; c++)
+    for (int it = 0; it < s->nt; it++)
+      Al[c * s->nt + it] = tracer_coef(s, s->fluid + (size_t)c * s->eos.df, s->rock + c * 8, s->tr_phase[it]);
+}
+
+/* tracer_decay: src/tracer.F90:48-61 (gas constant and tc_k of thermodynamics.F90) */
+static double tracer_decay_rate(double k0, double ea, double temperature) {
+  return k0 * exp(-ea / (8.3144598 * (temperature + 273.15)));
+}
+
+/* aux_rhs = flow_simulation_tracer_cell_inflows (:1560-1833) for tracer `it`: Ar on the scalar
+ * CSR pattern (rowptr/colidx), br with the boundary columns folded in */
+static void tracer_inflows(wo_sim *s, int it, double *Ar, double *br) {
+  const wo_eos *e = &s->eos;
+  int np = e->np, df = e->df, p = s->tr_phase[it], nc = e->nc;
+  int boff = 7 + nc - 1, pdof = 8 + nc - 1;
+  double flux[MAXBS + 4];
+  memset(Ar, 0, sizeof(double) * s->nnzb);
+  memset(br, 0, sizeof(double) * s->n_owned);
+  for (int f = 0; f < s->n_faces; f++) {
+    int cells[2] = {s->face_cells[2 * f], s->face_cells[2 * f + 1]};
+    const double *fg = s->face_geom + 12 * f;
+    const double *f1 = s->fluid + (size_t)cells[0] * df, *f2 = s->fluid + (size_t)cells[1] * df;
+    const double *r1 = s->rock + cells[0] * 8, *r2 = s->rock + cells[1] * 8;
+    wo_face_flux(e, fg, f1, r1, f2, r2, flux);
+    double phase_flux = flux[np + p];
+    int up = (phase_flux >= 0.0) ? 0 : 1;
+    double tracer_flow = phase_flux * fg[0];
+    /* face_diffusion_factor: face.F90:519-536, cell.F90:168-200 (porosity * density * saturation) */
+    double cf1 = r1[5] * f1[boff + p * pdof] * f1[boff + p * pdof + 2];
+    double cf2 = r2[5] * f2[boff + p * pdof] * f2[boff + p * pdof + 2];
+    double dfac = wo_harmonic_average(fg, cf1, cf2);
+    static const double sign[2] = {-1.0, 1.0};
+    for (int i = 0; i < 2; i++) {
+      int row = cells[i];
+      if (row >= s->n_owned) continue;
+      double vol = s->cell_geom[4 * row + 3];
+      /* advective, at the upstream cell's column */
+      double Ft = sign[i] * tracer_flow / vol;
+      int col = cells[up];
+      if (col < s->n_prim) Ar[find_col(s, row, col)] += Ft;
+      else br[row] += Ft * s->tr_bc[(col - s->n_prim) * s->nt + it];
+      /* diffusive */
+      for (int j = 0; j < 2; j++) {
+        col = cells[j];
+        Ft = -sign[i] * sign[j] * fg[0] * dfac * s->tr_diff[it] / (fg[3] * vol);
+        if (col < s->n_prim) Ar[find_col(s, row, col)] += Ft;
+        else br[row] += Ft * s->tr_bc[(col - s->n_prim) * s->nt + it];
+      }
+    }
+  }
+  /* sources (tracer_source_iterator :1722-1772): production takes the phase's flow fraction,
+   * injection adds the tracer injection rate */
+  for (int i = 0; i < s->n_src; i++) {
+    int c = s->src_cell[i];
+    if (c < 0 || c >= s->n_owned) continue;
+    double vol = s->cell_geom[4 * c + 3], rate = s->src_rate[i];
+    int comp = s->src_comp[i];
+    int component = rate > 0.0 ? (comp <= 0 ? 1 : comp) : (comp <= 0 ? 0 : comp);
+    if (!(component < np)) continue;
+    if (rate < 0.0) {
+      const double *fl = s->fluid + (size_t)c * df;
+      int phases = (int)lround(fl[4]);
+      double frac[4] = {0, 0, 0, 0}, sum = 0.0;
+      for (int q = 0; q < e->nph; q++)
+        if (phases & (1 << q)) {
+          const double *ph = fl + boff + q * pdof;
+          frac[q] = ph[3] * ph[0] / ph[1];
+        }
+      for (int q = 0; q < e->nph; q++) sum += frac[q];
+      Ar[find_col(s, c, c)] += (frac[p] / sum) * rate / vol;
+    } else br[c] += s->tr_inj[i * s->nt + it] / vol;
+  }
+  /* apply_tracer_decay :1776-1831 */
+  for (int c = 0; c < s->n_owned; c++) {
+    const double *fl = s->fluid + (size_t)c * df;
+    double a = -tracer_decay_rate(s->tr_decay[it], s->tr_act[it], fl[1]) *
+               tracer_coef(s, fl, s->rock + c * 8, p);
+    Ar[find_col(s, c, c)] += a;
+  }
+}
+
+/* One auxiliary solve (timestepper_step :2345-2355): the method's setup_linear (backward Euler
+ * :458-494, BDF2 :498-557, direct steady state :561-581), aux_pre_solve (phase absent -> mass
+ * fraction 0, :1883-1899, 1939-1942), KSPSolve with zero initial guess.
+ * alx_last / alx_last2: Al o X one / two steps back ([cell][tracer]); X: solution in/out
+ * ([cell][tracer]); alx_new: Al o X of the new state.  Returns the smallest KSP reason over the
+ * tracers; *its the summed iteration count. */
+/* the system of tracer `it` after setup_linear and aux_pre_solve: A on the scalar CSR pattern, b */
+void wo_tracer_system(wo_sim *s, int it, int method, double dt, double ratio,
+                      const double *alx_last, const double *alx_last2, double *A, double *b) {
+  int n = s->n_owned, nt = s->nt;
+  double *br = xmalloc(sizeof(double) * n), *Al = xmalloc(sizeof(double) * n * nt);
+  wo_tracer_lhs(s, Al);
+  tracer_inflows(s, it, A, br);
+  double r = ratio, r1 = r + 1.0;
+  double sA = method == 2 ? 1.0 : (method == 1 ? -dt * r1 : -dt);
+  for (int q = 0; q < s->nnzb; q++) A[q] *= sA;
+  for (int c = 0; c < n; c++) {
+    double al = Al[c * nt + it];
+    if (method == 0) {
+      A[find_col(s, c, c)] += al;
+      b[c] = alx_last[c * nt + it] + dt * br[c];
+    } else if (method == 1) {
+      A[find_col(s, c, c)] += al * (1.0 + 2.0 * r);
+      b[c] = (alx_last[c * nt + it] * (r1 * r1) + (-r * r) * alx_last2[c * nt + it]) + (dt * r1) * br[c];
+    } else b[c] = -br[c];
+  }
+  /* aux_pre_solve: rows of cells without the tracer's phase become identity, rhs 0 */
+  for (int c = 0; c < n; c++) {
+    int phases = (int)lround(s->fluid[(size_t)c * s->eos.df + 4]);
+    if (!(phases & (1 << s->tr_phase[it]))) {
+      for (int q = s->rowptr[c]; q < s->rowptr[c + 1]; q++) A[q] = (s->colidx[q] == c) ? 1.0 : 0.0;
+      b[c] = 0.0;
+    }
+  }
+  free(br); free(Al);
+}
+
+int wo_tracer_solve(wo_sim *s, int method, double dt, double ratio, const double *alx_last,
+                    const double *alx_last2, double *X, double *alx_new, int ksp_type, int restart,
+                    double rtol, double atol, int maxits, int *its) {
+  int n = s->n_owned, nt = s->nt, worst = 100;
+  double *A = xmalloc(sizeof(double) * s->nnzb), *b = xmalloc(sizeof(double) * n);
+  double *x = xmalloc(sizeof(double) * s->n_prim), *Al = xmalloc(sizeof(double) * n * nt);
+  *its = 0;
+  for (int it = 0; it < nt; it++) {
+    wo_tracer_system(s, it, method, dt, ratio, alx_last, alx_last2, A, b);
+    int k = 0;
+    double rn;
+    s->ksp_bs = 1;
+    int reason = wo_ksp_solve(s, ksp_type, restart, A, b, x, rtol, atol, maxits, &k, &rn, NULL);
+    s->ksp_bs = 0;
+    *its += k;
+    if (reason < worst) worst = reason;
+    for (int c = 0; c < n; c++) X[c * nt + it] = x[c];
+  }
+  wo_tracer_lhs(s, Al);
+  for (int c = 0; c < n; c++)
+    for (int it = 0; it < nt; it++) alx_new[c * nt + it] = Al[c * nt + it] * X[c * nt + it];
+  free(A); free(b); free(x); free(Al);
+  return worst;
 }
 
 /* ---- Newton protocol --------------------------------------------------------------------- */

@@ -101,6 +101,12 @@ def load(path):
         "wo_newton_opts_default": (None, [C.POINTER(NewtonOpts)]),
         "wo_newton_step": (i32, [C.c_void_p, C.POINTER(NewtonOpts), i32, d, pd, pd, pd, pi, pd]),
         "wo_timestep": (i32, [C.c_void_p, C.POINTER(NewtonOpts), d, pd, pi]),
+        "wo_sim_set_tracers": (i32, [C.c_void_p, i32, pi, pd, pd, pd]),
+        "wo_sim_set_tracer_bc": (None, [C.c_void_p, pd]),
+        "wo_sim_set_tracer_injection": (None, [C.c_void_p, pd]),
+        "wo_tracer_lhs": (None, [C.c_void_p, pd]),
+        "wo_tracer_system": (None, [C.c_void_p, i32, i32, d, d, pd, pd, pd, pd]),
+        "wo_tracer_solve": (i32, [C.c_void_p, i32, d, d, pd, pd, pd, pd, i32, i32, d, d, i32, pi]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -206,6 +212,41 @@ class OracleSim:
         reason = self.L.wo_ksp_solve(self.h, ksp_type, restart, dp(f64(val)), dp(f64(b)), dp(x),
                                      rtol, atol, maxits, C.byref(its), C.byref(rn), dp(hist))
         return reason, x[: self.n_owned * self.np], its.value, hist[: its.value + 1]
+
+    # ---- tracers (auxiliary linear problem) ----------------------------------------------------
+    def set_tracers(self, phase, decay=None, activation=None, diffusion=None, bc=None, injection=None):
+        nt = len(phase)
+        z = np.zeros(nt)
+        ph = i32a(phase)
+        assert self.L.wo_sim_set_tracers(self.h, nt, ip(ph), dp(f64(decay if decay is not None else z)),
+                                         dp(f64(activation if activation is not None else z)),
+                                         dp(f64(diffusion if diffusion is not None else z))) == 0
+        self.nt = nt
+        if bc is not None and self.mesh.n_bc:
+            self.L.wo_sim_set_tracer_bc(self.h, dp(f64(bc)))
+        if injection is not None and getattr(self.mesh, "n_src", 0):
+            self.L.wo_sim_set_tracer_injection(self.h, dp(f64(injection)))
+
+    def tracer_lhs(self):
+        out = np.zeros(self.n_owned * self.nt)
+        self.L.wo_tracer_lhs(self.h, dp(out))
+        return out
+
+    def tracer_system(self, it, method, dt, ratio, alx_last, alx_last2):
+        A, b = np.zeros(self.L.wo_sim_nnzb(self.h)), np.zeros(self.n_owned)
+        a2 = f64(alx_last2) if alx_last2 is not None else np.zeros(self.n_owned * self.nt)
+        self.L.wo_tracer_system(self.h, it, method, dt, ratio, dp(f64(alx_last)), dp(a2), dp(A), dp(b))
+        return A, b
+
+    def tracer_solve(self, method, dt, ratio, alx_last, alx_last2, X, ksp_type=1, restart=30,
+                     rtol=1e-5, atol=1e-50, maxits=10000):
+        """X: [cell][tracer] in/out (n_owned*nt); returns (reason, its, alx_new)"""
+        alx_new = np.zeros(self.n_owned * self.nt)
+        its = C.c_int(0)
+        a2 = dp(f64(alx_last2)) if alx_last2 is not None else dp(np.zeros(self.n_owned * self.nt))
+        r = self.L.wo_tracer_solve(self.h, method, dt, ratio, dp(f64(alx_last)), a2, dp(X), dp(alx_new),
+                                   ksp_type, restart, rtol, atol, maxits, C.byref(its))
+        return r, its.value, alx_new
 
     def opts(self):
         o = NewtonOpts()

@@ -1,0 +1,139 @@
+"""Oracle restatement of the tracer auxiliary linear problem (src/flow_simulation.F90:1489-1959,
+src/timestepper.F90:458-581).  Pinned on the reference's one-cell decay benchmark
+(test/benchmark/tracer/decay: analytic X0 exp(-k t), Arrhenius rate, BDF2, 20 one-day steps,
+the benchmark's own 1e-2 relative tolerance), then checked through what the transport
+equations guarantee: a uniform mass fraction stays uniform under pure advection, tracer mass
+is conserved in a closed box, an upwind front moves with the flow."""
+import math
+
+import numpy as np
+
+from tests import oracle_lib as ol
+from tests.cases import make_case, scaled
+
+DAY = 86400.0
+
+
+def setup(oracle, eos="we", **kw):
+    g, lm, prim, region = make_case(eos=eos, **kw)
+    osim = ol.OracleSim(oracle, lm, {"w": 0, "we": 1, "wce": 2}[eos])
+    osim.set_regions(region)
+    return g, lm, osim, osim.yvec(scaled(prim, region, eos).ravel().copy())
+
+
+def test_one_cell_decay_benchmark(oracle):
+    """test/benchmark/tracer/decay/run/decay.json: one cell at 10 bar / 60 degC, X0 = 1e-3,
+    tracers without decay, with constant decay 1e-6 /s, and with activation energy 2 kJ/mol"""
+    import waiwera_amd.mesh as M
+    g = M.StructuredGrid((1, 1, 1), brick=(1, 1, 1))
+    lm = g.local_mesh(0)
+    osim = ol.OracleSim(oracle, lm, 1)
+    osim.set_regions(np.ones(1, dtype=np.int32))
+    y = osim.yvec(np.array([1.0e6 / 1e6, 60.0 / 1e2]))
+    k0, ea, T, X0 = 1.0e-6, 2.0e3, 60.0, 1.0e-3
+    rates = [0.0, k0, k0 * math.exp(-ea / (8.3144598 * (T + 273.15)))]
+    osim.set_tracers([0, 0, 0], decay=[0.0, k0, k0], activation=[0.0, 0.0, ea])
+    o = osim.opts()
+    osim.set_timestep_method(1)
+    X = np.full(3, X0)
+    assert osim.pre_eval(y) == 0
+    alx = [osim.tracer_lhs() * X, None]
+    t, dt, dt_last = 0.0, DAY, None
+    for step in range(20):
+        r, k = osim.timestep(y, dt, o)
+        assert r >= 0
+        method = 1 if step > 0 else 0
+        reason, its, new = osim.tracer_solve(method, dt, dt / dt_last if dt_last else 0.0, alx[0], alx[1], X)
+        assert reason > 0
+        alx = [new, alx[0]]
+        dt_last = dt
+        t += dt
+        exact = np.array([X0 * math.exp(-kk * t) for kk in rates])
+        assert np.all(np.abs(X - exact) <= 1e-2 * exact + 1e-4 * 0)
+    assert X[0] == X0 or abs(X[0] - X0) < 1e-15
+    assert X[2] > X[1]      # the Arrhenius factor slows the decay
+    osim.close()
+
+
+def run_steps(osim, y, X, nsteps, dt, method=0, **kw):
+    o = osim.opts()
+    o.ksp_rtol, o.ftol_rel = 1e-10, 1e-10
+    osim.set_timestep_method(method)
+    assert osim.pre_eval(y) == 0
+    alx = [osim.tracer_lhs() * X, None]
+    dt_last = None
+    for step in range(nsteps):
+        r, k = osim.timestep(y, dt, o)
+        assert r > 0
+        m = method if (method != 1 or step > 0) else 0
+        reason, its, new = osim.tracer_solve(m, dt, dt / dt_last if dt_last else 0.0, alx[0], alx[1], X,
+                                             rtol=1e-12, **kw)
+        assert reason > 0
+        alx = [new, alx[0]]
+        dt_last = dt
+    return alx[0]
+
+
+def test_uniform_tracer_stays_uniform(oracle):
+    """single-phase liquid, injectors at the resident mass fraction, producers, Dirichlet top at
+    the same value: the tracer equation is then X0 times the water mass balance, so X = X0 to
+    the tolerance the flow step is converged to"""
+    g, lm, osim, y = setup(oracle, dims=(6, 5, 4), brick=(3, 5, 4), lens=False)
+    X0 = 2.0e-3
+    inj = np.where(np.asarray(lm.src_rate) > 0, np.asarray(lm.src_rate) * X0, 0.0)
+    osim.set_tracers([0], bc=np.full(lm.n_bc, X0), injection=inj)
+    X = np.full(lm.n_owned, X0)
+    run_steps(osim, y, X, 3, 2.0e4)
+    assert np.abs(X / X0 - 1.0).max() < 1e-7
+    osim.close()
+
+
+def test_tracer_mass_is_conserved_in_a_closed_box(oracle):
+    """no sources, no boundary: sum_i V_i Al_i X_i is constant while the flow (two-phase lens
+    relaxing under gravity) moves it around; with diffusion on as well"""
+    for method in (0, 1):
+        g, lm, osim, y = setup(oracle, dims=(5, 5, 6), brick=(5, 5, 3), lens=True, sources=False, top_bc=False)
+        osim.set_tracers([0, 1], diffusion=[1e-6, 1e-5])
+        rng = np.random.default_rng(3)
+        X = np.zeros(lm.n_owned * 2)
+        X[0::2] = rng.uniform(0, 1e-3, lm.n_owned)
+        X[1::2] = rng.uniform(0, 1e-3, lm.n_owned)
+        vol = np.asarray(lm.cell_geom).reshape(-1, 4)[: lm.n_owned, 3]
+        assert osim.pre_eval(y) == 0
+        m0 = (osim.tracer_lhs() * X).reshape(-1, 2) * vol[:, None]
+        alx = run_steps(osim, y, X, 4, 1.0e4, method=method)
+        m1 = alx.reshape(-1, 2) * vol[:, None]
+        assert np.all(np.abs(m1.sum(axis=0) - m0.sum(axis=0)) <= 1e-9 * m0.sum(axis=0))
+        # the vapour tracer only lives where there is vapour
+        fl = osim.fluid()[: lm.n_owned]
+        novap = (fl[:, 4].astype(int) & 2) == 0
+        assert np.all(X[1::2][novap] == 0.0)
+        osim.close()
+
+
+def test_upwind_front_in_a_uniform_column_flow(oracle):
+    """1-D column, liquid injected at the bottom with tracer, produced through the Dirichlet top:
+    backward Euler upwinding gives the monotone discrete front 0 <= X <= X_inj, increasing
+    toward the injector, and the tracer in place equals what was injected"""
+    import waiwera_amd.mesh as M
+    g = M.StructuredGrid((1, 1, 12), brick=(1, 1, 12))
+    src = [{"ijk": (0, 0, 11), "rate": 0.5, "enthalpy": 84.0e3, "component": 1}]
+    lm = g.local_mesh(0, top_bc=([1.0e5, 20.0], 1), sources=src)
+    prim, region = M.benchmark_initial_state(g, lm.extras["prim_ijk"], eos="we", lens=False)
+    osim = ol.OracleSim(oracle, lm, 1)
+    osim.set_regions(region)
+    y = osim.yvec(scaled(prim, region).ravel().copy())
+    Xinj = 1.0e-2
+    osim.set_tracers([0], bc=np.zeros(lm.n_bc), injection=np.array([0.5 * Xinj]))
+    X = np.zeros(lm.n_owned)
+    nsteps, dt = 6, 2.0e5
+    alx = run_steps(osim, y, X, nsteps, dt)
+    assert np.all(X >= -1e-15) and np.all(X <= Xinj * (1 + 1e-9))
+    order = np.argsort(np.asarray(lm.cell_geom).reshape(-1, 4)[: lm.n_owned, 2])   # by z: bottom first
+    assert np.all(np.diff(X[order]) <= 1e-12)
+    vol = np.asarray(lm.cell_geom).reshape(-1, 4)[: lm.n_owned, 3]
+    in_place = (alx * vol).sum()
+    injected = 0.5 * Xinj * nsteps * dt
+    assert in_place <= injected * (1 + 1e-9)     # some has left through the top
+    assert in_place > 0.5 * injected
+    osim.close()

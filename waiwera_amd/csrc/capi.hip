@@ -471,7 +471,8 @@ void free_all(wai_ctx* c) {
   F(k.R); F(k.RP); F(k.P); F(k.V); F(k.S); F(k.T); F(k.tmp); F(k.X); F(k.basis); F(k.partials); F(k.scal);
   if (k.h_scal) (void)hipHostFree(k.h_scal);
   F(c->flu); F(c->flu_last_iter); F(c->flu_last_step); F(c->flu_pert); F(c->hstep);
-  F(c->w_y); F(c->w_yold); F(c->w_delta); F(c->w_f); F(c->w_lhs); F(c->w_lhs2); F(c->w_hist); F(c->w_hist_prev); F(c->w_a); F(c->w_b); F(c->w_c);
+  F(c->w_y); F(c->w_yold); F(c->w_delta); F(c->w_f); F(c->w_lhs); F(c->w_lhs2); F(c->w_hist); F(c->w_hist_prev);
+  F(c->tr.bc); F(c->tr.inj); F(c->tr.val); F(c->w_a); F(c->w_b); F(c->w_c);
   F(c->d_flags); F(c->d_red);
   if (c->h_flags) (void)hipHostFree(c->h_flags);
   if (c->h_red) (void)hipHostFree(c->h_red);
@@ -1102,6 +1103,173 @@ int wai_ksp_solve(wai_ctx* c, const double* b, double* x, int* its, int* reason,
   if (bi.in(b, c->ks.n, 0) || xo.out_only(x, c->ks.n, 1)) return -1;
   if (do_ksp(c, bi.dev, xo.dev, its, reason, rnorm)) return -1;
   return xo.back();
+}
+
+// ---- passive tracers: the auxiliary linear problem -------------------------------------------
+int wai_set_tracers(wai_ctx* c, int n, const int* phase, const double* decay, const double* activation,
+                    const double* diffusion) {
+  if (!c || n < 0 || (n > 0 && !phase)) return -2;
+  if (n > wai::MAX_TRACERS) { c->err = "too many tracers (at most 8)"; return -1; }
+  const int nmob = c->kind == WAI_EOS_W ? 1 : 2;
+  Tracers& t = c->tr;
+  for (int i = 0; i < n; i++) {
+    if (phase[i] < 0 || phase[i] >= nmob) { c->err = "tracer phase index out of range"; return -1; }
+    t.phase[i] = phase[i];
+    t.decay[i] = decay ? decay[i] : 0.0;
+    t.activation[i] = activation ? activation[i] : 0.0;
+    t.diffusion[i] = diffusion ? diffusion[i] : 0.0;
+  }
+  t.nt = n;
+  auto F = [](double*& p) { if (p) (void)hipFree(p); p = nullptr; };
+  F(t.bc); F(t.inj); F(t.val);
+  if (n == 0) return 0;
+  const size_t nbc = (size_t)std::max(c->mesh.n_bc, 1) * n, nsrc = (size_t)std::max(c->src.n, 1) * n;
+  if (dev_alloc(c, &t.bc, nbc) || dev_alloc(c, &t.inj, nsrc) ||
+      dev_alloc(c, &t.val, (size_t)c->J.W * c->J.n))
+    return -1;
+  HIPCHK(c, hipMemset(t.bc, 0, nbc * sizeof(double)));
+  HIPCHK(c, hipMemset(t.inj, 0, nsrc * sizeof(double)));
+  return 0;
+}
+
+int wai_set_tracer_bc(wai_ctx* c, const double* x_bc) {
+  if (!c || !x_bc) return -2;
+  if (!c->tr.nt) { c->err = "no tracers set"; return -1; }
+  if (c->mesh.n_bc)
+    HIPCHK(c, hipMemcpy(c->tr.bc, x_bc, sizeof(double) * (size_t)c->mesh.n_bc * c->tr.nt, hipMemcpyDefault));
+  return 0;
+}
+
+int wai_set_tracer_injection(wai_ctx* c, const double* rate) {
+  if (!c || !rate) return -2;
+  if (!c->tr.nt) { c->err = "no tracers set"; return -1; }
+  // sized by the sources in force now: wai_set_sources first
+  if (c->tr.inj) (void)hipFree(c->tr.inj);
+  c->tr.inj = nullptr;
+  const size_t nsrc = (size_t)std::max(c->src.n, 1) * c->tr.nt;
+  if (dev_alloc(c, &c->tr.inj, nsrc)) return -1;
+  HIPCHK(c, hipMemset(c->tr.inj, 0, nsrc * sizeof(double)));
+  if (c->src.n)
+    HIPCHK(c, hipMemcpy(c->tr.inj, rate, sizeof(double) * (size_t)c->src.n * c->tr.nt, hipMemcpyDefault));
+  return 0;
+}
+
+int wai_set_aux_solver(wai_ctx* c, int ksp_type, int gmres_restart, double rtol, double atol, int max_its) {
+  if (!c) return -2;
+  if (ksp_type != WAI_KSP_BCGS && ksp_type != WAI_KSP_GMRES) { c->err = "unknown KSP type"; return -1; }
+  c->tr.ksp_type = ksp_type;
+  if (gmres_restart > 0) c->tr.restart = gmres_restart;
+  if (rtol > 0.0) c->tr.rtol = rtol;
+  if (atol > 0.0) c->tr.atol = atol;
+  if (max_its > 0) c->tr.max_its = max_its;
+  return 0;
+}
+
+int wai_tracer_lhs(wai_ctx* c, double* Al) {
+  if (!c || !Al) return -2;
+  if (!c->tr.nt) { c->err = "no tracers set"; return -1; }
+  VecArg o{c};
+  if (o.out_only(Al, (size_t)c->mesh.n_owned * c->tr.nt, 0)) return -1;
+  launch_tracer_lhs(c, o.dev);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return o.back();
+}
+
+namespace {
+// The Krylov drivers work on c->J / c->ilu / c->ks / c->np; for the scalar tracer systems those
+// are pointed at the auxiliary matrix (same sparsity, block size 1) for the scope's lifetime.
+struct AuxScope {
+  wai_ctx* c;
+  int np, n, nl, bs, ksp_type, restart, max_its;
+  double* val; double rtol, atol;
+  explicit AuxScope(wai_ctx* c_) : c(c_) {
+    np = c->np; n = c->ks.n; nl = c->ks.nl; bs = c->J.bs; val = c->J.val;
+    ksp_type = c->opts.ksp_type; restart = c->opts.gmres_restart; max_its = c->opts.ksp_max_its;
+    rtol = c->opts.ksp_rtol; atol = c->opts.ksp_atol;
+    c->np = 1; c->ks.n = c->mesh.n_owned; c->ks.nl = c->mesh.n_prim; c->J.bs = 1; c->J.val = c->tr.val;
+    c->opts.ksp_type = c->tr.ksp_type; c->opts.gmres_restart = c->tr.restart;
+    c->opts.ksp_max_its = c->tr.max_its; c->opts.ksp_rtol = c->tr.rtol; c->opts.ksp_atol = c->tr.atol;
+    c->ilu.factored = false;
+  }
+  ~AuxScope() {
+    c->np = np; c->ks.n = n; c->ks.nl = nl; c->J.bs = bs; c->J.val = val;
+    c->opts.ksp_type = ksp_type; c->opts.gmres_restart = restart; c->opts.ksp_max_its = max_its;
+    c->opts.ksp_rtol = rtol; c->opts.ksp_atol = atol;
+    c->ilu.factored = false;  // the factor buffers now hold a tracer system's factor
+  }
+};
+}  // namespace
+
+int wai_tracer_system(wai_ctx* c, int tracer, int method, double dt, double ratio, const double* alx_last,
+                      const double* alx_last2, double* val, double* b) {
+  if (!c || !val || !b) return -2;
+  Tracers& t = c->tr;
+  if (tracer < 0 || tracer >= t.nt) { c->err = "tracer index out of range"; return -1; }
+  if (method < WAI_METHOD_BEULER || method > WAI_METHOD_DIRECTSS) { c->err = "unknown time stepping method"; return -1; }
+  if (method != WAI_METHOD_DIRECTSS && !alx_last) return -2;
+  if (method == WAI_METHOD_BDF2 && !alx_last2) return -2;
+  const size_t nx = (size_t)c->mesh.n_owned * t.nt;
+  VecArg a1{c}, a2{c};
+  if (a1.in(alx_last, nx, 0) || a2.in(alx_last2, nx, 1)) return -1;
+  TracerForm tf;
+  tf.method = method; tf.it = tracer; tf.nt = t.nt; tf.phase = t.phase[tracer];
+  tf.dt = dt; tf.ratio = ratio; tf.decay = t.decay[tracer]; tf.activation = t.activation[tracer];
+  tf.diffusion = t.diffusion[tracer];
+  if (launch_tracer_assemble(c, tf, a1.dev, a2.dev, c->w_a)) return -1;
+  double* tmp = c->stage[2];  // nnzb scalars fit the staging buffer (>= 23 doubles per cell)
+  {
+    AuxScope scope(c);
+    launch_ell_to_bcsr(c, c->J.val, tmp);
+  }
+  HIPCHK(c, hipMemcpyAsync(val, tmp, sizeof(double) * c->J.nnzb, hipMemcpyDefault, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b, c->w_a, sizeof(double) * c->mesh.n_owned, hipMemcpyDefault, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int wai_tracer_solve(wai_ctx* c, int method, double dt, double ratio, const double* alx_last,
+                     const double* alx_last2, double* X, double* alx_new, int* its, int* reason) {
+  if (!c || !X || !alx_new || !its || !reason) return -2;
+  Tracers& t = c->tr;
+  if (!t.nt) { c->err = "no tracers set"; return -1; }
+  if (method < WAI_METHOD_BEULER || method > WAI_METHOD_DIRECTSS) { c->err = "unknown time stepping method"; return -1; }
+  if (method != WAI_METHOD_DIRECTSS && !alx_last) return -2;
+  if (method == WAI_METHOD_BDF2 && (!alx_last2 || !(ratio > 0.0))) { c->err = "BDF2 needs a step size ratio > 0 and Al o X two steps back"; return -1; }
+  const size_t nx = (size_t)c->mesh.n_owned * t.nt;
+  VecArg a1{c}, a2{c}, xx{c}, an{c};
+  if (a1.in(alx_last, nx, 0) || a2.in(alx_last2, nx, 1) || xx.in(X, nx, 2) || an.out_only(alx_new, nx, 3)) return -1;
+  *its = 0;
+  *reason = 100;
+  int rc = 0;
+  if (t.ksp_type == WAI_KSP_GMRES && !c->ks.basis) {  // the flow solver may never have needed one
+    if (dev_alloc(c, &c->ks.basis, (size_t)(c->ks.basis_m + 1) * c->ks.nl)) return -1;
+    HIPCHK(c, hipMemset(c->ks.basis, 0, (size_t)(c->ks.basis_m + 1) * c->ks.nl * sizeof(double)));
+  }
+  {
+    AuxScope scope(c);
+    double* b = c->w_a;
+    double* x = c->w_c;
+    for (int it = 0; it < t.nt && !rc; it++) {
+      TracerForm tf;
+      tf.method = method; tf.it = it; tf.nt = t.nt; tf.phase = t.phase[it];
+      tf.dt = dt; tf.ratio = ratio; tf.decay = t.decay[it]; tf.activation = t.activation[it];
+      tf.diffusion = t.diffusion[it];
+      if (launch_tracer_assemble(c, tf, a1.dev, a2.dev, b)) { rc = -1; break; }
+      c->ilu.factored = false;
+      int k = 0, r = 0;
+      double rn = 0.0;
+      vec_zero(c, x, c->ks.n);  // a failed factorisation returns before the solver zeroes it
+      if (do_ksp(c, b, x, &k, &r, &rn)) { rc = -1; break; }
+      *its += k;
+      if (r < *reason) *reason = r;
+      launch_tracer_put(c, x, it, xx.dev);
+    }
+  }
+  if (rc) return rc;
+  launch_tracer_alx(c, xx.dev, an.dev);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (xx.back() || an.back()) return -1;
+  return 0;
 }
 
 int wai_max_scaled(wai_ctx* c, const double* v, const double* scale, double tol, double* val, int* idx) {

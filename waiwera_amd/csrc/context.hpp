@@ -74,6 +74,26 @@ struct ResForm {
   const double* last2 = nullptr;  // BDF2: lhs one step further back
 };
 
+// Passive tracers (src/tracer.F90:30-40) and the auxiliary linear problem's solver settings
+// (timestepper.F90:2021-2022, 2061-2064: gmres + bjacobi unless configured)
+constexpr int MAX_TRACERS = 8;
+struct Tracers {
+  int nt = 0;
+  int phase[MAX_TRACERS] = {0};
+  double decay[MAX_TRACERS] = {0}, activation[MAX_TRACERS] = {0}, diffusion[MAX_TRACERS] = {0};
+  double* bc = nullptr;    // [n_bc][nt] Dirichlet mass fractions
+  double* inj = nullptr;   // [n_sources][nt] injection rates
+  double* val = nullptr;   // scalar block-ELL values of the system being solved, W x n
+  int ksp_type = 1, restart = 30, max_its = 10000;
+  double rtol = 1.e-5, atol = 1.e-50;
+};
+
+// one tracer's system: which tracer, and the method's combination (timestepper.F90:458-581)
+struct TracerForm {
+  int method, it, nt, phase;
+  double dt, ratio, decay, activation, diffusion;
+};
+
 struct Krylov {
   int n = 0, nl = 0;           // bs*n_owned, bs*n_prim
   double *R = nullptr, *RP = nullptr, *P = nullptr, *V = nullptr, *S = nullptr, *T = nullptr,
@@ -100,6 +120,7 @@ struct wai_ctx {
   wai::Bcsr J;
   wai::IluSchedule ilu;
   wai::Krylov ks;
+  wai::Tracers tr;
   // fluid state, SoA df x n_local each; perturbed states np x df x n_prim
   double *flu = nullptr, *flu_last_iter = nullptr, *flu_last_step = nullptr, *flu_pert = nullptr;
   double* hstep = nullptr;      // FD steps np x n_prim (interleaved like y)
@@ -148,6 +169,14 @@ int launch_residual(wai_ctx* c, double dt, const double* lhs_old, double* f, dou
                     double* rhs_out);
 int launch_jacobian(wai_ctx* c, double dt, const double* lhs_old);
 int launch_transitions(wai_ctx* c, const double* y_old, double* search, double* y);
+// tracer system of tf.it on the flow Jacobian's pattern: values -> c->tr.val, rhs -> b
+int launch_tracer_assemble(wai_ctx* c, const TracerForm& tf, const double* alx_last,
+                           const double* alx_last2, double* b);
+int launch_tracer_lhs(wai_ctx* c, double* Al);
+// X[cell][nt] <-> x[cell] of tracer it; alx = Al o X
+int launch_tracer_pick(wai_ctx* c, const double* X, int it, double* x);
+int launch_tracer_put(wai_ctx* c, const double* x, int it, double* X);
+int launch_tracer_alx(wai_ctx* c, const double* X, double* alx);
 int launch_max_scaled(wai_ctx* c, const double* v, const double* scale, double tol, double* val,
                       int* idx);
 int launch_fluid_aos(wai_ctx* c, const double* flu_soa, double* out_aos);

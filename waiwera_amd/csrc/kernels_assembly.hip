@@ -318,6 +318,160 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
   }
 }
 
+// ---- tracers: the auxiliary linear problem ------------------------------------------------------
+// One scalar system per tracer on the flow Jacobian's sparsity, one thread per owned cell (row):
+// aux_lhs (flow_simulation.F90:1489-1556), aux_rhs (:1560-1833: advection with the phase flux,
+// upstream by its sign; diffusion with the harmonic porosity*density*saturation factor;
+// production / injection; Arrhenius decay), the method's setup_linear (timestepper.F90:458-581)
+// and aux_pre_solve (:1837-1959) fused.  The phase fluxes are recomputed from the converged
+// fluid state rather than read from a flux store.  Dirichlet boundary cells are
+// eliminated into the right-hand side.
+template <int KIND>
+__device__ __forceinline__ double tracer_coef(const CellState<KIND>& s, const RockState& r, int p) {
+  double sat = 0.0, rho = 0.0;
+#pragma unroll
+  for (int q = 0; q < EosT<KIND>::nph; q++)
+    if (q == p) { sat = s.sat[q]; rho = s.rho[q]; }
+  return r.phi * sat * rho;  // cell_tracer_balance_coefs, cell.F90:146-164
+}
+
+template <int KIND>
+__global__ __launch_bounds__(TPB) void k_tracer_assemble(MeshView m, const double* __restrict__ flu,
+                                                         size_t stride, TracerForm tf, int n_prim, int W,
+                                                         const double* __restrict__ alx1,
+                                                         const double* __restrict__ alx2,
+                                                         const double* __restrict__ xbc,
+                                                         const double* __restrict__ inj,
+                                                         double* __restrict__ aval,
+                                                         double* __restrict__ b) {
+  using E = EosT<KIND>;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= m.n_owned) return;
+  const int p = tf.phase;
+  CellState<KIND> own;
+  RockState rown;
+  load_state<KIND>(flu, stride, c, own);
+  load_rock(m.rock, m.n_local, c, rown);
+  const double vol = m.vol[c];
+  const int dslot = m.diag_blk[c];
+  double row[MAXDEG];  // Ar by ELL slot
+#pragma unroll
+  for (int q = 0; q < MAXDEG; q++) row[q] = 0.0;
+  double diag = 0.0, br = 0.0;
+  const double cf_own = tracer_coef<KIND>(own, rown, p);  // cell_diffusion_factor: the same product
+  for (int s = 0; s < m.max_deg; s++) {
+    const int fs = m.adj_face[(size_t)s * m.n_owned + c];
+    if (fs < 0) continue;
+    const int o = m.adj_other[(size_t)s * m.n_owned + c];
+    const int blk = m.adj_blk[(size_t)s * m.n_owned + c];
+    const int side = fs & 1;
+    FaceGeom g;
+    load_face(m, fs >> 1, g);
+    CellState<KIND> oth;
+    RockState roth;
+    load_state<KIND>(flu, stride, o, oth);
+    load_rock(m.rock, m.n_local, o, roth);
+    const double pf = side == 0 ? face_phase_flux<KIND>(g, own, rown, oth, roth, p)
+                                : face_phase_flux<KIND>(g, oth, roth, own, rown, p);
+    const double sign = side ? 1.0 : -1.0;
+    // advective: at the upstream cell's column (phase flux >= 0: the face's first cell)
+    const bool up_is_own = (pf >= 0.0) == (side == 0);
+    const double fa = sign * (pf * g.area) / vol;
+    // diffusive: face_diffusion_factor (face.F90:519-536), cell factors porosity*density*saturation
+    const double cf_oth = tracer_coef<KIND>(oth, roth, p);
+    const double dfac = side == 0 ? harmonic(g, cf_own, cf_oth) : harmonic(g, cf_oth, cf_own);
+    const double fd = g.area * dfac * tf.diffusion / (g.d12 * vol);
+    double to_own = -fd, to_oth = fd;
+    if (up_is_own) to_own += fa; else to_oth += fa;
+    diag += to_own;
+    if (blk >= 0) {
+#pragma unroll
+      for (int q = 0; q < MAXDEG; q++) row[q] += (q == blk) ? to_oth : 0.0;
+    } else {
+      br += to_oth * xbc[(size_t)(o - n_prim) * tf.nt + tf.it];
+    }
+  }
+  // sources (tracer_source_iterator, flow_simulation.F90:1722-1772)
+  for (int si = m.cell_src[c]; si >= 0; si = m.src_next[si]) {
+    const double rate = m.src_rate[si];
+    const int comp = m.src_comp[si];
+    const int component = rate > 0.0 ? (comp <= 0 ? 1 : comp) : (comp <= 0 ? 0 : comp);
+    if (!(component < E::np)) continue;
+    if (rate < 0.0) {
+      const int ph = (int)own.phases;
+      double frac = 0.0, sum = 0.0;
+#pragma unroll
+      for (int q = 0; q < E::nph; q++)
+        if (ph & (1 << q)) {
+          const double mob = own.kr[q] * own.rho[q] / own.mu[q];
+          sum += mob;
+          if (q == p) frac = mob;
+        }
+      diag += (frac / sum) * rate / vol;
+    } else {
+      br += inj[(size_t)si * tf.nt + tf.it] / vol;
+    }
+  }
+  const double al = tracer_coef<KIND>(own, rown, p);
+  // apply_tracer_decay (:1776-1831), tracer_decay (tracer.F90:48-61)
+  diag += -(tf.decay * exp(-tf.activation / (8.3144598 * (own.T + 273.15)))) * al;
+  // setup_linear: A = cA Ar + cL Al, b from the history
+  const double r = tf.ratio, r1 = r + 1.0;
+  const double cA = tf.method == WAI_METHOD_DIRECTSS ? 1.0 : (tf.method == WAI_METHOD_BDF2 ? -tf.dt * r1 : -tf.dt);
+  const size_t ix = (size_t)c * tf.nt + tf.it;
+  // direct steady state: A = Ar, b = -br.  (Initialised here and overwritten below: leaving it
+  // uninitialised with a trailing `else rhs = -br` came out of hipcc 7.2 -O3 as rhs = r1.)
+  double rhs = -br;
+  diag *= cA;
+  if (tf.method == WAI_METHOD_BEULER) {
+    diag += al;
+    rhs = alx1[ix] + tf.dt * br;
+  } else if (tf.method == WAI_METHOD_BDF2) {
+    diag += al * (1.0 + 2.0 * r);
+    rhs = (alx1[ix] * (r1 * r1) + (-r * r) * alx2[ix]) + (tf.dt * r1) * br;
+  }
+  // aux_pre_solve: phase absent -> identity row, zero right-hand side
+  const bool absent = !(((int)own.phases) & (1 << p));
+  const size_t n = m.n_owned;
+#pragma unroll
+  for (int q = 0; q < MAXDEG; q++) {
+    if (q < W) {
+      double v = (q == dslot) ? diag : cA * row[q];
+      if (absent) v = (q == dslot) ? 1.0 : 0.0;
+      aval[(size_t)q * n + c] = v;
+    }
+  }
+  b[c] = absent ? 0.0 : rhs;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(TPB) void k_tracer_lhs(MeshView m, const double* __restrict__ flu, size_t stride,
+                                                    Tracers tr, double* __restrict__ Al) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= m.n_owned) return;
+  CellState<KIND> own;
+  RockState rown;
+  load_state<KIND>(flu, stride, c, own);
+  load_rock(m.rock, m.n_local, c, rown);
+  for (int it = 0; it < tr.nt; it++) Al[(size_t)c * tr.nt + it] = tracer_coef<KIND>(own, rown, tr.phase[it]);
+}
+
+__global__ __launch_bounds__(TPB) void k_tracer_pick(const double* __restrict__ X, int n, int nt, int it,
+                                                     double* __restrict__ x) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n) x[c] = X[(size_t)c * nt + it];
+}
+__global__ __launch_bounds__(TPB) void k_tracer_put(const double* __restrict__ x, int n, int nt, int it,
+                                                    double* __restrict__ X) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n) X[(size_t)c * nt + it] = x[c];
+}
+__global__ __launch_bounds__(TPB) void k_tracer_alx(const double* __restrict__ Al, const double* __restrict__ X,
+                                                    size_t n, double* __restrict__ alx) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) alx[i] = Al[i] * X[i];
+}
+
 // ---- K11: transitions ------------------------------------------------------------------------
 template <int KIND>
 __global__ __launch_bounds__(TPB) void k_transitions(EosParams ep, int n_owned,
@@ -476,6 +630,38 @@ int launch_jacobian(wai_ctx* c, double dt, const double* lhs_old) {
   hipMemsetAsync(c->J.val, 0, sizeof(double) * (size_t)c->J.W * c->np * c->np * c->J.n, c->stream);
   WAI_BY_EOS(c, k_jacobian, grid_for(m.n_owned), m, c->flu, stride, c->flu_pert, c->hstep, c->mesh.n_prim,
              res_form_of(c, dt, lhs_old), c->J.val);
+  return 0;
+}
+
+int launch_tracer_assemble(wai_ctx* c, const TracerForm& tf, const double* alx_last,
+                           const double* alx_last2, double* b) {
+  const MeshView m = view(c);
+  if (m.max_deg > MAXDEG || c->J.W > MAXDEG) { c->err = "cell with more than 8 faces not supported"; return -1; }
+  WAI_BY_EOS(c, k_tracer_assemble, grid_for(m.n_owned), m, c->flu, (size_t)c->mesh.n_local, tf,
+             c->mesh.n_prim, c->J.W, alx_last, alx_last2, c->tr.bc, c->tr.inj, c->tr.val, b);
+  return 0;
+}
+
+int launch_tracer_lhs(wai_ctx* c, double* Al) {
+  const MeshView m = view(c);
+  WAI_BY_EOS(c, k_tracer_lhs, grid_for(m.n_owned), m, c->flu, (size_t)c->mesh.n_local, c->tr, Al);
+  return 0;
+}
+
+int launch_tracer_pick(wai_ctx* c, const double* X, int it, double* x) {
+  const int n = c->mesh.n_owned;
+  hipLaunchKernelGGL(k_tracer_pick, grid_for(n), TPB, 0, c->stream, X, n, c->tr.nt, it, x);
+  return 0;
+}
+int launch_tracer_put(wai_ctx* c, const double* x, int it, double* X) {
+  const int n = c->mesh.n_owned;
+  hipLaunchKernelGGL(k_tracer_put, grid_for(n), TPB, 0, c->stream, x, n, c->tr.nt, it, X);
+  return 0;
+}
+int launch_tracer_alx(wai_ctx* c, const double* X, double* alx) {
+  const size_t n = (size_t)c->mesh.n_owned * c->tr.nt;
+  launch_tracer_lhs(c, alx);  // Al of the current fluid, multiplied in place
+  hipLaunchKernelGGL(k_tracer_alx, grid_for(n), TPB, 0, c->stream, alx, X, n, alx);
   return 0;
 }
 

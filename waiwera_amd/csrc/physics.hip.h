@@ -453,6 +453,39 @@ __device__ __forceinline__ void face_flux(const FaceGeom& g, const CellState<KIN
   }
 }
 
+// phase flux of mobile phase p through a face (the entries np+1.. of the reference's flux
+// store, face.F90:505-507, flow_simulation.F90:156-205), same arithmetic as face_flux
+template <int KIND>
+__device__ __forceinline__ double face_phase_flux(const FaceGeom& g, const CellState<KIND>& a,
+                                                  const RockState& ra, const CellState<KIND>& b,
+                                                  const RockState& rb, int p) {
+  using E = EosT<KIND>;
+  const int d = g.dir - 1;
+  const double ka = (d == 0) ? ra.k[0] : (d == 1 ? ra.k[1] : ra.k[2]);
+  const double kb = (d == 0) ? rb.k[0] : (d == 1 ? rb.k[1] : rb.k[2]);
+  const double k = harmonic(g, ka * a.permfac, kb * b.permfac);
+  const int pa = (int)a.phases, pb = (int)b.phases, present = pa | pb;
+  double out = 0.0;
+#pragma unroll
+  for (int q = 0; q < E::nmob; q++) {
+    if (q != p || !(present & (1 << q))) continue;
+    const double rho_f = (a.sat[q] * a.rho[q] + b.sat[q] * b.rho[q]) / (a.sat[q] + b.sat[q]);
+    const double dpdn = ((b.P + b.pc[q]) - (a.P + a.pc[q])) / g.d12;
+    const double G = dpdn - rho_f * g.gn;
+    const bool up1 = (G <= 0.0);
+    const int phup = up1 ? pa : pb;
+    if (!(phup & (1 << q))) continue;
+    const double kr = up1 ? a.kr[q] : b.kr[q], rho = up1 ? a.rho[q] : b.rho[q];
+    const double mu = up1 ? a.mu[q] : b.mu[q];
+    const double F = -k * (kr * rho / mu) * G;
+    double sum = 0.0;
+#pragma unroll
+    for (int c = 0; c < E::nc; c++) sum += F * (up1 ? a.x[q][c] : b.x[q][c]);
+    out = sum;
+  }
+  return out;
+}
+
 // source term (source.F90:386-480, fluid.F90:377-453): flow[np] for one source
 template <int KIND>
 __device__ __forceinline__ void source_flow(const CellState<KIND>& s, double rate, double enth,

@@ -46,6 +46,7 @@ class FlowSimulation:
         self.fluid_dof = LIB.wai_num_fluid_dof(h)
         self.n_owned, self.n_prim, self.n_local = mesh.n_owned, mesh.n_prim, mesh.n_local
         self.num_dof = self.n_owned * self.num_primary_variables
+        self.num_tracers, self.auxiliary = 0, False
         self.time = 0.0
         if mesh.n_bc:
             bp, br = _lib._f64(mesh.bc_primary), _lib._i32(mesh.bc_region)
@@ -221,6 +222,52 @@ class FlowSimulation:
         n, k, r = C.c_int(0), C.c_int(0), C.c_int(0)
         self._chk(LIB.wai_timestep(self.h, t, dt, _lib.ptr(y), C.byref(n), C.byref(k), C.byref(r)), "timestep")
         return r.value, n.value, k.value
+
+    # ---- tracers: the auxiliary linear problem (ode_type aux_lhs / aux_rhs / aux_pre_solve) ------
+    def set_tracers(self, phase, decay=None, activation=None, diffusion=None, bc=None, injection=None):
+        """Passive tracers (src/tracer.F90:30-40): 0-based phase index, decay constant, activation
+        energy, diffusion coefficient per tracer; bc [n_bc][nt] Dirichlet mass fractions, injection
+        [n_sources][nt] tracer injection rates."""
+        nt = len(phase)
+        ph = np.ascontiguousarray(phase, dtype=np.int32)
+
+        def arr(a):
+            return _lib._f64(np.zeros(nt) if a is None else np.asarray(a, dtype=np.float64))
+        dc, ac, df = arr(decay), arr(activation), arr(diffusion)
+        self._chk(LIB.wai_set_tracers(self.h, nt, ph.ctypes.data_as(C.POINTER(C.c_int)),
+                                      dc.ctypes.data_as(C.POINTER(C.c_double)),
+                                      ac.ctypes.data_as(C.POINTER(C.c_double)),
+                                      df.ctypes.data_as(C.POINTER(C.c_double))), "set_tracers")
+        self.num_tracers = nt
+        self.auxiliary = nt > 0
+        if bc is not None:
+            self._chk(LIB.wai_set_tracer_bc(self.h, _lib.ptr(_lib._f64(np.asarray(bc, dtype=np.float64)))), "set_tracer_bc")
+        if injection is not None:
+            self._chk(LIB.wai_set_tracer_injection(self.h, _lib.ptr(_lib._f64(np.asarray(injection, dtype=np.float64)))),
+                      "set_tracer_injection")
+
+    def set_aux_solver(self, ksp_type="gmres", restart=30, rtol=1e-5, atol=1e-50, max_its=10000):
+        return self._chk(LIB.wai_set_aux_solver(self.h, {"bcgs": 0, "gmres": 1}[ksp_type], restart, rtol, atol,
+                                                max_its), "set_aux_solver")
+
+    def aux_lhs(self, t, interval, Al):
+        return self._chk(LIB.wai_tracer_lhs(self.h, _lib.ptr(Al)), "tracer_lhs")
+
+    def aux_system(self, tracer, method, dt, ratio, alx_last, alx_last2):
+        """(scalar CSR values on setup_jacobian()'s pattern, rhs) of one tracer's system"""
+        nnzb = LIB.wai_jacobian_nnzb(self.h)
+        val, b = np.zeros(nnzb), np.zeros(self.n_owned)
+        self._chk(LIB.wai_tracer_system(self.h, tracer, _lib.METHOD_KIND[method], dt, ratio, _lib.ptr(alx_last),
+                                        _lib.ptr(alx_last2), val.ctypes.data, b.ctypes.data), "tracer_system")
+        return val, b
+
+    def aux_solve(self, method, dt, ratio, alx_last, alx_last2, X, alx_new):
+        """setup_linear + aux_pre_solve + KSPSolve (timestepper.F90:2345-2355); (reason, its)"""
+        its, reason = C.c_int(0), C.c_int(0)
+        self._chk(LIB.wai_tracer_solve(self.h, _lib.METHOD_KIND[method], dt, ratio, _lib.ptr(alx_last),
+                                       _lib.ptr(alx_last2), _lib.ptr(X), _lib.ptr(alx_new), C.byref(its),
+                                       C.byref(reason)), "tracer_solve")
+        return reason.value, its.value
 
     # ---- measurement ---------------------------------------------------------------------------
     def timer_start(self):

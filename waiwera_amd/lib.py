@@ -96,6 +96,13 @@ def _load():
         "wai_max_scaled": (i32, [vp, vp, vp, d, pd, pi]),
         "wai_newton_step": (i32, [vp, d, d, i32, vp, vp, vp, pi, pi, pd]),
         "wai_timestep": (i32, [vp, d, d, vp, pi, pi, pi]),
+        "wai_set_tracers": (i32, [vp, i32, pi, pd, pd, pd]),
+        "wai_set_tracer_bc": (i32, [vp, vp]),
+        "wai_set_tracer_injection": (i32, [vp, vp]),
+        "wai_set_aux_solver": (i32, [vp, i32, i32, d, d, i32]),
+        "wai_tracer_lhs": (i32, [vp, vp]),
+        "wai_tracer_system": (i32, [vp, i32, i32, d, d, vp, vp, vp, vp]),
+        "wai_tracer_solve": (i32, [vp, i32, d, d, vp, vp, vp, vp, pi, pi]),
         "wai_timer_start": (i32, [vp]),
         "wai_timer_stop": (i32, [vp, C.POINTER(C.c_float)]),
         "wai_synchronize": (i32, [vp]),

@@ -334,6 +334,8 @@ class StructuredGrid:
             m.bc_primary = np.tile(np.asarray(prim, dtype=np.float64), (nb, 1))
             m.bc_region = np.full(nb, int(region), dtype=np.int32)
         m.n_bc = bc_cells.size
+        fc = [a for a in fc if a.shape[0]] or [np.zeros((0, 2), dtype=np.int64)]
+        fg = [a for a in fg if a.shape[0]] or [np.zeros((0, 12))]
         m.face_cells = np.concatenate(fc).astype(np.int32)
         m.face_geom = np.concatenate(fg)
         m.n_faces = m.face_cells.shape[0]

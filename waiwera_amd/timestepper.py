@@ -13,13 +13,17 @@ What drives the hot path the way the reference drives it (src/timestepper.F90):
 * the methods "beuler" | "bdf2" | "directss" (:2262-2275): the residual form lives in the HIP
   kernels (`FlowSimulation.set_timestep_method`), the history is kept by `wai_timestep`.
 
-Checkpoints, output and the auxiliary (tracer) linear solve stay out of scope.
+* the auxiliary (tracer) linear problem after a converged nonlinear solve (:2345-2355) with the
+  method's setup_linear history (Al o X one and two steps back, :458-557) kept here like
+  `timestepper_steps_type` keeps it; a failed auxiliary solve retries the step (:1348-1350).
+
+Checkpoints and output scheduling stay out of scope.
 """
 
 # step status, timestepper.F90:40-42
-OK, NOT_CONVERGED, TOO_SMALL, TOO_BIG, ABORTED, FINAL = 0, 1, 2, 3, 4, 5
+OK, NOT_CONVERGED, TOO_SMALL, TOO_BIG, ABORTED, FINAL, AUX_NOT_CONVERGED = 0, 1, 2, 3, 4, 5, 6
 STATUS_STR = {OK: "OK", NOT_CONVERGED: "not converged", TOO_SMALL: "increase", TOO_BIG: "reduce",
-              ABORTED: "aborted", FINAL: "final"}
+              ABORTED: "aborted", FINAL: "final", AUX_NOT_CONVERGED: "aux not converged"}
 
 
 class StepFailed(RuntimeError):
@@ -57,7 +61,7 @@ class Timestepper:
     def __init__(self, ode, y, time=0.0, stepsize=0.1, method="beuler", adapt=False,
                  adapt_method="iteration", adapt_min=5.0, adapt_max=8.0, reduction=0.2,
                  amplification=2.0, max_stepsize=0.0, max_num_tries=10, stop_time=None,
-                 max_num_steps=100, stop_min_stepsize=-1.0, stop_max_stepsize=-1.0):
+                 max_num_steps=100, stop_min_stepsize=-1.0, stop_max_stepsize=-1.0, aux_solution=None):
         self.ode = ode
         self.y = y              # numpy array or torch tensor, scaled primaries, in/out
         self.time = time
@@ -80,6 +84,12 @@ class Timestepper:
         self.status = OK
         self.history = []       # (time, stepsize, newton its, krylov its, tries)
         self._last_lhs = None
+        # auxiliary problem: solution [cell][tracer] and Al o X one / two steps back
+        self.aux_solution = aux_solution
+        self.auxiliary = bool(getattr(ode, "auxiliary", False)) and aux_solution is not None
+        self._alx = [None, None]
+        self._last_stepsize = None
+        self.aux_history = []   # (aux KSP reason, iterations) per accepted step
         if hasattr(ode, "set_timestep_method"):
             ode.set_timestep_method(method)
         elif method != "beuler":
@@ -132,8 +142,14 @@ class Timestepper:
         self.ode.lhs(self.time, None, self.y, out)
         return out
 
-    def _set_status(self, converged, nits, tries):
+    def _set_status(self, converged, nits, tries, converged_aux=True):
         """set_current_status (:1304-1375)."""
+        if converged and not converged_aux and not self.steady_state:
+            if tries >= self.max_num_tries:
+                self.status, self.finished = ABORTED, True
+            else:
+                self.status, self.finished = AUX_NOT_CONVERGED, False
+            return
         if self.steady_state:
             self.status = FINAL if converged else ABORTED
             self.finished = True
@@ -163,7 +179,7 @@ class Timestepper:
         """adapt (:1457-1476): (accepted, next step size)."""
         if self.status == TOO_SMALL:
             return True, self.adaptor.increase(stepsize)
-        if self.status in (TOO_BIG, NOT_CONVERGED):
+        if self.status in (TOO_BIG, NOT_CONVERGED, AUX_NOT_CONVERGED):
             return False, self.adaptor.reduce(stepsize)
         return True, stepsize
 
@@ -189,7 +205,7 @@ class Timestepper:
                 if nxt >= self.sizes[self.fixed_step_index - 1]:
                     self.adaptor.on = False  # back to the fixed sizes
                     nxt = self.sizes[self.fixed_step_index - 1]
-        elif self.status in (TOO_BIG, NOT_CONVERGED):
+        elif self.status in (TOO_BIG, NOT_CONVERGED, AUX_NOT_CONVERGED):
             self.adaptor.on = True           # temporarily adaptive
             accepted, nxt = self._adapt(stepsize)
         else:
@@ -216,8 +232,11 @@ class Timestepper:
                 self.y[...] = y_start
             stepsize = self._check_finished(self.next_stepsize)
             reason, nits, kits = ode.timestep(self.time + stepsize, stepsize, self.y)
+            aux = None
+            if self.auxiliary and reason > 0:
+                aux = self._aux_solve(stepsize)
             tries += 1
-            self._set_status(reason > 0, nits, tries)
+            self._set_status(reason > 0, nits, tries, aux is None or aux[0] >= 0)
             accepted = self._set_next_stepsize(stepsize)
         if self.status == ABORTED:
             raise StepFailed("time step aborted after %d tries" % tries)
@@ -225,9 +244,41 @@ class Timestepper:
         if not self.steady_state:
             self.time += stepsize
         self.history.append((self.time, stepsize, nits, kits, tries))
+        if aux is not None:     # the accepted try's auxiliary solution becomes the state
+            self.aux_solution[...] = aux[2]
+            self._alx = [aux[3], self._alx[0]]
+            self.aux_history.append(aux[:2])
+        self._last_stepsize = stepsize
         ode.time = self.time
         ode.post_timestep()
         return nits, kits
+
+    def _aux_solve(self, stepsize):
+        """The method's setup_linear + aux_pre_solve + KSPSolve on a copy of the last auxiliary
+        solution (:2345-2355, initialize_try :1184-1186); (reason, its, X, Al o X)."""
+        ode = self.ode
+        X = self.aux_solution.clone() if hasattr(self.aux_solution, "clone") else self.aux_solution.copy()
+        new = X.clone() if hasattr(X, "clone") else X.copy()
+        if self._alx[0] is None:
+            raise RuntimeError("auxiliary history missing: call init_auxiliary() at the initial state")
+        if self.method == "directss":
+            method, ratio = "directss", 0.0
+        elif self.method == "bdf2" and self.taken > 0:
+            method, ratio = "bdf2", stepsize / self._last_stepsize
+        else:
+            method, ratio = "beuler", 0.0
+        last2 = self._alx[1] if self._alx[1] is not None else self._alx[0]
+        reason, its = ode.aux_solve(method, stepsize, ratio, self._alx[0], last2, X, new)
+        return reason, its, X, new
+
+    def init_auxiliary(self):
+        """Al o X of the initial state (timestepper_initial_function_calls :1106-1108); the fluid
+        state of `y` must be current (pre_eval)."""
+        if not self.auxiliary:
+            return
+        al = self.aux_solution.clone() if hasattr(self.aux_solution, "clone") else self.aux_solution.copy()
+        self.ode.aux_lhs(self.time, None, al)
+        self._alx = [al * self.aux_solution, None]
 
     def run(self, num_steps=None):
         """timestepper_run (:2380-2410): until finished, or `num_steps` accepted steps."""
