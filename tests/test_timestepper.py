@@ -186,3 +186,57 @@ def test_rejected_converged_step_restores_history():
     assert ode.taken == 1 and np.array_equal(ode.hist, ode.initial)
     ts.run()
     assert abs(ts.time - 1.0) < 1e-6 and ode.taken == ts.taken
+
+
+class AuxOdeDouble(OdeDouble):
+    """adds the auxiliary linear problem dX/dt = k X (the reference's exponential_ode_type has
+    aux_lhs = identity, aux_rhs = k, timestepper_test.F90:367-432) with its setup_linear forms"""
+    auxiliary = True
+    k = -5.0
+
+    def aux_lhs(self, t, interval, Al):
+        Al[:] = 1.0
+
+    def aux_solve(self, method, dt, ratio, alx_last, alx_last2, X, alx_new):
+        k, r = self.k, ratio
+        if method == "beuler":
+            X[:] = alx_last / (1.0 - dt * k)
+        elif method == "bdf2":
+            X[:] = ((r + 1) ** 2 * alx_last - r * r * alx_last2) / ((1 + 2 * r) - dt * (r + 1) * k)
+        else:
+            X[:] = 0.0
+        alx_new[:] = X
+        self.aux_calls = getattr(self, "aux_calls", 0) + 1
+        return (-3 if getattr(self, "aux_fail_above", None) is not None and dt > self.aux_fail_above else 2), 1
+
+
+def test_auxiliary_solution_follows_the_exponential():
+    """the auxiliary problem rides along every accepted step with the method's own history
+    (timestepper_test.F90 asserts the aux solution to the same tolerances: 0.12 / 0.04)"""
+    for method, tol, size in (("beuler", 0.12, 0.01), ("bdf2", 0.04, 0.05)):
+        e = exponential()
+        ode = AuxOdeDouble(e.rhs_fn, e.drhs, e.exact, e.initial)
+        y, X = ode.initial.copy(), ode.initial.copy()
+        ts = Timestepper(ode, y, stepsize=size, method=method, adapt=True, adapt_method="change",
+                         adapt_min=0.01, adapt_max=0.2, stop_time=1.0, max_num_steps=200, aux_solution=X)
+        ts.init_auxiliary()
+        while not ts.finished:
+            ts.step()
+            assert zofu_close(ode.exact(ts.time), X, tol)
+            assert zofu_close(ode.exact(ts.time), y, tol)
+        assert len(ts.aux_history) == ts.taken
+
+
+def test_failed_auxiliary_solve_retries_the_step():
+    """TIMESTEP_AUX_NOT_CONVERGED (:1348-1350): the try is rejected, the step size reduced, and the
+    auxiliary state / history are those of the last accepted step"""
+    e = linear()
+    ode = AuxOdeDouble(e.rhs_fn, e.drhs, e.exact, e.initial)
+    ode.aux_fail_above = 0.05
+    y, X = ode.initial.copy(), ode.initial.copy()
+    ts = Timestepper(ode, y, stepsize=1.0, aux_solution=X)
+    ts.init_auxiliary()
+    ts.step()
+    assert ts.history[-1][4] == 3 and np.isclose(ts.history[-1][1], 0.04)
+    assert np.allclose(X, ode.initial / (1.0 + 0.04 * 5.0))
+    assert np.allclose(y, ode.initial - 0.5 * 0.04)

@@ -187,6 +187,47 @@ module waiwera_hip_module
        integer(c_int), intent(out) :: ksp_its, reason
        real(c_double), intent(out) :: max_residual
      end function wai_newton_step
+     integer(c_int) function wai_set_tracers(ctx, n, phase, decay, activation, diffusion) &
+          bind(c, name = "wai_set_tracers")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n
+       integer(c_int), intent(in) :: phase(*)
+       real(c_double), intent(in) :: decay(*), activation(*), diffusion(*)
+     end function wai_set_tracers
+     integer(c_int) function wai_set_tracer_bc(ctx, x_bc) bind(c, name = "wai_set_tracer_bc")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: x_bc(*)
+     end function wai_set_tracer_bc
+     integer(c_int) function wai_set_tracer_injection(ctx, rate) bind(c, name = "wai_set_tracer_injection")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: rate(*)
+     end function wai_set_tracer_injection
+     integer(c_int) function wai_set_aux_solver(ctx, ksp_type, gmres_restart, rtol, atol, max_its) &
+          bind(c, name = "wai_set_aux_solver")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: ksp_type, gmres_restart, max_its
+       real(c_double), value :: rtol, atol
+     end function wai_set_aux_solver
+     integer(c_int) function wai_tracer_lhs(ctx, Al) bind(c, name = "wai_tracer_lhs")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: Al(*)
+     end function wai_tracer_lhs
+     integer(c_int) function wai_tracer_solve(ctx, method, dt, ratio, alx_last, alx_last2, X, alx_new, &
+          its, reason) bind(c, name = "wai_tracer_solve")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: method
+       real(c_double), value :: dt, ratio
+       real(c_double), intent(in) :: alx_last(*), alx_last2(*)
+       real(c_double), intent(in out) :: X(*)
+       real(c_double), intent(out) :: alx_new(*)
+       integer(c_int), intent(out) :: its, reason
+     end function wai_tracer_solve
      integer(c_int) function wai_timestep(ctx, t, dt, y, newton_its, ksp_its, reason) bind(c, name = "wai_timestep")
        import :: c_int, c_ptr, c_double
        type(c_ptr), value :: ctx
@@ -219,6 +260,8 @@ module waiwera_hip_module
      procedure, public :: setup_jacobian => hip_sim_setup_jacobian
      procedure, public :: set_residual_form => hip_sim_set_residual_form
      procedure, public :: set_timestep_method => hip_sim_set_timestep_method
+     procedure, public :: aux_lhs => hip_sim_aux_lhs
+     procedure, public :: aux_solve => hip_sim_aux_solve
      procedure, public :: residual => hip_sim_residual
      procedure, public :: jacobian => hip_sim_jacobian
      procedure, public :: ksp_solve => hip_sim_ksp_solve
@@ -226,6 +269,7 @@ module waiwera_hip_module
      procedure, public :: timestep => hip_sim_timestep
   end type hip_flow_simulation_type
 
+  public :: wai_set_tracers, wai_set_tracer_bc, wai_set_tracer_injection, wai_set_aux_solver
   public :: wai_default_eos, wai_default_opts, wai_set_bc, wai_set_sources, wai_set_regions, &
        wai_get_regions, wai_jacobian_nnzb, wai_jacobian_pattern, wai_jacobian_get_values
 
@@ -423,5 +467,32 @@ contains
     integer, intent(out) :: err
     err = wai_set_timestep_method(self%ctx, int(method, c_int))
   end subroutine hip_sim_set_timestep_method
+
+  subroutine hip_sim_aux_lhs(self, t, interval, Al, err)
+    !! ode_type aux_lhs (src/ode.F90, flow_simulation_tracer_cell_balances
+    !! src/flow_simulation.F90:1489-1556): diagonal of the tracer left-hand side matrix
+    class(hip_flow_simulation_type), intent(in out) :: self
+    real(dp), intent(in) :: t, interval(2)
+    real(dp), intent(out) :: Al(:)
+    integer, intent(out) :: err
+    err = wai_tracer_lhs(self%ctx, Al)
+  end subroutine hip_sim_aux_lhs
+
+  subroutine hip_sim_aux_solve(self, method, dt, ratio, alx_last, alx_last2, X, alx_new, its, reason, err)
+    !! setup_linear + aux_pre_solve + KSPSolve of the auxiliary problem
+    !! (src/timestepper.F90:458-581, 2347-2353); alx_* = aux_lhs_matrix * aux_solution of the
+    !! last / second-last stored step
+    class(hip_flow_simulation_type), intent(in out) :: self
+    integer, intent(in) :: method
+    real(dp), intent(in) :: dt, ratio
+    real(dp), intent(in) :: alx_last(:), alx_last2(:)
+    real(dp), intent(in out) :: X(:)
+    real(dp), intent(out) :: alx_new(:)
+    integer, intent(out) :: its, reason, err
+    integer(c_int) :: k, r
+    err = wai_tracer_solve(self%ctx, int(method, c_int), dt, ratio, alx_last, alx_last2, X, alx_new, k, r)
+    its = k
+    reason = r
+  end subroutine hip_sim_aux_solve
 
 end module waiwera_hip_module
