@@ -1,0 +1,40 @@
+"""The reference's model intercomparison study problem 1 (radial Avdonin problem) on the HIP path,
+through the C ABI and the Python Timestepper: against the analytical solution and AUTOUGH2's final
+table (both shipped with the reference's benchmark, tests/golden/benchmark_problem1_avdonin.json)
+and against the oracle run of the same steps."""
+import numpy as np
+import pytest
+
+from tests import benchmarks as B
+from tests import oracle_lib as ol
+from tests.test_oracle_benchmark import OracleOde
+from waiwera_amd.timestepper import Timestepper
+
+pytestmark = pytest.mark.gpu
+
+
+def test_avdonin_problem_on_gpu(oracle):
+    from waiwera_amd.flow_simulation import FlowSimulation
+    spec = B.load_problem1()
+    lm, prim, region = B.problem1_mesh(spec)
+    ftol = spec["input"]["time"]["step"]["solver"]["nonlinear"]["tolerance"]["function"]["relative"]
+    sim = FlowSimulation(lm, eos="we")
+    sim.set_regions(region)
+    sim.set_opts(ftol_rel=ftol)
+    y = (prim / np.array([1.0e6, 1.0e2])).ravel().copy()
+    times, T_obs, T_final = B.run_problem1(sim, y, spec, Timestepper)
+    assert abs(times[-1] - 1.0e9) < 1.0
+    rc = np.asarray(lm.cell_geom).reshape(-1, 4)[: lm.n_owned, 0]
+    e_hist, e_prof = B.compare_with_analytical(spec, times, T_obs, T_final, rc)
+    assert e_hist < 2.0 and e_prof < 2.0          # the reference's bar: 2e-2 relative = 3.2 degC
+    a = spec["autough2_final_table"]
+    assert np.abs(T_final - np.asarray(a["temperature"])).max() < 0.05
+    assert np.abs(y.reshape(-1, 2)[:, 0] * 1.0e6 - np.asarray(a["pressure"])).max() < 5.0e2
+    # the oracle through the same controller
+    osim = ol.OracleSim(oracle, lm, 1)
+    osim.set_regions(region)
+    yo = osim.yvec((prim / np.array([1.0e6, 1.0e2])).ravel())
+    to, To_obs, To_final = B.run_problem1(OracleOde(osim, ftol), yo, spec, Timestepper)
+    assert np.array_equal(times, to)
+    assert np.abs(T_final - To_final).max() < 1e-5 and np.abs(T_obs - To_obs).max() < 1e-5
+    sim.destroy(); osim.close()

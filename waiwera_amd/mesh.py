@@ -616,3 +616,68 @@ def partition_shape(n):
             p[a % 3] *= n
             n = 1
     return tuple(p)
+
+
+def radial_mesh_1d(r_edges, thickness, rock_record=None, outer_bc=None, sources=None, chunk=512):
+    """One row of cells in a 2-D radial mesh (`"mesh": {"radial": true}`), as the reference's
+    radial benchmark problems use: cell i spans r_edges[i]..r_edges[i+1] over `thickness`.
+    Geometry by Pappus' theorem like src/mesh.F90:369-432: volume = dr * thickness * 2 pi r_c,
+    face area = thickness * 2 pi r_f; faces are vertical, so the gravity term g.n is zero and the
+    permeability direction is 1.  outer_bc = (primary, region) puts a Dirichlet ghost cell on the
+    outermost face (distances (d, 0), src/mesh.F90:647-651).  sources: [{cell, rate, enthalpy,
+    component}].  Preconditioner subdomains: chunks of `chunk` consecutive cells."""
+    r = np.asarray(r_edges, dtype=np.float64)
+    n = r.size - 1
+    rc, dr = 0.5 * (r[1:] + r[:-1]), np.diff(r)
+    m = LocalMesh(dims=(n, 1, 1), spacing=(float(dr[0]), 0.0, float(thickness)), part=(1, 1, 1), rank=0,
+                  brick=(chunk, 1, 1), n_global=n)
+    m.n_owned, m.n_halo = n, 0
+    fc = np.stack([np.arange(n - 1), np.arange(1, n)], axis=1)
+    fg = np.zeros((n - 1, 12))
+    fg[:, 0] = thickness * 2.0 * np.pi * r[1:-1]
+    fg[:, 1] = 0.5 * dr[:-1]
+    fg[:, 2] = 0.5 * dr[1:]
+    fg[:, 3] = fg[:, 1] + fg[:, 2]
+    fg[:, 4] = 1.0
+    fg[:, 8] = r[1:-1]
+    fg[:, 10] = -0.5 * thickness
+    fg[:, 11] = 1
+    m.n_bc = 0
+    if outer_bc is not None:
+        g = np.zeros((1, 12))
+        g[0, 0] = thickness * 2.0 * np.pi * r[-1]
+        g[0, 1] = 0.5 * dr[-1]
+        g[0, 3] = 0.5 * dr[-1]
+        g[0, 4] = 1.0
+        g[0, 8] = r[-1]
+        g[0, 10] = -0.5 * thickness
+        g[0, 11] = 1
+        fc = np.concatenate([fc, np.array([[n - 1, n]])])
+        fg = np.concatenate([fg, g])
+        prim, region = outer_bc
+        m.bc_primary = np.asarray(prim, dtype=np.float64)[None, :]
+        m.bc_region = np.array([int(region)], dtype=np.int32)
+        m.n_bc = 1
+    m.face_cells, m.face_geom, m.n_faces = fc.astype(np.int32), fg, fc.shape[0]
+    cg = np.zeros((n + m.n_bc, 4))
+    cg[:n, 0], cg[:n, 2] = rc, -0.5 * thickness
+    cg[:n, 3] = dr * thickness * 2.0 * np.pi * rc
+    if m.n_bc:
+        cg[n, 0], cg[n, 2] = r[-1], -0.5 * thickness
+    m.cell_geom = cg
+    rock = np.zeros((n + m.n_bc, 8))
+    rock[:] = default_rock(1)[0] if rock_record is None else np.asarray(rock_record, dtype=np.float64)
+    m.rock = rock
+    m.sub_ptr = np.append(np.arange(0, n, chunk), n).astype(np.int32)
+    m.owned_gid = np.arange(n)
+    m.nbr_ranks = np.zeros(0, dtype=np.int32)
+    m.send_ptr = np.zeros(1, dtype=np.int32)
+    m.send_idx = np.zeros(0, dtype=np.int32)
+    m.recv_ptr = np.zeros(1, dtype=np.int32)
+    if sources:
+        m.n_src = len(sources)
+        m.src_cell = np.array([s["cell"] for s in sources], dtype=np.int32)
+        m.src_rate = np.array([s["rate"] for s in sources], dtype=np.float64)
+        m.src_enthalpy = np.array([s.get("enthalpy", 0.0) for s in sources], dtype=np.float64)
+        m.src_component = np.array([s.get("component", 0) for s in sources], dtype=np.int32)
+    return m
