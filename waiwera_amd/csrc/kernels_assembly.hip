@@ -24,6 +24,19 @@ namespace wai {
 constexpr int MAXDEG = 8;   // faces per cell held in registers (structured: 6, MINC: 7)
 constexpr int TPB = 256;
 
+// XCD-aware cell-block mapping for the gather-heavy sweeps: dispatch puts workgroup b on XCD
+// b % 8, so hand XCD j the j-th contiguous eighth of the cell blocks -- neighbouring half-bricks
+// then share one L2 instead of pulling the same fluid records into eight of them.  Grids are
+// rounded up to a multiple of 8; returns -1 for the padding workgroups.
+__device__ __forceinline__ int xcd_cell(int n_owned) {
+  const int nblk = (n_owned + (int)blockDim.x - 1) / (int)blockDim.x;
+  const int per = (nblk + 7) >> 3;
+  const int b = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (((int)blockIdx.x >> 3) >= per || b >= nblk) return -1;
+  const int c = b * (int)blockDim.x + (int)threadIdx.x;
+  return c < n_owned ? c : -1;
+}
+
 __device__ __forceinline__ double fd_step(double yv, double eps, double umin) {
   // MatFDColoring "ds" increment (doc/user/setup_time.rst:434-471)
   double dx = yv;
@@ -143,8 +156,8 @@ __global__ __launch_bounds__(TPB) void k_residual(MeshView m, const double* __re
                                                   double* __restrict__ f, double* __restrict__ lhs_out,
                                                   double* __restrict__ rhs_out) {
   using E = EosT<KIND>;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= m.n_owned) return;
+  const int c = xcd_cell(m.n_owned);
+  if (c < 0) return;
   CellState<KIND> own;
   RockState rown;
   load_state<KIND>(flu, stride, c, own);
@@ -189,8 +202,8 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
                                                   ResForm rf, double* __restrict__ val) {
   using E = EosT<KIND>;
   constexpr int np = E::np, bb = E::np * E::np;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= m.n_owned) return;
+  const int c = xcd_cell(m.n_owned);
+  if (c < 0) return;
   CellState<KIND> own0;
   RockState rown;
   load_state<KIND>(flu, stride, c, own0);
@@ -581,6 +594,7 @@ static MeshView view(wai_ctx* c) {
 }
 
 static inline int grid_for(size_t n) { return (int)((n + TPB - 1) / TPB); }
+static inline int grid8_for(size_t n) { return ((grid_for(n) + 7) / 8) * 8; }  // xcd_cell kernels
 
 // launch KERNEL<kind>(...) for the context's EOS
 #define WAI_BY_EOS(c, KERNEL, grid, ...)                                                          \
@@ -618,7 +632,7 @@ int launch_residual(wai_ctx* c, double dt, const double* lhs_old, double* f, dou
                     double* rhs_out) {
   const MeshView m = view(c);
   const size_t stride = c->mesh.n_local;
-  WAI_BY_EOS(c, k_residual, grid_for(m.n_owned), m, c->flu, stride, res_form_of(c, dt, lhs_old), f,
+  WAI_BY_EOS(c, k_residual, grid8_for(m.n_owned), m, c->flu, stride, res_form_of(c, dt, lhs_old), f,
              lhs_out, rhs_out);
   return 0;
 }
@@ -628,7 +642,7 @@ int launch_jacobian(wai_ctx* c, double dt, const double* lhs_old) {
   if (m.max_deg > MAXDEG) { c->err = "cell with more than 8 faces not supported"; return -1; }
   const size_t stride = c->mesh.n_local;
   hipMemsetAsync(c->J.val, 0, sizeof(double) * (size_t)c->J.W * c->np * c->np * c->J.n, c->stream);
-  WAI_BY_EOS(c, k_jacobian, grid_for(m.n_owned), m, c->flu, stride, c->flu_pert, c->hstep, c->mesh.n_prim,
+  WAI_BY_EOS(c, k_jacobian, grid8_for(m.n_owned), m, c->flu, stride, c->flu_pert, c->hstep, c->mesh.n_prim,
              res_form_of(c, dt, lhs_old), c->J.val);
   return 0;
 }
