@@ -33,6 +33,7 @@ typedef struct wai_ctx wai_ctx;
 enum { WAI_EOS_W = 0, WAI_EOS_WE = 1, WAI_EOS_WCE = 2 };
 /* time stepping methods (src/timestepper.F90:2262-2275 "beuler" | "bdf2" | "directss") */
 enum { WAI_METHOD_BEULER = 0, WAI_METHOD_BDF2 = 1, WAI_METHOD_DIRECTSS = 2 };
+enum { WAI_THERMO_IAPWS = 0, WAI_THERMO_IFC67 = 1 };
 enum { WAI_RP_FULLY_MOBILE = 0, WAI_RP_LINEAR = 1, WAI_RP_PICKENS = 2, WAI_RP_COREY = 3,
        WAI_RP_GRANT = 4, WAI_RP_VAN_GENUCHTEN = 5 };
 enum { WAI_CP_ZERO = 0, WAI_CP_LINEAR = 1, WAI_CP_VAN_GENUCHTEN = 2 };
@@ -70,6 +71,8 @@ typedef struct wai_eos_desc {
   double cp_par[6];
   double partial_pressure_scale; /* eos wce: "eos.primary.scale.partial_pressure"; 0 = adaptive
                                     Pg / P (the reference default, src/eos_wge.F90:95-104) */
+  int thermo;                /* "thermodynamics": WAI_THERMO_IAPWS (default, src/IAPWS.F90) |
+                                WAI_THERMO_IFC67 (src/IFC67.F90); src/thermodynamics_setup.F90 */
 } wai_eos_desc;
 
 /* "time.step.solver.*" keys: src/timestepper.F90:1567-1573,1645-1720,1998-2020 */

@@ -41,6 +41,14 @@ int wo_sat_temperature(double p, double *t);                       /* :793-818 *
 double wo_viscosity(double t, double rho);                         /* :412-443 */
 int wo_phase_composition(int region, double p, double t);          /* :317-365 */
 
+/* ---- IFC-67 ("thermodynamics": "ifc67", src/IFC67.F90); wo_ifc67.c ------------------------ */
+int wo_ifc67_region1(double p, double t, double max_temperature, double *rho, double *u);
+int wo_ifc67_region2(double p, double t, double *rho, double *u);
+int wo_ifc67_sat_pressure(double t, double *p);
+int wo_ifc67_sat_temperature(double p, double *t);
+double wo_ifc67_viscosity(int region, double t, double p, double rho);
+int wo_ifc67_phase_composition(int region);
+
 /* ---- CO2 as non-condensible gas (src/ncg_co2_thermodynamics.F90, src/ncg_thermodynamics.F90) -- */
 int wo_co2_properties(double pp, double t, double *rho, double *h);        /* :83-112 */
 double wo_co2_henrys_constant(double t);                                    /* :116-135 */
@@ -69,6 +77,7 @@ typedef struct wo_eos {
                                 * pressure scale means adaptive scaling Pg/P (eos_wge.F90:639-674) */
   int rp_type, cp_type;
   double rp_par[6], cp_par[6];
+  int thermo;                  /* "thermodynamics": 0 IAPWS-97 (default), 1 IFC-67 */
 } wo_eos;
 void wo_eos_init(wo_eos *e, int kind);
 void wo_eos_unscale(const wo_eos *e, const double *y, int region, double *primary);

@@ -128,6 +128,26 @@ int wo_phase_composition(int region, double p, double t) {
   return (p <= PCRITICAL) ? 2 : 4;
 }
 
+/* ---- thermodynamic formulation dispatch ("thermodynamics": "iapws" | "ifc67") -------------- */
+/* region 1 = liquid water, 2 = steam */
+static int th_props(const wo_eos *e, int region, double p, double t, double *rho, double *u) {
+  if (e->thermo == 1)
+    return region == 1 ? wo_ifc67_region1(p, t, 350.0, rho, u) : wo_ifc67_region2(p, t, rho, u);
+  return region == 1 ? wo_region1(p, t, rho, u) : wo_region2(p, t, rho, u);
+}
+static double th_viscosity(const wo_eos *e, int region, double t, double p, double rho) {
+  return e->thermo == 1 ? wo_ifc67_viscosity(region, t, p, rho) : wo_viscosity(t, rho);
+}
+static int th_sat_pressure(const wo_eos *e, double t, double *p) {
+  return e->thermo == 1 ? wo_ifc67_sat_pressure(t, p) : wo_sat_pressure(t, p);
+}
+static int th_sat_temperature(const wo_eos *e, double p, double *t) {
+  return e->thermo == 1 ? wo_ifc67_sat_temperature(p, t) : wo_sat_temperature(p, t);
+}
+static int th_phase_composition(const wo_eos *e, int region, double p, double t) {
+  return e->thermo == 1 ? wo_ifc67_phase_composition(region) : wo_phase_composition(region, p, t);
+}
+
 /* ---- CO2 NCG thermodynamics -------------------------------------------------------------- */
 #define CO2_MW 44.01             /* src/ncg_co2_thermodynamics.F90:14 */
 #define WATER_MW 18.01528        /* src/thermodynamics.F90:38 */
@@ -381,7 +401,7 @@ int wo_eos_bulk_properties(const wo_eos *e, const double *primary, double *fl) {
   if (e->kind == WO_EOS_W) {
     fl[F_T] = e->temperature;
     fl[phase_off(e, 0) + PH_SAT] = 1.0;
-    int ph = wo_phase_composition(region, fl[F_P], fl[F_T]);
+    int ph = th_phase_composition(e, region, fl[F_P], fl[F_T]);
     if (ph > 0) fl[F_PHASES] = (double)ph; else err = 1;
     fl[F_PERMFAC] = 1.0;
     fl[F_PP] = fl[F_P];
@@ -393,12 +413,12 @@ int wo_eos_bulk_properties(const wo_eos *e, const double *primary, double *fl) {
   }
   if (region == 4) {
     double t;
-    err = wo_sat_temperature(e->kind == WO_EOS_WCE ? fl[F_PP] : fl[F_P], &t);
+    err = th_sat_temperature(e, e->kind == WO_EOS_WCE ? fl[F_PP] : fl[F_P], &t);
     if (err == 0) fl[F_T] = t;
   } else fl[F_T] = primary[1];
   if (err) return err;
   fl[F_PERMFAC] = 1.0;
-  int ph = wo_phase_composition(region, fl[F_P], fl[F_T]);
+  int ph = th_phase_composition(e, region, fl[F_P], fl[F_T]);
   if (ph <= 0) return 1;
   fl[F_PHASES] = (double)ph;
   double *l = fl + phase_off(e, 0), *v = fl + phase_off(e, 1);
@@ -434,7 +454,7 @@ static int wce_phase_properties(const wo_eos *e, double *fl) {
         water_pressure = Pw; cap = 0.0; henry = 0.0; esol = 0.0;
       }
       double wrho, wu;
-      err = (p == 0) ? wo_region1(water_pressure, T, &wrho, &wu) : wo_region2(water_pressure, T, &wrho, &wu);
+      err = th_props(e, p == 0 ? 1 : 2, water_pressure, T, &wrho, &wu);
       if (err) return err;
       double grho = (p == 0) ? 0.0 : gas_rho; /* effective_properties: no free gas in liquid */
       double xg;
@@ -443,7 +463,7 @@ static int wce_phase_properties(const wo_eos *e, double *fl) {
         double tot = grho + wrho;
         xg = (tot < 1.e-30) ? 0.0 : grho / tot;
       }
-      double wmu = wo_viscosity(T, wrho), mu;
+      double wmu = th_viscosity(e, p == 0 ? 1 : 2, T, water_pressure, wrho), mu;
       if (p == 0) mu = wmu;
       else {
         double gmu;
@@ -474,11 +494,11 @@ int wo_eos_phase_properties(const wo_eos *e, const double *primary, double *fl) 
     int p = (int)lround(fl[F_REGION]); /* region 1 -> liquid, the only phase */
     double *ph = fl + phase_off(e, 0);
     double rho, u;
-    int err = (p == 1) ? wo_region1(P, T, &rho, &u) : wo_region2(P, T, &rho, &u);
+    int err = th_props(e, p == 1 ? 1 : 2, P, T, &rho, &u);
     if (err) return err;
     ph[PH_RHO] = rho; ph[PH_U] = u; ph[PH_H] = u + P / rho;
     ph[PH_KR] = 1.0; ph[PH_PC] = 0.0; ph[PH_X] = 1.0;
-    ph[PH_MU] = wo_viscosity(T, rho);
+    ph[PH_MU] = th_viscosity(e, p == 1 ? 1 : 2, T, P, rho);
     return 0;
   }
   if (e->kind == WO_EOS_WCE) return wce_phase_properties(e, fl);
@@ -492,11 +512,11 @@ int wo_eos_phase_properties(const wo_eos *e, const double *primary, double *fl) 
     double *ph = fl + phase_off(e, p);
     if (phases & (1 << p)) {
       double rho, u;
-      int err = (p == 0) ? wo_region1(P, T, &rho, &u) : wo_region2(P, T, &rho, &u);
+      int err = th_props(e, p == 0 ? 1 : 2, P, T, &rho, &u);
       if (err) return err;
       ph[PH_RHO] = rho; ph[PH_U] = u; ph[PH_H] = u + P / rho;
       ph[PH_X] = 1.0; ph[PH_KR] = rp[p]; ph[PH_PC] = cp[p];
-      ph[PH_MU] = wo_viscosity(T, rho);
+      ph[PH_MU] = th_viscosity(e, p == 0 ? 1 : 2, T, P, rho);
     } else {
       ph[PH_RHO] = 0.0; ph[PH_U] = 0.0; ph[PH_H] = 0.0; ph[PH_KR] = 0.0;
       ph[PH_PC] = 0.0; ph[PH_MU] = 0.0; ph[PH_X] = 0.0;
@@ -506,12 +526,12 @@ int wo_eos_phase_properties(const wo_eos *e, const double *primary, double *fl) 
 }
 
 /* saturation-line difference along the old->new primary segment: src/eos_we.F90:530-553 */
-typedef struct { double p0, t0, p1, t1, g0, g1; } satline_ctx; /* g: gas partial pressure (eos_wge.F90:678-701) */
+typedef struct { double p0, t0, p1, t1, g0, g1; const wo_eos *e; } satline_ctx; /* g: gas partial pressure (eos_wge.F90:678-701) */
 static double satline_diff(double x, void *vc) {
   satline_ctx *c = (satline_ctx *)vc;
   double P = (1.0 - x) * c->p0 + x * c->p1, T = (1.0 - x) * c->t0 + x * c->t1, Ps = 0.0;
   double Pg = (1.0 - x) * c->g0 + x * c->g1;
-  wo_sat_pressure(T, &Ps); /* error ignored, as the reference does */
+  th_sat_pressure(c->e, T, &Ps); /* error ignored, as the reference does */
   return P - Pg - Ps;
 }
 
@@ -551,11 +571,11 @@ int wo_eos_transition(const wo_eos *e, const double *oldp, double *prim, const d
       prim[0] = pfac * iw + ig;
       if (wce) prim[2] = ig;
       double t;
-      err = wo_sat_temperature(iw, &t);
+      err = th_sat_temperature(e, iw, &t);
       if (err == 0) { prim[1] = t; fluid[F_REGION] = (double)new_region; *transition = 1; }
     } else {
       double ps;
-      err = wo_sat_pressure(old_fluid[F_T], &ps);
+      err = th_sat_pressure(e, old_fluid[F_T], &ps);
       if (err == 0) {
         prim[0] = pfac * ps + (wce ? prim[2] : 0.0);
         prim[1] = old_fluid[F_T];
@@ -566,12 +586,12 @@ int wo_eos_transition(const wo_eos *e, const double *oldp, double *prim, const d
     return err;
   }
   double ps;
-  err = wo_sat_pressure(prim[1], &ps);
+  err = th_sat_pressure(e, prim[1], &ps);
   if (err) return err;
   double pw = prim[0] - (wce ? prim[2] : 0.0);
   if ((old_region == 1 && pw < ps) || (old_region == 2 && pw > ps)) {
     if (wce) prim[2] = fmax(0.0, fmin(prim[2], prim[0]));
-    satline_ctx c = {oldp[0], oldp[1], prim[0], prim[1], wce ? oldp[2] : 0.0, wce ? prim[2] : 0.0};
+    satline_ctx c = {oldp[0], oldp[1], prim[0], prim[1], wce ? oldp[2] : 0.0, wce ? prim[2] : 0.0, e};
     double root;
     int it;
     int rerr = wo_brent(satline_diff, &c, 0.0, 1.0, 1.e-8, 1.e-8, 100, &root, &it);

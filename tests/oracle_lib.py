@@ -16,7 +16,7 @@ class Eos(C.Structure):
     _fields_ = [("kind", i32), ("np", i32), ("nc", i32), ("nph", i32), ("nmob", i32),
                 ("df", i32), ("isothermal", i32), ("temperature", d),
                 ("scale", d * 4 * 5), ("rp_type", i32), ("cp_type", i32),
-                ("rp_par", d * 6), ("cp_par", d * 6)]
+                ("rp_par", d * 6), ("cp_par", d * 6), ("thermo", i32)]
 
 
 class NewtonOpts(C.Structure):
@@ -55,6 +55,9 @@ def load(path):
     sig = {
         "wo_region1": (i32, [d, d, pd, pd]), "wo_region2": (i32, [d, d, pd, pd]),
         "wo_sat_pressure": (i32, [d, pd]), "wo_sat_temperature": (i32, [d, pd]),
+        "wo_ifc67_region1": (i32, [d, d, d, pd, pd]), "wo_ifc67_region2": (i32, [d, d, pd, pd]),
+        "wo_ifc67_sat_pressure": (i32, [d, pd]), "wo_ifc67_sat_temperature": (i32, [d, pd]),
+        "wo_ifc67_viscosity": (d, [i32, d, d, d]), "wo_ifc67_phase_composition": (i32, [i32]),
         "wo_viscosity": (d, [d, d]), "wo_phase_composition": (i32, [i32, d, d]),
         "wo_relperm": (None, [i32, pd, d, pd]), "wo_capillary": (d, [i32, pd, d, d]),
         "wo_brent": (i32, [ROOTFN, C.c_void_p, d, d, d, d, i32, pd, pi]),
@@ -118,7 +121,7 @@ def load(path):
 class OracleSim:
     """Thin object wrapper over the oracle's wo_sim for the tests / cpu baseline."""
 
-    def __init__(self, L, mesh, eos_kind):
+    def __init__(self, L, mesh, eos_kind, thermo=0):
         self.L = L
         self.mesh = mesh
         self._keep = [f64(mesh.face_geom), f64(mesh.cell_geom), f64(mesh.rock), i32a(mesh.face_cells)]
@@ -126,6 +129,7 @@ class OracleSim:
         self.h = L.wo_sim_create(eos_kind, mesh.n_owned, mesh.n_halo, mesh.n_bc, mesh.n_faces,
                                  ip(fc), dp(fg), dp(cg), dp(rk))
         self.eos = L.wo_sim_eos(self.h).contents
+        self.eos.thermo = thermo   # 0 IAPWS-97, 1 IFC-67; before the boundary fluid is evaluated
         self.np = self.eos.np
         self.df = self.eos.df
         self.n_owned, self.n_prim = mesh.n_owned, mesh.n_owned + mesh.n_halo

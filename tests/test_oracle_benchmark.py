@@ -39,10 +39,14 @@ class OracleOde:
         return (1, r, k) if r >= 0 else (r, 0, k)
 
 
-def test_avdonin_problem_against_analytical_solution(oracle):
+import pytest
+
+
+@pytest.mark.parametrize("thermo", ["ifc67", "iapws"])
+def test_avdonin_problem_against_analytical_solution(oracle, thermo):
     spec = B.load_problem1()
     lm, prim, region = B.problem1_mesh(spec)
-    osim = ol.OracleSim(oracle, lm, 1)
+    osim = ol.OracleSim(oracle, lm, 1, thermo=1 if thermo == "ifc67" else 0)
     osim.set_regions(region)
     y = osim.yvec((prim / np.array([1.0e6, 1.0e2])).ravel())
     ode = OracleOde(osim, spec["input"]["time"]["step"]["solver"]["nonlinear"]["tolerance"]["function"]["relative"])
@@ -50,17 +54,19 @@ def test_avdonin_problem_against_analytical_solution(oracle):
     assert abs(times[-1] - 1.0e9) < 1.0
     rc = np.asarray(lm.cell_geom).reshape(-1, 4)[: lm.n_owned, 0]
     e_hist, e_prof = B.compare_with_analytical(spec, times, T_obs, T_final, rc)
-    print("max |dT| history %.3f degC, profile %.3f degC" % (e_hist, e_prof))
-    # the reference's bar is 2e-2 relative (3.2 degC at 160 degC); this restatement does better
-    assert e_hist < 0.02 * 160.0 and e_prof < 0.02 * 160.0
+    print("%s: max |dT| history %.3f degC, profile %.3f degC" % (thermo, e_hist, e_prof))
+    # the reference's bar against the analytical solution is 2e-2 relative (3.2 degC at 160 degC)
     assert e_hist < 2.0 and e_prof < 2.0
-    # AUTOUGH2's final table (the reference's own comparison, 1e-4 relative there with IFC-67 on both
-    # sides; here IAPWS-IF97 against IFC-67)
+    # AUTOUGH2's final table: the reference's own comparison asks 1e-4 relative on temperature
+    # (IFC-67 on both sides, as in the benchmark input); IAPWS-97 stays within 0.05 degC of it
     a = spec["autough2_final_table"]
-    dT = np.abs(T_final - np.asarray(a["temperature"]))
-    dP = np.abs(y[: 2 * lm.n_owned].reshape(-1, 2)[:, 0] * 1.0e6 - np.asarray(a["pressure"]))
-    print("vs AUTOUGH2: max |dT| %.4f degC, max |dP| %.1f Pa" % (dT.max(), dP.max()))
-    assert dT.max() < 0.05 and dP.max() < 5.0e2
-    # front has passed the observation cell: it sits at the injection temperature
+    Ta, Pa = np.asarray(a["temperature"]), np.asarray(a["pressure"])
+    dT = np.abs(T_final - Ta)
+    dP = np.abs(y[: 2 * lm.n_owned].reshape(-1, 2)[:, 0] * 1.0e6 - Pa)
+    print("%s vs AUTOUGH2: max |dT| %.5f degC (rel %.2e), max |dP| %.1f Pa" % (thermo, dT.max(), (dT / Ta).max(), dP.max()))
+    if thermo == "ifc67":
+        assert (dT / Ta).max() < 1.0e-4 and (dP / Pa).max() < 1.0e-4
+    else:
+        assert dT.max() < 0.05 and dP.max() < 5.0e2
     assert abs(T_obs[-1] - 160.0) < 0.25 and abs(T_final[-1] - 170.0) < 0.05
     osim.close()

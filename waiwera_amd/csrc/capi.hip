@@ -500,6 +500,7 @@ void wai_default_eos(wai_eos_desc* e, int kind) {
   e->rp_par[0] = 0.0; e->rp_par[1] = 1.0; e->rp_par[2] = 0.0; e->rp_par[3] = 1.0;
   e->cp_type = WAI_CP_ZERO;
   e->partial_pressure_scale = 0.0;
+  e->thermo = WAI_THERMO_IAPWS;
 }
 
 void wai_default_opts(wai_solver_opts* o) {
@@ -541,6 +542,8 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
   const double gs = ed->partial_pressure_scale > 0 ? ed->partial_pressure_scale : 0.0;
   c->ep.scale[1][2] = gs; c->ep.scale[2][2] = gs; c->ep.scale[4][2] = gs;
   c->ep.rp_type = ed->rp_type; c->ep.cp_type = ed->cp_type;
+  if (ed->thermo != WAI_THERMO_IAPWS && ed->thermo != WAI_THERMO_IFC67) { c->err = "unknown thermodynamic formulation"; return -2; }
+  c->ep.thermo = ed->thermo;
   for (int i = 0; i < 6; i++) { c->ep.rp_par[i] = ed->rp_par[i]; c->ep.cp_par[i] = ed->cp_par[i]; }
 
   DeviceMesh& m = c->mesh;

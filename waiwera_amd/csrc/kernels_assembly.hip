@@ -509,7 +509,7 @@ __global__ __launch_bounds__(TPB) void k_transitions(EosParams ep, int n_owned,
   eos_unscale<KIND>(ep, yo, old_region, oldp);
   flu[F_OLD_REGION * stride + c] = (double)region;
   bool transition = false, changed = false;
-  int err = eos_transition<KIND>(oldp, prim, old_region, old_t, region, transition);
+  int err = eos_transition<KIND>(ep.thermo, oldp, prim, old_region, old_t, region, transition);
   if (!err) err = eos_check_primary<KIND>(prim, region, changed);
   if (err) { flag_error(flags, c); return; }
   if (transition || changed) {

@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "if97.hip.h"
+#include "ifc67.hip.h"
 
 namespace wai {
 
@@ -49,7 +50,30 @@ struct EosParams {
                           // pressure scale selects adaptive scaling Pg/P (eos_wge.F90:639-674)
   int rp_type, cp_type;
   double rp_par[6], cp_par[6];
+  int thermo;             // "thermodynamics": THERMO_IAPWS (default) | THERMO_IFC67
 };
+
+// thermodynamic formulation dispatch (thermodynamics_type: src/thermodynamics.F90, IAPWS.F90,
+// IFC67.F90); `thermo` is uniform over a launch.  region 1 = liquid water, 2 = steam.
+enum { THERMO_IAPWS = 0, THERMO_IFC67 = 1 };
+namespace th {
+__device__ __forceinline__ int props(int thermo, int region, double p, double t, double& rho, double& u) {
+  if (thermo == THERMO_IFC67) return region == 1 ? ifc67::region1(p, t, rho, u) : ifc67::region2(p, t, rho, u);
+  return region == 1 ? if97::region1(p, t, rho, u) : if97::region2(p, t, rho, u);
+}
+__device__ __forceinline__ double viscosity(int thermo, int region, double t, double p, double rho) {
+  return thermo == THERMO_IFC67 ? ifc67::viscosity(region, t, p, rho) : if97::viscosity(t, rho);
+}
+__device__ __forceinline__ int sat_pressure(int thermo, double t, double& p) {
+  return thermo == THERMO_IFC67 ? ifc67::sat_pressure(t, p) : if97::sat_pressure(t, p);
+}
+__device__ __forceinline__ int sat_temperature(int thermo, double p, double& t) {
+  return thermo == THERMO_IFC67 ? ifc67::sat_temperature(p, t) : if97::sat_temperature(p, t);
+}
+__device__ __forceinline__ int phase_composition(int thermo, int region, double p, double t) {
+  return thermo == THERMO_IFC67 ? ifc67::phase_composition(region) : if97::phase_composition(region, p, t);
+}
+}  // namespace th
 
 // two-row table lookup with end clamping (interpolation.F90:202-222,388-404,494-510)
 __device__ __forceinline__ double lin2(double x, double x0, double x1, double y0, double y1) {
@@ -212,15 +236,15 @@ __device__ __forceinline__ int eos_eval(const EosParams& e, const double* y, int
     s.P = y[0] * e.scale[region][0];
     s.T = e.temperature;
     s.sat[0] = 1.0;
-    const int ph = if97::phase_composition(region, s.P, s.T);
+    const int ph = th::phase_composition(e.thermo, region, s.P, s.T);
     if (ph <= 0) return 1;
     s.phases = (double)ph;
     double rho, u;
-    const int err = (region == 1) ? if97::region1(s.P, s.T, rho, u) : if97::region2(s.P, s.T, rho, u);
+    const int err = th::props(e.thermo, region == 1 ? 1 : 2, s.P, s.T, rho, u);
     if (err) return err;
     s.rho[0] = rho; s.u[0] = u; s.h[0] = u + s.P / rho;
     s.kr[0] = 1.0; s.pc[0] = 0.0;
-    s.mu[0] = if97::viscosity(s.T, rho);
+    s.mu[0] = th::viscosity(e.thermo, region == 1 ? 1 : 2, s.T, s.P, rho);
     s.x[0][0] = 1.0; s.pp[0] = s.P;
     return 0;
   } else if constexpr (KIND == EOS_WCE) {
@@ -232,10 +256,10 @@ __device__ __forceinline__ int eos_eval(const EosParams& e, const double* y, int
     s.pp[0] = Pw; s.pp[1] = Pg;
     if (region == 4) {
       double t;
-      if (if97::sat_temperature(Pw, t)) return 1;
+      if (th::sat_temperature(e.thermo, Pw, t)) return 1;
       s.T = t;
     } else s.T = prim[1];
-    const int ph = if97::phase_composition(region, s.P, s.T);
+    const int ph = th::phase_composition(e.thermo, region, s.P, s.T);
     if (ph <= 0) return 1;
     s.phases = (double)ph;
     if (region == 1) { s.sat[0] = 1.0; s.sat[1] = 0.0; }
@@ -250,7 +274,7 @@ __device__ __forceinline__ int eos_eval(const EosParams& e, const double* y, int
       if (ph & (1 << p)) {
         const double wpres = (p == 0) ? s.P : Pw;
         double wrho, wu;
-        const int err = (p == 0) ? if97::region1(wpres, s.T, wrho, wu) : if97::region2(wpres, s.T, wrho, wu);
+        const int err = th::props(e.thermo, p == 0 ? 1 : 2, wpres, s.T, wrho, wu);
         if (err) return err;
         const double grho = (p == 0) ? 0.0 : gas_rho;
         double xg, esol = 0.0;
@@ -261,7 +285,7 @@ __device__ __forceinline__ int eos_eval(const EosParams& e, const double* y, int
           const double tot = grho + wrho;
           xg = (tot < 1.e-30) ? 0.0 : grho / tot;
         }
-        const double wmu = if97::viscosity(s.T, wrho);
+        const double wmu = th::viscosity(e.thermo, p == 0 ? 1 : 2, s.T, wpres, wrho);
         double mu = wmu;
         if (p == 1) {
           double gmu;
@@ -288,10 +312,10 @@ __device__ __forceinline__ int eos_eval(const EosParams& e, const double* y, int
     s.pp[0] = p0;
     if (region == 4) {
       double t;
-      if (if97::sat_temperature(s.P, t)) return 1;
+      if (th::sat_temperature(e.thermo, s.P, t)) return 1;
       s.T = t;
     } else s.T = p1;
-    const int ph = if97::phase_composition(region, s.P, s.T);
+    const int ph = th::phase_composition(e.thermo, region, s.P, s.T);
     if (ph <= 0) return 1;
     s.phases = (double)ph;
     if (region == 1) { s.sat[0] = 1.0; s.sat[1] = 0.0; }
@@ -304,12 +328,12 @@ __device__ __forceinline__ int eos_eval(const EosParams& e, const double* y, int
     for (int p = 0; p < E::nph; p++) {
       if (ph & (1 << p)) {
         double rho, u;
-        const int err = (p == 0) ? if97::region1(s.P, s.T, rho, u) : if97::region2(s.P, s.T, rho, u);
+        const int err = th::props(e.thermo, p == 0 ? 1 : 2, s.P, s.T, rho, u);
         if (err) return err;
         s.rho[p] = rho; s.u[p] = u; s.h[p] = u + s.P / rho;
         s.kr[p] = (p == 0) ? kl : kv;
         s.pc[p] = (p == 0) ? pcl : 0.0;
-        s.mu[p] = if97::viscosity(s.T, rho);
+        s.mu[p] = th::viscosity(e.thermo, p == 0 ? 1 : 2, s.T, s.P, rho);
         s.x[p][0] = 1.0;
       } else {
         s.rho[p] = 0.0; s.u[p] = 0.0; s.h[p] = 0.0; s.kr[p] = 0.0; s.pc[p] = 0.0; s.mu[p] = 0.0;
@@ -541,12 +565,12 @@ __device__ __forceinline__ void source_flow(const CellState<KIND>& s, double rat
 }
 
 // ---- Brent on the saturation line (root_finder.F90:127-248 / eos_we.F90:530-553) -----------
-struct SatLine { double p0, t0, p1, t1, g0, g1; };  // g: gas partial pressure (eos_wge.F90:678-701)
+struct SatLine { double p0, t0, p1, t1, g0, g1; int thermo; };  // g: gas partial pressure (eos_wge.F90:678-701)
 __device__ inline double satline_diff(double x, const SatLine& c) {
   const double P = (1.0 - x) * c.p0 + x * c.p1, T = (1.0 - x) * c.t0 + x * c.t1;
   const double Pg = (1.0 - x) * c.g0 + x * c.g1;
   double ps = 0.0;
-  if97::sat_pressure(T, ps);
+  th::sat_pressure(c.thermo, T, ps);
   return P - Pg - ps;
 }
 
@@ -596,11 +620,11 @@ __device__ __forceinline__ double lerp_clamped(double xi, double a, double b) {
 }
 
 template <int KIND>
-__device__ inline int eos_transition(const double* oldp, double* prim, int old_region,
+__device__ inline int eos_transition(int thermo, const double* oldp, double* prim, int old_region,
                                      double old_temperature, int& region, bool& transition) {
   transition = false;
   if constexpr (KIND == EOS_W) {
-    (void)oldp; (void)old_region; (void)old_temperature; (void)region;
+    (void)thermo; (void)oldp; (void)old_region; (void)old_temperature; (void)region;
     return 0;
   } else {
     constexpr bool wce = (KIND == EOS_WCE);
@@ -625,12 +649,12 @@ __device__ inline int eos_transition(const double* oldp, double* prim, int old_r
         prim[0] = pfac * iw + ig;
         if constexpr (wce) prim[2] = ig;
         double t;
-        const int err = if97::sat_temperature(iw, t);
+        const int err = th::sat_temperature(thermo, iw, t);
         if (err == 0) { prim[1] = t; region = new_region; transition = true; }
         return err;
       }
       double ps;
-      const int err = if97::sat_pressure(old_temperature, ps);
+      const int err = th::sat_pressure(thermo, old_temperature, ps);
       if (err == 0) {
         prim[0] = pfac * ps + (wce ? prim[ig_] : 0.0);
         prim[1] = old_temperature;
@@ -640,12 +664,12 @@ __device__ inline int eos_transition(const double* oldp, double* prim, int old_r
       return err;
     }
     double ps;
-    const int err = if97::sat_pressure(prim[1], ps);
+    const int err = th::sat_pressure(thermo, prim[1], ps);
     if (err) return err;
     const double pw = prim[0] - (wce ? prim[ig_] : 0.0);
     if ((old_region == 1 && pw < ps) || (old_region == 2 && pw > ps)) {
       if constexpr (wce) prim[2] = fmax(0.0, fmin(prim[2], prim[0]));
-      SatLine sl{oldp[0], oldp[1], prim[0], prim[1], wce ? oldp[ig_] : 0.0, wce ? prim[ig_] : 0.0};
+      SatLine sl{oldp[0], oldp[1], prim[0], prim[1], wce ? oldp[ig_] : 0.0, wce ? prim[ig_] : 0.0, thermo};
       double root;
       if (brent_satline(sl, root) == 0) {
         const double ig = wce ? lerp_clamped(root, oldp[ig_], prim[ig_]) : 0.0;

@@ -34,6 +34,7 @@ module waiwera_hip_module
      integer(c_int) :: cp_type
      real(c_double) :: cp_par(6)
      real(c_double) :: partial_pressure_scale
+     integer(c_int) :: thermo   !! 0 IAPWS-97, 1 IFC-67
   end type wai_eos_desc
 
   type, bind(c), public :: wai_solver_opts

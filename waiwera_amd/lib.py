@@ -22,6 +22,7 @@ d, i32 = C.c_double, C.c_int
 pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int)
 
 
+THERMO = {"iapws": 0, "ifc67": 1}   # "thermodynamics" (src/thermodynamics_setup.F90)
 METHOD_KIND = {"beuler": 0, "bdf2": 1, "directss": 2}  # src/timestepper.F90:2262-2275
 
 
@@ -34,7 +35,7 @@ class MeshDesc(C.Structure):
 class EosDesc(C.Structure):
     _fields_ = [("kind", i32), ("temperature", d), ("pressure_scale", d), ("temperature_scale", d),
                 ("rp_type", i32), ("rp_par", d * 6), ("cp_type", i32), ("cp_par", d * 6),
-                ("partial_pressure_scale", d)]
+                ("partial_pressure_scale", d), ("thermo", i32)]
 
 
 class SolverOpts(C.Structure):
@@ -153,7 +154,7 @@ def default_opts(**kw):
 
 
 def eos_desc(kind="we", temperature=20.0, relperm=("linear", [0.0, 1.0, 0.0, 1.0]),
-             capillary=("zero", []), pressure_scale=1.0e6, temperature_scale=1.0e2):
+             capillary=("zero", []), pressure_scale=1.0e6, temperature_scale=1.0e2, thermo="iapws"):
     e = EosDesc()
     LIB.wai_default_eos(C.byref(e), EOS_KIND[kind] if isinstance(kind, str) else kind)
     e.temperature = temperature
@@ -165,6 +166,7 @@ def eos_desc(kind="we", temperature=20.0, relperm=("linear", [0.0, 1.0, 0.0, 1.0
     e.cp_type = CP[capillary[0]]
     for k, v in enumerate(capillary[1]):
         e.cp_par[k] = v
+    e.thermo = THERMO[thermo]
     return e
 
 
