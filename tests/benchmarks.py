@@ -65,3 +65,62 @@ def compare_with_analytical(spec, times, T_obs, T_final, r_centres, max_radius=5
     simr = np.interp(tr[:, 0], r_centres, T_final)
     e_prof = np.abs(simr - tr[:, 1]).max()
     return e_hist, e_prof
+
+
+# ---- tracer/oned: 1-D single-phase and two-phase liquid tracer problems ------------------------
+def load_tracer_oned():
+    with open(os.path.join(HERE, "golden", "benchmark_tracer_oned.json")) as f:
+        return json.load(f)
+
+
+def rock_record(rt):
+    k = rt["permeability"]
+    return np.array([k[0], k[1], k[-1], rt["wet_conductivity"], rt["dry_conductivity"], rt["porosity"],
+                     rt["density"], rt["specific_heat"]])
+
+
+def tracer_oned_mesh(spec, case):
+    inp = spec["cases"][case]["steady_input"]
+    bc = inp["boundaries"][0]
+    src = [dict(cell=s["cell"], rate=s["rate"], enthalpy=s.get("enthalpy", 0.0), component=s.get("component", 0))
+           for s in inp["source"]]
+    ms = spec["mesh"]
+    lm = M.row_mesh_1d(ms["x_edges"], ms["thickness"], radial=False, height=ms["height"],
+                       rock_record=rock_record(inp["rock"]["types"][0]),
+                       inner_bc=(bc["primary"], bc["region"]), sources=src)
+    n = lm.n_owned
+    prim = np.tile(np.asarray(inp["initial"]["primary"], dtype=np.float64), (n, 1))
+    region = np.full(n, int(inp["initial"]["region"]), dtype=np.int32)
+    return lm, prim, region
+
+
+def scale_primaries(prim, region):
+    sc = np.where((region == 4)[:, None], np.array([1.0e6, 1.0]), np.array([1.0e6, 1.0e2]))
+    return (prim / sc).ravel().copy()
+
+
+def run_tracer_oned(make_ode, spec, case, ts_cls):
+    """The *_ss.json run first (adaptive steps to 1e15 s; for the single-phase case the benchmark's
+    transient run starts from the state Waiwera wrote at t = 0, i.e. the initial conditions, so no
+    steady run is made), then the transient tracer run from it.  make_ode(lm, region, y0) ->
+    (ode, y).  Returns (mesh, ode, y, X, timestepper, steady state reached as (P, T|Sv) or None)."""
+    c = spec["cases"][case]
+    lm, prim, region = tracer_oned_mesh(spec, case)
+    ode, y = make_ode(lm, region, scale_primaries(prim, region))
+    steady = None
+    if c["waiwera_steady_state"]["time"] > 0.0:
+        st = c["steady_input"]["time"]
+        ts = ts_cls(ode, y, time=0.0, stepsize=st["step"]["size"], adapt=True,
+                    stop_time=st["stop"], max_num_steps=st["step"]["maximum"]["number"])
+        ts.run()
+        assert ts.time == st["stop"]
+        steady = y[: 2 * lm.n_owned].reshape(-1, 2).copy()
+    tr = c["transient_input"]
+    X = np.zeros(lm.n_owned)
+    ode.set_tracers([0], bc=np.array([[tr["boundaries"][0]["tracer"]]]))
+    tt = tr["time"]
+    ts = ts_cls(ode, y, time=tt["start"], stepsize=tt["step"]["size"], stop_time=tt["stop"],
+                max_num_steps=tt["step"]["maximum"]["number"], aux_solution=X)
+    ts.init_auxiliary()
+    ts.run()
+    return lm, ode, y, X, ts, steady

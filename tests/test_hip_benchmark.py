@@ -43,3 +43,40 @@ def test_avdonin_problem_on_gpu(oracle, thermo):
     assert np.array_equal(times, to)
     assert np.abs(T_final - To_final).max() < 1e-5 and np.abs(T_obs - To_obs).max() < 1e-5
     sim.destroy(); osim.close()
+
+
+@pytest.mark.parametrize("case", ["single", "two"])
+def test_tracer_oned_on_gpu(oracle, case):
+    """test/benchmark/tracer/oned on the HIP path (IFC-67, tracer auxiliary solve on the device):
+    the two-phase steady state against the one the real Waiwera wrote (oned_two_phase_ss.h5),
+    final pressure / saturation / tracer mass fraction against AUTOUGH2 at the reference's 1e-3."""
+    from waiwera_amd.flow_simulation import FlowSimulation
+    spec = B.load_tracer_oned()
+    ftol = spec["cases"][case]["steady_input"]["time"]["step"]["solver"]["nonlinear"]["tolerance"]["function"]["relative"]
+    sims = []
+
+    def make_ode(lm, region, y0):
+        sim = FlowSimulation(lm, eos="we", thermo="ifc67")
+        sim.set_regions(region)
+        sim.set_opts(ftol_rel=ftol, ksp_rtol=1e-10)
+        sim.set_aux_solver("gmres", rtol=1e-10)
+        sims.append(sim)
+        return sim, y0.copy()
+
+    lm, sim, y, X, ts, steady = B.run_tracer_oned(make_ode, spec, case, Timestepper)
+    c = spec["cases"][case]
+    if steady is not None:
+        w = c["waiwera_steady_state"]
+        Pw = np.asarray(w["fluid_pressure"])
+        assert (np.abs(steady[:, 0] * 1.0e6 - Pw) / Pw).max() < 1.0e-6
+        assert np.abs(steady[:, 1] - np.asarray(w["fluid_vapour_saturation"])).max() < 1.0e-6
+        assert np.array_equal(sim.regions(), np.asarray(w["fluid_region"], dtype=np.int32))
+    a = c["autough2_final_table"]
+    P = y.reshape(-1, 2)[:, 0] * 1.0e6
+    Pa, Xa = np.asarray(a["Pressure"]), np.asarray(a["Tracer/liquid"])
+    assert (np.abs(P - Pa) / Pa).max() < 1.0e-3
+    eX = np.abs(X - Xa)
+    assert np.all((eX <= 1.0e-3 * Xa) | (eX <= 1.0e-4))
+    if case == "two":
+        assert np.abs(y.reshape(-1, 2)[:, 1] - np.asarray(a["Vapour saturation"])).max() < 1.0e-3
+    sim.destroy()

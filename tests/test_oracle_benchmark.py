@@ -38,6 +38,22 @@ class OracleOde:
         r, k = self.o.timestep(y, dt, self.opts)
         return (1, r, k) if r >= 0 else (r, 0, k)
 
+    # auxiliary (tracer) problem
+    auxiliary = False
+
+    def set_tracers(self, phase, **kw):
+        self.o.set_tracers(phase, **kw)
+        self.auxiliary = True
+
+    def aux_lhs(self, t, interval, Al):
+        Al[:] = self.o.tracer_lhs()
+
+    def aux_solve(self, method, dt, ratio, alx_last, alx_last2, X, alx_new):
+        m = {"beuler": 0, "bdf2": 1, "directss": 2}[method]
+        r, its, new = self.o.tracer_solve(m, dt, ratio, alx_last, alx_last2, X, rtol=1e-10)
+        alx_new[:] = new
+        return r, its
+
 
 import pytest
 
@@ -70,3 +86,37 @@ def test_avdonin_problem_against_analytical_solution(oracle, thermo):
         assert dT.max() < 0.05 and dP.max() < 5.0e2
     assert abs(T_obs[-1] - 160.0) < 0.25 and abs(T_final[-1] - 170.0) < 0.05
     osim.close()
+
+
+@pytest.mark.parametrize("case", ["single", "two"])
+def test_tracer_oned_against_autough2(oracle, case):
+    """test/benchmark/tracer/oned: steady flow toward a production well from a Dirichlet boundary
+    carrying tracer, then 10 (single-phase) / 30 (two-phase) steps of 10 days; the reference's test
+    asks pressure and tracer mass fraction within 1e-3 relative (1e-4 absolute) of AUTOUGH2"""
+    spec = B.load_tracer_oned()
+    ftol = spec["cases"][case]["steady_input"]["time"]["step"]["solver"]["nonlinear"]["tolerance"]["function"]["relative"]
+
+    def make_ode(lm, region, y0):
+        osim = ol.OracleSim(oracle, lm, 1, thermo=1)
+        osim.set_regions(region)
+        return OracleOde(osim, ftol), osim.yvec(y0)
+
+    lm, ode, y, X, ts, steady = B.run_tracer_oned(make_ode, spec, case, Timestepper)
+    if steady is not None:   # against the steady state the real Waiwera wrote (oned_two_phase_ss.h5)
+        w = spec["cases"][case]["waiwera_steady_state"]
+        eP = np.abs(steady[:, 0] * 1.0e6 - np.asarray(w["fluid_pressure"])) / np.asarray(w["fluid_pressure"])
+        eS = np.abs(steady[:, 1] - np.asarray(w["fluid_vapour_saturation"]))
+        print("steady state vs Waiwera: rel dP %.2e, dSv %.2e" % (eP.max(), eS.max()))
+        assert eP.max() < 1.0e-6 and eS.max() < 1.0e-6
+    a = spec["cases"][case]["autough2_final_table"]
+    P = y[: 2 * lm.n_owned].reshape(-1, 2)[:, 0] * 1.0e6
+    Pa, Xa = np.asarray(a["Pressure"]), np.asarray(a["Tracer/liquid"])
+    eP = np.abs(P - Pa) / Pa
+    eX = np.abs(X - Xa)
+    print(case, "max rel dP %.2e, max tracer err abs %.2e rel %.2e" % (eP.max(), eX.max(), (eX / np.maximum(Xa, 1e-30)).max()))
+    assert eP.max() < 1.0e-3
+    assert np.all((eX <= 1.0e-3 * Xa) | (eX <= 1.0e-4))
+    if case == "two":
+        Sv = y[: 2 * lm.n_owned].reshape(-1, 2)[:, 1]
+        assert np.abs(Sv - np.asarray(a["Vapour saturation"])).max() < 1.0e-3
+    ode.o.close()

@@ -1,0 +1,151 @@
+"""Generates the benchmark fixtures under tests/golden/ from the reference's benchmark suite
+(/root/reference/test/benchmark): inputs from the run/*.json files, mesh node coordinates from the
+binary gmsh 2.2 files, expected results from the analytical .dat files and from the last tables
+of the AUTOUGH2 listings the reference's own tests compare against.  Only data is transcribed.
+Run here (the reference tree does not exist on the GPU box):  python tools/make_benchmark_fixtures.py
+"""
+import json
+import os
+import re
+import struct
+
+import numpy as np
+
+REF = "/root/reference/test/benchmark"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def msh_nodes_elements(path):
+    b = open(path, "rb").read()
+    i = b.index(b"$Nodes\n") + 7
+    j = b.index(b"\n", i)
+    n = int(b[i:j])
+    p = j + 1
+    nodes = np.zeros((n, 3))
+    for k in range(n):
+        idx, x, y, z = struct.unpack("<iddd", b[p:p + 28])
+        p += 28
+        nodes[idx - 1] = (x, y, z)
+    i = b.index(b"$Elements\n") + 10
+    j = b.index(b"\n", i)
+    ne = int(b[i:j])
+    p = j + 1
+    nn_of = {1: 2, 2: 3, 3: 4, 4: 4, 5: 8, 6: 6, 15: 1}
+    elems, cnt = [], 0
+    while cnt < ne:
+        et, num, nt = struct.unpack("<iii", b[p:p + 12])
+        p += 12
+        nn = nn_of[et]
+        for _ in range(num):
+            vals = struct.unpack("<%di" % (1 + nt + nn), b[p:p + 4 * (1 + nt + nn)])
+            p += 4 * (1 + nt + nn)
+            elems.append((et, [v - 1 for v in vals[1 + nt:]]))
+            cnt += 1
+    return nodes, elems
+
+
+KNOWN_COLUMNS = ["Pressure", "Temperature", "Vapour saturation", "Liquid saturation", "Tracer/liquid",
+                 "Vapour density", "Liquid density", "Generation rate", "Enthalpy", "Tracer mass flow",
+                 "Tracer/sep.liq.", "Steam frac.", "Steam sepa.", "Wellbore pressur", "CO2 partial pres",
+                 "CO2 mass fraction in liquid", "CO2 mass fraction in vapour"]
+
+
+def last_table(listing, title):
+    """rows of the last `title` table of an AUTOUGH2 listing: (column names, {name: [values]})"""
+    lines = open(listing).read().split("\n")
+    idx = [i for i, l in enumerate(lines) if title in l][-1]
+    header = lines[idx + 2]
+    found = sorted((header.index(nm), nm) for nm in KNOWN_COLUMNS if nm in header)
+    cols = [nm for _, nm in found]
+    rows = []
+    for l in lines[idx + 3:]:
+        if rows and (not l.strip() or set(l.strip()) <= set("EGB")):
+            break
+        nums = re.findall(r"[-+]?\d\.\d+E[-+]\d+", l)
+        if nums:
+            rows.append([float(v) for v in nums])
+    ncol = len(rows[0])
+    names = cols[-ncol:]
+    return {nm: [r[k] for r in rows] for k, nm in enumerate(names)}
+
+
+def h5_last(path, dataset):
+    """last time row of a Waiwera output dataset, through h5dump (no h5py in this image)"""
+    import subprocess
+    txt = subprocess.check_output(["/opt/conda/bin/h5dump", "-m", "%.17g", "-d", dataset, "-w", "0", path], text=True)
+    rows = {}
+    for m in re.finditer(r"\((\d+),\d+(?:,\d+)?\):\s*([^\n]*)", txt):
+        rows.setdefault(int(m.group(1)), []).extend(float(v) for v in m.group(2).replace(",", " ").split())
+    return rows[max(rows)]
+
+
+def h5_state(path):
+    """final cell state of a Waiwera HDF5 output in natural cell order (cell_index maps natural
+    index -> row of the cell datasets, src/flow_simulation.F90 output)"""
+    import subprocess
+    txt = subprocess.check_output(["/opt/conda/bin/h5dump", "-d", "/cell_index", "-w", "0", path], text=True)
+    idx = [int(float(m.group(1))) for m in re.finditer(r"\(\d+,0\):\s*([-0-9.e+]+)", txt)]
+    out = {}
+    for name in ("fluid_pressure", "fluid_temperature", "fluid_vapour_saturation", "fluid_region"):
+        v = h5_last(path, "/cell_fields/" + name)
+        out[name] = [v[i] for i in idx]
+    out["time"] = h5_last(path, "/time")[0]
+    return out
+
+
+def trim_input(d, keep=("boundaries", "initial", "time", "source", "rock", "gravity", "eos", "thermodynamics", "tracer")):
+    out = {k: d[k] for k in keep if k in d}
+    for rt in out.get("rock", {}).get("types", []):
+        if "cells" in rt and len(rt["cells"]) > 8:
+            rt["cells"] = "all" if len(rt["cells"]) else []
+    return out
+
+
+def problem1():
+    base = os.path.join(REF, "model_intercomparison_study", "problem1")
+    d = json.load(open(os.path.join(base, "run", "problem1.json")))
+    nodes, elems = msh_nodes_elements(os.path.join(base, "run", "gproblem1.msh"))
+    xs = sorted(set(np.round(nodes[:, 0], 9)))
+    t = last_table(os.path.join(base, "run", "problem1.listing"), "ELEMENT TABLE")
+    out = {"source": "test/benchmark/model_intercomparison_study/problem1: run/problem1.json, run/gproblem1.msh "
+                     "(node x coordinates), data/*analytical.dat, run/problem1.listing (last ELEMENT TABLE)",
+           "temperature_time_analytical": np.loadtxt(os.path.join(base, "data", "problem1_temperature_time_analytical.dat")).tolist(),
+           "temperature_r_analytical": np.loadtxt(os.path.join(base, "data", "problem1_temperature_r_analytical.dat")).tolist(),
+           "input": trim_input(d),
+           "mesh": {"radial": True, "r_edges": xs, "thickness": float(-nodes[:, 1].min())},
+           "autough2_final_table": {
+               "note": "ELEMENT TABLE after 71 time steps (t = 1e9 s): the 40 cells, innermost first; the "
+                       "reference's test asks Waiwera's temperature to match within 1e-4 relative",
+               "pressure": t["Pressure"][:40], "temperature": t["Temperature"][:40]}}
+    json.dump(out, open(os.path.join(OUT, "benchmark_problem1_avdonin.json"), "w"), indent=1)
+
+
+def tracer_oned():
+    base = os.path.join(REF, "tracer", "oned", "run")
+    nodes, elems = msh_nodes_elements(os.path.join(base, "goned.msh"))
+    xs = sorted(set(np.round(nodes[:, 0], 9)))
+    out = {"source": "test/benchmark/tracer/oned: run/oned_{single,two}_phase{,_ss}.json, run/goned.msh (node "
+                     "coordinates), run/oned_{single,two}_phase.listing (last ELEMENT / GENERATION tables; the "
+                     "reference's test: pressure and tracer mass fraction within 1e-3 relative, 1e-4 absolute)",
+           "mesh": {"x_edges": xs, "height": float(-nodes[:, 1].min()), "thickness": 1.0}, "cases": {}}
+    for name in ("single", "two"):
+        ss = json.load(open(os.path.join(base, "oned_%s_phase_ss.json" % name)))
+        tr = json.load(open(os.path.join(base, "oned_%s_phase.json" % name)))
+        t = last_table(os.path.join(base, "oned_%s_phase.listing" % name), "ELEMENT TABLE")
+        g = last_table(os.path.join(base, "oned_%s_phase.listing" % name), "GENERATION TABLE")
+        n = len(xs) - 1
+        out["cases"][name] = {
+            "steady_input": trim_input(ss), "transient_input": trim_input(tr),
+            # the initial state of the transient run as shipped with the benchmark: Waiwera's own
+            # output of the *_ss.json run (single-phase: written at t = 0, i.e. the initial
+            # conditions; two-phase: the steady state reached at t = 1e15 s)
+            "waiwera_steady_state": h5_state(os.path.join(base, "oned_%s_phase_ss.h5" % name)),
+            "autough2_final_table": {k: t[k][:n] for k in ("Pressure", "Temperature", "Vapour saturation", "Tracer/liquid")},
+            "autough2_final_generation": {k: g[k][0] for k in ("Generation rate", "Enthalpy", "Tracer mass flow")}}
+    json.dump(out, open(os.path.join(OUT, "benchmark_tracer_oned.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    problem1()
+    tracer_oned()
+    print("fixtures written to", OUT)

@@ -618,52 +618,65 @@ def partition_shape(n):
     return tuple(p)
 
 
-def radial_mesh_1d(r_edges, thickness, rock_record=None, outer_bc=None, sources=None, chunk=512):
-    """One row of cells in a 2-D radial mesh (`"mesh": {"radial": true}`), as the reference's
-    radial benchmark problems use: cell i spans r_edges[i]..r_edges[i+1] over `thickness`.
-    Geometry by Pappus' theorem like src/mesh.F90:369-432: volume = dr * thickness * 2 pi r_c,
-    face area = thickness * 2 pi r_f; faces are vertical, so the gravity term g.n is zero and the
-    permeability direction is 1.  outer_bc = (primary, region) puts a Dirichlet ghost cell on the
-    outermost face (distances (d, 0), src/mesh.F90:647-651).  sources: [{cell, rate, enthalpy,
-    component}].  Preconditioner subdomains: chunks of `chunk` consecutive cells."""
-    r = np.asarray(r_edges, dtype=np.float64)
+def row_mesh_1d(edges, thickness, radial=False, height=1.0, rock_record=None, inner_bc=None,
+                outer_bc=None, sources=None, chunk=512):
+    """One row of cells of a 2-D mesh as the reference's 1-D benchmark problems use it: cell i spans
+    edges[i]..edges[i+1].  radial=True (`"mesh": {"radial": true}`): geometry by Pappus' theorem
+    like src/mesh.F90:369-432, volume = dr * thickness * 2 pi r_c, face area = thickness * 2 pi r_f
+    (`thickness` is then the vertical extent).  Cartesian (`"mesh": {"thickness": t}`, :355-364,
+    404-414): volume = dx * height * t, face area = height * t.  Faces are vertical planes: the
+    gravity term g.n is zero and the permeability direction is 1.  inner_bc / outer_bc = (primary,
+    region) put a Dirichlet ghost cell on the first / last face (distances (d, 0),
+    src/mesh.F90:647-651; boundary cells follow the owned cells in that order).  sources:
+    [{cell, rate, enthalpy, component}].  Preconditioner subdomains: chunks of consecutive cells."""
+    r = np.asarray(edges, dtype=np.float64)
     n = r.size - 1
     rc, dr = 0.5 * (r[1:] + r[:-1]), np.diff(r)
+
+    def area(x):
+        return thickness * 2.0 * np.pi * x if radial else height * thickness + 0.0 * x
+
+    zc = -0.5 * (thickness if radial else height)
     m = LocalMesh(dims=(n, 1, 1), spacing=(float(dr[0]), 0.0, float(thickness)), part=(1, 1, 1), rank=0,
                   brick=(chunk, 1, 1), n_global=n)
     m.n_owned, m.n_halo = n, 0
     fc = np.stack([np.arange(n - 1), np.arange(1, n)], axis=1)
     fg = np.zeros((n - 1, 12))
-    fg[:, 0] = thickness * 2.0 * np.pi * r[1:-1]
+    fg[:, 0] = area(r[1:-1])
     fg[:, 1] = 0.5 * dr[:-1]
     fg[:, 2] = 0.5 * dr[1:]
     fg[:, 3] = fg[:, 1] + fg[:, 2]
     fg[:, 4] = 1.0
     fg[:, 8] = r[1:-1]
-    fg[:, 10] = -0.5 * thickness
+    fg[:, 10] = zc
     fg[:, 11] = 1
-    m.n_bc = 0
-    if outer_bc is not None:
+    bcs = []
+    for which, bc in (("inner", inner_bc), ("outer", outer_bc)):
+        if bc is None:
+            continue
+        cell = 0 if which == "inner" else n - 1
+        xf = r[0] if which == "inner" else r[-1]
         g = np.zeros((1, 12))
-        g[0, 0] = thickness * 2.0 * np.pi * r[-1]
-        g[0, 1] = 0.5 * dr[-1]
-        g[0, 3] = 0.5 * dr[-1]
-        g[0, 4] = 1.0
-        g[0, 8] = r[-1]
-        g[0, 10] = -0.5 * thickness
+        g[0, 0] = area(np.array(xf))
+        g[0, 1] = 0.5 * dr[cell]
+        g[0, 3] = 0.5 * dr[cell]
+        g[0, 4] = -1.0 if which == "inner" else 1.0
+        g[0, 8] = xf
+        g[0, 10] = zc
         g[0, 11] = 1
-        fc = np.concatenate([fc, np.array([[n - 1, n]])])
+        fc = np.concatenate([fc, np.array([[cell, n + len(bcs)]])])
         fg = np.concatenate([fg, g])
-        prim, region = outer_bc
-        m.bc_primary = np.asarray(prim, dtype=np.float64)[None, :]
-        m.bc_region = np.array([int(region)], dtype=np.int32)
-        m.n_bc = 1
+        bcs.append((bc, xf))
+    m.n_bc = len(bcs)
+    if bcs:
+        m.bc_primary = np.array([np.asarray(b[0][0], dtype=np.float64) for b in bcs])
+        m.bc_region = np.array([int(b[0][1]) for b in bcs], dtype=np.int32)
     m.face_cells, m.face_geom, m.n_faces = fc.astype(np.int32), fg, fc.shape[0]
     cg = np.zeros((n + m.n_bc, 4))
-    cg[:n, 0], cg[:n, 2] = rc, -0.5 * thickness
-    cg[:n, 3] = dr * thickness * 2.0 * np.pi * rc
-    if m.n_bc:
-        cg[n, 0], cg[n, 2] = r[-1], -0.5 * thickness
+    cg[:n, 0], cg[:n, 2] = rc, zc
+    cg[:n, 3] = dr * thickness * 2.0 * np.pi * rc if radial else dr * height * thickness
+    for k, b in enumerate(bcs):
+        cg[n + k, 0], cg[n + k, 2] = b[1], zc
     m.cell_geom = cg
     rock = np.zeros((n + m.n_bc, 8))
     rock[:] = default_rock(1)[0] if rock_record is None else np.asarray(rock_record, dtype=np.float64)
@@ -681,3 +694,9 @@ def radial_mesh_1d(r_edges, thickness, rock_record=None, outer_bc=None, sources=
         m.src_enthalpy = np.array([s.get("enthalpy", 0.0) for s in sources], dtype=np.float64)
         m.src_component = np.array([s.get("component", 0) for s in sources], dtype=np.int32)
     return m
+
+
+def radial_mesh_1d(r_edges, thickness, rock_record=None, outer_bc=None, sources=None, chunk=512):
+    """1-D radial row (row_mesh_1d with radial=True)."""
+    return row_mesh_1d(r_edges, thickness, radial=True, rock_record=rock_record, outer_bc=outer_bc,
+                       sources=sources, chunk=chunk)
