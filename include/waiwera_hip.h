@@ -86,6 +86,7 @@ typedef struct wai_solver_opts {
   double ftol_rel, ftol_abs;   /* nonlinear.tolerance.function.{relative 1e-5, absolute 1} */
   double utol_rel, utol_abs;   /* nonlinear.tolerance.update.{relative 1e-10, absolute 1} */
   double fd_eps, fd_umin;      /* nonlinear.jacobian.differencing.{increment 1e-8, tolerance 1e-2} */
+  int min_newton_its;          /* nonlinear.minimum.iterations, default 0 (timestepper.F90:1930-1932) */
 } wai_solver_opts;
 
 void wai_default_eos(wai_eos_desc *e, int kind);

@@ -163,6 +163,7 @@ int wo_ksp_solve(wo_sim *s, int ksp_type, int restart, const double *val, const 
 typedef struct wo_newton_opts {
   int ksp_type, restart, ksp_maxits, max_newton_its, jac_mode;
   double ksp_rtol, ksp_atol, ftol_rel, ftol_abs, utol_rel, utol_abs, fd_eps, fd_umin;
+  int min_newton_its;          /* nonlinear.minimum.iterations (timestepper.F90:1930-1932) */
 } wo_newton_opts;
 void wo_newton_opts_default(wo_newton_opts *o);
 int wo_newton_step(wo_sim *s, const wo_newton_opts *o, int iter, double dt, double *y,

@@ -1144,6 +1144,7 @@ void wo_newton_opts_default(wo_newton_opts *o) {
   o->ftol_rel = 1.e-5; o->ftol_abs = 1.0;     /* timestepper.F90:1998-2001 */
   o->utol_rel = 1.e-10; o->utol_abs = 1.0;
   o->fd_eps = 1.e-8; o->fd_umin = 1.e-2;      /* timestepper.F90:1572-1573 */
+  o->min_newton_its = 0;
 }
 
 static double norm2(wo_sim *s, const double *v, int n) { return sqrt(gdot(s, v, v, n)); }
@@ -1159,7 +1160,8 @@ static int snes_convergence(wo_sim *s, const wo_newton_opts *o, int it, const do
   else if (it == 0) { if (fnorm < 1.e-50) reason = 3; }
   else if (fnorm <= 1.e-8 * fnorm0) reason = 4;
   else if (fnorm > 1.e8 * fnorm0) reason = -9;
-  if (*max_residual < o->ftol_rel) reason = 1;
+  if (it < o->min_newton_its) reason = 0; /* nonlinear_solver_minimum_iterations */
+  else if (*max_residual < o->ftol_rel) reason = 1;
   else if (it > 0) {
     double mu;
     wo_max_scaled(s, update, y, o->utol_abs, &mu, &loc);

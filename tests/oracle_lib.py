@@ -23,7 +23,7 @@ class NewtonOpts(C.Structure):
     _fields_ = [("ksp_type", i32), ("restart", i32), ("ksp_maxits", i32),
                 ("max_newton_its", i32), ("jac_mode", i32),
                 ("ksp_rtol", d), ("ksp_atol", d), ("ftol_rel", d), ("ftol_abs", d),
-                ("utol_rel", d), ("utol_abs", d), ("fd_eps", d), ("fd_umin", d)]
+                ("utol_rel", d), ("utol_abs", d), ("fd_eps", d), ("fd_umin", d), ("min_newton_its", i32)]
 
 
 ROOTFN = C.CFUNCTYPE(d, d, C.c_void_p)
@@ -121,7 +121,7 @@ def load(path):
 class OracleSim:
     """Thin object wrapper over the oracle's wo_sim for the tests / cpu baseline."""
 
-    def __init__(self, L, mesh, eos_kind, thermo=0):
+    def __init__(self, L, mesh, eos_kind, thermo=0, relperm=None):
         self.L = L
         self.mesh = mesh
         self._keep = [f64(mesh.face_geom), f64(mesh.cell_geom), f64(mesh.rock), i32a(mesh.face_cells)]
@@ -130,6 +130,10 @@ class OracleSim:
                                  ip(fc), dp(fg), dp(cg), dp(rk))
         self.eos = L.wo_sim_eos(self.h).contents
         self.eos.thermo = thermo   # 0 IAPWS-97, 1 IFC-67; before the boundary fluid is evaluated
+        if relperm is not None:    # (type name, parameters) like waiwera_amd.lib.eos_desc
+            self.eos.rp_type = RP[relperm[0]]
+            for k, v in enumerate(relperm[1]):
+                self.eos.rp_par[k] = v
         self.np = self.eos.np
         self.df = self.eos.df
         self.n_owned, self.n_prim = mesh.n_owned, mesh.n_owned + mesh.n_halo

@@ -80,3 +80,58 @@ def test_tracer_oned_on_gpu(oracle, case):
     if case == "two":
         assert np.abs(y.reshape(-1, 2)[:, 1] - np.asarray(a["Vapour saturation"])).max() < 1.0e-3
     sim.destroy()
+
+
+def _wce_sim(lm, region, y0, relperm, sims):
+    from waiwera_amd.flow_simulation import FlowSimulation
+
+    class Sim(FlowSimulation):
+        def state(self, y):
+            f = B.wce_fields(self.fluid()[:1])
+            return f["Pressure"][0], f["Temperature"][0], f["Vapour saturation"][0]
+
+    sim = Sim(lm, eos="wce", thermo="ifc67", relperm=relperm)
+    sim.set_regions(region)
+    sims.append(sim)
+    return sim, y0.copy()
+
+
+def test_co2_one_cell_on_gpu(oracle):
+    """test/benchmark/ncg/co2_one_cell on the HIP path (eos wce, IFC-67, Corey curves): histories
+    against AUTOUGH2 at the reference's 1e-3"""
+    spec = B.load_fixture("benchmark_co2_one_cell.json")
+    sims = []
+    hist, sim = B.run_co2_one_cell(lambda lm, r, y0, rp: _wce_sim(lm, r, y0, rp, sims), spec, Timestepper)
+    a = spec["autough2_history"]
+    assert np.allclose(hist[:, 0], a["time"])
+    for k, name in ((1, "Pressure"), (2, "Temperature"), (3, "Vapour saturation")):
+        ref = np.asarray(a[name])
+        assert (np.abs(hist[:, k] - ref) / np.abs(ref)).max() < 1.0e-3, name
+    sim.destroy()
+
+
+@pytest.mark.parametrize("case", ["0", "1"])
+def test_co2_column_on_gpu(oracle, case):
+    """test/benchmark/ncg/co2_column steady states on the HIP path, with the same bounds as the
+    oracle test (tests/test_oracle_benchmark.py) and against the oracle's own steady state"""
+    from tests.test_oracle_benchmark import OracleWceOde
+    spec = B.load_fixture("benchmark_co2_column.json")
+    sims = []
+    lm, sim, y, ts = B.run_co2_column(lambda lm, r, y0, rp: _wce_sim(lm, r, y0, rp, sims), spec, case, Timestepper)
+    assert ts.time == 1.0e15
+    f = B.wce_fields(sim.fluid()[: lm.n_owned])
+    names = ("Pressure", "Temperature", "Vapour saturation", "CO2 mass fraction")
+    worst = B.field_errors(f, spec["cases"][case]["autough2_final_table"], names)
+    assert max(worst[k][0] for k in ("Pressure", "Temperature")) < 2.0e-4
+    assert max(v[0] for v in worst.values()) < 2.0e-3 and max(v[1] for v in worst.values()) < 3.0e-3
+
+    def make_ode(lm_, region, y0, relperm):
+        osim = ol.OracleSim(oracle, lm_, 2, thermo=1, relperm=relperm)
+        osim.set_regions(region)
+        return OracleWceOde(osim, 1.0e-5), osim.yvec(y0)
+
+    lmo, ode, yo, tso = B.run_co2_column(make_ode, spec, case, Timestepper)
+    fo = B.wce_fields(ode.o.fluid()[: lm.n_owned])
+    both = B.field_errors(f, fo, names)
+    assert max(v[1] for v in both.values()) < 1.0e-5
+    sim.destroy(); ode.o.close()

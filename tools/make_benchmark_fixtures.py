@@ -47,7 +47,19 @@ def msh_nodes_elements(path):
 KNOWN_COLUMNS = ["Pressure", "Temperature", "Vapour saturation", "Liquid saturation", "Tracer/liquid",
                  "Vapour density", "Liquid density", "Generation rate", "Enthalpy", "Tracer mass flow",
                  "Tracer/sep.liq.", "Steam frac.", "Steam sepa.", "Wellbore pressur", "CO2 partial pres",
-                 "CO2 mass fraction in liquid", "CO2 mass fraction in vapour"]
+                 "Gas saturatio", "CO2 partial pres", "CO2 mass fractio", "Capillary press", "Gas density",
+                 "Liquid densit", "CO2 frac."]
+
+
+def header_columns(header):
+    """known column names present in a table header, left to right (longest name per position)"""
+    best = {}
+    for nm in KNOWN_COLUMNS:
+        if nm in header:
+            pos = header.index(nm)
+            if pos not in best or len(nm) > len(best[pos]):
+                best[pos] = nm
+    return [best[k] for k in sorted(best)]
 
 
 def last_table(listing, title):
@@ -55,8 +67,7 @@ def last_table(listing, title):
     lines = open(listing).read().split("\n")
     idx = [i for i, l in enumerate(lines) if title in l][-1]
     header = lines[idx + 2]
-    found = sorted((header.index(nm), nm) for nm in KNOWN_COLUMNS if nm in header)
-    cols = [nm for _, nm in found]
+    cols = header_columns(header)
     rows = []
     for l in lines[idx + 3:]:
         if rows and (not l.strip() or set(l.strip()) <= set("EGB")):
@@ -93,11 +104,34 @@ def h5_state(path):
     return out
 
 
+def all_tables(listing, title):
+    """every `title` table of a listing with its output time: [(time, {column: [values]})]"""
+    lines = open(listing, errors="replace").read().split("\n")
+    out, time = [], None
+    for i, l in enumerate(lines):
+        m = re.search(r"OUTPUT AFTER\s+\d+ TIME STEPS\s+([-+0-9.E]+) SECONDS", l)
+        if m:
+            time = float(m.group(1))
+        if title in l:
+            header = lines[i + 2]
+            rows = []
+            for r in lines[i + 3:]:
+                if rows and (not r.strip() or set(r.strip()) <= set("EGB")):
+                    break
+                nums = re.findall(r"[-+]?\d\.\d+E[-+]\d+", r)
+                if nums:
+                    rows.append([float(v) for v in nums])
+            names = header_columns(header)[-len(rows[0]):]
+            out.append((time, {nm: [r[k] for r in rows] for k, nm in enumerate(names)}))
+    return out
+
+
 def trim_input(d, keep=("boundaries", "initial", "time", "source", "rock", "gravity", "eos", "thermodynamics", "tracer")):
-    out = {k: d[k] for k in keep if k in d}
-    for rt in out.get("rock", {}).get("types", []):
-        if "cells" in rt and len(rt["cells"]) > 8:
-            rt["cells"] = "all" if len(rt["cells"]) else []
+    import copy
+    out = {k: copy.deepcopy(d[k]) for k in keep if k in d}
+    types = out.get("rock", {}).get("types", [])
+    if len(types) == 1 and "cells" in types[0]:
+        types[0]["cells"] = "all"
     return out
 
 
@@ -145,7 +179,52 @@ def tracer_oned():
     json.dump(out, open(os.path.join(OUT, "benchmark_tracer_oned.json"), "w"), indent=1)
 
 
+def co2_one_cell():
+    base = os.path.join(REF, "ncg", "co2_one_cell", "run")
+    d = json.load(open(os.path.join(base, "co2_one_cell.json")))
+    nodes, elems = msh_nodes_elements(os.path.join(base, "gco2_one_cell.msh"))
+    el = all_tables(os.path.join(base, "co2_one_cell.listing"), "ELEMENT TABLE")
+    ge = all_tables(os.path.join(base, "co2_one_cell.listing"), "GENERATION TABLE")
+    out = {"source": "test/benchmark/ncg/co2_one_cell: run/co2_one_cell.json, run/gco2_one_cell.msh, "
+                     "run/co2_one_cell.listing (ELEMENT / GENERATION table of every output; the reference's test: "
+                     "pressure, temperature, vapour saturation and source enthalpy histories within 1e-3 relative)",
+           "input": trim_input(d),
+           "mesh": {"x_edges": sorted(set(nodes[:, 0])), "height": float(-nodes[:, 1].min()), "thickness": 1.0},
+           "autough2_history": {
+               "time": [t for t, _ in el],
+               "Pressure": [tb["Pressure"][0] for _, tb in el],
+               "Temperature": [tb["Temperature"][0] for _, tb in el],
+               "Vapour saturation": [tb["Gas saturatio"][0] for _, tb in el],
+               "CO2 partial pressure": [tb["CO2 partial pres"][0] for _, tb in el],
+               "Enthalpy": [tb["Enthalpy"][0] for _, tb in ge]}}
+    json.dump(out, open(os.path.join(OUT, "benchmark_co2_one_cell.json"), "w"), indent=1)
+
+
+def co2_column():
+    base = os.path.join(REF, "ncg", "co2_column", "run")
+    nodes, elems = msh_nodes_elements(os.path.join(base, "gco2_column.msh"))
+    ys = sorted(set(np.round(nodes[:, 1], 9)), reverse=True)
+    out = {"source": "test/benchmark/ncg/co2_column: run/co2_column_*.json, run/gco2_column.msh, "
+                     "run/co2_column_*.listing (last ELEMENT TABLE without the atmosphere block; the reference's "
+                     "test: pressure, temperature, vapour saturation and total CO2 mass fraction of the steady "
+                     "state within 1e-3 relative)",
+           "mesh": {"z_edges": ys, "width": float(nodes[:, 0].max() - nodes[:, 0].min()), "thickness": 100.0},
+           "cases": {}}
+    for name in ("0", "0.1", "1", "5"):
+        d = json.load(open(os.path.join(base, "co2_column_%s.json" % name)))
+        t = last_table(os.path.join(base, "co2_column_%s.listing" % name), "ELEMENT TABLE")
+        n = len(ys) - 1
+        inp = trim_input(d)
+        out["cases"][name] = {"input": inp, "autough2_final_table": {
+            "Pressure": t["Pressure"][1:n + 1], "Temperature": t["Temperature"][1:n + 1],
+            "Vapour saturation": t["Gas saturatio"][1:n + 1], "CO2 partial pressure": t["CO2 partial pres"][1:n + 1],
+            "CO2 mass fraction": t["CO2 mass fractio"][1:n + 1]}}
+    json.dump(out, open(os.path.join(OUT, "benchmark_co2_column.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     problem1()
     tracer_oned()
+    co2_one_cell()
+    co2_column()
     print("fixtures written to", OUT)

@@ -253,9 +253,12 @@ int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, doub
     if ((rc = read_scal(c, 0, 16))) break;
     dp = std::sqrt(k.h_scal[S_DP2]);
     *its = i + 1;
-    if (k.h_scal[S_BREAK] != 0.0) *reason = -5;
+    const double brk = k.h_scal[S_BREAK];
+    if (brk == 1.0) *reason = -5;                             // (R,RP) or (V,RP) vanished
+    else if (brk == 2.0) *reason = (dp == 0.0) ? 3 : -5;      // (T,T) = 0: solved exactly, or breakdown
     else if (std::isnan(dp)) *reason = -9;
     else if (dp <= ttol) *reason = (dp <= atol) ? 3 : 2;
+    else if (brk == 3.0) *reason = -5;                        // next rho = 0 without convergence
     else if (dp >= 1.e4 * dp0) *reason = -4;
   }
   k.X = Xsave;
@@ -399,7 +402,8 @@ int snes_convergence(wai_ctx* c, int it, const double* f, const double* lhs_old,
   else if (it == 0) { if (fnorm < 1.e-50) r = 3; }
   else if (fnorm <= 1.e-8 * c->fnorm0) r = 4;
   else if (fnorm > 1.e8 * c->fnorm0) r = -9;
-  if (*max_residual < c->opts.ftol_rel) r = 1;
+  if (it < c->opts.min_newton_its) r = 0;  // nonlinear_solver_minimum_iterations (:1930-1932)
+  else if (*max_residual < c->opts.ftol_rel) r = 1;
   else if (it > 0) {
     double mu;
     if (do_max_scaled(c, update, y, c->opts.utol_abs, &mu, &loc)) return -1;
@@ -513,6 +517,7 @@ void wai_default_opts(wai_solver_opts* o) {
   o->ftol_rel = 1.e-5; o->ftol_abs = 1.0;
   o->utol_rel = 1.e-10; o->utol_abs = 1.0;
   o->fd_eps = 1.e-8; o->fd_umin = 1.e-2;
+  o->min_newton_its = 0;
 }
 
 int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_solver_opts* od,

@@ -860,12 +860,16 @@ __device__ __forceinline__ void derive_scalars(double* s, int phase) {
       s[S_ALPHA] = s[S_RHO] / s[S_D1];
       break;
     case 3:  // omega = (S,T)/(T,T)
-      if (s[S_D2] == 0.0) s[S_BREAK] = 2.0;
-      s[S_OMEGA] = s[S_D1] / s[S_D2];
+      // (T,T) = 0: KSPSolve_BCGS then tests (S,S) -- zero means the half step already solved the
+      // system (exact preconditioner: a single subdomain), x += alpha P and converged; otherwise
+      // breakdown.  omega = 0 makes the X/R update do exactly that: X += alpha P, R = S, so the
+      // (R,R) it reduces is (S,S) for the host to look at.
+      if (s[S_D2] == 0.0) { s[S_BREAK] = 2.0; s[S_OMEGA] = 0.0; }
+      else s[S_OMEGA] = s[S_D1] / s[S_D2];
       break;
     case 4:  // end of iteration: rotate rho, next beta = (rho/rhoold)*(alpha/omega)
       s[S_RHOOLD] = s[S_RHO]; s[S_RHO] = s[S_RHONEW];
-      if (s[S_RHO] == 0.0) s[S_BREAK] = 1.0;
+      if (s[S_RHO] == 0.0 && s[S_BREAK] == 0.0) s[S_BREAK] = 3.0;  // only matters if not converged
       s[S_BETA] = (s[S_RHO] / s[S_RHOOLD]) * (s[S_ALPHA] / s[S_OMEGA]);
       break;
     default: break;

@@ -42,6 +42,7 @@ module waiwera_hip_module
      real(c_double) :: ksp_rtol, ksp_atol
      integer(c_int) :: max_newton_its
      real(c_double) :: ftol_rel, ftol_abs, utol_rel, utol_abs, fd_eps, fd_umin
+     integer(c_int) :: min_newton_its
   end type wai_solver_opts
 
   interface

@@ -700,3 +700,71 @@ def radial_mesh_1d(r_edges, thickness, rock_record=None, outer_bc=None, sources=
     """1-D radial row (row_mesh_1d with radial=True)."""
     return row_mesh_1d(r_edges, thickness, radial=True, rock_record=rock_record, outer_bc=outer_bc,
                        sources=sources, chunk=chunk)
+
+
+def column_mesh_1d(z_edges, area, rock=None, top_bc=None, sources=None, chunk=512, perm_direction=3):
+    """A vertical column of cells, top first: cell i spans z_edges[i]..z_edges[i+1] (descending
+    elevations) with horizontal cross-section `area`.  Face i joins cell i (above) to cell i+1
+    (below), normal pointing down, so the gravity term g.n is +9.8; the Dirichlet ghost of top_bc =
+    (primary, region) sits on the top face (normal up, g.n = -9.8, distances (d, 0)).
+    perm_direction: rock permeability component across the faces (3 for a 3-D column, 2 for the
+    y-vertical 2-D meshes of the reference's column benchmarks).  rock: one (8,) record or (n, 8)."""
+    z = np.asarray(z_edges, dtype=np.float64)
+    n = z.size - 1
+    dz = -np.diff(z)
+    zc = 0.5 * (z[1:] + z[:-1])
+    m = LocalMesh(dims=(1, 1, n), spacing=(0.0, 0.0, float(dz[0])), part=(1, 1, 1), rank=0,
+                  brick=(1, 1, chunk), n_global=n)
+    m.n_owned, m.n_halo = n, 0
+    fc = np.stack([np.arange(n - 1), np.arange(1, n)], axis=1)
+    fg = np.zeros((n - 1, 12))
+    fg[:, 0] = area
+    fg[:, 1] = 0.5 * dz[:-1]
+    fg[:, 2] = 0.5 * dz[1:]
+    fg[:, 3] = fg[:, 1] + fg[:, 2]
+    fg[:, 6] = -1.0
+    fg[:, 7] = GRAVITY
+    fg[:, 10] = z[1:-1]
+    fg[:, 11] = perm_direction
+    m.n_bc = 0
+    if top_bc is not None:
+        g = np.zeros((1, 12))
+        g[0, 0] = area
+        g[0, 1] = 0.5 * dz[0]
+        g[0, 3] = 0.5 * dz[0]
+        g[0, 6] = 1.0
+        g[0, 7] = -GRAVITY
+        g[0, 10] = z[0]
+        g[0, 11] = perm_direction
+        fc = np.concatenate([fc, np.array([[0, n]])])
+        fg = np.concatenate([fg, g])
+        prim, region = top_bc
+        m.bc_primary = np.asarray(prim, dtype=np.float64)[None, :]
+        m.bc_region = np.array([int(region)], dtype=np.int32)
+        m.n_bc = 1
+    m.face_cells, m.face_geom, m.n_faces = fc.astype(np.int32), fg, fc.shape[0]
+    cg = np.zeros((n + m.n_bc, 4))
+    cg[:n, 2] = zc
+    cg[:n, 3] = area * dz
+    if m.n_bc:
+        cg[n, 2] = z[0]
+    m.cell_geom = cg
+    rk = np.zeros((n + m.n_bc, 8))
+    rock = default_rock(1)[0] if rock is None else np.asarray(rock, dtype=np.float64)
+    rk[:n] = rock
+    if m.n_bc:
+        rk[n] = rk[0]
+    m.rock = rk
+    m.sub_ptr = np.append(np.arange(0, n, chunk), n).astype(np.int32)
+    m.owned_gid = np.arange(n)
+    m.nbr_ranks = np.zeros(0, dtype=np.int32)
+    m.send_ptr = np.zeros(1, dtype=np.int32)
+    m.send_idx = np.zeros(0, dtype=np.int32)
+    m.recv_ptr = np.zeros(1, dtype=np.int32)
+    if sources:
+        m.n_src = len(sources)
+        m.src_cell = np.array([s["cell"] for s in sources], dtype=np.int32)
+        m.src_rate = np.array([s["rate"] for s in sources], dtype=np.float64)
+        m.src_enthalpy = np.array([s.get("enthalpy", 0.0) for s in sources], dtype=np.float64)
+        m.src_component = np.array([s.get("component", 0) for s in sources], dtype=np.int32)
+    return m
