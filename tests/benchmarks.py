@@ -243,3 +243,48 @@ def field_errors(got, expected, names):
         out[name] = (np.linalg.norm(d) / nrm if nrm > 0 else np.linalg.norm(d),
                      np.abs(d).max() / scale if scale > 0 else np.abs(d).max())
     return out
+
+
+# ---- minc/doublet_1d: injection / production doublet in a fractured row of cells (MINC) ---------
+def minc_doublet_mesh(spec, case):
+    c = spec["cases"][case]
+    inp, ms = c["input"], spec["mesh"]
+    types = {rt["name"].strip(): rt for rt in inp["rock"]["types"]}
+    g = M.StructuredGrid(tuple(ms["dims"]), spacing=tuple(ms["spacing"]), brick=tuple(ms["dims"]))
+    nx = ms["dims"][0]
+    srcs = [{"ijk": (s["cell"], 0, 0), "rate": s["rate"], "enthalpy": s.get("enthalpy", 0.0),
+             "component": s.get("component", 0)} for s in inp["source"]]
+    mspec = None
+    if inp.get("minc"):
+        mg = inp["minc"]["geometry"]
+        vols = [mg["fracture"]["volume"]] + list(mg["matrix"]["volume"])
+        sp = mg["fracture"]["spacing"]
+        sp = list(sp) if isinstance(sp, (list, tuple)) else [sp] * mg["fracture"]["planes"]
+        frock = rock_record(types[inp["minc"]["rock"]["fracture"]["type"]])
+        mspec = dict(geometry=M.MincGeometry(vols, sp), matrix_rock=rock_record(types[inp["minc"]["rock"]["matrix"]["type"]]))
+    else:
+        frock = rock_record(list(types.values())[0])
+    lm = g.local_mesh(0, rock_fn=lambda gid: np.tile(frock, (len(gid), 1)), sources=srcs, minc=mspec)
+    n = lm.n_owned
+    prim = np.tile(np.asarray(inp["initial"]["primary"], dtype=np.float64), (n, 1))
+    region = np.full(n, int(inp["initial"]["region"]), dtype=np.int32)
+    return lm, prim, region
+
+
+def run_minc_doublet(make_ode, spec, case, ts_cls):
+    lm, prim, region = minc_doublet_mesh(spec, case)
+    inp = spec["cases"][case]["input"]
+    ode, y = make_ode(lm, region, scale_primaries(prim, region), relperm_of(inp["rock"]))
+    tm = inp["time"]
+    ad = tm["step"]["adapt"]
+    ts = ts_cls(ode, y, time=tm["start"], stepsize=tm["step"]["size"], adapt=ad["on"], adapt_min=ad["minimum"],
+                adapt_max=ad["maximum"], reduction=ad["reduction"], amplification=ad["amplification"],
+                max_stepsize=tm["step"]["maximum"]["size"], stop_time=tm["stop"],
+                max_num_steps=tm["step"]["maximum"]["number"])
+    ts.run()
+    return lm, ode, y, ts
+
+
+def we_fields(fl):
+    """named columns of we fluid records"""
+    return {"Pressure": fl[:, 0], "Temperature": fl[:, 1], "Vapour saturation": fl[:, 7 + 8 + 2]}

@@ -135,3 +135,36 @@ def test_co2_column_on_gpu(oracle, case):
     both = B.field_errors(f, fo, names)
     assert max(v[1] for v in both.values()) < 1.0e-5
     sim.destroy(); ode.o.close()
+
+
+@pytest.mark.parametrize("case", ["single", "50", "200"])
+def test_minc_doublet_on_gpu(oracle, case):
+    """test/benchmark/minc/doublet_1d on the HIP path (MINC rows: 8-wide block-ELL, generic
+    substitution sweeps): final state within the reference's 2e-3 of AUTOUGH2, same number of
+    adaptive steps as the oracle run"""
+    from waiwera_amd.flow_simulation import FlowSimulation
+    from tests.test_oracle_benchmark import OracleOde
+    spec = B.load_fixture("benchmark_minc_doublet_1d.json")
+    ftol = spec["cases"][case]["input"]["time"]["step"]["solver"]["nonlinear"]["tolerance"]["function"]["relative"]
+
+    def make_gpu(lm, region, y0, relperm):
+        sim = FlowSimulation(lm, eos="we", thermo="ifc67", relperm=relperm)
+        sim.set_regions(region)
+        sim.set_opts(ftol_rel=ftol)
+        return sim, y0.copy()
+
+    def make_oracle(lm, region, y0, relperm):
+        osim = ol.OracleSim(oracle, lm, 1, thermo=1, relperm=relperm)
+        osim.set_regions(region)
+        return OracleOde(osim, ftol), osim.yvec(y0)
+
+    lm, sim, y, ts = B.run_minc_doublet(make_gpu, spec, case, Timestepper)
+    a = spec["cases"][case]["autough2_final_table"]
+    f = B.we_fields(sim.fluid()[: lm.n_owned])
+    worst = B.field_errors(f, a, ("Pressure", "Temperature", "Vapour saturation"))
+    assert max(v[0] for v in worst.values()) < 2.0e-3
+    lmo, ode, yo, tso = B.run_minc_doublet(make_oracle, spec, case, Timestepper)
+    assert ts.taken == tso.taken
+    both = B.field_errors(f, B.we_fields(ode.o.fluid()[: lm.n_owned]), ("Pressure", "Temperature", "Vapour saturation"))
+    assert max(v[1] for v in both.values()) < 1.0e-4
+    sim.destroy(); ode.o.close()

@@ -184,3 +184,26 @@ def test_co2_column_against_autough2(oracle, case):
     assert max(v[0] for v in worst.values()) < 2.0e-3
     assert max(v[1] for v in worst.values()) < 3.0e-3
     ode.o.close()
+
+
+@pytest.mark.parametrize("case", ["single", "50", "100", "200"])
+def test_minc_doublet_against_autough2(oracle, case):
+    """test/benchmark/minc/doublet_1d: cold injection / production doublet, two-phase, 50 years with
+    adaptive steps; porous medium and MINC (one matrix level, fracture spacing 50 / 100 / 200 m).
+    The reference's test: final pressure, temperature, vapour saturation within 2e-3 of AUTOUGH2."""
+    spec = B.load_fixture("benchmark_minc_doublet_1d.json")
+    ftol = spec["cases"][case]["input"]["time"]["step"]["solver"]["nonlinear"]["tolerance"]["function"]["relative"]
+
+    def make_ode(lm, region, y0, relperm):
+        osim = ol.OracleSim(oracle, lm, 1, thermo=1, relperm=relperm)
+        osim.set_regions(region)
+        return OracleOde(osim, ftol), osim.yvec(y0)
+
+    lm, ode, y, ts = B.run_minc_doublet(make_ode, spec, case, Timestepper)
+    a = spec["cases"][case]["autough2_final_table"]
+    assert lm.n_owned == len(a["Pressure"])
+    f = B.we_fields(ode.o.fluid()[: lm.n_owned])
+    worst = B.field_errors(f, a, ("Pressure", "Temperature", "Vapour saturation"))
+    print("minc doublet", case, {k: "%.1e / %.1e" % v for k, v in worst.items()}, "steps", ts.taken)
+    assert max(v[0] for v in worst.values()) < 2.0e-3
+    ode.o.close()

@@ -222,7 +222,25 @@ def co2_column():
     json.dump(out, open(os.path.join(OUT, "benchmark_co2_column.json"), "w"), indent=1)
 
 
+def minc_doublet_1d():
+    base = os.path.join(REF, "minc", "doublet_1d", "run")
+    out = {"source": "test/benchmark/minc/doublet_1d: run/minc_1d_{single,50,100,200}.json, run/gminc_1d.dat "
+                     "(10 cells of 50 x 50 x 50 m in a row), run/minc_1d_*.listing (last ELEMENT TABLE: fracture "
+                     "cells, then the matrix cells; the reference's test: pressure, temperature and vapour "
+                     "saturation after 50 years within 2e-3)",
+           "mesh": {"dims": [10, 1, 1], "spacing": [50.0, 50.0, 50.0]}, "cases": {}}
+    for name in ("single", "50", "100", "200"):
+        d = json.load(open(os.path.join(base, "minc_1d_%s.json" % name)))
+        t = last_table(os.path.join(base, "minc_1d_%s.listing" % name), "ELEMENT TABLE")
+        inp = trim_input(d)
+        inp["minc"] = d["mesh"].get("minc")
+        out["cases"][name] = {"input": inp, "autough2_final_table": {
+            k: t[k] for k in ("Pressure", "Temperature", "Vapour saturation")}}
+    json.dump(out, open(os.path.join(OUT, "benchmark_minc_doublet_1d.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
+    minc_doublet_1d()
     problem1()
     tracer_oned()
     co2_one_cell()
