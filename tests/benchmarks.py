@@ -288,3 +288,27 @@ def run_minc_doublet(make_ode, spec, case, ts_cls):
 def we_fields(fl):
     """named columns of we fluid records"""
     return {"Pressure": fl[:, 0], "Temperature": fl[:, 1], "Vapour saturation": fl[:, 7 + 8 + 2]}
+
+
+# ---- model intercomparison study problem 2 (radial: Theis, two-phase production, flashing front) --
+def problem2_mesh(spec, case):
+    inp, ms = spec["cases"][case]["input"], spec["mesh"]
+    src = [dict(cell=s["cell"], rate=s["rate"], enthalpy=s.get("enthalpy", 0.0), component=s.get("component", 0))
+           for s in inp["source"]]
+    lm = M.radial_mesh_1d(ms["r_edges"], ms["thickness"], rock_record=rock_record(inp["rock"]["types"][0]),
+                          sources=src)
+    n = lm.n_owned
+    prim = np.tile(np.asarray(inp["initial"]["primary"], dtype=np.float64), (n, 1))
+    region = np.full(n, int(inp["initial"]["region"]), dtype=np.int32)
+    return lm, prim, region
+
+
+def run_problem2(make_ode, spec, case, ts_cls):
+    lm, prim, region = problem2_mesh(spec, case)
+    inp = spec["cases"][case]["input"]
+    ode, y = make_ode(lm, region, scale_primaries(prim, region), relperm_of(inp["rock"]))
+    tm = inp["time"]
+    ts = ts_cls(ode, y, time=tm["start"], stepsize=tm["step"]["size"], stop_time=tm["stop"],
+                max_num_steps=tm["step"]["maximum"]["number"])
+    ts.run()
+    return lm, ode, y, ts

@@ -168,3 +168,25 @@ def test_minc_doublet_on_gpu(oracle, case):
     both = B.field_errors(f, B.we_fields(ode.o.fluid()[: lm.n_owned]), ("Pressure", "Temperature", "Vapour saturation"))
     assert max(v[1] for v in both.values()) < 1.0e-4
     sim.destroy(); ode.o.close()
+
+
+@pytest.mark.parametrize("case,tol", [("a", 1.0e-4), ("b", 1.0e-4), ("c", 1.0e-2)])
+def test_problem2_on_gpu(oracle, case, tol):
+    """model intercomparison study problem 2 on the HIP path (c crosses the saturation line: the
+    transition kernel with Brent on the IFC-67 saturation curve)"""
+    from waiwera_amd.flow_simulation import FlowSimulation
+    spec = B.load_fixture("benchmark_problem2.json")
+    ftol = spec["cases"][case]["input"]["time"]["step"]["solver"]["nonlinear"]["tolerance"]["function"]["relative"]
+
+    def make_gpu(lm, region, y0, relperm):
+        sim = FlowSimulation(lm, eos="we", thermo="ifc67", relperm=relperm)
+        sim.set_regions(region)
+        sim.set_opts(ftol_rel=ftol)
+        return sim, y0.copy()
+
+    lm, sim, y, ts = B.run_problem2(make_gpu, spec, case, Timestepper)
+    assert abs(ts.time - 86400.0) < 1e-6 and ts.taken == 23
+    f = B.we_fields(sim.fluid()[: lm.n_owned])
+    worst = B.field_errors(f, spec["cases"][case]["autough2_final_table"], ("Pressure", "Temperature", "Vapour saturation"))
+    assert max(v[0] for v in worst.values()) < tol
+    sim.destroy()

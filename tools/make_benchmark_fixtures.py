@@ -239,7 +239,27 @@ def minc_doublet_1d():
     json.dump(out, open(os.path.join(OUT, "benchmark_minc_doublet_1d.json"), "w"), indent=1)
 
 
+def problem2():
+    base = os.path.join(REF, "model_intercomparison_study", "problem2")
+    nodes, elems = msh_nodes_elements(os.path.join(base, "run", "gproblem2.msh"))
+    xs = sorted(set(np.round(nodes[:, 0], 9)))
+    out = {"source": "test/benchmark/model_intercomparison_study/problem2: run/problem2{a,b,c}.json, "
+                     "run/gproblem2.msh (node x coordinates), run/problem2*.listing (last ELEMENT TABLE, t = 1 day). "
+                     "Case a: Theis problem, b: radial two-phase production, c: radial flashing front; the "
+                     "reference's test holds Waiwera to AUTOUGH2 within 1e-4 (a, b) and 1e-2 (c) on the "
+                     "pressure / saturation histories at r = 0.5 and 1 m",
+           "mesh": {"radial": True, "r_edges": xs, "thickness": float(-nodes[:, 1].min())}, "cases": {}}
+    n = len(xs) - 1
+    for name in "abc":
+        d = json.load(open(os.path.join(base, "run", "problem2%s.json" % name)))
+        t = last_table(os.path.join(base, "run", "problem2%s.listing" % name), "ELEMENT TABLE")
+        out["cases"][name] = {"input": trim_input(d), "autough2_final_table": {
+            k: t[k][:n] for k in ("Pressure", "Temperature", "Vapour saturation")}}
+    json.dump(out, open(os.path.join(OUT, "benchmark_problem2.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
+    problem2()
     minc_doublet_1d()
     problem1()
     tracer_oned()
