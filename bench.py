@@ -94,9 +94,11 @@ def spmv_bytes(nnzb, n, bs):
 
 def pc_bytes(nnzb, n, bs):
     """Algorithmic bytes of one fused preconditioned-operator launch: the
-    matrix once (blocks + int32 columns), the inverted pivot blocks, the packed row descriptor,
-    and three vectors (x read, z written, aux read for the fused dot)."""
-    return nnzb * (8 * bs * bs + 4) + n * (8 * bs * bs + 4 + 3 * 8 * bs)
+    matrix once (blocks + int32 columns), the packed row descriptor, and three vectors (x read, z
+    written, aux read for the fused dot).  The inverted pivot blocks are only read when the
+    pivot-scaled rows are switched off (WAI_ILU_NOSCALE)."""
+    pivots = 8 * bs * bs if os.environ.get("WAI_ILU_NOSCALE") else 0
+    return nnzb * (8 * bs * bs + 4) + n * (pivots + 4 + 3 * 8 * bs)
 
 
 def traffic_from_profiles(dims):

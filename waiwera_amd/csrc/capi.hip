@@ -715,6 +715,7 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
     // barrier-per-level form on MI355X (0.373 vs 0.346 ms at 4.1 M rows): opt-in only
     s.level_sorted = level_sorted && getenv("WAI_ILU_WAVEPIPE");
     s.fast3 = fast3 && !getenv("WAI_ILU_NOFAST");
+    s.scaled = !getenv("WAI_ILU_NOSCALE");
     {
       const char* e = getenv("WAI_PC_PIPE");
       s.pipe = e && e[0] == '1';  // opt-in: measured slower than k_pc

@@ -59,6 +59,7 @@ struct IluSchedule {
                             // the inverted pivot block
   double* dinv = nullptr;   // inverted pivot blocks, SoA [bb][n]
   bool diag_only = false;   // ILU(0) touches no off-diagonal block in any subdomain (== DILU)
+  bool scaled = true;       // diag_only: rows pre-scaled by the inverted pivots (WAI_ILU_NOSCALE: off)
   bool fast3 = false;         // <= 3 lower and <= 3 upper in-subdomain couplings per row, offsets < 4
   bool level_sorted = false;  // every subdomain's rows are stored in dependency-level order
   bool factored = false;

@@ -231,6 +231,35 @@ __global__ void k_ilu_factor(int n, int nsub, const int* __restrict__ sub_ptr,
   }
 }
 
+// ---- pivot scaling for the diagonal-only case --------------------------------------------------
+// ILU(0) is invariant under block-diagonal row scaling: ILU(0)(S A) = (S L S^-1)(S U), so
+// (L'U')^-1 (S A) = (LU)^-1 A and (L'U')^-1 (S b) = (LU)^-1 b -- the preconditioned operator and
+// right-hand side PETSc's left-preconditioned Krylov methods see are unchanged.  With S = the
+// inverted pivots the scaled pivots are identities: the fused kernel then reads A' = S A (one
+// pass, written here after every factorisation) and no pivot blocks, 32 of ~336 bytes per row less.
+template <int BS>
+__global__ __launch_bounds__(TPB) void k_scale_rows(int n, int W, const double* __restrict__ aval,
+                                                    const double* __restrict__ dinv, double* __restrict__ sval) {
+  constexpr int BB = BS * BS;
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  double d[BB];
+  load_block<BS>(dinv, n, 0, i, d);
+  for (int q = 0; q < W; q++) {
+    double a[BB];
+    load_block<BS>(aval, n, q, i, a);
+#pragma unroll
+    for (int r = 0; r < BS; r++)
+#pragma unroll
+      for (int c = 0; c < BS; c++) {
+        double t = 0.0;
+#pragma unroll
+        for (int e = 0; e < BS; e++) t += d[r * BS + e] * a[e * BS + c];
+        sval[vix<BS>(n, q, r * BS + c, i)] = t;
+      }
+  }
+}
+
 // ---- K6+K8 fused: z = U^-1 L^-1 (A x)  or  z = U^-1 L^-1 r ------------------------------------
 template <int NS>
 __device__ __forceinline__ void wg_reduce_store(double (&v)[NS], double* red, double* partials,
@@ -259,7 +288,7 @@ __device__ __forceinline__ void wg_reduce_store(double (&v)[NS], double* red, do
 // L_ik = A_ik inv(D_k) and U_ij = A_ij exactly and the factor is just the modified pivots.  The
 // matrix row a thread pulled in for the SpMV is then reused for both substitutions and only the
 // inverted pivot block is read from the factor: ~300 instead of ~520 bytes per block row.
-template <int BS, bool SPMV, bool DILU, bool WP, bool FAST>
+template <int BS, bool SPMV, int DILU, bool WP, bool FAST>
 __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n, int W, int nsub, const int* __restrict__ sub_ptr,
                      const int* __restrict__ sub_nlev, const int* __restrict__ row_info,
                      const int* __restrict__ col, const double* __restrict__ aval,
@@ -268,6 +297,10 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
                      double* __restrict__ z, const double* __restrict__ aux, double* partials,
                      int nb_max, int dot, int dbg) {
   constexpr int BB = BS * BS;
+  // DILU == 2: rows pre-scaled by the inverted pivots (k_scale_rows): A' = inv(P) A lives in fval,
+  // the pivots of ILU(0)(A') are identities, so neither dinv nor its two products per row are needed
+  constexpr bool SC = (DILU == 2);
+  const double* __restrict__ mat = SC ? fval : aval;
   extern __shared__ double lds[];  // [T * BS] solution vector, then 32 doubles reduction scratch
   const int s = xcd_remap(blockIdx.x, nsub);
   if (s >= nsub) return;
@@ -317,7 +350,7 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
         if (q < W) {
           const int cg = col[(size_t)q * n + i];
           double blk[BB];
-          load_block<BS>(aval, n, q, i, blk);
+          load_block<BS>(mat, n, q, i, blk);
           if constexpr (SPMV) {
             double xv[BS];
             load_x<BS>(in, cg, xv);
@@ -352,7 +385,19 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
       }
       if constexpr (!SPMV) load_x<BS>(in, i, acc);
       if (SPMV && dot == 2) load_x<BS>(in, i, xin);
-      load_block<BS>(dinv, n, 0, i, dv);
+      if constexpr (!SC) load_block<BS>(dinv, n, 0, i, dv);
+      if constexpr (SC && !SPMV) {  // plain application to an unscaled vector: scale it first
+        load_block<BS>(dinv, n, 0, i, dv);
+        double w0[BS];
+#pragma unroll
+        for (int r = 0; r < BS; r++) {
+          w0[r] = 0.0;
+#pragma unroll
+          for (int k = 0; k < BS; k++) w0[r] += dv[r * BS + k] * acc[k];
+        }
+#pragma unroll
+        for (int r = 0; r < BS; r++) acc[r] = w0[r];
+      }
     } else {
       if constexpr (SPMV) {
 #pragma unroll
@@ -377,7 +422,7 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
           for (int e = 0; e < BB; e++) dv[e] = f[q][e];
         }
     }
-    if constexpr (DILU) {
+    if constexpr (DILU == 1) {
       if (lf == 0) {  // level-0 rows: w = inv(D) t straight away
         double w0[BS];
 #pragma unroll
@@ -469,7 +514,7 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
         }
       }
     }
-    if constexpr (DILU) {
+    if constexpr (DILU == 1) {
       double w1[BS];
 #pragma unroll
       for (int r = 0; r < BS; r++) {
@@ -506,7 +551,9 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
 #pragma unroll
     for (int r = 0; r < BS; r++) {
       double t = 0.0;
-      if constexpr (DILU) {
+      if constexpr (SC) {
+        out[r] = a[r] - sum[r];
+      } else if constexpr (DILU == 1) {
 #pragma unroll
         for (int c = 0; c < BS; c++) t += dv[r * BS + c] * sum[c];
         out[r] = a[r] - t;
@@ -1023,6 +1070,15 @@ int launch_ilu_factor(wai_ctx* c) {
     case 3: hipLaunchKernelGGL(k_ilu_factor<3>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
     default: return -1;
   }
+  if (s.diag_only && s.scaled) {  // fval is not read in the diagonal-only case: it holds inv(P) A from here on
+    const int g = (J.n + TPB - 1) / TPB;
+    switch (J.bs) {
+      case 1: hipLaunchKernelGGL(k_scale_rows<1>, g, TPB, 0, c->stream, J.n, J.W, J.val, s.dinv, s.fval); break;
+      case 2: hipLaunchKernelGGL(k_scale_rows<2>, g, TPB, 0, c->stream, J.n, J.W, J.val, s.dinv, s.fval); break;
+      case 3: hipLaunchKernelGGL(k_scale_rows<3>, g, TPB, 0, c->stream, J.n, J.W, J.val, s.dinv, s.fval); break;
+      default: return -1;
+    }
+  }
   c->ilu.factored = true;
   return 0;
 }
@@ -1056,11 +1112,13 @@ static void launch_pc_bs(wai_ctx* c, bool spmv, const double* in, double* z, int
     }
   }
   if (spmv) {
-    if (s.diag_only) { if (wp) PCL(true, true, true); else PCL(true, true, false); }
-    else { if (wp) PCL(true, false, true); else PCL(true, false, false); }
+    if (s.diag_only && s.scaled) { if (wp) PCL(true, 2, true); else PCL(true, 2, false); }
+    else if (s.diag_only) { if (wp) PCL(true, 1, true); else PCL(true, 1, false); }
+    else { if (wp) PCL(true, 0, true); else PCL(true, 0, false); }
   } else {
-    if (s.diag_only) { if (wp) PCL(false, true, true); else PCL(false, true, false); }
-    else { if (wp) PCL(false, false, true); else PCL(false, false, false); }
+    if (s.diag_only && s.scaled) { if (wp) PCL(false, 2, true); else PCL(false, 2, false); }
+    else if (s.diag_only) { if (wp) PCL(false, 1, true); else PCL(false, 1, false); }
+    else { if (wp) PCL(false, 0, true); else PCL(false, 0, false); }
   }
 #undef PCL
 }
