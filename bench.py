@@ -282,7 +282,7 @@ def main():
                                    % (dims + (grid.n_global,) + tuple(a.brick)),
                        "krylov_iterations_per_newton_step": kits / max(a.steps, 1),
                        "partition": "x".join(str(p) for p in grid.part), "ksp": a.ksp},
-            "roofline": {"bound": "hbm", "kernel": "k_pc<2,spmv,dilu> (fused BCSR SpMV + block ILU(0) apply + dot)",
+            "roofline": {"bound": "hbm", "kernel": "k_pc_park<spmv> (fused BCSR SpMV + block ILU(0) apply + dot; k_pc<2,spmv,dilu> with WAI_PC_PARK=0)",
                          "achieved": achieved_pc, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_pc / HBM_PEAK_GBS, "traffic": traffic_from_profiles(dims) if tuple(a.brick) == (8, 8, 8) else None,
                          "algorithmic_bytes_per_launch": b_pc, "ms_per_launch": ms_pc,

@@ -470,7 +470,7 @@ void free_all(wai_ctx* c) {
   F(c->src.cell); F(c->src.comp); F(c->src.next); F(c->src.rate); F(c->src.enth);
   F(c->J.rowptr); F(c->J.col); F(c->J.val);
   IluSchedule& s = c->ilu;
-  F(s.sub_ptr); F(s.sub_nlev); F(s.row_info); F(s.fval); F(s.dinv);
+  F(s.sub_ptr); F(s.sub_nlev); F(s.row_info); F(s.row_uoff); F(s.fval); F(s.dinv);
   Krylov& k = c->ks;
   F(k.R); F(k.RP); F(k.P); F(k.V); F(k.S); F(k.T); F(k.tmp); F(k.X); F(k.basis); F(k.partials); F(k.scal);
   if (k.h_scal) (void)hipHostFree(k.h_scal);
@@ -648,7 +648,7 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
     else sub = {0, N};
     s.nsub = (int)sub.size() - 1;
     if (sub.front() != 0 || sub.back() != N) { c->err = "sub_ptr must cover [0, n_owned]"; return -2; }
-    std::vector<int> info(N), levf(N), levb(N), nlev(s.nsub, 0);
+    std::vector<int> info(N), uoff(N, 0), levf(N), levb(N), nlev(s.nsub, 0);
     s.max_rows = 0; s.max_lev = 0;
     bool offdiag_fill = false, level_sorted = true, fast3 = true;
     for (int sd = 0; sd < s.nsub; sd++) {
@@ -692,10 +692,14 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
       }
       for (int i = lo; i + 1 < hi; i++)
         if (levf[i] > levf[i + 1] || levb[i] < levb[i + 1]) level_sorted = false;
+      int ucount = 0;
       for (int i = lo; i < hi; i++) {
         const int nL = diag[i] - lfirst[i - lo], nU = ulast[i - lo] - diag[i] - 1;
         if (nL > 3 || nU > 3 || lfirst[i - lo] > 3 || diag[i] > 3) fast3 = false;
+        uoff[i] = ucount;
+        ucount += nU;
       }
+      s.max_ublocks = std::max(s.max_ublocks, ucount);
       if (nlf > 1023 || nlb > 1023) { c->err = "more than 1023 dependency levels in a subdomain"; return -2; }
       for (int i = lo; i < hi; i++)
         info[i] = lfirst[i - lo] | (diag[i] << 4) | (ulast[i - lo] << 8) | (levf[i] << 12) | (levb[i] << 22);
@@ -708,6 +712,7 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
       return -2;
     }
     if (dev_upload(c, &s.sub_ptr, sub) || dev_upload(c, &s.sub_nlev, nlev) || dev_upload(c, &s.row_info, info) ||
+        dev_upload(c, &s.row_uoff, uoff) ||
         dev_alloc(c, &s.fval, (size_t)J.W * np * np * N) || dev_alloc(c, &s.dinv, (size_t)np * np * N))
       return -1;
     s.diag_only = !offdiag_fill && !getenv("WAI_ILU_GENERAL");
@@ -716,6 +721,12 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
     s.level_sorted = level_sorted && getenv("WAI_ILU_WAVEPIPE");
     s.fast3 = fast3 && !getenv("WAI_ILU_NOFAST");
     s.scaled = !getenv("WAI_ILU_NOSCALE");
+    {
+      const char* e = getenv("WAI_PC_PARK");
+      // 160 KB of LDS per CU; a workgroup may use 64 KB
+      const size_t need = ((size_t)(((s.max_rows + 63) / 64) * 64) * np + 32 + (size_t)s.max_ublocks * 4) * sizeof(double);
+      s.park = !(e && e[0] == '0') && need <= 64 * 1024;  // default on; WAI_PC_PARK=0: k_pc
+    }
     {
       const char* e = getenv("WAI_PC_PIPE");
       s.pipe = e && e[0] == '1';  // opt-in: measured slower than k_pc

@@ -637,6 +637,152 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
   }
 }
 
+// ---- K6+K8 fused, upper blocks parked in LDS (bs = 2, pivot-scaled DILU, <= 3+3 couplings) -----
+// k_pc holds a row's three lower and three upper blocks in registers through both sweeps (~100
+// VGPRs: two workgroups per CU), although the upper blocks are only needed once the forward sweep
+// is over and the lower ones are dead by then.  Here the upper blocks go to LDS as the row is
+// loaded (compactly: a brick has ~2.6 in-brick upper couplings per row, 43 KB for 8x8x8) and come
+// back into the lower blocks' registers for the backward sweep.  ~75 VGPRs, 6 waves per SIMD:
+// three resident workgroups per CU (3 x 51 KB of the 160 KB LDS), so one more brick's loads are in
+// flight to cover the latency-bound sweeps of the others.
+// MEASURED (216^3, MI355X, same box): 0.604 ms against k_pc's 0.709 ms; 68 VGPRs, no spills.
+template <bool SPMV>
+__global__ __launch_bounds__(512, 6) void k_pc_park(
+    int n, int W, int nsub, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev,
+    const int* __restrict__ row_info, const int* __restrict__ row_uoff, const int* __restrict__ col,
+    const double* __restrict__ sval, const double* __restrict__ dinv, const double* __restrict__ in,
+    double* __restrict__ z, const double* __restrict__ aux, double* partials, int nb_max, int dot) {
+  constexpr int BS = 2, BB = 4, MLU = 3;
+  extern __shared__ double lds[];  // [T*2] solution, [32] reduction scratch, then parked U blocks
+  const int s = xcd_remap(blockIdx.x, nsub);
+  if (s >= nsub) return;
+  const int lo = sub_ptr[s], R = sub_ptr[s + 1] - lo;
+  const int nl = sub_nlev[s];
+  const int nlf = nl & 0xffff, nlb = nl >> 16;
+  const int tid = threadIdx.x, i = lo + tid;
+  const bool active = tid < R;
+  double* ys = lds;
+  double* upark = lds + (size_t)blockDim.x * BS + 32;
+  double Lf[MLU][BB];
+  int Lc[MLU], Uc[MLU], lf = -1, lb = -1, uo = 0, nU = 0;
+  double xin[BS] = {0.0, 0.0};
+#pragma unroll
+  for (int p = 0; p < MLU; p++) {
+    Lc[p] = tid; Uc[p] = tid;
+#pragma unroll
+    for (int e = 0; e < BB; e++) Lf[p][e] = 0.0;
+  }
+  if (active) {
+    int lfirst, dslot, ulast;
+    unpack_info(row_info[i], lfirst, dslot, ulast, lf, lb);
+    uo = row_uoff[i];
+    nU = ulast - dslot - 1;
+    double acc[BS] = {0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < WMAX; q++) {
+      if (q < W) {
+        const int cg = col[(size_t)q * n + i];
+        double blk[BB];
+        load_block<BS>(sval, n, q, i, blk);
+        if constexpr (SPMV) {
+          double xv[BS];
+          load_x<BS>(in, cg, xv);
+          acc[0] += blk[0] * xv[0] + blk[1] * xv[1];
+          acc[1] += blk[2] * xv[0] + blk[3] * xv[1];
+        }
+        const bool isl = (q >= lfirst) && (q < dslot), isu = (q > dslot) && (q < ulast);
+#pragma unroll
+        for (int p = 0; p < MLU; p++) {
+          const bool tl = isl && (q - lfirst == p), tu = isu && (q - dslot - 1 == p);
+          Lc[p] = tl ? cg - lo : Lc[p];
+          Uc[p] = tu ? cg - lo : Uc[p];
+#pragma unroll
+          for (int e = 0; e < BB; e++) Lf[p][e] = tl ? blk[e] : Lf[p][e];
+        }
+        if (isu) {
+          double* dst = upark + (size_t)(uo + (q - dslot - 1)) * BB;
+          *reinterpret_cast<double2*>(dst) = make_double2(blk[0], blk[1]);
+          *reinterpret_cast<double2*>(dst + 2) = make_double2(blk[2], blk[3]);
+        }
+      }
+    }
+    if constexpr (!SPMV) {  // plain application to an unscaled vector: scale it by the inverted pivot
+      double r[BS], dv[BB];
+      load_x<BS>(in, i, r);
+      load_block<BS>(dinv, n, 0, i, dv);
+      acc[0] = dv[0] * r[0] + dv[1] * r[1];
+      acc[1] = dv[2] * r[0] + dv[3] * r[1];
+    }
+    if (SPMV && dot == 2) load_x<BS>(in, i, xin);
+    *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(acc[0], acc[1]);
+  }
+  __syncthreads();
+  auto gather3 = [&](const int (&cc)[MLU], const double (&ff)[MLU][BB], double* sum) {
+    double2 yk[MLU];
+#pragma unroll
+    for (int p = 0; p < MLU; p++) yk[p] = *reinterpret_cast<const double2*>(ys + cc[p] * 2);
+#pragma unroll
+    for (int r = 0; r < BS; r++) {
+      double part[MLU];
+#pragma unroll
+      for (int p = 0; p < MLU; p++) part[p] = ff[p][r * BS] * yk[p].x + ff[p][r * BS + 1] * yk[p].y;
+      sum[r] = (part[0] + part[1]) + part[2];
+    }
+  };
+  for (int lev = 1; lev < nlf; lev++) {  // forward: y_i = t_i - sum A'_ik y_k
+    if (lf == lev) {
+      const double2 a = *reinterpret_cast<const double2*>(ys + tid * 2);
+      double sum[BS];
+      gather3(Lc, Lf, sum);
+      *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(a.x - sum[0], a.y - sum[1]);
+    }
+    __syncthreads();
+  }
+  // the lower blocks are dead: their registers take the parked upper blocks
+#pragma unroll
+  for (int p = 0; p < MLU; p++) {
+    const bool have = p < nU;
+    const double* src = upark + (size_t)(uo + (have ? p : 0)) * BB;
+    const double2 u0 = *reinterpret_cast<const double2*>(src), u1 = *reinterpret_cast<const double2*>(src + 2);
+    Lf[p][0] = have ? u0.x : 0.0; Lf[p][1] = have ? u0.y : 0.0;
+    Lf[p][2] = have ? u1.x : 0.0; Lf[p][3] = have ? u1.y : 0.0;
+  }
+  double out[BS] = {0.0, 0.0};
+  for (int lev = 0; lev < nlb; lev++) {  // backward: x_i = y_i - sum A'_ij x_j
+    if (lb == lev) {
+      const double2 a = *reinterpret_cast<const double2*>(ys + tid * 2);
+      double sum[BS];
+      gather3(Uc, Lf, sum);
+      out[0] = a.x - sum[0];
+      out[1] = a.y - sum[1];
+      *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(out[0], out[1]);
+    }
+    if (lev + 1 < nlb) __syncthreads();
+  }
+  if (active) *reinterpret_cast<double2*>(z + (size_t)i * 2) = make_double2(out[0], out[1]);
+  if (dot != 0) {
+    double* red = lds + (size_t)blockDim.x * BS;
+    double v[2] = {0.0, 0.0};
+    int slots[2] = {S_D1, S_D2};
+    if (dot == 1) {
+      if (active) {
+        double av[BS];
+        load_x<BS>(aux, i, av);
+        v[0] = out[0] * av[0] + out[1] * av[1];
+      }
+    } else if (dot == 2) {
+      v[0] = xin[0] * out[0] + xin[1] * out[1];
+      v[1] = out[0] * out[0] + out[1] * out[1];
+    } else {
+      v[0] = out[0] * out[0] + out[1] * out[1];
+      slots[0] = S_DP2;
+    }
+    __syncthreads();
+    if (dot == 2) wg_reduce_store<2>(v, red, partials, nb_max, slots, s);
+    else { double v1[1] = {v[0]}; wg_reduce_store<1>(v1, red, partials, nb_max, slots, s); }
+  }
+}
+
 // ---- K6+K8 fused, software-pipelined over bricks (bs = 2, DILU, <= 3+3 couplings) --------------
 // k_pc alternates a load phase (matrix row, x gather: HBM/L2 latency) and the substitution
 // sweeps (LDS latency, ~2 x 22 barrier-separated levels for an 8x8x8 brick), and with ~100 VGPRs
@@ -1102,6 +1248,19 @@ static void launch_pc_bs(wai_ctx* c, bool spmv, const double* in, double* z, int
   } while (0)
   const bool wp = s.level_sorted && !(c->dbg & 2);
   if constexpr (BS == 2) {
+    // upper blocks parked in LDS: three resident workgroups per CU
+    if (s.park && s.diag_only && s.scaled && s.fast3 && T <= 512 && !c->dbg) {
+      const size_t lds_park = lds + (size_t)s.max_ublocks * 4 * sizeof(double);
+      if (spmv)
+        hipLaunchKernelGGL(k_pc_park<true>, grid, T, lds_park, c->stream, J.n, J.W, s.nsub, s.sub_ptr, s.sub_nlev,
+                           s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials,
+                           c->ks.nb_max, dot_mode);
+      else
+        hipLaunchKernelGGL(k_pc_park<false>, grid, T, lds_park, c->stream, J.n, J.W, s.nsub, s.sub_ptr, s.sub_nlev,
+                           s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials,
+                           c->ks.nb_max, dot_mode);
+      return;
+    }
     // software-pipelined persistent variant: needs a workgroup index below nsub for every
     // workgroup's partial, i.e. at least as many bricks as workgroups
     if (spmv && s.pipe && s.diag_only && s.fast3 && J.W == 7 && T <= 512 && !(c->dbg & 3) && s.nsub >= s.pipe_grid) {
