@@ -101,14 +101,14 @@ def pc_bytes(nnzb, n, bs):
     return nnzb * (8 * bs * bs + 4) + n * (pivots + 4 + 3 * 8 * bs)
 
 
-def traffic_from_profiles(dims):
+def traffic_from_profiles(dims, brick):
     """HBM bytes per k_pc launch from the committed rocprofv3 PMC passes (profiles/), collected
     and corrected as MI355X_MICROARCH.md prescribes; only valid for the mesh it was taken on."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic_r1.json")
     if os.path.exists(p):
         try:
             d = json.load(open(p))
-            if list(d.get("dims", [])) == list(dims):
+            if list(d.get("dims", [])) == list(dims) and list(d.get("brick", [])) == list(brick):
                 return d.get("k_pc_hbm_bytes_per_launch")
         except Exception:
             return None
@@ -285,7 +285,7 @@ def main():
                        "partition": "x".join(str(p) for p in grid.part), "ksp": a.ksp},
             "roofline": {"bound": "hbm", "kernel": "k_pc_park<spmv> (fused BCSR SpMV + block ILU(0) apply + dot; k_pc<2,spmv,dilu> with WAI_PC_PARK=0)",
                          "achieved": achieved_pc, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_pc / HBM_PEAK_GBS, "traffic": traffic_from_profiles(dims) if tuple(a.brick) == (8, 8, 8) else None,
+                         "frac": achieved_pc / HBM_PEAK_GBS, "traffic": traffic_from_profiles(dims, a.brick),
                          "algorithmic_bytes_per_launch": b_pc, "ms_per_launch": ms_pc,
                          "spmv": {"kernel": "k_spmv<2> (BCSR SpMV)", "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
                                   "algorithmic_bytes_per_launch": b_spmv, "ms_per_launch": ms}},

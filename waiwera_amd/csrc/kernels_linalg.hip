@@ -231,6 +231,78 @@ __global__ void k_ilu_factor(int n, int nsub, const int* __restrict__ sub_ptr,
   }
 }
 
+// ---- K7 for the diagonal-only case: pivots only ------------------------------------------------
+// When ILU(0) never updates an off-diagonal block (diag_only), the factor is the pivot blocks
+// P_i = A_ii - sum_{k < i in the subdomain} A_ik inv(P_k) A_ki; with the pivot-scaled rows nothing
+// else of the factor is ever read.  One workgroup per subdomain, rows by dependency level, the
+// inverted pivots of the subdomain in LDS; A_ki is the block of row k whose column is i (found
+// among k's <= 3..4 in-subdomain upper slots, served by L2: the subdomain's rows are contiguous).
+// No copy of the matrix, no in-place update of one: ~230 B per row read, 32 B written.
+template <int BS>
+__global__ void k_dilu_pivots(int n, int nsub, const int* __restrict__ sub_ptr,
+                              const int* __restrict__ sub_nlev, const int* __restrict__ row_info,
+                              const int* __restrict__ col, const double* __restrict__ aval,
+                              double* __restrict__ dinv, int* flags) {
+  constexpr int BB = BS * BS;
+  extern __shared__ double pinv[];  // [T][BB]
+  const int s = xcd_remap(blockIdx.x, nsub);
+  if (s >= nsub) return;
+  const int lo = sub_ptr[s], R = sub_ptr[s + 1] - lo;
+  const int nlf = sub_nlev[s] & 0xffff;
+  const int tid = threadIdx.x, i = lo + tid;
+  const bool active = tid < R;
+  int lfirst = 0, dslot = 0, ulast = 0, lf = -1, lb = 0;
+  double P[BB];
+#pragma unroll
+  for (int e = 0; e < BB; e++) P[e] = 0.0;
+  if (active) {
+    unpack_info(row_info[i], lfirst, dslot, ulast, lf, lb);
+    load_block<BS>(aval, n, dslot, i, P);
+  }
+  for (int lev = 0; lev < nlf; lev++) {
+    if (active && lf == lev) {
+      for (int q = lfirst; q < dslot; q++) {
+        const int k = col[(size_t)q * n + i];
+        int kl, kd, ku, kf, kb;
+        unpack_info(row_info[k], kl, kd, ku, kf, kb);
+        double aik[BB], aki[BB], t[BB];
+        load_block<BS>(aval, n, q, i, aik);
+#pragma unroll
+        for (int e = 0; e < BB; e++) aki[e] = 0.0;
+        for (int r2 = kd + 1; r2 < ku; r2++)
+          if (col[(size_t)r2 * n + k] == i) { load_block<BS>(aval, n, r2, k, aki); break; }
+        const double* pk = pinv + (size_t)(k - lo) * BB;
+#pragma unroll
+        for (int r = 0; r < BS; r++)
+#pragma unroll
+          for (int c = 0; c < BS; c++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int e = 0; e < BS; e++) acc += aik[r * BS + e] * pk[e * BS + c];
+            t[r * BS + c] = acc;
+          }
+#pragma unroll
+        for (int r = 0; r < BS; r++)
+#pragma unroll
+          for (int c = 0; c < BS; c++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int e = 0; e < BS; e++) acc += t[r * BS + e] * aki[e * BS + c];
+            P[r * BS + c] -= acc;
+          }
+      }
+      double inv[BB];
+      if (!block_inverse<BS>(P, inv)) atomicMax(&flags[0], 1);
+#pragma unroll
+      for (int e = 0; e < BB; e++) {
+        pinv[(size_t)tid * BB + e] = inv[e];
+        dinv[vix<BS>(n, 0, e, i)] = inv[e];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- pivot scaling for the diagonal-only case --------------------------------------------------
 // ILU(0) is invariant under block-diagonal row scaling: ILU(0)(S A) = (S L S^-1)(S U), so
 // (L'U')^-1 (S A) = (LU)^-1 A and (L'U')^-1 (S b) = (LU)^-1 b -- the preconditioned operator and
@@ -1208,13 +1280,24 @@ static inline int pc_threads(wai_ctx* c) { return ((c->ilu.max_rows + 63) / 64) 
 int launch_ilu_factor(wai_ctx* c) {
   const Bcsr& J = c->J;
   const IluSchedule& s = c->ilu;
-  hipMemcpyAsync(s.fval, J.val, sizeof(double) * (size_t)J.W * J.bs * J.bs * J.n, hipMemcpyDeviceToDevice, c->stream);
   const int grid = ((s.nsub + 7) / 8) * 8, T = pc_threads(c);
+  if (s.diag_only && s.scaled && !getenv("WAI_ILU_FULL_FACTOR")) {
+    // pivots only, then the scaled rows (below): the general factor is never read in this case
+    const size_t lds = (size_t)T * J.bs * J.bs * sizeof(double);
+    switch (J.bs) {
+      case 1: hipLaunchKernelGGL(k_dilu_pivots<1>, grid, T, lds, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.dinv, c->d_flags); break;
+      case 2: hipLaunchKernelGGL(k_dilu_pivots<2>, grid, T, lds, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.dinv, c->d_flags); break;
+      case 3: hipLaunchKernelGGL(k_dilu_pivots<3>, grid, T, lds, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.dinv, c->d_flags); break;
+      default: return -1;
+    }
+  } else {
+  hipMemcpyAsync(s.fval, J.val, sizeof(double) * (size_t)J.W * J.bs * J.bs * J.n, hipMemcpyDeviceToDevice, c->stream);
   switch (J.bs) {
     case 1: hipLaunchKernelGGL(k_ilu_factor<1>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
     case 2: hipLaunchKernelGGL(k_ilu_factor<2>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
     case 3: hipLaunchKernelGGL(k_ilu_factor<3>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
     default: return -1;
+  }
   }
   if (s.diag_only && s.scaled) {  // fval is not read in the diagonal-only case: it holds inv(P) A from here on
     const int g = (J.n + TPB - 1) / TPB;
