@@ -279,8 +279,9 @@ def main():
             "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%dx%dx%d structured eos_we mesh (%d cells), BE steps dt=1e4*2^n s, "
-                                   "BiCGStab + block-Jacobi(%dx%dx%d bricks)/ILU(0), rtol 1e-5"
-                                   % (dims + (grid.n_global,) + tuple(a.brick)),
+                                   "%s + block-Jacobi(%dx%dx%d bricks)/ILU(0), rtol 1e-5"
+                                   % (dims + (grid.n_global, {"bcgs": "BiCGStab", "gmres": "GMRES(30)"}.get(a.ksp, a.ksp))
+                                      + tuple(a.brick)),
                        "krylov_iterations_per_newton_step": kits / max(a.steps, 1),
                        "partition": "x".join(str(p) for p in grid.part), "ksp": a.ksp},
             "roofline": {"bound": "hbm", "kernel": "k_pc_park<spmv> (fused BCSR SpMV + block ILU(0) apply + dot; k_pc<2,spmv,dilu> with WAI_PC_PARK=0)",
