@@ -312,3 +312,34 @@ def run_problem2(make_ode, spec, case, ts_cls):
                 max_num_steps=tm["step"]["maximum"]["number"])
     ts.run()
     return lm, ode, y, ts
+
+
+# ---- model intercomparison study problem 4 (expanding two-phase system with drainage) ----------
+def problem4_mesh(spec):
+    inp, ms = spec["input"], spec["mesh"]
+    n = len(ms["z_edges"]) - 1
+    rock = np.zeros((n, 8))
+    for rt in inp["rock"]["types"]:
+        rock[np.asarray(rt["cells"], dtype=int)] = rock_record(rt)
+    bc = inp["boundaries"][0]
+    src = [dict(cell=s["cell"], rate=s["rate"], enthalpy=s.get("enthalpy", 0.0), component=s.get("component", 0))
+           for s in inp["source"]]
+    lm = M.column_mesh_1d(ms["z_edges"], ms["width"] * ms["thickness"], rock=rock,
+                          top_bc=(bc["primary"], bc["region"]), sources=src, perm_direction=2)
+    prim = np.asarray(inp["initial"]["primary"], dtype=np.float64)
+    region = np.full(n, int(inp["initial"]["region"]), dtype=np.int32)
+    return lm, prim, region
+
+
+def run_problem4(make_ode, spec, ts_cls):
+    lm, prim, region = problem4_mesh(spec)
+    inp = spec["input"]
+    ode, y = make_ode(lm, region, scale_primaries(prim, region), relperm_of(inp["rock"]))
+    tm = inp["time"]
+    ad = tm["step"]["adapt"]
+    ts = ts_cls(ode, y, time=tm["start"], stepsize=tm["step"]["size"], adapt=ad["on"], adapt_min=ad["minimum"],
+                adapt_max=ad["maximum"], reduction=ad["reduction"], amplification=ad["amplification"],
+                max_stepsize=tm["step"]["maximum"]["size"], stop_time=tm["stop"],
+                max_num_steps=tm["step"]["maximum"]["number"])
+    ts.run()
+    return lm, ode, y, ts

@@ -190,3 +190,24 @@ def test_problem2_on_gpu(oracle, case, tol):
     worst = B.field_errors(f, spec["cases"][case]["autough2_final_table"], ("Pressure", "Temperature", "Vapour saturation"))
     assert max(v[0] for v in worst.values()) < tol
     sim.destroy()
+
+
+def test_problem4_on_gpu(oracle):
+    """model intercomparison study problem 4 on the HIP path: 40 years of adaptive steps with the
+    two-phase zone growing through ten cells"""
+    from waiwera_amd.flow_simulation import FlowSimulation
+    spec = B.load_fixture("benchmark_problem4.json")
+    ftol = spec["input"]["time"]["step"]["solver"]["nonlinear"]["tolerance"]["function"]["relative"]
+
+    def make_gpu(lm, region, y0, relperm):
+        sim = FlowSimulation(lm, eos="we", thermo="ifc67", relperm=relperm)
+        sim.set_regions(region)
+        sim.set_opts(ftol_rel=ftol)
+        return sim, y0.copy()
+
+    lm, sim, y, ts = B.run_problem4(make_gpu, spec, Timestepper)
+    assert abs(ts.time - spec["input"]["time"]["stop"]) < 1.0
+    f = B.we_fields(sim.fluid()[: lm.n_owned])
+    worst = B.field_errors(f, spec["autough2_final_table"], ("Pressure", "Temperature", "Vapour saturation"))
+    assert max(v[0] for v in worst.values()) < 2.0e-3
+    sim.destroy()

@@ -229,3 +229,25 @@ def test_problem2_against_autough2(oracle, case, tol):
     print("problem2", case, {k: "%.1e / %.1e" % v for k, v in worst.items()}, "steps", ts.taken, "tries", sum(h[4] for h in ts.history))
     assert max(v[0] for v in worst.values()) < tol
     ode.o.close()
+
+
+def test_problem4_against_autough2(oracle):
+    """model intercomparison study problem 4: 2 km column heated from below, production from the
+    bottom cell for 40 years, a two-phase zone expanding upward against drainage (adaptive steps,
+    phase transitions in ten cells).  Final pressure, temperature and vapour saturation against
+    AUTOUGH2; the reference's test uses 2e-3 on the histories."""
+    spec = B.load_fixture("benchmark_problem4.json")
+    ftol = spec["input"]["time"]["step"]["solver"]["nonlinear"]["tolerance"]["function"]["relative"]
+
+    def make_ode(lm, region, y0, relperm):
+        osim = ol.OracleSim(oracle, lm, 1, thermo=1, relperm=relperm)
+        osim.set_regions(region)
+        return OracleOde(osim, ftol), osim.yvec(y0)
+
+    lm, ode, y, ts = B.run_problem4(make_ode, spec, Timestepper)
+    assert abs(ts.time - spec["input"]["time"]["stop"]) < 1.0
+    f = B.we_fields(ode.o.fluid()[: lm.n_owned])
+    worst = B.field_errors(f, spec["autough2_final_table"], ("Pressure", "Temperature", "Vapour saturation"))
+    print("problem4", {k: "%.1e / %.1e" % v for k, v in worst.items()}, "steps", ts.taken)
+    assert max(v[0] for v in worst.values()) < 2.0e-3
+    ode.o.close()

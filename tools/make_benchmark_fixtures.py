@@ -258,7 +258,26 @@ def problem2():
     json.dump(out, open(os.path.join(OUT, "benchmark_problem2.json"), "w"), indent=1)
 
 
+def problem4():
+    base = os.path.join(REF, "model_intercomparison_study", "problem4", "run")
+    d = json.load(open(os.path.join(base, "problem4.json")))
+    nodes, elems = msh_nodes_elements(os.path.join(base, "gproblem4.msh"))
+    ys = sorted(set(np.round(nodes[:, 1], 9)), reverse=True)
+    t = last_table(os.path.join(base, "problem4.listing"), "ELEMENT TABLE")
+    n = len(ys) - 1
+    # the atmosphere block, if listed, comes first: keep the last n rows
+    out = {"source": "test/benchmark/model_intercomparison_study/problem4: run/problem4.json, run/gproblem4.msh, "
+                     "run/problem4.listing (last ELEMENT TABLE, t = 40 years).  Expanding two-phase system with "
+                     "drainage: 2 km column, production from the bottom cell; the reference's test holds the "
+                     "pressure / temperature / saturation histories to AUTOUGH2 within 2e-3",
+           "mesh": {"z_edges": ys, "width": float(nodes[:, 0].max() - nodes[:, 0].min()), "thickness": d["mesh"]["thickness"]},
+           "input": trim_input(d),
+           "autough2_final_table": {k: t[k][-n:] for k in ("Pressure", "Temperature", "Vapour saturation")}}
+    json.dump(out, open(os.path.join(OUT, "benchmark_problem4.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
+    problem4()
     problem2()
     minc_doublet_1d()
     problem1()
