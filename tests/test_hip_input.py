@@ -1,0 +1,74 @@
+"""The input-file front end (waiwera_amd/simulation.py) on the HIP path: the reference's own
+benchmark inputs (JSON + gmsh files copied as data into tests/golden/inputs by
+tools/make_benchmark_fixtures.py) read, meshed by the generic finite-volume geometry, run, and
+compared with the AUTOUGH2 tables / analytical solutions of the fixtures."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from tests import benchmarks as B
+
+pytestmark = pytest.mark.gpu
+INPUTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inputs")
+
+
+def run(name):
+    from waiwera_amd.simulation import Simulation
+    sim = Simulation.from_json(os.path.join(INPUTS, name))
+    return sim, sim.run()
+
+
+def triple(out):
+    return {"Pressure": out["fluid_pressure"], "Temperature": out["fluid_temperature"],
+            "Vapour saturation": out["fluid_vapour_saturation"]}
+
+
+def test_problem5a():
+    sim, out = run("problem5a.json")
+    assert abs(out["time"] - 315360000.0) < 1.0 and sim.ts.taken == 200
+    worst = B.field_errors(triple(out), B.load_fixture("benchmark_problem5a.json")["autough2_final_table"],
+                           ("Pressure", "Temperature", "Vapour saturation"))
+    assert max(v[0] for v in worst.values()) < 1.0e-3      # the reference's bar
+    sim.ode.destroy()
+
+
+def test_problem1_and_problem2c():
+    sim, out = run("problem1.json")
+    a = B.load_problem1()["autough2_final_table"]
+    assert (np.abs(out["fluid_temperature"] - a["temperature"]) / np.asarray(a["temperature"])).max() < 1.0e-4
+    assert (np.abs(out["fluid_pressure"] - a["pressure"]) / np.asarray(a["pressure"])).max() < 1.0e-4
+    sim.ode.destroy()
+    sim, out = run("problem2c.json")
+    a = B.load_fixture("benchmark_problem2.json")["cases"]["c"]["autough2_final_table"]
+    assert max(v[0] for v in B.field_errors(triple(out), a, ("Pressure", "Temperature", "Vapour saturation")).values()) < 1.0e-2
+    sim.ode.destroy()
+
+
+def test_co2_one_cell_and_column():
+    sim, out = run("co2_one_cell.json")
+    a = B.load_fixture("benchmark_co2_one_cell.json")["autough2_history"]
+    assert abs(out["time"] - 19.0) < 1e-9
+    for name, key in (("Pressure", "fluid_pressure"), ("Temperature", "fluid_temperature"),
+                      ("Vapour saturation", "fluid_vapour_saturation")):
+        assert abs(out[key][0] - a[name][-1]) <= 1.0e-3 * abs(a[name][-1])
+    sim.ode.destroy()
+    sim, out = run("co2_column_1.json")
+    a = B.load_fixture("benchmark_co2_column.json")["cases"]["1"]["autough2_final_table"]
+    worst = B.field_errors(triple(out), a, ("Pressure", "Temperature", "Vapour saturation"))
+    assert max(worst[k][0] for k in ("Pressure", "Temperature")) < 2.0e-4
+    assert worst["Vapour saturation"][0] < 2.0e-3
+    sim.ode.destroy()
+
+
+def test_tracer_decay_input():
+    """test/benchmark/tracer/decay/run/decay.json as it is: three tracers, BDF2, 20 one-day steps"""
+    sim, out = run("decay.json")
+    k0, ea, T, X0 = 1.0e-6, 2.0e3, 60.0, 1.0e-3
+    t = out["time"]
+    assert abs(t - 1728000.0) < 1e-6
+    for name, k in (("no_decay", 0.0), ("constant", k0), ("temperature", k0 * math.exp(-ea / (8.3144598 * (T + 273.15))))):
+        exact = X0 * math.exp(-k * t)
+        assert abs(out["tracer_" + name][0] - exact) <= 1.0e-2 * exact
+    sim.ode.destroy()

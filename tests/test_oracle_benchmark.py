@@ -2,6 +2,8 @@
 Avdonin problem: 160 degC water injected into a 170 degC reservoir, heat conduction 20 W/m/K) run
 through the Python Timestepper with the benchmark's own step list, against the analytical solution
 the reference's benchmark suite ships (tolerance there: 2e-2 relative, i.e. ~3 degC)."""
+import os
+
 import numpy as np
 
 from tests import benchmarks as B
@@ -22,8 +24,27 @@ class OracleOde:
     def pre_eval(self, t, y):
         return self.o.pre_eval(y)
 
+    def fluid(self):
+        return self.o.fluid()
+
+    def set_regions(self, region):
+        self.o.set_regions(region)
+
+    def scale(self, primary, region):
+        prim = np.asarray(primary, dtype=np.float64)
+        region = np.asarray(region)
+        out = prim.copy()
+        out[:, 0] = prim[:, 0] / 1.0e6
+        if prim.shape[1] > 1:
+            out[:, 1] = np.where(region == 4, prim[:, 1], prim[:, 1] / 1.0e2)
+        if prim.shape[1] > 2:
+            out[:, 2] = prim[:, 2] / prim[:, 0]
+        return out
+
     def set_opts(self, **kw):
         for k, v in kw.items():
+            if k == "ksp_type" and isinstance(v, str):
+                v = {"bcgs": 0, "gmres": 1}[v]
             setattr(self.opts, k, v)
 
     def set_timestep_method(self, method):
@@ -251,3 +272,69 @@ def test_problem4_against_autough2(oracle):
     print("problem4", {k: "%.1e / %.1e" % v for k, v in worst.items()}, "steps", ts.taken)
     assert max(v[0] for v in worst.values()) < 2.0e-3
     ode.o.close()
+
+
+# ---- the input-file front end (waiwera_amd/simulation.py) with the oracle behind it -----------
+INPUTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inputs")
+
+
+def oracle_factory(oracle):
+    def make(lm, eos, thermo, relperm, capillary, temperature):
+        assert capillary[0] == "zero"
+        osim = ol.OracleSim(oracle, lm, {"w": 0, "we": 1, "wce": 2}[eos], thermo=1 if thermo == "ifc67" else 0,
+                            relperm=relperm)
+        ode = OracleWceOde(osim, 1.0e-5)
+        ode.num_primary_variables = osim.np
+        return ode
+    return make
+
+
+def run_input(oracle, name):
+    from waiwera_amd.simulation import Simulation
+    sim = Simulation.from_json(os.path.join(INPUTS, name), ode_factory=oracle_factory(oracle))
+    sim.y = sim.ts.y = sim.ode.o.yvec(sim.y)     # the oracle wants room for halo entries
+    out = sim.run()
+    return sim, out
+
+
+def test_input_files_reproduce_the_fixture_runs(oracle):
+    """the reference's own JSON + gmsh files through the generic reader / unstructured geometry give
+    what the hand-built meshes of the tests above give: same AUTOUGH2 agreement"""
+    sim, out = run_input(oracle, "problem1.json")
+    a = B.load_problem1()["autough2_final_table"]
+    assert (np.abs(out["fluid_temperature"] - a["temperature"]) / np.asarray(a["temperature"])).max() < 1.0e-4
+    assert (np.abs(out["fluid_pressure"] - a["pressure"]) / np.asarray(a["pressure"])).max() < 1.0e-4
+    sim.ode.o.close()
+    sim, out = run_input(oracle, "problem2b.json")
+    a = B.load_fixture("benchmark_problem2.json")["cases"]["b"]["autough2_final_table"]
+    got = {"Pressure": out["fluid_pressure"], "Temperature": out["fluid_temperature"], "Vapour saturation": out["fluid_vapour_saturation"]}
+    assert max(v[0] for v in B.field_errors(got, a, list(got)).values()) < 1.0e-4
+    sim.ode.o.close()
+    sim, out = run_input(oracle, "problem4.json")
+    a = B.load_fixture("benchmark_problem4.json")["autough2_final_table"]
+    got = {"Pressure": out["fluid_pressure"], "Temperature": out["fluid_temperature"], "Vapour saturation": out["fluid_vapour_saturation"]}
+    assert max(v[0] for v in B.field_errors(got, a, list(got)).values()) < 2.0e-3
+    sim.ode.o.close()
+    sim, out = run_input(oracle, "co2_column_1.json")
+    a = B.load_fixture("benchmark_co2_column.json")["cases"]["1"]["autough2_final_table"]
+    tot = out["fluid_liquid_saturation"] * out["fluid_liquid_density"] + out["fluid_vapour_saturation"] * out["fluid_vapour_density"]
+    xco2 = (out["fluid_liquid_saturation"] * out["fluid_liquid_density"] * out["fluid_liquid_CO2_mass_fraction"]
+            + out["fluid_vapour_saturation"] * out["fluid_vapour_density"] * out["fluid_vapour_CO2_mass_fraction"]) / tot
+    got = {"Pressure": out["fluid_pressure"], "Temperature": out["fluid_temperature"],
+           "Vapour saturation": out["fluid_vapour_saturation"], "CO2 mass fraction": xco2}
+    assert max(v[0] for v in B.field_errors(got, a, list(got)).values()) < 2.0e-3
+    sim.ode.o.close()
+
+
+def test_problem5a_input_file_against_autough2(oracle):
+    """model intercomparison study problem 5a (2-D areal, 96 cells, production well, cold recharge
+    along one side, 10 years in 200 steps), read from the reference's own input files; the
+    reference's test holds Waiwera to AUTOUGH2 within 1e-3 on the histories"""
+    sim, out = run_input(oracle, "problem5a.json")
+    assert abs(out["time"] - 315360000.0) < 1.0
+    a = B.load_fixture("benchmark_problem5a.json")["autough2_final_table"]
+    got = {"Pressure": out["fluid_pressure"], "Temperature": out["fluid_temperature"], "Vapour saturation": out["fluid_vapour_saturation"]}
+    worst = B.field_errors(got, a, list(got))
+    print("problem5a", {k: "%.1e / %.1e" % v for k, v in worst.items()}, "steps", sim.ts.taken)
+    assert max(v[0] for v in worst.values()) < 1.0e-3
+    sim.ode.o.close()

@@ -276,7 +276,43 @@ def problem4():
     json.dump(out, open(os.path.join(OUT, "benchmark_problem4.json"), "w"), indent=1)
 
 
+def input_files():
+    """The benchmark inputs themselves (JSON + gmsh mesh), for the input-file front end
+    (waiwera_amd/simulation.py): data files of the reference's benchmark suite, copied verbatim."""
+    import shutil
+    dst = os.path.join(OUT, "inputs")
+    os.makedirs(dst, exist_ok=True)
+    mis = os.path.join(REF, "model_intercomparison_study")
+    files = [(mis, "problem1/run/problem1.json"), (mis, "problem1/run/gproblem1.msh"),
+             (mis, "problem2/run/problem2b.json"), (mis, "problem2/run/problem2c.json"), (mis, "problem2/run/gproblem2.msh"),
+             (mis, "problem4/run/problem4.json"), (mis, "problem4/run/gproblem4.msh"),
+             (mis, "problem5/run/problem5a.json"), (mis, "problem5/run/gproblem5.msh"),
+             (REF, "ncg/co2_one_cell/run/co2_one_cell.json"), (REF, "ncg/co2_one_cell/run/gco2_one_cell.msh"),
+             (REF, "ncg/co2_column/run/co2_column_1.json"), (REF, "ncg/co2_column/run/gco2_column.msh"),
+             (REF, "tracer/decay/run/decay.json"), (REF, "tracer/decay/run/decay.msh")]
+    for base, rel in files:
+        src = os.path.join(base, rel)
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(dst, os.path.basename(rel)))
+        else:
+            print("missing", src)
+
+
+def problem5a():
+    base = os.path.join(REF, "model_intercomparison_study", "problem5", "run")
+    t = last_table(os.path.join(base, "problem5a.listing"), "ELEMENT TABLE")
+    d = json.load(open(os.path.join(base, "problem5a.json")))
+    n = len(d["initial"]["primary"])
+    out = {"source": "test/benchmark/model_intercomparison_study/problem5/run/problem5a.listing, last ELEMENT TABLE "
+                     "(t = 10 years; 2-D areal flow to a well with a cold recharge boundary; the reference's test holds "
+                     "the histories to AUTOUGH2 within 1e-3); the input is tests/golden/inputs/problem5a.json",
+           "autough2_final_table": {k: t[k][:n] for k in ("Pressure", "Temperature", "Vapour saturation")}}
+    json.dump(out, open(os.path.join(OUT, "benchmark_problem5a.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
+    input_files()
+    problem5a()
     problem4()
     problem2()
     minc_doublet_1d()

@@ -1,0 +1,283 @@
+"""Runs a simulation described by a Waiwera JSON input file (the subset the hot path covers) on the
+HIP library: the reference's own input format on one side of the path, its output field names on
+the other.
+
+Input keys handled, with the reference's defaults (src/flow_simulation.F90:296-670, 800-846;
+src/mesh.F90:270-300, 1640-1800; src/rock_setup.F90; src/initial.F90:421-677; src/source_setup.F90;
+src/timestepper.F90:1960-2275; src/tracer.F90:63-140; utils/input_schema.json):
+
+  mesh        filename (gmsh MSH 2.2), thickness, radial, zones (all / box ranges on x, y, z)
+  gravity     number | vector | null
+  eos         name w | we | wce, temperature
+  thermodynamics  iapws | ifc67
+  rock        types [cells | zones, permeability, porosity, density, specific_heat, wet / dry
+              conductivity], relative_permeability, capillary_pressure
+  initial     primary (one record or one per cell), region (one or per cell), tracer
+  boundaries  primary, region, faces {cells, normal} (one or a list), tracer
+  source      cell, rate, enthalpy, component, tracer (constant-rate sources only)
+  time        start, stop, step {size, adapt, maximum, method, solver.nonlinear, solver.linear}
+  tracer      name, phase, decay, activation, diffusion
+
+Anything else that changes results (source controls, MINC, rock controls, initial conditions from
+an HDF5 file, ...) raises NotImplementedError instead of being ignored.  Output: `Simulation.run`
+returns the final cell fields under the reference's HDF5 dataset names (fluid_pressure, ...), and
+`save` writes them as a .npz archive.
+"""
+import json
+import os
+
+import numpy as np
+
+from . import gmsh, unstructured
+from .timestepper import Timestepper
+
+UNSUPPORTED_SOURCE_KEYS = ("deliverability", "recharge", "limiter", "separator", "direction", "injectivity",
+                           "interpolation", "averaging", "factor", "network")
+
+
+def _get(d, path, default=None):
+    for k in path.split("."):
+        if not isinstance(d, dict) or k not in d or d[k] is None:
+            return default
+        d = d[k]
+    return d
+
+
+def relperm_spec(rp):
+    """rock.relative_permeability -> (type, parameters) of the library's EOS descriptor"""
+    if rp is None:
+        return "linear", [0.0, 1.0, 0.0, 1.0]
+    t = rp.get("type", "linear").lower()
+    if t == "linear":
+        return "linear", list(rp.get("liquid", [0.0, 1.0])) + list(rp.get("vapour", [0.0, 1.0]))
+    if t in ("fully mobile", "fully_mobile"):
+        return "fully_mobile", []
+    if t in ("corey", "grant"):
+        return t, [rp.get("slr", 0.3), rp.get("ssr", 0.05 if t == "corey" else 0.6)]
+    if t == "pickens":
+        return "pickens", [rp.get("power", 1.0)]
+    if t in ("van genuchten", "van_genuchten"):
+        return "van_genuchten", [rp.get("lambda", 0.45), rp.get("slr", 1.0e-3), rp.get("sls", 1.0),
+                                 1.0 if rp.get("sum_unity", True) else 0.0, rp.get("ssr", 0.6)]
+    raise NotImplementedError("relative permeability type %r" % t)
+
+
+def capillary_spec(cp):
+    if cp is None:
+        return "zero", []
+    t = cp.get("type", "zero").lower()
+    if t == "zero":
+        return "zero", []
+    if t == "linear":
+        s = cp.get("saturation_limits", [0.0, 1.0])
+        if cp.get("pressure", 0.125e5) == 0:
+            return "zero", []
+        return "linear", [s[0], s[1], cp.get("pressure", 0.125e5)]
+    if t in ("van genuchten", "van_genuchten"):
+        pmax = cp.get("Pmax")
+        return "van_genuchten", [cp.get("P0", 0.125e5), cp.get("lambda", 0.45), cp.get("slr", 1.0e-3),
+                                 cp.get("sls", 1.0), pmax if pmax is not None else 0.0, 1.0 if pmax is not None else 0.0]
+    raise NotImplementedError("capillary pressure type %r" % t)
+
+
+def rock_record(rt, dim):
+    k = rt.get("permeability", 1.0e-13)
+    k = [k] * 3 if np.isscalar(k) else list(k) + [k[-1]] * (3 - len(k))
+    return np.array([k[0], k[1], k[2], rt.get("wet_conductivity", 2.5), rt.get("dry_conductivity", rt.get("wet_conductivity", 2.5)),
+                     rt.get("porosity", 0.1), rt.get("density", 2200.0), rt.get("specific_heat", 1000.0)])
+
+
+def zone_cells(zone, centroids):
+    """cells of a "mesh.zones" entry: box ranges on x / y / z (a box without ranges is everything)"""
+    if zone is None:
+        return np.arange(len(centroids))
+    if isinstance(zone, dict):
+        if "cells" in zone:
+            return np.asarray(zone["cells"], dtype=int)
+        sel = np.ones(len(centroids), dtype=bool)
+        for ax, name in enumerate("xyz"):
+            if name in zone and zone[name] is not None:
+                lo, hi = zone[name]
+                sel &= (centroids[:, ax] >= lo) & (centroids[:, ax] <= hi)
+        unknown = set(zone) - {"x", "y", "z", "type", "cells"}
+        if unknown:
+            raise NotImplementedError("mesh zone keys %s" % sorted(unknown))
+        return np.nonzero(sel)[0]
+    raise NotImplementedError("mesh zone %r" % (zone,))
+
+
+class Simulation:
+    """One Waiwera input file -> mesh, flow simulation object and time stepper."""
+
+    def __init__(self, inp, base_dir=".", ode_factory=None, device=0):
+        self.inp = inp
+        if _get(inp, "mesh.minc") is not None:
+            raise NotImplementedError("MINC zones from an input file")
+        if isinstance(inp.get("initial"), dict) and "filename" in inp["initial"]:
+            raise NotImplementedError("initial conditions from an HDF5 file")
+        mesh = inp.get("mesh")
+        if isinstance(mesh, str):
+            mesh = {"filename": mesh}
+        nodes, cells, dim = gmsh.read_msh(os.path.join(base_dir, mesh["filename"]))
+        self.dim = dim
+        n = len(cells)
+        # gravity (flow_simulation.F90:800-846)
+        gin = inp.get("gravity")
+        grav = np.zeros(3)
+        if isinstance(gin, (list, tuple)):
+            grav[: len(gin)] = gin
+        else:
+            grav[dim - 1] = -(gin if gin is not None else (0.0 if dim == 2 else 9.8))
+        # EOS and thermodynamics
+        eos = inp.get("eos", "we")
+        self.eos = (eos.get("name", "we") if isinstance(eos, dict) else eos).lower()
+        temperature = eos.get("temperature", 20.0) if isinstance(eos, dict) else 20.0
+        th = inp.get("thermodynamics", "iapws")
+        self.thermo = (th.get("name", "iapws") if isinstance(th, dict) else th).lower()
+        if self.eos not in ("w", "we", "wce") or self.thermo not in ("iapws", "ifc67"):
+            raise NotImplementedError("eos %r / thermodynamics %r" % (self.eos, self.thermo))
+        # geometry first without rock (centroids are needed for zones), rock filled in below
+        bnds = []
+        for b in inp.get("boundaries", []) or []:
+            faces = b["faces"]
+            for f in (faces if isinstance(faces, list) else [faces]):
+                bnds.append((list(f["cells"]), list(f.get("normal", [0.0, 0.0, 1.0])), b["primary"], b.get("region", 1)))
+        srcs = []
+        for s in inp.get("source", []) or []:
+            bad = [k for k in UNSUPPORTED_SOURCE_KEYS if k in s]
+            if bad:
+                raise NotImplementedError("source controls %s" % bad)
+            if "cell" not in s:
+                raise NotImplementedError("sources given by zones or cell lists")
+            srcs.append(dict(cell=s["cell"], rate=s.get("rate", 0.0), enthalpy=s.get("enthalpy", 83.9e3),
+                             component=s.get("component", 0)))
+        lm = unstructured.build_mesh(nodes, cells, dim, thickness=mesh.get("thickness", 1.0),
+                                     radial=bool(mesh.get("radial", False)), gravity=grav, boundaries=bnds,
+                                     sources=srcs)
+        cen = lm.cell_geom[:n, :3]
+        rock = inp.get("rock", {}) or {}
+        zones = mesh.get("zones", {}) or {}
+        for rt in rock.get("types", []) or []:
+            rec = rock_record(rt, dim)
+            sel = []
+            if "cells" in rt and rt["cells"] is not None:
+                sel.append(np.asarray(rt["cells"], dtype=int))
+            if "zones" in rt and rt["zones"] is not None:
+                for z in ([rt["zones"]] if isinstance(rt["zones"], str) else rt["zones"]):
+                    sel.append(zone_cells(zones.get(z) if z in zones else (None if z == "all" else zones[z]), cen))
+            for idx in sel:
+                lm.rock[idx] = rec
+        for k in range(lm.n_bc):
+            lm.rock[n + k] = lm.rock[lm.face_cells[lm.n_faces - lm.n_bc + k, 0]]
+        self.mesh = lm
+        self.relperm = relperm_spec(rock.get("relative_permeability"))
+        self.capillary = capillary_spec(rock.get("capillary_pressure"))
+        # initial conditions
+        init = inp.get("initial", {}) or {}
+        npv = {"w": 1, "we": 2, "wce": 3}[self.eos]
+        prim = np.asarray(init.get("primary", [1.0e5, 20.0, 0.0][:npv]), dtype=np.float64)
+        prim = np.tile(prim, (n, 1)) if prim.ndim == 1 else prim
+        region = np.asarray(init.get("region", 1))
+        region = np.full(n, int(region), dtype=np.int32) if region.ndim == 0 else region.astype(np.int32)
+        self.primary, self.region = prim, region
+        # the flow object
+        if ode_factory is None:
+            from .flow_simulation import FlowSimulation
+            self.ode = FlowSimulation(lm, eos=self.eos, device=device, temperature=temperature,
+                                      relperm=self.relperm, capillary=self.capillary, thermo=self.thermo)
+        else:
+            self.ode = ode_factory(lm, self.eos, self.thermo, self.relperm, self.capillary, temperature)
+        self.ode.set_regions(region)
+        self.y = np.ascontiguousarray(self.ode.scale(prim, region).ravel())
+        # solver and time stepping parameters
+        step = _get(inp, "time.step", {}) or {}
+        nl = _get(step, "solver.nonlinear", {}) or {}
+        opts = {}
+        if _get(nl, "tolerance.function.relative") is not None:
+            opts["ftol_rel"] = nl["tolerance"]["function"]["relative"]
+        if _get(nl, "tolerance.function.absolute") is not None:
+            opts["ftol_abs"] = nl["tolerance"]["function"]["absolute"]
+        if _get(nl, "maximum.iterations") is not None:
+            opts["max_newton_its"] = nl["maximum"]["iterations"]
+        if _get(nl, "minimum.iterations") is not None:
+            opts["min_newton_its"] = nl["minimum"]["iterations"]
+        lin = _get(step, "solver.linear", {}) or {}
+        if lin.get("type") in ("bcgs", "gmres"):
+            opts["ksp_type"] = lin["type"]
+        elif lin.get("type") is not None:
+            raise NotImplementedError("linear solver type %r" % lin["type"])
+        if _get(lin, "tolerance.relative") is not None:
+            opts["ksp_rtol"] = lin["tolerance"]["relative"]
+        if opts:
+            self.ode.set_opts(**opts)
+        # tracers
+        tr = inp.get("tracer")
+        self.tracer_names = []
+        self.X = None
+        if tr:
+            tr = tr if isinstance(tr, list) else [tr]
+            phases = [{"liquid": 0, "vapour": 1}[t.get("phase", "liquid")] for t in tr]
+            self.tracer_names = [t.get("name", "tracer") for t in tr]
+            nt = len(tr)
+
+            def tvals(v):
+                v = 0.0 if v is None else v
+                return [v] * nt if np.isscalar(v) else list(v)
+            bc = np.array([tvals(b.get("tracer")) for b in inp.get("boundaries", []) or []
+                           for f in (b["faces"] if isinstance(b["faces"], list) else [b["faces"]]) for _ in f["cells"]])
+            inj = np.array([tvals(s.get("tracer")) for s in inp.get("source", []) or []]) if srcs else None
+            self.ode.set_tracers(phases, decay=[t.get("decay", 0.0) for t in tr],
+                                 activation=[t.get("activation", 0.0) for t in tr],
+                                 diffusion=[t.get("diffusion", 0.0) for t in tr],
+                                 bc=bc if lm.n_bc else None, injection=inj)
+            self.X = np.tile(np.asarray(tvals(init.get("tracer")), dtype=np.float64), n)
+        ad = step.get("adapt", {}) or {}
+        mx = step.get("maximum", {}) or {}
+        self.ts = Timestepper(
+            self.ode, self.y, time=_get(inp, "time.start", 0.0), stepsize=step.get("size", 0.1),
+            method=step.get("method", "beuler"), adapt=bool(ad.get("on", False)),
+            adapt_method=ad.get("method", "iteration"), adapt_min=ad.get("minimum", 5.0),
+            adapt_max=ad.get("maximum", 8.0), reduction=ad.get("reduction", 0.2),
+            amplification=ad.get("amplification", 2.0), max_stepsize=mx.get("size") or 0.0,
+            max_num_tries=_get(step, "maximum.tries", 10), stop_time=_get(inp, "time.stop"),
+            max_num_steps=mx.get("number") if mx.get("number") is not None else 100, aux_solution=self.X)
+
+    @classmethod
+    def from_json(cls, path, **kw):
+        with open(path) as f:
+            inp = json.load(f)
+        return cls(inp, base_dir=os.path.dirname(os.path.abspath(path)), **kw)
+
+    def run(self):
+        """timestepper_run; returns the final cell fields under the reference's output names"""
+        assert self.ode.pre_eval(self.ts.time, self.y) == 0
+        if self.X is not None:
+            self.ts.init_auxiliary()
+        self.ts.run()
+        return self.fields()
+
+    def fields(self):
+        n = self.mesh.n_owned
+        self.ode.pre_eval(self.ts.time, self.y)
+        fl = np.asarray(self.ode.fluid())[:n]
+        nc = {"w": 1, "we": 1, "wce": 2}[self.eos]
+        f0, pd = 6 + nc, 7 + nc
+        out = {"time": self.ts.time, "fluid_pressure": fl[:, 0].copy(), "fluid_temperature": fl[:, 1].copy(),
+               "fluid_region": fl[:, 2].copy(), "fluid_liquid_saturation": fl[:, f0 + 2].copy(),
+               "fluid_liquid_density": fl[:, f0].copy(),
+               "cell_geometry_centroid": self.mesh.cell_geom[:n, : self.dim].copy(),
+               "cell_geometry_volume": self.mesh.cell_geom[:n, 3].copy()}
+        if self.eos != "w":
+            out["fluid_vapour_saturation"] = fl[:, f0 + pd + 2].copy()
+            out["fluid_vapour_density"] = fl[:, f0 + pd].copy()
+        if self.eos == "wce":
+            out["fluid_CO2_partial_pressure"] = fl[:, 7].copy()
+            out["fluid_liquid_CO2_mass_fraction"] = fl[:, f0 + 8].copy()
+            out["fluid_vapour_CO2_mass_fraction"] = fl[:, f0 + pd + 8].copy()
+        if self.X is not None:
+            for k, name in enumerate(self.tracer_names):
+                out["tracer_" + name] = self.X.reshape(n, -1)[:, k].copy()
+        return out
+
+    def save(self, path):
+        np.savez(path, **self.fields())
