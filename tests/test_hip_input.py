@@ -72,3 +72,33 @@ def test_tracer_decay_input():
         exact = X0 * math.exp(-k * t)
         assert abs(out["tracer_" + name][0] - exact) <= 1.0e-2 * exact
     sim.ode.destroy()
+
+
+def test_restart_from_waiwera_hdf5_and_write_output(tmp_path):
+    """oned_two_phase.json restarts from the HDF5 file the real Waiwera wrote (initial.filename) and
+    runs the tracer on the device; the steady-state input run here writes an HDF5 file that equals
+    Waiwera's to 1e-6"""
+    import json
+    import shutil
+    from waiwera_amd import hdf5io
+    from waiwera_amd.simulation import Simulation
+    for f in ("oned_two_phase_ss.json", "oned_two_phase.json", "oned_two_phase_ss.h5", "goned.msh"):
+        shutil.copy(os.path.join(INPUTS, f), tmp_path / f)
+    sim = Simulation.from_json(str(tmp_path / "oned_two_phase.json"))
+    out = sim.run()
+    a = B.load_tracer_oned()["cases"]["two"]["autough2_final_table"]
+    eX = np.abs(out["tracer_tracer"] - np.asarray(a["Tracer/liquid"]))
+    assert np.all((eX <= 1.0e-3 * np.asarray(a["Tracer/liquid"])) | (eX <= 1.0e-4))
+    assert (np.abs(out["fluid_pressure"] - a["Pressure"]) / np.asarray(a["Pressure"])).max() < 1.0e-3
+    sim.ode.destroy()
+    inp = json.load(open(tmp_path / "oned_two_phase_ss.json"))
+    inp["output"] = {"filename": "mine_ss.h5", "initial": False, "frequency": 0, "final": True}
+    json.dump(inp, open(tmp_path / "oned_two_phase_ss.json", "w"))
+    sim = Simulation.from_json(str(tmp_path / "oned_two_phase_ss.json"))
+    sim.run()
+    assert not hasattr(sim, "output_error")
+    mine = hdf5io.read_state(str(tmp_path / "mine_ss.h5"))
+    ref = hdf5io.read_state(str(tmp_path / "oned_two_phase_ss.h5"))
+    for k in ("fluid_pressure", "fluid_temperature", "fluid_vapour_saturation", "fluid_region"):
+        assert np.abs(mine[k] - ref[k]).max() <= 1.0e-6 * np.abs(ref[k]).max(), k
+    sim.ode.destroy()

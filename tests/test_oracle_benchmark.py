@@ -2,6 +2,7 @@
 Avdonin problem: 160 degC water injected into a 170 degC reservoir, heat conduction 20 W/m/K) run
 through the Python Timestepper with the benchmark's own step list, against the analytical solution
 the reference's benchmark suite ships (tolerance there: 2e-2 relative, i.e. ~3 degC)."""
+import json
 import os
 
 import numpy as np
@@ -337,4 +338,39 @@ def test_problem5a_input_file_against_autough2(oracle):
     worst = B.field_errors(got, a, list(got))
     print("problem5a", {k: "%.1e / %.1e" % v for k, v in worst.items()}, "steps", sim.ts.taken)
     assert max(v[0] for v in worst.values()) < 1.0e-3
+    sim.ode.o.close()
+
+
+def test_restart_and_output_files(oracle, tmp_path):
+    """tracer/oned two-phase, the way the benchmark is run: the *_ss.json input to its steady state,
+    written as HDF5 in the reference's layout; then oned_two_phase.json restarting from that file
+    (`initial.filename`) with the tracer.  The written steady state equals the file the real Waiwera
+    wrote (shipped with the benchmark) and the tracer run equals AUTOUGH2 within 1e-3."""
+    import shutil
+    from waiwera_amd import hdf5io
+    from waiwera_amd.simulation import Simulation
+    for f in ("oned_two_phase_ss.json", "oned_two_phase.json", "goned.msh"):
+        shutil.copy(os.path.join(INPUTS, f), tmp_path / f)
+    inp = json.load(open(tmp_path / "oned_two_phase_ss.json"))
+    inp["output"] = {"filename": "oned_two_phase_ss.h5", "initial": False, "frequency": 0, "final": True}
+    json.dump(inp, open(tmp_path / "oned_two_phase_ss.json", "w"))
+    sim = Simulation.from_json(str(tmp_path / "oned_two_phase_ss.json"), ode_factory=oracle_factory(oracle))
+    sim.y = sim.ts.y = sim.ode.o.yvec(sim.y)
+    sim.ode.opts.ftol_rel = 1.0e-9
+    sim.run()
+    assert not hasattr(sim, "output_error")
+    sim.ode.o.close()
+    mine = hdf5io.read_state(str(tmp_path / "oned_two_phase_ss.h5"))
+    ref = hdf5io.read_state(os.path.join(INPUTS, "oned_two_phase_ss.h5"))
+    assert mine["time"] == ref["time"] == 1.0e15
+    for k in ("fluid_pressure", "fluid_temperature", "fluid_vapour_saturation", "fluid_region"):
+        assert np.abs(mine[k] - ref[k]).max() <= 1.0e-6 * np.abs(ref[k]).max(), k
+    sim = Simulation.from_json(str(tmp_path / "oned_two_phase.json"), ode_factory=oracle_factory(oracle))
+    sim.y = sim.ts.y = sim.ode.o.yvec(sim.y)
+    sim.ode.opts.ftol_rel = 1.0e-9
+    out = sim.run()
+    a = B.load_tracer_oned()["cases"]["two"]["autough2_final_table"]
+    eX = np.abs(out["tracer_tracer"] - np.asarray(a["Tracer/liquid"]))
+    assert np.all((eX <= 1.0e-3 * np.asarray(a["Tracer/liquid"])) | (eX <= 1.0e-4))
+    assert (np.abs(out["fluid_pressure"] - a["Pressure"]) / np.asarray(a["Pressure"])).max() < 1.0e-3
     sim.ode.o.close()

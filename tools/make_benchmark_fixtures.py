@@ -289,7 +289,10 @@ def input_files():
              (mis, "problem5/run/problem5a.json"), (mis, "problem5/run/gproblem5.msh"),
              (REF, "ncg/co2_one_cell/run/co2_one_cell.json"), (REF, "ncg/co2_one_cell/run/gco2_one_cell.msh"),
              (REF, "ncg/co2_column/run/co2_column_1.json"), (REF, "ncg/co2_column/run/gco2_column.msh"),
-             (REF, "tracer/decay/run/decay.json"), (REF, "tracer/decay/run/decay.msh")]
+             (REF, "tracer/decay/run/decay.json"), (REF, "tracer/decay/run/decay.msh"),
+             (REF, "tracer/oned/run/oned_two_phase.json"), (REF, "tracer/oned/run/oned_two_phase_ss.json"),
+             (REF, "tracer/oned/run/oned_two_phase_ss.h5"), (REF, "tracer/oned/run/oned_single_phase.json"),
+             (REF, "tracer/oned/run/oned_single_phase_ss.h5"), (REF, "tracer/oned/run/goned.msh")]
     for base, rel in files:
         src = os.path.join(base, rel)
         if os.path.exists(src):

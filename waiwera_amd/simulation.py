@@ -12,16 +12,20 @@ src/timestepper.F90:1960-2275; src/tracer.F90:63-140; utils/input_schema.json):
   thermodynamics  iapws | ifc67
   rock        types [cells | zones, permeability, porosity, density, specific_heat, wet / dry
               conductivity], relative_permeability, capillary_pressure
-  initial     primary (one record or one per cell), region (one or per cell), tracer
+  initial     primary (one record or one per cell), region (one or per cell), tracer; or
+              filename + index: restart from a Waiwera HDF5 output file
   boundaries  primary, region, faces {cells, normal} (one or a list), tracer
   source      cell, rate, enthalpy, component, tracer (constant-rate sources only)
   time        start, stop, step {size, adapt, maximum, method, solver.nonlinear, solver.linear}
   tracer      name, phase, decay, activation, diffusion
 
-Anything else that changes results (source controls, MINC, rock controls, initial conditions from
-an HDF5 file, ...) raises NotImplementedError instead of being ignored.  Output: `Simulation.run`
-returns the final cell fields under the reference's HDF5 dataset names (fluid_pressure, ...), and
-`save` writes them as a .npz archive.
+  output      filename, initial, final, frequency (cell fields only)
+
+Anything else that changes results (source controls, MINC, rock controls, ...) raises
+NotImplementedError instead of being ignored.  Output: `Simulation.run` returns the final cell
+fields under the reference's HDF5 dataset names (fluid_pressure, ...) and writes "output.filename"
+in the reference's HDF5 layout (waiwera_amd/hdf5io.py, HDF5 C library through ctypes); `save`
+writes a .npz archive.
 """
 import json
 import os
@@ -113,8 +117,7 @@ class Simulation:
         self.inp = inp
         if _get(inp, "mesh.minc") is not None:
             raise NotImplementedError("MINC zones from an input file")
-        if isinstance(inp.get("initial"), dict) and "filename" in inp["initial"]:
-            raise NotImplementedError("initial conditions from an HDF5 file")
+        self.base_dir = base_dir
         mesh = inp.get("mesh")
         if isinstance(mesh, str):
             mesh = {"filename": mesh}
@@ -175,10 +178,25 @@ class Simulation:
         # initial conditions
         init = inp.get("initial", {}) or {}
         npv = {"w": 1, "we": 2, "wce": 3}[self.eos]
-        prim = np.asarray(init.get("primary", [1.0e5, 20.0, 0.0][:npv]), dtype=np.float64)
-        prim = np.tile(prim, (n, 1)) if prim.ndim == 1 else prim
-        region = np.asarray(init.get("region", 1))
-        region = np.full(n, int(region), dtype=np.int32) if region.ndim == 0 else region.astype(np.int32)
+        if "filename" in init:
+            # restart from a Waiwera HDF5 output (setup_initial, src/initial.F90:421-677, 776, 922):
+            # primaries of each cell from its fluid fields by region (eos%primary_variables)
+            from . import hdf5io
+            st = hdf5io.read_state(os.path.join(base_dir, init["filename"]), init.get("index", -1))
+            region = np.rint(st["fluid_region"]).astype(np.int32) if "fluid_region" in st else np.ones(n, dtype=np.int32)
+            cols = [st["fluid_pressure"]]
+            if npv > 1:
+                cols.append(np.where(region == 4, st["fluid_vapour_saturation"], st["fluid_temperature"]))
+            if npv > 2:
+                cols.append(st["fluid_CO2_partial_pressure"])
+            prim = np.stack(cols, axis=1)
+            if prim.shape[0] != n:
+                raise ValueError("initial conditions file has %d cells, mesh has %d" % (prim.shape[0], n))
+        else:
+            prim = np.asarray(init.get("primary", [1.0e5, 20.0, 0.0][:npv]), dtype=np.float64)
+            prim = np.tile(prim, (n, 1)) if prim.ndim == 1 else prim
+            region = np.asarray(init.get("region", 1))
+            region = np.full(n, int(region), dtype=np.int32) if region.ndim == 0 else region.astype(np.int32)
         self.primary, self.region = prim, region
         # the flow object
         if ode_factory is None:
@@ -249,12 +267,43 @@ class Simulation:
         return cls(inp, base_dir=os.path.dirname(os.path.abspath(path)), **kw)
 
     def run(self):
-        """timestepper_run; returns the final cell fields under the reference's output names"""
+        """timestepper_run with the output schedule of "output" (initial / frequency / final,
+        src/timestepper.F90:2478-2560); returns the final cell fields under the reference's names
+        and, if "output.filename" is given (and the HDF5 library is there), writes that file"""
         assert self.ode.pre_eval(self.ts.time, self.y) == 0
         if self.X is not None:
             self.ts.init_auxiliary()
-        self.ts.run()
-        return self.fields()
+        oc = self.inp.get("output")
+        oc = {} if oc in (None, True) else ({"frequency": 0, "initial": False, "final": False} if oc is False else oc)
+        freq, self.outputs = oc.get("frequency", 1), []
+        if oc.get("initial", True):
+            self.outputs.append(self.fields())
+        while not self.ts.finished:
+            self.ts.step()
+            if (freq and self.ts.taken % freq == 0) or (self.ts.finished and oc.get("final", True)):
+                self.outputs.append(self.fields())
+        out = self.fields()
+        if oc.get("filename"):
+            try:
+                self.save_hdf5(os.path.join(self.base_dir, oc["filename"]))
+            except Exception as e:   # no HDF5 library, read-only directory: results are still returned
+                self.output_error = e
+        return out
+
+    def save_hdf5(self, path):
+        """the collected outputs in the reference's layout: /time, /cell_index, /cell_fields/*"""
+        from . import hdf5io
+        outs = getattr(self, "outputs", None) or [self.fields()]
+        n = self.mesh.n_owned
+        data = {"/time": np.array([[o["time"]] for o in outs]), "/cell_index": np.arange(n, dtype=np.int32)[:, None]}
+        for k in outs[0]:
+            if k == "time":
+                continue
+            if k.startswith("cell_geometry"):
+                data["/cell_fields/" + k] = outs[0][k]
+            else:
+                data["/cell_fields/" + k] = np.stack([o[k] for o in outs])
+        hdf5io.write_file(path, data)
 
     def fields(self):
         n = self.mesh.n_owned
