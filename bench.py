@@ -291,7 +291,7 @@ def main():
                          "spmv": {"kernel": "k_spmv<2> (BCSR SpMV)", "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
                                   "algorithmic_bytes_per_launch": b_spmv, "ms_per_launch": ms}},
         }
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:   # the CPU baseline is a single-GPU-run item
             cb = cpu_baseline(dims, a.brick)
             if cb:
                 out["cpu_baseline"] = cb
