@@ -105,6 +105,11 @@ int wai_set_bc(wai_ctx *ctx, const double *primary, const int *region);
 /* constant-rate sources (src/source.F90:386-480, source_network.F90:296-355) */
 int wai_set_sources(wai_ctx *ctx, int n, const int *cell, const double *rate,
                     const double *enthalpy, const int *component);
+/* new rates / enthalpies for the sources in force, in wai_set_sources order; either may be NULL
+ * (kept).  What the reference's table controls do to their sources before each residual
+ * (source_network%update, src/flow_simulation.F90:1469; table_object_control_update,
+ * src/control.F90:263-284): the host averages the tables over the step interval. */
+int wai_update_sources(wai_ctx *ctx, const double *rate, const double *enthalpy);
 /* thermodynamic region of every owned+halo cell (fluid%region, src/fluid.F90:77-80) */
 int wai_set_regions(wai_ctx *ctx, const int *region);
 int wai_get_regions(wai_ctx *ctx, int *region);

@@ -121,6 +121,8 @@ wo_sim *wo_sim_create(int eos_kind, int n_owned, int n_halo, int n_bc, int n_fac
 void wo_sim_destroy(wo_sim *s);
 wo_eos *wo_sim_eos(wo_sim *s);
 void wo_sim_set_comm(wo_sim *s, wo_halo_fn halo, wo_allreduce_fn ar, void *user);
+/* table controls: new rate / enthalpy per source (NULL = kept), src/control.F90:263-284 */
+void wo_sim_update_sources(wo_sim *s, const double *rate, const double *enthalpy);
 void wo_sim_set_sources(wo_sim *s, int n, const int *cell, const double *rate,
                         const double *enthalpy, const int *component);
 void wo_sim_set_subdomains(wo_sim *s, int nsub, const int *sub_ptr);

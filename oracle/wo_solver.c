@@ -220,6 +220,10 @@ void wo_sim_set_sources(wo_sim *s, int n, const int *cell, const double *rate,
   memcpy(s->src_rate, rate, sizeof(double) * n);
   memcpy(s->src_enth, enthalpy, sizeof(double) * n);
 }
+void wo_sim_update_sources(wo_sim *s, const double *rate, const double *enthalpy) {
+  if (rate) memcpy(s->src_rate, rate, sizeof(double) * s->n_src);
+  if (enthalpy) memcpy(s->src_enth, enthalpy, sizeof(double) * s->n_src);
+}
 void wo_sim_set_subdomains(wo_sim *s, int nsub, const int *sub_ptr) {
   free(s->sub_ptr);
   s->nsub = nsub;

@@ -83,6 +83,7 @@ def load(path):
         "wo_sim_eos": (C.POINTER(Eos), [C.c_void_p]),
         "wo_sim_set_comm": (None, [C.c_void_p, HALOFN, ARFN, C.c_void_p]),
         "wo_sim_set_sources": (None, [C.c_void_p, i32, pi, pd, pd, pi]),
+        "wo_sim_update_sources": (None, [C.c_void_p, pd, pd]),
         "wo_sim_set_subdomains": (None, [C.c_void_p, i32, pi]),
         "wo_sim_set_regions": (None, [C.c_void_p, pi]),
         "wo_sim_get_regions": (None, [C.c_void_p, pi]),
@@ -153,6 +154,11 @@ class OracleSim:
         if self.h:
             self.L.wo_sim_destroy(self.h)
             self.h = None
+
+    def set_source_rates(self, rate=None, enthalpy=None):
+        r = f64(rate) if rate is not None else None
+        e = f64(enthalpy) if enthalpy is not None else None
+        self.L.wo_sim_update_sources(self.h, dp(r) if r is not None else None, dp(e) if e is not None else None)
 
     def set_regions(self, region):
         r = i32a(region)

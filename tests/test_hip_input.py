@@ -34,6 +34,16 @@ def test_problem5a():
     sim.ode.destroy()
 
 
+def test_problem5b_rate_table():
+    """5a plus an injection well driven by a step rate table (wai_update_sources before each try)"""
+    sim, out = run("problem5b.json")
+    assert abs(out["time"] - 315360000.0) < 1.0 and sim.ts.taken == 200
+    worst = B.field_errors(triple(out), B.load_fixture("benchmark_problem5b.json")["autough2_final_table"],
+                           ("Pressure", "Temperature", "Vapour saturation"))
+    assert max(v[0] for v in worst.values()) < 1.0e-3
+    sim.ode.destroy()
+
+
 def test_problem1_and_problem2c():
     sim, out = run("problem1.json")
     a = B.load_problem1()["autough2_final_table"]

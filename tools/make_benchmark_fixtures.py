@@ -286,7 +286,8 @@ def input_files():
     files = [(mis, "problem1/run/problem1.json"), (mis, "problem1/run/gproblem1.msh"),
              (mis, "problem2/run/problem2b.json"), (mis, "problem2/run/problem2c.json"), (mis, "problem2/run/gproblem2.msh"),
              (mis, "problem4/run/problem4.json"), (mis, "problem4/run/gproblem4.msh"),
-             (mis, "problem5/run/problem5a.json"), (mis, "problem5/run/gproblem5.msh"),
+             (mis, "problem5/run/problem5a.json"), (mis, "problem5/run/problem5b.json"),
+             (mis, "problem5/run/gproblem5.msh"),
              (REF, "ncg/co2_one_cell/run/co2_one_cell.json"), (REF, "ncg/co2_one_cell/run/gco2_one_cell.msh"),
              (REF, "ncg/co2_column/run/co2_column_1.json"), (REF, "ncg/co2_column/run/gco2_column.msh"),
              (REF, "tracer/decay/run/decay.json"), (REF, "tracer/decay/run/decay.msh"),
@@ -301,11 +302,18 @@ def input_files():
             print("missing", src)
 
 
-def problem5a():
+def problem5(case="a"):
     base = os.path.join(REF, "model_intercomparison_study", "problem5", "run")
-    t = last_table(os.path.join(base, "problem5a.listing"), "ELEMENT TABLE")
-    d = json.load(open(os.path.join(base, "problem5a.json")))
+    t = last_table(os.path.join(base, "problem5%s.listing" % case), "ELEMENT TABLE")
+    d = json.load(open(os.path.join(base, "problem5%s.json" % case)))
     n = len(d["initial"]["primary"])
+    if case == "b":
+        out = {"source": "test/benchmark/model_intercomparison_study/problem5/run/problem5b.listing, last ELEMENT "
+                         "TABLE (t = 10 years; problem 5a plus an injection well switched on after one year by a "
+                         "step rate table); the input is tests/golden/inputs/problem5b.json",
+               "autough2_final_table": {k: t[k][:n] for k in ("Pressure", "Temperature", "Vapour saturation")}}
+        json.dump(out, open(os.path.join(OUT, "benchmark_problem5b.json"), "w"), indent=1)
+        return
     out = {"source": "test/benchmark/model_intercomparison_study/problem5/run/problem5a.listing, last ELEMENT TABLE "
                      "(t = 10 years; 2-D areal flow to a well with a cold recharge boundary; the reference's test holds "
                      "the histories to AUTOUGH2 within 1e-3); the input is tests/golden/inputs/problem5a.json",
@@ -315,7 +323,8 @@ def problem5a():
 
 if __name__ == "__main__":
     input_files()
-    problem5a()
+    problem5("a")
+    problem5("b")
     problem4()
     problem2()
     minc_doublet_1d()

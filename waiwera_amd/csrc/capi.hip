@@ -889,6 +889,16 @@ int wai_set_sources(wai_ctx* c, int n, const int* cell, const double* rate, cons
   return 0;
 }
 
+int wai_update_sources(wai_ctx* c, const double* rate, const double* enthalpy) {
+  if (!c) return -2;
+  const size_t nb = sizeof(double) * (size_t)c->src.n;
+  if (!c->src.n) return 0;
+  if (rate) HIPCHK(c, hipMemcpyAsync(c->src.rate, rate, nb, hipMemcpyDefault, c->stream));
+  if (enthalpy) HIPCHK(c, hipMemcpyAsync(c->src.enth, enthalpy, nb, hipMemcpyDefault, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 int wai_get_fluid(wai_ctx* c, int which, double* out) {
   if (!c || !out) return -2;
   const double* src = which == 0 ? c->flu : (which == 1 ? c->flu_last_iter : c->flu_last_step);

@@ -62,6 +62,16 @@ class FlowSimulation:
             self._chk(LIB.wai_set_halo(h, nr.size, nr.ctypes.data_as(_lib.pi), sp.ctypes.data_as(_lib.pi),
                                        si.ctypes.data_as(_lib.pi), rp.ctypes.data_as(_lib.pi)), "set_halo")
 
+    def set_source_rates(self, rate=None, enthalpy=None):
+        """new rates / enthalpies of the sources in force (what table controls do before a try)"""
+        r = _lib._f64(rate) if rate is not None else None
+        e = _lib._f64(enthalpy) if enthalpy is not None else None
+        for a in (r, e):
+            if a is not None and a.size != self.mesh.n_src:
+                raise ValueError("one value per source")
+        self._chk(LIB.wai_update_sources(self.h, r.ctypes.data_as(_lib.pd) if r is not None else None,
+                                         e.ctypes.data_as(_lib.pd) if e is not None else None), "update_sources")
+
     # ------------------------------------------------------------------------------------------
     def _chk(self, rc, what):
         if rc < 0:

@@ -80,6 +80,11 @@ module waiwera_hip_module
        integer(c_int), intent(in) :: cell(*), component(*)
        real(c_double), intent(in) :: rate(*), enthalpy(*)
      end function wai_set_sources
+     integer(c_int) function wai_update_sources(ctx, rate, enthalpy) bind(c, name = "wai_update_sources")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       type(c_ptr), value :: rate, enthalpy   ! c_loc of real(c_double) arrays or c_null_ptr (kept)
+     end function wai_update_sources
      integer(c_int) function wai_set_regions(ctx, region) bind(c, name = "wai_set_regions")
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx
@@ -272,7 +277,7 @@ module waiwera_hip_module
   end type hip_flow_simulation_type
 
   public :: wai_set_tracers, wai_set_tracer_bc, wai_set_tracer_injection, wai_set_aux_solver
-  public :: wai_default_eos, wai_default_opts, wai_set_bc, wai_set_sources, wai_set_regions, &
+  public :: wai_default_eos, wai_default_opts, wai_set_bc, wai_set_sources, wai_update_sources, wai_set_regions, &
        wai_get_regions, wai_jacobian_nnzb, wai_jacobian_pattern, wai_jacobian_get_values
 
 contains

@@ -66,6 +66,7 @@ def _load():
         "wai_set_opts": (i32, [vp, C.POINTER(SolverOpts)]),
         "wai_set_bc": (i32, [vp, pd, pi]),
         "wai_set_sources": (i32, [vp, i32, pi, pd, pd, pi]),
+        "wai_update_sources": (i32, [vp, pd, pd]),
         "wai_set_regions": (i32, [vp, pi]),
         "wai_get_regions": (i32, [vp, pi]),
         "wai_get_fluid": (i32, [vp, i32, vp]),

@@ -15,7 +15,8 @@ src/timestepper.F90:1960-2275; src/tracer.F90:63-140; utils/input_schema.json):
   initial     primary (one record or one per cell), region (one or per cell), tracer; or
               filename + index: restart from a Waiwera HDF5 output file
   boundaries  primary, region, faces {cells, normal} (one or a list), tracer
-  source      cell, rate, enthalpy, component, tracer (constant-rate sources only)
+  source      cell, rate, enthalpy (constants or [[t, v], ...] tables with "interpolation": linear|step and
+              "averaging": integrate|endpoint), component, tracer
   time        start, stop, step {size, adapt, maximum, method, solver.nonlinear, solver.linear}
   tracer      name, phase, decay, activation, diffusion
 
@@ -34,9 +35,10 @@ import numpy as np
 
 from . import gmsh, unstructured
 from .timestepper import Timestepper
+from .interpolation import Table
 
 UNSUPPORTED_SOURCE_KEYS = ("deliverability", "recharge", "limiter", "separator", "direction", "injectivity",
-                           "interpolation", "averaging", "factor", "network")
+                           "factor", "network")
 
 
 def _get(d, path, default=None):
@@ -145,14 +147,26 @@ class Simulation:
             faces = b["faces"]
             for f in (faces if isinstance(faces, list) else [faces]):
                 bnds.append((list(f["cells"]), list(f.get("normal", [0.0, 0.0, 1.0])), b["primary"], b.get("region", 1)))
-        srcs = []
+        srcs, self._tables = [], []
         for s in inp.get("source", []) or []:
             bad = [k for k in UNSUPPORTED_SOURCE_KEYS if k in s]
             if bad:
                 raise NotImplementedError("source controls %s" % bad)
             if "cell" not in s:
                 raise NotImplementedError("sources given by zones or cell lists")
-            srcs.append(dict(cell=s["cell"], rate=s.get("rate", 0.0), enthalpy=s.get("enthalpy", 83.9e3),
+            # rate / enthalpy tables ([[t, value], ...]; setup_table_controls, src/source_setup.F90):
+            # averaged over each step interval before the try, see _update_controls
+            vals = {}
+            for key, default in (("rate", 0.0), ("enthalpy", 83.9e3)):
+                v = s.get(key, default)
+                if isinstance(v, dict):
+                    raise NotImplementedError("source %s given as an object" % key)
+                if isinstance(v, (list, tuple)):
+                    tab = Table(v, s.get("interpolation", "linear"), s.get("averaging", "integrate"))
+                    self._tables.append((len(srcs), key, tab))
+                    v = float(tab.interpolate(_get(inp, "time.start", 0.0))[0])
+                vals[key] = v
+            srcs.append(dict(cell=s["cell"], rate=vals["rate"], enthalpy=vals["enthalpy"],
                              component=s.get("component", 0)))
         lm = unstructured.build_mesh(nodes, cells, dim, thickness=mesh.get("thickness", 1.0),
                                      radial=bool(mesh.get("radial", False)), gravity=grav, boundaries=bnds,
@@ -259,6 +273,17 @@ class Simulation:
             amplification=ad.get("amplification", 2.0), max_stepsize=mx.get("size") or 0.0,
             max_num_tries=_get(step, "maximum.tries", 10), stop_time=_get(inp, "time.stop"),
             max_num_steps=mx.get("number") if mx.get("number") is not None else 100, aux_solution=self.X)
+
+        if self._tables:
+            self.ts.controls = self._update_controls
+
+    def _update_controls(self, interval):
+        """table_object_control_update (src/control.F90:263-284): each table's average over the step
+        interval becomes the rate / enthalpy of its source"""
+        rate, enth = self.mesh.src_rate.copy(), self.mesh.src_enthalpy.copy()
+        for i, key, tab in self._tables:
+            (rate if key == "rate" else enth)[i] = tab.average(interval)[0]
+        self.ode.set_source_rates(rate, enth)
 
     @classmethod
     def from_json(cls, path, **kw):

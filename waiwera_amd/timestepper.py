@@ -79,6 +79,10 @@ class Timestepper:
         self.stop_min_stepsize = stop_min_stepsize
         self.stop_max_stepsize = stop_max_stepsize
         self.termination_tol = 1.0e-3
+        # callable(interval) run before each try: time-dependent controls averaged over the step
+        # interval [t, t + dt] (the interval argument of the reference's lhs / rhs calls,
+        # src/timestepper.F90 ode%rhs(t, interval, ...); src/flow_simulation.F90:1469)
+        self.controls = None
         self.taken = 0
         self.finished = False
         self.status = OK
@@ -231,6 +235,9 @@ class Timestepper:
                 ode.pre_retry_timestep()
                 self.y[...] = y_start
             stepsize = self._check_finished(self.next_stepsize)
+            if self.controls is not None:
+                t1 = self.time + stepsize     # direct steady state: [t, t] at the new time (:446)
+                self.controls((t1 if self.steady_state else self.time, t1))
             reason, nits, kits = ode.timestep(self.time + stepsize, stepsize, self.y)
             aux = None
             if self.auxiliary and reason > 0:
