@@ -190,11 +190,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (a.gpus, world))
+    # tests/test_hip_multirank.py only: every rank on cuda:0 with a loopback librccl (WAI_RCCL_LIB)
+    # and gloo for the host-side barrier, so that the N > 1 launch can be exercised on a 1-GPU box
+    loopback = os.environ.get("WAI_BENCH_LOOPBACK") == "1"
+    if loopback:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if loopback:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from waiwera_amd import lib as wl
     from waiwera_amd import mesh as M
@@ -241,7 +249,7 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([el], dtype=torch.float64, device="cpu" if loopback else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     kits = drv.krylov - k0

@@ -48,12 +48,12 @@ def _run_steps(sim, y, nsteps=2):
     return out
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, part=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     L = ol.load(os.path.join(ROOT, "oracle", "liboracle.so"))
-    g, lm, prim, region = _problem((world, 1, 1), rank)
+    g, lm, prim, region = _problem(part or (world, 1, 1), rank)
     sim = ol.OracleSim(L, lm, 1)
     sim.set_regions(region)
 
@@ -88,12 +88,15 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_oracle_matches_one_rank(oracle):
+@pytest.mark.parametrize("part", [(2, 1, 1), (1, 2, 1)])
+def test_two_rank_oracle_matches_one_rank(oracle, part):
+    """an x split and a y split (halo slabs along another axis, wells owned by other ranks); in both
+    the rank extents are whole bricks, so the preconditioner is the serial one"""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, part)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(world)]

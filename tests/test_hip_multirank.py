@@ -1,0 +1,129 @@
+"""The N > 1 path of the HIP library on ONE GPU: two processes, one rank each, both on cuda:0,
+with librccl replaced by the shared-memory loopback of tests/loopback_rccl (real RCCL refuses two
+ranks on one device; the test boxes have one).  Everything above the nine nccl* entry points is
+the product path: partition meshes and halo lists of waiwera_amd.mesh, pack / exchange / unpack
+kernels, the Krylov all-reduces and the collective flags of the Newton protocol.  Because
+preconditioner bricks never straddle ranks the 2-rank solve is algorithmically the 1-rank solve;
+results must agree to all-reduce rounding.  The same is done for bench.py as the driver launches it."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from tests.cases import scaled
+from waiwera_amd import mesh as M
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LOOPBACK = os.path.join(ROOT, "tests", "loopback_rccl", "libloopback_rccl.so")
+DIMS, BRICK = (16, 12, 8), (4, 4, 4)
+
+
+def _problem(part, rank):
+    g = M.StructuredGrid(DIMS, spacing=(10.0, 10.0, 500.0 / DIMS[2]), part=part, brick=BRICK)   # bottom layer in the lens
+    lm = g.local_mesh(rank, rock_fn=M.heterogeneous_rock(g.n_global), top_bc=([1.0e5, 20.0], 1),
+                      sources=M.benchmark_sources(g))
+    prim, region = M.benchmark_initial_state(g, lm.extras["prim_ijk"], lens=True)
+    return g, lm, prim, region
+
+
+def _run_steps(sim, y, nsteps=3):
+    sim.set_opts(ksp_rtol=1e-12, ftol_rel=1e-10)
+    dt, t, out = 2.0e4, 0.0, []
+    for _ in range(nsteps):
+        reason, nits, kits = sim.timestep(t, dt, y)
+        out.append((reason, nits, kits))
+        t += dt
+        dt *= 2
+    return out
+
+
+def _worker(rank, world, uid, q):
+    os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    from waiwera_amd.flow_simulation import FlowSimulation
+    g, lm, prim, region = _problem(M.partition_shape(world), rank)
+    sim = FlowSimulation(lm, eos="we", device=0)
+    sim.set_regions(region)
+    sim.comm_init(rank, world, uid)
+    y = scaled(prim, region).ravel().copy()
+    hist = _run_steps(sim, y)
+    q.put((rank, lm.owned_gid.copy(), y[: lm.n_owned * 2].copy(), hist, sim.regions()[: lm.n_owned].copy()))
+    sim.destroy()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_sharing_one_gpu_match_one_rank(world):
+    """2 ranks (2x1x1, bricks aligned with the serial ones) and 8 ranks (2x2x2: every rank has x, y
+    and z neighbours, only the upper ranks carry the boundary, 6-cell rank extents cut the 4-cell
+    bricks raggedly so the preconditioner differs from the serial one)"""
+    assert os.path.exists(LOOPBACK), "build first: python __graft_entry__.py"
+    os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    from waiwera_amd import lib as wl
+    from waiwera_amd.flow_simulation import FlowSimulation
+    uid = wl.comm_unique_id()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, uid, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=400) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g, lm, prim, region = _problem((1, 1, 1), 0)
+    sim = FlowSimulation(lm, eos="we", device=0)
+    sim.set_regions(region)
+    y = scaled(prim, region).ravel().copy()
+    hist = _run_steps(sim, y)
+    yser = np.zeros((g.n_global, 2))
+    yser[lm.owned_gid] = y[: lm.n_owned * 2].reshape(-1, 2)
+    rser = np.zeros(g.n_global, dtype=int)
+    rser[lm.owned_gid] = sim.regions()[: lm.n_owned]
+    sim.destroy()
+    ypar, rpar = np.zeros((g.n_global, 2)), np.zeros(g.n_global, dtype=int)
+    for rank, gid, yy, h, reg in res:
+        ypar[gid] = yy.reshape(-1, 2)
+        rpar[gid] = reg
+        assert all(r > 0 for r, _, _ in h)
+        assert [n for _, n, _ in h] == [n for _, n, _ in hist]        # same Newton iteration counts
+        for (_, _, k1), (_, _, k2) in zip(h, hist):
+            if world == 2:
+                assert abs(k1 - k2) <= max(3, k2 // 10)                # Krylov counts to all-reduce rounding
+    assert (rser != 1).any()                                           # the two-phase lens is in play
+    bad = np.nonzero(rpar != rser)[0]
+    err = np.abs(ypar - yser).max(axis=0) / np.abs(yser).max(axis=0)
+    assert bad.size == 0, (bad.size, bad[:20], rpar[bad[:20]], rser[bad[:20]], ypar[bad[:20]], yser[bad[:20]], err)
+    assert err.max() < 1e-7, err
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(900)
+def test_bench_as_the_driver_launches_it_two_ranks():
+    """bench.py --gpus 2 under torch.distributed.run, both ranks on cuda:0 over the loopback
+    (WAI_BENCH_LOOPBACK: gloo for the host-side barrier / max, device 0 for every rank)"""
+    env = dict(os.environ, WAI_RCCL_LIB=LOOPBACK, WAI_BENCH_LOOPBACK="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--dims", "32", "32", "16", "--brick", "8", "8", "2",
+           "--spmv-reps", "3", "--no-cpu"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
+    assert out["config"]["partition"] == "2x1x1"
+    assert out["config"]["krylov_iterations_per_newton_step"] > 0

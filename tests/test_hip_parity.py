@@ -225,7 +225,7 @@ def test_minc_dual_porosity(FS, oracle, eos):
     yo = osim.yvec(y)
     assert sim.pre_eval(0.0, y) == 0 and osim.pre_eval(yo) == 0
     L = osim.lhs()
-    dt = 1.0e2   # the fracture cells hold 10 % of the volume: injection needs small first steps
+    dt = 25.0    # the fracture cells hold 10 % of the volume: injection needs small first steps
     f = np.zeros(n)
     assert sim.residual(0.0, dt, y, L, f) == 0
     err, fo = osim.residual(yo, dt, L)

@@ -115,3 +115,20 @@ def test_minc_mesh_structure():
         sub = np.searchsorted(m.sub_ptr, np.arange(m.n_owned), side="right") - 1
         assert np.array_equal(sub[c1], sub[c2])
         assert np.all(m.send_idx < m.n_owned) and np.all(lev[m.send_idx] == 0)
+
+
+@pytest.mark.parametrize("part", [(1, 1, 1), (1, 2, 1), (2, 2, 2)])
+def test_local_id_follows_the_brick_numbering_and_sources_land_on_their_cells(part):
+    """local_id (used to place the wells) must give the level-ordered numbering local_mesh gives
+    the cells of a brick, also for the ragged bricks at rank edges: the wells of a partitioned mesh
+    are the wells of the serial one"""
+    dims, brick = (16, 12, 8), (4, 4, 4)
+    g = M.StructuredGrid(dims, part=part, brick=brick)
+    want = sorted((int(g.natural_id(*s["ijk"])), s["rate"]) for s in M.benchmark_sources(g))
+    got = []
+    for rank in range(g.nranks):
+        lm = g.local_mesh(rank, sources=M.benchmark_sources(g))
+        ijk = lm.extras["prim_ijk"][: lm.n_owned]
+        assert np.array_equal(g.local_id(rank, ijk[:, 0], ijk[:, 1], ijk[:, 2]), np.arange(lm.n_owned))
+        got += [(int(lm.owned_gid[c]), float(r)) for c, r in zip(lm.src_cell, lm.src_rate)]
+    assert sorted(got) == want

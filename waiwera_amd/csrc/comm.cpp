@@ -11,6 +11,7 @@
 // reused instead of a second one.
 #include "comm.hpp"
 #include <dlfcn.h>
+#include <cstdlib>
 #include <cstring>
 
 namespace wai {
@@ -34,7 +35,14 @@ bool load_api(std::string& err) {
   if (g_api.lib) return true;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
+  // WAI_RCCL_LIB names the library outright (the tests point it at a shared-memory loopback so
+  // that several ranks can share the one GPU of a test box, which RCCL itself refuses)
+  if (const char* forced = getenv("WAI_RCCL_LIB")) {
+    h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { err = std::string("cannot load WAI_RCCL_LIB: ") + dlerror(); return false; }
+  }
   for (const char* n : names) {  // prefer a copy that is already mapped
+    if (h) break;
     h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
     if (h) break;
   }

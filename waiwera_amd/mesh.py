@@ -151,6 +151,17 @@ class StructuredGrid:
         ax, ay, az = self.ax
         b = (az.brick_in_rank[k] * shape[1] + ay.brick_in_rank[j]) * shape[2] + ax.brick_in_rank[i]
         within = (az.off[k] * ay.bsize[j] + ay.off[j]) * ax.bsize[i] + ax.off[i]
+        if self.order == "hyperplane":
+            # position in the brick's level order: cells sorted by (ox + oy + oz, natural index),
+            # the numbering local_mesh gives the brick (few cells are asked for: sources)
+            within = np.asarray(within).copy()
+            for q in range(within.size):
+                sx, sy, sz = int(ax.bsize[i[q]]), int(ay.bsize[j[q]]), int(az.bsize[k[q]])
+                oz, oy, ox = np.meshgrid(np.arange(sz), np.arange(sy), np.arange(sx), indexing="ij")
+                nat = ((oz * sy + oy) * sx + ox).ravel()
+                key = (oz + oy + ox).ravel() * nat.size + nat
+                mine = (az.off[k[q]] + ay.off[j[q]] + ax.off[i[q]]) * nat.size + within[q]
+                within[q] = np.count_nonzero(key < mine)
         return (starts[b] + within).astype(np.int64)
 
     def natural_id(self, i, j, k):
