@@ -225,7 +225,9 @@ def test_minc_dual_porosity(FS, oracle, eos):
     yo = osim.yvec(y)
     assert sim.pre_eval(0.0, y) == 0 and osim.pre_eval(yo) == 0
     L = osim.lhs()
-    dt = 25.0    # the fracture cells hold 10 % of the volume: injection needs small first steps
+    dt = 10.0    # the fracture cells hold 10 % of the volume: injection needs small first steps
+                 # (at 25 s the wce case converges on the edge of the tolerance: 5 or 6 iterations
+                 # depending on the reduction order, also between oracle thread counts)
     f = np.zeros(n)
     assert sim.residual(0.0, dt, y, L, f) == 0
     err, fo = osim.residual(yo, dt, L)
