@@ -110,6 +110,34 @@ int wai_set_sources(wai_ctx *ctx, int n, const int *cell, const double *rate,
  * (source_network%update, src/flow_simulation.F90:1469; table_object_control_update,
  * src/control.F90:263-284): the host averages the tables over the step interval. */
 int wai_update_sources(wai_ctx *ctx, const double *rate, const double *enthalpy);
+/* State-dependent source controls, one record per source in wai_set_sources order (NULL: none).
+ * They are evaluated on the device inside every residual / Jacobian evaluation, on the cell's
+ * current fluid, as source_network%update is in the reference (src/source_network.F90:90-292
+ * called from src/flow_simulation.F90:1469), in the order the inline controls are set up
+ * (src/source_setup.F90:2381-2412):
+ *   kind 1 deliverability  rate = -coef * sum_phases mobility * (P - pressure)
+ *                          (src/source_control.F90:359-403; pressure constant for the step interval,
+ *                          or table_coord 1 / 2: interpolated in `table` against the flowing
+ *                          enthalpy / the pressure),
+ *   kind 2 recharge        rate = -coef * (P - pressure)                    (:553-578),
+ *   limiter 1 / 2 / 3      total / separated water / separated steam rate scaled down to `limit`
+ *                          (src/source_network_node.F90:247-315; single-stage separator with the
+ *                          saturated enthalpies sep_hf, sep_hg, src/separator.F90:139-166),
+ *   direction 1 / 2        production / injection only                      (:596-620).
+ * Time tables (productivity, reference pressure, limit) are averaged over the step interval by
+ * the host, which sets the records again before each try. */
+typedef struct wai_source_control {
+  int kind, direction, limiter, table_coord, n_table;
+  double coef, pressure, limit, sep_hf, sep_hg;
+  double table[16];   /* (x, pressure) pairs, linear, clamped; n_table <= 8 */
+} wai_source_control;
+int wai_set_source_controls(wai_ctx *ctx, const wai_source_control *controls);
+/* enthalpies of saturated water and steam at a separator pressure, in the context's
+ * thermodynamics (separator_stage_init, src/separator.F90:108-136): sep_hf, sep_hg above */
+int wai_separator_enthalpies(wai_ctx *ctx, double pressure, double *hf, double *hg);
+/* rate and enthalpy of every source on the current fluid (the source_rate / source_enthalpy
+ * output fields; flowing enthalpy for production, src/source.F90:386-480); enthalpy may be NULL */
+int wai_get_source_rates(wai_ctx *ctx, double *rate, double *enthalpy);
 /* thermodynamic region of every owned+halo cell (fluid%region, src/fluid.F90:77-80) */
 int wai_set_regions(wai_ctx *ctx, const int *region);
 int wai_get_regions(wai_ctx *ctx, int *region);

@@ -121,6 +121,28 @@ wo_sim *wo_sim_create(int eos_kind, int n_owned, int n_halo, int n_bc, int n_fac
 void wo_sim_destroy(wo_sim *s);
 wo_eos *wo_sim_eos(wo_sim *s);
 void wo_sim_set_comm(wo_sim *s, wo_halo_fn halo, wo_allreduce_fn ar, void *user);
+/* State-dependent source controls, one record per source in wo_sim_set_sources order, evaluated
+ * on the cell's current fluid at every residual (source_network_update,
+ * src/source_network.F90:90-292, in the order the controls are set up,
+ * src/source_setup.F90:2381-2412): deliverability (src/source_control.F90:359-403) or recharge
+ * (:553-578) gives the rate, the limiter scales it (total / separated water / separated steam,
+ * src/source_network_node.F90:247-315, single-stage separator src/separator.F90:139-166), the
+ * direction control zeroes flow the wrong way (:596-620). */
+typedef struct wo_src_ctl {
+  int kind;        /* 0 rate as given, 1 deliverability, 2 recharge */
+  int direction;   /* 0 both, 1 production only, 2 injection only */
+  int limiter;     /* 0 none, 1 total, 2 water, 3 steam */
+  int table_coord; /* deliverability reference pressure: 0 `pressure`, 1 table against flowing enthalpy, 2 against pressure */
+  int n_table;
+  double coef;     /* productivity index / recharge coefficient for the current step interval */
+  double pressure; /* reference pressure for the current step interval */
+  double limit;
+  double sep_hf, sep_hg;  /* saturated water / steam enthalpy at the separator pressure */
+  double table[16];       /* (x, pressure) pairs, linear, clamped */
+} wo_src_ctl;
+void wo_sim_set_source_controls(wo_sim *s, const wo_src_ctl *ctl); /* NULL: none */
+void wo_sim_source_rates(wo_sim *s, double *rate, double *enthalpy);
+int wo_separator_enthalpies(const wo_eos *e, double pressure, double *hf, double *hg);
 /* table controls: new rate / enthalpy per source (NULL = kept), src/control.F90:263-284 */
 void wo_sim_update_sources(wo_sim *s, const double *rate, const double *enthalpy);
 void wo_sim_set_sources(wo_sim *s, int n, const int *cell, const double *rate,

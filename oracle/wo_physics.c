@@ -703,3 +703,18 @@ void wo_face_flux(const wo_eos *e, const double *fg, const double *f1, const dou
     flux[np + p] = sum;
   }
 }
+
+/* separator_stage_init: src/separator.F90:108-136 -- enthalpies of saturated water and steam at
+ * the separator pressure */
+int wo_separator_enthalpies(const wo_eos *e, double pressure, double *hf, double *hg) {
+  double ts, rho, u;
+  int err = th_sat_temperature(e, pressure, &ts);
+  if (err) return err;
+  err = th_props(e, 1, pressure, ts, &rho, &u);
+  if (err) return err;
+  *hf = u + pressure / rho;
+  err = th_props(e, 2, pressure, ts, &rho, &u);
+  if (err) return err;
+  *hg = u + pressure / rho;
+  return 0;
+}

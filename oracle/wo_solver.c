@@ -33,6 +33,7 @@ struct wo_sim {
   int n_src;
   int *src_cell, *src_comp;
   double *src_rate, *src_enth;
+  wo_src_ctl *src_ctl;  /* NULL: all rates as given */
   int nsub;
   int *sub_ptr;
   wo_halo_fn halo;
@@ -170,7 +171,8 @@ void wo_sim_destroy(wo_sim *s) {
   free(s->face_cells); free(s->face_geom); free(s->cell_geom); free(s->rock);
   free(s->fluid); free(s->last_iteration_fluid); free(s->last_timestep_fluid);
   free(s->cf_ptr); free(s->cf_face); free(s->cf_side); free(s->rowptr); free(s->colidx);
-  free(s->src_cell); free(s->src_comp); free(s->src_rate); free(s->src_enth);
+  free(s->src_cell); free(s->src_comp); free(s->src_rate); free(s->src_enth); free(s->src_ctl);
+  s->src_ctl = NULL;
   free(s->sub_ptr); free(s->fval); free(s->dinv); free(s->lhs_last2); free(s->hist); free(s->hist_prev);
   free(s->tr_phase); free(s->tr_decay); free(s->tr_act); free(s->tr_diff); free(s->tr_bc); free(s->tr_inj);
   free(s);
@@ -209,7 +211,8 @@ void wo_sim_set_comm(wo_sim *s, wo_halo_fn halo, wo_allreduce_fn ar, void *user)
 }
 void wo_sim_set_sources(wo_sim *s, int n, const int *cell, const double *rate,
                         const double *enthalpy, const int *component) {
-  free(s->src_cell); free(s->src_comp); free(s->src_rate); free(s->src_enth);
+  free(s->src_cell); free(s->src_comp); free(s->src_rate); free(s->src_enth); free(s->src_ctl);
+  s->src_ctl = NULL;
   s->n_src = n;
   s->src_cell = (int *)xmalloc(sizeof(int) * n);
   s->src_comp = (int *)xmalloc(sizeof(int) * n);
@@ -219,6 +222,39 @@ void wo_sim_set_sources(wo_sim *s, int n, const int *cell, const double *rate,
   memcpy(s->src_comp, component, sizeof(int) * n);
   memcpy(s->src_rate, rate, sizeof(double) * n);
   memcpy(s->src_enth, enthalpy, sizeof(double) * n);
+}
+void wo_sim_set_source_controls(wo_sim *s, const wo_src_ctl *ctl) {
+  free(s->src_ctl);
+  s->src_ctl = NULL;
+  if (ctl && s->n_src) {
+    s->src_ctl = (wo_src_ctl *)xmalloc(sizeof(wo_src_ctl) * s->n_src);
+    memcpy(s->src_ctl, ctl, sizeof(wo_src_ctl) * s->n_src);
+  }
+}
+static double source_rate(const wo_eos *e, const double *fl, const wo_src_ctl *k, double rate);
+/* rate and enthalpy every source has on the current fluid (the source_rate / source_enthalpy
+ * output fields, src/source.F90:386-480): flowing enthalpy for production, given for injection */
+void wo_sim_source_rates(wo_sim *s, double *rate, double *enthalpy) {
+  const wo_eos *e = &s->eos;
+  int boff = 7 + e->nc - 1, pdof = 8 + e->nc - 1;
+  for (int i = 0; i < s->n_src; i++) {
+    const double *fl = s->fluid + (size_t)s->src_cell[i] * e->df;
+    double q = source_rate(e, fl, s->src_ctl ? s->src_ctl + i : NULL, s->src_rate[i]);
+    double h = s->src_enth[i];
+    if (!(q > 0.0)) {
+      int phases = (int)lround(fl[4]);
+      double sum = 0.0;
+      h = 0.0;
+      for (int p = 0; p < e->nph; p++)
+        if (phases & (1 << p)) sum += fl[boff + p * pdof + 3] * fl[boff + p * pdof] / fl[boff + p * pdof + 1];
+      if (!e->isothermal)
+        for (int p = 0; p < e->nph; p++)
+          if (phases & (1 << p))
+            h += (fl[boff + p * pdof + 3] * fl[boff + p * pdof] / fl[boff + p * pdof + 1] / sum) * fl[boff + p * pdof + 5];
+    }
+    rate[i] = q;
+    if (enthalpy) enthalpy[i] = h;
+  }
 }
 void wo_sim_update_sources(wo_sim *s, const double *rate, const double *enthalpy) {
   if (rate) memcpy(s->src_rate, rate, sizeof(double) * s->n_src);
@@ -327,6 +363,62 @@ void wo_lhs(wo_sim *s, double *lhs) {
     wo_cell_balance(&s->eos, s->fluid + (size_t)c * df, s->rock + c * 8, lhs + c * np);
 }
 
+/* linear, clamped table lookup (interpolation_table_interpolate, src/interpolation.F90:500-545) */
+static double ctl_table(const wo_src_ctl *k, double x) {
+  int n = k->n_table;
+  if (x <= k->table[0]) return k->table[1];
+  if (x >= k->table[2 * (n - 1)]) return k->table[2 * (n - 1) + 1];
+  int i = 0;
+  while (x >= k->table[2 * (i + 1)]) i++;
+  double xi = (x - k->table[2 * i]) / (k->table[2 * (i + 1)] - k->table[2 * i]);
+  return (1.0 - xi) * k->table[2 * i + 1] + xi * k->table[2 * (i + 1) + 1];
+}
+
+/* rate of a controlled source on the cell's fluid fl: see wo_src_ctl in wai_oracle.h */
+static double source_rate(const wo_eos *e, const double *fl, const wo_src_ctl *k, double rate) {
+  if (!k) return rate;
+  int nph = e->nph, boff = 7 + e->nc - 1, pdof = 8 + e->nc - 1;
+  int phases = (int)lround(fl[4]);
+  double mob[4] = {0, 0, 0, 0}, sum = 0.0, h = 0.0;
+  for (int p = 0; p < nph; p++)
+    if (phases & (1 << p)) {
+      const double *ph = fl + boff + p * pdof;
+      mob[p] = ph[3] * ph[0] / ph[1];
+    }
+  for (int p = 0; p < nph; p++) sum += mob[p];
+  if (!e->isothermal)
+    for (int p = 0; p < nph; p++)
+      if (phases & (1 << p)) h += (mob[p] / sum) * fl[boff + p * pdof + 5];
+  if (k->kind == 1) {
+    double pref = k->pressure;
+    if (k->table_coord == 1) pref = ctl_table(k, h);
+    else if (k->table_coord == 2) pref = ctl_table(k, fl[0]);
+    double dp = fl[0] - pref;
+    rate = 0.0;
+    for (int p = 0; p < nph; p++)
+      if (phases & (1 << p)) rate = rate - k->coef * mob[p] * dp;
+  } else if (k->kind == 2) {
+    rate = -k->coef * (fl[0] - k->pressure);
+  }
+  if (k->limiter) {
+    double r = rate;
+    if (k->limiter > 1) {
+      double f = 0.0; /* separated flows are zero unless producing */
+      if (rate < 0.0) {
+        if (h <= k->sep_hf) f = 0.0;
+        else if (h <= k->sep_hg) f = (h - k->sep_hf) / (k->sep_hg - k->sep_hf);
+        else f = 1.0;
+        r = k->limiter == 2 ? (1.0 - f) * rate : f * rate;
+      } else r = 0.0;
+    }
+    double a = fabs(r);
+    if (a > k->limit && a > 1.0e-6) rate = rate * (k->limit / a);
+  }
+  if (k->direction == 1 && !(rate < 0.0)) rate = 0.0;
+  if (k->direction == 2 && !(rate > 0.0)) rate = 0.0;
+  return rate;
+}
+
 /* source term for one cell: src/source.F90:386-480, fluid.F90:377-453; flow[np] */
 static void source_flow(const wo_eos *e, const double *fl, double rate, double enth, int comp,
                         double *flow) {
@@ -390,8 +482,9 @@ void wo_rhs(wo_sim *s, double *rhs) {
     int c = s->src_cell[i];
     if (c < 0 || c >= s->n_owned) continue;
     double flow[MAXBS];
-    source_flow(&s->eos, s->fluid + (size_t)c * df, s->src_rate[i], s->src_enth[i],
-                s->src_comp[i], flow);
+    const double *fl = s->fluid + (size_t)c * df;
+    source_flow(&s->eos, fl, source_rate(&s->eos, fl, s->src_ctl ? s->src_ctl + i : NULL, s->src_rate[i]),
+                s->src_enth[i], s->src_comp[i], flow);
     for (int q = 0; q < np; q++) rhs[c * np + q] += flow[q] / s->cell_geom[4 * c + 3];
   }
 }
@@ -457,7 +550,8 @@ static void cell_residual(const wo_sim *s, int c, double dt, const double *lhs_o
   for (int i = 0; i < s->n_src; i++)
     if (s->src_cell[i] == c) {
       double flow[MAXBS];
-      source_flow(e, own, s->src_rate[i], s->src_enth[i], s->src_comp[i], flow);
+      source_flow(e, own, source_rate(e, own, s->src_ctl ? s->src_ctl + i : NULL, s->src_rate[i]),
+                  s->src_enth[i], s->src_comp[i], flow);
       for (int k = 0; k < np; k++) R[k] += flow[k] / vol;
     }
   for (int k = 0; k < np; k++) out[k] = res_form(s, dt, L[k], R[k], lhs_old, c * np + k);
@@ -1048,7 +1142,8 @@ static void tracer_inflows(wo_sim *s, int it, double *Ar, double *br) {
   for (int i = 0; i < s->n_src; i++) {
     int c = s->src_cell[i];
     if (c < 0 || c >= s->n_owned) continue;
-    double vol = s->cell_geom[4 * c + 3], rate = s->src_rate[i];
+    double vol = s->cell_geom[4 * c + 3];
+    double rate = source_rate(e, s->fluid + (size_t)c * df, s->src_ctl ? s->src_ctl + i : NULL, s->src_rate[i]);
     int comp = s->src_comp[i];
     int component = rate > 0.0 ? (comp <= 0 ? 1 : comp) : (comp <= 0 ? 0 : comp);
     if (!(component < np)) continue;

@@ -343,3 +343,69 @@ def run_problem4(make_ode, spec, ts_cls):
                 max_num_steps=tm["step"]["maximum"]["number"])
     ts.run()
     return lm, ode, y, ts
+
+
+# ---- source controls: deliverability and recharge benchmarks -------------------------------------
+class RowMeshBuilder:
+    """the ten-cube row of test/benchmark/source/*/run/g*.dat for Simulation(mesh_builder=...)"""
+    dim = 3
+
+    def __init__(self, spec):
+        self.spec = spec
+        self.n_cells = len(spec["edges"]) - 1
+
+    def __call__(self, boundaries, sources):
+        from waiwera_amd import mesh as M
+        m = self.spec
+        outer = None
+        for cells, normal, primary, region in boundaries:
+            assert cells == [self.n_cells - 1] and normal[0] > 0.0
+            outer = (primary, region)
+        return M.row_mesh_1d(m["edges"], m["thickness"], height=m["height"], outer_bc=outer, sources=sources)
+
+
+def run_source_control(name, ode_factory=None, after_init=None):
+    """one run of the source-control fixture through the input front end; returns the simulation
+    and {times, cell history, source history, final fields}"""
+    from waiwera_amd.simulation import Simulation
+    fx = load_fixture("benchmark_source_controls.json")
+    run = fx["runs"][name]
+    import copy
+    inp = dict(copy.deepcopy(run["input"]), output={"initial": True, "frequency": 1, "final": True})
+    for rt in inp["rock"]["types"]:
+        if rt.get("cells") == "all":      # the fixture's shorthand for the full cell list
+            rt["cells"] = list(range(len(fx["mesh"]["edges"]) - 1))
+    sim = Simulation(inp, ode_factory=ode_factory, mesh_builder=RowMeshBuilder(fx["mesh"]))
+    if after_init:
+        after_init(sim)
+    sim.run()
+    w = run["watch_cell"]
+    outs = sim.outputs
+    got = {"times": np.array([o["time"] for o in outs]),
+           "history": {"Pressure": np.array([o["fluid_pressure"][w] for o in outs]),
+                       "Temperature": np.array([o["fluid_temperature"][w] for o in outs]),
+                       "Vapour saturation": np.array([o["fluid_vapour_saturation"][w] for o in outs])},
+           "source_history": {"Generation rate": np.array([o["source_rate"][0] for o in outs]),
+                              "Enthalpy": np.array([o["source_enthalpy"][0] for o in outs])},
+           "final": {"Pressure": outs[-1]["fluid_pressure"], "Temperature": outs[-1]["fluid_temperature"],
+                     "Vapour saturation": outs[-1]["fluid_vapour_saturation"]}}
+    return sim, run, got
+
+
+def source_control_errors(run, got):
+    """deviations from the AUTOUGH2 listing in the norms of field_errors: final fields, and the
+    histories at the listing's own output times (matched by time)"""
+    ta, tg = np.asarray(run["times"]), got["times"]
+    near = np.array([int(np.argmin(np.abs(tg - t))) for t in ta])
+    # AUTOUGH2 rounds the prescribed step sizes to its input format (times agree to 1e-4) and, in
+    # the recharge run, cut its last step short: that one output has no counterpart
+    ok = np.abs(tg[near] - ta) <= 1e-4 * np.maximum(ta, 1.0)
+    assert ok.sum() >= len(ta) - 1, "output times differ from the listing's"
+    idx, sel = near[ok], np.nonzero(ok)[0]
+    out = {}
+    for k, v in run["final"].items():
+        out["final " + k] = field_errors({k: got["final"][k]}, {k: v}, [k])[k]
+    for group in ("history", "source_history"):
+        for k, v in run[group].items():
+            out[group + " " + k] = field_errors({k: got[group][k][idx]}, {k: np.asarray(v)[sel]}, [k])[k]
+    return out

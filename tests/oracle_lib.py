@@ -84,6 +84,9 @@ def load(path):
         "wo_sim_set_comm": (None, [C.c_void_p, HALOFN, ARFN, C.c_void_p]),
         "wo_sim_set_sources": (None, [C.c_void_p, i32, pi, pd, pd, pi]),
         "wo_sim_update_sources": (None, [C.c_void_p, pd, pd]),
+        "wo_sim_set_source_controls": (None, [C.c_void_p, C.c_void_p]),
+        "wo_sim_source_rates": (None, [C.c_void_p, pd, pd]),
+        "wo_separator_enthalpies": (i32, [C.c_void_p, C.c_double, pd, pd]),
         "wo_sim_set_subdomains": (None, [C.c_void_p, i32, pi]),
         "wo_sim_set_regions": (None, [C.c_void_p, pi]),
         "wo_sim_get_regions": (None, [C.c_void_p, pi]),
@@ -159,6 +162,24 @@ class OracleSim:
         r = f64(rate) if rate is not None else None
         e = f64(enthalpy) if enthalpy is not None else None
         self.L.wo_sim_update_sources(self.h, dp(r) if r is not None else None, dp(e) if e is not None else None)
+
+    def set_source_controls(self, records):
+        # wo_src_ctl has the layout of wai_source_control: reuse the host-side packer
+        from waiwera_amd.lib import source_controls
+        self._ctl = source_controls(records) if records is not None else None
+        self.L.wo_sim_set_source_controls(self.h, C.cast(self._ctl, C.c_void_p) if self._ctl is not None else None)
+
+    def separator_enthalpies(self, pressure):
+        hf, hg = np.zeros(1), np.zeros(1)
+        assert self.L.wo_separator_enthalpies(C.byref(self.eos), pressure, dp(hf), dp(hg)) == 0
+        return float(hf[0]), float(hg[0])
+
+    def source_rates(self):
+        n = getattr(self.mesh, "n_src", 0)
+        r, e = np.zeros(n), np.zeros(n)
+        if n:
+            self.L.wo_sim_source_rates(self.h, dp(r), dp(e))
+        return r, e
 
     def set_regions(self, region):
         r = i32a(region)

@@ -112,3 +112,19 @@ def test_restart_from_waiwera_hdf5_and_write_output(tmp_path):
     for k in ("fluid_pressure", "fluid_temperature", "fluid_vapour_saturation", "fluid_region"):
         assert np.abs(mine[k] - ref[k]).max() <= 1.0e-6 * np.abs(ref[k]).max(), k
     sim.ode.destroy()
+
+
+@pytest.mark.parametrize("name", ["deliv_delv", "deliv_delg_flow", "deliv_delg_pi_table", "deliv_delg_pwb_table",
+                                  "deliv_delg_limit", "deliv_delt", "deliv_delw", "recharge_outflow"])
+def test_source_controls_against_autough2(name):
+    """the reference's deliverability and recharge benchmarks on the HIP path: the controls are
+    evaluated on the device inside every residual / Jacobian (wai_set_source_controls)"""
+    sim, run, got = B.run_source_control(name)
+    worst = B.source_control_errors(run, got)
+    recharge = name.startswith("recharge")
+    for k, (l2, linf) in worst.items():
+        if k.startswith("final"):
+            assert l2 < (1.0e-4 if recharge else 5.0e-3), (k, l2)
+        else:
+            assert l2 < (1.0e-3 if recharge and k.startswith("history") else 1.0e-2), (k, l2)
+    sim.ode.destroy()

@@ -420,3 +420,60 @@ def test_pipelined_pc_kernel(FS, oracle, monkeypatch):
             res[pipe, ksp] = its
         sim.destroy(); osim.close()
     assert abs(res["1", "bcgs"] - res["0", "bcgs"]) <= 2 and abs(res["1", "gmres"] - res["0", "gmres"]) <= 1
+
+
+def test_state_dependent_source_controls(FS, oracle):
+    """deliverability (constant and enthalpy-table wellbore pressure), recharge, the three
+    limiters behind a separator and the direction control, evaluated inside the residual and the FD
+    Jacobian: rates, residual and Jacobian against the oracle on a state with a two-phase lens"""
+    g, lm, sim, osim, y, region = build(FS, oracle, eos="we", lens=True, dims=(8, 8, 8), brick=(4, 4, 4))
+    assert lm.n_src == 8
+    hf, hg = sim.separator_enthalpies(7.0e5)
+    ohf, ohg = osim.separator_enthalpies(7.0e5)
+    assert abs(hf - ohf) <= 1e-12 * ohf and abs(hg - ohg) <= 1e-12 * ohg
+    recs = [dict(kind="deliverability", coef=1.0e-11, pressure=2.0e5, direction="production"),
+            dict(kind="deliverability", coef=3.0e-12, table_coord="enthalpy",
+                 table=[(0.0, 1.5e5), (2.0e5, 2.5e5), (1.2e6, 4.0e5)]),
+            dict(kind="recharge", coef=1.0e-3, pressure=1.0e6),
+            dict(kind="recharge", coef=1.0e-3, pressure=1.0e8, direction="out"),          # would inject: zeroed
+            dict(kind="deliverability", coef=1.0e-10, pressure=1.0e5, limiter="total", limit=3.0),
+            dict(kind="deliverability", coef=1.0e-10, pressure=1.0e5, limiter="steam", limit=0.5, sep_hf=hf, sep_hg=hg),
+            dict(kind="deliverability", coef=1.0e-10, pressure=1.0e5, limiter="water", limit=2.0, sep_hf=hf, sep_hg=hg),
+            dict(limiter="total", limit=1.0)]                                              # fixed rate, limited
+    sim.set_source_controls(recs)
+    osim.set_source_controls(recs)
+    yo = osim.yvec(y)
+    assert sim.pre_eval(0.0, y) == 0 and osim.pre_eval(yo) == 0
+    rg, eg = sim.source_rates()
+    ro, eo = osim.source_rates()
+    assert np.abs(rg - ro).max() <= 1e-11 * np.abs(ro).max() and np.abs(eg - eo).max() <= 1e-11 * np.abs(eo).max()
+    assert ro[3] == 0.0 and abs(abs(ro[4]) - 3.0) < 1e-12 and abs(abs(ro[7]) - 1.0) < 1e-12 and ro[0] < 0.0
+    n = sim.n_owned * sim.num_primary_variables
+    L = osim.lhs()
+    dt = 1.0e4
+    f = np.zeros(n)
+    assert sim.residual(0.0, dt, y, L, f) == 0
+    err, fo = osim.residual(yo, dt, L)
+    assert np.abs(f - fo).max() <= 1e-11 * np.abs(fo).max()
+    assert sim.jacobian(0.0, dt, y, L) == 0
+    err, Jo = osim.jacobian(yo, dt, L, fo, mode=0)
+    assert np.abs(sim.jacobian_values() - Jo).max() <= 1e-5 * np.abs(Jo).max()
+    # the controls are part of the Jacobian: without them it differs
+    sim.set_source_controls(None)
+    assert sim.jacobian(0.0, dt, y, L) == 0
+    assert np.abs(sim.jacobian_values() - Jo).max() > 1e-3 * np.abs(Jo).max()
+    # and a few time steps
+    sim.set_source_controls(recs)
+    sim.set_opts(ksp_rtol=1e-10, ftol_rel=1e-9)
+    o = osim.opts()
+    o.ksp_rtol, o.ftol_rel = 1e-10, 1e-9
+    yg = y.copy()
+    dt = 1.0e3
+    for step in range(3):
+        reason, nits, kits = sim.timestep(0.0, dt, yg)
+        r, ok = osim.timestep(yo, dt, o)
+        assert reason > 0 and r > 0 and nits == r
+        assert np.array_equal(sim.regions(), osim.regions())
+        assert relmax(yg, yo[: yg.size]) < 1e-7
+        dt *= 2
+    sim.destroy(); osim.close()

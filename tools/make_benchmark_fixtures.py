@@ -321,7 +321,35 @@ def problem5(case="a"):
     json.dump(out, open(os.path.join(OUT, "benchmark_problem5a.json"), "w"), indent=1)
 
 
+def source_controls():
+    """test/benchmark/source/deliverability (7 runs) and source/recharge: a row of ten 100 m cubes
+    (gdeliv.dat / grecharge.dat: vertices 0..1000 m by 100 m, one layer 0..-100 m; the mesh file
+    itself is ExodusII), no gravity, a well on deliverability / a recharge outflow in cell 0.  From
+    each AUTOUGH2 listing: every output time, the history in the cell the reference's test watches,
+    the source's generation rate and enthalpy history, and the final element table."""
+    out = {"source": "test/benchmark/source/{deliverability,recharge}/run/*.json and *.listing",
+           "mesh": {"edges": [100.0 * i for i in range(11)], "height": 100.0, "thickness": 100.0}, "runs": {}}
+    runs = [("deliverability", "deliv_" + r, 4) for r in
+            ("delv", "delg_flow", "delg_pi_table", "delg_pwb_table", "delg_limit", "delt", "delw")]
+    runs.append(("recharge", "recharge_outflow", 0))
+    for bench, name, watch in runs:
+        base = os.path.join(REF, "source", bench, "run")
+        d = json.load(open(os.path.join(base, name + ".json")))
+        n = 10
+        elem = all_tables(os.path.join(base, name + ".listing"), "ELEMENT TABLE")
+        gen = all_tables(os.path.join(base, name + ".listing"), "GENERATION TABLE")
+        assert len(elem) == len(gen)
+        fields = [k for k in ("Pressure", "Temperature", "Vapour saturation") if k in elem[0][1]]
+        out["runs"][name] = {
+            "input": trim_input(d), "watch_cell": watch, "times": [t for t, _ in elem],
+            "history": {k: [tab[k][watch] for _, tab in elem] for k in fields},
+            "source_history": {k: [tab[k][0] for _, tab in gen] for k in ("Generation rate", "Enthalpy")},
+            "final": {k: elem[-1][1][k][:n] for k in fields}}
+    json.dump(out, open(os.path.join(OUT, "benchmark_source_controls.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
+    source_controls()
     input_files()
     problem5("a")
     problem5("b")

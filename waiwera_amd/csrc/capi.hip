@@ -467,7 +467,7 @@ void free_all(wai_ctx* c) {
   DeviceMesh& m = c->mesh;
   F(m.rock); F(m.vol); F(m.fgeom); F(m.fdir); F(m.adj_face); F(m.adj_other); F(m.adj_blk);
   F(m.diag_blk); F(m.cell_src);
-  F(c->src.cell); F(c->src.comp); F(c->src.next); F(c->src.rate); F(c->src.enth);
+  F(c->src.cell); F(c->src.comp); F(c->src.next); F(c->src.rate); F(c->src.enth); F(c->src.ctl);
   F(c->J.rowptr); F(c->J.col); F(c->J.val);
   IluSchedule& s = c->ilu;
   F(s.sub_ptr); F(s.sub_nlev); F(s.row_info); F(s.row_uoff); F(s.fval); F(s.dinv);
@@ -869,7 +869,7 @@ int wai_set_sources(wai_ctx* c, int n, const int* cell, const double* rate, cons
   if (!c || n < 0) return -2;
   Sources& s = c->src;
   auto F = [](void* p) { if (p) (void)hipFree(p); };
-  F(s.cell); F(s.comp); F(s.next); F(s.rate); F(s.enth);
+  F(s.cell); F(s.comp); F(s.next); F(s.rate); F(s.enth); F(s.ctl);
   s = Sources();
   s.n = n;
   const int N = c->mesh.n_owned;
@@ -896,6 +896,59 @@ int wai_update_sources(wai_ctx* c, const double* rate, const double* enthalpy) {
   if (rate) HIPCHK(c, hipMemcpyAsync(c->src.rate, rate, nb, hipMemcpyDefault, c->stream));
   if (enthalpy) HIPCHK(c, hipMemcpyAsync(c->src.enth, enthalpy, nb, hipMemcpyDefault, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static_assert(sizeof(wai_source_control) == sizeof(SrcCtl), "wai_source_control and the device record differ");
+
+int wai_set_source_controls(wai_ctx* c, const wai_source_control* controls) {
+  if (!c) return -2;
+  Sources& s = c->src;
+  if (!controls || !s.n) {
+    if (s.ctl) (void)hipFree(s.ctl);
+    s.ctl = nullptr;
+    return 0;
+  }
+  for (int i = 0; i < s.n; i++) {
+    const wai_source_control& k = controls[i];
+    if (k.kind < 0 || k.kind > 2 || k.direction < 0 || k.direction > 2 || k.limiter < 0 || k.limiter > 3 ||
+        k.table_coord < 0 || k.table_coord > 2 || (k.table_coord && (k.n_table < 1 || k.n_table > 8))) {
+      c->err = "bad source control record";
+      return -1;
+    }
+  }
+  if (!s.ctl) HIPCHK(c, hipMalloc(&s.ctl, sizeof(SrcCtl) * (size_t)s.n));
+  HIPCHK(c, hipMemcpyAsync(s.ctl, controls, sizeof(SrcCtl) * (size_t)s.n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int wai_separator_enthalpies(wai_ctx* c, double pressure, double* hf, double* hg) {
+  if (!c || !hf || !hg) return -2;
+  double* tmp = nullptr;
+  double host[3];
+  HIPCHK(c, hipMalloc(&tmp, 3 * sizeof(double)));
+  launch_separator(c, pressure, tmp);
+  HIPCHK(c, hipMemcpyAsync(host, tmp, sizeof host, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(tmp);
+  if (host[2] != 0.0) { c->err = "separator pressure outside the saturation line"; return -1; }
+  *hf = host[0];
+  *hg = host[1];
+  return 0;
+}
+
+int wai_get_source_rates(wai_ctx* c, double* rate, double* enthalpy) {
+  if (!c || !rate) return -2;
+  const size_t n = (size_t)c->src.n;
+  if (!n) return 0;
+  double* tmp = nullptr;
+  HIPCHK(c, hipMalloc(&tmp, 2 * n * sizeof(double)));
+  launch_source_rates(c, tmp);
+  HIPCHK(c, hipMemcpyAsync(rate, tmp, n * sizeof(double), hipMemcpyDefault, c->stream));
+  if (enthalpy) HIPCHK(c, hipMemcpyAsync(enthalpy, tmp + n, n * sizeof(double), hipMemcpyDefault, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(tmp);
   return 0;
 }
 

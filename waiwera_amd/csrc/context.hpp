@@ -32,6 +32,7 @@ struct Sources {
   int n = 0;
   int* cell = nullptr; int* comp = nullptr; int* next = nullptr;
   double* rate = nullptr; double* enth = nullptr;
+  SrcCtl* ctl = nullptr;   // state-dependent controls (wai_set_source_controls), null: none
 };
 
 // Block matrix in HBM: block-ELL, slot-major struct-of-arrays ("SELL" with one slice):
@@ -177,6 +178,8 @@ int launch_transitions(wai_ctx* c, const double* y_old, double* search, double* 
 int launch_tracer_assemble(wai_ctx* c, const TracerForm& tf, const double* alx_last,
                            const double* alx_last2, double* b);
 int launch_tracer_lhs(wai_ctx* c, double* Al);
+int launch_separator(wai_ctx* c, double pressure, double* out);   // out[3] on the device: hf, hg, err
+int launch_source_rates(wai_ctx* c, double* out);   // out[0..n) rates, out[n..2n) enthalpies (device)
 // X[cell][nt] <-> x[cell] of tracer it; alx = Al o X
 int launch_tracer_pick(wai_ctx* c, const double* X, int it, double* x);
 int launch_tracer_put(wai_ctx* c, const double* x, int it, double* X);

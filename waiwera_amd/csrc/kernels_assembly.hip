@@ -100,6 +100,7 @@ struct MeshView {
   const int* adj_face; const int* adj_other; const int* adj_blk; const int* diag_blk;
   const int* cell_src;
   const int* src_next; const int* src_comp; const double* src_rate; const double* src_enth;
+  const SrcCtl* src_ctl;   // null: all rates as given
   int n_owned, n_local, n_faces, max_deg;
 };
 
@@ -129,7 +130,7 @@ __device__ __forceinline__ void source_terms(const MeshView& m, int c, const Cel
   using E = EosT<KIND>;
   for (int si = m.cell_src[c]; si >= 0; si = m.src_next[si]) {
     double flow[E::np];
-    source_flow<KIND>(s, m.src_rate[si], m.src_enth[si], m.src_comp[si], flow);
+    source_flow<KIND>(s, source_rate<KIND>(s, m.src_ctl, si, m.src_rate[si]), m.src_enth[si], m.src_comp[si], flow);
 #pragma unroll
     for (int k = 0; k < E::np; k++) R[k] += flow[k] / vol;
   }
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(TPB) void k_tracer_assemble(MeshView m, const doubl
   }
   // sources (tracer_source_iterator, flow_simulation.F90:1722-1772)
   for (int si = m.cell_src[c]; si >= 0; si = m.src_next[si]) {
-    const double rate = m.src_rate[si];
+    const double rate = source_rate<KIND>(own, m.src_ctl, si, m.src_rate[si]);
     const int comp = m.src_comp[si];
     const int component = rate > 0.0 ? (comp <= 0 ? 1 : comp) : (comp <= 0 ? 0 : comp);
     if (!(component < E::np)) continue;
@@ -467,6 +468,47 @@ __global__ __launch_bounds__(TPB) void k_tracer_lhs(MeshView m, const double* __
   load_state<KIND>(flu, stride, c, own);
   load_rock(m.rock, m.n_local, c, rown);
   for (int it = 0; it < tr.nt; it++) Al[(size_t)c * tr.nt + it] = tracer_coef<KIND>(own, rown, tr.phase[it]);
+}
+
+// rate and (flowing or injection) enthalpy of every source on the current fluid: the source_rate /
+// source_enthalpy output fields
+template <int KIND>
+__global__ __launch_bounds__(TPB) void k_source_rates(MeshView m, const int* __restrict__ src_cell, int n_src,
+                                                      const double* __restrict__ flu, size_t stride,
+                                                      double* __restrict__ out) {
+  using E = EosT<KIND>;
+  const int si = blockIdx.x * blockDim.x + threadIdx.x;
+  if (si >= n_src) return;
+  CellState<KIND> s;
+  load_state<KIND>(flu, stride, src_cell[si], s);
+  const double q = source_rate<KIND>(s, m.src_ctl, si, m.src_rate[si]);
+  double h = m.src_enth[si];
+  if (!(q > 0.0)) {
+    const int phases = (int)s.phases;
+    double sum = 0.0;
+    h = 0.0;
+#pragma unroll
+    for (int p = 0; p < E::nph; p++) if (phases & (1 << p)) sum += s.kr[p] * s.rho[p] / s.mu[p];
+    if constexpr (!E::isothermal) {
+#pragma unroll
+      for (int p = 0; p < E::nph; p++)
+        if (phases & (1 << p)) h += (s.kr[p] * s.rho[p] / s.mu[p] / sum) * s.h[p];
+    }
+  }
+  out[si] = q;
+  out[n_src + si] = h;
+}
+
+// separator_stage_init (separator.F90:108-136): enthalpies of saturated water and steam at the
+// separator pressure; out = {hf, hg, err}
+__global__ void k_separator(int thermo, double pressure, double* __restrict__ out) {
+  double ts = 0.0, rho = 0.0, u = 0.0;
+  int err = th::sat_temperature(thermo, pressure, ts);
+  if (!err) err = th::props(thermo, 1, pressure, ts, rho, u);
+  out[0] = u + pressure / rho;
+  if (!err) err = th::props(thermo, 2, pressure, ts, rho, u);
+  out[1] = u + pressure / rho;
+  out[2] = (double)err;
 }
 
 __global__ __launch_bounds__(TPB) void k_tracer_pick(const double* __restrict__ X, int n, int nt, int it,
@@ -587,7 +629,7 @@ static MeshView view(wai_ctx* c) {
   m.adj_face = c->mesh.adj_face; m.adj_other = c->mesh.adj_other; m.adj_blk = c->mesh.adj_blk;
   m.diag_blk = c->mesh.diag_blk; m.cell_src = c->mesh.cell_src;
   m.src_next = c->src.next; m.src_comp = c->src.comp; m.src_rate = c->src.rate;
-  m.src_enth = c->src.enth;
+  m.src_enth = c->src.enth; m.src_ctl = c->src.ctl;
   m.n_owned = c->mesh.n_owned; m.n_local = c->mesh.n_local; m.n_faces = c->mesh.n_faces;
   m.max_deg = c->mesh.max_deg;
   return m;
@@ -659,6 +701,17 @@ int launch_tracer_assemble(wai_ctx* c, const TracerForm& tf, const double* alx_l
 int launch_tracer_lhs(wai_ctx* c, double* Al) {
   const MeshView m = view(c);
   WAI_BY_EOS(c, k_tracer_lhs, grid_for(m.n_owned), m, c->flu, (size_t)c->mesh.n_local, c->tr, Al);
+  return 0;
+}
+
+int launch_separator(wai_ctx* c, double pressure, double* out) {
+  hipLaunchKernelGGL(k_separator, 1, 1, 0, c->stream, c->ep.thermo, pressure, out);
+  return 0;
+}
+
+int launch_source_rates(wai_ctx* c, double* out) {
+  const MeshView m = view(c);
+  WAI_BY_EOS(c, k_source_rates, grid_for(c->src.n), m, c->src.cell, c->src.n, c->flu, (size_t)c->mesh.n_local, out);
   return 0;
 }
 

@@ -510,6 +510,75 @@ __device__ __forceinline__ double face_phase_flux(const FaceGeom& g, const CellS
   return out;
 }
 
+// State-dependent source controls: the record of include/waiwera_hip.h (wai_source_control),
+// evaluated on the cell's current -- base or perturbed -- state, so that the FD Jacobian carries
+// d(rate)/d(primaries) as it does in the reference, where source_network%update runs inside every
+// cell_inflows call (flow_simulation.F90:1469).  Order as the controls are set up
+// (source_setup.F90:2381-2412): deliverability (source_control.F90:359-403) or recharge (:553-578)
+// gives the rate, the limiter scales it (source_network_node.F90:247-315; water / steam through a
+// single-stage separator, separator.F90:139-166), the direction control zeroes it (:596-620).
+struct SrcCtl {
+  int kind, direction, limiter, table_coord, n_table;
+  double coef, pressure, limit, sep_hf, sep_hg;
+  double table[16];
+};
+
+__device__ inline double ctl_table(const SrcCtl& k, double x) {
+  const int n = k.n_table;
+  if (x <= k.table[0]) return k.table[1];
+  if (x >= k.table[2 * (n - 1)]) return k.table[2 * (n - 1) + 1];
+  int i = 0;
+  while (x >= k.table[2 * (i + 1)]) i++;
+  const double xi = (x - k.table[2 * i]) / (k.table[2 * (i + 1)] - k.table[2 * i]);
+  return (1.0 - xi) * k.table[2 * i + 1] + xi * k.table[2 * (i + 1) + 1];
+}
+
+template <int KIND>
+__device__ inline double source_rate(const CellState<KIND>& s, const SrcCtl* ctl, int si, double rate) {
+  using E = EosT<KIND>;
+  if (!ctl) return rate;
+  const SrcCtl& k = ctl[si];
+  const int phases = (int)s.phases;
+  double mob[E::nph], sum = 0.0, h = 0.0;
+#pragma unroll
+  for (int p = 0; p < E::nph; p++) {
+    mob[p] = (phases & (1 << p)) ? s.kr[p] * s.rho[p] / s.mu[p] : 0.0;
+    sum += mob[p];
+  }
+  if constexpr (!E::isothermal) {
+#pragma unroll
+    for (int p = 0; p < E::nph; p++) if (phases & (1 << p)) h += (mob[p] / sum) * s.h[p];
+  }
+  if (k.kind == 1) {
+    double pref = k.pressure;
+    if (k.table_coord == 1) pref = ctl_table(k, h);
+    else if (k.table_coord == 2) pref = ctl_table(k, s.P);
+    const double dp = s.P - pref;
+    rate = 0.0;
+#pragma unroll
+    for (int p = 0; p < E::nph; p++) if (phases & (1 << p)) rate = rate - k.coef * s.permfac * mob[p] * dp;
+  } else if (k.kind == 2) {
+    rate = -k.coef * (s.P - k.pressure);
+  }
+  if (k.limiter) {
+    double r = rate;
+    if (k.limiter > 1) {
+      if (rate < 0.0) {
+        double f;
+        if (h <= k.sep_hf) f = 0.0;
+        else if (h <= k.sep_hg) f = (h - k.sep_hf) / (k.sep_hg - k.sep_hf);
+        else f = 1.0;
+        r = k.limiter == 2 ? (1.0 - f) * rate : f * rate;
+      } else r = 0.0;
+    }
+    const double a = fabs(r);
+    if (a > k.limit && a > 1.0e-6) rate = rate * (k.limit / a);
+  }
+  if (k.direction == 1 && !(rate < 0.0)) rate = 0.0;
+  if (k.direction == 2 && !(rate > 0.0)) rate = 0.0;
+  return rate;
+}
+
 // source term (source.F90:386-480, fluid.F90:377-453): flow[np] for one source
 template <int KIND>
 __device__ __forceinline__ void source_flow(const CellState<KIND>& s, double rate, double enth,

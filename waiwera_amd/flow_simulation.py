@@ -72,6 +72,27 @@ class FlowSimulation:
         self._chk(LIB.wai_update_sources(self.h, r.ctypes.data_as(_lib.pd) if r is not None else None,
                                          e.ctypes.data_as(_lib.pd) if e is not None else None), "update_sources")
 
+    def set_source_controls(self, records):
+        """state-dependent controls, one dict per source (waiwera_amd.lib.source_controls) or None"""
+        if records is None:
+            self._chk(LIB.wai_set_source_controls(self.h, None), "set_source_controls")
+            return
+        if len(records) != self.mesh.n_src:
+            raise ValueError("one control record per source")
+        self._chk(LIB.wai_set_source_controls(self.h, _lib.source_controls(records)), "set_source_controls")
+
+    def separator_enthalpies(self, pressure):
+        hf, hg = C.c_double(0.0), C.c_double(0.0)
+        self._chk(LIB.wai_separator_enthalpies(self.h, pressure, C.byref(hf), C.byref(hg)), "separator_enthalpies")
+        return hf.value, hg.value
+
+    def source_rates(self):
+        """(rate, enthalpy) of every source on the current fluid"""
+        r, e = np.zeros(self.mesh.n_src), np.zeros(self.mesh.n_src)
+        if self.mesh.n_src:
+            self._chk(LIB.wai_get_source_rates(self.h, r.ctypes.data_as(_lib.pd), e.ctypes.data_as(_lib.pd)), "get_source_rates")
+        return r, e
+
     # ------------------------------------------------------------------------------------------
     def _chk(self, rc, what):
         if rc < 0:

@@ -37,6 +37,13 @@ module waiwera_hip_module
      integer(c_int) :: thermo   !! 0 IAPWS-97, 1 IFC-67
   end type wai_eos_desc
 
+  type, bind(c), public :: wai_source_control
+     integer(c_int) :: kind = 0, direction = 0, limiter = 0, table_coord = 0, n_table = 0
+     real(c_double) :: coef = 0._c_double, pressure = 0._c_double, limit = 0._c_double
+     real(c_double) :: sep_hf = 0._c_double, sep_hg = 0._c_double
+     real(c_double) :: table(16) = 0._c_double
+  end type wai_source_control
+
   type, bind(c), public :: wai_solver_opts
      integer(c_int) :: ksp_type, gmres_restart, ksp_max_its
      real(c_double) :: ksp_rtol, ksp_atol
@@ -85,6 +92,22 @@ module waiwera_hip_module
        type(c_ptr), value :: ctx
        type(c_ptr), value :: rate, enthalpy   ! c_loc of real(c_double) arrays or c_null_ptr (kept)
      end function wai_update_sources
+     integer(c_int) function wai_set_source_controls(ctx, controls) bind(c, name = "wai_set_source_controls")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       type(c_ptr), value :: controls   ! c_loc of a wai_source_control array, or c_null_ptr
+     end function wai_set_source_controls
+     integer(c_int) function wai_separator_enthalpies(ctx, pressure, hf, hg) bind(c, name = "wai_separator_enthalpies")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: pressure
+       real(c_double), intent(out) :: hf, hg
+     end function wai_separator_enthalpies
+     integer(c_int) function wai_get_source_rates(ctx, rate, enthalpy) bind(c, name = "wai_get_source_rates")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: rate(*), enthalpy(*)
+     end function wai_get_source_rates
      integer(c_int) function wai_set_regions(ctx, region) bind(c, name = "wai_set_regions")
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx
@@ -277,7 +300,7 @@ module waiwera_hip_module
   end type hip_flow_simulation_type
 
   public :: wai_set_tracers, wai_set_tracer_bc, wai_set_tracer_injection, wai_set_aux_solver
-  public :: wai_default_eos, wai_default_opts, wai_set_bc, wai_set_sources, wai_update_sources, wai_set_regions, &
+  public :: wai_default_eos, wai_default_opts, wai_set_bc, wai_set_sources, wai_update_sources, wai_set_source_controls, wai_get_source_rates, wai_separator_enthalpies, wai_set_regions, &
        wai_get_regions, wai_jacobian_nnzb, wai_jacobian_pattern, wai_jacobian_get_values
 
 contains

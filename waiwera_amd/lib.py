@@ -38,6 +38,38 @@ class EosDesc(C.Structure):
                 ("partial_pressure_scale", d), ("thermo", i32)]
 
 
+class SourceControl(C.Structure):
+    """wai_source_control (include/waiwera_hip.h): state-dependent control of one source"""
+    _fields_ = [("kind", i32), ("direction", i32), ("limiter", i32), ("table_coord", i32), ("n_table", i32),
+                ("coef", d), ("pressure", d), ("limit", d), ("sep_hf", d), ("sep_hg", d), ("table", d * 16)]
+
+
+SRC_KIND = {"rate": 0, "deliverability": 1, "recharge": 2}
+SRC_DIRECTION = {"both": 0, "production": 1, "out": 1, "injection": 2, "in": 2}
+SRC_LIMITER = {None: 0, "total": 1, "water": 2, "steam": 3}
+
+
+def source_controls(records):
+    """array of SourceControl from dicts {kind, direction, limiter, coef, pressure, limit, sep_hf,
+    sep_hg, table_coord, table} (missing keys: no control of that sort)"""
+    arr = (SourceControl * max(len(records), 1))()
+    for k, r in zip(arr, records):
+        k.kind = SRC_KIND[r.get("kind", "rate")]
+        k.direction = SRC_DIRECTION[r.get("direction", "both")]
+        k.limiter = SRC_LIMITER[r.get("limiter")]
+        k.coef, k.pressure = r.get("coef", 0.0), r.get("pressure", 0.0)
+        k.limit, k.sep_hf, k.sep_hg = r.get("limit", 0.0), r.get("sep_hf", 0.0), r.get("sep_hg", 0.0)
+        tab = r.get("table")
+        k.table_coord = {None: 0, "enthalpy": 1, "pressure": 2}[r.get("table_coord")] if tab is not None else 0
+        if tab is not None:
+            if len(tab) > 8:
+                raise ValueError("reference pressure tables hold at most 8 points")
+            k.n_table = len(tab)
+            for q, (x, v) in enumerate(tab):
+                k.table[2 * q], k.table[2 * q + 1] = x, v
+    return arr
+
+
 class SolverOpts(C.Structure):
     _fields_ = [("ksp_type", i32), ("gmres_restart", i32), ("ksp_max_its", i32),
                 ("ksp_rtol", d), ("ksp_atol", d), ("max_newton_its", i32),
@@ -67,6 +99,9 @@ def _load():
         "wai_set_bc": (i32, [vp, pd, pi]),
         "wai_set_sources": (i32, [vp, i32, pi, pd, pd, pi]),
         "wai_update_sources": (i32, [vp, pd, pd]),
+        "wai_set_source_controls": (i32, [vp, C.POINTER(SourceControl)]),
+        "wai_get_source_rates": (i32, [vp, pd, pd]),
+        "wai_separator_enthalpies": (i32, [vp, d, pd, pd]),
         "wai_set_regions": (i32, [vp, pi]),
         "wai_get_regions": (i32, [vp, pi]),
         "wai_get_fluid": (i32, [vp, i32, vp]),

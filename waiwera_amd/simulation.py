@@ -37,8 +37,7 @@ from . import gmsh, unstructured
 from .timestepper import Timestepper
 from .interpolation import Table
 
-UNSUPPORTED_SOURCE_KEYS = ("deliverability", "recharge", "limiter", "separator", "direction", "injectivity",
-                           "factor", "network")
+UNSUPPORTED_SOURCE_KEYS = ("injectivity", "factor", "network")
 
 
 def _get(d, path, default=None):
@@ -115,7 +114,7 @@ def zone_cells(zone, centroids):
 class Simulation:
     """One Waiwera input file -> mesh, flow simulation object and time stepper."""
 
-    def __init__(self, inp, base_dir=".", ode_factory=None, device=0):
+    def __init__(self, inp, base_dir=".", ode_factory=None, device=0, mesh_builder=None):
         self.inp = inp
         if _get(inp, "mesh.minc") is not None:
             raise NotImplementedError("MINC zones from an input file")
@@ -123,9 +122,15 @@ class Simulation:
         mesh = inp.get("mesh")
         if isinstance(mesh, str):
             mesh = {"filename": mesh}
-        nodes, cells, dim = gmsh.read_msh(os.path.join(base_dir, mesh["filename"]))
+        if mesh_builder is None:
+            nodes, cells, dim = gmsh.read_msh(os.path.join(base_dir, mesh["filename"]))
+            n = len(cells)
+        else:
+            # mesh_builder(boundaries, sources) -> LocalMesh for meshes that are not gmsh files (the
+            # ExodusII meshes of some reference benchmarks are rebuilt from their description);
+            # mesh_builder.dim, mesh_builder.n_cells describe it
+            dim, n = mesh_builder.dim, mesh_builder.n_cells
         self.dim = dim
-        n = len(cells)
         # gravity (flow_simulation.F90:800-846)
         gin = inp.get("gravity")
         grav = np.zeros(3)
@@ -168,12 +173,15 @@ class Simulation:
                 vals[key] = v
             srcs.append(dict(cell=s["cell"], rate=vals["rate"], enthalpy=vals["enthalpy"],
                              component=s.get("component", 0)))
-        lm = unstructured.build_mesh(nodes, cells, dim, thickness=mesh.get("thickness", 1.0),
-                                     radial=bool(mesh.get("radial", False)), gravity=grav, boundaries=bnds,
-                                     sources=srcs)
+        if mesh_builder is None:
+            lm = unstructured.build_mesh(nodes, cells, dim, thickness=mesh.get("thickness", 1.0),
+                                         radial=bool(mesh.get("radial", False)), gravity=grav, boundaries=bnds,
+                                         sources=srcs)
+        else:
+            lm = mesh_builder(bnds, srcs)
         cen = lm.cell_geom[:n, :3]
         rock = inp.get("rock", {}) or {}
-        zones = mesh.get("zones", {}) or {}
+        zones = (mesh or {}).get("zones", {}) or {}
         for rt in rock.get("types", []) or []:
             rec = rock_record(rt, dim)
             sel = []
@@ -274,16 +282,118 @@ class Simulation:
             max_num_tries=_get(step, "maximum.tries", 10), stop_time=_get(inp, "time.stop"),
             max_num_steps=mx.get("number") if mx.get("number") is not None else 100, aux_solution=self.X)
 
-        if self._tables:
+        self._setup_source_controls(inp.get("source", []) or [], _get(inp, "time.start", 0.0))
+        if self._tables or self._ctl_tables:
             self.ts.controls = self._update_controls
+
+    # ---- state-dependent source controls -------------------------------------------------------
+    def _setup_source_controls(self, sources, t0):
+        """Deliverability, recharge, limiter, separator and direction of each source
+        (setup_inline_source_controls, src/source_setup.F90:2340-2412) as the control records the
+        device evaluates (include/waiwera_hip.h, wai_source_control); their time tables are kept
+        here and averaged over every step interval (_update_controls)"""
+        self._ctl, self._ctl_tables = None, []
+        if not any(k in s for s in sources for k in ("deliverability", "recharge", "limiter", "direction")):
+            return
+        recs = [dict() for _ in sources]
+        fl = None
+
+        def timed(v, default, s):     # number | [[t, v], ...] | {"time": [[t, v], ...]} -> Table
+            if isinstance(v, dict):
+                v = v.get("time")
+            if v is None:
+                v = default
+            data = v if isinstance(v, (list, tuple)) else [[0.0, float(v)]]
+            return Table(data, s.get("interpolation", "linear"), s.get("averaging", "integrate"))
+
+        def cell_fluid(cell):
+            nonlocal fl
+            if fl is None:
+                assert self.ode.pre_eval(t0, self.y) == 0
+                fl = np.asarray(self.ode.fluid())
+            return fl[cell]
+
+        nc = {"w": 1, "we": 1, "wce": 2}[self.eos]
+        f0, pd = 6 + nc, 7 + nc
+
+        def mobility_sum(f):
+            phases = int(round(f[4]))
+            return sum(f[f0 + p * pd + 3] * f[f0 + p * pd] / f[f0 + p * pd + 1] for p in range(2) if phases & (1 << p))
+
+        for i, s in enumerate(sources):
+            r = recs[i]
+            for key, kind, cdef, ckey in (("deliverability", "deliverability", 1.0e-11, "productivity"),
+                                          ("recharge", "recharge", 0.0, "coefficient")):
+                if key not in s:
+                    continue
+                spec = s[key] if isinstance(s[key], dict) else {}
+                if spec.get("threshold", -1.0) > 0.0:
+                    raise NotImplementedError("deliverability threshold")
+                r["kind"] = kind
+                pr = spec.get("pressure", 1.0e5)
+                if isinstance(pr, str):
+                    if pr.lower() != "initial":
+                        raise ValueError("reference pressure %r" % pr)
+                    pr = float(cell_fluid(s["cell"])[0])      # set_reference_pressure_initial
+                if isinstance(pr, dict) and ("enthalpy" in pr or "pressure" in pr):
+                    if kind != "deliverability" or s.get("interpolation", "linear") != "linear":
+                        raise NotImplementedError("reference pressure table against enthalpy / pressure")
+                    r["table_coord"] = "enthalpy" if "enthalpy" in pr else "pressure"
+                    r["table"] = [tuple(q) for q in pr[r["table_coord"]]]
+                else:
+                    self._ctl_tables.append((i, "pressure", timed(pr, 1.0e5, s)))
+                if ckey in spec or kind == "recharge" or "rate" not in s:
+                    self._ctl_tables.append((i, "coef", timed(spec.get(ckey), cdef, s)))
+                else:
+                    # productivity index from the initial rate (calculate_PI_from_rate,
+                    # src/source_control.F90:407-468) on the initial fluid
+                    f = cell_fluid(s["cell"])
+                    pref = r["table"][0][1] if "table" in r else self._ctl_tables[-1][2].interpolate(t0)[0]
+                    factor = mobility_sum(f) * (f[0] - pref)
+                    r["coef"] = abs(s["rate"]) / factor if abs(factor) > 1.0e-9 else cdef
+            if "limiter" in s:
+                lim = s["limiter"]
+                if "limit" not in lim and "type" not in lim:
+                    raise NotImplementedError("limiters on several flow types")
+                r["limiter"] = lim.get("type", "total")
+                ls = dict(s, **{k: lim[k] for k in ("interpolation", "averaging") if k in lim})
+                self._ctl_tables.append((i, "limit", timed(lim.get("limit"), 1.0, ls)))
+            sep = s.get("separator")
+            psep = None
+            if sep is not None and sep is not False:
+                psep = sep.get("pressure", 0.55e6) if isinstance(sep, dict) else 0.55e6
+            elif "limiter" in s and "separator_pressure" in s["limiter"]:
+                psep = s["limiter"]["separator_pressure"]
+            if isinstance(psep, (list, tuple)):
+                if len(psep) > 1:
+                    raise NotImplementedError("multi-stage separators")
+                psep = psep[0]
+            if r.get("limiter") in ("water", "steam"):
+                if psep is None or psep <= 0.0:
+                    r["limiter"] = None      # no separator: separated flows are zero, never over the limit
+                else:
+                    r["sep_hf"], r["sep_hg"] = self.ode.separator_enthalpies(float(psep))
+            if "direction" in s:
+                r["direction"] = s["direction"].lower()
+        self._ctl = recs
+        self._apply_controls((t0, t0))
+
+    def _apply_controls(self, interval):
+        for i, key, tab in self._ctl_tables:
+            self._ctl[i][key] = float(tab.average(interval)[0])
+        self.ode.set_source_controls(self._ctl)
 
     def _update_controls(self, interval):
         """table_object_control_update (src/control.F90:263-284): each table's average over the step
-        interval becomes the rate / enthalpy of its source"""
-        rate, enth = self.mesh.src_rate.copy(), self.mesh.src_enthalpy.copy()
-        for i, key, tab in self._tables:
-            (rate if key == "rate" else enth)[i] = tab.average(interval)[0]
-        self.ode.set_source_rates(rate, enth)
+        interval becomes the rate / enthalpy of its source; likewise the productivity, reference
+        pressure and limit tables of the state-dependent controls"""
+        if self._tables:
+            rate, enth = self.mesh.src_rate.copy(), self.mesh.src_enthalpy.copy()
+            for i, key, tab in self._tables:
+                (rate if key == "rate" else enth)[i] = tab.average(interval)[0]
+            self.ode.set_source_rates(rate, enth)
+        if self._ctl_tables:
+            self._apply_controls(interval)
 
     @classmethod
     def from_json(cls, path, **kw):
@@ -316,7 +426,8 @@ class Simulation:
         return out
 
     def save_hdf5(self, path):
-        """the collected outputs in the reference's layout: /time, /cell_index, /cell_fields/*"""
+        """the collected outputs in the reference's layout: /time, /cell_index, /cell_fields/*,
+        /source_fields/source_rate and source_enthalpy"""
         from . import hdf5io
         outs = getattr(self, "outputs", None) or [self.fields()]
         n = self.mesh.n_owned
@@ -324,7 +435,9 @@ class Simulation:
         for k in outs[0]:
             if k == "time":
                 continue
-            if k.startswith("cell_geometry"):
+            if k.startswith("source_"):
+                data["/source_fields/" + k] = np.stack([o[k] for o in outs])
+            elif k.startswith("cell_geometry"):
                 data["/cell_fields/" + k] = outs[0][k]
             else:
                 data["/cell_fields/" + k] = np.stack([o[k] for o in outs])
@@ -351,6 +464,8 @@ class Simulation:
         if self.X is not None:
             for k, name in enumerate(self.tracer_names):
                 out["tracer_" + name] = self.X.reshape(n, -1)[:, k].copy()
+        if self.mesh.n_src and hasattr(self.ode, "source_rates"):
+            out["source_rate"], out["source_enthalpy"] = self.ode.source_rates()
         return out
 
     def save(self, path):
