@@ -409,3 +409,23 @@ def source_control_errors(run, got):
         for k, v in run[group].items():
             out[group + " " + k] = field_errors({k: got[group][k][idx]}, {k: np.asarray(v)[sel]}, [k])[k]
     return out
+
+
+# ---- tracer/doublet ------------------------------------------------------------------------------
+def doublet_errors(sim, fx):
+    """tracer mass fraction fields at the listing's output times and the production well's tracer
+    mass flow history, as (relative to the field's maximum, absolute)"""
+    tg = np.array([o["time"] for o in sim.outputs])
+    worst_field, worst_flow, matched = 0.0, 0.0, 0
+    flows = np.array([o["source_rate"][1] * o["tracer_tracer1"][99] for o in sim.outputs])
+    scale_flow = np.abs(np.asarray(fx["production"]["tracer_flow"])).max()
+    for t, X, q in zip(fx["times"], fx["tracer"], fx["production"]["tracer_flow"]):
+        k = int(np.argmin(np.abs(tg - t)))
+        if abs(tg[k] - t) > 1e-6 * t:
+            continue
+        matched += 1
+        X = np.asarray(X)
+        worst_field = max(worst_field, np.abs(sim.outputs[k]["tracer_tracer1"] - X).max() / max(X.max(), 1e-30)
+                          if X.max() > 1e-6 else 0.0)
+        worst_flow = max(worst_flow, abs(flows[k] - q) / scale_flow)
+    return worst_field, worst_flow, matched

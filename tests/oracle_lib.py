@@ -262,6 +262,9 @@ class OracleSim:
         if injection is not None and getattr(self.mesh, "n_src", 0):
             self.L.wo_sim_set_tracer_injection(self.h, dp(f64(injection)))
 
+    def set_tracer_injection(self, injection):
+        self.L.wo_sim_set_tracer_injection(self.h, dp(f64(injection)))
+
     def tracer_lhs(self):
         out = np.zeros(self.n_owned * self.nt)
         self.L.wo_tracer_lhs(self.h, dp(out))

@@ -128,3 +128,15 @@ def test_source_controls_against_autough2(name):
         else:
             assert l2 < (1.0e-3 if recharge and k.startswith("history") else 1.0e-2), (k, l2)
     sim.ode.destroy()
+
+
+def test_tracer_doublet():
+    """tracer/doublet on the HIP path: restart from Waiwera's own steady state file, tracer
+    injection table, production on deliverability behind a limiter, 189 adaptive steps"""
+    sim, out = run("doublet.json")
+    fx = B.load_fixture("benchmark_tracer_doublet.json")
+    worst_field, worst_flow, matched = B.doublet_errors(sim, fx)
+    assert matched >= 17 and worst_field < 1.0e-3 and worst_flow < 1.0e-3
+    Pa = np.asarray(fx["pressure"])
+    assert (np.abs(out["fluid_pressure"] - Pa) / Pa).max() < 1.0e-4
+    sim.ode.destroy()

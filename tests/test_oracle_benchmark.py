@@ -86,6 +86,9 @@ class OracleOde:
         self.o.set_tracers(phase, **kw)
         self.auxiliary = True
 
+    def set_tracer_injection(self, injection):
+        self.o.set_tracer_injection(injection)
+
     def aux_lhs(self, t, interval, Al):
         Al[:] = self.o.tracer_lhs()
 
@@ -422,4 +425,25 @@ def test_source_controls_against_autough2(oracle, name):
             assert l2 < (1.0e-4 if recharge else 5.0e-3), (k, l2)
         else:
             assert l2 < (1.0e-3 if recharge and k.startswith("history") else 1.0e-2), (k, l2)
+    sim.ode.o.close()
+
+
+def test_tracer_doublet_against_autough2(oracle):
+    """test/benchmark/tracer/doublet: injection / production doublet in a 100-cell row, restarted
+    from the steady state file the real Waiwera wrote; tracer injected for 12960 s (step table),
+    production well on deliverability behind a total-rate limiter, tracer diffusion; adaptive
+    steps.  The reference's test: tracer mass fraction fields within 1e-3 (absolute 1e-6) and the
+    tracer production rate history within 1e-3 of AUTOUGH2."""
+    fx = B.load_fixture("benchmark_tracer_doublet.json")
+    from waiwera_amd.simulation import Simulation
+    sim = Simulation.from_json(os.path.join(INPUTS, "doublet.json"), ode_factory=oracle_factory(oracle))
+    sim.y = sim.ts.y = sim.ode.o.yvec(sim.y)
+    out = sim.run()
+    worst_field, worst_flow, matched = B.doublet_errors(sim, fx)
+    print("doublet: tracer field %.2e, tracer production %.2e of their maxima over %d outputs, %d steps"
+          % (worst_field, worst_flow, matched, sim.ts.taken))
+    assert matched >= 17
+    assert worst_field < 1.0e-3 and worst_flow < 1.0e-3
+    Pa = np.asarray(fx["pressure"])
+    assert (np.abs(out["fluid_pressure"] - Pa) / Pa).max() < 1.0e-4
     sim.ode.o.close()

@@ -293,7 +293,9 @@ def input_files():
              (REF, "tracer/decay/run/decay.json"), (REF, "tracer/decay/run/decay.msh"),
              (REF, "tracer/oned/run/oned_two_phase.json"), (REF, "tracer/oned/run/oned_two_phase_ss.json"),
              (REF, "tracer/oned/run/oned_two_phase_ss.h5"), (REF, "tracer/oned/run/oned_single_phase.json"),
-             (REF, "tracer/oned/run/oned_single_phase_ss.h5"), (REF, "tracer/oned/run/goned.msh")]
+             (REF, "tracer/oned/run/oned_single_phase_ss.h5"), (REF, "tracer/oned/run/goned.msh"),
+             (REF, "tracer/doublet/run/doublet.json"), (REF, "tracer/doublet/run/doublet_ss.json"),
+             (REF, "tracer/doublet/run/doublet_ss.h5"), (REF, "tracer/doublet/run/gdoublet.msh")]
     for base, rel in files:
         src = os.path.join(base, rel)
         if os.path.exists(src):
@@ -348,7 +350,25 @@ def source_controls():
     json.dump(out, open(os.path.join(OUT, "benchmark_source_controls.json"), "w"), indent=1)
 
 
+def tracer_doublet():
+    """test/benchmark/tracer/doublet: every ELEMENT / GENERATION table of the AUTOUGH2 listing
+    (tracer mass fraction field, tracer mass flow of the production well) and the steady state the
+    real Waiwera wrote; the inputs are tests/golden/inputs/doublet*.json"""
+    base = os.path.join(REF, "tracer", "doublet", "run")
+    elem = all_tables(os.path.join(base, "doublet.listing"), "ELEMENT TABLE")
+    gen = all_tables(os.path.join(base, "doublet.listing"), "GENERATION TABLE")
+    out = {"source": "test/benchmark/tracer/doublet/run/doublet.listing, doublet_ss.h5",
+           "times": [t for t, _ in elem],
+           "tracer": [tab["Tracer/liquid"] for _, tab in elem],
+           "pressure": elem[-1][1]["Pressure"],
+           "production": {"times": [t for t, _ in gen], "rate": [tab["Generation rate"][1] for _, tab in gen],
+                          "tracer_flow": [tab["Tracer mass flow"][1] for _, tab in gen]},
+           "waiwera_steady_state": h5_state(os.path.join(base, "doublet_ss.h5"))}
+    json.dump(out, open(os.path.join(OUT, "benchmark_tracer_doublet.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
+    tracer_doublet()
     source_controls()
     input_files()
     problem5("a")

@@ -254,6 +254,11 @@ class FlowSimulation:
         self._chk(LIB.wai_timestep(self.h, t, dt, _lib.ptr(y), C.byref(n), C.byref(k), C.byref(r)), "timestep")
         return r.value, n.value, k.value
 
+    def set_tracer_injection(self, injection):
+        """[n_sources][nt] tracer injection rates (tracer table controls set them per step interval)"""
+        self._chk(LIB.wai_set_tracer_injection(self.h, _lib.ptr(_lib._f64(np.asarray(injection, dtype=np.float64)))),
+                  "set_tracer_injection")
+
     # ---- tracers: the auxiliary linear problem (ode_type aux_lhs / aux_rhs / aux_pre_solve) ------
     def set_tracers(self, phase, decay=None, activation=None, diffusion=None, bc=None, injection=None):
         """Passive tracers (src/tracer.F90:30-40): 0-based phase index, decay constant, activation

@@ -265,7 +265,20 @@ class Simulation:
                 return [v] * nt if np.isscalar(v) else list(v)
             bc = np.array([tvals(b.get("tracer")) for b in inp.get("boundaries", []) or []
                            for f in (b["faces"] if isinstance(b["faces"], list) else [b["faces"]]) for _ in f["cells"]])
-            inj = np.array([tvals(s.get("tracer")) for s in inp.get("source", []) or []]) if srcs else None
+            # tracer injection rates: numbers, or [[t, q], ...] tables averaged over each step interval
+            # like the rate tables (tracer table source controls, src/source_setup.F90:2415-2560)
+            self._tracer_tables, rows = [], []
+            for i, s in enumerate(inp.get("source", []) or []):
+                v = s.get("tracer")
+                if isinstance(v, (list, tuple)) and v and isinstance(v[0], (list, tuple)):
+                    if nt != 1:
+                        raise NotImplementedError("tracer injection tables with several tracers")
+                    tab = Table(v, s.get("interpolation", "linear"), s.get("averaging", "integrate"))
+                    self._tracer_tables.append((i, 0, tab))
+                    v = float(tab.interpolate(_get(inp, "time.start", 0.0))[0])
+                rows.append(tvals(v))
+            inj = np.array(rows) if srcs else None
+            self._tracer_injection = inj
             self.ode.set_tracers(phases, decay=[t.get("decay", 0.0) for t in tr],
                                  activation=[t.get("activation", 0.0) for t in tr],
                                  diffusion=[t.get("diffusion", 0.0) for t in tr],
@@ -283,7 +296,7 @@ class Simulation:
             max_num_steps=mx.get("number") if mx.get("number") is not None else 100, aux_solution=self.X)
 
         self._setup_source_controls(inp.get("source", []) or [], _get(inp, "time.start", 0.0))
-        if self._tables or self._ctl_tables:
+        if self._tables or self._ctl_tables or getattr(self, "_tracer_tables", None):
             self.ts.controls = self._update_controls
 
     # ---- state-dependent source controls -------------------------------------------------------
@@ -394,6 +407,10 @@ class Simulation:
             self.ode.set_source_rates(rate, enth)
         if self._ctl_tables:
             self._apply_controls(interval)
+        if getattr(self, "_tracer_tables", None):
+            for i, it, tab in self._tracer_tables:
+                self._tracer_injection[i, it] = tab.average(interval)[0]
+            self.ode.set_tracer_injection(self._tracer_injection)
 
     @classmethod
     def from_json(cls, path, **kw):
