@@ -429,3 +429,18 @@ def doublet_errors(sim, fx):
                           if X.max() > 1e-6 else 0.0)
         worst_flow = max(worst_flow, abs(flows[k] - q) / scale_flow)
     return worst_field, worst_flow, matched
+
+
+# ---- model intercomparison problem 6 ---------------------------------------------------------------
+def problem6_errors(sim, out, fx):
+    got = {"Pressure": out["fluid_pressure"], "Temperature": out["fluid_temperature"], "Vapour saturation": out["fluid_vapour_saturation"]}
+    worst = field_errors(got, fx["autough2_final_table"], list(got))
+    w = fx["watch_cell"]
+    tg = np.array([o["time"] for o in sim.outputs])
+    ta = np.asarray(fx["times"])
+    near = np.array([int(np.argmin(np.abs(tg - t))) for t in ta])
+    ok = np.abs(tg[near] - ta) <= 1e-6 * np.maximum(ta, 1.0)
+    for k, name in (("Pressure", "fluid_pressure"), ("Temperature", "fluid_temperature"), ("Vapour saturation", "fluid_vapour_saturation")):
+        h = np.array([sim.outputs[i][name][w] for i in near[ok]])
+        worst["history " + k] = field_errors({k: h}, {k: np.asarray(fx["history"][k])[ok]}, [k])[k]
+    return worst, int(ok.sum())

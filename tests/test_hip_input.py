@@ -140,3 +140,16 @@ def test_tracer_doublet():
     Pa = np.asarray(fx["pressure"])
     assert (np.abs(out["fluid_pressure"] - Pa) / Pa).max() < 1.0e-4
     sim.ode.destroy()
+
+
+def test_problem6_from_mulgraph_geometry():
+    """3-D problem 6 on the HIP path, mesh from the MULgraph geometry file beside the input (the
+    input names an ExodusII file); the reference's bar against AUTOUGH2 is 2e-2"""
+    from waiwera_amd.simulation import Simulation
+    fx = B.load_fixture("benchmark_problem6.json")
+    sim = Simulation.from_json(os.path.join(INPUTS, "problem6.json"), mesh_file=os.path.join(INPUTS, "gproblem6.dat"))
+    out = sim.run()
+    worst, matched = B.problem6_errors(sim, out, fx)
+    assert abs(out["time"] - 216000000.0) < 1.0 and matched > 130
+    assert max(v[0] for v in worst.values()) < 2.0e-2
+    sim.ode.destroy()

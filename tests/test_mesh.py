@@ -132,3 +132,17 @@ def test_local_id_follows_the_brick_numbering_and_sources_land_on_their_cells(pa
         assert np.array_equal(g.local_id(rank, ijk[:, 0], ijk[:, 1], ijk[:, 2]), np.arange(lm.n_owned))
         got += [(int(lm.owned_gid[c]), float(r)) for c, r in zip(lm.src_cell, lm.src_rate)]
     assert sorted(got) == want
+
+
+def test_mulgraph_geometry_reader():
+    """gproblem6.dat: 5 x 5 columns of 1000 m x 800 m, layers 300, 300, 300, 300, 600 m thick"""
+    import os
+    from waiwera_amd import mulgrid, unstructured
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inputs", "gproblem6.dat")
+    nodes, cells, dim = mulgrid.read_geometry(path)
+    assert dim == 3 and len(cells) == 125 and nodes.shape == (36 * 6, 3)
+    lm = unstructured.build_mesh(nodes, cells, 3, gravity=[0.0, 0.0, -9.8])
+    vol = lm.cell_geom[:125, 3]
+    assert np.allclose(vol[:100], 1000.0 * 800.0 * 300.0) and np.allclose(vol[100:], 1000.0 * 800.0 * 600.0)
+    assert np.allclose(lm.cell_geom[0, :3], [500.0, 400.0, -150.0]) and np.allclose(lm.cell_geom[124, :3], [4500.0, 3600.0, -1500.0])
+    assert lm.n_faces == 5 * (2 * 5 * 4) + 4 * 25            # in-layer faces + faces between layers

@@ -447,3 +447,21 @@ def test_tracer_doublet_against_autough2(oracle):
     Pa = np.asarray(fx["pressure"])
     assert (np.abs(out["fluid_pressure"] - Pa) / Pa).max() < 1.0e-4
     sim.ode.o.close()
+
+
+def test_problem6_three_dimensional_against_autough2(oracle):
+    """model intercomparison problem 6: 5 x 5 x 5 blocks (the mesh from the MULgraph geometry file
+    next to the input), gravity, a two-phase layer under a cap, Corey curves, production stepped up
+    by a rate table over 6.8 years with adaptive steps.  The reference's test asks the production
+    block's history within 2e-2 of AUTOUGH2."""
+    from waiwera_amd.simulation import Simulation
+    fx = B.load_fixture("benchmark_problem6.json")
+    sim = Simulation.from_json(os.path.join(INPUTS, "problem6.json"), mesh_file=os.path.join(INPUTS, "gproblem6.dat"),
+                               ode_factory=oracle_factory(oracle))
+    sim.y = sim.ts.y = sim.ode.o.yvec(sim.y)
+    out = sim.run()
+    worst, matched = B.problem6_errors(sim, out, fx)
+    print("problem6", {k: "%.1e / %.1e" % v for k, v in worst.items()}, "steps", sim.ts.taken, "matched outputs", matched)
+    assert abs(out["time"] - 216000000.0) < 1.0
+    assert max(v[0] for v in worst.values()) < 2.0e-2
+    sim.ode.o.close()

@@ -294,6 +294,7 @@ def input_files():
              (REF, "tracer/oned/run/oned_two_phase.json"), (REF, "tracer/oned/run/oned_two_phase_ss.json"),
              (REF, "tracer/oned/run/oned_two_phase_ss.h5"), (REF, "tracer/oned/run/oned_single_phase.json"),
              (REF, "tracer/oned/run/oned_single_phase_ss.h5"), (REF, "tracer/oned/run/goned.msh"),
+             (mis, "problem6/run/problem6.json"), (mis, "problem6/run/gproblem6.dat"),
              (REF, "tracer/doublet/run/doublet.json"), (REF, "tracer/doublet/run/doublet_ss.json"),
              (REF, "tracer/doublet/run/doublet_ss.h5"), (REF, "tracer/doublet/run/gdoublet.msh")]
     for base, rel in files:
@@ -350,6 +351,22 @@ def source_controls():
     json.dump(out, open(os.path.join(OUT, "benchmark_source_controls.json"), "w"), indent=1)
 
 
+def problem6():
+    """model intercomparison problem 6 (3-D, 5 x 5 columns x 5 layers, two-phase layer, production
+    stepped up over 6.8 years): final element table and the production block's history"""
+    base = os.path.join(REF, "model_intercomparison_study", "problem6", "run")
+    elem = all_tables(os.path.join(base, "problem6.listing"), "ELEMENT TABLE")
+    n, atm = 125, 25         # one atmosphere block per column comes first in the listing
+    watch = 75               # the production block (obs_position of test_problem6.py = the source's cell)
+    fields = ("Pressure", "Temperature", "Vapour saturation")
+    out = {"source": "test/benchmark/model_intercomparison_study/problem6/run/problem6.listing; inputs are "
+                     "tests/golden/inputs/problem6.json and gproblem6.dat",
+           "watch_cell": watch, "times": [t for t, _ in elem],
+           "history": {k: [tab[k][atm + watch] for _, tab in elem] for k in fields},
+           "autough2_final_table": {k: elem[-1][1][k][atm: atm + n] for k in fields}}
+    json.dump(out, open(os.path.join(OUT, "benchmark_problem6.json"), "w"), indent=1)
+
+
 def tracer_doublet():
     """test/benchmark/tracer/doublet: every ELEMENT / GENERATION table of the AUTOUGH2 listing
     (tracer mass fraction field, tracer mass flow of the production well) and the steady state the
@@ -368,6 +385,7 @@ def tracer_doublet():
 
 
 if __name__ == "__main__":
+    problem6()
     tracer_doublet()
     source_controls()
     input_files()

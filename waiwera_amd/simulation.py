@@ -114,7 +114,7 @@ def zone_cells(zone, centroids):
 class Simulation:
     """One Waiwera input file -> mesh, flow simulation object and time stepper."""
 
-    def __init__(self, inp, base_dir=".", ode_factory=None, device=0, mesh_builder=None):
+    def __init__(self, inp, base_dir=".", ode_factory=None, device=0, mesh_builder=None, mesh_file=None):
         self.inp = inp
         if _get(inp, "mesh.minc") is not None:
             raise NotImplementedError("MINC zones from an input file")
@@ -123,7 +123,14 @@ class Simulation:
         if isinstance(mesh, str):
             mesh = {"filename": mesh}
         if mesh_builder is None:
-            nodes, cells, dim = gmsh.read_msh(os.path.join(base_dir, mesh["filename"]))
+            # gmsh 2.2 ASCII, or (mesh_file: the input names an ExodusII file, which cannot be read
+            # here) the MULgraph geometry file the reference's benchmarks keep beside it
+            mpath = mesh_file or os.path.join(base_dir, mesh["filename"])
+            if mpath.endswith(".dat"):
+                from . import mulgrid
+                nodes, cells, dim = mulgrid.read_geometry(mpath)
+            else:
+                nodes, cells, dim = gmsh.read_msh(mpath)
             n = len(cells)
         else:
             # mesh_builder(boundaries, sources) -> LocalMesh for meshes that are not gmsh files (the
