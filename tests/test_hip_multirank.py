@@ -110,20 +110,24 @@ def _free_port():
     return p
 
 
-@pytest.mark.timeout(900)
-def test_bench_as_the_driver_launches_it_two_ranks():
-    """bench.py --gpus 2 under torch.distributed.run, both ranks on cuda:0 over the loopback
-    (WAI_BENCH_LOOPBACK: gloo for the host-side barrier / max, device 0 for every rank)"""
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("world,dims,brick,part", [(2, (32, 32, 16), (8, 8, 2), "2x1x1"),
+                                                   (8, (72, 72, 56), (16, 16, 2), "2x2x2")])
+def test_bench_as_the_driver_launches_it(world, dims, brick, part):
+    """bench.py --gpus N under torch.distributed.run, all ranks on cuda:0 over the loopback
+    (WAI_BENCH_LOOPBACK: gloo for the host-side barrier / max, device 0 for every rank).  The
+    8-rank case has the default brick shape cut raggedly by 36-cell rank extents (as 108-cell
+    extents are at full size) and is deep enough for the two-phase lens."""
     env = dict(os.environ, WAI_RCCL_LIB=LOOPBACK, WAI_BENCH_LOOPBACK="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "1", "--dims", "32", "32", "16", "--brick", "8", "8", "2",
-           "--spmv-reps", "3", "--no-cpu"]
+           "--gpus", str(world), "--steps", "2", "--warmup", "1", "--dims"] + [str(v) for v in dims] + \
+          ["--brick"] + [str(v) for v in brick] + ["--spmv-reps", "3", "--no-cpu"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
-    assert out["config"]["partition"] == "2x1x1"
+    assert out["n_gpus"] == world and out["steps"] == 2 and out["value"] > 0
+    assert out["config"]["partition"] == part
     assert out["config"]["krylov_iterations_per_newton_step"] > 0

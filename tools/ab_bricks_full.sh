@@ -1,6 +1,6 @@
 # Whole-protocol A/B of preconditioner brick shapes (default bench: 10 warm-up + 20 timed Newton
 # steps at 216^3); the transient is chaotic in its step failures, so repeat shapes to see the spread
-shapes=("32 16 1" "22 22 1" "16 16 1" "24 20 1" "20 12 2" "16 32 1" "16 16 3")
+shapes=("8 8 8" "16 16 2" "20 12 2" "18 12 2" "12 18 2" "16 16 1" "32 16 1" "24 20 1" "12 12 3" "16 8 4" "8 8 4" "16 16 3")
 for b in "${shapes[@]}"; do
   python bench.py --brick $b --steps 20 --warmup 10 --no-cpu 2>&1 | grep -E "^\{" | python -c "
 import sys, json
