@@ -153,3 +153,17 @@ def test_problem6_from_mulgraph_geometry():
     assert abs(out["time"] - 216000000.0) < 1.0 and matched > 130
     assert max(v[0] for v in worst.values()) < 2.0e-2
     sim.ode.destroy()
+
+
+@pytest.mark.parametrize("name,geometry,key", [("minc_column_minc.json", "gminc_column.dat", "column_minc"),
+                                               ("minc_3d_base.json", "gminc_3d_base.dat", "production3d_base")])
+def test_minc_zones_from_input_files(name, geometry, key):
+    """`mesh.minc` zones of the reference's MINC benchmarks on the HIP path (fracture and matrix
+    blocks against AUTOUGH2 in the reference's cell order)"""
+    from waiwera_amd.simulation import Simulation
+    fx = B.load_fixture("benchmark_minc_column.json")[key]
+    sim = Simulation.from_json(os.path.join(INPUTS, name), mesh_file=os.path.join(INPUTS, geometry))
+    out = sim.run()
+    worst = B.field_errors(triple(out), fx, ("Pressure", "Temperature", "Vapour saturation"))
+    assert max(v[0] for v in worst.values()) < 5.0e-3
+    sim.ode.destroy()

@@ -146,3 +146,27 @@ def test_mulgraph_geometry_reader():
     assert np.allclose(vol[:100], 1000.0 * 800.0 * 300.0) and np.allclose(vol[100:], 1000.0 * 800.0 * 600.0)
     assert np.allclose(lm.cell_geom[0, :3], [500.0, 400.0, -150.0]) and np.allclose(lm.cell_geom[124, :3], [4500.0, 3600.0, -1500.0])
     assert lm.n_faces == 5 * (2 * 5 * 4) + 4 * 25            # in-layer faces + faces between layers
+
+
+def test_minc_zones_on_part_of_a_mesh():
+    """add_minc_zones: matrix cells join their fracture cell's subdomain, the chain faces carry the
+    nested-cube areas and distances, volumes add up, boundary faces stay last, sources follow"""
+    m0 = M.column_mesh_1d(-np.array([0.0, 40.0, 90.0, 150.0, 220.0]), 100.0, top_bc=([1.0e5, 20.0], 1),
+                          sources=[dict(cell=3, rate=1.0, enthalpy=1.0e5, component=1)])
+    geo = M.MincGeometry([0.1, 0.3, 0.6], [5.0, 5.0, 5.0])
+    mrock = M.default_rock(1)[0] * 2.0
+    m = M.add_minc_zones(m0, [dict(cells=np.array([1, 2]), geometry=geo, matrix_rock=mrock, fracture_rock=None)])
+    assert m.n_owned == 4 + 4 and m.n_bc == 1 and m.n_faces == m0.n_faces + 4
+    assert np.all(m.face_cells[-1] == [0, 8])                           # the boundary face, remapped
+    order = m.extras["waiwera_order"]
+    assert list(order[:4]) == list(m.extras["fracture_index"]) and sorted(order) == list(range(8))
+    vol = m.cell_geom[:8, 3][order]
+    v0 = m0.cell_geom[:4, 3]
+    assert np.allclose(vol[:4], v0 * [1.0, 0.1, 0.1, 1.0])
+    assert np.allclose(vol[4:6], v0[1:3] * 0.3) and np.allclose(vol[6:8], v0[1:3] * 0.6)
+    assert np.allclose(m.rock[order[4:]], mrock) and np.allclose(m.rock[order[:4]], m0.rock[:4])
+    assert m.src_cell[0] == m.extras["fracture_index"][3]
+    chain = m.face_geom[m0.n_faces - 1: m0.n_faces + 3]
+    assert np.allclose(chain[[0, 2], 0], v0[1:3] * geo.connection_area[0])
+    assert np.allclose(chain[:, 4:8], 0.0) and np.all(chain[:, 11] == 1.0)
+    assert m.sub_ptr[-1] == 8

@@ -465,3 +465,29 @@ def test_problem6_three_dimensional_against_autough2(oracle):
     assert abs(out["time"] - 216000000.0) < 1.0
     assert max(v[0] for v in worst.values()) < 2.0e-2
     sim.ode.o.close()
+
+
+MINC_INPUT_RUNS = [("minc_column_single.json", "gminc_column.dat", "column_single", 11),
+                   ("minc_column_minc.json", "gminc_column.dat", "column_minc", 23),
+                   ("minc_3d_base.json", "gminc_3d_base.dat", "production3d_base", 161)]
+
+
+@pytest.mark.parametrize("name,geometry,key,ncells", MINC_INPUT_RUNS)
+def test_minc_zones_from_input_files_against_autough2(oracle, name, geometry, key, ncells):
+    """test/benchmark/minc/column (boiling column, MINC with two matrix levels in six of its eleven
+    blocks; and the same column single-porosity) and minc/production3d (5 x 5 x 5 blocks, MINC in a
+    3 x 3 x 2 zone, 26 wells, 80 adaptive steps over 4 years), run from the reference's own input
+    files: `mesh.minc` zones, rock types by name, mesh from the MULgraph geometry file.  Fracture and
+    matrix blocks are compared in the reference's cell order; its bars are 2.5e-2 / 2e-2."""
+    from waiwera_amd.simulation import Simulation
+    fx = B.load_fixture("benchmark_minc_column.json")[key]
+    sim = Simulation.from_json(os.path.join(INPUTS, name), mesh_file=os.path.join(INPUTS, geometry),
+                               ode_factory=oracle_factory(oracle))
+    sim.y = sim.ts.y = sim.ode.o.yvec(sim.y)
+    out = sim.run()
+    assert sim.mesh.n_owned == ncells == len(fx["Pressure"])
+    got = {"Pressure": out["fluid_pressure"], "Temperature": out["fluid_temperature"], "Vapour saturation": out["fluid_vapour_saturation"]}
+    worst = B.field_errors(got, fx, list(got))
+    print(name, {k: "%.1e / %.1e" % v for k, v in worst.items()}, "steps", sim.ts.taken)
+    assert max(v[0] for v in worst.values()) < 5.0e-3
+    sim.ode.o.close()

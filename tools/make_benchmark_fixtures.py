@@ -294,6 +294,9 @@ def input_files():
              (REF, "tracer/oned/run/oned_two_phase.json"), (REF, "tracer/oned/run/oned_two_phase_ss.json"),
              (REF, "tracer/oned/run/oned_two_phase_ss.h5"), (REF, "tracer/oned/run/oned_single_phase.json"),
              (REF, "tracer/oned/run/oned_single_phase_ss.h5"), (REF, "tracer/oned/run/goned.msh"),
+             (REF, "minc/column/run/minc_column_minc.json"), (REF, "minc/column/run/minc_column_single.json"),
+             (REF, "minc/column/run/gminc_column.dat"),
+             (REF, "minc/production3d/run/minc_3d_base.json"), (REF, "minc/production3d/run/gminc_3d_base.dat"),
              (mis, "problem6/run/problem6.json"), (mis, "problem6/run/gproblem6.dat"),
              (REF, "tracer/doublet/run/doublet.json"), (REF, "tracer/doublet/run/doublet_ss.json"),
              (REF, "tracer/doublet/run/doublet_ss.h5"), (REF, "tracer/doublet/run/gdoublet.msh")]
@@ -351,6 +354,35 @@ def source_controls():
     json.dump(out, open(os.path.join(OUT, "benchmark_source_controls.json"), "w"), indent=1)
 
 
+def minc_tables(listing, n, levels, zone_count):
+    """final ELEMENT TABLE of an AUTOUGH2 MINC listing in the reference's cell order: the n original
+    blocks (after the atmosphere block), then all level-1 matrix blocks, then level 2, ...; the
+    listing interleaves the levels block by block"""
+    t = last_table(listing, "ELEMENT TABLE")
+    out = {}
+    for k in ("Pressure", "Temperature", "Vapour saturation"):
+        v = t[k]
+        atm = len(v) - n - levels * zone_count
+        frac, mat = v[atm: atm + n], v[atm + n:]
+        out[k] = frac + [mat[c * levels + lev] for lev in range(levels) for c in range(zone_count)]
+    return out
+
+
+def minc_column_and_3d():
+    """test/benchmark/minc/column (11-block column, MINC in the 6 blocks between -100 and -600 m, two
+    matrix levels; also the single-porosity run) and minc/production3d base (125 blocks)"""
+    base = os.path.join(REF, "minc", "column", "run")
+    out = {"source": "test/benchmark/minc/column/run/*.listing, minc/production3d/run/minc_3d_base.listing; the "
+                     "inputs are tests/golden/inputs/minc_*.json with the MULgraph geometry files",
+           "column_minc": minc_tables(os.path.join(base, "minc_column_minc.listing"), 11, 2, 6),
+           "column_single": minc_tables(os.path.join(base, "minc_column_single.listing"), 11, 0, 0)}
+    b3 = os.path.join(REF, "minc", "production3d", "run")
+    nrows = len(last_table(os.path.join(b3, "minc_3d_base.listing"), "ELEMENT TABLE")["Pressure"])
+    zone = (nrows - 125 - 25) // 2         # an atmosphere block per column, two matrix levels per zone block
+    out["production3d_base"] = minc_tables(os.path.join(b3, "minc_3d_base.listing"), 125, 2, zone)
+    json.dump(out, open(os.path.join(OUT, "benchmark_minc_column.json"), "w"), indent=1)
+
+
 def problem6():
     """model intercomparison problem 6 (3-D, 5 x 5 columns x 5 layers, two-phase layer, production
     stepped up over 6.8 years): final element table and the production block's history"""
@@ -385,6 +417,7 @@ def tracer_doublet():
 
 
 if __name__ == "__main__":
+    minc_column_and_3d()
     problem6()
     tracer_doublet()
     source_controls()

@@ -526,6 +526,107 @@ def _add_minc(grid, base, minc):
     return m
 
 
+def add_minc_zones(base, zones):
+    """MINC matrix cells for part of a single-rank mesh (`"mesh": {"minc": ...}` of an input file,
+    src/mesh.F90:3026-3186, src/minc.F90:58-374).  zones: [dict(cells=original cell indices,
+    geometry=MincGeometry, matrix_rock=(8,), fracture_rock=(8,) or None)].  A zone cell becomes the
+    fracture cell (volume times the fracture fraction, optionally the fracture rock type); its matrix
+    cells of level m are connected in a chain by faces of area V*connection_area(m), distances
+    (cd(m), cd(m+1)), zero normal and gravity term, permeability direction 1.  Storage order: inside
+    each preconditioner subdomain the original cells, then its level-1 cells, then level 2, ...;
+    `extras["waiwera_order"]` lists the new indices in the reference's cell order (original cells,
+    then all level-1 cells in zone order, then level 2, ...) for output."""
+    no = base.n_owned
+    assert base.n_halo == 0
+    sp = base.sub_ptr.astype(np.int64)
+    nsub = sp.size - 1
+    sub_of = np.repeat(np.arange(nsub), np.diff(sp))
+    # matrix cells to create: (original cell, level, zone)
+    entries = []
+    for z, zone in enumerate(zones):
+        for c in np.asarray(zone["cells"], dtype=np.int64):
+            for lev in range(1, zone["geometry"].num_levels + 1):
+                entries.append((int(sub_of[c]), lev, int(c), z))
+    entries.sort(key=lambda e: (e[0], e[1]))          # stable: zone / cell order inside a level
+    added = np.bincount([e[0] for e in entries], minlength=nsub)
+    new_sp = np.concatenate([[0], np.cumsum(np.diff(sp) + added)])
+    new_of_orig = new_sp[sub_of] + (np.arange(no) - sp[sub_of])
+    n_new = int(new_sp[-1])
+    pos = (new_sp[:-1] + np.diff(sp)).copy()           # next free slot per subdomain
+    matrix_new = {}
+    for s, lev, c, z in entries:
+        matrix_new[(c, lev)] = int(pos[s])
+        pos[s] += 1
+
+    def remap(idx):
+        idx = np.asarray(idx, dtype=np.int64)
+        out = idx + (n_new - no)                       # boundary cells follow the owned ones
+        own = idx < no
+        out[own] = new_of_orig[idx[own]]
+        return out
+    m = LocalMesh(dims=base.dims, spacing=base.spacing, part=base.part, rank=base.rank, brick=base.brick,
+                  n_global=base.n_global)
+    m.n_owned, m.n_halo, m.n_bc = n_new, 0, base.n_bc
+    cg, rock = np.zeros((m.n_local, 4)), np.zeros((m.n_local, 8))
+    cg[remap(np.arange(base.n_local))] = base.cell_geom
+    rock[remap(np.arange(base.n_local))] = base.rock
+    level = np.zeros(n_new, dtype=np.int32)
+    parent = np.full(n_new, -1, dtype=np.int64)
+    parent[new_of_orig] = np.arange(no)
+    fc, fg = [remap(base.face_cells.ravel()).reshape(-1, 2)], [base.face_geom]
+    for zone in zones:
+        geo = zone["geometry"]
+        for c in np.asarray(zone["cells"], dtype=np.int64):
+            v0 = base.cell_geom[c, 3]
+            f = new_of_orig[c]
+            cg[f, 3] = v0 * geo.volume[0]
+            if zone.get("fracture_rock") is not None:
+                rock[f] = zone["fracture_rock"]
+            prev = f
+            for lev in range(1, geo.num_levels + 1):
+                q = matrix_new[(int(c), lev)]
+                cg[q, 0:3] = base.cell_geom[c, 0:3]
+                cg[q, 3] = v0 * geo.volume[lev]
+                rock[q] = zone["matrix_rock"]
+                level[q], parent[q] = lev, c
+                g = np.zeros(12)
+                g[0] = v0 * geo.connection_area[lev - 1]
+                g[1], g[2] = geo.connection_distance[lev - 1], geo.connection_distance[lev]
+                g[3] = g[1] + g[2]
+                g[8:11] = base.cell_geom[c, 0:3]
+                g[11] = 1.0
+                fc.append(np.array([[prev, q]]))
+                fg.append(g[None, :])
+                prev = q
+    m.cell_geom, m.rock = cg, rock
+    # interior faces first, boundary faces last (the order the library expects)
+    nint = base.n_faces - base.n_bc
+    allc, allg = np.concatenate(fc), np.concatenate(fg)
+    order = np.concatenate([np.arange(nint), np.arange(base.n_faces, allc.shape[0]), np.arange(nint, base.n_faces)])
+    m.face_cells = allc[order].astype(np.int32)
+    m.face_geom = allg[order]
+    m.n_faces = m.face_cells.shape[0]
+    m.sub_ptr = new_sp.astype(np.int32)
+    m.bc_primary, m.bc_region = base.bc_primary, base.bc_region
+    m.owned_gid = np.full(n_new, -1, dtype=np.int64)
+    m.owned_gid[new_of_orig] = base.owned_gid if base.owned_gid is not None else np.arange(no)
+    m.extras = dict(base.extras)
+    m.extras["minc_level"], m.extras["minc_parent"] = level, parent
+    m.extras["fracture_index"] = new_of_orig
+    worder = list(new_of_orig)
+    maxlev = max(z["geometry"].num_levels for z in zones)
+    for lev in range(1, maxlev + 1):
+        for zone in zones:
+            if lev <= zone["geometry"].num_levels:
+                worder += [matrix_new[(int(c), lev)] for c in np.asarray(zone["cells"], dtype=np.int64)]
+    m.extras["waiwera_order"] = np.array(worder, dtype=np.int64)
+    m.n_src = base.n_src
+    if base.n_src:
+        m.src_cell = new_of_orig[base.src_cell].astype(np.int32)
+        m.src_rate, m.src_enthalpy, m.src_component = base.src_rate, base.src_enthalpy, base.src_component
+    return m
+
+
 def default_rock(n):
     """Reference default rock (src/rock.F90:69-76): k 1e-13, cond 2.5, phi 0.1, 2200, 1000."""
     r = np.zeros((n, 8))

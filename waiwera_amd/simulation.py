@@ -22,7 +22,7 @@ src/timestepper.F90:1960-2275; src/tracer.F90:63-140; utils/input_schema.json):
 
   output      filename, initial, final, frequency (cell fields only)
 
-Anything else that changes results (source controls, MINC, rock controls, ...) raises
+Anything else that changes results (source groups, reinjectors, rock controls, ...) raises
 NotImplementedError instead of being ignored.  Output: `Simulation.run` returns the final cell
 fields under the reference's HDF5 dataset names (fluid_pressure, ...) and writes "output.filename"
 in the reference's HDF5 layout (waiwera_amd/hdf5io.py, HDF5 C library through ctypes); `save`
@@ -116,8 +116,6 @@ class Simulation:
 
     def __init__(self, inp, base_dir=".", ode_factory=None, device=0, mesh_builder=None, mesh_file=None):
         self.inp = inp
-        if _get(inp, "mesh.minc") is not None:
-            raise NotImplementedError("MINC zones from an input file")
         self.base_dir = base_dir
         mesh = inp.get("mesh")
         if isinstance(mesh, str):
@@ -180,10 +178,14 @@ class Simulation:
                 vals[key] = v
             srcs.append(dict(cell=s["cell"], rate=vals["rate"], enthalpy=vals["enthalpy"],
                              component=s.get("component", 0)))
+        minc_in = (mesh or {}).get("minc")
+        minc_in = [] if minc_in is None else (minc_in if isinstance(minc_in, list) else [minc_in])
+        # matrix cells join their fracture cell's preconditioner subdomain (<= 1024 rows each)
+        max_levels = max([len(np.atleast_1d(_get(mz, "geometry.matrix.volume", [0.9]))) for mz in minc_in] or [0])
         if mesh_builder is None:
             lm = unstructured.build_mesh(nodes, cells, dim, thickness=mesh.get("thickness", 1.0),
                                          radial=bool(mesh.get("radial", False)), gravity=grav, boundaries=bnds,
-                                         sources=srcs)
+                                         sources=srcs, chunk=512 // (1 + max_levels) if max_levels else 512)
         else:
             lm = mesh_builder(bnds, srcs)
         cen = lm.cell_geom[:n, :3]
@@ -201,6 +203,46 @@ class Simulation:
                 lm.rock[idx] = rec
         for k in range(lm.n_bc):
             lm.rock[n + k] = lm.rock[lm.face_cells[lm.n_faces - lm.n_bc + k, 0]]
+        # MINC zones (setup of src/minc.F90:58-374): the zone's cells become fracture cells with
+        # nested matrix cells behind them
+        self._order = None
+        if minc_in:
+            from . import mesh as M
+            by_name = {rt.get("name", "").strip(): rt for rt in rock.get("types", []) or []}
+            zlist = []
+            for mz in minc_in:
+                fv = _get(mz, "geometry.fracture.volume")
+                mv = list(np.atleast_1d(_get(mz, "geometry.matrix.volume", [0.9])))
+                fv = 1.0 - sum(mv) if fv is None else fv
+                planes = _get(mz, "geometry.fracture.planes", 1)
+                spc = _get(mz, "geometry.fracture.spacing", 50.0)
+                spc = [float(spc)] * planes if np.isscalar(spc) else (list(spc) + [spc[0]] * planes)[:planes]
+                geo = M.MincGeometry([fv] + mv, spc, _get(mz, "geometry.fracture.connection", 0.0))
+                rk = mz.get("rock", {}) or {}
+                if isinstance(rk, list):
+                    raise NotImplementedError("several rock specifications in one MINC zone")
+                sel = []
+                if rk.get("zones") is not None:
+                    for zn in ([rk["zones"]] if isinstance(rk["zones"], str) else rk["zones"]):
+                        sel.append(zone_cells(zones[zn], cen))
+                if rk.get("types") is not None:
+                    for tn in ([rk["types"]] if isinstance(rk["types"], str) else rk["types"]):
+                        rt = by_name[tn.strip()]
+                        if rt.get("cells") is not None:
+                            sel.append(np.asarray(rt["cells"], dtype=int))
+                        for zn in ([rt["zones"]] if isinstance(rt.get("zones"), str) else rt.get("zones") or []):
+                            sel.append(zone_cells(zones[zn], cen))
+                zc = np.unique(np.concatenate(sel)) if sel else np.arange(n)
+
+                def named(key):
+                    tn = _get(rk, key + ".type")
+                    return rock_record(by_name[tn.strip()], dim) if tn is not None else None
+                mrock = named("matrix")
+                if mrock is None:
+                    raise NotImplementedError("MINC matrix rock given by properties instead of a rock type")
+                zlist.append(dict(cells=zc, geometry=geo, matrix_rock=mrock, fracture_rock=named("fracture")))
+            lm = M.add_minc_zones(lm, zlist)
+            self._order = lm.extras["waiwera_order"]
         self.mesh = lm
         self.relperm = relperm_spec(rock.get("relative_permeability"))
         self.capillary = capillary_spec(rock.get("capillary_pressure"))
@@ -219,13 +261,23 @@ class Simulation:
             if npv > 2:
                 cols.append(st["fluid_CO2_partial_pressure"])
             prim = np.stack(cols, axis=1)
-            if prim.shape[0] != n:
+            if prim.shape[0] != n and not (self._order is not None and prim.shape[0] == lm.n_owned):
                 raise ValueError("initial conditions file has %d cells, mesh has %d" % (prim.shape[0], n))
         else:
             prim = np.asarray(init.get("primary", [1.0e5, 20.0, 0.0][:npv]), dtype=np.float64)
             prim = np.tile(prim, (n, 1)) if prim.ndim == 1 else prim
             region = np.asarray(init.get("region", 1))
             region = np.full(n, int(region), dtype=np.int32) if region.ndim == 0 else region.astype(np.int32)
+        if self._order is not None:
+            # matrix cells start from their fracture cell's state (src/initial.F90: MINC cells copy
+            # the original cell's values unless the file holds them); file order = reference order
+            nt = lm.n_owned
+            src = np.empty(nt, dtype=np.int64)
+            if prim.shape[0] == nt:        # restart file of a MINC run: already one record per cell
+                src[self._order] = np.arange(nt)
+            else:
+                src[:] = lm.extras["minc_parent"]
+            prim, region = prim[src], region[src]
         self.primary, self.region = prim, region
         # the flow object
         if ode_factory is None:
@@ -290,7 +342,7 @@ class Simulation:
                                  activation=[t.get("activation", 0.0) for t in tr],
                                  diffusion=[t.get("diffusion", 0.0) for t in tr],
                                  bc=bc if lm.n_bc else None, injection=inj)
-            self.X = np.tile(np.asarray(tvals(init.get("tracer")), dtype=np.float64), n)
+            self.X = np.tile(np.asarray(tvals(init.get("tracer")), dtype=np.float64), lm.n_owned)
         ad = step.get("adapt", {}) or {}
         mx = step.get("maximum", {}) or {}
         self.ts = Timestepper(
@@ -471,13 +523,16 @@ class Simulation:
         n = self.mesh.n_owned
         self.ode.pre_eval(self.ts.time, self.y)
         fl = np.asarray(self.ode.fluid())[:n]
+        geom = self.mesh.cell_geom[:n]
+        if self._order is not None:      # MINC: the reference's cell order (original cells, then level by level)
+            fl, geom = fl[self._order], geom[self._order]
         nc = {"w": 1, "we": 1, "wce": 2}[self.eos]
         f0, pd = 6 + nc, 7 + nc
         out = {"time": self.ts.time, "fluid_pressure": fl[:, 0].copy(), "fluid_temperature": fl[:, 1].copy(),
                "fluid_region": fl[:, 2].copy(), "fluid_liquid_saturation": fl[:, f0 + 2].copy(),
                "fluid_liquid_density": fl[:, f0].copy(),
-               "cell_geometry_centroid": self.mesh.cell_geom[:n, : self.dim].copy(),
-               "cell_geometry_volume": self.mesh.cell_geom[:n, 3].copy()}
+               "cell_geometry_centroid": geom[:, : self.dim].copy(),
+               "cell_geometry_volume": geom[:, 3].copy()}
         if self.eos != "w":
             out["fluid_vapour_saturation"] = fl[:, f0 + pd + 2].copy()
             out["fluid_vapour_density"] = fl[:, f0 + pd].copy()
@@ -487,7 +542,8 @@ class Simulation:
             out["fluid_vapour_CO2_mass_fraction"] = fl[:, f0 + pd + 8].copy()
         if self.X is not None:
             for k, name in enumerate(self.tracer_names):
-                out["tracer_" + name] = self.X.reshape(n, -1)[:, k].copy()
+                xk = self.X.reshape(n, -1)[:, k]
+                out["tracer_" + name] = (xk[self._order] if self._order is not None else xk).copy()
         if self.mesh.n_src and hasattr(self.ode, "source_rates"):
             out["source_rate"], out["source_enthalpy"] = self.ode.source_rates()
         return out
