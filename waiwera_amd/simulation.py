@@ -15,12 +15,16 @@ src/timestepper.F90:1960-2275; src/tracer.F90:63-140; utils/input_schema.json):
   initial     primary (one record or one per cell), region (one or per cell), tracer; or
               filename + index: restart from a Waiwera HDF5 output file
   boundaries  primary, region, faces {cells, normal} (one or a list), tracer
-  source      cell, rate, enthalpy (constants or [[t, v], ...] tables with "interpolation": linear|step and
-              "averaging": integrate|endpoint), component, tracer
+  mesh        filename (gmsh 2.2 ASCII; or mesh_file=: a MULgraph geometry file), thickness, radial,
+              zones (boxes, cell lists), minc {geometry, rock {fracture, matrix, zones | types}}
+  source      cell, rate, enthalpy, tracer (constants or [[t, v], ...] tables with "interpolation":
+              linear|step and "averaging": integrate|endpoint), component, deliverability {productivity,
+              pressure}, recharge {coefficient, pressure}, limiter {type, limit, separator_pressure},
+              separator {pressure}, direction
   time        start, stop, step {size, adapt, maximum, method, solver.nonlinear, solver.linear}
   tracer      name, phase, decay, activation, diffusion
 
-  output      filename, initial, final, frequency (cell fields only)
+  output      filename, initial, final, frequency (cell fields, source rate and enthalpy)
 
 Anything else that changes results (source groups, reinjectors, rock controls, ...) raises
 NotImplementedError instead of being ignored.  Output: `Simulation.run` returns the final cell
