@@ -143,6 +143,14 @@ typedef struct wo_src_ctl {
 void wo_sim_set_source_controls(wo_sim *s, const wo_src_ctl *ctl); /* NULL: none */
 void wo_sim_source_rates(wo_sim *s, double *rate, double *enthalpy);
 int wo_separator_enthalpies(const wo_eos *e, double pressure, double *hf, double *hg);
+/* salt thermodynamics, src/salt_thermodynamics.F90 (water side through e->thermo) */
+int wo_halite_solubility(double t, double *s);
+int wo_halite_solubility_two_phase(const wo_eos *e, double p, double *s);
+int wo_halite_properties(double p, double t, double *rho, double *u);
+int wo_brine_sat_pressure(const wo_eos *e, double t, double xs, double *ps);
+int wo_brine_sat_temperature(const wo_eos *e, double p, double xs, double *ts);
+int wo_brine_properties(const wo_eos *e, double p, double t, double xs, double *rho, double *u);
+int wo_brine_viscosity(const wo_eos *e, double t, double p, double xs, double *mu);
 /* table controls: new rate / enthalpy per source (NULL = kept), src/control.F90:263-284 */
 void wo_sim_update_sources(wo_sim *s, const double *rate, const double *enthalpy);
 void wo_sim_set_sources(wo_sim *s, int n, const int *cell, const double *rate,

@@ -718,3 +718,200 @@ int wo_separator_enthalpies(const wo_eos *e, double pressure, double *hf, double
   *hg = u + pressure / rho;
   return 0;
 }
+
+/* ==== salt (NaCl) thermodynamics: src/salt_thermodynamics.F90 ================================ */
+/* Correlation data as held at src/salt_thermodynamics.F90:12-30 (Driesner 2007; Battistelli 2012;
+ * Haas 1976; Phillips et al. 1981). */
+#define SALT_MW 58.443
+static const double HALITE_DENSITY[3] = {2.1704e3, -2.4599e-1, -9.5797e-5};
+static const double HALITE_ENTHALPY[4] = {-5.615174e5, 8.766380e2, 6.413881e-2, 8.810112e-5};
+static const double HALITE_SOLUBILITY[7] = {0.2627980, 3.130833e-2, 2.136495, -9.371763, 3.083588e1,
+                                            -3.959050e1, 1.711302e1};
+static const double HALITE_SOLUBILITY_2PH[5] = {0.2876823, 0.30122157, -0.39877656, 0.31352381, -0.09062578};
+static const double BRINE_PSAT_A[4] = {0.0, 5.93582e-1, -5.19386, 1.23156};
+static const double BRINE_PSAT_B[6] = {0.0, 1.15420, 1.41254, -1.92476, -1.70717, 1.05390};
+static const double BRINE_VISC[4] = {1.0, 0.0816, 0.0122, 1.28e-4};
+
+/* polynomial_single, src/utils.F90:224-241 (Horner) */
+static double poly(const double *a, int n, double x) {
+  double p = a[n - 1];
+  for (int i = n - 2; i >= 0; i--) p = a[i] + x * p;
+  return p;
+}
+
+/* newton1d_general, src/utils.F90:651-709: FD Newton with relative increment of the start value */
+typedef double (*newton_fn)(double x, void *ctx, int *err);
+static int newton1d(newton_fn f, void *ctx, double *x, double ftol, double xtol, int maxit, double inc) {
+  double delx = inc * (*x);
+  int err = 0, found = 0;
+  for (int i = 0; i < maxit; i++) {
+    double fx = f(*x, ctx, &err);
+    if (err) break;
+    if (fabs(fx) <= ftol) { found = 1; break; }
+    double fxd = f(*x + delx, ctx, &err);
+    if (err) break;
+    double df = (fxd - fx) / delx, dx = -fx / df;
+    *x += dx;
+    if (fabs(dx) <= xtol) { found = 1; break; }
+  }
+  if (!err && !found) err = 1;
+  return err;
+}
+
+/* halite_solubility :44-61 */
+int wo_halite_solubility(double t, double *s) {
+  if (0.0 <= t) { *s = poly(HALITE_SOLUBILITY, 7, t * 1.0e-3); return 0; }
+  *s = 0.0;
+  return 1;
+}
+/* halite_properties :108-134 -> density, internal energy */
+int wo_halite_properties(double p, double t, double *rho, double *u) {
+  const double l3 = 5.727e-3, l4 = 2.715e-3, l5 = 733.4;
+  double pbar = p / 1.0e5;
+  double density0 = poly(HALITE_DENSITY, 3, t);
+  double l = l3 + l4 * exp(t / l5);
+  *rho = density0 + l * pbar;
+  double h1 = poly(HALITE_ENTHALPY, 4, t);
+  double h = h1 + 44.14 * (pbar - 1.0);
+  *u = h - p / *rho;
+  return 0;
+}
+/* salt_mole_fraction :140-148 (molality-like measure used by the Haas / Phillips fits) */
+static double salt_mole_fraction(double xs) { return 1.0e3 * xs / (SALT_MW * (1.0 - xs)); }
+
+/* brine_saturation_pressure :152-176 */
+int wo_brine_sat_pressure(const wo_eos *e, double t, double xs, double *ps) {
+  double smol = salt_mole_fraction(xs);
+  double a = 1.0 + 1.0e-5 * poly(BRINE_PSAT_A, 4, smol);
+  double b = 1.0e-5 * poly(BRINE_PSAT_B, 6, 0.1 * smol);
+  double tk = t + TC_K;
+  double teff = exp(log(tk) / (a + b * tk)) - TC_K;
+  return th_sat_pressure(e, teff, ps);
+}
+struct bst_ctx { const wo_eos *e; double p, xs; };
+static double bst_f(double x, void *c, int *err) {
+  struct bst_ctx *k = (struct bst_ctx *)c;
+  double ps = 0.0;
+  *err = wo_brine_sat_pressure(k->e, x, k->xs, &ps);
+  return k->p - ps;
+}
+/* brine_saturation_temperature :180-217 */
+int wo_brine_sat_temperature(const wo_eos *e, double p, double xs, double *ts) {
+  double t;
+  int err = th_sat_temperature(e, p, &t);
+  if (err) return err;
+  struct bst_ctx k = {e, p, xs};
+  err = newton1d(bst_f, &k, &t, 1.0e-10 * p, 1.0e-10, 100, 1.0e-8);
+  *ts = t;
+  return err;
+}
+struct hs2_ctx { const wo_eos *e; double p; };
+static double hs2_f(double x, void *c, int *err) {
+  struct hs2_ctx *k = (struct hs2_ctx *)c;
+  double t, s;
+  *err = wo_brine_sat_temperature(k->e, k->p, x, &t);
+  if (*err) return -1.0;
+  *err = wo_halite_solubility(t, &s);
+  return x - s;
+}
+/* halite_solubility_two_phase :65-104 */
+int wo_halite_solubility_two_phase(const wo_eos *e, double p, double *s) {
+  double xs = poly(HALITE_SOLUBILITY_2PH, 5, p / 1.0e7);
+  struct hs2_ctx k = {e, p};
+  int err = newton1d(hs2_f, &k, &xs, 1.0e-10, 1.0e-10, 100, 1.0e-8);
+  *s = xs;
+  return err;
+}
+
+/* brine_properties :221-389 (Driesner 2007): density and internal energy */
+int wo_brine_properties(const wo_eos *e, double p, double t, double xs, double *rho_out, double *u_out) {
+  double pbar = p / 1.0e5;
+  double f = 1.0 / (xs + (1.0 - xs) * SALT_MW / WATER_MW);
+  double xmol = xs * f, xmol1 = 1.0 - xmol, xmol12 = xmol1 * xmol1;
+  double bmw = SALT_MW * f;
+  int err = 0;
+  /* density */
+  double n11 = -54.2958 - 45.7623 * exp(-9.44785e-4 * pbar);
+  double n21 = -2.6142 - 0.000239092 * pbar;
+  const double c22[3] = {0.0356828, 4.37235e-3, 2.0566e-3};
+  double n22 = poly(c22, 3, pbar / 1.0e3);
+  double c1[4] = {330.47 + 0.942876 * sqrt(pbar), 8.17193, -2.47556e-4, 3.45052e-4};
+  double n1x1 = poly(c1, 4, pbar / 1.0e2);
+  double c2[4] = {-0.0370751 + 0.00237723 * sqrt(pbar), 5.42049e-1, 5.84709e-1, -5.99373e-1};
+  double n2x1 = poly(c2, 4, pbar / 1.0e4);
+  double n10 = n1x1, n20 = 1.0 - n21 * sqrt(n22), n12 = -n11 - n10;
+  double n23 = n2x1 - n20 - n21 * sqrt(1.0 + n22);
+  double n1 = n10 + n11 * xmol1 + n12 * xmol12;
+  double n2 = n20 + n21 * sqrt(xmol + n22) + n23 * xmol;
+  /* deviation, eq. 14 */
+  double pp = pbar + 472.051;
+  double n300 = 7.60664e6 / (pp * pp);
+  double n301 = -50.0 - 86.1446 * exp(-6.21128e-4 * pbar);
+  double n302 = 294.318 * exp(-5.66735e-3 * pbar);
+  double n310 = -0.0732761 * exp(-2.3772e-3 * pbar) - 5.2948e-5 * pbar;
+  double n311 = -47.2747 + 24.3653 * exp(-1.25533e-3 * pbar);
+  double n312 = -0.278529 - 0.00081381 * pbar;
+  double n30 = n300 * (exp(n301 * xmol) - 1.0) + n302 * xmol;
+  double n31 = n310 * exp(n311 * xmol) + n312 * xmol;
+  double tstar_v = n1 + n2 * t + n30 * exp(n31 * t);
+  double pcrit = e->thermo == 1 ? 22.12e6 : PCRITICAL; /* src/IFC67.F90:159, IAPWS.F90:275 */
+  double ts = 0.0, rho = 0.0, rw, uw;
+  int extrapolate = 0;
+  if (p <= pcrit) {
+    err = th_sat_temperature(e, p, &ts);
+    if (!err) extrapolate = tstar_v > ts;
+  }
+  if (err) return err;
+  if (extrapolate) { /* eq. 17 */
+    const double dt = 0.2;
+    err = th_props(e, 1, p, ts, &rw, &uw);
+    if (err) return err;
+    double vws = 1.0e3 * WATER_MW / rw;
+    err = th_props(e, 1, p, ts - dt, &rw, &uw);
+    if (err) return err;
+    double vws1 = 1.0e3 * WATER_MW / rw;
+    double dvdt = (vws - vws1) / dt, logp = log(pbar);
+    double co[3] = {2.0125e-7 + 3.29977e-9 * exp(-4.31279 * logp), -1.17748e-7, 7.58009e-8};
+    double o2 = poly(co, 3, logp), ts2 = ts * ts;
+    double o1 = dvdt - 3.0 * o2 * ts2;
+    double o0 = vws - ts * (o1 + o2 * ts2);
+    double cv[4] = {o0, o1, 0.0, o2};
+    double vb = poly(cv, 4, tstar_v);
+    rho = 1.0e3 * bmw / vb;
+  } else {
+    err = th_props(e, 1, p, tstar_v, &rw, &uw);
+    if (err) return err;
+    rho = rw * bmw / WATER_MW;
+  }
+  /* internal energy */
+  double q11 = -32.1724 + 0.0621255 * pbar;
+  const double cq21[3] = {-1.69513, -4.52781, -6.04279};
+  double q21 = poly(cq21, 3, pbar / 1.0e4);
+  double q22 = 0.0612567 + 1.88082e-5 * pbar;
+  const double cq1[3] = {47.9048, -9.36994, 6.51059};
+  double q1x1 = poly(cq1, 3, pbar / 1.0e3);
+  const double cq2[3] = {0.241022, 3.45087e-1, -4.28356e-1};
+  double q2x1 = poly(cq2, 3, pbar / 1.0e4);
+  double q10 = q1x1, q20 = 1.0 - q21 * sqrt(q22), q12 = -q11 - q10;
+  double q23 = q2x1 - q20 - q21 * sqrt(1.0 + q22);
+  double q1 = q10 + q11 * xmol1 + q12 * xmol12;
+  double q2 = q20 + q21 * sqrt(xmol + q22) + q23 * xmol;
+  double tstar_h = q1 + q2 * t;
+  err = th_props(e, 1, p, tstar_h, &rw, &uw);
+  if (err) return err;
+  double hb = uw + p / rw;
+  *rho_out = rho;
+  *u_out = hb - p / rho;
+  return 0;
+}
+
+/* brine_viscosity :393-423 */
+int wo_brine_viscosity(const wo_eos *e, double t, double p, double xs, double *mu) {
+  double smol = salt_mole_fraction(xs);
+  double factor = poly(BRINE_VISC, 4, smol) + 6.29e-4 * t * (1.0 - exp(-0.7 * smol));
+  double rw, uw;
+  int err = th_props(e, 1, p, t, &rw, &uw);
+  if (err) return err;
+  *mu = factor * th_viscosity(e, 1, t, p, rw);
+  return 0;
+}

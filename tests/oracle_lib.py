@@ -87,6 +87,14 @@ def load(path):
         "wo_sim_set_source_controls": (None, [C.c_void_p, C.c_void_p]),
         "wo_sim_source_rates": (None, [C.c_void_p, pd, pd]),
         "wo_separator_enthalpies": (i32, [C.c_void_p, C.c_double, pd, pd]),
+        "wo_halite_solubility": (i32, [d, pd]), "wo_halite_properties": (i32, [d, d, pd, pd]),
+        "wo_halite_solubility_two_phase": (i32, [C.c_void_p, d, pd]),
+        "wo_brine_sat_pressure": (i32, [C.c_void_p, d, d, pd]), "wo_brine_sat_temperature": (i32, [C.c_void_p, d, d, pd]),
+        "wo_brine_properties": (i32, [C.c_void_p, d, d, d, pd, pd]), "wo_brine_viscosity": (i32, [C.c_void_p, d, d, d, pd]),
+        "wo_halite_solubility": (i32, [d, pd]), "wo_halite_properties": (i32, [d, d, pd, pd]),
+        "wo_halite_solubility_two_phase": (i32, [C.c_void_p, d, pd]),
+        "wo_brine_sat_pressure": (i32, [C.c_void_p, d, d, pd]), "wo_brine_sat_temperature": (i32, [C.c_void_p, d, d, pd]),
+        "wo_brine_properties": (i32, [C.c_void_p, d, d, d, pd, pd]), "wo_brine_viscosity": (i32, [C.c_void_p, d, d, d, pd]),
         "wo_sim_set_subdomains": (None, [C.c_void_p, i32, pi]),
         "wo_sim_set_regions": (None, [C.c_void_p, pi]),
         "wo_sim_get_regions": (None, [C.c_void_p, pi]),

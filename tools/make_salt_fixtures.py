@@ -1,0 +1,53 @@
+"""Known answers of the reference's salt thermodynamics unit test
+(test/unit/src/salt_thermodynamics_test.F90, IFC-67 water side, tolerance 1e-6 relative there) as
+data: tests/golden/reference_unit_values_salt.json.  Only numbers are taken (inputs and expected
+values of the *_case calls and the expected_density / expected_enthalpy tables)."""
+import json
+import os
+import re
+
+SRC = "/root/reference/test/unit/src/salt_thermodynamics_test.F90"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                   "reference_unit_values_salt.json")
+
+
+def num(s):
+    return float(s.replace("_dp", "").replace("E", "e"))
+
+
+def main():
+    txt = open(SRC).read()
+    out = {"source": "test/unit/src/salt_thermodynamics_test.F90 (IFC-67)", "halite_solubility": [],
+           "halite_properties": [], "brine_saturation_pressure": [], "brine_viscosity": []}
+    sub = {name: txt[txt.index("subroutine test_" + name): txt.index("end subroutine test_" + name.rstrip("("))]
+           for name in ("halite_solubility(", "halite_properties", "brine_saturation_pressure", "brine_viscosity",
+                        "brine_properties")}
+    for m in re.finditer(r'solubility_case\("[^"]*",\s*([-\d.e_dp]+),\s*([-\d.e_dp]+),\s*(\d)\)', sub["halite_solubility("]):
+        out["halite_solubility"].append({"t": num(m.group(1)), "expected": num(m.group(2)), "err": int(m.group(3))})
+    for m in re.finditer(r'properties_case\("[^"]*",\s*([-\d.e_dp]+),\s*\[([^\]]+)\],\s*(\d)\)', sub["halite_properties"]):
+        out["halite_properties"].append({"t": num(m.group(1)), "expected": [num(v) for v in m.group(2).split(",")]})
+    for key, pat in (("brine_saturation_pressure", "sat_case"), ("brine_viscosity", "visc_case")):
+        for m in re.finditer(pat + r'\("[^"]*",\s*([-\d.e_dp]+),\s*([-\d.e_dp]+),\s*([-\d.e_dp]+),\s*(\d)\)', sub[key]):
+            out[key].append({"t": num(m.group(1)), "xs": num(m.group(2)), "expected": num(m.group(3))})
+    bp = sub["brine_properties"]
+    tabs = {}
+    for name in ("expected_density", "expected_enthalpy"):
+        body = bp[bp.index(name + "(size"):]
+        body = body[body.index("reshape([") + 9: body.index("], &\n         [size")]
+        tabs[name] = [num(v) for v in re.findall(r"[-\d.]+E[-+]\d+_dp", body)]
+    p, t, xs = [1.0e5, 10.0e5, 100.0e5], [10.0, 100.0, 200.0, 300.0], [0.0, 0.1, 0.2, 0.25]
+    out["brine_properties"] = []
+    q = 0
+    for pi in p:           # reshape order [xs, t, p], xs fastest
+        for ti in t:
+            for xi in xs:
+                out["brine_properties"].append({"p": pi, "t": ti, "xs": xi, "density": tabs["expected_density"][q],
+                                                "enthalpy": tabs["expected_enthalpy"][q]})
+                q += 1
+    assert q == 48 and len(out["brine_saturation_pressure"]) == 20 and len(out["brine_viscosity"]) == 20
+    json.dump(out, open(OUT, "w"), indent=1)
+    print("written", OUT, {k: len(v) for k, v in out.items() if isinstance(v, list)})
+
+
+if __name__ == "__main__":
+    main()
