@@ -360,6 +360,14 @@ int wo_brent(wo_rootfn f, void *ctx, double a, double b, double xtol, double fto
 #define PH_X 7
 static inline int phase_off(const wo_eos *e, int p) { return (7 + e->nc - 1) + p * (8 + e->nc - 1); }
 
+/* eos_wse: mixture region -> water region / halite presence (src/eos_wse.F90:131-134) */
+static const int WSE_WATER_REGION[9] = {0, 1, 2, 0, 4, 1, 2, 0, 4};
+static const int WSE_HALITE[9] = {0, 0, 0, 0, 0, 1, 1, 0, 1};
+static int wse_bulk_properties(const wo_eos *e, const double *primary, double *fl);
+static int wse_phase_properties(const wo_eos *e, const double *primary, double *fl);
+static int wse_transition(const wo_eos *e, const double *oldp, double *prim, const double *old_fluid,
+                          double *fluid, int *transition);
+
 void wo_eos_init(wo_eos *e, int kind) {
   memset(e, 0, sizeof(*e));
   e->kind = kind;
@@ -374,6 +382,15 @@ void wo_eos_init(wo_eos *e, int kind) {
     e->scale[2][0] = 1.e6; e->scale[2][1] = 1.e2;
     e->scale[4][0] = 1.e6; e->scale[4][1] = 1.0;
     if (kind == WO_EOS_WCE) { e->np = 3; e->nc = 2; } /* scale[.][2] = 0: adaptive Pg/P */
+    if (kind == WO_EOS_WSE) { /* src/eos_wse.F90:123-165: solid third phase, regions 5, 6, 8 = 1, 2, 4 + halite */
+      e->np = 3; e->nc = 2; e->nph = 3;
+      for (int r = 1; r <= 8; r++) {
+        if (r == 3 || r == 7) continue;
+        e->scale[r][0] = 1.e6;
+        e->scale[r][1] = (r == 4 || r == 8) ? 1.0 : 1.e2;
+        e->scale[r][2] = 1.0;
+      }
+    }
   }
   e->df = (7 + e->nc - 1) + e->nph * (8 + e->nc - 1);
   /* reference defaults: linear [0,1]/[0,1] rel perm, zero Pc
@@ -407,6 +424,7 @@ int wo_eos_bulk_properties(const wo_eos *e, const double *primary, double *fl) {
     fl[F_PP] = fl[F_P];
     return err;
   }
+  if (e->kind == WO_EOS_WSE) return wse_bulk_properties(e, primary, fl);
   if (e->kind == WO_EOS_WCE) { /* src/eos_wge.F90:350-389 */
     fl[F_PP] = fl[F_P] - primary[2];
     fl[F_PP + 1] = primary[2];
@@ -502,6 +520,7 @@ int wo_eos_phase_properties(const wo_eos *e, const double *primary, double *fl) 
     return 0;
   }
   if (e->kind == WO_EOS_WCE) return wce_phase_properties(e, fl);
+  if (e->kind == WO_EOS_WSE) return wse_phase_properties(e, primary, fl);
   int phases = (int)lround(fl[F_PHASES]);
   double sl = fl[phase_off(e, 0) + PH_SAT];
   double rp[2], cp[2];
@@ -546,6 +565,7 @@ int wo_eos_transition(const wo_eos *e, const double *oldp, double *prim, const d
                       double *fluid, int *transition) {
   *transition = 0;
   if (e->kind == WO_EOS_W) return 0;
+  if (e->kind == WO_EOS_WSE) return wse_transition(e, oldp, prim, old_fluid, fluid, transition);
   const double small = 1.e-6;
   const int wce = (e->kind == WO_EOS_WCE);
   int old_region = (int)lround(old_fluid[F_REGION]);
@@ -610,6 +630,15 @@ int wo_eos_transition(const wo_eos *e, const double *oldp, double *prim, const d
 /* src/eos_we.F90:486-526, src/eos_w.F90:232-255, src/eos_wge.F90:573-635 */
 int wo_eos_check_primary(const wo_eos *e, const double *fluid, double *prim, int *changed) {
   *changed = 0;
+  if (e->kind == WO_EOS_WSE) { /* src/eos_wse.F90:891-938 */
+    if (prim[2] < 0.0) { prim[2] = 0.0; *changed = 1; }
+    else if (prim[2] > 1.0) return 1;
+    if (prim[0] < 0.0 || prim[0] > 100.e6) return 1;
+    if (WSE_WATER_REGION[(int)lround(fluid[F_REGION])] == 4) {
+      if (prim[1] < -1.0 || prim[1] > 2.0) return 1;
+    } else if (prim[1] < 0.0 || prim[1] > 800.0) return 1;
+    return 0;
+  }
   if (e->kind == WO_EOS_WCE) {
     const double small = 1.e-6;
     if (!(prim[0] > 0.0)) return 1;
@@ -914,4 +943,221 @@ int wo_brine_viscosity(const wo_eos *e, double t, double p, double xs, double *m
   if (err) return err;
   *mu = factor * th_viscosity(e, 1, t, p, rw);
   return 0;
+}
+
+/* ==== eos_wse: water, salt, energy (src/eos_wse.F90) ======================================== */
+/* bulk properties :645-688, phase saturations :692-726 (permeability modifier "none": factor 1,
+ * src/fluid.F90:588-596) */
+static int wse_bulk_properties(const wo_eos *e, const double *primary, double *fl) {
+  int region = (int)lround(fl[F_REGION]);
+  int wr = WSE_WATER_REGION[region], halite = WSE_HALITE[region];
+  int err = 0;
+  fl[F_P] = primary[0];
+  if (wr == 4) {
+    double xs = primary[2], t;
+    if (region != 4) err = wo_halite_solubility_two_phase(e, fl[F_P], &xs);
+    if (!err) err = wo_brine_sat_temperature(e, fl[F_P], xs, &t);
+    if (!err) fl[F_T] = t;
+  } else fl[F_T] = primary[1];
+  if (err) return err;
+  int ph = th_phase_composition(e, wr, fl[F_P], fl[F_T]);
+  if (ph <= 0) return 1;
+  fl[F_PHASES] = (double)ph;
+  double ss = (halite || region == 2) ? primary[2] : 0.0, fs = 1.0 - ss;
+  double *l = fl + phase_off(e, 0), *v = fl + phase_off(e, 1), *h = fl + phase_off(e, 2);
+  switch (wr) {
+  case 1: l[PH_SAT] = fs; v[PH_SAT] = 0.0; break;
+  case 2: l[PH_SAT] = 0.0; v[PH_SAT] = fs; break;
+  case 4: l[PH_SAT] = fs - primary[1]; v[PH_SAT] = primary[1]; break;
+  }
+  h[PH_SAT] = ss;
+  fl[F_PERMFAC] = 1.0;
+  fl[F_PP] = fl[F_P];
+  fl[F_PP + 1] = 0.0;
+  return 0;
+}
+
+static void phase_zero(const wo_eos *e, double *ph) {
+  ph[PH_RHO] = 0.0; ph[PH_U] = 0.0; ph[PH_H] = 0.0; ph[PH_KR] = 0.0; ph[PH_PC] = 0.0; ph[PH_MU] = 0.0;
+  for (int c = 0; c < e->nc; c++) ph[PH_X + c] = 0.0;
+}
+
+/* phase properties :730-857 */
+static int wse_phase_properties(const wo_eos *e, const double *primary, double *fl) {
+  double P = fl[F_P], T = fl[F_T];
+  int phases = (int)lround(fl[F_PHASES]), region = (int)lround(fl[F_REGION]);
+  int halite = WSE_HALITE[region];
+  double xs = 0.0;
+  int err = 0;
+  if (halite) err = wo_halite_solubility(T, &xs);
+  else if (region == 2) xs = 0.0;
+  else xs = primary[2];
+  if (err) return err;
+  double sl = fl[phase_off(e, 0) + PH_SAT], ss = fl[phase_off(e, 2) + PH_SAT];
+  double sle = sl / (1.0 - ss);
+  double rp[2], cp[2];
+  wo_relperm(e->rp_type, e->rp_par, sle, rp);
+  cp[0] = wo_capillary(e->cp_type, e->cp_par, sle, T);
+  cp[1] = 0.0;
+  for (int p = 0; p < e->nmob; p++) {
+    double *ph = fl + phase_off(e, p);
+    if (phases & (1 << p)) {
+      double rho, u, xp;
+      if (p == 0) { err = wo_brine_properties(e, P, T, xs, &rho, &u); xp = xs; }
+      else { err = th_props(e, 2, P, T, &rho, &u); xp = 0.0; }
+      if (err) return err;
+      ph[PH_RHO] = rho; ph[PH_U] = u; ph[PH_H] = u + P / rho;
+      ph[PH_X] = 1.0 - xp; ph[PH_X + 1] = xp;
+      ph[PH_KR] = rp[p]; ph[PH_PC] = cp[p];
+      if (p == 0) { err = wo_brine_viscosity(e, T, P, xs, &ph[PH_MU]); if (err) return err; }
+      else ph[PH_MU] = th_viscosity(e, 2, T, P, rho);
+    } else phase_zero(e, ph);
+  }
+  double *h = fl + phase_off(e, 2);
+  if (halite || region == 2) {
+    double rho, u;
+    err = wo_halite_properties(P, T, &rho, &u);
+    if (err) return err;
+    phase_zero(e, h);
+    h[PH_RHO] = rho; h[PH_U] = u; h[PH_H] = u + P / rho;
+    h[PH_X] = 0.0; h[PH_X + 1] = 1.0;
+  } else phase_zero(e, h);
+  return 0;
+}
+
+/* eos_wse_saturation_difference :942-974 along the old -> new primary segment */
+typedef struct { const double *a, *b; int halite, wr; const wo_eos *e; } wse_line;
+static double wse_satline_diff(double x, void *vc) {
+  wse_line *c = (wse_line *)vc;
+  double P = (1.0 - x) * c->a[0] + x * c->b[0], T = (1.0 - x) * c->a[1] + x * c->b[1];
+  double xs = (1.0 - x) * c->a[2] + x * c->b[2], Ps = 0.0;
+  if (c->wr == 1) {
+    if (c->halite) wo_halite_solubility(T, &xs);
+    wo_brine_sat_pressure(c->e, T, xs, &Ps);
+  } else th_sat_pressure(c->e, T, &Ps);
+  return P - Ps;
+}
+
+/* transition_to_single_phase :203-337 */
+static int wse_to_single_phase(const wo_eos *e, const double *oldp, const double *old_fluid, int new_region,
+                               double *prim, double *fluid, int *transition) {
+  const double small = 1.e-6;
+  int old_region = (int)lround(old_fluid[F_REGION]);
+  int old_halite = WSE_HALITE[old_region], nwr = WSE_WATER_REGION[new_region];
+  double ss = old_halite ? prim[2] : 0.0;
+  double bound = (nwr == 1) ? 0.0 : 1.0 - ss;
+  double pfac = (nwr == 1) ? 1.0 + small : 1.0 - small;
+  int err = 0;
+  /* inverse linear interpolant on component 2 (src/interpolation.F90:407-435, :571-584) */
+  double v1 = oldp[1], v2 = prim[1], vmax = fmax(fabs(v1), fabs(v2));
+  if (fabs(v2 - v1) >= 1.e-8 * vmax) {
+    double xi = (bound / vmax - v1 / vmax) / (v2 / vmax - v1 / vmax);
+    double ip = lerp_clamped(xi, oldp[0], prim[0]), is = lerp_clamped(xi, oldp[2], prim[2]);
+    double t, xs;
+    prim[0] = pfac * ip;
+    prim[2] = fmax(0.0, is);
+    if (nwr == 1) {
+      if (old_halite) err = wo_halite_solubility_two_phase(e, ip, &xs);
+      else xs = prim[2];
+      if (!err) err = wo_brine_sat_temperature(e, ip, xs, &t);
+    } else err = th_sat_temperature(e, ip, &t);
+    if (!err) { prim[1] = t; fluid[F_REGION] = (double)new_region; *transition = 1; }
+  } else {
+    double xs, ps;
+    if (nwr == 1) {
+      if (old_halite) err = wo_halite_solubility(old_fluid[F_T], &xs);
+      else xs = oldp[2];
+      if (!err) { xs = fmax(0.0, xs); err = wo_brine_sat_pressure(e, old_fluid[F_T], xs, &ps); }
+    } else err = th_sat_pressure(e, old_fluid[F_T], &ps);
+    if (!err) {
+      prim[0] = pfac * ps;
+      prim[1] = old_fluid[F_T];
+      fluid[F_REGION] = (double)new_region;
+      *transition = 1;
+    }
+  }
+  return err;
+}
+
+/* halite_transition :413-525 */
+static int wse_halite_transition(const wo_eos *e, const double *old_fluid, double *prim, double *fluid,
+                                 int *transition, int err) {
+  const double small = 1.e-6;
+  int region = (int)lround(fluid[F_REGION]);
+  double t, sol;
+  switch (region) {
+  case 1: case 4:
+    if (region == 1) t = prim[1];
+    else err = wo_brine_sat_temperature(e, prim[0], prim[2], &t);
+    if (!err) {
+      err = wo_halite_solubility(t, &sol);
+      if (prim[2] > sol) { prim[2] = small; fluid[F_REGION] = region + 4; *transition = 1; }
+    }
+    break;
+  case 2:
+    if (prim[2] > 0.0) { prim[2] = small; fluid[F_REGION] = 6.0; *transition = 1; }
+    break;
+  case 5: case 8:
+    if (prim[2] < 0.0) {
+      if (region == 5) {
+        err = wo_halite_solubility(prim[1], &sol);
+        if (!err) { prim[2] = sol - small; fluid[F_REGION] = 1.0; *transition = 1; }
+      } else {
+        int cur_old = (int)lround(fluid[F_OLD_REGION]), last_old = (int)lround(old_fluid[F_OLD_REGION]);
+        if (cur_old == 6 || last_old == 6) { prim[2] = small; fluid[F_REGION] = 4.0; *transition = 1; }
+        else {
+          err = wo_halite_solubility_two_phase(e, prim[0], &sol);
+          if (!err) { prim[2] = sol - small; fluid[F_REGION] = 4.0; *transition = 1; }
+        }
+      }
+    }
+    break;
+  case 6:
+    if (prim[2] < 0.0) { prim[2] = 0.0; fluid[F_REGION] = 2.0; *transition = 1; }
+    break;
+  }
+  return err;
+}
+
+/* eos_wse_transition :529-617 with transition_to_two_phase :341-409 */
+static int wse_transition(const wo_eos *e, const double *oldp, double *prim, const double *old_fluid,
+                          double *fluid, int *transition) {
+  const double small = 1.e-6;
+  int old_region = (int)lround(old_fluid[F_REGION]);
+  int owr = WSE_WATER_REGION[old_region], old_halite = WSE_HALITE[old_region];
+  int err = 0;
+  if (owr == 4) {
+    int off = old_halite ? 4 : 0;
+    double sv = prim[1];
+    if (sv < 0.0) err = wse_to_single_phase(e, oldp, old_fluid, off + 1, prim, fluid, transition);
+    else {
+      double ss = old_halite ? prim[2] : 0.0;
+      if (sv > 1.0 - ss) err = wse_to_single_phase(e, oldp, old_fluid, off + 2, prim, fluid, transition);
+    }
+  } else {
+    double xs, ps;
+    if (owr == 1) {
+      if (old_halite) err = wo_halite_solubility(prim[1], &xs);
+      else xs = prim[2];
+      if (!err) { xs = fmax(0.0, xs); err = wo_brine_sat_pressure(e, prim[1], xs, &ps); }
+    } else err = th_sat_pressure(e, prim[1], &ps);
+    if (!err && ((owr == 1 && prim[0] < ps) || (owr == 2 && prim[0] > ps))) {
+      int new_region = old_halite ? 8 : 4;
+      prim[2] = fmax(0.0, prim[2]);
+      wse_line c = {oldp, prim, old_halite, owr, e};
+      double root;
+      int it;
+      if (wo_brent(wse_satline_diff, &c, 0.0, 1.0, 1.e-8, 1.e-8, 100, &root, &it) == 0) {
+        double ip = lerp_clamped(root, oldp[0], prim[0]), is = lerp_clamped(root, oldp[2], prim[2]);
+        prim[0] = ip;
+        prim[2] = is;
+      } else prim[0] = ps;
+      double ss = old_halite ? prim[2] : 0.0;
+      prim[1] = (owr == 1) ? small : 1.0 - ss - small;
+      fluid[F_REGION] = (double)new_region;
+      *transition = 1;
+    }
+  }
+  if (!err) err = wse_halite_transition(e, old_fluid, prim, fluid, transition, err);
+  return err;
 }

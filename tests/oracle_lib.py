@@ -15,7 +15,7 @@ pi = C.POINTER(C.c_int)
 class Eos(C.Structure):
     _fields_ = [("kind", i32), ("np", i32), ("nc", i32), ("nph", i32), ("nmob", i32),
                 ("df", i32), ("isothermal", i32), ("temperature", d),
-                ("scale", d * 4 * 5), ("rp_type", i32), ("cp_type", i32),
+                ("scale", d * 4 * 9), ("rp_type", i32), ("cp_type", i32),
                 ("rp_par", d * 6), ("cp_par", d * 6), ("thermo", i32)]
 
 

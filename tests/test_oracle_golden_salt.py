@@ -73,3 +73,59 @@ def test_brine_properties_and_viscosity(oracle):
         h = u.value + c["p"] / rho.value
         assert abs(rho.value - c["density"]) <= TOL * c["density"], c
         assert abs(h - c["enthalpy"]) <= TOL * c["enthalpy"], c
+
+
+def _wse(oracle, thermo=0):
+    e = ol.Eos()
+    oracle.wo_eos_init(C.byref(e), 3)
+    e.thermo = thermo
+    return e
+
+
+def test_eos_wse_fluid_properties(oracle):
+    """test_eos_wse_fluid_properties of the reference: region 8 (two-phase with halite), IAPWS-97"""
+    c = FX["eos_wse_fluid_properties"]
+    e = _wse(oracle)
+    e.rp_type = ol.RP["linear"]
+    for k, v in enumerate([0.35, 1.0, 0.0, 0.7]):
+        e.rp_par[k] = v
+    assert (e.np, e.nc, e.nph, e.nmob) == (3, 2, 3, 2)
+    fl = np.zeros(e.df)
+    fl[2] = 8
+    prim = np.array([c["pressure"], c["vapour_saturation"], c["solid_saturation"]])
+    assert oracle.wo_eos_bulk_properties(C.byref(e), ol.dp(prim), ol.dp(fl)) == 0
+    assert oracle.wo_eos_phase_properties(C.byref(e), ol.dp(prim), ol.dp(fl)) == 0
+    b, pd_ = 7 + e.nc - 1, 8 + e.nc - 1
+    liq, vap, sol = fl[b: b + pd_], fl[b + pd_: b + 2 * pd_], fl[b + 2 * pd_: b + 3 * pd_]
+
+    def close(a, x):
+        return abs(a - x) <= 1e-6 * max(abs(x), 1e-300) if x != 0.0 else a == 0.0
+    assert close(fl[0], c["pressure"]) and close(fl[1], c["temperature"]) and int(fl[4]) == 3
+    assert close(liq[0], c["expected_liquid_density"]) and close(liq[6], c["expected_liquid_internal_energy"])
+    assert close(liq[1], c["expected_liquid_viscosity"])
+    assert close(liq[2], 1.0 - c["solid_saturation"] - c["vapour_saturation"])
+    assert close(liq[3], c["expected_liquid_relative_permeability"]) and liq[4] == 0.0
+    assert close(liq[8], c["expected_liquid_salt_mass_fraction"]) and close(liq[7], 1.0 - c["expected_liquid_salt_mass_fraction"])
+    assert close(vap[0], c["expected_vapour_density"]) and close(vap[6], c["expected_vapour_internal_energy"])
+    assert close(vap[1], c["expected_vapour_viscosity"]) and close(vap[2], c["vapour_saturation"])
+    assert close(vap[3], c["expected_vapour_relative_permeability"]) and vap[7] == 1.0 and vap[8] == 0.0
+    assert close(sol[2], c["solid_saturation"]) and close(sol[0], c["expected_solid_density"])
+    assert close(sol[6], c["expected_solid_internal_energy"]) and sol[7] == 0.0 and sol[8] == 1.0
+
+
+def test_eos_wse_transitions(oracle):
+    """the 22 cases of the reference's test_eos_wse_transition (boiling / condensing with and
+    without salt, halite precipitating and dissolving in every region)"""
+    e = _wse(oracle)
+    for c in FX["eos_wse_transition"]:
+        ofl, fl = np.zeros(e.df), np.zeros(e.df)
+        ofl[2], fl[2] = c["old_region"], c["region"]
+        ofl[1] = c.get("old_temperature", 0.0)
+        oldp, prim = np.array(c["old_primary"]), np.array(c["primary"])
+        tr = C.c_int(0)
+        err = oracle.wo_eos_transition(C.byref(e), ol.dp(oldp), ol.dp(prim), ol.dp(ofl), ol.dp(fl), C.byref(tr))
+        assert err == 0, c["title"]
+        assert bool(tr.value) == c["expected_transition"], c["title"]
+        assert int(fl[2]) == c["expected_region"], c["title"]
+        for a, b in zip(prim, c["expected_primary"]):
+            assert abs(a - b) <= 1e-6 * max(abs(b), 1e-12) + 1e-12, (c["title"], list(prim), c["expected_primary"])

@@ -15,6 +15,69 @@ def num(s):
     return float(s.replace("_dp", "").replace("E", "e"))
 
 
+WSE = "/root/reference/test/unit/src/eos_wse_test.F90"
+
+
+def wse_transition_cases():
+    """the cases of test_eos_wse_transition (IAPWS-97 water side): region and temperature of the old
+    fluid, old and new primaries, expected region / primaries / transition flag.  State set by one
+    case and not reset stays in force for the next ones, as in the test."""
+    src = open(WSE).read()
+    body = src[src.index("subroutine test_eos_wse_transition"): src.index("end subroutine test_eos_wse_transition")]
+    joined = []
+    for ln in body.split("\n"):
+        if joined and joined[-1].rstrip().endswith("&"):
+            joined[-1] = joined[-1].rstrip()[:-1] + " " + ln.strip().lstrip("&")
+        else:
+            joined.append(ln)
+
+    def ev(expr, env):
+        e = expr.replace("_dp", "").replace("small", "1.0e-6").replace("dble(", "(").strip()
+        for k, v in env.items():
+            e = re.sub(r"\b%s\b" % k, repr(v), e)
+        return eval(e, {"__builtins__": {}}, {})
+    cases, env, vals = [], {}, {}
+    for ln in joined:
+        s = ln.strip()
+        m = re.match(r'title = "(.*)"', s)
+        if m:
+            vals["title"] = m.group(1)
+            continue
+        m = re.match(r"(\w+(?:%\w+)?)\s*=\s*(.+)$", s)
+        if m and not s.startswith("call"):
+            key, expr = m.group(1), m.group(2)
+            if key == "temperature":
+                env["temperature"] = ev(expr, env)
+            elif key == "old_fluid%region":
+                vals["old_region"] = int(ev(expr, env))
+            elif key == "fluid%region":
+                vals["region"] = vals["old_region"] if "old_fluid%region" in expr else int(ev(expr, env))
+            elif key == "old_fluid%temperature":
+                vals["old_temperature"] = ev(expr, env)
+            elif key == "expected_region":
+                vals[key] = int(ev(expr, env))
+            elif key == "expected_transition":
+                vals[key] = "TRUE" in expr
+            elif key in ("expected_primary", "old_primary", "primary"):
+                vals[key] = list(vals["expected_primary"]) if expr.strip() == "expected_primary" else [float(v) for v in ev(expr, env)]
+        if s.startswith("call eos%transition"):
+            cases.append(dict(vals))
+    assert len(cases) == 22
+    return cases
+
+
+def wse_fluid_case():
+    """test_eos_wse_fluid_properties: region 8 (two-phase with halite), IAPWS-97, linear relative
+    permeability liquid [0.35, 1], vapour [0, 0.7]"""
+    src = open(WSE).read()
+    body = src[src.index("subroutine test_eos_wse_fluid_properties"): src.index("end subroutine test_eos_wse_fluid_properties")]
+    out = {}
+    for m in re.finditer(r"PetscReal, parameter :: (\w+) = ([-\d.e]+)_dp\s*$", body, re.M):
+        out[m.group(1)] = float(m.group(2))
+    assert len(out) >= 15
+    return out
+
+
 def main():
     txt = open(SRC).read()
     out = {"source": "test/unit/src/salt_thermodynamics_test.F90 (IFC-67)", "halite_solubility": [],
@@ -45,6 +108,8 @@ def main():
                                                 "enthalpy": tabs["expected_enthalpy"][q]})
                 q += 1
     assert q == 48 and len(out["brine_saturation_pressure"]) == 20 and len(out["brine_viscosity"]) == 20
+    out["eos_wse_transition"] = wse_transition_cases()
+    out["eos_wse_fluid_properties"] = wse_fluid_case()
     json.dump(out, open(OUT, "w"), indent=1)
     print("written", OUT, {k: len(v) for k, v in out.items() if isinstance(v, list)})
 
