@@ -11,10 +11,11 @@ def make_case(dims=(8, 8, 8), brick=(4, 4, 4), eos="we", lens=False, sources=Tru
         # layer falls inside it (otherwise lens=True silently means no lens)
         spacing = (10.0, 10.0, 500.0 / dims[2]) if lens and dims[2] * 10.0 < 450.0 else (10.0, 10.0, 10.0)
     g = M.StructuredGrid(dims, spacing=spacing, brick=brick, part=part)
-    srcs = M.benchmark_sources(g, co2_fraction=0.05 if eos == "wce" else 0.0) if sources else None
+    srcs = M.benchmark_sources(g, co2_fraction=0.05 if eos in ("wce", "wse") else 0.0) if sources else None   # wse: 5 % salt
     bc = None
     if top_bc:
-        bc = {"we": ([1.0e5, 20.0], 1), "w": ([1.0e5], 1), "wce": ([1.0e5, 20.0, 0.02e5], 1)}[eos]
+        bc = {"we": ([1.0e5, 20.0], 1), "w": ([1.0e5], 1), "wce": ([1.0e5, 20.0, 0.02e5], 1),
+              "wse": ([1.0e5, 20.0, 0.05], 1)}[eos]
     rock = M.heterogeneous_rock(g.n_global) if hetero else None
     mspec = None
     if minc:  # fracture fraction 0.1, one matrix level, 3 planes, 50 m
@@ -27,11 +28,11 @@ def make_case(dims=(8, 8, 8), brick=(4, 4, 4), eos="we", lens=False, sources=Tru
 
 
 def scaled(prim, region, eos="we"):
-    sc = np.ones((5, prim.shape[1]))
-    for r in (1, 2, 4):
+    sc = np.ones((9, prim.shape[1]))
+    for r in (1, 2, 4, 5, 6, 8):
         sc[r, 0] = 1.0e6
         if prim.shape[1] > 1:
-            sc[r, 1] = 1.0e2 if r != 4 else 1.0
+            sc[r, 1] = 1.0e2 if r not in (4, 8) else 1.0
     out = prim / sc[region]
     if eos == "wce":  # adaptive partial-pressure scaling Pg / P (src/eos_wge.F90:639-655)
         out[:, 2] = prim[:, 2] / prim[:, 0]

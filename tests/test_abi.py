@@ -47,6 +47,6 @@ def test_no_product_code_touches_the_oracle():
             for f in files:
                 if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h", ".F90")):
                     t = open(os.path.join(dp, f), errors="ignore").read()
-                    if re.search(r"oracle_lib|liboracle|wai_oracle|wo_[a-z]+\(", t):
+                    if re.search(r"oracle_lib|liboracle|wai_oracle|\bwo_[a-z]+\(", t):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad

@@ -49,8 +49,8 @@ class OracleOde:
         out = prim.copy()
         out[:, 0] = prim[:, 0] / 1.0e6
         if prim.shape[1] > 1:
-            out[:, 1] = np.where(region == 4, prim[:, 1], prim[:, 1] / 1.0e2)
-        if prim.shape[1] > 2:
+            out[:, 1] = np.where(np.isin(region, (4, 8)), prim[:, 1], prim[:, 1] / 1.0e2)
+        if prim.shape[1] > 2 and self.o.eos.kind != 3:     # wce: Pg / P; wse: salt variable unscaled
             out[:, 2] = prim[:, 2] / prim[:, 0]
         return out
 
@@ -297,7 +297,7 @@ INPUTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inp
 def oracle_factory(oracle):
     def make(lm, eos, thermo, relperm, capillary, temperature):
         assert capillary[0] == "zero"
-        osim = ol.OracleSim(oracle, lm, {"w": 0, "we": 1, "wce": 2}[eos], thermo=1 if thermo == "ifc67" else 0,
+        osim = ol.OracleSim(oracle, lm, {"w": 0, "we": 1, "wce": 2, "wse": 3}[eos], thermo=1 if thermo == "ifc67" else 0,
                             relperm=relperm)
         ode = OracleWceOde(osim, 1.0e-5)
         ode.num_primary_variables = osim.np

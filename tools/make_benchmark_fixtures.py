@@ -294,6 +294,8 @@ def input_files():
              (REF, "tracer/oned/run/oned_two_phase.json"), (REF, "tracer/oned/run/oned_two_phase_ss.json"),
              (REF, "tracer/oned/run/oned_two_phase_ss.h5"), (REF, "tracer/oned/run/oned_single_phase.json"),
              (REF, "tracer/oned/run/oned_single_phase_ss.h5"), (REF, "tracer/oned/run/goned.msh"),
+             (REF, "salt/column/run/salt_column.json"), (REF, "salt/column/run/gsalt_column.msh"),
+             (REF, "salt/production/run/salt_production.json"), (REF, "salt/production/run/gsalt_production.msh"),
              (REF, "minc/column/run/minc_column_minc.json"), (REF, "minc/column/run/minc_column_single.json"),
              (REF, "minc/column/run/gminc_column.dat"),
              (REF, "minc/production3d/run/minc_3d_base.json"), (REF, "minc/production3d/run/gminc_3d_base.dat"),
@@ -352,6 +354,38 @@ def source_controls():
             "source_history": {k: [tab[k][0] for _, tab in gen] for k in ("Generation rate", "Enthalpy")},
             "final": {k: elem[-1][1][k][:n] for k in fields}}
     json.dump(out, open(os.path.join(OUT, "benchmark_source_controls.json"), "w"), indent=1)
+
+
+def salt():
+    """test/benchmark/salt/column (steady state of a 30-block column with water + salt injected at
+    the bottom) and salt/production (radial, 40 blocks, production with halite precipitating at the
+    well): final AUTOUGH2 (EWASG) tables.  The reference's own tolerances are 1e-2 ... 5e-2 because
+    EWASG uses other brine correlations."""
+    out = {"source": "test/benchmark/salt/{column,production}/run/*.listing; inputs are tests/golden/inputs/salt_*.json"}
+    for name, n in (("column", 30), ("production", 40)):
+        # EWASG listing: 13-character columns whose names are cut off ("Gas saturati", "Liquid satur",
+        # "NaCl liquid "): take the numbers of each row by position
+        lines = open(os.path.join(REF, "salt", name, "run", "salt_%s.listing" % name)).read().split("\n")
+        idx = [i for i, l in enumerate(lines) if "ELEMENT TABLE" in l][-1]
+        assert lines[idx + 2].split()[2:7] == ["Pressure", "Temperature", "Gas", "saturati", "Liquid"]
+        rows = []
+        for l in lines[idx + 3:]:
+            nums = re.findall(r"[-+]?\d\.\d+E[-+]\d+", l)
+            if rows and not nums:
+                break
+            if nums:
+                rows.append([float(v) for v in nums])
+        names = ["Pressure", "Temperature", "Gas satur", "Liquid satur", "NaCl liquid"]
+
+        def col(prefix):
+            return [r[names.index(prefix)] for r in rows]
+        atm = len(rows) - n
+        sg, sl = col("Gas satur")[atm:], col("Liquid satur")[atm:]
+        out[name] = {"Pressure": col("Pressure")[atm:], "Temperature": col("Temperature")[atm:],
+                     "Vapour saturation": sg, "Liquid saturation": sl,
+                     "Solid saturation": [1.0 - a - b for a, b in zip(sg, sl)],
+                     "Liquid salt mass fraction": col("NaCl liquid")[atm:]}
+    json.dump(out, open(os.path.join(OUT, "benchmark_salt.json"), "w"), indent=1)
 
 
 def minc_tables(listing, n, levels, zone_count):
@@ -417,6 +451,7 @@ def tracer_doublet():
 
 
 if __name__ == "__main__":
+    salt()
     minc_column_and_3d()
     problem6()
     tracer_doublet()

@@ -535,6 +535,7 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
   if (c->kind == WAI_EOS_W) { c->np = 1; c->df = 15; }
   else if (c->kind == WAI_EOS_WE) { c->np = 2; c->df = 23; }
   else if (c->kind == WAI_EOS_WCE) { c->np = 3; c->df = 26; }
+  else if (c->kind == WAI_EOS_WSE) { c->np = 3; c->df = 35; }
   else { c->err = "unsupported eos kind"; return -2; }
   std::memset(&c->ep, 0, sizeof(c->ep));
   c->ep.temperature = ed->temperature;
@@ -546,6 +547,12 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
   // eos.primary.scale.partial_pressure: absent/<= 0 = adaptive Pg/P (eos_wge.F90:95-104)
   const double gs = ed->partial_pressure_scale > 0 ? ed->partial_pressure_scale : 0.0;
   c->ep.scale[1][2] = gs; c->ep.scale[2][2] = gs; c->ep.scale[4][2] = gs;
+  if (c->kind == WAI_EOS_WSE) {   // eos_wse.F90:155-165: regions 5, 6, 8 scale like 1, 2, 4; salt variable unscaled
+    for (int r : {1, 2, 4}) {
+      c->ep.scale[r][2] = 1.0;
+      for (int k = 0; k < 3; k++) c->ep.scale[r + 4][k] = c->ep.scale[r][k];
+    }
+  }
   c->ep.rp_type = ed->rp_type; c->ep.cp_type = ed->cp_type;
   if (ed->thermo != WAI_THERMO_IAPWS && ed->thermo != WAI_THERMO_IFC67) { c->err = "unknown thermodynamic formulation"; return -2; }
   c->ep.thermo = ed->thermo;
@@ -843,7 +850,8 @@ int wai_set_bc(wai_ctx* c, const double* primary, const int* region) {
   std::vector<double> reg(nb), ys((size_t)(first + nb) * np, 0.0);
   for (int b = 0; b < nb; b++) {
     const int rg = region[b];
-    if (rg < 1 || rg > 4 || rg == 3) { c->err = "bad bc region"; return -2; }
+    const int rmax = c->kind == WAI_EOS_WSE ? 8 : 4;
+    if (rg < 1 || rg > rmax || rg == 3 || rg == 7) { c->err = "bad bc region"; return -2; }
     reg[b] = (double)rg;
     for (int k = 0; k < np; k++) {
       const double sc = c->ep.scale[rg][k];

@@ -551,7 +551,12 @@ __global__ __launch_bounds__(TPB) void k_transitions(EosParams ep, int n_owned,
   eos_unscale<KIND>(ep, yo, old_region, oldp);
   flu[F_OLD_REGION * stride + c] = (double)region;
   bool transition = false, changed = false;
-  int err = eos_transition<KIND>(ep.thermo, oldp, prim, old_region, old_t, region, transition);
+  int err;
+  if constexpr (KIND == EOS_WSE)
+    err = eos_transition_wse(ep.thermo, oldp, prim, old_region, old_t, region,
+                             (int)flu_old[F_OLD_REGION * stride + c], region, transition);
+  else
+    err = eos_transition<KIND>(ep.thermo, oldp, prim, old_region, old_t, region, transition);
   if (!err) err = eos_check_primary<KIND>(prim, region, changed);
   if (err) { flag_error(flags, c); return; }
   if (transition || changed) {
@@ -643,6 +648,7 @@ static inline int grid8_for(size_t n) { return ((grid_for(n) + 7) / 8) * 8; }  /
   do {                                                                                           \
     if ((c)->kind == EOS_W) hipLaunchKernelGGL(KERNEL<EOS_W>, grid, TPB, 0, (c)->stream, __VA_ARGS__);        \
     else if ((c)->kind == EOS_WE) hipLaunchKernelGGL(KERNEL<EOS_WE>, grid, TPB, 0, (c)->stream, __VA_ARGS__); \
+    else if ((c)->kind == EOS_WSE) hipLaunchKernelGGL(KERNEL<EOS_WSE>, grid, TPB, 0, (c)->stream, __VA_ARGS__); \
     else hipLaunchKernelGGL(KERNEL<EOS_WCE>, grid, TPB, 0, (c)->stream, __VA_ARGS__);                         \
   } while (0)
 

@@ -17,7 +17,7 @@
 
 namespace wai {
 
-enum { EOS_W = 0, EOS_WE = 1, EOS_WCE = 2 };
+enum { EOS_W = 0, EOS_WE = 1, EOS_WCE = 2, EOS_WSE = 3 };
 enum { RP_FULLY_MOBILE = 0, RP_LINEAR = 1, RP_PICKENS = 2, RP_COREY = 3, RP_GRANT = 4,
        RP_VAN_GENUCHTEN = 5 };
 enum { CP_ZERO = 0, CP_LINEAR = 1, CP_VAN_GENUCHTEN = 2 };
@@ -43,10 +43,15 @@ template <> struct EosT<EOS_WCE> {  // water + CO2 + energy (eos_wge.F90 + eos_w
   static constexpr bool isothermal = false;
 };
 
+template <> struct EosT<EOS_WSE> {  // water + salt + energy (eos_wse.F90): third phase = solid halite, immobile
+  static constexpr int np = 3, nc = 2, nph = 3, nmob = 2, df = 35, f_phase0 = 8, ph_dof = 9;
+  static constexpr bool isothermal = false;
+};
+
 // run-time EOS parameters (kernel argument, lives in SGPRs / constant cache)
 struct EosParams {
   double temperature;     // eos_w
-  double scale[5][3];     // primary_scale(var, region)  (eos_we.F90:104-109); a zero partial-
+  double scale[9][3];     // primary_scale(var, region)  (eos_we.F90:104-109; eos_wse: regions 1..8); a zero partial-
                           // pressure scale selects adaptive scaling Pg/P (eos_wge.F90:639-674)
   int rp_type, cp_type;
   double rp_par[6], cp_par[6];
@@ -74,6 +79,9 @@ __device__ __forceinline__ int phase_composition(int thermo, int region, double 
   return thermo == THERMO_IFC67 ? ifc67::phase_composition(region) : if97::phase_composition(region, p, t);
 }
 }  // namespace th
+}  // namespace wai
+#include "salt.hip.h"
+namespace wai {
 
 // two-row table lookup with end clamping (interpolation.F90:202-222,388-404,494-510)
 __device__ __forceinline__ double lin2(double x, double x0, double x1, double y0, double y1) {
@@ -215,6 +223,10 @@ __device__ __forceinline__ void eos_scale(const EosParams& e, const double* prim
   if constexpr (KIND == EOS_WCE) { if (e.scale[region][2] == 0.0) y[2] = prim[2] / prim[0]; }
 }
 
+// eos_wse: mixture region -> water region / halite presence (eos_wse.F90:131-134)
+__device__ __forceinline__ int wse_water_region(int region) { return region > 4 ? region - 4 : region; }
+__device__ __forceinline__ bool wse_halite(int region) { return region > 4; }
+
 // ---- cell state in registers ---------------------------------------------------------------
 template <int KIND> struct CellState {
   using E = EosT<KIND>;
@@ -246,6 +258,65 @@ __device__ __forceinline__ int eos_eval(const EosParams& e, const double* y, int
     s.kr[0] = 1.0; s.pc[0] = 0.0;
     s.mu[0] = th::viscosity(e.thermo, region == 1 ? 1 : 2, s.T, s.P, rho);
     s.x[0][0] = 1.0; s.pp[0] = s.P;
+    return 0;
+  } else if constexpr (KIND == EOS_WSE) {
+    // eos_wse_bulk_properties / phase_saturations / phase_properties (eos_wse.F90:645-857);
+    // permeability modifier "none" (fluid.F90:588-596)
+    const int wr = wse_water_region(region);
+    const bool halite = wse_halite(region);
+    double prim[3];
+    eos_unscale<KIND>(e, y, region, prim);
+    s.P = prim[0];
+    s.pp[0] = s.P; s.pp[1] = 0.0;
+    if (wr == 4) {
+      double xs2 = prim[2], t;
+      if (region != 4) { if (salt::halite_solubility_two_phase(e.thermo, s.P, xs2)) return 1; }
+      if (salt::brine_sat_temperature(e.thermo, s.P, xs2, t)) return 1;
+      s.T = t;
+    } else s.T = prim[1];
+    const int ph = th::phase_composition(e.thermo, wr, s.P, s.T);
+    if (ph <= 0) return 1;
+    s.phases = (double)ph;
+    const double ss = (halite || region == 2) ? prim[2] : 0.0, fs = 1.0 - ss;
+    if (wr == 1) { s.sat[0] = fs; s.sat[1] = 0.0; }
+    else if (wr == 2) { s.sat[0] = 0.0; s.sat[1] = fs; }
+    else { s.sat[0] = fs - prim[1]; s.sat[1] = prim[1]; }
+    s.sat[2] = ss;
+    double xs = 0.0;
+    if (halite) { if (salt::halite_solubility(s.T, xs)) return 1; }
+    else if (region != 2) xs = prim[2];
+    const double sle = s.sat[0] / (1.0 - ss);
+    double kl, kv;
+    relperm(e, sle, kl, kv);
+    const double pcl = capillary(e, sle);
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      if (ph & (1 << p)) {
+        double rho, u;
+        const int err = (p == 0) ? salt::brine_properties(e.thermo, s.P, s.T, xs, rho, u)
+                                 : th::props(e.thermo, 2, s.P, s.T, rho, u);
+        if (err) return err;
+        const double xp = (p == 0) ? xs : 0.0;
+        s.rho[p] = rho; s.u[p] = u; s.h[p] = u + s.P / rho;
+        s.x[p][0] = 1.0 - xp; s.x[p][1] = xp;
+        s.kr[p] = (p == 0) ? kl : kv;
+        s.pc[p] = (p == 0) ? pcl : 0.0;
+        if (p == 0) { if (salt::brine_viscosity(e.thermo, s.T, s.P, xs, s.mu[p])) return 1; }
+        else s.mu[p] = th::viscosity(e.thermo, 2, s.T, s.P, rho);
+      } else {
+        s.rho[p] = 0.0; s.u[p] = 0.0; s.h[p] = 0.0; s.kr[p] = 0.0; s.pc[p] = 0.0; s.mu[p] = 0.0;
+        s.x[p][0] = 0.0; s.x[p][1] = 0.0;
+      }
+    }
+    s.kr[2] = 0.0; s.pc[2] = 0.0; s.mu[2] = 0.0;
+    if (halite || region == 2) {
+      double rho, u;
+      salt::halite_properties(s.P, s.T, rho, u);
+      s.rho[2] = rho; s.u[2] = u; s.h[2] = u + s.P / rho;
+      s.x[2][0] = 0.0; s.x[2][1] = 1.0;
+    } else {
+      s.rho[2] = 0.0; s.u[2] = 0.0; s.h[2] = 0.0; s.x[2][0] = 0.0; s.x[2][1] = 0.0;
+    }
     return 0;
   } else if constexpr (KIND == EOS_WCE) {
     // eos_wge_bulk_properties / phase_properties (eos_wge.F90:350-543) with CO2 (eos_wce.F90)
@@ -643,10 +714,11 @@ __device__ inline double satline_diff(double x, const SatLine& c) {
   return P - Pg - ps;
 }
 
-__device__ inline int brent_satline(const SatLine& sl, double& root) {
+template <class F>
+__device__ inline int brent_unit(const F& fn, double& root) {
   const double xtol = 1.e-8, ftol = 1.e-8, small = 1.e-16;
   double a = 0.0, b = 1.0;
-  double fa = satline_diff(a, sl), fb = satline_diff(b, sl);
+  double fa = fn(a), fb = fn(b);
   root = 0.0;
   if (fa * fb > 0.0) return 1;
   double c = b, fc = fb, d = 0.0, e = 0.0;
@@ -674,10 +746,14 @@ __device__ inline int brent_satline(const SatLine& sl, double& root) {
     a = b; fa = fb;
     if (fabs(d) > xtol) b += d;
     else b += (dx >= 0.0 ? xtol : -xtol);
-    fb = satline_diff(b, sl);
+    fb = fn(b);
   }
   root = b;
   return found ? 0 : 2;
+}
+
+__device__ inline int brent_satline(const SatLine& sl, double& root) {
+  return brent_unit([&](double x) { return satline_diff(x, sl); }, root);
 }
 
 // eos%transition (eos_we.F90:149-323; eos_wge.F90:154-346; eos_w.F90:103-122).
@@ -753,11 +829,138 @@ __device__ inline int eos_transition(int thermo, const double* oldp, double* pri
   }
 }
 
+// eos_wse transitions (eos_wse.F90:203-617): boiling / condensing along the *brine* saturation
+// line, then halite precipitation / dissolution.  cur_old_region = the cell's region on entry
+// (fluid%old_region as set by flow_simulation.F90:2502), last_old_region = that field of the
+// last-iteration fluid.
+__device__ inline int wse_to_single_phase(int thermo, const double* oldp, double* prim, int old_region,
+                                          double old_t, int new_region, int& region, bool& transition) {
+  const double small = 1.e-6;
+  const bool old_halite = wse_halite(old_region);
+  const int nwr = wse_water_region(new_region);
+  const double ss = old_halite ? prim[2] : 0.0;
+  const double bound = (nwr == 1) ? 0.0 : 1.0 - ss;
+  const double pfac = (nwr == 1) ? 1.0 + small : 1.0 - small;
+  int err = 0;
+  const double v1 = oldp[1], v2 = prim[1], vmax = fmax(fabs(v1), fabs(v2));
+  if (fabs(v2 - v1) >= 1.e-8 * vmax) {
+    const double xi = (bound / vmax - v1 / vmax) / (v2 / vmax - v1 / vmax);
+    const double ip = lerp_clamped(xi, oldp[0], prim[0]), is = lerp_clamped(xi, oldp[2], prim[2]);
+    double t, xs;
+    prim[0] = pfac * ip;
+    prim[2] = fmax(0.0, is);
+    if (nwr == 1) {
+      if (old_halite) err = salt::halite_solubility_two_phase(thermo, ip, xs);
+      else xs = prim[2];
+      if (!err) err = salt::brine_sat_temperature(thermo, ip, xs, t);
+    } else err = th::sat_temperature(thermo, ip, t);
+    if (!err) { prim[1] = t; region = new_region; transition = true; }
+  } else {
+    double xs, ps;
+    if (nwr == 1) {
+      if (old_halite) err = salt::halite_solubility(old_t, xs);
+      else xs = oldp[2];
+      if (!err) { xs = fmax(0.0, xs); err = salt::brine_sat_pressure(thermo, old_t, xs, ps); }
+    } else err = th::sat_pressure(thermo, old_t, ps);
+    if (!err) { prim[0] = pfac * ps; prim[1] = old_t; region = new_region; transition = true; }
+  }
+  return err;
+}
+
+__device__ inline int eos_transition_wse(int thermo, const double* oldp, double* prim, int old_region,
+                                         double old_t, int cur_old_region, int last_old_region,
+                                         int& region, bool& transition) {
+  const double small = 1.e-6;
+  transition = false;
+  const int owr = wse_water_region(old_region);
+  const bool old_halite = wse_halite(old_region);
+  int err = 0;
+  if (owr == 4) {
+    const int off = old_halite ? 4 : 0;
+    const double sv = prim[1];
+    if (sv < 0.0) err = wse_to_single_phase(thermo, oldp, prim, old_region, old_t, off + 1, region, transition);
+    else {
+      const double ss = old_halite ? prim[2] : 0.0;
+      if (sv > 1.0 - ss) err = wse_to_single_phase(thermo, oldp, prim, old_region, old_t, off + 2, region, transition);
+    }
+  } else {
+    double xs, ps;
+    if (owr == 1) {
+      if (old_halite) err = salt::halite_solubility(prim[1], xs);
+      else xs = prim[2];
+      if (!err) { xs = fmax(0.0, xs); err = salt::brine_sat_pressure(thermo, prim[1], xs, ps); }
+    } else err = th::sat_pressure(thermo, prim[1], ps);
+    if (!err && ((owr == 1 && prim[0] < ps) || (owr == 2 && prim[0] > ps))) {
+      prim[2] = fmax(0.0, prim[2]);
+      const double a0 = oldp[0], a1 = oldp[1], a2 = oldp[2], b0 = prim[0], b1 = prim[1], b2 = prim[2];
+      double root;
+      const int rerr = brent_unit([&](double x) {   // eos_wse_saturation_difference :942-974
+        const double P = (1.0 - x) * a0 + x * b0, T = (1.0 - x) * a1 + x * b1;
+        double xq = (1.0 - x) * a2 + x * b2, Ps = 0.0;
+        if (owr == 1) {
+          if (old_halite) salt::halite_solubility(T, xq);
+          salt::brine_sat_pressure(thermo, T, xq, Ps);
+        } else th::sat_pressure(thermo, T, Ps);
+        return P - Ps;
+      }, root);
+      if (rerr == 0) {
+        prim[0] = lerp_clamped(root, a0, b0);
+        prim[2] = lerp_clamped(root, a2, b2);
+      } else prim[0] = ps;
+      const double ss = old_halite ? prim[2] : 0.0;
+      prim[1] = (owr == 1) ? small : 1.0 - ss - small;
+      region = old_halite ? 8 : 4;
+      transition = true;
+    }
+  }
+  if (err) return err;
+  // halite_transition :413-525
+  double t, sol;
+  switch (region) {
+    case 1: case 4:
+      if (region == 1) t = prim[1];
+      else err = salt::brine_sat_temperature(thermo, prim[0], prim[2], t);
+      if (!err) {
+        err = salt::halite_solubility(t, sol);
+        if (prim[2] > sol) { prim[2] = small; region += 4; transition = true; }
+      }
+      break;
+    case 2:
+      if (prim[2] > 0.0) { prim[2] = small; region = 6; transition = true; }
+      break;
+    case 5: case 8:
+      if (prim[2] < 0.0) {
+        if (region == 5) {
+          err = salt::halite_solubility(prim[1], sol);
+          if (!err) { prim[2] = sol - small; region = 1; transition = true; }
+        } else if (cur_old_region == 6 || last_old_region == 6) {
+          prim[2] = small; region = 4; transition = true;
+        } else {
+          err = salt::halite_solubility_two_phase(thermo, prim[0], sol);
+          if (!err) { prim[2] = sol - small; region = 4; transition = true; }
+        }
+      }
+      break;
+    case 6:
+      if (prim[2] < 0.0) { prim[2] = 0.0; region = 2; transition = true; }
+      break;
+  }
+  return err;
+}
+
 // eos%check_primary_variables (eos_we.F90:486-526; eos_w.F90:232-255; eos_wge.F90:573-635:
 // the gas partial pressure is clamped to [0, (1-1e-6) P] and reported as `changed`)
 template <int KIND>
 __device__ __forceinline__ int eos_check_primary(double* prim, int region, bool& changed) {
   changed = false;
+  if constexpr (KIND == EOS_WSE) {   // eos_wse.F90:891-938
+    if (prim[2] < 0.0) { prim[2] = 0.0; changed = true; }
+    else if (prim[2] > 1.0) return 1;
+    if (prim[0] < 0.0 || prim[0] > 100.e6) return 1;
+    if (wse_water_region(region) == 4) { if (prim[1] < -1.0 || prim[1] > 2.0) return 1; }
+    else if (prim[1] < 0.0 || prim[1] > 800.0) return 1;
+    return 0;
+  }
   if constexpr (KIND == EOS_WCE) {
     const double small = 1.e-6;
     if (!(prim[0] > 0.0)) return 1;

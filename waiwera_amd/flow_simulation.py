@@ -138,12 +138,12 @@ class FlowSimulation:
 
     def scale(self, primary, region):
         """eos%scale (src/eos.F90:186-197): unscaled primaries (n, np) -> scaled y."""
-        sc = np.ones((5, self.num_primary_variables))
+        sc = np.ones((9, self.num_primary_variables))
         ps, ts = self.eos_desc.pressure_scale, self.eos_desc.temperature_scale
-        for r in (1, 2, 4):
+        for r in (1, 2, 4, 5, 6, 8):     # 5, 6, 8: eos wse regions with halite (src/eos_wse.F90:155-165)
             sc[r, 0] = ps
             if self.num_primary_variables > 1:
-                sc[r, 1] = ts if r != 4 else 1.0
+                sc[r, 1] = ts if r not in (4, 8) else 1.0
         prim = np.asarray(primary, dtype=np.float64)
         out = prim / sc[np.asarray(region)]
         if self.eos_name == "wce" and self.eos_desc.partial_pressure_scale <= 0:

@@ -153,7 +153,7 @@ class Simulation:
         temperature = eos.get("temperature", 20.0) if isinstance(eos, dict) else 20.0
         th = inp.get("thermodynamics", "iapws")
         self.thermo = (th.get("name", "iapws") if isinstance(th, dict) else th).lower()
-        if self.eos not in ("w", "we", "wce") or self.thermo not in ("iapws", "ifc67"):
+        if self.eos not in ("w", "we", "wce", "wse") or self.thermo not in ("iapws", "ifc67"):
             raise NotImplementedError("eos %r / thermodynamics %r" % (self.eos, self.thermo))
         # geometry first without rock (centroids are needed for zones), rock filled in below
         bnds = []
@@ -252,7 +252,7 @@ class Simulation:
         self.capillary = capillary_spec(rock.get("capillary_pressure"))
         # initial conditions
         init = inp.get("initial", {}) or {}
-        npv = {"w": 1, "we": 2, "wce": 3}[self.eos]
+        npv = {"w": 1, "we": 2, "wce": 3, "wse": 3}[self.eos]
         if "filename" in init:
             # restart from a Waiwera HDF5 output (setup_initial, src/initial.F90:421-677, 776, 922):
             # primaries of each cell from its fluid fields by region (eos%primary_variables)
@@ -262,7 +262,11 @@ class Simulation:
             cols = [st["fluid_pressure"]]
             if npv > 1:
                 cols.append(np.where(region == 4, st["fluid_vapour_saturation"], st["fluid_temperature"]))
-            if npv > 2:
+            if npv > 2 and self.eos == "wse":
+                halite = np.isin(region, (5, 6, 8))
+                cols[1] = np.where(np.isin(region, (4, 8)), st["fluid_vapour_saturation"], st["fluid_temperature"])
+                cols.append(np.where(halite, st["fluid_solid_saturation"], st["fluid_liquid_salt_mass_fraction"]))
+            elif npv > 2:
                 cols.append(st["fluid_CO2_partial_pressure"])
             prim = np.stack(cols, axis=1)
             if prim.shape[0] != n and not (self._order is not None and prim.shape[0] == lm.n_owned):
@@ -389,7 +393,7 @@ class Simulation:
                 fl = np.asarray(self.ode.fluid())
             return fl[cell]
 
-        nc = {"w": 1, "we": 1, "wce": 2}[self.eos]
+        nc = {"w": 1, "we": 1, "wce": 2, "wse": 2}[self.eos]
         f0, pd = 6 + nc, 7 + nc
 
         def mobility_sum(f):
@@ -530,7 +534,7 @@ class Simulation:
         geom = self.mesh.cell_geom[:n]
         if self._order is not None:      # MINC: the reference's cell order (original cells, then level by level)
             fl, geom = fl[self._order], geom[self._order]
-        nc = {"w": 1, "we": 1, "wce": 2}[self.eos]
+        nc = {"w": 1, "we": 1, "wce": 2, "wse": 2}[self.eos]
         f0, pd = 6 + nc, 7 + nc
         out = {"time": self.ts.time, "fluid_pressure": fl[:, 0].copy(), "fluid_temperature": fl[:, 1].copy(),
                "fluid_region": fl[:, 2].copy(), "fluid_liquid_saturation": fl[:, f0 + 2].copy(),
@@ -540,6 +544,9 @@ class Simulation:
         if self.eos != "w":
             out["fluid_vapour_saturation"] = fl[:, f0 + pd + 2].copy()
             out["fluid_vapour_density"] = fl[:, f0 + pd].copy()
+        if self.eos == "wse":
+            out["fluid_liquid_salt_mass_fraction"] = fl[:, f0 + 8].copy()
+            out["fluid_solid_saturation"] = fl[:, f0 + 2 * pd + 2].copy()
         if self.eos == "wce":
             out["fluid_CO2_partial_pressure"] = fl[:, 7].copy()
             out["fluid_liquid_CO2_mass_fraction"] = fl[:, f0 + 8].copy()
