@@ -69,7 +69,7 @@ int wo_brent(wo_rootfn f, void *ctx, double a, double b, double xtol, double fto
              double *root, int *iters);
 
 /* ---- EOS (src/eos.F90, src/eos_w.F90, src/eos_we.F90) ----------------------------------- */
-enum { WO_EOS_W = 0, WO_EOS_WE = 1, WO_EOS_WCE = 2, WO_EOS_WSE = 3 };
+enum { WO_EOS_W = 0, WO_EOS_WE = 1, WO_EOS_WCE = 2, WO_EOS_WSE = 3, WO_EOS_WAE = 4 };
 typedef struct wo_eos {
   int kind, np, nc, nph, nmob, df, isothermal;
   double temperature;          /* eos_w only (eos_w.F90:97-98) */
@@ -143,6 +143,11 @@ typedef struct wo_src_ctl {
 void wo_sim_set_source_controls(wo_sim *s, const wo_src_ctl *ctl); /* NULL: none */
 void wo_sim_source_rates(wo_sim *s, double *rate, double *enthalpy);
 int wo_separator_enthalpies(const wo_eos *e, double pressure, double *hf, double *hg);
+/* air NCG thermodynamics, src/ncg_air_thermodynamics.F90 */
+int wo_air_properties(double partial_pressure, double t, double *rho, double *h);
+double wo_air_henrys_constant(double t);
+double wo_air_energy_solution(double t);
+double wo_air_mixture_viscosity(double water_viscosity, double t, double xg);
 /* salt thermodynamics, src/salt_thermodynamics.F90 (water side through e->thermo) */
 int wo_halite_solubility(double t, double *s);
 int wo_halite_solubility_two_phase(const wo_eos *e, double p, double *s);

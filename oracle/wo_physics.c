@@ -210,6 +210,72 @@ int wo_co2_viscosity(double partial_pressure, double t, double *visc) {
   return 0;
 }
 
+/* ---- air NCG thermodynamics: src/ncg_air_thermodynamics.F90 -------------------------------- */
+/* correlation data as held at :15-41 (Irvine & Liley 1984 enthalpy; D'Amore & Truesdell 1988,
+ * Cramer 1982, Cygan 1991 Henry's constants of N2 / O2; Hirschfelder et al. 1954 viscosity) */
+#define AIR_MW 28.96
+#define IS_WGE(e) ((e)->kind == WO_EOS_WCE || (e)->kind == WO_EOS_WAE)
+static const double AIR_ENTHALPY[4] = {1.20740, 9.24502, 0.115984, -5.63568e-4};
+static const double AIR_WEIGHT[2] = {0.79, 0.21};
+static const double AIR_HENRY_P0[2] = {1.01325e5, 1.e5};
+static const double AIR_HENRY[2][7] = {
+    {0.513726, 1.58603, -5.9378e-1, -6.98282e-1, 5.10330e-1, -1.21388e-1, 1.00041e-2},
+    {0.26234, 0.610628, 7.00732e-1, -0.139299e1, 7.13850e-1, -1.54216e-1, 1.23190e-2}};
+/* ncg_air_properties :90-114 */
+int wo_air_properties(double partial_pressure, double t, double *rho, double *h) {
+  double tk = t + TC_K;
+  double shift = horner(AIR_ENTHALPY, 4, (0.01 + TC_K) / 100.0); /* zero enthalpy at the triple point, :77-80 */
+  *rho = partial_pressure * AIR_MW / (1.e3 * GAS_CONSTANT * 1.0 * tk);
+  *h = 1.e4 * (horner(AIR_ENTHALPY, 4, tk / 100.0) - shift);
+  return 0;
+}
+/* ncg_air_henrys_constant :118-137 */
+static void air_henry_constituents(double t, double *hc) {
+  for (int i = 0; i < 2; i++) hc[i] = 1.e5 * AIR_HENRY_P0[i] * horner(AIR_HENRY[i], 7, t / 100.0);
+}
+double wo_air_henrys_constant(double t) {
+  double hc[2];
+  air_henry_constituents(t, hc);
+  return AIR_WEIGHT[0] * hc[0] + AIR_WEIGHT[1] * hc[1];
+}
+/* ncg_air_henrys_derivative :174-199 and the energy of solution (ncg_thermodynamics.F90:187-231) */
+double wo_air_energy_solution(double t) {
+  double hc[2], d = 0.0;
+  air_henry_constituents(t, hc);
+  for (int i = 0; i < 2; i++) {
+    double dc[6];
+    for (int k = 1; k < 7; k++) dc[k - 1] = k * AIR_HENRY[i][k]; /* polynomial_derivative */
+    double dhinv = 1.e5 * horner(dc, 6, t / 100.0);
+    d += AIR_WEIGHT[i] * (AIR_HENRY_P0[i] * dhinv / (hc[i] * 100.0));
+  }
+  double tk = t + TC_K;
+  return -1.e3 * GAS_CONSTANT * tk * tk * d / AIR_MW;
+}
+/* ncg_air_mixture_viscosity :260-338, gas phase (the liquid keeps the water viscosity) */
+static double air_covis(double trd, double c, double ome, double rm, double f) {
+  return 266.93e-7 * sqrt(rm * trd * f) / (c * c * ome * trd);
+}
+double wo_air_mixture_viscosity(double water_viscosity, double t, double xg) {
+  const double fair = 97.0, fwat = 363.0, cair = 3.617, cwat = 2.655;
+  const double fmix = sqrt(fair * fwat), cmix = 0.5 * (cair + cwat);
+  const double rm1 = AIR_MW, rm2 = WATER_MW;
+  double w = xg / rm1, x1 = w / (w + (1.0 - xg) / rm2), x2 = 1.0 - x1;
+  double tk = t + TC_K, trd1 = tk / fair, trd3 = tk / fmix;
+  double ome1 = (1.188 - 0.051 * trd1) / trd1;
+  double ome3 = (1.48 - 0.412 * log(trd3)) / trd3;
+  double ard = 1.095 / trd3;
+  double rm3 = 2.0 * rm1 * rm2 / (rm1 + rm2);
+  double vis1 = air_covis(trd1, cair, ome1, rm1, fair);
+  double vis2 = 10.0 * water_viscosity;
+  double vis3 = air_covis(trd3, cmix, ome3, rm3, fmix);
+  double z1 = x1 * x1 / vis1 + 2.0 * x2 * x1 / vis3 + x2 * x2 / vis2;
+  double g = x1 * x1 * rm1 / rm2, h = x2 * x2 * rm2 / rm1;
+  double ee = (2.0 * x1 * x2 * rm1 * rm2 / (rm3 * rm3)) * vis3 / (vis1 * vis2);
+  double z2 = 0.6 * ard * (g / vis1 + ee + h / vis2);
+  double z3 = 0.6 * ard * (g + ee * (vis1 + vis2) - 2.0 * x1 * x2 + h);
+  return 0.1 * (1.0 + z3) / (z1 + z2);
+}
+
 /* src/ncg_thermodynamics.F90:155-167 */
 double wo_ncg_mole_to_mass(double xmole, double mw) {
   double w = xmole * mw;
@@ -381,7 +447,7 @@ void wo_eos_init(wo_eos *e, int kind) {
     e->scale[1][0] = 1.e6; e->scale[1][1] = 1.e2;
     e->scale[2][0] = 1.e6; e->scale[2][1] = 1.e2;
     e->scale[4][0] = 1.e6; e->scale[4][1] = 1.0;
-    if (kind == WO_EOS_WCE) { e->np = 3; e->nc = 2; } /* scale[.][2] = 0: adaptive Pg/P */
+    if (kind == WO_EOS_WCE || kind == WO_EOS_WAE) { e->np = 3; e->nc = 2; } /* scale[.][2] = 0: adaptive Pg/P */
     if (kind == WO_EOS_WSE) { /* src/eos_wse.F90:123-165: solid third phase, regions 5, 6, 8 = 1, 2, 4 + halite */
       e->np = 3; e->nc = 2; e->nph = 3;
       for (int r = 1; r <= 8; r++) {
@@ -403,11 +469,11 @@ void wo_eos_init(wo_eos *e, int kind) {
 /* src/eos.F90:186-210 */
 void wo_eos_unscale(const wo_eos *e, const double *y, int region, double *primary) {
   for (int k = 0; k < e->np; k++) primary[k] = y[k] * e->scale[region][k];
-  if (e->kind == WO_EOS_WCE && e->scale[region][2] == 0.0) primary[2] = y[2] * primary[0]; /* eos_wge.F90:659-674 */
+  if (IS_WGE(e) && e->scale[region][2] == 0.0) primary[2] = y[2] * primary[0]; /* eos_wge.F90:659-674 */
 }
 void wo_eos_scale(const wo_eos *e, const double *primary, int region, double *y) {
   for (int k = 0; k < e->np; k++) y[k] = primary[k] / e->scale[region][k];
-  if (e->kind == WO_EOS_WCE && e->scale[region][2] == 0.0) y[2] = primary[2] / primary[0];   /* eos_wge.F90:639-655 */
+  if (IS_WGE(e) && e->scale[region][2] == 0.0) y[2] = primary[2] / primary[0];   /* eos_wge.F90:639-655 */
 }
 
 /* src/eos_we.F90:327-390 (we), src/eos_w.F90:126-147 (w); phase composition eos.F90:214-236 */
@@ -425,13 +491,13 @@ int wo_eos_bulk_properties(const wo_eos *e, const double *primary, double *fl) {
     return err;
   }
   if (e->kind == WO_EOS_WSE) return wse_bulk_properties(e, primary, fl);
-  if (e->kind == WO_EOS_WCE) { /* src/eos_wge.F90:350-389 */
+  if (IS_WGE(e)) { /* src/eos_wge.F90:350-389 */
     fl[F_PP] = fl[F_P] - primary[2];
     fl[F_PP + 1] = primary[2];
   }
   if (region == 4) {
     double t;
-    err = th_sat_temperature(e, e->kind == WO_EOS_WCE ? fl[F_PP] : fl[F_P], &t);
+    err = th_sat_temperature(e, IS_WGE(e) ? fl[F_PP] : fl[F_P], &t);
     if (err == 0) fl[F_T] = t;
   } else fl[F_T] = primary[1];
   if (err) return err;
@@ -445,7 +511,7 @@ int wo_eos_bulk_properties(const wo_eos *e, const double *primary, double *fl) {
   case 2: l[PH_SAT] = 0.0; v[PH_SAT] = 1.0; break;
   case 4: l[PH_SAT] = 1.0 - primary[1]; v[PH_SAT] = primary[1]; break;
   }
-  if (e->kind != WO_EOS_WCE) fl[F_PP] = fl[F_P];
+  if (!IS_WGE(e)) fl[F_PP] = fl[F_P];
   return 0;
 }
 
@@ -457,7 +523,9 @@ static int wce_phase_properties(const wo_eos *e, double *fl) {
   double rp[2];
   wo_relperm(e->rp_type, e->rp_par, sl, rp);
   double gas_rho, gas_h;
-  int err = wo_co2_properties(Pg, T, &gas_rho, &gas_h);
+  const int air = (e->kind == WO_EOS_WAE);
+  const double gas_mw = air ? AIR_MW : CO2_MW;
+  int err = air ? wo_air_properties(Pg, T, &gas_rho, &gas_h) : wo_co2_properties(Pg, T, &gas_rho, &gas_h);
   if (err) return err;
   for (int p = 0; p < e->nph; p++) {
     double *ph = fl + phase_off(e, p);
@@ -466,8 +534,8 @@ static int wce_phase_properties(const wo_eos *e, double *fl) {
       if (p == 0) {
         water_pressure = P;
         cap = wo_capillary(e->cp_type, e->cp_par, sl, T);
-        henry = wo_co2_henrys_constant(T);
-        esol = wo_co2_energy_solution(T);
+        henry = air ? wo_air_henrys_constant(T) : wo_co2_henrys_constant(T);
+        esol = air ? wo_air_energy_solution(T) : wo_co2_energy_solution(T);
       } else {
         water_pressure = Pw; cap = 0.0; henry = 0.0; esol = 0.0;
       }
@@ -476,13 +544,14 @@ static int wce_phase_properties(const wo_eos *e, double *fl) {
       if (err) return err;
       double grho = (p == 0) ? 0.0 : gas_rho; /* effective_properties: no free gas in liquid */
       double xg;
-      if (p == 0) xg = wo_ncg_mole_to_mass(Pg / henry, CO2_MW);
+      if (p == 0) xg = wo_ncg_mole_to_mass(Pg / henry, gas_mw);
       else {
         double tot = grho + wrho;
         xg = (tot < 1.e-30) ? 0.0 : grho / tot;
       }
       double wmu = th_viscosity(e, p == 0 ? 1 : 2, T, water_pressure, wrho), mu;
       if (p == 0) mu = wmu;
+      else if (air) mu = wo_air_mixture_viscosity(wmu, T, xg);
       else {
         double gmu;
         err = wo_co2_viscosity(Pg, T, &gmu);
@@ -519,7 +588,7 @@ int wo_eos_phase_properties(const wo_eos *e, const double *primary, double *fl) 
     ph[PH_MU] = th_viscosity(e, p == 1 ? 1 : 2, T, P, rho);
     return 0;
   }
-  if (e->kind == WO_EOS_WCE) return wce_phase_properties(e, fl);
+  if (IS_WGE(e)) return wce_phase_properties(e, fl);
   if (e->kind == WO_EOS_WSE) return wse_phase_properties(e, primary, fl);
   int phases = (int)lround(fl[F_PHASES]);
   double sl = fl[phase_off(e, 0) + PH_SAT];
@@ -567,7 +636,7 @@ int wo_eos_transition(const wo_eos *e, const double *oldp, double *prim, const d
   if (e->kind == WO_EOS_W) return 0;
   if (e->kind == WO_EOS_WSE) return wse_transition(e, oldp, prim, old_fluid, fluid, transition);
   const double small = 1.e-6;
-  const int wce = (e->kind == WO_EOS_WCE);
+  const int wce = IS_WGE(e);
   int old_region = (int)lround(old_fluid[F_REGION]);
   int err = 0;
   if (old_region == 4) {
@@ -639,7 +708,7 @@ int wo_eos_check_primary(const wo_eos *e, const double *fluid, double *prim, int
     } else if (prim[1] < 0.0 || prim[1] > 800.0) return 1;
     return 0;
   }
-  if (e->kind == WO_EOS_WCE) {
+  if (IS_WGE(e)) {
     const double small = 1.e-6;
     if (!(prim[0] > 0.0)) return 1;
     double maxpp = (1.0 - small) * prim[0];

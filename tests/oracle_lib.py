@@ -87,6 +87,8 @@ def load(path):
         "wo_sim_set_source_controls": (None, [C.c_void_p, C.c_void_p]),
         "wo_sim_source_rates": (None, [C.c_void_p, pd, pd]),
         "wo_separator_enthalpies": (i32, [C.c_void_p, C.c_double, pd, pd]),
+        "wo_air_properties": (i32, [d, d, pd, pd]), "wo_air_henrys_constant": (d, [d]),
+        "wo_air_energy_solution": (d, [d]), "wo_air_mixture_viscosity": (d, [d, d, d]),
         "wo_halite_solubility": (i32, [d, pd]), "wo_halite_properties": (i32, [d, d, pd, pd]),
         "wo_halite_solubility_two_phase": (i32, [C.c_void_p, d, pd]),
         "wo_brine_sat_pressure": (i32, [C.c_void_p, d, d, pd]), "wo_brine_sat_temperature": (i32, [C.c_void_p, d, d, pd]),
@@ -133,7 +135,7 @@ def load(path):
 class OracleSim:
     """Thin object wrapper over the oracle's wo_sim for the tests / cpu baseline."""
 
-    def __init__(self, L, mesh, eos_kind, thermo=0, relperm=None):
+    def __init__(self, L, mesh, eos_kind, thermo=0, relperm=None, capillary=None):
         self.L = L
         self.mesh = mesh
         self._keep = [f64(mesh.face_geom), f64(mesh.cell_geom), f64(mesh.rock), i32a(mesh.face_cells)]
@@ -146,6 +148,10 @@ class OracleSim:
             self.eos.rp_type = RP[relperm[0]]
             for k, v in enumerate(relperm[1]):
                 self.eos.rp_par[k] = v
+        if capillary is not None:
+            self.eos.cp_type = CP[capillary[0]]
+            for k, v in enumerate(capillary[1]):
+                self.eos.cp_par[k] = v
         self.np = self.eos.np
         self.df = self.eos.df
         self.n_owned, self.n_prim = mesh.n_owned, mesh.n_owned + mesh.n_halo

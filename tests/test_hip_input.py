@@ -167,3 +167,20 @@ def test_minc_zones_from_input_files(name, geometry, key):
     worst = B.field_errors(triple(out), fx, ("Pressure", "Temperature", "Vapour saturation"))
     assert max(v[0] for v in worst.values()) < 5.0e-3
     sim.ode.destroy()
+
+
+def test_air_benchmarks():
+    """eos wae on the HIP path: ncg/infiltration at its checkpoint times and ncg/heat_pipe at 1 and 10
+    years against AUTOUGH2"""
+    from tests.test_oracle_benchmark import air_errors
+    fx = B.load_fixture("benchmark_air.json")
+    sim, out = run("infiltration.json")
+    errs = air_errors(sim, fx["infiltration"])
+    assert sorted(errs) == [0.0, 864.0, 5184.0, 9504.0]
+    assert max(v[0] for e in errs.values() for v in e.values()) < 1.0e-4
+    sim.ode.destroy()
+    sim, out = run("heat_pipe.json")
+    errs = air_errors(sim, fx["heat_pipe"])
+    ends = [e for t, e in errs.items() if t > 3.0e8 or t < 4.0e7]
+    assert len(ends) >= 2 and max(v[0] for e in ends for v in e.values()) < 5.0e-3
+    sim.ode.destroy()

@@ -240,3 +240,24 @@ def test_failed_auxiliary_solve_retries_the_step():
     assert ts.history[-1][4] == 3 and np.isclose(ts.history[-1][1], 0.04)
     assert np.allclose(X, ode.initial / (1.0 + 0.04 * 5.0))
     assert np.allclose(y, ode.initial - 0.5 * 0.04)
+
+
+def test_output_checkpoints_shorten_the_step_and_restore_its_size():
+    """checkpoints (timestepper.F90:863-968, 1278-1301): a step that would reach the checkpoint time
+    (within tolerance x step size) is shortened onto it, flagged, and the size in force before is
+    restored afterwards without consulting the adaptor"""
+    ode = linear()
+    y = ode.initial.copy()
+    ts = Timestepper(ode, y, stepsize=0.3, stop_time=3.0, max_num_steps=1000, checkpoints=[1.0, 2.0],
+                     checkpoint_tolerance=0.1)
+    hits = []
+    while not ts.finished:
+        ts.step()
+        if ts.checkpoint_hit:
+            hits.append(ts.time)
+            ts.checkpoint_update()
+    times = [round(h[0], 10) for h in ts.history]
+    assert hits == [1.0, 2.0]
+    assert times[:5] == [0.3, 0.6, 0.9, 1.0, 1.3]                 # 0.9 + 0.3 + 0.03 >= 1.0: shortened to 0.1
+    assert np.isclose(ts.history[3][1], 0.1) and np.isclose(ts.history[4][1], 0.3)   # restored
+    assert 2.0 in times and times[-1] == 3.0

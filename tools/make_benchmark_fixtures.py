@@ -294,6 +294,8 @@ def input_files():
              (REF, "tracer/oned/run/oned_two_phase.json"), (REF, "tracer/oned/run/oned_two_phase_ss.json"),
              (REF, "tracer/oned/run/oned_two_phase_ss.h5"), (REF, "tracer/oned/run/oned_single_phase.json"),
              (REF, "tracer/oned/run/oned_single_phase_ss.h5"), (REF, "tracer/oned/run/goned.msh"),
+             (REF, "ncg/heat_pipe/run/heat_pipe.json"), (REF, "ncg/heat_pipe/run/gheat_pipe.msh"),
+             (REF, "ncg/infiltration/run/infiltration.json"), (REF, "ncg/infiltration/run/ginfiltration.msh"),
              (REF, "salt/column/run/salt_column.json"), (REF, "salt/column/run/gsalt_column.msh"),
              (REF, "salt/production/run/salt_production.json"), (REF, "salt/production/run/gsalt_production.msh"),
              (REF, "minc/column/run/minc_column_minc.json"), (REF, "minc/column/run/minc_column_single.json"),
@@ -354,6 +356,42 @@ def source_controls():
             "source_history": {k: [tab[k][0] for _, tab in gen] for k in ("Generation rate", "Enthalpy")},
             "final": {k: elem[-1][1][k][:n] for k in fields}}
     json.dump(out, open(os.path.join(OUT, "benchmark_source_controls.json"), "w"), indent=1)
+
+
+def wide_tables(listing, names):
+    """every ELEMENT TABLE of a listing with 13-character columns whose names are cut off: rows of
+    numbers by position -> [(time, {name: column})]"""
+    lines = open(listing, errors="replace").read().split("\n")
+    out, time = [], None
+    for i, l in enumerate(lines):
+        m = re.search(r"OUTPUT AFTER\s+\d+ TIME STEPS\s+([-+0-9.E]+) SECONDS", l)
+        if m:
+            time = float(m.group(1))
+        if "ELEMENT TABLE" in l:
+            rows = []
+            for r in lines[i + 3:]:
+                nums = re.findall(r"[-+]?\d\.\d+E[-+]\d+", r)
+                if rows and not nums:
+                    break
+                if nums:
+                    rows.append([float(v) for v in nums])
+            out.append((time, {nm: [r[k] for r in rows] for k, nm in enumerate(names)}))
+    return out
+
+
+def air():
+    """test/benchmark/ncg/heat_pipe (radial heat pipe, eos wae, van Genuchten curves, 10 years) and
+    ncg/infiltration (water infiltrating a partially saturated column, eos wae): AUTOUGH2 (EOS3)
+    tables at every output time"""
+    names = ["Pressure", "Temperature", "Vapour saturation", "Vapour air mass fraction", "Liquid air mass fraction",
+             "Air partial pressure", "Capillary pressure", "Vapour density", "Liquid density"]
+    out = {"source": "test/benchmark/ncg/{heat_pipe,infiltration}/run/*.listing; inputs are tests/golden/inputs/"}
+    for name, n in (("heat_pipe", 120), ("infiltration", 40)):
+        tabs = wide_tables(os.path.join(REF, "ncg", name, "run", name + ".listing"), names)
+        keep = ("Pressure", "Temperature", "Vapour saturation", "Vapour air mass fraction", "Air partial pressure")
+        # the boundary block comes last in these listings
+        out[name] = [{"time": t, **{k: tab[k][:n] for k in keep}} for t, tab in tabs]
+    json.dump(out, open(os.path.join(OUT, "benchmark_air.json"), "w"), indent=1)
 
 
 def salt():
@@ -451,6 +489,7 @@ def tracer_doublet():
 
 
 if __name__ == "__main__":
+    air()
     salt()
     minc_column_and_3d()
     problem6()

@@ -536,6 +536,7 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
   else if (c->kind == WAI_EOS_WE) { c->np = 2; c->df = 23; }
   else if (c->kind == WAI_EOS_WCE) { c->np = 3; c->df = 26; }
   else if (c->kind == WAI_EOS_WSE) { c->np = 3; c->df = 35; }
+  else if (c->kind == WAI_EOS_WAE) { c->np = 3; c->df = 26; }
   else { c->err = "unsupported eos kind"; return -2; }
   std::memset(&c->ep, 0, sizeof(c->ep));
   c->ep.temperature = ed->temperature;

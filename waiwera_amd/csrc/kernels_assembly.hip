@@ -649,6 +649,7 @@ static inline int grid8_for(size_t n) { return ((grid_for(n) + 7) / 8) * 8; }  /
     if ((c)->kind == EOS_W) hipLaunchKernelGGL(KERNEL<EOS_W>, grid, TPB, 0, (c)->stream, __VA_ARGS__);        \
     else if ((c)->kind == EOS_WE) hipLaunchKernelGGL(KERNEL<EOS_WE>, grid, TPB, 0, (c)->stream, __VA_ARGS__); \
     else if ((c)->kind == EOS_WSE) hipLaunchKernelGGL(KERNEL<EOS_WSE>, grid, TPB, 0, (c)->stream, __VA_ARGS__); \
+    else if ((c)->kind == EOS_WAE) hipLaunchKernelGGL(KERNEL<EOS_WAE>, grid, TPB, 0, (c)->stream, __VA_ARGS__); \
     else hipLaunchKernelGGL(KERNEL<EOS_WCE>, grid, TPB, 0, (c)->stream, __VA_ARGS__);                         \
   } while (0)
 

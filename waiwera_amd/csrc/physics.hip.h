@@ -17,7 +17,9 @@
 
 namespace wai {
 
-enum { EOS_W = 0, EOS_WE = 1, EOS_WCE = 2, EOS_WSE = 3 };
+enum { EOS_W = 0, EOS_WE = 1, EOS_WCE = 2, EOS_WSE = 3, EOS_WAE = 4 };
+// water + non-condensible gas + energy (eos_wge.F90): CO2 (eos_wce.F90) or air (eos_wae.F90)
+template <int KIND> constexpr bool is_wge = (KIND == EOS_WCE || KIND == EOS_WAE);
 enum { RP_FULLY_MOBILE = 0, RP_LINEAR = 1, RP_PICKENS = 2, RP_COREY = 3, RP_GRANT = 4,
        RP_VAN_GENUCHTEN = 5 };
 enum { CP_ZERO = 0, CP_LINEAR = 1, CP_VAN_GENUCHTEN = 2 };
@@ -43,6 +45,10 @@ template <> struct EosT<EOS_WCE> {  // water + CO2 + energy (eos_wge.F90 + eos_w
   static constexpr bool isothermal = false;
 };
 
+template <> struct EosT<EOS_WAE> {  // water + air + energy (eos_wge.F90 + eos_wae.F90)
+  static constexpr int np = 3, nc = 2, nph = 2, nmob = 2, df = 26, f_phase0 = 8, ph_dof = 9;
+  static constexpr bool isothermal = false;
+};
 template <> struct EosT<EOS_WSE> {  // water + salt + energy (eos_wse.F90): third phase = solid halite, immobile
   static constexpr int np = 3, nc = 2, nph = 3, nmob = 2, df = 35, f_phase0 = 8, ph_dof = 9;
   static constexpr bool isothermal = false;
@@ -207,20 +213,89 @@ __device__ __forceinline__ double mole_to_mass(double xmole) {
 }
 }  // namespace co2
 
+// air NCG thermodynamics (ncg_air_thermodynamics.F90; correlation data as held at :15-41:
+// Irvine & Liley 1984 enthalpy; D'Amore & Truesdell 1988 / Cramer 1982 / Cygan 1991 Henry's
+// constants of N2 and O2; Hirschfelder et al. 1954 mixture viscosity)
+namespace air {
+constexpr double MW = 28.96, WATER_MW = 18.01528, GAS_CONSTANT = 8.3144598;
+__device__ __forceinline__ double horner4(const double* a, double x) { return a[0] + x * (a[1] + x * (a[2] + x * a[3])); }
+__device__ __forceinline__ void properties(double partial_pressure, double t, double& rho, double& h) {   // :90-114
+  const double c[4] = {1.20740, 9.24502, 0.115984, -5.63568e-4};
+  const double tk = t + if97::TC_K;
+  const double shift = horner4(c, (0.01 + if97::TC_K) / 100.0);   // zero at the triple point of water, :77-80
+  rho = partial_pressure * MW / (1.e3 * GAS_CONSTANT * 1.0 * tk);
+  h = 1.e4 * (horner4(c, tk / 100.0) - shift);
+}
+__device__ __forceinline__ void henry_constituents(double t, double* hc, double* dhinv) {
+  const double p0[2] = {1.01325e5, 1.e5};
+  const double a[2][7] = {{0.513726, 1.58603, -5.9378e-1, -6.98282e-1, 5.10330e-1, -1.21388e-1, 1.00041e-2},
+                          {0.26234, 0.610628, 7.00732e-1, -0.139299e1, 7.13850e-1, -1.54216e-1, 1.23190e-2}};
+  const double x = t / 100.0;
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    double p = a[i][6], d = 6.0 * a[i][6];
+#pragma unroll
+    for (int k = 5; k >= 0; k--) p = a[i][k] + x * p;
+#pragma unroll
+    for (int k = 5; k >= 1; k--) d = k * a[i][k] + x * d;          // polynomial_derivative, Horner
+    hc[i] = 1.e5 * p0[i] * p;
+    dhinv[i] = p0[i] * (1.e5 * d) / (hc[i] * 100.0);
+  }
+}
+__device__ __forceinline__ double henrys_constant(double t) {      // :118-137
+  double hc[2], d[2];
+  henry_constituents(t, hc, d);
+  return 0.79 * hc[0] + 0.21 * hc[1];
+}
+__device__ __forceinline__ double energy_solution(double t) {      // :174-199, ncg_thermodynamics.F90:187-231
+  double hc[2], d[2];
+  henry_constituents(t, hc, d);
+  const double tk = t + if97::TC_K;
+  return -1.e3 * GAS_CONSTANT * tk * tk * (0.79 * d[0] + 0.21 * d[1]) / MW;
+}
+__device__ __forceinline__ double mole_to_mass(double xmole) {
+  const double w = xmole * MW;
+  return w / (w + (1.0 - xmole) * WATER_MW);
+}
+__device__ __forceinline__ double covis(double trd, double c, double ome, double rm, double f) {
+  return 266.93e-7 * sqrt(rm * trd * f) / (c * c * ome * trd);
+}
+__device__ inline double mixture_viscosity(double water_viscosity, double t, double xg) {   // :260-338, gas phase
+  const double fair = 97.0, fwat = 363.0, cair = 3.617, cwat = 2.655;
+  const double fmix = sqrt(fair * fwat), cmix = 0.5 * (cair + cwat);
+  const double rm1 = MW, rm2 = WATER_MW;
+  const double w = xg / rm1, x1 = w / (w + (1.0 - xg) / rm2), x2 = 1.0 - x1;
+  const double tk = t + if97::TC_K, trd1 = tk / fair, trd3 = tk / fmix;
+  const double ome1 = (1.188 - 0.051 * trd1) / trd1;
+  const double ome3 = (1.48 - 0.412 * log(trd3)) / trd3;
+  const double ard = 1.095 / trd3;
+  const double rm3 = 2.0 * rm1 * rm2 / (rm1 + rm2);
+  const double vis1 = covis(trd1, cair, ome1, rm1, fair);
+  const double vis2 = 10.0 * water_viscosity;
+  const double vis3 = covis(trd3, cmix, ome3, rm3, fmix);
+  const double z1 = x1 * x1 / vis1 + 2.0 * x2 * x1 / vis3 + x2 * x2 / vis2;
+  const double g = x1 * x1 * rm1 / rm2, h = x2 * x2 * rm2 / rm1;
+  const double ee = (2.0 * x1 * x2 * rm1 * rm2 / (rm3 * rm3)) * vis3 / (vis1 * vis2);
+  const double z2 = 0.6 * ard * (g / vis1 + ee + h / vis2);
+  const double z3 = 0.6 * ard * (g + ee * (vis1 + vis2) - 2.0 * x1 * x2 + h);
+  return 0.1 * (1.0 + z3) / (z1 + z2);
+}
+}  // namespace air
+
 // eos%unscale / eos%scale (eos.F90:186-210; adaptive third variable eos_wge.F90:639-674)
 template <int KIND>
 __device__ __forceinline__ void eos_unscale(const EosParams& e, const double* y, int region, double* prim) {
   using E = EosT<KIND>;
 #pragma unroll
   for (int k = 0; k < E::np; k++) prim[k] = y[k] * e.scale[region][k];
-  if constexpr (KIND == EOS_WCE) { if (e.scale[region][2] == 0.0) prim[2] = y[2] * prim[0]; }
+  if constexpr (is_wge<KIND>) { if (e.scale[region][2] == 0.0) prim[2] = y[2] * prim[0]; }
 }
 template <int KIND>
 __device__ __forceinline__ void eos_scale(const EosParams& e, const double* prim, int region, double* y) {
   using E = EosT<KIND>;
 #pragma unroll
   for (int k = 0; k < E::np; k++) y[k] = prim[k] / e.scale[region][k];
-  if constexpr (KIND == EOS_WCE) { if (e.scale[region][2] == 0.0) y[2] = prim[2] / prim[0]; }
+  if constexpr (is_wge<KIND>) { if (e.scale[region][2] == 0.0) y[2] = prim[2] / prim[0]; }
 }
 
 // eos_wse: mixture region -> water region / halite presence (eos_wse.F90:131-134)
@@ -318,7 +393,8 @@ __device__ __forceinline__ int eos_eval(const EosParams& e, const double* y, int
       s.rho[2] = 0.0; s.u[2] = 0.0; s.h[2] = 0.0; s.x[2][0] = 0.0; s.x[2][1] = 0.0;
     }
     return 0;
-  } else if constexpr (KIND == EOS_WCE) {
+  } else if constexpr (is_wge<KIND>) {
+    constexpr bool air_gas = (KIND == EOS_WAE);
     // eos_wge_bulk_properties / phase_properties (eos_wge.F90:350-543) with CO2 (eos_wce.F90)
     double prim[3];
     eos_unscale<KIND>(e, y, region, prim);
@@ -339,7 +415,8 @@ __device__ __forceinline__ int eos_eval(const EosParams& e, const double* y, int
     double kl, kv;
     relperm(e, s.sat[0], kl, kv);
     double gas_rho, gas_h;
-    co2::properties(Pg, s.T, gas_rho, gas_h);
+    if constexpr (air_gas) air::properties(Pg, s.T, gas_rho, gas_h);
+    else co2::properties(Pg, s.T, gas_rho, gas_h);
 #pragma unroll
     for (int p = 0; p < 2; p++) {
       if (ph & (1 << p)) {
@@ -350,8 +427,13 @@ __device__ __forceinline__ int eos_eval(const EosParams& e, const double* y, int
         const double grho = (p == 0) ? 0.0 : gas_rho;
         double xg, esol = 0.0;
         if (p == 0) {
-          xg = co2::mole_to_mass(Pg / co2::henrys_constant(s.T));
-          esol = co2::energy_solution(s.T);
+          if constexpr (air_gas) {
+            xg = air::mole_to_mass(Pg / air::henrys_constant(s.T));
+            esol = air::energy_solution(s.T);
+          } else {
+            xg = co2::mole_to_mass(Pg / co2::henrys_constant(s.T));
+            esol = co2::energy_solution(s.T);
+          }
         } else {
           const double tot = grho + wrho;
           xg = (tot < 1.e-30) ? 0.0 : grho / tot;
@@ -359,9 +441,12 @@ __device__ __forceinline__ int eos_eval(const EosParams& e, const double* y, int
         const double wmu = th::viscosity(e.thermo, p == 0 ? 1 : 2, s.T, wpres, wrho);
         double mu = wmu;
         if (p == 1) {
-          double gmu;
-          if (co2::viscosity(Pg, s.T, gmu)) return 1;
-          mu = wmu * (1.0 - xg) + gmu * xg;
+          if constexpr (air_gas) mu = air::mixture_viscosity(wmu, s.T, xg);
+          else {
+            double gmu;
+            if (co2::viscosity(Pg, s.T, gmu)) return 1;
+            mu = wmu * (1.0 - xg) + gmu * xg;
+          }
         }
         s.mu[p] = mu;
         s.rho[p] = wrho + grho;
@@ -772,7 +857,7 @@ __device__ inline int eos_transition(int thermo, const double* oldp, double* pri
     (void)thermo; (void)oldp; (void)old_region; (void)old_temperature; (void)region;
     return 0;
   } else {
-    constexpr bool wce = (KIND == EOS_WCE);
+    constexpr bool wce = is_wge<KIND>;
     constexpr int ig_ = wce ? 2 : 0;
     const double small = 1.e-6;
     if (old_region == 4) {
@@ -961,7 +1046,7 @@ __device__ __forceinline__ int eos_check_primary(double* prim, int region, bool&
     else if (prim[1] < 0.0 || prim[1] > 800.0) return 1;
     return 0;
   }
-  if constexpr (KIND == EOS_WCE) {
+  if constexpr (is_wge<KIND>) {
     const double small = 1.e-6;
     if (!(prim[0] > 0.0)) return 1;
     const double maxpp = (1.0 - small) * prim[0];

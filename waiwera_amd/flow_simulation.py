@@ -146,7 +146,7 @@ class FlowSimulation:
                 sc[r, 1] = ts if r not in (4, 8) else 1.0
         prim = np.asarray(primary, dtype=np.float64)
         out = prim / sc[np.asarray(region)]
-        if self.eos_name == "wce" and self.eos_desc.partial_pressure_scale <= 0:
+        if self.eos_name in ("wce", "wae") and self.eos_desc.partial_pressure_scale <= 0:
             out[..., 2] = prim[..., 2] / prim[..., 0]  # adaptive Pg / P (eos_wge.F90:639-655)
         return out
 

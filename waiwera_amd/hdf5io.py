@@ -138,7 +138,7 @@ def read_state(path, index=-1):
     ci = read_dataset(path, "/cell_index").ravel()
     out = {"time": float(t[k])}
     for name in ("fluid_pressure", "fluid_temperature", "fluid_vapour_saturation", "fluid_region",
-                 "fluid_CO2_partial_pressure", "fluid_liquid_salt_mass_fraction", "fluid_solid_saturation"):
+                 "fluid_CO2_partial_pressure", "fluid_air_partial_pressure", "fluid_liquid_salt_mass_fraction", "fluid_solid_saturation"):
         if has_dataset(path, "/cell_fields/" + name):
             out[name] = read_dataset(path, "/cell_fields/" + name)[k][ci]
     return out

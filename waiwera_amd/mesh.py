@@ -678,7 +678,7 @@ def benchmark_initial_state(grid, ijk, eos="we", lens=True):
     if eos == "w":
         return P[:, None].copy(), region
     second = T.copy()
-    if eos == "wce":
+    if eos in ("wce", "wae"):
         # CO2 partial pressure 2 % of the total pressure
         return np.stack([P, second, 0.02 * P], axis=1), region
     if eos == "wse":

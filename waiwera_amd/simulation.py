@@ -153,7 +153,7 @@ class Simulation:
         temperature = eos.get("temperature", 20.0) if isinstance(eos, dict) else 20.0
         th = inp.get("thermodynamics", "iapws")
         self.thermo = (th.get("name", "iapws") if isinstance(th, dict) else th).lower()
-        if self.eos not in ("w", "we", "wce", "wse") or self.thermo not in ("iapws", "ifc67"):
+        if self.eos not in ("w", "we", "wce", "wse", "wae") or self.thermo not in ("iapws", "ifc67"):
             raise NotImplementedError("eos %r / thermodynamics %r" % (self.eos, self.thermo))
         # geometry first without rock (centroids are needed for zones), rock filled in below
         bnds = []
@@ -252,7 +252,7 @@ class Simulation:
         self.capillary = capillary_spec(rock.get("capillary_pressure"))
         # initial conditions
         init = inp.get("initial", {}) or {}
-        npv = {"w": 1, "we": 2, "wce": 3, "wse": 3}[self.eos]
+        npv = {"w": 1, "we": 2, "wce": 3, "wse": 3, "wae": 3}[self.eos]
         if "filename" in init:
             # restart from a Waiwera HDF5 output (setup_initial, src/initial.F90:421-677, 776, 922):
             # primaries of each cell from its fluid fields by region (eos%primary_variables)
@@ -267,7 +267,7 @@ class Simulation:
                 cols[1] = np.where(np.isin(region, (4, 8)), st["fluid_vapour_saturation"], st["fluid_temperature"])
                 cols.append(np.where(halite, st["fluid_solid_saturation"], st["fluid_liquid_salt_mass_fraction"]))
             elif npv > 2:
-                cols.append(st["fluid_CO2_partial_pressure"])
+                cols.append(st["fluid_CO2_partial_pressure" if self.eos == "wce" else "fluid_air_partial_pressure"])
             prim = np.stack(cols, axis=1)
             if prim.shape[0] != n and not (self._order is not None and prim.shape[0] == lm.n_owned):
                 raise ValueError("initial conditions file has %d cells, mesh has %d" % (prim.shape[0], n))
@@ -360,7 +360,11 @@ class Simulation:
             adapt_max=ad.get("maximum", 8.0), reduction=ad.get("reduction", 0.2),
             amplification=ad.get("amplification", 2.0), max_stepsize=mx.get("size") or 0.0,
             max_num_tries=_get(step, "maximum.tries", 10), stop_time=_get(inp, "time.stop"),
-            max_num_steps=mx.get("number") if mx.get("number") is not None else 100, aux_solution=self.X)
+            max_num_steps=mx.get("number") if mx.get("number") is not None else 100, aux_solution=self.X,
+            checkpoints=_get(inp, "output.checkpoint.time"),
+            checkpoint_tolerance=_get(inp, "output.checkpoint.tolerance", 0.1))
+        if _get(inp, "output.checkpoint.repeat") not in (None, False, 1):
+            raise NotImplementedError("repeated output checkpoints")
 
         self._setup_source_controls(inp.get("source", []) or [], _get(inp, "time.start", 0.0))
         if self._tables or self._ctl_tables or getattr(self, "_tracer_tables", None):
@@ -393,7 +397,7 @@ class Simulation:
                 fl = np.asarray(self.ode.fluid())
             return fl[cell]
 
-        nc = {"w": 1, "we": 1, "wce": 2, "wse": 2}[self.eos]
+        nc = {"w": 1, "we": 1, "wce": 2, "wse": 2, "wae": 2}[self.eos]
         f0, pd = 6 + nc, 7 + nc
 
         def mobility_sum(f):
@@ -499,8 +503,11 @@ class Simulation:
             self.outputs.append(self.fields())
         while not self.ts.finished:
             self.ts.step()
-            if (freq and self.ts.taken % freq == 0) or (self.ts.finished and oc.get("final", True)):
+            hit = self.ts.checkpoint_hit
+            if hit or (freq and self.ts.taken % freq == 0) or (self.ts.finished and oc.get("final", True)):
                 self.outputs.append(self.fields())
+            if hit:
+                self.ts.checkpoint_update()
         out = self.fields()
         if oc.get("filename"):
             try:
@@ -534,7 +541,7 @@ class Simulation:
         geom = self.mesh.cell_geom[:n]
         if self._order is not None:      # MINC: the reference's cell order (original cells, then level by level)
             fl, geom = fl[self._order], geom[self._order]
-        nc = {"w": 1, "we": 1, "wce": 2, "wse": 2}[self.eos]
+        nc = {"w": 1, "we": 1, "wce": 2, "wse": 2, "wae": 2}[self.eos]
         f0, pd = 6 + nc, 7 + nc
         out = {"time": self.ts.time, "fluid_pressure": fl[:, 0].copy(), "fluid_temperature": fl[:, 1].copy(),
                "fluid_region": fl[:, 2].copy(), "fluid_liquid_saturation": fl[:, f0 + 2].copy(),
@@ -547,10 +554,11 @@ class Simulation:
         if self.eos == "wse":
             out["fluid_liquid_salt_mass_fraction"] = fl[:, f0 + 8].copy()
             out["fluid_solid_saturation"] = fl[:, f0 + 2 * pd + 2].copy()
-        if self.eos == "wce":
-            out["fluid_CO2_partial_pressure"] = fl[:, 7].copy()
-            out["fluid_liquid_CO2_mass_fraction"] = fl[:, f0 + 8].copy()
-            out["fluid_vapour_CO2_mass_fraction"] = fl[:, f0 + pd + 8].copy()
+        if self.eos in ("wce", "wae"):
+            gas = "CO2" if self.eos == "wce" else "air"
+            out["fluid_%s_partial_pressure" % gas] = fl[:, 7].copy()
+            out["fluid_liquid_%s_mass_fraction" % gas] = fl[:, f0 + 8].copy()
+            out["fluid_vapour_%s_mass_fraction" % gas] = fl[:, f0 + pd + 8].copy()
         if self.X is not None:
             for k, name in enumerate(self.tracer_names):
                 xk = self.X.reshape(n, -1)[:, k]

@@ -21,9 +21,9 @@ Checkpoints and output scheduling stay out of scope.
 """
 
 # step status, timestepper.F90:40-42
-OK, NOT_CONVERGED, TOO_SMALL, TOO_BIG, ABORTED, FINAL, AUX_NOT_CONVERGED = 0, 1, 2, 3, 4, 5, 6
+OK, NOT_CONVERGED, TOO_SMALL, TOO_BIG, ABORTED, FINAL, AUX_NOT_CONVERGED, RESTORE = 0, 1, 2, 3, 4, 5, 6, 7
 STATUS_STR = {OK: "OK", NOT_CONVERGED: "not converged", TOO_SMALL: "increase", TOO_BIG: "reduce",
-              ABORTED: "aborted", FINAL: "final", AUX_NOT_CONVERGED: "aux not converged"}
+              ABORTED: "aborted", FINAL: "final", AUX_NOT_CONVERGED: "aux not converged", RESTORE: "restore"}
 
 
 class StepFailed(RuntimeError):
@@ -61,7 +61,8 @@ class Timestepper:
     def __init__(self, ode, y, time=0.0, stepsize=0.1, method="beuler", adapt=False,
                  adapt_method="iteration", adapt_min=5.0, adapt_max=8.0, reduction=0.2,
                  amplification=2.0, max_stepsize=0.0, max_num_tries=10, stop_time=None,
-                 max_num_steps=100, stop_min_stepsize=-1.0, stop_max_stepsize=-1.0, aux_solution=None):
+                 max_num_steps=100, stop_min_stepsize=-1.0, stop_max_stepsize=-1.0, aux_solution=None,
+                 checkpoints=None, checkpoint_tolerance=0.1):
         self.ode = ode
         self.y = y              # numpy array or torch tensor, scaled primaries, in/out
         self.time = time
@@ -79,6 +80,11 @@ class Timestepper:
         self.stop_min_stepsize = stop_min_stepsize
         self.stop_max_stepsize = stop_max_stepsize
         self.termination_tol = 1.0e-3
+        # output checkpoints (timestepper_checkpoints_type :95-113, :863-968): times the steps are
+        # shortened to land on; the step size in force is restored afterwards
+        self.checkpoints = sorted(float(t) for t in (checkpoints or []))
+        self.checkpoint_tol = max(checkpoint_tolerance, 1.0e-6)
+        self.checkpoint_index, self.checkpoint_hit, self._restore_stepsize = 0, False, None
         # callable(interval) run before each try: time-dependent controls averaged over the step
         # interval [t, t + dt] (the interval argument of the reference's lhs / rhs calls,
         # src/timestepper.F90 ode%rhs(t, interval, ...); src/flow_simulation.F90:1469)
@@ -127,6 +133,23 @@ class Timestepper:
             self.finished = True
         return stepsize
 
+    def _check_checkpoints(self, stepsize):
+        """check_checkpoints (:1278-1301): shorten the step onto the next checkpoint time"""
+        self.checkpoint_hit = False
+        if self.steady_state or self.checkpoint_index >= len(self.checkpoints):
+            return stepsize
+        nxt = self.checkpoints[self.checkpoint_index]
+        if self.time + stepsize + self.checkpoint_tol * stepsize >= nxt:
+            self.checkpoint_hit = True
+            self._restore_stepsize = stepsize
+            return nxt - self.time
+        return stepsize
+
+    def checkpoint_update(self):
+        """checkpoints%update (:915-945) after the checkpoint's output (no repeats)"""
+        self.checkpoint_index += 1
+        self.checkpoint_hit = False
+
     def _monitor(self, nits):
         if self.adaptor.method == "iteration":
             return float(nits)           # iteration_monitor :277-284
@@ -162,6 +185,9 @@ class Timestepper:
             if self.finished and self.status != ABORTED:
                 self.status = FINAL
                 return
+            if self.checkpoint_hit:
+                self.status = RESTORE
+                return
             if self.adaptor.on or (self.fixed_step_index == len(self.sizes) and not self.fixed):
                 eta = self._monitor(nits)
                 if eta < self.adaptor.monitor_min:
@@ -175,8 +201,10 @@ class Timestepper:
         elif tries >= self.max_num_tries:
             self.status = ABORTED
             self.finished = True
+            self.checkpoint_hit = False
         else:
             self.status = NOT_CONVERGED
+            self.checkpoint_hit = False
             self.finished = False
 
     def _adapt(self, stepsize):
@@ -201,6 +229,9 @@ class Timestepper:
     def _set_next_stepsize(self, stepsize):
         """set_next_stepsize (:1412-1453)."""
         if self.steady_state:
+            return True
+        if self.checkpoint_hit and self.status == RESTORE:      # :1400-1401, :1423-1425
+            self.next_stepsize = self._restore_stepsize
             return True
         if self.adaptor.on:
             accepted, nxt = self._adapt(stepsize)
@@ -234,7 +265,7 @@ class Timestepper:
             if tries > 0:
                 ode.pre_retry_timestep()
                 self.y[...] = y_start
-            stepsize = self._check_finished(self.next_stepsize)
+            stepsize = self._check_finished(self._check_checkpoints(self.next_stepsize))
             if self.controls is not None:
                 t1 = self.time + stepsize     # direct steady state: [t, t] at the new time (:446)
                 self.controls((t1 if self.steady_state else self.time, t1))
