@@ -8,7 +8,7 @@ src/timestepper.F90:1960-2275; src/tracer.F90:63-140; utils/input_schema.json):
 
   mesh        filename (gmsh MSH 2.2), thickness, radial, zones (all / box ranges on x, y, z)
   gravity     number | vector | null
-  eos         name w | we | wce, temperature
+  eos         name w | we | wce | wae | wse, temperature
   thermodynamics  iapws | ifc67
   rock        types [cells | zones, permeability, porosity, density, specific_heat, wet / dry
               conductivity], relative_permeability, capillary_pressure
@@ -24,7 +24,8 @@ src/timestepper.F90:1960-2275; src/tracer.F90:63-140; utils/input_schema.json):
   time        start, stop, step {size, adapt, maximum, method, solver.nonlinear, solver.linear}
   tracer      name, phase, decay, activation, diffusion
 
-  output      filename, initial, final, frequency (cell fields, source rate and enthalpy)
+  output      filename, initial, final, frequency, checkpoint {time, tolerance} (cell fields, source
+              rate and enthalpy)
 
 Anything else that changes results (source groups, reinjectors, rock controls, ...) raises
 NotImplementedError instead of being ignored.  Output: `Simulation.run` returns the final cell
