@@ -73,6 +73,9 @@ typedef struct wai_eos_desc {
                                     Pg / P (the reference default, src/eos_wge.F90:95-104) */
   int thermo;                /* "thermodynamics": WAI_THERMO_IAPWS (default, src/IAPWS.F90) |
                                 WAI_THERMO_IFC67 (src/IFC67.F90); src/thermodynamics_setup.F90 */
+  int perm_type;             /* eos wse "eos.permeability_modifier.type": 0 none, 1 power, 2 Verma-Pruess */
+  double perm_par[3];        /* exponent, phir, gamma (src/fluid.F90:601-664): the factor the face
+                                permeabilities of a cell are multiplied by as halite fills its pores */
 } wai_eos_desc;
 
 /* "time.step.solver.*" keys: src/timestepper.F90:1567-1573,1645-1720,1998-2020 */

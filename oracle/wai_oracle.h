@@ -78,7 +78,10 @@ typedef struct wo_eos {
   int rp_type, cp_type;
   double rp_par[6], cp_par[6];
   int thermo;                  /* "thermodynamics": 0 IAPWS-97 (default), 1 IFC-67 */
+  int perm_type;               /* eos wse permeability modifier: 0 none, 1 power, 2 Verma-Pruess */
+  double perm_par[3];          /* exponent, phir, gamma (src/fluid.F90:601-664) */
 } wo_eos;
+double wo_permeability_factor(const wo_eos *e, double pore_fraction);
 void wo_eos_init(wo_eos *e, int kind);
 void wo_eos_unscale(const wo_eos *e, const double *y, int region, double *primary);
 void wo_eos_scale(const wo_eos *e, const double *primary, int region, double *y);

@@ -1015,8 +1015,20 @@ int wo_brine_viscosity(const wo_eos *e, double t, double p, double xs, double *m
 }
 
 /* ==== eos_wse: water, salt, energy (src/eos_wse.F90) ======================================== */
-/* bulk properties :645-688, phase saturations :692-726 (permeability modifier "none": factor 1,
- * src/fluid.F90:588-596) */
+/* fluid_permeability_factor_{null,power,verma_pruess}_modify: src/fluid.F90:588-664 */
+double wo_permeability_factor(const wo_eos *e, double pf) {
+  if (e->perm_type == 1) return pow(pf, e->perm_par[0]);
+  if (e->perm_type == 2) {
+    double n = e->perm_par[0], phir = e->perm_par[1], gamma = e->perm_par[2];
+    double omega = 1.0 + (1.0 / (gamma * (1.0 / phir - 1.0)));
+    double theta = (pf - phir) / (1.0 - phir);
+    return pow(theta, n) * (1.0 - gamma + gamma / pow(omega, n)) /
+           (1.0 - gamma + gamma * pow(theta / (theta + omega - 1.0), n));
+  }
+  return 1.0;
+}
+
+/* bulk properties :645-688, phase saturations :692-726 */
 static int wse_bulk_properties(const wo_eos *e, const double *primary, double *fl) {
   int region = (int)lround(fl[F_REGION]);
   int wr = WSE_WATER_REGION[region], halite = WSE_HALITE[region];
@@ -1040,7 +1052,7 @@ static int wse_bulk_properties(const wo_eos *e, const double *primary, double *f
   case 4: l[PH_SAT] = fs - primary[1]; v[PH_SAT] = primary[1]; break;
   }
   h[PH_SAT] = ss;
-  fl[F_PERMFAC] = 1.0;
+  fl[F_PERMFAC] = wo_permeability_factor(e, l[PH_SAT] + v[PH_SAT]);
   fl[F_PP] = fl[F_P];
   fl[F_PP + 1] = 0.0;
   return 0;

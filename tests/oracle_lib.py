@@ -16,7 +16,7 @@ class Eos(C.Structure):
     _fields_ = [("kind", i32), ("np", i32), ("nc", i32), ("nph", i32), ("nmob", i32),
                 ("df", i32), ("isothermal", i32), ("temperature", d),
                 ("scale", d * 4 * 9), ("rp_type", i32), ("cp_type", i32),
-                ("rp_par", d * 6), ("cp_par", d * 6), ("thermo", i32)]
+                ("rp_par", d * 6), ("cp_par", d * 6), ("thermo", i32), ("perm_type", i32), ("perm_par", d * 3)]
 
 
 class NewtonOpts(C.Structure):
@@ -87,6 +87,7 @@ def load(path):
         "wo_sim_set_source_controls": (None, [C.c_void_p, C.c_void_p]),
         "wo_sim_source_rates": (None, [C.c_void_p, pd, pd]),
         "wo_separator_enthalpies": (i32, [C.c_void_p, C.c_double, pd, pd]),
+        "wo_permeability_factor": (d, [C.c_void_p, d]),
         "wo_air_properties": (i32, [d, d, pd, pd]), "wo_air_henrys_constant": (d, [d]),
         "wo_air_energy_solution": (d, [d]), "wo_air_mixture_viscosity": (d, [d, d, d]),
         "wo_halite_solubility": (i32, [d, pd]), "wo_halite_properties": (i32, [d, d, pd, pd]),
@@ -135,7 +136,7 @@ def load(path):
 class OracleSim:
     """Thin object wrapper over the oracle's wo_sim for the tests / cpu baseline."""
 
-    def __init__(self, L, mesh, eos_kind, thermo=0, relperm=None, capillary=None):
+    def __init__(self, L, mesh, eos_kind, thermo=0, relperm=None, capillary=None, permeability_modifier=None):
         self.L = L
         self.mesh = mesh
         self._keep = [f64(mesh.face_geom), f64(mesh.cell_geom), f64(mesh.rock), i32a(mesh.face_cells)]
@@ -148,6 +149,10 @@ class OracleSim:
             self.eos.rp_type = RP[relperm[0]]
             for k, v in enumerate(relperm[1]):
                 self.eos.rp_par[k] = v
+        if permeability_modifier is not None:
+            self.eos.perm_type = {"power": 1, "verma-pruess": 2}[permeability_modifier[0]]
+            for k, v in enumerate(permeability_modifier[1]):
+                self.eos.perm_par[k] = v
         if capillary is not None:
             self.eos.cp_type = CP[capillary[0]]
             for k, v in enumerate(capillary[1]):

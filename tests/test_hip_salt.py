@@ -92,3 +92,43 @@ def test_salt_benchmarks(name):
     for k, bar in SALT_BARS[name].items():
         assert worst[k][0] < bar, (k, worst[k])
     sim.ode.destroy()
+
+
+@pytest.mark.parametrize("modifier", [("power", [3.0]), ("verma-pruess", [2.0, 0.1, 0.8])])
+def test_halite_permeability_modifier_against_the_oracle(oracle, modifier):
+    """eos.permeability_modifier: the factor from the open pore fraction goes into the fluid record,
+    the face permeabilities (residual, FD Jacobian) and a few time steps, like on the oracle"""
+    from tests import oracle_lib as ol
+    from tests.cases import make_case, scaled
+    from waiwera_amd.flow_simulation import FlowSimulation
+    g, lm, prim, region = make_case(dims=(8, 8, 8), brick=(4, 4, 4), eos="wse", lens=False, sources=False)
+    assert (region == 5).sum() > 0
+    sim = FlowSimulation(lm, eos="wse", permeability_modifier=modifier)
+    osim = ol.OracleSim(oracle, lm, 3, permeability_modifier=modifier)
+    sim.set_regions(region); osim.set_regions(region)
+    y = scaled(prim, region, "wse").ravel().copy()
+    yo = osim.yvec(y)
+    assert sim.pre_eval(0.0, y) == 0 and osim.pre_eval(yo) == 0
+    fg, fo = sim.fluid(), osim.fluid()
+    assert np.abs(fg[:, 5] - fo[:, 5]).max() < 1e-14 and fo[region == 5, 5].max() < 0.97 and fo[region == 1, 5].min() == 1.0
+    n = sim.n_owned * 3
+    L = osim.lhs()
+    f = np.zeros(n)
+    dt = 1.0e3
+    assert sim.residual(0.0, dt, y, L, f) == 0
+    err, fo_ = osim.residual(yo, dt, L)
+    assert np.abs(f - fo_).max() <= 1e-11 * np.abs(fo_).max()
+    assert sim.jacobian(0.0, dt, y, L) == 0
+    err, Jo = osim.jacobian(yo, dt, L, fo_, mode=0)
+    assert np.abs(sim.jacobian_values() - Jo).max() <= 1e-5 * np.abs(Jo).max()
+    sim.set_opts(ksp_rtol=1e-10, ftol_rel=1e-9)
+    o = osim.opts()
+    o.ksp_rtol, o.ftol_rel = 1e-10, 1e-9
+    yg = y.copy()
+    for step in range(3):
+        reason, nits, kits = sim.timestep(0.0, dt, yg)
+        r, ok = osim.timestep(yo, dt, o)
+        assert reason > 0 and r > 0 and nits == r and np.array_equal(sim.regions(), osim.regions())
+        assert np.abs(yg - yo[: yg.size]).max() <= 1e-7 * np.abs(yo).max()
+        dt *= 2
+    sim.destroy(); osim.close()

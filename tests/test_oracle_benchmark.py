@@ -295,9 +295,9 @@ INPUTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inp
 
 
 def oracle_factory(oracle):
-    def make(lm, eos, thermo, relperm, capillary, temperature):
+    def make(lm, eos, thermo, relperm, capillary, temperature, permeability_modifier=None):
         osim = ol.OracleSim(oracle, lm, {"w": 0, "we": 1, "wce": 2, "wse": 3, "wae": 4}[eos], thermo=1 if thermo == "ifc67" else 0,
-                            relperm=relperm, capillary=capillary)
+                            relperm=relperm, capillary=capillary, permeability_modifier=permeability_modifier)
         ode = OracleWceOde(osim, 1.0e-5)
         ode.num_primary_variables = osim.np
         return ode

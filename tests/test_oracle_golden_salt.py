@@ -129,3 +129,19 @@ def test_eos_wse_transitions(oracle):
         assert int(fl[2]) == c["expected_region"], c["title"]
         for a, b in zip(prim, c["expected_primary"]):
             assert abs(a - b) <= 1e-6 * max(abs(b), 1e-12) + 1e-12, (c["title"], list(prim), c["expected_primary"])
+
+
+def test_halite_permeability_modifiers(oracle):
+    """fluid_permeability_factor_power / verma_pruess against the reference's fluid unit test
+    (test/unit/src/fluid_test.F90:256-320): pore fraction left open = S_l + S_v"""
+    e = ol.Eos()
+    e.perm_type, e.perm_par[0] = 1, 2.0
+    assert abs(oracle.wo_permeability_factor(C.byref(e), 0.6 + 0.3) - 0.81) < 1e-12
+    e.perm_type, e.perm_par[0], e.perm_par[1], e.perm_par[2] = 2, 2.0, 0.2, 0.8
+    assert abs(oracle.wo_permeability_factor(C.byref(e), 7.46061e-1 + 1.36511e-1) - 7.69471e-1) < 1e-6
+    assert abs(oracle.wo_permeability_factor(C.byref(e), 8.43640e-1 + 1.47812e-1) - 9.82261697e-1) < 1e-8
+    e.perm_par[0], e.perm_par[1], e.perm_par[2] = 3.0, 0.1, 0.7
+    assert abs(oracle.wo_permeability_factor(C.byref(e), 0.9) - 0.7238998749370428) < 1e-12
+    assert oracle.wo_permeability_factor(C.byref(e), 0.1 + 0.0) == 0.0
+    e.perm_type = 0
+    assert oracle.wo_permeability_factor(C.byref(e), 0.5) == 1.0

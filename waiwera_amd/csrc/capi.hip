@@ -505,6 +505,7 @@ void wai_default_eos(wai_eos_desc* e, int kind) {
   e->cp_type = WAI_CP_ZERO;
   e->partial_pressure_scale = 0.0;
   e->thermo = WAI_THERMO_IAPWS;
+  e->perm_type = 0;
 }
 
 void wai_default_opts(wai_solver_opts* o) {
@@ -557,6 +558,9 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
   c->ep.rp_type = ed->rp_type; c->ep.cp_type = ed->cp_type;
   if (ed->thermo != WAI_THERMO_IAPWS && ed->thermo != WAI_THERMO_IFC67) { c->err = "unknown thermodynamic formulation"; return -2; }
   c->ep.thermo = ed->thermo;
+  if (ed->perm_type < 0 || ed->perm_type > 2) { c->err = "unknown permeability modifier"; return -2; }
+  c->ep.perm_type = ed->perm_type;
+  for (int i = 0; i < 3; i++) c->ep.perm_par[i] = ed->perm_par[i];
   for (int i = 0; i < 6; i++) { c->ep.rp_par[i] = ed->rp_par[i]; c->ep.cp_par[i] = ed->cp_par[i]; }
 
   DeviceMesh& m = c->mesh;

@@ -62,6 +62,8 @@ struct EosParams {
   int rp_type, cp_type;
   double rp_par[6], cp_par[6];
   int thermo;             // "thermodynamics": THERMO_IAPWS (default) | THERMO_IFC67
+  int perm_type;          // eos wse permeability modifier: 0 none, 1 power, 2 Verma-Pruess
+  double perm_par[3];     // exponent, phir, gamma
 };
 
 // thermodynamic formulation dispatch (thermodynamics_type: src/thermodynamics.F90, IAPWS.F90,
@@ -302,6 +304,20 @@ __device__ __forceinline__ void eos_scale(const EosParams& e, const double* prim
 __device__ __forceinline__ int wse_water_region(int region) { return region > 4 ? region - 4 : region; }
 __device__ __forceinline__ bool wse_halite(int region) { return region > 4; }
 
+// fluid_permeability_factor_*_modify (fluid.F90:588-664): factor on the permeability from the pore
+// fraction pf = S_l + S_v left open by halite
+__device__ __forceinline__ double permeability_factor(const EosParams& e, double pf) {
+  if (e.perm_type == 1) return pow(pf, e.perm_par[0]);
+  if (e.perm_type == 2) {
+    const double n = e.perm_par[0], phir = e.perm_par[1], gamma = e.perm_par[2];
+    const double omega = 1.0 + (1.0 / (gamma * (1.0 / phir - 1.0)));
+    const double theta = (pf - phir) / (1.0 - phir);
+    return pow(theta, n) * (1.0 - gamma + gamma / pow(omega, n)) /
+           (1.0 - gamma + gamma * pow(theta / (theta + omega - 1.0), n));
+  }
+  return 1.0;
+}
+
 // ---- cell state in registers ---------------------------------------------------------------
 template <int KIND> struct CellState {
   using E = EosT<KIND>;
@@ -357,6 +373,7 @@ __device__ __forceinline__ int eos_eval(const EosParams& e, const double* y, int
     else if (wr == 2) { s.sat[0] = 0.0; s.sat[1] = fs; }
     else { s.sat[0] = fs - prim[1]; s.sat[1] = prim[1]; }
     s.sat[2] = ss;
+    s.permfac = permeability_factor(e, s.sat[0] + s.sat[1]);
     double xs = 0.0;
     if (halite) { if (salt::halite_solubility(s.T, xs)) return 1; }
     else if (region != 2) xs = prim[2];

@@ -17,7 +17,8 @@ from .lib import LIB, WaiError
 
 class FlowSimulation:
     def __init__(self, mesh, eos="we", opts=None, device=0, temperature=20.0,
-                 relperm=("linear", [0.0, 1.0, 0.0, 1.0]), capillary=("zero", []), thermo="iapws"):
+                 relperm=("linear", [0.0, 1.0, 0.0, 1.0]), capillary=("zero", []), thermo="iapws",
+                 permeability_modifier=None):
         self.mesh = mesh
         self.eos_name = eos
         self._keep = dict(
@@ -34,7 +35,8 @@ class FlowSimulation:
         if k["sub_ptr"] is not None:
             md.n_sub = k["sub_ptr"].size - 1
             md.sub_ptr = k["sub_ptr"].ctypes.data_as(_lib.pi)
-        self.eos_desc = _lib.eos_desc(eos, temperature, relperm, capillary, thermo=thermo)
+        self.eos_desc = _lib.eos_desc(eos, temperature, relperm, capillary, thermo=thermo,
+                                      permeability_modifier=permeability_modifier)
         self.opts = opts or _lib.default_opts()
         h = C.c_void_p()
         rc = LIB.wai_ctx_create(C.byref(md), C.byref(self.eos_desc), C.byref(self.opts), device, C.byref(h))

@@ -35,6 +35,8 @@ module waiwera_hip_module
      real(c_double) :: cp_par(6)
      real(c_double) :: partial_pressure_scale
      integer(c_int) :: thermo   !! 0 IAPWS-97, 1 IFC-67
+     integer(c_int) :: perm_type = 0   !! eos wse permeability modifier: 0 none, 1 power, 2 Verma-Pruess
+     real(c_double) :: perm_par(3) = 0._c_double   !! exponent, phir, gamma
   end type wai_eos_desc
 
   type, bind(c), public :: wai_source_control

@@ -35,7 +35,10 @@ class MeshDesc(C.Structure):
 class EosDesc(C.Structure):
     _fields_ = [("kind", i32), ("temperature", d), ("pressure_scale", d), ("temperature_scale", d),
                 ("rp_type", i32), ("rp_par", d * 6), ("cp_type", i32), ("cp_par", d * 6),
-                ("partial_pressure_scale", d), ("thermo", i32)]
+                ("partial_pressure_scale", d), ("thermo", i32), ("perm_type", i32), ("perm_par", d * 3)]
+
+
+PERM = {"none": 0, "power": 1, "verma-pruess": 2, "verma_pruess": 2}
 
 
 class SourceControl(C.Structure):
@@ -190,7 +193,8 @@ def default_opts(**kw):
 
 
 def eos_desc(kind="we", temperature=20.0, relperm=("linear", [0.0, 1.0, 0.0, 1.0]),
-             capillary=("zero", []), pressure_scale=1.0e6, temperature_scale=1.0e2, thermo="iapws"):
+             capillary=("zero", []), pressure_scale=1.0e6, temperature_scale=1.0e2, thermo="iapws",
+             permeability_modifier=None):
     e = EosDesc()
     LIB.wai_default_eos(C.byref(e), EOS_KIND[kind] if isinstance(kind, str) else kind)
     e.temperature = temperature
@@ -203,6 +207,10 @@ def eos_desc(kind="we", temperature=20.0, relperm=("linear", [0.0, 1.0, 0.0, 1.0
     for k, v in enumerate(capillary[1]):
         e.cp_par[k] = v
     e.thermo = THERMO[thermo]
+    if permeability_modifier is not None:     # (type, [exponent, phir, gamma]), eos wse only
+        e.perm_type = PERM[permeability_modifier[0].lower()]
+        for k, v in enumerate(permeability_modifier[1]):
+            e.perm_par[k] = v
     return e
 
 

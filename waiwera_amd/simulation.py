@@ -152,6 +152,16 @@ class Simulation:
         eos = inp.get("eos", "we")
         self.eos = (eos.get("name", "we") if isinstance(eos, dict) else eos).lower()
         temperature = eos.get("temperature", 20.0) if isinstance(eos, dict) else 20.0
+        pm = eos.get("permeability_modifier") if isinstance(eos, dict) else None
+        self.permeability_modifier = None
+        if pm is not None and (pm.get("type", "none").lower() != "none"):
+            kind = pm["type"].lower()
+            if kind == "power":
+                self.permeability_modifier = ("power", [pm.get("exponent", 3.0)])
+            elif kind in ("verma-pruess", "verma_pruess"):
+                self.permeability_modifier = ("verma-pruess", [pm.get("exponent", 2.0), pm.get("phir", 0.1), pm.get("gamma", 0.7)])
+            else:
+                raise NotImplementedError("permeability modifier %r" % pm["type"])
         th = inp.get("thermodynamics", "iapws")
         self.thermo = (th.get("name", "iapws") if isinstance(th, dict) else th).lower()
         if self.eos not in ("w", "we", "wce", "wse", "wae") or self.thermo not in ("iapws", "ifc67"):
@@ -292,7 +302,11 @@ class Simulation:
         if ode_factory is None:
             from .flow_simulation import FlowSimulation
             self.ode = FlowSimulation(lm, eos=self.eos, device=device, temperature=temperature,
-                                      relperm=self.relperm, capillary=self.capillary, thermo=self.thermo)
+                                      relperm=self.relperm, capillary=self.capillary, thermo=self.thermo,
+                                      permeability_modifier=self.permeability_modifier)
+        elif self.permeability_modifier is not None:
+            self.ode = ode_factory(lm, self.eos, self.thermo, self.relperm, self.capillary, temperature,
+                                   permeability_modifier=self.permeability_modifier)
         else:
             self.ode = ode_factory(lm, self.eos, self.thermo, self.relperm, self.capillary, temperature)
         self.ode.set_regions(region)
