@@ -110,7 +110,9 @@ def test_halite_permeability_modifier_against_the_oracle(oracle, modifier):
     yo = osim.yvec(y)
     assert sim.pre_eval(0.0, y) == 0 and osim.pre_eval(yo) == 0
     fg, fo = sim.fluid(), osim.fluid()
-    assert np.abs(fg[:, 5] - fo[:, 5]).max() < 1e-14 and fo[region == 5, 5].max() < 0.97 and fo[region == 1, 5].min() == 1.0
+    no = lm.n_owned
+    assert np.abs(fg[:, 5] - fo[:, 5]).max() < 1e-14
+    assert fo[:no][region[:no] == 5, 5].max() < 0.97 and fo[:no][region[:no] == 1, 5].min() == 1.0
     n = sim.n_owned * 3
     L = osim.lhs()
     f = np.zeros(n)
