@@ -112,7 +112,7 @@ def test_halite_permeability_modifier_against_the_oracle(oracle, modifier):
     fg, fo = sim.fluid(), osim.fluid()
     no = lm.n_owned
     assert np.abs(fg[:, 5] - fo[:, 5]).max() < 1e-14
-    assert fo[:no][region[:no] == 5, 5].max() < 0.97 and fo[:no][region[:no] == 1, 5].min() == 1.0
+    assert fo[:no][region[:no] == 5, 5].max() < 0.97 and fo[:no][region[:no] == 1, 5].min() > 1.0 - 1e-12
     n = sim.n_owned * 3
     L = osim.lhs()
     f = np.zeros(n)
