@@ -229,15 +229,24 @@ int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, doub
   double* Xsave = k.X;
   k.X = x;  // X aliases the caller's x during the iteration
   int rc = 0;
-  for (int i = 0; i < maxits && !*reason && !rc; i++) {
+  // first half of an iteration: P update, V = B^-1 A P with (V, RP), alpha, S.  It touches P, V, S
+  // and the device scalars only -- not X, R -- so the next iteration's first half is enqueued
+  // *before* the host waits for this iteration's residual norm: the device never idles through the
+  // read-back, and if the norm says "converged" the speculative half is simply discarded.
+  auto first_half = [&]() -> int {
     { Prof p(c, KC_VECTOR); bcgs_update_p(c); }
-    if ((rc = pc_amul(c, k.P, k.V, 1, k.RP))) break;
-    {
-      Prof p(c, KC_VECTOR);
-      vec_finalize(c, nsub, S_D1, 1, multi ? -1 : 2);
-      if (multi) { if ((rc = allreduce_scal(c, S_D1, 1))) break; bcgs_scalars(c, 2); }
-      bcgs_update_s(c);
-    }
+    if (int e = pc_amul(c, k.P, k.V, 1, k.RP)) return e;
+    Prof p(c, KC_VECTOR);
+    vec_finalize(c, nsub, S_D1, 1, multi ? -1 : 2);
+    if (multi) { if (int e = allreduce_scal(c, S_D1, 1)) return e; bcgs_scalars(c, 2); }
+    bcgs_update_s(c);
+    return 0;
+  };
+  const bool speculate = getenv("WAI_BCGS_NO_SPECULATION") == nullptr;
+  bool have_first_half = false;
+  for (int i = 0; i < maxits && !*reason && !rc; i++) {
+    if (!have_first_half && (rc = first_half())) break;
+    have_first_half = false;
     if ((rc = pc_amul(c, k.S, k.T, 2, nullptr))) break;
     {
       Prof p(c, KC_VECTOR);
@@ -250,7 +259,13 @@ int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, doub
         bcgs_scalars(c, 4);
       }
     }
-    if ((rc = read_scal(c, 0, 16))) break;
+    if (speculate && i + 1 < maxits) {
+      HIPCHK(c, hipMemcpyAsync(k.h_scal, k.scal, 16 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipEventRecord(c->ev_scal, c->stream));
+      if ((rc = first_half())) break;
+      have_first_half = true;
+      HIPCHK(c, hipEventSynchronize(c->ev_scal));
+    } else if ((rc = read_scal(c, 0, 16))) break;
     dp = std::sqrt(k.h_scal[S_DP2]);
     *its = i + 1;
     const double brk = k.h_scal[S_BREAK];
@@ -484,6 +499,7 @@ void free_all(wai_ctx* c) {
   F(c->d_send_idx); F(c->d_sendbuf); F(c->d_recvbuf);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->ev_scal) (void)hipEventDestroy(c->ev_scal);
   if (c->pev0) (void)hipEventDestroy(c->pev0);
   if (c->pev1) (void)hipEventDestroy(c->pev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -530,6 +546,7 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
   HIPCHK(c, hipSetDevice(device));
   HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(c, hipEventCreate(&c->ev0)); HIPCHK(c, hipEventCreate(&c->ev1));
+  HIPCHK(c, hipEventCreateWithFlags(&c->ev_scal, hipEventDisableTiming));
   HIPCHK(c, hipEventCreate(&c->pev0)); HIPCHK(c, hipEventCreate(&c->pev1));
   if (od) c->opts = *od; else wai_default_opts(&c->opts);
   c->kind = ed->kind;

@@ -139,6 +139,7 @@ struct wai_ctx {
   double* stage[4] = {nullptr, nullptr, nullptr, nullptr};  // host-vector staging
   size_t stage_len = 0;
   wai::Comm* comm = nullptr;
+  hipEvent_t ev_scal = nullptr;   // marks the scalar read-back of a Krylov iteration (ksp_bcgs)
   // halo
   int n_nbr = 0;
   std::vector<int> nbr_rank, send_ptr, recv_ptr;
