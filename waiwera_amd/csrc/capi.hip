@@ -722,11 +722,12 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
       for (int i = lo; i + 1 < hi; i++)
         if (levf[i] > levf[i + 1] || levb[i] < levb[i + 1]) level_sorted = false;
       int ucount = 0;
+      const int park_max = getenv("WAI_PC_PARK2") ? 2 : 3;
       for (int i = lo; i < hi; i++) {
         const int nL = diag[i] - lfirst[i - lo], nU = ulast[i - lo] - diag[i] - 1;
         if (nL > 3 || nU > 3 || lfirst[i - lo] > 3 || diag[i] > 3) fast3 = false;
         uoff[i] = ucount;
-        ucount += nU;
+        ucount += std::min(nU, park_max);
       }
       s.max_ublocks = std::max(s.max_ublocks, ucount);
       if (nlf > 1023 || nlb > 1023) { c->err = "more than 1023 dependency levels in a subdomain"; return -2; }
@@ -755,6 +756,7 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
       // 160 KB of LDS per CU; a workgroup may use 64 KB
       const size_t need = ((size_t)(((s.max_rows + 63) / 64) * 64) * np + 32 + (size_t)s.max_ublocks * 4) * sizeof(double);
       s.park = !(e && e[0] == '0') && need <= 64 * 1024;  // default on; WAI_PC_PARK=0: k_pc
+      s.park2 = getenv("WAI_PC_PARK2") != nullptr;        // experiment: two parked upper blocks per row
     }
     {
       const char* e = getenv("WAI_PC_PIPE");

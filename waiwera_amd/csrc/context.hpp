@@ -63,6 +63,7 @@ struct IluSchedule {
   bool scaled = true;       // diag_only: rows pre-scaled by the inverted pivots (WAI_ILU_NOSCALE: off)
   bool park = true;         // k_pc_park: upper blocks parked in LDS (WAI_PC_PARK=0: off)
   int* row_uoff = nullptr;  // first parked upper block of a row inside its subdomain
+  bool park2 = false;
   int max_ublocks = 0;      // most in-subdomain upper blocks of any subdomain
   bool fast3 = false;         // <= 3 lower and <= 3 upper in-subdomain couplings per row, offsets < 4
   bool level_sorted = false;  // every subdomain's rows are stored in dependency-level order

@@ -759,8 +759,11 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
 // three resident workgroups per CU (3 x 51 KB of the 160 KB LDS), so one more brick's loads are in
 // flight to cover the latency-bound sweeps of the others.
 // MEASURED (216^3, MI355X, same box): 0.604 ms against k_pc's 0.709 ms; 68 VGPRs, no spills.
-template <bool SPMV>
-__global__ __launch_bounds__(512, 6) void k_pc_park(
+// P2: at most two of a row's upper blocks are parked, the third (rows with all three in-brick
+// upper neighbours) is fetched again from the matrix after the forward sweep: 40 KB of LDS per
+// workgroup instead of 47-51 KB, i.e. a fourth resident workgroup per CU if 64 VGPRs suffice.
+template <bool SPMV, bool P2 = false>
+__global__ __launch_bounds__(512, P2 ? 8 : 6) void k_pc_park(
     int n, int W, int nsub, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev,
     const int* __restrict__ row_info, const int* __restrict__ row_uoff, const int* __restrict__ col,
     const double* __restrict__ sval, const double* __restrict__ dinv, const double* __restrict__ in,
@@ -812,7 +815,7 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
 #pragma unroll
           for (int e = 0; e < BB; e++) Lf[p][e] = tl ? blk[e] : Lf[p][e];
         }
-        if (isu) {
+        if (isu && (!P2 || q - dslot - 1 < 2)) {
           double* dst = upark + (size_t)(uo + (q - dslot - 1)) * BB;
           *reinterpret_cast<double2*>(dst) = make_double2(blk[0], blk[1]);
           *reinterpret_cast<double2*>(dst + 2) = make_double2(blk[2], blk[3]);
@@ -855,6 +858,17 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
 #pragma unroll
   for (int p = 0; p < MLU; p++) {
     const bool have = p < nU;
+    if (P2 && p == 2) {
+      double blk[BB] = {0.0, 0.0, 0.0, 0.0};
+      if (have) {
+        int lfirst, dslot, ulast, a_, b_;
+        unpack_info(row_info[i], lfirst, dslot, ulast, a_, b_);
+        load_block<BS>(sval, n, dslot + 3, i, blk);
+      }
+#pragma unroll
+      for (int e = 0; e < BB; e++) Lf[p][e] = blk[e];
+      continue;
+    }
     const double* src = upark + (size_t)(uo + (have ? p : 0)) * BB;
     const double2 u0 = *reinterpret_cast<const double2*>(src), u1 = *reinterpret_cast<const double2*>(src + 2);
     Lf[p][0] = have ? u0.x : 0.0; Lf[p][1] = have ? u0.y : 0.0;
@@ -1392,6 +1406,17 @@ static void launch_pc_bs(wai_ctx* c, bool spmv, const double* in, double* z, int
     // upper blocks parked in LDS: three resident workgroups per CU
     if (s.park && s.diag_only && s.scaled && s.fast3 && T <= 512 && !c->dbg) {
       const size_t lds_park = lds + (size_t)s.max_ublocks * 4 * sizeof(double);
+      if (s.park2) {
+        if (spmv)
+          hipLaunchKernelGGL((k_pc_park<true, true>), grid, T, lds_park, c->stream, J.n, J.W, s.nsub, s.sub_ptr, s.sub_nlev,
+                             s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials,
+                             c->ks.nb_max, dot_mode);
+        else
+          hipLaunchKernelGGL((k_pc_park<false, true>), grid, T, lds_park, c->stream, J.n, J.W, s.nsub, s.sub_ptr, s.sub_nlev,
+                             s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials,
+                             c->ks.nb_max, dot_mode);
+        return;
+      }
       if (spmv)
         hipLaunchKernelGGL(k_pc_park<true>, grid, T, lds_park, c->stream, J.n, J.W, s.nsub, s.sub_ptr, s.sub_nlev,
                            s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials,
