@@ -69,11 +69,11 @@ int wo_brent(wo_rootfn f, void *ctx, double a, double b, double xtol, double fto
              double *root, int *iters);
 
 /* ---- EOS (src/eos.F90, src/eos_w.F90, src/eos_we.F90) ----------------------------------- */
-enum { WO_EOS_W = 0, WO_EOS_WE = 1, WO_EOS_WCE = 2, WO_EOS_WSE = 3, WO_EOS_WAE = 4 };
+enum { WO_EOS_W = 0, WO_EOS_WE = 1, WO_EOS_WCE = 2, WO_EOS_WSE = 3, WO_EOS_WAE = 4, WO_EOS_WSCE = 5, WO_EOS_WSAE = 6 };
 typedef struct wo_eos {
   int kind, np, nc, nph, nmob, df, isothermal;
   double temperature;          /* eos_w only (eos_w.F90:97-98) */
-  double scale[9][4];          /* primary_scale(var, region), region 1..4 (wse: 1..8); a zero partial-
+  double scale[9][4];          /* primary_scale(var, region), region 1..4 (wse, wsce, wsae: 1..8); a zero partial-
                                 * pressure scale means adaptive scaling Pg/P (eos_wge.F90:639-674) */
   int rp_type, cp_type;
   double rp_par[6], cp_par[6];

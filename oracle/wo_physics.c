@@ -215,6 +215,10 @@ int wo_co2_viscosity(double partial_pressure, double t, double *visc) {
  * Cramer 1982, Cygan 1991 Henry's constants of N2 / O2; Hirschfelder et al. 1954 viscosity) */
 #define AIR_MW 28.96
 #define IS_WGE(e) ((e)->kind == WO_EOS_WCE || (e)->kind == WO_EOS_WAE)
+/* salt family: wse, and with a gas (eos_wsge.F90) wsce / wsae: 4th primary = gas partial pressure */
+#define IS_WSGE(e) ((e)->kind == WO_EOS_WSCE || (e)->kind == WO_EOS_WSAE)
+#define IS_SALT(e) ((e)->kind == WO_EOS_WSE || IS_WSGE(e))
+#define GAS_IS_AIR(e) ((e)->kind == WO_EOS_WAE || (e)->kind == WO_EOS_WSAE)
 static const double AIR_ENTHALPY[4] = {1.20740, 9.24502, 0.115984, -5.63568e-4};
 static const double AIR_WEIGHT[2] = {0.79, 0.21};
 static const double AIR_HENRY_P0[2] = {1.01325e5, 1.e5};
@@ -448,8 +452,11 @@ void wo_eos_init(wo_eos *e, int kind) {
     e->scale[2][0] = 1.e6; e->scale[2][1] = 1.e2;
     e->scale[4][0] = 1.e6; e->scale[4][1] = 1.0;
     if (kind == WO_EOS_WCE || kind == WO_EOS_WAE) { e->np = 3; e->nc = 2; } /* scale[.][2] = 0: adaptive Pg/P */
-    if (kind == WO_EOS_WSE) { /* src/eos_wse.F90:123-165: solid third phase, regions 5, 6, 8 = 1, 2, 4 + halite */
+    if (kind == WO_EOS_WSE || kind == WO_EOS_WSCE || kind == WO_EOS_WSAE) {
+      /* src/eos_wse.F90:123-165, eos_wsge.F90:85-140: solid third phase, regions 5, 6, 8 = 1, 2, 4 + halite;
+       * with a gas: components water, salt, gas; 4th primary scale 0 = adaptive Pg / P */
       e->np = 3; e->nc = 2; e->nph = 3;
+      if (kind != WO_EOS_WSE) { e->np = 4; e->nc = 3; }
       for (int r = 1; r <= 8; r++) {
         if (r == 3 || r == 7) continue;
         e->scale[r][0] = 1.e6;
@@ -470,10 +477,12 @@ void wo_eos_init(wo_eos *e, int kind) {
 void wo_eos_unscale(const wo_eos *e, const double *y, int region, double *primary) {
   for (int k = 0; k < e->np; k++) primary[k] = y[k] * e->scale[region][k];
   if (IS_WGE(e) && e->scale[region][2] == 0.0) primary[2] = y[2] * primary[0]; /* eos_wge.F90:659-674 */
+  if (IS_WSGE(e) && e->scale[region][3] == 0.0) primary[3] = y[3] * primary[0];   /* eos_wsge.F90:984-998 */
 }
 void wo_eos_scale(const wo_eos *e, const double *primary, int region, double *y) {
   for (int k = 0; k < e->np; k++) y[k] = primary[k] / e->scale[region][k];
   if (IS_WGE(e) && e->scale[region][2] == 0.0) y[2] = primary[2] / primary[0];   /* eos_wge.F90:639-655 */
+  if (IS_WSGE(e) && e->scale[region][3] == 0.0) y[3] = primary[3] / primary[0];  /* eos_wsge.F90:962-980 */
 }
 
 /* src/eos_we.F90:327-390 (we), src/eos_w.F90:126-147 (w); phase composition eos.F90:214-236 */
@@ -490,7 +499,7 @@ int wo_eos_bulk_properties(const wo_eos *e, const double *primary, double *fl) {
     fl[F_PP] = fl[F_P];
     return err;
   }
-  if (e->kind == WO_EOS_WSE) return wse_bulk_properties(e, primary, fl);
+  if (IS_SALT(e)) return wse_bulk_properties(e, primary, fl);
   if (IS_WGE(e)) { /* src/eos_wge.F90:350-389 */
     fl[F_PP] = fl[F_P] - primary[2];
     fl[F_PP + 1] = primary[2];
@@ -589,7 +598,7 @@ int wo_eos_phase_properties(const wo_eos *e, const double *primary, double *fl) 
     return 0;
   }
   if (IS_WGE(e)) return wce_phase_properties(e, fl);
-  if (e->kind == WO_EOS_WSE) return wse_phase_properties(e, primary, fl);
+  if (IS_SALT(e)) return wse_phase_properties(e, primary, fl);
   int phases = (int)lround(fl[F_PHASES]);
   double sl = fl[phase_off(e, 0) + PH_SAT];
   double rp[2], cp[2];
@@ -634,7 +643,7 @@ int wo_eos_transition(const wo_eos *e, const double *oldp, double *prim, const d
                       double *fluid, int *transition) {
   *transition = 0;
   if (e->kind == WO_EOS_W) return 0;
-  if (e->kind == WO_EOS_WSE) return wse_transition(e, oldp, prim, old_fluid, fluid, transition);
+  if (IS_SALT(e)) return wse_transition(e, oldp, prim, old_fluid, fluid, transition);
   const double small = 1.e-6;
   const int wce = IS_WGE(e);
   int old_region = (int)lround(old_fluid[F_REGION]);
@@ -699,6 +708,20 @@ int wo_eos_transition(const wo_eos *e, const double *oldp, double *prim, const d
 /* src/eos_we.F90:486-526, src/eos_w.F90:232-255, src/eos_wge.F90:573-635 */
 int wo_eos_check_primary(const wo_eos *e, const double *fluid, double *prim, int *changed) {
   *changed = 0;
+  if (IS_WSGE(e)) { /* src/eos_wsge.F90:890-958 */
+    const double small = 1.e-6;
+    if (!(prim[0] > 0.0)) return 1;
+    double maxpp = (1.0 - small) * prim[0];
+    if (prim[3] > maxpp) { prim[3] = maxpp; *changed = 1; }
+    else if (prim[3] < 0.0) { prim[3] = 0.0; *changed = 1; }
+    if (prim[2] < 0.0) { prim[2] = 0.0; *changed = 1; }
+    else if (prim[2] > 1.0) return 1;
+    if (prim[0] - prim[3] > 100.e6) return 1;
+    if (WSE_WATER_REGION[(int)lround(fluid[F_REGION])] == 4) {
+      if (prim[1] < -1.0 || prim[1] > 2.0) return 1;
+    } else if (prim[1] < 0.0 || prim[1] > 800.0) return 1;
+    return 0;
+  }
   if (e->kind == WO_EOS_WSE) { /* src/eos_wse.F90:891-938 */
     if (prim[2] < 0.0) { prim[2] = 0.0; *changed = 1; }
     else if (prim[2] > 1.0) return 1;
@@ -1014,6 +1037,40 @@ int wo_brine_viscosity(const wo_eos *e, double t, double p, double xs, double *m
   return 0;
 }
 
+/* Henry's constant and energy of solution of the gas in brine of salt mass fraction xs
+ * (henrys_constant_salt / henrys_derivative_salt + ncg_energy_solution_salt:
+ * src/ncg_co2_thermodynamics.F90:139-232, src/ncg_air_thermodynamics.F90:141-238,
+ * src/ncg_thermodynamics.F90:187-261) */
+static const double CO2_HENRY_SALT[5] = {1.19784e-1, -7.17823e-2, 4.93854e-2, -1.03826e-2, 1.08233e-3};
+static const double AIR_HENRY_SALT[2][5] = {{0.183369, -0.236905, 0.242438, -7.30134e-2, 8.58723e-3},
+                                            {0.16218, -1.16909e-1, 5.55185e-2, -8.75443e-3, 9.91567e-4}};
+static void gas_henry_salt(const wo_eos *e, double t, double xs, double *henry, double *esol) {
+  double m = salt_mole_fraction(xs), x = t / 100.0, tk = t + TC_K, deriv;
+  if (GAS_IS_AIR(e)) {
+    double hc[2], h = 0.0;
+    air_henry_constituents(t, hc);
+    deriv = 0.0;
+    for (int i = 0; i < 2; i++) {
+      double dc[6], ds[4];
+      for (int k = 1; k < 7; k++) dc[k - 1] = k * AIR_HENRY[i][k];
+      for (int k = 1; k < 5; k++) ds[k - 1] = k * AIR_HENRY_SALT[i][k];
+      double kb = horner(AIR_HENRY_SALT[i], 5, x);
+      h += AIR_WEIGHT[i] * hc[i] * pow(10.0, m * kb);
+      double d0 = AIR_HENRY_P0[i] * (1.e5 * horner(dc, 6, x)) / (hc[i] * 100.0);
+      deriv += AIR_WEIGHT[i] * (d0 + log(10.0) * m * (horner(ds, 4, x) / 100.0));
+    }
+    *henry = h;
+    *esol = -1.e3 * GAS_CONSTANT * tk * tk * deriv / AIR_MW;
+  } else {
+    double h0 = wo_co2_henrys_constant(t), d[5], ds[4];
+    for (int i = 0; i < 5; i++) d[i] = (i + 1) * CO2_HENRY[i + 1];
+    for (int k = 1; k < 5; k++) ds[k - 1] = k * CO2_HENRY_SALT[k];
+    *henry = h0 * pow(10.0, m * horner(CO2_HENRY_SALT, 5, x));
+    deriv = 1.e8 * horner(d, 5, x) / (h0 * 100.0) + log(10.0) * m * (horner(ds, 4, x) / 100.0);
+    *esol = -1.e3 * GAS_CONSTANT * tk * tk * deriv / CO2_MW;
+  }
+}
+
 /* ==== eos_wse: water, salt, energy (src/eos_wse.F90) ======================================== */
 /* fluid_permeability_factor_{null,power,verma_pruess}_modify: src/fluid.F90:588-664 */
 double wo_permeability_factor(const wo_eos *e, double pf) {
@@ -1034,10 +1091,11 @@ static int wse_bulk_properties(const wo_eos *e, const double *primary, double *f
   int wr = WSE_WATER_REGION[region], halite = WSE_HALITE[region];
   int err = 0;
   fl[F_P] = primary[0];
+  const double pg = IS_WSGE(e) ? primary[3] : 0.0, pw = fl[F_P] - pg;   /* brine pressure (eos_wsge.F90:645-650) */
   if (wr == 4) {
     double xs = primary[2], t;
-    if (region != 4) err = wo_halite_solubility_two_phase(e, fl[F_P], &xs);
-    if (!err) err = wo_brine_sat_temperature(e, fl[F_P], xs, &t);
+    if (region != 4) err = wo_halite_solubility_two_phase(e, pw, &xs);
+    if (!err) err = wo_brine_sat_temperature(e, pw, xs, &t);
     if (!err) fl[F_T] = t;
   } else fl[F_T] = primary[1];
   if (err) return err;
@@ -1053,8 +1111,9 @@ static int wse_bulk_properties(const wo_eos *e, const double *primary, double *f
   }
   h[PH_SAT] = ss;
   fl[F_PERMFAC] = wo_permeability_factor(e, l[PH_SAT] + v[PH_SAT]);
-  fl[F_PP] = fl[F_P];
+  fl[F_PP] = pw;
   fl[F_PP + 1] = 0.0;
+  if (IS_WSGE(e)) fl[F_PP + 2] = pg;
   return 0;
 }
 
@@ -1080,20 +1139,52 @@ static int wse_phase_properties(const wo_eos *e, const double *primary, double *
   wo_relperm(e->rp_type, e->rp_par, sle, rp);
   cp[0] = wo_capillary(e->cp_type, e->cp_par, sle, T);
   cp[1] = 0.0;
+  const int gas = IS_WSGE(e), nc = e->nc;
+  const double pw = fl[F_PP], pg = gas ? fl[F_PP + 2] : 0.0;   /* brine pressure, gas partial pressure */
+  double gas_rho = 0.0, gas_h = 0.0;
+  if (gas) {   /* eos_wsge_phase_properties: src/eos_wsge.F90:675-852 */
+    err = GAS_IS_AIR(e) ? wo_air_properties(pg, T, &gas_rho, &gas_h) : wo_co2_properties(pg, T, &gas_rho, &gas_h);
+    if (err) return err;
+  }
   for (int p = 0; p < e->nmob; p++) {
     double *ph = fl + phase_off(e, p);
     if (phases & (1 << p)) {
-      double rho, u, xp;
-      if (p == 0) { err = wo_brine_properties(e, P, T, xs, &rho, &u); xp = xs; }
-      else { err = th_props(e, 2, P, T, &rho, &u); xp = 0.0; }
+      double rho, u, xp, bp, mu;
+      if (p == 0) { bp = P; err = wo_brine_properties(e, bp, T, xs, &rho, &u); xp = xs; }
+      else { bp = gas ? pw : P; err = th_props(e, 2, bp, T, &rho, &u); xp = 0.0; }
       if (err) return err;
-      ph[PH_RHO] = rho; ph[PH_U] = u; ph[PH_H] = u + P / rho;
-      ph[PH_X] = 1.0 - xp; ph[PH_X + 1] = xp;
+      if (p == 0) { err = wo_brine_viscosity(e, T, P, xs, &mu); if (err) return err; }
+      else mu = th_viscosity(e, 2, T, P, rho);
+      double xg = 0.0, grho = 0.0, esol = 0.0;
+      if (gas) {
+        if (p == 0) {
+          double henry;
+          gas_henry_salt(e, T, xs, &henry, &esol);
+          xg = wo_ncg_mole_to_mass(pg / henry, GAS_IS_AIR(e) ? AIR_MW : CO2_MW);
+        } else {
+          grho = gas_rho;
+          double tot = grho + rho;
+          xg = (tot < 1.e-30) ? 0.0 : grho / tot;
+          if (GAS_IS_AIR(e)) mu = wo_air_mixture_viscosity(mu, T, xg);
+          else {
+            double gmu;
+            err = wo_co2_viscosity(pg, T, &gmu);
+            if (err) return err;
+            mu = mu * (1.0 - xg) + gmu * xg;
+          }
+        }
+      }
+      ph[PH_MU] = mu;
+      ph[PH_RHO] = rho + grho;
+      ph[PH_X] = 1.0 - xp - xg; ph[PH_X + 1] = xp;
+      if (gas) ph[PH_X + 2] = xg;
       ph[PH_KR] = rp[p]; ph[PH_PC] = cp[p];
-      if (p == 0) { err = wo_brine_viscosity(e, T, P, xs, &ph[PH_MU]); if (err) return err; }
-      else ph[PH_MU] = th_viscosity(e, 2, T, P, rho);
+      double bh = u + bp / rho;
+      ph[PH_H] = gas ? bh * (1.0 - xg) + (gas_h + esol) * xg : bh;
+      ph[PH_U] = gas ? ph[PH_H] - P / ph[PH_RHO] : u;
     } else phase_zero(e, ph);
   }
+  (void)nc;
   double *h = fl + phase_off(e, 2);
   if (halite || region == 2) {
     double rho, u;
@@ -1112,11 +1203,12 @@ static double wse_satline_diff(double x, void *vc) {
   wse_line *c = (wse_line *)vc;
   double P = (1.0 - x) * c->a[0] + x * c->b[0], T = (1.0 - x) * c->a[1] + x * c->b[1];
   double xs = (1.0 - x) * c->a[2] + x * c->b[2], Ps = 0.0;
+  double Pg = IS_WSGE(c->e) ? (1.0 - x) * c->a[3] + x * c->b[3] : 0.0;   /* eos_wsge.F90:1002-1036 */
   if (c->wr == 1) {
     if (c->halite) wo_halite_solubility(T, &xs);
     wo_brine_sat_pressure(c->e, T, xs, &Ps);
   } else th_sat_pressure(c->e, T, &Ps);
-  return P - Ps;
+  return P - Pg - Ps;
 }
 
 /* transition_to_single_phase :203-337 */
@@ -1129,19 +1221,26 @@ static int wse_to_single_phase(const wo_eos *e, const double *oldp, const double
   double bound = (nwr == 1) ? 0.0 : 1.0 - ss;
   double pfac = (nwr == 1) ? 1.0 + small : 1.0 - small;
   int err = 0;
+  const int gas = IS_WSGE(e);
+  if (gas) { /* eos_wsge.F90:222-226: salt and gas variables clipped before interpolating */
+    prim[2] = fmax(0.0, prim[2]);
+    prim[3] = fmax(0.0, fmin(prim[3], prim[0]));
+  }
   /* inverse linear interpolant on component 2 (src/interpolation.F90:407-435, :571-584) */
   double v1 = oldp[1], v2 = prim[1], vmax = fmax(fabs(v1), fabs(v2));
   if (fabs(v2 - v1) >= 1.e-8 * vmax) {
     double xi = (bound / vmax - v1 / vmax) / (v2 / vmax - v1 / vmax);
     double ip = lerp_clamped(xi, oldp[0], prim[0]), is = lerp_clamped(xi, oldp[2], prim[2]);
+    double ig = gas ? lerp_clamped(xi, oldp[3], prim[3]) : 0.0, ibp = ip - ig;   /* interpolated brine pressure */
     double t, xs;
-    prim[0] = pfac * ip;
-    prim[2] = fmax(0.0, is);
+    prim[0] = pfac * ibp + ig;
+    prim[2] = gas ? is : fmax(0.0, is);
+    if (gas) prim[3] = ig;
     if (nwr == 1) {
-      if (old_halite) err = wo_halite_solubility_two_phase(e, ip, &xs);
+      if (old_halite) err = wo_halite_solubility_two_phase(e, ibp, &xs);
       else xs = prim[2];
-      if (!err) err = wo_brine_sat_temperature(e, ip, xs, &t);
-    } else err = th_sat_temperature(e, ip, &t);
+      if (!err) err = wo_brine_sat_temperature(e, ibp, xs, &t);
+    } else err = th_sat_temperature(e, ibp, &t);
     if (!err) { prim[1] = t; fluid[F_REGION] = (double)new_region; *transition = 1; }
   } else {
     double xs, ps;
@@ -1151,7 +1250,7 @@ static int wse_to_single_phase(const wo_eos *e, const double *oldp, const double
       if (!err) { xs = fmax(0.0, xs); err = wo_brine_sat_pressure(e, old_fluid[F_T], xs, &ps); }
     } else err = th_sat_pressure(e, old_fluid[F_T], &ps);
     if (!err) {
-      prim[0] = pfac * ps;
+      prim[0] = pfac * ps + (gas ? prim[3] : 0.0);
       prim[1] = old_fluid[F_T];
       fluid[F_REGION] = (double)new_region;
       *transition = 1;
@@ -1160,7 +1259,7 @@ static int wse_to_single_phase(const wo_eos *e, const double *oldp, const double
   return err;
 }
 
-/* halite_transition :413-525 */
+/* halite_transition :413-525 (eos_wsge.F90:416-532: brine pressure = P - Pg) */
 static int wse_halite_transition(const wo_eos *e, const double *old_fluid, double *prim, double *fluid,
                                  int *transition, int err) {
   const double small = 1.e-6;
@@ -1169,7 +1268,7 @@ static int wse_halite_transition(const wo_eos *e, const double *old_fluid, doubl
   switch (region) {
   case 1: case 4:
     if (region == 1) t = prim[1];
-    else err = wo_brine_sat_temperature(e, prim[0], prim[2], &t);
+    else err = wo_brine_sat_temperature(e, prim[0] - (IS_WSGE(e) ? prim[3] : 0.0), prim[2], &t);
     if (!err) {
       err = wo_halite_solubility(t, &sol);
       if (prim[2] > sol) { prim[2] = small; fluid[F_REGION] = region + 4; *transition = 1; }
@@ -1187,7 +1286,7 @@ static int wse_halite_transition(const wo_eos *e, const double *old_fluid, doubl
         int cur_old = (int)lround(fluid[F_OLD_REGION]), last_old = (int)lround(old_fluid[F_OLD_REGION]);
         if (cur_old == 6 || last_old == 6) { prim[2] = small; fluid[F_REGION] = 4.0; *transition = 1; }
         else {
-          err = wo_halite_solubility_two_phase(e, prim[0], &sol);
+          err = wo_halite_solubility_two_phase(e, prim[0] - (IS_WSGE(e) ? prim[3] : 0.0), &sol);
           if (!err) { prim[2] = sol - small; fluid[F_REGION] = 4.0; *transition = 1; }
         }
       }
@@ -1222,17 +1321,22 @@ static int wse_transition(const wo_eos *e, const double *oldp, double *prim, con
       else xs = prim[2];
       if (!err) { xs = fmax(0.0, xs); err = wo_brine_sat_pressure(e, prim[1], xs, &ps); }
     } else err = th_sat_pressure(e, prim[1], &ps);
-    if (!err && ((owr == 1 && prim[0] < ps) || (owr == 2 && prim[0] > ps))) {
+    const int gas = IS_WSGE(e);
+    double pwat = prim[0] - (gas ? prim[3] : 0.0);
+    if (!err && ((owr == 1 && pwat < ps) || (owr == 2 && pwat > ps))) {
       int new_region = old_halite ? 8 : 4;
       prim[2] = fmax(0.0, prim[2]);
+      if (gas) prim[3] = fmax(0.0, fmin(prim[3], prim[0]));
       wse_line c = {oldp, prim, old_halite, owr, e};
       double root;
       int it;
       if (wo_brent(wse_satline_diff, &c, 0.0, 1.0, 1.e-8, 1.e-8, 100, &root, &it) == 0) {
         double ip = lerp_clamped(root, oldp[0], prim[0]), is = lerp_clamped(root, oldp[2], prim[2]);
+        double ig = gas ? lerp_clamped(root, oldp[3], prim[3]) : 0.0;
         prim[0] = ip;
         prim[2] = is;
-      } else prim[0] = ps;
+        if (gas) prim[3] = ig;
+      } else prim[0] = ps + (gas ? prim[3] : 0.0);
       double ss = old_halite ? prim[2] : 0.0;
       prim[1] = (owr == 1) ? small : 1.0 - ss - small;
       fluid[F_REGION] = (double)new_region;

@@ -145,3 +145,50 @@ def test_halite_permeability_modifiers(oracle):
     assert oracle.wo_permeability_factor(C.byref(e), 0.1 + 0.0) == 0.0
     e.perm_type = 0
     assert oracle.wo_permeability_factor(C.byref(e), 0.5) == 1.0
+
+
+def test_eos_wsge_transitions(oracle):
+    """the 33 cases of the reference's test_eos_wsge_transition (water + salt + gas: the wse cases
+    with Pg = 0 and with a gas partial pressure, where the water pressure P - Pg is what meets the
+    brine saturation line)"""
+    e = ol.Eos()
+    oracle.wo_eos_init(C.byref(e), 5)      # wsce
+    assert (e.np, e.nc, e.nph, e.nmob) == (4, 3, 3, 2)
+    for c in FX["eos_wsge_transition"]:
+        ofl, fl = np.zeros(e.df), np.zeros(e.df)
+        ofl[2], fl[2] = c["old_region"], c["region"]
+        ofl[1] = c.get("old_temperature", 0.0)
+        oldp, prim = np.array(c["old_primary"]), np.array(c["primary"])
+        tr = C.c_int(0)
+        err = oracle.wo_eos_transition(C.byref(e), ol.dp(oldp), ol.dp(prim), ol.dp(ofl), ol.dp(fl), C.byref(tr))
+        assert err == 0, c["title"]
+        assert bool(tr.value) == c["expected_transition"], c["title"]
+        assert int(fl[2]) == c["expected_region"], c["title"]
+        for a, b in zip(prim, c["expected_primary"]):
+            assert abs(a - b) <= 1e-6 * max(abs(b), 1e-12) + 1e-12, (c["title"], list(prim), c["expected_primary"])
+
+
+def test_eos_wsce_without_gas_is_eos_wse(oracle):
+    """test_eos_wsge_fluid_properties of the reference: with zero gas partial pressure the water +
+    salt + CO2 EOS gives the water + salt fluid (region 8 case above), gas mass fractions zero"""
+    c = FX["eos_wse_fluid_properties"]
+    recs = []
+    for kind in (3, 5):
+        e = ol.Eos()
+        oracle.wo_eos_init(C.byref(e), kind)
+        e.rp_type = ol.RP["linear"]
+        for k, v in enumerate([0.35, 1.0, 0.0, 0.7]):
+            e.rp_par[k] = v
+        fl = np.zeros(e.df)
+        fl[2] = 8
+        prim = np.array([c["pressure"], c["vapour_saturation"], c["solid_saturation"]] + ([0.0] if kind == 5 else []))
+        assert oracle.wo_eos_bulk_properties(C.byref(e), ol.dp(prim), ol.dp(fl)) == 0
+        assert oracle.wo_eos_phase_properties(C.byref(e), ol.dp(prim), ol.dp(fl)) == 0
+        recs.append((e.nc, fl))
+    (nc3, a), (nc5, b) = recs
+    assert abs(a[1] - b[1]) <= 1e-12 * a[1]           # temperature
+    for p in range(3):
+        pa, pb = a[7 + nc3 - 1 + p * (8 + nc3 - 1):], b[7 + nc5 - 1 + p * (8 + nc5 - 1):]
+        for q in range(7):          # density ... internal energy
+            assert abs(pa[q] - pb[q]) <= 1e-12 * max(abs(pa[q]), 1e-300), (p, q)
+        assert abs(pa[7] - pb[7]) <= 1e-14 and abs(pa[8] - pb[8]) <= 1e-14 and pb[9] == 0.0

@@ -18,12 +18,12 @@ def num(s):
 WSE = "/root/reference/test/unit/src/eos_wse_test.F90"
 
 
-def wse_transition_cases():
+def wse_transition_cases(path=None, name="test_eos_wse_transition", count=22):
     """the cases of test_eos_wse_transition (IAPWS-97 water side): region and temperature of the old
     fluid, old and new primaries, expected region / primaries / transition flag.  State set by one
     case and not reset stays in force for the next ones, as in the test."""
-    src = open(WSE).read()
-    body = src[src.index("subroutine test_eos_wse_transition"): src.index("end subroutine test_eos_wse_transition")]
+    src = open(path or WSE).read()
+    body = src[src.index("subroutine " + name): src.index("end subroutine " + name)]
     joined = []
     for ln in body.split("\n"):
         if joined and joined[-1].rstrip().endswith("&"):
@@ -62,7 +62,7 @@ def wse_transition_cases():
                 vals[key] = list(vals["expected_primary"]) if expr.strip() == "expected_primary" else [float(v) for v in ev(expr, env)]
         if s.startswith("call eos%transition"):
             cases.append(dict(vals))
-    assert len(cases) == 22
+    assert len(cases) == count, len(cases)
     return cases
 
 
@@ -110,6 +110,9 @@ def main():
     assert q == 48 and len(out["brine_saturation_pressure"]) == 20 and len(out["brine_viscosity"]) == 20
     out["eos_wse_transition"] = wse_transition_cases()
     out["eos_wse_fluid_properties"] = wse_fluid_case()
+    # water + salt + gas (src/eos_wsge.F90): four primaries, the fourth the gas partial pressure
+    out["eos_wsge_transition"] = wse_transition_cases(WSE.replace("eos_wse_test", "eos_wsge_test"),
+                                                      "test_eos_wsge_transition", 33)
     json.dump(out, open(OUT, "w"), indent=1)
     print("written", OUT, {k: len(v) for k, v in out.items() if isinstance(v, list)})
 
