@@ -151,6 +151,8 @@ int wo_air_properties(double partial_pressure, double t, double *rho, double *h)
 double wo_air_henrys_constant(double t);
 double wo_air_energy_solution(double t);
 double wo_air_mixture_viscosity(double water_viscosity, double t, double xg);
+/* Henry's constant and energy of solution of the EOS's gas (CO2: wce, wsce; air: wae, wsae) in brine */
+void wo_gas_henry_salt(const wo_eos *e, double t, double xs, double *henry, double *esol);
 /* salt thermodynamics, src/salt_thermodynamics.F90 (water side through e->thermo) */
 int wo_halite_solubility(double t, double *s);
 int wo_halite_solubility_two_phase(const wo_eos *e, double p, double *s);

@@ -1044,7 +1044,9 @@ int wo_brine_viscosity(const wo_eos *e, double t, double p, double xs, double *m
 static const double CO2_HENRY_SALT[5] = {1.19784e-1, -7.17823e-2, 4.93854e-2, -1.03826e-2, 1.08233e-3};
 static const double AIR_HENRY_SALT[2][5] = {{0.183369, -0.236905, 0.242438, -7.30134e-2, 8.58723e-3},
                                             {0.16218, -1.16909e-1, 5.55185e-2, -8.75443e-3, 9.91567e-4}};
-static void gas_henry_salt(const wo_eos *e, double t, double xs, double *henry, double *esol) {
+void wo_gas_henry_salt(const wo_eos *e, double t, double xs, double *henry, double *esol);
+#define gas_henry_salt wo_gas_henry_salt
+void wo_gas_henry_salt(const wo_eos *e, double t, double xs, double *henry, double *esol) {
   double m = salt_mole_fraction(xs), x = t / 100.0, tk = t + TC_K, deriv;
   if (GAS_IS_AIR(e)) {
     double hc[2], h = 0.0;
