@@ -30,7 +30,7 @@ extern "C" {
 
 typedef struct wai_ctx wai_ctx;
 
-enum { WAI_EOS_W = 0, WAI_EOS_WE = 1, WAI_EOS_WCE = 2, WAI_EOS_WSE = 3, WAI_EOS_WAE = 4 };  /* wse: water + salt + energy, src/eos_wse.F90; wae: water + air + energy, src/eos_wae.F90 */
+enum { WAI_EOS_W = 0, WAI_EOS_WE = 1, WAI_EOS_WCE = 2, WAI_EOS_WSE = 3, WAI_EOS_WAE = 4, WAI_EOS_WSCE = 5, WAI_EOS_WSAE = 6 };  /* wse: water + salt + energy, src/eos_wse.F90; wae: water + air + energy, src/eos_wae.F90; wsce / wsae: water + salt + CO2 / air + energy, src/eos_wsge.F90 (4 x 4 blocks) */
 /* time stepping methods (src/timestepper.F90:2262-2275 "beuler" | "bdf2" | "directss") */
 enum { WAI_METHOD_BEULER = 0, WAI_METHOD_BDF2 = 1, WAI_METHOD_DIRECTSS = 2 };
 enum { WAI_THERMO_IAPWS = 0, WAI_THERMO_IFC67 = 1 };

@@ -11,11 +11,12 @@ def make_case(dims=(8, 8, 8), brick=(4, 4, 4), eos="we", lens=False, sources=Tru
         # layer falls inside it (otherwise lens=True silently means no lens)
         spacing = (10.0, 10.0, 500.0 / dims[2]) if lens and dims[2] * 10.0 < 450.0 else (10.0, 10.0, 10.0)
     g = M.StructuredGrid(dims, spacing=spacing, brick=brick, part=part)
-    srcs = M.benchmark_sources(g, co2_fraction=0.05 if eos in ("wce", "wse", "wae") else 0.0) if sources else None   # wse: 5 % salt
+    srcs = M.benchmark_sources(g, co2_fraction=0.05 if eos in ("wce", "wse", "wae", "wsce", "wsae") else 0.0) if sources else None   # wse: 5 % salt
     bc = None
     if top_bc:
         bc = {"we": ([1.0e5, 20.0], 1), "w": ([1.0e5], 1), "wce": ([1.0e5, 20.0, 0.02e5], 1), "wae": ([1.0e5, 20.0, 0.02e5], 1),
-              "wse": ([1.0e5, 20.0, 0.05], 1)}[eos]
+              "wse": ([1.0e5, 20.0, 0.05], 1), "wsce": ([1.0e5, 20.0, 0.05, 0.02e5], 1),
+              "wsae": ([1.0e5, 20.0, 0.05, 0.02e5], 1)}[eos]
     rock = M.heterogeneous_rock(g.n_global) if hetero else None
     mspec = None
     if minc:  # fracture fraction 0.1, one matrix level, 3 planes, 50 m
@@ -34,6 +35,8 @@ def scaled(prim, region, eos="we"):
         if prim.shape[1] > 1:
             sc[r, 1] = 1.0e2 if r not in (4, 8) else 1.0
     out = prim / sc[region]
+    if eos in ("wsce", "wsae"):
+        out[:, 3] = prim[:, 3] / prim[:, 0]
     if eos in ("wce", "wae"):  # adaptive partial-pressure scaling Pg / P (src/eos_wge.F90:639-655)
         out[:, 2] = prim[:, 2] / prim[:, 0]
     return out

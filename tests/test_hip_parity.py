@@ -15,7 +15,7 @@ from tests.cases import make_case, scaled
 
 pytestmark = pytest.mark.gpu
 
-KIND = {"w": 0, "we": 1, "wce": 2, "wse": 3, "wae": 4}
+KIND = {"w": 0, "we": 1, "wce": 2, "wse": 3, "wae": 4, "wsce": 5, "wsae": 6}
 
 
 def relmax(a, b):
@@ -30,7 +30,7 @@ def FS():
 
 
 def build(FS, oracle, eos="we", dims=(8, 8, 8), brick=(4, 4, 4), lens=False, **kw):
-    if eos == "wse" and not lens:
+    if eos in ("wse", "wsce", "wsae") and not lens:
         # the shallow box with its 10 m cells and halite-bearing cells does not survive the wells'
         # rates with the denser, more viscous brine at any step size: salt case without wells here,
         # with wells in the (deeper, stretched) lens case
@@ -44,7 +44,7 @@ def build(FS, oracle, eos="we", dims=(8, 8, 8), brick=(4, 4, 4), lens=False, **k
     return g, lm, sim, osim, y, region
 
 
-@pytest.mark.parametrize("eos,lens", [("we", False), ("we", True), ("w", False), ("wce", False), ("wse", False), ("wse", True), ("wae", False)])
+@pytest.mark.parametrize("eos,lens", [("we", False), ("we", True), ("w", False), ("wce", False), ("wse", False), ("wse", True), ("wae", False), ("wsce", False), ("wsce", True), ("wsae", False)])
 def test_fluid_properties_and_residual(FS, oracle, eos, lens):
     g, lm, sim, osim, y, region = build(FS, oracle, eos=eos, lens=lens, dims=(10, 9, 8), brick=(4, 4, 4))
     n = sim.n_owned * sim.num_primary_variables
@@ -70,7 +70,7 @@ def test_fluid_properties_and_residual(FS, oracle, eos, lens):
     sim.destroy(); osim.close()
 
 
-@pytest.mark.parametrize("eos,lens", [("we", False), ("we", True), ("w", False), ("wce", False), ("wse", False), ("wse", True), ("wae", False)])
+@pytest.mark.parametrize("eos,lens", [("we", False), ("we", True), ("w", False), ("wce", False), ("wse", False), ("wse", True), ("wae", False), ("wsce", False), ("wsce", True), ("wsae", False)])
 def test_jacobian(FS, oracle, eos, lens):
     g, lm, sim, osim, y, region = build(FS, oracle, eos=eos, lens=lens)
     bs = sim.num_primary_variables
@@ -98,8 +98,8 @@ def test_jacobian(FS, oracle, eos, lens):
         # eos wse: the two-phase temperature comes out of a nested Newton solve stopped at 1e-10 P
         # (brine_saturation_temperature), so a difference over h ~ 1e-8 carries its rounding 1e4
         # times amplified, differently on the two paths
-        tol = 1e-3 if (eos == "wse" and lens) else 1e-5
-        if eos == "wae":   # the air balance of single-phase liquid holds ~1e-5 kg/m3 of dissolved air: its
+        tol = 1e-3 if (eos in ("wse", "wsce") and lens) else 1e-5
+        if eos in ("wae", "wsae"):   # the air balance of single-phase liquid holds ~1e-5 kg/m3 of dissolved air: its
             tol = 2e-4     # rows are differences of nearly equal small numbers, rounding shows at 5e-5
         assert (np.abs(Jg[:, r, :] - Jo[:, r, :]) / np.maximum(sc, 1e-300)).max() < tol
     sim.destroy(); osim.close()
@@ -203,7 +203,7 @@ def test_transitions(FS, oracle):
     sim.destroy(); osim.close()
 
 
-@pytest.mark.parametrize("eos,lens", [("we", False), ("we", True), ("w", False), ("wce", False), ("wse", False), ("wse", True), ("wae", False)])
+@pytest.mark.parametrize("eos,lens", [("we", False), ("we", True), ("w", False), ("wce", False), ("wse", False), ("wse", True), ("wae", False), ("wsce", False), ("wsce", True), ("wsae", False)])
 def test_timesteps(FS, oracle, eos, lens):
     """Backward-Euler steps (SNESSolve): Newton / Krylov iteration counts and the step solution
     against the oracle, with both paths solved tightly (KSP rtol 1e-10, function tol 1e-9)."""
@@ -212,7 +212,8 @@ def test_timesteps(FS, oracle, eos, lens):
     o = osim.opts()
     o.ksp_rtol, o.ftol_rel = 1e-10, 1e-9
     yg, yo = y.copy(), osim.yvec(y)
-    dt = {"wce": 5.0e2, "wae": 5.0e2, "wse": 5.0e1 if lens else 5.0e2}.get(eos, 1.0e4)   # CO2 / salt injection needs the smaller first steps
+    dt = {"wce": 5.0e2, "wae": 5.0e2, "wse": 5.0e1 if lens else 5.0e2, "wsce": 5.0e1 if lens else 5.0e2,
+          "wsae": 5.0e2}.get(eos, 1.0e4)   # CO2 / salt injection needs the smaller first steps
     for step in range(4):
         reason, nits, kits = sim.timestep(0.0, dt, yg)
         r, ok = osim.timestep(yo, dt, o)

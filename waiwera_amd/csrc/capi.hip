@@ -555,6 +555,7 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
   else if (c->kind == WAI_EOS_WCE) { c->np = 3; c->df = 26; }
   else if (c->kind == WAI_EOS_WSE) { c->np = 3; c->df = 35; }
   else if (c->kind == WAI_EOS_WAE) { c->np = 3; c->df = 26; }
+  else if (c->kind == WAI_EOS_WSCE || c->kind == WAI_EOS_WSAE) { c->np = 4; c->df = 39; }
   else { c->err = "unsupported eos kind"; return -2; }
   std::memset(&c->ep, 0, sizeof(c->ep));
   c->ep.temperature = ed->temperature;
@@ -566,10 +567,13 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
   // eos.primary.scale.partial_pressure: absent/<= 0 = adaptive Pg/P (eos_wge.F90:95-104)
   const double gs = ed->partial_pressure_scale > 0 ? ed->partial_pressure_scale : 0.0;
   c->ep.scale[1][2] = gs; c->ep.scale[2][2] = gs; c->ep.scale[4][2] = gs;
-  if (c->kind == WAI_EOS_WSE) {   // eos_wse.F90:155-165: regions 5, 6, 8 scale like 1, 2, 4; salt variable unscaled
+  if (c->kind == WAI_EOS_WSE || c->kind == WAI_EOS_WSCE || c->kind == WAI_EOS_WSAE) {
+    // eos_wse.F90:155-165, eos_wsge.F90:118-140: regions 5, 6, 8 scale like 1, 2, 4; salt variable
+    // unscaled; gas partial pressure (4th) adaptive Pg / P unless a scale is given
     for (int r : {1, 2, 4}) {
       c->ep.scale[r][2] = 1.0;
-      for (int k = 0; k < 3; k++) c->ep.scale[r + 4][k] = c->ep.scale[r][k];
+      c->ep.scale[r][3] = gs;
+      for (int k = 0; k < 4; k++) c->ep.scale[r + 4][k] = c->ep.scale[r][k];
     }
   }
   c->ep.rp_type = ed->rp_type; c->ep.cp_type = ed->cp_type;
@@ -874,7 +878,7 @@ int wai_set_bc(wai_ctx* c, const double* primary, const int* region) {
   std::vector<double> reg(nb), ys((size_t)(first + nb) * np, 0.0);
   for (int b = 0; b < nb; b++) {
     const int rg = region[b];
-    const int rmax = c->kind == WAI_EOS_WSE ? 8 : 4;
+    const int rmax = (c->kind == WAI_EOS_WSE || c->kind == WAI_EOS_WSCE || c->kind == WAI_EOS_WSAE) ? 8 : 4;
     if (rg < 1 || rg > rmax || rg == 3 || rg == 7) { c->err = "bad bc region"; return -2; }
     reg[b] = (double)rg;
     for (int k = 0; k < np; k++) {

@@ -552,8 +552,8 @@ __global__ __launch_bounds__(TPB) void k_transitions(EosParams ep, int n_owned,
   flu[F_OLD_REGION * stride + c] = (double)region;
   bool transition = false, changed = false;
   int err;
-  if constexpr (KIND == EOS_WSE)
-    err = eos_transition_wse(ep.thermo, oldp, prim, old_region, old_t, region,
+  if constexpr (is_salt<KIND>)
+    err = eos_transition_wse<is_wsge<KIND>>(ep.thermo, oldp, prim, old_region, old_t, region,
                              (int)flu_old[F_OLD_REGION * stride + c], region, transition);
   else
     err = eos_transition<KIND>(ep.thermo, oldp, prim, old_region, old_t, region, transition);
@@ -650,6 +650,8 @@ static inline int grid8_for(size_t n) { return ((grid_for(n) + 7) / 8) * 8; }  /
     else if ((c)->kind == EOS_WE) hipLaunchKernelGGL(KERNEL<EOS_WE>, grid, TPB, 0, (c)->stream, __VA_ARGS__); \
     else if ((c)->kind == EOS_WSE) hipLaunchKernelGGL(KERNEL<EOS_WSE>, grid, TPB, 0, (c)->stream, __VA_ARGS__); \
     else if ((c)->kind == EOS_WAE) hipLaunchKernelGGL(KERNEL<EOS_WAE>, grid, TPB, 0, (c)->stream, __VA_ARGS__); \
+    else if ((c)->kind == EOS_WSCE) hipLaunchKernelGGL(KERNEL<EOS_WSCE>, grid, TPB, 0, (c)->stream, __VA_ARGS__); \
+    else if ((c)->kind == EOS_WSAE) hipLaunchKernelGGL(KERNEL<EOS_WSAE>, grid, TPB, 0, (c)->stream, __VA_ARGS__); \
     else hipLaunchKernelGGL(KERNEL<EOS_WCE>, grid, TPB, 0, (c)->stream, __VA_ARGS__);                         \
   } while (0)
 

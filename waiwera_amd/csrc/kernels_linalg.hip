@@ -1342,6 +1342,7 @@ int launch_spmv(wai_ctx* c, const double* x, double* y) {
     case 1: hipLaunchKernelGGL(k_spmv<1>, grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, x, y); break;
     case 2: hipLaunchKernelGGL(k_spmv<2>, grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, x, y); break;
     case 3: hipLaunchKernelGGL(k_spmv<3>, grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, x, y); break;
+    case 4: hipLaunchKernelGGL(k_spmv<4>, grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, x, y); break;
     default: return -1;
   }
   return 0;
@@ -1360,6 +1361,7 @@ int launch_ilu_factor(wai_ctx* c) {
       case 1: hipLaunchKernelGGL(k_dilu_pivots<1>, grid, T, lds, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.dinv, c->d_flags); break;
       case 2: hipLaunchKernelGGL(k_dilu_pivots<2>, grid, T, lds, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.dinv, c->d_flags); break;
       case 3: hipLaunchKernelGGL(k_dilu_pivots<3>, grid, T, lds, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.dinv, c->d_flags); break;
+      case 4: hipLaunchKernelGGL(k_dilu_pivots<4>, grid, T, lds, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.dinv, c->d_flags); break;
       default: return -1;
     }
   } else {
@@ -1368,6 +1370,7 @@ int launch_ilu_factor(wai_ctx* c) {
     case 1: hipLaunchKernelGGL(k_ilu_factor<1>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
     case 2: hipLaunchKernelGGL(k_ilu_factor<2>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
     case 3: hipLaunchKernelGGL(k_ilu_factor<3>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
+    case 4: hipLaunchKernelGGL(k_ilu_factor<4>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
     default: return -1;
   }
   }
@@ -1377,6 +1380,7 @@ int launch_ilu_factor(wai_ctx* c) {
       case 1: hipLaunchKernelGGL(k_scale_rows<1>, g, TPB, 0, c->stream, J.n, J.W, J.val, s.dinv, s.fval); break;
       case 2: hipLaunchKernelGGL(k_scale_rows<2>, g, TPB, 0, c->stream, J.n, J.W, J.val, s.dinv, s.fval); break;
       case 3: hipLaunchKernelGGL(k_scale_rows<3>, g, TPB, 0, c->stream, J.n, J.W, J.val, s.dinv, s.fval); break;
+      case 4: hipLaunchKernelGGL(k_scale_rows<4>, g, TPB, 0, c->stream, J.n, J.W, J.val, s.dinv, s.fval); break;
       default: return -1;
     }
   }
@@ -1453,6 +1457,7 @@ int launch_pc(wai_ctx* c, bool spmv, const double* in, double* z, int dot_mode, 
     case 1: launch_pc_bs<1>(c, spmv, in, z, dot_mode, aux); break;
     case 2: launch_pc_bs<2>(c, spmv, in, z, dot_mode, aux); break;
     case 3: launch_pc_bs<3>(c, spmv, in, z, dot_mode, aux); break;
+    case 4: launch_pc_bs<4>(c, spmv, in, z, dot_mode, aux); break;
     default: return -1;
   }
   return 0;

@@ -17,9 +17,14 @@
 
 namespace wai {
 
-enum { EOS_W = 0, EOS_WE = 1, EOS_WCE = 2, EOS_WSE = 3, EOS_WAE = 4 };
+enum { EOS_W = 0, EOS_WE = 1, EOS_WCE = 2, EOS_WSE = 3, EOS_WAE = 4, EOS_WSCE = 5, EOS_WSAE = 6 };
 // water + non-condensible gas + energy (eos_wge.F90): CO2 (eos_wce.F90) or air (eos_wae.F90)
 template <int KIND> constexpr bool is_wge = (KIND == EOS_WCE || KIND == EOS_WAE);
+// salt family: water + salt + energy (eos_wse.F90), and with a gas as a third component and fourth
+// primary (eos_wsge.F90: wsce, wsae)
+template <int KIND> constexpr bool is_wsge = (KIND == EOS_WSCE || KIND == EOS_WSAE);
+template <int KIND> constexpr bool is_salt = (KIND == EOS_WSE || is_wsge<KIND>);
+template <int KIND> constexpr bool gas_is_air = (KIND == EOS_WAE || KIND == EOS_WSAE);
 enum { RP_FULLY_MOBILE = 0, RP_LINEAR = 1, RP_PICKENS = 2, RP_COREY = 3, RP_GRANT = 4,
        RP_VAN_GENUCHTEN = 5 };
 enum { CP_ZERO = 0, CP_LINEAR = 1, CP_VAN_GENUCHTEN = 2 };
@@ -54,10 +59,19 @@ template <> struct EosT<EOS_WSE> {  // water + salt + energy (eos_wse.F90): thir
   static constexpr bool isothermal = false;
 };
 
+template <> struct EosT<EOS_WSCE> {  // water + salt + CO2 + energy (eos_wsge.F90 + eos_wsce.F90): 4 x 4 blocks
+  static constexpr int np = 4, nc = 3, nph = 3, nmob = 2, df = 39, f_phase0 = 9, ph_dof = 10;
+  static constexpr bool isothermal = false;
+};
+template <> struct EosT<EOS_WSAE> {  // water + salt + air + energy (eos_wsae.F90)
+  static constexpr int np = 4, nc = 3, nph = 3, nmob = 2, df = 39, f_phase0 = 9, ph_dof = 10;
+  static constexpr bool isothermal = false;
+};
+
 // run-time EOS parameters (kernel argument, lives in SGPRs / constant cache)
 struct EosParams {
   double temperature;     // eos_w
-  double scale[9][3];     // primary_scale(var, region)  (eos_we.F90:104-109; eos_wse: regions 1..8); a zero partial-
+  double scale[9][4];     // primary_scale(var, region)  (eos_we.F90:104-109; eos_wse: regions 1..8); a zero partial-
                           // pressure scale selects adaptive scaling Pg/P (eos_wge.F90:639-674)
   int rp_type, cp_type;
   double rp_par[6], cp_par[6];
@@ -284,6 +298,39 @@ __device__ inline double mixture_viscosity(double water_viscosity, double t, dou
 }
 }  // namespace air
 
+// Henry's constant and energy of solution of the gas in brine (henrys_constant_salt,
+// henrys_derivative_salt, ncg_energy_solution_salt: ncg_co2_thermodynamics.F90:139-232,
+// ncg_air_thermodynamics.F90:141-238, ncg_thermodynamics.F90:187-261)
+template <bool AIR>
+__device__ inline void gas_henry_salt(double t, double xs, double& henry, double& esol) {
+  const double m = 1.0e3 * xs / (58.443 * (1.0 - xs)), x = t / 100.0, tk = t + if97::TC_K;
+  if constexpr (AIR) {
+    const double w[2] = {0.79, 0.21};
+    const double ks[2][5] = {{0.183369, -0.236905, 0.242438, -7.30134e-2, 8.58723e-3},
+                             {0.16218, -1.16909e-1, 5.55185e-2, -8.75443e-3, 9.91567e-4}};
+    double hc[2], d0[2], h = 0.0, deriv = 0.0;
+    air::henry_constituents(t, hc, d0);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const double kb = ks[i][0] + x * (ks[i][1] + x * (ks[i][2] + x * (ks[i][3] + x * ks[i][4])));
+      const double dkb = ks[i][1] + x * (2.0 * ks[i][2] + x * (3.0 * ks[i][3] + x * 4.0 * ks[i][4]));
+      h += w[i] * hc[i] * pow(10.0, m * kb);
+      deriv += w[i] * (d0[i] + log(10.0) * m * (dkb / 100.0));
+    }
+    henry = h;
+    esol = -1.e3 * air::GAS_CONSTANT * tk * tk * deriv / air::MW;
+  } else {
+    const double ks[5] = {1.19784e-1, -7.17823e-2, 4.93854e-2, -1.03826e-2, 1.08233e-3};
+    const double h0 = co2::henrys_constant(t);
+    const double kb = ks[0] + x * (ks[1] + x * (ks[2] + x * (ks[3] + x * ks[4])));
+    const double dkb = ks[1] + x * (2.0 * ks[2] + x * (3.0 * ks[3] + x * 4.0 * ks[4]));
+    const double dpoly = 1.96025 + x * (2.0 * 8.20574 + x * (3.0 * -7.40674 + x * (4.0 * 2.18380 + x * (5.0 * -0.220999))));
+    const double deriv = 1.e8 * dpoly / (h0 * 100.0) + log(10.0) * m * (dkb / 100.0);
+    henry = h0 * pow(10.0, m * kb);
+    esol = -1.e3 * co2::GAS_CONSTANT * tk * tk * deriv / co2::MW;
+  }
+}
+
 // eos%unscale / eos%scale (eos.F90:186-210; adaptive third variable eos_wge.F90:639-674)
 template <int KIND>
 __device__ __forceinline__ void eos_unscale(const EosParams& e, const double* y, int region, double* prim) {
@@ -291,6 +338,7 @@ __device__ __forceinline__ void eos_unscale(const EosParams& e, const double* y,
 #pragma unroll
   for (int k = 0; k < E::np; k++) prim[k] = y[k] * e.scale[region][k];
   if constexpr (is_wge<KIND>) { if (e.scale[region][2] == 0.0) prim[2] = y[2] * prim[0]; }
+  if constexpr (is_wsge<KIND>) { if (e.scale[region][3] == 0.0) prim[3] = y[3] * prim[0]; }   // eos_wsge.F90:984-998
 }
 template <int KIND>
 __device__ __forceinline__ void eos_scale(const EosParams& e, const double* prim, int region, double* y) {
@@ -298,6 +346,7 @@ __device__ __forceinline__ void eos_scale(const EosParams& e, const double* prim
 #pragma unroll
   for (int k = 0; k < E::np; k++) y[k] = prim[k] / e.scale[region][k];
   if constexpr (is_wge<KIND>) { if (e.scale[region][2] == 0.0) y[2] = prim[2] / prim[0]; }
+  if constexpr (is_wsge<KIND>) { if (e.scale[region][3] == 0.0) y[3] = prim[3] / prim[0]; }   // eos_wsge.F90:962-980
 }
 
 // eos_wse: mixture region -> water region / halite presence (eos_wse.F90:131-134)
@@ -350,19 +399,24 @@ __device__ __forceinline__ int eos_eval(const EosParams& e, const double* y, int
     s.mu[0] = th::viscosity(e.thermo, region == 1 ? 1 : 2, s.T, s.P, rho);
     s.x[0][0] = 1.0; s.pp[0] = s.P;
     return 0;
-  } else if constexpr (KIND == EOS_WSE) {
-    // eos_wse_bulk_properties / phase_saturations / phase_properties (eos_wse.F90:645-857);
-    // permeability modifier "none" (fluid.F90:588-596)
+  } else if constexpr (is_salt<KIND>) {
+    // eos_wse_bulk_properties / phase_saturations / phase_properties (eos_wse.F90:645-857), with a
+    // gas eos_wsge.F90:625-852: brine pressure = P - Pg, components water, salt, gas
+    constexpr bool gas = is_wsge<KIND>;
     const int wr = wse_water_region(region);
     const bool halite = wse_halite(region);
-    double prim[3];
+    double prim[E::np];
     eos_unscale<KIND>(e, y, region, prim);
     s.P = prim[0];
-    s.pp[0] = s.P; s.pp[1] = 0.0;
+    double pg = 0.0;
+    if constexpr (gas) pg = prim[3];
+    const double pw = s.P - pg;
+    s.pp[0] = pw; s.pp[1] = 0.0;
+    if constexpr (gas) s.pp[2] = pg;
     if (wr == 4) {
       double xs2 = prim[2], t;
-      if (region != 4) { if (salt::halite_solubility_two_phase(e.thermo, s.P, xs2)) return 1; }
-      if (salt::brine_sat_temperature(e.thermo, s.P, xs2, t)) return 1;
+      if (region != 4) { if (salt::halite_solubility_two_phase(e.thermo, pw, xs2)) return 1; }
+      if (salt::brine_sat_temperature(e.thermo, pw, xs2, t)) return 1;
       s.T = t;
     } else s.T = prim[1];
     const int ph = th::phase_composition(e.thermo, wr, s.P, s.T);
@@ -381,33 +435,70 @@ __device__ __forceinline__ int eos_eval(const EosParams& e, const double* y, int
     double kl, kv;
     relperm(e, sle, kl, kv);
     const double pcl = capillary(e, sle);
+    double gas_rho = 0.0, gas_h = 0.0;
+    if constexpr (gas) {
+      if constexpr (gas_is_air<KIND>) air::properties(pg, s.T, gas_rho, gas_h);
+      else co2::properties(pg, s.T, gas_rho, gas_h);
+    }
 #pragma unroll
     for (int p = 0; p < 2; p++) {
       if (ph & (1 << p)) {
-        double rho, u;
-        const int err = (p == 0) ? salt::brine_properties(e.thermo, s.P, s.T, xs, rho, u)
-                                 : th::props(e.thermo, 2, s.P, s.T, rho, u);
+        double rho, u, mu;
+        const double bp = (p == 0 || !gas) ? s.P : pw;
+        const int err = (p == 0) ? salt::brine_properties(e.thermo, bp, s.T, xs, rho, u)
+                                 : th::props(e.thermo, 2, bp, s.T, rho, u);
         if (err) return err;
         const double xp = (p == 0) ? xs : 0.0;
-        s.rho[p] = rho; s.u[p] = u; s.h[p] = u + s.P / rho;
-        s.x[p][0] = 1.0 - xp; s.x[p][1] = xp;
+        if (p == 0) { if (salt::brine_viscosity(e.thermo, s.T, s.P, xs, mu)) return 1; }
+        else mu = th::viscosity(e.thermo, 2, s.T, s.P, rho);
+        double xg = 0.0, grho = 0.0, esol = 0.0;
+        if constexpr (gas) {
+          if (p == 0) {
+            double henry;
+            gas_henry_salt<gas_is_air<KIND>>(s.T, xs, henry, esol);
+            xg = gas_is_air<KIND> ? air::mole_to_mass(pg / henry) : co2::mole_to_mass(pg / henry);
+          } else {
+            grho = gas_rho;
+            const double tot = grho + rho;
+            xg = (tot < 1.e-30) ? 0.0 : grho / tot;
+            if constexpr (gas_is_air<KIND>) mu = air::mixture_viscosity(mu, s.T, xg);
+            else {
+              double gmu;
+              if (co2::viscosity(pg, s.T, gmu)) return 1;
+              mu = mu * (1.0 - xg) + gmu * xg;
+            }
+          }
+        }
+        s.mu[p] = mu;
+        s.rho[p] = rho + grho;
+        s.x[p][0] = 1.0 - xp - xg; s.x[p][1] = xp;
+        if constexpr (gas) s.x[p][2] = xg;
         s.kr[p] = (p == 0) ? kl : kv;
         s.pc[p] = (p == 0) ? pcl : 0.0;
-        if (p == 0) { if (salt::brine_viscosity(e.thermo, s.T, s.P, xs, s.mu[p])) return 1; }
-        else s.mu[p] = th::viscosity(e.thermo, 2, s.T, s.P, rho);
+        const double bh = u + bp / rho;
+        if constexpr (gas) {
+          s.h[p] = bh * (1.0 - xg) + (gas_h + esol) * xg;
+          s.u[p] = s.h[p] - s.P / s.rho[p];
+        } else {
+          s.h[p] = bh;
+          s.u[p] = u;
+        }
       } else {
         s.rho[p] = 0.0; s.u[p] = 0.0; s.h[p] = 0.0; s.kr[p] = 0.0; s.pc[p] = 0.0; s.mu[p] = 0.0;
-        s.x[p][0] = 0.0; s.x[p][1] = 0.0;
+#pragma unroll
+        for (int q = 0; q < E::nc; q++) s.x[p][q] = 0.0;
       }
     }
     s.kr[2] = 0.0; s.pc[2] = 0.0; s.mu[2] = 0.0;
+#pragma unroll
+    for (int q = 0; q < E::nc; q++) s.x[2][q] = 0.0;
     if (halite || region == 2) {
       double rho, u;
       salt::halite_properties(s.P, s.T, rho, u);
       s.rho[2] = rho; s.u[2] = u; s.h[2] = u + s.P / rho;
-      s.x[2][0] = 0.0; s.x[2][1] = 1.0;
+      s.x[2][1] = 1.0;
     } else {
-      s.rho[2] = 0.0; s.u[2] = 0.0; s.h[2] = 0.0; s.x[2][0] = 0.0; s.x[2][1] = 0.0;
+      s.rho[2] = 0.0; s.u[2] = 0.0; s.h[2] = 0.0;
     }
     return 0;
   } else if constexpr (is_wge<KIND>) {
@@ -935,6 +1026,7 @@ __device__ inline int eos_transition(int thermo, const double* oldp, double* pri
 // line, then halite precipitation / dissolution.  cur_old_region = the cell's region on entry
 // (fluid%old_region as set by flow_simulation.F90:2502), last_old_region = that field of the
 // last-iteration fluid.
+template <bool GAS>
 __device__ inline int wse_to_single_phase(int thermo, const double* oldp, double* prim, int old_region,
                                           double old_t, int new_region, int& region, bool& transition) {
   const double small = 1.e-6;
@@ -944,18 +1036,26 @@ __device__ inline int wse_to_single_phase(int thermo, const double* oldp, double
   const double bound = (nwr == 1) ? 0.0 : 1.0 - ss;
   const double pfac = (nwr == 1) ? 1.0 + small : 1.0 - small;
   int err = 0;
+  if constexpr (GAS) {   // eos_wsge.F90:222-226
+    prim[2] = fmax(0.0, prim[2]);
+    prim[3] = fmax(0.0, fmin(prim[3], prim[0]));
+  }
   const double v1 = oldp[1], v2 = prim[1], vmax = fmax(fabs(v1), fabs(v2));
   if (fabs(v2 - v1) >= 1.e-8 * vmax) {
     const double xi = (bound / vmax - v1 / vmax) / (v2 / vmax - v1 / vmax);
     const double ip = lerp_clamped(xi, oldp[0], prim[0]), is = lerp_clamped(xi, oldp[2], prim[2]);
+    double ig = 0.0;
+    if constexpr (GAS) ig = lerp_clamped(xi, oldp[3], prim[3]);
+    const double ibp = ip - ig;   // interpolated brine pressure
     double t, xs;
-    prim[0] = pfac * ip;
-    prim[2] = fmax(0.0, is);
+    prim[0] = pfac * ibp + ig;
+    prim[2] = GAS ? is : fmax(0.0, is);
+    if constexpr (GAS) prim[3] = ig;
     if (nwr == 1) {
-      if (old_halite) err = salt::halite_solubility_two_phase(thermo, ip, xs);
+      if (old_halite) err = salt::halite_solubility_two_phase(thermo, ibp, xs);
       else xs = prim[2];
-      if (!err) err = salt::brine_sat_temperature(thermo, ip, xs, t);
-    } else err = th::sat_temperature(thermo, ip, t);
+      if (!err) err = salt::brine_sat_temperature(thermo, ibp, xs, t);
+    } else err = th::sat_temperature(thermo, ibp, t);
     if (!err) { prim[1] = t; region = new_region; transition = true; }
   } else {
     double xs, ps;
@@ -964,11 +1064,16 @@ __device__ inline int wse_to_single_phase(int thermo, const double* oldp, double
       else xs = oldp[2];
       if (!err) { xs = fmax(0.0, xs); err = salt::brine_sat_pressure(thermo, old_t, xs, ps); }
     } else err = th::sat_pressure(thermo, old_t, ps);
-    if (!err) { prim[0] = pfac * ps; prim[1] = old_t; region = new_region; transition = true; }
+    if (!err) {
+      double pgk = 0.0;
+      if constexpr (GAS) pgk = prim[3];
+      prim[0] = pfac * ps + pgk; prim[1] = old_t; region = new_region; transition = true;
+    }
   }
   return err;
 }
 
+template <bool GAS>
 __device__ inline int eos_transition_wse(int thermo, const double* oldp, double* prim, int old_region,
                                          double old_t, int cur_old_region, int last_old_region,
                                          int& region, bool& transition) {
@@ -980,10 +1085,10 @@ __device__ inline int eos_transition_wse(int thermo, const double* oldp, double*
   if (owr == 4) {
     const int off = old_halite ? 4 : 0;
     const double sv = prim[1];
-    if (sv < 0.0) err = wse_to_single_phase(thermo, oldp, prim, old_region, old_t, off + 1, region, transition);
+    if (sv < 0.0) err = wse_to_single_phase<GAS>(thermo, oldp, prim, old_region, old_t, off + 1, region, transition);
     else {
       const double ss = old_halite ? prim[2] : 0.0;
-      if (sv > 1.0 - ss) err = wse_to_single_phase(thermo, oldp, prim, old_region, old_t, off + 2, region, transition);
+      if (sv > 1.0 - ss) err = wse_to_single_phase<GAS>(thermo, oldp, prim, old_region, old_t, off + 2, region, transition);
     }
   } else {
     double xs, ps;
@@ -992,8 +1097,12 @@ __device__ inline int eos_transition_wse(int thermo, const double* oldp, double*
       else xs = prim[2];
       if (!err) { xs = fmax(0.0, xs); err = salt::brine_sat_pressure(thermo, prim[1], xs, ps); }
     } else err = th::sat_pressure(thermo, prim[1], ps);
-    if (!err && ((owr == 1 && prim[0] < ps) || (owr == 2 && prim[0] > ps))) {
+    double pwat = prim[0];
+    if constexpr (GAS) pwat -= prim[3];
+    if (!err && ((owr == 1 && pwat < ps) || (owr == 2 && pwat > ps))) {
       prim[2] = fmax(0.0, prim[2]);
+      double a3 = 0.0, b3 = 0.0;
+      if constexpr (GAS) { prim[3] = fmax(0.0, fmin(prim[3], prim[0])); a3 = oldp[3]; b3 = prim[3]; }
       const double a0 = oldp[0], a1 = oldp[1], a2 = oldp[2], b0 = prim[0], b1 = prim[1], b2 = prim[2];
       double root;
       const int rerr = brent_unit([&](double x) {   // eos_wse_saturation_difference :942-974
@@ -1003,12 +1112,13 @@ __device__ inline int eos_transition_wse(int thermo, const double* oldp, double*
           if (old_halite) salt::halite_solubility(T, xq);
           salt::brine_sat_pressure(thermo, T, xq, Ps);
         } else th::sat_pressure(thermo, T, Ps);
-        return P - Ps;
+        return P - ((1.0 - x) * a3 + x * b3) - Ps;   // eos_wsge.F90:1002-1036
       }, root);
       if (rerr == 0) {
         prim[0] = lerp_clamped(root, a0, b0);
         prim[2] = lerp_clamped(root, a2, b2);
-      } else prim[0] = ps;
+        if constexpr (GAS) prim[3] = lerp_clamped(root, a3, b3);
+      } else prim[0] = ps + b3;
       const double ss = old_halite ? prim[2] : 0.0;
       prim[1] = (owr == 1) ? small : 1.0 - ss - small;
       region = old_halite ? 8 : 4;
@@ -1021,7 +1131,11 @@ __device__ inline int eos_transition_wse(int thermo, const double* oldp, double*
   switch (region) {
     case 1: case 4:
       if (region == 1) t = prim[1];
-      else err = salt::brine_sat_temperature(thermo, prim[0], prim[2], t);
+      else {
+        double bpk = prim[0];
+        if constexpr (GAS) bpk -= prim[3];
+        err = salt::brine_sat_temperature(thermo, bpk, prim[2], t);
+      }
       if (!err) {
         err = salt::halite_solubility(t, sol);
         if (prim[2] > sol) { prim[2] = small; region += 4; transition = true; }
@@ -1038,7 +1152,9 @@ __device__ inline int eos_transition_wse(int thermo, const double* oldp, double*
         } else if (cur_old_region == 6 || last_old_region == 6) {
           prim[2] = small; region = 4; transition = true;
         } else {
-          err = salt::halite_solubility_two_phase(thermo, prim[0], sol);
+          double bpk = prim[0];
+          if constexpr (GAS) bpk -= prim[3];
+          err = salt::halite_solubility_two_phase(thermo, bpk, sol);
           if (!err) { prim[2] = sol - small; region = 4; transition = true; }
         }
       }
@@ -1055,6 +1171,19 @@ __device__ inline int eos_transition_wse(int thermo, const double* oldp, double*
 template <int KIND>
 __device__ __forceinline__ int eos_check_primary(double* prim, int region, bool& changed) {
   changed = false;
+  if constexpr (is_wsge<KIND>) {   // eos_wsge.F90:890-958
+    const double small = 1.e-6;
+    if (!(prim[0] > 0.0)) return 1;
+    const double maxpp = (1.0 - small) * prim[0];
+    if (prim[3] > maxpp) { prim[3] = maxpp; changed = true; }
+    else if (prim[3] < 0.0) { prim[3] = 0.0; changed = true; }
+    if (prim[2] < 0.0) { prim[2] = 0.0; changed = true; }
+    else if (prim[2] > 1.0) return 1;
+    if (prim[0] - prim[3] > 100.e6) return 1;
+    if (wse_water_region(region) == 4) { if (prim[1] < -1.0 || prim[1] > 2.0) return 1; }
+    else if (prim[1] < 0.0 || prim[1] > 800.0) return 1;
+    return 0;
+  }
   if constexpr (KIND == EOS_WSE) {   // eos_wse.F90:891-938
     if (prim[2] < 0.0) { prim[2] = 0.0; changed = true; }
     else if (prim[2] > 1.0) return 1;

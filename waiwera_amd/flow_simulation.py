@@ -150,6 +150,9 @@ class FlowSimulation:
         out = prim / sc[np.asarray(region)]
         if self.eos_name in ("wce", "wae") and self.eos_desc.partial_pressure_scale <= 0:
             out[..., 2] = prim[..., 2] / prim[..., 0]  # adaptive Pg / P (eos_wge.F90:639-655)
+        if self.eos_name in ("wsce", "wsae"):           # 4th primary: Pg / P, or Pg over its scale
+            ppsc = self.eos_desc.partial_pressure_scale
+            out[..., 3] = prim[..., 3] / (prim[..., 0] if ppsc <= 0 else ppsc)
         return out
 
     # ---- ode_type hooks ------------------------------------------------------------------------

@@ -16,7 +16,7 @@ module waiwera_hip_module
   private
 
   integer, parameter, public :: dp = c_double
-  integer(c_int), parameter, public :: WAI_EOS_W = 0, WAI_EOS_WE = 1, WAI_EOS_WCE = 2, WAI_EOS_WSE = 3, WAI_EOS_WAE = 4
+  integer(c_int), parameter, public :: WAI_EOS_W = 0, WAI_EOS_WE = 1, WAI_EOS_WCE = 2, WAI_EOS_WSE = 3, WAI_EOS_WAE = 4, WAI_EOS_WSCE = 5, WAI_EOS_WSAE = 6
   integer(c_int), parameter, public :: WAI_KSP_BCGS = 0, WAI_KSP_GMRES = 1
 
   type, bind(c), public :: wai_mesh_desc

@@ -10,8 +10,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libwaiwera_hip.so")
 
-EOS_W, EOS_WE, EOS_WCE, EOS_WSE, EOS_WAE = 0, 1, 2, 3, 4
-EOS_KIND = {"w": EOS_W, "we": EOS_WE, "wce": EOS_WCE, "wse": EOS_WSE, "wae": EOS_WAE}
+EOS_W, EOS_WE, EOS_WCE, EOS_WSE, EOS_WAE, EOS_WSCE, EOS_WSAE = 0, 1, 2, 3, 4, 5, 6
+EOS_KIND = {"w": EOS_W, "we": EOS_WE, "wce": EOS_WCE, "wse": EOS_WSE, "wae": EOS_WAE, "wsce": EOS_WSCE,
+            "wsae": EOS_WSAE}
 RP = {"fully_mobile": 0, "fully mobile": 0, "linear": 1, "pickens": 2, "corey": 3, "grant": 4,
       "van_genuchten": 5, "van genuchten": 5}
 CP = {"zero": 0, "linear": 1, "van_genuchten": 2, "van genuchten": 2}

@@ -681,7 +681,7 @@ def benchmark_initial_state(grid, ijk, eos="we", lens=True):
     if eos in ("wce", "wae"):
         # CO2 partial pressure 2 % of the total pressure
         return np.stack([P, second, 0.02 * P], axis=1), region
-    if eos == "wse":
+    if eos in ("wse", "wsce", "wsae"):
         # salt family: 5 % salt everywhere, the two-phase lens as for eos we, and halite (region 5,
         # solid saturation 2 %) in a sprinkling of single-phase cells of the layer above the bottom
         third = np.full(ijk.shape[0], 0.05)
@@ -693,10 +693,12 @@ def benchmark_initial_state(grid, ijk, eos="we", lens=True):
         inl = (depth >= 400.0) & (depth <= 500.0) & (r < 200.0)
         region[inl] = 4
         second[inl] = 0.1 + 0.4 * r[inl] / 200.0
-    if eos == "wse":
+    if eos in ("wse", "wsce", "wsae"):
         hal = (region == 1) & (k == max(nz - 2, 0)) & ((i + 2 * j) % 5 == 0)
         region[hal] = 5
         third[hal] = 0.02
+        if eos != "wse":     # gas partial pressure 2 % of the total pressure
+            return np.stack([P, second, third, 0.02 * P], axis=1), region
         return np.stack([P, second, third], axis=1), region
     return np.stack([P, second], axis=1), region
 

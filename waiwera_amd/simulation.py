@@ -8,7 +8,7 @@ src/timestepper.F90:1960-2275; src/tracer.F90:63-140; utils/input_schema.json):
 
   mesh        filename (gmsh MSH 2.2), thickness, radial, zones (all / box ranges on x, y, z)
   gravity     number | vector | null
-  eos         name w | we | wce | wae | wse, temperature
+  eos         name w | we | wce | wae | wse | wsce | wsae, temperature, permeability_modifier
   thermodynamics  iapws | ifc67
   rock        types [cells | zones, permeability, porosity, density, specific_heat, wet / dry
               conductivity], relative_permeability, capillary_pressure
@@ -164,7 +164,7 @@ class Simulation:
                 raise NotImplementedError("permeability modifier %r" % pm["type"])
         th = inp.get("thermodynamics", "iapws")
         self.thermo = (th.get("name", "iapws") if isinstance(th, dict) else th).lower()
-        if self.eos not in ("w", "we", "wce", "wse", "wae") or self.thermo not in ("iapws", "ifc67"):
+        if self.eos not in ("w", "we", "wce", "wse", "wae", "wsce", "wsae") or self.thermo not in ("iapws", "ifc67"):
             raise NotImplementedError("eos %r / thermodynamics %r" % (self.eos, self.thermo))
         # geometry first without rock (centroids are needed for zones), rock filled in below
         bnds = []
@@ -263,7 +263,7 @@ class Simulation:
         self.capillary = capillary_spec(rock.get("capillary_pressure"))
         # initial conditions
         init = inp.get("initial", {}) or {}
-        npv = {"w": 1, "we": 2, "wce": 3, "wse": 3, "wae": 3}[self.eos]
+        npv = {"w": 1, "we": 2, "wce": 3, "wse": 3, "wae": 3, "wsce": 4, "wsae": 4}[self.eos]
         if "filename" in init:
             # restart from a Waiwera HDF5 output (setup_initial, src/initial.F90:421-677, 776, 922):
             # primaries of each cell from its fluid fields by region (eos%primary_variables)
@@ -273,6 +273,8 @@ class Simulation:
             cols = [st["fluid_pressure"]]
             if npv > 1:
                 cols.append(np.where(region == 4, st["fluid_vapour_saturation"], st["fluid_temperature"]))
+            if npv > 3:
+                raise NotImplementedError("restart files for eos %s" % self.eos)
             if npv > 2 and self.eos == "wse":
                 halite = np.isin(region, (5, 6, 8))
                 cols[1] = np.where(np.isin(region, (4, 8)), st["fluid_vapour_saturation"], st["fluid_temperature"])
@@ -412,7 +414,7 @@ class Simulation:
                 fl = np.asarray(self.ode.fluid())
             return fl[cell]
 
-        nc = {"w": 1, "we": 1, "wce": 2, "wse": 2, "wae": 2}[self.eos]
+        nc = {"w": 1, "we": 1, "wce": 2, "wse": 2, "wae": 2, "wsce": 3, "wsae": 3}[self.eos]
         f0, pd = 6 + nc, 7 + nc
 
         def mobility_sum(f):
@@ -556,7 +558,7 @@ class Simulation:
         geom = self.mesh.cell_geom[:n]
         if self._order is not None:      # MINC: the reference's cell order (original cells, then level by level)
             fl, geom = fl[self._order], geom[self._order]
-        nc = {"w": 1, "we": 1, "wce": 2, "wse": 2, "wae": 2}[self.eos]
+        nc = {"w": 1, "we": 1, "wce": 2, "wse": 2, "wae": 2, "wsce": 3, "wsae": 3}[self.eos]
         f0, pd = 6 + nc, 7 + nc
         out = {"time": self.ts.time, "fluid_pressure": fl[:, 0].copy(), "fluid_temperature": fl[:, 1].copy(),
                "fluid_region": fl[:, 2].copy(), "fluid_liquid_saturation": fl[:, f0 + 2].copy(),
@@ -566,9 +568,14 @@ class Simulation:
         if self.eos != "w":
             out["fluid_vapour_saturation"] = fl[:, f0 + pd + 2].copy()
             out["fluid_vapour_density"] = fl[:, f0 + pd].copy()
-        if self.eos == "wse":
+        if self.eos in ("wse", "wsce", "wsae"):
             out["fluid_liquid_salt_mass_fraction"] = fl[:, f0 + 8].copy()
             out["fluid_solid_saturation"] = fl[:, f0 + 2 * pd + 2].copy()
+        if self.eos in ("wsce", "wsae"):
+            gas = "CO2" if self.eos == "wsce" else "air"
+            out["fluid_%s_partial_pressure" % gas] = fl[:, 8].copy()
+            out["fluid_liquid_%s_mass_fraction" % gas] = fl[:, f0 + 9].copy()
+            out["fluid_vapour_%s_mass_fraction" % gas] = fl[:, f0 + pd + 9].copy()
         if self.eos in ("wce", "wae"):
             gas = "CO2" if self.eos == "wce" else "air"
             out["fluid_%s_partial_pressure" % gas] = fl[:, 7].copy()
