@@ -105,7 +105,7 @@ def test_jacobian(FS, oracle, eos, lens):
     sim.destroy(); osim.close()
 
 
-@pytest.mark.parametrize("eos", ["we", "w", "wce"])
+@pytest.mark.parametrize("eos", ["we", "w", "wce", "wsce"])
 def test_spmv_ilu_krylov(FS, oracle, eos):
     g, lm, sim, osim, y, region = build(FS, oracle, eos=eos, dims=(12, 10, 9), brick=(4, 4, 4))
     bs = sim.num_primary_variables

@@ -18,12 +18,15 @@ FX = json.load(open(os.path.join(HERE, "golden", "reference_unit_values_salt.jso
 INPUTS = os.path.join(HERE, "golden", "inputs")
 
 
-def test_reference_transition_cases_on_the_device():
+@pytest.mark.parametrize("eos,key", [("wse", "eos_wse_transition"), ("wsce", "eos_wsge_transition")])
+def test_reference_transition_cases_on_the_device(eos, key):
+    """22 cases of test_eos_wse_transition, 33 of test_eos_wsge_transition (four primaries, water
+    pressure P - Pg against the brine saturation line)"""
     from waiwera_amd.flow_simulation import FlowSimulation
-    cases = FX["eos_wse_transition"]
+    cases = FX[key]
     n = len(cases)
     lm = M.row_mesh_1d(np.arange(n + 1) * 10.0, 10.0, height=10.0)       # one cell per case
-    sim = FlowSimulation(lm, eos="wse", thermo="iapws")
+    sim = FlowSimulation(lm, eos=eos, thermo="iapws")
     old_region = np.array([c["old_region"] for c in cases], dtype=np.int32)
     oldp = np.array([c["old_primary"] for c in cases])
     newp = np.array([c["primary"] for c in cases])
@@ -38,7 +41,7 @@ def test_reference_transition_cases_on_the_device():
     cs, cy, err = sim.post_linesearch(y_old, search, y)
     assert err == 0
     regions = sim.regions()
-    got = y.reshape(n, 3).copy()
+    got = y.reshape(n, -1).copy()
     for k, c in enumerate(cases):
         assert regions[k] == c["expected_region"], c["title"]
         exp = sim.scale(np.array([c["expected_primary"]]), np.array([c["expected_region"]]))[0]
