@@ -294,7 +294,7 @@ def main():
                        "partition": "x".join(str(p) for p in grid.part), "ksp": a.ksp},
             "roofline": {"bound": "hbm", "kernel": "k_pc_park<spmv> (fused BCSR SpMV + block ILU(0) apply + dot; k_pc<2,spmv,dilu> with WAI_PC_PARK=0)",
                          "achieved": achieved_pc, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_pc / HBM_PEAK_GBS, "traffic": traffic_from_profiles(dims, a.brick),
+                         "frac": achieved_pc / HBM_PEAK_GBS, "traffic": traffic_from_profiles(dims, a.brick) if world == 1 else None,
                          "algorithmic_bytes_per_launch": b_pc, "ms_per_launch": ms_pc,
                          "spmv": {"kernel": "k_spmv<2> (BCSR SpMV)", "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
                                   "algorithmic_bytes_per_launch": b_spmv, "ms_per_launch": ms}},
