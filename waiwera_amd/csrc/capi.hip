@@ -192,6 +192,25 @@ int do_pc_setup(wai_ctx* c) {
 
 // z = B^-1 A x  (x has halo room); optional fused dot products of the result
 int pc_amul(wai_ctx* c, double* x, double* z, int dot_mode = 0, const double* aux = nullptr) {
+  const IluSchedule& s = c->ilu;
+  if (c->comm && c->mesh.n_halo && c->comm_stream && s.n_int > 0 && s.n_bnd > 0 && !c->prof_on) {
+    // The partition-ghost values are needed only by the bricks on the rank's faces: pack on the
+    // compute stream, send / receive / unpack on the communication stream while the interior bricks
+    // run, then the face bricks.  (xGMI transfers and RCCL's launch latency hide behind ~90 % of
+    // the kernel at 108^3 cells per rank.)
+    if (c->np > c->max_dof_buf) { c->err = "halo dof too large"; return -1; }
+    pack_halo(c, x, c->np);
+    HIPCHK(c, hipEventRecord(c->ev_pack, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
+    if (comm_exchange(c->comm, c->n_nbr, c->nbr_rank.data(), c->send_ptr.data(), c->recv_ptr.data(), c->np,
+                      c->d_sendbuf, c->d_recvbuf, c->comm_stream, c->err))
+      return -1;
+    if (unpack_halo(c, x, c->np, c->comm_stream)) return -1;
+    HIPCHK(c, hipEventRecord(c->ev_halo, c->comm_stream));
+    if (launch_pc(c, true, x, z, dot_mode, aux, s.sub_int, s.n_int)) return -1;
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+    return launch_pc(c, true, x, z, dot_mode, aux, s.sub_bnd, s.n_bnd);
+  }
   if (halo_exchange(c, x, c->np)) return -1;
   Prof p(c, KC_PC_APPLY);
   return launch_pc(c, true, x, z, dot_mode, aux);
@@ -485,7 +504,7 @@ void free_all(wai_ctx* c) {
   F(c->src.cell); F(c->src.comp); F(c->src.next); F(c->src.rate); F(c->src.enth); F(c->src.ctl);
   F(c->J.rowptr); F(c->J.col); F(c->J.val);
   IluSchedule& s = c->ilu;
-  F(s.sub_ptr); F(s.sub_nlev); F(s.row_info); F(s.row_uoff); F(s.fval); F(s.dinv);
+  F(s.sub_ptr); F(s.sub_nlev); F(s.row_info); F(s.row_uoff); F(s.fval); F(s.dinv); F(s.sub_int); F(s.sub_bnd);
   Krylov& k = c->ks;
   F(k.R); F(k.RP); F(k.P); F(k.V); F(k.S); F(k.T); F(k.tmp); F(k.X); F(k.basis); F(k.partials); F(k.scal);
   if (k.h_scal) (void)hipHostFree(k.h_scal);
@@ -500,6 +519,9 @@ void free_all(wai_ctx* c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->ev_scal) (void)hipEventDestroy(c->ev_scal);
+  if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
+  if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
+  if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   if (c->pev0) (void)hipEventDestroy(c->pev0);
   if (c->pev1) (void)hipEventDestroy(c->pev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -739,6 +761,21 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
         info[i] = lfirst[i - lo] | (diag[i] << 4) | (ulast[i - lo] << 8) | (levf[i] << 12) | (levb[i] << 22);
       nlev[sd] = nlf | (nlb << 16);
       s.max_lev = std::max(s.max_lev, std::max(nlf, nlb));
+    }
+    {   // subdomains without / with partition-ghost columns (for the overlapped halo exchange)
+      std::vector<int> li, lb;
+      for (int sd = 0; sd < s.nsub; sd++) {
+        bool ghost = false;
+        for (int i = sub[sd]; i < sub[sd + 1] && !ghost; i++)
+          for (int q = J.h_rowptr[i]; q < J.h_rowptr[i + 1]; q++)
+            if (J.h_colidx[q] >= N) { ghost = true; break; }
+        (ghost ? lb : li).push_back(sd);
+      }
+      s.n_int = (int)li.size();
+      s.n_bnd = (int)lb.size();
+      if (m.n_halo > 0 && s.n_int > 0 && s.n_bnd > 0) {
+        if (dev_upload(c, &s.sub_int, li) || dev_upload(c, &s.sub_bnd, lb)) return -1;
+      }
     }
     if (s.max_rows > 1024) {
       c->err = "preconditioner subdomain larger than 1024 rows (one thread per row, one workgroup "
@@ -1030,7 +1067,13 @@ int wai_comm_init(wai_ctx* c, int rank, int nranks, const char id[128]) {
   HIPCHK(c, hipSetDevice(c->device));
   comm_destroy(c->comm);
   c->comm = comm_create(rank, nranks, id, c->err);
-  return c->comm ? 0 : -1;
+  if (!c->comm) return -1;
+  if (nranks > 1 && !c->comm_stream && !getenv("WAI_NO_HALO_OVERLAP")) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
+  }
+  return 0;
 }
 
 int wai_halo_exchange(wai_ctx* c, double* vec, int dof) {

@@ -64,6 +64,9 @@ struct IluSchedule {
   bool park = true;         // k_pc_park: upper blocks parked in LDS (WAI_PC_PARK=0: off)
   int* row_uoff = nullptr;  // first parked upper block of a row inside its subdomain
   bool park2 = false;
+  int* sub_int = nullptr;   // subdomains none of whose rows has a partition-ghost column ...
+  int* sub_bnd = nullptr;   // ... and the others (device lists; null on a single rank)
+  int n_int = 0, n_bnd = 0;
   int max_ublocks = 0;      // most in-subdomain upper blocks of any subdomain
   bool fast3 = false;         // <= 3 lower and <= 3 upper in-subdomain couplings per row, offsets < 4
   bool level_sorted = false;  // every subdomain's rows are stored in dependency-level order
@@ -141,6 +144,9 @@ struct wai_ctx {
   size_t stage_len = 0;
   wai::Comm* comm = nullptr;
   hipEvent_t ev_scal = nullptr;   // marks the scalar read-back of a Krylov iteration (ksp_bcgs)
+  // halo exchange overlapped with the preconditioned operator on the bricks that touch no ghost
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
   // halo
   int n_nbr = 0;
   std::vector<int> nbr_rank, send_ptr, recv_ptr;
@@ -197,7 +203,9 @@ int launch_ilu_factor(wai_ctx* c);
 // z = B^-1 r (spmv = false) or z = B^-1 (A x) (spmv = true: x is `in`, haloed by the caller).
 // dot_mode 0: none; 1: scal-partials S_D1 += (z, aux); 2: S_D1 += (in, z), S_D2 += (z, z);
 // 3: S_DP2 += (z, z)
-int launch_pc(wai_ctx* c, bool spmv, const double* in, double* z, int dot_mode, const double* aux);
+// list / nrun: run only the listed subdomains (null: all)
+int launch_pc(wai_ctx* c, bool spmv, const double* in, double* z, int dot_mode, const double* aux,
+              const int* list = nullptr, int nrun = 0);
 int launch_ell_to_bcsr(wai_ctx* c, const double* ell, double* bcsr);
 int launch_bcsr_to_ell(wai_ctx* c, const double* bcsr, double* ell);
 // reductions: partial sums live in ks.partials[slot][block]; finalize sums nb partials of
@@ -215,6 +223,6 @@ int gmres_mdot(wai_ctx* c, const double* w, int k);          // scal[16+i] = (w,
 int gmres_maxpy_norm(wai_ctx* c, double* w, int k);          // w -= sum h_i v_i ; scal[8] = |w|^2
 int gmres_scale_to(wai_ctx* c, double* dst, const double* src, int slot_norm2, int n);
 int gmres_update_x(wai_ctx* c, double* x, const double* ycoef_host, int k);
-int pack_halo(wai_ctx* c, const double* vec, int dof);
-int unpack_halo(wai_ctx* c, double* vec, int dof);
+int pack_halo(wai_ctx* c, const double* vec, int dof, hipStream_t stream = nullptr);
+int unpack_halo(wai_ctx* c, double* vec, int dof, hipStream_t stream = nullptr);
 }  // namespace wai

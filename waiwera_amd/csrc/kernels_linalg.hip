@@ -408,15 +408,17 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
                      const double* __restrict__ fval, const double* __restrict__ dinv,
                      const double* __restrict__ in,
                      double* __restrict__ z, const double* __restrict__ aux, double* partials,
-                     int nb_max, int dot, int dbg) {
+                     int nb_max, int dot, int dbg,
+    const int* __restrict__ sub_list) {
   constexpr int BB = BS * BS;
   // DILU == 2: rows pre-scaled by the inverted pivots (k_scale_rows): A' = inv(P) A lives in fval,
   // the pivots of ILU(0)(A') are identities, so neither dinv nor its two products per row are needed
   constexpr bool SC = (DILU == 2);
   const double* __restrict__ mat = SC ? fval : aval;
   extern __shared__ double lds[];  // [T * BS] solution vector, then 32 doubles reduction scratch
-  const int s = xcd_remap(blockIdx.x, nsub);
+  int s = xcd_remap(blockIdx.x, nsub);
   if (s >= nsub) return;
+  if (sub_list) s = sub_list[s];
   const int lo = sub_ptr[s], R = sub_ptr[s + 1] - lo;
   const int nl = sub_nlev[s];
   const int nlf = (dbg & 1) ? 0 : (nl & 0xffff), nlb = (dbg & 1) ? 1 : (nl >> 16);  // dbg: timing probe
@@ -767,11 +769,15 @@ __global__ __launch_bounds__(512, P2 ? 8 : 6) void k_pc_park(
     int n, int W, int nsub, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev,
     const int* __restrict__ row_info, const int* __restrict__ row_uoff, const int* __restrict__ col,
     const double* __restrict__ sval, const double* __restrict__ dinv, const double* __restrict__ in,
-    double* __restrict__ z, const double* __restrict__ aux, double* partials, int nb_max, int dot) {
+    double* __restrict__ z, const double* __restrict__ aux, double* partials, int nb_max, int dot,
+    const int* __restrict__ sub_list) {
   constexpr int BS = 2, BB = 4, MLU = 3;
   extern __shared__ double lds[];  // [T*2] solution, [32] reduction scratch, then parked U blocks
-  const int s = xcd_remap(blockIdx.x, nsub);
+  // nsub subdomains to run: all of them, or (sub_list) the listed ones -- the bricks that touch no
+  // partition ghost while the halo exchange is in flight, the others after it
+  int s = xcd_remap(blockIdx.x, nsub);
   if (s >= nsub) return;
+  if (sub_list) s = sub_list[s];
   const int lo = sub_ptr[s], R = sub_ptr[s + 1] - lo;
   const int nl = sub_nlev[s];
   const int nlf = nl & 0xffff, nlb = nl >> 16;
@@ -1389,21 +1395,23 @@ int launch_ilu_factor(wai_ctx* c) {
 }
 
 template <int BS>
-static void launch_pc_bs(wai_ctx* c, bool spmv, const double* in, double* z, int dot_mode, const double* aux) {
+static void launch_pc_bs(wai_ctx* c, bool spmv, const double* in, double* z, int dot_mode, const double* aux,
+                         const int* list, int nrun) {
   const Bcsr& J = c->J;
   const IluSchedule& s = c->ilu;
-  const int grid = ((s.nsub + 7) / 8) * 8, T = pc_threads(c);
+  if (!list) nrun = s.nsub;
+  const int grid = ((nrun + 7) / 8) * 8, T = pc_threads(c);
   const size_t lds = ((size_t)T * BS + 32) * sizeof(double);
 #define PCL(SP, DI, WPP)                                                                        \
   do {                                                                                           \
     if (s.fast3)                                                                                 \
       hipLaunchKernelGGL((k_pc<BS, SP, DI, WPP, true>), grid, T, lds, c->stream, J.n, J.W,       \
-                         s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.fval,        \
-                         s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, c->dbg);    \
+                         nrun, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.fval,          \
+                         s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, c->dbg, list); \
     else                                                                                         \
       hipLaunchKernelGGL((k_pc<BS, SP, DI, WPP, false>), grid, T, lds, c->stream, J.n, J.W,      \
-                         s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.fval,        \
-                         s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, c->dbg);    \
+                         nrun, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.fval,          \
+                         s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, c->dbg, list); \
   } while (0)
   const bool wp = s.level_sorted && !(c->dbg & 2);
   if constexpr (BS == 2) {
@@ -1412,28 +1420,28 @@ static void launch_pc_bs(wai_ctx* c, bool spmv, const double* in, double* z, int
       const size_t lds_park = lds + (size_t)s.max_ublocks * 4 * sizeof(double);
       if (s.park2) {
         if (spmv)
-          hipLaunchKernelGGL((k_pc_park<true, true>), grid, T, lds_park, c->stream, J.n, J.W, s.nsub, s.sub_ptr, s.sub_nlev,
+          hipLaunchKernelGGL((k_pc_park<true, true>), grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,
                              s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials,
-                             c->ks.nb_max, dot_mode);
+                             c->ks.nb_max, dot_mode, list);
         else
-          hipLaunchKernelGGL((k_pc_park<false, true>), grid, T, lds_park, c->stream, J.n, J.W, s.nsub, s.sub_ptr, s.sub_nlev,
+          hipLaunchKernelGGL((k_pc_park<false, true>), grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,
                              s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials,
-                             c->ks.nb_max, dot_mode);
+                             c->ks.nb_max, dot_mode, list);
         return;
       }
       if (spmv)
-        hipLaunchKernelGGL(k_pc_park<true>, grid, T, lds_park, c->stream, J.n, J.W, s.nsub, s.sub_ptr, s.sub_nlev,
+        hipLaunchKernelGGL(k_pc_park<true>, grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,
                            s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials,
-                           c->ks.nb_max, dot_mode);
+                           c->ks.nb_max, dot_mode, list);
       else
-        hipLaunchKernelGGL(k_pc_park<false>, grid, T, lds_park, c->stream, J.n, J.W, s.nsub, s.sub_ptr, s.sub_nlev,
+        hipLaunchKernelGGL(k_pc_park<false>, grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,
                            s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials,
-                           c->ks.nb_max, dot_mode);
+                           c->ks.nb_max, dot_mode, list);
       return;
     }
     // software-pipelined persistent variant: needs a workgroup index below nsub for every
     // workgroup's partial, i.e. at least as many bricks as workgroups
-    if (spmv && s.pipe && s.diag_only && s.fast3 && J.W == 7 && T <= 512 && !(c->dbg & 3) && s.nsub >= s.pipe_grid) {
+    if (!list && spmv && s.pipe && s.diag_only && s.fast3 && J.W == 7 && T <= 512 && !(c->dbg & 3) && s.nsub >= s.pipe_grid) {
       hipLaunchKernelGGL(k_pc_pipe, s.pipe_grid, T, lds, c->stream, J.n, s.nsub, s.sub_ptr,
                          s.sub_nlev, s.row_info, J.col, J.val, s.dinv, in, z, aux, c->ks.partials,
                          c->ks.nb_max, dot_mode, c->dbg >> 2);
@@ -1452,12 +1460,13 @@ static void launch_pc_bs(wai_ctx* c, bool spmv, const double* in, double* z, int
 #undef PCL
 }
 
-int launch_pc(wai_ctx* c, bool spmv, const double* in, double* z, int dot_mode, const double* aux) {
+int launch_pc(wai_ctx* c, bool spmv, const double* in, double* z, int dot_mode, const double* aux,
+              const int* list, int nrun) {
   switch (c->J.bs) {
-    case 1: launch_pc_bs<1>(c, spmv, in, z, dot_mode, aux); break;
-    case 2: launch_pc_bs<2>(c, spmv, in, z, dot_mode, aux); break;
-    case 3: launch_pc_bs<3>(c, spmv, in, z, dot_mode, aux); break;
-    case 4: launch_pc_bs<4>(c, spmv, in, z, dot_mode, aux); break;
+    case 1: launch_pc_bs<1>(c, spmv, in, z, dot_mode, aux, list, nrun); break;
+    case 2: launch_pc_bs<2>(c, spmv, in, z, dot_mode, aux, list, nrun); break;
+    case 3: launch_pc_bs<3>(c, spmv, in, z, dot_mode, aux, list, nrun); break;
+    case 4: launch_pc_bs<4>(c, spmv, in, z, dot_mode, aux, list, nrun); break;
     default: return -1;
   }
   return 0;
@@ -1544,19 +1553,19 @@ int gmres_update_x(wai_ctx* c, double* x, const double* ycoef_host, int k) {
                      c->ks.n, dcoef);
   return 0;
 }
-int pack_halo(wai_ctx* c, const double* vec, int dof) {
+int pack_halo(wai_ctx* c, const double* vec, int dof, hipStream_t stream) {
   const int n = c->send_total;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(k_pack, (n * dof + TPB - 1) / TPB, TPB, 0, c->stream, vec, c->d_send_idx, n, dof,
-                     c->d_sendbuf);
+  hipLaunchKernelGGL(k_pack, (n * dof + TPB - 1) / TPB, TPB, 0, stream ? stream : c->stream, vec, c->d_send_idx, n,
+                     dof, c->d_sendbuf);
   return 0;
 }
-int unpack_halo(wai_ctx* c, double* vec, int dof) {
+int unpack_halo(wai_ctx* c, double* vec, int dof, hipStream_t stream) {
   // halo cells are contiguous after the owned cells and the receive buffer is in halo order
   const size_t n = (size_t)c->mesh.n_halo * dof;
   if (n == 0) return 0;
   return hipMemcpyAsync(vec + (size_t)c->mesh.n_owned * dof, c->d_recvbuf, n * sizeof(double),
-                        hipMemcpyDeviceToDevice, c->stream) == hipSuccess ? 0 : -1;
+                        hipMemcpyDeviceToDevice, stream ? stream : c->stream) == hipSuccess ? 0 : -1;
 }
 
 }  // namespace wai
