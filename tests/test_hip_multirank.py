@@ -57,6 +57,14 @@ def _worker(rank, world, uid, q):
 
 
 @pytest.mark.timeout(900)
+def test_overlapped_halo_exchange_two_ranks(monkeypatch):
+    """WAI_HALO_OVERLAP=1: ghost values travel on a communication stream while the bricks that touch
+    no partition ghost run; same results as one rank"""
+    monkeypatch.setenv("WAI_HALO_OVERLAP", "1")
+    test_ranks_sharing_one_gpu_match_one_rank(2)
+
+
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("world", [2, 8])
 def test_ranks_sharing_one_gpu_match_one_rank(world):
     """2 ranks (2x1x1, bricks aligned with the serial ones) and 8 ranks (2x2x2: every rank has x, y

@@ -1068,7 +1068,9 @@ int wai_comm_init(wai_ctx* c, int rank, int nranks, const char id[128]) {
   comm_destroy(c->comm);
   c->comm = comm_create(rank, nranks, id, c->err);
   if (!c->comm) return -1;
-  if (nranks > 1 && !c->comm_stream && !getenv("WAI_NO_HALO_OVERLAP")) {
+  // opt-in (WAI_HALO_OVERLAP=1): correct under the loopback transport of the tests, but unmeasured on
+  // xGMI, and eight processes sharing one test GPU run it 30x slower than the in-order exchange
+  if (nranks > 1 && !c->comm_stream && getenv("WAI_HALO_OVERLAP")) {
     HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
