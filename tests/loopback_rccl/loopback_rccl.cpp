@@ -92,7 +92,12 @@ extern "C" {
 int ncclGetUniqueId(void* out) {
   Id id;
   std::memset(&id, 0, sizeof id);
-  std::snprintf(id.name, sizeof id.name, "/wai_loopback_%d_%ld", (int)getpid(), (long)time(nullptr));
+  // unique per call: two communicators made by one process within a second must not meet in one segment
+  static int serial = 0;
+  timespec ts;
+  clock_gettime(CLOCK_REALTIME, &ts);
+  std::snprintf(id.name, sizeof id.name, "/wai_loopback_%d_%ld_%ld_%d", (int)getpid(), (long)ts.tv_sec, (long)ts.tv_nsec,
+                serial++);
   std::memcpy(out, &id, sizeof id);
   return 0;
 }
