@@ -126,13 +126,16 @@ int wai_update_sources(wai_ctx *ctx, const double *rate, const double *enthalpy)
  *   limiter 1 / 2 / 3      total / separated water / separated steam rate scaled down to `limit`
  *                          (src/source_network_node.F90:247-315; single-stage separator with the
  *                          saturated enthalpies sep_hf, sep_hg, src/separator.F90:139-166),
- *   direction 1 / 2        production / injection only                      (:596-620).
+ *   direction 1 / 2        production / injection only                      (:596-620),
+ *   factor                 the rate multiplied by a factor                  (:178-193).
  * Time tables (productivity, reference pressure, limit) are averaged over the step interval by
  * the host, which sets the records again before each try. */
 typedef struct wai_source_control {
   int kind, direction, limiter, table_coord, n_table;
   double coef, pressure, limit, sep_hf, sep_hg;
   double table[16];   /* (x, pressure) pairs, linear, clamped; n_table <= 8 */
+  double factor;      /* rate factor for the step interval, applied last ("factor",
+                         rate_factor_table_source_control, src/source_control.F90:178-193); 0 = none */
 } wai_source_control;
 int wai_set_source_controls(wai_ctx *ctx, const wai_source_control *controls);
 /* enthalpies of saturated water and steam at a separator pressure, in the context's

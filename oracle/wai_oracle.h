@@ -142,6 +142,7 @@ typedef struct wo_src_ctl {
   double limit;
   double sep_hf, sep_hg;  /* saturated water / steam enthalpy at the separator pressure */
   double table[16];       /* (x, pressure) pairs, linear, clamped */
+  double factor;          /* rate factor applied last (src/source_control.F90:178-193); 0 = none */
 } wo_src_ctl;
 void wo_sim_set_source_controls(wo_sim *s, const wo_src_ctl *ctl); /* NULL: none */
 void wo_sim_source_rates(wo_sim *s, double *rate, double *enthalpy);

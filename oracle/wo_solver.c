@@ -416,6 +416,7 @@ static double source_rate(const wo_eos *e, const double *fl, const wo_src_ctl *k
   }
   if (k->direction == 1 && !(rate < 0.0)) rate = 0.0;
   if (k->direction == 2 && !(rate > 0.0)) rate = 0.0;
+  if (k->factor != 0.0) rate *= k->factor;
   return rate;
 }
 

@@ -451,7 +451,7 @@ def test_state_dependent_source_controls(FS, oracle):
             dict(kind="deliverability", coef=1.0e-10, pressure=1.0e5, limiter="total", limit=3.0),
             dict(kind="deliverability", coef=1.0e-10, pressure=1.0e5, limiter="steam", limit=0.5, sep_hf=hf, sep_hg=hg),
             dict(kind="deliverability", coef=1.0e-10, pressure=1.0e5, limiter="water", limit=2.0, sep_hf=hf, sep_hg=hg),
-            dict(limiter="total", limit=1.0)]                                              # fixed rate, limited
+            dict(limiter="total", limit=1.0, factor=0.25)]                                 # fixed rate, limited, then scaled
     sim.set_source_controls(recs)
     osim.set_source_controls(recs)
     yo = osim.yvec(y)
@@ -459,7 +459,7 @@ def test_state_dependent_source_controls(FS, oracle):
     rg, eg = sim.source_rates()
     ro, eo = osim.source_rates()
     assert np.abs(rg - ro).max() <= 1e-11 * np.abs(ro).max() and np.abs(eg - eo).max() <= 1e-11 * np.abs(eo).max()
-    assert ro[3] == 0.0 and abs(abs(ro[4]) - 3.0) < 1e-12 and abs(abs(ro[7]) - 1.0) < 1e-12 and ro[0] < 0.0
+    assert ro[3] == 0.0 and abs(abs(ro[4]) - 3.0) < 1e-12 and abs(abs(ro[7]) - 0.25) < 1e-12 and ro[0] < 0.0
     n = sim.n_owned * sim.num_primary_variables
     L = osim.lhs()
     dt = 1.0e4

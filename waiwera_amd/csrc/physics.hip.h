@@ -785,6 +785,7 @@ struct SrcCtl {
   int kind, direction, limiter, table_coord, n_table;
   double coef, pressure, limit, sep_hf, sep_hg;
   double table[16];
+  double factor;
 };
 
 __device__ inline double ctl_table(const SrcCtl& k, double x) {
@@ -840,6 +841,7 @@ __device__ inline double source_rate(const CellState<KIND>& s, const SrcCtl* ctl
   }
   if (k.direction == 1 && !(rate < 0.0)) rate = 0.0;
   if (k.direction == 2 && !(rate > 0.0)) rate = 0.0;
+  if (k.factor != 0.0) rate *= k.factor;
   return rate;
 }
 

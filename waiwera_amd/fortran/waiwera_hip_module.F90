@@ -44,6 +44,7 @@ module waiwera_hip_module
      real(c_double) :: coef = 0._c_double, pressure = 0._c_double, limit = 0._c_double
      real(c_double) :: sep_hf = 0._c_double, sep_hg = 0._c_double
      real(c_double) :: table(16) = 0._c_double
+     real(c_double) :: factor = 0._c_double
   end type wai_source_control
 
   type, bind(c), public :: wai_solver_opts

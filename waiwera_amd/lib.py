@@ -45,7 +45,8 @@ PERM = {"none": 0, "power": 1, "verma-pruess": 2, "verma_pruess": 2}
 class SourceControl(C.Structure):
     """wai_source_control (include/waiwera_hip.h): state-dependent control of one source"""
     _fields_ = [("kind", i32), ("direction", i32), ("limiter", i32), ("table_coord", i32), ("n_table", i32),
-                ("coef", d), ("pressure", d), ("limit", d), ("sep_hf", d), ("sep_hg", d), ("table", d * 16)]
+                ("coef", d), ("pressure", d), ("limit", d), ("sep_hf", d), ("sep_hg", d), ("table", d * 16),
+                ("factor", d)]
 
 
 SRC_KIND = {"rate": 0, "deliverability": 1, "recharge": 2}
@@ -63,6 +64,7 @@ def source_controls(records):
         k.limiter = SRC_LIMITER[r.get("limiter")]
         k.coef, k.pressure = r.get("coef", 0.0), r.get("pressure", 0.0)
         k.limit, k.sep_hf, k.sep_hg = r.get("limit", 0.0), r.get("sep_hf", 0.0), r.get("sep_hg", 0.0)
+        k.factor = r.get("factor", 0.0)
         tab = r.get("table")
         k.table_coord = {None: 0, "enthalpy": 1, "pressure": 2}[r.get("table_coord")] if tab is not None else 0
         if tab is not None:

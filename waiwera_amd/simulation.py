@@ -42,7 +42,7 @@ from . import gmsh, unstructured
 from .timestepper import Timestepper
 from .interpolation import Table
 
-UNSUPPORTED_SOURCE_KEYS = ("injectivity", "factor", "network")
+UNSUPPORTED_SOURCE_KEYS = ("network",)
 
 
 def _get(d, path, default=None):
@@ -394,7 +394,8 @@ class Simulation:
         device evaluates (include/waiwera_hip.h, wai_source_control); their time tables are kept
         here and averaged over every step interval (_update_controls)"""
         self._ctl, self._ctl_tables = None, []
-        if not any(k in s for s in sources for k in ("deliverability", "recharge", "limiter", "direction")):
+        if not any(k in s for s in sources for k in ("deliverability", "recharge", "injectivity", "limiter",
+                                                     "direction", "factor")):
             return
         recs = [dict() for _ in sources]
         fl = None
@@ -424,7 +425,8 @@ class Simulation:
         for i, s in enumerate(sources):
             r = recs[i]
             for key, kind, cdef, ckey in (("deliverability", "deliverability", 1.0e-11, "productivity"),
-                                          ("recharge", "recharge", 0.0, "coefficient")):
+                                          ("recharge", "recharge", 0.0, "coefficient"),
+                                          ("injectivity", "recharge", 0.0, "coefficient")):   # same control, :3013
                 if key not in s:
                     continue
                 spec = s[key] if isinstance(s[key], dict) else {}
@@ -476,6 +478,12 @@ class Simulation:
                     r["sep_hf"], r["sep_hg"] = self.ode.separator_enthalpies(float(psep))
             if "direction" in s:
                 r["direction"] = s["direction"].lower()
+            if "factor" in s:      # rate factor, applied after every other control (:2615-2660)
+                fac = s["factor"]
+                fs = dict(s)
+                if isinstance(fac, dict):
+                    fs.update({k: fac[k] for k in ("interpolation", "averaging") if k in fac})
+                self._ctl_tables.append((i, "factor", timed(fac, 1.0, fs)))
         self._ctl = recs
         self._apply_controls((t0, t0))
 
