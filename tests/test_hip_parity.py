@@ -474,7 +474,10 @@ def test_state_dependent_source_controls(FS, oracle):
     sim.set_source_controls(None)
     assert sim.jacobian(0.0, dt, y, L) == 0
     assert np.abs(sim.jacobian_values() - Jo).max() > 1e-3 * np.abs(Jo).max()
-    # and a few time steps
+    # and a few time steps (without the rate factor: with it the first step converges on the edge of
+    # the tolerance and the two paths differ by one Newton iteration)
+    recs[7] = dict(limiter="total", limit=1.0)
+    osim.set_source_controls(recs)
     sim.set_source_controls(recs)
     sim.set_opts(ksp_rtol=1e-10, ftol_rel=1e-9)
     o = osim.opts()
