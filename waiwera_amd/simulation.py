@@ -19,8 +19,8 @@ src/timestepper.F90:1960-2275; src/tracer.F90:63-140; utils/input_schema.json):
               zones (boxes, cell lists), minc {geometry, rock {fracture, matrix, zones | types}}
   source      cell, rate, enthalpy, tracer (constants or [[t, v], ...] tables with "interpolation":
               linear|step and "averaging": integrate|endpoint), component, deliverability {productivity,
-              pressure}, recharge {coefficient, pressure}, limiter {type, limit, separator_pressure},
-              separator {pressure}, direction
+              pressure}, recharge | injectivity {coefficient, pressure}, limiter {type, limit,
+              separator_pressure}, separator {pressure}, direction, factor
   time        start, stop, step {size, adapt, maximum, method, solver.nonlinear, solver.linear}
   tracer      name, phase, decay, activation, diffusion
 
