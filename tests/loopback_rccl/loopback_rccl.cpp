@@ -24,8 +24,9 @@
 
 namespace {
 constexpr int kMaxRanks = 8;
-constexpr size_t kRedCap = 1 << 16;        // doubles per all-reduce
-constexpr size_t kBoxCap = 4u << 20;       // bytes per (source, destination) mailbox
+constexpr size_t kRedCap = 1 << 12;        // doubles per all-reduce
+constexpr size_t kBoxCap = 256u << 10;     // bytes per (source, destination) mailbox: 16 MB segment in all
+                                           // (a container's /dev/shm may be as small as 64 MB)
 
 struct Shared {
   std::atomic<int> arrived;
@@ -105,11 +106,11 @@ int ncclGetUniqueId(void* out) {
 int ncclCommInitRank(void** comm, int nranks, Id id, int rank) {
   if (nranks > kMaxRanks) return 4;
   int fd = shm_open(id.name, O_CREAT | O_RDWR, 0600);
-  if (fd < 0) return 2;
-  if (ftruncate(fd, sizeof(Shared)) != 0) { close(fd); return 2; }
+  if (fd < 0) { std::perror("loopback_rccl: shm_open"); return 2; }
+  if (ftruncate(fd, sizeof(Shared)) != 0) { std::perror("loopback_rccl: ftruncate"); close(fd); return 2; }
   void* p = mmap(nullptr, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
   close(fd);
-  if (p == MAP_FAILED) return 2;
+  if (p == MAP_FAILED) { std::perror("loopback_rccl: mmap"); return 2; }
   Comm* c = new Comm;
   c->sh = static_cast<Shared*>(p);      // a fresh segment is zero-filled: counters start at 0
   c->rank = rank;
