@@ -26,7 +26,8 @@ def main(src="gpurun_out", dst="profiles/pmc_traffic_r1.json", dims=(216, 216, 2
     n = dims[0] * dims[1] * dims[2]
     nnzb = 7 * n - 2 * (dims[0] * dims[1] + dims[1] * dims[2] + dims[0] * dims[2])
     b_pc, b_spmv = pc_bytes(nnzb, n, 2), spmv_bytes(nnzb, n, 2)
-    pc, sp = "void wai::k_pc_park<true>", "void wai::k_spmv<2>"
+    pc = [k for k in fe if k.startswith("void wai::k_pc_park<true")][0]
+    sp = "void wai::k_spmv<2>"
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python "
                      "bench.py --steps 1 --warmup 0 --no-cpu --spmv-reps 10 on 1 x MI355X, %dx%dx%d eos_we, bricks %dx%dx%d"
                      % (dims + brick),
