@@ -124,8 +124,10 @@ int wai_update_sources(wai_ctx *ctx, const double *rate, const double *enthalpy)
  *                          enthalpy / the pressure),
  *   kind 2 recharge        rate = -coef * (P - pressure)                    (:553-578),
  *   limiter 1 / 2 / 3      total / separated water / separated steam rate scaled down to `limit`
- *                          (src/source_network_node.F90:247-315; single-stage separator with the
- *                          saturated enthalpies sep_hf, sep_hg, src/separator.F90:139-166),
+ *                          (src/source_network_node.F90:247-315; separator with the saturated
+ *                          enthalpies sep_hf, sep_hg of its first stage and sep_more of up to three
+ *                          further stages fed with the water of the stage before,
+ *                          src/separator.F90:139-166, :212-260),
  *   direction 1 / 2        production / injection only                      (:596-620),
  *   factor                 the rate multiplied by a factor                  (:178-193).
  * Time tables (productivity, reference pressure, limit) are averaged over the step interval by
@@ -136,6 +138,7 @@ typedef struct wai_source_control {
   double table[16];   /* (x, pressure) pairs, linear, clamped; n_table <= 8 */
   double factor;      /* rate factor for the step interval, applied last ("factor",
                          rate_factor_table_source_control, src/source_control.F90:178-193); 0 = none */
+  double sep_more[6]; /* (hf, hg) of separator stages 2..4; hg = 0 ends the list */
 } wai_source_control;
 int wai_set_source_controls(wai_ctx *ctx, const wai_source_control *controls);
 /* enthalpies of saturated water and steam at a separator pressure, in the context's

@@ -143,7 +143,10 @@ typedef struct wo_src_ctl {
   double sep_hf, sep_hg;  /* saturated water / steam enthalpy at the separator pressure */
   double table[16];       /* (x, pressure) pairs, linear, clamped */
   double factor;          /* rate factor applied last (src/source_control.F90:178-193); 0 = none */
+  double sep_more[6];     /* (hf, hg) of separator stages 2..4, hg = 0 ends the list (src/separator.F90:212-260) */
 } wo_src_ctl;
+/* steam fraction of a flow of enthalpy h through the separator of a control record */
+double wo_separator_steam_fraction(const wo_src_ctl *k, double h);
 void wo_sim_set_source_controls(wo_sim *s, const wo_src_ctl *ctl); /* NULL: none */
 void wo_sim_source_rates(wo_sim *s, double *rate, double *enthalpy);
 int wo_separator_enthalpies(const wo_eos *e, double pressure, double *hf, double *hg);

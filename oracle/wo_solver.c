@@ -195,6 +195,26 @@ int wo_sim_set_residual_form(wo_sim *s, int method, double ratio, const double *
   return 0;
 }
 
+
+/* separator: src/separator.F90:139-166 (one stage) and :212-260 (the water of a stage feeds the next;
+ * steam fraction = total steam rate / rate fed in).  Stage 1 is (sep_hf, sep_hg), stages 2..4 sep_more. */
+double wo_separator_steam_fraction(const wo_src_ctl *k, double h) {
+  double q = 1.0, hh = h, steam = 0.0;
+  for (int i = 0; i < 4; i++) {
+    double hf = i == 0 ? k->sep_hf : k->sep_more[2 * (i - 1)];
+    double hg = i == 0 ? k->sep_hg : k->sep_more[2 * (i - 1) + 1];
+    if (i > 0 && !(hg > 0.0)) break;
+    double f, hw;
+    if (hh <= hf) { f = 0.0; hw = hh; }
+    else if (hh <= hg) { f = (hh - hf) / (hg - hf); hw = hf; }
+    else { f = 1.0; hw = 0.0; }
+    steam += f * q;
+    q = (1.0 - f) * q;
+    hh = hw;
+  }
+  return steam;
+}
+
 /* method wo_timestep integrates with (timestepper.F90:2262-2275 "beuler" | "bdf2" | "directss");
  * clears the step history, so BDF2 starts with a backward Euler step (:391-394) */
 int wo_sim_set_timestep_method(wo_sim *s, int method) {
@@ -403,11 +423,9 @@ static double source_rate(const wo_eos *e, const double *fl, const wo_src_ctl *k
   if (k->limiter) {
     double r = rate;
     if (k->limiter > 1) {
-      double f = 0.0; /* separated flows are zero unless producing */
+      /* separated flows are zero unless producing */
       if (rate < 0.0) {
-        if (h <= k->sep_hf) f = 0.0;
-        else if (h <= k->sep_hg) f = (h - k->sep_hf) / (k->sep_hg - k->sep_hf);
-        else f = 1.0;
+        double f = wo_separator_steam_fraction(k, h);
         r = k->limiter == 2 ? (1.0 - f) * rate : f * rate;
       } else r = 0.0;
     }

@@ -87,6 +87,7 @@ def load(path):
         "wo_sim_set_source_controls": (None, [C.c_void_p, C.c_void_p]),
         "wo_sim_source_rates": (None, [C.c_void_p, pd, pd]),
         "wo_separator_enthalpies": (i32, [C.c_void_p, C.c_double, pd, pd]),
+        "wo_separator_steam_fraction": (C.c_double, [C.c_void_p, C.c_double]),
         "wo_permeability_factor": (d, [C.c_void_p, d]),
         "wo_gas_henry_salt": (None, [C.c_void_p, d, d, pd, pd]), "wo_co2_henrys_constant": (d, [d]),
         "wo_air_properties": (i32, [d, d, pd, pd]), "wo_air_henrys_constant": (d, [d]),

@@ -450,7 +450,8 @@ def test_state_dependent_source_controls(FS, oracle):
             dict(kind="recharge", coef=1.0e-3, pressure=1.0e8, direction="out"),          # would inject: zeroed
             dict(kind="deliverability", coef=1.0e-10, pressure=1.0e5, limiter="total", limit=3.0),
             dict(kind="deliverability", coef=1.0e-10, pressure=1.0e5, limiter="steam", limit=0.5, sep_hf=hf, sep_hg=hg),
-            dict(kind="deliverability", coef=1.0e-10, pressure=1.0e5, limiter="water", limit=2.0, sep_hf=hf, sep_hg=hg),
+            dict(kind="deliverability", coef=1.0e-10, pressure=1.0e5, limiter="water", limit=2.0, sep_hf=hf, sep_hg=hg,
+                 sep_more=[sim.separator_enthalpies(3.0e5), sim.separator_enthalpies(1.2e5)]),   # three stages
             dict(limiter="total", limit=1.0, factor=0.25)]                                 # fixed rate, limited, then scaled
     sim.set_source_controls(recs)
     osim.set_source_controls(recs)

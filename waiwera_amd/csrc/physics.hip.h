@@ -780,13 +780,36 @@ __device__ __forceinline__ double face_phase_flux(const FaceGeom& g, const CellS
 // cell_inflows call (flow_simulation.F90:1469).  Order as the controls are set up
 // (source_setup.F90:2381-2412): deliverability (source_control.F90:359-403) or recharge (:553-578)
 // gives the rate, the limiter scales it (source_network_node.F90:247-315; water / steam through a
-// single-stage separator, separator.F90:139-166), the direction control zeroes it (:596-620).
+// separator, separator.F90:139-166, :212-260), the direction control zeroes it (:596-620).
 struct SrcCtl {
   int kind, direction, limiter, table_coord, n_table;
   double coef, pressure, limit, sep_hf, sep_hg;
   double table[16];
   double factor;
+  double sep_more[6];
 };
+
+// one separator stage (separator.F90:139-166): steam fraction f of a flow of enthalpy h, hw the
+// enthalpy of the water that goes on to the next stage
+__device__ inline double separator_stage(double hf, double hg, double h, double& hw) {
+  if (h <= hf) { hw = h; return 0.0; }
+  if (h <= hg) { hw = hf; return (h - hf) / (hg - hf); }
+  hw = 0.0;
+  return 1.0;
+}
+// all stages (separator.F90:212-260): total steam rate over the rate fed in
+__device__ inline double separator_steam_fraction(const SrcCtl& k, double h) {
+  double hw;
+  const double f1 = separator_stage(k.sep_hf, k.sep_hg, h, hw);
+  if (!(k.sep_more[1] > 0.0)) return f1;
+  double steam = f1, water = 1.0 - f1;
+  for (int i = 0; i < 3 && k.sep_more[2 * i + 1] > 0.0; i++) {
+    const double f = separator_stage(k.sep_more[2 * i], k.sep_more[2 * i + 1], hw, hw);
+    steam += f * water;
+    water *= 1.0 - f;
+  }
+  return steam;
+}
 
 __device__ inline double ctl_table(const SrcCtl& k, double x) {
   const int n = k.n_table;
@@ -829,10 +852,7 @@ __device__ inline double source_rate(const CellState<KIND>& s, const SrcCtl* ctl
     double r = rate;
     if (k.limiter > 1) {
       if (rate < 0.0) {
-        double f;
-        if (h <= k.sep_hf) f = 0.0;
-        else if (h <= k.sep_hg) f = (h - k.sep_hf) / (k.sep_hg - k.sep_hf);
-        else f = 1.0;
+        const double f = separator_steam_fraction(k, h);
         r = k.limiter == 2 ? (1.0 - f) * rate : f * rate;
       } else r = 0.0;
     }

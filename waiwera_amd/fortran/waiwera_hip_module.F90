@@ -45,6 +45,7 @@ module waiwera_hip_module
      real(c_double) :: sep_hf = 0._c_double, sep_hg = 0._c_double
      real(c_double) :: table(16) = 0._c_double
      real(c_double) :: factor = 0._c_double
+     real(c_double) :: sep_more(6) = 0._c_double   !! (hf, hg) of separator stages 2..4; hg = 0 ends the list
   end type wai_source_control
 
   type, bind(c), public :: wai_solver_opts

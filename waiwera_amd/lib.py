@@ -46,7 +46,7 @@ class SourceControl(C.Structure):
     """wai_source_control (include/waiwera_hip.h): state-dependent control of one source"""
     _fields_ = [("kind", i32), ("direction", i32), ("limiter", i32), ("table_coord", i32), ("n_table", i32),
                 ("coef", d), ("pressure", d), ("limit", d), ("sep_hf", d), ("sep_hg", d), ("table", d * 16),
-                ("factor", d)]
+                ("factor", d), ("sep_more", d * 6)]
 
 
 SRC_KIND = {"rate": 0, "deliverability": 1, "recharge": 2}
@@ -56,7 +56,7 @@ SRC_LIMITER = {None: 0, "total": 1, "water": 2, "steam": 3}
 
 def source_controls(records):
     """array of SourceControl from dicts {kind, direction, limiter, coef, pressure, limit, sep_hf,
-    sep_hg, table_coord, table} (missing keys: no control of that sort)"""
+    sep_hg, sep_more, table_coord, table} (missing keys: no control of that sort)"""
     arr = (SourceControl * max(len(records), 1))()
     for k, r in zip(arr, records):
         k.kind = SRC_KIND[r.get("kind", "rate")]
@@ -65,6 +65,11 @@ def source_controls(records):
         k.coef, k.pressure = r.get("coef", 0.0), r.get("pressure", 0.0)
         k.limit, k.sep_hf, k.sep_hg = r.get("limit", 0.0), r.get("sep_hf", 0.0), r.get("sep_hg", 0.0)
         k.factor = r.get("factor", 0.0)
+        more = r.get("sep_more", ())      # (hf, hg) of separator stages 2..4
+        if len(more) > 3:
+            raise ValueError("separators have at most 4 stages")
+        for q, (hf, hg) in enumerate(more):
+            k.sep_more[2 * q], k.sep_more[2 * q + 1] = hf, hg
         tab = r.get("table")
         k.table_coord = {None: 0, "enthalpy": 1, "pressure": 2}[r.get("table_coord")] if tab is not None else 0
         if tab is not None:

@@ -467,15 +467,15 @@ class Simulation:
                 psep = sep.get("pressure", 0.55e6) if isinstance(sep, dict) else 0.55e6
             elif "limiter" in s and "separator_pressure" in s["limiter"]:
                 psep = s["limiter"]["separator_pressure"]
-            if isinstance(psep, (list, tuple)):
-                if len(psep) > 1:
-                    raise NotImplementedError("multi-stage separators")
-                psep = psep[0]
+            stages = list(psep) if isinstance(psep, (list, tuple)) else [psep]
+            if len(stages) > 4:
+                raise NotImplementedError("separators with more than 4 stages")
             if r.get("limiter") in ("water", "steam"):
-                if psep is None or psep <= 0.0:
+                if psep is None or not stages or not all(p > 0.0 for p in stages):   # separator_init, separator.F90:182
                     r["limiter"] = None      # no separator: separated flows are zero, never over the limit
                 else:
-                    r["sep_hf"], r["sep_hg"] = self.ode.separator_enthalpies(float(psep))
+                    r["sep_hf"], r["sep_hg"] = self.ode.separator_enthalpies(float(stages[0]))
+                    r["sep_more"] = [self.ode.separator_enthalpies(float(p)) for p in stages[1:]]
             if "direction" in s:
                 r["direction"] = s["direction"].lower()
             if "factor" in s:      # rate factor, applied after every other control (:2615-2660)
