@@ -43,9 +43,18 @@ def _run_steps(sim, y, nsteps=3):
     return out
 
 
-def _worker(rank, world, uid, q):
+def _worker(rank, world, uid_q, q):
     os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    from waiwera_amd import lib as wl
     from waiwera_amd.flow_simulation import FlowSimulation
+    # rank 0 makes the id in its own fresh process: the pytest process may already hold the real
+    # librccl (tests/test_hip_comm.py), whose ids are not the loopback's segment names
+    if rank == 0:
+        uid = wl.comm_unique_id()
+        for _ in range(world - 1):
+            uid_q.put(uid)
+    else:
+        uid = uid_q.get(timeout=300)
     g, lm, prim, region = _problem(M.partition_shape(world), rank)
     sim = FlowSimulation(lm, eos="we", device=0)
     sim.set_regions(region)
@@ -72,12 +81,10 @@ def test_ranks_sharing_one_gpu_match_one_rank(world):
     bricks raggedly so the preconditioner differs from the serial one)"""
     assert os.path.exists(LOOPBACK), "build first: python __graft_entry__.py"
     os.environ["WAI_RCCL_LIB"] = LOOPBACK
-    from waiwera_amd import lib as wl
     from waiwera_amd.flow_simulation import FlowSimulation
-    uid = wl.comm_unique_id()
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, uid, q)) for r in range(world)]
+    q, uid_q = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, uid_q, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=400) for _ in range(world)]
