@@ -1,21 +1,30 @@
 #!/usr/bin/env python
-"""Headline benchmark: Newton steps/s of the eos_we hot path on a 216^3 (10 077 696-cell)
-synthetic structured mesh (BASELINE.json metric / SURVEY.md section 8d workload), plus the
-BCSR SpMV roofline and the CPU oracle timed on a bounded sample.
+"""Headline benchmark: Newton steps/s of the Newton-step hot path on the synthetic structured
+meshes of SURVEY.md section 8d (BASELINE.json metric), the roofline of the dominant kernel, and the
+CPU oracle timed on the same mesh.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W           # N > 1: spawns its own N ranks
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+Workloads (--config): c3 (default) 216^3 = 10 077 696-cell eos we; c2 100^3 eos we; c4 172x172x170
+eos wce (3 x 3 blocks); c5 100^3 fracture cells + 1 MINC matrix level, eos wce.
+
 A "step" is one Newton iteration of a backward-Euler time step: FD Jacobian assembly,
-block-Jacobi ILU(0) set-up, BiCGStab solve to rtol 1e-5, full-step line search with phase
-transitions, and the new residual (src/timestepper.F90:587-735).  Time steps follow
-dt = 1e4 * 2^n s; a converged step moves on to the next one, a failed one is retried with
-dt * 0.2 like the reference (src/timestepper.F90:1353-1375).  Total work is fixed as N grows
-(the 10 M-cell mesh is split over the ranks): scaling = strong.
+preconditioner set-up, BiCGStab solve to rtol 1e-5, full-step line search with phase transitions,
+and the new residual (src/timestepper.F90:587-735).  Time steps follow the reference's controller
+with dt doubling after a converged step and dt * 0.2 after a failed one
+(src/timestepper.F90:1353-1375) from dt = 1e4 s.  The *measured window is fixed*: the first
+`--lead` (3) accepted time steps are a lead-in outside all timing; warm-up and timed Newton steps
+walk through accepted time steps 3..7 of the trajectory (SURVEY.md section 8d "measure steps 3-7"),
+failed tries included, and start over from the saved state at the start of step 3 when they reach
+the end of step 7 -- so --warmup only moves the phase inside that cycle, not the part of the
+trajectory that is measured.  Total work is fixed as N grows (the mesh is split over the ranks):
+scaling = strong.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,6 +34,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+CONFIGS = {  # C2 .. C5
+    "c2": dict(dims=(100, 100, 100), eos="we", minc=False),
+    "c3": dict(dims=(216, 216, 216), eos="we", minc=False),
+    "c4": dict(dims=(172, 172, 170), eos="wce", minc=False),
+    "c5": dict(dims=(100, 100, 100), eos="wce", minc=True),
+}
 
 
 def log(*a):
@@ -46,6 +62,20 @@ class NewtonDriver:
         self.log = []
         self.tries = 0
         self.krylov = 0
+        self.window = None   # (first step, last step + 1): cycle through these accepted steps
+
+    def snapshot(self):
+        """state at the start of a time step (no Newton iteration in flight)"""
+        assert self.it < 0
+        self.sim.synchronize()
+        return dict(y=self.y.clone(), regions=self.sim.regions().copy(), t=self.t, dt=self.dt, nstep=self.nstep)
+
+    def restore(self, s):
+        self.sim.synchronize()
+        self.y.copy_(s["y"])
+        self.torch.cuda.synchronize()
+        self.sim.set_regions(s["regions"])
+        self.t, self.dt, self.nstep, self.it, self.tries = s["t"], s["dt"], s["nstep"], -1, 0
 
     def _begin(self):
         s = self.sim
@@ -61,13 +91,17 @@ class NewtonDriver:
         self.it = 0
 
     def newton_step(self):
+        t0 = time.perf_counter()
         if self.it < 0:
+            if self.window and self.nstep >= self.window[1]:
+                self.restore(self.window[2])
             self._begin()
         s = self.sim
         reason, kits, maxres = s.newton_step(self.t + self.dt, self.dt, self.it, self.y, self.lhs_old, self.f)
         self.krylov += kits
         self.it += 1
-        self.log.append((self.nstep, self.dt, self.it, kits, reason, maxres))
+        rec = [self.nstep, self.dt, self.it, kits, reason, maxres, 0.0]
+        self.log.append(rec)
         if reason > 0:  # converged: next time step, doubled dt (synthetic schedule)
             self.t += self.dt
             self.dt *= 2.0
@@ -84,6 +118,7 @@ class NewtonDriver:
             self.it = -1
             if self.tries > 10:
                 raise RuntimeError("time step failed 10 times")
+        rec[6] = time.perf_counter() - t0
         return reason, kits
 
 
@@ -101,26 +136,31 @@ def pc_bytes(nnzb, n, bs):
     return nnzb * (8 * bs * bs + 4) + n * (pivots + 4 + 3 * 8 * bs)
 
 
-def traffic_from_profiles(dims, brick):
-    """HBM bytes per k_pc launch from the committed rocprofv3 PMC passes (profiles/), collected
+def traffic_from_profiles(cfg, dims, brick):
+    """HBM bytes per fused-kernel launch from the committed rocprofv3 PMC passes (profiles/), collected
     and corrected as MI355X_MICROARCH.md prescribes; only valid for the mesh it was taken on."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic_r1.json")
-    if os.path.exists(p):
-        try:
-            d = json.load(open(p))
-            if list(d.get("dims", [])) == list(dims) and list(d.get("brick", [])) == list(brick):
-                return d.get("k_pc_hbm_bytes_per_launch")
-        except Exception:
-            return None
+    for name in ("pmc_traffic_r2_%s.json" % cfg, "pmc_traffic_r2.json", "pmc_traffic_r1.json"):
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            try:
+                d = json.load(open(p))
+                if list(d.get("dims", [])) == list(dims) and list(d.get("brick", [])) == list(brick):
+                    return d.get("k_pc_hbm_bytes_per_launch")
+            except Exception:
+                return None
     return None
 
 
-def cpu_baseline(dims_full, brick=(16, 16, 2)):
-    """Oracle (CPU restatement of the reference path, OpenMP) on a bounded sample of the same
-    workload: the first backward-Euler step (dt = 2e3 s, 4 Newton iterations) of the same
-    synthetic problem on a 96^3 box, run at several thread counts; the best rate is reported
-    (cores = the thread count that achieved it) and scaled by cell count to the full mesh."""
-    import ctypes
+def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0):
+    """The oracle (CPU restatement of the reference's path, OpenMP) timed on the SAME mesh and the same
+    state the timed window starts from -- one Newton step, piece by piece: unperturbed residual, FD
+    Jacobian (per-row differencing, and the reference's coloured MatFDColoring sweep when it fits the
+    time budget), ILU(0) set-up with one subdomain per thread (what `mpiexec -np T` gives the
+    reference's block preconditioner), and K BiCGStab iterations.  The Newton step's time is
+    t_residual + t_jacobian + t_setup + (Krylov iterations per Newton step measured on the GPU
+    trajectory) x t_iteration: only the iteration *count* is carried over, every time is measured
+    on this mesh."""
+    import ctypes as C
     so = os.path.join(ROOT, "oracle", "liboracle.so")
     if not os.path.exists(so):
         return None
@@ -128,73 +168,153 @@ def cpu_baseline(dims_full, brick=(16, 16, 2)):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(avail))
     from tests import oracle_lib as ol
-    from tests.cases import scaled
-    from waiwera_amd import mesh as M
     L = ol.load(so)
     try:
-        gomp = ctypes.CDLL("libgomp.so.1")
+        gomp = C.CDLL("libgomp.so.1")
     except OSError:
         gomp = None
-    dims = (96, 96, 96) if avail >= 16 else (40, 40, 40)
-    g = M.StructuredGrid(dims, brick=tuple(brick))
-    lm = g.local_mesh(0, rock_fn=M.heterogeneous_rock(g.n_global), top_bc=([1.0e5, 20.0], 1),
-                      sources=M.benchmark_sources(g))
-    prim, region = M.benchmark_initial_state(g, lm.extras["prim_ijk"], lens=True)
-    trials = sorted({t for t in (16, 32, 64, 128) if t <= avail} or {avail}) if gomp else [avail]
-    best = None
-    for t in trials:
+    kind = {"w": 0, "we": 1, "wce": 2}[eos]
+    t_all = time.time()
+    osim = ol.OracleSim(L, lm, kind)
+    osim.set_regions(region0)
+    y = osim.yvec(y0)
+    n = osim.n_owned
+    rp, ci = osim.pattern()
+    bs = osim.np
+
+    def set_threads(t):
         if gomp:
-            gomp.omp_set_num_threads(t)
-        osim = ol.OracleSim(L, lm, 1)
-        osim.set_regions(region)
-        y = osim.yvec(scaled(prim, region).ravel())
+            gomp.omp_set_num_threads(int(t))
+        sp = np.linspace(0, n, int(t) + 1).astype(np.int32)   # one ILU(0) subdomain per thread
+        L.wo_sim_set_subdomains(osim.h, int(t), ol.ip(sp))
+
+    # thread count: the SpMV-bound Krylov iteration decides; probe a few counts on the matrix pattern
+    trials = sorted({t for t in (16, 32, 64, 128, 192, 256) if t <= avail} | {min(avail, 8)}) if gomp else [1]
+    val = np.zeros(rp[-1] * bs * bs)
+    x = np.ones(osim.n_prim * bs)
+    out = np.zeros(n * bs)
+    best_t, best = trials[0], None
+    for t in trials:
+        set_threads(t)
+        L.wo_bcsr_spmv(n, bs, ol.ip(rp), ol.ip(ci), ol.dp(val), ol.dp(x), ol.dp(out))
         t0 = time.time()
-        r, k = osim.timestep(y, 2.0e3, osim.opts())
-        el = time.time() - t0
-        osim.close()
-        steps = r if r > 0 else osim.opts().max_newton_its
-        log("  cpu baseline: %d threads: %d Newton steps, %d Krylov its in %.2f s" % (t, steps, k, el))
-        if best is None or steps / el > best[0]:
-            best = (steps / el, t, steps, k, el)
-    rate, t, steps, k, el = best
-    n_s, n_f = dims[0] * dims[1] * dims[2], dims_full[0] * dims_full[1] * dims_full[2]
-    return {"value": rate * n_s / n_f, "unit": "Newton steps/s", "cores": t, "kind": "port",
-            "sample": "first BE step (dt 2e3 s): %d Newton steps, %d Krylov iterations of the same synthetic eos_we "
-                      "problem on a %dx%dx%d box in %.1f s with %d OpenMP threads (best of %s threads on a %d-thread "
-                      "host), scaled by cell count (%d / %d) to the %dx%dx%d mesh"
-                      % (steps, k, dims[0], dims[1], dims[2], el, t, "/".join(str(x) for x in trials), avail, n_s, n_f,
-                         dims_full[0], dims_full[1], dims_full[2])}
+        for _ in range(3):
+            L.wo_bcsr_spmv(n, bs, ol.ip(rp), ol.ip(ci), ol.dp(val), ol.dp(x), ol.dp(out))
+        el = (time.time() - t0) / 3
+        log("  cpu baseline: %3d threads: SpMV %.3f s" % (t, el))
+        if best is None or el < best:
+            best, best_t = el, t
+    del val, x, out
+    set_threads(best_t)
+    L.wo_pre_timestep(osim.h)
+    t0 = time.time()
+    assert osim.pre_eval(y) == 0
+    lhs_old = osim.lhs()
+    err, f = osim.residual(y, dt, lhs_old)
+    t_res = time.time() - t0
+    L.wo_pre_iteration(osim.h)
+    t0 = time.time()
+    err, J = osim.jacobian(y, dt, lhs_old, f, mode=0)
+    t_jac = time.time() - t0
+    t_col = None
+    if time.time() - t_all + 12.0 * t_jac < budget_s:   # coloured FD: 1 + ncolors x bs full sweeps
+        t0 = time.time()
+        err, J2 = osim.jacobian(y, dt, lhs_old, f, mode=1)
+        t_col = time.time() - t0
+        del J2
+    t0 = time.time()
+    assert osim.pc_setup(J) == 0
+    t_setup = time.time() - t0
+    K = 8
+    xs = np.zeros(osim.n_prim * bs)
+    its = C.c_int(0)
+    rn = C.c_double(0)
+    t0 = time.time()
+    L.wo_ksp_solve(osim.h, 0, 30, ol.dp(J), ol.dp(f), ol.dp(xs), 1e-30, 1e-50, K, C.byref(its), C.byref(rn), None)
+    t_solveK = time.time() - t0
+    t_iter = max(t_solveK - t_setup, 1e-9) / max(its.value, 1)     # wo_ksp_solve factors again
+    osim.close()
+    t_newton = t_res + t_jac + t_setup + kits_per_newton * t_iter
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    sample = ("same mesh (%d cells), same state as the timed window's first Newton step, dt %.3g s: residual %.2f s, "
+              "FD Jacobian %.2f s (per-row differencing%s), ILU(0) set-up %.2f s with one subdomain per thread, "
+              "BiCGStab %.3f s/iteration over %d iterations; Newton step = residual + Jacobian + set-up + %.1f "
+              "iterations (the count measured on the GPU trajectory) x s/iteration = %.1f s; %d OpenMP threads "
+              "(best SpMV of %s) on %d hardware threads, %s"
+              % (n, dt, t_res, t_jac, "; reference-style coloured sweeps %.2f s" % t_col if t_col else "", t_setup,
+                 t_iter, its.value, kits_per_newton, t_newton, best_t, "/".join(str(t) for t in trials), avail, model))
+    out = {"value": 1.0 / t_newton, "unit": "Newton steps/s", "cores": best_t, "kind": "port", "sample": sample,
+           "seconds": {"residual": t_res, "jacobian_per_row": t_jac, "jacobian_coloured": t_col, "pc_setup": t_setup,
+                       "krylov_iteration": t_iter}}
+    if t_col:
+        out["value_with_coloured_jacobian"] = 1.0 / (t_newton - t_jac + t_col)
+    return out
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one per device)."""
+    import torch
+    loopback = os.environ.get("WAI_BENCH_LOOPBACK") == "1"
+    have = torch.cuda.device_count()
+    if have < a.gpus and not loopback:
+        print("bench.py: --gpus %d but only %d visible device(s)" % (a.gpus, have), file=sys.stderr)
+        return 2
+    port = os.environ.get("MASTER_PORT") or str(29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--dims", type=int, nargs=3, default=[216, 216, 216])
-    ap.add_argument("--brick", type=int, nargs=3, default=[16, 16, 2],
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--dims", type=int, nargs=3, default=None)
+    ap.add_argument("--eos", default=None, choices=["we", "wce"])
+    ap.add_argument("--minc", action="store_true", default=None)
+    ap.add_argument("--brick", type=int, nargs=3, default=None,
                     help="preconditioner subdomain shape (cells): wide in x, y and thin in z because k_z = 0.1 k_x")
     ap.add_argument("--dt0", type=float, default=1.0e4)
+    ap.add_argument("--lead", type=int, default=3, help="accepted time steps run before the measured window")
+    ap.add_argument("--window", type=int, default=5, help="accepted time steps in the measured cycle")
     ap.add_argument("--ksp", default="bcgs")
+    ap.add_argument("--pc", default="bjacobi", choices=["bjacobi", "asm", "none"])
     ap.add_argument("--no-lens", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--spmv-reps", type=int, default=200)
     ap.add_argument("--profile", action="store_true", help="per-kernel-class HIP event timing (serialises)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (a.gpus, world))
+        print("bench.py: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
+        sys.exit(2)
     # tests/test_hip_multirank.py only: every rank on cuda:0 with a loopback librccl (WAI_RCCL_LIB)
     # and gloo for the host-side barrier, so that the N > 1 launch can be exercised on a 1-GPU box
     loopback = os.environ.get("WAI_BENCH_LOOPBACK") == "1"
     if loopback:
         local_rank = 0
+    elif world > torch.cuda.device_count():
+        print("bench.py: %d ranks but %d visible device(s)" % (world, torch.cuda.device_count()), file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -207,27 +327,38 @@ def main():
     from waiwera_amd import lib as wl
     from waiwera_amd import mesh as M
     from waiwera_amd.flow_simulation import FlowSimulation
-    from tests.cases import scaled
+    from tests.cases import make_case, scaled
 
     t_setup = time.time()
-    dims = tuple(a.dims)
-    grid = M.StructuredGrid(dims, part=M.partition_shape(world), brick=tuple(a.brick))
-    lm = grid.local_mesh(rank, rock_fn=M.heterogeneous_rock(grid.n_global),
-                         top_bc=([1.0e5, 20.0], 1), sources=M.benchmark_sources(grid))
-    prim, region = M.benchmark_initial_state(grid, lm.extras["prim_ijk"], lens=not a.no_lens)
-    opts = wl.default_opts(ksp_type=a.ksp)
-    sim = FlowSimulation(lm, eos="we", opts=opts, device=local_rank)
+    cfg = dict(CONFIGS[a.config])
+    if a.dims:
+        cfg["dims"] = tuple(a.dims)
+    if a.eos:
+        cfg["eos"] = a.eos
+    if a.minc:
+        cfg["minc"] = True
+    dims, eos, minc = tuple(cfg["dims"]), cfg["eos"], cfg["minc"]
+    # bricks: wide in x, y, thin in z (k_z = 0.1 k_x); with a MINC level the matrix cells join their
+    # fracture cell's brick, so the fracture bricks are half as large
+    brick = tuple(a.brick) if a.brick else ((16, 16, 1) if minc else (16, 16, 2))
+    grid, lm, prim, region = make_case(dims=dims, brick=brick, eos=eos, lens=not a.no_lens, minc=minc,
+                                       part=M.partition_shape(world), rank=rank)
+    opts = wl.default_opts(ksp_type=a.ksp, pc_type=a.pc)
+    sim = FlowSimulation(lm, eos=eos, opts=opts, device=local_rank)
     sim.set_regions(region)
     if world > 1:
         uid = [wl.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         sim.comm_init(rank, world, uid[0])
+        if sim.comm_size() != world:
+            raise RuntimeError("RCCL communicator has %d ranks, expected %d" % (sim.comm_size(), world))
     bs = sim.num_primary_variables
     y = torch.zeros(sim.n_prim * bs, dtype=torch.float64, device="cuda")
-    y.copy_(torch.from_numpy(scaled(prim, region).ravel()))
+    y.copy_(torch.from_numpy(scaled(prim, region, eos).ravel()))
     torch.cuda.synchronize()
-    log("setup %.1f s: %d owned cells/rank, %d faces, %d subdomains, nnzb %d"
-        % (time.time() - t_setup, lm.n_owned, lm.n_faces, lm.sub_ptr.size - 1, wl.LIB.wai_jacobian_nnzb(sim.h)))
+    n_cells = grid.n_global * (2 if minc else 1)
+    log("setup %.1f s: config %s, %d owned cells/rank, %d faces, %d subdomains, nnzb %d"
+        % (time.time() - t_setup, a.config, lm.n_owned, lm.n_faces, lm.sub_ptr.size - 1, wl.LIB.wai_jacobian_nnzb(sim.h)))
 
     drv = NewtonDriver(sim, y, a.dt0, torch)
 
@@ -237,12 +368,21 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # lead-in: the first accepted time steps, outside warm-up and timing
+    t_lead = time.time()
+    while drv.nstep < a.lead:
+        drv.newton_step()
+    n_lead = len(drv.log)
+    start = drv.snapshot()
+    drv.window = (a.lead, a.lead + a.window, start)
+    log("lead-in: %d Newton steps for %d accepted time steps in %.1f s; window starts at t = %.4g s, dt = %.4g s"
+        % (n_lead, a.lead, time.time() - t_lead, start["t"], start["dt"]))
     for _ in range(a.warmup):
         drv.newton_step()
     if a.profile:
         sim.profile(True)
     barrier()
-    k0 = drv.krylov
+    k0, l0 = drv.krylov, len(drv.log)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         drv.newton_step()
@@ -253,21 +393,24 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     kits = drv.krylov - k0
+    timed = drv.log[l0:]
     prof = sim.profile_get() if a.profile else None
     sim.profile(False)
-    for rec in drv.log:
-        log("  step %d dt %.3g newton %d krylov %d reason %d maxres %.3e" % rec)
+    for i, rec in enumerate(drv.log):
+        tag = "lead" if i < n_lead else ("warm" if i < l0 else "TIME")
+        log("  %s step %d dt %.3g newton %d krylov %d reason %d maxres %.3e  %.3f s" % ((tag,) + tuple(rec)))
+    # least squares: seconds per Newton step = fixed part (Jacobian, set-up, residual, transitions)
+    # + Krylov iterations x seconds per iteration
+    A = np.array([[1.0, r[3]] for r in timed])
+    b = np.array([r[6] for r in timed])
+    fixed_s, iter_s = (np.linalg.lstsq(A, b, rcond=None)[0] if len(timed) > 2 and np.ptp(A[:, 1]) > 0 else (0.0, 0.0))
 
     # Kernel roofline, measured live with HIP events on the library's stream on the last
     # assembled Jacobian.  Dominant kernel of a Newton step: the fused preconditioned operator
     # k_pc (block SpMV t = A x, block-Jacobi ILU(0) solve z = U^-1 L^-1 t, dot (z, aux)), run
     # twice per BiCGStab iteration.  Plain block SpMV is reported beside it.
-    n = lm.n_owned * bs
     nnzb = wl.LIB.wai_jacobian_nnzb(sim.h)
-    names = ["spmv", "ilu_apply", "fused_pc_amul", "probe_ilu_nosweep", "probe_fused_nosweep",
-             "ilu_apply_barrier_path", "fused_barrier_path"]
-    if os.environ.get("WAI_PC_PIPE") == "1":  # opt-in pipelined kernel: then 2 is that kernel, plus its probes
-        names += ["probe_pipe_nosweep", "probe_pipe_noloads"]
+    names = ["spmv", "ilu_apply", "fused_pc_amul"]
     kb = {name: sim.bench_kernel(w, a.spmv_reps if w in (0, 2) else 20) for w, name in enumerate(names)}
     log("kernel microbench (ms/launch): " + json.dumps(kb))
     b_spmv = spmv_bytes(nnzb, lm.n_owned, bs)
@@ -281,26 +424,39 @@ def main():
         log("kernel-class time inside the timed region (ms, launches): " + json.dumps(prof))
 
     if rank == 0:
+        ksp_name = {"bcgs": "BiCGStab", "gmres": "GMRES(30)"}.get(a.ksp, a.ksp)
+        pc_name = {"bjacobi": "block-Jacobi", "asm": "ASM overlap 1 (restricted)", "none": "no preconditioner"}[a.pc]
         out = {
-            "metric": "Newton steps/sec, 10M-cell eos_we (BCSR SpMV GB/s in roofline)",
+            "metric": "Newton steps/sec, 10M-cell eos_we (BCSR SpMV GB/s in roofline)" if a.config == "c3"
+                      else "Newton steps/sec, config %s" % a.config,
             "value": a.steps / el, "unit": "Newton steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%dx%dx%d structured eos_we mesh (%d cells), BE steps dt=1e4*2^n s, "
-                                   "%s + block-Jacobi(%dx%dx%d bricks)/ILU(0), rtol 1e-5"
-                                   % (dims + (grid.n_global, {"bcgs": "BiCGStab", "gmres": "GMRES(30)"}.get(a.ksp, a.ksp))
-                                      + tuple(a.brick)),
+            "config": {"workload": "%s: %dx%dx%d structured eos_%s mesh%s (%d cells), BE time steps %d-%d of the dt=1e4*2^n / "
+                                   "retry*0.2 trajectory (cyclic), %s + %s(%dx%dx%d bricks)/ILU(0), rtol 1e-5"
+                                   % ((a.config,) + dims + (eos, " + 1 MINC level" if minc else "", n_cells, a.lead,
+                                                            a.lead + a.window - 1, ksp_name, pc_name) + brick),
                        "krylov_iterations_per_newton_step": kits / max(a.steps, 1),
-                       "partition": "x".join(str(p) for p in grid.part), "ksp": a.ksp},
-            "roofline": {"bound": "hbm", "kernel": "k_pc_park<spmv> (fused BCSR SpMV + block ILU(0) apply + dot; k_pc<2,spmv,dilu> with WAI_PC_PARK=0)",
+                       "krylov_iterations": kits,
+                       "ms_per_krylov_iteration": 1e3 * iter_s, "ms_fixed_per_newton_step": 1e3 * fixed_s,
+                       "timed_newton_steps": [{"time_step": r[0], "dt": r[1], "newton": r[2], "krylov": r[3],
+                                               "reason": r[4], "ms": 1e3 * r[6]} for r in timed],
+                       "partition": "x".join(str(p) for p in grid.part), "ksp": a.ksp, "pc": a.pc},
+            "roofline": {"bound": "hbm", "kernel": sim.pc_kernel_name() + " (fused BCSR SpMV + block ILU(0) apply + dot)",
                          "achieved": achieved_pc, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_pc / HBM_PEAK_GBS, "traffic": traffic_from_profiles(dims, a.brick) if world == 1 else None,
+                         "frac": achieved_pc / HBM_PEAK_GBS,
+                         "traffic": traffic_from_profiles(a.config, dims, brick) if world == 1 else None,
                          "algorithmic_bytes_per_launch": b_pc, "ms_per_launch": ms_pc,
-                         "spmv": {"kernel": "k_spmv<2> (BCSR SpMV)", "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+                         "spmv": {"kernel": "k_spmv<%d> (BCSR SpMV)" % bs, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
                                   "algorithmic_bytes_per_launch": b_spmv, "ms_per_launch": ms}},
         }
         if not a.no_cpu and world == 1:   # the CPU baseline is a single-GPU-run item
-            cb = cpu_baseline(dims, a.brick)
+            try:
+                cb = cpu_baseline(lm, eos, start["y"].cpu().numpy(), start["regions"], start["dt"],
+                                  kits / max(a.steps, 1))
+            except Exception as e:   # the reported baseline must not take the measurement down with it
+                log("cpu baseline failed: %r" % (e,))
+                cb = None
             if cb:
                 out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)

@@ -38,13 +38,20 @@ enum { WAI_RP_FULLY_MOBILE = 0, WAI_RP_LINEAR = 1, WAI_RP_PICKENS = 2, WAI_RP_CO
        WAI_RP_GRANT = 4, WAI_RP_VAN_GENUCHTEN = 5 };
 enum { WAI_CP_ZERO = 0, WAI_CP_LINEAR = 1, WAI_CP_VAN_GENUCHTEN = 2 };
 enum { WAI_KSP_BCGS = 0, WAI_KSP_GMRES = 1 };
+/* linear.preconditioner.type (src/timestepper.F90:1745-1757): "bjacobi" PCBJACOBI, "asm" PCASM (the
+ * reference's default: restricted, overlap 1), "none" PCNONE; the blocks' sub-preconditioner is
+ * ILU(0) (:1668-1669, 1809-1834).  "ilu" of a serial run is bjacobi / asm with sub_ptr = NULL. */
+enum { WAI_PC_BJACOBI = 0, WAI_PC_ASM = 1, WAI_PC_NONE = 2 };
 
 /* DMPlex-local arrays in the reference's own record layouts (AoS), host memory:
  *   face_geom 12/face  src/face.F90:67-76,119-135   cell_geom 4/cell  src/cell.F90:54-61
  *   rock 8/cell        src/rock.F90:56-65,97-112     face_cells 2/face (DMPlexGetSupport order,
  *                                                    normal from cell 1 to cell 2)
- * sub_ptr[n_sub+1]: block-Jacobi subdomains of the preconditioner as contiguous owned-row
- * ranges (PCBJACOBI blocks, src/timestepper.F90:1668-1669); NULL = one block per rank. */
+ * sub_ptr[n_sub+1]: subdomains of the preconditioner (PCBJACOBI / PCASM blocks,
+ * src/timestepper.F90:1668-1669) as contiguous owned-row ranges; NULL = one block per rank, the
+ * reference's layout.  Blocks of up to 1024 rows (bricks of the mesh) run on the fused
+ * one-workgroup-per-block kernels; larger ones -- any size -- on the launch-per-dependency-level
+ * path, which is general but several times slower per application. */
 typedef struct wai_mesh_desc {
   int n_owned, n_halo, n_bc, n_faces;
   const int *face_cells;
@@ -90,6 +97,8 @@ typedef struct wai_solver_opts {
   double utol_rel, utol_abs;   /* nonlinear.tolerance.update.{relative 1e-10, absolute 1} */
   double fd_eps, fd_umin;      /* nonlinear.jacobian.differencing.{increment 1e-8, tolerance 1e-2} */
   int min_newton_its;          /* nonlinear.minimum.iterations, default 0 (timestepper.F90:1930-1932) */
+  int pc_type;                 /* linear.preconditioner.type: WAI_PC_BJACOBI (default here) | WAI_PC_ASM | WAI_PC_NONE */
+  int asm_overlap;             /* PCASM overlap, PETSc default 1; does not reach across ranks */
 } wai_solver_opts;
 
 void wai_default_eos(wai_eos_desc *e, int kind);
@@ -164,6 +173,7 @@ int wai_set_halo(wai_ctx *ctx, int n_nbr, const int *nbr_rank, const int *send_p
 int wai_comm_unique_id(char id[128]);                       /* rank 0, then broadcast by host */
 int wai_comm_init(wai_ctx *ctx, int rank, int nranks, const char id[128]);
 int wai_halo_exchange(wai_ctx *ctx, double *vec, int dof);  /* vec has dof*(n_owned+n_halo) */
+int wai_comm_size(wai_ctx *ctx);   /* ranks the RCCL communicator reports (1 without one) */
 
 /* ---- ode_type surface (src/ode.F90:39-108 as overridden by src/flow_simulation.F90) ------ */
 int wai_pre_timestep(wai_ctx *ctx);                 /* flow_simulation.F90:2022-2035 */
@@ -201,7 +211,7 @@ int wai_jacobian_get_values(wai_ctx *ctx, double *val);            /* bs*bs row-
 int wai_jacobian_set_values(wai_ctx *ctx, const double *val);
 /* MatMult_SeqBAIJ / MPIBAIJ: y = J x (x haloed internally) */
 int wai_spmv(wai_ctx *ctx, const double *x, double *y);
-/* PCSetUp / PCApply of bjacobi + ilu(0) (:1668-1669,1789-1834) */
+/* PCSetUp / PCApply of bjacobi | asm + ilu(0), or none (:1668-1669,1745-1757,1789-1834) */
 int wai_pc_setup(wai_ctx *ctx);
 int wai_pc_apply(wai_ctx *ctx, const double *r, double *z);
 /* KSPSolve (:1645-1836): left-preconditioned BiCGStab / GMRES(m), zero initial guess.
@@ -261,9 +271,9 @@ int wai_timer_stop(wai_ctx *ctx, float *ms);
 int wai_synchronize(wai_ctx *ctx);
 /* HIP-event timed repetitions of one kernel on the library's stream (needs an assembled
  * Jacobian): which 0 block SpMV, 1 ILU(0) apply, 2 fused SpMV + ILU(0) apply + dot,
- * 3/4 timing probes of 1/2 without the substitution sweeps, 5/6 = 1/2 on the per-level barrier
- * path, 7/8 probes of the opt-in pipelined kernel (WAI_PC_PIPE=1: sweeps / prefetch skipped) */
+ * 3/4 timing probes of 1/2 without the substitution sweeps (generic brick kernel only) */
 int wai_bench_kernel(wai_ctx *ctx, int which, int reps, float *ms_per_launch);
+const char *wai_pc_kernel_name(wai_ctx *ctx);   /* kernel / path of a preconditioned-operator application */
 /* accumulated HIP-event time (ms) and launch counts per kernel class since the last reset;
  * classes: 0 eos, 1 residual, 2 jacobian, 3 spmv, 4 pc_apply, 5 pc_setup, 6 vector, 7 transitions */
 int wai_profile_enable(wai_ctx *ctx, int on);

@@ -170,6 +170,14 @@ void wo_sim_update_sources(wo_sim *s, const double *rate, const double *enthalpy
 void wo_sim_set_sources(wo_sim *s, int n, const int *cell, const double *rate,
                         const double *enthalpy, const int *component);
 void wo_sim_set_subdomains(wo_sim *s, int nsub, const int *sub_ptr);
+/* PCASM, restricted, `overlap` layers of matrix-graph neighbours around every subdomain (the
+ * reference's default preconditioner: src/timestepper.F90:1668-1669, 1753-1757; PETSc default
+ * overlap 1); 0 = block Jacobi (PCBJACOBI).  Call after wo_sim_set_subdomains. */
+void wo_sim_set_asm(wo_sim *s, int overlap);
+int wo_sim_asm_rows(wo_sim *s, int *ptr, int *rows);
+void wo_sim_set_pc_none(wo_sim *s, int none);   /* PCNONE (:1747-1748) */
+int wo_pc_setup(wo_sim *s, const double *val);
+void wo_pc_apply(wo_sim *s, const double *r, double *z);
 void wo_sim_set_regions(wo_sim *s, const int *region /* n_owned+n_halo */);
 void wo_sim_get_regions(wo_sim *s, int *region);
 int wo_sim_init_bc(wo_sim *s, const double *primary /* unscaled, n_bc*np */, const int *region);

@@ -40,6 +40,13 @@ struct wo_sim {
   wo_allreduce_fn ar;
   void *user;
   double *fval, *dinv;
+  /* PCASM (restricted additive Schwarz, overlap >= 1) over the same subdomains: per subdomain
+   * the overlapped row set, its local CSR pattern with the index of every kept block in the
+   * global matrix, and its own ILU(0) factor */
+  int asm_overlap, pc_none;
+  int *asm_ptr, *asm_rows;      /* overlapped rows of subdomain s: asm_rows[asm_ptr[s] .. asm_ptr[s+1]) ascending */
+  int *asm_rowptr, *asm_col, *asm_src; /* local CSR over all overlapped rows; columns local to the subdomain */
+  double *asm_fval, *asm_dinv;
   /* residual form of the time stepping method (see res_form) */
   int method;           /* 0 backward Euler, 1 BDF2, 2 direct steady state */
   double ratio;         /* BDF2: dt / last dt */
@@ -173,6 +180,8 @@ void wo_sim_destroy(wo_sim *s) {
   free(s->cf_ptr); free(s->cf_face); free(s->cf_side); free(s->rowptr); free(s->colidx);
   free(s->src_cell); free(s->src_comp); free(s->src_rate); free(s->src_enth); free(s->src_ctl);
   s->src_ctl = NULL;
+  free(s->asm_ptr); free(s->asm_rows); free(s->asm_rowptr); free(s->asm_col); free(s->asm_src);
+  free(s->asm_fval); free(s->asm_dinv);
   free(s->sub_ptr); free(s->fval); free(s->dinv); free(s->lhs_last2); free(s->hist); free(s->hist_prev);
   free(s->tr_phase); free(s->tr_decay); free(s->tr_act); free(s->tr_diff); free(s->tr_bc); free(s->tr_inj);
   free(s);
@@ -797,7 +806,7 @@ int wo_bilu0_factor(int n, int bs, const int *rowptr, const int *colidx, const d
                     int nsub, const int *sub_ptr, double *fval, double *dinv) {
   int bb = bs * bs, err = 0;
   memcpy(fval, val, sizeof(double) * (size_t)rowptr[n] * bb);
-#pragma omp parallel for reduction(| : err) schedule(dynamic, 8)
+#pragma omp parallel for reduction(| : err) schedule(dynamic, 1)
   for (int sd = 0; sd < nsub; sd++) {
     int lo = sub_ptr[sd], hi = sub_ptr[sd + 1];
     for (int i = lo; i < hi; i++) {
@@ -834,7 +843,7 @@ void wo_bilu0_apply(int n, int bs, const int *rowptr, const int *colidx, const d
                     double *z) {
   int bb = bs * bs;
   (void)n;
-#pragma omp parallel for schedule(dynamic, 8)
+#pragma omp parallel for schedule(dynamic, 1)
   for (int sd = 0; sd < nsub; sd++) {
     int lo = sub_ptr[sd], hi = sub_ptr[sd + 1];
     for (int i = lo; i < hi; i++) { /* forward: L y = r */
@@ -869,6 +878,139 @@ void wo_bilu0_apply(int n, int bs, const int *rowptr, const int *colidx, const d
   }
 }
 
+/* ---- PCASM [PETSc]: restricted additive Schwarz, the reference's default preconditioner
+ * (src/timestepper.F90:1668-1669 default "asm", :1753-1757; PETSc defaults: overlap 1,
+ * PC_ASM_RESTRICT, sorted indices, sub-PC ILU(0) :1809-1834).  Subdomain s = rows
+ * [sub_ptr[s], sub_ptr[s+1]); its overlapped set adds `overlap` layers of matrix-graph
+ * neighbours among the owned rows of this rank (MatIncreaseOverlap), local order = ascending
+ * index.  z = sum_s R0_s^T ILU0(A[O_s,O_s])^-1 R_s r: the residual is restricted to the
+ * overlapped set, only the subdomain's own rows are prolonged back.  overlap = 0 is block Jacobi.
+ * Overlap does not reach across ranks here (the halo cells' matrix rows live on the neighbour). */
+void wo_sim_set_asm(wo_sim *s, int overlap) {
+  free(s->asm_ptr); free(s->asm_rows); free(s->asm_rowptr); free(s->asm_col); free(s->asm_src);
+  free(s->asm_fval); free(s->asm_dinv);
+  s->asm_ptr = s->asm_rows = s->asm_rowptr = s->asm_col = s->asm_src = NULL;
+  s->asm_fval = s->asm_dinv = NULL;
+  s->asm_overlap = overlap > 0 ? overlap : 0;
+  if (!s->asm_overlap) return;
+  int n = s->n_owned, nsub = s->nsub;
+  int *mark = (int *)xmalloc(sizeof(int) * n), *loc = (int *)xmalloc(sizeof(int) * n);
+  for (int i = 0; i < n; i++) mark[i] = -1;
+  s->asm_ptr = (int *)xmalloc(sizeof(int) * (nsub + 1));
+  size_t cap = (size_t)n * 2 + 16, nrows = 0;
+  s->asm_rows = (int *)xmalloc(sizeof(int) * cap);
+  for (int sd = 0; sd < nsub; sd++) {
+    size_t start = nrows;
+    s->asm_ptr[sd] = (int)start;
+    for (int i = s->sub_ptr[sd]; i < s->sub_ptr[sd + 1]; i++) {
+      if (nrows + 1 > cap) { cap *= 2; s->asm_rows = (int *)realloc(s->asm_rows, sizeof(int) * cap); }
+      s->asm_rows[nrows++] = i; mark[i] = sd;
+    }
+    size_t layer_lo = start;
+    for (int l = 0; l < s->asm_overlap; l++) {
+      size_t layer_hi = nrows;
+      for (size_t q = layer_lo; q < layer_hi; q++) {
+        int i = s->asm_rows[q];
+        for (int e = s->rowptr[i]; e < s->rowptr[i + 1]; e++) {
+          int j = s->colidx[e];
+          if (j >= n || mark[j] == sd) continue;
+          if (nrows + 1 > cap) { cap *= 2; s->asm_rows = (int *)realloc(s->asm_rows, sizeof(int) * cap); }
+          s->asm_rows[nrows++] = j; mark[j] = sd;
+        }
+      }
+      layer_lo = layer_hi;
+    }
+    qsort(s->asm_rows + start, nrows - start, sizeof(int), cmp_int);
+  }
+  s->asm_ptr[nsub] = (int)nrows;
+  /* local CSR */
+  s->asm_rowptr = (int *)xmalloc(sizeof(int) * (nrows + 1));
+  size_t nz = 0;
+  for (int i = 0; i < n; i++) mark[i] = -1;
+  for (int pass = 0; pass < 2; pass++) {
+    nz = 0;
+    for (int sd = 0; sd < nsub; sd++) {
+      int a = s->asm_ptr[sd], b = s->asm_ptr[sd + 1];
+      for (int q = a; q < b; q++) { mark[s->asm_rows[q]] = sd; loc[s->asm_rows[q]] = q - a; }
+      for (int q = a; q < b; q++) {
+        int i = s->asm_rows[q];
+        if (pass) s->asm_rowptr[q] = (int)nz;
+        for (int e = s->rowptr[i]; e < s->rowptr[i + 1]; e++) {
+          int j = s->colidx[e];
+          if (j >= n || mark[j] != sd) continue;
+          if (pass) { s->asm_col[nz] = loc[j]; s->asm_src[nz] = e; }
+          nz++;
+        }
+      }
+    }
+    if (!pass) {
+      s->asm_col = (int *)xmalloc(sizeof(int) * nz);
+      s->asm_src = (int *)xmalloc(sizeof(int) * nz);
+    }
+  }
+  s->asm_rowptr[nrows] = (int)nz;
+  int bb = MAXBS * MAXBS;
+  s->asm_fval = (double *)xmalloc(sizeof(double) * nz * bb);
+  s->asm_dinv = (double *)xmalloc(sizeof(double) * nrows * bb);
+  free(mark); free(loc);
+}
+int wo_sim_asm_rows(wo_sim *s, int *ptr, int *rows) { /* sizes: nsub+1, asm_ptr[nsub]; NULL: count only */
+  if (!s->asm_overlap) return 0;
+  if (ptr) memcpy(ptr, s->asm_ptr, sizeof(int) * (s->nsub + 1));
+  if (rows) memcpy(rows, s->asm_rows, sizeof(int) * s->asm_ptr[s->nsub]);
+  return s->asm_ptr[s->nsub];
+}
+void wo_sim_set_pc_none(wo_sim *s, int none) { s->pc_none = none; }
+
+static int pc_setup(wo_sim *s, const double *val) {
+  int bs = s->ksp_bs > 0 ? s->ksp_bs : s->eos.np, bb = bs * bs;
+  if (s->pc_none) return 0;
+  if (!s->asm_overlap)
+    return wo_bilu0_factor(s->n_owned, bs, s->rowptr, s->colidx, val, s->nsub, s->sub_ptr, s->fval, s->dinv);
+  int err = 0;
+#pragma omp parallel for reduction(| : err) schedule(dynamic, 1)
+  for (int sd = 0; sd < s->nsub; sd++) {
+    int a = s->asm_ptr[sd], m = s->asm_ptr[sd + 1] - a, z0 = s->asm_rowptr[a];
+    int nzl = s->asm_rowptr[a + m] - z0;
+    int *lrp = (int *)xmalloc(sizeof(int) * (m + 1));
+    for (int q = 0; q <= m; q++) lrp[q] = s->asm_rowptr[a + q] - z0;
+    double *lv = (double *)xmalloc(sizeof(double) * (size_t)nzl * bb);
+    for (int e = 0; e < nzl; e++) memcpy(lv + (size_t)e * bb, val + (size_t)s->asm_src[z0 + e] * bb, sizeof(double) * bb);
+    int sp[2] = {0, m};
+    err |= wo_bilu0_factor(m, bs, lrp, s->asm_col + z0, lv, 1, sp, s->asm_fval + (size_t)z0 * bb,
+                           s->asm_dinv + (size_t)a * bb);
+    free(lrp); free(lv);
+  }
+  return err;
+}
+
+static void pc_apply(wo_sim *s, const double *r, double *z) {
+  int bs = s->ksp_bs > 0 ? s->ksp_bs : s->eos.np, bb = bs * bs;
+  if (s->pc_none) { memcpy(z, r, sizeof(double) * (size_t)bs * s->n_owned); return; }
+  if (!s->asm_overlap) {
+    wo_bilu0_apply(s->n_owned, bs, s->rowptr, s->colidx, s->fval, s->dinv, s->nsub, s->sub_ptr, r, z);
+    return;
+  }
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int sd = 0; sd < s->nsub; sd++) {
+    int a = s->asm_ptr[sd], m = s->asm_ptr[sd + 1] - a, z0 = s->asm_rowptr[a];
+    int *lrp = (int *)xmalloc(sizeof(int) * (m + 1));
+    for (int q = 0; q <= m; q++) lrp[q] = s->asm_rowptr[a + q] - z0;
+    double *lr = (double *)xmalloc(sizeof(double) * (size_t)m * bs), *lz = (double *)xmalloc(sizeof(double) * (size_t)m * bs);
+    for (int q = 0; q < m; q++) memcpy(lr + (size_t)q * bs, r + (size_t)s->asm_rows[a + q] * bs, sizeof(double) * bs);
+    int sp[2] = {0, m};
+    wo_bilu0_apply(m, bs, lrp, s->asm_col + z0, s->asm_fval + (size_t)z0 * bb, s->asm_dinv + (size_t)a * bb, 1, sp, lr, lz);
+    for (int q = 0; q < m; q++) {
+      int i = s->asm_rows[a + q];
+      if (i >= s->sub_ptr[sd] && i < s->sub_ptr[sd + 1]) memcpy(z + (size_t)i * bs, lz + (size_t)q * bs, sizeof(double) * bs);
+    }
+    free(lrp); free(lr); free(lz);
+  }
+}
+/* z = B^-1 r with the preconditioner last set up by wo_ksp_solve / wo_pc_setup (tests) */
+int wo_pc_setup(wo_sim *s, const double *val) { return pc_setup(s, val); }
+void wo_pc_apply(wo_sim *s, const double *r, double *z) { pc_apply(s, r, z); }
+
 /* ---- Krylov [PETSc KSPBCGS / KSPGMRES, left preconditioning, preconditioned norm] -------- */
 static double gdot(wo_sim *s, const double *a, const double *b, int n) {
   double t = 0.0;
@@ -885,8 +1027,7 @@ static void pc_amul(wo_sim *s, const double *val, double *x, double *tmp, double
   int bs = ksp_bs(s);
   if (s->halo && s->n_halo) s->halo(s->user, x, bs);
   wo_bcsr_spmv(s->n_owned, bs, s->rowptr, s->colidx, val, x, tmp);
-  wo_bilu0_apply(s->n_owned, bs, s->rowptr, s->colidx, s->fval, s->dinv, s->nsub, s->sub_ptr,
-                 tmp, z);
+  pc_apply(s, tmp, z);
 }
 
 static int ksp_bcgs(wo_sim *s, const double *val, const double *b, double *x, double rtol,
@@ -898,8 +1039,7 @@ static int ksp_bcgs(wo_sim *s, const double *val, const double *b, double *x, do
   double *tmp = xmalloc(sizeof(double) * n);
   int reason = 0, i;
   memset(x, 0, sizeof(double) * n);
-  wo_bilu0_apply(s->n_owned, bs, s->rowptr, s->colidx, s->fval, s->dinv, s->nsub, s->sub_ptr,
-                 b, R);
+  pc_apply(s, b, R);
   double dp = sqrt(gdot(s, R, R, n));
   double ttol = fmax(rtol * dp, atol), dp0 = dp;
   if (hist) hist[0] = dp;
@@ -968,15 +1108,13 @@ static int ksp_gmres(wo_sim *s, int m, const double *val, const double *b, doubl
     /* r = B^-1 (b - A x) */
     double *v0 = Vb;
     if (it == 0) {
-      wo_bilu0_apply(s->n_owned, bs, s->rowptr, s->colidx, s->fval, s->dinv, s->nsub,
-                     s->sub_ptr, b, v0);
+      pc_apply(s, b, v0);
     } else {
       memcpy(xl, x, sizeof(double) * n);
       if (s->halo && s->n_halo) s->halo(s->user, xl, bs);
       wo_bcsr_spmv(s->n_owned, bs, s->rowptr, s->colidx, val, xl, tmp);
       for (int q = 0; q < n; q++) tmp[q] = b[q] - tmp[q];
-      wo_bilu0_apply(s->n_owned, bs, s->rowptr, s->colidx, s->fval, s->dinv, s->nsub,
-                     s->sub_ptr, tmp, v0);
+      pc_apply(s, tmp, v0);
     }
     res = sqrt(gdot(s, v0, v0, n));
     if (it == 0) {
@@ -1057,9 +1195,8 @@ int wo_ksp_solve(wo_sim *s, int ksp_type, int restart, const double *val, const 
                  double *x, double rtol, double atol, int maxits, int *its, double *rnorm,
                  double *hist) {
   int bs = ksp_bs(s);
-  if (wo_bilu0_factor(s->n_owned, bs, s->rowptr, s->colidx, val, s->nsub, s->sub_ptr, s->fval,
-                      s->dinv))
-    return -11; /* KSP_DIVERGED_PC_FAILED */
+  (void)bs;
+  if (pc_setup(s, val)) return -11; /* KSP_DIVERGED_PC_FAILED */
   if (ksp_type == 1) return ksp_gmres(s, restart > 0 ? restart : 30, val, b, x, rtol, atol,
                                       maxits, its, rnorm, hist);
   return ksp_bcgs(s, val, b, x, rtol, atol, maxits, its, rnorm, hist);

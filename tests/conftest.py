@@ -4,7 +4,13 @@ import sys
 
 import pytest
 
+import glob
+import tempfile
+
 os.environ.setdefault("OMP_NUM_THREADS", "1")  # the oracle is the checker: keep it deterministic
+# simulation output files (output.filename of the reference's input files) go to a scratch
+# directory, never beside the golden inputs
+os.environ.setdefault("WAIWERA_OUTPUT_DIR", tempfile.mkdtemp(prefix="waiwera_amd_out_"))
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
@@ -19,8 +25,7 @@ def pytest_configure(config):
 def oracle():
     """The CPU oracle (test infrastructure). Built on demand with gcc."""
     so = os.path.join(ROOT, "oracle", "liboracle.so")
-    srcs = [os.path.join(ROOT, "oracle", f) for f in
-            ("wo_physics.c", "wo_solver.c", "wai_oracle.h", "if97_tables.h")]
+    srcs = glob.glob(os.path.join(ROOT, "oracle", "*.c")) + glob.glob(os.path.join(ROOT, "oracle", "*.h"))
     if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")],
                               stdout=subprocess.DEVNULL)

@@ -101,6 +101,11 @@ def load(path):
         "wo_brine_sat_pressure": (i32, [C.c_void_p, d, d, pd]), "wo_brine_sat_temperature": (i32, [C.c_void_p, d, d, pd]),
         "wo_brine_properties": (i32, [C.c_void_p, d, d, d, pd, pd]), "wo_brine_viscosity": (i32, [C.c_void_p, d, d, d, pd]),
         "wo_sim_set_subdomains": (None, [C.c_void_p, i32, pi]),
+        "wo_sim_set_asm": (None, [C.c_void_p, i32]),
+        "wo_sim_asm_rows": (i32, [C.c_void_p, pi, pi]),
+        "wo_sim_set_pc_none": (None, [C.c_void_p, i32]),
+        "wo_pc_setup": (i32, [C.c_void_p, pd]),
+        "wo_pc_apply": (None, [C.c_void_p, pd, pd]),
         "wo_sim_set_regions": (None, [C.c_void_p, pi]),
         "wo_sim_get_regions": (None, [C.c_void_p, pi]),
         "wo_sim_init_bc": (i32, [C.c_void_p, pd, pi]),
@@ -201,6 +206,26 @@ class OracleSim:
         if n:
             self.L.wo_sim_source_rates(self.h, dp(r), dp(e))
         return r, e
+
+    def set_asm(self, overlap, *_):
+        """PCASM (restricted) with `overlap` layers around the subdomains; 0: block Jacobi"""
+        self.L.wo_sim_set_asm(self.h, int(overlap))
+
+    def asm_rows(self):
+        n = self.L.wo_sim_asm_rows(self.h, None, None)
+        ptr = np.zeros(len(self.mesh.sub_ptr), dtype=np.int32)
+        rows = np.zeros(n, dtype=np.int32)
+        if n:
+            self.L.wo_sim_asm_rows(self.h, ip(ptr), ip(rows))
+        return ptr, rows
+
+    def pc_setup(self, val):
+        return self.L.wo_pc_setup(self.h, dp(f64(val)))
+
+    def pc_apply(self, r):
+        z = np.zeros(self.n_owned * self.np)
+        self.L.wo_pc_apply(self.h, dp(f64(r)), dp(z))
+        return z
 
     def set_regions(self, region):
         r = i32a(region)

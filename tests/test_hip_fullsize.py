@@ -3,9 +3,13 @@ properties -- the oracle would need minutes here, so no element-wise comparison:
 linearity of the block SpMV, SpMV against the BCSR values fetched through the ABI, the Krylov
 solution verified by an independent residual, mass conservation of the flux sweep, and
 Newton-step residual reduction."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
+
+from tests import oracle_lib as ol
 
 from tests.cases import scaled
 from waiwera_amd import mesh as M
@@ -138,4 +142,91 @@ def test_other_block_sizes_at_scale(eos, minc, dims):
     z, zb = np.zeros(n), np.zeros(n)
     sim.pc_apply(A @ x - f, z); sim.pc_apply(f, zb)
     assert np.linalg.norm(z) <= 2e-8 * np.linalg.norm(zb)
+    sim.destroy()
+
+
+@pytest.mark.parametrize("name,dims,eos,minc,brick", [
+    ("c3", (216, 216, 216), "we", False, (16, 16, 2)),       # BASELINE configs[2]: 10 077 696 cells
+    ("c4", (172, 172, 170), "wce", False, (16, 16, 2)),      # configs[3]: 5 029 280 cells, 3 x 3 blocks
+    ("c5", (100, 100, 100), "wce", True, (16, 16, 1)),       # configs[4]: 1 M fracture + 1 M matrix cells
+])
+def test_baseline_configs_at_their_stated_sizes(oracle, name, dims, eos, minc, brick):
+    """bench.py's set-up (bricks, top Dirichlet boundary, wells, lens) at the sizes BASELINE.json
+    states, checked through properties that need no oracle run: component mass conservation of the flux
+    sweep (closed sides: what is left is the wells and the open top), the block SpMV against scipy's BSR
+    product on the values fetched through the ABI, a Krylov solve verified with that independent
+    operator, and a backward-Euler step whose Newton iterations reduce the scaled residual"""
+    from tests.cases import make_case
+    from waiwera_amd.flow_simulation import FlowSimulation
+    g, lm, prim, region = make_case(dims=dims, brick=brick, eos=eos, lens=True, minc=minc)
+    sim = FlowSimulation(lm, eos=eos)
+    sim.set_regions(region)
+    y = scaled(prim, region, eos).ravel().copy()
+    bs = sim.num_primary_variables
+    n = sim.n_owned * bs
+    assert sim.n_owned == dims[0] * dims[1] * dims[2] * (2 if minc else 1)
+    assert sim.pre_eval(0.0, y) == 0
+    R = np.zeros(n)
+    sim.rhs(0.0, (0.0, 0.0), y, R)
+    vol = lm.cell_geom[: lm.n_owned, 3]
+    # interior fluxes cancel pairwise; what is left of every mass component is the wells' rates and
+    # the inflow through the open top, which the oracle's face-flux kernel evaluates independently on
+    # the boundary faces alone (fluid records of their two cells fetched through the ABI)
+    total = np.sum(vol[:, None] * R.reshape(-1, bs)[:, : bs - 1], axis=0)
+    wells = np.zeros(bs - 1)
+    for rate, comp in zip(lm.src_rate, lm.src_component):
+        wells[max(int(comp) - 1, 0)] += rate
+    e = ol.Eos()
+    oracle.wo_eos_init(C.byref(e), {"we": 1, "wce": 2}[eos])
+    fl = sim.fluid()
+    inflow = np.zeros(bs - 1)
+    flux = np.zeros(bs + 2)
+    bfaces = np.nonzero(lm.face_cells[:, 1] >= lm.n_owned + lm.n_halo)[0]
+    assert bfaces.size == lm.n_bc
+    for fidx in bfaces:
+        c1, c2 = lm.face_cells[fidx]
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in
+                (lm.face_geom[fidx], fl[c1], lm.rock[c1], fl[c2], lm.rock[c2])]
+        oracle.wo_face_flux(C.byref(e), *[ol.dp(a) for a in arrs], ol.dp(flux))
+        inflow -= flux[: bs - 1] * lm.face_geom[fidx, 0]
+    del fl
+    assert np.all(np.abs(total - (wells + inflow)) <= 1e-8 * (np.abs(wells).sum() + np.abs(inflow).sum()))
+    assert np.isfinite(R).all()
+    L, f = np.zeros(n), np.zeros(n)
+    sim.lhs(0.0, (0.0, 0.0), y, L)
+    dt = 2.0e3
+    assert sim.residual(dt, dt, y, L, f) == 0
+    assert sim.jacobian(dt, dt, y, L) == 0
+    rp, ci = sim.setup_jacobian()
+    val = sim.jacobian_values().reshape(-1, bs, bs)
+    A = sp.bsr_matrix((val, ci, rp), shape=(n, n))
+    x1 = np.random.default_rng(3).uniform(-1, 1, n)
+    y1 = np.zeros(n)
+    sim.spmv(x1, y1)
+    ref = A @ x1
+    assert np.abs(y1 - ref).max() <= 1e-12 * np.abs(ref).max()
+    sim.set_opts(ksp_rtol=1e-8)
+    x = np.zeros(n)
+    its, reason, rn = sim.ksp_solve(f, x)
+    assert reason > 0
+    z, zb = np.zeros(n), np.zeros(n)
+    sim.pc_apply(A @ x - f, z); sim.pc_apply(f, zb)
+    assert np.linalg.norm(z) <= 2e-8 * np.linalg.norm(zb)
+    del A, val, ref
+    sim.set_opts(ksp_rtol=1e-5)
+    # Newton iterations of a backward-Euler step
+    yy = y.copy()
+    sim.pre_timestep()
+    assert sim.pre_eval(0.0, yy) == 0
+    sim.lhs(0.0, (0.0, 0.0), yy, L)
+    assert sim.residual(dt, dt, yy, L, f) == 0
+    r0, _ = sim.max_scaled(f, L, 1.0)
+    hist = [r0]
+    for it in range(6):
+        reason, kits, maxres = sim.newton_step(dt, dt, it, yy, L, f)
+        assert reason >= 0
+        hist.append(maxres)
+        if reason > 0:
+            break
+    assert hist[-1] < 1e-2 * hist[0]
     sim.destroy()

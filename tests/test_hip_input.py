@@ -104,7 +104,7 @@ def test_restart_from_waiwera_hdf5_and_write_output(tmp_path):
     inp = json.load(open(tmp_path / "oned_two_phase_ss.json"))
     inp["output"] = {"filename": "mine_ss.h5", "initial": False, "frequency": 0, "final": True}
     json.dump(inp, open(tmp_path / "oned_two_phase_ss.json", "w"))
-    sim = Simulation.from_json(str(tmp_path / "oned_two_phase_ss.json"))
+    sim = Simulation.from_json(str(tmp_path / "oned_two_phase_ss.json"), output_dir=str(tmp_path))
     sim.run()
     assert not hasattr(sim, "output_error")
     mine = hdf5io.read_state(str(tmp_path / "mine_ss.h5"))

@@ -402,38 +402,6 @@ def test_direct_steady_state(FS, oracle):
     sim.destroy(); osim.close()
 
 
-def test_pipelined_pc_kernel(FS, oracle, monkeypatch):
-    """The software-pipelined persistent k_pc_pipe (normally only taken when there are at least
-    as many bricks as CUs) forced onto a 24-brick mesh with 8 workgroups, so every workgroup
-    walks three bricks: BiCGStab (both fused dot modes) and GMRES against the oracle, and the
-    same iteration counts as the one-brick-per-workgroup kernel."""
-    res = {}
-    for pipe in ("1", "0"):
-        monkeypatch.setenv("WAI_PC_PIPE", pipe)
-        monkeypatch.setenv("WAI_PC_PIPE_GRID", "8")
-        g, lm, sim, osim, y, region = build(FS, oracle, eos="we", lens=True, dims=(16, 16, 44), brick=(8, 8, 8))
-        n = sim.num_dof
-        dt = 5.0e4
-        yo = osim.yvec(y)
-        assert osim.pre_eval(yo) == 0
-        L = osim.lhs()
-        err, fo = osim.residual(yo, dt, L)
-        err, Jo = osim.jacobian(yo, dt, L, fo, mode=0)
-        sim.set_jacobian_values(Jo)
-        assert sim.pc_setup() == 0
-        for ksp, kt in (("bcgs", 0), ("gmres", 1)):
-            sim.set_opts(ksp_type=ksp, ksp_rtol=1e-12)
-            xg = np.zeros(n)
-            its, reason, rn = sim.ksp_solve(fo, xg)
-            oreason, xo, oits, hist = osim.ksp_solve(Jo, fo, ksp_type=kt, rtol=1e-12)
-            assert reason > 0 and oreason > 0
-            assert relmax(xg, xo) < 1e-8
-            assert abs(its - oits) <= max(2, oits // 10)
-            res[pipe, ksp] = its
-        sim.destroy(); osim.close()
-    assert abs(res["1", "bcgs"] - res["0", "bcgs"]) <= 2 and abs(res["1", "gmres"] - res["0", "gmres"]) <= 1
-
-
 def test_state_dependent_source_controls(FS, oracle):
     """deliverability (constant and enthalpy-table wellbore pressure), recharge, the three
     limiters behind a separator and the direction control, evaluated inside the residual and the FD

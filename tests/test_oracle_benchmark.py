@@ -381,11 +381,11 @@ def test_restart_and_output_files(oracle, tmp_path):
     inp = json.load(open(tmp_path / "oned_two_phase_ss.json"))
     inp["output"] = {"filename": "oned_two_phase_ss.h5", "initial": False, "frequency": 0, "final": True}
     json.dump(inp, open(tmp_path / "oned_two_phase_ss.json", "w"))
-    sim = Simulation.from_json(str(tmp_path / "oned_two_phase_ss.json"), ode_factory=oracle_factory(oracle))
+    sim = Simulation.from_json(str(tmp_path / "oned_two_phase_ss.json"), output_dir=str(tmp_path), ode_factory=oracle_factory(oracle))
     sim.y = sim.ts.y = sim.ode.o.yvec(sim.y)
     sim.ode.opts.ftol_rel = 1.0e-9
     sim.run()
-    assert not hasattr(sim, "output_error")
+    assert sim.output_error is None
     sim.ode.o.close()
     mine = hdf5io.read_state(str(tmp_path / "oned_two_phase_ss.h5"))
     ref = hdf5io.read_state(os.path.join(INPUTS, "oned_two_phase_ss.h5"))

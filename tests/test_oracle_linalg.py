@@ -158,3 +158,64 @@ def test_newton_protocol_converges_quadratically(oracle):
     r, k = sim.timestep(y, dt, o)
     assert 0 < r <= 6
     sim.close()
+
+
+def _dense_ilu0(B):
+    """ILU(0) of a dense matrix on its own nonzero pattern; returns L (unit) and U as dense arrays"""
+    n = B.shape[0]
+    pat = B != 0.0
+    F = B.copy()
+    for i in range(n):
+        for k in range(i):
+            if not pat[i, k]:
+                continue
+            F[i, k] /= F[k, k]
+            for j in range(k + 1, n):
+                if pat[i, j]:
+                    F[i, j] -= F[i, k] * F[k, j]
+    return np.tril(F, -1) + np.eye(n), np.triu(F)
+
+
+def test_restricted_asm_matches_its_definition(oracle):
+    """PCASM as PETSc defines it (overlap 1, restrict, ILU(0) of the overlapped diagonal block in
+    ascending index order), built here from dense sub-matrices of an eos w problem (scalar blocks, so
+    block ILU(0) is plain ILU(0)); overlap 0 equals block Jacobi"""
+    lm, sim, y, L, f, J, dt = setup(oracle, dims=(6, 5, 4), brick=(3, 3, 2), eos="w")
+    A = to_bsr(sim, J).toarray()[:, : sim.n_owned]
+    r = np.random.default_rng(5).normal(size=sim.n_owned)
+    sim.set_asm(0)
+    assert sim.pc_setup(J) == 0
+    z_bj = sim.pc_apply(r)
+    for overlap in (1, 2):
+        sim.set_asm(overlap)
+        ptr, rows = sim.asm_rows()
+        assert sim.pc_setup(J) == 0
+        z = sim.pc_apply(r)
+        ref = np.zeros_like(r)
+        for s in range(len(lm.sub_ptr) - 1):
+            own = np.arange(lm.sub_ptr[s], lm.sub_ptr[s + 1])
+            ext = set(own.tolist())
+            for _ in range(overlap):
+                ext |= {int(j) for i in ext for j in np.nonzero(A[i])[0]}
+            ext = np.array(sorted(ext))
+            assert np.array_equal(ext, rows[ptr[s]:ptr[s + 1]])
+            Lf, Uf = _dense_ilu0(A[np.ix_(ext, ext)])
+            zl = np.linalg.solve(Uf, np.linalg.solve(Lf, r[ext]))
+            keep = np.isin(ext, own)
+            ref[ext[keep]] = zl[keep]
+        assert np.allclose(z, ref, rtol=1e-11, atol=1e-13 * np.abs(ref).max())
+        assert not np.allclose(z, z_bj)
+    sim.close()
+
+
+def test_asm_cuts_or_keeps_krylov_iterations(oracle):
+    """with overlap the BiCGStab solve still converges to the same solution"""
+    lm, sim, y, L, f, J, dt = setup(oracle, dims=(8, 8, 6), brick=(4, 4, 2), lens=True, dt=1.0e5)
+    res = {}
+    for overlap in (0, 1):
+        sim.set_asm(overlap)
+        reason, x, its, hist = sim.ksp_solve(J, f, rtol=1e-10)
+        assert reason > 0
+        res[overlap] = (x, its)
+    assert np.allclose(res[0][0], res[1][0], rtol=1e-6, atol=1e-9 * np.abs(res[0][0]).max())
+    sim.close()

@@ -261,3 +261,31 @@ def test_output_checkpoints_shorten_the_step_and_restore_its_size():
     assert times[:5] == [0.3, 0.6, 0.9, 1.0, 1.3]                 # 0.9 + 0.3 + 0.03 >= 1.0: shortened to 0.1
     assert np.isclose(ts.history[3][1], 0.1) and np.isclose(ts.history[4][1], 0.3)   # restored
     assert 2.0 in times and times[-1] == 3.0
+
+
+def test_checkpoints_before_the_start_time_are_passed_over():
+    """timestepper_checkpoints_init (timestepper.F90:884-887): a run (re)started past a listed
+    checkpoint never takes a step backwards onto it"""
+    ode = linear()
+    y = ode.initial.copy()
+    ts = Timestepper(ode, y, time=100.0, stepsize=30.0, max_num_steps=4, checkpoints=[50.0, 150.0])
+    assert ts.checkpoint_index == 1
+    ts.step()
+    assert ts.history[-1][1] > 0.0 and np.isclose(ts.time, 130.0) and not ts.checkpoint_hit
+    ts.step()
+    assert ts.checkpoint_hit and np.isclose(ts.time, 150.0) and np.isclose(ts.history[-1][1], 20.0)
+
+
+def test_fixed_size_list_moves_on_after_a_checkpoint():
+    """get_next_fixed_stepsize (timestepper.F90:1380-1408): with the adaptor off a checkpoint hit does
+    not restore the shortened step's size, the next listed size is taken (10, 15, 40 -- not 10, 15, 20, 40)"""
+    ode = linear()
+    y = ode.initial.copy()
+    ts = Timestepper(ode, y, stepsize=[10.0, 20.0, 40.0], max_num_steps=3, checkpoints=[25.0])
+    sizes = []
+    while not ts.finished:
+        ts.step()
+        sizes.append(ts.history[-1][1])
+        if ts.checkpoint_hit:
+            ts.checkpoint_update()
+    assert np.allclose(sizes, [10.0, 15.0, 40.0])

@@ -11,8 +11,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwaiwera_hip.so")
 SOURCES = ["capi.hip", "kernels_assembly.hip", "kernels_linalg.hip", "comm.cpp"]
-HEADERS = ["context.hpp", "comm.hpp", "physics.hip.h", "if97.hip.h", "if97_tables.hip.h",
-           os.path.join("..", "..", "include", "waiwera_hip.h")]
+import glob  # noqa: E402
+# every header any source could include: a stale object after a header edit is worse than a rebuild
+HEADERS = sorted(os.path.basename(h) for pat in ("*.h", "*.hpp") for h in glob.glob(os.path.join(CSRC, pat))) + \
+    [os.path.join("..", "..", "include", "waiwera_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
          "-Wno-unused-value"] + os.environ.get("WAI_EXTRA_HIPCC_FLAGS", "").split()
 

@@ -97,6 +97,215 @@ struct Prof {
   }
 };
 
+// Symbolic phase of block-Jacobi ILU(0) on a block matrix given as host CSR (ascending columns):
+// per-row slot ranges inside the row's subdomain, dependency levels of both substitutions, whether
+// ILU(0) ever touches an off-diagonal block (if not it is DILU and the fused kernels apply), the
+// compact / parked kernel conditions -- or, for subdomains of more than 1024 rows, the level sets
+// of the launch-per-level path.  `ghosts`: rows may have columns >= n (partition ghosts).
+int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, const std::vector<int>& colidx,
+                   const std::vector<int>& sub, int N, int W, int np, bool ghosts) {
+  s.nsub = (int)sub.size() - 1;
+  if (sub.front() != 0 || sub.back() != N) { c->err = "sub_ptr must cover [0, n_owned]"; return -2; }
+  std::vector<int> diag(N);
+  for (int i = 0; i < N; i++) {
+    const int* row = colidx.data() + rowptr[i];
+    diag[i] = (int)(std::lower_bound(row, row + (rowptr[i + 1] - rowptr[i]), i) - row);
+  }
+  std::vector<int> info(N), uoff(N, 0), levf(N), levb(N), nlev(s.nsub, 0), lfirst(N), ulast(N);
+  s.max_rows = 0; s.max_lev = 0; s.max_ublocks = 0;
+  bool offdiag_fill = false, fast3 = true;
+  int nlf_all = 0, nlb_all = 0;
+  for (int sd = 0; sd < s.nsub; sd++) {
+    const int lo = sub[sd], hi = sub[sd + 1];
+    if (hi < lo) { c->err = "sub_ptr not monotone"; return -2; }
+    s.max_rows = std::max(s.max_rows, hi - lo);
+    int nlf = 0, nlb = 0;
+    for (int i = lo; i < hi; i++) {
+      const int* row = colidx.data() + rowptr[i];
+      const int cnt = rowptr[i + 1] - rowptr[i];
+      int ls = 0;
+      while (ls < cnt && row[ls] < lo) ls++;
+      int ue = cnt;
+      while (ue > 0 && row[ue - 1] >= hi) ue--;
+      lfirst[i] = ls; ulast[i] = ue;
+      int lv = 0;
+      for (int q = ls; q < diag[i]; q++) lv = std::max(lv, levf[row[q]] + 1);
+      levf[i] = lv;
+      nlf = std::max(nlf, lv + 1);
+    }
+    for (int i = hi - 1; i >= lo; i--) {
+      const int* row = colidx.data() + rowptr[i];
+      int lv = 0;
+      for (int q = diag[i] + 1; q < ulast[i]; q++) lv = std::max(lv, levb[row[q]] + 1);
+      levb[i] = lv;
+      nlb = std::max(nlb, lv + 1);
+    }
+    // does the IKJ elimination ever update an off-diagonal block of a row in this subdomain?
+    for (int i = lo; i < hi && !offdiag_fill; i++) {
+      const int* row = colidx.data() + rowptr[i];
+      for (int q = lfirst[i]; q < diag[i] && !offdiag_fill; q++) {
+        const int k = row[q];
+        const int* rk = colidx.data() + rowptr[k];
+        for (int r2 = diag[k] + 1; r2 < ulast[k]; r2++) {
+          const int j = rk[r2];
+          if (j == i) continue;
+          if (std::binary_search(row + q + 1, row + ulast[i], j)) { offdiag_fill = true; break; }
+        }
+      }
+    }
+    int ucount = 0;
+    for (int i = lo; i < hi; i++) {
+      const int nL = diag[i] - lfirst[i], nU = ulast[i] - diag[i] - 1;
+      if (nL > 3 || nU > 3 || lfirst[i] > 3 || diag[i] > 3) fast3 = false;
+      uoff[i] = ucount;
+      ucount += std::min(nU, 3);
+    }
+    s.max_ublocks = std::max(s.max_ublocks, ucount);
+    nlev[sd] = (nlf & 0xffff) | (nlb << 16);
+    s.max_lev = std::max(s.max_lev, std::max(nlf, nlb));
+    nlf_all = std::max(nlf_all, nlf); nlb_all = std::max(nlb_all, nlb);
+  }
+  s.big = s.max_rows > 1024;
+  if (!s.big && s.max_lev > 1023) { c->err = "more than 1023 dependency levels in a subdomain"; return -2; }
+  for (int i = 0; i < N; i++)
+    info[i] = lfirst[i] | (diag[i] << 4) | (ulast[i] << 8) | (s.big ? 0 : ((levf[i] << 12) | (levb[i] << 22)));
+  if (ghosts) {   // subdomains without / with partition-ghost columns (for the overlapped halo exchange)
+    std::vector<int> li, lb;
+    for (int sd = 0; sd < s.nsub; sd++) {
+      bool ghost = false;
+      for (int i = sub[sd]; i < sub[sd + 1] && !ghost; i++)
+        for (int q = rowptr[i]; q < rowptr[i + 1]; q++)
+          if (colidx[q] >= N) { ghost = true; break; }
+      (ghost ? lb : li).push_back(sd);
+    }
+    s.n_int = (int)li.size();
+    s.n_bnd = (int)lb.size();
+    if (c->mesh.n_halo > 0 && s.n_int > 0 && s.n_bnd > 0) {
+      if (dev_upload(c, &s.sub_int, li) || dev_upload(c, &s.sub_bnd, lb)) return -1;
+    }
+  }
+  if (s.big) {
+    // level sets over all subdomains: rows of one level are independent wherever they live
+    s.nlev_f = nlf_all; s.nlev_b = nlb_all;
+    std::vector<int> of(N), ob(N);
+    s.lev_f_ptr.assign(nlf_all + 1, 0); s.lev_b_ptr.assign(nlb_all + 1, 0);
+    for (int i = 0; i < N; i++) { s.lev_f_ptr[levf[i] + 1]++; s.lev_b_ptr[levb[i] + 1]++; }
+    for (int l = 0; l < nlf_all; l++) s.lev_f_ptr[l + 1] += s.lev_f_ptr[l];
+    for (int l = 0; l < nlb_all; l++) s.lev_b_ptr[l + 1] += s.lev_b_ptr[l];
+    std::vector<int> pf(s.lev_f_ptr.begin(), s.lev_f_ptr.end() - 1), pb(s.lev_b_ptr.begin(), s.lev_b_ptr.end() - 1);
+    for (int i = 0; i < N; i++) { of[pf[levf[i]]++] = i; ob[pb[levb[i]]++] = i; }
+    if (dev_upload(c, &s.ord_f, of) || dev_upload(c, &s.ord_b, ob)) return -1;
+  }
+  if (dev_upload(c, &s.sub_ptr, sub) || dev_upload(c, &s.sub_nlev, nlev) || dev_upload(c, &s.row_info, info) ||
+      dev_upload(c, &s.row_uoff, uoff) ||
+      dev_alloc(c, &s.fval, (size_t)W * np * np * N) || dev_alloc(c, &s.dinv, (size_t)np * np * N))
+    return -1;
+  s.diag_only = !offdiag_fill && !s.big && !getenv("WAI_ILU_GENERAL");
+  s.level_sorted = false;
+  s.fast3 = fast3 && !getenv("WAI_ILU_NOFAST");
+  s.scaled = !getenv("WAI_ILU_NOSCALE");
+  {
+    const char* e = getenv("WAI_PC_PARK");
+    // 160 KB of LDS per CU; a workgroup may use 64 KB
+    const size_t need = ((size_t)(((s.max_rows + 63) / 64) * 64) * np + 32 + (size_t)s.max_ublocks * 4) * sizeof(double);
+    s.park = !(e && e[0] == '0') && need <= 64 * 1024;  // default on; WAI_PC_PARK=0: k_pc
+  }
+  s.built = true;
+  s.factored = false;
+  return 0;
+}
+
+void free_schedule(IluSchedule& s) {
+  hipFree(s.sub_ptr); hipFree(s.sub_nlev); hipFree(s.row_info); hipFree(s.fval); hipFree(s.dinv);
+  hipFree(s.row_uoff); hipFree(s.sub_int); hipFree(s.sub_bnd); hipFree(s.ord_f); hipFree(s.ord_b);
+  s = IluSchedule();
+}
+void free_asm(wai_ctx* c) {
+  AsmSystem& a = c->as;
+  free_schedule(a.sched);
+  hipFree(a.E.col); hipFree(a.E.val); hipFree(a.ext_row); hipFree(a.gmap); hipFree(a.r_ext);
+  a = AsmSystem();
+}
+
+// PCASM: the overlapped row set of every subdomain (MatIncreaseOverlap over the matrix graph, owned
+// rows only), the extended block-ELL matrix that holds each set as its own block, and the map that
+// fills it from the Jacobian.  Local order inside a block = ascending row index (PETSc sorts the
+// subdomain index sets).
+int build_asm(wai_ctx* c, int overlap) {
+  AsmSystem& a = c->as;
+  free_asm(c);
+  const Bcsr& J = c->J;
+  const int N = J.n, np = J.bs;
+  std::vector<int> sub((size_t)c->ilu.nsub + 1);
+  HIPCHK(c, hipMemcpy(sub.data(), c->ilu.sub_ptr, sizeof(int) * sub.size(), hipMemcpyDeviceToHost));
+  const int nsub = c->ilu.nsub;
+  std::vector<int> ext_ptr(nsub + 1, 0), ext_rows, mark(N, -1), loc(N, 0);
+  ext_rows.reserve((size_t)N * 2);
+  for (int sd = 0; sd < nsub; sd++) {
+    const size_t start = ext_rows.size();
+    for (int i = sub[sd]; i < sub[sd + 1]; i++) { ext_rows.push_back(i); mark[i] = sd; }
+    size_t lo = start;
+    for (int l = 0; l < overlap; l++) {
+      const size_t hi = ext_rows.size();
+      for (size_t q = lo; q < hi; q++) {
+        const int i = ext_rows[q];
+        for (int e = J.h_rowptr[i]; e < J.h_rowptr[i + 1]; e++) {
+          const int j = J.h_colidx[e];
+          if (j >= N || mark[j] == sd) continue;
+          ext_rows.push_back(j); mark[j] = sd;
+        }
+      }
+      lo = hi;
+    }
+    std::sort(ext_rows.begin() + start, ext_rows.end());
+    ext_ptr[sd + 1] = (int)ext_rows.size();
+  }
+  const int n_ext = (int)ext_rows.size();
+  std::fill(mark.begin(), mark.end(), -1);
+  std::vector<int> erp(n_ext + 1, 0), ecol, esrc;
+  ecol.reserve((size_t)n_ext * 7); esrc.reserve((size_t)n_ext * 7);
+  int W = 1;
+  for (int sd = 0; sd < nsub; sd++) {
+    const int a0 = ext_ptr[sd], b0 = ext_ptr[sd + 1];
+    for (int q = a0; q < b0; q++) { mark[ext_rows[q]] = sd; loc[ext_rows[q]] = q; }
+    for (int q = a0; q < b0; q++) {
+      const int i = ext_rows[q];
+      for (int e = J.h_rowptr[i]; e < J.h_rowptr[i + 1]; e++) {
+        const int j = J.h_colidx[e];
+        if (j >= N || mark[j] != sd) continue;
+        ecol.push_back(loc[j]);
+        esrc.push_back((e - J.h_rowptr[i]) * N + i);   // slot * n + row in J's block-ELL planes
+      }
+      erp[q + 1] = (int)ecol.size();
+      W = std::max(W, erp[q + 1] - erp[q]);
+    }
+  }
+  std::vector<int> ell_col((size_t)W * n_ext), gmap((size_t)W * n_ext, -1), erow(n_ext);
+  for (int sd = 0; sd < nsub; sd++)
+    for (int q = ext_ptr[sd]; q < ext_ptr[sd + 1]; q++) {
+      const int i = ext_rows[q];
+      const bool own = i >= sub[sd] && i < sub[sd + 1];
+      erow[q] = own ? (int)((unsigned)i | 0x80000000u) : i;
+      const int cnt = erp[q + 1] - erp[q];
+      for (int t = 0; t < W; t++) {
+        ell_col[(size_t)t * n_ext + q] = t < cnt ? ecol[erp[q] + t] : q;
+        gmap[(size_t)t * n_ext + q] = t < cnt ? esrc[erp[q] + t] : -1;
+      }
+    }
+  // (re)build
+  IluSchedule fresh;
+  a.sched = fresh;
+  a.n_ext = n_ext;
+  a.E.n = n_ext; a.E.ncols = n_ext; a.E.bs = np; a.E.W = W; a.E.nnzb = (int)ecol.size();
+  a.E.h_rowptr = erp; a.E.h_colidx = ecol;
+  if (dev_upload(c, &a.E.col, ell_col) || dev_upload(c, &a.gmap, gmap) || dev_upload(c, &a.ext_row, erow) ||
+      dev_alloc(c, &a.E.val, (size_t)W * np * np * n_ext) || dev_alloc(c, &a.r_ext, (size_t)np * n_ext + 16))
+    return -1;
+  if (int e = build_schedule(c, a.sched, erp, ecol, ext_ptr, n_ext, W, np, false)) return e;
+  a.overlap = overlap;
+  return 0;
+}
+
 // read and clear the device flags; collective over ranks
 int fetch_flags(wai_ctx* c, int out[4]) {
   if (c->comm && c->comm->nranks > 1) {
@@ -180,19 +389,66 @@ int do_jacobian(wai_ctx* c, double dt, const double* y, const double* lhs_old) {
   return 0;
 }
 
+// which preconditioner path is in force: the fused brick kernels (block Jacobi, every subdomain
+// <= 1024 rows) or the general one (PCASM's extended system, subdomains of any size, PCNONE)
+bool pc_fused(const wai_ctx* c) {
+  return c->opts.pc_type == WAI_PC_BJACOBI && !c->ilu.big;
+}
+
 int do_pc_setup(wai_ctx* c) {
+  if (c->opts.pc_type == WAI_PC_NONE) { c->ilu.factored = true; return 0; }
   {
     Prof p(c, KC_PC_SETUP);
-    if (launch_ilu_factor(c)) return -1;
+    if (c->opts.pc_type == WAI_PC_ASM) {
+      const int ov = c->opts.asm_overlap > 0 ? c->opts.asm_overlap : 1;
+      if (c->as.overlap != ov) { if (int e = build_asm(c, ov)) return e < 0 ? -1 : e; }
+      launch_asm_gather_matrix(c);
+      if (launch_ilu_factor_on(c, c->as.E, c->as.sched)) return -1;
+      c->ilu.factored = true;
+    } else if (launch_ilu_factor(c)) return -1;
   }
   int fl[4];
   if (fetch_flags(c, fl)) return -1;
   return fl[0] ? 1 : 0;
 }
 
+// dot products the Krylov drivers want of a preconditioner result (see launch_pc): general path
+int pc_dots(wai_ctx* c, int dot_mode, const double* x, const double* z, const double* aux) {
+  const int n = c->ks.n;
+  if (dot_mode == 1) return vec_dots(c, z, aux, S_D1, nullptr, nullptr, 0, n);
+  if (dot_mode == 2) return vec_dots(c, x, z, S_D1, z, z, S_D2, n);
+  if (dot_mode == 3) return vec_dots(c, z, z, S_DP2, nullptr, nullptr, 0, n);
+  return 0;
+}
+
+// z = B^-1 r; dot_mode as launch_pc, with `x` the partner of mode 2
+int pc_solve(wai_ctx* c, const double* r, double* z, int dot_mode, const double* x, const double* aux) {
+  if (pc_fused(c)) return launch_pc(c, false, r, z, dot_mode, dot_mode == 2 ? x : aux);
+  const size_t n = (size_t)c->ks.n;
+  if (c->opts.pc_type == WAI_PC_NONE) {
+    if (z != r) vec_copy(c, z, r, n);
+  } else if (c->opts.pc_type == WAI_PC_ASM) {
+    AsmSystem& a = c->as;
+    launch_asm_gather(c, r);
+    if (a.sched.big) { if (launch_big_solve(c, a.E, a.sched, a.r_ext)) return -1; }
+    else if (launch_pc_on(c, a.E, a.sched, false, a.r_ext, a.r_ext, 0, nullptr)) return -1;
+    launch_asm_scatter(c, z);
+  } else {   // block Jacobi with subdomains of more than 1024 rows
+    if (z != r) vec_copy(c, z, r, n);
+    if (launch_big_solve(c, c->J, c->ilu, z)) return -1;
+  }
+  return pc_dots(c, dot_mode, x, z, aux);
+}
+
 // z = B^-1 A x  (x has halo room); optional fused dot products of the result
 int pc_amul(wai_ctx* c, double* x, double* z, int dot_mode = 0, const double* aux = nullptr) {
   const IluSchedule& s = c->ilu;
+  if (!pc_fused(c)) {   // unfused: t = A x, then the general preconditioner
+    if (halo_exchange(c, x, c->np)) return -1;
+    { Prof p(c, KC_SPMV); launch_spmv(c, x, c->ks.tmp); }
+    Prof p(c, KC_PC_APPLY);
+    return pc_solve(c, c->ks.tmp, z, dot_mode, x, aux);
+  }
   if (c->comm && c->mesh.n_halo && c->comm_stream && s.n_int > 0 && s.n_bnd > 0 && !c->prof_on) {
     // The partition-ghost values are needed only by the bricks on the rank's faces: pack on the
     // compute stream, send / receive / unpack on the communication stream while the interior bricks
@@ -221,7 +477,7 @@ int pc_amul(wai_ctx* c, double* x, double* z, int dot_mode = 0, const double* au
 // A*S + ILU solve + (S,T),(T,T), omega, fused X/R update + (R,R),(R,RP), rho/beta.
 int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
   Krylov& k = c->ks;
-  const int n = k.n, nsub = c->ilu.nsub;
+  const int n = k.n;
   const double rtol = c->opts.ksp_rtol, atol = c->opts.ksp_atol;
   const int maxits = c->opts.ksp_max_its;
   vec_zero(c, x, n);
@@ -229,11 +485,11 @@ int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, doub
   vec_zero(c, k.V, n);
   {
     Prof p(c, KC_PC_APPLY);
-    launch_pc(c, false, b, k.R, 3, nullptr);  // R = B^-1 b, partial (R,R)
+    if (pc_solve(c, b, k.R, 3, nullptr, nullptr)) return -1;  // R = B^-1 b, partial (R,R)
   }
   {
     Prof p(c, KC_VECTOR);
-    vec_finalize(c, nsub, S_DP2, 1, (c->comm && c->comm->nranks > 1) ? -1 : 0);
+    vec_finalize(c, k.nb_pc, S_DP2, 1, (c->comm && c->comm->nranks > 1) ? -1 : 0);
     if (c->comm && c->comm->nranks > 1) { if (allreduce_scal(c, S_DP2, 1)) return -1; bcgs_scalars(c, 0); }
     vec_copy(c, k.RP, k.R, n);
   }
@@ -256,7 +512,7 @@ int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, doub
     { Prof p(c, KC_VECTOR); bcgs_update_p(c); }
     if (int e = pc_amul(c, k.P, k.V, 1, k.RP)) return e;
     Prof p(c, KC_VECTOR);
-    vec_finalize(c, nsub, S_D1, 1, multi ? -1 : 2);
+    vec_finalize(c, k.nb_pc, S_D1, 1, multi ? -1 : 2);
     if (multi) { if (int e = allreduce_scal(c, S_D1, 1)) return e; bcgs_scalars(c, 2); }
     bcgs_update_s(c);
     return 0;
@@ -269,7 +525,7 @@ int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, doub
     if ((rc = pc_amul(c, k.S, k.T, 2, nullptr))) break;
     {
       Prof p(c, KC_VECTOR);
-      vec_finalize(c, nsub, S_D1, 2, multi ? -1 : 3);
+      vec_finalize(c, k.nb_pc, S_D1, 2, multi ? -1 : 3);
       if (multi) { if ((rc = allreduce_scal(c, S_D1, 2))) break; bcgs_scalars(c, 3); }
       bcgs_update_xr(c);
       vec_finalize(c, k.nblocks, S_DP2, 2, multi ? -1 : 4);
@@ -318,14 +574,14 @@ int ksp_gmres(wai_ctx* c, const double* b, double* x, int* its, int* reason, dou
     double* v0 = k.basis;
     if (it == 0) {
       Prof p(c, KC_PC_APPLY);
-      launch_pc(c, false, b, v0, 0, nullptr);
+      if (pc_solve(c, b, v0, 0, nullptr, nullptr)) return -1;
     } else {
       vec_copy(c, k.P, x, n);
       if (halo_exchange(c, k.P, c->np)) return -1;
       { Prof p(c, KC_SPMV); launch_spmv(c, k.P, k.tmp); }
       vec_waxpy(c, k.tmp, -1.0, k.tmp, b, n);
       Prof p(c, KC_PC_APPLY);
-      launch_pc(c, false, k.tmp, v0, 0, nullptr);
+      if (pc_solve(c, k.tmp, v0, 0, nullptr, nullptr)) return -1;
     }
     {
       Prof p(c, KC_VECTOR);
@@ -503,8 +759,8 @@ void free_all(wai_ctx* c) {
   F(m.diag_blk); F(m.cell_src);
   F(c->src.cell); F(c->src.comp); F(c->src.next); F(c->src.rate); F(c->src.enth); F(c->src.ctl);
   F(c->J.rowptr); F(c->J.col); F(c->J.val);
-  IluSchedule& s = c->ilu;
-  F(s.sub_ptr); F(s.sub_nlev); F(s.row_info); F(s.row_uoff); F(s.fval); F(s.dinv); F(s.sub_int); F(s.sub_bnd);
+  free_schedule(c->ilu);
+  free_asm(c);
   Krylov& k = c->ks;
   F(k.R); F(k.RP); F(k.P); F(k.V); F(k.S); F(k.T); F(k.tmp); F(k.X); F(k.basis); F(k.partials); F(k.scal);
   if (k.h_scal) (void)hipHostFree(k.h_scal);
@@ -557,6 +813,8 @@ void wai_default_opts(wai_solver_opts* o) {
   o->utol_rel = 1.e-10; o->utol_abs = 1.0;
   o->fd_eps = 1.e-8; o->fd_umin = 1.e-2;
   o->min_newton_its = 0;
+  o->pc_type = WAI_PC_BJACOBI;
+  o->asm_overlap = 1;
 }
 
 int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_solver_opts* od,
@@ -697,116 +955,10 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
   }
   // block-Jacobi subdomains + dependency levels of the ILU(0) factors (symbolic phase, once)
   {
-    IluSchedule& s = c->ilu;
     std::vector<int> sub;
     if (md->sub_ptr && md->n_sub > 0) sub.assign(md->sub_ptr, md->sub_ptr + md->n_sub + 1);
-    else sub = {0, N};
-    s.nsub = (int)sub.size() - 1;
-    if (sub.front() != 0 || sub.back() != N) { c->err = "sub_ptr must cover [0, n_owned]"; return -2; }
-    std::vector<int> info(N), uoff(N, 0), levf(N), levb(N), nlev(s.nsub, 0);
-    s.max_rows = 0; s.max_lev = 0;
-    bool offdiag_fill = false, level_sorted = true, fast3 = true;
-    for (int sd = 0; sd < s.nsub; sd++) {
-      const int lo = sub[sd], hi = sub[sd + 1];
-      if (hi < lo) { c->err = "sub_ptr not monotone"; return -2; }
-      s.max_rows = std::max(s.max_rows, hi - lo);
-      int nlf = 0, nlb = 0;
-      std::vector<int> lfirst(hi - lo), ulast(hi - lo);
-      for (int i = lo; i < hi; i++) {
-        const int* row = J.h_colidx.data() + J.h_rowptr[i];
-        const int cnt = J.h_rowptr[i + 1] - J.h_rowptr[i];
-        int ls = 0;
-        while (ls < cnt && row[ls] < lo) ls++;
-        int ue = cnt;
-        while (ue > 0 && row[ue - 1] >= hi) ue--;
-        lfirst[i - lo] = ls; ulast[i - lo] = ue;
-        int lv = 0;
-        for (int q = ls; q < diag[i]; q++) lv = std::max(lv, levf[row[q]] + 1);
-        levf[i] = lv;
-        nlf = std::max(nlf, lv + 1);
-      }
-      for (int i = hi - 1; i >= lo; i--) {
-        const int* row = J.h_colidx.data() + J.h_rowptr[i];
-        int lv = 0;
-        for (int q = diag[i] + 1; q < ulast[i - lo]; q++) lv = std::max(lv, levb[row[q]] + 1);
-        levb[i] = lv;
-        nlb = std::max(nlb, lv + 1);
-      }
-      // does the IKJ elimination ever update an off-diagonal block of a row in this subdomain?
-      for (int i = lo; i < hi && !offdiag_fill; i++) {
-        const int* row = J.h_colidx.data() + J.h_rowptr[i];
-        for (int q = lfirst[i - lo]; q < diag[i] && !offdiag_fill; q++) {
-          const int k = row[q];
-          const int* rk = J.h_colidx.data() + J.h_rowptr[k];
-          for (int r2 = diag[k] + 1; r2 < ulast[k - lo]; r2++) {
-            const int j = rk[r2];
-            if (j == i) continue;
-            if (std::binary_search(row + q + 1, row + ulast[i - lo], j)) { offdiag_fill = true; break; }
-          }
-        }
-      }
-      for (int i = lo; i + 1 < hi; i++)
-        if (levf[i] > levf[i + 1] || levb[i] < levb[i + 1]) level_sorted = false;
-      int ucount = 0;
-      const int park_max = getenv("WAI_PC_PARK2") ? 2 : 3;
-      for (int i = lo; i < hi; i++) {
-        const int nL = diag[i] - lfirst[i - lo], nU = ulast[i - lo] - diag[i] - 1;
-        if (nL > 3 || nU > 3 || lfirst[i - lo] > 3 || diag[i] > 3) fast3 = false;
-        uoff[i] = ucount;
-        ucount += std::min(nU, park_max);
-      }
-      s.max_ublocks = std::max(s.max_ublocks, ucount);
-      if (nlf > 1023 || nlb > 1023) { c->err = "more than 1023 dependency levels in a subdomain"; return -2; }
-      for (int i = lo; i < hi; i++)
-        info[i] = lfirst[i - lo] | (diag[i] << 4) | (ulast[i - lo] << 8) | (levf[i] << 12) | (levb[i] << 22);
-      nlev[sd] = nlf | (nlb << 16);
-      s.max_lev = std::max(s.max_lev, std::max(nlf, nlb));
-    }
-    {   // subdomains without / with partition-ghost columns (for the overlapped halo exchange)
-      std::vector<int> li, lb;
-      for (int sd = 0; sd < s.nsub; sd++) {
-        bool ghost = false;
-        for (int i = sub[sd]; i < sub[sd + 1] && !ghost; i++)
-          for (int q = J.h_rowptr[i]; q < J.h_rowptr[i + 1]; q++)
-            if (J.h_colidx[q] >= N) { ghost = true; break; }
-        (ghost ? lb : li).push_back(sd);
-      }
-      s.n_int = (int)li.size();
-      s.n_bnd = (int)lb.size();
-      if (m.n_halo > 0 && s.n_int > 0 && s.n_bnd > 0) {
-        if (dev_upload(c, &s.sub_int, li) || dev_upload(c, &s.sub_bnd, lb)) return -1;
-      }
-    }
-    if (s.max_rows > 1024) {
-      c->err = "preconditioner subdomain larger than 1024 rows (one thread per row, one workgroup "
-               "per subdomain); use smaller bricks";
-      return -2;
-    }
-    if (dev_upload(c, &s.sub_ptr, sub) || dev_upload(c, &s.sub_nlev, nlev) || dev_upload(c, &s.row_info, info) ||
-        dev_upload(c, &s.row_uoff, uoff) ||
-        dev_alloc(c, &s.fval, (size_t)J.W * np * np * N) || dev_alloc(c, &s.dinv, (size_t)np * np * N))
-      return -1;
-    s.diag_only = !offdiag_fill && !getenv("WAI_ILU_GENERAL");
-    // wave-pipelined sweeps (one wave at a time, no per-level barrier) measured slower than the
-    // barrier-per-level form on MI355X (0.373 vs 0.346 ms at 4.1 M rows): opt-in only
-    s.level_sorted = level_sorted && getenv("WAI_ILU_WAVEPIPE");
-    s.fast3 = fast3 && !getenv("WAI_ILU_NOFAST");
-    s.scaled = !getenv("WAI_ILU_NOSCALE");
-    {
-      const char* e = getenv("WAI_PC_PARK");
-      // 160 KB of LDS per CU; a workgroup may use 64 KB
-      const size_t need = ((size_t)(((s.max_rows + 63) / 64) * 64) * np + 32 + (size_t)s.max_ublocks * 4) * sizeof(double);
-      s.park = !(e && e[0] == '0') && need <= 64 * 1024;  // default on; WAI_PC_PARK=0: k_pc
-      s.park2 = getenv("WAI_PC_PARK2") != nullptr;        // experiment: two parked upper blocks per row
-    }
-    {
-      const char* e = getenv("WAI_PC_PIPE");
-      s.pipe = e && e[0] == '1';  // opt-in: measured slower than k_pc
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
-        s.pipe_grid = ((prop.multiProcessorCount + 7) / 8) * 8;
-      if (const char* g = getenv("WAI_PC_PIPE_GRID")) s.pipe_grid = std::max(8, (atoi(g) / 8) * 8);
-    }
+    else sub = {0, N};   // one block per rank: the reference's PCBJACOBI / PCASM default
+    if (int e = build_schedule(c, c->ilu, J.h_rowptr, J.h_colidx, sub, N, J.W, np, true)) return e;
   }
   // state and work vectors
   const size_t nl = (size_t)np * m.n_prim, n = (size_t)np * N;
@@ -872,6 +1024,8 @@ const char* wai_last_error(wai_ctx* c) { return c ? c->err.c_str() : "null conte
 int wai_set_opts(wai_ctx* c, const wai_solver_opts* o) {
   if (!c || !o) return -2;
   const int old_type = c->opts.ksp_type;
+  if (o->pc_type < WAI_PC_BJACOBI || o->pc_type > WAI_PC_NONE) { c->err = "unknown preconditioner type"; return -2; }
+  if (o->pc_type != c->opts.pc_type || o->asm_overlap != c->opts.asm_overlap) c->ilu.factored = false;
   c->opts = *o;
   if (o->ksp_type == WAI_KSP_GMRES && (old_type != WAI_KSP_GMRES || !c->ks.basis)) {
     if (c->ks.basis) (void)hipFree(c->ks.basis);
@@ -1256,7 +1410,7 @@ int wai_pc_apply(wai_ctx* c, const double* r, double* z) {
   if (ri.in(r, c->ks.n, 0) || zo.out_only(z, c->ks.n, 1)) return -1;
   {
     Prof p(c, KC_PC_APPLY);
-    launch_pc(c, false, ri.dev, zo.dev, 0, nullptr);
+    if (pc_solve(c, ri.dev, zo.dev, 0, nullptr, nullptr)) return -1;
   }
   return zo.back();
 }
@@ -1538,12 +1692,11 @@ int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
   auto run = [&]() {
     switch (which) {
       case 0: launch_spmv(c, k.P, k.tmp); break;
-      case 1: case 3: case 5: launch_pc(c, false, k.P, k.V, 0, nullptr); break;
-      default: launch_pc(c, true, k.P, k.V, 1, k.RP); break;
+      case 1: case 3: pc_solve(c, k.P, k.V, 0, nullptr, nullptr); break;
+      default: pc_amul(c, k.P, k.V, 1, k.RP); break;   // what a BiCGStab half-iteration runs (no halo on one rank)
     }
   };
-  // 7/8: probes of the pipelined kernel (sweeps skipped / next-brick loads skipped)
-  c->dbg = (which == 3 || which == 4) ? 1 : (which == 7 ? 4 : which == 8 ? 8 : which >= 5 ? 2 : 0);
+  c->dbg = (which == 3 || which == 4) && pc_fused(c) && !(c->J.bs == 2 && c->ilu.park) ? 1 : 0;
   for (int i = 0; i < 5; i++) run();
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   for (int i = 0; i < reps; i++) run();
@@ -1555,6 +1708,21 @@ int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
   *ms_per_launch = ms / reps;
   return 0;
 }
+
+// name of the kernel (or path) a preconditioned-operator application runs on, for reports
+const char* wai_pc_kernel_name(wai_ctx* c) {
+  if (!c) return "";
+  const IluSchedule& s = c->ilu;
+  if (c->opts.pc_type == WAI_PC_NONE) return "k_spmv (no preconditioner)";
+  if (c->opts.pc_type == WAI_PC_ASM) return c->as.sched.big ? "k_spmv + k_lvl_solve per level (ASM, extended system)" : "k_spmv + k_pc on the extended ASM system";
+  if (s.big) return "k_spmv + k_lvl_solve per level";
+  if (c->J.bs == 2 && s.park && s.diag_only && s.scaled && s.fast3 && s.max_rows <= 512) return "k_pc_park<spmv>";
+  static thread_local char buf[96];
+  snprintf(buf, sizeof(buf), "k_pc<%d,spmv,%s,%s>", c->J.bs, s.diag_only ? (s.scaled ? "dilu-scaled" : "dilu") : "ilu",
+           s.fast3 ? "compact3" : "generic");
+  return buf;
+}
+int wai_comm_size(wai_ctx* c) { return c ? comm_count(c->comm) : -2; }
 
 int wai_timer_start(wai_ctx* c) { if (!c) return -2; HIPCHK(c, hipEventRecord(c->ev0, c->stream)); return 0; }
 int wai_timer_stop(wai_ctx* c, float* ms) {

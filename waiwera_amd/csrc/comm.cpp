@@ -22,6 +22,7 @@ struct Api {
   int (*GetUniqueId)(void*) = nullptr;
   int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;   // optional
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
@@ -64,6 +65,7 @@ bool load_api(std::string& err) {
   SYM(GroupEnd, "ncclGroupEnd")
   SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+  *reinterpret_cast<void**>(&g_api.CommCount) = dlsym(h, "ncclCommCount");
   g_api.lib = h;
   return true;
 }
@@ -90,6 +92,13 @@ Comm* comm_create(int rank, int nranks, const char id[128], std::string& err) {
   const int r = g_api.CommInitRank(&c->handle, nranks, u, rank);
   if (r) { err = g_api.GetErrorString(r); delete c; return nullptr; }
   return c;
+}
+
+int comm_count(Comm* c) {   // ranks the communicator itself reports (ncclCommCount)
+  if (!c) return 1;
+  int n = c->nranks;
+  if (c->handle && g_api.CommCount && g_api.CommCount(c->handle, &n) != 0) return -1;
+  return n;
 }
 
 void comm_destroy(Comm* c) {

@@ -15,6 +15,7 @@ struct Comm {
 int comm_unique_id(char id[128], std::string& err);
 Comm* comm_create(int rank, int nranks, const char id[128], std::string& err);
 void comm_destroy(Comm* c);
+int comm_count(Comm* c);
 // op: 0 sum, 1 max, 2 min; in place on a device buffer, enqueued on stream
 int comm_allreduce(Comm* c, double* buf, size_t count, int op, hipStream_t stream, std::string& err);
 // neighbour exchange of packed slabs (doubles), enqueued on stream

@@ -71,8 +71,30 @@ struct IluSchedule {
   bool fast3 = false;         // <= 3 lower and <= 3 upper in-subdomain couplings per row, offsets < 4
   bool level_sorted = false;  // every subdomain's rows are stored in dependency-level order
   bool factored = false;
-  bool pipe = false;          // software-pipelined persistent k_pc_pipe where it applies (WAI_PC_PIPE=1: on)
-  int pipe_grid = 256;        // its workgroups: one per CU
+  // subdomains of more than 1024 rows ("one block per rank", sub_ptr = NULL, is the reference's
+  // PCBJACOBI / PCASM default): rows of equal dependency level are independent across all
+  // subdomains, so the factorisation and the two substitutions run as one launch per level over
+  // the rows of that level (stored factor, unfused)
+  bool big = false;
+  int nlev_f = 0, nlev_b = 0;
+  int* ord_f = nullptr;       // rows sorted by forward level, ...
+  int* ord_b = nullptr;       // ... by backward level
+  std::vector<int> lev_f_ptr, lev_b_ptr;   // host: row ranges of each level in ord_f / ord_b
+  bool built = false;
+};
+
+// PCASM (restricted additive Schwarz) system: every subdomain's overlapped row set is stored as
+// its own block of an extended matrix E (couplings leaving the set dropped), so the block-Jacobi
+// machinery applies to E unchanged: gather r -> r_ext, ILU(0) solve per block, scatter the owned
+// rows back (src/timestepper.F90:1668-1669,1753-1757; PETSc PCASM defaults: overlap 1, restrict)
+struct AsmSystem {
+  int overlap = 0;            // what E was built for (0: not built)
+  int n_ext = 0;
+  Bcsr E;                     // block-ELL over the n_ext rows, columns in ext numbering
+  IluSchedule sched;
+  int* ext_row = nullptr;     // [n_ext] row of the global system, bit 31 set: owned by this block
+  int* gmap = nullptr;        // [W * n_ext] plane position (slot * n + row) of the source block in J, -1: none
+  double* r_ext = nullptr;    // [bs * n_ext] gathered right-hand side / solution
 };
 
 // Residual form of the time stepping method (src/timestepper.F90:345-452), by value to kernels
@@ -114,6 +136,7 @@ struct Krylov {
   double* scal = nullptr;      // device scalars
   double* h_scal = nullptr;    // pinned host mirror
   int nblocks = 0;
+  int nb_pc = 0;               // partial-sum blocks the last preconditioner application left per slot
 };
 
 }  // namespace wai
@@ -128,6 +151,7 @@ struct wai_ctx {
   wai::Sources src;
   wai::Bcsr J;
   wai::IluSchedule ilu;
+  wai::AsmSystem as;
   wai::Krylov ks;
   wai::Tracers tr;
   // fluid state, SoA df x n_local each; perturbed states np x df x n_prim
@@ -200,6 +224,19 @@ int launch_region_set(wai_ctx* c, const double* in, int first, int count);
 
 int launch_spmv(wai_ctx* c, const double* x, double* y);
 int launch_ilu_factor(wai_ctx* c);
+// the same on any (matrix, schedule) pair: the Jacobian with the brick schedule, or the extended
+// ASM system with its own
+int launch_ilu_factor_on(wai_ctx* c, const Bcsr& M, IluSchedule& s);
+int launch_pc_on(wai_ctx* c, const Bcsr& M, const IluSchedule& s, bool spmv, const double* in, double* z,
+                 int dot_mode, const double* aux, const int* list = nullptr, int nrun = 0);
+// subdomains of any size: level-by-level launches, in place on z (z = r on entry)
+int launch_big_solve(wai_ctx* c, const Bcsr& M, const IluSchedule& s, double* z);
+int launch_asm_gather_matrix(wai_ctx* c);                   // E.val <- J.val
+int launch_asm_gather(wai_ctx* c, const double* r);        // as.r_ext <- r
+int launch_asm_scatter(wai_ctx* c, double* z);             // z[owned] <- as.r_ext
+// up to two dot products (a1,b1) -> slot1, (a2,b2) -> slot2 (a2 null: one); partial blocks in ks.nb_pc
+int vec_dots(wai_ctx* c, const double* a1, const double* b1, int slot1, const double* a2, const double* b2,
+             int slot2, int n);
 // z = B^-1 r (spmv = false) or z = B^-1 (A x) (spmv = true: x is `in`, haloed by the caller).
 // dot_mode 0: none; 1: scal-partials S_D1 += (z, aux); 2: S_D1 += (in, z), S_D2 += (z, z);
 // 3: S_DP2 += (z, z)

@@ -401,7 +401,7 @@ __device__ __forceinline__ void wg_reduce_store(double (&v)[NS], double* red, do
 // L_ik = A_ik inv(D_k) and U_ij = A_ij exactly and the factor is just the modified pivots.  The
 // matrix row a thread pulled in for the SpMV is then reused for both substitutions and only the
 // inverted pivot block is read from the factor: ~300 instead of ~520 bytes per block row.
-template <int BS, bool SPMV, int DILU, bool WP, bool FAST>
+template <int BS, bool SPMV, int DILU, bool FAST>
 __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n, int W, int nsub, const int* __restrict__ sub_ptr,
                      const int* __restrict__ sub_nlev, const int* __restrict__ row_info,
                      const int* __restrict__ col, const double* __restrict__ aval,
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
         }
       }
       if constexpr (!SPMV) load_x<BS>(in, i, acc);
-      if (SPMV && dot == 2) load_x<BS>(in, i, xin);
+      if (dot == 2) load_x<BS>(SPMV ? in : aux, i, xin);
       if constexpr (!SC) load_block<BS>(dinv, n, 0, i, dv);
       if constexpr (SC && !SPMV) {  // plain application to an unscaled vector: scale it first
         load_block<BS>(dinv, n, 0, i, dv);
@@ -521,6 +521,7 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
         if (dot == 2) load_x<BS>(in, i, xin);
       } else {
         load_x<BS>(in, i, acc);
+        if (dot == 2) load_x<BS>(aux, i, xin);
       }
       // factor row -> registers (independent loads, all in flight before the first barrier)
 #pragma unroll
@@ -681,36 +682,7 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
 #pragma unroll
     for (int r = 0; r < BS; r++) ys[tid * BS + r] = out[r];
   };
-  if constexpr (WP) {
-    // Rows are stored in level order (forward levels ascending, backward levels descending along
-    // the subdomain), so wave w owns a contiguous run of levels.  Waves take turns: inside its
-    // turn a wave walks its levels with no barrier at all (LDS traffic of one wave is in order),
-    // and only the hand-over to the next wave is a workgroup barrier: 2 x (#waves) barriers
-    // instead of one per level.
-    const int wave = tid >> 6, nw = (int)(blockDim.x >> 6);
-    const int nact = min(64, max(0, R - wave * 64));  // active lanes form a prefix of the wave
-    const int lf_first = __shfl(lf, 0), lf_last = __shfl(lf, nact > 0 ? nact - 1 : 0);
-    const int lb_first = __shfl(lb, 0), lb_last = __shfl(lb, nact > 0 ? nact - 1 : 0);
-    for (int ph = 0; ph < ((dbg & 1) ? 0 : nw); ph++) {
-      if (wave == ph && nact > 0) {
-        for (int lev = max(lf_first, DILU ? 1 : 1); lev <= lf_last; lev++) {
-          if (lf == lev) fwd_row();
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-      __syncthreads();
-    }
-    if (dbg & 1) bwd_row();
-    for (int ph = ((dbg & 1) ? -1 : nw - 1); ph >= 0; ph--) {
-      if (wave == ph && nact > 0) {
-        for (int lev = lb_last; lev <= lb_first; lev++) {
-          if (lb == lev) bwd_row();
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-      if (ph > 0) __syncthreads();
-    }
-  } else {
+  {
     for (int lev = 1; lev < nlf; lev++) {  // level-0 rows have no lower couplings
       if (lf == lev) fwd_row();
       __syncthreads();
@@ -761,11 +733,8 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
 // three resident workgroups per CU (3 x 51 KB of the 160 KB LDS), so one more brick's loads are in
 // flight to cover the latency-bound sweeps of the others.
 // MEASURED (216^3, MI355X, same box): 0.604 ms against k_pc's 0.709 ms; 68 VGPRs, no spills.
-// P2: at most two of a row's upper blocks are parked, the third (rows with all three in-brick
-// upper neighbours) is fetched again from the matrix after the forward sweep: 40 KB of LDS per
-// workgroup instead of 47-51 KB, i.e. a fourth resident workgroup per CU if 64 VGPRs suffice.
-template <bool SPMV, bool P2 = false>
-__global__ __launch_bounds__(512, P2 ? 8 : 6) void k_pc_park(
+template <bool SPMV>
+__global__ __launch_bounds__(512, 6) void k_pc_park(
     int n, int W, int nsub, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev,
     const int* __restrict__ row_info, const int* __restrict__ row_uoff, const int* __restrict__ col,
     const double* __restrict__ sval, const double* __restrict__ dinv, const double* __restrict__ in,
@@ -821,7 +790,7 @@ __global__ __launch_bounds__(512, P2 ? 8 : 6) void k_pc_park(
 #pragma unroll
           for (int e = 0; e < BB; e++) Lf[p][e] = tl ? blk[e] : Lf[p][e];
         }
-        if (isu && (!P2 || q - dslot - 1 < 2)) {
+        if (isu) {
           double* dst = upark + (size_t)(uo + (q - dslot - 1)) * BB;
           *reinterpret_cast<double2*>(dst) = make_double2(blk[0], blk[1]);
           *reinterpret_cast<double2*>(dst + 2) = make_double2(blk[2], blk[3]);
@@ -835,7 +804,7 @@ __global__ __launch_bounds__(512, P2 ? 8 : 6) void k_pc_park(
       acc[0] = dv[0] * r[0] + dv[1] * r[1];
       acc[1] = dv[2] * r[0] + dv[3] * r[1];
     }
-    if (SPMV && dot == 2) load_x<BS>(in, i, xin);
+    if (dot == 2) load_x<BS>(SPMV ? in : aux, i, xin);
     *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(acc[0], acc[1]);
   }
   __syncthreads();
@@ -864,17 +833,6 @@ __global__ __launch_bounds__(512, P2 ? 8 : 6) void k_pc_park(
 #pragma unroll
   for (int p = 0; p < MLU; p++) {
     const bool have = p < nU;
-    if (P2 && p == 2) {
-      double blk[BB] = {0.0, 0.0, 0.0, 0.0};
-      if (have) {
-        int lfirst, dslot, ulast, a_, b_;
-        unpack_info(row_info[i], lfirst, dslot, ulast, a_, b_);
-        load_block<BS>(sval, n, dslot + 3, i, blk);
-      }
-#pragma unroll
-      for (int e = 0; e < BB; e++) Lf[p][e] = blk[e];
-      continue;
-    }
     const double* src = upark + (size_t)(uo + (have ? p : 0)) * BB;
     const double2 u0 = *reinterpret_cast<const double2*>(src), u1 = *reinterpret_cast<const double2*>(src + 2);
     Lf[p][0] = have ? u0.x : 0.0; Lf[p][1] = have ? u0.y : 0.0;
@@ -913,213 +871,6 @@ __global__ __launch_bounds__(512, P2 ? 8 : 6) void k_pc_park(
     __syncthreads();
     if (dot == 2) wg_reduce_store<2>(v, red, partials, nb_max, slots, s);
     else { double v1[1] = {v[0]}; wg_reduce_store<1>(v1, red, partials, nb_max, slots, s); }
-  }
-}
-
-// ---- K6+K8 fused, software-pipelined over bricks (bs = 2, DILU, <= 3+3 couplings) --------------
-// k_pc alternates a load phase (matrix row, x gather: HBM/L2 latency) and the substitution
-// sweeps (LDS latency, ~2 x 22 barrier-separated levels for an 8x8x8 brick), and with ~100 VGPRs
-// only two workgroups fit a CU, so the sweeps (15-20 % of the kernel) are not hidden behind other
-// workgroups' loads.  Here a persistent workgroup walks its share of the bricks and issues the
-// next brick's loads before it starts the current brick's sweeps: the sweeps only touch LDS
-// (lgkmcnt), the global loads stay in flight across the level barriers (vmcnt is not waited on:
-// the barrier below is `s_waitcnt lgkmcnt(0); s_barrier`, not __syncthreads, whose fence would
-// drain vmcnt), and the x gather -- which needs the column indices -- is issued between the
-// forward and the backward sweep.  ~200 VGPRs, 2 waves/SIMD, one workgroup per CU.  Block-ELL
-// width 7 (3-D 7-point stencils) is compiled in; other widths take k_pc.
-// MEASURED (216^3, MI355X): 0.895 ms against k_pc's 0.776 ms, so it is opt-in (WAI_PC_PIPE=1).
-// Probes: loads only 0.68 ms, sweeps only 0.64 ms -- with one workgroup per CU a brick's 43
-// levels cost 8.3 us (~460 cycles per level: LDS round trip + dependent FMAs + barrier), longer
-// than the brick's 7.7 us share of HBM time, so the sweeps become the critical path; k_pc's two
-// resident workgroups per CU hide them better than prefetching does.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-__global__ __launch_bounds__(512, 2) void k_pc_pipe(
-    int n, int nsub, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev,
-    const int* __restrict__ row_info, const int* __restrict__ col, const double* __restrict__ aval,
-    const double* __restrict__ dinv, const double* __restrict__ in, double* __restrict__ z,
-    const double* __restrict__ aux, double* partials, int nb_max, int dot, int dbg) {
-  constexpr int BS = 2, BB = 4, MLU = 3, WW = 7;
-  extern __shared__ double lds[];
-  double* ys = lds;
-  const int tid = threadIdx.x;
-  // XCD-aware brick schedule: workgroup (xcd, k) of the gx workgroups on its XCD takes bricks
-  // xcd*per + k, + gx, + 2 gx ... of the XCD's contiguous eighth
-  const int xcd = blockIdx.x & 7, k0 = blockIdx.x >> 3, gx = gridDim.x >> 3, per = (nsub + 7) >> 3;
-  auto brick = [&](int m) {
-    const int k = k0 + gx * m;
-    const int s = xcd * per + k;
-    return (k < per && s < nsub) ? s : -1;
-  };
-  // in-flight row of the next brick
-  double nb[WW][BB], ndv[BB], nx[WW][BS];
-  double2 nex = make_double2(0.0, 0.0);  // in[i] (dot 2) or aux[i] (dot 1) of the row
-  const double* exv = dot == 1 ? aux : in;  // always read: no conditional register merge around the load
-  int ncg[WW], ninfo = 0, nlo = 0, nR = 0, nnl = 0;
-#pragma unroll
-  for (int q = 0; q < WW; q++) {
-    ncg[q] = 0;
-#pragma unroll
-    for (int e = 0; e < BB; e++) nb[q][e] = 0.0;
-#pragma unroll
-    for (int r = 0; r < BS; r++) nx[q][r] = 0.0;
-  }
-#pragma unroll
-  for (int e = 0; e < BB; e++) ndv[e] = 0.0;
-  auto issue_main = [&](int s) {
-    nlo = sub_ptr[s]; nR = sub_ptr[s + 1] - nlo; nnl = sub_nlev[s];
-    if (tid < nR) {
-      const int i = nlo + tid;
-#pragma unroll
-      for (int q = 0; q < WW; q++)
-        ncg[q] = col[(size_t)q * n + i];
-      ninfo = row_info[i];
-      load_block<BS>(dinv, n, 0, i, ndv);
-#pragma unroll
-      for (int q = 0; q < WW; q++)
-        load_block<BS>(aval, n, q, i, nb[q]);
-    }
-  };
-  auto issue_x = [&]() {
-    nex = make_double2(0.0, 0.0);
-    if (tid < nR) {
-      const int i = nlo + tid;
-#pragma unroll
-      for (int q = 0; q < WW; q++)
-        load_x<BS>(in, ncg[q], nx[q]);
-      nex = *reinterpret_cast<const double2*>(exv + (size_t)i * 2);
-    }
-  };
-  double v0 = 0.0, v1 = 0.0;  // dot accumulators over this workgroup's bricks
-  int s = brick(0);
-  if (s >= 0) { issue_main(s); issue_x(); }
-  for (int m = 0; s >= 0; m++) {
-    // ---- consume the landed row: SpMV, compaction of the lower / upper blocks ----------------
-    // everything in flight has to land before the row is consumed; said once, outside the
-    // `active` branch, so the compiler's wait-count tracking starts every iteration from "nothing
-    // pending" instead of merging the skipped branch's state into conservative waits further down
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
-    const int lo = nlo, R = nR;
-    const int nlf = (dbg & 1) ? 0 : (nnl & 0xffff), nlb = (dbg & 1) ? 1 : (nnl >> 16);  // dbg: timing probes
-    const bool active = tid < R;
-    const int i = lo + tid;
-    double Lf[MLU][BB], Uf[MLU][BB], dv[BB];
-    const double2 ex = nex;
-    int Lc[MLU], Uc[MLU], lf = -1, lb = -1;
-#pragma unroll
-    for (int p = 0; p < MLU; p++) {
-      Lc[p] = tid; Uc[p] = tid;
-#pragma unroll
-      for (int e = 0; e < BB; e++) { Lf[p][e] = 0.0; Uf[p][e] = 0.0; }
-    }
-#pragma unroll
-    for (int e = 0; e < BB; e++) dv[e] = ndv[e];
-    if (active) {
-      int lfirst, dslot, ulast;
-      unpack_info(ninfo, lfirst, dslot, ulast, lf, lb);
-      double acc[BS] = {0.0, 0.0};
-#pragma unroll
-      for (int q = 0; q < WW; q++) {
-        {
-#pragma unroll
-          for (int r = 0; r < BS; r++)
-#pragma unroll
-            for (int k = 0; k < BS; k++) acc[r] += nb[q][r * BS + k] * nx[q][k];
-          const bool isl = (q >= lfirst) && (q < dslot), isu = (q > dslot) && (q < ulast);
-#pragma unroll
-          for (int p = 0; p < MLU; p++) {
-            const bool tl = isl && (q - lfirst == p), tu = isu && (q - dslot - 1 == p);
-            Lc[p] = tl ? ncg[q] - lo : Lc[p];
-            Uc[p] = tu ? ncg[q] - lo : Uc[p];
-#pragma unroll
-            for (int e = 0; e < BB; e++) {
-              Lf[p][e] = tl ? nb[q][e] : Lf[p][e];
-              Uf[p][e] = tu ? nb[q][e] : Uf[p][e];
-            }
-          }
-        }
-      }
-      if (lf == 0) {  // level-0 rows: w = inv(D) t straight away
-        const double w0 = dv[0] * acc[0] + dv[1] * acc[1], w1 = dv[2] * acc[0] + dv[3] * acc[1];
-        acc[0] = w0; acc[1] = w1;
-      }
-      *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(acc[0], acc[1]);
-    }
-    lds_barrier();
-    // ---- next brick's matrix row goes in flight now ---------------------------------------------
-    const int snext = brick(m + 1);
-    if (snext >= 0 && !(dbg & 2)) issue_main(snext);
-    auto gather3 = [&](const int (&cc)[MLU], const double (&ff)[MLU][BB], double* sum) {
-      double2 yk[MLU];
-#pragma unroll
-      for (int p = 0; p < MLU; p++) yk[p] = *reinterpret_cast<const double2*>(ys + cc[p] * 2);
-#pragma unroll
-      for (int r = 0; r < BS; r++) {
-        double part[MLU];
-#pragma unroll
-        for (int p = 0; p < MLU; p++) part[p] = ff[p][r * BS] * yk[p].x + ff[p][r * BS + 1] * yk[p].y;
-        sum[r] = (part[0] + part[1]) + part[2];
-      }
-    };
-    // forward: y_i = t_i - sum A_ik w_k, w_i = inv(D_i) y_i (LDS holds w)
-    for (int lev = 1; lev < nlf; lev++) {
-      if (lf == lev) {
-        const double2 a = *reinterpret_cast<const double2*>(ys + tid * 2);
-        double sum[BS];
-        gather3(Lc, Lf, sum);
-        const double a0 = a.x - sum[0], a1 = a.y - sum[1];
-        *reinterpret_cast<double2*>(ys + tid * 2) =
-            make_double2(dv[0] * a0 + dv[1] * a1, dv[2] * a0 + dv[3] * a1);
-      }
-      lds_barrier();
-    }
-    // the column indices of the next row have landed by now: x gather in flight under the
-    // backward sweep
-    if (snext >= 0 && !(dbg & 2)) issue_x();
-    // backward: x_i = w_i - inv(D_i) sum A_ij x_j
-    double out[BS] = {0.0, 0.0};
-    for (int lev = 0; lev < nlb; lev++) {
-      if (lb == lev) {
-        const double2 a = *reinterpret_cast<const double2*>(ys + tid * 2);
-        double sum[BS];
-        gather3(Uc, Uf, sum);
-        out[0] = a.x - (dv[0] * sum[0] + dv[1] * sum[1]);
-        out[1] = a.y - (dv[2] * sum[0] + dv[3] * sum[1]);
-        *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(out[0], out[1]);
-      }
-      lds_barrier();  // also fences this brick's last LDS reads from the next brick's writes
-    }
-    if (active) {
-      *reinterpret_cast<double2*>(z + (size_t)i * 2) = make_double2(out[0], out[1]);
-      if (dot == 1) v0 += out[0] * ex.x + out[1] * ex.y;
-      else if (dot == 2) { v0 += ex.x * out[0] + ex.y * out[1]; v1 += out[0] * out[0] + out[1] * out[1]; }
-      else if (dot == 3) v0 += out[0] * out[0] + out[1] * out[1];
-    }
-    s = snext;
-  }
-  if (dot != 0) {
-    // one partial per workgroup; the reduction kernel sums nsub entries per slot, so the
-    // remaining entries of this workgroup's stride are zeroed
-    double* red = lds + (size_t)blockDim.x * BS;
-    const int G = gridDim.x;
-    __syncthreads();
-    if (dot == 2) {
-      double v[2] = {v0, v1};
-      const int slots[2] = {S_D1, S_D2};
-      wg_reduce_store<2>(v, red, partials, nb_max, slots, blockIdx.x);
-      for (int j = blockIdx.x + G + tid * G; j < nsub; j += G * blockDim.x) {
-        partials[(size_t)S_D1 * nb_max + j] = 0.0;
-        partials[(size_t)S_D2 * nb_max + j] = 0.0;
-      }
-    } else {
-      double v[1] = {v0};
-      const int slots[1] = {dot == 1 ? S_D1 : S_DP2};
-      wg_reduce_store<1>(v, red, partials, nb_max, slots, blockIdx.x);
-      for (int j = blockIdx.x + G + tid * G; j < nsub; j += G * blockDim.x)
-        partials[(size_t)slots[0] * nb_max + j] = 0.0;
-    }
   }
 }
 
@@ -1354,12 +1105,176 @@ int launch_spmv(wai_ctx* c, const double* x, double* y) {
   return 0;
 }
 
-static inline int pc_threads(wai_ctx* c) { return ((c->ilu.max_rows + 63) / 64) * 64; }
+// ---- subdomains of any size: one launch per dependency level ------------------------------------
+// Rows of equal level are independent (across all subdomains), so the ILU(0) factorisation and the
+// two substitutions of PCBJACOBI / PCASM with arbitrarily large blocks -- the reference's default is
+// one block per MPI rank, src/timestepper.F90:1668-1669 -- run as a sequence of launches over the
+// rows of each level; kernel boundaries order the levels.  Stored factor (L multipliers, U, inverted
+// pivots), unfused.  This is the general path; the brick kernels above are the fast one.
+template <int BS>
+__global__ __launch_bounds__(TPB) void k_lvl_factor(int n, int cnt, const int* __restrict__ ord,
+                                                    const int* __restrict__ row_info, const int* __restrict__ col,
+                                                    double* fval, double* __restrict__ dinv, int* flags) {
+  constexpr int BB = BS * BS;
+  const int t = blockIdx.x * TPB + threadIdx.x;
+  if (t >= cnt) return;
+  const int i = ord[t];
+  int lfirst, dslot, ulast, lf, lb;
+  unpack_info(row_info[i], lfirst, dslot, ulast, lf, lb);
+  for (int q = lfirst; q < dslot; q++) {
+    const int k = col[(size_t)q * n + i];
+    int kl, kd, ku, kf, kb;
+    unpack_info(row_info[k], kl, kd, ku, kf, kb);
+    double w[BB], d[BB], tt[BB];
+#pragma unroll
+    for (int z = 0; z < BB; z++) { w[z] = fval[vix<BS>(n, q, z, i)]; d[z] = dinv[vix<BS>(n, 0, z, k)]; }
+#pragma unroll
+    for (int r = 0; r < BS; r++)
+#pragma unroll
+      for (int c = 0; c < BS; c++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int e = 0; e < BS; e++) acc += w[r * BS + e] * d[e * BS + c];
+        tt[r * BS + c] = acc;
+      }
+#pragma unroll
+    for (int z = 0; z < BB; z++) fval[vix<BS>(n, q, z, i)] = tt[z];
+    for (int r2 = kd + 1; r2 < ku; r2++) {
+      const int j = col[(size_t)r2 * n + k];
+      for (int q2 = q + 1; q2 < ulast; q2++) {
+        if (col[(size_t)q2 * n + i] != j) continue;
+        double u[BB];
+#pragma unroll
+        for (int z = 0; z < BB; z++) u[z] = fval[vix<BS>(n, r2, z, k)];
+#pragma unroll
+        for (int r = 0; r < BS; r++)
+#pragma unroll
+          for (int c = 0; c < BS; c++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int e = 0; e < BS; e++) acc += tt[r * BS + e] * u[e * BS + c];
+            fval[vix<BS>(n, q2, r * BS + c, i)] -= acc;
+          }
+        break;
+      }
+    }
+  }
+  double piv[BB], inv[BB];
+#pragma unroll
+  for (int z = 0; z < BB; z++) piv[z] = fval[vix<BS>(n, dslot, z, i)];
+  if (!block_inverse<BS>(piv, inv)) atomicMax(&flags[0], 1);
+#pragma unroll
+  for (int z = 0; z < BB; z++) dinv[vix<BS>(n, 0, z, i)] = inv[z];
+}
 
-int launch_ilu_factor(wai_ctx* c) {
-  const Bcsr& J = c->J;
-  const IluSchedule& s = c->ilu;
-  const int grid = ((s.nsub + 7) / 8) * 8, T = pc_threads(c);
+// forward (FWD): y_i = t_i - sum_{k < i} L_ik y_k; backward: x_i = inv(D_i) (y_i - sum_{j > i} U_ij x_j); in place
+template <int BS, bool FWD>
+__global__ __launch_bounds__(TPB) void k_lvl_solve(int n, int cnt, const int* __restrict__ ord,
+                                                   const int* __restrict__ row_info, const int* __restrict__ col,
+                                                   const double* __restrict__ fval, const double* __restrict__ dinv,
+                                                   double* z) {
+  constexpr int BB = BS * BS;
+  const int t = blockIdx.x * TPB + threadIdx.x;
+  if (t >= cnt) return;
+  const int i = ord[t];
+  int lfirst, dslot, ulast, lf, lb;
+  unpack_info(row_info[i], lfirst, dslot, ulast, lf, lb);
+  double acc[BS];
+#pragma unroll
+  for (int r = 0; r < BS; r++) acc[r] = z[(size_t)i * BS + r];
+  const int q0 = FWD ? lfirst : dslot + 1, q1 = FWD ? dslot : ulast;
+  for (int q = q0; q < q1; q++) {
+    const int k = col[(size_t)q * n + i];
+    double m[BB];
+#pragma unroll
+    for (int e = 0; e < BB; e++) m[e] = fval[vix<BS>(n, q, e, i)];
+#pragma unroll
+    for (int r = 0; r < BS; r++)
+#pragma unroll
+      for (int c = 0; c < BS; c++) acc[r] -= m[r * BS + c] * z[(size_t)k * BS + c];
+  }
+  if constexpr (FWD) {
+#pragma unroll
+    for (int r = 0; r < BS; r++) z[(size_t)i * BS + r] = acc[r];
+  } else {
+    double d[BB];
+#pragma unroll
+    for (int e = 0; e < BB; e++) d[e] = dinv[vix<BS>(n, 0, e, i)];
+#pragma unroll
+    for (int r = 0; r < BS; r++) {
+      double o = 0.0;
+#pragma unroll
+      for (int c = 0; c < BS; c++) o += d[r * BS + c] * acc[c];
+      z[(size_t)i * BS + r] = o;
+    }
+  }
+}
+
+// ---- PCASM: extended system ---------------------------------------------------------------------
+// E.val plane element <- J.val plane element (gmap = slot*n + row of the source block, -1: none)
+__global__ __launch_bounds__(TPB) void k_asm_gather_matrix(int n, int n_ext, int W_ext, int bs,
+                                                           const int* __restrict__ gmap,
+                                                           const double* __restrict__ jval, double* __restrict__ eval) {
+  const size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (t >= (size_t)W_ext * n_ext) return;
+  const int s = (int)(t / n_ext), q = (int)(t - (size_t)s * n_ext);
+  const int g = gmap[t];
+  const int ss = g < 0 ? 0 : g / n, i = g < 0 ? 0 : g - ss * n;
+  for (int r = 0; r < bs; r++)
+    for (int k = 0; k < bs; k++)
+      eval[((size_t)(s * bs + r) * n_ext + q) * bs + k] = g < 0 ? 0.0 : jval[((size_t)(ss * bs + r) * n + i) * bs + k];
+}
+__global__ __launch_bounds__(TPB) void k_asm_gather(int n_ext, int bs, const int* __restrict__ ext_row,
+                                                    const double* __restrict__ r, double* __restrict__ r_ext) {
+  const int q = blockIdx.x * TPB + threadIdx.x;
+  if (q >= n_ext) return;
+  const int i = ext_row[q] & 0x7fffffff;
+  for (int k = 0; k < bs; k++) r_ext[(size_t)q * bs + k] = r[(size_t)i * bs + k];
+}
+__global__ __launch_bounds__(TPB) void k_asm_scatter(int n_ext, int bs, const int* __restrict__ ext_row,
+                                                     const double* __restrict__ z_ext, double* __restrict__ z) {
+  const int q = blockIdx.x * TPB + threadIdx.x;
+  if (q >= n_ext) return;
+  const int e = ext_row[q];
+  if (e >= 0) return;  // overlap row: not prolonged back (PC_ASM_RESTRICT)
+  const int i = e & 0x7fffffff;
+  for (int k = 0; k < bs; k++) z[(size_t)i * bs + k] = z_ext[(size_t)q * bs + k];
+}
+
+__global__ __launch_bounds__(TPB) void k_dots(const double* __restrict__ a1, const double* __restrict__ b1, int slot1,
+                                              const double* __restrict__ a2, const double* __restrict__ b2, int slot2,
+                                              int n, double* partials, int nb_max) {
+  double v[2] = {0.0, 0.0};
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+    v[0] += a1[i] * b1[i];
+    if (a2) v[1] += a2[i] * b2[i];
+  }
+  const int slots[2] = {slot1, a2 ? slot2 : slot1};
+  if (a2) block_reduce_store<2>(v, partials, nb_max, slots);
+  else { double v1[1] = {v[0]}; const int s1[1] = {slot1}; block_reduce_store<1>(v1, partials, nb_max, s1); }
+}
+
+static inline int pc_threads(const IluSchedule& s) { return ((s.max_rows + 63) / 64) * 64; }
+
+int launch_ilu_factor_on(wai_ctx* c, const Bcsr& J, IluSchedule& s) {
+  if (s.big) {
+    // one launch per forward level; the factor starts as a copy of the matrix
+    hipMemcpyAsync(s.fval, J.val, sizeof(double) * (size_t)J.W * J.bs * J.bs * J.n, hipMemcpyDeviceToDevice, c->stream);
+    for (int lev = 0; lev < s.nlev_f; lev++) {
+      const int a = s.lev_f_ptr[lev], cnt = s.lev_f_ptr[lev + 1] - a, g = (cnt + TPB - 1) / TPB;
+      if (cnt <= 0) continue;
+      switch (J.bs) {
+        case 1: hipLaunchKernelGGL(k_lvl_factor<1>, g, TPB, 0, c->stream, J.n, cnt, s.ord_f + a, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
+        case 2: hipLaunchKernelGGL(k_lvl_factor<2>, g, TPB, 0, c->stream, J.n, cnt, s.ord_f + a, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
+        case 3: hipLaunchKernelGGL(k_lvl_factor<3>, g, TPB, 0, c->stream, J.n, cnt, s.ord_f + a, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
+        case 4: hipLaunchKernelGGL(k_lvl_factor<4>, g, TPB, 0, c->stream, J.n, cnt, s.ord_f + a, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
+        default: return -1;
+      }
+    }
+    s.factored = true;
+    return 0;
+  }
+  const int grid = ((s.nsub + 7) / 8) * 8, T = pc_threads(s);
   if (s.diag_only && s.scaled && !getenv("WAI_ILU_FULL_FACTOR")) {
     // pivots only, then the scaled rows (below): the general factor is never read in this case
     const size_t lds = (size_t)T * J.bs * J.bs * sizeof(double);
@@ -1371,14 +1286,14 @@ int launch_ilu_factor(wai_ctx* c) {
       default: return -1;
     }
   } else {
-  hipMemcpyAsync(s.fval, J.val, sizeof(double) * (size_t)J.W * J.bs * J.bs * J.n, hipMemcpyDeviceToDevice, c->stream);
-  switch (J.bs) {
-    case 1: hipLaunchKernelGGL(k_ilu_factor<1>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
-    case 2: hipLaunchKernelGGL(k_ilu_factor<2>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
-    case 3: hipLaunchKernelGGL(k_ilu_factor<3>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
-    case 4: hipLaunchKernelGGL(k_ilu_factor<4>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
-    default: return -1;
-  }
+    hipMemcpyAsync(s.fval, J.val, sizeof(double) * (size_t)J.W * J.bs * J.bs * J.n, hipMemcpyDeviceToDevice, c->stream);
+    switch (J.bs) {
+      case 1: hipLaunchKernelGGL(k_ilu_factor<1>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
+      case 2: hipLaunchKernelGGL(k_ilu_factor<2>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
+      case 3: hipLaunchKernelGGL(k_ilu_factor<3>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
+      case 4: hipLaunchKernelGGL(k_ilu_factor<4>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
+      default: return -1;
+    }
   }
   if (s.diag_only && s.scaled) {  // fval is not read in the diagonal-only case: it holds inv(P) A from here on
     const int g = (J.n + TPB - 1) / TPB;
@@ -1390,45 +1305,51 @@ int launch_ilu_factor(wai_ctx* c) {
       default: return -1;
     }
   }
-  c->ilu.factored = true;
+  s.factored = true;
+  return 0;
+}
+int launch_ilu_factor(wai_ctx* c) { return launch_ilu_factor_on(c, c->J, c->ilu); }
+
+int launch_big_solve(wai_ctx* c, const Bcsr& J, const IluSchedule& s, double* z) {
+#define LVL(FW, ORD, PTR, NLEV)                                                                     \
+  for (int lev = 0; lev < NLEV; lev++) {                                                            \
+    const int a = PTR[lev], cnt = PTR[lev + 1] - a, g = (cnt + TPB - 1) / TPB;                       \
+    if (cnt <= 0) continue;                                                                         \
+    switch (J.bs) {                                                                                 \
+      case 1: hipLaunchKernelGGL((k_lvl_solve<1, FW>), g, TPB, 0, c->stream, J.n, cnt, ORD + a, s.row_info, J.col, s.fval, s.dinv, z); break; \
+      case 2: hipLaunchKernelGGL((k_lvl_solve<2, FW>), g, TPB, 0, c->stream, J.n, cnt, ORD + a, s.row_info, J.col, s.fval, s.dinv, z); break; \
+      case 3: hipLaunchKernelGGL((k_lvl_solve<3, FW>), g, TPB, 0, c->stream, J.n, cnt, ORD + a, s.row_info, J.col, s.fval, s.dinv, z); break; \
+      case 4: hipLaunchKernelGGL((k_lvl_solve<4, FW>), g, TPB, 0, c->stream, J.n, cnt, ORD + a, s.row_info, J.col, s.fval, s.dinv, z); break; \
+      default: return -1;                                                                           \
+    }                                                                                               \
+  }
+  LVL(true, s.ord_f, s.lev_f_ptr, s.nlev_f)   // level-0 rows of the forward sweep have nothing to subtract, but the launch is harmless
+  LVL(false, s.ord_b, s.lev_b_ptr, s.nlev_b)
+#undef LVL
   return 0;
 }
 
 template <int BS>
-static void launch_pc_bs(wai_ctx* c, bool spmv, const double* in, double* z, int dot_mode, const double* aux,
-                         const int* list, int nrun) {
-  const Bcsr& J = c->J;
-  const IluSchedule& s = c->ilu;
+static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool spmv, const double* in, double* z,
+                         int dot_mode, const double* aux, const int* list, int nrun) {
   if (!list) nrun = s.nsub;
-  const int grid = ((nrun + 7) / 8) * 8, T = pc_threads(c);
+  const int grid = ((nrun + 7) / 8) * 8, T = pc_threads(s);
   const size_t lds = ((size_t)T * BS + 32) * sizeof(double);
-#define PCL(SP, DI, WPP)                                                                        \
+#define PCL(SP, DI)                                                                              \
   do {                                                                                           \
     if (s.fast3)                                                                                 \
-      hipLaunchKernelGGL((k_pc<BS, SP, DI, WPP, true>), grid, T, lds, c->stream, J.n, J.W,       \
+      hipLaunchKernelGGL((k_pc<BS, SP, DI, true>), grid, T, lds, c->stream, J.n, J.W,            \
                          nrun, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.fval,          \
                          s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, c->dbg, list); \
     else                                                                                         \
-      hipLaunchKernelGGL((k_pc<BS, SP, DI, WPP, false>), grid, T, lds, c->stream, J.n, J.W,      \
+      hipLaunchKernelGGL((k_pc<BS, SP, DI, false>), grid, T, lds, c->stream, J.n, J.W,           \
                          nrun, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.fval,          \
                          s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, c->dbg, list); \
   } while (0)
-  const bool wp = s.level_sorted && !(c->dbg & 2);
   if constexpr (BS == 2) {
     // upper blocks parked in LDS: three resident workgroups per CU
     if (s.park && s.diag_only && s.scaled && s.fast3 && T <= 512 && !c->dbg) {
       const size_t lds_park = lds + (size_t)s.max_ublocks * 4 * sizeof(double);
-      if (s.park2) {
-        if (spmv)
-          hipLaunchKernelGGL((k_pc_park<true, true>), grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,
-                             s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials,
-                             c->ks.nb_max, dot_mode, list);
-        else
-          hipLaunchKernelGGL((k_pc_park<false, true>), grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,
-                             s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials,
-                             c->ks.nb_max, dot_mode, list);
-        return;
-      }
       if (spmv)
         hipLaunchKernelGGL(k_pc_park<true>, grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,
                            s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials,
@@ -1439,36 +1360,51 @@ static void launch_pc_bs(wai_ctx* c, bool spmv, const double* in, double* z, int
                            c->ks.nb_max, dot_mode, list);
       return;
     }
-    // software-pipelined persistent variant: needs a workgroup index below nsub for every
-    // workgroup's partial, i.e. at least as many bricks as workgroups
-    if (!list && spmv && s.pipe && s.diag_only && s.fast3 && J.W == 7 && T <= 512 && !(c->dbg & 3) && s.nsub >= s.pipe_grid) {
-      hipLaunchKernelGGL(k_pc_pipe, s.pipe_grid, T, lds, c->stream, J.n, s.nsub, s.sub_ptr,
-                         s.sub_nlev, s.row_info, J.col, J.val, s.dinv, in, z, aux, c->ks.partials,
-                         c->ks.nb_max, dot_mode, c->dbg >> 2);
-      return;
-    }
   }
   if (spmv) {
-    if (s.diag_only && s.scaled) { if (wp) PCL(true, 2, true); else PCL(true, 2, false); }
-    else if (s.diag_only) { if (wp) PCL(true, 1, true); else PCL(true, 1, false); }
-    else { if (wp) PCL(true, 0, true); else PCL(true, 0, false); }
+    if (s.diag_only && s.scaled) PCL(true, 2);
+    else if (s.diag_only) PCL(true, 1);
+    else PCL(true, 0);
   } else {
-    if (s.diag_only && s.scaled) { if (wp) PCL(false, 2, true); else PCL(false, 2, false); }
-    else if (s.diag_only) { if (wp) PCL(false, 1, true); else PCL(false, 1, false); }
-    else { if (wp) PCL(false, 0, true); else PCL(false, 0, false); }
+    if (s.diag_only && s.scaled) PCL(false, 2);
+    else if (s.diag_only) PCL(false, 1);
+    else PCL(false, 0);
   }
 #undef PCL
 }
 
-int launch_pc(wai_ctx* c, bool spmv, const double* in, double* z, int dot_mode, const double* aux,
-              const int* list, int nrun) {
-  switch (c->J.bs) {
-    case 1: launch_pc_bs<1>(c, spmv, in, z, dot_mode, aux, list, nrun); break;
-    case 2: launch_pc_bs<2>(c, spmv, in, z, dot_mode, aux, list, nrun); break;
-    case 3: launch_pc_bs<3>(c, spmv, in, z, dot_mode, aux, list, nrun); break;
-    case 4: launch_pc_bs<4>(c, spmv, in, z, dot_mode, aux, list, nrun); break;
+int launch_pc_on(wai_ctx* c, const Bcsr& M, const IluSchedule& s, bool spmv, const double* in, double* z,
+                 int dot_mode, const double* aux, const int* list, int nrun) {
+  switch (M.bs) {
+    case 1: launch_pc_bs<1>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun); break;
+    case 2: launch_pc_bs<2>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun); break;
+    case 3: launch_pc_bs<3>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun); break;
+    case 4: launch_pc_bs<4>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun); break;
     default: return -1;
   }
+  c->ks.nb_pc = s.nsub;
+  return 0;
+}
+int launch_pc(wai_ctx* c, bool spmv, const double* in, double* z, int dot_mode, const double* aux,
+              const int* list, int nrun) {
+  return launch_pc_on(c, c->J, c->ilu, spmv, in, z, dot_mode, aux, list, nrun);
+}
+
+int launch_asm_gather_matrix(wai_ctx* c) {
+  const AsmSystem& a = c->as;
+  const size_t tot = (size_t)a.E.W * a.n_ext;
+  hipLaunchKernelGGL(k_asm_gather_matrix, (int)((tot + TPB - 1) / TPB), TPB, 0, c->stream, c->J.n, a.n_ext, a.E.W,
+                     a.E.bs, a.gmap, c->J.val, a.E.val);
+  return 0;
+}
+int launch_asm_gather(wai_ctx* c, const double* r) {
+  const AsmSystem& a = c->as;
+  hipLaunchKernelGGL(k_asm_gather, (a.n_ext + TPB - 1) / TPB, TPB, 0, c->stream, a.n_ext, a.E.bs, a.ext_row, r, a.r_ext);
+  return 0;
+}
+int launch_asm_scatter(wai_ctx* c, double* z) {
+  const AsmSystem& a = c->as;
+  hipLaunchKernelGGL(k_asm_scatter, (a.n_ext + TPB - 1) / TPB, TPB, 0, c->stream, a.n_ext, a.E.bs, a.ext_row, a.r_ext, z);
   return 0;
 }
 
@@ -1496,6 +1432,13 @@ int vec_dot(wai_ctx* c, const double* a, const double* b, int n, int slot) {
   const int g = vgrid(n);
   hipLaunchKernelGGL(k_dot, g, TPB, 0, c->stream, a, b, n, c->ks.partials, c->ks.nb_max, slot);
   return vec_finalize(c, g, slot, 1, -1);
+}
+int vec_dots(wai_ctx* c, const double* a1, const double* b1, int slot1, const double* a2, const double* b2,
+             int slot2, int n) {
+  const int g = vgrid(n);
+  hipLaunchKernelGGL(k_dots, g, TPB, 0, c->stream, a1, b1, slot1, a2, b2, slot2, n, c->ks.partials, c->ks.nb_max);
+  c->ks.nb_pc = g;
+  return 0;
 }
 int vec_copy(wai_ctx* c, double* dst, const double* src, size_t n) {
   return hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream) == hipSuccess ? 0 : -1;

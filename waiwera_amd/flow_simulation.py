@@ -116,11 +116,19 @@ class FlowSimulation:
         for k, v in kw.items():
             if k == "ksp_type" and isinstance(v, str):
                 v = _lib.KSP[v]
+            if k == "pc_type" and isinstance(v, str):
+                v = _lib.PC[v]
             setattr(self.opts, k, v)
         self._chk(LIB.wai_set_opts(self.h, C.byref(self.opts)), "set_opts")
 
     def comm_init(self, rank, nranks, unique_id):
         self._chk(LIB.wai_comm_init(self.h, rank, nranks, unique_id), "comm_init")
+
+    def comm_size(self):
+        return LIB.wai_comm_size(self.h)
+
+    def pc_kernel_name(self):
+        return LIB.wai_pc_kernel_name(self.h).decode()
 
     def set_regions(self, region):
         r = _lib._i32(region)

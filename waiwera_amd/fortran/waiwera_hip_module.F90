@@ -54,6 +54,8 @@ module waiwera_hip_module
      integer(c_int) :: max_newton_its
      real(c_double) :: ftol_rel, ftol_abs, utol_rel, utol_abs, fd_eps, fd_umin
      integer(c_int) :: min_newton_its
+     integer(c_int) :: pc_type        !! 0 bjacobi, 1 asm (restricted), 2 none (timestepper.F90:1745-1757)
+     integer(c_int) :: asm_overlap    !! PETSc default 1
   end type wai_solver_opts
 
   interface

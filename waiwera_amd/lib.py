@@ -17,6 +17,7 @@ RP = {"fully_mobile": 0, "fully mobile": 0, "linear": 1, "pickens": 2, "corey": 
       "van_genuchten": 5, "van genuchten": 5}
 CP = {"zero": 0, "linear": 1, "van_genuchten": 2, "van genuchten": 2}
 KSP = {"bcgs": 0, "gmres": 1}
+PC = {"bjacobi": 0, "asm": 1, "none": 2}   # linear.preconditioner.type (src/timestepper.F90:1745-1757)
 KCLASS = ["eos", "residual", "jacobian", "spmv", "pc_apply", "pc_setup", "vector", "transitions"]
 
 d, i32 = C.c_double, C.c_int
@@ -85,7 +86,7 @@ class SolverOpts(C.Structure):
     _fields_ = [("ksp_type", i32), ("gmres_restart", i32), ("ksp_max_its", i32),
                 ("ksp_rtol", d), ("ksp_atol", d), ("max_newton_its", i32),
                 ("ftol_rel", d), ("ftol_abs", d), ("utol_rel", d), ("utol_abs", d),
-                ("fd_eps", d), ("fd_umin", d), ("min_newton_its", i32)]
+                ("fd_eps", d), ("fd_umin", d), ("min_newton_its", i32), ("pc_type", i32), ("asm_overlap", i32)]
 
 
 class WaiError(RuntimeError):
@@ -122,6 +123,8 @@ def _load():
         "wai_comm_unique_id": (i32, [C.c_char_p]),
         "wai_comm_init": (i32, [vp, i32, i32, C.c_char_p]),
         "wai_halo_exchange": (i32, [vp, vp, i32]),
+        "wai_comm_size": (i32, [vp]),
+        "wai_pc_kernel_name": (C.c_char_p, [vp]),
         "wai_pre_timestep": (i32, [vp]),
         "wai_pre_retry_timestep": (i32, [vp]),
         "wai_pre_iteration": (i32, [vp]),
@@ -196,6 +199,8 @@ def default_opts(**kw):
     for k, v in kw.items():
         if k == "ksp_type" and isinstance(v, str):
             v = KSP[v]
+        if k == "pc_type" and isinstance(v, str):
+            v = PC[v]
         setattr(o, k, v)
     return o
 

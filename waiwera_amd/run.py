@@ -21,6 +21,9 @@ def main(argv=None):
     print("finished at t = %.6e s after %d steps" % (out["time"], sim.ts.taken))
     if a.output:
         sim.save(a.output)
+    if sim.output_error is not None:
+        print("error: output file not written: %s" % sim.output_error, file=sys.stderr)
+        return 1
     return 0
 
 

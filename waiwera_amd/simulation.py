@@ -119,7 +119,11 @@ def zone_cells(zone, centroids):
 class Simulation:
     """One Waiwera input file -> mesh, flow simulation object and time stepper."""
 
-    def __init__(self, inp, base_dir=".", ode_factory=None, device=0, mesh_builder=None, mesh_file=None):
+    def __init__(self, inp, base_dir=".", ode_factory=None, device=0, mesh_builder=None, mesh_file=None,
+                 output_dir=None):
+        # output files go to output_dir (default: $WAIWERA_OUTPUT_DIR, else beside the input file)
+        self.output_dir = output_dir or os.environ.get("WAIWERA_OUTPUT_DIR") or base_dir
+        self.output_error = None
         self.inp = inp
         self.base_dir = base_dir
         mesh = inp.get("mesh")
@@ -332,6 +336,19 @@ class Simulation:
             raise NotImplementedError("linear solver type %r" % lin["type"])
         if _get(lin, "tolerance.relative") is not None:
             opts["ksp_rtol"] = lin["tolerance"]["relative"]
+        if _get(lin, "maximum.iterations") is not None:
+            opts["ksp_max_its"] = lin["maximum"]["iterations"]
+        if _get(lin, "options.gmres.restart") is not None:
+            opts["gmres_restart"] = lin["options"]["gmres"]["restart"]
+        # preconditioner (src/timestepper.F90:1745-1757, default "asm"); "ilu" of a serial run is the
+        # one-block case of either.  Only the ILU(0) sub-preconditioner exists here.
+        pct = (_get(lin, "preconditioner.type") or "asm").lower()
+        if pct not in ("asm", "bjacobi", "ilu", "none"):
+            raise NotImplementedError("preconditioner type %r" % pct)
+        opts["pc_type"] = {"ilu": "bjacobi"}.get(pct, pct)
+        sub = _get(lin, "preconditioner.sub.preconditioner", {}) or {}
+        if (sub.get("type") or "ilu").lower() != "ilu" or (_get(sub, "factor.levels") or 0) != 0:
+            raise NotImplementedError("sub-preconditioner %r" % (sub,))
         if opts:
             self.ode.set_opts(**opts)
         # tracers
@@ -526,20 +543,25 @@ class Simulation:
         freq, self.outputs = oc.get("frequency", 1), []
         if oc.get("initial", True):
             self.outputs.append(self.fields())
-        while not self.ts.finished:
-            self.ts.step()
-            hit = self.ts.checkpoint_hit
-            if hit or (freq and self.ts.taken % freq == 0) or (self.ts.finished and oc.get("final", True)):
-                self.outputs.append(self.fields())
-            if hit:
-                self.ts.checkpoint_update()
-        out = self.fields()
-        if oc.get("filename"):
-            try:
-                self.save_hdf5(os.path.join(self.base_dir, oc["filename"]))
-            except Exception as e:   # no HDF5 library, read-only directory: results are still returned
-                self.output_error = e
-        return out
+        try:
+            while not self.ts.finished:
+                self.ts.step()
+                hit = self.ts.checkpoint_hit
+                if hit or (freq and self.ts.taken % freq == 0) or (self.ts.finished and oc.get("final", True)):
+                    self.outputs.append(self.fields())
+                if hit:
+                    self.ts.checkpoint_update()
+        finally:
+            # the reference keeps what it has written when a step aborts; a file that cannot be written
+            # is reported, not swallowed (the results are still returned)
+            if oc.get("filename") and self.outputs:
+                try:
+                    self.save_hdf5(os.path.join(self.output_dir, oc["filename"]))
+                except Exception as e:
+                    self.output_error = e
+                    import sys
+                    print("waiwera_amd: output file %r not written: %s" % (oc["filename"], e), file=sys.stderr)
+        return self.fields()
 
     def save_hdf5(self, path):
         """the collected outputs in the reference's layout: /time, /cell_index, /cell_fields/*,

@@ -85,6 +85,9 @@ class Timestepper:
         self.checkpoints = sorted(float(t) for t in (checkpoints or []))
         self.checkpoint_tol = max(checkpoint_tolerance, 1.0e-6)
         self.checkpoint_index, self.checkpoint_hit, self._restore_stepsize = 0, False, None
+        # timestepper_checkpoints_init (:884-887): checkpoints before the start time are passed over
+        while self.checkpoint_index < len(self.checkpoints) and self.checkpoints[self.checkpoint_index] < time:
+            self.checkpoint_index += 1
         # callable(interval) run before each try: time-dependent controls averaged over the step
         # interval [t, t + dt] (the interval argument of the reference's lhs / rhs calls,
         # src/timestepper.F90 ode%rhs(t, interval, ...); src/flow_simulation.F90:1469)
@@ -139,7 +142,7 @@ class Timestepper:
         if self.steady_state or self.checkpoint_index >= len(self.checkpoints):
             return stepsize
         nxt = self.checkpoints[self.checkpoint_index]
-        if self.time + stepsize + self.checkpoint_tol * stepsize >= nxt:
+        if self.time + stepsize + self.checkpoint_tol * stepsize >= nxt and nxt > self.time:
             self.checkpoint_hit = True
             self._restore_stepsize = stepsize
             return nxt - self.time
@@ -224,17 +227,19 @@ class Timestepper:
         if self.fixed:
             return True, self.sizes[-1]
         self.adaptor.on = True
+        if self.checkpoint_hit:                                  # :1400-1401
+            return True, self._restore_stepsize
         return self._adapt(stepsize)
 
     def _set_next_stepsize(self, stepsize):
         """set_next_stepsize (:1412-1453)."""
         if self.steady_state:
             return True
-        if self.checkpoint_hit and self.status == RESTORE:      # :1400-1401, :1423-1425
-            self.next_stepsize = self._restore_stepsize
-            return True
         if self.adaptor.on:
-            accepted, nxt = self._adapt(stepsize)
+            if self.checkpoint_hit:                              # :1423-1425
+                accepted, nxt = True, self._restore_stepsize
+            else:
+                accepted, nxt = self._adapt(stepsize)
             n = len(self.sizes)
             if self.fixed_step_index < n or (self.fixed_step_index >= n and self.fixed):
                 if nxt >= self.sizes[self.fixed_step_index - 1]:
