@@ -112,7 +112,7 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
     diag[i] = (int)(std::lower_bound(row, row + (rowptr[i + 1] - rowptr[i]), i) - row);
   }
   std::vector<int> info(N), uoff(N, 0), levf(N), levb(N), nlev(s.nsub, 0), lfirst(N), ulast(N);
-  s.max_rows = 0; s.max_lev = 0; s.max_ublocks = 0;
+  s.max_rows = 0; s.max_lev = 0; s.max_ublocks = 0; s.max_nlu = 0;
   bool offdiag_fill = false, fast3 = true;
   int nlf_all = 0, nlb_all = 0;
   for (int sd = 0; sd < s.nsub; sd++) {
@@ -157,6 +157,7 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
     for (int i = lo; i < hi; i++) {
       const int nL = diag[i] - lfirst[i], nU = ulast[i] - diag[i] - 1;
       if (nL > 3 || nU > 3 || lfirst[i] > 3 || diag[i] > 3) fast3 = false;
+      s.max_nlu = std::max(s.max_nlu, std::max(nL, nU));
       uoff[i] = ucount;
       ucount += std::min(nU, 3);
     }
@@ -209,6 +210,14 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
     // 160 KB of LDS per CU; a workgroup may use 64 KB
     const size_t need = ((size_t)(((s.max_rows + 63) / 64) * 64) * np + 32 + (size_t)s.max_ublocks * 4) * sizeof(double);
     s.park = !(e && e[0] == '0') && need <= 64 * 1024;  // default on; WAI_PC_PARK=0: k_pc
+  }
+  {
+    // one thread per scalar row: needs the pivot-scaled DILU form, <= 4 + 4 couplings and a brick whose
+    // scalar rows fit one workgroup.  Default for block sizes 3 and 4, where a whole block row per
+    // thread does not fit the register file; WAI_PC_ROWS=0 / 1 forces it off / on (bs <= 2 too).
+    const char* e = getenv("WAI_PC_ROWS");
+    const bool can = s.diag_only && s.scaled && !s.big && s.max_nlu <= 4 && s.max_rows * np <= 1024 && W <= 8;
+    s.rows_kernel = can && (e ? e[0] == '1' : np >= 3);
   }
   s.built = true;
   s.factored = false;
@@ -1716,6 +1725,7 @@ const char* wai_pc_kernel_name(wai_ctx* c) {
   if (c->opts.pc_type == WAI_PC_NONE) return "k_spmv (no preconditioner)";
   if (c->opts.pc_type == WAI_PC_ASM) return c->as.sched.big ? "k_spmv + k_lvl_solve per level (ASM, extended system)" : "k_spmv + k_pc on the extended ASM system";
   if (s.big) return "k_spmv + k_lvl_solve per level";
+  if (s.rows_kernel) { static thread_local char b2[64]; snprintf(b2, sizeof(b2), "k_pc_rows<%d,spmv,%d+%d>", c->J.bs, s.max_nlu <= 3 ? 3 : 4, s.max_nlu <= 3 ? 3 : 4); return b2; }
   if (c->J.bs == 2 && s.park && s.diag_only && s.scaled && s.fast3 && s.max_rows <= 512) return "k_pc_park<spmv>";
   static thread_local char buf[96];
   snprintf(buf, sizeof(buf), "k_pc<%d,spmv,%s,%s>", c->J.bs, s.diag_only ? (s.scaled ? "dilu-scaled" : "dilu") : "ilu",

@@ -874,6 +874,142 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
   }
 }
 
+// ---- K6+K8 fused, one thread per SCALAR row (any block size; pivot-scaled DILU) ---------------
+// With the rows pre-scaled by the inverted pivots the diagonal blocks of the factor are identities,
+// so the BS components of a block row no longer depend on each other inside a substitution level:
+//   y_i[r] = t_i[r] - sum_p L_p[r][:] . y_p[:]          x_i[r] = y_i[r] - sum_p U_p[r][:] . x_p[:]
+// Thread (i, r) therefore owns block-row r of every block of row i: NL + NU rows of BS doubles stay in
+// registers through both sweeps (3 x 3 blocks, 3 + 3 couplings: 36 VGPRs instead of the 108 a whole
+// block row costs, which is what pushed the one-thread-per-block-row kernel into scratch memory for
+// bs = 3, 4: MEASURED 3.25 ms at 5 M rows, 12 % of HBM peak), nothing is parked in LDS, and a
+// workgroup of up to 16 waves per brick keeps the loads of 2 bricks (32 waves) in flight per CU.
+// Threads are component-major (tid = r * R + row), so a wave instruction reads 64 consecutive
+// BS-vectors of one (slot, r) plane.  Vectors move through LDS in block order: the result is written
+// (and the dot-product partners are read) with tid-linear, fully coalesced accesses.
+// registers: 58 (bs 2), 69 (bs 3), 90 (bs 4) without spills -> 8 / 7 / 5 waves per SIMD; asking for 8
+// everywhere spills 150-600 registers at bs = 3, 4
+template <int BS, bool SPMV, int NL, int NU>
+__global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? 7 : 5))) void k_pc_rows(
+    int n, int W, int nsub, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev,
+    const int* __restrict__ row_info, const int* __restrict__ col, const double* __restrict__ sval,
+    const double* __restrict__ dinv, const double* __restrict__ in, double* __restrict__ z,
+    const double* __restrict__ aux, double* partials, int nb_max, int dot, const int* __restrict__ sub_list) {
+  extern __shared__ double lds[];  // [R*BS] solution in block order, [BS] zeros, then reduction scratch
+  int s = xcd_remap(blockIdx.x, nsub);
+  if (s >= nsub) return;
+  if (sub_list) s = sub_list[s];
+  const int lo = sub_ptr[s], R = sub_ptr[s + 1] - lo;
+  const int nl = sub_nlev[s];
+  const int nlf = nl & 0xffff, nlb = nl >> 16;
+  const int tid = threadIdx.x;
+  const int r = tid / R, il = tid - r * R, i = lo + il;
+  const bool active = tid < R * BS;
+  double* ys = lds;
+  double Lf[NL][BS], Uf[NU][BS];
+  int Lc[NL], Uc[NU], lf = -1, lb = -1;
+#pragma unroll
+  for (int p = 0; p < NL; p++) {
+    Lc[p] = R * BS;  // the zero entries behind the vector
+#pragma unroll
+    for (int k = 0; k < BS; k++) Lf[p][k] = 0.0;
+  }
+#pragma unroll
+  for (int p = 0; p < NU; p++) {
+    Uc[p] = R * BS;
+#pragma unroll
+    for (int k = 0; k < BS; k++) Uf[p][k] = 0.0;
+  }
+  if (tid < BS) ys[R * BS + tid] = 0.0;
+  if (active) {
+    int lfirst, dslot, ulast;
+    unpack_info(row_info[i], lfirst, dslot, ulast, lf, lb);
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < WMAX; q++) {
+      if (q < W) {
+        const int cg = load_col(col, (size_t)q * n + i);
+        double blk[BS];
+        const double* src = sval + ((size_t)(q * BS + r) * n + i) * BS;
+#pragma unroll
+        for (int k = 0; k < BS; k++) blk[k] = __builtin_nontemporal_load(src + k);
+        if constexpr (SPMV) {
+          double xv[BS];
+          load_x<BS>(in, cg, xv);
+#pragma unroll
+          for (int k = 0; k < BS; k++) acc += blk[k] * xv[k];
+        }
+        const bool isl = (q >= lfirst) && (q < dslot), isu = (q > dslot) && (q < ulast);
+#pragma unroll
+        for (int p = 0; p < NL; p++) {
+          const bool tl = isl && (q - lfirst == p);
+          Lc[p] = tl ? (cg - lo) * BS : Lc[p];
+#pragma unroll
+          for (int k = 0; k < BS; k++) Lf[p][k] = tl ? blk[k] : Lf[p][k];
+        }
+#pragma unroll
+        for (int p = 0; p < NU; p++) {
+          const bool tu = isu && (q - dslot - 1 == p);
+          Uc[p] = tu ? (cg - lo) * BS : Uc[p];
+#pragma unroll
+          for (int k = 0; k < BS; k++) Uf[p][k] = tu ? blk[k] : Uf[p][k];
+        }
+      }
+    }
+    if constexpr (!SPMV) {  // plain application to an unscaled vector: scale it by the inverted pivot
+      const double* dv = dinv + ((size_t)r * n + i) * BS;
+#pragma unroll
+      for (int k = 0; k < BS; k++) acc += dv[k] * in[(size_t)i * BS + k];
+    }
+    ys[il * BS + r] = acc;
+  }
+  __syncthreads();
+  for (int lev = 1; lev < nlf; lev++) {  // forward: y_i = t_i - sum A'_ik y_k
+    if (lf == lev) {
+      double a = ys[il * BS + r];
+#pragma unroll
+      for (int p = 0; p < NL; p++)
+#pragma unroll
+        for (int k = 0; k < BS; k++) a -= Lf[p][k] * ys[Lc[p] + k];
+      ys[il * BS + r] = a;
+    }
+    __syncthreads();
+  }
+  for (int lev = 0; lev < nlb; lev++) {  // backward: x_i = y_i - sum A'_ij x_j
+    if (lb == lev) {
+      double a = ys[il * BS + r];
+#pragma unroll
+      for (int p = 0; p < NU; p++)
+#pragma unroll
+        for (int k = 0; k < BS; k++) a -= Uf[p][k] * ys[Uc[p] + k];
+      ys[il * BS + r] = a;
+    }
+    __syncthreads();
+  }
+  // block-order, tid-linear epilogue: store the result, reduce the dot products
+  double out = 0.0;
+  const size_t g = (size_t)lo * BS + tid;
+  if (active) {
+    out = ys[tid];
+    __builtin_nontemporal_store(out, z + g);
+  }
+  if (dot != 0) {
+    double* red = lds + (size_t)R * BS + BS;
+    double v[2] = {0.0, 0.0};
+    int slots[2] = {S_D1, S_D2};
+    if (dot == 1) {
+      if (active) v[0] = out * __builtin_nontemporal_load(aux + g);
+    } else if (dot == 2) {
+      if (active) { v[0] = (SPMV ? in : aux)[g] * out; v[1] = out * out; }
+    } else {
+      v[0] = out * out;
+      slots[0] = S_DP2;
+    }
+    __syncthreads();
+    if (dot == 2) wg_reduce_store<2>(v, red, partials, nb_max, slots, s);
+    else { double v1[1] = {v[0]}; wg_reduce_store<1>(v1, red, partials, nb_max, slots, s); }
+  }
+}
+
 // ---- layout conversion (C ABI exchanges BCSR) -------------------------------------------------
 __global__ __launch_bounds__(TPB) void k_ell_to_bcsr(int n, int W, int bs, const int* __restrict__ rowptr,
                                                      const double* __restrict__ ell, double* __restrict__ bcsr) {
@@ -1346,6 +1482,19 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
                          nrun, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.fval,          \
                          s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, c->dbg, list); \
   } while (0)
+  // one thread per scalar row: block sizes 3 and 4 (and 2 when asked for: WAI_PC_ROWS=1)
+  if (s.rows_kernel && !c->dbg) {
+    const int TR = ((s.max_rows * BS + 63) / 64) * 64;
+    const size_t lds_r = ((size_t)s.max_rows * BS + BS + 2 * 16 + 8) * sizeof(double);
+#define PCR(SP, NLU)                                                                               \
+    hipLaunchKernelGGL((k_pc_rows<BS, SP, NLU, NLU>), grid, TR, lds_r, c->stream, J.n, J.W, nrun, s.sub_ptr,  \
+                       s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, \
+                       dot_mode, list)
+    if (s.max_nlu <= 3) { if (spmv) PCR(true, 3); else PCR(false, 3); }
+    else { if (spmv) PCR(true, 4); else PCR(false, 4); }
+#undef PCR
+    return;
+  }
   if constexpr (BS == 2) {
     // upper blocks parked in LDS: three resident workgroups per CU
     if (s.park && s.diag_only && s.scaled && s.fast3 && T <= 512 && !c->dbg) {
