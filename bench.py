@@ -337,10 +337,11 @@ def main():
     if a.minc:
         cfg["minc"] = True
     dims, eos, minc = tuple(cfg["dims"]), cfg["eos"], cfg["minc"]
-    # bricks: wide in x, y, thin in z (k_z = 0.1 k_x).  3 x 3 blocks run one thread per scalar row, two
-    # 14-wave workgroups per CU: 288 block rows per brick; with a MINC level the matrix cells join their
-    # fracture cell's brick, so the fracture bricks are half as large
-    brick = tuple(a.brick) if a.brick else ((12, 12, 1) if minc else ((12, 12, 2) if eos == "wce" else (16, 16, 2)))
+    # bricks: wide in x, y, thin in z (k_z = 0.1 k_x).  3 x 3 blocks run one thread per scalar row: 256
+    # block rows = 12 waves per brick, two bricks per CU (MEASURED at 172x172x170: 16x8x2 0.846 ms per
+    # fused launch, 12x12x2 -- 13.5 waves, one brick per CU -- 1.319 ms); with a MINC level the matrix
+    # cells join their fracture cell's brick, so the fracture bricks are half as large
+    brick = tuple(a.brick) if a.brick else ((16, 8, 1) if minc else ((16, 8, 2) if eos == "wce" else (16, 16, 2)))
     grid, lm, prim, region = make_case(dims=dims, brick=brick, eos=eos, lens=not a.no_lens, minc=minc,
                                        part=M.partition_shape(world), rank=rank)
     opts = wl.default_opts(ksp_type=a.ksp, pc_type=a.pc)

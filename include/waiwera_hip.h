@@ -174,6 +174,9 @@ int wai_comm_unique_id(char id[128]);                       /* rank 0, then broa
 int wai_comm_init(wai_ctx *ctx, int rank, int nranks, const char id[128]);
 int wai_halo_exchange(wai_ctx *ctx, double *vec, int dof);  /* vec has dof*(n_owned+n_halo) */
 int wai_comm_size(wai_ctx *ctx);   /* ranks the RCCL communicator reports (1 without one) */
+/* collectives enqueued on this rank so far: all-reduces (Krylov inner products, flags, norms) and
+ * neighbour exchanges (halos); a BiCGStab iteration costs 2 all-reduces and 2 exchanges */
+int wai_comm_stats(wai_ctx *ctx, long long *allreduces, long long *exchanges);
 
 /* ---- ode_type surface (src/ode.F90:39-108 as overridden by src/flow_simulation.F90) ------ */
 int wai_pre_timestep(wai_ctx *ctx);                 /* flow_simulation.F90:2022-2035 */

@@ -61,7 +61,14 @@ def _worker(rank, world, uid_q, q):
     sim.comm_init(rank, world, uid)
     y = scaled(prim, region).ravel().copy()
     hist = _run_steps(sim, y)
-    q.put((rank, lm.owned_gid.copy(), y[: lm.n_owned * 2].copy(), hist, sim.regions()[: lm.n_owned].copy()))
+    # collectives of one Krylov solve: 2 all-reduces per BiCGStab iteration (+ a constant)
+    a0, e0 = sim.comm_stats()
+    n = lm.n_owned * 2
+    b, x = np.ones(n), np.zeros(n)
+    kits, kreason, _ = sim.ksp_solve(b, x)
+    a1, e1 = sim.comm_stats()
+    q.put((rank, lm.owned_gid.copy(), y[: lm.n_owned * 2].copy(), hist, sim.regions()[: lm.n_owned].copy(),
+           (kits, a1 - a0, e1 - e0)))
     sim.destroy()
 
 
@@ -102,7 +109,11 @@ def test_ranks_sharing_one_gpu_match_one_rank(world):
     rser[lm.owned_gid] = sim.regions()[: lm.n_owned]
     sim.destroy()
     ypar, rpar = np.zeros((g.n_global, 2)), np.zeros(g.n_global, dtype=int)
-    for rank, gid, yy, h, reg in res:
+    for rank, gid, yy, h, reg, (kits, n_ar, n_ex) in res:
+        # per BiCGStab iteration: (V,RP), then the five merged inner products; the speculative first half
+        # of an iteration that is then not needed adds one; set-up adds (R,R)
+        assert kits > 0 and n_ar <= 2 * kits + 4, (kits, n_ar)
+        assert n_ex <= 2 * kits + 4, (kits, n_ex)
         ypar[gid] = yy.reshape(-1, 2)
         rpar[gid] = reg
         assert all(r > 0 for r, _, _ in h)
@@ -136,7 +147,7 @@ def test_bench_as_the_driver_launches_it(world, dims, brick, part):
     env = dict(os.environ, WAI_RCCL_LIB=LOOPBACK, WAI_BENCH_LOOPBACK="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-           "--gpus", str(world), "--steps", "2", "--warmup", "1", "--dims"] + [str(v) for v in dims] + \
+           "--gpus", str(world), "--steps", "2", "--warmup", "1", "--lead", "1", "--window", "2", "--dims"] + [str(v) for v in dims] + \
           ["--brick"] + [str(v) for v in brick] + ["--spmv-reps", "3", "--no-cpu"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -146,3 +157,20 @@ def test_bench_as_the_driver_launches_it(world, dims, brick, part):
     assert out["n_gpus"] == world and out["steps"] == 2 and out["value"] > 0
     assert out["config"]["partition"] == part
     assert out["config"]["krylov_iterations_per_newton_step"] > 0
+
+
+@pytest.mark.timeout(1200)
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher, as the driver calls it: bench.py starts the two
+    ranks itself (here on the loopback, both on cuda:0)"""
+    env = dict(os.environ, WAI_RCCL_LIB=LOOPBACK, WAI_BENCH_LOOPBACK="1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--lead", "1",
+           "--window", "2", "--dims", "32", "32", "16", "--brick", "8", "8", "2", "--spmv-reps", "3", "--no-cpu"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["partition"] == "2x1x1" and out["value"] > 0

@@ -259,7 +259,9 @@ def test_minc_dual_porosity(FS, oracle, eos):
         assert (reason > 0) == (r > 0)
         if reason > 0:
             converged += 1
-            assert nits == r and np.array_equal(sim.regions(), osim.regions())
+            # the wce case converges on the edge of the function tolerance: one Newton iteration more or
+            # less with the reduction order (also between oracle thread counts); the states agree
+            assert abs(nits - r) <= (1 if eos == "wce" else 0) and np.array_equal(sim.regions(), osim.regions())
             assert relmax(yg, yo[: yg.size]) < 1e-7
         dt *= 2
     assert converged == 3

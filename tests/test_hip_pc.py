@@ -124,3 +124,20 @@ def test_time_step_with_asm_matches_the_oracle(oracle):
     assert relmax(y, yo[: y.size]) < 1e-7
     assert np.array_equal(sim.regions(), osim.regions())
     sim.destroy(); osim.close()
+
+
+@pytest.mark.parametrize("eos,brick", [("we", (4, 4, 2)), ("wce", (4, 4, 2))])
+def test_bicgstab_with_merged_reductions(oracle, eos, brick, monkeypatch):
+    """the form ranks > 1 run -- (S,T), (T,T), (S,S), (S,RP), (T,RP) in one reduction, (R,R) and (R,RP)
+    derived from them -- forced onto one rank: same solution as the oracle's KSPBCGS, iteration
+    count within rounding"""
+    monkeypatch.setenv("WAI_BCGS_MERGED", "1")
+    lm, sim, osim, J, f = system(oracle, eos, (8, 8, 6), brick, lens=(eos == "we"))
+    n = sim.num_dof
+    sim.set_opts(ksp_rtol=1e-12)
+    x = np.zeros(n)
+    its, reason, rn = sim.ksp_solve(f, x)
+    oreason, xo, oits, hist = osim.ksp_solve(J, f, rtol=1e-12)
+    assert reason > 0 and oreason > 0
+    assert relmax(x, xo) < 1e-8 and abs(its - oits) <= max(2, oits // 10)
+    sim.destroy(); osim.close()

@@ -1,12 +1,14 @@
-"""profiles/pmc_traffic_r1.json from the two PMC summaries of tools/gpu_profile_r1.sh
-(rocprof_pmc_fetch_r1.txt, rocprof_pmc_write_r1.txt: `kernel | counter | dispatches | avg | ...`,
-KiB per dispatch).  HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE (gfx950 correction of
-MI355X_MICROARCH.md, calibrated on k_bcgs_p: 3 vectors read, 1 written)."""
-import json
-import sys
+"""pmc_traffic_<tag>.json from the two PMC summaries of tools/gpu_profile.sh
+(rocprof_pmc_fetch_<tag>.txt, rocprof_pmc_write_<tag>.txt: `kernel | counter | dispatches | avg | ...`,
+KiB per dispatch) and the bench line of the same run (algorithmic bytes).  HBM bytes =
+2 * FETCH_SIZE + WRITE_SIZE (gfx950 correction of MI355X_MICROARCH.md, calibrated on k_bcgs_p:
+3 vectors read, 1 written).
 
-sys.path.insert(0, ".")
-from bench import pc_bytes, spmv_bytes  # noqa: E402
+    python tools/pmc_traffic.py <dir> <tag> <out.json>
+"""
+import json
+import re
+import sys
 
 
 def table(path):
@@ -18,34 +20,42 @@ def table(path):
     return out
 
 
-def main(src="gpurun_out", dst="profiles/pmc_traffic_r1.json", dims=(216, 216, 216), brick=(16, 16, 2)):
-    fe, wr = table(src + "/rocprof_pmc_fetch_r1.txt"), table(src + "/rocprof_pmc_write_r1.txt")
+def main(src, tag, dst):
+    fe, wr = table("%s/rocprof_pmc_fetch_%s.txt" % (src, tag)), table("%s/rocprof_pmc_write_%s.txt" % (src, tag))
+    bench = json.load(open("%s/bench_%s.json" % (src, tag)))
+    roof = bench["roofline"]
 
     def hbm(k):
         return 2.0 * fe[k] * 1024.0 + wr[k] * 1024.0
-    n = dims[0] * dims[1] * dims[2]
-    nnzb = 7 * n - 2 * (dims[0] * dims[1] + dims[1] * dims[2] + dims[0] * dims[2])
-    b_pc, b_spmv = pc_bytes(nnzb, n, 2), spmv_bytes(nnzb, n, 2)
-    pc = [k for k in fe if k.startswith("void wai::k_pc_park<true")][0]
-    sp = "void wai::k_spmv<2>"
+
+    def find(pat):
+        ks = [k for k in fe if re.search(pat, k) and k in wr]
+        return max(ks, key=lambda k: fe[k]) if ks else None
+    m = re.search(r"(\d+)x(\d+)x(\d+) structured", bench["config"]["workload"])
+    dims = [int(v) for v in m.groups()]
+    mb = re.search(r"\((\d+)x(\d+)x(\d+) bricks\)", bench["config"]["workload"])
+    brick = [int(v) for v in mb.groups()]
+    pc = find(r"k_pc_park<true|k_pc_rows<\d, true|k_pc<\d, true")
+    sp = find(r"k_spmv<")
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python "
-                     "bench.py --steps 1 --warmup 0 --no-cpu --spmv-reps 10 on 1 x MI355X, %dx%dx%d eos_we, bricks %dx%dx%d"
-                     % (dims + brick),
+                     "bench.py --config ... --lead 1 --steps 1 --warmup 0 --no-cpu --spmv-reps 10 on 1 x MI355X; " +
+                     bench["config"]["workload"],
            "correction": "HBM bytes = 2*FETCH_SIZE[KiB]*1024 + WRITE_SIZE[KiB]*1024 (gfx950: FETCH_SIZE tallies 128-B "
-                         "requests at 64 B; calibrated on k_bcgs_p: 3 vectors read = 483.7 MB -> 2*%.0f KiB; 1 vector "
-                         "written = 161.2 MB -> %.0f KiB)" % (fe["wai::k_bcgs_p"], wr["wai::k_bcgs_p"]),
-           "dims": list(dims), "brick": list(brick),
-           "k_pc_hbm_bytes_per_launch": hbm(pc), "k_pc_algorithmic_bytes": b_pc,
-           "k_pc_traffic_over_algorithmic": hbm(pc) / b_pc,
-           "k_spmv_hbm_bytes_per_launch": hbm(sp), "k_spmv_algorithmic_bytes": b_spmv,
-           "k_spmv_traffic_over_algorithmic": hbm(sp) / b_spmv,
-           "k_bcgs_p_hbm_bytes_per_launch": hbm("wai::k_bcgs_p"),
-           "k_jacobian_hbm_bytes_per_launch": hbm("void wai::k_jacobian<1>"),
-           "k_residual_hbm_bytes_per_launch": hbm("void wai::k_residual<1>"),
-           "note": "k_pc = k_pc_park<spmv> (pivot-scaled rows, upper blocks parked in LDS)"}
+                         "requests at 64 B; calibrated on k_bcgs_p: 3 vectors read -> 2*%.0f KiB; 1 vector written -> "
+                         "%.0f KiB)" % (fe.get("wai::k_bcgs_p", 0.0), wr.get("wai::k_bcgs_p", 0.0)),
+           "dims": dims, "brick": brick, "k_pc_kernel": pc,
+           "k_pc_hbm_bytes_per_launch": hbm(pc), "k_pc_algorithmic_bytes": roof["algorithmic_bytes_per_launch"],
+           "k_pc_traffic_over_algorithmic": hbm(pc) / roof["algorithmic_bytes_per_launch"],
+           "k_spmv_hbm_bytes_per_launch": hbm(sp), "k_spmv_algorithmic_bytes": roof["spmv"]["algorithmic_bytes_per_launch"],
+           "k_spmv_traffic_over_algorithmic": hbm(sp) / roof["spmv"]["algorithmic_bytes_per_launch"]}
+    for name, pat in (("k_bcgs_p", r"k_bcgs_p"), ("k_jacobian", r"k_jacobian"), ("k_residual", r"k_residual"),
+                      ("k_eos_pert", r"k_eos_pert")):
+        k = find(pat)
+        if k:
+            out[name + "_hbm_bytes_per_launch"] = hbm(k)
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
-    main()
+    main(*sys.argv[1:4])

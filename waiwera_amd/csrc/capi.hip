@@ -426,6 +426,11 @@ int pc_dots(wai_ctx* c, int dot_mode, const double* x, const double* z, const do
   const int n = c->ks.n;
   if (dot_mode == 1) return vec_dots(c, z, aux, S_D1, nullptr, nullptr, 0, n);
   if (dot_mode == 2) return vec_dots(c, x, z, S_D1, z, z, S_D2, n);
+  if (dot_mode == 4) {   // merged BiCGStab reductions: (x,z), (z,z), (x,x), (x,aux), (z,aux)
+    vec_dots(c, x, z, S_D1, z, z, S_D2, n);
+    vec_dots(c, x, x, S_DP2, x, aux, S_RHONEW, n);
+    return vec_dots(c, z, aux, S_W2, nullptr, nullptr, 0, n);
+  }
   if (dot_mode == 3) return vec_dots(c, z, z, S_DP2, nullptr, nullptr, 0, n);
   return 0;
 }
@@ -527,20 +532,29 @@ int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, doub
     return 0;
   };
   const bool speculate = getenv("WAI_BCGS_NO_SPECULATION") == nullptr;
+  // More than one rank: the second half's five inner products travel in ONE all-reduce -- (S,T), (T,T)
+  // for omega and (S,S), (S,RP), (T,RP), from which (R,R) and (R,RP) of R = S - omega T follow -- so an
+  // iteration costs two all-reduces ((V,RP); these five) instead of three.  On one rank the
+  // reductions stay where KSPSolve_BCGS has them (WAI_BCGS_MERGED=1 forces the merged form: tests).
+  const bool merged = multi || getenv("WAI_BCGS_MERGED") != nullptr;
   bool have_first_half = false;
   for (int i = 0; i < maxits && !*reason && !rc; i++) {
     if (!have_first_half && (rc = first_half())) break;
     have_first_half = false;
-    if ((rc = pc_amul(c, k.S, k.T, 2, nullptr))) break;
+    if ((rc = pc_amul(c, k.S, k.T, merged ? 4 : 2, merged ? k.RP : nullptr))) break;
     {
       Prof p(c, KC_VECTOR);
-      vec_finalize(c, k.nb_pc, S_D1, 2, multi ? -1 : 3);
-      if (multi) { if ((rc = allreduce_scal(c, S_D1, 2))) break; bcgs_scalars(c, 3); }
-      bcgs_update_xr(c);
-      vec_finalize(c, k.nblocks, S_DP2, 2, multi ? -1 : 4);
-      if (multi) {  // (R,R) and (R,RP) sit in adjacent slots: one 16-byte all-reduce
-        if ((rc = allreduce_scal(c, S_DP2, 2))) break;
+      if (merged) {
+        vec_finalize(c, k.nb_pc, S_D1, 4, -1);
+        vec_finalize(c, k.nb_pc, S_W2, 1, -1);
+        if (multi && (rc = allreduce_scal(c, S_D1, 5))) break;
+        bcgs_scalars(c, 5);
+        bcgs_update_xr(c, false);
         bcgs_scalars(c, 4);
+      } else {
+        vec_finalize(c, k.nb_pc, S_D1, 2, 3);
+        bcgs_update_xr(c);
+        vec_finalize(c, k.nblocks, S_DP2, 2, 4);
       }
     }
     if (speculate && i + 1 < maxits) {
@@ -1733,6 +1747,12 @@ const char* wai_pc_kernel_name(wai_ctx* c) {
   return buf;
 }
 int wai_comm_size(wai_ctx* c) { return c ? comm_count(c->comm) : -2; }
+int wai_comm_stats(wai_ctx* c, long long* allreduces, long long* exchanges) {
+  if (!c) return -2;
+  if (allreduces) *allreduces = c->comm ? c->comm->n_allreduce : 0;
+  if (exchanges) *exchanges = c->comm ? c->comm->n_exchange : 0;
+  return 0;
+}
 
 int wai_timer_start(wai_ctx* c) { if (!c) return -2; HIPCHK(c, hipEventRecord(c->ev0, c->stream)); return 0; }
 int wai_timer_stop(wai_ctx* c, float* ms) {

@@ -10,6 +10,7 @@ struct NcclId { char internal[128]; };  // ncclUniqueId
 struct Comm {
   void* handle = nullptr;  // ncclComm_t
   int rank = 0, nranks = 1;
+  long long n_allreduce = 0, n_exchange = 0;   // collectives enqueued so far (tests, reports)
 };
 
 int comm_unique_id(char id[128], std::string& err);

@@ -257,7 +257,7 @@ int vec_waxpy(wai_ctx* c, double* w, double alpha, const double* x, const double
 int bcgs_scalars(wai_ctx* c, int phase);
 int bcgs_update_p(wai_ctx* c);
 int bcgs_update_s(wai_ctx* c);
-int bcgs_update_xr(wai_ctx* c);   // leaves partials in S_DP2, S_RHONEW; returns #blocks via ks.nblocks
+int bcgs_update_xr(wai_ctx* c, bool dots = true);   // dots: leaves partials in S_DP2, S_RHONEW; #blocks via ks.nblocks
 int gmres_mdot(wai_ctx* c, const double* w, int k);          // scal[16+i] = (w, v_i), i<k
 int gmres_maxpy_norm(wai_ctx* c, double* w, int k);          // w -= sum h_i v_i ; scal[8] = |w|^2
 int gmres_scale_to(wai_ctx* c, double* dst, const double* src, int slot_norm2, int n);

@@ -415,7 +415,7 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
   // the pivots of ILU(0)(A') are identities, so neither dinv nor its two products per row are needed
   constexpr bool SC = (DILU == 2);
   const double* __restrict__ mat = SC ? fval : aval;
-  extern __shared__ double lds[];  // [T * BS] solution vector, then 32 doubles reduction scratch
+  extern __shared__ double lds[];  // [T * BS] solution vector, then 80 doubles reduction scratch
   int s = xcd_remap(blockIdx.x, nsub);
   if (s >= nsub) return;
   if (sub_list) s = sub_list[s];
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
         }
       }
       if constexpr (!SPMV) load_x<BS>(in, i, acc);
-      if (dot == 2) load_x<BS>(SPMV ? in : aux, i, xin);
+      if (dot == 2 || dot == 4) load_x<BS>(in, i, xin);
       if constexpr (!SC) load_block<BS>(dinv, n, 0, i, dv);
       if constexpr (SC && !SPMV) {  // plain application to an unscaled vector: scale it first
         load_block<BS>(dinv, n, 0, i, dv);
@@ -518,10 +518,9 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
 #pragma unroll
         for (int r = 0; r < BS; r++) acc[r] = 0.0;
         ell_row_mult<BS>(n, W, i, col, aval, in, acc);
-        if (dot == 2) load_x<BS>(in, i, xin);
+        if (dot == 2 || dot == 4) load_x<BS>(in, i, xin);
       } else {
         load_x<BS>(in, i, acc);
-        if (dot == 2) load_x<BS>(aux, i, xin);
       }
       // factor row -> registers (independent loads, all in flight before the first barrier)
 #pragma unroll
@@ -701,8 +700,8 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
   }
   if (dot != 0) {
     double* red = lds + (size_t)blockDim.x * BS;
-    double v[2] = {0.0, 0.0};
-    int slots[2] = {S_D1, S_D2};
+    double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    int slots[5] = {S_D1, S_D2, S_DP2, S_RHONEW, S_W2};
     if (dot == 1) {  // (z, aux)
       if (active) {
         double av[BS];
@@ -713,13 +712,24 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
     } else if (dot == 2) {  // (in, z), (z, z)
 #pragma unroll
       for (int r = 0; r < BS; r++) { v[0] += xin[r] * out[r]; v[1] += out[r] * out[r]; }
+    } else if (dot == 4) {  // merged BiCGStab reductions: (in,z), (z,z), (in,in), (in,aux), (z,aux)
+      if (active) {
+        double av[BS];
+        load_x_stream<BS>(aux, i, av);
+#pragma unroll
+        for (int r = 0; r < BS; r++) {
+          v[0] += xin[r] * out[r]; v[1] += out[r] * out[r]; v[2] += xin[r] * xin[r];
+          v[3] += xin[r] * av[r]; v[4] += out[r] * av[r];
+        }
+      }
     } else {  // (z, z)
 #pragma unroll
       for (int r = 0; r < BS; r++) v[0] += out[r] * out[r];
       slots[0] = S_DP2;
     }
     __syncthreads();
-    if (dot == 2) wg_reduce_store<2>(v, red, partials, nb_max, slots, s);
+    if (dot == 4) wg_reduce_store<5>(v, red, partials, nb_max, slots, s);
+    else if (dot == 2) { double v2[2] = {v[0], v[1]}; wg_reduce_store<2>(v2, red, partials, nb_max, slots, s); }
     else { double v1[1] = {v[0]}; wg_reduce_store<1>(v1, red, partials, nb_max, slots, s); }
   }
 }
@@ -741,7 +751,7 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
     double* __restrict__ z, const double* __restrict__ aux, double* partials, int nb_max, int dot,
     const int* __restrict__ sub_list) {
   constexpr int BS = 2, BB = 4, MLU = 3;
-  extern __shared__ double lds[];  // [T*2] solution, [32] reduction scratch, then parked U blocks
+  extern __shared__ double lds[];  // [T*2] solution, [80] reduction scratch, then parked U blocks
   // nsub subdomains to run: all of them, or (sub_list) the listed ones -- the bricks that touch no
   // partition ghost while the halo exchange is in flight, the others after it
   int s = xcd_remap(blockIdx.x, nsub);
@@ -753,7 +763,7 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
   const int tid = threadIdx.x, i = lo + tid;
   const bool active = tid < R;
   double* ys = lds;
-  double* upark = lds + (size_t)blockDim.x * BS + 32;
+  double* upark = lds + (size_t)blockDim.x * BS + 80;
   double Lf[MLU][BB];
   int Lc[MLU], Uc[MLU], lf = -1, lb = -1, uo = 0, nU = 0;
   double xin[BS] = {0.0, 0.0};
@@ -804,7 +814,7 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
       acc[0] = dv[0] * r[0] + dv[1] * r[1];
       acc[1] = dv[2] * r[0] + dv[3] * r[1];
     }
-    if (dot == 2) load_x<BS>(SPMV ? in : aux, i, xin);
+    if (dot == 2 || dot == 4) load_x<BS>(in, i, xin);
     *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(acc[0], acc[1]);
   }
   __syncthreads();
@@ -853,8 +863,8 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
   if (active) store_z2(z, (size_t)i, out[0], out[1]);
   if (dot != 0) {
     double* red = lds + (size_t)blockDim.x * BS;
-    double v[2] = {0.0, 0.0};
-    int slots[2] = {S_D1, S_D2};
+    double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    int slots[5] = {S_D1, S_D2, S_DP2, S_RHONEW, S_W2};
     if (dot == 1) {
       if (active) {
         double av[BS];
@@ -864,12 +874,23 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
     } else if (dot == 2) {
       v[0] = xin[0] * out[0] + xin[1] * out[1];
       v[1] = out[0] * out[0] + out[1] * out[1];
+    } else if (dot == 4) {  // merged BiCGStab reductions: (in,z), (z,z), (in,in), (in,aux), (z,aux)
+      if (active) {
+        double av[BS];
+        load_x_stream<BS>(aux, i, av);
+        v[0] = xin[0] * out[0] + xin[1] * out[1];
+        v[1] = out[0] * out[0] + out[1] * out[1];
+        v[2] = xin[0] * xin[0] + xin[1] * xin[1];
+        v[3] = xin[0] * av[0] + xin[1] * av[1];
+        v[4] = out[0] * av[0] + out[1] * av[1];
+      }
     } else {
       v[0] = out[0] * out[0] + out[1] * out[1];
       slots[0] = S_DP2;
     }
     __syncthreads();
-    if (dot == 2) wg_reduce_store<2>(v, red, partials, nb_max, slots, s);
+    if (dot == 4) wg_reduce_store<5>(v, red, partials, nb_max, slots, s);
+    else if (dot == 2) { double v2[2] = {v[0], v[1]}; wg_reduce_store<2>(v2, red, partials, nb_max, slots, s); }
     else { double v1[1] = {v[0]}; wg_reduce_store<1>(v1, red, partials, nb_max, slots, s); }
   }
 }
@@ -994,18 +1015,24 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? 7 : 5))) void k_pc_
   }
   if (dot != 0) {
     double* red = lds + (size_t)R * BS + BS;
-    double v[2] = {0.0, 0.0};
-    int slots[2] = {S_D1, S_D2};
+    double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    int slots[5] = {S_D1, S_D2, S_DP2, S_RHONEW, S_W2};
     if (dot == 1) {
       if (active) v[0] = out * __builtin_nontemporal_load(aux + g);
     } else if (dot == 2) {
-      if (active) { v[0] = (SPMV ? in : aux)[g] * out; v[1] = out * out; }
+      if (active) { v[0] = in[g] * out; v[1] = out * out; }
+    } else if (dot == 4) {
+      if (active) {
+        const double xi = in[g], av = __builtin_nontemporal_load(aux + g);
+        v[0] = xi * out; v[1] = out * out; v[2] = xi * xi; v[3] = xi * av; v[4] = out * av;
+      }
     } else {
       v[0] = out * out;
       slots[0] = S_DP2;
     }
     __syncthreads();
-    if (dot == 2) wg_reduce_store<2>(v, red, partials, nb_max, slots, s);
+    if (dot == 4) wg_reduce_store<5>(v, red, partials, nb_max, slots, s);
+    else if (dot == 2) { double v2[2] = {v[0], v[1]}; wg_reduce_store<2>(v2, red, partials, nb_max, slots, s); }
     else { double v1[1] = {v[0]}; wg_reduce_store<1>(v1, red, partials, nb_max, slots, s); }
   }
 }
@@ -1080,6 +1107,18 @@ __device__ __forceinline__ void derive_scalars(double* s, int phase) {
       if (s[S_D2] == 0.0) { s[S_BREAK] = 2.0; s[S_OMEGA] = 0.0; }
       else s[S_OMEGA] = s[S_D1] / s[S_D2];
       break;
+    case 5: {  // merged reductions (multi-rank): slots hold (S,T), (T,T), (S,S), (S,RP), (T,RP).
+      // omega as in case 3; then, with R = S - omega T:  (R,RP) = (S,RP) - omega (T,RP)  and
+      // (R,R) = (S,S) - 2 omega (S,T) + omega^2 (T,T) -- one all-reduce instead of two
+      const double st = s[S_D1], tt = s[S_D2], ss = s[S_DP2], srp = s[S_RHONEW], trp = s[S_W2];
+      if (tt == 0.0) { s[S_BREAK] = 2.0; s[S_OMEGA] = 0.0; }
+      else s[S_OMEGA] = st / tt;
+      const double om = s[S_OMEGA];
+      const double rr = (ss - 2.0 * om * st) + om * om * tt;
+      s[S_DP2] = rr > 0.0 ? rr : 0.0;
+      s[S_RHONEW] = srp - om * trp;
+      break;
+    }
     case 4:  // end of iteration: rotate rho, next beta = (rho/rhoold)*(alpha/omega)
       s[S_RHOOLD] = s[S_RHO]; s[S_RHO] = s[S_RHONEW];
       if (s[S_RHO] == 0.0 && s[S_BREAK] == 0.0) s[S_BREAK] = 3.0;  // only matters if not converged
@@ -1146,7 +1185,9 @@ __global__ __launch_bounds__(TPB) void k_bcgs_s(double* __restrict__ S, const do
   for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) stv(S + i, ldv(R + i) - alpha * ldv(V + i));
 
 }
-// X += alpha P + omega S ; R = S - omega T ; partial (R,R) and (R,RP)
+// X += alpha P + omega S ; R = S - omega T ; partial (R,R) and (R,RP) unless the caller already has
+// them from the merged reductions (DOTS = false)
+template <bool DOTS>
 __global__ __launch_bounds__(TPB) void k_bcgs_xr(double* __restrict__ X, double* __restrict__ R,
                                                  const double* __restrict__ P, const double* __restrict__ S,
                                                  const double* __restrict__ T, const double* __restrict__ RP,
@@ -1159,11 +1200,15 @@ __global__ __launch_bounds__(TPB) void k_bcgs_xr(double* __restrict__ X, double*
     stv(X + i, ldv(X + i) + alpha * ldv(P + i) + omega * si);
     const double r = si - omega * ldv(T + i);
     stv(R + i, r);
-    v[0] += r * r;
-    v[1] += r * ldv(RP + i);
+    if constexpr (DOTS) {
+      v[0] += r * r;
+      v[1] += r * ldv(RP + i);
+    }
   }
-  const int slots[2] = {S_DP2, S_RHONEW};
-  block_reduce_store<2>(v, partials, nb_max, slots);
+  if constexpr (DOTS) {
+    const int slots[2] = {S_DP2, S_RHONEW};
+    block_reduce_store<2>(v, partials, nb_max, slots);
+  }
 }
 
 __global__ __launch_bounds__(TPB) void k_waxpy(double* w, double alpha, const double* x, const double* y, int n) {
@@ -1470,7 +1515,7 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
                          int dot_mode, const double* aux, const int* list, int nrun) {
   if (!list) nrun = s.nsub;
   const int grid = ((nrun + 7) / 8) * 8, T = pc_threads(s);
-  const size_t lds = ((size_t)T * BS + 32) * sizeof(double);
+  const size_t lds = ((size_t)T * BS + 80) * sizeof(double);
 #define PCL(SP, DI)                                                                              \
   do {                                                                                           \
     if (s.fast3)                                                                                 \
@@ -1485,7 +1530,7 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
   // one thread per scalar row: block sizes 3 and 4 (and 2 when asked for: WAI_PC_ROWS=1)
   if (s.rows_kernel && !c->dbg) {
     const int TR = ((s.max_rows * BS + 63) / 64) * 64;
-    const size_t lds_r = ((size_t)s.max_rows * BS + BS + 2 * 16 + 8) * sizeof(double);
+    const size_t lds_r = ((size_t)s.max_rows * BS + BS + 5 * 16 + 8) * sizeof(double);
 #define PCR(SP, NLU)                                                                               \
     hipLaunchKernelGGL((k_pc_rows<BS, SP, NLU, NLU>), grid, TR, lds_r, c->stream, J.n, J.W, nrun, s.sub_ptr,  \
                        s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, \
@@ -1611,10 +1656,14 @@ int bcgs_update_s(wai_ctx* c) {
   hipLaunchKernelGGL(k_bcgs_s, vgrid(c->ks.n), TPB, 0, c->stream, c->ks.S, c->ks.R, c->ks.V, c->ks.n, c->ks.scal);
   return 0;
 }
-int bcgs_update_xr(wai_ctx* c) {
+int bcgs_update_xr(wai_ctx* c, bool dots) {
   const int g = vgrid(c->ks.n);
-  hipLaunchKernelGGL(k_bcgs_xr, g, TPB, 0, c->stream, c->ks.X, c->ks.R, c->ks.P, c->ks.S, c->ks.T,
-                     c->ks.RP, c->ks.n, c->ks.scal, c->ks.partials, c->ks.nb_max);
+  if (dots)
+    hipLaunchKernelGGL(k_bcgs_xr<true>, g, TPB, 0, c->stream, c->ks.X, c->ks.R, c->ks.P, c->ks.S, c->ks.T,
+                       c->ks.RP, c->ks.n, c->ks.scal, c->ks.partials, c->ks.nb_max);
+  else
+    hipLaunchKernelGGL(k_bcgs_xr<false>, g, TPB, 0, c->stream, c->ks.X, c->ks.R, c->ks.P, c->ks.S, c->ks.T,
+                       c->ks.RP, c->ks.n, c->ks.scal, c->ks.partials, c->ks.nb_max);
   c->ks.nblocks = g;
   return 0;
 }

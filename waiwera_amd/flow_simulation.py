@@ -127,6 +127,11 @@ class FlowSimulation:
     def comm_size(self):
         return LIB.wai_comm_size(self.h)
 
+    def comm_stats(self):
+        a, e = C.c_longlong(0), C.c_longlong(0)
+        LIB.wai_comm_stats(self.h, C.byref(a), C.byref(e))
+        return a.value, e.value
+
     def pc_kernel_name(self):
         return LIB.wai_pc_kernel_name(self.h).decode()
 

@@ -124,6 +124,7 @@ def _load():
         "wai_comm_init": (i32, [vp, i32, i32, C.c_char_p]),
         "wai_halo_exchange": (i32, [vp, vp, i32]),
         "wai_comm_size": (i32, [vp]),
+        "wai_comm_stats": (i32, [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
         "wai_pc_kernel_name": (C.c_char_p, [vp]),
         "wai_pre_timestep": (i32, [vp]),
         "wai_pre_retry_timestep": (i32, [vp]),
