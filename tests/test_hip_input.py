@@ -106,7 +106,7 @@ def test_restart_from_waiwera_hdf5_and_write_output(tmp_path):
     json.dump(inp, open(tmp_path / "oned_two_phase_ss.json", "w"))
     sim = Simulation.from_json(str(tmp_path / "oned_two_phase_ss.json"), output_dir=str(tmp_path))
     sim.run()
-    assert not hasattr(sim, "output_error")
+    assert sim.output_error is None
     mine = hdf5io.read_state(str(tmp_path / "mine_ss.h5"))
     ref = hdf5io.read_state(str(tmp_path / "oned_two_phase_ss.h5"))
     for k in ("fluid_pressure", "fluid_temperature", "fluid_vapour_saturation", "fluid_region"):
