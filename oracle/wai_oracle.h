@@ -175,7 +175,8 @@ void wo_sim_set_subdomains(wo_sim *s, int nsub, const int *sub_ptr);
  * overlap 1); 0 = block Jacobi (PCBJACOBI).  Call after wo_sim_set_subdomains. */
 void wo_sim_set_asm(wo_sim *s, int overlap);
 int wo_sim_asm_rows(wo_sim *s, int *ptr, int *rows);
-void wo_sim_set_pc_none(wo_sim *s, int none);   /* PCNONE (:1747-1748) */
+void wo_sim_set_pc_none(wo_sim *s, int none);
+void wo_sim_spread_pages(wo_sim *s);  /* first-touch re-homing of the matrix pattern over the OpenMP team */   /* PCNONE (:1747-1748) */
 int wo_pc_setup(wo_sim *s, const double *val);
 void wo_pc_apply(wo_sim *s, const double *r, double *z);
 void wo_sim_set_regions(wo_sim *s, const int *region /* n_owned+n_halo */);

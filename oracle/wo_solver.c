@@ -295,6 +295,22 @@ void wo_sim_set_subdomains(wo_sim *s, int nsub, const int *sub_ptr) {
   s->sub_ptr = (int *)xmalloc(sizeof(int) * (nsub + 1));
   memcpy(s->sub_ptr, sub_ptr, sizeof(int) * (nsub + 1));
 }
+/* Re-home the matrix pattern: the arrays wo_sim_create filled on one thread are copied by the team in
+ * the static row partition the SpMV uses, so their pages sit next to the threads that stream them
+ * (first touch).  For the many-core CPU baseline of bench.py; results do not change. */
+void wo_sim_spread_pages(wo_sim *s) {
+  int n = s->n_owned;
+  int *rp = (int *)malloc(sizeof(int) * ((size_t)n + 1)), *ci = (int *)malloc(sizeof(int) * (size_t)s->nnzb);
+  if (!rp || !ci) { free(rp); free(ci); return; }
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; i++) {
+    rp[i] = s->rowptr[i];
+    for (int q = s->rowptr[i]; q < s->rowptr[i + 1]; q++) ci[q] = s->colidx[q];
+  }
+  rp[n] = s->rowptr[n];
+  free(s->rowptr); free(s->colidx);
+  s->rowptr = rp; s->colidx = ci;
+}
 void wo_sim_set_regions(wo_sim *s, const int *region) {
   int df = s->eos.df;
   for (int c = 0; c < s->n_prim; c++) {
@@ -799,16 +815,31 @@ static void bmm(int bs, const double *a, const double *b, double *c) { /* c = a 
     }
 }
 
+/* Loops over subdomains: few subdomains (one per thread: the domain-decomposed CPU baseline) are
+ * dealt out statically, so that a thread always works on the same rows and their pages stay where it
+ * first touched them; many small ones (bricks) dynamically. */
+static void sub_schedule(int nsub) {
+#ifdef _OPENMP
+  if (nsub <= 4 * omp_get_max_threads()) omp_set_schedule(omp_sched_static, 0);
+  else omp_set_schedule(omp_sched_dynamic, 1);
+#else
+  (void)nsub;
+#endif
+}
+
 /* block ILU(0), IKJ form, restricted to each subdomain's diagonal block (PCBJACOBI + PCILU
  * levels 0: src/timestepper.F90:1668-1669,1789-1834).  L carries the multipliers
  * A_ik * inv(U_kk) (unit block diagonal), U's pivots are stored inverted in dinv. */
 int wo_bilu0_factor(int n, int bs, const int *rowptr, const int *colidx, const double *val,
                     int nsub, const int *sub_ptr, double *fval, double *dinv) {
   int bb = bs * bs, err = 0;
-  memcpy(fval, val, sizeof(double) * (size_t)rowptr[n] * bb);
-#pragma omp parallel for reduction(| : err) schedule(dynamic, 1)
+  sub_schedule(nsub);
+#pragma omp parallel for reduction(| : err) schedule(runtime)
   for (int sd = 0; sd < nsub; sd++) {
     int lo = sub_ptr[sd], hi = sub_ptr[sd + 1];
+    /* the subdomain's rows of the factor start as a copy of the matrix: copied by the thread that
+     * factors and later applies them (first touch places the pages next to it) */
+    memcpy(fval + (size_t)rowptr[lo] * bb, val + (size_t)rowptr[lo] * bb, sizeof(double) * (size_t)(rowptr[hi] - rowptr[lo]) * bb);
     for (int i = lo; i < hi; i++) {
       int qdiag = -1;
       for (int q = rowptr[i]; q < rowptr[i + 1]; q++) {
@@ -843,7 +874,8 @@ void wo_bilu0_apply(int n, int bs, const int *rowptr, const int *colidx, const d
                     double *z) {
   int bb = bs * bs;
   (void)n;
-#pragma omp parallel for schedule(dynamic, 1)
+  sub_schedule(nsub);
+#pragma omp parallel for schedule(runtime)
   for (int sd = 0; sd < nsub; sd++) {
     int lo = sub_ptr[sd], hi = sub_ptr[sd + 1];
     for (int i = lo; i < hi; i++) { /* forward: L y = r */
@@ -1038,14 +1070,16 @@ static int ksp_bcgs(wo_sim *s, const double *val, const double *b, double *x, do
   double *S = xmalloc(sizeof(double) * nl), *T = xmalloc(sizeof(double) * n);
   double *tmp = xmalloc(sizeof(double) * n);
   int reason = 0, i;
-  memset(x, 0, sizeof(double) * n);
+#pragma omp parallel for schedule(static)
+  for (int q = 0; q < n; q++) x[q] = 0.0;
   pc_apply(s, b, R);
   double dp = sqrt(gdot(s, R, R, n));
   double ttol = fmax(rtol * dp, atol), dp0 = dp;
   if (hist) hist[0] = dp;
   *its = 0;
   if (dp <= ttol) reason = (dp <= atol) ? 3 : 2;
-  memcpy(RP, R, sizeof(double) * n);
+#pragma omp parallel for schedule(static)
+  for (int q = 0; q < n; q++) { RP[q] = R[q]; P[q] = 0.0; V[q] = 0.0; }
   double rhoold = 1.0, alphaold = 1.0, omegaold = 1.0;
   for (i = 0; i < maxits && !reason; i++) {
     double rho = gdot(s, R, RP, n);

@@ -104,6 +104,7 @@ def load(path):
         "wo_sim_set_asm": (None, [C.c_void_p, i32]),
         "wo_sim_asm_rows": (i32, [C.c_void_p, pi, pi]),
         "wo_sim_set_pc_none": (None, [C.c_void_p, i32]),
+        "wo_sim_spread_pages": (None, [C.c_void_p]),
         "wo_pc_setup": (i32, [C.c_void_p, pd]),
         "wo_pc_apply": (None, [C.c_void_p, pd, pd]),
         "wo_sim_set_regions": (None, [C.c_void_p, pi]),
