@@ -168,6 +168,16 @@ def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
+    # CPU time the container may use (cgroup v2 cpu.max "quota period"): more threads than that are
+    # throttled, not run -- MEASURED on the GPU box: quota 16 CPUs of a 2 x 64-core host, block SpMV
+    # 130 GB/s at 16 threads, 33 GB/s at 128, 6 GB/s at 256
+    quota = avail
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, min(avail, int(round(float(q) / float(per)))))
+    except (OSError, ValueError):
+        pass
     # one thread per core, spread over the sockets (read by libgomp when it is first loaded)
     os.environ.setdefault("OMP_PROC_BIND", "spread")
     os.environ.setdefault("OMP_PLACES", "cores")
@@ -192,7 +202,8 @@ def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0):
         sp = np.linspace(0, n, int(t) + 1).astype(np.int32)   # one ILU(0) subdomain per thread
         L.wo_sim_set_subdomains(osim.h, int(t), ol.ip(sp))
 
-    set_threads(min(avail, 64))
+    set_threads(quota)
+    L.wo_sim_spread_pages(osim.h)
     L.wo_pre_timestep(osim.h)
     t0 = time.time()
     assert osim.pre_eval(y) == 0
@@ -224,7 +235,7 @@ def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0):
         L.wo_ksp_solve(osim.h, 0, 30, ol.dp(J), ol.dp(f), ol.dp(xs), 1e-30, 1e-50, k, C.byref(its), C.byref(rn), None)
         return ts, max(time.time() - t0 - ts, 1e-9) / max(its.value, 1)     # wo_ksp_solve factors again
 
-    trials = sorted({t for t in (16, 32, 64, 128, 256) if t <= avail} | {min(avail, 8)}) if gomp else [1]
+    trials = sorted({max(1, quota // 2), quota, min(avail, 2 * quota)}, reverse=True) if gomp else [1]
     best_t, best = trials[0], None
     for t in trials:
         ts, ti = solve(t, 2)
@@ -247,9 +258,9 @@ def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0):
               "FD Jacobian %.2f s (per-row differencing%s), ILU(0) set-up %.2f s with one subdomain per thread, "
               "BiCGStab %.3f s/iteration over %d iterations; Newton step = residual + Jacobian + set-up + %.1f "
               "iterations (the count measured on the GPU trajectory) x s/iteration = %.1f s; %d OpenMP threads "
-              "(best Krylov iteration of %s) on %d hardware threads, %s"
+              "(best Krylov iteration of %s; the container's CPU quota is %d CPUs) on %d hardware threads, %s"
               % (n, dt, t_res, t_jac, "; reference-style coloured sweeps %.2f s" % t_col if t_col else "", t_setup,
-                 t_iter, K, kits_per_newton, t_newton, best_t, "/".join(str(t) for t in trials), avail, model))
+                 t_iter, K, kits_per_newton, t_newton, best_t, "/".join(str(t) for t in trials), quota, avail, model))
     out = {"value": 1.0 / t_newton, "unit": "Newton steps/s", "cores": best_t, "kind": "port", "sample": sample,
            "seconds": {"residual": t_res, "jacobian_per_row": t_jac, "jacobian_coloured": t_col, "pc_setup": t_setup,
                        "krylov_iteration": t_iter}}

@@ -132,9 +132,11 @@ __device__ __forceinline__ void ell_row_mult(int n, int W, int i, const int* __r
 }
 
 // ---- K6: block SpMV --------------------------------------------------------------------------
+// rowptr (may be null): rows shorter than the block-ELL width (MINC matrix cells: 2 blocks of 8)
+// skip their padding slots instead of streaming zeros
 template <int BS>
 __global__ __launch_bounds__(TPB) void k_spmv(int n, int W, int nblk, const int* __restrict__ col,
-                                              const double* __restrict__ val,
+                                              const double* __restrict__ val, const int* __restrict__ rowptr,
                                               const double* __restrict__ x, double* __restrict__ y) {
   const int b = xcd_remap(blockIdx.x, nblk);
   const int i = b * TPB + threadIdx.x;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(TPB) void k_spmv(int n, int W, int nblk, const int*
   double acc[BS];
 #pragma unroll
   for (int r = 0; r < BS; r++) acc[r] = 0.0;
-  ell_row_mult<BS>(n, W, i, col, val, x, acc);
+  ell_row_mult<BS>(n, rowptr ? rowptr[i + 1] - rowptr[i] : W, i, col, val, x, acc);
   if constexpr (BS == 2) store_z2(y, (size_t)i, acc[0], acc[1]);
   else {
 #pragma unroll
@@ -914,7 +916,8 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? 7 : 5))) void k_pc_
     int n, int W, int nsub, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev,
     const int* __restrict__ row_info, const int* __restrict__ col, const double* __restrict__ sval,
     const double* __restrict__ dinv, const double* __restrict__ in, double* __restrict__ z,
-    const double* __restrict__ aux, double* partials, int nb_max, int dot, const int* __restrict__ sub_list) {
+    const double* __restrict__ aux, double* partials, int nb_max, int dot, const int* __restrict__ sub_list,
+    const int* __restrict__ rowptr) {
   extern __shared__ double lds[];  // [R*BS] solution in block order, [BS] zeros, then reduction scratch
   int s = xcd_remap(blockIdx.x, nsub);
   if (s >= nsub) return;
@@ -944,10 +947,11 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? 7 : 5))) void k_pc_
   if (active) {
     int lfirst, dslot, ulast;
     unpack_info(row_info[i], lfirst, dslot, ulast, lf, lb);
+    const int cnt = rowptr ? rowptr[i + 1] - rowptr[i] : W;   // padding slots of short rows are not read
     double acc = 0.0;
 #pragma unroll
     for (int q = 0; q < WMAX; q++) {
-      if (q < W) {
+      if (q < cnt) {
         const int cg = load_col(col, (size_t)q * n + i);
         double blk[BS];
         const double* src = sval + ((size_t)(q * BS + r) * n + i) * BS;
@@ -1276,11 +1280,12 @@ int launch_spmv(wai_ctx* c, const double* x, double* y) {
   const Bcsr& J = c->J;
   const int nblk = (J.n + TPB - 1) / TPB;
   const int grid = ((nblk + 7) / 8) * 8;
+  const int* rp = (size_t)J.nnzb * 10 < (size_t)J.n * J.W * 9 ? J.rowptr : nullptr;   // > 10 % padding
   switch (J.bs) {
-    case 1: hipLaunchKernelGGL(k_spmv<1>, grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, x, y); break;
-    case 2: hipLaunchKernelGGL(k_spmv<2>, grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, x, y); break;
-    case 3: hipLaunchKernelGGL(k_spmv<3>, grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, x, y); break;
-    case 4: hipLaunchKernelGGL(k_spmv<4>, grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, x, y); break;
+    case 1: hipLaunchKernelGGL(k_spmv<1>, grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, rp, x, y); break;
+    case 2: hipLaunchKernelGGL(k_spmv<2>, grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, rp, x, y); break;
+    case 3: hipLaunchKernelGGL(k_spmv<3>, grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, rp, x, y); break;
+    case 4: hipLaunchKernelGGL(k_spmv<4>, grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, rp, x, y); break;
     default: return -1;
   }
   return 0;
@@ -1531,10 +1536,11 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
   if (s.rows_kernel && !c->dbg) {
     const int TR = ((s.max_rows * BS + 63) / 64) * 64;
     const size_t lds_r = ((size_t)s.max_rows * BS + BS + 5 * 16 + 8) * sizeof(double);
+    const int* rp = (size_t)J.nnzb * 10 < (size_t)J.n * J.W * 9 ? J.rowptr : nullptr;   // > 10 % padding
 #define PCR(SP, NLU)                                                                               \
     hipLaunchKernelGGL((k_pc_rows<BS, SP, NLU, NLU>), grid, TR, lds_r, c->stream, J.n, J.W, nrun, s.sub_ptr,  \
                        s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, \
-                       dot_mode, list)
+                       dot_mode, list, rp)
     if (s.max_nlu <= 3) { if (spmv) PCR(true, 3); else PCR(false, 3); }
     else { if (spmv) PCR(true, 4); else PCR(false, 4); }
 #undef PCR
