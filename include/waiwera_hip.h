@@ -35,8 +35,9 @@ enum { WAI_EOS_W = 0, WAI_EOS_WE = 1, WAI_EOS_WCE = 2, WAI_EOS_WSE = 3, WAI_EOS_
 enum { WAI_METHOD_BEULER = 0, WAI_METHOD_BDF2 = 1, WAI_METHOD_DIRECTSS = 2 };
 enum { WAI_THERMO_IAPWS = 0, WAI_THERMO_IFC67 = 1 };
 enum { WAI_RP_FULLY_MOBILE = 0, WAI_RP_LINEAR = 1, WAI_RP_PICKENS = 2, WAI_RP_COREY = 3,
-       WAI_RP_GRANT = 4, WAI_RP_VAN_GENUCHTEN = 5 };
-enum { WAI_CP_ZERO = 0, WAI_CP_LINEAR = 1, WAI_CP_VAN_GENUCHTEN = 2 };
+       WAI_RP_GRANT = 4, WAI_RP_VAN_GENUCHTEN = 5, WAI_RP_TABLE = 6 };
+enum { WAI_CP_ZERO = 0, WAI_CP_LINEAR = 1, WAI_CP_VAN_GENUCHTEN = 2, WAI_CP_TABLE = 3 };
+enum { WAI_INTERP_LINEAR = 0, WAI_INTERP_STEP = 1, WAI_INTERP_PCHIP = 2 };
 enum { WAI_KSP_BCGS = 0, WAI_KSP_GMRES = 1 };
 /* linear.preconditioner.type (src/timestepper.F90:1745-1757): "bjacobi" PCBJACOBI, "asm" PCASM (the
  * reference's default: restricted, overlap 1), "none" PCNONE; the blocks' sub-preconditioner is
@@ -110,6 +111,14 @@ int wai_ctx_create(const wai_mesh_desc *mesh, const wai_eos_desc *eos,
 int wai_ctx_destroy(wai_ctx *ctx);
 const char *wai_last_error(wai_ctx *ctx);
 int wai_set_opts(wai_ctx *ctx, const wai_solver_opts *opts);
+
+/* "table" curves (relative_permeability_table_type, src/relative_permeability.F90:123-132,500-558;
+ * capillary_pressure_table_type, src/capillary_pressure.F90:88-96,311-358): which 0 liquid relative
+ * permeability against liquid saturation, 1 vapour relative permeability against vapour saturation,
+ * 2 capillary pressure against liquid saturation; n <= 12 points xy[n][2] with increasing x,
+ * interpolation WAI_INTERP_* (src/interpolation.F90).  Takes effect with rp_type = WAI_RP_TABLE /
+ * cp_type = WAI_CP_TABLE; call before wai_set_bc (the boundary fluid is evaluated there). */
+int wai_set_curve_table(wai_ctx *ctx, int which, int interpolation, int n, const double *xy);
 
 /* boundary-condition ghost cells: unscaled primaries + region per bc cell
  * (mesh_set_boundary_conditions, src/mesh.F90:1069-1264; fluid filled once :1199-1202) */

@@ -58,8 +58,15 @@ double wo_ncg_mole_to_mass(double xmole, double mw);  /* ncg_thermodynamics.F90:
 
 /* ---- curves (src/relative_permeability.F90, src/capillary_pressure.F90) ---------------- */
 enum { WO_RP_FULLY_MOBILE = 0, WO_RP_LINEAR = 1, WO_RP_PICKENS = 2, WO_RP_COREY = 3,
-       WO_RP_GRANT = 4, WO_RP_VAN_GENUCHTEN = 5 };
-enum { WO_CP_ZERO = 0, WO_CP_LINEAR = 1, WO_CP_VAN_GENUCHTEN = 2 };
+       WO_RP_GRANT = 4, WO_RP_VAN_GENUCHTEN = 5, WO_RP_TABLE = 6 };
+enum { WO_CP_ZERO = 0, WO_CP_LINEAR = 1, WO_CP_VAN_GENUCHTEN = 2, WO_CP_TABLE = 3 };
+/* table curve (src/interpolation.F90 interpolation_table_type): interp 0 linear, 1 step, 2 pchip */
+#define WO_MAX_CURVE_POINTS 12
+typedef struct wo_curve_table {
+  int n, interp;
+  double x[WO_MAX_CURVE_POINTS], v[WO_MAX_CURVE_POINTS], d[WO_MAX_CURVE_POINTS];
+} wo_curve_table;
+double wo_curve_table_value(const wo_curve_table *t, double x);
 void wo_relperm(int type, const double *par, double sl, double rp[2]);
 double wo_capillary(int type, const double *par, double sl, double t);
 
@@ -80,7 +87,11 @@ typedef struct wo_eos {
   int thermo;                  /* "thermodynamics": 0 IAPWS-97 (default), 1 IFC-67 */
   int perm_type;               /* eos wse permeability modifier: 0 none, 1 power, 2 Verma-Pruess */
   double perm_par[3];          /* exponent, phir, gamma (src/fluid.F90:601-664) */
+  wo_curve_table tab[3];       /* "table" curves: liquid / vapour relative permeability, capillary pressure */
 } wo_eos;
+/* which 0 liquid k_r(S_l), 1 vapour k_r(S_v), 2 P_c(S_l); xy[n][2]; src/relative_permeability.F90:500-558,
+ * src/capillary_pressure.F90:311-358 */
+int wo_eos_set_curve_table(wo_eos *e, int which, int interp, int n, const double *xy);
 double wo_permeability_factor(const wo_eos *e, double pore_fraction);
 void wo_eos_init(wo_eos *e, int kind);
 void wo_eos_unscale(const wo_eos *e, const double *y, int region, double *primary);

@@ -298,6 +298,70 @@ static double lin2(double x, double x0, double x1, double y0, double y1) {
 
 /* src/relative_permeability.F90:197-492.  par: linear [l0,l1,v0,v1]; pickens [power];
  * corey/grant [slr,ssr]; van Genuchten [lambda,slr,sls,sum_unity,ssr] */
+/* interpolation_table_type (src/interpolation.F90): find :202-222, clamped ends :494-510, linear
+ * :388-404, step :715-720, pchip derivatives :810-885 and polynomial :891-925 */
+static int sign_test(double a, double b) {
+  if ((a > 0.0 && b > 0.0) || (a < 0.0 && b < 0.0)) return 1;
+  if (a == 0.0 || b == 0.0) return 0;
+  return -1;
+}
+static void pchip_deriv(int n, const double *x, const double *f, double *d) {
+  if (n == 1) { d[0] = 0.0; return; }
+  double h1 = x[1] - x[0], del1 = (f[1] - f[0]) / h1;
+  if (n == 2) { d[0] = d[1] = del1; return; }
+  double h2 = x[2] - x[1], del2 = (f[2] - f[1]) / h2, hsum = h1 + h2;
+  double w1 = (h1 + hsum) / hsum, w2 = -h1 / hsum, dmax, dmin;
+  d[0] = w1 * del1 + w2 * del2;
+  if (sign_test(d[0], del1) <= 0) d[0] = 0.0;
+  else if (sign_test(del1, del2) < 0) { dmax = 3.0 * del1; if (fabs(d[0]) > fabs(dmax)) d[0] = dmax; }
+  for (int i = 1; i < n - 1; i++) {
+    if (i > 1) { h1 = h2; h2 = x[i + 1] - x[i]; hsum = h1 + h2; del1 = del2; del2 = (f[i + 1] - f[i]) / h2; }
+    if (sign_test(del1, del2) > 0) {
+      w1 = (hsum + h1) / (3.0 * hsum); w2 = (hsum + h2) / (3.0 * hsum);
+      dmax = fmax(fabs(del1), fabs(del2)); dmin = fmin(fabs(del1), fabs(del2));
+      d[i] = dmin / (w1 * (del1 / dmax) + w2 * (del2 / dmax));
+    } else d[i] = 0.0;
+  }
+  w1 = -h2 / hsum; w2 = (h2 + hsum) / hsum;
+  d[n - 1] = w1 * del1 + w2 * del2;
+  if (sign_test(d[n - 1], del2) <= 0) d[n - 1] = 0.0;
+  else if (sign_test(del1, del2) < 0) { dmax = 3.0 * del2; if (fabs(d[n - 1]) > fabs(dmax)) d[n - 1] = dmax; }
+}
+int wo_eos_set_curve_table(wo_eos *e, int which, int interp, int n, const double *xy) {
+  if (which < 0 || which > 2 || n < 1 || n > WO_MAX_CURVE_POINTS || interp < 0 || interp > 2) return 1;
+  wo_curve_table *t = &e->tab[which];
+  t->n = n; t->interp = interp;
+  for (int i = 0; i < n; i++) { t->x[i] = xy[2 * i]; t->v[i] = xy[2 * i + 1]; t->d[i] = 0.0; }
+  if (interp == 2) pchip_deriv(n, t->x, t->v, t->d);
+  return 0;
+}
+double wo_curve_table_value(const wo_curve_table *t, double x) {
+  if (x <= t->x[0]) return t->v[0];
+  if (x >= t->x[t->n - 1]) return t->v[t->n - 1];
+  int i = 0;
+  while (i + 1 < t->n - 1 && x >= t->x[i + 1]) i++;
+  double x0 = t->x[i], x1 = t->x[i + 1], v0 = t->v[i], v1 = t->v[i + 1];
+  if (t->interp == 1) return v0;
+  if (t->interp == 2) {
+    double h = x1 - x0, delta = (v1 - v0) / h;
+    double del1 = (t->d[i] - delta) / h, del2 = (t->d[i + 1] - delta) / h;
+    double c2 = -(2.0 * del1 + del2), c3 = (del1 + del2) / h, dx = x - x0;
+    return v0 + dx * (t->d[i] + dx * (c2 + dx * c3));
+  }
+  double xi = (x - x0) / (x1 - x0);
+  return (1.0 - xi) * v0 + xi * v1;
+}
+static void eos_relperm(const wo_eos *e, double sl, double rp[2]) {
+  if (e->rp_type == WO_RP_TABLE) {   /* relative_permeability_table_values :547-558 */
+    rp[0] = wo_curve_table_value(&e->tab[0], sl);
+    rp[1] = wo_curve_table_value(&e->tab[1], 1.0 - sl);
+  } else wo_relperm(e->rp_type, e->rp_par, sl, rp);
+}
+static double eos_capillary(const wo_eos *e, double sl, double t) {
+  if (e->cp_type == WO_CP_TABLE) return wo_curve_table_value(&e->tab[2], sl);   /* capillary_pressure.F90:349-358 */
+  return wo_capillary(e->cp_type, e->cp_par, sl, t);
+}
+
 void wo_relperm(int type, const double *par, double sl, double rp[2]) {
   switch (type) {
   case WO_RP_FULLY_MOBILE:
@@ -443,6 +507,12 @@ void wo_eos_init(wo_eos *e, int kind) {
   e->kind = kind;
   e->nc = 1;
   e->temperature = 20.0;
+  {   /* default tables: k_r = S on [0, 1] (relative_permeability.F90:513-516), P_c = 0 (capillary_pressure.F90:324-325) */
+    const double kr[4] = {0.0, 0.0, 1.0, 1.0}, pc[4] = {0.0, 0.0, 1.0, 0.0};
+    wo_eos_set_curve_table(e, 0, 0, 2, kr);
+    wo_eos_set_curve_table(e, 1, 0, 2, kr);
+    wo_eos_set_curve_table(e, 2, 0, 2, pc);
+  }
   if (kind == WO_EOS_W) { /* src/eos_w.F90:50-99 */
     e->np = 1; e->nph = 1; e->nmob = 1; e->isothermal = 1;
     e->scale[1][0] = 1.e6; e->scale[2][0] = 1.e6;
@@ -530,7 +600,7 @@ static int wce_phase_properties(const wo_eos *e, double *fl) {
   int phases = (int)lround(fl[F_PHASES]);
   double sl = fl[phase_off(e, 0) + PH_SAT];
   double rp[2];
-  wo_relperm(e->rp_type, e->rp_par, sl, rp);
+  eos_relperm(e, sl, rp);
   double gas_rho, gas_h;
   const int air = (e->kind == WO_EOS_WAE);
   const double gas_mw = air ? AIR_MW : CO2_MW;
@@ -542,7 +612,7 @@ static int wce_phase_properties(const wo_eos *e, double *fl) {
       double water_pressure, cap, henry, esol;
       if (p == 0) {
         water_pressure = P;
-        cap = wo_capillary(e->cp_type, e->cp_par, sl, T);
+        cap = eos_capillary(e, sl, T);
         henry = air ? wo_air_henrys_constant(T) : wo_co2_henrys_constant(T);
         esol = air ? wo_air_energy_solution(T) : wo_co2_energy_solution(T);
       } else {
@@ -602,8 +672,8 @@ int wo_eos_phase_properties(const wo_eos *e, const double *primary, double *fl) 
   int phases = (int)lround(fl[F_PHASES]);
   double sl = fl[phase_off(e, 0) + PH_SAT];
   double rp[2], cp[2];
-  wo_relperm(e->rp_type, e->rp_par, sl, rp);
-  cp[0] = wo_capillary(e->cp_type, e->cp_par, sl, T);
+  eos_relperm(e, sl, rp);
+  cp[0] = eos_capillary(e, sl, T);
   cp[1] = 0.0;
   for (int p = 0; p < e->nph; p++) {
     double *ph = fl + phase_off(e, p);
@@ -1138,8 +1208,8 @@ static int wse_phase_properties(const wo_eos *e, const double *primary, double *
   double sl = fl[phase_off(e, 0) + PH_SAT], ss = fl[phase_off(e, 2) + PH_SAT];
   double sle = sl / (1.0 - ss);
   double rp[2], cp[2];
-  wo_relperm(e->rp_type, e->rp_par, sle, rp);
-  cp[0] = wo_capillary(e->cp_type, e->cp_par, sle, T);
+  eos_relperm(e, sle, rp);
+  cp[0] = eos_capillary(e, sle, T);
   cp[1] = 0.0;
   const int gas = IS_WSGE(e), nc = e->nc;
   const double pw = fl[F_PP], pg = gas ? fl[F_PP + 2] : 0.0;   /* brine pressure, gas partial pressure */

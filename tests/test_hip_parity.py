@@ -464,3 +464,39 @@ def test_state_dependent_source_controls(FS, oracle):
         assert relmax(yg, yo[: yg.size]) < 1e-7
         dt *= 2
     sim.destroy(); osim.close()
+
+
+@pytest.mark.parametrize("interp", ["linear", "pchip", "step"])
+def test_table_curves(FS, oracle, interp):
+    """"table" relative permeability and capillary pressure curves (relative_permeability.F90:500-558,
+    capillary_pressure.F90:311-358, the three interpolation types of interpolation.F90) in the two-phase
+    lens: fluid records, residual and a time step against the oracle"""
+    rp = ("table", {"liquid": [[0, 0], [0.7, 0.01], [0.95, 0.99], [1, 1]],
+                    "vapour": [[0, 0], [0.05, 0.01], [0.3, 0.99], [1, 1]], "interpolation": interp})
+    cp = ("table", {"pressure": [[0, -5.0e5], [0.4, -1.0e5], [0.7, 0]], "interpolation": interp})
+    g, lm, prim, region = make_case(dims=(8, 8, 6), brick=(4, 4, 2), eos="we", lens=True)
+    sim = FS(lm, eos="we", relperm=rp, capillary=cp)
+    osim = ol.OracleSim(oracle, lm, 1, relperm=rp, capillary=cp)
+    sim.set_regions(region); osim.set_regions(region)
+    y = scaled(prim, region).ravel().copy()
+    yo = osim.yvec(y)
+    assert sim.pre_eval(0.0, y) == 0 and osim.pre_eval(yo) == 0
+    fg, fo = sim.fluid(), osim.fluid()
+    scale = np.maximum(np.abs(fo).max(axis=0), 1e-300)
+    assert (np.abs(fg - fo) / scale).max() < 1e-12
+    assert np.abs(fo[:, 7 + 4]).max() > 0 and (fo[:, 7 + 3] < 1.0).any()     # capillary pressure and k_r in play
+    n = sim.num_dof
+    L = osim.lhs()
+    f = np.zeros(n)
+    dt = 1.0e4
+    assert sim.residual(dt, dt, y, L, f) == 0
+    err, fo_ = osim.residual(yo, dt, L)
+    assert np.abs(f - fo_).max() <= 1e-11 * np.abs(fo_).max()
+    sim.set_opts(ksp_rtol=1e-10, ftol_rel=1e-9)
+    o = osim.opts(); o.ksp_rtol, o.ftol_rel = 1e-10, 1e-9
+    reason, nits, kits = sim.timestep(dt, dt, y)
+    r, ok = osim.timestep(yo, dt, o)
+    assert (reason > 0) == (r > 0)
+    if reason > 0:
+        assert nits == r and relmax(y, yo[: y.size]) < 1e-7
+    sim.destroy(); osim.close()

@@ -269,3 +269,20 @@ def test_flow_simulation_lhs_fixture(oracle):
     bal = np.zeros(1)
     oracle.wo_cell_balance(C.byref(e), ol.dp(fl), ol.dp(rock), ol.dp(bal))
     assert rel(bal[0], g["lhs"]) < g["tol"]
+
+
+def test_table_curves(oracle):
+    """relative_permeability_test.F90:251-313 (linear and pchip tables) and
+    capillary_pressure_test.F90:170-201"""
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_unit_values_tables.json")))
+    e = _eos(oracle, 1)
+    for interp in ("linear", "pchip"):
+        ol.set_curve_tables(oracle, e, relperm=("table", {"liquid": g["relperm"]["liquid"], "vapour": g["relperm"]["vapour"],
+                                                          "interpolation": interp}))
+        for sl, expected in g["relperm"][interp]:
+            kl = oracle.wo_curve_table_value(C.byref(e.tab[0]), sl)
+            kv = oracle.wo_curve_table_value(C.byref(e.tab[1]), 1.0 - sl)
+            assert abs(kl - expected[0]) <= g["tol"] and abs(kv - expected[1]) <= g["tol"], (interp, sl, kl, kv)
+    ol.set_curve_tables(oracle, e, capillary=("table", {"pressure": g["capillary"]["pressure"]}))
+    for sl, expected in g["capillary"]["cases"]:
+        assert abs(oracle.wo_curve_table_value(C.byref(e.tab[2]), sl) - expected) <= g["tol"] * 1e5

@@ -886,6 +886,11 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
   c->ep.perm_type = ed->perm_type;
   for (int i = 0; i < 3; i++) c->ep.perm_par[i] = ed->perm_par[i];
   for (int i = 0; i < 6; i++) { c->ep.rp_par[i] = ed->rp_par[i]; c->ep.cp_par[i] = ed->cp_par[i]; }
+  for (int w = 0; w < 3; w++) {   // default tables of the reference: k_r = S on [0, 1]; P_c = 0
+    CurveTable& t = c->ep.tab[w];
+    t.n = 2; t.interp = 0;
+    t.x[0] = 0.0; t.x[1] = 1.0; t.v[0] = 0.0; t.v[1] = w < 2 ? 1.0 : 0.0;
+  }
 
   DeviceMesh& m = c->mesh;
   m.n_owned = md->n_owned; m.n_halo = md->n_halo; m.n_bc = md->n_bc;
@@ -1079,6 +1084,47 @@ int wai_get_regions(wai_ctx* c, int* region) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(r.data(), c->flu + (size_t)F_REGION * c->mesh.n_local, n * sizeof(double), hipMemcpyDeviceToHost));
   for (int i = 0; i < n; i++) region[i] = (int)std::lround(r[i]);
+  return 0;
+}
+
+// Fritsch-Carlson derivatives of a PCHIP table (src/interpolation.F90:810-885, after SLATEC's PCHIM)
+static void pchip_derivatives(int n, const double* x, const double* f, double* d) {
+  auto sign_test = [](double a, double b) { return (a > 0.0 && b > 0.0) || (a < 0.0 && b < 0.0) ? 1 : ((a == 0.0 || b == 0.0) ? 0 : -1); };
+  if (n == 1) { d[0] = 0.0; return; }
+  double h1 = x[1] - x[0], del1 = (f[1] - f[0]) / h1;
+  if (n == 2) { d[0] = d[1] = del1; return; }
+  double h2 = x[2] - x[1], del2 = (f[2] - f[1]) / h2, hsum = h1 + h2;
+  double w1 = (h1 + hsum) / hsum, w2 = -h1 / hsum;
+  d[0] = w1 * del1 + w2 * del2;
+  if (sign_test(d[0], del1) <= 0) d[0] = 0.0;
+  else if (sign_test(del1, del2) < 0) { const double dmax = 3.0 * del1; if (std::fabs(d[0]) > std::fabs(dmax)) d[0] = dmax; }
+  for (int i = 1; i < n - 1; i++) {
+    if (i > 1) { h1 = h2; h2 = x[i + 1] - x[i]; hsum = h1 + h2; del1 = del2; del2 = (f[i + 1] - f[i]) / h2; }
+    if (sign_test(del1, del2) > 0) {
+      w1 = (hsum + h1) / (3.0 * hsum); w2 = (hsum + h2) / (3.0 * hsum);
+      const double dmax = std::max(std::fabs(del1), std::fabs(del2)), dmin = std::min(std::fabs(del1), std::fabs(del2));
+      d[i] = dmin / (w1 * (del1 / dmax) + w2 * (del2 / dmax));
+    } else d[i] = 0.0;
+  }
+  w1 = -h2 / hsum; w2 = (h2 + hsum) / hsum;
+  d[n - 1] = w1 * del1 + w2 * del2;
+  if (sign_test(d[n - 1], del2) <= 0) d[n - 1] = 0.0;
+  else if (sign_test(del1, del2) < 0) { const double dmax = 3.0 * del2; if (std::fabs(d[n - 1]) > std::fabs(dmax)) d[n - 1] = dmax; }
+}
+
+int wai_set_curve_table(wai_ctx* c, int which, int interpolation, int n, const double* xy) {
+  if (!c || !xy) return -2;
+  if (which < 0 || which > 2 || n < 1 || n > MAX_CURVE_POINTS || interpolation < 0 || interpolation > 2) {
+    c->err = "curve table: which 0..2, 1..12 points, interpolation 0..2";
+    return -2;
+  }
+  CurveTable& t = c->ep.tab[which];
+  t.n = n; t.interp = interpolation;
+  for (int i = 0; i < n; i++) {
+    t.x[i] = xy[2 * i]; t.v[i] = xy[2 * i + 1]; t.d[i] = 0.0;
+    if (i > 0 && !(t.x[i] > t.x[i - 1])) { c->err = "curve table coordinates must increase strictly"; return -2; }
+  }
+  if (interpolation == WAI_INTERP_PCHIP) pchip_derivatives(n, t.x, t.v, t.d);
   return 0;
 }
 

@@ -26,8 +26,8 @@ template <int KIND> constexpr bool is_wsge = (KIND == EOS_WSCE || KIND == EOS_WS
 template <int KIND> constexpr bool is_salt = (KIND == EOS_WSE || is_wsge<KIND>);
 template <int KIND> constexpr bool gas_is_air = (KIND == EOS_WAE || KIND == EOS_WSAE);
 enum { RP_FULLY_MOBILE = 0, RP_LINEAR = 1, RP_PICKENS = 2, RP_COREY = 3, RP_GRANT = 4,
-       RP_VAN_GENUCHTEN = 5 };
-enum { CP_ZERO = 0, CP_LINEAR = 1, CP_VAN_GENUCHTEN = 2 };
+       RP_VAN_GENUCHTEN = 5, RP_TABLE = 6 };
+enum { CP_ZERO = 0, CP_LINEAR = 1, CP_VAN_GENUCHTEN = 2, CP_TABLE = 3 };
 
 // fluid record field indices (fluid.F90:212-267): 6 bulk fields, nc partial pressures, then per
 // phase 7 scalars + nc mass fractions
@@ -68,6 +68,15 @@ template <> struct EosT<EOS_WSAE> {  // water + salt + air + energy (eos_wsae.F9
   static constexpr bool isothermal = false;
 };
 
+// piecewise table curve (interpolation_table_type, src/interpolation.F90): n points (x, v), end values
+// held outside the data (:494-510); interpolation 0 linear (:388-404), 1 step (:715-720), 2 pchip with
+// the Fritsch-Carlson derivatives d computed once on the host (:761-887, polynomial of :891-925)
+constexpr int MAX_CURVE_POINTS = 12;
+struct CurveTable {
+  int n, interp;
+  double x[MAX_CURVE_POINTS], v[MAX_CURVE_POINTS], d[MAX_CURVE_POINTS];
+};
+
 // run-time EOS parameters (kernel argument, lives in SGPRs / constant cache)
 struct EosParams {
   double temperature;     // eos_w
@@ -78,6 +87,7 @@ struct EosParams {
   int thermo;             // "thermodynamics": THERMO_IAPWS (default) | THERMO_IFC67
   int perm_type;          // eos wse permeability modifier: 0 none, 1 power, 2 Verma-Pruess
   double perm_par[3];     // exponent, phir, gamma
+  CurveTable tab[3];      // "table" curves: liquid / vapour relative permeability, capillary pressure
 };
 
 // thermodynamic formulation dispatch (thermodynamics_type: src/thermodynamics.F90, IAPWS.F90,
@@ -113,9 +123,33 @@ __device__ __forceinline__ double lin2(double x, double x0, double x1, double y0
   return (1.0 - xi) * y0 + xi * y1;
 }
 
+// interpolation_table_interpolate (src/interpolation.F90:533-543): index with val(i) <= x < val(i+1),
+// clamped to the end values
+__device__ __forceinline__ double curve_table(const CurveTable& t, double x) {
+  if (x <= t.x[0]) return t.v[0];
+  if (x >= t.x[t.n - 1]) return t.v[t.n - 1];
+  int i = 0;
+  for (int k = 1; k < MAX_CURVE_POINTS - 1; k++)
+    if (k < t.n - 1 && x >= t.x[k]) i = k;
+  const double x0 = t.x[i], x1 = t.x[i + 1], v0 = t.v[i], v1 = t.v[i + 1];
+  if (t.interp == 1) return v0;
+  if (t.interp == 2) {
+    const double h = x1 - x0, delta = (v1 - v0) / h;
+    const double del1 = (t.d[i] - delta) / h, del2 = (t.d[i + 1] - delta) / h;
+    const double c2 = -(2.0 * del1 + del2), c3 = (del1 + del2) / h, dx = x - x0;
+    return v0 + dx * (t.d[i] + dx * (c2 + dx * c3));
+  }
+  const double xi = (x - x0) / (x1 - x0);
+  return (1.0 - xi) * v0 + xi * v1;
+}
+
 __device__ __forceinline__ void relperm(const EosParams& e, double sl, double& kl, double& kv) {
   const double* par = e.rp_par;
   switch (e.rp_type) {
+    case RP_TABLE:   // relative_permeability_table_values, src/relative_permeability.F90:547-558
+      kl = curve_table(e.tab[0], sl);
+      kv = curve_table(e.tab[1], 1.0 - sl);
+      break;
     case RP_FULLY_MOBILE: kl = 1.0; kv = 1.0; break;
     case RP_LINEAR:
       kl = lin2(sl, par[0], par[1], 0.0, 1.0);
@@ -154,6 +188,7 @@ __device__ __forceinline__ void relperm(const EosParams& e, double sl, double& k
 __device__ __forceinline__ double capillary(const EosParams& e, double sl) {
   const double* par = e.cp_par;
   switch (e.cp_type) {
+    case CP_TABLE: return curve_table(e.tab[2], sl);   // src/capillary_pressure.F90:349-358
     case CP_LINEAR: return lin2(sl, par[0], par[1], -fabs(par[2]), 0.0);
     case CP_VAN_GENUCHTEN: {
       const double eps = 1.e-3;

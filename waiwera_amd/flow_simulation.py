@@ -44,6 +44,14 @@ class FlowSimulation:
         if rc != 0:
             msg = LIB.wai_last_error(h).decode() if h else "?"
             raise WaiError("wai_ctx_create failed (%d): %s" % (rc, msg))
+        # "table" curves (before the boundary fluid is evaluated in wai_set_bc)
+        for spec, keys in ((relperm, ((0, "liquid", [[0, 0], [1, 1]]), (1, "vapour", [[0, 0], [1, 1]]))),
+                           (capillary, ((2, "pressure", [[0, 0], [1, 0]]),))):
+            if spec[0] == "table":
+                for which, key, default in keys:
+                    xy = _lib._f64(spec[1].get(key, default))
+                    self._chk(LIB.wai_set_curve_table(h, which, _lib.INTERP[spec[1].get("interpolation", "linear")],
+                                                      len(xy), xy.ctypes.data_as(_lib.pd)), "set_curve_table")
         self.num_primary_variables = LIB.wai_block_size(h)
         self.fluid_dof = LIB.wai_num_fluid_dof(h)
         self.n_owned, self.n_prim, self.n_local = mesh.n_owned, mesh.n_prim, mesh.n_local

@@ -14,8 +14,9 @@ EOS_W, EOS_WE, EOS_WCE, EOS_WSE, EOS_WAE, EOS_WSCE, EOS_WSAE = 0, 1, 2, 3, 4, 5,
 EOS_KIND = {"w": EOS_W, "we": EOS_WE, "wce": EOS_WCE, "wse": EOS_WSE, "wae": EOS_WAE, "wsce": EOS_WSCE,
             "wsae": EOS_WSAE}
 RP = {"fully_mobile": 0, "fully mobile": 0, "linear": 1, "pickens": 2, "corey": 3, "grant": 4,
-      "van_genuchten": 5, "van genuchten": 5}
-CP = {"zero": 0, "linear": 1, "van_genuchten": 2, "van genuchten": 2}
+      "van_genuchten": 5, "van genuchten": 5, "table": 6}
+CP = {"zero": 0, "linear": 1, "van_genuchten": 2, "van genuchten": 2, "table": 3}
+INTERP = {"linear": 0, "step": 1, "pchip": 2}   # src/interpolation.F90:139-156
 KSP = {"bcgs": 0, "gmres": 1}
 PC = {"bjacobi": 0, "asm": 1, "none": 2}   # linear.preconditioner.type (src/timestepper.F90:1745-1757)
 KCLASS = ["eos", "residual", "jacobian", "spmv", "pc_apply", "pc_setup", "vector", "transitions"]
@@ -109,6 +110,7 @@ def _load():
         "wai_last_error": (C.c_char_p, [vp]),
         "wai_set_opts": (i32, [vp, C.POINTER(SolverOpts)]),
         "wai_set_bc": (i32, [vp, pd, pi]),
+        "wai_set_curve_table": (i32, [vp, i32, i32, i32, pd]),
         "wai_set_sources": (i32, [vp, i32, pi, pd, pd, pi]),
         "wai_update_sources": (i32, [vp, pd, pd]),
         "wai_set_source_controls": (i32, [vp, C.POINTER(SourceControl)]),
@@ -215,11 +217,13 @@ def eos_desc(kind="we", temperature=20.0, relperm=("linear", [0.0, 1.0, 0.0, 1.0
     e.pressure_scale = pressure_scale
     e.temperature_scale = temperature_scale
     e.rp_type = RP[relperm[0]]
-    for k, v in enumerate(relperm[1]):
-        e.rp_par[k] = v
+    if relperm[0] != "table":      # ("table", {"liquid": [[S, k], ...], "vapour": ..., "interpolation": ...})
+        for k, v in enumerate(relperm[1]):
+            e.rp_par[k] = v
     e.cp_type = CP[capillary[0]]
-    for k, v in enumerate(capillary[1]):
-        e.cp_par[k] = v
+    if capillary[0] != "table":    # ("table", {"pressure": [[S, P], ...], "interpolation": ...})
+        for k, v in enumerate(capillary[1]):
+            e.cp_par[k] = v
     e.thermo = THERMO[thermo]
     if permeability_modifier is not None:     # (type, [exponent, phir, gamma]), eos wse only
         e.perm_type = PERM[permeability_modifier[0].lower()]

@@ -69,6 +69,12 @@ def relperm_spec(rp):
     if t in ("van genuchten", "van_genuchten"):
         return "van_genuchten", [rp.get("lambda", 0.45), rp.get("slr", 1.0e-3), rp.get("sls", 1.0),
                                  1.0 if rp.get("sum_unity", True) else 0.0, rp.get("ssr", 0.6)]
+    if t == "table":   # src/relative_permeability.F90:500-543
+        spec = {"interpolation": rp.get("interpolation", "linear")}
+        for k in ("liquid", "vapour"):
+            if rp.get(k) is not None:
+                spec[k] = [list(map(float, row)) for row in rp[k]]
+        return "table", spec
     raise NotImplementedError("relative permeability type %r" % t)
 
 
@@ -87,6 +93,11 @@ def capillary_spec(cp):
         pmax = cp.get("Pmax")
         return "van_genuchten", [cp.get("P0", 0.125e5), cp.get("lambda", 0.45), cp.get("slr", 1.0e-3),
                                  cp.get("sls", 1.0), pmax if pmax is not None else 0.0, 1.0 if pmax is not None else 0.0]
+    if t == "table":   # src/capillary_pressure.F90:311-345
+        spec = {"interpolation": cp.get("interpolation", "linear")}
+        if cp.get("pressure") is not None:
+            spec["pressure"] = [list(map(float, row)) for row in cp["pressure"]]
+        return "table", spec
     raise NotImplementedError("capillary pressure type %r" % t)
 
 
