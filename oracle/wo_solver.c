@@ -1225,6 +1225,78 @@ static int ksp_gmres(wo_sim *s, int m, const double *val, const double *b, doubl
   return reason;
 }
 
+/* KSPBCGSL [PETSc]: BiCGStab(L) of Sleijpen & Fokkema (ETNA 1, 1993), L = 2 (PETSc's default ell),
+ * no residual replacement (delta 0), minimum-residual polynomial from the normal equations; left
+ * preconditioning, preconditioned residual norm tested after every sweep of L BiCG steps, which
+ * count as L iterations.  "linear.type": "bcgsl", src/timestepper.F90:1733-1734. */
+static int ksp_bcgsl(wo_sim *s, const double *val, const double *b, double *x, double rtol,
+                     double atol, int maxits, int *its, double *rnorm, double *hist) {
+  enum { L = 2 };
+  int bs = ksp_bs(s), n = bs * s->n_owned, nl = bs * s->n_prim;
+  double *r[L + 1], *u[L + 1];
+  for (int j = 0; j <= L; j++) { r[j] = xmalloc(sizeof(double) * nl); u[j] = xmalloc(sizeof(double) * nl); }
+  double *rt = xmalloc(sizeof(double) * n), *tmp = xmalloc(sizeof(double) * n);
+  int reason = 0;
+  memset(x, 0, sizeof(double) * n);
+  pc_apply(s, b, r[0]);
+  memcpy(rt, r[0], sizeof(double) * n);
+  double dp = sqrt(gdot(s, r[0], r[0], n)), dp0 = dp, ttol = fmax(rtol * dp, atol);
+  if (hist) hist[0] = dp;
+  *its = 0;
+  if (dp <= ttol) reason = (dp <= atol) ? 3 : 2;
+  double rho0 = 1.0, alpha = 0.0, omega = 1.0;
+  while (!reason && *its < maxits) {
+    rho0 = -omega * rho0;
+    for (int j = 0; j < L && !reason; j++) {
+      double rho1 = gdot(s, r[j], rt, n);
+      if (rho0 == 0.0) { reason = -5; break; }
+      double beta = alpha * (rho1 / rho0);
+      rho0 = rho1;
+      for (int i = 0; i <= j; i++)
+        for (int q = 0; q < n; q++) u[i][q] = r[i][q] - beta * u[i][q];
+      pc_amul(s, val, u[j], tmp, u[j + 1]);
+      double gamma = gdot(s, u[j + 1], rt, n);
+      if (gamma == 0.0) { reason = -5; break; }
+      alpha = rho0 / gamma;
+      for (int i = 0; i <= j; i++)
+        for (int q = 0; q < n; q++) r[i][q] -= alpha * u[i + 1][q];
+      pc_amul(s, val, r[j], tmp, r[j + 1]);
+      for (int q = 0; q < n; q++) x[q] += alpha * u[0][q];
+    }
+    if (reason) break;
+    /* minimum-residual part: g = argmin || r_0 - sum_j g_j r_j ||, j = 1..L */
+    double Z[L][L], z[L], g[L];
+    for (int i = 0; i < L; i++) {
+      for (int j = i; j < L; j++) Z[i][j] = Z[j][i] = gdot(s, r[i + 1], r[j + 1], n);
+      z[i] = gdot(s, r[i + 1], r[0], n);
+    }
+    double det = Z[0][0] * Z[1][1] - Z[0][1] * Z[1][0];
+    if (det == 0.0) { reason = -5; break; }
+    g[0] = (z[0] * Z[1][1] - z[1] * Z[0][1]) / det;
+    g[1] = (Z[0][0] * z[1] - Z[1][0] * z[0]) / det;
+    for (int j = 0; j < L; j++)
+      for (int q = 0; q < n; q++) {
+        x[q] += g[j] * r[j][q];
+        u[0][q] -= g[j] * u[j + 1][q];
+      }
+    for (int j = 0; j < L; j++)   /* after x: r_0 is an input of the x update above for j = 0 */
+      for (int q = 0; q < n; q++) r[0][q] -= g[j] * r[j + 1][q];
+    omega = g[L - 1];
+    *its += L;
+    dp = sqrt(gdot(s, r[0], r[0], n));
+    if (hist) { hist[*its - 1] = dp; hist[*its] = dp; }
+    if (isnan(dp)) reason = -9;
+    else if (dp <= ttol) reason = (dp <= atol) ? 3 : 2;
+    else if (dp >= 1.e4 * dp0) reason = -4;
+    else if (omega == 0.0) reason = -5;
+  }
+  if (!reason) reason = -3;
+  *rnorm = dp;
+  for (int j = 0; j <= L; j++) { free(r[j]); free(u[j]); }
+  free(rt); free(tmp);
+  return reason;
+}
+
 int wo_ksp_solve(wo_sim *s, int ksp_type, int restart, const double *val, const double *b,
                  double *x, double rtol, double atol, int maxits, int *its, double *rnorm,
                  double *hist) {
@@ -1233,6 +1305,7 @@ int wo_ksp_solve(wo_sim *s, int ksp_type, int restart, const double *val, const 
   if (pc_setup(s, val)) return -11; /* KSP_DIVERGED_PC_FAILED */
   if (ksp_type == 1) return ksp_gmres(s, restart > 0 ? restart : 30, val, b, x, rtol, atol,
                                       maxits, its, rnorm, hist);
+  if (ksp_type == 2) return ksp_bcgsl(s, val, b, x, rtol, atol, maxits, its, rnorm, hist);
   return ksp_bcgs(s, val, b, x, rtol, atol, maxits, its, rnorm, hist);
 }
 

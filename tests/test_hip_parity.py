@@ -473,7 +473,7 @@ def test_table_curves(FS, oracle, interp):
     lens: fluid records, residual and a time step against the oracle"""
     rp = ("table", {"liquid": [[0, 0], [0.7, 0.01], [0.95, 0.99], [1, 1]],
                     "vapour": [[0, 0], [0.05, 0.01], [0.3, 0.99], [1, 1]], "interpolation": interp})
-    cp = ("table", {"pressure": [[0, -5.0e5], [0.4, -1.0e5], [0.7, 0]], "interpolation": interp})
+    cp = ("table", {"pressure": [[0, -5.0e5], [0.4, -1.0e5], [0.85, -2.0e4], [1, 0]], "interpolation": interp})
     g, lm, prim, region = make_case(dims=(8, 8, 6), brick=(4, 4, 2), eos="we", lens=True)
     sim = FS(lm, eos="we", relperm=rp, capillary=cp)
     osim = ol.OracleSim(oracle, lm, 1, relperm=rp, capillary=cp)

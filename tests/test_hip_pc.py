@@ -141,3 +141,19 @@ def test_bicgstab_with_merged_reductions(oracle, eos, brick, monkeypatch):
     assert reason > 0 and oreason > 0
     assert relmax(x, xo) < 1e-8 and abs(its - oits) <= max(2, oits // 10)
     sim.destroy(); osim.close()
+
+
+@pytest.mark.parametrize("eos,pc", [("we", "bjacobi"), ("wce", "bjacobi"), ("we", "asm")])
+def test_bcgsl(oracle, eos, pc):
+    """BiCGStab(2) ("linear.type": "bcgsl") against the oracle's restatement"""
+    lm, sim, osim, J, f = system(oracle, eos, (8, 8, 6), (4, 4, 2), lens=(eos == "we"))
+    n = sim.num_dof
+    sim.set_opts(ksp_type="bcgsl", pc_type=pc, ksp_rtol=1e-12)
+    if pc == "asm":
+        osim.set_asm(1)
+    x = np.zeros(n)
+    its, reason, rn = sim.ksp_solve(f, x)
+    oreason, xo, oits, hist = osim.ksp_solve(J, f, ksp_type=2, rtol=1e-12)
+    assert reason > 0 and oreason > 0 and its % 2 == 0
+    assert relmax(x, xo) < 1e-8 and abs(its - oits) <= max(2, oits // 10)
+    sim.destroy(); osim.close()

@@ -219,3 +219,17 @@ def test_asm_cuts_or_keeps_krylov_iterations(oracle):
         res[overlap] = (x, its)
     assert np.allclose(res[0][0], res[1][0], rtol=1e-6, atol=1e-9 * np.abs(res[0][0]).max())
     sim.close()
+
+
+def test_bcgsl_solves_to_the_dense_solution(oracle):
+    """BiCGStab(2): same solution as a dense solve, and no more preconditioned operator applications
+    than BiCGStab needs plus one sweep"""
+    lm, sim, y, L, f, J, dt = setup(oracle, dims=(8, 8, 6), brick=(4, 4, 2), lens=True, dt=1.0e5)
+    A = to_bsr(sim, J).toarray()[:, : sim.n_owned * sim.np]
+    xd = np.linalg.solve(A, f)
+    r1, x1, its1, h1 = sim.ksp_solve(J, f, ksp_type=0, rtol=1e-11)
+    r2, x2, its2, h2 = sim.ksp_solve(J, f, ksp_type=2, rtol=1e-11)
+    assert r1 > 0 and r2 > 0 and its2 % 2 == 0
+    assert np.allclose(x2, xd, rtol=1e-7, atol=1e-9 * np.abs(xd).max())
+    assert its2 <= its1 + 4
+    sim.close()

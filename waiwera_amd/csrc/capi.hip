@@ -676,6 +676,102 @@ int ksp_gmres(wai_ctx* c, const double* b, double* x, int* its, int* reason, dou
   return 0;
 }
 
+// up to two inner products brought to the host: (a1,b1) -> out[0], (a2,b2) -> out[1] (a2 null: one);
+// one all-reduce on several ranks
+int host_dots(wai_ctx* c, const double* a1, const double* b1, const double* a2, const double* b2, double* out) {
+  Krylov& k = c->ks;
+  {
+    Prof p(c, KC_VECTOR);
+    vec_dots(c, a1, b1, S_D1, a2, b2, S_D2, k.n);
+    vec_finalize(c, k.nb_pc, S_D1, a2 ? 2 : 1, -1);
+    if (allreduce_scal(c, S_D1, a2 ? 2 : 1)) return -1;
+  }
+  if (read_scal(c, S_D1, 2)) return -1;
+  out[0] = k.h_scal[S_D1];
+  if (a2) out[1] = k.h_scal[S_D2];
+  return 0;
+}
+
+// KSPBCGSL [PETSc]: BiCGStab(L), L = 2 (PETSc's default), of Sleijpen & Fokkema; left preconditioning,
+// preconditioned residual norm tested after every sweep of L BiCG steps (counted as L iterations);
+// "linear.type": "bcgsl", src/timestepper.F90:1733-1734.  The preconditioned operator runs on the
+// fused kernels; the vector updates and inner products use the generic vector kernels with the
+// scalars formed on the host (the documented use of this solver is the occasional ill-conditioned
+// system, not the headline path).
+int ksp_bcgsl(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
+  constexpr int L = 2;
+  Krylov& k = c->ks;
+  const int n = k.n;
+  const size_t nl = (size_t)k.nl;
+  if (!k.bl) {
+    if (dev_alloc(c, &k.bl, (2 * (L + 1) + 1) * (nl + 16))) return -1;
+    HIPCHK(c, hipMemsetAsync(k.bl, 0, (2 * (L + 1) + 1) * (nl + 16) * sizeof(double), c->stream));
+  }
+  double *r[L + 1], *u[L + 1];
+  for (int j = 0; j <= L; j++) { r[j] = k.bl + (size_t)j * (nl + 16); u[j] = k.bl + (size_t)(L + 1 + j) * (nl + 16); }
+  double* rt = k.bl + (size_t)(2 * (L + 1)) * (nl + 16);
+  const double rtol = c->opts.ksp_rtol, atol = c->opts.ksp_atol;
+  const int maxits = c->opts.ksp_max_its;
+  vec_zero(c, x, n);
+  for (int j = 0; j <= L; j++) vec_zero(c, u[j], nl);
+  { Prof p(c, KC_PC_APPLY); if (pc_solve(c, b, r[0], 0, nullptr, nullptr)) return -1; }
+  vec_copy(c, rt, r[0], n);
+  double d[2];
+  if (host_dots(c, r[0], r[0], nullptr, nullptr, d)) return -1;
+  double dp = std::sqrt(d[0]);
+  const double dp0 = dp, ttol = std::max(rtol * dp, atol);
+  *its = 0; *reason = 0;
+  if (std::isnan(dp)) *reason = -9;
+  else if (dp <= ttol) *reason = (dp <= atol) ? 3 : 2;
+  double rho0 = 1.0, alpha = 0.0, omega = 1.0;
+  while (!*reason && *its < maxits) {
+    rho0 = -omega * rho0;
+    for (int j = 0; j < L && !*reason; j++) {
+      if (host_dots(c, r[j], rt, nullptr, nullptr, d)) return -1;
+      const double rho1 = d[0];
+      if (rho0 == 0.0) { *reason = -5; break; }
+      const double beta = alpha * (rho1 / rho0);
+      rho0 = rho1;
+      for (int i = 0; i <= j; i++) vec_waxpy(c, u[i], -beta, u[i], r[i], n);     // u_i = r_i - beta u_i
+      if (pc_amul(c, u[j], u[j + 1])) return -1;
+      if (host_dots(c, u[j + 1], rt, nullptr, nullptr, d)) return -1;
+      if (d[0] == 0.0) { *reason = -5; break; }
+      alpha = rho0 / d[0];
+      for (int i = 0; i <= j; i++) vec_waxpy(c, r[i], -alpha, u[i + 1], r[i], n);  // r_i -= alpha u_{i+1}
+      if (pc_amul(c, r[j], r[j + 1])) return -1;
+      vec_waxpy(c, x, alpha, u[0], x, n);
+    }
+    if (*reason) break;
+    double Z[L][L], z[L], g[L], t2[2];
+    if (host_dots(c, r[1], r[1], r[1], r[2], t2)) return -1;
+    Z[0][0] = t2[0]; Z[0][1] = Z[1][0] = t2[1];
+    if (host_dots(c, r[2], r[2], r[1], r[0], t2)) return -1;
+    Z[1][1] = t2[0]; z[0] = t2[1];
+    if (host_dots(c, r[2], r[0], nullptr, nullptr, t2)) return -1;
+    z[1] = t2[0];
+    const double det = Z[0][0] * Z[1][1] - Z[0][1] * Z[1][0];
+    if (det == 0.0) { *reason = -5; break; }
+    g[0] = (z[0] * Z[1][1] - z[1] * Z[0][1]) / det;
+    g[1] = (Z[0][0] * z[1] - Z[1][0] * z[0]) / det;
+    for (int j = 0; j < L; j++) {
+      vec_waxpy(c, x, g[j], r[j], x, n);
+      vec_waxpy(c, u[0], -g[j], u[j + 1], u[0], n);
+    }
+    for (int j = 0; j < L; j++) vec_waxpy(c, r[0], -g[j], r[j + 1], r[0], n);
+    omega = g[L - 1];
+    *its += L;
+    if (host_dots(c, r[0], r[0], nullptr, nullptr, d)) return -1;
+    dp = std::sqrt(d[0]);
+    if (std::isnan(dp)) *reason = -9;
+    else if (dp <= ttol) *reason = (dp <= atol) ? 3 : 2;
+    else if (dp >= 1.e4 * dp0) *reason = -4;
+    else if (omega == 0.0) *reason = -5;
+  }
+  if (!*reason) *reason = -3;
+  *rnorm = dp;
+  return 0;
+}
+
 int do_ksp(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
   if (!c->ilu.factored) {
     const int e = do_pc_setup(c);
@@ -683,6 +779,7 @@ int do_ksp(wai_ctx* c, const double* b, double* x, int* its, int* reason, double
     if (e > 0) { *reason = -11; *its = 0; *rnorm = 0.0; return 0; }
   }
   if (c->opts.ksp_type == WAI_KSP_GMRES) return ksp_gmres(c, b, x, its, reason, rnorm);
+  if (c->opts.ksp_type == WAI_KSP_BCGSL) return ksp_bcgsl(c, b, x, its, reason, rnorm);
   return ksp_bcgs(c, b, x, its, reason, rnorm);
 }
 
@@ -785,7 +882,7 @@ void free_all(wai_ctx* c) {
   free_schedule(c->ilu);
   free_asm(c);
   Krylov& k = c->ks;
-  F(k.R); F(k.RP); F(k.P); F(k.V); F(k.S); F(k.T); F(k.tmp); F(k.X); F(k.basis); F(k.partials); F(k.scal);
+  F(k.R); F(k.RP); F(k.P); F(k.V); F(k.S); F(k.T); F(k.tmp); F(k.X); F(k.basis); F(k.bl); F(k.partials); F(k.scal);
   if (k.h_scal) (void)hipHostFree(k.h_scal);
   F(c->flu); F(c->flu_last_iter); F(c->flu_last_step); F(c->flu_pert); F(c->hstep);
   F(c->w_y); F(c->w_yold); F(c->w_delta); F(c->w_f); F(c->w_lhs); F(c->w_lhs2); F(c->w_hist); F(c->w_hist_prev);

@@ -131,6 +131,7 @@ struct Krylov {
   int n = 0, nl = 0;           // bs*n_owned, bs*n_prim
   double *R = nullptr, *RP = nullptr, *P = nullptr, *V = nullptr, *S = nullptr, *T = nullptr,
          *tmp = nullptr, *X = nullptr;
+  double* bl = nullptr;        // BiCGStab(L): r_0..r_L, u_0..u_L, r~ (allocated on first use)
   double* basis = nullptr;     // GMRES: (m+1) vectors of nl
   int basis_m = 0;
   double* partials = nullptr;  // [slots][nb_max]

@@ -134,7 +134,7 @@ __device__ __forceinline__ void ell_row_mult(int n, int W, int i, const int* __r
 // ---- K6: block SpMV --------------------------------------------------------------------------
 // rowptr (may be null): rows shorter than the block-ELL width (MINC matrix cells: 2 blocks of 8)
 // skip their padding slots instead of streaming zeros
-template <int BS>
+template <int BS, bool SHORT>
 __global__ __launch_bounds__(TPB) void k_spmv(int n, int W, int nblk, const int* __restrict__ col,
                                               const double* __restrict__ val, const int* __restrict__ rowptr,
                                               const double* __restrict__ x, double* __restrict__ y) {
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(TPB) void k_spmv(int n, int W, int nblk, const int*
   double acc[BS];
 #pragma unroll
   for (int r = 0; r < BS; r++) acc[r] = 0.0;
-  ell_row_mult<BS>(n, rowptr ? rowptr[i + 1] - rowptr[i] : W, i, col, val, x, acc);
+  ell_row_mult<BS>(n, SHORT ? rowptr[i + 1] - rowptr[i] : W, i, col, val, x, acc);
   if constexpr (BS == 2) store_z2(y, (size_t)i, acc[0], acc[1]);
   else {
 #pragma unroll
@@ -1282,10 +1282,10 @@ int launch_spmv(wai_ctx* c, const double* x, double* y) {
   const int grid = ((nblk + 7) / 8) * 8;
   const int* rp = (size_t)J.nnzb * 10 < (size_t)J.n * J.W * 9 ? J.rowptr : nullptr;   // > 10 % padding
   switch (J.bs) {
-    case 1: hipLaunchKernelGGL(k_spmv<1>, grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, rp, x, y); break;
-    case 2: hipLaunchKernelGGL(k_spmv<2>, grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, rp, x, y); break;
-    case 3: hipLaunchKernelGGL(k_spmv<3>, grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, rp, x, y); break;
-    case 4: hipLaunchKernelGGL(k_spmv<4>, grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, rp, x, y); break;
+    case 1: if (rp) hipLaunchKernelGGL((k_spmv<1, true>), grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, rp, x, y); else hipLaunchKernelGGL((k_spmv<1, false>), grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, rp, x, y); break;
+    case 2: if (rp) hipLaunchKernelGGL((k_spmv<2, true>), grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, rp, x, y); else hipLaunchKernelGGL((k_spmv<2, false>), grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, rp, x, y); break;
+    case 3: if (rp) hipLaunchKernelGGL((k_spmv<3, true>), grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, rp, x, y); else hipLaunchKernelGGL((k_spmv<3, false>), grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, rp, x, y); break;
+    case 4: if (rp) hipLaunchKernelGGL((k_spmv<4, true>), grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, rp, x, y); else hipLaunchKernelGGL((k_spmv<4, false>), grid, TPB, 0, c->stream, J.n, J.W, nblk, J.col, J.val, rp, x, y); break;
     default: return -1;
   }
   return 0;
