@@ -159,6 +159,35 @@ typedef struct wai_source_control {
   double sep_more[6]; /* (hf, hg) of separator stages 2..4; hg = 0 ends the list */
 } wai_source_control;
 int wai_set_source_controls(wai_ctx *ctx, const wai_source_control *controls);
+/* Source network: groups and reinjectors (src/source_network_group.F90, source_network_reinjector.F90;
+ * input "network.group" / "network.reinject"), evaluated on the host inside every residual evaluation,
+ * after the sources' own controls, as source_network%update is (src/source_network.F90:90-130):
+ *   group       sums its inputs (sources or earlier groups: rate, enthalpy, separated water / steam);
+ *               limiters on the total / water / steam rate scale the inputs back -- scaling 0 uniform
+ *               (one factor), 1 progressive (inputs in order until the limit is met);
+ *   reinjector  delivers the separated water / steam of its input (source or group; none: what an
+ *               upstream reinjector sends) to its outputs in order -- a rate, a proportion of the input
+ *               (-1: not given) or whatever is left, never more than the receiving source's own
+ *               specified rate -- and the rest to its overflow (a reinjector or a source).  Output
+ *               enthalpy: the given one (> 0) or the input's.
+ * Node references are (kind, index): 0 none, 1 source (wai_set_sources order), 2 group, 3 reinjector.
+ * rate_specified / enthalpy_specified per source: whether the input gives the source a rate (value or
+ * control) / an enthalpy of its own.  limit_type 0 total, 1 water, 2 steam, -1 unused (3 per group).
+ * The FD Jacobian differences with the network's factors held at the last pass: the couplings between
+ * cells that src/flow_simulation.F90:3023-3084 adds to the matrix are not there (inexact Newton).
+ * All sources of the network must live on this rank.  Call after wai_set_sources / controls. */
+int wai_set_source_network(wai_ctx *ctx, const int *rate_specified, const int *enthalpy_specified,
+                           int n_groups, const int *grp_ptr, const int *grp_in_kind, const int *grp_in,
+                           const int *grp_scaling, const int *grp_limit_type, const double *grp_limit,
+                           int n_reinjectors, const int *rj_in_kind, const int *rj_in, const int *rj_out_ptr,
+                           const int *out_flow, const int *out_kind, const int *out_node,
+                           const double *out_rate, const double *out_proportion, const double *out_enthalpy,
+                           const int *rj_overflow_kind, const int *rj_overflow);
+/* after the last pass: groups 6 doubles each (rate, enthalpy, water_rate, water_enthalpy, steam_rate,
+ * steam_enthalpy), reinjectors 8 each (output water / steam rate, overflow rate, enthalpy, water rate,
+ * water enthalpy, steam rate, steam enthalpy) -- the network_group / network_reinject output fields */
+int wai_get_source_network(wai_ctx *ctx, double *groups, double *reinjectors);
+
 /* enthalpies of saturated water and steam at a separator pressure, in the context's
  * thermodynamics (separator_stage_init, src/separator.F90:108-136): sep_hf, sep_hg above */
 int wai_separator_enthalpies(wai_ctx *ctx, double pressure, double *hf, double *hg);

@@ -184,3 +184,40 @@ def test_air_benchmarks():
     ends = [e for t, e in errs.items() if t > 3.0e8 or t < 4.0e7]
     assert len(ends) >= 2 and max(v[0] for e in ends for v in e.values()) < 5.0e-3
     sim.ode.destroy()
+
+
+@pytest.mark.parametrize("name,geometry", [("makeup_uniform", "gmakeup.dat"), ("makeup_progressive", "gmakeup.dat"),
+                                           ("reinjection", "greinjection.dat")])
+def test_source_networks_against_autough2(name, geometry):
+    """the reference's source/makeup and source/reinjection benchmarks from its own input files: a group
+    of three wells on deliverability behind separators with a steam limiter (uniform / progressive
+    scaling), and a group feeding a reinjector (rate, proportion and unrated outputs, an overflow
+    reinjector, an injection well on injectivity behind its own limiter).  The network pass runs on the
+    host inside every residual evaluation.  The reference's bars against AUTOUGH2: fields 2e-2,
+    histories 1.5e-2, source rates 6e-2 (test_reinjection.py)."""
+    from waiwera_amd.simulation import Simulation
+    fx = B.load_fixture("benchmark_source_networks.json")[name]
+    sim = Simulation.from_json(os.path.join(INPUTS, name + ".json"), mesh_file=os.path.join(INPUTS, geometry))
+    sim.run()
+    outs = sim.outputs
+    tg = np.array([o["time"] for o in outs])
+    ta = np.asarray(fx["times"])
+    assert abs(tg[-1] - ta[-1]) <= 1e-6 * ta[-1]
+    worst = {"Pressure": 0.0, "Temperature": 0.0, "Vapour saturation": 0.0, "rate": 0.0}
+    keys = {"Pressure": "fluid_pressure", "Temperature": "fluid_temperature", "Vapour saturation": "fluid_vapour_saturation"}
+    matched = 0
+    for k, t in enumerate(ta):
+        j = int(np.argmin(np.abs(tg - t)))
+        if abs(tg[j] - t) > 1e-4 * max(t, 1.0):
+            continue       # the step sequences differ: compare where both have an output
+        matched += 1
+        for f, key in keys.items():
+            a, g = np.asarray(fx["fields"][f][k]), outs[j][key]
+            scale = max(np.abs(a).max(), 1.0 if f != "Vapour saturation" else 1.0)
+            worst[f] = max(worst[f], np.abs(g - a).max() / scale)
+        ra, rg = np.asarray(fx["rates"][k]), outs[j]["source_rate"]
+        worst["rate"] = max(worst["rate"], np.abs(rg - ra).max() / max(np.abs(ra).max(), 1.0))
+    assert matched >= 10, matched
+    assert worst["Pressure"] < 2e-2 and worst["Temperature"] < 2e-2 and worst["Vapour saturation"] < 2e-2, worst
+    assert worst["rate"] < 6e-2, worst
+    sim.ode.destroy()

@@ -358,6 +358,31 @@ def source_controls():
     json.dump(out, open(os.path.join(OUT, "benchmark_source_controls.json"), "w"), indent=1)
 
 
+def source_networks():
+    """test/benchmark/source/makeup (group of three production wells behind separators, steam limiter,
+    uniform / progressive scaling) and source/reinjection (group -> reinjector with rate, proportion
+    and unrated outputs, overflow reinjector): AUTOUGH2's element and generation tables at every output.
+    The input files (data) are copied to tests/golden/inputs/ with their MULgraph geometry files."""
+    import shutil
+    out = {"source": "test/benchmark/source/{makeup,reinjection}/run/*.listing; inputs in tests/golden/inputs/"}
+    for bench, names, geo in (("makeup", ("makeup_uniform", "makeup_progressive"), "gmakeup.dat"),
+                              ("reinjection", ("reinjection",), "greinjection.dat")):
+        base = os.path.join(REF, "source", bench, "run")
+        shutil.copy(os.path.join(base, geo), os.path.join(OUT, "inputs", geo))
+        for name in names:
+            shutil.copy(os.path.join(base, name + ".json"), os.path.join(OUT, "inputs", name + ".json"))
+            elem = all_tables(os.path.join(base, name + ".listing"), "ELEMENT TABLE")
+            gen = all_tables(os.path.join(base, name + ".listing"), "GENERATION TABLE")
+            assert len(elem) == len(gen)
+            n = len(json.load(open(os.path.join(base, name + ".json")))["rock"]["types"][0]["cells"])
+            keep = [k for k in ("Pressure", "Temperature", "Vapour saturation") if k in elem[0][1]]
+            out[name] = {"times": [t for t, _ in elem],
+                         "fields": {k: [tab[k][-n:] for _, tab in elem] for k in keep},   # the atmosphere block comes first
+                         "rates": [tab["Generation rate"] for _, tab in gen],
+                         "enthalpies": [tab["Enthalpy"] for _, tab in gen]}
+    json.dump(out, open(os.path.join(OUT, "benchmark_source_networks.json"), "w"), indent=1)
+
+
 def wide_tables(listing, names):
     """every ELEMENT TABLE of a listing with 13-character columns whose names are cut off: rows of
     numbers by position -> [(time, {name: column})]"""
@@ -495,6 +520,7 @@ if __name__ == "__main__":
     problem6()
     tracer_doublet()
     source_controls()
+    source_networks()
     input_files()
     problem5("a")
     problem5("b")

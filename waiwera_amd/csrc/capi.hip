@@ -10,6 +10,7 @@
 #include <cstring>
 #include <numeric>
 #include "comm.hpp"
+#include <functional>
 #include "context.hpp"
 
 using namespace wai;
@@ -359,6 +360,210 @@ int read_scal(wai_ctx* c, int first, int count) {
   return 0;
 }
 
+// ---- source network: groups and reinjectors, one pass on the host -------------------------------
+// source_network%update (src/source_network.F90:90-130) after the sources' own controls: group sums
+// (source_network_group.F90:239-287) and limiters with uniform (:479-534) or progressive (:652-763;
+// array_progressive_limit, utils.F90:607-647) scaling, reinjector capacities
+// (source_network_reinjector.F90:1014-1112) and distribution with overflow (:1115-1292, :970-1010).
+// Serial: every source of the network lives on this rank.
+void net_separate(const SrcCtl& k, double rate, double enth, NetNode& n) {   // separator.F90:139-166, 212-260
+  double q = rate, h = enth, steam_m = 0.0, steam_e = 0.0;
+  for (int st = 0; st < 4; st++) {
+    const double hf = st == 0 ? k.sep_hf : k.sep_more[2 * (st - 1)], hg = st == 0 ? k.sep_hg : k.sep_more[2 * (st - 1) + 1];
+    if (st > 0 && !(hg > 0.0)) break;
+    double f, hw, hs;
+    if (h <= hf) { f = 0.0; hw = h; hs = 0.0; }
+    else if (h <= hg) { f = (h - hf) / (hg - hf); hw = hf; hs = hg; }
+    else { f = 1.0; hw = 0.0; hs = h; }
+    const double sr = f * q;
+    steam_m += sr; steam_e += sr * hs;
+    q = (1.0 - f) * q; h = hw;
+  }
+  n.wrate = q; n.wenth = h; n.srate = steam_m;
+  n.senth = std::fabs(steam_m) > 1.e-9 ? steam_e / steam_m : 0.0;
+}
+void net_zero_separated(NetNode& n) { n.wrate = n.wenth = n.srate = n.senth = 0.0; }
+void net_source_set_rate(Network& nw, int i, double rate) {   // source_network_node_set_rate + get_separated_flows
+  NetNode& n = nw.src[i];
+  n.rate = rate;
+  if (rate < 0.0 && i < (int)nw.h_ctl.size() && nw.h_ctl[i].sep_hg > 0.0) net_separate(nw.h_ctl[i], rate, n.enth, n);
+  else net_zero_separated(n);
+}
+NetNode& net_node(Network& nw, const NetRef& r) { return r.kind == 1 ? nw.src[r.index] : nw.groups[r.index].node; }
+double net_rate_by_type(const NetNode& n, int type) { return type == 1 ? n.wrate : (type == 2 ? n.srate : n.rate); }
+void net_group_sum(Network& nw, NetGroup& g) {   // source_network_group_sum + default_separated_flows
+  double q = 0.0, qh = 0.0;
+  for (const NetRef& r : g.in) { const NetNode& n = net_node(nw, r); q += n.rate; qh += n.rate * n.enth; }
+  g.node.enth = std::fabs(q) > 1.e-9 ? qh / q : 0.0;
+  g.node.rate = q;
+  if (q < 0.0) {
+    double wq = 0, wqh = 0, sq = 0, sqh = 0;
+    for (const NetRef& r : g.in) {
+      const NetNode& n = net_node(nw, r);
+      wq += n.wrate; wqh += n.wrate * n.wenth; sq += n.srate; sqh += n.srate * n.senth;
+    }
+    g.node.wrate = wq; g.node.srate = sq;
+    g.node.wenth = std::fabs(wq) > 1.e-9 ? wqh / wq : 0.0;
+    g.node.senth = std::fabs(sq) > 1.e-9 ? sqh / sq : 0.0;
+  } else net_zero_separated(g.node);
+}
+void net_scale(Network& nw, const NetRef& r, double scale) {   // scale_rate, recursive through groups
+  if (r.kind == 1) { net_source_set_rate(nw, r.index, nw.src[r.index].rate * scale); return; }
+  NetGroup& g = nw.groups[r.index];
+  for (const NetRef& q : g.in) net_scale(nw, q, scale);
+  net_group_sum(nw, g);
+}
+bool net_min_limit_scale(const NetNode& n, int nl, const int* type, const double* limit, double& scale) {
+  bool over = false;
+  scale = 1.0;
+  for (int i = 0; i < nl; i++) {
+    const double a = std::fabs(net_rate_by_type(n, type[i]));
+    if (a > limit[i]) { over = true; if (a > 1.e-6) scale = std::min(scale, limit[i] / a); }
+  }
+  return over;
+}
+void net_limit_inputs(Network& nw, const NetRef& r, int nl, const int* type, const double* limit);
+void net_limit_rate(Network& nw, const NetRef& r, int nl, const int* type, const double* limit) {
+  double scale;
+  if (r.kind == 1 || nw.groups[r.index].scaling == 0) {   // node / uniform group: one factor for everything below
+    if (net_min_limit_scale(net_node(nw, r), nl, type, limit, scale)) net_scale(nw, r, scale);
+    return;
+  }
+  bool over = false;
+  for (int i = 0; i < nl; i++) over = over || std::fabs(net_rate_by_type(nw.groups[r.index].node, type[i])) > limit[i];
+  if (over) net_limit_inputs(nw, r, nl, type, limit);
+}
+void net_limit_inputs(Network& nw, const NetRef& r, int nl, const int* type, const double* limit) {
+  if (r.kind == 1 || nw.groups[r.index].scaling == 0) { net_limit_rate(nw, r, nl, type, limit); return; }
+  NetGroup& g = nw.groups[r.index];   // progressive: inputs are limited in order until the total is met
+  const size_t m = g.in.size();
+  std::vector<double> node_limit(m * 3, 0.0);
+  for (int il = 0; il < nl; il++) {
+    double sum = 0.0;
+    for (size_t i = 0; i < m; i++) {
+      const double a = std::fabs(net_rate_by_type(net_node(nw, g.in[i]), type[il]));
+      if (sum + a > limit[il]) { node_limit[i * 3 + il] = limit[il] - sum; break; }
+      node_limit[i * 3 + il] = a;
+      sum += a;
+    }
+  }
+  for (size_t i = 0; i < m; i++) net_limit_inputs(nw, g.in[i], nl, type, &node_limit[i * 3]);
+  net_group_sum(nw, g);
+}
+void net_node_limit_rate(double node_rate, double& rate) {   // reinjector.F90:199-215
+  if (node_rate > -1.0) rate = rate > -1.0 ? std::min(rate, node_rate) : node_rate;
+}
+void net_total(double wr, double wh, double sr, double sh, double& rate, double& enth) {
+  rate = wr + sr;
+  enth = rate > 1.e-6 ? (wr * wh + sr * sh) / rate : 0.0;
+}
+
+int network_update(wai_ctx* c) {
+  Network& nw = c->net;
+  const int n = c->src.n;
+  if (!nw.on || n == 0) return 0;
+  // the sources' own (controlled) rates and flowing enthalpies on the current fluid
+  launch_source_rates(c, nw.d_raw, true);
+  HIPCHK(c, hipMemcpyAsync(nw.h_raw.data(), nw.d_raw, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; i++) { nw.src[i].enth = nw.h_raw[n + i]; net_source_set_rate(nw, i, nw.h_raw[i]); }
+  for (NetGroup& g : nw.groups) net_group_sum(nw, g);
+  for (size_t gi = 0; gi < nw.groups.size(); gi++) {
+    NetGroup& g = nw.groups[gi];
+    if (!g.n_limit) continue;
+    NetRef self; self.kind = 2; self.index = (int)gi;
+    net_limit_rate(nw, self, g.n_limit, g.limit_type, g.limit);
+    for (size_t gj = gi + 1; gj < nw.groups.size(); gj++) net_group_sum(nw, nw.groups[gj]);   // sum_out
+  }
+  // what the injection sources can take: their own specified rate, -1 if none
+  auto specified = [&](int i) { return nw.rate_specified[i] ? nw.h_raw[i] : -1.0; };
+  std::vector<double> out_rate(n, 0.0), out_enth(n, 0.0);
+  std::vector<char> is_out(n, 0);
+  for (NetReinjector& r : nw.reinjectors) r.fed = false;
+  for (int ri : nw.reinj_order) {   // capacities, downstream first
+    NetReinjector& r = nw.reinjectors[ri];
+    double cap[3] = {0.0, 0.0, 0.0};
+    for (const NetOutput& o : r.out) {
+      double node_rate = -1.0;
+      if (o.out.kind == 1) node_rate = specified(o.out.index);
+      else if (o.out.kind == 3) node_rate = o.flow == 1 ? nw.reinjectors[o.out.index].node.wrate : nw.reinjectors[o.out.index].node.srate;
+      else continue;
+      double& cc = cap[o.flow];
+      if (node_rate > -1.0) { if (cc > -1.0) cc += node_rate; } else cc = -1.0;
+    }
+    r.node.wrate = cap[1]; r.node.srate = cap[2];
+  }
+  for (auto it = nw.reinj_order.rbegin(); it != nw.reinj_order.rend(); ++it) {   // distribution, upstream first
+    NetReinjector& r = nw.reinjectors[*it];
+    if (r.in.kind == 1 || r.in.kind == 2) {
+      const NetNode& in = net_node(nw, r.in);
+      r.in_w = std::fabs(in.wrate); r.in_wh = in.wenth; r.in_s = std::fabs(in.srate); r.in_sh = in.senth;
+    } else if (!r.fed) { r.in_w = r.in_wh = r.in_s = r.in_sh = 0.0; }
+    double wbal = r.in_w, sbal = r.in_s;
+    r.out_w = r.out_s = 0.0;
+    for (NetOutput& o : r.out) {
+      double qw = 0.0, qs = 0.0;
+      double& q = o.flow == 1 ? qw : qs;
+      if (o.rate > -1.0) q = o.rate;                                              // rate output (:463-480)
+      else if (o.proportion >= 0.0) q = o.proportion * (o.flow == 1 ? r.in_w : r.in_s);   // proportion output (:484-501)
+      else q = -1.0;                                                              // whatever is left
+      double node_rate = -1.0;
+      if (o.out.kind == 1) node_rate = specified(o.out.index);
+      else if (o.out.kind == 3) node_rate = o.flow == 1 ? nw.reinjectors[o.out.index].node.wrate : nw.reinjectors[o.out.index].node.srate;
+      if (o.out.kind) net_node_limit_rate(node_rate, q);
+      double& bal = o.flow == 1 ? wbal : sbal;
+      double& tot = o.flow == 1 ? r.out_w : r.out_s;
+      if (q < 0.0) q = bal;
+      q = std::min(q, bal);
+      bal = std::max(bal - q, 0.0);
+      tot += q;
+      // enthalpies: specified for this flow type, or the input's
+      const double wh = (o.enthalpy > 0.0 && o.flow == 1) ? o.enthalpy : (o.enthalpy > 0.0 ? 0.0 : r.in_wh);
+      const double sh = (o.enthalpy > 0.0 && o.flow == 2) ? o.enthalpy : (o.enthalpy > 0.0 ? 0.0 : r.in_sh);
+      o.node.wrate = qw; o.node.wenth = wh; o.node.srate = qs; o.node.senth = sh;
+      net_total(qw, wh, qs, sh, o.node.rate, o.node.enth);
+      if (o.out.kind == 1) {
+        const int i = o.out.index;
+        is_out[i] = 1; out_rate[i] = o.node.rate; out_enth[i] = o.node.enth;
+      } else if (o.out.kind == 3) {
+        NetReinjector& d = nw.reinjectors[o.out.index];
+        if (!d.fed) { d.in_w = d.in_wh = d.in_s = d.in_sh = 0.0; d.fed = true; }
+        if (o.flow == 1) { d.in_w += qw; d.in_wh = wh; } else { d.in_s += qs; d.in_sh = sh; }
+      }
+    }
+    r.over.wrate = wbal; r.over.wenth = r.in_wh; r.over.srate = sbal; r.over.senth = r.in_sh;
+    net_total(wbal, r.in_wh, sbal, r.in_sh, r.over.rate, r.over.enth);
+    if (r.overflow.kind == 3) {
+      NetReinjector& d = nw.reinjectors[r.overflow.index];
+      d.in_w = wbal; d.in_wh = r.in_wh; d.in_s = sbal; d.in_sh = r.in_sh; d.fed = true;
+    } else if (r.overflow.kind == 1) {
+      const int i = r.overflow.index;
+      double q = r.over.rate;
+      net_node_limit_rate(specified(i), q);
+      is_out[i] = 1; out_rate[i] = q; out_enth[i] = r.over.enth;
+    }
+  }
+  // hand the result to the device: scale factors of group members, rates / enthalpies of reinjection sources
+  bool enth_changed = false;
+  for (int i = 0; i < n; i++) {
+    double mode = 0.0, val = 0.0;
+    if (is_out[i]) {
+      mode = 2.0; val = out_rate[i];
+      const double e = nw.enth_specified[i] ? nw.h_enth0[i] : out_enth[i];
+      if (e != nw.h_enth[i]) { nw.h_enth[i] = e; enth_changed = true; }
+      nw.src[i].rate = val; nw.src[i].enth = e;
+    } else if (nw.src[i].rate != nw.h_raw[i]) {
+      mode = 1.0; val = nw.h_raw[i] != 0.0 ? nw.src[i].rate / nw.h_raw[i] : 1.0;
+    }
+    nw.h_net[2 * i] = mode; nw.h_net[2 * i + 1] = val;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->src.net, nw.h_net.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
+  if (enth_changed)
+    HIPCHK(c, hipMemcpyAsync(c->src.enth, nw.h_enth.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // h_net / h_enth are reused by the next pass
+  return 0;
+}
+
 // ---- fluid_properties / pre_eval on device vectors -------------------------------------------
 int do_pre_eval(wai_ctx* c, double* y /* nl, device */) {
   if (c->comm && c->mesh.n_halo) {
@@ -379,6 +584,7 @@ int do_pre_eval(wai_ctx* c, double* y /* nl, device */) {
 int do_residual(wai_ctx* c, double dt, double* y, const double* lhs_old, double* f) {
   int e = do_pre_eval(c, y);
   if (e) return e;
+  if (c->net.on && network_update(c)) return -1;
   Prof p(c, KC_RESIDUAL);
   launch_residual(c, dt, lhs_old, f, nullptr, nullptr);
   return 0;
@@ -877,7 +1083,7 @@ void free_all(wai_ctx* c) {
   DeviceMesh& m = c->mesh;
   F(m.rock); F(m.vol); F(m.fgeom); F(m.fdir); F(m.adj_face); F(m.adj_other); F(m.adj_blk);
   F(m.diag_blk); F(m.cell_src);
-  F(c->src.cell); F(c->src.comp); F(c->src.next); F(c->src.rate); F(c->src.enth); F(c->src.ctl);
+  F(c->src.cell); F(c->src.comp); F(c->src.next); F(c->src.rate); F(c->src.enth); F(c->src.ctl); F(c->src.net); F(c->net.d_raw);
   F(c->J.rowptr); F(c->J.col); F(c->J.val);
   free_schedule(c->ilu);
   free_asm(c);
@@ -1262,7 +1468,7 @@ int wai_set_sources(wai_ctx* c, int n, const int* cell, const double* rate, cons
   if (!c || n < 0) return -2;
   Sources& s = c->src;
   auto F = [](void* p) { if (p) (void)hipFree(p); };
-  F(s.cell); F(s.comp); F(s.next); F(s.rate); F(s.enth); F(s.ctl);
+  F(s.cell); F(s.comp); F(s.next); F(s.rate); F(s.enth); F(s.ctl); F(s.net); F(c->net.d_raw);
   s = Sources();
   s.n = n;
   const int N = c->mesh.n_owned;
@@ -1279,6 +1485,8 @@ int wai_set_sources(wai_ctx* c, int n, const int* cell, const double* rate, cons
   if (dev_upload(c, &s.cell, vc) || dev_upload(c, &s.comp, vk) || dev_upload(c, &s.next, next) ||
       dev_upload(c, &s.rate, vr) || dev_upload(c, &s.enth, ve))
     return -1;
+  c->net = Network();   // a network refers to sources by index: set it again after the sources
+  c->net.h_enth0 = ve;
   return 0;
 }
 
@@ -1289,6 +1497,10 @@ int wai_update_sources(wai_ctx* c, const double* rate, const double* enthalpy) {
   if (rate) HIPCHK(c, hipMemcpyAsync(c->src.rate, rate, nb, hipMemcpyDefault, c->stream));
   if (enthalpy) HIPCHK(c, hipMemcpyAsync(c->src.enth, enthalpy, nb, hipMemcpyDefault, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (enthalpy && c->net.h_enth0.size() == (size_t)c->src.n && !is_device_ptr(enthalpy)) {
+    c->net.h_enth0.assign(enthalpy, enthalpy + c->src.n);
+    c->net.h_enth = c->net.h_enth0;
+  }
   return 0;
 }
 
@@ -1311,8 +1523,112 @@ int wai_set_source_controls(wai_ctx* c, const wai_source_control* controls) {
     }
   }
   if (!s.ctl) HIPCHK(c, hipMalloc(&s.ctl, sizeof(SrcCtl) * (size_t)s.n));
+  c->net.h_ctl.assign(reinterpret_cast<const SrcCtl*>(controls), reinterpret_cast<const SrcCtl*>(controls) + s.n);
   HIPCHK(c, hipMemcpyAsync(s.ctl, controls, sizeof(SrcCtl) * (size_t)s.n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// Source network (src/source_network_group.F90, source_network_reinjector.F90; input "network.group",
+// "network.reinject").  Node references are (kind, index) pairs: kind 0 none, 1 source, 2 group,
+// 3 reinjector.  Groups in dependency order (a group after the groups it takes in).
+int wai_set_source_network(wai_ctx* c, const int* rate_specified, const int* enthalpy_specified, int n_groups,
+                           const int* grp_ptr, const int* grp_in_kind, const int* grp_in, const int* grp_scaling,
+                           const int* grp_limit_type, const double* grp_limit, int n_reinj, const int* rj_in_kind,
+                           const int* rj_in, const int* rj_out_ptr, const int* out_flow, const int* out_kind,
+                           const int* out_node, const double* out_rate, const double* out_proportion,
+                           const double* out_enthalpy, const int* rj_overflow_kind, const int* rj_overflow) {
+  if (!c) return -2;
+  Network& nw = c->net;
+  const int n = c->src.n;
+  auto ctl = nw.h_ctl; auto e0 = nw.h_enth0;
+  if (nw.d_raw) (void)hipFree(nw.d_raw);
+  if (c->src.net) { (void)hipFree(c->src.net); c->src.net = nullptr; }
+  nw = Network();
+  nw.h_ctl = ctl; nw.h_enth0 = e0;
+  if (n_groups <= 0 && n_reinj <= 0) return 0;
+  if (!n || !rate_specified || !enthalpy_specified) { c->err = "source network without sources"; return -2; }
+  auto ok = [&](int kind, int idx) {
+    return kind == 0 || (kind == 1 && idx >= 0 && idx < n) || (kind == 2 && idx >= 0 && idx < n_groups) ||
+           (kind == 3 && idx >= 0 && idx < n_reinj);
+  };
+  nw.rate_specified.assign(rate_specified, rate_specified + n);
+  nw.enth_specified.assign(enthalpy_specified, enthalpy_specified + n);
+  nw.groups.resize(std::max(n_groups, 0));
+  for (int g = 0; g < n_groups; g++) {
+    NetGroup& G = nw.groups[g];
+    for (int q = grp_ptr[g]; q < grp_ptr[g + 1]; q++) {
+      if (!ok(grp_in_kind[q], grp_in[q]) || grp_in_kind[q] == 0 || grp_in_kind[q] == 3 || (grp_in_kind[q] == 2 && grp_in[q] >= g)) {
+        c->err = "source network group: inputs are sources or earlier groups"; return -2;
+      }
+      NetRef r; r.kind = grp_in_kind[q]; r.index = grp_in[q];
+      G.in.push_back(r);
+    }
+    G.scaling = grp_scaling ? grp_scaling[g] : 0;
+    for (int l = 0; l < 3; l++)
+      if (grp_limit_type && grp_limit_type[3 * g + l] >= 0) {
+        G.limit_type[G.n_limit] = grp_limit_type[3 * g + l]; G.limit[G.n_limit] = grp_limit[3 * g + l]; G.n_limit++;
+      }
+  }
+  nw.reinjectors.resize(std::max(n_reinj, 0));
+  for (int r = 0; r < n_reinj; r++) {
+    NetReinjector& R = nw.reinjectors[r];
+    if (!ok(rj_in_kind[r], rj_in[r]) || rj_in_kind[r] == 3 || !ok(rj_overflow_kind[r], rj_overflow[r]) || rj_overflow_kind[r] == 2) {
+      c->err = "source network reinjector: bad input / overflow reference"; return -2;
+    }
+    R.in.kind = rj_in_kind[r]; R.in.index = rj_in[r];
+    R.overflow.kind = rj_overflow_kind[r]; R.overflow.index = rj_overflow[r];
+    for (int q = rj_out_ptr[r]; q < rj_out_ptr[r + 1]; q++) {
+      if (!ok(out_kind[q], out_node[q]) || out_kind[q] == 2 || (out_flow[q] != 1 && out_flow[q] != 2)) {
+        c->err = "source network reinjector: bad output"; return -2;
+      }
+      NetOutput o;
+      o.flow = out_flow[q]; o.out.kind = out_kind[q]; o.out.index = out_node[q];
+      o.rate = out_rate[q]; o.proportion = out_proportion[q]; o.enthalpy = out_enthalpy[q];
+      R.out.push_back(o);
+    }
+  }
+  {   // order: a reinjector after every reinjector it delivers or overflows to
+    std::vector<int> state(n_reinj, 0);
+    std::function<bool(int)> visit = [&](int r) -> bool {
+      if (state[r] == 2) return true;
+      if (state[r] == 1) return false;
+      state[r] = 1;
+      const NetReinjector& R = nw.reinjectors[r];
+      for (const NetOutput& o : R.out) if (o.out.kind == 3 && !visit(o.out.index)) return false;
+      if (R.overflow.kind == 3 && !visit(R.overflow.index)) return false;
+      state[r] = 2;
+      nw.reinj_order.push_back(r);
+      return true;
+    };
+    for (int r = 0; r < n_reinj; r++) if (!visit(r)) { c->err = "source network reinjectors form a cycle"; return -2; }
+  }
+  nw.src.assign(n, NetNode());
+  nw.h_net.assign(2 * (size_t)n, 0.0);
+  nw.h_raw.assign(2 * (size_t)n, 0.0);
+  if (nw.h_enth0.size() != (size_t)n) nw.h_enth0.assign(n, 0.0);
+  nw.h_enth = nw.h_enth0;
+  if (dev_alloc(c, &nw.d_raw, 2 * (size_t)n) || dev_alloc(c, &c->src.net, 2 * (size_t)n)) return -1;
+  HIPCHK(c, hipMemset(c->src.net, 0, sizeof(double) * 2 * n));
+  nw.on = true;
+  return 0;
+}
+// state of the network after the last pass: groups 6 doubles each (rate, enthalpy, water_rate,
+// water_enthalpy, steam_rate, steam_enthalpy); reinjectors 8 each (output water / steam rate, overflow
+// rate, enthalpy, water rate, water enthalpy, steam rate, steam enthalpy)
+int wai_get_source_network(wai_ctx* c, double* groups, double* reinjectors) {
+  if (!c) return -2;
+  const Network& nw = c->net;
+  for (size_t g = 0; groups && g < nw.groups.size(); g++) {
+    const NetNode& n = nw.groups[g].node;
+    const double v[6] = {n.rate, n.enth, n.wrate, n.wenth, n.srate, n.senth};
+    std::memcpy(groups + 6 * g, v, sizeof(v));
+  }
+  for (size_t r = 0; reinjectors && r < nw.reinjectors.size(); r++) {
+    const NetReinjector& R = nw.reinjectors[r];
+    const double v[8] = {R.out_w, R.out_s, R.over.rate, R.over.enth, R.over.wrate, R.over.wenth, R.over.srate, R.over.senth};
+    std::memcpy(reinjectors + 8 * r, v, sizeof(v));
+  }
   return 0;
 }
 
@@ -1464,6 +1780,7 @@ int wai_rhs(wai_ctx* c, double t, const double* y, double* rhs) {
   if (!c || !rhs) return -2;
   VecArg o{c};
   if (o.out_only(rhs, c->ks.n, 0)) return -1;
+  if (c->net.on && network_update(c)) return -1;
   {
     Prof p(c, KC_RESIDUAL);
     launch_residual(c, 0.0, nullptr, nullptr, nullptr, o.dev);

@@ -33,6 +33,48 @@ struct Sources {
   int* cell = nullptr; int* comp = nullptr; int* next = nullptr;
   double* rate = nullptr; double* enth = nullptr;
   SrcCtl* ctl = nullptr;   // state-dependent controls (wai_set_source_controls), null: none
+  double* net = nullptr;   // [2 n] what the source network does to each source (source_network_rate), null: no network
+};
+
+// Source network: groups and reinjectors (src/source_network_group.F90, source_network_reinjector.F90),
+// evaluated on the host between the EOS sweep and the residual kernel of every residual evaluation,
+// as source_network%update is (src/source_network.F90:90-130).  Nodes carry the six flow values of
+// source_network_node_type.
+struct NetNode { double rate = 0, enth = 0, wrate = 0, wenth = 0, srate = 0, senth = 0; };
+struct NetRef { int kind = 0, index = -1; };       // 0 none, 1 source, 2 group, 3 reinjector
+struct NetGroup {
+  std::vector<NetRef> in;
+  int scaling = 0;                                 // 0 uniform, 1 progressive
+  int n_limit = 0, limit_type[3] = {0, 0, 0};      // 0 total, 1 water, 2 steam
+  double limit[3] = {0, 0, 0};
+  NetNode node;
+};
+struct NetOutput {
+  int flow = 1;                                    // 1 water, 2 steam
+  NetRef out;
+  double rate = -1.0, proportion = -1.0, enthalpy = -1.0;
+  NetNode node;
+};
+struct NetReinjector {
+  NetRef in;                                       // source / group; none: fed by another reinjector
+  std::vector<NetOutput> out;
+  NetRef overflow;
+  NetNode node;                                    // water / steam rate = capacity (-1 unrated)
+  double in_w = 0, in_wh = 0, in_s = 0, in_sh = 0; // input flows
+  double out_w = 0, out_s = 0;                     // delivered
+  NetNode over;                                    // overflow
+  bool fed = false;                                // input set by an upstream reinjector this pass
+};
+struct Network {
+  bool on = false;
+  std::vector<NetGroup> groups;
+  std::vector<NetReinjector> reinjectors;
+  std::vector<int> reinj_order;                    // outputs / overflow targets before their feeders
+  std::vector<int> rate_specified, enth_specified; // per source
+  std::vector<NetNode> src;                        // per source, last pass
+  std::vector<double> h_net, h_enth0, h_enth, h_raw;
+  std::vector<SrcCtl> h_ctl;                       // host copy of the control records (separators)
+  double* d_raw = nullptr;                         // device scratch: raw rates and enthalpies, 2 n
 };
 
 // Block matrix in HBM: block-ELL, slot-major struct-of-arrays ("SELL" with one slice):
@@ -152,6 +194,7 @@ struct wai_ctx {
   wai_solver_opts opts{};
   wai::DeviceMesh mesh;
   wai::Sources src;
+  wai::Network net;
   wai::Bcsr J;
   wai::IluSchedule ilu;
   wai::AsmSystem as;
@@ -214,7 +257,7 @@ int launch_tracer_assemble(wai_ctx* c, const TracerForm& tf, const double* alx_l
                            const double* alx_last2, double* b);
 int launch_tracer_lhs(wai_ctx* c, double* Al);
 int launch_separator(wai_ctx* c, double pressure, double* out);   // out[3] on the device: hf, hg, err
-int launch_source_rates(wai_ctx* c, double* out);   // out[0..n) rates, out[n..2n) enthalpies (device)
+int launch_source_rates(wai_ctx* c, double* out, bool raw = false);   // out[0..n) rates, out[n..2n) enthalpies (device); raw: before the network pass
 // X[cell][nt] <-> x[cell] of tracer it; alx = Al o X
 int launch_tracer_pick(wai_ctx* c, const double* X, int it, double* x);
 int launch_tracer_put(wai_ctx* c, const double* x, int it, double* X);

@@ -101,6 +101,7 @@ struct MeshView {
   const int* cell_src;
   const int* src_next; const int* src_comp; const double* src_rate; const double* src_enth;
   const SrcCtl* src_ctl;   // null: all rates as given
+  const double* src_net;   // null: no source network (source_network_rate)
   int n_owned, n_local, n_faces, max_deg;
 };
 
@@ -130,7 +131,7 @@ __device__ __forceinline__ void source_terms(const MeshView& m, int c, const Cel
   using E = EosT<KIND>;
   for (int si = m.cell_src[c]; si >= 0; si = m.src_next[si]) {
     double flow[E::np];
-    source_flow<KIND>(s, source_rate<KIND>(s, m.src_ctl, si, m.src_rate[si]), m.src_enth[si], m.src_comp[si], flow);
+    source_flow<KIND>(s, source_rate<KIND>(s, m.src_ctl, si, m.src_rate[si], m.src_net), m.src_enth[si], m.src_comp[si], flow);
 #pragma unroll
     for (int k = 0; k < E::np; k++) R[k] += flow[k] / vol;
   }
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(TPB) void k_tracer_assemble(MeshView m, const doubl
   }
   // sources (tracer_source_iterator, flow_simulation.F90:1722-1772)
   for (int si = m.cell_src[c]; si >= 0; si = m.src_next[si]) {
-    const double rate = source_rate<KIND>(own, m.src_ctl, si, m.src_rate[si]);
+    const double rate = source_rate<KIND>(own, m.src_ctl, si, m.src_rate[si], m.src_net);
     const int comp = m.src_comp[si];
     const int component = rate > 0.0 ? (comp <= 0 ? 1 : comp) : (comp <= 0 ? 0 : comp);
     if (!(component < E::np)) continue;
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(TPB) void k_source_rates(MeshView m, const int* __r
   if (si >= n_src) return;
   CellState<KIND> s;
   load_state<KIND>(flu, stride, src_cell[si], s);
-  const double q = source_rate<KIND>(s, m.src_ctl, si, m.src_rate[si]);
+  const double q = source_rate<KIND>(s, m.src_ctl, si, m.src_rate[si], m.src_net);
   double h = m.src_enth[si];
   if (!(q > 0.0)) {
     const int phases = (int)s.phases;
@@ -634,7 +635,7 @@ static MeshView view(wai_ctx* c) {
   m.adj_face = c->mesh.adj_face; m.adj_other = c->mesh.adj_other; m.adj_blk = c->mesh.adj_blk;
   m.diag_blk = c->mesh.diag_blk; m.cell_src = c->mesh.cell_src;
   m.src_next = c->src.next; m.src_comp = c->src.comp; m.src_rate = c->src.rate;
-  m.src_enth = c->src.enth; m.src_ctl = c->src.ctl;
+  m.src_enth = c->src.enth; m.src_ctl = c->src.ctl; m.src_net = c->src.net;
   m.n_owned = c->mesh.n_owned; m.n_local = c->mesh.n_local; m.n_faces = c->mesh.n_faces;
   m.max_deg = c->mesh.max_deg;
   return m;
@@ -718,8 +719,9 @@ int launch_separator(wai_ctx* c, double pressure, double* out) {
   return 0;
 }
 
-int launch_source_rates(wai_ctx* c, double* out) {
-  const MeshView m = view(c);
+int launch_source_rates(wai_ctx* c, double* out, bool raw) {
+  MeshView m = view(c);
+  if (raw) m.src_net = nullptr;   // rates of the sources' own controls, before the network pass
   WAI_BY_EOS(c, k_source_rates, grid_for(c->src.n), m, c->src.cell, c->src.n, c->flu, (size_t)c->mesh.n_local, out);
   return 0;
 }

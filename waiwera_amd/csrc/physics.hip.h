@@ -856,10 +856,22 @@ __device__ inline double ctl_table(const SrcCtl& k, double x) {
   return (1.0 - xi) * k.table[2 * i + 1] + xi * k.table[2 * (i + 1) + 1];
 }
 
+// what the source network did to a source in the last network pass (host side, capi.hip): net[2 si]
+// 0 nothing, 1 its rate is scaled by net[2 si + 1] (member of a limited group), 2 its rate IS
+// net[2 si + 1] (output of a reinjector); src/source_network_group.F90, source_network_reinjector.F90
+__device__ inline double source_network_rate(const double* net, int si, double rate) {
+  if (!net) return rate;
+  const double mode = net[2 * si];
+  if (mode == 1.0) return rate * net[2 * si + 1];
+  if (mode == 2.0) return net[2 * si + 1];
+  return rate;
+}
+
 template <int KIND>
-__device__ inline double source_rate(const CellState<KIND>& s, const SrcCtl* ctl, int si, double rate) {
+__device__ inline double source_rate(const CellState<KIND>& s, const SrcCtl* ctl, int si, double rate,
+                                     const double* net = nullptr) {
   using E = EosT<KIND>;
-  if (!ctl) return rate;
+  if (!ctl) return source_network_rate(net, si, rate);
   const SrcCtl& k = ctl[si];
   const int phases = (int)s.phases;
   double mob[E::nph], sum = 0.0, h = 0.0;
@@ -897,7 +909,7 @@ __device__ inline double source_rate(const CellState<KIND>& s, const SrcCtl* ctl
   if (k.direction == 1 && !(rate < 0.0)) rate = 0.0;
   if (k.direction == 2 && !(rate > 0.0)) rate = 0.0;
   if (k.factor != 0.0) rate *= k.factor;
-  return rate;
+  return source_network_rate(net, si, rate);
 }
 
 // source term (source.F90:386-480, fluid.F90:377-453): flow[np] for one source

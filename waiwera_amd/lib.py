@@ -115,6 +115,8 @@ def _load():
         "wai_update_sources": (i32, [vp, pd, pd]),
         "wai_set_source_controls": (i32, [vp, C.POINTER(SourceControl)]),
         "wai_get_source_rates": (i32, [vp, pd, pd]),
+        "wai_set_source_network": (i32, [vp, pi, pi, i32, pi, pi, pi, pi, pi, pd, i32, pi, pi, pi, pi, pi, pi, pd, pd, pd, pi, pi]),
+        "wai_get_source_network": (i32, [vp, pd, pd]),
         "wai_separator_enthalpies": (i32, [vp, d, pd, pd]),
         "wai_set_regions": (i32, [vp, pi]),
         "wai_get_regions": (i32, [vp, pi]),

@@ -42,7 +42,7 @@ from . import gmsh, unstructured
 from .timestepper import Timestepper
 from .interpolation import Table
 
-UNSUPPORTED_SOURCE_KEYS = ("network",)
+UNSUPPORTED_SOURCE_KEYS = ()
 
 
 def _get(d, path, default=None):
@@ -412,8 +412,70 @@ class Simulation:
             raise NotImplementedError("repeated output checkpoints")
 
         self._setup_source_controls(inp.get("source", []) or [], _get(inp, "time.start", 0.0))
+        self._setup_network(inp)
         if self._tables or self._ctl_tables or getattr(self, "_tracer_tables", None):
             self.ts.controls = self._update_controls
+
+    # ---- source network --------------------------------------------------------------------------
+    def _setup_network(self, inp):
+        """"network": {"group": [...], "reinject": [...]} (setup_source_network_groups / reinjectors,
+        src/source_setup.F90) as the flat description of wai_set_source_network"""
+        net = inp.get("network") or {}
+        groups, reinj = list(net.get("group") or []), list(net.get("reinject") or [])
+        self.network_names = {"group": [g.get("name", "") for g in groups], "reinject": [r.get("name", "") for r in reinj]}
+        if not groups and not reinj:
+            return
+        sources = inp.get("source", []) or []
+        sidx = {s["name"]: i for i, s in enumerate(sources) if "name" in s}
+        # groups in dependency order
+        gnames = [g.get("name", "") for g in groups]
+        order, done = [], set()
+        while len(order) < len(groups):
+            progress = False
+            for gi, g in enumerate(groups):
+                if gi in done:
+                    continue
+                if all(n in sidx or (n in gnames and gnames.index(n) in done) for n in g.get("in", [])):
+                    order.append(gi); done.add(gi); progress = True
+            if not progress:
+                raise ValueError("network groups refer to unknown nodes or to each other in a cycle")
+        groups = [groups[gi] for gi in order]
+        gidx = {g.get("name", ""): k for k, g in enumerate(groups)}
+        ridx = {r.get("name", ""): k for k, r in enumerate(reinj)}
+        self.network_names["group"] = [g.get("name", "") for g in groups]
+
+        def ref(name, allowed):
+            for kind, table in ((1, sidx), (2, gidx), (3, ridx)):
+                if kind in allowed and name in table:
+                    return kind, table[name]
+            raise ValueError("network node %r not found" % (name,))
+        FLOW = {"total": 0, "water": 1, "steam": 2}
+        spec = dict(rate_specified=[int("rate" in s or any(k in s for k in ("deliverability", "recharge", "injectivity")))
+                                    for s in sources],
+                    enthalpy_specified=[int("enthalpy" in s) for s in sources], groups=[], reinjectors=[])
+        for g in groups:
+            if g.get("separator"):
+                raise NotImplementedError("separator on a network group")
+            lim = g.get("limiter") or {}
+            if "type" in lim:
+                lim = {lim["type"]: lim.get("limit")}
+            limits = [(FLOW[k], float(lim[k])) for k in ("total", "water", "steam") if lim.get(k) is not None]
+            spec["groups"].append(dict(inputs=[ref(n, (1, 2)) for n in g.get("in", [])],
+                                       scaling={"uniform": 0, "progressive": 1}[g.get("scaling", "uniform")], limits=limits))
+        for r in reinj:
+            outs = []
+            for flow, key in ((1, "water"), (2, "steam")):
+                for o in r.get(key) or []:
+                    outs.append(dict(flow=flow, out=ref(o["out"], (1, 3)) if o.get("out") else (0, -1),
+                                     rate=float(o["rate"]) if o.get("rate") is not None else -1.0,
+                                     proportion=float(o["proportion"]) if (o.get("proportion") is not None and o.get("rate") is None) else -1.0,
+                                     enthalpy=float(o["enthalpy"]) if o.get("enthalpy") is not None else -1.0))
+            over = r.get("overflow")
+            if isinstance(over, dict):
+                over = over.get("out")
+            spec["reinjectors"].append(dict(input=ref(r["in"], (1, 2)) if r.get("in") else (0, -1), outputs=outs,
+                                            overflow=ref(over, (1, 3)) if over else (0, -1)))
+        self.ode.set_source_network(spec)
 
     # ---- state-dependent source controls -------------------------------------------------------
     def _setup_source_controls(self, sources, t0):
@@ -423,7 +485,7 @@ class Simulation:
         here and averaged over every step interval (_update_controls)"""
         self._ctl, self._ctl_tables = None, []
         if not any(k in s for s in sources for k in ("deliverability", "recharge", "injectivity", "limiter",
-                                                     "direction", "factor")):
+                                                     "direction", "factor", "separator")):
             return
         recs = [dict() for _ in sources]
         fl = None
@@ -485,7 +547,10 @@ class Simulation:
             if "limiter" in s:
                 lim = s["limiter"]
                 if "limit" not in lim and "type" not in lim:
-                    raise NotImplementedError("limiters on several flow types")
+                    kinds = [k for k in ("total", "water", "steam") if k in lim]
+                    if len(kinds) != 1:
+                        raise NotImplementedError("limiters on several flow types")
+                    lim = dict(lim, type=kinds[0], limit=lim[kinds[0]])    # {"total": 2.0} form
                 r["limiter"] = lim.get("type", "total")
                 ls = dict(s, **{k: lim[k] for k in ("interpolation", "averaging") if k in lim})
                 self._ctl_tables.append((i, "limit", timed(lim.get("limit"), 1.0, ls)))
@@ -498,12 +563,12 @@ class Simulation:
             stages = list(psep) if isinstance(psep, (list, tuple)) else [psep]
             if len(stages) > 4:
                 raise NotImplementedError("separators with more than 4 stages")
-            if r.get("limiter") in ("water", "steam"):
-                if psep is None or not stages or not all(p > 0.0 for p in stages):   # separator_init, separator.F90:182
-                    r["limiter"] = None      # no separator: separated flows are zero, never over the limit
-                else:
-                    r["sep_hf"], r["sep_hg"] = self.ode.separator_enthalpies(float(stages[0]))
-                    r["sep_more"] = [self.ode.separator_enthalpies(float(p)) for p in stages[1:]]
+            has_sep = psep is not None and stages and all(p is not None and p > 0.0 for p in stages)   # separator_init, separator.F90:182
+            if has_sep:     # also what the source network separates the source's flow with
+                r["sep_hf"], r["sep_hg"] = self.ode.separator_enthalpies(float(stages[0]))
+                r["sep_more"] = [self.ode.separator_enthalpies(float(p)) for p in stages[1:]]
+            elif r.get("limiter") in ("water", "steam"):
+                r["limiter"] = None      # no separator: separated flows are zero, never over the limit
             if "direction" in s:
                 r["direction"] = s["direction"].lower()
             if "factor" in s:      # rate factor, applied after every other control (:2615-2660)
