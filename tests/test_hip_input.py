@@ -202,21 +202,25 @@ def test_source_networks_against_autough2(name, geometry):
     outs = sim.outputs
     tg = np.array([o["time"] for o in outs])
     ta = np.asarray(fx["times"])
-    assert abs(tg[-1] - ta[-1]) <= 1e-6 * ta[-1]
+    assert abs(tg[-1] - ta[-1]) <= 1e-3 * ta[-1]       # the listing prints times to four digits
     worst = {"Pressure": 0.0, "Temperature": 0.0, "Vapour saturation": 0.0, "rate": 0.0}
     keys = {"Pressure": "fluid_pressure", "Temperature": "fluid_temperature", "Vapour saturation": "fluid_vapour_saturation"}
     matched = 0
     for k, t in enumerate(ta):
         j = int(np.argmin(np.abs(tg - t)))
-        if abs(tg[j] - t) > 1e-4 * max(t, 1.0):
+        if abs(tg[j] - t) > 1e-3 * max(t, 1.0):
             continue       # the step sequences differ: compare where both have an output
         matched += 1
         for f, key in keys.items():
             a, g = np.asarray(fx["fields"][f][k]), outs[j][key]
             scale = max(np.abs(a).max(), 1.0 if f != "Vapour saturation" else 1.0)
             worst[f] = max(worst[f], np.abs(g - a).max() / scale)
-        ra, rg = np.asarray(fx["rates"][k]), outs[j]["source_rate"]
-        worst["rate"] = max(worst["rate"], np.abs(rg - ra).max() / max(np.abs(ra).max(), 1.0))
+        rg = outs[j]["source_rate"]
+        ra = np.asarray(fx["rates"][k])[: rg.size]      # the makeup listings carry one more generator (AUTOUGH2's makeup well entry)
+        e = np.abs(rg - ra).max() / max(np.abs(ra).max(), 1.0)
+        if e > worst["rate"]:
+            worst["rate"], worst["rate_at"] = e, (float(t), [round(float(v), 3) for v in rg], [round(float(v), 3) for v in ra])
+    print(name, 'matched', matched, 'of', len(ta), worst, 'steps', sim.ts.taken)
     assert matched >= 10, matched
     assert worst["Pressure"] < 2e-2 and worst["Temperature"] < 2e-2 and worst["Vapour saturation"] < 2e-2, worst
     assert worst["rate"] < 6e-2, worst

@@ -1651,6 +1651,7 @@ int wai_get_source_rates(wai_ctx* c, double* rate, double* enthalpy) {
   if (!c || !rate) return -2;
   const size_t n = (size_t)c->src.n;
   if (!n) return 0;
+  if (c->net.on && network_update(c)) return -1;   // on the fluid state in force, like the residual's pass
   double* tmp = nullptr;
   HIPCHK(c, hipMalloc(&tmp, 2 * n * sizeof(double)));
   launch_source_rates(c, tmp);
