@@ -201,6 +201,14 @@ int wai_get_regions(wai_ctx *ctx, int *region);
  * 1 last_iteration_fluid, 2 last_timestep_fluid (src/flow_simulation.F90:53-56) */
 int wai_get_fluid(wai_ctx *ctx, int which, double *out);
 int wai_num_fluid_dof(wai_ctx *ctx);
+/* the reference's flux vector (src/flow_simulation.F90:156-205, filled :1436-1440): per face np
+ * component fluxes (mass components, then energy) + one flux per mobile phase, per unit area, positive
+ * from cell 1 to cell 2, for the fluid state in force; out has n_faces * wai_num_flux_dof doubles */
+int wai_get_fluxes(wai_ctx *ctx, double *out);
+int wai_num_flux_dof(wai_ctx *ctx);
+/* separated flows of every source: [source][water_rate, water_enthalpy, steam_rate, steam_enthalpy]
+ * (source_network_node_type; src/separator.F90:212-260) -- the source_water_rate ... output fields */
+int wai_get_source_separated(wai_ctx *ctx, double *out4);
 int wai_block_size(wai_ctx *ctx);
 
 /* partition ghost exchange (DMGlobalToLocal, src/dm_utils.F90:480-498) over RCCL.

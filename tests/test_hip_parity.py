@@ -500,3 +500,26 @@ def test_table_curves(FS, oracle, interp):
     if reason > 0:
         assert nits == r and relmax(y, yo[: y.size]) < 1e-7
     sim.destroy(); osim.close()
+
+
+@pytest.mark.parametrize("eos", ["we", "wce"])
+def test_flux_vector(FS, oracle, eos):
+    """the reference's flux store (flow_simulation.F90:156-205): component and phase fluxes of every face
+    against the oracle's face kernel on the fluid records fetched through the ABI"""
+    import ctypes as C
+    g, lm, sim, osim, y, region = build(FS, oracle, eos=eos, lens=(eos == "we"), dims=(8, 8, 6), brick=(4, 4, 2))
+    assert sim.pre_eval(0.0, y) == 0 and osim.pre_eval(osim.yvec(y)) == 0
+    fx = sim.fluxes()
+    fl = osim.fluid()
+    nf = fx.shape[1]
+    ref = np.zeros_like(fx)
+    out = np.zeros(nf)
+    for f in range(lm.n_faces):
+        c1, c2 = lm.face_cells[f]
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (lm.face_geom[f], fl[c1], lm.rock[c1], fl[c2], lm.rock[c2])]
+        oracle.wo_face_flux(C.byref(osim.eos), *[ol.dp(a) for a in arrs], ol.dp(out))
+        ref[f] = out
+    scale = np.maximum(np.abs(ref).max(axis=0), 1e-300)
+    assert (np.abs(fx - ref) / scale).max() < 1e-11
+    assert np.abs(ref[:, -2:]).max() > 0        # phase fluxes present
+    sim.destroy(); osim.close()

@@ -1082,7 +1082,7 @@ void free_all(wai_ctx* c) {
   auto F = [](void* p) { if (p) (void)hipFree(p); };
   DeviceMesh& m = c->mesh;
   F(m.rock); F(m.vol); F(m.fgeom); F(m.fdir); F(m.adj_face); F(m.adj_other); F(m.adj_blk);
-  F(m.diag_blk); F(m.cell_src);
+  F(m.diag_blk); F(m.cell_src); F(m.face_cells);
   F(c->src.cell); F(c->src.comp); F(c->src.next); F(c->src.rate); F(c->src.enth); F(c->src.ctl); F(c->src.net); F(c->net.d_raw);
   F(c->J.rowptr); F(c->J.col); F(c->J.val);
   free_schedule(c->ilu);
@@ -1273,6 +1273,10 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
       const int* p = std::lower_bound(row, row + cnt, o);
       adj_blk[(size_t)s * N + i] = (int)(p - row);
     }
+  }
+  {
+    std::vector<int> fc(md->face_cells, md->face_cells + (size_t)2 * NF);
+    if (dev_upload(c, &m.face_cells, fc)) return -1;
   }
   if (dev_upload(c, &m.adj_face, adj_face) || dev_upload(c, &m.adj_other, adj_other) ||
       dev_upload(c, &m.adj_blk, adj_blk) || dev_upload(c, &m.diag_blk, diag) ||
@@ -1659,6 +1663,41 @@ int wai_get_source_rates(wai_ctx* c, double* rate, double* enthalpy) {
   if (enthalpy) HIPCHK(c, hipMemcpyAsync(enthalpy, tmp + n, n * sizeof(double), hipMemcpyDefault, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   (void)hipFree(tmp);
+  return 0;
+}
+
+// the flux vector of the reference (flow_simulation.F90:156-205): per face np component fluxes + nmob
+// phase fluxes per unit area, positive from cell 1 to cell 2, on the fluid state in force
+int wai_get_fluxes(wai_ctx* c, double* out) {
+  if (!c || !out) return -2;
+  const int nmob = (c->kind == WAI_EOS_W) ? 1 : 2;
+  const size_t n = (size_t)c->mesh.n_faces * (c->np + nmob);
+  if (!n) return 0;
+  double* tmp = nullptr;
+  HIPCHK(c, hipMalloc(&tmp, n * sizeof(double)));
+  launch_face_fluxes(c, c->mesh.face_cells, tmp);
+  HIPCHK(c, hipMemcpyAsync(out, tmp, n * sizeof(double), hipMemcpyDefault, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(tmp);
+  return 0;
+}
+int wai_num_flux_dof(wai_ctx* c) { return c ? c->np + ((c->kind == WAI_EOS_W) ? 1 : 2) : -2; }
+
+// separated water / steam flows of every source (source_network_node_type: water_rate, water_enthalpy,
+// steam_rate, steam_enthalpy; separator.F90:212-260) for the rates and enthalpies in force; zero for
+// sources without a separator and for injection
+int wai_get_source_separated(wai_ctx* c, double* out4) {
+  if (!c || !out4) return -2;
+  const int n = c->src.n;
+  if (!n) return 0;
+  std::vector<double> q(n), h(n);
+  if (int e = wai_get_source_rates(c, q.data(), h.data())) return e;
+  for (int i = 0; i < n; i++) {
+    NetNode nd;
+    nd.rate = q[i]; nd.enth = h[i];
+    if (q[i] < 0.0 && i < (int)c->net.h_ctl.size() && c->net.h_ctl[i].sep_hg > 0.0) net_separate(c->net.h_ctl[i], q[i], h[i], nd);
+    out4[4 * i] = nd.wrate; out4[4 * i + 1] = nd.wenth; out4[4 * i + 2] = nd.srate; out4[4 * i + 3] = nd.senth;
+  }
   return 0;
 }
 

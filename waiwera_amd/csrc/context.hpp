@@ -26,6 +26,7 @@ struct DeviceMesh {
   int* adj_blk = nullptr;    // matrix slot of (cell, other) in the cell's block row, -1 for a bc cell
   int* diag_blk = nullptr;   // matrix slot of (cell, cell)
   int* cell_src = nullptr;   // first source in the cell or -1
+  int* face_cells = nullptr; // [2 n_faces] (cell 1, cell 2) of every face: flux output only
 };
 
 struct Sources {
@@ -257,6 +258,7 @@ int launch_tracer_assemble(wai_ctx* c, const TracerForm& tf, const double* alx_l
                            const double* alx_last2, double* b);
 int launch_tracer_lhs(wai_ctx* c, double* Al);
 int launch_separator(wai_ctx* c, double pressure, double* out);   // out[3] on the device: hf, hg, err
+int launch_face_fluxes(wai_ctx* c, const int* face_cells, double* out);   // [face][np + nmob]
 int launch_source_rates(wai_ctx* c, double* out, bool raw = false);   // out[0..n) rates, out[n..2n) enthalpies (device); raw: before the network pass
 // X[cell][nt] <-> x[cell] of tracer it; alx = Al o X
 int launch_tracer_pick(wai_ctx* c, const double* X, int it, double* x);

@@ -500,6 +500,33 @@ __global__ __launch_bounds__(TPB) void k_source_rates(MeshView m, const int* __r
   out[n_src + si] = h;
 }
 
+// the reference's flux store (flow_simulation.F90:156-205, 1436-1440): per face the np component
+// fluxes (mass components, then energy) and the nmob phase fluxes, from cell 1 to cell 2, per unit area
+template <int KIND>
+__global__ __launch_bounds__(TPB) void k_face_fluxes(MeshView m, const int* __restrict__ face_cells,
+                                                     const double* __restrict__ flu, size_t stride,
+                                                     double* __restrict__ out) {
+  using E = EosT<KIND>;
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= m.n_faces) return;
+  const int c1 = face_cells[2 * f], c2 = face_cells[2 * f + 1];
+  FaceGeom g;
+  load_face(m, f, g);
+  CellState<KIND> a, b;
+  RockState ra, rb;
+  load_state<KIND>(flu, stride, c1, a);
+  load_state<KIND>(flu, stride, c2, b);
+  load_rock(m.rock, m.n_local, c1, ra);
+  load_rock(m.rock, m.n_local, c2, rb);
+  double flux[E::np];
+  face_flux<KIND>(g, a, ra, b, rb, flux);
+  constexpr int nf = E::np + E::nmob;
+#pragma unroll
+  for (int k = 0; k < E::np; k++) out[(size_t)f * nf + k] = flux[k];
+#pragma unroll
+  for (int p = 0; p < E::nmob; p++) out[(size_t)f * nf + E::np + p] = face_phase_flux<KIND>(g, a, ra, b, rb, p);
+}
+
 // separator_stage_init (separator.F90:108-136): enthalpies of saturated water and steam at the
 // separator pressure; out = {hf, hg, err}
 __global__ void k_separator(int thermo, double pressure, double* __restrict__ out) {
@@ -723,6 +750,12 @@ int launch_source_rates(wai_ctx* c, double* out, bool raw) {
   MeshView m = view(c);
   if (raw) m.src_net = nullptr;   // rates of the sources' own controls, before the network pass
   WAI_BY_EOS(c, k_source_rates, grid_for(c->src.n), m, c->src.cell, c->src.n, c->flu, (size_t)c->mesh.n_local, out);
+  return 0;
+}
+
+int launch_face_fluxes(wai_ctx* c, const int* face_cells, double* out) {
+  const MeshView m = view(c);
+  WAI_BY_EOS(c, k_face_fluxes, grid_for(c->mesh.n_faces), m, face_cells, c->flu, (size_t)c->mesh.n_local, out);
   return 0;
 }
 

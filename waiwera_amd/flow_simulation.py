@@ -200,6 +200,20 @@ class FlowSimulation:
         self._chk(LIB.wai_get_fluid(self.h, which, out.ctypes.data), "get_fluid")
         return out
 
+    def fluxes(self):
+        """(n_faces, np + nmob): component and phase fluxes per unit area, cell 1 -> cell 2 (the reference's flux vector)"""
+        nf = LIB.wai_num_flux_dof(self.h)
+        out = np.zeros((self.mesh.n_faces, nf))
+        self._chk(LIB.wai_get_fluxes(self.h, out.ctypes.data), "get_fluxes")
+        return out
+
+    def source_separated(self):
+        """(n_sources, 4): water_rate, water_enthalpy, steam_rate, steam_enthalpy behind each source's separator"""
+        out = np.zeros((max(self.mesh.n_src, 1), 4))
+        if self.mesh.n_src:
+            self._chk(LIB.wai_get_source_separated(self.h, out.ctypes.data_as(_lib.pd)), "get_source_separated")
+        return out[: self.mesh.n_src]
+
     def scale(self, primary, region):
         """eos%scale (src/eos.F90:186-197): unscaled primaries (n, np) -> scaled y."""
         sc = np.ones((9, self.num_primary_variables))

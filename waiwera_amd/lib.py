@@ -122,6 +122,9 @@ def _load():
         "wai_get_regions": (i32, [vp, pi]),
         "wai_get_fluid": (i32, [vp, i32, vp]),
         "wai_num_fluid_dof": (i32, [vp]),
+        "wai_get_fluxes": (i32, [vp, vp]),
+        "wai_num_flux_dof": (i32, [vp]),
+        "wai_get_source_separated": (i32, [vp, pd]),
         "wai_block_size": (i32, [vp]),
         "wai_set_halo": (i32, [vp, i32, pi, pi, pi, pi]),
         "wai_comm_unique_id": (i32, [C.c_char_p]),

@@ -649,8 +649,14 @@ class Simulation:
         for k in outs[0]:
             if k == "time":
                 continue
-            if k.startswith("source_"):
+            if k.startswith("source_") or k.startswith("network_"):
                 data["/source_fields/" + k] = np.stack([o[k] for o in outs])
+            elif k.startswith("flux_"):
+                data["/face_fields/" + k] = np.stack([o[k] for o in outs])
+            elif k.startswith("face_geometry"):
+                data["/face_fields/" + k] = outs[0][k]
+            elif k.startswith("face_cell_"):
+                data["/" + k] = np.asarray(outs[0][k], dtype=np.int32)[:, None]
             elif k.startswith("cell_geometry"):
                 data["/cell_fields/" + k] = outs[0][k]
             else:
@@ -693,6 +699,47 @@ class Simulation:
                 out["tracer_" + name] = (xk[self._order] if self._order is not None else xk).copy()
         if self.mesh.n_src and hasattr(self.ode, "source_rates"):
             out["source_rate"], out["source_enthalpy"] = self.ode.source_rates()
+        oc = self.inp.get("output")
+        want = (oc.get("fields") if isinstance(oc, dict) else None) or {}
+        # face fields: "output.fields.flux" (src/flow_simulation.F90:460-504): the flux vector's
+        # components and phases by name, per unit area, positive from face_cell_1 to face_cell_2
+        flux_names = want.get("flux") or []
+        if flux_names and hasattr(self.ode, "fluxes"):
+            comps = {"w": ["water"], "we": ["water", "energy"], "wce": ["water", "CO2", "energy"],
+                     "wae": ["water", "air", "energy"], "wse": ["water", "salt", "energy"],
+                     "wsce": ["water", "salt", "CO2", "energy"], "wsae": ["water", "salt", "air", "energy"]}[self.eos]
+            names = comps + (["liquid"] if self.eos == "w" else ["liquid", "vapour"])
+            fx = self.ode.fluxes()
+            for nm in (names if flux_names == "all" or "all" in flux_names else flux_names):
+                out["flux_" + nm] = fx[:, names.index(nm)].copy()
+            fc = np.asarray(self.mesh.face_cells)
+            c2 = fc[:, 1].astype(np.int64)
+            bnd = c2 >= self.mesh.n_owned + self.mesh.n_halo
+            spec = np.asarray(self.mesh.extras.get("bc_spec", np.zeros(self.mesh.n_bc, dtype=np.int64)))
+            c2 = np.where(bnd, -1 - spec[np.clip(c2 - self.mesh.n_owned - self.mesh.n_halo, 0, max(self.mesh.n_bc - 1, 0))], c2)
+            out["face_cell_1"], out["face_cell_2"] = fc[:, 0].copy(), c2
+            out["face_geometry_area"] = np.asarray(self.mesh.face_geom)[:, 0].copy()
+        # separated water / steam flows of the sources and the source network's nodes
+        src_want = want.get("source") or []
+        if self.mesh.n_src and hasattr(self.ode, "source_separated") and \
+                any(k in src_want for k in ("water_rate", "water_enthalpy", "steam_rate", "steam_enthalpy")):
+            sep = self.ode.source_separated()
+            for j, k in enumerate(("water_rate", "water_enthalpy", "steam_rate", "steam_enthalpy")):
+                if k in src_want:
+                    out["source_" + k] = sep[:, j].copy()
+        if getattr(self, "network_names", None) and hasattr(self.ode, "source_network") and \
+                (self.network_names["group"] or self.network_names["reinject"]):
+            G, R = self.ode.source_network()
+            gcols = ("rate", "enthalpy", "water_rate", "water_enthalpy", "steam_rate", "steam_enthalpy")
+            for k in (want.get("network_group") or []):
+                if k in gcols and len(G):
+                    out["network_group_" + k] = G[:, gcols.index(k)].copy()
+            rcols = ("output_water_rate", "output_steam_rate", "overflow_rate", "overflow_enthalpy", "overflow_water_rate",
+                     "overflow_water_enthalpy", "overflow_steam_rate", "overflow_steam_enthalpy")
+            for k in (want.get("network_reinject") or ["output_water_rate", "output_steam_rate", "overflow_water_rate",
+                                                       "overflow_steam_rate"]):
+                if k in rcols and len(R):
+                    out["network_reinject_" + k] = R[:, rcols.index(k)].copy()
         return out
 
     def save(self, path):
