@@ -424,6 +424,9 @@ def main():
     nnzb = wl.LIB.wai_jacobian_nnzb(sim.h)
     names = ["spmv", "ilu_apply", "fused_pc_amul"]
     kb = {name: sim.bench_kernel(w, a.spmv_reps if w in (0, 2) else 20) for w, name in enumerate(names)}
+    if world == 1 and not minc and a.pc == "bjacobi":   # the two launches of the overlapped halo exchange, timed alone
+        kb["fused_interior_bricks"] = sim.bench_kernel(9, a.spmv_reps)
+        kb["fused_face_bricks"] = sim.bench_kernel(10, a.spmv_reps)
     log("kernel microbench (ms/launch): " + json.dumps(kb))
     b_spmv = spmv_bytes(nnzb, lm.n_owned, bs)
     b_pc = pc_bytes(nnzb, lm.n_owned, bs)

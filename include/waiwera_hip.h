@@ -320,7 +320,8 @@ int wai_timer_stop(wai_ctx *ctx, float *ms);
 int wai_synchronize(wai_ctx *ctx);
 /* HIP-event timed repetitions of one kernel on the library's stream (needs an assembled
  * Jacobian): which 0 block SpMV, 1 ILU(0) apply, 2 fused SpMV + ILU(0) apply + dot,
- * 3/4 timing probes of 1/2 without the substitution sweeps (generic brick kernel only) */
+ * 3/4 timing probes of 1/2 without the substitution sweeps (generic brick kernel only), 9 / 10 the fused
+ * kernel on the interior / the face bricks alone (the two launches of the overlapped halo exchange) */
 int wai_bench_kernel(wai_ctx *ctx, int which, int reps, float *ms_per_launch);
 const char *wai_pc_kernel_name(wai_ctx *ctx);   /* kernel / path of a preconditioned-operator application */
 /* accumulated HIP-event time (ms) and launch counts per kernel class since the last reset;

@@ -180,9 +180,20 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
           if (colidx[q] >= N) { ghost = true; break; }
       (ghost ? lb : li).push_back(sd);
     }
+    if (c->mesh.n_halo == 0 && W == 7) {
+      // one rank: for the split-kernel measurement (wai_bench_kernel 9, 10) take the bricks on the
+      // faces of the box -- rows with fewer than six neighbours -- as if every face were a partition
+      // boundary (what an interior rank of a larger decomposition sees)
+      li.clear(); lb.clear();
+      for (int sd = 0; sd < s.nsub; sd++) {
+        bool face = false;
+        for (int i = sub[sd]; i < sub[sd + 1] && !face; i++) face = rowptr[i + 1] - rowptr[i] < 7;
+        (face ? lb : li).push_back(sd);
+      }
+    }
     s.n_int = (int)li.size();
     s.n_bnd = (int)lb.size();
-    if (c->mesh.n_halo > 0 && s.n_int > 0 && s.n_bnd > 0) {
+    if (s.n_int > 0 && s.n_bnd > 0) {
       if (dev_upload(c, &s.sub_int, li) || dev_upload(c, &s.sub_bnd, lb)) return -1;
     }
   }
@@ -2216,6 +2227,8 @@ int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
     switch (which) {
       case 0: launch_spmv(c, k.P, k.tmp); break;
       case 1: case 3: pc_solve(c, k.P, k.V, 0, nullptr, nullptr); break;
+      case 9: if (c->ilu.n_int > 0) launch_pc(c, true, k.P, k.V, 1, k.RP, c->ilu.sub_int, c->ilu.n_int); break;   // interior bricks only
+      case 10: if (c->ilu.n_bnd > 0) launch_pc(c, true, k.P, k.V, 1, k.RP, c->ilu.sub_bnd, c->ilu.n_bnd); break;  // face bricks only
       default: pc_amul(c, k.P, k.V, 1, k.RP); break;   // what a BiCGStab half-iteration runs (no halo on one rank)
     }
   };
