@@ -45,6 +45,7 @@ def _run_steps(sim, y, nsteps=3):
 
 def _worker(rank, world, uid_q, q):
     os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    os.environ.setdefault("WAI_HALO_OVERLAP", "0")   # the loopback time-slices the ranks on one GPU: in-order exchange unless asked
     from waiwera_amd import lib as wl
     from waiwera_amd.flow_simulation import FlowSimulation
     # rank 0 makes the id in its own fresh process: the pytest process may already hold the real
@@ -144,7 +145,7 @@ def test_bench_as_the_driver_launches_it(world, dims, brick, part):
     (WAI_BENCH_LOOPBACK: gloo for the host-side barrier / max, device 0 for every rank).  The
     8-rank case has the default brick shape cut raggedly by 36-cell rank extents (as 108-cell
     extents are at full size) and is deep enough for the two-phase lens."""
-    env = dict(os.environ, WAI_RCCL_LIB=LOOPBACK, WAI_BENCH_LOOPBACK="1")
+    env = dict(os.environ, WAI_RCCL_LIB=LOOPBACK, WAI_BENCH_LOOPBACK="1", WAI_HALO_OVERLAP="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", str(world), "--steps", "2", "--warmup", "1", "--lead", "1", "--window", "2", "--dims"] + [str(v) for v in dims] + \
@@ -163,7 +164,7 @@ def test_bench_as_the_driver_launches_it(world, dims, brick, part):
 def test_bench_spawns_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher, as the driver calls it: bench.py starts the two
     ranks itself (here on the loopback, both on cuda:0)"""
-    env = dict(os.environ, WAI_RCCL_LIB=LOOPBACK, WAI_BENCH_LOOPBACK="1", MASTER_PORT=str(_free_port()))
+    env = dict(os.environ, WAI_RCCL_LIB=LOOPBACK, WAI_BENCH_LOOPBACK="1", WAI_HALO_OVERLAP="0", MASTER_PORT=str(_free_port()))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--lead", "1",

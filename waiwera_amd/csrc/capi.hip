@@ -1755,9 +1755,14 @@ int wai_comm_init(wai_ctx* c, int rank, int nranks, const char id[128]) {
   comm_destroy(c->comm);
   c->comm = comm_create(rank, nranks, id, c->err);
   if (!c->comm) return -1;
-  // opt-in (WAI_HALO_OVERLAP=1): correct under the loopback transport of the tests, but unmeasured on
-  // xGMI, and eight processes sharing one test GPU run it 30x slower than the in-order exchange
-  if (nranks > 1 && !c->comm_stream && getenv("WAI_HALO_OVERLAP")) {
+  // Halo exchange behind the interior bricks: on by default (WAI_HALO_OVERLAP=0: in-order exchange).
+  // MEASURED on one GPU at 108^3 (one rank's share of the 8-GPU run): fused kernel 96.9 us in one
+  // launch, 54.3 us (interior bricks) + 51.5 us (face bricks) in two -- splitting costs 8.9 us per
+  // application, and the interior launch is long enough to cover three 187-KB xGMI messages and RCCL's
+  // send/recv launch latency, which the in-order exchange exposes in full twice per BiCGStab iteration.
+  // (The tests' loopback transport time-slices all ranks on one GPU and switches it off.)
+  const char* ov = getenv("WAI_HALO_OVERLAP");
+  if (nranks > 1 && !c->comm_stream && !(ov && ov[0] == '0')) {
     HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
