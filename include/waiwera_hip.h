@@ -42,7 +42,7 @@ enum { WAI_KSP_BCGS = 0, WAI_KSP_GMRES = 1, WAI_KSP_BCGSL = 2 };   /* linear.typ
 /* linear.preconditioner.type (src/timestepper.F90:1745-1757): "bjacobi" PCBJACOBI, "asm" PCASM (the
  * reference's default: restricted, overlap 1), "none" PCNONE; the blocks' sub-preconditioner is
  * ILU(0) (:1668-1669, 1809-1834).  "ilu" of a serial run is bjacobi / asm with sub_ptr = NULL. */
-enum { WAI_PC_BJACOBI = 0, WAI_PC_ASM = 1, WAI_PC_NONE = 2 };
+enum { WAI_PC_BJACOBI = 0, WAI_PC_ASM = 1, WAI_PC_NONE = 2, WAI_PC_LU = 3 };   /* lu: exact solves of the blocks (dense inverses, <= 8192 unknowns per block: small systems, "for testing purposes" as the reference puts it); one block = PCLU */
 
 /* DMPlex-local arrays in the reference's own record layouts (AoS), host memory:
  *   face_geom 12/face  src/face.F90:67-76,119-135   cell_geom 4/cell  src/cell.F90:54-61
@@ -98,7 +98,7 @@ typedef struct wai_solver_opts {
   double utol_rel, utol_abs;   /* nonlinear.tolerance.update.{relative 1e-10, absolute 1} */
   double fd_eps, fd_umin;      /* nonlinear.jacobian.differencing.{increment 1e-8, tolerance 1e-2} */
   int min_newton_its;          /* nonlinear.minimum.iterations, default 0 (timestepper.F90:1930-1932) */
-  int pc_type;                 /* linear.preconditioner.type: WAI_PC_BJACOBI (default here) | WAI_PC_ASM | WAI_PC_NONE */
+  int pc_type;                 /* linear.preconditioner.type: WAI_PC_BJACOBI (default here) | WAI_PC_ASM | WAI_PC_NONE | WAI_PC_LU */
   int asm_overlap;             /* PCASM overlap, PETSc default 1; does not reach across ranks */
 } wai_solver_opts;
 

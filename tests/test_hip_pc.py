@@ -157,3 +157,30 @@ def test_bcgsl(oracle, eos, pc):
     assert reason > 0 and oreason > 0 and its % 2 == 0
     assert relmax(x, xo) < 1e-8 and abs(its - oits) <= max(2, oits // 10)
     sim.destroy(); osim.close()
+
+
+def test_lu_blocks(oracle):
+    """"lu": exact block solves.  One block (sub_ptr = NULL): the preconditioner is the inverse, BiCGStab
+    stops after one iteration at the dense solution; bricks: each block solved exactly"""
+    import scipy.sparse as sp
+    for one_block in (True, False):
+        lm, sim, osim, J, f = system(oracle, "we", (6, 6, 4), (6, 6, 4) if one_block else (3, 3, 2), one_block=one_block)
+        n = sim.num_dof
+        rp, ci = osim.pattern()
+        A = sp.bsr_matrix((J.reshape(-1, 2, 2), ci, rp), shape=(n, n)).toarray()
+        sim.set_opts(pc_type="lu", ksp_rtol=1e-10)
+        assert sim.pc_setup() == 0
+        r = np.random.default_rng(14).normal(size=n)
+        z = np.zeros(n)
+        sim.pc_apply(r, z)
+        ref = np.zeros(n)
+        sub = [0, lm.n_owned] if one_block else list(lm.sub_ptr)
+        for a, b in zip(sub[:-1], sub[1:]):
+            ref[2 * a:2 * b] = np.linalg.solve(A[2 * a:2 * b, 2 * a:2 * b], r[2 * a:2 * b])
+        assert relmax(z, ref) < 1e-9
+        x = np.zeros(n)
+        its, reason, rn = sim.ksp_solve(f, x)
+        assert reason > 0 and relmax(x, np.linalg.solve(A, f)) < 1e-7
+        if one_block:
+            assert its <= 2
+        sim.destroy(); osim.close()

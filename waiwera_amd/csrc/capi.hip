@@ -621,8 +621,75 @@ bool pc_fused(const wai_ctx* c) {
   return c->opts.pc_type == WAI_PC_BJACOBI && !c->ilu.big;
 }
 
+// PCLU: dense inverse of every preconditioner block (one block per rank with sub_ptr = NULL), by
+// Gauss-Jordan elimination with partial pivoting on the host.  Meant for small systems.
+int lu_setup(wai_ctx* c) {
+  const Bcsr& J = c->J;
+  const int bs = J.bs, bb = bs * bs, nsub = c->ilu.nsub;
+  std::vector<int> sub((size_t)nsub + 1);
+  HIPCHK(c, hipMemcpy(sub.data(), c->ilu.sub_ptr, sizeof(int) * sub.size(), hipMemcpyDeviceToHost));
+  LuBlocks& L = c->lu;
+  if (L.h_inv_ptr.empty()) {
+    L.h_inv_ptr.assign((size_t)nsub + 1, 0);
+    for (int s = 0; s < nsub; s++) {
+      const size_t m = (size_t)(sub[s + 1] - sub[s]) * bs;
+      if (m > 8192) { c->err = "preconditioner lu: a block has more than 8192 unknowns (dense inverses; use ilu)"; return -2; }
+      L.h_inv_ptr[s + 1] = L.h_inv_ptr[s] + m * m;
+    }
+    L.total = L.h_inv_ptr[nsub];
+    if (L.total > ((size_t)1 << 29)) { c->err = "preconditioner lu: more than 4 GB of dense block inverses"; return -2; }
+    if (dev_alloc(c, &L.inv, L.total) || dev_upload(c, &L.inv_ptr, L.h_inv_ptr)) return -1;
+  }
+  std::vector<double> val((size_t)J.nnzb * bb), inv(L.total), A;
+  {
+    double* tmp = nullptr;
+    if (dev_alloc(c, &tmp, val.size())) return -1;
+    launch_ell_to_bcsr(c, J.val, tmp);
+    HIPCHK(c, hipMemcpyAsync(val.data(), tmp, val.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(tmp);
+  }
+  for (int s = 0; s < nsub; s++) {
+    const int lo = sub[s], hi = sub[s + 1], m = (hi - lo) * bs;
+    A.assign((size_t)m * m, 0.0);
+    double* B = inv.data() + L.h_inv_ptr[s];
+    std::fill(B, B + (size_t)m * m, 0.0);
+    for (int i = 0; i < m; i++) B[(size_t)i * m + i] = 1.0;
+    for (int i = lo; i < hi; i++)
+      for (int q = J.h_rowptr[i]; q < J.h_rowptr[i + 1]; q++) {
+        const int j = J.h_colidx[q];
+        if (j < lo || j >= hi) continue;   // couplings leaving the block are dropped (block Jacobi)
+        for (int r = 0; r < bs; r++)
+          for (int k = 0; k < bs; k++) A[(size_t)((i - lo) * bs + r) * m + (j - lo) * bs + k] = val[(size_t)q * bb + r * bs + k];
+      }
+    for (int p = 0; p < m; p++) {   // Gauss-Jordan with partial pivoting on [A | B]
+      int piv = p;
+      for (int r = p + 1; r < m; r++) if (std::fabs(A[(size_t)r * m + p]) > std::fabs(A[(size_t)piv * m + p])) piv = r;
+      if (A[(size_t)piv * m + p] == 0.0) return 1;   // singular block: recoverable (KSP_DIVERGED_PC_FAILED)
+      if (piv != p)
+        for (int k = 0; k < m; k++) { std::swap(A[(size_t)p * m + k], A[(size_t)piv * m + k]); std::swap(B[(size_t)p * m + k], B[(size_t)piv * m + k]); }
+      const double d = 1.0 / A[(size_t)p * m + p];
+      for (int k = 0; k < m; k++) { A[(size_t)p * m + k] *= d; B[(size_t)p * m + k] *= d; }
+      for (int r = 0; r < m; r++) {
+        const double f = A[(size_t)r * m + p];
+        if (r == p || f == 0.0) continue;
+        for (int k = 0; k < m; k++) { A[(size_t)r * m + k] -= f * A[(size_t)p * m + k]; B[(size_t)r * m + k] -= f * B[(size_t)p * m + k]; }
+      }
+    }
+  }
+  HIPCHK(c, hipMemcpyAsync(L.inv, inv.data(), L.total * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 int do_pc_setup(wai_ctx* c) {
   if (c->opts.pc_type == WAI_PC_NONE) { c->ilu.factored = true; return 0; }
+  if (c->opts.pc_type == WAI_PC_LU) {
+    Prof p(c, KC_PC_SETUP);
+    const int e = lu_setup(c);
+    if (e == 0) c->ilu.factored = true;
+    return e;
+  }
   {
     Prof p(c, KC_PC_SETUP);
     if (c->opts.pc_type == WAI_PC_ASM) {
@@ -658,6 +725,8 @@ int pc_solve(wai_ctx* c, const double* r, double* z, int dot_mode, const double*
   const size_t n = (size_t)c->ks.n;
   if (c->opts.pc_type == WAI_PC_NONE) {
     if (z != r) vec_copy(c, z, r, n);
+  } else if (c->opts.pc_type == WAI_PC_LU) {
+    if (launch_lu_apply(c, r, z)) return -1;
   } else if (c->opts.pc_type == WAI_PC_ASM) {
     AsmSystem& a = c->as;
     launch_asm_gather(c, r);
@@ -1098,6 +1167,7 @@ void free_all(wai_ctx* c) {
   F(c->J.rowptr); F(c->J.col); F(c->J.val);
   free_schedule(c->ilu);
   free_asm(c);
+  F(c->lu.inv); F(c->lu.inv_ptr);
   Krylov& k = c->ks;
   F(k.R); F(k.RP); F(k.P); F(k.V); F(k.S); F(k.T); F(k.tmp); F(k.X); F(k.basis); F(k.bl); F(k.partials); F(k.scal);
   if (k.h_scal) (void)hipHostFree(k.h_scal);
@@ -1370,7 +1440,7 @@ const char* wai_last_error(wai_ctx* c) { return c ? c->err.c_str() : "null conte
 int wai_set_opts(wai_ctx* c, const wai_solver_opts* o) {
   if (!c || !o) return -2;
   const int old_type = c->opts.ksp_type;
-  if (o->pc_type < WAI_PC_BJACOBI || o->pc_type > WAI_PC_NONE) { c->err = "unknown preconditioner type"; return -2; }
+  if (o->pc_type < WAI_PC_BJACOBI || o->pc_type > WAI_PC_LU) { c->err = "unknown preconditioner type"; return -2; }
   if (o->pc_type != c->opts.pc_type || o->asm_overlap != c->opts.asm_overlap) c->ilu.factored = false;
   c->opts = *o;
   if (o->ksp_type == WAI_KSP_GMRES && (old_type != WAI_KSP_GMRES || !c->ks.basis)) {
@@ -2255,6 +2325,7 @@ const char* wai_pc_kernel_name(wai_ctx* c) {
   if (!c) return "";
   const IluSchedule& s = c->ilu;
   if (c->opts.pc_type == WAI_PC_NONE) return "k_spmv (no preconditioner)";
+  if (c->opts.pc_type == WAI_PC_LU) return "k_spmv + k_lu_apply (dense block inverses)";
   if (c->opts.pc_type == WAI_PC_ASM) return c->as.sched.big ? "k_spmv + k_lvl_solve per level (ASM, extended system)" : "k_spmv + k_pc on the extended ASM system";
   if (s.big) return "k_spmv + k_lvl_solve per level";
   if (s.rows_kernel) { static thread_local char b2[64]; snprintf(b2, sizeof(b2), "k_pc_rows<%d,spmv,%d+%d>", c->J.bs, s.max_nlu <= 3 ? 3 : 4, s.max_nlu <= 3 ? 3 : 4); return b2; }

@@ -187,6 +187,19 @@ struct Krylov {
 
 }  // namespace wai
 
+namespace wai {
+// PCLU / sub-preconditioner "lu" (src/timestepper.F90:1749-1750; the reference lists it "for testing
+// purposes"): exact solves of the preconditioner blocks.  Each block's dense inverse, formed on the
+// host with partial pivoting at every set-up, applied on the device as one dense product per block.
+struct LuBlocks {
+  double* inv = nullptr;      // concatenated dense inverses, block b at inv_ptr[b], row-major m_b x m_b
+  size_t* inv_ptr = nullptr;  // device, nsub + 1
+  std::vector<size_t> h_inv_ptr;
+  size_t total = 0;
+};
+int launch_lu_apply(wai_ctx* c, const double* r, double* z);
+}  // namespace wai
+
 struct wai_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -199,6 +212,7 @@ struct wai_ctx {
   wai::Bcsr J;
   wai::IluSchedule ilu;
   wai::AsmSystem as;
+  wai::LuBlocks lu;
   wai::Krylov ks;
   wai::Tracers tr;
   // fluid state, SoA df x n_local each; perturbed states np x df x n_prim

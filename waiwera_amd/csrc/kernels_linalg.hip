@@ -1440,6 +1440,28 @@ __global__ __launch_bounds__(TPB) void k_dots(const double* __restrict__ a1, con
   else { double v1[1] = {v[0]}; const int s1[1] = {slot1}; block_reduce_store<1>(v1, partials, nb_max, s1); }
 }
 
+// z_b = inv(A_b) r_b: one workgroup per block, one wave per output row at a time (coalesced row reads)
+__global__ __launch_bounds__(256) void k_lu_apply(int nsub, int bs, const int* __restrict__ sub_ptr,
+                                                  const size_t* __restrict__ inv_ptr, const double* __restrict__ inv,
+                                                  const double* __restrict__ r, double* __restrict__ z) {
+  const int s = blockIdx.x;
+  if (s >= nsub) return;
+  const int lo = sub_ptr[s] * bs, m = (sub_ptr[s + 1] - sub_ptr[s]) * bs;
+  const double* A = inv + inv_ptr[s];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int i = w; i < m; i += nw) {
+    double t = 0.0;
+    for (int j = lane; j < m; j += 64) t += A[(size_t)i * m + j] * r[lo + j];
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+    if (lane == 0) z[lo + i] = t;
+  }
+}
+int launch_lu_apply(wai_ctx* c, const double* r, double* z) {
+  hipLaunchKernelGGL(k_lu_apply, c->ilu.nsub, 256, 0, c->stream, c->ilu.nsub, c->J.bs, c->ilu.sub_ptr, c->lu.inv_ptr,
+                     c->lu.inv, r, z);
+  return 0;
+}
+
 static inline int pc_threads(const IluSchedule& s) { return ((s.max_rows + 63) / 64) * 64; }
 
 int launch_ilu_factor_on(wai_ctx* c, const Bcsr& J, IluSchedule& s) {

@@ -354,11 +354,14 @@ class Simulation:
         # preconditioner (src/timestepper.F90:1745-1757, default "asm"); "ilu" of a serial run is the
         # one-block case of either.  Only the ILU(0) sub-preconditioner exists here.
         pct = (_get(lin, "preconditioner.type") or "asm").lower()
-        if pct not in ("asm", "bjacobi", "ilu", "none"):
+        if pct not in ("asm", "bjacobi", "ilu", "lu", "none"):
             raise NotImplementedError("preconditioner type %r" % pct)
         opts["pc_type"] = {"ilu": "bjacobi"}.get(pct, pct)
         sub = _get(lin, "preconditioner.sub.preconditioner", {}) or {}
-        if (sub.get("type") or "ilu").lower() != "ilu" or (_get(sub, "factor.levels") or 0) != 0:
+        subt = (sub.get("type") or "ilu").lower()
+        if subt == "lu" and pct in ("bjacobi", "asm"):
+            opts["pc_type"] = "lu"       # exact block solves (block Jacobi; no overlap)
+        elif subt != "ilu" or (_get(sub, "factor.levels") or 0) != 0:
             raise NotImplementedError("sub-preconditioner %r" % (sub,))
         if opts:
             self.ode.set_opts(**opts)
