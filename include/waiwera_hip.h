@@ -38,7 +38,7 @@ enum { WAI_RP_FULLY_MOBILE = 0, WAI_RP_LINEAR = 1, WAI_RP_PICKENS = 2, WAI_RP_CO
        WAI_RP_GRANT = 4, WAI_RP_VAN_GENUCHTEN = 5, WAI_RP_TABLE = 6 };
 enum { WAI_CP_ZERO = 0, WAI_CP_LINEAR = 1, WAI_CP_VAN_GENUCHTEN = 2, WAI_CP_TABLE = 3 };
 enum { WAI_INTERP_LINEAR = 0, WAI_INTERP_STEP = 1, WAI_INTERP_PCHIP = 2 };
-enum { WAI_KSP_BCGS = 0, WAI_KSP_GMRES = 1, WAI_KSP_BCGSL = 2 };   /* linear.type (src/timestepper.F90:1725-1739): bcgs, gmres, bcgsl (BiCGStab(2)) */
+enum { WAI_KSP_BCGS = 0, WAI_KSP_GMRES = 1, WAI_KSP_BCGSL = 2, WAI_KSP_LGMRES = 3 };   /* linear.type (src/timestepper.F90:1725-1739): bcgs, gmres, bcgsl (BiCGStab(2)), lgmres (restart = Krylov directions + 2 error approximations) */
 /* linear.preconditioner.type (src/timestepper.F90:1745-1757): "bjacobi" PCBJACOBI, "asm" PCASM (the
  * reference's default: restricted, overlap 1), "none" PCNONE; the blocks' sub-preconditioner is
  * ILU(0) (:1668-1669, 1809-1834).  "ilu" of a serial run is bjacobi / asm with sub_ptr = NULL. */
@@ -88,7 +88,7 @@ typedef struct wai_eos_desc {
 
 /* "time.step.solver.*" keys: src/timestepper.F90:1567-1573,1645-1720,1998-2020 */
 typedef struct wai_solver_opts {
-  int ksp_type;            /* linear.type: bcgs (default) | gmres | bcgsl */
+  int ksp_type;            /* linear.type: bcgs (default) | gmres | bcgsl | lgmres */
   int gmres_restart;       /* linear.options.gmres.restart, PETSc default 30 */
   int ksp_max_its;         /* linear.maximum.iterations, PETSc default 10000 */
   double ksp_rtol;         /* linear.tolerance.relative, PETSc default 1e-5 */

@@ -1225,6 +1225,117 @@ static int ksp_gmres(wo_sim *s, int m, const double *val, const double *b, doubl
   return reason;
 }
 
+/* KSPLGMRES [PETSc]: "loose" GMRES of Baker, Jessup & Manteuffel (SIAM J. Matrix Anal. Appl. 26, 2005):
+ * restarted GMRES whose approximation space is augmented with the last AUG error approximations
+ * z = (x_i - x_{i-1}) / |x_i - x_{i-1}|.  PETSc's defaults: restart 30 = Krylov directions + error
+ * approximations once both are there (28 + 2; -ksp_lgmres_augment 2, not "constant": the first cycle
+ * builds 28 directions, the second 28 + 1), classical Gram-Schmidt without refinement, left
+ * preconditioning.  "linear.type": "lgmres", src/timestepper.F90:1729-1730. */
+static int ksp_lgmres(wo_sim *s, int restart, const double *val, const double *b, double *x,
+                      double rtol, double atol, int maxits, int *its, double *rnorm, double *hist) {
+  enum { AUG = 2 };
+  int bs = ksp_bs(s), n = bs * s->n_owned, nl = bs * s->n_prim;
+  int mk = restart - AUG > 1 ? restart - AUG : 1, mt = mk + AUG;
+  double *Vb = xmalloc(sizeof(double) * (size_t)nl * (mt + 1));
+  double *Z = xmalloc(sizeof(double) * (size_t)nl * AUG);     /* Z[0] most recent */
+  double *H = xmalloc(sizeof(double) * (mt + 1) * mt), *cs = xmalloc(sizeof(double) * mt);
+  double *sn = xmalloc(sizeof(double) * mt), *g = xmalloc(sizeof(double) * (mt + 1));
+  double *w = xmalloc(sizeof(double) * n), *tmp = xmalloc(sizeof(double) * n);
+  double *xl = xmalloc(sizeof(double) * nl), *yv = xmalloc(sizeof(double) * mt), *dx = xmalloc(sizeof(double) * nl);
+  int reason = 0, it = 0, naug = 0;
+  double ttol = 0.0, res = 0.0, res0 = 0.0;
+  memset(x, 0, sizeof(double) * n);
+  while (!reason) {
+    double *v0 = Vb;
+    if (it == 0) pc_apply(s, b, v0);
+    else {
+      memcpy(xl, x, sizeof(double) * n);
+      if (s->halo && s->n_halo) s->halo(s->user, xl, bs);
+      wo_bcsr_spmv(s->n_owned, bs, s->rowptr, s->colidx, val, xl, tmp);
+      for (int q = 0; q < n; q++) tmp[q] = b[q] - tmp[q];
+      pc_apply(s, tmp, v0);
+    }
+    res = sqrt(gdot(s, v0, v0, n));
+    if (it == 0) {
+      res0 = res;
+      ttol = fmax(rtol * res, atol);
+      if (hist) hist[0] = res;
+      if (res <= ttol) { reason = (res <= atol) ? 3 : 2; break; }
+    }
+    if (res == 0.0) { reason = 3; break; }
+    for (int q = 0; q < n; q++) v0[q] /= res;
+    memset(g, 0, sizeof(double) * (mt + 1));
+    g[0] = res;
+    int ms = mk + naug, j;
+    for (j = 0; j < ms && !reason; j++) {
+      double *vn = Vb + (size_t)nl * (j + 1);
+      double *dir = j < mk ? Vb + (size_t)nl * j : Z + (size_t)nl * (j - mk);   /* Krylov direction, then error approximations */
+      memcpy(xl, dir, sizeof(double) * n);
+      pc_amul(s, val, xl, tmp, w);
+      double hh[64];
+      for (int i = 0; i <= j; i++) {
+        const double *vi = Vb + (size_t)nl * i;
+        double t = 0.0;
+        for (int q = 0; q < n; q++) t += w[q] * vi[q];
+        hh[i] = t;
+      }
+      if (s->ar) s->ar(s->user, hh, j + 1, 0);
+      for (int i = 0; i <= j; i++) {
+        const double *vi = Vb + (size_t)nl * i;
+        H[i * mt + j] = hh[i];
+        for (int q = 0; q < n; q++) w[q] -= hh[i] * vi[q];
+      }
+      double hn = sqrt(gdot(s, w, w, n));
+      H[(j + 1) * mt + j] = hn;
+      if (hn != 0.0)
+        for (int q = 0; q < n; q++) vn[q] = w[q] / hn;
+      for (int i = 0; i < j; i++) {
+        double a = H[i * mt + j], bq = H[(i + 1) * mt + j];
+        H[i * mt + j] = cs[i] * a + sn[i] * bq;
+        H[(i + 1) * mt + j] = -sn[i] * a + cs[i] * bq;
+      }
+      {
+        double a = H[j * mt + j], bq = H[(j + 1) * mt + j], d = sqrt(a * a + bq * bq);
+        cs[j] = a / d; sn[j] = bq / d;
+        H[j * mt + j] = d; H[(j + 1) * mt + j] = 0.0;
+        g[j + 1] = -sn[j] * g[j];
+        g[j] = cs[j] * g[j];
+      }
+      res = fabs(g[j + 1]);
+      it++;
+      if (hist) hist[it] = res;
+      if (isnan(res)) reason = -9;
+      else if (res <= ttol) reason = (res <= atol) ? 3 : 2;
+      else if (res >= 1.e4 * res0) reason = -4;
+      else if (it >= maxits) reason = -3;
+      else if (hn == 0.0) reason = 3;
+    }
+    int k = j;
+    for (int i = k - 1; i >= 0; i--) {
+      double t = g[i];
+      for (int q = i + 1; q < k; q++) t -= H[i * mt + q] * yv[q];
+      yv[i] = t / H[i * mt + i];
+    }
+    memset(dx, 0, sizeof(double) * n);
+    for (int i = 0; i < k; i++) {
+      const double *di = i < mk ? Vb + (size_t)nl * i : Z + (size_t)nl * (i - mk);
+      for (int q = 0; q < n; q++) dx[q] += yv[i] * di[q];
+    }
+    for (int q = 0; q < n; q++) x[q] += dx[q];
+    /* the new error approximation goes to the front */
+    double dn = sqrt(gdot(s, dx, dx, n));
+    if (dn > 0.0) {
+      for (int a = AUG - 1; a > 0; a--) memcpy(Z + (size_t)nl * a, Z + (size_t)nl * (a - 1), sizeof(double) * n);
+      for (int q = 0; q < n; q++) Z[q] = dx[q] / dn;
+      if (naug < AUG) naug++;
+    }
+  }
+  *its = it;
+  *rnorm = res;
+  free(Vb); free(Z); free(H); free(cs); free(sn); free(g); free(w); free(tmp); free(xl); free(yv); free(dx);
+  return reason;
+}
+
 /* KSPBCGSL [PETSc]: BiCGStab(L) of Sleijpen & Fokkema (ETNA 1, 1993), L = 2 (PETSc's default ell),
  * no residual replacement (delta 0), minimum-residual polynomial from the normal equations; left
  * preconditioning, preconditioned residual norm tested after every sweep of L BiCG steps, which
@@ -1306,6 +1417,7 @@ int wo_ksp_solve(wo_sim *s, int ksp_type, int restart, const double *val, const 
   if (ksp_type == 1) return ksp_gmres(s, restart > 0 ? restart : 30, val, b, x, rtol, atol,
                                       maxits, its, rnorm, hist);
   if (ksp_type == 2) return ksp_bcgsl(s, val, b, x, rtol, atol, maxits, its, rnorm, hist);
+  if (ksp_type == 3) return ksp_lgmres(s, restart > 0 ? restart : 30, val, b, x, rtol, atol, maxits, its, rnorm, hist);
   return ksp_bcgs(s, val, b, x, rtol, atol, maxits, its, rnorm, hist);
 }
 

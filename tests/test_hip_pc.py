@@ -184,3 +184,17 @@ def test_lu_blocks(oracle):
         if one_block:
             assert its <= 2
         sim.destroy(); osim.close()
+
+
+def test_lgmres(oracle):
+    """LGMRES ("linear.type": "lgmres"; restart 10 = 8 Krylov directions + 2 error approximations)
+    against the oracle's restatement"""
+    lm, sim, osim, J, f = system(oracle, "we", (8, 8, 6), (4, 4, 2))
+    n = sim.num_dof
+    sim.set_opts(ksp_type="lgmres", gmres_restart=10, ksp_rtol=1e-11, ksp_max_its=3000)
+    x = np.zeros(n)
+    its, reason, rn = sim.ksp_solve(f, x)
+    oreason, xo, oits, hist = osim.ksp_solve(J, f, ksp_type=3, restart=10, rtol=1e-11, maxits=3000)
+    assert reason > 0 and oreason > 0
+    assert relmax(x, xo) < 1e-7 and abs(its - oits) <= max(3, oits // 8)
+    sim.destroy(); osim.close()

@@ -233,3 +233,17 @@ def test_bcgsl_solves_to_the_dense_solution(oracle):
     assert np.allclose(x2, xd, rtol=1e-7, atol=1e-9 * np.abs(xd).max())
     assert its2 <= its1 + 4
     sim.close()
+
+
+def test_lgmres_solves_and_beats_restarted_gmres(oracle):
+    """LGMRES(restart 8: 6 Krylov directions + 2 error approximations): the dense solution, in no more
+    iterations than GMRES(8) on the same operator"""
+    lm, sim, y, L, f, J, dt = setup(oracle, dims=(8, 8, 6), brick=(4, 4, 2), lens=True, dt=1.0e5)
+    A = to_bsr(sim, J).toarray()[:, : sim.n_owned * sim.np]
+    xd = np.linalg.solve(A, f)
+    r1, x1, its1, h1 = sim.ksp_solve(J, f, ksp_type=1, restart=8, rtol=1e-10, maxits=2000)
+    r3, x3, its3, h3 = sim.ksp_solve(J, f, ksp_type=3, restart=8, rtol=1e-10, maxits=2000)
+    assert r1 > 0 and r3 > 0
+    assert np.allclose(x3, xd, rtol=1e-6, atol=1e-8 * np.abs(xd).max())
+    assert its3 <= its1
+    sim.close()

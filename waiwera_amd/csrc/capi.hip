@@ -962,6 +962,121 @@ int ksp_gmres(wai_ctx* c, const double* b, double* x, int* its, int* reason, dou
   return 0;
 }
 
+// KSPLGMRES [PETSc]: "loose" GMRES (Baker, Jessup & Manteuffel 2005): restarted GMRES augmented with the
+// last two error approximations z = (x_i - x_{i-1}) / |.|; PETSc's defaults: restart 30 = 28 Krylov
+// directions + 2 error approximations, classical Gram-Schmidt, left preconditioning.  "linear.type":
+// "lgmres", src/timestepper.F90:1729-1730.  Same kernels as ksp_gmres; the Arnoldi step multiplies a basis
+// vector or an error approximation.
+int ksp_lgmres(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
+  Krylov& k = c->ks;
+  constexpr int AUG = 2;
+  const int n = k.n, mt = std::min(std::max(c->opts.gmres_restart, AUG + 1), k.basis_m), mk = mt - AUG, m = mt;
+  double* Z = k.basis + (size_t)(mt + 1) * k.nl;          // Z[0] most recent
+  double* dx = k.basis + (size_t)(mt + 1 + AUG) * k.nl;
+  int naug = 0;
+  const size_t ld = (size_t)k.nl;
+  const double rtol = c->opts.ksp_rtol, atol = c->opts.ksp_atol;
+  const int maxits = c->opts.ksp_max_its;
+  std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), yv(m);
+  vec_zero(c, x, n);
+  int it = 0;
+  double res = 0.0, res0 = 0.0, ttol = 0.0;
+  *reason = 0;
+  while (!*reason) {
+    double* v0 = k.basis;
+    if (it == 0) {
+      Prof p(c, KC_PC_APPLY);
+      if (pc_solve(c, b, v0, 0, nullptr, nullptr)) return -1;
+    } else {
+      vec_copy(c, k.P, x, n);
+      if (halo_exchange(c, k.P, c->np)) return -1;
+      { Prof p(c, KC_SPMV); launch_spmv(c, k.P, k.tmp); }
+      vec_waxpy(c, k.tmp, -1.0, k.tmp, b, n);
+      Prof p(c, KC_PC_APPLY);
+      if (pc_solve(c, k.tmp, v0, 0, nullptr, nullptr)) return -1;
+    }
+    {
+      Prof p(c, KC_VECTOR);
+      vec_dot(c, v0, v0, n, S_W2);
+      if (allreduce_scal(c, S_W2, 1)) return -1;
+    }
+    if (read_scal(c, S_W2, 1)) return -1;
+    res = std::sqrt(k.h_scal[S_W2]);
+    if (it == 0) {
+      res0 = res;
+      ttol = std::max(rtol * res, atol);
+      if (std::isnan(res)) { *reason = -9; break; }
+      if (res <= ttol) { *reason = (res <= atol) ? 3 : 2; break; }
+    }
+    if (res == 0.0) { *reason = 3; break; }
+    gmres_scale_to(c, v0, v0, S_W2, n);
+    std::fill(g.begin(), g.end(), 0.0);
+    g[0] = res;
+    int j = 0;
+    const int ms = mk + naug;
+    for (; j < ms && !*reason; j++) {
+      double* vj = j < mk ? k.basis + ld * j : Z + ld * (j - mk);   // Krylov direction, then error approximations
+      double* vn = k.basis + ld * (j + 1);
+      double* w = k.T;
+      if (pc_amul(c, vj, w)) return -1;
+      {
+        Prof p(c, KC_VECTOR);
+        gmres_mdot(c, w, j + 1);
+        if (allreduce_scal(c, S_H, j + 1)) return -1;
+        gmres_maxpy_norm(c, w, j + 1);
+        if (allreduce_scal(c, S_W2, 1)) return -1;
+        gmres_scale_to(c, vn, w, S_W2, n);
+      }
+      if (read_scal(c, S_W2, S_H + j + 1 - S_W2)) return -1;  // |w|^2 and h_0..h_j
+      for (int i = 0; i <= j; i++) H[(size_t)i * m + j] = k.h_scal[S_H + i];
+      const double hn = std::sqrt(k.h_scal[S_W2]);
+      H[(size_t)(j + 1) * m + j] = hn;
+      for (int i = 0; i < j; i++) {
+        const double a = H[(size_t)i * m + j], bq = H[(size_t)(i + 1) * m + j];
+        H[(size_t)i * m + j] = cs[i] * a + sn[i] * bq;
+        H[(size_t)(i + 1) * m + j] = -sn[i] * a + cs[i] * bq;
+      }
+      const double a = H[(size_t)j * m + j], bq = H[(size_t)(j + 1) * m + j], d = std::sqrt(a * a + bq * bq);
+      cs[j] = a / d; sn[j] = bq / d;
+      H[(size_t)j * m + j] = d; H[(size_t)(j + 1) * m + j] = 0.0;
+      g[j + 1] = -sn[j] * g[j];
+      g[j] = cs[j] * g[j];
+      res = std::fabs(g[j + 1]);
+      it++;
+      if (std::isnan(res)) *reason = -9;
+      else if (res <= ttol) *reason = (res <= atol) ? 3 : 2;
+      else if (res >= 1.e4 * res0) *reason = -4;
+      else if (it >= maxits) *reason = -3;
+      else if (hn == 0.0) *reason = 3;
+    }
+    const int kk = j;
+    for (int i = kk - 1; i >= 0; i--) {
+      double t = g[i];
+      for (int q = i + 1; q < kk; q++) t -= H[(size_t)i * m + q] * yv[q];
+      yv[i] = t / H[(size_t)i * m + i];
+    }
+    {
+      Prof p(c, KC_VECTOR);
+      vec_zero(c, dx, n);
+      gmres_update_x(c, dx, yv.data(), std::min(kk, mk));
+      HIPCHK(c, hipStreamSynchronize(c->stream));  // yv is reused by the next cycle
+      for (int i = mk; i < kk; i++) vec_waxpy(c, dx, yv[i], Z + ld * (i - mk), dx, n);
+      vec_waxpy(c, x, 1.0, dx, x, n);
+      vec_dot(c, dx, dx, n, S_W2);
+      if (allreduce_scal(c, S_W2, 1)) return -1;
+    }
+    if (read_scal(c, S_W2, 1)) return -1;
+    if (k.h_scal[S_W2] > 0.0) {   // the new error approximation goes to the front
+      for (int a = AUG - 1; a > 0; a--) vec_copy(c, Z + ld * a, Z + ld * (a - 1), n);
+      gmres_scale_to(c, Z, dx, S_W2, n);
+      if (naug < AUG) naug++;
+    }
+  }
+  *its = it;
+  *rnorm = res;
+  return 0;
+}
+
 // up to two inner products brought to the host: (a1,b1) -> out[0], (a2,b2) -> out[1] (a2 null: one);
 // one all-reduce on several ranks
 int host_dots(wai_ctx* c, const double* a1, const double* b1, const double* a2, const double* b2, double* out) {
@@ -1066,6 +1181,7 @@ int do_ksp(wai_ctx* c, const double* b, double* x, int* its, int* reason, double
   }
   if (c->opts.ksp_type == WAI_KSP_GMRES) return ksp_gmres(c, b, x, its, reason, rnorm);
   if (c->opts.ksp_type == WAI_KSP_BCGSL) return ksp_bcgsl(c, b, x, its, reason, rnorm);
+  if (c->opts.ksp_type == WAI_KSP_LGMRES) return ksp_lgmres(c, b, x, its, reason, rnorm);
   return ksp_bcgs(c, b, x, its, reason, rnorm);
 }
 
@@ -1403,9 +1519,9 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
     HIPCHK(c, hipMemset(*p, 0, (nl + 16) * sizeof(double)));
   }
   k.basis_m = std::max(1, std::min(c->opts.gmres_restart > 0 ? c->opts.gmres_restart : 30, 40));
-  if (c->opts.ksp_type == WAI_KSP_GMRES) {
-    if (dev_alloc(c, &k.basis, (size_t)(k.basis_m + 1) * nl)) return -1;
-    HIPCHK(c, hipMemset(k.basis, 0, (size_t)(k.basis_m + 1) * nl * sizeof(double)));
+  if (c->opts.ksp_type == WAI_KSP_GMRES || c->opts.ksp_type == WAI_KSP_LGMRES) {
+    if (dev_alloc(c, &k.basis, (size_t)(k.basis_m + 4) * nl)) return -1;
+    HIPCHK(c, hipMemset(k.basis, 0, (size_t)(k.basis_m + 4) * nl * sizeof(double)));
   }
   k.nb_max = std::max(1024, c->ilu.nsub);
   if (dev_alloc(c, &k.partials, (size_t)NSLOTS * k.nb_max) || dev_alloc(c, &k.scal, (size_t)NSCAL)) return -1;
@@ -1443,10 +1559,15 @@ int wai_set_opts(wai_ctx* c, const wai_solver_opts* o) {
   if (o->pc_type < WAI_PC_BJACOBI || o->pc_type > WAI_PC_LU) { c->err = "unknown preconditioner type"; return -2; }
   if (o->pc_type != c->opts.pc_type || o->asm_overlap != c->opts.asm_overlap) c->ilu.factored = false;
   c->opts = *o;
-  if (o->ksp_type == WAI_KSP_GMRES && (old_type != WAI_KSP_GMRES || !c->ks.basis)) {
-    if (c->ks.basis) (void)hipFree(c->ks.basis);
-    c->ks.basis_m = std::max(1, std::min(o->gmres_restart > 0 ? o->gmres_restart : 30, 40));
-    if (dev_alloc(c, &c->ks.basis, (size_t)(c->ks.basis_m + 1) * c->ks.nl)) return -1;
+  (void)old_type;
+  if (o->ksp_type == WAI_KSP_GMRES || o->ksp_type == WAI_KSP_LGMRES) {
+    const int want = std::max(1, std::min(o->gmres_restart > 0 ? o->gmres_restart : 30, 40));
+    if (!c->ks.basis || c->ks.basis_m < want) {
+      if (c->ks.basis) (void)hipFree(c->ks.basis);
+      c->ks.basis_m = want;
+      if (dev_alloc(c, &c->ks.basis, (size_t)(want + 4) * c->ks.nl)) return -1;   // + 2 error approximations + the update (lgmres)
+      HIPCHK(c, hipMemset(c->ks.basis, 0, (size_t)(want + 4) * c->ks.nl * sizeof(double)));
+    }
   }
   return 0;
 }
@@ -2169,8 +2290,8 @@ int wai_tracer_solve(wai_ctx* c, int method, double dt, double ratio, const doub
   *reason = 100;
   int rc = 0;
   if (t.ksp_type == WAI_KSP_GMRES && !c->ks.basis) {  // the flow solver may never have needed one
-    if (dev_alloc(c, &c->ks.basis, (size_t)(c->ks.basis_m + 1) * c->ks.nl)) return -1;
-    HIPCHK(c, hipMemset(c->ks.basis, 0, (size_t)(c->ks.basis_m + 1) * c->ks.nl * sizeof(double)));
+    if (dev_alloc(c, &c->ks.basis, (size_t)(c->ks.basis_m + 4) * c->ks.nl)) return -1;
+    HIPCHK(c, hipMemset(c->ks.basis, 0, (size_t)(c->ks.basis_m + 4) * c->ks.nl * sizeof(double)));
   }
   {
     AuxScope scope(c);

@@ -17,7 +17,7 @@ RP = {"fully_mobile": 0, "fully mobile": 0, "linear": 1, "pickens": 2, "corey": 
       "van_genuchten": 5, "van genuchten": 5, "table": 6}
 CP = {"zero": 0, "linear": 1, "van_genuchten": 2, "van genuchten": 2, "table": 3}
 INTERP = {"linear": 0, "step": 1, "pchip": 2}   # src/interpolation.F90:139-156
-KSP = {"bcgs": 0, "gmres": 1, "bcgsl": 2}
+KSP = {"bcgs": 0, "gmres": 1, "bcgsl": 2, "lgmres": 3}
 PC = {"bjacobi": 0, "asm": 1, "none": 2, "lu": 3}   # linear.preconditioner.type (src/timestepper.F90:1745-1757)
 KCLASS = ["eos", "residual", "jacobian", "spmv", "pc_apply", "pc_setup", "vector", "transitions"]
 

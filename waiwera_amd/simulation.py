@@ -341,7 +341,7 @@ class Simulation:
         if _get(nl, "minimum.iterations") is not None:
             opts["min_newton_its"] = nl["minimum"]["iterations"]
         lin = _get(step, "solver.linear", {}) or {}
-        if lin.get("type") in ("bcgs", "gmres", "bcgsl"):
+        if lin.get("type") in ("bcgs", "gmres", "bcgsl", "lgmres"):
             opts["ksp_type"] = lin["type"]
         elif lin.get("type") is not None:
             raise NotImplementedError("linear solver type %r" % lin["type"])
