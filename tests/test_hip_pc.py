@@ -177,10 +177,10 @@ def test_lu_blocks(oracle):
         sub = [0, lm.n_owned] if one_block else list(lm.sub_ptr)
         for a, b in zip(sub[:-1], sub[1:]):
             ref[2 * a:2 * b] = np.linalg.solve(A[2 * a:2 * b, 2 * a:2 * b], r[2 * a:2 * b])
-        assert relmax(z, ref) < 1e-9
+        assert relmax(z, ref) < 1e-6        # cond(A) ~ 6e10: an explicit inverse is good to cond x eps
         x = np.zeros(n)
         its, reason, rn = sim.ksp_solve(f, x)
-        assert reason > 0 and relmax(x, np.linalg.solve(A, f)) < 1e-7
+        assert reason > 0 and relmax(x, np.linalg.solve(A, f)) < 1e-5
         if one_block:
             assert its <= 2
         sim.destroy(); osim.close()
