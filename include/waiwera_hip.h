@@ -173,13 +173,16 @@ int wai_set_source_controls(wai_ctx *ctx, const wai_source_control *controls);
  * Node references are (kind, index): 0 none, 1 source (wai_set_sources order), 2 group, 3 reinjector.
  * rate_specified / enthalpy_specified per source: whether the input gives the source a rate (value or
  * control) / an enthalpy of its own.  limit_type 0 total, 1 water, 2 steam, -1 unused (3 per group).
+ * grp_sep (may be NULL): a group's own separator, 8 doubles per group -- (hf, hg) of stage 1 from
+ * wai_separator_enthalpies, then (hf, hg) of stages 2..4; hg = 0: none (the separated flows are then
+ * the sums of the inputs').
  * The FD Jacobian differences with the network's factors held at the last pass: the couplings between
  * cells that src/flow_simulation.F90:3023-3084 adds to the matrix are not there (inexact Newton).
  * All sources of the network must live on this rank.  Call after wai_set_sources / controls. */
 int wai_set_source_network(wai_ctx *ctx, const int *rate_specified, const int *enthalpy_specified,
                            int n_groups, const int *grp_ptr, const int *grp_in_kind, const int *grp_in,
                            const int *grp_scaling, const int *grp_limit_type, const double *grp_limit,
-                           int n_reinjectors, const int *rj_in_kind, const int *rj_in, const int *rj_out_ptr,
+                           const double *grp_sep, int n_reinjectors, const int *rj_in_kind, const int *rj_in, const int *rj_out_ptr,
                            const int *out_flow, const int *out_kind, const int *out_node,
                            const double *out_rate, const double *out_proportion, const double *out_enthalpy,
                            const int *rj_overflow_kind, const int *rj_overflow);
@@ -187,6 +190,18 @@ int wai_set_source_network(wai_ctx *ctx, const int *rate_specified, const int *e
  * steam_enthalpy), reinjectors 8 each (output water / steam rate, overflow rate, enthalpy, water rate,
  * water enthalpy, steam rate, steam enthalpy) -- the network_group / network_reinject output fields */
 int wai_get_source_network(wai_ctx *ctx, double *groups, double *reinjectors);
+/* the same network pass on given source rates / enthalpies, without a context or a device (host logic
+ * only: tests pin it on the known answers of test/unit/src/source_network_reinjector_test.F90).
+ * src_sep: 8 doubles per source like grp_sep; sources_out / groups_out 6 doubles per node (rate,
+ * enthalpy, water_rate, water_enthalpy, steam_rate, steam_enthalpy), reinjectors_out 8 each. */
+int wai_network_evaluate(int n_sources, const double *rate, const double *enthalpy, const double *src_sep,
+                         const int *rate_specified, const int *enthalpy_specified, int n_groups,
+                         const int *grp_ptr, const int *grp_in_kind, const int *grp_in, const int *grp_scaling,
+                         const int *grp_limit_type, const double *grp_limit, const double *grp_sep,
+                         int n_reinjectors, const int *rj_in_kind, const int *rj_in, const int *rj_out_ptr,
+                         const int *out_flow, const int *out_kind, const int *out_node, const double *out_rate,
+                         const double *out_proportion, const double *out_enthalpy, const int *rj_overflow_kind,
+                         const int *rj_overflow, double *sources_out, double *groups_out, double *reinjectors_out);
 
 /* enthalpies of saturated water and steam at a separator pressure, in the context's
  * thermodynamics (separator_stage_init, src/separator.F90:108-136): sep_hf, sep_hg above */

@@ -407,7 +407,8 @@ void net_group_sum(Network& nw, NetGroup& g) {   // source_network_group_sum + d
   for (const NetRef& r : g.in) { const NetNode& n = net_node(nw, r); q += n.rate; qh += n.rate * n.enth; }
   g.node.enth = std::fabs(q) > 1.e-9 ? qh / q : 0.0;
   g.node.rate = q;
-  if (q < 0.0) {
+  if (q < 0.0 && g.sep.sep_hg > 0.0) net_separate(g.sep, q, g.node.enth, g.node);   // the group's own separator (:375-403)
+  else if (q < 0.0) {
     double wq = 0, wqh = 0, sq = 0, sqh = 0;
     for (const NetRef& r : g.in) {
       const NetNode& n = net_node(nw, r);
@@ -469,14 +470,10 @@ void net_total(double wr, double wh, double sr, double sh, double& rate, double&
   enth = rate > 1.e-6 ? (wr * wh + sr * sh) / rate : 0.0;
 }
 
-int network_update(wai_ctx* c) {
-  Network& nw = c->net;
-  const int n = c->src.n;
-  if (!nw.on || n == 0) return 0;
-  // the sources' own (controlled) rates and flowing enthalpies on the current fluid
-  launch_source_rates(c, nw.d_raw, true);
-  HIPCHK(c, hipMemcpyAsync(nw.h_raw.data(), nw.d_raw, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+// one pass of the network on the host: nw.h_raw (rates, then enthalpies of the sources' own controls) ->
+// node states, nw.is_out / out_rate / out_enth for the sources the reinjectors feed
+void network_evaluate(Network& nw) {
+  const int n = (int)nw.src.size();
   for (int i = 0; i < n; i++) { nw.src[i].enth = nw.h_raw[n + i]; net_source_set_rate(nw, i, nw.h_raw[i]); }
   for (NetGroup& g : nw.groups) net_group_sum(nw, g);
   for (size_t gi = 0; gi < nw.groups.size(); gi++) {
@@ -488,8 +485,10 @@ int network_update(wai_ctx* c) {
   }
   // what the injection sources can take: their own specified rate, -1 if none
   auto specified = [&](int i) { return nw.rate_specified[i] ? nw.h_raw[i] : -1.0; };
-  std::vector<double> out_rate(n, 0.0), out_enth(n, 0.0);
-  std::vector<char> is_out(n, 0);
+  std::vector<double>& out_rate = nw.out_rate;
+  std::vector<double>& out_enth = nw.out_enth;
+  std::vector<char>& is_out = nw.is_out;
+  out_rate.assign(n, 0.0); out_enth.assign(n, 0.0); is_out.assign(n, 0);
   for (NetReinjector& r : nw.reinjectors) r.fed = false;
   for (int ri : nw.reinj_order) {   // capacities, downstream first
     NetReinjector& r = nw.reinjectors[ri];
@@ -536,6 +535,7 @@ int network_update(wai_ctx* c) {
       if (o.out.kind == 1) {
         const int i = o.out.index;
         is_out[i] = 1; out_rate[i] = o.node.rate; out_enth[i] = o.node.enth;
+        nw.src[i].wrate = qw; nw.src[i].wenth = wh; nw.src[i].srate = qs; nw.src[i].senth = sh;
       } else if (o.out.kind == 3) {
         NetReinjector& d = nw.reinjectors[o.out.index];
         if (!d.fed) { d.in_w = d.in_wh = d.in_s = d.in_sh = 0.0; d.fed = true; }
@@ -547,22 +547,39 @@ int network_update(wai_ctx* c) {
     if (r.overflow.kind == 3) {
       NetReinjector& d = nw.reinjectors[r.overflow.index];
       d.in_w = wbal; d.in_wh = r.in_wh; d.in_s = sbal; d.in_sh = r.in_sh; d.fed = true;
-    } else if (r.overflow.kind == 1) {
+    } else if (r.overflow.kind == 1) {   // an overflow source takes what is left, whatever its own rate says (:1002-1006)
       const int i = r.overflow.index;
-      double q = r.over.rate;
-      net_node_limit_rate(specified(i), q);
-      is_out[i] = 1; out_rate[i] = q; out_enth[i] = r.over.enth;
+      is_out[i] = 1; out_rate[i] = r.over.rate; out_enth[i] = r.over.enth;
+      nw.src[i].wrate = wbal; nw.src[i].wenth = r.in_wh; nw.src[i].srate = sbal; nw.src[i].senth = r.in_sh;
     }
   }
+  for (int i = 0; i < n; i++)
+    if (is_out[i]) {   // reinjector_output_update (:283-320): rate always, enthalpy unless the source has its own
+      nw.src[i].rate = out_rate[i];
+      nw.src[i].enth = (nw.enth_specified[i] && i < (int)nw.h_enth0.size()) ? nw.h_enth0[i] : out_enth[i];
+    }
+}
+
+int network_update(wai_ctx* c) {
+  Network& nw = c->net;
+  const int n = c->src.n;
+  if (!nw.on || n == 0) return 0;
+  // the sources' own (controlled) rates and flowing enthalpies on the current fluid
+  launch_source_rates(c, nw.d_raw, true);
+  HIPCHK(c, hipMemcpyAsync(nw.h_raw.data(), nw.d_raw, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  network_evaluate(nw);
+  const std::vector<double>& out_rate = nw.out_rate;
+  const std::vector<double>& out_enth = nw.out_enth;
+  const std::vector<char>& is_out = nw.is_out;
   // hand the result to the device: scale factors of group members, rates / enthalpies of reinjection sources
   bool enth_changed = false;
   for (int i = 0; i < n; i++) {
     double mode = 0.0, val = 0.0;
     if (is_out[i]) {
       mode = 2.0; val = out_rate[i];
-      const double e = nw.enth_specified[i] ? nw.h_enth0[i] : out_enth[i];
+      const double e = nw.src[i].enth;
       if (e != nw.h_enth[i]) { nw.h_enth[i] = e; enth_changed = true; }
-      nw.src[i].rate = val; nw.src[i].enth = e;
     } else if (nw.src[i].rate != nw.h_raw[i]) {
       mode = 1.0; val = nw.h_raw[i] != 0.0 ? nw.src[i].rate / nw.h_raw[i] : 1.0;
     }
@@ -1735,37 +1752,28 @@ int wai_set_source_controls(wai_ctx* c, const wai_source_control* controls) {
   return 0;
 }
 
-// Source network (src/source_network_group.F90, source_network_reinjector.F90; input "network.group",
-// "network.reinject").  Node references are (kind, index) pairs: kind 0 none, 1 source, 2 group,
-// 3 reinjector.  Groups in dependency order (a group after the groups it takes in).
-int wai_set_source_network(wai_ctx* c, const int* rate_specified, const int* enthalpy_specified, int n_groups,
-                           const int* grp_ptr, const int* grp_in_kind, const int* grp_in, const int* grp_scaling,
-                           const int* grp_limit_type, const double* grp_limit, int n_reinj, const int* rj_in_kind,
-                           const int* rj_in, const int* rj_out_ptr, const int* out_flow, const int* out_kind,
-                           const int* out_node, const double* out_rate, const double* out_proportion,
-                           const double* out_enthalpy, const int* rj_overflow_kind, const int* rj_overflow) {
-  if (!c) return -2;
-  Network& nw = c->net;
-  const int n = c->src.n;
-  auto ctl = nw.h_ctl; auto e0 = nw.h_enth0;
-  if (nw.d_raw) (void)hipFree(nw.d_raw);
-  if (c->src.net) { (void)hipFree(c->src.net); c->src.net = nullptr; }
-  nw = Network();
-  nw.h_ctl = ctl; nw.h_enth0 = e0;
-  if (n_groups <= 0 && n_reinj <= 0) return 0;
-  if (!n || !rate_specified || !enthalpy_specified) { c->err = "source network without sources"; return -2; }
+}  // extern "C"
+namespace {
+// the flat description of wai_set_source_network -> Network (no device involved)
+int network_build(Network& nw, int n, const int* rate_specified, const int* enthalpy_specified, int n_groups,
+                  const int* grp_ptr, const int* grp_in_kind, const int* grp_in, const int* grp_scaling,
+                  const int* grp_limit_type, const double* grp_limit, const double* grp_sep, int n_reinj,
+                  const int* rj_in_kind, const int* rj_in, const int* rj_out_ptr, const int* out_flow,
+                  const int* out_kind, const int* out_node, const double* out_rate, const double* out_proportion,
+                  const double* out_enthalpy, const int* rj_overflow_kind, const int* rj_overflow, std::string& err) {
+  if (!n || !rate_specified || !enthalpy_specified) { err = "source network without sources"; return -2; }
   auto ok = [&](int kind, int idx) {
     return kind == 0 || (kind == 1 && idx >= 0 && idx < n) || (kind == 2 && idx >= 0 && idx < n_groups) ||
            (kind == 3 && idx >= 0 && idx < n_reinj);
   };
   nw.rate_specified.assign(rate_specified, rate_specified + n);
   nw.enth_specified.assign(enthalpy_specified, enthalpy_specified + n);
-  nw.groups.resize(std::max(n_groups, 0));
+  nw.groups.assign(std::max(n_groups, 0), NetGroup());
   for (int g = 0; g < n_groups; g++) {
     NetGroup& G = nw.groups[g];
     for (int q = grp_ptr[g]; q < grp_ptr[g + 1]; q++) {
       if (!ok(grp_in_kind[q], grp_in[q]) || grp_in_kind[q] == 0 || grp_in_kind[q] == 3 || (grp_in_kind[q] == 2 && grp_in[q] >= g)) {
-        c->err = "source network group: inputs are sources or earlier groups"; return -2;
+        err = "source network group: inputs are sources or earlier groups"; return -2;
       }
       NetRef r; r.kind = grp_in_kind[q]; r.index = grp_in[q];
       G.in.push_back(r);
@@ -1775,18 +1783,23 @@ int wai_set_source_network(wai_ctx* c, const int* rate_specified, const int* ent
       if (grp_limit_type && grp_limit_type[3 * g + l] >= 0) {
         G.limit_type[G.n_limit] = grp_limit_type[3 * g + l]; G.limit[G.n_limit] = grp_limit[3 * g + l]; G.n_limit++;
       }
+    std::memset(&G.sep, 0, sizeof(G.sep));
+    if (grp_sep) {
+      G.sep.sep_hf = grp_sep[8 * g]; G.sep.sep_hg = grp_sep[8 * g + 1];
+      for (int q = 0; q < 6; q++) G.sep.sep_more[q] = grp_sep[8 * g + 2 + q];
+    }
   }
-  nw.reinjectors.resize(std::max(n_reinj, 0));
+  nw.reinjectors.assign(std::max(n_reinj, 0), NetReinjector());
   for (int r = 0; r < n_reinj; r++) {
     NetReinjector& R = nw.reinjectors[r];
     if (!ok(rj_in_kind[r], rj_in[r]) || rj_in_kind[r] == 3 || !ok(rj_overflow_kind[r], rj_overflow[r]) || rj_overflow_kind[r] == 2) {
-      c->err = "source network reinjector: bad input / overflow reference"; return -2;
+      err = "source network reinjector: bad input / overflow reference"; return -2;
     }
     R.in.kind = rj_in_kind[r]; R.in.index = rj_in[r];
     R.overflow.kind = rj_overflow_kind[r]; R.overflow.index = rj_overflow[r];
     for (int q = rj_out_ptr[r]; q < rj_out_ptr[r + 1]; q++) {
       if (!ok(out_kind[q], out_node[q]) || out_kind[q] == 2 || (out_flow[q] != 1 && out_flow[q] != 2)) {
-        c->err = "source network reinjector: bad output"; return -2;
+        err = "source network reinjector: bad output"; return -2;
       }
       NetOutput o;
       o.flow = out_flow[q]; o.out.kind = out_kind[q]; o.out.index = out_node[q];
@@ -1795,7 +1808,8 @@ int wai_set_source_network(wai_ctx* c, const int* rate_specified, const int* ent
     }
   }
   {   // order: a reinjector after every reinjector it delivers or overflows to
-    std::vector<int> state(n_reinj, 0);
+    nw.reinj_order.clear();
+    std::vector<int> state(std::max(n_reinj, 0), 0);
     std::function<bool(int)> visit = [&](int r) -> bool {
       if (state[r] == 2) return true;
       if (state[r] == 1) return false;
@@ -1807,16 +1821,83 @@ int wai_set_source_network(wai_ctx* c, const int* rate_specified, const int* ent
       nw.reinj_order.push_back(r);
       return true;
     };
-    for (int r = 0; r < n_reinj; r++) if (!visit(r)) { c->err = "source network reinjectors form a cycle"; return -2; }
+    for (int r = 0; r < n_reinj; r++) if (!visit(r)) { err = "source network reinjectors form a cycle"; return -2; }
   }
   nw.src.assign(n, NetNode());
   nw.h_net.assign(2 * (size_t)n, 0.0);
   nw.h_raw.assign(2 * (size_t)n, 0.0);
   if (nw.h_enth0.size() != (size_t)n) nw.h_enth0.assign(n, 0.0);
   nw.h_enth = nw.h_enth0;
+  return 0;
+}
+}  // namespace
+extern "C" {
+
+// Source network (src/source_network_group.F90, source_network_reinjector.F90; input "network.group",
+// "network.reinject").  Node references are (kind, index) pairs: kind 0 none, 1 source, 2 group,
+// 3 reinjector.  Groups in dependency order (a group after the groups it takes in).
+int wai_set_source_network(wai_ctx* c, const int* rate_specified, const int* enthalpy_specified, int n_groups,
+                           const int* grp_ptr, const int* grp_in_kind, const int* grp_in, const int* grp_scaling,
+                           const int* grp_limit_type, const double* grp_limit, const double* grp_sep, int n_reinj,
+                           const int* rj_in_kind, const int* rj_in, const int* rj_out_ptr, const int* out_flow,
+                           const int* out_kind, const int* out_node, const double* out_rate,
+                           const double* out_proportion, const double* out_enthalpy, const int* rj_overflow_kind,
+                           const int* rj_overflow) {
+  if (!c) return -2;
+  Network& nw = c->net;
+  const int n = c->src.n;
+  auto ctl = nw.h_ctl; auto e0 = nw.h_enth0;
+  if (nw.d_raw) (void)hipFree(nw.d_raw);
+  if (c->src.net) { (void)hipFree(c->src.net); c->src.net = nullptr; }
+  nw = Network();
+  nw.h_ctl = ctl; nw.h_enth0 = e0;
+  if (n_groups <= 0 && n_reinj <= 0) return 0;
+  if (c->comm && c->comm->nranks > 1) { c->err = "source networks across ranks are not supported"; return -2; }
+  if (int e = network_build(nw, n, rate_specified, enthalpy_specified, n_groups, grp_ptr, grp_in_kind, grp_in, grp_scaling,
+                            grp_limit_type, grp_limit, grp_sep, n_reinj, rj_in_kind, rj_in, rj_out_ptr, out_flow, out_kind,
+                            out_node, out_rate, out_proportion, out_enthalpy, rj_overflow_kind, rj_overflow, c->err))
+    return e;
   if (dev_alloc(c, &nw.d_raw, 2 * (size_t)n) || dev_alloc(c, &c->src.net, 2 * (size_t)n)) return -1;
   HIPCHK(c, hipMemset(c->src.net, 0, sizeof(double) * 2 * n));
   nw.on = true;
+  return 0;
+}
+// The same network pass without a context or a device (host logic only; tests): the sources' own rates
+// and enthalpies and their separators (8 doubles per source: hf, hg of stage 1, then (hf, hg) of stages
+// 2..4, hg = 0: no separator / no further stage) in, node states out -- sources and groups 6 doubles each
+// (rate, enthalpy, water_rate, water_enthalpy, steam_rate, steam_enthalpy), reinjectors 8 each as
+// wai_get_source_network.
+int wai_network_evaluate(int n_sources, const double* rate, const double* enthalpy, const double* src_sep,
+                         const int* rate_specified, const int* enthalpy_specified, int n_groups,
+                         const int* grp_ptr, const int* grp_in_kind, const int* grp_in, const int* grp_scaling,
+                         const int* grp_limit_type, const double* grp_limit, const double* grp_sep, int n_reinj,
+                         const int* rj_in_kind, const int* rj_in, const int* rj_out_ptr, const int* out_flow,
+                         const int* out_kind, const int* out_node, const double* out_rate,
+                         const double* out_proportion, const double* out_enthalpy, const int* rj_overflow_kind,
+                         const int* rj_overflow, double* sources_out, double* groups_out, double* reinjectors_out) {
+  if (!rate || !enthalpy || n_sources <= 0) return -2;
+  Network nw;
+  std::string err;
+  nw.h_enth0.assign(enthalpy, enthalpy + n_sources);
+  if (int e = network_build(nw, n_sources, rate_specified, enthalpy_specified, n_groups, grp_ptr, grp_in_kind, grp_in,
+                            grp_scaling, grp_limit_type, grp_limit, grp_sep, n_reinj, rj_in_kind, rj_in, rj_out_ptr, out_flow,
+                            out_kind, out_node, out_rate, out_proportion, out_enthalpy, rj_overflow_kind, rj_overflow, err))
+    return e;
+  nw.h_ctl.assign(n_sources, SrcCtl{});
+  for (int i = 0; i < n_sources && src_sep; i++) {
+    nw.h_ctl[i].sep_hf = src_sep[8 * i]; nw.h_ctl[i].sep_hg = src_sep[8 * i + 1];
+    for (int q = 0; q < 6; q++) nw.h_ctl[i].sep_more[q] = src_sep[8 * i + 2 + q];
+  }
+  for (int i = 0; i < n_sources; i++) { nw.h_raw[i] = rate[i]; nw.h_raw[n_sources + i] = enthalpy[i]; }
+  network_evaluate(nw);
+  auto put = [](const NetNode& n, double* o) { o[0] = n.rate; o[1] = n.enth; o[2] = n.wrate; o[3] = n.wenth; o[4] = n.srate; o[5] = n.senth; };
+  for (int i = 0; sources_out && i < n_sources; i++) put(nw.src[i], sources_out + 6 * i);
+  for (size_t g = 0; groups_out && g < nw.groups.size(); g++) put(nw.groups[g].node, groups_out + 6 * g);
+  for (size_t r = 0; reinjectors_out && r < nw.reinjectors.size(); r++) {
+    const NetReinjector& R = nw.reinjectors[r];
+    const double v[8] = {R.out_w, R.out_s, R.over.rate, R.over.enth, R.over.wrate, R.over.wenth, R.over.srate, R.over.senth};
+    std::memcpy(reinjectors_out + 8 * r, v, sizeof(v));
+  }
   return 0;
 }
 // state of the network after the last pass: groups 6 doubles each (rate, enthalpy, water_rate,

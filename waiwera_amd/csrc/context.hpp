@@ -48,6 +48,7 @@ struct NetGroup {
   int scaling = 0;                                 // 0 uniform, 1 progressive
   int n_limit = 0, limit_type[3] = {0, 0, 0};      // 0 total, 1 water, 2 steam
   double limit[3] = {0, 0, 0};
+  SrcCtl sep{};                                    // the group's own separator (sep_hf, sep_hg, sep_more); sep_hg = 0: none
   NetNode node;
 };
 struct NetOutput {
@@ -73,7 +74,8 @@ struct Network {
   std::vector<int> reinj_order;                    // outputs / overflow targets before their feeders
   std::vector<int> rate_specified, enth_specified; // per source
   std::vector<NetNode> src;                        // per source, last pass
-  std::vector<double> h_net, h_enth0, h_enth, h_raw;
+  std::vector<double> h_net, h_enth0, h_enth, h_raw, out_rate, out_enth;
+  std::vector<char> is_out;                        // sources a reinjector feeds (last pass)
   std::vector<SrcCtl> h_ctl;                       // host copy of the control records (separators)
   double* d_raw = nullptr;                         // device scratch: raw rates and enthalpies, 2 n
 };

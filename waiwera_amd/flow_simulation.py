@@ -96,31 +96,9 @@ class FlowSimulation:
         enthalpy_specified per source; groups [dict(inputs=[(kind, index)], scaling 0 | 1, limits=[(type, limit)])];
         reinjectors [dict(input=(kind, index), outputs=[dict(flow 1 | 2, out=(kind, index), rate, proportion,
         enthalpy)], overflow=(kind, index))]); kinds 0 none, 1 source, 2 group, 3 reinjector"""
-        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)   # noqa: E731
-        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
-        P = lambda a, t: a.ctypes.data_as(t)                       # noqa: E731
         g, r = spec["groups"], spec["reinjectors"]
-        gptr = i32(np.concatenate([[0], np.cumsum([len(x["inputs"]) for x in g])])) if g else i32([0])
-        gk = i32([k for x in g for k, _ in x["inputs"]] or [0]); gi = i32([i for x in g for _, i in x["inputs"]] or [0])
-        gs = i32([x["scaling"] for x in g] or [0])
-        glt, gl = np.full(3 * max(len(g), 1), -1, dtype=np.int32), np.zeros(3 * max(len(g), 1))
-        for q, x in enumerate(g):
-            for l, (t, v) in enumerate(x["limits"]):
-                glt[3 * q + l], gl[3 * q + l] = t, v
-        rk = i32([x["input"][0] for x in r] or [0]); ri = i32([x["input"][1] for x in r] or [0])
-        rptr = i32(np.concatenate([[0], np.cumsum([len(x["outputs"]) for x in r])])) if r else i32([0])
-        outs = [o for x in r for o in x["outputs"]]
-        of = i32([o["flow"] for o in outs] or [1]); ok = i32([o["out"][0] for o in outs] or [0])
-        on = i32([o["out"][1] for o in outs] or [0])
-        orate = f64([o["rate"] for o in outs] or [0]); oprop = f64([o["proportion"] for o in outs] or [0])
-        oenth = f64([o["enthalpy"] for o in outs] or [0])
-        vk = i32([x["overflow"][0] for x in r] or [0]); vi = i32([x["overflow"][1] for x in r] or [0])
-        rs, es = i32(spec["rate_specified"]), i32(spec["enthalpy_specified"])
-        pi, pd = _lib.pi, _lib.pd
-        self._chk(LIB.wai_set_source_network(self.h, P(rs, pi), P(es, pi), len(g), P(gptr, pi), P(gk, pi), P(gi, pi), P(gs, pi),
-                                             P(glt, pi), P(gl, pd), len(r), P(rk, pi), P(ri, pi), P(rptr, pi), P(of, pi),
-                                             P(ok, pi), P(on, pi), P(orate, pd), P(oprop, pd), P(oenth, pd), P(vk, pi), P(vi, pi)),
-                  "set_source_network")
+        self._net_keep, args = _lib.network_arrays(spec)
+        self._chk(LIB.wai_set_source_network(self.h, *args), "set_source_network")
         self._net_sizes = (len(g), len(r))
 
     def source_network(self):

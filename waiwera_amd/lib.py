@@ -115,7 +115,9 @@ def _load():
         "wai_update_sources": (i32, [vp, pd, pd]),
         "wai_set_source_controls": (i32, [vp, C.POINTER(SourceControl)]),
         "wai_get_source_rates": (i32, [vp, pd, pd]),
-        "wai_set_source_network": (i32, [vp, pi, pi, i32, pi, pi, pi, pi, pi, pd, i32, pi, pi, pi, pi, pi, pi, pd, pd, pd, pi, pi]),
+        "wai_set_source_network": (i32, [vp, pi, pi, i32, pi, pi, pi, pi, pi, pd, pd, i32, pi, pi, pi, pi, pi, pi, pd, pd, pd, pi, pi]),
+        "wai_network_evaluate": (i32, [i32, pd, pd, pd, pi, pi, i32, pi, pi, pi, pi, pi, pd, pd, i32, pi, pi, pi, pi, pi, pi, pd, pd,
+                                       pd, pi, pi, pd, pd, pd]),
         "wai_get_source_network": (i32, [vp, pd, pd]),
         "wai_separator_enthalpies": (i32, [vp, d, pd, pd]),
         "wai_set_regions": (i32, [vp, pi]),
@@ -242,3 +244,56 @@ def comm_unique_id():
     if LIB.wai_comm_unique_id(buf) != 0:
         raise WaiError("cannot create an RCCL unique id")
     return buf.raw
+
+
+def network_arrays(spec):
+    """the flat arrays of wai_set_source_network / wai_network_evaluate from a network description:
+    dict(rate_specified, enthalpy_specified per source; groups [dict(inputs=[(kind, index)], scaling 0 | 1,
+    limits=[(type, limit)], separator=[(hf, hg), ...] or None)]; reinjectors [dict(input=(kind, index),
+    outputs=[dict(flow 1 | 2, out=(kind, index), rate, proportion, enthalpy)], overflow=(kind, index))]);
+    kinds 0 none, 1 source, 2 group, 3 reinjector.  Returns (arrays kept alive, ctypes arguments)"""
+    g, r = spec["groups"], spec["reinjectors"]
+    gptr = _i32(np.concatenate([[0], np.cumsum([len(x["inputs"]) for x in g])])) if g else _i32([0])
+    gk = _i32([k for x in g for k, _ in x["inputs"]] or [0])
+    gi = _i32([i for x in g for _, i in x["inputs"]] or [0])
+    gs = _i32([x["scaling"] for x in g] or [0])
+    glt, gl = np.full(3 * max(len(g), 1), -1, dtype=np.int32), np.zeros(3 * max(len(g), 1))
+    gsep = np.zeros(8 * max(len(g), 1))
+    for q, x in enumerate(g):
+        for j, (t, v) in enumerate(x["limits"]):
+            glt[3 * q + j], gl[3 * q + j] = t, v
+        for j, (hf, hg) in enumerate(x.get("separator") or []):
+            gsep[8 * q + 2 * j], gsep[8 * q + 2 * j + 1] = hf, hg
+    rk = _i32([x["input"][0] for x in r] or [0])
+    ri = _i32([x["input"][1] for x in r] or [0])
+    rptr = _i32(np.concatenate([[0], np.cumsum([len(x["outputs"]) for x in r])])) if r else _i32([0])
+    outs = [o for x in r for o in x["outputs"]]
+    of = _i32([o["flow"] for o in outs] or [1])
+    ok = _i32([o["out"][0] for o in outs] or [0])
+    on = _i32([o["out"][1] for o in outs] or [0])
+    orate = _f64([o["rate"] for o in outs] or [0])
+    oprop = _f64([o["proportion"] for o in outs] or [0])
+    oenth = _f64([o["enthalpy"] for o in outs] or [0])
+    vk = _i32([x["overflow"][0] for x in r] or [0])
+    vi = _i32([x["overflow"][1] for x in r] or [0])
+    rs, es = _i32(spec["rate_specified"]), _i32(spec["enthalpy_specified"])
+    keep = [rs, es, gptr, gk, gi, gs, glt, gl, gsep, rk, ri, rptr, of, ok, on, orate, oprop, oenth, vk, vi]
+    P = lambda a: a.ctypes.data_as(pi if a.dtype == np.int32 else pd)   # noqa: E731
+    args = [P(rs), P(es), len(g), P(gptr), P(gk), P(gi), P(gs), P(glt), P(gl), P(gsep), len(r), P(rk), P(ri), P(rptr),
+            P(of), P(ok), P(on), P(orate), P(oprop), P(oenth), P(vk), P(vi)]
+    return keep, args
+
+
+def network_evaluate(spec, rate, enthalpy, src_sep=None):
+    """one network pass on the host (wai_network_evaluate): node states of sources (n, 6), groups (n, 6),
+    reinjectors (n, 8)"""
+    n = len(rate)
+    keep, args = network_arrays(spec)
+    q, h = _f64(rate), _f64(enthalpy)
+    sep = _f64(src_sep if src_sep is not None else np.zeros(8 * n))
+    S = np.zeros((n, 6)); G = np.zeros((max(len(spec["groups"]), 1), 6)); R = np.zeros((max(len(spec["reinjectors"]), 1), 8))
+    rc = LIB.wai_network_evaluate(n, q.ctypes.data_as(pd), h.ctypes.data_as(pd), sep.ctypes.data_as(pd), *args,
+                                  S.ctypes.data_as(pd), G.ctypes.data_as(pd), R.ctypes.data_as(pd))
+    if rc != 0:
+        raise WaiError("wai_network_evaluate failed (%d)" % rc)
+    return S, G[: len(spec["groups"])], R[: len(spec["reinjectors"])]

@@ -127,6 +127,91 @@ def zone_cells(zone, centroids):
     raise NotImplementedError("mesh zone %r" % (zone,))
 
 
+def network_spec(inp, interval, separator_enthalpies=None):
+    """"network": {"group": [...], "reinject": [...]} of an input file (setup_source_network_groups /
+    _reinjectors, src/source_setup.F90) as the description waiwera_amd.lib.network_arrays flattens for
+    wai_set_source_network.  Rates, proportions and enthalpies given as time tables are averaged over
+    `interval` (table_object_control_update, src/control.F90:263-284).  Returns (spec or None, names of
+    the groups / reinjectors in spec order, whether anything is a time table)."""
+    net = inp.get("network") or {}
+    groups, reinj = list(net.get("group") or []), list(net.get("reinject") or [])
+    names = {"group": [g.get("name", "") for g in groups], "reinject": [r.get("name", "") for r in reinj]}
+    if not groups and not reinj:
+        return None, names, False
+    sources = inp.get("source", []) or []
+    sidx = {s["name"]: i for i, s in enumerate(sources) if "name" in s}
+    gnames = [g.get("name", "") for g in groups]
+    order, done = [], set()
+    while len(order) < len(groups):      # groups in dependency order
+        progress = False
+        for gi, g in enumerate(groups):
+            if gi in done:
+                continue
+            if all(n in sidx or (n in gnames and gnames.index(n) in done) for n in g.get("in", [])):
+                order.append(gi); done.add(gi); progress = True
+        if not progress:
+            raise ValueError("network groups refer to unknown nodes or to each other in a cycle")
+    groups = [groups[gi] for gi in order]
+    gidx = {g.get("name", ""): k for k, g in enumerate(groups)}
+    ridx = {r.get("name", ""): k for k, r in enumerate(reinj)}
+    names["group"] = [g.get("name", "") for g in groups]
+    timed = [False]
+
+    def ref(name, allowed):
+        for kind, table in ((1, sidx), (2, gidx), (3, ridx)):
+            if kind in allowed and name in table:
+                return kind, table[name]
+        raise ValueError("network node %r not found" % (name,))
+
+    def value(v, o, default):
+        if v is None:
+            return default
+        if isinstance(v, dict):
+            v = v.get("time")
+        if isinstance(v, (list, tuple)):
+            timed[0] = True
+            return float(Table(v, o.get("interpolation", "linear"), o.get("averaging", "integrate")).average(interval)[0])
+        return float(v)
+
+    def separator(sp):
+        if not sp:
+            return None
+        if separator_enthalpies is None:
+            raise NotImplementedError("separator on a network group needs the thermodynamics (separator_enthalpies)")
+        ps = sp.get("pressure", 0.55e6) if isinstance(sp, dict) else 0.55e6
+        ps = list(ps) if isinstance(ps, (list, tuple)) else [ps]
+        if len(ps) > 4:
+            raise NotImplementedError("separators with more than 4 stages")
+        return [separator_enthalpies(float(q)) for q in ps]
+    FLOW = {"total": 0, "water": 1, "steam": 2}
+    spec = dict(rate_specified=[int("rate" in s or any(k in s for k in ("deliverability", "recharge", "injectivity")))
+                                for s in sources],
+                enthalpy_specified=[int("enthalpy" in s) for s in sources], groups=[], reinjectors=[])
+    for g in groups:
+        lim = g.get("limiter") or {}
+        if "type" in lim:
+            lim = {lim["type"]: lim.get("limit")}
+        limits = [(FLOW[k], value(lim[k], lim, 0.0)) for k in ("total", "water", "steam") if lim.get(k) is not None]
+        spec["groups"].append(dict(inputs=[ref(n, (1, 2)) for n in g.get("in", [])],
+                                   scaling={"uniform": 0, "progressive": 1}[g.get("scaling", "uniform")], limits=limits,
+                                   separator=separator(g.get("separator"))))
+    for r in reinj:
+        outs = []
+        for flow, key in ((1, "water"), (2, "steam")):
+            for o in r.get(key) or []:
+                has_rate = o.get("rate") is not None
+                outs.append(dict(flow=flow, out=ref(o["out"], (1, 3)) if o.get("out") else (0, -1),
+                                 rate=value(o.get("rate"), o, -1.0),
+                                 proportion=value(o.get("proportion"), o, -1.0) if not has_rate else -1.0,
+                                 enthalpy=value(o.get("enthalpy"), o, -1.0)))
+        over = r.get("overflow")
+        if isinstance(over, dict):
+            over = over.get("out")
+        spec["reinjectors"].append(dict(input=ref(r["in"], (1, 2)) if r.get("in") else (0, -1), outputs=outs,
+                                        overflow=ref(over, (1, 3)) if over else (0, -1)))
+    return spec, names, timed[0]
+
+
 class Simulation:
     """One Waiwera input file -> mesh, flow simulation object and time stepper."""
 
@@ -416,69 +501,19 @@ class Simulation:
 
         self._setup_source_controls(inp.get("source", []) or [], _get(inp, "time.start", 0.0))
         self._setup_network(inp)
-        if self._tables or self._ctl_tables or getattr(self, "_tracer_tables", None):
+        if self._tables or self._ctl_tables or getattr(self, "_tracer_tables", None) or getattr(self, "_network_timed", False):
             self.ts.controls = self._update_controls
 
     # ---- source network --------------------------------------------------------------------------
     def _setup_network(self, inp):
-        """"network": {"group": [...], "reinject": [...]} (setup_source_network_groups / reinjectors,
-        src/source_setup.F90) as the flat description of wai_set_source_network"""
-        net = inp.get("network") or {}
-        groups, reinj = list(net.get("group") or []), list(net.get("reinject") or [])
-        self.network_names = {"group": [g.get("name", "") for g in groups], "reinject": [r.get("name", "") for r in reinj]}
-        if not groups and not reinj:
-            return
-        sources = inp.get("source", []) or []
-        sidx = {s["name"]: i for i, s in enumerate(sources) if "name" in s}
-        # groups in dependency order
-        gnames = [g.get("name", "") for g in groups]
-        order, done = [], set()
-        while len(order) < len(groups):
-            progress = False
-            for gi, g in enumerate(groups):
-                if gi in done:
-                    continue
-                if all(n in sidx or (n in gnames and gnames.index(n) in done) for n in g.get("in", [])):
-                    order.append(gi); done.add(gi); progress = True
-            if not progress:
-                raise ValueError("network groups refer to unknown nodes or to each other in a cycle")
-        groups = [groups[gi] for gi in order]
-        gidx = {g.get("name", ""): k for k, g in enumerate(groups)}
-        ridx = {r.get("name", ""): k for k, r in enumerate(reinj)}
-        self.network_names["group"] = [g.get("name", "") for g in groups]
-
-        def ref(name, allowed):
-            for kind, table in ((1, sidx), (2, gidx), (3, ridx)):
-                if kind in allowed and name in table:
-                    return kind, table[name]
-            raise ValueError("network node %r not found" % (name,))
-        FLOW = {"total": 0, "water": 1, "steam": 2}
-        spec = dict(rate_specified=[int("rate" in s or any(k in s for k in ("deliverability", "recharge", "injectivity")))
-                                    for s in sources],
-                    enthalpy_specified=[int("enthalpy" in s) for s in sources], groups=[], reinjectors=[])
-        for g in groups:
-            if g.get("separator"):
-                raise NotImplementedError("separator on a network group")
-            lim = g.get("limiter") or {}
-            if "type" in lim:
-                lim = {lim["type"]: lim.get("limit")}
-            limits = [(FLOW[k], float(lim[k])) for k in ("total", "water", "steam") if lim.get(k) is not None]
-            spec["groups"].append(dict(inputs=[ref(n, (1, 2)) for n in g.get("in", [])],
-                                       scaling={"uniform": 0, "progressive": 1}[g.get("scaling", "uniform")], limits=limits))
-        for r in reinj:
-            outs = []
-            for flow, key in ((1, "water"), (2, "steam")):
-                for o in r.get(key) or []:
-                    outs.append(dict(flow=flow, out=ref(o["out"], (1, 3)) if o.get("out") else (0, -1),
-                                     rate=float(o["rate"]) if o.get("rate") is not None else -1.0,
-                                     proportion=float(o["proportion"]) if (o.get("proportion") is not None and o.get("rate") is None) else -1.0,
-                                     enthalpy=float(o["enthalpy"]) if o.get("enthalpy") is not None else -1.0))
-            over = r.get("overflow")
-            if isinstance(over, dict):
-                over = over.get("out")
-            spec["reinjectors"].append(dict(input=ref(r["in"], (1, 2)) if r.get("in") else (0, -1), outputs=outs,
-                                            overflow=ref(over, (1, 3)) if over else (0, -1)))
-        self.ode.set_source_network(spec)
+        """"network": {"group": [...], "reinject": [...]} handed to wai_set_source_network; descriptions
+        with time tables are sent again for every step interval (_update_controls)"""
+        t0 = _get(inp, "time.start", 0.0)
+        spec, names, timed = network_spec(inp, (t0, t0), self.ode.separator_enthalpies if hasattr(self.ode, "separator_enthalpies") else None)
+        self.network_names = names
+        self._network_timed = timed
+        if spec is not None:
+            self.ode.set_source_network(spec)
 
     # ---- state-dependent source controls -------------------------------------------------------
     def _setup_source_controls(self, sources, t0):
@@ -599,6 +634,9 @@ class Simulation:
             self.ode.set_source_rates(rate, enth)
         if self._ctl_tables:
             self._apply_controls(interval)
+        if getattr(self, "_network_timed", False):
+            spec, _, _ = network_spec(self.inp, interval, self.ode.separator_enthalpies)
+            self.ode.set_source_network(spec)
         if getattr(self, "_tracer_tables", None):
             for i, it, tab in self._tracer_tables:
                 self._tracer_injection[i, it] = tab.average(interval)[0]
