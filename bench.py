@@ -305,6 +305,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--spmv-reps", type=int, default=200)
     ap.add_argument("--profile", action="store_true", help="per-kernel-class HIP event timing (serialises)")
+    ap.add_argument("--micro-only", action="store_true",
+                    help="kernel A/B runs: assemble one Jacobian, set up the preconditioner, print the kernel microbench, exit")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -379,6 +381,18 @@ def main():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
+
+    if a.micro_only:   # no JSON line: not a bench result
+        drv._begin()
+        sim.jacobian(drv.t + drv.dt, drv.dt, y, drv.lhs_old)
+        sim.pc_setup()
+        names = ["spmv", "ilu_apply", "fused_pc_amul"]
+        kb = {name: sim.bench_kernel(w, a.spmv_reps if w in (0, 2) else 20) for w, name in enumerate(names)}
+        nnzb = wl.LIB.wai_jacobian_nnzb(sim.h)
+        log("micro %s [%s]: spmv %.4f ms (%.1f%% of HBM peak), pc apply %.4f ms, fused pc %.4f ms (%.1f%%)"
+            % (a.config, sim.pc_kernel_name(), kb["spmv"], 100 * spmv_bytes(nnzb, lm.n_owned, bs) / kb["spmv"] / 1e6 / HBM_PEAK_GBS,
+               kb["ilu_apply"], kb["fused_pc_amul"], 100 * pc_bytes(nnzb, lm.n_owned, bs) / kb["fused_pc_amul"] / 1e6 / HBM_PEAK_GBS))
+        return
 
     # lead-in: the first accepted time steps, outside warm-up and timing
     t_lead = time.time()
