@@ -350,11 +350,16 @@ def main():
     if a.minc:
         cfg["minc"] = True
     dims, eos, minc = tuple(cfg["dims"]), cfg["eos"], cfg["minc"]
-    # bricks: wide in x, y, thin in z (k_z = 0.1 k_x).  3 x 3 blocks run one thread per scalar row: 256
-    # block rows = 12 waves per brick, two bricks per CU (MEASURED at 172x172x170: 16x8x2 0.846 ms per
-    # fused launch, 12x12x2 -- 13.5 waves, one brick per CU -- 1.319 ms); with a MINC level the matrix
-    # cells join their fracture cell's brick, so the fracture bricks are half as large
-    brick = tuple(a.brick) if a.brick else ((16, 8, 1) if minc else ((16, 8, 2) if eos == "wce" else (16, 16, 2)))
+    # bricks: wide in x, y, thin in z (k_z = 0.1 k_x).  3 x 3 blocks run one thread per scalar row; a brick
+    # of 160 block rows is 480 threads = 8 waves, three bricks per CU.  MEASURED (tools/brick_scan.sh,
+    # 172x172x170 eos_wce, same box; Newton steps/s, Krylov iterations per Newton step, fused launch):
+    #   16x8x2 2.45 / 194 / 44.9 %   10x8x2 2.71 / 186 / 49.0 %   12x7x2 2.76 / 183 / 49.4 %
+    #   8x10x2 2.77 / 182 / 49.7 %   12x10x2 2.61 / 172 / 42.6 %  13x13x1 2.46 / 190 / 44.6 %
+    # with a MINC level the matrix cells join their fracture cell's brick (80 + 80 block rows):
+    #   16x8x1 10.8 / 93 / 29.8 %    8x10x1 11.5 / 104 / 37.4 %   10x8x1 11.1 / 110 / 37.9 %
+    # 2 x 2 blocks (k_pc_park, one thread per block row, 512 rows): 16x16x2 3.21 / 171; every other
+    # shape of 256-512 cells tried at 216^3 needs 190-1360 iterations (18x12x2 195, 16x8x2 304, 8x8x8 1363)
+    brick = tuple(a.brick) if a.brick else ((8, 10, 1) if minc else ((8, 10, 2) if eos == "wce" else (16, 16, 2)))
     grid, lm, prim, region = make_case(dims=dims, brick=brick, eos=eos, lens=not a.no_lens, minc=minc,
                                        part=M.partition_shape(world), rank=rank)
     opts = wl.default_opts(ksp_type=a.ksp, pc_type=a.pc)

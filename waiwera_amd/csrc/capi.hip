@@ -230,11 +230,6 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
     const char* e = getenv("WAI_PC_ROWS");
     const bool can = s.diag_only && s.scaled && !s.big && s.max_nlu <= 4 && s.max_rows * np <= 1024 && W <= 8;
     s.rows_kernel = can && (e ? e[0] == '1' : np >= 3);
-    // the persistent pipelined form of it: compact rows (fast3), bricks of at most 1024 (bs 2) / 768
-    // (bs 3) scalar rows.  WAI_PC_PIPE=0 / 1 forces it off / on.
-    const char* ep = getenv("WAI_PC_PIPE");
-    const bool canp = can && s.fast3 && s.max_nlu <= 3 && (np == 2 || np == 3) && s.max_rows * np <= (np == 3 ? 768 : 1024);
-    s.pipe = canp && (ep ? ep[0] == '1' : false);
   }
   s.built = true;
   s.factored = false;
@@ -2535,7 +2530,6 @@ const char* wai_pc_kernel_name(wai_ctx* c) {
   if (c->opts.pc_type == WAI_PC_LU) return "k_spmv + k_lu_apply (dense block inverses)";
   if (c->opts.pc_type == WAI_PC_ASM) return c->as.sched.big ? "k_spmv + k_lvl_solve per level (ASM, extended system)" : "k_spmv + k_pc on the extended ASM system";
   if (s.big) return "k_spmv + k_lvl_solve per level";
-  if (s.pipe && (c->J.bs == 2 || c->J.bs == 3)) { static thread_local char b3[64]; snprintf(b3, sizeof(b3), "k_pc_pipe<%d,spmv>", c->J.bs); return b3; }
   if (s.rows_kernel) { static thread_local char b2[64]; snprintf(b2, sizeof(b2), "k_pc_rows<%d,spmv,%d+%d>", c->J.bs, s.max_nlu <= 3 ? 3 : 4, s.max_nlu <= 3 ? 3 : 4); return b2; }
   if (c->J.bs == 2 && s.park && s.diag_only && s.scaled && s.fast3 && s.max_rows <= 512) return "k_pc_park<spmv>";
   static thread_local char buf[96];

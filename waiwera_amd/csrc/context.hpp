@@ -116,7 +116,6 @@ struct IluSchedule {
   bool fast3 = false;         // <= 3 lower and <= 3 upper in-subdomain couplings per row, offsets < 4
   int max_nlu = 0;            // most lower or upper in-subdomain couplings of any row
   bool rows_kernel = false;   // k_pc_rows (one thread per scalar row) applies and is selected
-  bool pipe = false;          // k_pc_pipe (persistent, loads of the next brick in flight during the sweeps) is selected
   bool level_sorted = false;  // every subdomain's rows are stored in dependency-level order
   bool factored = false;
   // subdomains of more than 1024 rows ("one block per rank", sub_ptr = NULL, is the reference's

@@ -912,9 +912,7 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
 // registers: 58 (bs 2), 69 (bs 3), 90 (bs 4) without spills -> 8 / 7 / 5 waves per SIMD; asking for 8
 // everywhere spills 150-600 registers at bs = 3, 4.  Four couplings per sweep (NL = 4: MINC inside 3-D
 // bricks) cost 12 more: 5 and 4 waves (at 7 and 5 they spilled 200 bytes per lane)
-// WT: slots handled (7 or 8); FIXW: every row has exactly WT slots (no rowptr, W == WT), so that the
-// load phase is straight-line code and the loads of all slots are in flight together
-template <int BS, bool SPMV, int NL, int NU, int WT, bool FIXW>
+template <int BS, bool SPMV, int NL, int NU>
 __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) : (NL <= 3 ? 5 : 4)))) void k_pc_rows(
     int n, int W, int nsub, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev,
     const int* __restrict__ row_info, const int* __restrict__ col, const double* __restrict__ sval,
@@ -950,20 +948,12 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
   if (active) {
     int lfirst, dslot, ulast;
     unpack_info(row_info[i], lfirst, dslot, ulast, lf, lb);
-    // padding slots of short rows are not read
-    const int cnt = FIXW ? WT : (rowptr ? rowptr[i + 1] - rowptr[i] : W);
-    // the column indices of all slots first: one round trip instead of one per slot
-    int cgs[WT];
-#pragma unroll
-    for (int q = 0; q < WT; q++) {
-      cgs[q] = i;
-      if (q < cnt) cgs[q] = load_col(col, (size_t)q * n + i);
-    }
+    const int cnt = rowptr ? rowptr[i + 1] - rowptr[i] : W;   // padding slots of short rows are not read
     double acc = 0.0;
 #pragma unroll
-    for (int q = 0; q < WT; q++) {
+    for (int q = 0; q < WMAX; q++) {
       if (q < cnt) {
-        const int cg = cgs[q];
+        const int cg = load_col(col, (size_t)q * n + i);
         double blk[BS];
         const double* src = sval + ((size_t)(q * BS + r) * n + i) * BS;
 #pragma unroll
@@ -1049,234 +1039,6 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
     if (dot == 4) wg_reduce_store<5>(v, red, partials, nb_max, slots, s);
     else if (dot == 2) { double v2[2] = {v[0], v[1]}; wg_reduce_store<2>(v2, red, partials, nb_max, slots, s); }
     else { double v1[1] = {v[0]}; wg_reduce_store<1>(v1, red, partials, nb_max, slots, s); }
-  }
-}
-
-// ---- K6+K8 fused, persistent and software-pipelined over bricks --------------------------------
-// k_pc_rows spends a brick's life in two phases that do not overlap inside a workgroup: the loads
-// (HBM bound) and the two substitution sweeps (latency bound: one barrier, one LDS round trip and a
-// chain of BS*3 dependent FMAs per dependency level, no memory traffic).  Co-resident workgroups only
-// hide one behind the other by accident.  Here ONE workgroup per CU walks through its bricks and, before
-// it enters the sweeps of brick k, issues the loads of brick k+1 (matrix rows, gathered vector
-// entries, dot-product partners) and the column indices of brick k+2; they land during the sweeps.
-// A wave then holds ~150 registers, which a CU can afford for its 12-16 waves (3-4 per SIMD), and
-// 150 KB of loads are in flight per CU (Little: 31 GB/s per CU x ~2 us = 62 KB are needed).
-// Same thread layout, level schedule, arithmetic and summation order inside a brick as k_pc_rows; the
-// dot-product partials are accumulated per workgroup over its bricks (one partial per workgroup).
-// Needs the compact row form (fast3: at most 3 + 3 in-brick couplings, diagonal within the first four
-// slots), so that the in-brick lower / upper blocks are picked out of the row with 4-way selects.
-template <int BS, int WT>
-__device__ __forceinline__ void pick_row(const double (&b)[WT][BS], int base, int p, double* out) {
-  // out = b[base + p], base in 0..3 (indices past the row are clamped: such a coupling is switched off
-  // by its LDS offset, which then points at the zero entries)
-  constexpr int L = WT - 1;
-  const int i0 = p < L ? p : L, i1 = p + 1 < L ? p + 1 : L, i2 = p + 2 < L ? p + 2 : L, i3 = p + 3 < L ? p + 3 : L;
-#pragma unroll
-  for (int k = 0; k < BS; k++) {
-    const double a0 = b[i0][k], a1 = b[i1][k], a2 = b[i2][k], a3 = b[i3][k];   // values, not a select of addresses
-    out[k] = base == 0 ? a0 : (base == 1 ? a1 : (base == 2 ? a2 : a3));
-  }
-}
-template <int WT>
-__device__ __forceinline__ int pick_col(const int (&c)[WT], int base, int p) {
-  constexpr int L = WT - 1;
-  const int i0 = p < L ? p : L, i1 = p + 1 < L ? p + 1 : L, i2 = p + 2 < L ? p + 2 : L, i3 = p + 3 < L ? p + 3 : L;
-  const int a0 = c[i0], a1 = c[i1], a2 = c[i2], a3 = c[i3];
-  return base == 0 ? a0 : (base == 1 ? a1 : (base == 2 ? a2 : a3));
-}
-
-template <int BS, bool SPMV, int WT, bool FIXW>
-__global__ __launch_bounds__(BS >= 3 ? 768 : 1024) void k_pc_pipe(
-    int n, int W, int nrun, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev,
-    const int* __restrict__ row_info, const int* __restrict__ col, const double* __restrict__ sval,
-    const double* __restrict__ dinv, const double* __restrict__ in, double* __restrict__ z,
-    const double* __restrict__ aux, double* partials, int nb_max, int dot, const int* __restrict__ sub_list,
-    const int* __restrict__ rowptr, int zoff, int pbase) {
-  constexpr int NLU = 3;
-  extern __shared__ double lds[];  // [zoff] solution in block order, [BS] zeros, then reduction scratch
-  double* ys = lds;
-  const int tid = threadIdx.x, G = gridDim.x;
-  const int vend = ((nrun + 7) >> 3) << 3;
-  if (tid < BS) ys[zoff + tid] = 0.0;
-  const bool want_in = (dot == 2 || dot == 4), want_aux = (dot == 1 || dot == 4);
-
-  // brick identity of a virtual block id (uniform): rows lo .. lo + R, packed level counts
-  auto ident = [&](int v, int& lo, int& R, int& nl) {
-    lo = 0; R = 0; nl = 0;
-    if (v < vend) {
-      int s = xcd_remap(v, nrun);
-      if (s < nrun) {
-        if (sub_list) s = sub_list[s];
-        lo = sub_ptr[s]; R = sub_ptr[s + 1] - lo; nl = sub_nlev[s];
-      }
-    }
-  };
-  // ---- stage 2 (two bricks ahead): column indices, row descriptor, row length
-  int lo2, R2, nl2, i2 = 0, r2 = 0, info2 = 0, cnt2 = 0, cg2[WT];
-  bool act2 = false;
-  auto issue2 = [&](int v) {
-    ident(v, lo2, R2, nl2);
-    act2 = tid < R2 * BS;
-#pragma unroll
-    for (int q = 0; q < WT; q++) cg2[q] = 0;
-    info2 = 0; cnt2 = 0; r2 = 0; i2 = 0;
-    if (act2) {
-      r2 = tid / R2;
-      i2 = lo2 + (tid - r2 * R2);
-      info2 = row_info[i2];
-      cnt2 = FIXW ? WT : (rowptr ? rowptr[i2 + 1] - rowptr[i2] : W);
-#pragma unroll
-      for (int q = 0; q < WT; q++)
-        if (FIXW || q < W) cg2[q] = load_col(col, (size_t)q * n + i2);
-    }
-  };
-  // ---- stage 1 (next brick): matrix rows, gathered vector entries, dot-product partners
-  int lo1 = 0, R1 = 0, nl1 = 0, i1 = 0, r1 = 0, info1 = 0, cnt1 = 0, cg1[WT];
-  bool act1 = false;
-  double blk1[WT][BS], xv1[2][BS], xin1 = 0.0, av1 = 0.0;   // plain application: xv1 = pivot row, vector entry
-  auto issue1 = [&]() {
-#pragma unroll
-    for (int q = 0; q < WT; q++)
-#pragma unroll
-      for (int k = 0; k < BS; k++) { blk1[q][k] = 0.0; xv1[q & 1][k] = 0.0; }
-    xin1 = 0.0; av1 = 0.0;
-    if (act1) {
-#pragma unroll
-      for (int q = 0; q < WT; q++) {
-        if (FIXW || q < cnt1) {
-          const double* src = sval + ((size_t)(q * BS + r1) * n + i1) * BS;
-#pragma unroll
-          for (int k = 0; k < BS; k++) blk1[q][k] = __builtin_nontemporal_load(src + k);
-        }
-      }
-      if constexpr (!SPMV) {  // plain application: the vector entry scaled by the inverted pivot
-        const double* dv = dinv + ((size_t)r1 * n + i1) * BS;
-#pragma unroll
-        for (int k = 0; k < BS; k++) { xv1[0][k] = dv[k]; xv1[1][k] = in[(size_t)i1 * BS + k]; }
-      }
-      const size_t g1 = (size_t)lo1 * BS + tid;
-      if (want_in) xin1 = in[g1];
-      if (want_aux) av1 = __builtin_nontemporal_load(aux + g1);
-    }
-  };
-  auto rotate = [&]() {  // stage 2 -> stage 1
-    lo1 = lo2; R1 = R2; nl1 = nl2; i1 = i2; r1 = r2; info1 = info2; cnt1 = cnt2; act1 = act2;
-#pragma unroll
-    for (int q = 0; q < WT; q++) cg1[q] = cg2[q];
-  };
-
-  int v = blockIdx.x;
-  issue2(v);
-  rotate();
-  issue1();
-  v += G;
-  issue2(v);
-
-  double dv5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  while (R1 > 0) {
-    // ---- A: brick k = stage 1 has landed: row product, in-brick couplings, right-hand side into LDS
-    const int lo = lo1, R = R1, nlf = nl1 & 0xffff, nlb = nl1 >> 16;
-    const bool active = act1;
-    const double xin = xin1, av = av1;
-    double Lf[NLU][BS], Uf[NLU][BS];
-    int Lc[NLU], Uc[NLU], lf = -1, lb = -1;
-    const int me = (i1 - lo) * BS + r1;   // this thread's row in the block-ordered LDS vector
-    {
-      int lfirst, dslot, ulast;
-      unpack_info(info1, lfirst, dslot, ulast, lf, lb);
-      if (!active) { lf = -1; lb = -1; }
-      double acc = 0.0;
-      if constexpr (SPMV) {
-        // the vector entries are gathered now (they hit L2: neighbouring bricks ran on this XCD a moment
-        // ago); holding them in flight through the sweeps as well would cost the sweeps their registers
-        double xg[WT][BS];
-#pragma unroll
-        for (int q = 0; q < WT; q++) {
-#pragma unroll
-          for (int k = 0; k < BS; k++) xg[q][k] = 0.0;
-          if (active && (FIXW || q < cnt1)) load_x<BS>(in, cg1[q], xg[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < WT; q++)
-#pragma unroll
-          for (int k = 0; k < BS; k++) acc += blk1[q][k] * xg[q][k];   // slots past the row hold zeros
-      } else {
-#pragma unroll
-        for (int k = 0; k < BS; k++) acc += xv1[0][k] * xv1[1][k];
-      }
-#pragma unroll
-      for (int p = 0; p < NLU; p++) {
-        pick_row<BS, WT>(blk1, lfirst, p, Lf[p]);
-        pick_row<BS, WT>(blk1, dslot, p + 1, Uf[p]);
-        const bool vl = active && (lfirst + p < dslot), vu = active && (dslot + 1 + p < ulast);
-        Lc[p] = vl ? (pick_col<WT>(cg1, lfirst, p) - lo) * BS : zoff;
-        Uc[p] = vu ? (pick_col<WT>(cg1, dslot, p + 1) - lo) * BS : zoff;
-      }
-      if (active) ys[me] = acc;
-    }
-    // ---- B: loads of brick k+1, column indices of brick k+2
-    rotate();
-    issue1();
-    v += G;
-    issue2(v);
-    // ---- C: the sweeps of brick k.  One LDS round trip per level: all neighbour entries are read
-    // before the first product, and the three couplings are summed independently
-    __syncthreads();
-    for (int lev = 1; lev < nlf; lev++) {  // forward: y_i = t_i - sum A'_ik y_k
-      if (lf == lev) {
-        const double a = ys[me];
-        double yk[NLU][BS], part[NLU];
-#pragma unroll
-        for (int p = 0; p < NLU; p++)
-#pragma unroll
-          for (int k = 0; k < BS; k++) yk[p][k] = ys[Lc[p] + k];
-#pragma unroll
-        for (int p = 0; p < NLU; p++) {
-          part[p] = Lf[p][0] * yk[p][0];
-#pragma unroll
-          for (int k = 1; k < BS; k++) part[p] += Lf[p][k] * yk[p][k];
-        }
-        ys[me] = a - ((part[0] + part[1]) + part[2]);
-      }
-      __syncthreads();
-    }
-    for (int lev = 0; lev < nlb; lev++) {  // backward: x_i = y_i - sum A'_ij x_j
-      if (lb == lev) {
-        const double a = ys[me];
-        double yk[NLU][BS], part[NLU];
-#pragma unroll
-        for (int p = 0; p < NLU; p++)
-#pragma unroll
-          for (int k = 0; k < BS; k++) yk[p][k] = ys[Uc[p] + k];
-#pragma unroll
-        for (int p = 0; p < NLU; p++) {
-          part[p] = Uf[p][0] * yk[p][0];
-#pragma unroll
-          for (int k = 1; k < BS; k++) part[p] += Uf[p][k] * yk[p][k];
-        }
-        ys[me] = a - ((part[0] + part[1]) + part[2]);
-      }
-      __syncthreads();
-    }
-    // block-order, tid-linear epilogue: store the result, accumulate the dot products
-    if (active) {
-      const double out = ys[tid];
-      __builtin_nontemporal_store(out, z + (size_t)lo * BS + tid);
-      if (dot == 1) dv5[0] += out * av;
-      else if (dot == 2) { dv5[0] += xin * out; dv5[1] += out * out; }
-      else if (dot == 4) { dv5[0] += xin * out; dv5[1] += out * out; dv5[2] += xin * xin; dv5[3] += xin * av; dv5[4] += out * av; }
-      else if (dot != 0) dv5[0] += out * out;
-    }
-    __syncthreads();   // the next brick's right-hand side goes into the same LDS
-  }
-  if (dot != 0) {
-    double* red = lds + (size_t)zoff + BS;
-    int slots[5] = {S_D1, S_D2, S_DP2, S_RHONEW, S_W2};
-    if (dot != 1 && dot != 2 && dot != 4) slots[0] = S_DP2;
-    const int pb = pbase + blockIdx.x;
-    if (dot == 4) wg_reduce_store<5>(dv5, red, partials, nb_max, slots, pb);
-    else if (dot == 2) { double v2[2] = {dv5[0], dv5[1]}; wg_reduce_store<2>(v2, red, partials, nb_max, slots, pb); }
-    else { double v1[1] = {dv5[0]}; wg_reduce_store<1>(v1, red, partials, nb_max, slots, pb); }
   }
 }
 
@@ -1776,21 +1538,6 @@ int launch_big_solve(wai_ctx* c, const Bcsr& J, const IluSchedule& s, double* z)
   return 0;
 }
 
-// workgroups of the persistent kernel: one per CU (a multiple of 8: a workgroup stays on its XCD)
-static int pipe_grid(wai_ctx* c, int nrun) {
-  static int ncu = 0, per_cu = 0;
-  if (!ncu) {
-    hipDeviceProp_t pr;
-    int dev = 0;
-    hipGetDevice(&dev);
-    ncu = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
-    const char* e = getenv("WAI_PIPE_WGS");
-    per_cu = e ? std::max(1, atoi(e)) : 1;
-  }
-  const int want = ((ncu * per_cu + 7) / 8) * 8, have = ((nrun + 7) / 8) * 8;
-  return std::min(want, have);
-}
-
 template <int BS>
 static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool spmv, const double* in, double* z,
                          int dot_mode, const double* aux, const int* list, int nrun) {
@@ -1808,38 +1555,17 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
                          nrun, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.fval,          \
                          s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, c->dbg, list); \
   } while (0)
-  // persistent, software-pipelined over bricks: one workgroup per CU
-  if (s.pipe && !c->dbg) {
-    if constexpr (BS == 2 || BS == 3) {
-      const int zoff = s.max_rows * BS;
-      const int TR = ((zoff + 63) / 64) * 64;
-      const size_t lds_p = ((size_t)zoff + BS + 5 * 16 + 8) * sizeof(double);
-      const int* rp = (size_t)J.nnzb * 10 < (size_t)J.n * J.W * 9 ? J.rowptr : nullptr;   // > 10 % padding
-      const int gp = pipe_grid(c, nrun);
-      // the two launches of the overlapped halo exchange write their partials side by side
-      const int pbase = (list && list == s.sub_bnd) ? pipe_grid(c, s.n_int) : 0;
-#define PCP(SP, WT, FX)                                                                            \
-      hipLaunchKernelGGL((k_pc_pipe<BS, SP, WT, FX>), gp, TR, lds_p, c->stream, J.n, J.W, nrun, s.sub_ptr,  \
-                         s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, \
-                         dot_mode, list, rp, zoff, pbase)
-      if (J.W == 7 && !rp) { if (spmv) PCP(true, 7, true); else PCP(false, 7, true); }
-      else { if (spmv) PCP(true, WMAX, false); else PCP(false, WMAX, false); }
-#undef PCP
-      return;
-    }
-  }
   // one thread per scalar row: block sizes 3 and 4 (and 2 when asked for: WAI_PC_ROWS=1)
   if (s.rows_kernel && !c->dbg) {
     const int TR = ((s.max_rows * BS + 63) / 64) * 64;
     const size_t lds_r = ((size_t)s.max_rows * BS + BS + 5 * 16 + 8) * sizeof(double);
     const int* rp = (size_t)J.nnzb * 10 < (size_t)J.n * J.W * 9 ? J.rowptr : nullptr;   // > 10 % padding
-#define PCR(SP, NLU, WT, FX)                                                                       \
-    hipLaunchKernelGGL((k_pc_rows<BS, SP, NLU, NLU, WT, FX>), grid, TR, lds_r, c->stream, J.n, J.W, nrun, s.sub_ptr, \
+#define PCR(SP, NLU)                                                                               \
+    hipLaunchKernelGGL((k_pc_rows<BS, SP, NLU, NLU>), grid, TR, lds_r, c->stream, J.n, J.W, nrun, s.sub_ptr,  \
                        s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, \
                        dot_mode, list, rp)
-    if (s.max_nlu <= 3 && J.W == 7 && !rp) { if (spmv) PCR(true, 3, 7, true); else PCR(false, 3, 7, true); }
-    else if (s.max_nlu <= 3) { if (spmv) PCR(true, 3, WMAX, false); else PCR(false, 3, WMAX, false); }
-    else { if (spmv) PCR(true, 4, WMAX, false); else PCR(false, 4, WMAX, false); }
+    if (s.max_nlu <= 3) { if (spmv) PCR(true, 3); else PCR(false, 3); }
+    else { if (spmv) PCR(true, 4); else PCR(false, 4); }
 #undef PCR
     return;
   }
@@ -1880,8 +1606,6 @@ int launch_pc_on(wai_ctx* c, const Bcsr& M, const IluSchedule& s, bool spmv, con
     default: return -1;
   }
   c->ks.nb_pc = s.nsub;
-  if (s.pipe && !c->dbg && (M.bs == 2 || M.bs == 3))   // one partial per workgroup (both launches of a split pass)
-    c->ks.nb_pc = list ? pipe_grid(c, s.n_int) + pipe_grid(c, s.n_bnd) : pipe_grid(c, s.nsub);
   return 0;
 }
 int launch_pc(wai_ctx* c, bool spmv, const double* in, double* z, int dot_mode, const double* aux,
