@@ -350,16 +350,17 @@ def main():
     if a.minc:
         cfg["minc"] = True
     dims, eos, minc = tuple(cfg["dims"]), cfg["eos"], cfg["minc"]
-    # bricks: wide in x, y, thin in z (k_z = 0.1 k_x).  3 x 3 blocks run one thread per scalar row; a brick
-    # of 160 block rows is 480 threads = 8 waves, three bricks per CU.  MEASURED (tools/brick_scan.sh,
-    # 172x172x170 eos_wce, same box; Newton steps/s, Krylov iterations per Newton step, fused launch):
-    #   16x8x2 2.45 / 194 / 44.9 %   10x8x2 2.71 / 186 / 49.0 %   12x7x2 2.76 / 183 / 49.4 %
-    #   8x10x2 2.77 / 182 / 49.7 %   12x10x2 2.61 / 172 / 42.6 %  13x13x1 2.46 / 190 / 44.6 %
-    # with a MINC level the matrix cells join their fracture cell's brick (80 + 80 block rows):
-    #   16x8x1 10.8 / 93 / 29.8 %    8x10x1 11.5 / 104 / 37.4 %   10x8x1 11.1 / 110 / 37.9 %
+    # bricks: wide in x, y, thin in z (k_z = 0.1 k_x).  3 x 3 blocks run one thread per scalar row and the
+    # substitution sweeps of a brick are hidden by the loads of the OTHER bricks on its CU: 80 block rows =
+    # 240 threads = 4 waves, seven bricks per CU.  MEASURED (tools/brick_scan.sh, 172x172x170 eos_wce;
+    # Newton steps/s, Krylov iterations per Newton step, fused launch as a fraction of 8 TB/s):
+    #   16x8x2 2.45 / 194 / 44.9 %   8x10x2 2.79 / 182 / 50.0 %   8x5x2 3.04 / 176 / 54.8 %
+    #   4x10x2 2.75 / 199 / 55.9 %   4x5x4 2.76 / 203 / 57.5 %    16x5x1 2.55 / 201 / 51.2 %
+    # with a MINC level the matrix cells join their fracture cell's brick (40 + 40 block rows):
+    #   16x8x1 10.8 / 93 / 29.8 %    8x10x1 11.5 / 104 / 37.5 %   8x5x1 11.8 / 110 / 42.6 %   5x8x1 12.1 / 107 / 42.5 %
     # 2 x 2 blocks (k_pc_park, one thread per block row, 512 rows): 16x16x2 3.21 / 171; every other
     # shape of 256-512 cells tried at 216^3 needs 190-1360 iterations (18x12x2 195, 16x8x2 304, 8x8x8 1363)
-    brick = tuple(a.brick) if a.brick else ((8, 10, 1) if minc else ((8, 10, 2) if eos == "wce" else (16, 16, 2)))
+    brick = tuple(a.brick) if a.brick else ((5, 8, 1) if minc else ((8, 5, 2) if eos == "wce" else (16, 16, 2)))
     grid, lm, prim, region = make_case(dims=dims, brick=brick, eos=eos, lens=not a.no_lens, minc=minc,
                                        part=M.partition_shape(world), rank=rank)
     opts = wl.default_opts(ksp_type=a.ksp, pc_type=a.pc)

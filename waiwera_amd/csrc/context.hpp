@@ -9,6 +9,15 @@
 
 namespace wai {
 
+// Element (s, r, k) of block row i in a block-ELL value array of n block rows (layout rationale:
+// kernels_linalg.hip, "Matrix entry addressing").  WAI_ELL_ROWS builds the block-row layout for every bs.
+__host__ __device__ __forceinline__ size_t ell_ix(int bs, size_t n, int s, int r, int k, size_t i) {
+#ifndef WAI_ELL_ROWS
+  if (bs >= 3) return ((size_t)((s * bs + r) * bs + k)) * n + i;
+#endif
+  return ((size_t)(s * bs + r) * n + i) * bs + k;
+}
+
 enum KClass { KC_EOS = 0, KC_RESIDUAL = 1, KC_JACOBIAN = 2, KC_SPMV = 3, KC_PC_APPLY = 4,
               KC_PC_SETUP = 5, KC_VECTOR = 6, KC_TRANSITIONS = 7, KC_COUNT = 8 };
 

@@ -258,10 +258,10 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
   }
 
   // diagonal block: own state perturbed in component k
-  // block-ELL planes: row r of the block in slot q of block-row c is the np-vector at
-  // val[((q*np + r)*n_owned + c)*np + k]  (kernels_linalg.hip, vix)
+  // block-ELL planes: element (r, k) of the block in slot q of block-row c is val[ell_ix(np, n_owned, q, r, k, c)]
+  // (context.hpp; kernels_linalg.hip, "Matrix entry addressing")
   const size_t nrow = m.n_owned;
-  double* dblk = val + ((size_t)m.diag_blk[c] * np * nrow + c) * np;
+  const int dq = m.diag_blk[c];
 #pragma unroll
   for (int k = 0; k < np; k++) {
     CellState<KIND> ownk;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
 #pragma unroll
     for (int r = 0; r < np; r++) {
       const double f1 = res_form(rf, Lk[r], R[r], lold[r], lold2[r]);
-      dblk[(size_t)r * nrow * np + k] = (f1 - f0[r]) / h;
+      val[ell_ix(np, nrow, dq, r, k, (size_t)c)] = (f1 - f0[r]) / h;
     }
   }
 
@@ -307,7 +307,6 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
     load_face(m, fs >> 1, g);
     RockState roth;
     load_rock(m.rock, m.n_local, o, roth);
-    double* oblk = val + ((size_t)blk * np * nrow + c) * np;
 #pragma unroll
     for (int k = 0; k < np; k++) {
       CellState<KIND> othk;
@@ -327,7 +326,7 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
 #pragma unroll
       for (int r = 0; r < np; r++) {
         const double f1 = res_form(rf, L0[r], R[r] + src0[r], lold[r], lold2[r]);
-        oblk[(size_t)r * nrow * np + k] += (f1 - f0[r]) / h;
+        val[ell_ix(np, nrow, blk, r, k, (size_t)c)] += (f1 - f0[r]) / h;
       }
     }
   }

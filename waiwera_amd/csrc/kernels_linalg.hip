@@ -38,12 +38,16 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
   return (b & 7) * per + (b >> 3);
 }
 
-// Matrix entry addressing.  Planes are indexed by (slot, row-in-block); element i of a plane is
-// the BS-vector holding that block row of block-row i:  val[((s*BS + r)*n + i)*BS + k].  For
-// BS = 2 a lane's access is one 16-byte double2 and a wave instruction moves 1 KiB.
+// Matrix entry addressing (ell_ix, context.hpp).  Block sizes 1 and 2: planes are indexed by (slot,
+// row-in-block) and element i of a plane is the BS-vector holding that block row of block-row i,
+// val[((s*BS + r)*n + i)*BS + k] -- for BS = 2 a lane's access is one 16-byte double2 and a wave
+// instruction moves 1 KiB.  Block sizes >= 3: one plane per block ELEMENT, val[((s*BS + r)*BS + k)*n + i]:
+// a 24-byte block row per lane costs a dwordx4 and a dwordx2 that each touch every 128-byte line, MEASURED
+// 5.5 TB/s streaming against 6.2-6.4 TB/s for element planes (tools/micro/layout_bs3.hip), where every
+// wave instruction reads 512 contiguous bytes.
 template <int BS>
 __device__ __forceinline__ size_t vix(int n, int s, int e, int i) {
-  return ((size_t)(s * BS + e / BS) * n + i) * BS + (e % BS);
+  return ell_ix(BS, (size_t)n, s, e / BS, e % BS, (size_t)i);
 }
 // load the BS x BS block (slot s, block row i) into b[].  The matrix (values, column indices) is
 // read once per launch and the result vector written once: these streams carry the non-temporal
@@ -955,9 +959,8 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
       if (q < cnt) {
         const int cg = load_col(col, (size_t)q * n + i);
         double blk[BS];
-        const double* src = sval + ((size_t)(q * BS + r) * n + i) * BS;
 #pragma unroll
-        for (int k = 0; k < BS; k++) blk[k] = __builtin_nontemporal_load(src + k);
+        for (int k = 0; k < BS; k++) blk[k] = __builtin_nontemporal_load(sval + ell_ix(BS, (size_t)n, q, r, k, (size_t)i));
         if constexpr (SPMV) {
           double xv[BS];
           load_x<BS>(in, cg, xv);
@@ -982,9 +985,8 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
       }
     }
     if constexpr (!SPMV) {  // plain application to an unscaled vector: scale it by the inverted pivot
-      const double* dv = dinv + ((size_t)r * n + i) * BS;
 #pragma unroll
-      for (int k = 0; k < BS; k++) acc += dv[k] * in[(size_t)i * BS + k];
+      for (int k = 0; k < BS; k++) acc += dinv[ell_ix(BS, (size_t)n, 0, r, k, (size_t)i)] * in[(size_t)i * BS + k];
     }
     ys[il * BS + r] = acc;
   }
@@ -1050,7 +1052,7 @@ __global__ __launch_bounds__(TPB) void k_ell_to_bcsr(int n, int W, int bs, const
   const int s = (int)(t / n), i = (int)(t - (size_t)s * n);
   const int a = rowptr[i], cnt = rowptr[i + 1] - a, bb = bs * bs;
   if (s >= cnt) return;
-  for (int e = 0; e < bb; e++) bcsr[(size_t)(a + s) * bb + e] = ell[((size_t)(s * bs + e / bs) * n + i) * bs + (e % bs)];
+  for (int e = 0; e < bb; e++) bcsr[(size_t)(a + s) * bb + e] = ell[ell_ix(bs, (size_t)n, s, e / bs, e % bs, (size_t)i)];
 }
 __global__ __launch_bounds__(TPB) void k_bcsr_to_ell(int n, int W, int bs, const int* __restrict__ rowptr,
                                                      const double* __restrict__ bcsr, double* __restrict__ ell) {
@@ -1059,7 +1061,7 @@ __global__ __launch_bounds__(TPB) void k_bcsr_to_ell(int n, int W, int bs, const
   const int s = (int)(t / n), i = (int)(t - (size_t)s * n);
   const int a = rowptr[i], cnt = rowptr[i + 1] - a, bb = bs * bs;
   for (int e = 0; e < bb; e++)
-    ell[((size_t)(s * bs + e / bs) * n + i) * bs + (e % bs)] = (s < cnt) ? bcsr[(size_t)(a + s) * bb + e] : 0.0;
+    ell[ell_ix(bs, (size_t)n, s, e / bs, e % bs, (size_t)i)] = (s < cnt) ? bcsr[(size_t)(a + s) * bb + e] : 0.0;
 }
 
 // ---- K9: fused vector kernels -----------------------------------------------------------------
@@ -1409,7 +1411,7 @@ __global__ __launch_bounds__(TPB) void k_asm_gather_matrix(int n, int n_ext, int
   const int ss = g < 0 ? 0 : g / n, i = g < 0 ? 0 : g - ss * n;
   for (int r = 0; r < bs; r++)
     for (int k = 0; k < bs; k++)
-      eval[((size_t)(s * bs + r) * n_ext + q) * bs + k] = g < 0 ? 0.0 : jval[((size_t)(ss * bs + r) * n + i) * bs + k];
+      eval[ell_ix(bs, (size_t)n_ext, s, r, k, (size_t)q)] = g < 0 ? 0.0 : jval[ell_ix(bs, (size_t)n, ss, r, k, (size_t)i)];
 }
 __global__ __launch_bounds__(TPB) void k_asm_gather(int n_ext, int bs, const int* __restrict__ ext_row,
                                                     const double* __restrict__ r, double* __restrict__ r_ext) {
