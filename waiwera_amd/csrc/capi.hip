@@ -231,13 +231,30 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
     const bool can = s.diag_only && s.scaled && !s.big && s.max_nlu <= 4 && s.max_rows * np <= 1024 && W <= 8;
     s.rows_kernel = can && (e ? e[0] == '1' : np >= 3);
   }
+  if (s.rows_kernel) {
+    // bricks whose long rows come first (MINC: fracture cells, then their matrix cells with 2 of 8
+    // slots): k_pc_rows maps the long rows of all components to the first waves, so that a wave is
+    // all-long or all-short and the short ones skip the slot loop instead of idling in it
+    std::vector<int> split(s.nsub);
+    bool any = false;
+    for (int sd = 0; sd < s.nsub; sd++) {
+      const int lo = sub[sd], hi = sub[sd + 1];
+      int r1 = lo;
+      while (r1 < hi && (rowptr[r1 + 1] - rowptr[r1]) * 2 > W) r1++;
+      bool sorted = true;
+      for (int i = r1; i < hi && sorted; i++) sorted = (rowptr[i + 1] - rowptr[i]) * 2 <= W;
+      split[sd] = (sorted && r1 > lo) ? r1 - lo : hi - lo;
+      any = any || split[sd] != hi - lo;
+    }
+    if (any && !getenv("WAI_PC_NOSPLIT") && dev_upload(c, &s.sub_split, split)) return -1;
+  }
   s.built = true;
   s.factored = false;
   return 0;
 }
 
 void free_schedule(IluSchedule& s) {
-  hipFree(s.sub_ptr); hipFree(s.sub_nlev); hipFree(s.row_info); hipFree(s.fval); hipFree(s.dinv);
+  hipFree(s.sub_ptr); hipFree(s.sub_nlev); hipFree(s.sub_split); hipFree(s.row_info); hipFree(s.fval); hipFree(s.dinv);
   hipFree(s.row_uoff); hipFree(s.sub_int); hipFree(s.sub_bnd); hipFree(s.ord_f); hipFree(s.ord_b);
   s = IluSchedule();
 }

@@ -109,6 +109,7 @@ struct IluSchedule {
   int nsub = 0, max_rows = 0, max_lev = 0;
   int* sub_ptr = nullptr;   // nsub+1 row ranges
   int* sub_nlev = nullptr;  // per subdomain: forward levels | backward levels << 16
+  int* sub_split = nullptr; // per subdomain: leading rows longer than half the block-ELL width (k_pc_rows: MINC bricks), or null
   int* row_info = nullptr;  // per row: lfirst | dslot<<4 | ulast<<8 | lev_f<<12 | lev_b<<22
   double* fval = nullptr;   // factor in the matrix' block-ELL layout; the diagonal slot holds
                             // the inverted pivot block

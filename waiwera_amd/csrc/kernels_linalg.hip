@@ -922,7 +922,7 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
     const int* __restrict__ row_info, const int* __restrict__ col, const double* __restrict__ sval,
     const double* __restrict__ dinv, const double* __restrict__ in, double* __restrict__ z,
     const double* __restrict__ aux, double* partials, int nb_max, int dot, const int* __restrict__ sub_list,
-    const int* __restrict__ rowptr) {
+    const int* __restrict__ rowptr, const int* __restrict__ sub_split) {
   extern __shared__ double lds[];  // [R*BS] solution in block order, [BS] zeros, then reduction scratch
   int s = xcd_remap(blockIdx.x, nsub);
   if (s >= nsub) return;
@@ -931,7 +931,11 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
   const int nl = sub_nlev[s];
   const int nlf = nl & 0xffff, nlb = nl >> 16;
   const int tid = threadIdx.x;
-  const int r = tid / R, il = tid - r * R, i = lo + il;
+  // component-major over the R1 leading (long) rows, then component-major over the short ones
+  const int R1 = sub_split ? sub_split[s] : R;
+  const bool shortrow = tid >= R1 * BS;
+  const int tt = shortrow ? tid - R1 * BS : tid, RR = shortrow ? max(R - R1, 1) : R1;
+  const int r = min(tt / RR, BS - 1), il = (shortrow ? R1 : 0) + tt - (tt / RR) * RR, i = lo + il;
   const bool active = tid < R * BS;
   double* ys = lds;
   double Lf[NL][BS], Uf[NU][BS];
@@ -1565,7 +1569,7 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
 #define PCR(SP, NLU)                                                                               \
     hipLaunchKernelGGL((k_pc_rows<BS, SP, NLU, NLU>), grid, TR, lds_r, c->stream, J.n, J.W, nrun, s.sub_ptr,  \
                        s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, \
-                       dot_mode, list, rp)
+                       dot_mode, list, rp, s.sub_split)
     if (s.max_nlu <= 3) { if (spmv) PCR(true, 3); else PCR(false, 3); }
     else { if (spmv) PCR(true, 4); else PCR(false, 4); }
 #undef PCR
