@@ -332,6 +332,198 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
   }
 }
 
+// ---- K5': the same Jacobian with the own-perturbed states parked in LDS ---------------------------
+// k_jacobian reads a neighbour's unperturbed state once for the base residual and once more for every
+// own-perturbed evaluation (the perturbation loop is outside the face loop, because only one perturbed
+// own state fits the registers next to the base state and the neighbour's).  None of these re-reads
+// hits a cache: between two of them a wave streams ~140 KB and an XCD's 32 CUs ~36 MB through the 4 MB
+// L2 (PMC: 9.6 KB of L2-miss traffic per cell = every load of the kernel).  Here the np own-perturbed
+// states go to LDS once (np x 18-34 doubles per thread, field-major: conflict-free) and the face loop
+// is outermost for the base and the own-perturbed evaluations together, so a neighbour's state, rock
+// and face record are loaded once for all of them: 21 instead of 33 state records per cell for np = 2,
+// 13 instead of 25 rock records, 12 instead of 24 face records.  Same evaluations, same summation
+// order, bit-identical blocks.
+template <int KIND> struct ParkT {
+  using E = EosT<KIND>;
+  static constexpr int nld = 4 + E::nph * (7 + (E::nc > 1 ? E::nc : 0));   // doubles load_state reads
+  static constexpr int threads = E::np <= 2 ? 128 : 64;   // LDS per workgroup: np * (nld + MAXDEG) * 8 * threads
+};
+template <int KIND>
+__device__ __forceinline__ void park_state(const CellState<KIND>& s, double* __restrict__ b, int st) {
+  using E = EosT<KIND>;
+  int f = 0;
+  b[(f++) * st] = s.P; b[(f++) * st] = s.T; b[(f++) * st] = s.phases; b[(f++) * st] = s.permfac;
+#pragma unroll
+  for (int p = 0; p < E::nph; p++) {
+    b[(f++) * st] = s.rho[p]; b[(f++) * st] = s.mu[p]; b[(f++) * st] = s.sat[p]; b[(f++) * st] = s.kr[p];
+    b[(f++) * st] = s.pc[p]; b[(f++) * st] = s.h[p]; b[(f++) * st] = s.u[p];
+    if constexpr (E::nc > 1) {
+#pragma unroll
+      for (int q = 0; q < E::nc; q++) b[(f++) * st] = s.x[p][q];
+    }
+  }
+}
+template <int KIND>
+__device__ __forceinline__ void unpark_state(const double* __restrict__ b, int st, CellState<KIND>& s) {
+  using E = EosT<KIND>;
+  int f = 0;
+  s.P = b[(f++) * st]; s.T = b[(f++) * st]; s.phases = b[(f++) * st]; s.permfac = b[(f++) * st];
+  s.region = 0.0;
+#pragma unroll
+  for (int q = 0; q < E::nc; q++) s.pp[q] = 0.0;
+#pragma unroll
+  for (int p = 0; p < E::nph; p++) {
+    s.rho[p] = b[(f++) * st]; s.mu[p] = b[(f++) * st]; s.sat[p] = b[(f++) * st]; s.kr[p] = b[(f++) * st];
+    s.pc[p] = b[(f++) * st]; s.h[p] = b[(f++) * st]; s.u[p] = b[(f++) * st];
+    if constexpr (E::nc == 1) {
+      s.x[p][0] = (((int)s.phases >> p) & 1) ? 1.0 : 0.0;
+    } else {
+#pragma unroll
+      for (int q = 0; q < E::nc; q++) s.x[p][q] = b[(f++) * st];
+    }
+  }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(ParkT<KIND>::threads, (EosT<KIND>::np <= 2 ? 2 : 1)) void k_jacobian_park(MeshView m, const double* __restrict__ flu,
+                                                  size_t stride, const double* __restrict__ flu_pert,
+                                                  const double* __restrict__ hstep, int n_prim,
+                                                  ResForm rf, double* __restrict__ val) {
+  using E = EosT<KIND>;
+  constexpr int np = E::np, bb = E::np * E::np;
+  const int c = xcd_cell(m.n_owned);
+  if (c < 0) return;
+  CellState<KIND> own0;
+  RockState rown;
+  load_state<KIND>(flu, stride, c, own0);
+  load_rock(m.rock, m.n_local, c, rown);
+  const double vol = m.vol[c];
+  double lold[np], lold2[np];
+#pragma unroll
+  for (int k = 0; k < np; k++) {
+    lold[k] = rf.method == WAI_METHOD_DIRECTSS ? 0.0 : rf.last[(size_t)c * np + k];
+    lold2[k] = rf.method == WAI_METHOD_BDF2 ? rf.last2[(size_t)c * np + k] : 0.0;
+  }
+
+  // own-perturbed states: accumulation terms now, the states themselves into LDS (thread-private columns)
+  extern __shared__ double park[];
+  constexpr int nld = ParkT<KIND>::nld;
+  const int st = (int)blockDim.x;
+  double Lk[np][np], Rk[np][np];
+#pragma unroll
+  for (int k = 0; k < np; k++) {
+    CellState<KIND> ownk;
+    load_state<KIND>(flu_pert + (size_t)k * E::df * n_prim, (size_t)n_prim, c, ownk);
+    cell_balance<KIND>(ownk, rown, Lk[k]);
+    park_state<KIND>(ownk, park + (size_t)k * nld * st + threadIdx.x, st);
+#pragma unroll
+    for (int q = 0; q < np; q++) Rk[k][q] = 0.0;
+  }
+  // base residual, keeping every slot's contribution (in LDS too: [slot][component][thread], so that the
+  // face loops need not be unrolled); the own-perturbed evaluations of the same face with it
+  double* terms0 = park + (size_t)np * nld * st + threadIdx.x;
+  double L0[np], src0[np], f0[np];
+  cell_balance<KIND>(own0, rown, L0);
+  unsigned valid = 0u;
+#pragma unroll 1
+  for (int s = 0; s < m.max_deg; s++) {
+    const int fs = m.adj_face[(size_t)s * m.n_owned + c];
+    if (fs < 0) continue;
+    valid |= 1u << s;
+    const int o = m.adj_other[(size_t)s * m.n_owned + c];
+    FaceGeom g;
+    load_face(m, fs >> 1, g);
+    CellState<KIND> oth;
+    RockState roth;
+    load_state<KIND>(flu, stride, o, oth);
+    load_rock(m.rock, m.n_local, o, roth);
+    double t0[np];
+    slot_term<KIND>(g, fs & 1, own0, rown, oth, roth, vol, t0);
+#pragma unroll
+    for (int q = 0; q < np; q++) terms0[(size_t)(s * np + q) * st] = t0[q];
+#pragma unroll
+    for (int k = 0; k < np; k++) {
+      CellState<KIND> ownk;
+      unpark_state<KIND>(park + (size_t)k * nld * st + threadIdx.x, st, ownk);
+      double term[np];
+      slot_term<KIND>(g, fs & 1, ownk, rown, oth, roth, vol, term);
+#pragma unroll
+      for (int q = 0; q < np; q++) Rk[k][q] += term[q];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < np; k++) src0[k] = 0.0;
+  source_terms<KIND>(m, c, own0, vol, src0);
+  {
+    double R[np];
+#pragma unroll
+    for (int k = 0; k < np; k++) R[k] = 0.0;
+#pragma unroll 1
+    for (int s = 0; s < m.max_deg; s++) {
+      if ((valid >> s) & 1u) {
+#pragma unroll
+        for (int k = 0; k < np; k++) R[k] += terms0[(size_t)(s * np + k) * st];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < np; k++) { R[k] += src0[k]; f0[k] = res_form(rf, L0[k], R[k], lold[k], lold2[k]); }
+  }
+
+  // diagonal block: own state perturbed in component k
+  // block-ELL planes: element (r, k) of the block in slot q of block-row c is val[ell_ix(np, n_owned, q, r, k, c)]
+  // (context.hpp; kernels_linalg.hip, "Matrix entry addressing")
+  const size_t nrow = m.n_owned;
+  const int dq = m.diag_blk[c];
+#pragma unroll
+  for (int k = 0; k < np; k++) {
+    CellState<KIND> ownk;
+    unpark_state<KIND>(park + (size_t)k * nld * st + threadIdx.x, st, ownk);
+    source_terms<KIND>(m, c, ownk, vol, Rk[k]);
+    const double h = hstep[(size_t)c * np + k];
+#pragma unroll
+    for (int r = 0; r < np; r++) {
+      const double f1 = res_form(rf, Lk[k][r], Rk[k][r], lold[r], lold2[r]);
+      val[ell_ix(np, nrow, dq, r, k, (size_t)c)] = (f1 - f0[r]) / h;
+    }
+  }
+
+  // off-diagonal blocks: neighbour across slot s perturbed in component k
+#pragma unroll 1
+  for (int s = 0; s < m.max_deg; s++) {
+    if (!((valid >> s) & 1u)) continue;
+    const int blk = m.adj_blk[(size_t)s * m.n_owned + c];
+    if (blk < 0) continue;  // Dirichlet ghost: no column
+    const int fs = m.adj_face[(size_t)s * m.n_owned + c];
+    const int o = m.adj_other[(size_t)s * m.n_owned + c];
+    FaceGeom g;
+    load_face(m, fs >> 1, g);
+    RockState roth;
+    load_rock(m.rock, m.n_local, o, roth);
+#pragma unroll
+    for (int k = 0; k < np; k++) {
+      CellState<KIND> othk;
+      load_state<KIND>(flu_pert + (size_t)k * E::df * n_prim, (size_t)n_prim, o, othk);
+      double term[np], R[np];
+      slot_term<KIND>(g, fs & 1, own0, rown, othk, roth, vol, term);
+#pragma unroll
+      for (int q = 0; q < np; q++) R[q] = 0.0;
+#pragma unroll 1
+      for (int s2 = 0; s2 < m.max_deg; s2++) {
+        if ((valid >> s2) & 1u) {
+#pragma unroll
+          for (int q = 0; q < np; q++) R[q] += (s2 == s) ? term[q] : terms0[(size_t)(s2 * np + q) * st];
+        }
+      }
+      const double h = hstep[(size_t)o * np + k];
+#pragma unroll
+      for (int r = 0; r < np; r++) {
+        const double f1 = res_form(rf, L0[r], R[r] + src0[r], lold[r], lold2[r]);
+        val[ell_ix(np, nrow, blk, r, k, (size_t)c)] += (f1 - f0[r]) / h;
+      }
+    }
+  }
+}
+
 // ---- tracers: the auxiliary linear problem ------------------------------------------------------
 // One scalar system per tracer on the flow Jacobian's sparsity, one thread per owned cell (row):
 // aux_lhs (flow_simulation.F90:1489-1556), aux_rhs (:1560-1833: advection with the phase flux,
@@ -720,6 +912,26 @@ int launch_jacobian(wai_ctx* c, double dt, const double* lhs_old) {
   if (m.max_deg > MAXDEG) { c->err = "cell with more than 8 faces not supported"; return -1; }
   const size_t stride = c->mesh.n_local;
   hipMemsetAsync(c->J.val, 0, sizeof(double) * (size_t)c->J.W * c->np * c->np * c->J.n, c->stream);
+  static const bool park = !(getenv("WAI_JAC_PARK") && getenv("WAI_JAC_PARK")[0] == '0');
+  if (park) {
+#define JP(K)                                                                                             \
+    do {                                                                                                  \
+      constexpr int T = ParkT<K>::threads;                                                                \
+      const int g = (((int)((m.n_owned + T - 1) / T) + 7) / 8) * 8;                                        \
+      hipLaunchKernelGGL(k_jacobian_park<K>, g, T, sizeof(double) * EosT<K>::np * (ParkT<K>::nld + MAXDEG) * T, c->stream, \
+                         m, c->flu, stride, c->flu_pert, c->hstep, c->mesh.n_prim, res_form_of(c, dt, lhs_old), \
+                         c->J.val);                                                                       \
+    } while (0)
+    if (c->kind == EOS_W) JP(EOS_W);
+    else if (c->kind == EOS_WE) JP(EOS_WE);
+    else if (c->kind == EOS_WSE) JP(EOS_WSE);
+    else if (c->kind == EOS_WAE) JP(EOS_WAE);
+    else if (c->kind == EOS_WSCE) JP(EOS_WSCE);
+    else if (c->kind == EOS_WSAE) JP(EOS_WSAE);
+    else JP(EOS_WCE);
+#undef JP
+    return 0;
+  }
   WAI_BY_EOS(c, k_jacobian, grid8_for(m.n_owned), m, c->flu, stride, c->flu_pert, c->hstep, c->mesh.n_prim,
              res_form_of(c, dt, lhs_old), c->J.val);
   return 0;
