@@ -346,7 +346,11 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
 template <int KIND> struct ParkT {
   using E = EosT<KIND>;
   static constexpr int nld = 4 + E::nph * (7 + (E::nc > 1 ? E::nc : 0));   // doubles load_state reads
-  static constexpr int threads = E::np <= 2 ? 128 : 64;   // LDS per workgroup: np * (nld + MAXDEG) * 8 * threads
+  static constexpr int threads = E::np <= 2 ? 128 : 64;
+  static constexpr int lds_bytes = E::np * (nld + MAXDEG) * 8 * threads;   // parked states + base terms
+  // three workgroups per CU or the plain kernel: MEASURED 13.7 -> 10.4 ms (we, 216^3), 12.5 -> 11.0 (wce,
+  // 172x172x170; 14.7 with 128 threads = one workgroup per CU); the three-phase salt EOS would hold one
+  static constexpr bool use = lds_bytes <= 54 * 1024;
 };
 template <int KIND>
 __device__ __forceinline__ void park_state(const CellState<KIND>& s, double* __restrict__ b, int st) {
@@ -918,9 +922,14 @@ int launch_jacobian(wai_ctx* c, double dt, const double* lhs_old) {
     do {                                                                                                  \
       constexpr int T = ParkT<K>::threads;                                                                \
       const int g = (((int)((m.n_owned + T - 1) / T) + 7) / 8) * 8;                                        \
-      hipLaunchKernelGGL(k_jacobian_park<K>, g, T, sizeof(double) * EosT<K>::np * (ParkT<K>::nld + MAXDEG) * T, c->stream, \
-                         m, c->flu, stride, c->flu_pert, c->hstep, c->mesh.n_prim, res_form_of(c, dt, lhs_old), \
-                         c->J.val);                                                                       \
+      if (ParkT<K>::use)                                                                                  \
+        hipLaunchKernelGGL(k_jacobian_park<K>, g, T, ParkT<K>::lds_bytes, c->stream,                       \
+                           m, c->flu, stride, c->flu_pert, c->hstep, c->mesh.n_prim, res_form_of(c, dt, lhs_old), \
+                           c->J.val);                                                                     \
+      else                                                                                                \
+        hipLaunchKernelGGL(k_jacobian<K>, grid8_for(m.n_owned), TPB, 0, c->stream,                        \
+                           m, c->flu, stride, c->flu_pert, c->hstep, c->mesh.n_prim, res_form_of(c, dt, lhs_old), \
+                           c->J.val);                                                                     \
     } while (0)
     if (c->kind == EOS_W) JP(EOS_W);
     else if (c->kind == EOS_WE) JP(EOS_WE);
