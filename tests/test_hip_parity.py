@@ -105,6 +105,29 @@ def test_jacobian(FS, oracle, eos, lens):
     sim.destroy(); osim.close()
 
 
+@pytest.mark.parametrize("eos", ["w", "we", "wce", "wae"])
+def test_jacobian_kernels_agree_bitwise(FS, oracle, eos, monkeypatch):
+    """k_jacobian_park (own-perturbed states in LDS, face loop outermost; the default where three
+    workgroups fit a CU) and k_jacobian (WAI_JAC_PARK=0) do the same evaluations in the same order:
+    identical blocks, with the two-phase lens in the mesh."""
+    g, lm, sim, osim, y, region = build(FS, oracle, eos=eos, dims=(12, 12, 12), brick=(4, 4, 2), lens=True)
+    n = sim.n_owned * sim.num_primary_variables
+    dt = 2.0e4
+    yo = osim.yvec(y)
+    assert sim.pre_eval(0.0, y) == 0 and osim.pre_eval(yo) == 0
+    L = osim.lhs()
+    f = np.zeros(n)
+    assert sim.residual(0.0, dt, y, L, f) == 0
+    vals = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("WAI_JAC_PARK", flag)
+        assert sim.jacobian(0.0, dt, y, L) == 0
+        vals[flag] = sim.jacobian_values().copy()
+    assert np.abs(vals["0"]).max() > 0.0
+    assert np.array_equal(vals["0"], vals["1"])
+    sim.destroy(); osim.close()
+
+
 @pytest.mark.parametrize("eos", ["we", "w", "wce", "wsce"])
 def test_spmv_ilu_krylov(FS, oracle, eos):
     g, lm, sim, osim, y, region = build(FS, oracle, eos=eos, dims=(12, 10, 9), brick=(4, 4, 4))
