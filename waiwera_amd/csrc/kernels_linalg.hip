@@ -815,7 +815,7 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
   double* upark = lds + (size_t)blockDim.x * BS + 80;
   double Lf[MLU][BB];
   int Lc[MLU], Uc[MLU], lf = -1, lb = -1, uo = 0, nU = 0;
-  double xin[BS] = {0.0, 0.0};
+  double xin[BS] = {0.0, 0.0}, avp[BS] = {0.0, 0.0};
 #pragma unroll
   for (int p = 0; p < MLU; p++) {
     Lc[p] = tid; Uc[p] = tid;
@@ -874,6 +874,7 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
       acc[1] = dv[2] * r[0] + dv[3] * r[1];
     }
     if (dot == 2 || dot == 4) load_x<BS>(in, i, xin);
+    if (dot == 1 || dot == 4) load_x_stream<BS>(aux, i, avp);   // the dot product's partner: in flight through the sweeps
     *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(acc[0], acc[1]);
   }
   __syncthreads();
@@ -925,18 +926,13 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
     double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     int slots[5] = {S_D1, S_D2, S_DP2, S_RHONEW, S_W2};
     if (dot == 1) {
-      if (active) {
-        double av[BS];
-        load_x_stream<BS>(aux, i, av);
-        v[0] = out[0] * av[0] + out[1] * av[1];
-      }
+      if (active) v[0] = out[0] * avp[0] + out[1] * avp[1];
     } else if (dot == 2) {
       v[0] = xin[0] * out[0] + xin[1] * out[1];
       v[1] = out[0] * out[0] + out[1] * out[1];
     } else if (dot == 4) {  // merged BiCGStab reductions: (in,z), (z,z), (in,in), (in,aux), (z,aux)
       if (active) {
-        double av[BS];
-        load_x_stream<BS>(aux, i, av);
+        const double* av = avp;
         v[0] = xin[0] * out[0] + xin[1] * out[1];
         v[1] = out[0] * out[0] + out[1] * out[1];
         v[2] = xin[0] * xin[0] + xin[1] * xin[1];
@@ -1057,6 +1053,9 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
     }
     ys[il * BS + r] = acc;
   }
+  // the dot product's partner (block order, tid-linear): in flight through the sweeps
+  double avp = 0.0;
+  if (active && (dot == 1 || dot == 4)) avp = __builtin_nontemporal_load(aux + (size_t)lo * BS + tid);
   __syncthreads();
   for (int lev = 1; lev < nlf; lev++) {  // forward: y_i = t_i - sum A'_ik y_k
     if (lf == lev) {
@@ -1092,12 +1091,12 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
     double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     int slots[5] = {S_D1, S_D2, S_DP2, S_RHONEW, S_W2};
     if (dot == 1) {
-      if (active) v[0] = out * __builtin_nontemporal_load(aux + g);
+      if (active) v[0] = out * avp;
     } else if (dot == 2) {
       if (active) { v[0] = in[g] * out; v[1] = out * out; }
     } else if (dot == 4) {
       if (active) {
-        const double xi = in[g], av = __builtin_nontemporal_load(aux + g);
+        const double xi = in[g], av = avp;
         v[0] = xi * out; v[1] = out * out; v[2] = xi * xi; v[3] = xi * av; v[4] = out * av;
       }
     } else {
