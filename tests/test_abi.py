@@ -50,3 +50,13 @@ def test_no_product_code_touches_the_oracle():
                     if re.search(r"oracle_lib|liboracle|wai_oracle|\bwo_[a-z]+\(", t):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_assembly_kernels_and_oracle_round_alike():
+    """The assembly / EOS kernels and the oracle are both built without FMA contraction: the FD Jacobian
+    then does not depend on how a kernel orders its loops, and the device follows the oracle's Krylov
+    counts."""
+    from waiwera_amd import build as B
+    assert "-ffp-contract=off" in B.PER_FILE.get("kernels_assembly.hip", [])
+    mk = open(os.path.join(ROOT, "oracle", "Makefile")).read()
+    assert "-ffp-contract=off" in mk
