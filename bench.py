@@ -358,9 +358,12 @@ def main():
     #   4x10x2 2.75 / 199 / 55.9 %   4x5x4 2.76 / 203 / 57.5 %    16x5x1 2.55 / 201 / 51.2 %
     # with a MINC level the matrix cells join their fracture cell's brick (40 + 40 block rows):
     #   16x8x1 10.8 / 93 / 29.8 %    8x10x1 11.5 / 104 / 37.5 %   8x5x1 11.8 / 110 / 42.6 %   5x8x1 12.1 / 107 / 42.5 %
+    # and, with the final kernels and the driver's 20-step window on one box: 5x8x1 11.9 / 125 / 50.9 %,
+    # 4x8x1 12.4 / 125 / 54.2 %, 8x4x1 (32 + 32 block rows, 3 waves) 12.8 / 121 / 54.4 %, 4x4x1 10.7 / 136 / 50.8 %
+    # (3 x 3 blocks there: 8x5x2 2.84 / 208 / 61.0 %, 8x4x2 2.82 / 224 / 67.2 %, 6x6x2 2.80 / 210, 4x5x2 2.58 / 227)
     # 2 x 2 blocks (k_pc_park, one thread per block row, 512 rows): 16x16x2 3.21 / 171; every other
     # shape of 256-512 cells tried at 216^3 needs 190-1360 iterations (18x12x2 195, 16x8x2 304, 8x8x8 1363)
-    brick = tuple(a.brick) if a.brick else ((5, 8, 1) if minc else ((8, 5, 2) if eos == "wce" else (16, 16, 2)))
+    brick = tuple(a.brick) if a.brick else ((8, 4, 1) if minc else ((8, 5, 2) if eos == "wce" else (16, 16, 2)))
     grid, lm, prim, region = make_case(dims=dims, brick=brick, eos=eos, lens=not a.no_lens, minc=minc,
                                        part=M.partition_shape(world), rank=rank)
     opts = wl.default_opts(ksp_type=a.ksp, pc_type=a.pc)
