@@ -1,10 +1,10 @@
 """GPU parity tests: every HIP kernel / solver stage against the CPU oracle on the same seeded
 inputs, through the C ABI (waiwera_amd.lib -> libwaiwera_hip.so).
 
-Tolerances (fp64): the device code evaluates the same formulas with FMA contraction and a
-different (compile-time) power evaluation order, so kernel outputs agree to ~1e-13 relative;
-finite-difference Jacobian entries amplify that by 1/h ~ 1e8 relative to the residual terms,
-hence 1e-5 of the block-row scale; Krylov/Newton results are compared at the tolerance the
+Tolerances (fp64): the device code evaluates the same formulas with a different (compile-time)
+power evaluation order (the assembly kernels, like the oracle, without FMA contraction), so kernel
+outputs agree to ~1e-13 relative; finite-difference Jacobian entries amplify that by 1/h ~ 1e8
+relative to the residual terms, hence 2e-5 of the block-row scale for every EOS (measured <= 8e-6); Krylov/Newton results are compared at the tolerance the
 solves are run to.
 """
 import numpy as np
@@ -95,13 +95,14 @@ def test_jacobian(FS, oracle, eos, lens):
         rowscale = np.zeros(sim.n_owned)
         np.maximum.at(rowscale, np.repeat(np.arange(sim.n_owned), np.diff(rp)), np.abs(Jo[:, r, :]).max(axis=1))
         sc = np.repeat(rowscale, np.diff(rp))[:, None]
-        # eos wse: the two-phase temperature comes out of a nested Newton solve stopped at 1e-10 P
-        # (brine_saturation_temperature), so a difference over h ~ 1e-8 carries its rounding 1e4
-        # times amplified, differently on the two paths
-        tol = 1e-3 if (eos in ("wse", "wsce") and lens) else 1e-5
-        if eos in ("wae", "wsae"):   # the air balance of single-phase liquid holds ~1e-5 kg/m3 of dissolved air: its
-            tol = 2e-4     # rows are differences of nearly equal small numbers, rounding shows at 5e-5
-        assert (np.abs(Jg[:, r, :] - Jo[:, r, :]) / np.maximum(sc, 1e-300)).max() < tol
+        # one tolerance for every EOS: with the assembly kernels built without FMA contraction (as the
+        # oracle is) the worst entry measured on an MI355X is 8.0e-6 of its block row's scale (eos wce / wae,
+        # pressure row; 4.4e-6 in the wse / wsce two-phase lens, which needed 1e-3 before, 8.0e-6 for the
+        # air rows, which needed 2e-4) -- the figures are printed below (pytest -s)
+        tol = 2e-5
+        worst = (np.abs(Jg[:, r, :] - Jo[:, r, :]) / np.maximum(sc, 1e-300)).max()
+        print("jacobian parity %s lens=%s row %d: %.3e (tol %.0e)" % (eos, lens, r, worst, tol))   # pytest -s
+        assert worst < tol
     sim.destroy(); osim.close()
 
 
