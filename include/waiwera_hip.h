@@ -176,8 +176,9 @@ int wai_set_source_controls(wai_ctx *ctx, const wai_source_control *controls);
  * grp_sep (may be NULL): a group's own separator, 8 doubles per group -- (hf, hg) of stage 1 from
  * wai_separator_enthalpies, then (hf, hg) of stages 2..4; hg = 0: none (the separated flows are then
  * the sums of the inputs').
- * The FD Jacobian differences with the network's factors held at the last pass: the couplings between
- * cells that src/flow_simulation.F90:3023-3084 adds to the matrix are not there (inexact Newton).
+ * The dependencies between cells that the network adds to the Jacobian (flow_simulation_modify_jacobian,
+ * src/flow_simulation.F90:3023-3084; source_network_identify_source_dependencies,
+ * src/source_network.F90:359-498) are kept beside the 7-point matrix: see wai_get_network_couplings.
  * All sources of the network must live on this rank.  Call after wai_set_sources / controls. */
 int wai_set_source_network(wai_ctx *ctx, const int *rate_specified, const int *enthalpy_specified,
                            int n_groups, const int *grp_ptr, const int *grp_in_kind, const int *grp_in,
@@ -186,6 +187,16 @@ int wai_set_source_network(wai_ctx *ctx, const int *rate_specified, const int *e
                            const int *out_flow, const int *out_kind, const int *out_node,
                            const double *out_rate, const double *out_proportion, const double *out_enthalpy,
                            const int *rj_overflow_kind, const int *rj_overflow);
+/* The network's Jacobian blocks (replaces flow_simulation_modify_jacobian + the part of MatFDColoringApply
+ * that fills the added entries, src/flow_simulation.F90:3023-3084): wai_jacobian differences the 7-point
+ * matrix A with the network's factors held and then E = dR/dy through the network pass on the m distinct
+ * cells of the network's sources (same increment rule; two residual evaluations per column).  Every
+ * operator application of the Krylov solvers and wai_spmv is (A + E) x; the preconditioner is built from
+ * A alone.  n_cells = m (0: no network, switched off, or E = 0 at this state); cells (may be NULL) m local
+ * cell indices, ascending; values (may be NULL) m x m blocks of bs x bs, row-major [row cell][col cell][r][k].
+ * wai_set_network_couplings(ctx, 0) holds the factors instead (round 1's inexact Newton); default on. */
+int wai_set_network_couplings(wai_ctx *ctx, int on);
+int wai_get_network_couplings(wai_ctx *ctx, int *n_cells, int *cells, double *values);
 /* after the last pass: groups 6 doubles each (rate, enthalpy, water_rate, water_enthalpy, steam_rate,
  * steam_enthalpy), reinjectors 8 each (output water / steam rate, overflow rate, enthalpy, water rate,
  * water enthalpy, steam rate, steam enthalpy) -- the network_group / network_reinject output fields */

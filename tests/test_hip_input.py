@@ -225,3 +225,86 @@ def test_source_networks_against_autough2(name, geometry):
     assert worst["Pressure"] < 2e-2 and worst["Temperature"] < 2e-2 and worst["Vapour saturation"] < 2e-2, worst
     assert worst["rate"] < 6e-2, worst
     sim.ode.destroy()
+
+
+@pytest.mark.parametrize("name,geometry,steps", [("makeup_uniform", "gmakeup.dat", 3), ("reinjection", "greinjection.dat", 3)])
+def test_network_couplings_are_the_literal_fd_columns(name, geometry, steps):
+    """flow_simulation_modify_jacobian (flow_simulation.F90:3023-3084) widens the Jacobian by the network's
+    dependencies and MatFDColoring differences the whole residual function into it.  Here A (7-point,
+    network factors held) + E (wai_get_network_couplings) must be exactly that: every column of a network
+    cell, assembled from A and E, against the forward difference of wai_residual -- network pass included --
+    with the same increment, on *all* rows (so a dependency outside E's cells would show)."""
+    from waiwera_amd.simulation import Simulation
+    sim = Simulation.from_json(os.path.join(INPUTS, name + ".json"), mesh_file=os.path.join(INPUTS, geometry))
+    ode = sim.ode
+    assert ode.pre_eval(sim.ts.time, sim.y) == 0
+    sim.ts.run(num_steps=steps)          # wells flowing, limiter / reinjector at work
+    y, t, dt = np.array(sim.y, dtype=float).copy(), sim.ts.time, sim.ts.stepsize
+    bs, n = ode.num_primary_variables, y.size
+    L, f0 = np.zeros(n), np.zeros(n)
+    assert ode.pre_eval(t, y) == 0
+    assert ode.lhs(t, (t, t + dt), y, L) == 0
+    assert ode.residual(t + dt, dt, y, L, f0) == 0
+    assert ode.jacobian(t + dt, dt, y, L) == 0
+    rp, ci = ode.setup_jacobian()
+    A = ode.jacobian_values().reshape(-1, bs, bs)
+    cells, E = ode.network_couplings()
+    assert cells.size >= 2 and np.abs(E).max() > 0.0
+    rows_of = np.repeat(np.arange(rp.size - 1), np.diff(rp))
+    worst, offdiag = 0.0, 0.0
+    for j, c in enumerate(cells):
+        for k in range(bs):
+            yp = y.copy()
+            dx = yp[c * bs + k]
+            if abs(dx) < 1e-2:
+                dx = 1e-2 if dx >= 0.0 else -1e-2
+            h = dx * 1e-8
+            yp[c * bs + k] += h
+            fp = np.zeros(n)
+            assert ode.residual(t + dt, dt, yp, L, fp) == 0
+            col = (fp - f0) / h
+            asm = np.zeros(n)
+            for b in np.nonzero(ci == c)[0]:
+                asm[rows_of[b] * bs:(rows_of[b] + 1) * bs] += A[b][:, k]
+            for i, r in enumerate(cells):
+                asm[r * bs:(r + 1) * bs] += E[i, j, :, k]
+                if i != j:
+                    offdiag = max(offdiag, np.abs(E[i, j, :, k]).max())
+            # per equation: the energy rows are ~1e6 times the mass rows
+            for q in range(bs):
+                sc = max(np.abs(col[q::bs]).max(), 1e-300)
+                worst = max(worst, np.abs(col[q::bs] - asm[q::bs]).max() / sc)
+    print(name, "network cells", cells.tolist(), "worst column difference", worst, "largest coupling entry", offdiag)
+    assert offdiag > 0.0            # the network really couples different cells at this state
+    assert worst < 1e-5, worst
+    # the operator the Krylov solvers see is A + E
+    x = np.random.default_rng(3).uniform(-1, 1, n)
+    ax = np.zeros(n)
+    assert ode.spmv(x, ax) == 0
+    ref = np.zeros(n)
+    for b in range(ci.size):
+        ref[rows_of[b] * bs:(rows_of[b] + 1) * bs] += A[b] @ x[ci[b] * bs:(ci[b] + 1) * bs]
+    for i, r in enumerate(cells):
+        for j, c in enumerate(cells):
+            ref[r * bs:(r + 1) * bs] += E[i, j] @ x[c * bs:(c + 1) * bs]
+    assert np.abs(ax - ref).max() <= 1e-12 * np.abs(ref).max()
+    ode.set_network_couplings(False)
+    assert ode.residual(t + dt, dt, y, L, f0) == 0
+    assert ode.jacobian(t + dt, dt, y, L) == 0
+    assert ode.network_couplings()[0].size == 0
+    ode.destroy()
+
+
+def test_reinjection_with_and_without_network_couplings():
+    """the couplings are what the reference's Newton iteration has: the run with them must not take more
+    time steps / Newton iterations than the run that holds the network's factors"""
+    from waiwera_amd.simulation import Simulation
+    taken = {}
+    for on in (True, False):
+        sim = Simulation.from_json(os.path.join(INPUTS, "reinjection.json"), mesh_file=os.path.join(INPUTS, "greinjection.dat"))
+        sim.ode.set_network_couplings(on)
+        sim.run()
+        taken[on] = (sim.ts.taken, sum(h[2] if isinstance(h, (list, tuple)) and len(h) > 2 else 0 for h in getattr(sim.ts, "history", [])))
+        sim.ode.destroy()
+    print("reinjection: (time steps, newton iterations) with couplings", taken[True], "without", taken[False])
+    assert taken[True][0] <= taken[False][0]

@@ -609,6 +609,104 @@ int network_update(wai_ctx* c) {
   return 0;
 }
 
+// ---- Jacobian couplings through the source network ---------------------------------------------
+// flow_simulation_modify_jacobian (src/flow_simulation.F90:3023-3084) widens the Jacobian's pattern by the
+// network's dependencies and MatFDColoring then differences the whole residual function -- network pass
+// included -- into it.  Here the 7-point part A is differenced with the network's factors held
+// (k_jacobian), and the rest, E = dR/dy *through the network pass*, is differenced separately on the cells
+// of the network's sources: for every such cell j and primary k, with y_jk + h (the same h as A's
+// columns), E[:, j][:, k] = (R(network pass redone) - R(factors held)) / h on the rows of those cells.
+// Two residual launches and two host passes per column: networks tie tens of cells together, not millions.
+__global__ void k_gather_rows(int m, int bs, const int* __restrict__ cells, const double* __restrict__ f,
+                              double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= m * bs) return;
+  out[t] = f[(size_t)cells[t / bs] * bs + t % bs];
+}
+
+// t += E x on the network's rows: thread (i, r) sums its row over the m column cells (cells are distinct: no race)
+__global__ void k_coupling_apply(int m, int bs, const int* __restrict__ cells, const double* __restrict__ val,
+                                 const double* __restrict__ x, double* __restrict__ t) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= m * bs) return;
+  const int i = id / bs, r = id % bs;
+  double s = 0.0;
+  for (int j = 0; j < m; j++) {
+    const double* e = val + ((size_t)(i * m + j) * bs + r) * bs;
+    const double* xj = x + (size_t)cells[j] * bs;
+    for (int k = 0; k < bs; k++) s += e[k] * xj[k];
+  }
+  t[(size_t)cells[i] * bs + r] += s;
+}
+
+int network_couplings(wai_ctx* c, double dt, double* y, const double* lhs_old) {
+  Network& nw = c->net;
+  nw.cp_valid = false;
+  if (!nw.on || !nw.coupling || nw.cp_cells.empty()) return 0;
+  const int m = (int)nw.cp_cells.size(), bs = c->np, mb = m * bs;
+  if (!nw.d_cp_cells) {
+    if (dev_upload(c, &nw.d_cp_cells, nw.cp_cells) || dev_alloc(c, &nw.d_cp_val, (size_t)m * m * bs * bs) ||
+        dev_alloc(c, &nw.d_cp_f, (size_t)c->mesh.n_local * bs) || dev_alloc(c, &nw.d_cp_g, (size_t)2 * mb))
+      return -1;
+  }
+  nw.h_cp_val.assign((size_t)m * m * bs * bs, 0.0);
+  std::vector<double> g((size_t)2 * mb), yc((size_t)bs);
+  const int grid = (mb + 63) / 64;
+  auto set_y = [&](int cell, int k, double v) -> int {
+    HIPCHK(c, hipMemcpyAsync(y + (size_t)cell * bs + k, &v, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    launch_eos(c, y, cell, 1, false);
+    return 0;
+  };
+  if (network_update(c)) return -1;   // the factors A was differenced with
+  bool any = false;
+  for (int j = 0; j < m; j++) {
+    const int cell = nw.cp_cells[j];
+    HIPCHK(c, hipMemcpyAsync(yc.data(), y + (size_t)cell * bs, sizeof(double) * bs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < bs; k++) {
+      double dx = yc[k];   // MatFDColoring "ds" increment, as fd_step (kernels_assembly.hip)
+      if (std::fabs(dx) < c->opts.fd_umin) dx = dx >= 0.0 ? c->opts.fd_umin : -c->opts.fd_umin;
+      const double h = dx * c->opts.fd_eps;
+      if (set_y(cell, k, yc[k] + h)) return -1;
+      launch_residual(c, dt, lhs_old, nw.d_cp_f, nullptr, nullptr);                 // factors held
+      hipLaunchKernelGGL(k_gather_rows, grid, 64, 0, c->stream, m, bs, nw.d_cp_cells, nw.d_cp_f, nw.d_cp_g);
+      if (network_update(c)) return -1;
+      launch_residual(c, dt, lhs_old, nw.d_cp_f, nullptr, nullptr);                 // network pass redone
+      hipLaunchKernelGGL(k_gather_rows, grid, 64, 0, c->stream, m, bs, nw.d_cp_cells, nw.d_cp_f, nw.d_cp_g + mb);
+      HIPCHK(c, hipMemcpyAsync(g.data(), nw.d_cp_g, sizeof(double) * 2 * mb, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      for (int i = 0; i < m; i++)
+        for (int r = 0; r < bs; r++) {
+          const double e = (g[(size_t)mb + i * bs + r] - g[(size_t)i * bs + r]) / h;
+          nw.h_cp_val[((size_t)(i * m + j) * bs + r) * bs + k] = e;
+          any = any || e != 0.0;
+        }
+      if (set_y(cell, k, yc[k])) return -1;   // back to the unperturbed state and its network factors
+      if (network_update(c)) return -1;
+    }
+  }
+  // a perturbed state outside the EOS's range was already reported by the perturbed-state sweep of A
+  HIPCHK(c, hipMemsetAsync(c->d_flags, 0, sizeof(int), c->stream));
+  if (any) {
+    HIPCHK(c, hipMemcpyAsync(nw.d_cp_val, nw.h_cp_val.data(), sizeof(double) * nw.h_cp_val.size(), hipMemcpyHostToDevice,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  nw.cp_valid = any;
+  return 0;
+}
+
+// t = (A + E) x: the block-ELL SpMV and, when the network couples cells, its blocks on top
+void apply_operator(wai_ctx* c, const double* x, double* t) {
+  launch_spmv(c, x, t);
+  const Network& nw = c->net;
+  if (nw.cp_valid) {
+    const int m = (int)nw.cp_cells.size();
+    hipLaunchKernelGGL(k_coupling_apply, (m * c->np + 63) / 64, 64, 0, c->stream, m, c->np, nw.d_cp_cells, nw.d_cp_val, x, t);
+  }
+}
+
 // ---- fluid_properties / pre_eval on device vectors -------------------------------------------
 int do_pre_eval(wai_ctx* c, double* y /* nl, device */) {
   if (c->comm && c->mesh.n_halo) {
@@ -646,7 +744,7 @@ int do_jacobian(wai_ctx* c, double dt, const double* y, const double* lhs_old) {
   Prof p(c, KC_JACOBIAN);
   if (launch_jacobian(c, dt, lhs_old)) return -1;
   c->ilu.factored = false;
-  return 0;
+  return network_couplings(c, dt, const_cast<double*>(y), lhs_old);   // y is perturbed and restored in place
 }
 
 // which preconditioner path is in force: the fused brick kernels (block Jacobi, every subdomain
@@ -777,9 +875,9 @@ int pc_solve(wai_ctx* c, const double* r, double* z, int dot_mode, const double*
 // z = B^-1 A x  (x has halo room); optional fused dot products of the result
 int pc_amul(wai_ctx* c, double* x, double* z, int dot_mode = 0, const double* aux = nullptr) {
   const IluSchedule& s = c->ilu;
-  if (!pc_fused(c)) {   // unfused: t = A x, then the general preconditioner
+  if (!pc_fused(c) || c->net.cp_valid) {   // unfused: t = A x (+ the network's blocks), then the preconditioner
     if (halo_exchange(c, x, c->np)) return -1;
-    { Prof p(c, KC_SPMV); launch_spmv(c, x, c->ks.tmp); }
+    { Prof p(c, KC_SPMV); apply_operator(c, x, c->ks.tmp); }
     Prof p(c, KC_PC_APPLY);
     return pc_solve(c, c->ks.tmp, z, dot_mode, x, aux);
   }
@@ -921,7 +1019,7 @@ int ksp_gmres(wai_ctx* c, const double* b, double* x, int* its, int* reason, dou
     } else {
       vec_copy(c, k.P, x, n);
       if (halo_exchange(c, k.P, c->np)) return -1;
-      { Prof p(c, KC_SPMV); launch_spmv(c, k.P, k.tmp); }
+      { Prof p(c, KC_SPMV); apply_operator(c, k.P, k.tmp); }
       vec_waxpy(c, k.tmp, -1.0, k.tmp, b, n);
       Prof p(c, KC_PC_APPLY);
       if (pc_solve(c, k.tmp, v0, 0, nullptr, nullptr)) return -1;
@@ -1024,7 +1122,7 @@ int ksp_lgmres(wai_ctx* c, const double* b, double* x, int* its, int* reason, do
     } else {
       vec_copy(c, k.P, x, n);
       if (halo_exchange(c, k.P, c->np)) return -1;
-      { Prof p(c, KC_SPMV); launch_spmv(c, k.P, k.tmp); }
+      { Prof p(c, KC_SPMV); apply_operator(c, k.P, k.tmp); }
       vec_waxpy(c, k.tmp, -1.0, k.tmp, b, n);
       Prof p(c, KC_PC_APPLY);
       if (pc_solve(c, k.tmp, v0, 0, nullptr, nullptr)) return -1;
@@ -1313,7 +1411,7 @@ void free_all(wai_ctx* c) {
   DeviceMesh& m = c->mesh;
   F(m.rock); F(m.vol); F(m.fgeom); F(m.fdir); F(m.adj_face); F(m.adj_other); F(m.adj_blk);
   F(m.diag_blk); F(m.cell_src); F(m.face_cells);
-  F(c->src.cell); F(c->src.comp); F(c->src.next); F(c->src.rate); F(c->src.enth); F(c->src.ctl); F(c->src.net); F(c->net.d_raw);
+  F(c->src.cell); F(c->src.comp); F(c->src.next); F(c->src.rate); F(c->src.enth); F(c->src.ctl); F(c->src.net); c->net.free_device();
   F(c->J.rowptr); F(c->J.col); F(c->J.val);
   free_schedule(c->ilu);
   free_asm(c);
@@ -1708,7 +1806,7 @@ int wai_set_sources(wai_ctx* c, int n, const int* cell, const double* rate, cons
   if (!c || n < 0) return -2;
   Sources& s = c->src;
   auto F = [](void* p) { if (p) (void)hipFree(p); };
-  F(s.cell); F(s.comp); F(s.next); F(s.rate); F(s.enth); F(s.ctl); F(s.net); F(c->net.d_raw);
+  F(s.cell); F(s.comp); F(s.next); F(s.rate); F(s.enth); F(s.ctl); F(s.net); c->net.free_device();
   s = Sources();
   s.n = n;
   const int N = c->mesh.n_owned;
@@ -1725,8 +1823,11 @@ int wai_set_sources(wai_ctx* c, int n, const int* cell, const double* rate, cons
   if (dev_upload(c, &s.cell, vc) || dev_upload(c, &s.comp, vk) || dev_upload(c, &s.next, next) ||
       dev_upload(c, &s.rate, vr) || dev_upload(c, &s.enth, ve))
     return -1;
+  const bool coupling = c->net.coupling;
   c->net = Network();   // a network refers to sources by index: set it again after the sources
   c->net.h_enth0 = ve;
+  c->net.h_cell.assign(vc.begin(), vc.begin() + n);
+  c->net.coupling = coupling;
   return 0;
 }
 
@@ -1863,11 +1964,12 @@ int wai_set_source_network(wai_ctx* c, const int* rate_specified, const int* ent
   if (!c) return -2;
   Network& nw = c->net;
   const int n = c->src.n;
-  auto ctl = nw.h_ctl; auto e0 = nw.h_enth0;
-  if (nw.d_raw) (void)hipFree(nw.d_raw);
+  auto ctl = nw.h_ctl; auto e0 = nw.h_enth0; auto cells = nw.h_cell;
+  const bool coupling = nw.coupling;
+  nw.free_device();
   if (c->src.net) { (void)hipFree(c->src.net); c->src.net = nullptr; }
   nw = Network();
-  nw.h_ctl = ctl; nw.h_enth0 = e0;
+  nw.h_ctl = ctl; nw.h_enth0 = e0; nw.h_cell = cells; nw.coupling = coupling;
   if (n_groups <= 0 && n_reinj <= 0) return 0;
   if (c->comm && c->comm->nranks > 1) { c->err = "source networks across ranks are not supported"; return -2; }
   if (int e = network_build(nw, n, rate_specified, enthalpy_specified, n_groups, grp_ptr, grp_in_kind, grp_in, grp_scaling,
@@ -1877,6 +1979,34 @@ int wai_set_source_network(wai_ctx* c, const int* rate_specified, const int* ent
   if (dev_alloc(c, &nw.d_raw, 2 * (size_t)n) || dev_alloc(c, &c->src.net, 2 * (size_t)n)) return -1;
   HIPCHK(c, hipMemset(c->src.net, 0, sizeof(double) * 2 * n));
   nw.on = true;
+  // the cells whose equations and unknowns the network ties together: every source a group, a reinjector
+  // input, output or overflow names (source_network.F90:359-498 walks the same lists)
+  {
+    std::vector<char> in_net((size_t)n, 0);
+    auto mark = [&](const NetRef& r) { if (r.kind == 1 && r.index >= 0 && r.index < n) in_net[r.index] = 1; };
+    for (const NetGroup& g : nw.groups) for (const NetRef& r : g.in) mark(r);
+    for (const NetReinjector& r : nw.reinjectors) { mark(r.in); mark(r.overflow); for (const NetOutput& o : r.out) mark(o.out); }
+    for (int i = 0; i < n && i < (int)nw.h_cell.size(); i++) if (in_net[i]) nw.cp_cells.push_back(nw.h_cell[i]);
+    std::sort(nw.cp_cells.begin(), nw.cp_cells.end());
+    nw.cp_cells.erase(std::unique(nw.cp_cells.begin(), nw.cp_cells.end()), nw.cp_cells.end());
+  }
+  return 0;
+}
+
+int wai_set_network_couplings(wai_ctx* c, int on) {
+  if (!c) return -2;
+  c->net.coupling = on != 0;
+  if (!on) c->net.cp_valid = false;
+  return 0;
+}
+
+int wai_get_network_couplings(wai_ctx* c, int* n_cells, int* cells, double* values) {
+  if (!c || !n_cells) return -2;
+  const Network& nw = c->net;
+  const int m = (nw.on && nw.coupling && nw.cp_valid) ? (int)nw.cp_cells.size() : 0;
+  *n_cells = m;
+  if (cells) for (int i = 0; i < m; i++) cells[i] = nw.cp_cells[i];
+  if (values && m) std::memcpy(values, nw.h_cp_val.data(), sizeof(double) * nw.h_cp_val.size());
   return 0;
 }
 // The same network pass without a context or a device (host logic only; tests): the sources' own rates
@@ -2212,6 +2342,7 @@ int wai_jacobian_set_values(wai_ctx* c, const double* val) {
   (void)hipFree(tmp);
   HIPCHK(c, e);
   c->ilu.factored = false;
+  c->net.cp_valid = false;   // values from outside: the network's blocks of the last wai_jacobian no longer belong
   return 0;
 }
 
@@ -2224,7 +2355,7 @@ int wai_spmv(wai_ctx* c, const double* x, double* y) {
   if (yo.out_only(y, c->ks.n, 1)) return -1;
   {
     Prof p(c, KC_SPMV);
-    launch_spmv(c, xd, yo.dev);
+    apply_operator(c, xd, yo.dev);
   }
   return yo.back();
 }

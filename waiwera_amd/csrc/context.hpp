@@ -87,6 +87,26 @@ struct Network {
   std::vector<char> is_out;                        // sources a reinjector feeds (last pass)
   std::vector<SrcCtl> h_ctl;                       // host copy of the control records (separators)
   double* d_raw = nullptr;                         // device scratch: raw rates and enthalpies, 2 n
+  // Jacobian couplings through the network (flow_simulation_modify_jacobian, src/flow_simulation.F90:3023-3084,
+  // dependencies of src/source_network.F90:359-498): blocks E[i][j] = d R(cell i) / d y(cell j) *through the
+  // network pass* for the cells of the network's sources (the reference inserts the outer product of its
+  // dependency rows and columns; pairs without a dependence difference to exact zeros), by the FD rule of
+  // the Jacobian.  The operator is A + E; the preconditioner is built from A.
+  std::vector<int> h_cell;                         // cell of every source
+  bool coupling = true;                            // wai_set_network_couplings
+  bool cp_valid = false;                           // E belongs to the Jacobian in force and has a nonzero entry
+  std::vector<int> cp_cells;                       // distinct cells of the network's sources, ascending
+  std::vector<double> h_cp_val;                    // [m][m][bs][bs] row-major, m = cp_cells.size()
+  int* d_cp_cells = nullptr;
+  double *d_cp_val = nullptr, *d_cp_f = nullptr, *d_cp_g = nullptr;
+  void free_device() {
+    if (d_raw) (void)hipFree(d_raw);
+    if (d_cp_cells) (void)hipFree(d_cp_cells);
+    if (d_cp_val) (void)hipFree(d_cp_val);
+    if (d_cp_f) (void)hipFree(d_cp_f);
+    if (d_cp_g) (void)hipFree(d_cp_g);
+    d_raw = d_cp_val = d_cp_f = d_cp_g = nullptr; d_cp_cells = nullptr;
+  }
 };
 
 // Block matrix in HBM: block-ELL, slot-major struct-of-arrays ("SELL" with one slice):

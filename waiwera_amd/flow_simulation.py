@@ -110,6 +110,22 @@ class FlowSimulation:
         self._chk(LIB.wai_get_source_network(self.h, G.ctypes.data_as(_lib.pd), R.ctypes.data_as(_lib.pd)), "get_source_network")
         return G[:ng], R[:nr]
 
+    def set_network_couplings(self, on=True):
+        """the network's Jacobian blocks (flow_simulation_modify_jacobian, flow_simulation.F90:3023-3084) on / off"""
+        self._chk(LIB.wai_set_network_couplings(self.h, 1 if on else 0), "set_network_couplings")
+
+    def network_couplings(self):
+        """(cells (m,), E (m, m, bs, bs)): d R(cell i) / d y(cell j) through the network pass, of the last
+        wai_jacobian (wai_get_network_couplings); m = 0 without a network or when E vanishes"""
+        m = C.c_int(0)
+        self._chk(LIB.wai_get_network_couplings(self.h, C.byref(m), None, None), "get_network_couplings")
+        bs = self.num_primary_variables
+        cells, E = np.zeros(m.value, dtype=np.int32), np.zeros((m.value, m.value, bs, bs))
+        if m.value:
+            self._chk(LIB.wai_get_network_couplings(self.h, C.byref(m), cells.ctypes.data_as(_lib.pi),
+                                                    E.ctypes.data_as(_lib.pd)), "get_network_couplings")
+        return cells, E
+
     def separator_enthalpies(self, pressure):
         hf, hg = C.c_double(0.0), C.c_double(0.0)
         self._chk(LIB.wai_separator_enthalpies(self.h, pressure, C.byref(hf), C.byref(hg)), "separator_enthalpies")

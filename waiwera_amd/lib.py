@@ -119,6 +119,8 @@ def _load():
         "wai_network_evaluate": (i32, [i32, pd, pd, pd, pi, pi, i32, pi, pi, pi, pi, pi, pd, pd, i32, pi, pi, pi, pi, pi, pi, pd, pd,
                                        pd, pi, pi, pd, pd, pd]),
         "wai_get_source_network": (i32, [vp, pd, pd]),
+        "wai_set_network_couplings": (i32, [vp, i32]),
+        "wai_get_network_couplings": (i32, [vp, pi, pi, pd]),
         "wai_separator_enthalpies": (i32, [vp, d, pd, pd]),
         "wai_set_regions": (i32, [vp, pi]),
         "wai_get_regions": (i32, [vp, pi]),
