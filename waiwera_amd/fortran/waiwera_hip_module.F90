@@ -114,6 +114,38 @@ module waiwera_hip_module
        type(c_ptr), value :: ctx
        real(c_double), intent(out) :: rate(*), enthalpy(*)
      end function wai_get_source_rates
+     ! source network: groups and reinjectors (src/source_network_group.F90, source_network_reinjector.F90;
+     ! set-up of src/source_setup.F90) as flat arrays, node references (kind, index); see include/waiwera_hip.h
+     integer(c_int) function wai_set_source_network(ctx, rate_specified, enthalpy_specified, n_groups, grp_ptr, &
+          grp_in_kind, grp_in, grp_scaling, grp_limit_type, grp_limit, grp_sep, n_reinjectors, rj_in_kind, rj_in, &
+          rj_out_ptr, out_flow, out_kind, out_node, out_rate, out_proportion, out_enthalpy, rj_overflow_kind, &
+          rj_overflow) bind(c, name = "wai_set_source_network")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n_groups, n_reinjectors
+       ! c_loc of integer(c_int) / real(c_double) arrays, c_null_ptr where the header allows NULL
+       type(c_ptr), value :: rate_specified, enthalpy_specified, grp_ptr, grp_in_kind, grp_in, grp_scaling, &
+            grp_limit_type, grp_limit, grp_sep, rj_in_kind, rj_in, rj_out_ptr, out_flow, out_kind, out_node, &
+            out_rate, out_proportion, out_enthalpy, rj_overflow_kind, rj_overflow
+     end function wai_set_source_network
+     integer(c_int) function wai_get_source_network(ctx, groups, reinjectors) bind(c, name = "wai_get_source_network")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: groups(6, *), reinjectors(8, *)
+     end function wai_get_source_network
+     ! the Jacobian blocks the network adds between cells (flow_simulation_modify_jacobian,
+     ! src/flow_simulation.F90:3023-3084): on by default; values(bs, bs, m, m) in Fortran order = [k][r][col][row]
+     integer(c_int) function wai_set_network_couplings(ctx, on) bind(c, name = "wai_set_network_couplings")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: on
+     end function wai_set_network_couplings
+     integer(c_int) function wai_get_network_couplings(ctx, n_cells, cells, values) bind(c, name = "wai_get_network_couplings")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), intent(out) :: n_cells
+       type(c_ptr), value :: cells, values   ! c_loc of integer(c_int) / real(c_double) arrays, or c_null_ptr
+     end function wai_get_network_couplings
      integer(c_int) function wai_set_regions(ctx, region) bind(c, name = "wai_set_regions")
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx
@@ -306,6 +338,7 @@ module waiwera_hip_module
   end type hip_flow_simulation_type
 
   public :: wai_set_tracers, wai_set_tracer_bc, wai_set_tracer_injection, wai_set_aux_solver
+  public :: wai_set_source_network, wai_get_source_network, wai_set_network_couplings, wai_get_network_couplings
   public :: wai_default_eos, wai_default_opts, wai_set_bc, wai_set_sources, wai_update_sources, wai_set_source_controls, wai_get_source_rates, wai_separator_enthalpies, wai_set_regions, &
        wai_get_regions, wai_jacobian_nnzb, wai_jacobian_pattern, wai_jacobian_get_values
 
