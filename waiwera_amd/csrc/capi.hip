@@ -616,7 +616,8 @@ int network_update(wai_ctx* c) {
 // (k_jacobian), and the rest, E = dR/dy *through the network pass*, is differenced separately on the cells
 // of the network's sources: for every such cell j and primary k, with y_jk + h (the same h as A's
 // columns), E[:, j][:, k] = (R(network pass redone) - R(factors held)) / h on the rows of those cells.
-// Two residual launches and two host passes per column: networks tie tens of cells together, not millions.
+// Two residual launches on the network's rows alone (k_residual's row list: the same code path per row, so
+// the same bits as a full sweep) and three host passes per column: the cost does not grow with the mesh.
 __global__ void k_gather_rows(int m, int bs, const int* __restrict__ cells, const double* __restrict__ f,
                               double* __restrict__ out) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -669,10 +670,10 @@ int network_couplings(wai_ctx* c, double dt, double* y, const double* lhs_old) {
       if (std::fabs(dx) < c->opts.fd_umin) dx = dx >= 0.0 ? c->opts.fd_umin : -c->opts.fd_umin;
       const double h = dx * c->opts.fd_eps;
       if (set_y(cell, k, yc[k] + h)) return -1;
-      launch_residual(c, dt, lhs_old, nw.d_cp_f, nullptr, nullptr);                 // factors held
+      launch_residual(c, dt, lhs_old, nw.d_cp_f, nullptr, nullptr, nw.d_cp_cells, m);   // factors held; the network's rows alone
       hipLaunchKernelGGL(k_gather_rows, grid, 64, 0, c->stream, m, bs, nw.d_cp_cells, nw.d_cp_f, nw.d_cp_g);
       if (network_update(c)) return -1;
-      launch_residual(c, dt, lhs_old, nw.d_cp_f, nullptr, nullptr);                 // network pass redone
+      launch_residual(c, dt, lhs_old, nw.d_cp_f, nullptr, nullptr, nw.d_cp_cells, m);   // network pass redone
       hipLaunchKernelGGL(k_gather_rows, grid, 64, 0, c->stream, m, bs, nw.d_cp_cells, nw.d_cp_f, nw.d_cp_g + mb);
       HIPCHK(c, hipMemcpyAsync(g.data(), nw.d_cp_g, sizeof(double) * 2 * mb, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -296,7 +296,7 @@ struct wai_ctx {
 namespace wai {
 int launch_eos(wai_ctx* c, const double* y, int first, int count, bool perturbed);
 int launch_residual(wai_ctx* c, double dt, const double* lhs_old, double* f, double* lhs_out,
-                    double* rhs_out);
+                    double* rhs_out, const int* only = nullptr, int n_only = 0);   // only: these rows alone (device list)
 int launch_jacobian(wai_ctx* c, double dt, const double* lhs_old);
 int launch_transitions(wai_ctx* c, const double* y_old, double* search, double* y);
 // tracer system of tf.it on the flow Jacobian's pattern: values -> c->tr.val, rhs -> b

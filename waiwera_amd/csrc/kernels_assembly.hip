@@ -156,10 +156,18 @@ template <int KIND>
 __global__ __launch_bounds__(TPB) void k_residual(MeshView m, const double* __restrict__ flu,
                                                   size_t stride, ResForm rf,
                                                   double* __restrict__ f, double* __restrict__ lhs_out,
-                                                  double* __restrict__ rhs_out) {
+                                                  double* __restrict__ rhs_out,
+                                                  const int* __restrict__ only, int n_only) {
   using E = EosT<KIND>;
-  const int c = xcd_cell(m.n_owned);
-  if (c < 0) return;
+  int c;
+  if (only) {   // the listed rows alone (the source network's cells, network_couplings in capi.hip)
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= n_only) return;
+    c = only[t];
+  } else {
+    c = xcd_cell(m.n_owned);
+    if (c < 0) return;
+  }
   CellState<KIND> own;
   RockState rown;
   load_state<KIND>(flu, stride, c, own);
@@ -903,11 +911,11 @@ static ResForm res_form_of(const wai_ctx* c, double dt, const double* lhs_old) {
 }
 
 int launch_residual(wai_ctx* c, double dt, const double* lhs_old, double* f, double* lhs_out,
-                    double* rhs_out) {
+                    double* rhs_out, const int* only, int n_only) {
   const MeshView m = view(c);
   const size_t stride = c->mesh.n_local;
-  WAI_BY_EOS(c, k_residual, grid8_for(m.n_owned), m, c->flu, stride, res_form_of(c, dt, lhs_old), f,
-             lhs_out, rhs_out);
+  WAI_BY_EOS(c, k_residual, only ? grid_for(n_only) : grid8_for(m.n_owned), m, c->flu, stride,
+             res_form_of(c, dt, lhs_old), f, lhs_out, rhs_out, only, n_only);
   return 0;
 }
 
