@@ -282,9 +282,10 @@ int wai_residual(wai_ctx *ctx, double t, double dt, const double *y, const doubl
 int wai_jacobian(wai_ctx *ctx, double t, double dt, const double *y, const double *lhs_old);
 int wai_jacobian_nnzb(wai_ctx *ctx);
 int wai_jacobian_pattern(wai_ctx *ctx, int *rowptr, int *colidx);  /* ode_setup_jacobian, ode.F90:266-287 */
-int wai_jacobian_get_values(wai_ctx *ctx, double *val);            /* bs*bs row-major blocks */
-int wai_jacobian_set_values(wai_ctx *ctx, const double *val);
-/* MatMult_SeqBAIJ / MPIBAIJ: y = J x (x haloed internally) */
+int wai_jacobian_get_values(wai_ctx *ctx, double *val);            /* bs*bs row-major blocks (the 7-point part A) */
+int wai_jacobian_set_values(wai_ctx *ctx, const double *val);      /* drops the source network's blocks of the last wai_jacobian */
+/* MatMult_SeqBAIJ / MPIBAIJ: y = J x (x haloed internally); J = A + the source network's blocks
+ * (wai_get_network_couplings) when wai_jacobian assembled any */
 int wai_spmv(wai_ctx *ctx, const double *x, double *y);
 /* PCSetUp / PCApply of bjacobi | asm + ilu(0), or none (:1668-1669,1745-1757,1789-1834) */
 int wai_pc_setup(wai_ctx *ctx);
