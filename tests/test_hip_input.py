@@ -288,6 +288,22 @@ def test_network_couplings_are_the_literal_fd_columns(name, geometry, steps):
         for j, c in enumerate(cells):
             ref[r * bs:(r + 1) * bs] += E[i, j] @ x[c * bs:(c + 1) * bs]
     assert np.abs(ax - ref).max() <= 1e-12 * np.abs(ref).max()
+    # ... and what they solve: x of wai_ksp_solve satisfies (A + E) x = b, with the host-assembled A + E
+    import scipy.sparse as sp
+    M = sp.bsr_matrix((A, ci, rp), shape=(n, n)).tolil()
+    for i, r in enumerate(cells):
+        for j, c in enumerate(cells):
+            M[r * bs:(r + 1) * bs, c * bs:(c + 1) * bs] += E[i, j]
+    M = M.tocsr()
+    b = M @ x
+    xs = np.zeros(n)
+    assert ode.pc_setup() == 0
+    its, reason, rn = ode.ksp_solve(b, xs)
+    assert reason > 0, (its, reason, rn)
+    res = np.abs(M @ xs - b).max() / np.abs(b).max()
+    res_without_E = np.abs(sp.bsr_matrix((A, ci, rp), shape=(n, n)) @ xs - b).max() / np.abs(b).max()
+    print(name, "krylov its", its, "residual of (A+E)x=b", res, "of Ax=b", res_without_E)
+    assert res < 1e-3 and res_without_E > 10.0 * res
     ode.set_network_couplings(False)
     assert ode.residual(t + dt, dt, y, L, f0) == 0
     assert ode.jacobian(t + dt, dt, y, L) == 0
