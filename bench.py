@@ -181,7 +181,7 @@ def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0):
     # one thread per core, spread over the sockets (read by libgomp when it is first loaded)
     os.environ.setdefault("OMP_PROC_BIND", "spread")
     os.environ.setdefault("OMP_PLACES", "cores")
-    from tests import oracle_lib as ol
+    from oracle import binding as ol
     L = ol.load(so)
     try:
         gomp = C.CDLL("libgomp.so.1")
@@ -339,7 +339,7 @@ def main():
     from waiwera_amd import lib as wl
     from waiwera_amd import mesh as M
     from waiwera_amd.flow_simulation import FlowSimulation
-    from tests.cases import make_case, scaled
+    from waiwera_amd.cases import make_case, scaled
 
     t_setup = time.time()
     cfg = dict(CONFIGS[a.config])

@@ -228,7 +228,7 @@ def test_source_networks_against_autough2(name, geometry):
 
 
 @pytest.mark.parametrize("name,geometry,steps", [("makeup_uniform", "gmakeup.dat", 3), ("reinjection", "greinjection.dat", 3)])
-def test_network_couplings_are_the_literal_fd_columns(name, geometry, steps):
+def test_network_couplings_are_the_literal_fd_columns(name, geometry, steps, monkeypatch):
     """flow_simulation_modify_jacobian (flow_simulation.F90:3023-3084) widens the Jacobian by the network's
     dependencies and MatFDColoring differences the whole residual function into it.  Here A (7-point,
     network factors held) + E (wai_get_network_couplings) must be exactly that: every column of a network
@@ -304,6 +304,22 @@ def test_network_couplings_are_the_literal_fd_columns(name, geometry, steps):
     res_without_E = np.abs(sp.bsr_matrix((A, ci, rp), shape=(n, n)) @ xs - b).max() / np.abs(b).max()
     print(name, "krylov its", its, "residual of (A+E)x=b", res, "of Ax=b", res_without_E)
     assert res < 1e-3 and res_without_E > 10.0 * res
+    # the same under block Jacobi (the C / Fortran ABI default), whose fused kernels then run behind the
+    # unfused operator (A + E) x: BiCGStab's inner products must pair the result with x, not with (A + E) x --
+    # with the reductions where KSPSolve_BCGS has them and in the merged (multi-rank) form
+    for merged in (False, True):
+        if merged:
+            monkeypatch.setenv("WAI_BCGS_MERGED", "1")
+        ode.set_opts(pc_type="bjacobi", ksp_rtol=1e-8)
+        assert ode.pc_setup() == 0
+        xs[:] = 0.0
+        its_b, reason, rn = ode.ksp_solve(b, xs)
+        assert reason > 0, (merged, its_b, reason, rn)
+        res_b = np.abs(M @ xs - b).max() / np.abs(b).max()
+        print(name, "bjacobi", "merged" if merged else "petsc order", "krylov its", its_b, "residual", res_b)
+        assert res_b < 1e-5, (merged, res_b)
+    monkeypatch.delenv("WAI_BCGS_MERGED")
+    ode.set_opts(pc_type="asm", ksp_rtol=1e-5)
     ode.set_network_couplings(False)
     assert ode.residual(t + dt, dt, y, L, f0) == 0
     assert ode.jacobian(t + dt, dt, y, L) == 0

@@ -198,3 +198,20 @@ def test_lgmres(oracle):
     assert reason > 0 and oreason > 0
     assert relmax(x, xo) < 1e-7 and abs(its - oits) <= max(3, oits // 8)
     sim.destroy(); osim.close()
+
+
+@pytest.mark.timeout(120)
+def test_lgmres_with_a_tiny_restart_and_the_restart_cap(oracle):
+    """restart <= 2 leaves LGMRES no Krylov direction beside its two error approximations: it runs with
+    one (restart 3) instead of spinning; a restart above the basis cap is refused, not silently cut"""
+    lm, sim, osim, J, f = system(oracle, "we", (8, 8, 6), (4, 4, 2))
+    n = sim.num_dof
+    for restart in (1, 2, 3):
+        sim.set_opts(ksp_type="lgmres", gmres_restart=restart, ksp_rtol=1e-6, ksp_max_its=400)
+        x = np.zeros(n)
+        its, reason, rn = sim.ksp_solve(f, x)
+        assert reason != 0 and 0 < its <= 400, (restart, its, reason)
+    from waiwera_amd.lib import WaiError
+    with pytest.raises(WaiError, match="restart"):
+        sim.set_opts(ksp_type="gmres", gmres_restart=41)
+    sim.destroy(); osim.close()

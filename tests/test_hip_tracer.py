@@ -112,6 +112,48 @@ def test_tracer_solve_parity(FS, oracle, eos, phases):
     sim.destroy(); osim.close()
 
 
+@pytest.mark.parametrize("eos", ["we", "wce"])
+def test_tracer_solve_under_asm_on_a_block_system(FS, eos):
+    """PCASM is the input front end's default; the scalar tracer systems then need their own extended
+    system (block size 1) beside the flow's (block size 2 / 3): same solutions as under block Jacobi, no
+    more iterations than block Jacobi needs (overlap only helps), and the flow solve afterwards still
+    runs on its own extended system"""
+    g, lm, prim, region = make_case(eos=eos, dims=(8, 7, 9), brick=(4, 7, 3), lens=(eos == "we"))
+    y = scaled(prim, region, eos).ravel().copy()
+    nt = 2
+    rng = np.random.default_rng(5)
+    bc = rng.uniform(0, 1e-3, (lm.n_bc, nt))
+    inj = np.where(np.asarray(lm.src_rate)[:, None] > 0, rng.uniform(0, 1e-2, (lm.n_src, nt)), 0.0)
+    n = lm.n_owned * nt
+    X0 = rng.uniform(0, 1e-3, n)
+    dt = 5.0e2 if eos == "wce" else 1.0e4
+    out = {}
+    for pc in ("bjacobi", "asm"):
+        sim = FS(lm, eos=eos)
+        sim.set_regions(region)
+        sim.set_tracers([0, 1], [1e-8, 1e-7], [0.0, 0.0], [1e-6, 2e-5], bc=bc, injection=inj)
+        sim.set_aux_solver("bcgs", rtol=1e-12)
+        sim.set_opts(pc_type=pc, ksp_rtol=1e-10, ftol_rel=1e-9)
+        yg = y.copy()
+        assert sim.pre_eval(0.0, yg) == 0
+        Al = np.zeros(n)
+        sim.aux_lhs(0.0, None, Al)
+        reason, nits, kits = sim.timestep(0.0, dt, yg)
+        assert reason > 0
+        X, new = X0.copy(), np.zeros(n)
+        r, its = sim.aux_solve("beuler", dt, 1.0, Al * X0, None, X, new)
+        assert r > 0
+        reason2, nits2, kits2 = sim.timestep(dt, dt, yg)   # the flow solver again, on its own preconditioner
+        assert reason2 > 0
+        out[pc] = (X, its, yg, kits2)
+        sim.destroy()
+    print(eos, "tracer BiCGStab iterations: bjacobi", out["bjacobi"][1], "asm", out["asm"][1],
+          "; next flow step's Krylov iterations", out["bjacobi"][3], out["asm"][3])
+    assert relmax(out["asm"][0], out["bjacobi"][0]) < 1e-8
+    assert out["asm"][1] <= out["bjacobi"][1], (out["asm"][1], out["bjacobi"][1])
+    assert relmax(out["asm"][2], out["bjacobi"][2]) < 1e-7
+
+
 def test_one_cell_decay_benchmark_on_gpu(FS, oracle):
     """decay.json: BDF2, 20 steps of one day, X0 = 1e-3, decay 0 / 1e-6 / Arrhenius(2 kJ/mol) at
     60 degC -- X0 exp(-k t) within the benchmark's 1e-2 relative tolerance at every step"""

@@ -31,6 +31,11 @@ enum { S_RHO = 0, S_RHOOLD = 1, S_ALPHA = 2, S_OMEGA = 3, S_BETA = 4, S_D1 = 5, 
 constexpr int NSLOTS = 64;
 constexpr int NSCAL = 128;
 
+// GMRES / LGMRES basis: restart vectors, at least 3 (LGMRES: one Krylov direction + 2 error approximations),
+// at most MAX_RESTART (the Hessenberg column travels through the scalar / partial-sum slots S_H ..)
+constexpr int MAX_RESTART = 40;
+int basis_vectors(int restart) { return std::max(3, std::min(restart > 0 ? restart : 30, MAX_RESTART)); }
+
 template <typename T>
 int dev_alloc(wai_ctx* c, T** p, size_t n) {
   *p = nullptr;
@@ -258,8 +263,7 @@ void free_schedule(IluSchedule& s) {
   hipFree(s.row_uoff); hipFree(s.sub_int); hipFree(s.sub_bnd); hipFree(s.ord_f); hipFree(s.ord_b);
   s = IluSchedule();
 }
-void free_asm(wai_ctx* c) {
-  AsmSystem& a = c->as;
+void free_asm(AsmSystem& a) {
   free_schedule(a.sched);
   hipFree(a.E.col); hipFree(a.E.val); hipFree(a.ext_row); hipFree(a.gmap); hipFree(a.r_ext);
   a = AsmSystem();
@@ -271,7 +275,7 @@ void free_asm(wai_ctx* c) {
 // subdomain index sets).
 int build_asm(wai_ctx* c, int overlap) {
   AsmSystem& a = c->as;
-  free_asm(c);
+  free_asm(a);
   const Bcsr& J = c->J;
   const int N = J.n, np = J.bs;
   std::vector<int> sub((size_t)c->ilu.nsub + 1);
@@ -827,7 +831,7 @@ int do_pc_setup(wai_ctx* c) {
     Prof p(c, KC_PC_SETUP);
     if (c->opts.pc_type == WAI_PC_ASM) {
       const int ov = c->opts.asm_overlap > 0 ? c->opts.asm_overlap : 1;
-      if (c->as.overlap != ov) { if (int e = build_asm(c, ov)) return e < 0 ? -1 : e; }
+      if (c->as.overlap != ov || c->as.E.bs != c->J.bs) { if (int e = build_asm(c, ov)) return e < 0 ? -1 : e; }
       launch_asm_gather_matrix(c);
       if (launch_ilu_factor_on(c, c->as.E, c->as.sched)) return -1;
       c->ilu.factored = true;
@@ -854,7 +858,15 @@ int pc_dots(wai_ctx* c, int dot_mode, const double* x, const double* z, const do
 
 // z = B^-1 r; dot_mode as launch_pc, with `x` the partner of mode 2
 int pc_solve(wai_ctx* c, const double* r, double* z, int dot_mode, const double* x, const double* aux) {
-  if (pc_fused(c)) return launch_pc(c, false, r, z, dot_mode, dot_mode == 2 ? x : aux);
+  if (pc_fused(c)) {
+    // the fused kernels take the partner of modes 2 and 4 from their own input vector (the x of
+    // z = B^-1 A x); here the input is r = (A + E) x, so those inner products are reduced separately
+    if (dot_mode == 2 || dot_mode == 4) {
+      if (launch_pc(c, false, r, z, 0, nullptr)) return -1;
+      return pc_dots(c, dot_mode, x, z, aux);
+    }
+    return launch_pc(c, false, r, z, dot_mode, aux);
+  }
   const size_t n = (size_t)c->ks.n;
   if (c->opts.pc_type == WAI_PC_NONE) {
     if (z != r) vec_copy(c, z, r, n);
@@ -1103,7 +1115,9 @@ int ksp_gmres(wai_ctx* c, const double* b, double* x, int* its, int* reason, dou
 int ksp_lgmres(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
   Krylov& k = c->ks;
   constexpr int AUG = 2;
-  const int n = k.n, mt = std::min(std::max(c->opts.gmres_restart, AUG + 1), k.basis_m), mk = mt - AUG, m = mt;
+  // restart = Krylov directions + AUG error approximations: at least one direction (wai_set_opts / wai_ctx_create
+  // size the basis for restart >= AUG + 1 and refuse a restart beyond the basis cap)
+  const int n = k.n, mt = std::max(std::min(std::max(c->opts.gmres_restart, AUG + 1), k.basis_m), AUG + 1), mk = mt - AUG, m = mt;
   double* Z = k.basis + (size_t)(mt + 1) * k.nl;          // Z[0] most recent
   double* dx = k.basis + (size_t)(mt + 1 + AUG) * k.nl;
   int naug = 0;
@@ -1415,7 +1429,8 @@ void free_all(wai_ctx* c) {
   F(c->src.cell); F(c->src.comp); F(c->src.next); F(c->src.rate); F(c->src.enth); F(c->src.ctl); F(c->src.net); c->net.free_device();
   F(c->J.rowptr); F(c->J.col); F(c->J.val);
   free_schedule(c->ilu);
-  free_asm(c);
+  free_asm(c->as);
+  free_asm(c->as_aux);
   F(c->lu.inv); F(c->lu.inv_ptr);
   Krylov& k = c->ks;
   F(k.R); F(k.RP); F(k.P); F(k.V); F(k.S); F(k.T); F(k.tmp); F(k.X); F(k.basis); F(k.bl); F(k.partials); F(k.scal);
@@ -1651,7 +1666,8 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
     if (dev_alloc(c, p, nl + 16)) return -1;
     HIPCHK(c, hipMemset(*p, 0, (nl + 16) * sizeof(double)));
   }
-  k.basis_m = std::max(1, std::min(c->opts.gmres_restart > 0 ? c->opts.gmres_restart : 30, 40));
+  if (c->opts.gmres_restart > MAX_RESTART) { c->err = "gmres restart above 40 is not supported"; return -2; }
+  k.basis_m = basis_vectors(c->opts.gmres_restart);
   if (c->opts.ksp_type == WAI_KSP_GMRES || c->opts.ksp_type == WAI_KSP_LGMRES) {
     if (dev_alloc(c, &k.basis, (size_t)(k.basis_m + 4) * nl)) return -1;
     HIPCHK(c, hipMemset(k.basis, 0, (size_t)(k.basis_m + 4) * nl * sizeof(double)));
@@ -1691,10 +1707,11 @@ int wai_set_opts(wai_ctx* c, const wai_solver_opts* o) {
   const int old_type = c->opts.ksp_type;
   if (o->pc_type < WAI_PC_BJACOBI || o->pc_type > WAI_PC_LU) { c->err = "unknown preconditioner type"; return -2; }
   if (o->pc_type != c->opts.pc_type || o->asm_overlap != c->opts.asm_overlap) c->ilu.factored = false;
+  if (o->gmres_restart > MAX_RESTART) { c->err = "gmres restart above 40 is not supported"; return -2; }
   c->opts = *o;
   (void)old_type;
   if (o->ksp_type == WAI_KSP_GMRES || o->ksp_type == WAI_KSP_LGMRES) {
-    const int want = std::max(1, std::min(o->gmres_restart > 0 ? o->gmres_restart : 30, 40));
+    const int want = basis_vectors(o->gmres_restart);
     if (!c->ks.basis || c->ks.basis_m < want) {
       if (c->ks.basis) (void)hipFree(c->ks.basis);
       c->ks.basis_m = want;
@@ -2435,6 +2452,7 @@ int wai_set_tracer_injection(wai_ctx* c, const double* rate) {
 int wai_set_aux_solver(wai_ctx* c, int ksp_type, int gmres_restart, double rtol, double atol, int max_its) {
   if (!c) return -2;
   if (ksp_type != WAI_KSP_BCGS && ksp_type != WAI_KSP_GMRES) { c->err = "unknown KSP type"; return -1; }
+  if (gmres_restart > MAX_RESTART) { c->err = "gmres restart above 40 is not supported"; return -1; }
   c->tr.ksp_type = ksp_type;
   if (gmres_restart > 0) c->tr.restart = gmres_restart;
   if (rtol > 0.0) c->tr.rtol = rtol;
@@ -2460,7 +2478,12 @@ struct AuxScope {
   wai_ctx* c;
   int np, n, nl, bs, ksp_type, restart, max_its;
   double* val; double rtol, atol;
+  bool cp_valid;
   explicit AuxScope(wai_ctx* c_) : c(c_) {
+    // the network's coupling blocks E belong to the flow Jacobian, and the extended ASM system is laid
+    // out for its block size: the scalar systems get their own (built on first use)
+    cp_valid = c->net.cp_valid; c->net.cp_valid = false;
+    std::swap(c->as, c->as_aux);
     np = c->np; n = c->ks.n; nl = c->ks.nl; bs = c->J.bs; val = c->J.val;
     ksp_type = c->opts.ksp_type; restart = c->opts.gmres_restart; max_its = c->opts.ksp_max_its;
     rtol = c->opts.ksp_rtol; atol = c->opts.ksp_atol;
@@ -2473,6 +2496,8 @@ struct AuxScope {
     c->np = np; c->ks.n = n; c->ks.nl = nl; c->J.bs = bs; c->J.val = val;
     c->opts.ksp_type = ksp_type; c->opts.gmres_restart = restart; c->opts.ksp_max_its = max_its;
     c->opts.ksp_rtol = rtol; c->opts.ksp_atol = atol;
+    c->net.cp_valid = cp_valid;
+    std::swap(c->as, c->as_aux);
     c->ilu.factored = false;  // the factor buffers now hold a tracer system's factor
   }
 };

@@ -244,6 +244,7 @@ struct wai_ctx {
   wai::Bcsr J;
   wai::IluSchedule ilu;
   wai::AsmSystem as;
+  wai::AsmSystem as_aux;   // the extended system of the scalar (tracer) problems, block size 1 (AuxScope swaps it in)
   wai::LuBlocks lu;
   wai::Krylov ks;
   wai::Tracers tr;

@@ -184,6 +184,10 @@ def network_spec(inp, interval, separator_enthalpies=None):
             raise NotImplementedError("separators with more than 4 stages")
         return [separator_enthalpies(float(q)) for q in ps]
     FLOW = {"total": 0, "water": 1, "steam": 2}
+    # rate_specified: a "rate" in the input (source_setup.F90:2087-2118, get_initial_rate) -- or a deliverability
+    # (:2911) or recharge / injectivity (:3081) control, whose set-up sets source%rate_specified = PETSC_TRUE; the
+    # control's rate then becomes the specified rate with every source%set_rate (source.F90:276-288), so a
+    # reinjector output into such a well is capped by what the control gives (source.F90:292-303)
     spec = dict(rate_specified=[int("rate" in s or any(k in s for k in ("deliverability", "recharge", "injectivity")))
                                 for s in sources],
                 enthalpy_specified=[int("enthalpy" in s) for s in sources], groups=[], reinjectors=[])
