@@ -11,15 +11,22 @@ eos wce (3 x 3 blocks); c5 100^3 fracture cells + 1 MINC matrix level, eos wce.
 
 A "step" is one Newton iteration of a backward-Euler time step: FD Jacobian assembly,
 preconditioner set-up, BiCGStab solve to rtol 1e-5, full-step line search with phase transitions,
-and the new residual (src/timestepper.F90:587-735).  Time steps follow the reference's controller
-with dt doubling after a converged step and dt * 0.2 after a failed one
-(src/timestepper.F90:1353-1375) from dt = 1e4 s.  The *measured window is fixed*: the first
+and the new residual (src/timestepper.F90:587-735).  Time steps follow the reference's adaptive controller
+(time.step.adapt, src/timestepper.F90:772-858, 1304-1476: dt x 2 after a step that converged in fewer than 5
+Newton iterations, unchanged after 5..8, dt x 0.2 after a failed one) from dt = 1e4 s; `--controller double`
+doubles after every converged step (rounds 1 and 2).  The *measured window is fixed*: the first
 `--lead` (3) accepted time steps are a lead-in outside all timing; warm-up and timed Newton steps
 walk through accepted time steps 3..7 of the trajectory (SURVEY.md section 8d "measure steps 3-7"),
 failed tries included, and start over from the saved state at the start of step 3 when they reach
 the end of step 7 -- so --warmup only moves the phase inside that cycle, not the part of the
 trajectory that is measured.  Total work is fixed as N grows (the mesh is split over the ranks):
 scaling = strong.
+
+    python bench.py --rank-share 8 [--config c3]    # one rank's share of the N-GPU run, on one GPU
+
+runs the 1/N sub-box of the config (c3 / 8 = 108^3, c4 / 4 = 86 x 86 x 170) with the N-rank brick tiling
+through the same protocol and reports what an iteration costs at that size: ms per Krylov iteration,
+launches per iteration, and the fused / vector-update split against the ideal (full-size time / N).
 """
 import argparse
 import json
@@ -51,8 +58,9 @@ def log(*a):
 class NewtonDriver:
     """PETSc-free restatement of the timestepper's step/retry protocol around wai_newton_step."""
 
-    def __init__(self, sim, y, dt0, torch):
+    def __init__(self, sim, y, dt0, torch, controller="adapt"):
         self.sim, self.y, self.torch = sim, y, torch
+        self.controller = controller
         n = sim.n_owned * sim.num_primary_variables
         self.lhs_old = torch.zeros(n, dtype=torch.float64, device=y.device)
         self.f = torch.zeros(n, dtype=torch.float64, device=y.device)
@@ -102,9 +110,12 @@ class NewtonDriver:
         self.it += 1
         rec = [self.nstep, self.dt, self.it, kits, reason, maxres, 0.0]
         self.log.append(rec)
-        if reason > 0:  # converged: next time step, doubled dt (synthetic schedule)
+        if reason > 0:  # converged: next time step
             self.t += self.dt
-            self.dt *= 2.0
+            # adaptor with the iteration monitor, band 5..8 (timestepper.F90:277-310, 1380-1476, defaults
+            # :1971-2007): fewer than 5 Newton iterations -> dt x 2; "double": after every converged step
+            if self.controller == "double" or self.it < 5:
+                self.dt *= 2.0
             self.nstep += 1
             self.tries = 0
             self.it = -1
@@ -130,28 +141,27 @@ def spmv_bytes(nnzb, n, bs):
 def pc_bytes(nnzb, n, bs):
     """Algorithmic bytes of one fused preconditioned-operator launch: the
     matrix once (blocks + int32 columns), the packed row descriptor, and three vectors (x read, z
-    written, aux read for the fused dot).  The inverted pivot blocks are only read when the
-    pivot-scaled rows are switched off (WAI_ILU_NOSCALE)."""
-    pivots = 8 * bs * bs if os.environ.get("WAI_ILU_NOSCALE") else 0
-    return nnzb * (8 * bs * bs + 4) + n * (pivots + 4 + 3 * 8 * bs)
+    written, aux read for the fused dot).  Pivot-scaled rows: no pivot blocks are read."""
+    return nnzb * (8 * bs * bs + 4) + n * (4 + 3 * 8 * bs)
 
 
 def traffic_from_profiles(cfg, dims, brick):
-    """HBM bytes per fused-kernel launch from the committed rocprofv3 PMC passes (profiles/), collected
-    and corrected as MI355X_MICROARCH.md prescribes; only valid for the mesh it was taken on."""
-    for name in ("pmc_traffic_r2_%s.json" % cfg, "pmc_traffic_r2.json", "pmc_traffic_r1.json"):
+    """(HBM bytes per fused-kernel launch, where from): read from the committed rocprofv3 PMC passes (profiles/;
+    collected and corrected as MI355X_MICROARCH.md prescribes, tools/pmc_traffic.py) -- counters cannot be collected
+    inside this run; only valid for the mesh and bricks they were taken on, None otherwise."""
+    for name in ("pmc_traffic_r3_%s.json" % cfg, "pmc_traffic_r2_%s.json" % cfg):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             try:
                 d = json.load(open(p))
                 if list(d.get("dims", [])) == list(dims) and list(d.get("brick", [])) == list(brick):
-                    return d.get("k_pc_hbm_bytes_per_launch")
+                    return d.get("k_pc_hbm_bytes_per_launch"), "profiles/%s (separate rocprofv3 --pmc passes of this command; not measured in this run)" % name
             except Exception:
                 return None
     return None
 
 
-def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0):
+def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0, gpu_state=None, minc=False, brick=None):
     """The oracle (CPU restatement of the reference's path, OpenMP) timed on the SAME mesh and the same
     state the timed window starts from -- one Newton step, piece by piece: unperturbed residual, FD
     Jacobian (per-row differencing, and the reference's coloured MatFDColoring sweep when it fits the
@@ -214,12 +224,41 @@ def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0):
     t0 = time.time()
     err, J = osim.jacobian(y, dt, lhs_old, f, mode=0)
     t_jac = time.time() - t0
-    t_col = None
+    # the checker at work: the device's residual and FD Jacobian of the same state against the oracle's,
+    # element by element (residual relative to its largest entry, Jacobian entries relative to the largest
+    # entry of their block row's equation, as tests/test_hip_parity.py compares them)
+    vs_oracle = None
+    if gpu_state is not None:
+        worst, worst_ulp = ol.jacobian_parity(gpu_state["J"], J, rp, ci, y, lhs_old, bs)
+        fg = gpu_state["f"]
+        vs_oracle = {"residual_vs_oracle": float(np.abs(fg - f).max() / np.abs(f).max()), "residual_tolerance": 1e-11,
+                     "jacobian_vs_oracle": worst, "jacobian_tolerance": 2e-5,
+                     # entries above the tolerance, in units of eps |L_i| / |h_j| (the rounding of the row's accumulation
+                     # term over the FD step): two correct residual evaluations may differ by a few of these
+                     "jacobian_worst_in_ulp_steps": worst_ulp, "jacobian_ulp_step_tolerance": 16.0, "cells": int(n)}
+    t_col, col_note = None, ""
     if time.time() - t_all + 14.0 * t_jac < budget_s:   # coloured FD: 1 + ncolors x bs full sweeps
         t0 = time.time()
         err, J2 = osim.jacobian(y, dt, lhs_old, f, mode=1)
         t_col = time.time() - t0
         del J2
+    elif brick is not None:
+        # does not fit the budget on this mesh: the coloured / per-row cost ratio measured on the 1 M-cell mesh of
+        # the same kind (C2's size; both sweeps are linear in the cell count) carries it over
+        from waiwera_amd.cases import make_case, scaled as scaled_
+        g2, lm2, prim2, region2 = make_case(dims=(100, 100, 100), brick=brick, eos=eos, lens=True, minc=minc)
+        o2 = ol.OracleSim(L, lm2, kind)
+        o2.set_regions(region2)
+        y2 = o2.yvec(scaled_(prim2, region2, eos).ravel())
+        assert o2.pre_eval(y2) == 0
+        l2 = o2.lhs()
+        e2, f2 = o2.residual(y2, dt, l2)
+        L.wo_pre_iteration(o2.h)
+        t0 = time.time(); o2.jacobian(y2, dt, l2, f2, mode=0); t_row2 = time.time() - t0
+        t0 = time.time(); o2.jacobian(y2, dt, l2, f2, mode=1); t_col2 = time.time() - t0
+        o2.close()
+        t_col = t_jac * t_col2 / t_row2
+        col_note = " (scaled from the 100^3 mesh of the same kind: %.2f s coloured against %.2f s per-row there)" % (t_col2, t_row2)
     # thread count: the memory-bound Krylov iteration decides.  Each trial = ILU(0) set-up with one
     # subdomain per thread + a few BiCGStab iterations; the best count is then timed over K iterations
     xs = np.zeros(osim.n_prim * bs)
@@ -259,13 +298,17 @@ def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0):
               "BiCGStab %.3f s/iteration over %d iterations; Newton step = residual + Jacobian + set-up + %.1f "
               "iterations (the count measured on the GPU trajectory) x s/iteration = %.1f s; %d OpenMP threads "
               "(best Krylov iteration of %s; the container's CPU quota is %d CPUs) on %d hardware threads, %s"
-              % (n, dt, t_res, t_jac, "; reference-style coloured sweeps %.2f s" % t_col if t_col else "", t_setup,
+              % (n, dt, t_res, t_jac, "; reference-style coloured sweeps %.2f s%s" % (t_col, col_note) if t_col else "", t_setup,
                  t_iter, K, kits_per_newton, t_newton, best_t, "/".join(str(t) for t in trials), quota, avail, model))
-    out = {"value": 1.0 / t_newton, "unit": "Newton steps/s", "cores": best_t, "kind": "port", "sample": sample,
+    # "modelled": the Newton step is put together from pieces timed on this mesh and the GPU trajectory's
+    # iteration count, not run as a whole
+    out = {"value": 1.0 / t_newton, "unit": "Newton steps/s", "cores": best_t, "kind": "port, modelled", "sample": sample,
            "seconds": {"residual": t_res, "jacobian_per_row": t_jac, "jacobian_coloured": t_col, "pc_setup": t_setup,
                        "krylov_iteration": t_iter}}
     if t_col:
         out["value_with_coloured_jacobian"] = 1.0 / (t_newton - t_jac + t_col)
+    if vs_oracle:
+        out["vs_oracle"] = vs_oracle
     return out
 
 
@@ -299,6 +342,10 @@ def main():
     ap.add_argument("--dt0", type=float, default=1.0e4)
     ap.add_argument("--lead", type=int, default=3, help="accepted time steps run before the measured window")
     ap.add_argument("--window", type=int, default=5, help="accepted time steps in the measured cycle")
+    ap.add_argument("--controller", default="adapt", choices=["adapt", "double"],
+                    help="step size after a converged step: the reference's adaptor (x 2 below 5 Newton iterations) or x 2 always")
+    ap.add_argument("--rank-share", type=int, default=0,
+                    help="run one rank's share of the N-GPU decomposition (dims / partition) on one GPU and report the iteration's cost")
     ap.add_argument("--ksp", default="bcgs")
     ap.add_argument("--pc", default="bjacobi", choices=["bjacobi", "asm", "none"])
     ap.add_argument("--no-lens", action="store_true")
@@ -350,6 +397,12 @@ def main():
     if a.minc:
         cfg["minc"] = True
     dims, eos, minc = tuple(cfg["dims"]), cfg["eos"], cfg["minc"]
+    full_dims = dims
+    if a.rank_share > 1:   # one rank's sub-box of the N-rank block partition (balanced split, the largest share)
+        if world != 1:
+            print("bench.py: --rank-share runs on one GPU", file=sys.stderr)
+            sys.exit(2)
+        dims = tuple(-(-d // p) for d, p in zip(dims, M.partition_shape(a.rank_share)))
     # bricks: wide in x, y, thin in z (k_z = 0.1 k_x).  3 x 3 blocks run one thread per scalar row and the
     # substitution sweeps of a brick are hidden by the loads of the OTHER bricks on its CU: 80 block rows =
     # 240 threads = 4 waves, seven bricks per CU.  MEASURED (tools/brick_scan.sh, 172x172x170 eos_wce;
@@ -383,7 +436,7 @@ def main():
     log("setup %.1f s: config %s, %d owned cells/rank, %d faces, %d subdomains, nnzb %d"
         % (time.time() - t_setup, a.config, lm.n_owned, lm.n_faces, lm.sub_ptr.size - 1, wl.LIB.wai_jacobian_nnzb(sim.h)))
 
-    drv = NewtonDriver(sim, y, a.dt0, torch)
+    drv = NewtonDriver(sim, y, a.dt0, torch, a.controller)
 
     def barrier():
         sim.synchronize()
@@ -414,34 +467,94 @@ def main():
         % (n_lead, a.lead, time.time() - t_lead, start["t"], start["dt"]))
     for _ in range(a.warmup):
         drv.newton_step()
+    while drv.it >= 0:      # (untimed) to the end of the try in flight: the timed region starts at a try's first iteration
+        drv.newton_step()
     if a.profile:
         sim.profile(True)
     barrier()
     k0, l0 = drv.krylov, len(drv.log)
+    ls0 = sim.launch_stats()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         drv.newton_step()
     barrier()
     el = time.perf_counter() - t0
+    ls1 = sim.launch_stats()
+    l1 = len(drv.log)
+    while drv.it >= 0:      # (untimed) how the last timed try ends
+        drv.newton_step()
     if dist is not None:
         tt = torch.tensor([el], dtype=torch.float64, device="cpu" if loopback else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
-    kits = drv.krylov - k0
-    timed = drv.log[l0:]
+    timed = drv.log[l0:l1]
+    kits = sum(r[3] for r in timed)
+    # Newton iterations that belong to accepted time steps (tries that end converged), and their time
+    acc_n, acc_s, ok = 0, 0.0, None
+    for r in reversed(drv.log[l0:]):
+        if r[4] != 0:
+            ok = r[4] > 0
+        r.append(bool(ok))
+    for r in timed:
+        if r[7]:
+            acc_n += 1
+            acc_s += r[6]
+    last_ok = [r for r in drv.log if r[4] > 0][-1]
     prof = sim.profile_get() if a.profile else None
     sim.profile(False)
     for i, rec in enumerate(drv.log):
-        tag = "lead" if i < n_lead else ("warm" if i < l0 else "TIME")
-        log("  %s step %d dt %.3g newton %d krylov %d reason %d maxres %.3e  %.3f s" % ((tag,) + tuple(rec)))
+        tag = "lead" if i < n_lead else ("warm" if i < l0 else ("TIME" if i < l1 else "tail"))
+        log("  %s step %d dt %.3g newton %d krylov %d reason %d maxres %.3e  %.3f s" % ((tag,) + tuple(rec[:7])))
     # least squares: seconds per Newton step = fixed part (Jacobian, set-up, residual, transitions)
     # + Krylov iterations x seconds per iteration
     A = np.array([[1.0, r[3]] for r in timed])
     b = np.array([r[6] for r in timed])
     fixed_s, iter_s = (np.linalg.lstsq(A, b, rcond=None)[0] if len(timed) > 2 and np.ptp(A[:, 1]) > 0 else (0.0, 0.0))
 
-    # Kernel roofline, measured live with HIP events on the library's stream on the last
-    # assembled Jacobian.  Dominant kernel of a Newton step: the fused preconditioned operator
+    # Correctness gate (`check` in the line).  (i) the last accepted time step's convergence measure, as
+    # SNES_convergence forms it; (ii) global balance of that step's discrete equations, per equation:
+    # sum_i V_i (L_i(y_new) - L_i(y_old) - dt R_i(y_new)) against sum_i V_i |L_i(y_new) - L_i(y_old)| -- wai_lhs /
+    # wai_rhs evaluated afresh on the accepted state, not Newton's own residual vector; (iii) in the CPU-baseline
+    # leg the oracle's residual and FD Jacobian at the window's first state against the device's (below).
+    check = {"max_scaled_residual_last_accepted_step": last_ok[5], "nonlinear_tolerance": 1e-5}
+    gpu_state = None
+    if world == 1:
+        n_dof = lm.n_owned * bs
+        vol = torch.from_numpy(np.ascontiguousarray(lm.cell_geom[: lm.n_owned, 3])).cuda()
+        # one more accepted time step from where the trajectory stands, kept out of every timing
+        lhs0 = torch.zeros(n_dof, dtype=torch.float64, device="cuda")
+        r_chk = 0
+        for _ in range(60):
+            r_chk, _ = drv.newton_step()      # lhs_old = L(y_old) is set when a try begins and kept through it
+            if r_chk > 0:
+                lhs0.copy_(drv.lhs_old)
+                dt_chk = drv.log[-1][1]
+                t_old = drv.t - dt_chk
+                break
+        if r_chk > 0:
+            lhs1 = torch.zeros_like(lhs0)
+            rhs1 = torch.zeros_like(lhs0)
+            assert sim.pre_eval(t_old + dt_chk, y) == 0
+            sim.lhs(t_old + dt_chk, (t_old, t_old + dt_chk), y, lhs1)
+            sim.rhs(t_old + dt_chk, (t_old, t_old + dt_chk), y, rhs1)
+            torch.cuda.synchronize()
+            dl = (lhs1 - lhs0).view(-1, bs) * vol[:, None]
+            bal = (dl - dt_chk * rhs1.view(-1, bs) * vol[:, None]).sum(dim=0).abs() / dl.abs().sum(dim=0).clamp_min(1e-300)
+            check["step_balance_defect_per_equation"] = [float(v) for v in bal.cpu()]
+            check["step_balance_of"] = "accepted step at t = %.6g s, dt = %.4g s" % (t_old, dt_chk)
+            del lhs1, rhs1, dl
+        # the window's first state again: residual and Jacobian the oracle is compared with, and the matrix
+        # the kernel microbenchmarks run on
+        drv.restore(start)
+        drv._begin()
+        sim.jacobian(drv.t + drv.dt, drv.dt, y, drv.lhs_old)
+        sim.pc_setup()
+        if not a.no_cpu:
+            gpu_state = dict(f=drv.f.cpu().numpy().copy(), J=sim.jacobian_values())
+        drv.it = -1
+
+    # Kernel roofline, measured live with HIP events on the library's stream on the Jacobian of the window's
+    # first Newton step.  Dominant kernel of a Newton step: the fused preconditioned operator
     # k_pc (block SpMV t = A x, block-Jacobi ILU(0) solve z = U^-1 L^-1 t, dot (z, aux)), run
     # twice per BiCGStab iteration.  Plain block SpMV is reported beside it.
     nnzb = wl.LIB.wai_jacobian_nnzb(sim.h)
@@ -450,6 +563,9 @@ def main():
     if world == 1 and not minc and a.pc == "bjacobi":   # the two launches of the overlapped halo exchange, timed alone
         kb["fused_interior_bricks"] = sim.bench_kernel(9, a.spmv_reps)
         kb["fused_face_bricks"] = sim.bench_kernel(10, a.spmv_reps)
+    if world == 1 and a.ksp == "bcgs" and a.pc == "bjacobi":   # the iteration's five launches back to back, and its vector updates alone
+        kb["bicgstab_iteration_device_only"] = sim.bench_kernel(5, 50)
+        kb["bicgstab_vector_updates"] = sim.bench_kernel(6, 50)
     log("kernel microbench (ms/launch): " + json.dumps(kb))
     b_spmv = spmv_bytes(nnzb, lm.n_owned, bs)
     b_pc = pc_bytes(nnzb, lm.n_owned, bs)
@@ -460,42 +576,74 @@ def main():
         % (ms, achieved, 100 * achieved / HBM_PEAK_GBS, HBM_PEAK_GBS, ms_pc, achieved_pc, 100 * achieved_pc / HBM_PEAK_GBS))
     if prof:
         log("kernel-class time inside the timed region (ms, launches): " + json.dumps(prof))
+    traffic = traffic_from_profiles(a.config, dims, brick) if world == 1 else None
 
     if rank == 0:
         ksp_name = {"bcgs": "BiCGStab", "gmres": "GMRES(30)"}.get(a.ksp, a.ksp)
         pc_name = {"bjacobi": "block-Jacobi", "asm": "ASM overlap 1 (restricted)", "none": "no preconditioner"}[a.pc]
+        n_newton = max(a.steps, 1)
+        launches = (ls1[0] - ls0[0]) / max(kits, 1)
+        ctl = ("adaptive dt (x2 below 5 Newton iterations, x0.2 after a failed step)" if a.controller == "adapt"
+               else "dt=1e4*2^n / retry*0.2 trajectory")
+        share = " [rank share 1/%d of %dx%dx%d]" % ((a.rank_share,) + full_dims) if a.rank_share > 1 else ""
         out = {
-            "metric": "Newton steps/sec, 10M-cell eos_we (BCSR SpMV GB/s in roofline)" if a.config == "c3"
-                      else "Newton steps/sec, config %s" % a.config,
+            "metric": ("Newton steps/sec, 10M-cell eos_we (BCSR SpMV GB/s in roofline)" if a.config == "c3" and not share
+                       else "Newton steps/sec, config %s%s" % (a.config, share)),
             "value": a.steps / el, "unit": "Newton steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %dx%dx%d structured eos_%s mesh%s (%d cells), BE time steps %d-%d of the dt=1e4*2^n / "
-                                   "retry*0.2 trajectory (cyclic), %s + %s(%dx%dx%d bricks)/ILU(0), rtol 1e-5"
-                                   % ((a.config,) + dims + (eos, " + 1 MINC level" if minc else "", n_cells, a.lead,
-                                                            a.lead + a.window - 1, ksp_name, pc_name) + brick),
-                       "krylov_iterations_per_newton_step": kits / max(a.steps, 1),
+            # Newton iterations of accepted time steps only / their time: what the window costs without the tries
+            # that are thrown away
+            "value_accepted_steps": (acc_n / acc_s) if acc_s > 0 else None,
+            "accepted_newton_steps": acc_n,
+            "check": check,
+            "config": {"workload": "%s%s: %dx%dx%d structured eos_%s mesh%s (%d cells), BE time steps %d-%d, %s (cyclic), "
+                                   "%s + %s(%dx%dx%d bricks)/ILU(0), rtol 1e-5"
+                                   % ((a.config, share) + dims + (eos, " + 1 MINC level" if minc else "", n_cells, a.lead,
+                                                                  a.lead + a.window - 1, ctl, ksp_name, pc_name) + brick),
+                       "controller": a.controller,
+                       "krylov_iterations_per_newton_step": kits / n_newton,
                        "krylov_iterations": kits,
                        "ms_per_krylov_iteration": 1e3 * iter_s, "ms_fixed_per_newton_step": 1e3 * fixed_s,
+                       "launches_per_krylov_iteration": launches,
+                       "copies_per_krylov_iteration": (ls1[1] - ls0[1]) / max(kits, 1),
                        "timed_newton_steps": [{"time_step": r[0], "dt": r[1], "newton": r[2], "krylov": r[3],
-                                               "reason": r[4], "ms": 1e3 * r[6]} for r in timed],
+                                               "reason": r[4], "ms": 1e3 * r[6], "accepted": r[7]} for r in timed],
                        "partition": "x".join(str(p) for p in grid.part), "ksp": a.ksp, "pc": a.pc},
             "roofline": {"bound": "hbm", "kernel": sim.pc_kernel_name() + " (fused BCSR SpMV + block ILU(0) apply + dot)",
                          "achieved": achieved_pc, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_pc / HBM_PEAK_GBS,
-                         "traffic": traffic_from_profiles(a.config, dims, brick) if world == 1 else None,
+                         "traffic": traffic[0] if traffic else None,
+                         "traffic_source": traffic[1] if traffic else None,
                          "algorithmic_bytes_per_launch": b_pc, "ms_per_launch": ms_pc,
-                         "spmv": {"kernel": "k_spmv<%d> (BCSR SpMV)" % bs, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
-                                  "algorithmic_bytes_per_launch": b_spmv, "ms_per_launch": ms}},
+                         # the metric's second half, flat: BCSR SpMV achieved GB/s and fraction of HBM peak
+                         "spmv_gbs": achieved, "spmv_frac": achieved / HBM_PEAK_GBS, "spmv_ms_per_launch": ms,
+                         "spmv_algorithmic_bytes_per_launch": b_spmv, "spmv_kernel": "k_spmv<%d> (BCSR SpMV)" % bs},
         }
+        if "bicgstab_iteration_device_only" in kb:
+            out["config"]["ms_per_krylov_iteration_device_only"] = kb["bicgstab_iteration_device_only"]
+            out["config"]["ms_vector_updates_per_iteration"] = kb["bicgstab_vector_updates"]
+            out["config"]["ms_fused_per_iteration"] = 2.0 * ms_pc
+        if a.rank_share > 1:
+            out["rank_share"] = {"n": a.rank_share, "full_dims": list(full_dims), "dims": list(dims),
+                                 "ms_per_krylov_iteration": 1e3 * iter_s,
+                                 "ms_per_krylov_iteration_device_only": kb.get("bicgstab_iteration_device_only"),
+                                 "launches_per_krylov_iteration": launches}
         if not a.no_cpu and world == 1:   # the CPU baseline is a single-GPU-run item
             try:
                 cb = cpu_baseline(lm, eos, start["y"].cpu().numpy(), start["regions"], start["dt"],
-                                  kits / max(a.steps, 1))
+                                  kits / max(a.steps, 1), gpu_state=gpu_state, minc=minc, brick=brick)
             except Exception as e:   # the reported baseline must not take the measurement down with it
                 log("cpu baseline failed: %r" % (e,))
                 cb = None
             if cb:
+                vo = cb.pop("vs_oracle", None)
+                if vo:   # the correctness gate's third part: device against oracle on the window's first state
+                    out["check"].update(vo)
+                    out["check"]["passed"] = bool(vo["residual_vs_oracle"] < vo["residual_tolerance"]
+                                                  and (vo["jacobian_vs_oracle"] < vo["jacobian_tolerance"]
+                                                       or vo["jacobian_worst_in_ulp_steps"] < vo["jacobian_ulp_step_tolerance"])
+                                                  and out["check"]["max_scaled_residual_last_accepted_step"] < 1e-5)
                 out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     sim.destroy()

@@ -213,6 +213,18 @@ int wai_network_evaluate(int n_sources, const double *rate, const double *enthal
                          const int *out_flow, const int *out_kind, const int *out_node, const double *out_rate,
                          const double *out_proportion, const double *out_enthalpy, const int *rj_overflow_kind,
                          const int *rj_overflow, double *sources_out, double *groups_out, double *reinjectors_out);
+/* the cells between which wai_jacobian forms the network's coupling blocks (every cell of a source that a group
+ * or a reinjector names), for given source cells and the network description of wai_set_source_network -- no
+ * context, no device.  A superset of the reference's dependency list (source_network_identify_source_dependencies,
+ * src/source_network.F90:359-498; tests pin it on the 52 pairs of source_network_reinjector_test.F90:85-95).
+ * cells: room for n_sources entries, ascending and distinct on return */
+int wai_network_cells(int n_sources, const int *source_cell, const int *rate_specified, const int *enthalpy_specified,
+                      int n_groups, const int *grp_ptr, const int *grp_in_kind, const int *grp_in, const int *grp_scaling,
+                      const int *grp_limit_type, const double *grp_limit, const double *grp_sep,
+                      int n_reinjectors, const int *rj_in_kind, const int *rj_in, const int *rj_out_ptr,
+                      const int *out_flow, const int *out_kind, const int *out_node, const double *out_rate,
+                      const double *out_proportion, const double *out_enthalpy, const int *rj_overflow_kind,
+                      const int *rj_overflow, int *n_cells, int *cells);
 
 /* enthalpies of saturated water and steam at a separator pressure, in the context's
  * thermodynamics (separator_stage_init, src/separator.F90:108-136): sep_hf, sep_hg above */
@@ -249,6 +261,11 @@ int wai_comm_size(wai_ctx *ctx);   /* ranks the RCCL communicator reports (1 wit
 /* collectives enqueued on this rank so far: all-reduces (Krylov inner products, flags, norms) and
  * neighbour exchanges (halos); a BiCGStab iteration costs 2 all-reduces and 2 exchanges */
 int wai_comm_stats(wai_ctx *ctx, long long *allreduces, long long *exchanges);
+/* kernels launched and copies enqueued by the linear-solver helpers so far (SpMV, preconditioner, vector
+ * updates, reductions, halo pack / unpack, scalar read-backs): a BiCGStab iteration on one rank is 5 kernels
+ * and no copy -- every reduction is finished by the last workgroup of its producer and the residual norm is
+ * posted to pinned host memory */
+int wai_launch_stats(wai_ctx *ctx, long long *kernels, long long *copies);
 
 /* ---- ode_type surface (src/ode.F90:39-108 as overridden by src/flow_simulation.F90) ------ */
 int wai_pre_timestep(wai_ctx *ctx);                 /* flow_simulation.F90:2022-2035 */

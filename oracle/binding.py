@@ -367,3 +367,35 @@ class OracleSim:
         k = C.c_int(0)
         r = self.L.wo_timestep(self.h, C.byref(o), dt, dp(y), C.byref(k))
         return r, k.value
+
+
+def jacobian_parity(Jg, Jo, rowptr, colidx, y, lhs, bs, fd_eps=1.0e-8, fd_umin=1.0e-2):
+    """Two finite-difference Jacobians of the same residual function, entry by entry (BCSR values, row-major blocks).
+
+    An entry J[i,r; j,k] = (f_ir(y + h_jk e_jk) - f_ir(y)) / h_jk carries the rounding of f_ir divided by the step:
+    two correct evaluations of f that differ in the last bits of its accumulation term L_ir differ in the entry by a
+    few eps |L_ir| / |h_jk| -- which for a small scaled primary (a gas partial-pressure fraction of 0.02 has
+    h = 2e-10) is 1e-5 of the entry scale.  Returns (worst difference relative to the largest entry of the block
+    row's equation, worst difference in units of eps |L_ir| / |h_jk| among the entries above 2e-5 of that scale)."""
+    n = rowptr.size - 1
+    Jg = np.asarray(Jg).reshape(-1, bs, bs)
+    Jo = np.asarray(Jo).reshape(-1, bs, bs)
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    yb = np.asarray(y, dtype=np.float64)[: (int(colidx.max()) + 1) * bs].reshape(-1, bs)
+    dx = np.where(np.abs(yb) < fd_umin, np.where(yb >= 0.0, fd_umin, -fd_umin), yb)
+    h = np.abs(dx * fd_eps)                      # MatFDColoring "ds" increment on the scaled variables
+    Lb = np.abs(np.asarray(lhs, dtype=np.float64)[: n * bs].reshape(-1, bs))
+    eps = np.finfo(np.float64).eps
+    worst_rel, worst_ulp = 0.0, 0.0
+    for r in range(bs):
+        rowscale = np.zeros(n)
+        np.maximum.at(rowscale, rows, np.abs(Jo[:, r, :]).max(axis=1))
+        for k in range(bs):
+            d = np.abs(Jg[:, r, k] - Jo[:, r, k])
+            rel = d / np.maximum(rowscale[rows], 1e-300)
+            worst_rel = max(worst_rel, float(rel.max()))
+            big = rel > 2.0e-5
+            if big.any():
+                ulp = d[big] / (eps * np.maximum(Lb[rows[big], r], 1e-300) / h[colidx[big], k])
+                worst_ulp = max(worst_ulp, float(ulp.max()))
+    return worst_rel, worst_ulp

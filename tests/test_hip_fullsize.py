@@ -1,8 +1,16 @@
-"""Full-size (BASELINE configs[1]: 100^3 = 1 M cells, eos we) checks through size-independent
-properties -- the oracle would need minutes here, so no element-wise comparison:
-linearity of the block SpMV, SpMV against the BCSR values fetched through the ABI, the Krylov
-solution verified by an independent residual, mass conservation of the flux sweep, and
-Newton-step residual reduction."""
+"""The BASELINE configurations at their stated sizes (configs[1] 100^3 we; configs[2] 216^3 we;
+configs[3] 172 x 172 x 170 wce; configs[4] 100^3 + 1 MINC level wce).
+
+* size-independent properties: linearity of the block SpMV, SpMV against the BCSR values fetched through the
+  ABI, the Krylov solution verified by an independent residual, mass conservation of the flux sweep,
+  Newton-step residual reduction;
+* element by element against the oracle, on bench.py's exact set-up: the oracle is an OpenMP program and does
+  a 10 M-cell residual in about a second and the FD Jacobian in a few (these tests lift the suite's
+  OMP_NUM_THREADS=1 for their duration): fluid records 1e-12, lhs 1e-13, rhs / residual 1e-11, FD Jacobian
+  2e-5 of the block row's scale, block SpMV 1e-14, one brick-ILU(0) application 1e-11;
+* a whole backward-Euler time step at 100^3 on both paths: same Newton iteration count, same regions,
+  solution to 1e-7."""
+import os
 import ctypes as C
 
 import numpy as np
@@ -234,3 +242,160 @@ def test_baseline_configs_at_their_stated_sizes(oracle, name, dims, eos, minc, b
             break
     assert hist[-1] < 1e-2 * hist[0]
     sim.destroy()
+
+
+# ---- element by element against the oracle at the BASELINE sizes ---------------------------------------
+
+def _oracle_threads(n=None):
+    """the oracle's OpenMP team for the full-size comparisons (the suite runs it on one thread): the CPUs the
+    container may use (cgroup quota), at most 32"""
+    try:
+        gomp = C.CDLL("libgomp.so.1")
+    except OSError:
+        return None, 1
+    if n is None:
+        n = len(os.sched_getaffinity(0))
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                n = max(1, min(n, int(round(float(q) / float(per)))))
+        except (OSError, ValueError):
+            pass
+        n = min(n, 32)
+    gomp.omp_set_num_threads(int(n))
+    return gomp, n
+
+
+def _colmax_rel(a, b):
+    """max_j ( max_i |a_ij - b_ij| / max_i |b_ij| ), column by column (no full-size temporaries)"""
+    worst = 0.0
+    for j in range(b.shape[1]):
+        sc = max(float(np.abs(b[:, j]).max()), 1e-300)
+        worst = max(worst, float(np.abs(a[:, j] - b[:, j]).max()) / sc)
+    return worst
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("name,dims,eos,minc,brick", [
+    ("c3", (216, 216, 216), "we", False, (16, 16, 2)),
+    ("c4", (172, 172, 170), "wce", False, (8, 5, 2)),
+    ("c5", (100, 100, 100), "wce", True, (8, 4, 1)),
+])
+def test_elementwise_oracle_parity_at_baseline_sizes(oracle, name, dims, eos, minc, brick):
+    from tests.cases import make_case
+    from waiwera_amd.flow_simulation import FlowSimulation
+    gomp, nthreads = _oracle_threads()
+    try:
+        g, lm, prim, region = make_case(dims=dims, brick=brick, eos=eos, lens=True, minc=minc)
+        sim = FlowSimulation(lm, eos=eos)
+        osim = ol.OracleSim(oracle, lm, {"we": 1, "wce": 2}[eos])
+        sim.set_regions(region); osim.set_regions(region)
+        y = scaled(prim, region, eos).ravel().copy()
+        yo = osim.yvec(y)
+        bs = sim.num_primary_variables
+        n = sim.n_owned * bs
+        assert sim.n_owned == dims[0] * dims[1] * dims[2] * (2 if minc else 1)
+        assert sim.pre_eval(0.0, y) == 0 and osim.pre_eval(yo) == 0
+        # fluid records, field by field
+        fg, fo = sim.fluid(), osim.fluid()
+        assert fg.shape == fo.shape
+        e_fluid = _colmax_rel(fg, fo)
+        del fg
+        L, R = np.zeros(n), np.zeros(n)
+        assert sim.lhs(0.0, (0.0, 0.0), y, L) == 0 and sim.rhs(0.0, (0.0, 0.0), y, R) == 0
+        Lo, Ro = osim.lhs(), osim.rhs()
+        e_lhs = np.abs(L - Lo).max() / np.abs(Lo).max()
+        e_rhs = np.abs(R - Ro).max() / np.abs(Ro).max()
+        dt = 2.0e3
+        f = np.zeros(n)
+        assert sim.residual(dt, dt, y, Lo, f) == 0
+        err, fo_ = osim.residual(yo, dt, Lo)
+        assert err == 0
+        e_res = np.abs(f - fo_).max() / np.abs(fo_).max()
+        # FD Jacobian
+        assert sim.jacobian(dt, dt, y, Lo) == 0
+        err, Jo = osim.jacobian(yo, dt, Lo, fo_, mode=0)
+        assert err == 0
+        rp, ci = sim.setup_jacobian()
+        orp, oci = osim.pattern()
+        assert np.array_equal(rp, orp) and np.array_equal(ci, oci)
+        # entries within 2e-5 of the largest entry of their block row's equation -- or, where the FD step is tiny
+        # (the CO2 partial-pressure fraction 0.02 has h = 2e-10), within a few ulps of the row's accumulation
+        # term divided by the step, which is what two correct evaluations of the residual may differ by
+        e_jac, e_jac_ulp = ol.jacobian_parity(sim.jacobian_values(), Jo, rp, ci, y, Lo, bs)
+        # block SpMV and one brick-ILU(0) application on the oracle's matrix
+        sim.set_jacobian_values(Jo)
+        x = np.random.default_rng(7).uniform(-1, 1, n)
+        yg, yref = np.zeros(n), np.zeros(n)
+        assert sim.spmv(x, yg) == 0
+        oracle.wo_bcsr_spmv(sim.n_owned, bs, ol.ip(rp), ol.ip(ci), ol.dp(Jo), ol.dp(x), ol.dp(yref))
+        e_spmv = np.abs(yg - yref).max() / np.abs(yref).max()
+        sp_ = ol.i32a(lm.sub_ptr)
+        fval, dinv = np.zeros_like(Jo), np.zeros(sim.n_owned * bs * bs)
+        assert oracle.wo_bilu0_factor(sim.n_owned, bs, ol.ip(rp), ol.ip(ci), ol.dp(Jo), sp_.size - 1, ol.ip(sp_),
+                                      ol.dp(fval), ol.dp(dinv)) == 0
+        zref, zg = np.zeros(n), np.zeros(n)
+        oracle.wo_bilu0_apply(sim.n_owned, bs, ol.ip(rp), ol.ip(ci), ol.dp(fval), ol.dp(dinv), sp_.size - 1, ol.ip(sp_),
+                              ol.dp(yref), ol.dp(zref))
+        assert sim.pc_setup() == 0
+        assert sim.pc_apply(yref, zg) == 0
+        e_pc = np.abs(zg - zref).max() / np.abs(zref).max()
+        # how much the oracle's own result moves when every matrix entry moves by one rounding: the conditioning of
+        # the pivot blocks (3 x 3 blocks whose mass and energy rows are 1e6 apart) sets what two correct
+        # substitutions -- stored L / U factor and pivots there, rows pre-multiplied by the inverted pivots here --
+        # can agree to
+        zpert = np.zeros(n)
+        Jpert = Jo * (1.0 + np.finfo(float).eps * np.random.default_rng(11).choice([-1.0, 1.0], Jo.size))
+        assert oracle.wo_bilu0_factor(sim.n_owned, bs, ol.ip(rp), ol.ip(ci), ol.dp(Jpert), sp_.size - 1, ol.ip(sp_),
+                                      ol.dp(fval), ol.dp(dinv)) == 0
+        oracle.wo_bilu0_apply(sim.n_owned, bs, ol.ip(rp), ol.ip(ci), ol.dp(fval), ol.dp(dinv), sp_.size - 1, ol.ip(sp_),
+                              ol.dp(yref), ol.dp(zpert))
+        del Jpert
+        e_cond = np.abs(zpert - zref).max() / np.abs(zref).max()
+        print("%s (%d cells, %d oracle threads): fluid %.2e  lhs %.2e  rhs %.2e  residual %.2e  jacobian %.2e (%.1f ulp-steps)  "
+              "spmv %.2e  ilu(0) apply %.2e (one rounding of the matrix entries moves the oracle's by %.2e)"
+              % (name, sim.n_owned, nthreads, e_fluid, e_lhs, e_rhs, e_res, e_jac, e_jac_ulp, e_spmv, e_pc, e_cond))
+        assert e_fluid < 1e-12 and e_lhs < 1e-13 and e_rhs < 1e-11 and e_res < 1e-11
+        assert e_jac < 2e-5 or e_jac_ulp < 16.0, (e_jac, e_jac_ulp)
+        assert e_spmv < 1e-14
+        assert e_pc < max(1e-11, 20.0 * e_cond), (e_pc, e_cond)
+        sim.destroy(); osim.close()
+    finally:
+        if gomp:
+            gomp.omp_set_num_threads(1)
+
+
+@pytest.mark.timeout(1800)
+def test_whole_time_step_at_c2_matches_the_oracle(oracle):
+    """BASELINE configs[1] (100^3 eos we, bench.py's bricks, lens, wells, top boundary): one backward-Euler step
+    on both paths with the Krylov solves run to 1e-10 and the Newton iteration to 1e-9 -- same Newton
+    iteration count, same region map, solution to 1e-7"""
+    from tests.cases import make_case
+    from waiwera_amd.flow_simulation import FlowSimulation
+    gomp, nthreads = _oracle_threads()
+    try:
+        g, lm, prim, region = make_case(dims=(100, 100, 100), brick=(16, 16, 2), eos="we", lens=True)
+        sim = FlowSimulation(lm, eos="we")
+        osim = ol.OracleSim(oracle, lm, 1)
+        sim.set_regions(region); osim.set_regions(region)
+        y = scaled(prim, region).ravel().copy()
+        yo = osim.yvec(y)
+        sim.set_opts(ksp_rtol=1e-10, ftol_rel=1e-9)
+        o = osim.opts()
+        o.ksp_rtol, o.ftol_rel = 1e-10, 1e-9
+        dt = 2.0e3
+        reason, nits, kits = sim.timestep(0.0, dt, y)
+        r, ok = osim.timestep(yo, dt, o)
+        assert reason > 0 and r > 0, (reason, r)
+        ys, yos = y.reshape(-1, 2), yo[: y.size].reshape(-1, 2)
+        err = (np.abs(ys - yos).max(axis=0) / np.abs(yos).max(axis=0)).max()
+        print("c2 time step: newton %d (oracle %d), krylov %d (oracle %d), solution %.2e, regions differ in %d cells"
+              % (nits, r, kits, ok, err, int((sim.regions() != osim.regions()).sum())))
+        assert nits == r
+        assert np.array_equal(sim.regions(), osim.regions())
+        assert (sim.regions() != 1).any()          # the two-phase lens is in play
+        assert err < 1e-7
+        sim.destroy(); osim.close()
+    finally:
+        if gomp:
+            gomp.omp_set_num_threads(1)

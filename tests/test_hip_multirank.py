@@ -24,8 +24,8 @@ LOOPBACK = os.path.join(ROOT, "tests", "loopback_rccl", "libloopback_rccl.so")
 DIMS, BRICK = (16, 12, 8), (4, 4, 4)
 
 
-def _problem(part, rank):
-    g = M.StructuredGrid(DIMS, spacing=(10.0, 10.0, 500.0 / DIMS[2]), part=part, brick=BRICK)   # bottom layer in the lens
+def _problem(part, rank, dims=DIMS, brick=BRICK):
+    g = M.StructuredGrid(dims, spacing=(10.0, 10.0, 500.0 / dims[2]), part=part, brick=brick)   # bottom layer in the lens
     lm = g.local_mesh(rank, rock_fn=M.heterogeneous_rock(g.n_global), top_bc=([1.0e5, 20.0], 1),
                       sources=M.benchmark_sources(g))
     prim, region = M.benchmark_initial_state(g, lm.extras["prim_ijk"], lens=True)
@@ -43,7 +43,7 @@ def _run_steps(sim, y, nsteps=3):
     return out
 
 
-def _worker(rank, world, uid_q, q):
+def _worker(rank, world, uid_q, q, dims=DIMS, brick=BRICK):
     os.environ["WAI_RCCL_LIB"] = LOOPBACK
     os.environ.setdefault("WAI_HALO_OVERLAP", "0")   # the loopback time-slices the ranks on one GPU: in-order exchange unless asked
     from waiwera_amd import lib as wl
@@ -56,7 +56,7 @@ def _worker(rank, world, uid_q, q):
             uid_q.put(uid)
     else:
         uid = uid_q.get(timeout=300)
-    g, lm, prim, region = _problem(M.partition_shape(world), rank)
+    g, lm, prim, region = _problem(M.partition_shape(world), rank, dims, brick)
     sim = FlowSimulation(lm, eos="we", device=0)
     sim.set_regions(region)
     sim.comm_init(rank, world, uid)
@@ -81,9 +81,18 @@ def test_overlapped_halo_exchange_two_ranks(monkeypatch):
     test_ranks_sharing_one_gpu_match_one_rank(2)
 
 
+@pytest.mark.timeout(2400)
+def test_overlapped_halo_exchange_eight_ranks(monkeypatch):
+    """the multi-rank default (ghost values in flight behind the interior bricks) on the 2 x 2 x 2 partition:
+    every rank has x, y and z neighbours and both brick lists are non-empty"""
+    monkeypatch.setenv("WAI_HALO_OVERLAP", "1")
+    # 12 x 12 x 8 cells per rank in 3 x 3 x 4 bricks: 12 of a rank's 36 bricks touch no partition ghost
+    test_ranks_sharing_one_gpu_match_one_rank(8, dims=(24, 24, 16), brick=(4, 4, 2))
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("world", [2, 8])
-def test_ranks_sharing_one_gpu_match_one_rank(world):
+def test_ranks_sharing_one_gpu_match_one_rank(world, dims=DIMS, brick=BRICK):
     """2 ranks (2x1x1, bricks aligned with the serial ones) and 8 ranks (2x2x2: every rank has x, y
     and z neighbours, only the upper ranks carry the boundary, 6-cell rank extents cut the 4-cell
     bricks raggedly so the preconditioner differs from the serial one)"""
@@ -92,14 +101,14 @@ def test_ranks_sharing_one_gpu_match_one_rank(world):
     from waiwera_amd.flow_simulation import FlowSimulation
     ctx = mp.get_context("spawn")
     q, uid_q = ctx.Queue(), ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, uid_q, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, uid_q, q, dims, brick)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=400) for _ in range(world)]
+    res = [q.get(timeout=2000 if os.environ.get("WAI_HALO_OVERLAP") == "1" and world > 2 else 400) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    g, lm, prim, region = _problem((1, 1, 1), 0)
+    g, lm, prim, region = _problem((1, 1, 1), 0, dims, brick)
     sim = FlowSimulation(lm, eos="we", device=0)
     sim.set_regions(region)
     y = scaled(prim, region).ravel().copy()

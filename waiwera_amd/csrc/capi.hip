@@ -117,8 +117,8 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
     const int* row = colidx.data() + rowptr[i];
     diag[i] = (int)(std::lower_bound(row, row + (rowptr[i + 1] - rowptr[i]), i) - row);
   }
-  std::vector<int> info(N), uoff(N, 0), levf(N), levb(N), nlev(s.nsub, 0), lfirst(N), ulast(N);
-  s.max_rows = 0; s.max_lev = 0; s.max_ublocks = 0; s.max_nlu = 0;
+  std::vector<int> info(N), uoff(N, 0), levf(N), levb(N), nlev(s.nsub, 0), lfirst(N), ulast(N), tslot(N, 0);
+  s.max_rows = 0; s.max_lev = 0; s.max_ublocks = 0; s.max_nlu = 0; s.max_nl = 0;
   bool offdiag_fill = false, fast3 = true;
   int nlf_all = 0, nlb_all = 0;
   for (int sd = 0; sd < s.nsub; sd++) {
@@ -158,6 +158,21 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
           if (std::binary_search(row + q + 1, row + ulast[i], j)) { offdiag_fill = true; break; }
         }
       }
+    }
+    // per in-subdomain lower coupling (i, k): the slot of row k that holds A_ki (15: structurally absent), four
+    // bits each -- the pivot recurrence reads A_ki without chasing row k's descriptor and columns
+    for (int i = lo; i < hi; i++) {
+      const int* row = colidx.data() + rowptr[i];
+      int pack = 0;
+      for (int q = lfirst[i], p = 0; q < diag[i] && p < 4; q++, p++) {
+        const int k = row[q];
+        const int* rk = colidx.data() + rowptr[k];
+        const int* e = std::lower_bound(rk + diag[k] + 1, rk + ulast[k], i);
+        const int r2 = (e < rk + ulast[k] && *e == i) ? (int)(e - rk) : 15;
+        pack |= (r2 & 15) << (4 * p);
+      }
+      tslot[i] = pack;
+      s.max_nl = std::max(s.max_nl, diag[i] - lfirst[i]);
     }
     int ucount = 0;
     for (int i = lo; i < hi; i++) {
@@ -215,26 +230,43 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
     if (dev_upload(c, &s.ord_f, of) || dev_upload(c, &s.ord_b, ob)) return -1;
   }
   if (dev_upload(c, &s.sub_ptr, sub) || dev_upload(c, &s.sub_nlev, nlev) || dev_upload(c, &s.row_info, info) ||
-      dev_upload(c, &s.row_uoff, uoff) ||
+      dev_upload(c, &s.row_uoff, uoff) || dev_upload(c, &s.row_tslot, tslot) ||
       dev_alloc(c, &s.fval, (size_t)W * np * np * N) || dev_alloc(c, &s.dinv, (size_t)np * np * N))
     return -1;
-  s.diag_only = !offdiag_fill && !s.big && !getenv("WAI_ILU_GENERAL");
+  // Kernel-selection switches are build-time (A/B builds: WAI_EXTRA_HIPCC_FLAGS="-DWAI_ILU_GENERAL" ...); the
+  // run-time environment only steers what the tests compare in one process (WAI_BCGS_MERGED, WAI_JAC_PARK,
+  // WAI_HALO_OVERLAP) and the transport library (WAI_RCCL_LIB).
+  s.diag_only = !offdiag_fill && !s.big;
   s.level_sorted = false;
-  s.fast3 = fast3 && !getenv("WAI_ILU_NOFAST");
-  s.scaled = !getenv("WAI_ILU_NOSCALE");
+  s.fast3 = fast3;
+  s.scaled = true;
+#ifdef WAI_ILU_GENERAL
+  s.diag_only = false;     // stored L / U factor everywhere
+#endif
+#ifdef WAI_ILU_NOFAST
+  s.fast3 = false;         // no compacted 3 + 3 couplings
+#endif
+#ifdef WAI_ILU_NOSCALE
+  s.scaled = false;        // DILU with the inverted pivots read per application
+#endif
   {
-    const char* e = getenv("WAI_PC_PARK");
     // 160 KB of LDS per CU; a workgroup may use 64 KB
     const size_t need = ((size_t)(((s.max_rows + 63) / 64) * 64) * np + 32 + (size_t)s.max_ublocks * 4) * sizeof(double);
-    s.park = !(e && e[0] == '0') && need <= 64 * 1024;  // default on; WAI_PC_PARK=0: k_pc
+    s.park = need <= 64 * 1024;
+#ifdef WAI_PC_NOPARK
+    s.park = false;        // k_pc instead of k_pc_park
+#endif
   }
   {
     // one thread per scalar row: needs the pivot-scaled DILU form, <= 4 + 4 couplings and a brick whose
     // scalar rows fit one workgroup.  Default for block sizes 3 and 4, where a whole block row per
-    // thread does not fit the register file; WAI_PC_ROWS=0 / 1 forces it off / on (bs <= 2 too).
-    const char* e = getenv("WAI_PC_ROWS");
+    // thread does not fit the register file (-DWAI_PC_ROWS=0 / 1 forces it off / on, bs <= 2 too).
     const bool can = s.diag_only && s.scaled && !s.big && s.max_nlu <= 4 && s.max_rows * np <= 1024 && W <= 8;
-    s.rows_kernel = can && (e ? e[0] == '1' : np >= 3);
+#ifdef WAI_PC_ROWS
+    s.rows_kernel = can && (WAI_PC_ROWS != 0);
+#else
+    s.rows_kernel = can && np >= 3;
+#endif
   }
   if (s.rows_kernel) {
     // bricks whose long rows come first (MINC: fracture cells, then their matrix cells with 2 of 8
@@ -251,7 +283,7 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
       split[sd] = (sorted && r1 > lo) ? r1 - lo : hi - lo;
       any = any || split[sd] != hi - lo;
     }
-    if (any && !getenv("WAI_PC_NOSPLIT") && dev_upload(c, &s.sub_split, split)) return -1;
+    if (any && dev_upload(c, &s.sub_split, split)) return -1;
   }
   s.built = true;
   s.factored = false;
@@ -260,7 +292,7 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
 
 void free_schedule(IluSchedule& s) {
   hipFree(s.sub_ptr); hipFree(s.sub_nlev); hipFree(s.sub_split); hipFree(s.row_info); hipFree(s.fval); hipFree(s.dinv);
-  hipFree(s.row_uoff); hipFree(s.sub_int); hipFree(s.sub_bnd); hipFree(s.ord_f); hipFree(s.ord_b);
+  hipFree(s.row_uoff); hipFree(s.row_tslot); hipFree(s.sub_int); hipFree(s.sub_bnd); hipFree(s.ord_f); hipFree(s.ord_b);
   s = IluSchedule();
 }
 void free_asm(AsmSystem& a) {
@@ -386,6 +418,7 @@ int allreduce_scal(wai_ctx* c, int slot, int count) {
 }
 
 int read_scal(wai_ctx* c, int first, int count) {
+  c->ks.n_copy++;
   HIPCHK(c, hipMemcpyAsync(c->ks.h_scal + first, c->ks.scal + first, count * sizeof(double),
                            hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -856,14 +889,37 @@ int pc_dots(wai_ctx* c, int dot_mode, const double* x, const double* z, const do
   return 0;
 }
 
-// z = B^-1 r; dot_mode as launch_pc, with `x` the partner of mode 2
-int pc_solve(wai_ctx* c, const double* r, double* z, int dot_mode, const double* x, const double* aux) {
+// the reduction slots a dot mode leaves partial sums in: first slot, count
+void mode_slots(int dot_mode, int& slot0, int& nslots) {
+  slot0 = dot_mode == 3 ? S_DP2 : S_D1;
+  nslots = dot_mode == 2 ? 2 : (dot_mode == 4 ? 5 : 1);
+}
+// sum the partials a preconditioner application left (general path: separate one-block launches)
+int pc_finalize(wai_ctx* c, int dot_mode, int phase) {
+  if (!dot_mode) return 0;
+  int slot0, nslots;
+  mode_slots(dot_mode, slot0, nslots);
+  if (nslots == 5) { vec_finalize(c, c->ks.nb_pc, slot0, 4, -1); return vec_finalize(c, c->ks.nb_pc, slot0 + 4, 1, phase); }
+  return vec_finalize(c, c->ks.nb_pc, slot0, nslots, phase);
+}
+
+// z = B^-1 r; dot_mode as launch_pc, with `x` the partner of mode 2.  fin_phase >= -1: the partial sums of
+// the dot products are summed into the device scalars (and the BiCGStab scalars of that phase derived) --
+// in the fused kernel's last workgroup, or by a k_finalize launch on the general path; -2: left as partials
+int pc_solve(wai_ctx* c, const double* r, double* z, int dot_mode, const double* x, const double* aux, int fin_phase = -2) {
   if (pc_fused(c)) {
     // the fused kernels take the partner of modes 2 and 4 from their own input vector (the x of
     // z = B^-1 A x); here the input is r = (A + E) x, so those inner products are reduced separately
     if (dot_mode == 2 || dot_mode == 4) {
       if (launch_pc(c, false, r, z, 0, nullptr)) return -1;
-      return pc_dots(c, dot_mode, x, z, aux);
+      if (pc_dots(c, dot_mode, x, z, aux)) return -1;
+      return fin_phase >= -1 ? pc_finalize(c, dot_mode, fin_phase) : 0;
+    }
+    if (fin_phase >= -1 && dot_mode) {
+      int slot0, nslots;
+      mode_slots(dot_mode, slot0, nslots);
+      const Fin fin = make_fin(c, slot0, nslots, fin_phase);
+      return launch_pc(c, false, r, z, dot_mode, aux, nullptr, 0, &fin);
     }
     return launch_pc(c, false, r, z, dot_mode, aux);
   }
@@ -882,17 +938,26 @@ int pc_solve(wai_ctx* c, const double* r, double* z, int dot_mode, const double*
     if (z != r) vec_copy(c, z, r, n);
     if (launch_big_solve(c, c->J, c->ilu, z)) return -1;
   }
-  return pc_dots(c, dot_mode, x, z, aux);
+  if (pc_dots(c, dot_mode, x, z, aux)) return -1;
+  return fin_phase >= -1 ? pc_finalize(c, dot_mode, fin_phase) : 0;
 }
 
-// z = B^-1 A x  (x has halo room); optional fused dot products of the result
-int pc_amul(wai_ctx* c, double* x, double* z, int dot_mode = 0, const double* aux = nullptr) {
+// z = B^-1 A x  (x has halo room); optional fused dot products of the result, summed as pc_solve sums them
+int pc_amul(wai_ctx* c, double* x, double* z, int dot_mode = 0, const double* aux = nullptr, int fin_phase = -2) {
   const IluSchedule& s = c->ilu;
   if (!pc_fused(c) || c->net.cp_valid) {   // unfused: t = A x (+ the network's blocks), then the preconditioner
     if (halo_exchange(c, x, c->np)) return -1;
     { Prof p(c, KC_SPMV); apply_operator(c, x, c->ks.tmp); }
     Prof p(c, KC_PC_APPLY);
-    return pc_solve(c, c->ks.tmp, z, dot_mode, x, aux);
+    return pc_solve(c, c->ks.tmp, z, dot_mode, x, aux, fin_phase);
+  }
+  Fin fin;
+  const Fin* fp = nullptr;
+  if (fin_phase >= -1 && dot_mode) {
+    int slot0, nslots;
+    mode_slots(dot_mode, slot0, nslots);
+    fin = make_fin(c, slot0, nslots, fin_phase);
+    fp = &fin;
   }
   if (c->comm && c->mesh.n_halo && c->comm_stream && s.n_int > 0 && s.n_bnd > 0 && !c->prof_on) {
     // The partition-ghost values are needed only by the bricks on the rank's faces: pack on the
@@ -908,13 +973,33 @@ int pc_amul(wai_ctx* c, double* x, double* z, int dot_mode = 0, const double* au
       return -1;
     if (unpack_halo(c, x, c->np, c->comm_stream)) return -1;
     HIPCHK(c, hipEventRecord(c->ev_halo, c->comm_stream));
-    if (launch_pc(c, true, x, z, dot_mode, aux, s.sub_int, s.n_int)) return -1;
+    if (launch_pc(c, true, x, z, dot_mode, aux, s.sub_int, s.n_int)) return -1;   // its partials wait for ...
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_halo, 0));
-    return launch_pc(c, true, x, z, dot_mode, aux, s.sub_bnd, s.n_bnd);
+    return launch_pc(c, true, x, z, dot_mode, aux, s.sub_bnd, s.n_bnd, fp);        // ... the face bricks' last workgroup
   }
   if (halo_exchange(c, x, c->np)) return -1;
   Prof p(c, KC_PC_APPLY);
-  return launch_pc(c, true, x, z, dot_mode, aux);
+  return launch_pc(c, true, x, z, dot_mode, aux, nullptr, 0, fp);
+}
+
+// wait for the scalars a kernel posted to the host mirror with sequence number `seq` (Fin / k_bcgs_scalars):
+// no copy, no event -- the host spins on the pinned word the device writes last
+int wait_post(wai_ctx* c, int seq) {
+  Krylov& k = c->ks;
+  volatile double* post = k.h_scal + POST_OFF;
+  const double want = (double)seq;
+  for (unsigned long long spin = 1; post[16] != want; spin++) {
+    if ((spin & 0x3fff) == 0) {   // a stream that ran dry without posting, or a device error: do not spin forever
+      const hipError_t e = hipStreamQuery(c->stream);
+      if (e != hipErrorNotReady && post[16] != want) {
+        c->err = e == hipSuccess ? "scalars were not posted by the device" : std::string("stream: ") + hipGetErrorString(e);
+        return -1;
+      }
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  for (int i = 0; i < 16; i++) k.h_scal[i] = post[i];
+  return 0;
 }
 
 // KSPBCGS [PETSc], left preconditioning, preconditioned residual norm, zero initial guess.
@@ -928,14 +1013,15 @@ int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, doub
   vec_zero(c, x, n);
   vec_zero(c, k.P, k.nl);
   vec_zero(c, k.V, n);
+  partials_clear(c, S_D1, 5);   // S_D1 .. S_W2: whatever an aborted solve or a probe left behind
+  const bool multi = c->comm && c->comm->nranks > 1;
   {
     Prof p(c, KC_PC_APPLY);
-    if (pc_solve(c, b, k.R, 3, nullptr, nullptr)) return -1;  // R = B^-1 b, partial (R,R)
+    if (pc_solve(c, b, k.R, 3, nullptr, nullptr, multi ? -1 : 0)) return -1;  // R = B^-1 b, (R,R), first rho / beta
   }
   {
     Prof p(c, KC_VECTOR);
-    vec_finalize(c, k.nb_pc, S_DP2, 1, (c->comm && c->comm->nranks > 1) ? -1 : 0);
-    if (c->comm && c->comm->nranks > 1) { if (allreduce_scal(c, S_DP2, 1)) return -1; bcgs_scalars(c, 0); }
+    if (multi) { if (allreduce_scal(c, S_DP2, 1)) return -1; bcgs_scalars(c, 0); }
     vec_copy(c, k.RP, k.R, n);
   }
   if (read_scal(c, S_DP2, 1)) return -1;
@@ -945,24 +1031,30 @@ int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, doub
   *reason = 0;
   if (std::isnan(dp)) *reason = -9;
   else if (dp <= ttol) *reason = (dp <= atol) ? 3 : 2;
-  const bool multi = c->comm && c->comm->nranks > 1;
   double* Xsave = k.X;
   k.X = x;  // X aliases the caller's x during the iteration
   int rc = 0;
+  // One rank: every reduction is finished by the last workgroup of the kernel that produces it (Fin), so
+  // an iteration is five launches -- P update, fused A*P + ILU solve + (V,RP) + alpha, S update, fused
+  // A*S + ILU solve + (S,T),(T,T) + omega, X/R update + (R,R),(R,RP) + rho/beta -- and the last of them
+  // posts the scalars to the pinned host mirror: no k_finalize launches, no copy, no event.
   // first half of an iteration: P update, V = B^-1 A P with (V, RP), alpha, S.  It touches P, V, S
   // and the device scalars only -- not X, R -- so the next iteration's first half is enqueued
   // *before* the host waits for this iteration's residual norm: the device never idles through the
   // read-back, and if the norm says "converged" the speculative half is simply discarded.
   auto first_half = [&]() -> int {
     { Prof p(c, KC_VECTOR); bcgs_update_p(c); }
-    if (int e = pc_amul(c, k.P, k.V, 1, k.RP)) return e;
+    if (int e = pc_amul(c, k.P, k.V, 1, k.RP, multi ? -1 : 2)) return e;
     Prof p(c, KC_VECTOR);
-    vec_finalize(c, k.nb_pc, S_D1, 1, multi ? -1 : 2);
     if (multi) { if (int e = allreduce_scal(c, S_D1, 1)) return e; bcgs_scalars(c, 2); }
     bcgs_update_s(c);
     return 0;
   };
-  const bool speculate = getenv("WAI_BCGS_NO_SPECULATION") == nullptr;
+#ifdef WAI_BCGS_NO_SPECULATION
+  const bool speculate = false;
+#else
+  const bool speculate = true;
+#endif
   // More than one rank: the second half's five inner products travel in ONE all-reduce -- (S,T), (T,T)
   // for omega and (S,S), (S,RP), (T,RP), from which (R,R) and (R,RP) of R = S - omega T follow -- so an
   // iteration costs two all-reduces ((V,RP); these five) instead of three.  On one rank the
@@ -972,29 +1064,23 @@ int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, doub
   for (int i = 0; i < maxits && !*reason && !rc; i++) {
     if (!have_first_half && (rc = first_half())) break;
     have_first_half = false;
-    if ((rc = pc_amul(c, k.S, k.T, merged ? 4 : 2, merged ? k.RP : nullptr))) break;
+    if ((rc = pc_amul(c, k.S, k.T, merged ? 4 : 2, merged ? k.RP : nullptr, merged ? -1 : 3))) break;
     {
       Prof p(c, KC_VECTOR);
       if (merged) {
-        vec_finalize(c, k.nb_pc, S_D1, 4, -1);
-        vec_finalize(c, k.nb_pc, S_W2, 1, -1);
         if (multi && (rc = allreduce_scal(c, S_D1, 5))) break;
-        bcgs_scalars(c, 5);
+        bcgs_scalars(c, 6, true);   // omega, (R,R), (R,RP), rotation; posted: the host sees the norm before X, R are updated
         bcgs_update_xr(c, false);
-        bcgs_scalars(c, 4);
       } else {
-        vec_finalize(c, k.nb_pc, S_D1, 2, 3);
-        bcgs_update_xr(c);
-        vec_finalize(c, k.nblocks, S_DP2, 2, 4);
+        bcgs_update_xr(c, true, 4, true);
       }
     }
+    const int seq = k.seq;
     if (speculate && i + 1 < maxits) {
-      HIPCHK(c, hipMemcpyAsync(k.h_scal, k.scal, 16 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipEventRecord(c->ev_scal, c->stream));
       if ((rc = first_half())) break;
       have_first_half = true;
-      HIPCHK(c, hipEventSynchronize(c->ev_scal));
-    } else if ((rc = read_scal(c, 0, 16))) break;
+    }
+    if ((rc = wait_post(c, seq))) break;
     dp = std::sqrt(k.h_scal[S_DP2]);
     *its = i + 1;
     const double brk = k.h_scal[S_BREAK];
@@ -1674,9 +1760,17 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
   }
   k.nb_max = std::max(1024, c->ilu.nsub);
   if (dev_alloc(c, &k.partials, (size_t)NSLOTS * k.nb_max) || dev_alloc(c, &k.scal, (size_t)NSCAL)) return -1;
-  HIPCHK(c, hipMemset(k.partials, 0, (size_t)NSLOTS * k.nb_max * sizeof(double)));
+  partials_clear(c, 0, NSLOTS);   // every reduction slot starts empty (fin_block reads arrival off the data)
   HIPCHK(c, hipMemset(k.scal, 0, NSCAL * sizeof(double)));
-  HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&k.h_scal), NSCAL * sizeof(double)));
+  // pinned, coherent, device-mapped: the kernels that finish a BiCGStab iteration write the scalars the host
+  // tests straight into h_scal[POST_OFF ..] (wait_post)
+  HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&k.h_scal), NSCAL * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
+  std::memset(k.h_scal, 0, NSCAL * sizeof(double));
+  {
+    void* dp = nullptr;
+    HIPCHK(c, hipHostGetDevicePointer(&dp, k.h_scal, 0));
+    k.d_post = reinterpret_cast<double*>(dp) + POST_OFF;
+  }
   if (dev_alloc(c, &c->d_flags, (size_t)4) || dev_alloc(c, &c->d_red, (size_t)4096)) return -1;
   HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_flags), 4 * sizeof(int)));
   HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_red), 64 * sizeof(double)));
@@ -1966,6 +2060,21 @@ int network_build(Network& nw, int n, const int* rate_specified, const int* enth
   nw.h_enth = nw.h_enth0;
   return 0;
 }
+// the cells whose equations and unknowns the network ties together: every source a group, a reinjector input,
+// output or overflow names (source_network_identify_source_dependencies, source_network.F90:359-498, walks the
+// same lists: production cells of a reinjector's input x cells of the sources it -- or the reinjectors
+// it delivers or overflows to -- feeds; the members of a limited group among each other).  The coupling
+// blocks E cover all pairs of these cells, a superset of the reference's dependency list.
+void network_cells(Network& nw, int n) {
+  std::vector<char> in_net((size_t)n, 0);
+  auto mark = [&](const NetRef& r) { if (r.kind == 1 && r.index >= 0 && r.index < n) in_net[r.index] = 1; };
+  for (const NetGroup& g : nw.groups) for (const NetRef& r : g.in) mark(r);
+  for (const NetReinjector& r : nw.reinjectors) { mark(r.in); mark(r.overflow); for (const NetOutput& o : r.out) mark(o.out); }
+  nw.cp_cells.clear();
+  for (int i = 0; i < n && i < (int)nw.h_cell.size(); i++) if (in_net[i]) nw.cp_cells.push_back(nw.h_cell[i]);
+  std::sort(nw.cp_cells.begin(), nw.cp_cells.end());
+  nw.cp_cells.erase(std::unique(nw.cp_cells.begin(), nw.cp_cells.end()), nw.cp_cells.end());
+}
 }  // namespace
 extern "C" {
 
@@ -1997,17 +2106,7 @@ int wai_set_source_network(wai_ctx* c, const int* rate_specified, const int* ent
   if (dev_alloc(c, &nw.d_raw, 2 * (size_t)n) || dev_alloc(c, &c->src.net, 2 * (size_t)n)) return -1;
   HIPCHK(c, hipMemset(c->src.net, 0, sizeof(double) * 2 * n));
   nw.on = true;
-  // the cells whose equations and unknowns the network ties together: every source a group, a reinjector
-  // input, output or overflow names (source_network.F90:359-498 walks the same lists)
-  {
-    std::vector<char> in_net((size_t)n, 0);
-    auto mark = [&](const NetRef& r) { if (r.kind == 1 && r.index >= 0 && r.index < n) in_net[r.index] = 1; };
-    for (const NetGroup& g : nw.groups) for (const NetRef& r : g.in) mark(r);
-    for (const NetReinjector& r : nw.reinjectors) { mark(r.in); mark(r.overflow); for (const NetOutput& o : r.out) mark(o.out); }
-    for (int i = 0; i < n && i < (int)nw.h_cell.size(); i++) if (in_net[i]) nw.cp_cells.push_back(nw.h_cell[i]);
-    std::sort(nw.cp_cells.begin(), nw.cp_cells.end());
-    nw.cp_cells.erase(std::unique(nw.cp_cells.begin(), nw.cp_cells.end()), nw.cp_cells.end());
-  }
+  network_cells(nw, n);
   return 0;
 }
 
@@ -2063,6 +2162,29 @@ int wai_network_evaluate(int n_sources, const double* rate, const double* enthal
     const double v[8] = {R.out_w, R.out_s, R.over.rate, R.over.enth, R.over.wrate, R.over.wenth, R.over.srate, R.over.senth};
     std::memcpy(reinjectors_out + 8 * r, v, sizeof(v));
   }
+  return 0;
+}
+// The cells between which wai_jacobian forms the network's coupling blocks, for the given sources' cells and
+// network description -- no context, no device (tests pin it on the reference's dependency list).
+// cells: room for n_sources entries; *n_cells: how many were written (ascending, distinct)
+int wai_network_cells(int n_sources, const int* source_cell, const int* rate_specified, const int* enthalpy_specified,
+                      int n_groups, const int* grp_ptr, const int* grp_in_kind, const int* grp_in, const int* grp_scaling,
+                      const int* grp_limit_type, const double* grp_limit, const double* grp_sep, int n_reinj,
+                      const int* rj_in_kind, const int* rj_in, const int* rj_out_ptr, const int* out_flow,
+                      const int* out_kind, const int* out_node, const double* out_rate, const double* out_proportion,
+                      const double* out_enthalpy, const int* rj_overflow_kind, const int* rj_overflow, int* n_cells,
+                      int* cells) {
+  if (!source_cell || !n_cells || !cells || n_sources <= 0) return -2;
+  Network nw;
+  std::string err;
+  if (int e = network_build(nw, n_sources, rate_specified, enthalpy_specified, n_groups, grp_ptr, grp_in_kind, grp_in,
+                            grp_scaling, grp_limit_type, grp_limit, grp_sep, n_reinj, rj_in_kind, rj_in, rj_out_ptr, out_flow,
+                            out_kind, out_node, out_rate, out_proportion, out_enthalpy, rj_overflow_kind, rj_overflow, err))
+    return e;
+  nw.h_cell.assign(source_cell, source_cell + n_sources);
+  network_cells(nw, n_sources);
+  *n_cells = (int)nw.cp_cells.size();
+  for (size_t i = 0; i < nw.cp_cells.size(); i++) cells[i] = nw.cp_cells[i];
   return 0;
 }
 // state of the network after the last pass: groups 6 doubles each (rate, enthalpy, water_rate,
@@ -2668,8 +2790,10 @@ int wai_timestep(wai_ctx* c, double t, double dt, double* y, int* newton_its, in
 }
 
 // Micro-benchmark of one kernel on the library's stream, HIP-event timed: which 0 = block SpMV,
-// 1 = ILU(0) apply z = B^-1 r, 2 = fused z = B^-1 (A x) with the (z, aux) reduction,
-// 3/4 = probes of 1/2 with the substitution sweeps skipped (load/compute phase split).
+// 1 = ILU(0) apply z = B^-1 r, 2 = fused z = B^-1 (A x) with the (z, aux) reduction finished in the kernel,
+// 3/4 = probes of 1/2 with the substitution sweeps skipped (load/compute phase split), 5 = the five launches
+// of a whole BiCGStab iteration (overwrites the Krylov work vectors), 6 = its vector updates alone,
+// 9 / 10 = the fused kernel on the interior / face bricks only.
 int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
   if (!c || !ms_per_launch || reps <= 0) return -2;
   if (which > 0 && !c->ilu.factored) { const int e = do_pc_setup(c); if (e) return e < 0 ? -1 : e; }
@@ -2680,16 +2804,25 @@ int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
       case 1: case 3: pc_solve(c, k.P, k.V, 0, nullptr, nullptr); break;
       case 9: if (c->ilu.n_int > 0) launch_pc(c, true, k.P, k.V, 1, k.RP, c->ilu.sub_int, c->ilu.n_int); break;   // interior bricks only
       case 10: if (c->ilu.n_bnd > 0) launch_pc(c, true, k.P, k.V, 1, k.RP, c->ilu.sub_bnd, c->ilu.n_bnd); break;  // face bricks only
-      default: pc_amul(c, k.P, k.V, 1, k.RP); break;   // what a BiCGStab half-iteration runs (no halo on one rank)
+      case 5:   // the launches of one BiCGStab iteration back to back, no host in the loop: the iteration's floor
+        bcgs_update_p(c); pc_amul(c, k.P, k.V, 1, k.RP, 2); bcgs_update_s(c); pc_amul(c, k.S, k.T, 2, nullptr, 3);
+        bcgs_update_xr(c, true, 4, false);
+        break;
+      case 6:   // its three vector updates alone
+        bcgs_update_p(c); bcgs_update_s(c); bcgs_update_xr(c, true, 4, false);
+        break;
+      default: pc_amul(c, k.P, k.V, 1, k.RP, 2); break;   // what a BiCGStab half-iteration runs (no halo on one rank)
     }
   };
   c->dbg = (which == 3 || which == 4) && pc_fused(c) && !(c->J.bs == 2 && c->ilu.park) ? 1 : 0;
+  partials_clear(c, S_D1, 5);
   for (int i = 0; i < 5; i++) run();
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   for (int i = 0; i < reps; i++) run();
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   HIPCHK(c, hipEventSynchronize(c->ev1));
   c->dbg = 0;
+  partials_clear(c, S_D1, 5);   // the interior- / face-only launches leave partials nobody sums
   float ms = 0.f;
   HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
   *ms_per_launch = ms / reps;
@@ -2712,6 +2845,12 @@ const char* wai_pc_kernel_name(wai_ctx* c) {
   return buf;
 }
 int wai_comm_size(wai_ctx* c) { return c ? comm_count(c->comm) : -2; }
+int wai_launch_stats(wai_ctx* c, long long* kernels, long long* copies) {
+  if (!c) return -2;
+  if (kernels) *kernels = c->ks.n_launch;
+  if (copies) *copies = c->ks.n_copy;
+  return 0;
+}
 int wai_comm_stats(wai_ctx* c, long long* allreduces, long long* exchanges) {
   if (!c) return -2;
   if (allreduces) *allreduces = c->comm ? c->comm->n_allreduce : 0;

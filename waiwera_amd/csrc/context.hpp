@@ -138,6 +138,8 @@ struct IluSchedule {
   bool scaled = true;       // diag_only: rows pre-scaled by the inverted pivots (WAI_ILU_NOSCALE: off)
   bool park = true;         // k_pc_park: upper blocks parked in LDS (WAI_PC_PARK=0: off)
   int* row_uoff = nullptr;  // first parked upper block of a row inside its subdomain
+  int* row_tslot = nullptr; // per row: slot of A_ki in row k for each of its (<= 4) in-subdomain lower couplings k, 4 bits each (15: none)
+  int max_nl = 0;           // most in-subdomain lower couplings of any row
   bool park2 = false;
   int* sub_int = nullptr;   // subdomains none of whose rows has a partition-ghost column ...
   int* sub_bnd = nullptr;   // ... and the others (device lists; null on a single rank)
@@ -185,6 +187,7 @@ struct ResForm {
 // Passive tracers (src/tracer.F90:30-40) and the auxiliary linear problem's solver settings
 // (timestepper.F90:2021-2022, 2061-2064: gmres + bjacobi unless configured)
 constexpr int MAX_TRACERS = 8;
+constexpr int POST_OFF = 64;   // h_scal[POST_OFF .. POST_OFF + 16]: scalars and sequence number posted by the device
 struct Tracers {
   int nt = 0;
   int phase[MAX_TRACERS] = {0};
@@ -202,8 +205,26 @@ struct TracerForm {
   double dt, ratio, decay, activation, diffusion;
 };
 
+// Finalisation of a producer kernel's partial sums inside its own launch (fin_block, kernels_linalg.hip): one
+// extra workgroup waits for the partials of `nslots` consecutive reduction slots, sums them into the device
+// scalars -- in the order k_finalize sums them --, derives the BiCGStab scalars of `phase` and, when asked,
+// posts the scalars to the pinned host mirror.  Replaces a one-block k_finalize launch (and the 128-byte
+// copy) behind every producer.
+struct Fin {
+  int count = 0;               // workgroups of this launch that store partials; 0: no finalisation here (no extra workgroup)
+  int nb = 0;                  // partials per slot to sum (an earlier launch may have left some of them)
+  int slot0 = 0, nslots = 0;
+  int phase = -1;              // derive_scalars phase, -1: sums only
+  int seq = 0;                 // > 0: post scal[0..16) and this sequence number to `post`
+  double* scal = nullptr;
+  double* post = nullptr;      // device address of the pinned host mirror: [16] scalars, [16] = seq
+};
+
 struct Krylov {
   int n = 0, nl = 0;           // bs*n_owned, bs*n_prim
+  double* d_post = nullptr;    // device address of h_scal + POST_OFF
+  int seq = 0;                 // last sequence number handed out
+  long long n_launch = 0, n_copy = 0;   // kernels launched / copies enqueued by the Krylov helpers (wai_launch_stats)
   double *R = nullptr, *RP = nullptr, *P = nullptr, *V = nullptr, *S = nullptr, *T = nullptr,
          *tmp = nullptr, *X = nullptr;
   double* bl = nullptr;        // BiCGStab(L): r_0..r_L, u_0..u_L, r~ (allocated on first use)
@@ -323,7 +344,7 @@ int launch_ilu_factor(wai_ctx* c);
 // ASM system with its own
 int launch_ilu_factor_on(wai_ctx* c, const Bcsr& M, IluSchedule& s);
 int launch_pc_on(wai_ctx* c, const Bcsr& M, const IluSchedule& s, bool spmv, const double* in, double* z,
-                 int dot_mode, const double* aux, const int* list = nullptr, int nrun = 0);
+                 int dot_mode, const double* aux, const int* list = nullptr, int nrun = 0, const Fin* fin = nullptr);
 // subdomains of any size: level-by-level launches, in place on z (z = r on entry)
 int launch_big_solve(wai_ctx* c, const Bcsr& M, const IluSchedule& s, double* z);
 int launch_asm_gather_matrix(wai_ctx* c);                   // E.val <- J.val
@@ -336,21 +357,27 @@ int vec_dots(wai_ctx* c, const double* a1, const double* b1, int slot1, const do
 // dot_mode 0: none; 1: scal-partials S_D1 += (z, aux); 2: S_D1 += (in, z), S_D2 += (z, z);
 // 3: S_DP2 += (z, z)
 // list / nrun: run only the listed subdomains (null: all)
+// fin (optional): finalise the dot products in the kernel's last workgroup instead of a k_finalize launch
 int launch_pc(wai_ctx* c, bool spmv, const double* in, double* z, int dot_mode, const double* aux,
-              const int* list = nullptr, int nrun = 0);
+              const int* list = nullptr, int nrun = 0, const Fin* fin = nullptr);
+// finalisation descriptor for slots [slot0, slot0 + nslots) (the launcher fills in the workgroup counts);
+// post: mirror the scalars to the host with a fresh sequence number (left in ks.seq)
+Fin make_fin(wai_ctx* c, int slot0, int nslots, int phase, bool post = false);
 int launch_ell_to_bcsr(wai_ctx* c, const double* ell, double* bcsr);
 int launch_bcsr_to_ell(wai_ctx* c, const double* bcsr, double* ell);
 // reductions: partial sums live in ks.partials[slot][block]; finalize sums nb partials of
 // nslots consecutive slots into ks.scal and (phase >= 0) derives the BiCGStab scalars
 int vec_finalize(wai_ctx* c, int nb, int slot0, int nslots, int phase);
 int vec_dot(wai_ctx* c, const double* a, const double* b, int n, int slot);
+int partials_clear(wai_ctx* c, int slot0, int nslots);   // reduction slots emptied (FIN_EMPTY)
 int vec_copy(wai_ctx* c, double* dst, const double* src, size_t n);
 int vec_zero(wai_ctx* c, double* dst, size_t n);
 int vec_waxpy(wai_ctx* c, double* w, double alpha, const double* x, const double* y, int n);
-int bcgs_scalars(wai_ctx* c, int phase);
+int bcgs_scalars(wai_ctx* c, int phase, bool post = false);
 int bcgs_update_p(wai_ctx* c);
 int bcgs_update_s(wai_ctx* c);
-int bcgs_update_xr(wai_ctx* c, bool dots = true);   // dots: leaves partials in S_DP2, S_RHONEW; #blocks via ks.nblocks
+// dots: reduces (R,R), (R,RP) into S_DP2, S_RHONEW and (fin_phase >= -1) finalises them in its last workgroup
+int bcgs_update_xr(wai_ctx* c, bool dots = true, int fin_phase = -2, bool post = false);
 int gmres_mdot(wai_ctx* c, const double* w, int k);          // scal[16+i] = (w, v_i), i<k
 int gmres_maxpy_norm(wai_ctx* c, double* w, int k);          // w -= sum h_i v_i ; scal[8] = |w|^2
 int gmres_scale_to(wai_ctx* c, double* dst, const double* src, int slot_norm2, int n);

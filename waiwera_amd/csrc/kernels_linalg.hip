@@ -393,6 +393,101 @@ __global__ void k_dilu_pivots(int n, int nsub, const int* __restrict__ sub_ptr,
   }
 }
 
+// The same recurrence for block sizes 3 and 4, where the lower couplings' blocks do not fit the registers
+// beside the pivot and its inverse (k_dilu_pivots<3, PRE> measured no faster than the pointer-chasing loop):
+// A_ik and A_ki of every lower coupling go to LDS before the level loop -- thread-private columns,
+// [coupling][element][row], so neither the store nor the reload conflicts -- and A_ki is addressed through the
+// transposed slot the symbolic phase recorded (row_tslot), i.e. two dependent global round trips per brick
+// (column, blocks) instead of four per level.  Same products in the same order as k_dilu_pivots: identical pivots.
+template <int BS, int NPL>
+__global__ __launch_bounds__(256) void k_dilu_pivots_lds(int n, int nsub, int cap, const int* __restrict__ sub_ptr,
+                                  const int* __restrict__ sub_nlev, const int* __restrict__ row_info,
+                                  const int* __restrict__ row_tslot, const int* __restrict__ col,
+                                  const double* __restrict__ aval, double* __restrict__ dinv, int* flags) {
+  constexpr int BB = BS * BS;
+  extern __shared__ double sm[];  // pinv [BB][cap], A_ik [NPL][BB][cap], A_ki [NPL][BB][cap]
+  const int s = xcd_remap(blockIdx.x, nsub);
+  if (s >= nsub) return;
+  const int lo = sub_ptr[s], R = sub_ptr[s + 1] - lo;
+  const int nlf = sub_nlev[s] & 0xffff;
+  const int tid = threadIdx.x, i = lo + tid;
+  const bool active = tid < R;
+  double* pinv = sm;
+  double* laik = sm + (size_t)BB * cap;
+  double* laki = laik + (size_t)NPL * BB * cap;
+  int lfirst = 0, dslot = 0, ulast = 0, lf = -1, lb = 0;
+  int koff[NPL];
+  double P[BB];
+#pragma unroll
+  for (int e = 0; e < BB; e++) P[e] = 0.0;
+#pragma unroll
+  for (int p = 0; p < NPL; p++) koff[p] = -1;
+  if (active) {
+    unpack_info(row_info[i], lfirst, dslot, ulast, lf, lb);
+    const int tp = row_tslot[i];
+    int ks[NPL];
+#pragma unroll
+    for (int p = 0; p < NPL; p++) {
+      ks[p] = i;
+      if (lfirst + p < dslot) ks[p] = col[(size_t)(lfirst + p) * n + i];
+    }
+    load_block<BS>(aval, n, dslot, i, P);
+#pragma unroll
+    for (int p = 0; p < NPL; p++) {
+      const int q = lfirst + p;
+      if (q < dslot) {
+        const int k = ks[p], r2 = (tp >> (4 * p)) & 15;
+        koff[p] = k - lo;
+#pragma unroll
+        for (int e = 0; e < BB; e++) {
+          laik[(size_t)(p * BB + e) * cap + tid] = aval[vix<BS>(n, q, e, i)];
+          laki[(size_t)(p * BB + e) * cap + tid] = r2 == 15 ? 0.0 : aval[vix<BS>(n, r2, e, k)];
+        }
+      }
+    }
+  }
+  for (int lev = 0; lev < nlf; lev++) {
+    if (active && lf == lev) {
+#pragma unroll
+      for (int p = 0; p < NPL; p++) {
+        if (koff[p] >= 0) {   // P -= (A_ik inv(P_k)) A_ki
+          double aik[BB], pk[BB], t[BB];
+#pragma unroll
+          for (int e = 0; e < BB; e++) { aik[e] = laik[(size_t)(p * BB + e) * cap + tid]; pk[e] = pinv[(size_t)e * cap + koff[p]]; }
+#pragma unroll
+          for (int r = 0; r < BS; r++)
+#pragma unroll
+            for (int c = 0; c < BS; c++) {
+              double acc = 0.0;
+#pragma unroll
+              for (int e = 0; e < BS; e++) acc += aik[r * BS + e] * pk[e * BS + c];
+              t[r * BS + c] = acc;
+            }
+#pragma unroll
+          for (int e = 0; e < BB; e++) aik[e] = laki[(size_t)(p * BB + e) * cap + tid];   // A_ki
+#pragma unroll
+          for (int r = 0; r < BS; r++)
+#pragma unroll
+            for (int c = 0; c < BS; c++) {
+              double acc = 0.0;
+#pragma unroll
+              for (int e = 0; e < BS; e++) acc += t[r * BS + e] * aik[e * BS + c];
+              P[r * BS + c] -= acc;
+            }
+        }
+      }
+      double inv[BB];
+      if (!block_inverse<BS>(P, inv)) atomicMax(&flags[0], 1);
+#pragma unroll
+      for (int e = 0; e < BB; e++) {
+        pinv[(size_t)e * cap + tid] = inv[e];
+        dinv[vix<BS>(n, 0, e, i)] = inv[e];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- pivot scaling for the diagonal-only case --------------------------------------------------
 // ILU(0) is invariant under block-diagonal row scaling: ILU(0)(S A) = (S L S^-1)(S U), so
 // (L'U')^-1 (S A) = (LU)^-1 A and (L'U')^-1 (S b) = (LU)^-1 b -- the preconditioned operator and
@@ -422,7 +517,127 @@ __global__ __launch_bounds__(TPB) void k_scale_rows(int n, int W, const double* 
   }
 }
 
+// ---- reductions finished inside the producing kernel ---------------------------------------------
+// The scalars the host tests after an iteration, written straight into pinned host memory: the 16 scalars,
+// then -- once those stores have completed -- the sequence number the host spins on (wait_post, capi.hip).
+__device__ __forceinline__ void post_scalars(const double* scal, double* post, int seq) {
+  for (int i = 0; i < 16; i++) __hip_atomic_store(post + i, scal[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  __builtin_amdgcn_s_waitcnt(0);
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  __hip_atomic_store(post + 16, (double)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void derive_scalars(double* s, int phase) {
+  switch (phase) {  // PETSc KSPSolve_BCGS order of operations
+    case 0:  // after R = B^-1 b: DP2 = (R,R); rho = (R,RP) with RP = R
+      s[S_RHO] = s[S_DP2]; s[S_RHOOLD] = 1.0; s[S_ALPHA] = 1.0; s[S_OMEGA] = 1.0; s[S_BREAK] = 0.0;
+      s[S_BETA] = (s[S_RHO] / s[S_RHOOLD]) * (s[S_ALPHA] / s[S_OMEGA]);
+      if (s[S_RHO] == 0.0) s[S_BREAK] = 1.0;
+      break;
+    case 2:  // alpha = rho / (V,RP)
+      if (s[S_D1] == 0.0) s[S_BREAK] = 1.0;
+      s[S_ALPHA] = s[S_RHO] / s[S_D1];
+      break;
+    case 3:  // omega = (S,T)/(T,T)
+      // (T,T) = 0: KSPSolve_BCGS then tests (S,S) -- zero means the half step already solved the
+      // system (exact preconditioner: a single subdomain), x += alpha P and converged; otherwise
+      // breakdown.  omega = 0 makes the X/R update do exactly that: X += alpha P, R = S, so the
+      // (R,R) it reduces is (S,S) for the host to look at.
+      if (s[S_D2] == 0.0) { s[S_BREAK] = 2.0; s[S_OMEGA] = 0.0; }
+      else s[S_OMEGA] = s[S_D1] / s[S_D2];
+      break;
+    case 5: {  // merged reductions (multi-rank): slots hold (S,T), (T,T), (S,S), (S,RP), (T,RP).
+      // omega as in case 3; then, with R = S - omega T:  (R,RP) = (S,RP) - omega (T,RP)  and
+      // (R,R) = (S,S) - 2 omega (S,T) + omega^2 (T,T) -- one all-reduce instead of two
+      const double st = s[S_D1], tt = s[S_D2], ss = s[S_DP2], srp = s[S_RHONEW], trp = s[S_W2];
+      if (tt == 0.0) { s[S_BREAK] = 2.0; s[S_OMEGA] = 0.0; }
+      else s[S_OMEGA] = st / tt;
+      const double om = s[S_OMEGA];
+      const double rr = (ss - 2.0 * om * st) + om * om * tt;
+      s[S_DP2] = rr > 0.0 ? rr : 0.0;
+      s[S_RHONEW] = srp - om * trp;
+      break;
+    }
+    case 6:  // merged reductions, then the end-of-iteration rotation: the X / R update that runs between the
+             // two in KSPSolve_BCGS reads alpha and omega only, which the rotation leaves alone
+      derive_scalars(s, 5);
+      derive_scalars(s, 4);
+      break;
+    case 4:  // end of iteration: rotate rho, next beta = (rho/rhoold)*(alpha/omega)
+      s[S_RHOOLD] = s[S_RHO]; s[S_RHO] = s[S_RHONEW];
+      if (s[S_RHO] == 0.0 && s[S_BREAK] == 0.0) s[S_BREAK] = 3.0;  // only matters if not converged
+      s[S_BETA] = (s[S_RHO] / s[S_RHOOLD]) * (s[S_ALPHA] / s[S_OMEGA]);
+      break;
+    default: break;
+  }
+}
+
+// Finalisation inside the producing launch (Fin, context.hpp).  A launch that carries a Fin has ONE
+// workgroup more than it has work: the extra one -- the last index, dispatched after every other -- waits
+// for the partial sums to arrive, sums them and derives the BiCGStab scalars.  The working workgroups do
+// nothing beyond storing their partial (agent scope: written through, coherent across the XCDs' L2s).
+// Arrival is read off the data: an empty partial slot holds FIN_EMPTY (a NaN payload no sum produces), and
+// whoever consumes a partial -- this workgroup or k_finalize -- leaves the slot empty again.
+// The sums are formed exactly as k_finalize forms them (virtual threads v < VT stride over the partials, a
+// 64-lane shuffle tree per virtual wave, the wave sums added in order): the bits do not depend on timing
+// and equal what the separate launch gave.
+// MEASURED dead ends at 216^3 (k_pc_park, 0.60 ms per launch without any of this): arrival through a
+// device-scope fence + counter in every workgroup, 1.435 ms (__threadfence writes back and invalidates the
+// XCD's whole L2, 21 168 times: the x gathers lose their reuse); relaxed agent-scope atomics on two-level
+// counters, no fence, 0.70 ms (each workgroup holds its CU slot ~2 us longer for the store acknowledgement
+// and the returning atomic).
+constexpr unsigned long long FIN_EMPTY = 0x7FF4DEADBEEF0001ull;
+__device__ __forceinline__ double fin_take(const double* p, bool wait) {
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(const_cast<double*>(p));
+  unsigned long long u = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // bounded: a partial that never arrives becomes a NaN sum (KSP_DIVERGED_NANORINF), not a hung device
+  for (int spin = 0; wait && u == FIN_EMPTY && spin < (1 << 22); spin++) {
+    __builtin_amdgcn_s_sleep(8);
+    u = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __hip_atomic_store(q, FIN_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __longlong_as_double((long long)u);   // FIN_EMPTY itself is a NaN
+}
+// sums of nslots slots -> scal, k_finalize's order, by a workgroup of any size (multiple of 64)
+__device__ __forceinline__ void sum_partials(const double* partials, int nb_max, int nb, int slot0, int nslots,
+                                             double* scal, bool wait) {
+  __shared__ double fsm[16];
+  const int VT = nb > 256 ? 1024 : 256;
+  for (int s = 0; s < nslots; s++) {
+    const double* ps = partials + (size_t)(slot0 + s) * nb_max;
+    for (int v = threadIdx.x; v < VT; v += blockDim.x) {   // whole waves: blockDim is a multiple of 64
+      double t = 0.0;
+      for (int i = v; i < nb; i += VT) t += fin_take(ps + i, wait);
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+      if ((v & 63) == 0) fsm[v >> 6] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tot = 0.0;
+      for (int w = 0; w < (VT >> 6); w++) tot += fsm[w];
+      scal[slot0 + s] = tot;
+    }
+    __syncthreads();
+  }
+}
+// is this workgroup the launch's finaliser?  If so do the finalisation (the caller returns)
+__device__ __forceinline__ bool fin_block(const Fin& f, const double* partials, int nb_max) {
+  if (f.count == 0 || blockIdx.x != gridDim.x - 1) return false;
+  sum_partials(partials, nb_max, f.nb, f.slot0, f.nslots, f.scal, true);
+  if (threadIdx.x == 0) {
+    if (f.phase >= 0) derive_scalars(f.scal, f.phase);
+    if (f.seq > 0) post_scalars(f.scal, f.post, f.seq);
+  }
+  return true;
+}
+
 // ---- K6+K8 fused: z = U^-1 L^-1 (A x)  or  z = U^-1 L^-1 r ------------------------------------
+// A workgroup's partial sum: stored at agent scope (written through to memory, coherent across the XCDs' L2s)
+// so that the workgroup that finishes a reduction (fin_tail) can read it without any cache-wide fence
+__device__ __forceinline__ void store_partial(double* p, double t) {
+  __hip_atomic_store(p, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int NS>
 __device__ __forceinline__ void wg_reduce_store(double (&v)[NS], double* red, double* partials,
                                                 int nb_max, const int* slots, int blk) {
@@ -440,7 +655,7 @@ __device__ __forceinline__ void wg_reduce_store(double (&v)[NS], double* red, do
     for (int s = 0; s < NS; s++) {
       double t = 0.0;
       for (int q = 0; q < nw; q++) t += red[s * 16 + q];
-      partials[(size_t)slots[s] * nb_max + blk] = t;
+      store_partial(partials + (size_t)slots[s] * nb_max + blk, t);
     }
   }
 }
@@ -458,13 +673,14 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
                      const double* __restrict__ in,
                      double* __restrict__ z, const double* __restrict__ aux, double* partials,
                      int nb_max, int dot, int dbg,
-    const int* __restrict__ sub_list) {
+    const int* __restrict__ sub_list, Fin fin) {
   constexpr int BB = BS * BS;
   // DILU == 2: rows pre-scaled by the inverted pivots (k_scale_rows): A' = inv(P) A lives in fval,
   // the pivots of ILU(0)(A') are identities, so neither dinv nor its two products per row are needed
   constexpr bool SC = (DILU == 2);
   const double* __restrict__ mat = SC ? fval : aval;
   extern __shared__ double lds[];  // [T * BS] solution vector, then 80 doubles reduction scratch
+  if (fin_block(fin, partials, nb_max)) return;
   int s = xcd_remap(blockIdx.x, nsub);
   if (s >= nsub) return;
   if (sub_list) s = sub_list[s];
@@ -798,11 +1014,12 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
     const int* __restrict__ row_info, const int* __restrict__ row_uoff, const int* __restrict__ col,
     const double* __restrict__ sval, const double* __restrict__ dinv, const double* __restrict__ in,
     double* __restrict__ z, const double* __restrict__ aux, double* partials, int nb_max, int dot,
-    const int* __restrict__ sub_list) {
+    const int* __restrict__ sub_list, Fin fin) {
   constexpr int BS = 2, BB = 4, MLU = 3;
   extern __shared__ double lds[];  // [T*2] solution, [80] reduction scratch, then parked U blocks
   // nsub subdomains to run: all of them, or (sub_list) the listed ones -- the bricks that touch no
   // partition ghost while the halo exchange is in flight, the others after it
+  if (fin_block(fin, partials, nb_max)) return;
   int s = xcd_remap(blockIdx.x, nsub);
   if (s >= nsub) return;
   if (sub_list) s = sub_list[s];
@@ -971,8 +1188,9 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
     const int* __restrict__ row_info, const int* __restrict__ col, const double* __restrict__ sval,
     const double* __restrict__ dinv, const double* __restrict__ in, double* __restrict__ z,
     const double* __restrict__ aux, double* partials, int nb_max, int dot, const int* __restrict__ sub_list,
-    const int* __restrict__ rowptr, const int* __restrict__ sub_split) {
+    const int* __restrict__ rowptr, const int* __restrict__ sub_split, Fin fin) {
   extern __shared__ double lds[];  // [R*BS] solution in block order, [BS] zeros, then reduction scratch
+  if (fin_block(fin, partials, nb_max)) return;
   int s = xcd_remap(blockIdx.x, nsub);
   if (s >= nsub) return;
   if (sub_list) s = sub_list[s];
@@ -1148,7 +1366,7 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[NS], double* part
       double t = 0.0;
 #pragma unroll
       for (int w = 0; w < TPB / 64; w++) t += sm[s][w];
-      partials[(size_t)slots[s] * nb_max + blockIdx.x] = t;
+      store_partial(partials + (size_t)slots[s] * nb_max + blockIdx.x, t);
     }
   }
 }
@@ -1161,69 +1379,24 @@ __global__ __launch_bounds__(TPB) void k_dot(const double* __restrict__ a, const
   block_reduce_store<1>(v, partials, nb_max, slots);
 }
 
-__device__ __forceinline__ void derive_scalars(double* s, int phase) {
-  switch (phase) {  // PETSc KSPSolve_BCGS order of operations
-    case 0:  // after R = B^-1 b: DP2 = (R,R); rho = (R,RP) with RP = R
-      s[S_RHO] = s[S_DP2]; s[S_RHOOLD] = 1.0; s[S_ALPHA] = 1.0; s[S_OMEGA] = 1.0; s[S_BREAK] = 0.0;
-      s[S_BETA] = (s[S_RHO] / s[S_RHOOLD]) * (s[S_ALPHA] / s[S_OMEGA]);
-      if (s[S_RHO] == 0.0) s[S_BREAK] = 1.0;
-      break;
-    case 2:  // alpha = rho / (V,RP)
-      if (s[S_D1] == 0.0) s[S_BREAK] = 1.0;
-      s[S_ALPHA] = s[S_RHO] / s[S_D1];
-      break;
-    case 3:  // omega = (S,T)/(T,T)
-      // (T,T) = 0: KSPSolve_BCGS then tests (S,S) -- zero means the half step already solved the
-      // system (exact preconditioner: a single subdomain), x += alpha P and converged; otherwise
-      // breakdown.  omega = 0 makes the X/R update do exactly that: X += alpha P, R = S, so the
-      // (R,R) it reduces is (S,S) for the host to look at.
-      if (s[S_D2] == 0.0) { s[S_BREAK] = 2.0; s[S_OMEGA] = 0.0; }
-      else s[S_OMEGA] = s[S_D1] / s[S_D2];
-      break;
-    case 5: {  // merged reductions (multi-rank): slots hold (S,T), (T,T), (S,S), (S,RP), (T,RP).
-      // omega as in case 3; then, with R = S - omega T:  (R,RP) = (S,RP) - omega (T,RP)  and
-      // (R,R) = (S,S) - 2 omega (S,T) + omega^2 (T,T) -- one all-reduce instead of two
-      const double st = s[S_D1], tt = s[S_D2], ss = s[S_DP2], srp = s[S_RHONEW], trp = s[S_W2];
-      if (tt == 0.0) { s[S_BREAK] = 2.0; s[S_OMEGA] = 0.0; }
-      else s[S_OMEGA] = st / tt;
-      const double om = s[S_OMEGA];
-      const double rr = (ss - 2.0 * om * st) + om * om * tt;
-      s[S_DP2] = rr > 0.0 ? rr : 0.0;
-      s[S_RHONEW] = srp - om * trp;
-      break;
-    }
-    case 4:  // end of iteration: rotate rho, next beta = (rho/rhoold)*(alpha/omega)
-      s[S_RHOOLD] = s[S_RHO]; s[S_RHO] = s[S_RHONEW];
-      if (s[S_RHO] == 0.0 && s[S_BREAK] == 0.0) s[S_BREAK] = 3.0;  // only matters if not converged
-      s[S_BETA] = (s[S_RHO] / s[S_RHOOLD]) * (s[S_ALPHA] / s[S_OMEGA]);
-      break;
-    default: break;
-  }
-}
-
 // sum the per-block partials of up to 4 reduction slots into scal[...], then derive
 __global__ __launch_bounds__(1024) void k_finalize(const double* __restrict__ partials, int nb_max, int nb,
-                                                   int4 slots, int nslots, double* scal, int phase) {
-  __shared__ double sm[16];
-  const int sl[4] = {slots.x, slots.y, slots.z, slots.w};
-  for (int s = 0; s < nslots; s++) {
-    double t = 0.0;
-    for (int i = threadIdx.x; i < nb; i += blockDim.x) t += partials[(size_t)sl[s] * nb_max + i];
-    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double tot = 0.0;
-      for (int w = 0; w < (int)(blockDim.x >> 6); w++) tot += sm[w];
-      scal[sl[s]] = tot;
-    }
-    __syncthreads();
-  }
+                                                   int slot0, int nslots, double* scal, int phase) {
+  sum_partials(partials, nb_max, nb, slot0, nslots, scal, false);   // consumed slots are left empty (FIN_EMPTY)
   if (threadIdx.x == 0 && phase >= 0) derive_scalars(scal, phase);
 }
 
-__global__ void k_bcgs_scalars(double* s, int phase) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) derive_scalars(s, phase);
+// every partial slot of [slot0, slot0 + nslots) empty: before a solve, whatever an aborted one left
+__global__ __launch_bounds__(TPB) void k_partials_clear(double* partials, int nb_max, int slot0, int nslots) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i < (size_t)nslots * nb_max) reinterpret_cast<unsigned long long*>(partials)[(size_t)slot0 * nb_max + i] = FIN_EMPTY;
+}
+
+__global__ void k_bcgs_scalars(double* s, int phase, double* post, int seq) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    derive_scalars(s, phase);
+    if (seq > 0) post_scalars(s, post, seq);
+  }
 }
 
 // streaming vector accesses of the BiCGStab updates: every element is touched once per launch
@@ -1265,10 +1438,12 @@ __global__ __launch_bounds__(TPB) void k_bcgs_xr(double* __restrict__ X, double*
                                                  const double* __restrict__ P, const double* __restrict__ S,
                                                  const double* __restrict__ T, const double* __restrict__ RP,
                                                  int n, const double* __restrict__ s, double* partials,
-                                                 int nb_max) {
+                                                 int nb_max, Fin fin) {
+  if (fin_block(fin, partials, nb_max)) return;
+  const int nblk = fin.count > 0 ? gridDim.x - 1 : gridDim.x;   // the finaliser is one workgroup more
   const double alpha = s[S_ALPHA], omega = s[S_OMEGA];
   double v[2] = {0.0, 0.0};
-  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += nblk * TPB) {
     const double si = ldv(S + i);
     stv(X + i, ldv(X + i) + alpha * ldv(P + i) + omega * si);
     const double r = si - omega * ldv(T + i);
@@ -1347,6 +1522,7 @@ static inline int vgrid(int n) {
 
 int launch_spmv(wai_ctx* c, const double* x, double* y) {
   const Bcsr& J = c->J;
+  c->ks.n_launch++;
   const int nblk = (J.n + TPB - 1) / TPB;
   const int grid = ((nblk + 7) / 8) * 8;
   const int* rp = (size_t)J.nnzb * 10 < (size_t)J.n * J.W * 9 ? J.rowptr : nullptr;   // > 10 % padding
@@ -1552,7 +1728,7 @@ int launch_ilu_factor_on(wai_ctx* c, const Bcsr& J, IluSchedule& s) {
     return 0;
   }
   const int grid = ((s.nsub + 7) / 8) * 8, T = pc_threads(s);
-  if (s.diag_only && s.scaled && !getenv("WAI_ILU_FULL_FACTOR")) {
+  if (s.diag_only && s.scaled) {
     // pivots only, then the scaled rows (below): the general factor is never read in this case
     const size_t lds = (size_t)T * J.bs * J.bs * sizeof(double);
     switch (J.bs) {
@@ -1562,7 +1738,22 @@ int launch_ilu_factor_on(wai_ctx* c, const Bcsr& J, IluSchedule& s) {
       case 2: if (s.fast3) hipLaunchKernelGGL((k_dilu_pivots<2, true>), grid, T, lds, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.dinv, c->d_flags);
               else hipLaunchKernelGGL((k_dilu_pivots<2, false>), grid, T, lds, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.dinv, c->d_flags);
               break;
-      case 3: hipLaunchKernelGGL((k_dilu_pivots<3, false>), grid, T, lds, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.dinv, c->d_flags); break;
+      case 3: {
+        // couplings' blocks staged in LDS when a brick's fit 64 KB (<= 130 rows with 3 lower couplings); 4 x 4
+        // blocks stay on the general kernel (the staged one compiles to 256 VGPRs + scratch there: not measured)
+        const int npl = s.max_nl <= 3 ? 3 : 4;
+        const size_t lds2 = (size_t)(1 + 2 * npl) * 9 * s.max_rows * sizeof(double);
+        if (s.max_nl <= 4 && lds2 <= 64 * 1024 && T <= 256) {
+          if (npl == 3)
+            hipLaunchKernelGGL((k_dilu_pivots_lds<3, 3>), grid, T, lds2, c->stream, J.n, s.nsub, s.max_rows, s.sub_ptr, s.sub_nlev,
+                               s.row_info, s.row_tslot, J.col, J.val, s.dinv, c->d_flags);
+          else
+            hipLaunchKernelGGL((k_dilu_pivots_lds<3, 4>), grid, T, lds2, c->stream, J.n, s.nsub, s.max_rows, s.sub_ptr, s.sub_nlev,
+                               s.row_info, s.row_tslot, J.col, J.val, s.dinv, c->d_flags);
+        } else
+          hipLaunchKernelGGL((k_dilu_pivots<3, false>), grid, T, lds, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.dinv, c->d_flags);
+        break;
+      }
       case 4: hipLaunchKernelGGL((k_dilu_pivots<4, false>), grid, T, lds, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.dinv, c->d_flags); break;
       default: return -1;
     }
@@ -1612,20 +1803,24 @@ int launch_big_solve(wai_ctx* c, const Bcsr& J, const IluSchedule& s, double* z)
 
 template <int BS>
 static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool spmv, const double* in, double* z,
-                         int dot_mode, const double* aux, const int* list, int nrun) {
+                         int dot_mode, const double* aux, const int* list, int nrun, const Fin* finp) {
   if (!list) nrun = s.nsub;
-  const int grid = ((nrun + 7) / 8) * 8, T = pc_threads(s);
+  const bool with_fin = finp && dot_mode != 0;
+  Fin fin;
+  if (finp && dot_mode != 0) { fin = *finp; fin.count = nrun; fin.nb = s.nsub; }   // all subdomains' partials are summed
+  c->ks.n_launch++;
+  const int grid = ((nrun + 7) / 8) * 8 + (with_fin ? 1 : 0), T = pc_threads(s);   // + the finaliser (fin_block)
   const size_t lds = ((size_t)T * BS + 80) * sizeof(double);
 #define PCL(SP, DI)                                                                              \
   do {                                                                                           \
     if (s.fast3)                                                                                 \
       hipLaunchKernelGGL((k_pc<BS, SP, DI, true>), grid, T, lds, c->stream, J.n, J.W,            \
                          nrun, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.fval,          \
-                         s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, c->dbg, list); \
+                         s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, c->dbg, list, fin); \
     else                                                                                         \
       hipLaunchKernelGGL((k_pc<BS, SP, DI, false>), grid, T, lds, c->stream, J.n, J.W,           \
                          nrun, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.fval,          \
-                         s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, c->dbg, list); \
+                         s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, c->dbg, list, fin); \
   } while (0)
   // one thread per scalar row: block sizes 3 and 4 (and 2 when asked for: WAI_PC_ROWS=1)
   if (s.rows_kernel && !c->dbg) {
@@ -1635,7 +1830,7 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
 #define PCR(SP, NLU)                                                                               \
     hipLaunchKernelGGL((k_pc_rows<BS, SP, NLU, NLU>), grid, TR, lds_r, c->stream, J.n, J.W, nrun, s.sub_ptr,  \
                        s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, \
-                       dot_mode, list, rp, s.sub_split)
+                       dot_mode, list, rp, s.sub_split, fin)
     if (s.max_nlu <= 3) { if (spmv) PCR(true, 3); else PCR(false, 3); }
     else { if (spmv) PCR(true, 4); else PCR(false, 4); }
 #undef PCR
@@ -1648,11 +1843,11 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
       if (spmv)
         hipLaunchKernelGGL(k_pc_park<true>, grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,
                            s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials,
-                           c->ks.nb_max, dot_mode, list);
+                           c->ks.nb_max, dot_mode, list, fin);
       else
         hipLaunchKernelGGL(k_pc_park<false>, grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,
                            s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials,
-                           c->ks.nb_max, dot_mode, list);
+                           c->ks.nb_max, dot_mode, list, fin);
       return;
     }
   }
@@ -1669,20 +1864,27 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
 }
 
 int launch_pc_on(wai_ctx* c, const Bcsr& M, const IluSchedule& s, bool spmv, const double* in, double* z,
-                 int dot_mode, const double* aux, const int* list, int nrun) {
+                 int dot_mode, const double* aux, const int* list, int nrun, const Fin* fin) {
   switch (M.bs) {
-    case 1: launch_pc_bs<1>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun); break;
-    case 2: launch_pc_bs<2>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun); break;
-    case 3: launch_pc_bs<3>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun); break;
-    case 4: launch_pc_bs<4>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun); break;
+    case 1: launch_pc_bs<1>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun, fin); break;
+    case 2: launch_pc_bs<2>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun, fin); break;
+    case 3: launch_pc_bs<3>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun, fin); break;
+    case 4: launch_pc_bs<4>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun, fin); break;
     default: return -1;
   }
   c->ks.nb_pc = s.nsub;
   return 0;
 }
 int launch_pc(wai_ctx* c, bool spmv, const double* in, double* z, int dot_mode, const double* aux,
-              const int* list, int nrun) {
-  return launch_pc_on(c, c->J, c->ilu, spmv, in, z, dot_mode, aux, list, nrun);
+              const int* list, int nrun, const Fin* fin) {
+  return launch_pc_on(c, c->J, c->ilu, spmv, in, z, dot_mode, aux, list, nrun, fin);
+}
+Fin make_fin(wai_ctx* c, int slot0, int nslots, int phase, bool post) {
+  Fin f;   // count / nb: filled in by the launcher
+  f.slot0 = slot0; f.nslots = nslots; f.phase = phase;
+  f.scal = c->ks.scal; f.post = c->ks.d_post;
+  f.seq = post ? ++c->ks.seq : 0;
+  return f;
 }
 
 int launch_asm_gather_matrix(wai_ctx* c) {
@@ -1717,54 +1919,70 @@ int launch_bcsr_to_ell(wai_ctx* c, const double* bcsr, double* ell) {
 }
 
 int vec_finalize(wai_ctx* c, int nb, int slot0, int nslots, int phase) {
-  int4 sl = make_int4(slot0, slot0 + 1, slot0 + 2, slot0 + 3);
   const int T = nb > 256 ? 1024 : 256;
-  hipLaunchKernelGGL(k_finalize, 1, T, 0, c->stream, c->ks.partials, c->ks.nb_max, nb, sl, nslots, c->ks.scal, phase);
+  c->ks.n_launch++;
+  hipLaunchKernelGGL(k_finalize, 1, T, 0, c->stream, c->ks.partials, c->ks.nb_max, nb, slot0, nslots, c->ks.scal, phase);
   return 0;
 }
 
 int vec_dot(wai_ctx* c, const double* a, const double* b, int n, int slot) {
   const int g = vgrid(n);
+  c->ks.n_launch++;
   hipLaunchKernelGGL(k_dot, g, TPB, 0, c->stream, a, b, n, c->ks.partials, c->ks.nb_max, slot);
   return vec_finalize(c, g, slot, 1, -1);
 }
 int vec_dots(wai_ctx* c, const double* a1, const double* b1, int slot1, const double* a2, const double* b2,
              int slot2, int n) {
   const int g = vgrid(n);
+  c->ks.n_launch++;
   hipLaunchKernelGGL(k_dots, g, TPB, 0, c->stream, a1, b1, slot1, a2, b2, slot2, n, c->ks.partials, c->ks.nb_max);
   c->ks.nb_pc = g;
   return 0;
 }
+int partials_clear(wai_ctx* c, int slot0, int nslots) {
+  const size_t tot = (size_t)nslots * c->ks.nb_max;
+  c->ks.n_launch++;
+  hipLaunchKernelGGL(k_partials_clear, (int)((tot + TPB - 1) / TPB), TPB, 0, c->stream, c->ks.partials, c->ks.nb_max, slot0, nslots);
+  return 0;
+}
 int vec_copy(wai_ctx* c, double* dst, const double* src, size_t n) {
+  c->ks.n_copy++;
   return hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream) == hipSuccess ? 0 : -1;
 }
 int vec_zero(wai_ctx* c, double* dst, size_t n) {
   return hipMemsetAsync(dst, 0, n * sizeof(double), c->stream) == hipSuccess ? 0 : -1;
 }
 int vec_waxpy(wai_ctx* c, double* w, double alpha, const double* x, const double* y, int n) {
+  c->ks.n_launch++;
   hipLaunchKernelGGL(k_waxpy, vgrid(n), TPB, 0, c->stream, w, alpha, x, y, n);
   return 0;
 }
-int bcgs_scalars(wai_ctx* c, int phase) {
-  hipLaunchKernelGGL(k_bcgs_scalars, 1, 64, 0, c->stream, c->ks.scal, phase);
+int bcgs_scalars(wai_ctx* c, int phase, bool post) {
+  c->ks.n_launch++;
+  hipLaunchKernelGGL(k_bcgs_scalars, 1, 64, 0, c->stream, c->ks.scal, phase, c->ks.d_post, post ? ++c->ks.seq : 0);
   return 0;
 }
 int bcgs_update_p(wai_ctx* c) {
+  c->ks.n_launch++;
   hipLaunchKernelGGL(k_bcgs_p, vgrid(c->ks.n), TPB, 0, c->stream, c->ks.P, c->ks.R, c->ks.V, c->ks.n, c->ks.scal);
   return 0;
 }
 int bcgs_update_s(wai_ctx* c) {
+  c->ks.n_launch++;
   hipLaunchKernelGGL(k_bcgs_s, vgrid(c->ks.n), TPB, 0, c->stream, c->ks.S, c->ks.R, c->ks.V, c->ks.n, c->ks.scal);
   return 0;
 }
-int bcgs_update_xr(wai_ctx* c, bool dots) {
+int bcgs_update_xr(wai_ctx* c, bool dots, int fin_phase, bool post) {
   const int g = vgrid(c->ks.n);
+  Fin fin;
+  if (dots && fin_phase >= -1) { fin = make_fin(c, S_DP2, 2, fin_phase, post); fin.count = g; fin.nb = g; }
+  c->ks.n_launch++;
   if (dots)
-    hipLaunchKernelGGL(k_bcgs_xr<true>, g, TPB, 0, c->stream, c->ks.X, c->ks.R, c->ks.P, c->ks.S, c->ks.T,
-                       c->ks.RP, c->ks.n, c->ks.scal, c->ks.partials, c->ks.nb_max);
+    hipLaunchKernelGGL(k_bcgs_xr<true>, g + (fin.count > 0 ? 1 : 0), TPB, 0, c->stream, c->ks.X, c->ks.R, c->ks.P, c->ks.S, c->ks.T,
+                       c->ks.RP, c->ks.n, c->ks.scal, c->ks.partials, c->ks.nb_max, fin);
   else
     hipLaunchKernelGGL(k_bcgs_xr<false>, g, TPB, 0, c->stream, c->ks.X, c->ks.R, c->ks.P, c->ks.S, c->ks.T,
-                       c->ks.RP, c->ks.n, c->ks.scal, c->ks.partials, c->ks.nb_max);
+                       c->ks.RP, c->ks.n, c->ks.scal, c->ks.partials, c->ks.nb_max, fin);
   c->ks.nblocks = g;
   return 0;
 }
@@ -1798,6 +2016,7 @@ int gmres_update_x(wai_ctx* c, double* x, const double* ycoef_host, int k) {
 int pack_halo(wai_ctx* c, const double* vec, int dof, hipStream_t stream) {
   const int n = c->send_total;
   if (n <= 0) return 0;
+  c->ks.n_launch++;
   hipLaunchKernelGGL(k_pack, (n * dof + TPB - 1) / TPB, TPB, 0, stream ? stream : c->stream, vec, c->d_send_idx, n,
                      dof, c->d_sendbuf);
   return 0;
@@ -1806,6 +2025,7 @@ int unpack_halo(wai_ctx* c, double* vec, int dof, hipStream_t stream) {
   // halo cells are contiguous after the owned cells and the receive buffer is in halo order
   const size_t n = (size_t)c->mesh.n_halo * dof;
   if (n == 0) return 0;
+  c->ks.n_copy++;
   return hipMemcpyAsync(vec + (size_t)c->mesh.n_owned * dof, c->d_recvbuf, n * sizeof(double),
                         hipMemcpyDeviceToDevice, stream ? stream : c->stream) == hipSuccess ? 0 : -1;
 }

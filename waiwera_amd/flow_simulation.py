@@ -175,6 +175,12 @@ class FlowSimulation:
         LIB.wai_comm_stats(self.h, C.byref(a), C.byref(e))
         return a.value, e.value
 
+    def launch_stats(self):
+        """(kernels launched, copies enqueued) by the linear-solver helpers so far"""
+        a, e = C.c_longlong(0), C.c_longlong(0)
+        LIB.wai_launch_stats(self.h, C.byref(a), C.byref(e))
+        return a.value, e.value
+
     def pc_kernel_name(self):
         return LIB.wai_pc_kernel_name(self.h).decode()
 

@@ -118,6 +118,8 @@ def _load():
         "wai_set_source_network": (i32, [vp, pi, pi, i32, pi, pi, pi, pi, pi, pd, pd, i32, pi, pi, pi, pi, pi, pi, pd, pd, pd, pi, pi]),
         "wai_network_evaluate": (i32, [i32, pd, pd, pd, pi, pi, i32, pi, pi, pi, pi, pi, pd, pd, i32, pi, pi, pi, pi, pi, pi, pd, pd,
                                        pd, pi, pi, pd, pd, pd]),
+        "wai_network_cells": (i32, [i32, pi, pi, pi, i32, pi, pi, pi, pi, pi, pd, pd, i32, pi, pi, pi, pi, pi, pi, pd, pd,
+                                    pd, pi, pi, pi, pi]),
         "wai_get_source_network": (i32, [vp, pd, pd]),
         "wai_set_network_couplings": (i32, [vp, i32]),
         "wai_get_network_couplings": (i32, [vp, pi, pi, pd]),
@@ -136,6 +138,7 @@ def _load():
         "wai_halo_exchange": (i32, [vp, vp, i32]),
         "wai_comm_size": (i32, [vp]),
         "wai_comm_stats": (i32, [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+        "wai_launch_stats": (i32, [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
         "wai_pc_kernel_name": (C.c_char_p, [vp]),
         "wai_pre_timestep": (i32, [vp]),
         "wai_pre_retry_timestep": (i32, [vp]),
@@ -284,6 +287,18 @@ def network_arrays(spec):
     args = [P(rs), P(es), len(g), P(gptr), P(gk), P(gi), P(gs), P(glt), P(gl), P(gsep), len(r), P(rk), P(ri), P(rptr),
             P(of), P(ok), P(on), P(orate), P(oprop), P(oenth), P(vk), P(vi)]
     return keep, args
+
+
+def network_cells(spec, source_cell):
+    """the cells between which the network's Jacobian coupling blocks are formed (wai_network_cells)"""
+    keep, args = network_arrays(spec)
+    sc = _i32(source_cell)
+    out = np.zeros(len(sc), dtype=np.int32)
+    m = C.c_int(0)
+    rc = LIB.wai_network_cells(len(sc), sc.ctypes.data_as(pi), *args, C.byref(m), out.ctypes.data_as(pi))
+    if rc != 0:
+        raise WaiError("wai_network_cells failed (%d)" % rc)
+    return out[: m.value].copy()
 
 
 def network_evaluate(spec, rate, enthalpy, src_sep=None):
