@@ -125,6 +125,8 @@ def load(path):
         "wo_sim_set_asm": (None, [C.c_void_p, i32]),
         "wo_sim_asm_rows": (i32, [C.c_void_p, pi, pi]),
         "wo_sim_set_pc_none": (None, [C.c_void_p, i32]),
+        "wo_sim_set_ilu_levels": (None, [C.c_void_p, i32]),
+        "wo_sim_local_pattern": (i32, [C.c_void_p, i32, pi, pi]),
         "wo_sim_spread_pages": (None, [C.c_void_p]),
         "wo_pc_setup": (i32, [C.c_void_p, pd]),
         "wo_pc_apply": (None, [C.c_void_p, pd, pd]),
@@ -235,6 +237,19 @@ class OracleSim:
     def set_asm(self, overlap, *_):
         """PCASM (restricted) with `overlap` layers around the subdomains; 0: block Jacobi"""
         self.L.wo_sim_set_asm(self.h, int(overlap))
+
+    def set_ilu_levels(self, levels):
+        """ILU(k) sub-preconditioner: levels of fill (0: ILU(0)); with block Jacobi or PCASM"""
+        self.L.wo_sim_set_ilu_levels(self.h, int(levels))
+
+    def local_pattern(self, sd):
+        """(rowptr, colidx) of subdomain sd's local system after fill, local column indices"""
+        nz = self.L.wo_sim_local_pattern(self.h, int(sd), None, None)
+        ptr, rows = self.asm_rows()
+        m = int(ptr[sd + 1] - ptr[sd])
+        rp, ci = np.zeros(m + 1, dtype=np.int32), np.zeros(max(nz, 1), dtype=np.int32)
+        self.L.wo_sim_local_pattern(self.h, int(sd), ip(rp), ip(ci))
+        return rp, ci[:nz]
 
     def asm_rows(self):
         n = self.L.wo_sim_asm_rows(self.h, None, None)

@@ -186,6 +186,11 @@ void wo_sim_set_subdomains(wo_sim *s, int nsub, const int *sub_ptr);
  * overlap 1); 0 = block Jacobi (PCBJACOBI).  Call after wo_sim_set_subdomains. */
 void wo_sim_set_asm(wo_sim *s, int overlap);
 int wo_sim_asm_rows(wo_sim *s, int *ptr, int *rows);
+/* ILU(k) sub-preconditioner: levels of fill ("sub_preconditioner": {"factor": {"levels": k}},
+ * src/timestepper.F90:1716-1718, 1827; PETSc PCFactorSetLevels); 0 = ILU(0).  With block Jacobi or PCASM. */
+void wo_sim_set_ilu_levels(wo_sim *s, int levels);
+/* the filled pattern of subdomain sd's local system (local columns): nnz returned; arrays may be NULL (count) */
+int wo_sim_local_pattern(wo_sim *s, int sd, int *rowptr, int *colidx);
 void wo_sim_set_pc_none(wo_sim *s, int none);
 void wo_sim_spread_pages(wo_sim *s);  /* first-touch re-homing of the matrix pattern over the OpenMP team */   /* PCNONE (:1747-1748) */
 int wo_pc_setup(wo_sim *s, const double *val);

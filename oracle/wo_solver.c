@@ -44,6 +44,7 @@ struct wo_sim {
    * the overlapped row set, its local CSR pattern with the index of every kept block in the
    * global matrix, and its own ILU(0) factor */
   int asm_overlap, pc_none;
+  int ilu_levels;       /* PCFactorSetLevels (src/timestepper.F90:1716-1718, 1827): fill levels of the sub-preconditioner's ILU(k) */
   int *asm_ptr, *asm_rows;      /* overlapped rows of subdomain s: asm_rows[asm_ptr[s] .. asm_ptr[s+1]) ascending */
   int *asm_rowptr, *asm_col, *asm_src; /* local CSR over all overlapped rows; columns local to the subdomain */
   double *asm_fval, *asm_dinv;
@@ -918,13 +919,77 @@ void wo_bilu0_apply(int n, int bs, const int *rowptr, const int *colidx, const d
  * index.  z = sum_s R0_s^T ILU0(A[O_s,O_s])^-1 R_s r: the residual is restricted to the
  * overlapped set, only the subdomain's own rows are prolonged back.  overlap = 0 is block Jacobi.
  * Overlap does not reach across ranks here (the halo cells' matrix rows live on the neighbour). */
+/* ---- ILU(k) [PETSc MatILUFactorSymbolic, levels of fill] ---------------------------------------
+ * "sub_preconditioner": {"factor": {"levels": k}} (src/timestepper.F90:1716-1718, PCFactorSetLevels :1827).
+ * Symbolic phase on one subdomain's local CSR (ascending local columns): an entry (i, j) created while
+ * eliminating k gets the level lev(i, k) + lev(k, j) + 1 (original entries have level 0, an entry reached
+ * twice keeps the smaller level) and is kept when that is <= k.  The numeric factorisation is then the IKJ
+ * elimination restricted to the kept pattern -- i.e. wo_bilu0_factor on the pattern with explicit zeros.
+ * Returns the filled CSR; src2 maps an entry to its source in the input (-1: fill). */
+static void iluk_fill(int m, const int *rp, const int *col, const int *src, int levels,
+                      int **rp2, int **col2, int **src2) {
+  size_t cap = (size_t)(rp[m] - rp[0]) * (size_t)(1 + 2 * levels) + 64, nz = 0;
+  int *orp = (int *)xmalloc(sizeof(int) * (m + 1)), *ocol = (int *)xmalloc(sizeof(int) * cap);
+  int *osrc = (int *)xmalloc(sizeof(int) * cap), *olev = (int *)xmalloc(sizeof(int) * cap);
+  int *odiag = (int *)xmalloc(sizeof(int) * m);       /* position of the diagonal of every finished row */
+  int wcap = 256, wn;
+  int *wc = (int *)xmalloc(sizeof(int) * wcap), *wl = (int *)xmalloc(sizeof(int) * wcap), *ws = (int *)xmalloc(sizeof(int) * wcap);
+  for (int i = 0; i < m; i++) {
+    wn = 0;
+    for (int q = rp[i]; q < rp[i + 1]; q++) {
+      if (wn + 1 > wcap) { wcap *= 2; wc = (int *)realloc(wc, sizeof(int) * wcap); wl = (int *)realloc(wl, sizeof(int) * wcap); ws = (int *)realloc(ws, sizeof(int) * wcap); }
+      wc[wn] = col[q]; wl[wn] = 0; ws[wn] = src ? src[q] : q; wn++;
+    }
+    for (int a = 0; a < wn && wc[a] < i; a++) {         /* eliminate with row k = wc[a], in ascending order */
+      int k = wc[a], lik = wl[a];
+      for (size_t r = (size_t)odiag[k] + 1; r < (size_t)orp[k + 1]; r++) {
+        int j = ocol[r], lv = lik + olev[r] + 1;
+        if (lv > levels) continue;
+        int b = a + 1;
+        while (b < wn && wc[b] < j) b++;
+        if (b < wn && wc[b] == j) { if (lv < wl[b]) wl[b] = lv; continue; }
+        if (wn + 1 > wcap) { wcap *= 2; wc = (int *)realloc(wc, sizeof(int) * wcap); wl = (int *)realloc(wl, sizeof(int) * wcap); ws = (int *)realloc(ws, sizeof(int) * wcap); }
+        memmove(wc + b + 1, wc + b, sizeof(int) * (wn - b));
+        memmove(wl + b + 1, wl + b, sizeof(int) * (wn - b));
+        memmove(ws + b + 1, ws + b, sizeof(int) * (wn - b));
+        wc[b] = j; wl[b] = lv; ws[b] = -1; wn++;
+      }
+    }
+    if (nz + wn > cap) {
+      cap = (nz + wn) * 2;
+      ocol = (int *)realloc(ocol, sizeof(int) * cap); osrc = (int *)realloc(osrc, sizeof(int) * cap); olev = (int *)realloc(olev, sizeof(int) * cap);
+    }
+    orp[i] = (int)nz;
+    odiag[i] = -1;
+    for (int a = 0; a < wn; a++) {
+      if (wc[a] == i) odiag[i] = (int)nz;
+      ocol[nz] = wc[a]; osrc[nz] = ws[a]; olev[nz] = wl[a]; nz++;
+    }
+    orp[i + 1] = (int)nz;
+    if (odiag[i] < 0) odiag[i] = orp[i + 1] - 1;        /* structurally missing diagonal: the factorisation reports it */
+  }
+  free(wc); free(wl); free(ws); free(olev); free(odiag);
+  *rp2 = orp; *col2 = ocol; *src2 = osrc;
+}
+
+static void asm_build(wo_sim *s);
 void wo_sim_set_asm(wo_sim *s, int overlap) {
+  s->asm_overlap = overlap > 0 ? overlap : 0;
+  asm_build(s);
+}
+/* fill levels of the sub-preconditioner's ILU(k); 0: ILU(0).  Call after wo_sim_set_subdomains. */
+void wo_sim_set_ilu_levels(wo_sim *s, int levels) {
+  s->ilu_levels = levels > 0 ? levels : 0;
+  asm_build(s);
+}
+/* the local systems of the general preconditioner path: overlapped row sets (overlap >= 1) and / or
+ * ILU(k) fill (levels >= 1) */
+static void asm_build(wo_sim *s) {
   free(s->asm_ptr); free(s->asm_rows); free(s->asm_rowptr); free(s->asm_col); free(s->asm_src);
   free(s->asm_fval); free(s->asm_dinv);
   s->asm_ptr = s->asm_rows = s->asm_rowptr = s->asm_col = s->asm_src = NULL;
   s->asm_fval = s->asm_dinv = NULL;
-  s->asm_overlap = overlap > 0 ? overlap : 0;
-  if (!s->asm_overlap) return;
+  if (!s->asm_overlap && !s->ilu_levels) return;
   int n = s->n_owned, nsub = s->nsub;
   int *mark = (int *)xmalloc(sizeof(int) * n), *loc = (int *)xmalloc(sizeof(int) * n);
   for (int i = 0; i < n; i++) mark[i] = -1;
@@ -981,23 +1046,57 @@ void wo_sim_set_asm(wo_sim *s, int overlap) {
     }
   }
   s->asm_rowptr[nrows] = (int)nz;
+  if (s->ilu_levels > 0) {   /* level-k fill inside every local system */
+    int **frp = (int **)xmalloc(sizeof(int *) * nsub), **fcol = (int **)xmalloc(sizeof(int *) * nsub), **fsrc = (int **)xmalloc(sizeof(int *) * nsub);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int sd = 0; sd < nsub; sd++) {
+      int a = s->asm_ptr[sd], m = s->asm_ptr[sd + 1] - a, z0 = s->asm_rowptr[a];
+      int *lrp = (int *)xmalloc(sizeof(int) * (m + 1));
+      for (int q = 0; q <= m; q++) lrp[q] = s->asm_rowptr[a + q] - z0;
+      iluk_fill(m, lrp, s->asm_col + z0, s->asm_src + z0, s->ilu_levels, &frp[sd], &fcol[sd], &fsrc[sd]);
+      free(lrp);
+    }
+    size_t tot = 0;
+    for (int sd = 0; sd < nsub; sd++) tot += (size_t)frp[sd][s->asm_ptr[sd + 1] - s->asm_ptr[sd]];
+    free(s->asm_col); free(s->asm_src);
+    s->asm_col = (int *)xmalloc(sizeof(int) * tot);
+    s->asm_src = (int *)xmalloc(sizeof(int) * tot);
+    nz = 0;
+    for (int sd = 0; sd < nsub; sd++) {
+      int a = s->asm_ptr[sd], m = s->asm_ptr[sd + 1] - a;
+      for (int q = 0; q < m; q++) s->asm_rowptr[a + q] = (int)nz + frp[sd][q];
+      memcpy(s->asm_col + nz, fcol[sd], sizeof(int) * frp[sd][m]);
+      memcpy(s->asm_src + nz, fsrc[sd], sizeof(int) * frp[sd][m]);
+      nz += (size_t)frp[sd][m];
+      free(frp[sd]); free(fcol[sd]); free(fsrc[sd]);
+    }
+    s->asm_rowptr[nrows] = (int)nz;
+    free(frp); free(fcol); free(fsrc);
+  }
   int bb = MAXBS * MAXBS;
   s->asm_fval = (double *)xmalloc(sizeof(double) * nz * bb);
   s->asm_dinv = (double *)xmalloc(sizeof(double) * nrows * bb);
   free(mark); free(loc);
 }
 int wo_sim_asm_rows(wo_sim *s, int *ptr, int *rows) { /* sizes: nsub+1, asm_ptr[nsub]; NULL: count only */
-  if (!s->asm_overlap) return 0;
+  if (!s->asm_overlap && !s->ilu_levels) return 0;
   if (ptr) memcpy(ptr, s->asm_ptr, sizeof(int) * (s->nsub + 1));
   if (rows) memcpy(rows, s->asm_rows, sizeof(int) * s->asm_ptr[s->nsub]);
   return s->asm_ptr[s->nsub];
+}
+int wo_sim_local_pattern(wo_sim *s, int sd, int *rowptr, int *colidx) {
+  if ((!s->asm_overlap && !s->ilu_levels) || sd < 0 || sd >= s->nsub) return 0;
+  int a = s->asm_ptr[sd], m = s->asm_ptr[sd + 1] - a, z0 = s->asm_rowptr[a];
+  if (rowptr) for (int q = 0; q <= m; q++) rowptr[q] = s->asm_rowptr[a + q] - z0;
+  if (colidx) memcpy(colidx, s->asm_col + z0, sizeof(int) * (s->asm_rowptr[a + m] - z0));
+  return s->asm_rowptr[a + m] - z0;
 }
 void wo_sim_set_pc_none(wo_sim *s, int none) { s->pc_none = none; }
 
 static int pc_setup(wo_sim *s, const double *val) {
   int bs = s->ksp_bs > 0 ? s->ksp_bs : s->eos.np, bb = bs * bs;
   if (s->pc_none) return 0;
-  if (!s->asm_overlap)
+  if (!s->asm_overlap && !s->ilu_levels)
     return wo_bilu0_factor(s->n_owned, bs, s->rowptr, s->colidx, val, s->nsub, s->sub_ptr, s->fval, s->dinv);
   int err = 0;
 #pragma omp parallel for reduction(| : err) schedule(dynamic, 1)
@@ -1007,7 +1106,10 @@ static int pc_setup(wo_sim *s, const double *val) {
     int *lrp = (int *)xmalloc(sizeof(int) * (m + 1));
     for (int q = 0; q <= m; q++) lrp[q] = s->asm_rowptr[a + q] - z0;
     double *lv = (double *)xmalloc(sizeof(double) * (size_t)nzl * bb);
-    for (int e = 0; e < nzl; e++) memcpy(lv + (size_t)e * bb, val + (size_t)s->asm_src[z0 + e] * bb, sizeof(double) * bb);
+    for (int e = 0; e < nzl; e++) {
+      if (s->asm_src[z0 + e] >= 0) memcpy(lv + (size_t)e * bb, val + (size_t)s->asm_src[z0 + e] * bb, sizeof(double) * bb);
+      else memset(lv + (size_t)e * bb, 0, sizeof(double) * bb);   /* ILU(k) fill entry */
+    }
     int sp[2] = {0, m};
     err |= wo_bilu0_factor(m, bs, lrp, s->asm_col + z0, lv, 1, sp, s->asm_fval + (size_t)z0 * bb,
                            s->asm_dinv + (size_t)a * bb);
@@ -1019,7 +1121,7 @@ static int pc_setup(wo_sim *s, const double *val) {
 static void pc_apply(wo_sim *s, const double *r, double *z) {
   int bs = s->ksp_bs > 0 ? s->ksp_bs : s->eos.np, bb = bs * bs;
   if (s->pc_none) { memcpy(z, r, sizeof(double) * (size_t)bs * s->n_owned); return; }
-  if (!s->asm_overlap) {
+  if (!s->asm_overlap && !s->ilu_levels) {
     wo_bilu0_apply(s->n_owned, bs, s->rowptr, s->colidx, s->fval, s->dinv, s->nsub, s->sub_ptr, r, z);
     return;
   }

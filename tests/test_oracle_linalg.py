@@ -4,6 +4,7 @@ derivatives of the residual."""
 import ctypes as C
 
 import numpy as np
+import pytest
 import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
@@ -246,4 +247,115 @@ def test_lgmres_solves_and_beats_restarted_gmres(oracle):
     assert r1 > 0 and r3 > 0
     assert np.allclose(x3, xd, rtol=1e-6, atol=1e-8 * np.abs(xd).max())
     assert its3 <= its1
+    sim.close()
+
+
+def _fill_levels_by_paths(pat):
+    """Level of fill by its graph definition (Hysom & Pothen): lev(i, j) = (length of the shortest path from i to
+    j through vertices numbered below min(i, j)) - 1 -- independent of the elimination order the oracle walks"""
+    n = pat.shape[0]
+    lev = np.full((n, n), np.iinfo(np.int32).max, dtype=np.int64)
+    for i in range(n):
+        for j in range(n):
+            if i == j:
+                lev[i, j] = 0
+                continue
+            lim = min(i, j)
+            dist = {i: 0}
+            frontier = [i]
+            found = None
+            while frontier and found is None:
+                nxt = []
+                for u in frontier:
+                    for v in np.nonzero(pat[u])[0]:
+                        v = int(v)
+                        if v == j:
+                            found = dist[u] + 1
+                            break
+                        if v < lim and v not in dist:
+                            dist[v] = dist[u] + 1
+                            nxt.append(v)
+                    if found is not None:
+                        break
+                frontier = nxt
+            if found is not None:
+                lev[i, j] = found - 1
+    return lev
+
+
+def _dense_ilu_on_pattern(A, pat):
+    """IKJ elimination restricted to a pattern; unit lower factor and upper factor"""
+    n = A.shape[0]
+    F = A.copy()
+    for i in range(n):
+        for k in range(i):
+            if pat[i, k]:
+                F[i, k] /= F[k, k]
+                for j in range(k + 1, n):
+                    if pat[i, j]:
+                        F[i, j] -= F[i, k] * F[k, j]
+    F[~pat] = 0.0
+    return np.tril(F, -1) + np.eye(n), np.triu(F)
+
+
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_iluk_matches_its_definition(oracle, overlap):
+    """ILU(k), k = 1, 2 ("sub_preconditioner": {"factor": {"levels": k}}; PCFactorSetLevels, src/timestepper.F90:
+    1716-1718, 1827): the kept pattern equals the shortest-fill-path definition of the level of fill, and the
+    application equals dense triangular solves with the IKJ elimination restricted to that pattern -- under block
+    Jacobi and under restricted ASM (eos w: scalar blocks)"""
+    lm, sim, y, L, f, J, dt = setup(oracle, dims=(6, 5, 4), brick=(3, 3, 2), eos="w")
+    A = to_bsr(sim, J).toarray()[:, : sim.n_owned]
+    r = np.random.default_rng(5).normal(size=sim.n_owned)
+    sim.set_asm(overlap)
+    assert sim.pc_setup(J) == 0
+    z0 = sim.pc_apply(r)
+    prev_nnz = None
+    for k in (1, 2):
+        sim.set_ilu_levels(k)
+        ptr, rows = sim.asm_rows()
+        assert sim.pc_setup(J) == 0
+        z = sim.pc_apply(r)
+        ref = np.zeros_like(r)
+        nnz = 0
+        for s in range(len(lm.sub_ptr) - 1):
+            own = np.arange(lm.sub_ptr[s], lm.sub_ptr[s + 1])
+            ext = rows[ptr[s]:ptr[s + 1]]
+            if overlap == 0:
+                assert np.array_equal(ext, own)
+            Al = A[np.ix_(ext, ext)]
+            pat = _fill_levels_by_paths(Al != 0.0) <= k
+            rp, ci = sim.local_pattern(s)
+            got = np.zeros_like(pat)
+            got[np.repeat(np.arange(ext.size), np.diff(rp)), ci] = True
+            assert np.array_equal(got, pat), (k, s)
+            nnz += int(pat.sum())
+            Lf, Uf = _dense_ilu_on_pattern(Al, pat)
+            zl = np.linalg.solve(Uf, np.linalg.solve(Lf, r[ext]))
+            keep = np.isin(ext, own)
+            ref[ext[keep]] = zl[keep]
+        assert np.allclose(z, ref, rtol=1e-11, atol=1e-13 * np.abs(ref).max())
+        assert not np.allclose(z, z0)
+        assert prev_nnz is None or nnz > prev_nnz      # every level adds fill on a 3-D stencil
+        prev_nnz = nnz
+    sim.set_ilu_levels(0)
+    assert sim.pc_setup(J) == 0
+    assert np.array_equal(sim.pc_apply(r), z0)
+    sim.close()
+
+
+def test_iluk_block_systems_cut_krylov_iterations(oracle):
+    """2 x 2 blocks (eos we, two-phase lens): BiCGStab reaches the dense solution under ILU(1) and ILU(2) in no
+    more iterations than under ILU(0)"""
+    lm, sim, y, L, f, J, dt = setup(oracle, dims=(8, 8, 6), brick=(4, 4, 3), lens=True, dt=1.0e5)
+    A = to_bsr(sim, J).toarray()[:, : sim.n_owned * sim.np]
+    xd = np.linalg.solve(A, f)
+    its = {}
+    for k in (0, 1, 2):
+        sim.set_ilu_levels(k)
+        reason, x, its[k], hist = sim.ksp_solve(J, f, rtol=1e-11)
+        assert reason > 0
+        assert np.allclose(x, xd, rtol=1e-7, atol=1e-9 * np.abs(xd).max())
+    print("BiCGStab iterations under ILU(0), ILU(1), ILU(2):", its)
+    assert its[1] <= its[0] and its[2] <= its[1] + 1
     sim.close()

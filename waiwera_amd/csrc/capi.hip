@@ -187,10 +187,13 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
     s.max_lev = std::max(s.max_lev, std::max(nlf, nlb));
     nlf_all = std::max(nlf_all, nlf); nlb_all = std::max(nlb_all, nlb);
   }
-  s.big = s.max_rows > 1024;
+  // the brick kernels hold a row's <= 8 blocks in registers and pack slot numbers in 4 bits: wider rows (ILU(k)
+  // fill) and subdomains of more than 1024 rows take the launch-per-level path, whose descriptor has 8-bit slots
+  s.big = s.max_rows > 1024 || W > 8;
   if (!s.big && s.max_lev > 1023) { c->err = "more than 1023 dependency levels in a subdomain"; return -2; }
   for (int i = 0; i < N; i++)
-    info[i] = lfirst[i] | (diag[i] << 4) | (ulast[i] << 8) | (s.big ? 0 : ((levf[i] << 12) | (levb[i] << 22)));
+    info[i] = s.big ? (lfirst[i] | (diag[i] << 8) | (ulast[i] << 16))
+                    : (lfirst[i] | (diag[i] << 4) | (ulast[i] << 8) | (levf[i] << 12) | (levb[i] << 22));
   if (ghosts) {   // subdomains without / with partition-ghost columns (for the overlapped halo exchange)
     std::vector<int> li, lb;
     for (int sd = 0; sd < s.nsub; sd++) {
@@ -301,11 +304,50 @@ void free_asm(AsmSystem& a) {
   a = AsmSystem();
 }
 
+// ILU(k) symbolic phase on the blocks of a block matrix (host CSR, ascending columns, all columns inside the
+// row's block): level-of-fill rule of PETSc's MatILUFactorSymbolic -- an entry created while row k is
+// eliminated from row i gets lev(i,k) + lev(k,j) + 1, an entry reached twice keeps the smaller level, kept when
+// <= levels ("sub_preconditioner": {"factor": {"levels": k}}, src/timestepper.F90:1716-1718, 1827).  ILU(k)'s
+// numeric phase is ILU(0) on the filled pattern with explicit zeros, which is how it runs here.
+// src: per entry the index it is filled from (kept for original entries, -1 for fill).
+void iluk_fill(const std::vector<int>& ptr, int levels, std::vector<int>& rp, std::vector<int>& col, std::vector<int>& src) {
+  const int n = (int)rp.size() - 1;
+  std::vector<int> orp(n + 1, 0), ocol, osrc, olev, odiag(n, 0);
+  ocol.reserve(col.size() * (size_t)(1 + 2 * levels)); osrc.reserve(ocol.capacity()); olev.reserve(ocol.capacity());
+  std::vector<int> wc, wl, ws;
+  for (size_t b = 0; b + 1 < ptr.size(); b++)
+    for (int i = ptr[b]; i < ptr[b + 1]; i++) {
+      wc.assign(col.begin() + rp[i], col.begin() + rp[i + 1]);
+      ws.assign(src.begin() + rp[i], src.begin() + rp[i + 1]);
+      wl.assign(wc.size(), 0);
+      for (size_t a = 0; a < wc.size() && wc[a] < i; a++) {   // eliminate with row k = wc[a], ascending (fill included)
+        const int k = wc[a], lik = wl[a];
+        for (int r = odiag[k] + 1; r < orp[k + 1]; r++) {
+          const int j = ocol[r], lv = lik + olev[r] + 1;
+          if (lv > levels) continue;
+          const size_t pos = (size_t)(std::lower_bound(wc.begin() + a + 1, wc.end(), j) - wc.begin());
+          if (pos < wc.size() && wc[pos] == j) { wl[pos] = std::min(wl[pos], lv); continue; }
+          wc.insert(wc.begin() + pos, j); wl.insert(wl.begin() + pos, lv); ws.insert(ws.begin() + pos, -1);
+        }
+      }
+      orp[i] = (int)ocol.size();
+      odiag[i] = -1;
+      for (size_t a = 0; a < wc.size(); a++) {
+        if (wc[a] == i) odiag[i] = (int)ocol.size();
+        ocol.push_back(wc[a]); osrc.push_back(ws[a]); olev.push_back(wl[a]);
+      }
+      orp[i + 1] = (int)ocol.size();
+      if (odiag[i] < 0) odiag[i] = orp[i + 1] - 1;
+    }
+  rp.swap(orp); col.swap(ocol); src.swap(osrc);
+}
+
 // PCASM: the overlapped row set of every subdomain (MatIncreaseOverlap over the matrix graph, owned
 // rows only), the extended block-ELL matrix that holds each set as its own block, and the map that
 // fills it from the Jacobian.  Local order inside a block = ascending row index (PETSc sorts the
 // subdomain index sets).
-int build_asm(wai_ctx* c, int overlap) {
+// levels > 0: ILU(k) fill inside every block; overlap 0 with levels > 0 is block Jacobi + ILU(k) on the same path
+int build_asm(wai_ctx* c, int overlap, int levels) {
   AsmSystem& a = c->as;
   free_asm(a);
   const Bcsr& J = c->J;
@@ -351,9 +393,12 @@ int build_asm(wai_ctx* c, int overlap) {
         esrc.push_back((e - J.h_rowptr[i]) * N + i);   // slot * n + row in J's block-ELL planes
       }
       erp[q + 1] = (int)ecol.size();
-      W = std::max(W, erp[q + 1] - erp[q]);
     }
   }
+  // (columns are positions in the extended numbering: block b's rows are ext_ptr[b] .. ext_ptr[b + 1])
+  if (levels > 0) iluk_fill(ext_ptr, levels, erp, ecol, esrc);
+  for (int q = 0; q < n_ext; q++) W = std::max(W, erp[q + 1] - erp[q]);
+  if (W > 255) { c->err = "ILU(k): more than 255 blocks in a factor row"; return -2; }
   std::vector<int> ell_col((size_t)W * n_ext), gmap((size_t)W * n_ext, -1), erow(n_ext);
   for (int sd = 0; sd < nsub; sd++)
     for (int q = ext_ptr[sd]; q < ext_ptr[sd + 1]; q++) {
@@ -377,6 +422,7 @@ int build_asm(wai_ctx* c, int overlap) {
     return -1;
   if (int e = build_schedule(c, a.sched, erp, ecol, ext_ptr, n_ext, W, np, false)) return e;
   a.overlap = overlap;
+  a.levels = levels;
   return 0;
 }
 
@@ -788,7 +834,11 @@ int do_jacobian(wai_ctx* c, double dt, const double* y, const double* lhs_old) {
 // which preconditioner path is in force: the fused brick kernels (block Jacobi, every subdomain
 // <= 1024 rows) or the general one (PCASM's extended system, subdomains of any size, PCNONE)
 bool pc_fused(const wai_ctx* c) {
-  return c->opts.pc_type == WAI_PC_BJACOBI && !c->ilu.big;
+  return c->opts.pc_type == WAI_PC_BJACOBI && !c->ilu.big && c->opts.ilu_levels <= 0;
+}
+// the extended-system path: PCASM's overlapped row sets and / or ILU(k)'s filled pattern
+bool pc_extended(const wai_ctx* c) {
+  return c->opts.pc_type == WAI_PC_ASM || (c->opts.pc_type == WAI_PC_BJACOBI && c->opts.ilu_levels > 0);
 }
 
 // PCLU: dense inverse of every preconditioner block (one block per rank with sub_ptr = NULL), by
@@ -862,9 +912,10 @@ int do_pc_setup(wai_ctx* c) {
   }
   {
     Prof p(c, KC_PC_SETUP);
-    if (c->opts.pc_type == WAI_PC_ASM) {
-      const int ov = c->opts.asm_overlap > 0 ? c->opts.asm_overlap : 1;
-      if (c->as.overlap != ov || c->as.E.bs != c->J.bs) { if (int e = build_asm(c, ov)) return e < 0 ? -1 : e; }
+    if (pc_extended(c)) {
+      const int ov = c->opts.pc_type == WAI_PC_ASM ? (c->opts.asm_overlap > 0 ? c->opts.asm_overlap : 1) : 0;
+      const int lv = std::max(c->opts.ilu_levels, 0);
+      if (c->as.overlap != ov || c->as.levels != lv || c->as.E.bs != c->J.bs) { if (int e = build_asm(c, ov, lv)) return e < 0 ? -1 : e; }
       launch_asm_gather_matrix(c);
       if (launch_ilu_factor_on(c, c->as.E, c->as.sched)) return -1;
       c->ilu.factored = true;
@@ -928,7 +979,7 @@ int pc_solve(wai_ctx* c, const double* r, double* z, int dot_mode, const double*
     if (z != r) vec_copy(c, z, r, n);
   } else if (c->opts.pc_type == WAI_PC_LU) {
     if (launch_lu_apply(c, r, z)) return -1;
-  } else if (c->opts.pc_type == WAI_PC_ASM) {
+  } else if (pc_extended(c)) {
     AsmSystem& a = c->as;
     launch_asm_gather(c, r);
     if (a.sched.big) { if (launch_big_solve(c, a.E, a.sched, a.r_ext)) return -1; }
@@ -1572,6 +1623,7 @@ void wai_default_opts(wai_solver_opts* o) {
   o->min_newton_its = 0;
   o->pc_type = WAI_PC_BJACOBI;
   o->asm_overlap = 1;
+  o->ilu_levels = 0;
 }
 
 int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_solver_opts* od,
@@ -1800,7 +1852,8 @@ int wai_set_opts(wai_ctx* c, const wai_solver_opts* o) {
   if (!c || !o) return -2;
   const int old_type = c->opts.ksp_type;
   if (o->pc_type < WAI_PC_BJACOBI || o->pc_type > WAI_PC_LU) { c->err = "unknown preconditioner type"; return -2; }
-  if (o->pc_type != c->opts.pc_type || o->asm_overlap != c->opts.asm_overlap) c->ilu.factored = false;
+  if (o->ilu_levels < 0 || o->ilu_levels > 8) { c->err = "ILU(k): levels 0..8"; return -2; }
+  if (o->pc_type != c->opts.pc_type || o->asm_overlap != c->opts.asm_overlap || o->ilu_levels != c->opts.ilu_levels) c->ilu.factored = false;
   if (o->gmres_restart > MAX_RESTART) { c->err = "gmres restart above 40 is not supported"; return -2; }
   c->opts = *o;
   (void)old_type;
@@ -2835,7 +2888,12 @@ const char* wai_pc_kernel_name(wai_ctx* c) {
   const IluSchedule& s = c->ilu;
   if (c->opts.pc_type == WAI_PC_NONE) return "k_spmv (no preconditioner)";
   if (c->opts.pc_type == WAI_PC_LU) return "k_spmv + k_lu_apply (dense block inverses)";
-  if (c->opts.pc_type == WAI_PC_ASM) return c->as.sched.big ? "k_spmv + k_lvl_solve per level (ASM, extended system)" : "k_spmv + k_pc on the extended ASM system";
+  if (pc_extended(c)) {
+    static thread_local char b3[96];
+    snprintf(b3, sizeof(b3), "k_spmv + %s on the extended system (%s, ILU(%d))", c->as.sched.big ? "k_lvl_solve per level" : "k_pc",
+             c->opts.pc_type == WAI_PC_ASM ? "ASM" : "block Jacobi", std::max(c->opts.ilu_levels, 0));
+    return b3;
+  }
   if (s.big) return "k_spmv + k_lvl_solve per level";
   if (s.rows_kernel) { static thread_local char b2[64]; snprintf(b2, sizeof(b2), "k_pc_rows<%d,spmv,%d+%d>", c->J.bs, s.max_nlu <= 3 ? 3 : 4, s.max_nlu <= 3 ? 3 : 4); return b2; }
   if (c->J.bs == 2 && s.park && s.diag_only && s.scaled && s.fast3 && s.max_rows <= 512) return "k_pc_park<spmv>";

@@ -167,7 +167,8 @@ struct IluSchedule {
 // machinery applies to E unchanged: gather r -> r_ext, ILU(0) solve per block, scatter the owned
 // rows back (src/timestepper.F90:1668-1669,1753-1757; PETSc PCASM defaults: overlap 1, restrict)
 struct AsmSystem {
-  int overlap = 0;            // what E was built for (0: not built)
+  int overlap = -1;           // what E was built for (-1: not built; 0: no overlap, fill only)
+  int levels = 0;             // ILU(k) fill levels E's pattern carries
   int n_ext = 0;
   Bcsr E;                     // block-ELL over the n_ext rows, columns in ext numbering
   IluSchedule sched;

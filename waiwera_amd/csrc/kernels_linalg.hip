@@ -209,6 +209,11 @@ __device__ __forceinline__ void unpack_info(int info, int& lfirst, int& dslot, i
   lf = (info >> 12) & 1023; lb = (info >> 22) & 1023;
 }
 
+// descriptor of the launch-per-level path (subdomains of any size, rows of any width: ILU(k) fill): 8-bit slots
+__device__ __forceinline__ void unpack_info_wide(int info, int& lfirst, int& dslot, int& ulast) {
+  lfirst = info & 255; dslot = (info >> 8) & 255; ulast = (info >> 16) & 255;
+}
+
 // ---- K7: block ILU(0) numeric factorisation (IKJ), one workgroup per subdomain ----------------
 // Works in place on fval (a copy of the matrix); rows of one dependency level are independent.
 // On exit the diagonal slot of every row holds the inverted pivot block.
@@ -1550,12 +1555,12 @@ __global__ __launch_bounds__(TPB) void k_lvl_factor(int n, int cnt, const int* _
   const int t = blockIdx.x * TPB + threadIdx.x;
   if (t >= cnt) return;
   const int i = ord[t];
-  int lfirst, dslot, ulast, lf, lb;
-  unpack_info(row_info[i], lfirst, dslot, ulast, lf, lb);
+  int lfirst, dslot, ulast;
+  unpack_info_wide(row_info[i], lfirst, dslot, ulast);
   for (int q = lfirst; q < dslot; q++) {
     const int k = col[(size_t)q * n + i];
-    int kl, kd, ku, kf, kb;
-    unpack_info(row_info[k], kl, kd, ku, kf, kb);
+    int kl, kd, ku;
+    unpack_info_wide(row_info[k], kl, kd, ku);
     double w[BB], d[BB], tt[BB];
 #pragma unroll
     for (int z = 0; z < BB; z++) { w[z] = fval[vix<BS>(n, q, z, i)]; d[z] = dinv[vix<BS>(n, 0, z, k)]; }
@@ -1608,8 +1613,8 @@ __global__ __launch_bounds__(TPB) void k_lvl_solve(int n, int cnt, const int* __
   const int t = blockIdx.x * TPB + threadIdx.x;
   if (t >= cnt) return;
   const int i = ord[t];
-  int lfirst, dslot, ulast, lf, lb;
-  unpack_info(row_info[i], lfirst, dslot, ulast, lf, lb);
+  int lfirst, dslot, ulast;
+  unpack_info_wide(row_info[i], lfirst, dslot, ulast);
   double acc[BS];
 #pragma unroll
   for (int r = 0; r < BS; r++) acc[r] = z[(size_t)i * BS + r];

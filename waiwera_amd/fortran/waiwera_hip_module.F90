@@ -56,6 +56,7 @@ module waiwera_hip_module
      integer(c_int) :: min_newton_its
      integer(c_int) :: pc_type        !! 0 bjacobi, 1 asm (restricted), 2 none (timestepper.F90:1745-1757)
      integer(c_int) :: asm_overlap    !! PETSc default 1
+     integer(c_int) :: ilu_levels     !! sub_preconditioner.factor.levels (ILU(k)), default 0
   end type wai_solver_opts
 
   interface

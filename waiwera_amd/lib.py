@@ -87,7 +87,8 @@ class SolverOpts(C.Structure):
     _fields_ = [("ksp_type", i32), ("gmres_restart", i32), ("ksp_max_its", i32),
                 ("ksp_rtol", d), ("ksp_atol", d), ("max_newton_its", i32),
                 ("ftol_rel", d), ("ftol_abs", d), ("utol_rel", d), ("utol_abs", d),
-                ("fd_eps", d), ("fd_umin", d), ("min_newton_its", i32), ("pc_type", i32), ("asm_overlap", i32)]
+                ("fd_eps", d), ("fd_umin", d), ("min_newton_its", i32), ("pc_type", i32), ("asm_overlap", i32),
+                ("ilu_levels", i32)]
 
 
 class WaiError(RuntimeError):

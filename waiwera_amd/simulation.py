@@ -441,7 +441,7 @@ class Simulation:
         if _get(lin, "options.gmres.restart") is not None:
             opts["gmres_restart"] = lin["options"]["gmres"]["restart"]
         # preconditioner (src/timestepper.F90:1745-1757, default "asm"); "ilu" of a serial run is the
-        # one-block case of either.  Only the ILU(0) sub-preconditioner exists here.
+        # one-block case of either.  Sub-preconditioner ilu with "factor.levels" k (ILU(k), :1716-1718, 1827) or lu.
         pct = (_get(lin, "preconditioner.type") or "asm").lower()
         if pct not in ("asm", "bjacobi", "ilu", "lu", "none"):
             raise NotImplementedError("preconditioner type %r" % pct)
@@ -450,8 +450,13 @@ class Simulation:
         subt = (sub.get("type") or "ilu").lower()
         if subt == "lu" and pct in ("bjacobi", "asm"):
             opts["pc_type"] = "lu"       # exact block solves (block Jacobi; no overlap)
-        elif subt != "ilu" or (_get(sub, "factor.levels") or 0) != 0:
+        elif subt != "ilu":
             raise NotImplementedError("sub-preconditioner %r" % (sub,))
+        else:
+            levels = int(_get(sub, "factor.levels") or 0)
+            if levels and opts["pc_type"] not in ("asm", "bjacobi"):
+                raise NotImplementedError("factor.levels needs a block Jacobi or ASM preconditioner")
+            opts["ilu_levels"] = levels
         if opts:
             self.ode.set_opts(**opts)
         # tracers
