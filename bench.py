@@ -348,6 +348,7 @@ def main():
                     help="run one rank's share of the N-GPU decomposition (dims / partition) on one GPU and report the iteration's cost")
     ap.add_argument("--ksp", default="bcgs")
     ap.add_argument("--pc", default="bjacobi", choices=["bjacobi", "asm", "none"])
+    ap.add_argument("--ilu-levels", type=int, default=0, help="ILU(k) sub-preconditioner (factor.levels); k > 0 runs the unfused extended-system path")
     ap.add_argument("--no-lens", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--spmv-reps", type=int, default=200)
@@ -419,7 +420,7 @@ def main():
     brick = tuple(a.brick) if a.brick else ((8, 4, 1) if minc else ((8, 5, 2) if eos == "wce" else (16, 16, 2)))
     grid, lm, prim, region = make_case(dims=dims, brick=brick, eos=eos, lens=not a.no_lens, minc=minc,
                                        part=M.partition_shape(world), rank=rank)
-    opts = wl.default_opts(ksp_type=a.ksp, pc_type=a.pc)
+    opts = wl.default_opts(ksp_type=a.ksp, pc_type=a.pc, ilu_levels=a.ilu_levels)
     sim = FlowSimulation(lm, eos=eos, opts=opts, device=local_rank)
     sim.set_regions(region)
     if world > 1:
@@ -560,10 +561,10 @@ def main():
     nnzb = wl.LIB.wai_jacobian_nnzb(sim.h)
     names = ["spmv", "ilu_apply", "fused_pc_amul"]
     kb = {name: sim.bench_kernel(w, a.spmv_reps if w in (0, 2) else 20) for w, name in enumerate(names)}
-    if world == 1 and not minc and a.pc == "bjacobi":   # the two launches of the overlapped halo exchange, timed alone
+    if world == 1 and not minc and a.pc == "bjacobi" and a.ilu_levels == 0:   # the two launches of the overlapped halo exchange, timed alone
         kb["fused_interior_bricks"] = sim.bench_kernel(9, a.spmv_reps)
         kb["fused_face_bricks"] = sim.bench_kernel(10, a.spmv_reps)
-    if world == 1 and a.ksp == "bcgs" and a.pc == "bjacobi":   # the iteration's five launches back to back, and its vector updates alone
+    if world == 1 and a.ksp == "bcgs" and a.pc == "bjacobi" and a.ilu_levels == 0:   # the iteration's five launches back to back, and its vector updates alone
         kb["bicgstab_iteration_device_only"] = sim.bench_kernel(5, 50)
         kb["bicgstab_vector_updates"] = sim.bench_kernel(6, 50)
     log("kernel microbench (ms/launch): " + json.dumps(kb))
@@ -581,6 +582,7 @@ def main():
     if rank == 0:
         ksp_name = {"bcgs": "BiCGStab", "gmres": "GMRES(30)"}.get(a.ksp, a.ksp)
         pc_name = {"bjacobi": "block-Jacobi", "asm": "ASM overlap 1 (restricted)", "none": "no preconditioner"}[a.pc]
+        ilu_name = "ILU(%d)" % a.ilu_levels
         n_newton = max(a.steps, 1)
         launches = (ls1[0] - ls0[0]) / max(kits, 1)
         ctl = ("adaptive dt (x2 below 5 Newton iterations, x0.2 after a failed step)" if a.controller == "adapt"
@@ -598,9 +600,9 @@ def main():
             "accepted_newton_steps": acc_n,
             "check": check,
             "config": {"workload": "%s%s: %dx%dx%d structured eos_%s mesh%s (%d cells), BE time steps %d-%d, %s (cyclic), "
-                                   "%s + %s(%dx%dx%d bricks)/ILU(0), rtol 1e-5"
+                                   "%s + %s(%dx%dx%d bricks)/%s, rtol 1e-5"
                                    % ((a.config, share) + dims + (eos, " + 1 MINC level" if minc else "", n_cells, a.lead,
-                                                                  a.lead + a.window - 1, ctl, ksp_name, pc_name) + brick),
+                                                                  a.lead + a.window - 1, ctl, ksp_name, pc_name) + brick + (ilu_name,)),
                        "controller": a.controller,
                        "krylov_iterations_per_newton_step": kits / n_newton,
                        "krylov_iterations": kits,
@@ -609,7 +611,7 @@ def main():
                        "copies_per_krylov_iteration": (ls1[1] - ls0[1]) / max(kits, 1),
                        "timed_newton_steps": [{"time_step": r[0], "dt": r[1], "newton": r[2], "krylov": r[3],
                                                "reason": r[4], "ms": 1e3 * r[6], "accepted": r[7]} for r in timed],
-                       "partition": "x".join(str(p) for p in grid.part), "ksp": a.ksp, "pc": a.pc},
+                       "partition": "x".join(str(p) for p in grid.part), "ksp": a.ksp, "pc": a.pc, "ilu_levels": a.ilu_levels},
             "roofline": {"bound": "hbm", "kernel": sim.pc_kernel_name() + " (fused BCSR SpMV + block ILU(0) apply + dot)",
                          "achieved": achieved_pc, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_pc / HBM_PEAK_GBS,

@@ -99,7 +99,8 @@ typedef struct wai_solver_opts {
   double fd_eps, fd_umin;      /* nonlinear.jacobian.differencing.{increment 1e-8, tolerance 1e-2} */
   int min_newton_its;          /* nonlinear.minimum.iterations, default 0 (timestepper.F90:1930-1932) */
   int pc_type;                 /* linear.preconditioner.type: WAI_PC_BJACOBI (default here) | WAI_PC_ASM | WAI_PC_NONE | WAI_PC_LU */
-  int asm_overlap;             /* PCASM overlap, PETSc default 1; does not reach across ranks */
+  int asm_overlap;             /* PCASM overlap, PETSc default 1; reaches one cell layer across rank boundaries (the
+                                  partition-ghost cells' matrix rows come from their owners at every set-up) */
   int ilu_levels;              /* linear.sub_preconditioner.factor.levels (src/timestepper.F90:1716-1718, PCFactorSetLevels
                                   :1827): levels of fill of the sub-preconditioner's ILU(k), default 0; with block Jacobi or PCASM */
 } wai_solver_opts;

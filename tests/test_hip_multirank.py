@@ -86,8 +86,9 @@ def test_overlapped_halo_exchange_eight_ranks(monkeypatch):
     """the multi-rank default (ghost values in flight behind the interior bricks) on the 2 x 2 x 2 partition:
     every rank has x, y and z neighbours and both brick lists are non-empty"""
     monkeypatch.setenv("WAI_HALO_OVERLAP", "1")
-    # 12 x 12 x 8 cells per rank in 3 x 3 x 4 bricks: 12 of a rank's 36 bricks touch no partition ghost
-    test_ranks_sharing_one_gpu_match_one_rank(8, dims=(24, 24, 16), brick=(4, 4, 2))
+    # 8 x 8 x 8 cells per rank in 4 x 4 x 4 bricks of 2 x 2 x 2: 27 of a rank's 64 bricks touch no partition ghost
+    # (the loopback time-slices eight processes with two streams each on one GPU: a small mesh keeps it to a minute)
+    test_ranks_sharing_one_gpu_match_one_rank(8, dims=(16, 16, 16), brick=(2, 2, 2))
 
 
 @pytest.mark.timeout(900)
@@ -148,11 +149,11 @@ def _free_port():
 
 @pytest.mark.timeout(1200)
 @pytest.mark.parametrize("world,dims,brick,part", [(2, (32, 32, 16), (8, 8, 2), "2x1x1"),
-                                                   (8, (72, 72, 56), (16, 16, 2), "2x2x2")])
+                                                   (8, (40, 40, 48), (16, 16, 2), "2x2x2")])
 def test_bench_as_the_driver_launches_it(world, dims, brick, part):
     """bench.py --gpus N under torch.distributed.run, all ranks on cuda:0 over the loopback
     (WAI_BENCH_LOOPBACK: gloo for the host-side barrier / max, device 0 for every rank).  The
-    8-rank case has the default brick shape cut raggedly by 36-cell rank extents (as 108-cell
+    8-rank case has the default brick shape cut raggedly by 20-cell rank extents (as 108-cell
     extents are at full size) and is deep enough for the two-phase lens."""
     env = dict(os.environ, WAI_RCCL_LIB=LOOPBACK, WAI_BENCH_LOOPBACK="1", WAI_HALO_OVERLAP="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
@@ -184,3 +185,128 @@ def test_bench_spawns_its_own_ranks():
     assert len(lines) == 1, p.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["partition"] == "2x1x1" and out["value"] > 0
+
+
+# ---- PCASM with the overlap reaching across rank boundaries ---------------------------------------
+
+def _asm_worker(rank, world, uid_q, q, dims, brick, eos):
+    os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    os.environ.setdefault("WAI_HALO_OVERLAP", "0")
+    from waiwera_amd import lib as wl
+    from waiwera_amd.cases import make_case
+    from waiwera_amd.flow_simulation import FlowSimulation
+    if rank == 0:
+        uid = wl.comm_unique_id()
+        for _ in range(world - 1):
+            uid_q.put(uid)
+    else:
+        uid = uid_q.get(timeout=300)
+    g, lm, prim, region = make_case(dims=dims, brick=brick, eos=eos, lens=(eos == "we"), part=M.partition_shape(world), rank=rank)
+    sim = FlowSimulation(lm, eos=eos, device=0)
+    sim.set_regions(region)
+    sim.comm_init(rank, world, uid)
+    sim.set_opts(pc_type="asm", asm_overlap=1, ksp_rtol=1e-12, ftol_rel=1e-10)
+    bs = sim.num_primary_variables
+    y = scaled(prim, region, eos).ravel().copy()
+    n = lm.n_owned * bs
+    dt = 2.0e4
+    assert sim.pre_eval(0.0, y) == 0
+    L, f = np.zeros(n), np.zeros(n)
+    sim.lhs(0.0, (0.0, 0.0), y, L)
+    assert sim.residual(dt, dt, y, L, f) == 0
+    assert sim.jacobian(dt, dt, y, L) == 0
+    assert sim.pc_setup() == 0
+    nx, ny, nz = dims
+    ijk = lm.extras["prim_ijk"]
+    gid = (ijk[:, 2] * ny + ijk[:, 1]) * nx + ijk[:, 0]
+    r = np.sin(0.37 * np.repeat(gid[: lm.n_owned], bs) + np.tile(np.arange(bs), lm.n_owned))
+    z = np.zeros(n)
+    assert sim.pc_apply(r, z) == 0
+    x = np.zeros(n)
+    its, reason, rn = sim.ksp_solve(f, x)
+    q.put((rank, gid.copy(), lm.n_owned, np.asarray(lm.sub_ptr).copy(), z, x, its, reason))
+    sim.destroy()
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("world,eos", [(2, "w"), (2, "we"), (8, "we")])
+def test_asm_overlap_reaches_across_ranks(world, eos):
+    """The reference's default preconditioner on more than one rank: PCASM overlap 1 whose overlapped row sets
+    contain the neighbour ranks' cells (their matrix rows arrive from their owners at every set-up, the residual's
+    ghost entries by one halo exchange per application).  Every rank's application must equal the definition --
+    restricted additive Schwarz with ILU(0) of the overlapped diagonal block in the rank's own ascending local
+    order -- built here from the GLOBAL matrix of a one-rank run; and the Krylov solution the one-rank solution."""
+    import scipy.sparse as sp
+    from tests.test_oracle_linalg import _dense_ilu_on_pattern
+    from waiwera_amd.cases import make_case
+    from waiwera_amd.flow_simulation import FlowSimulation
+    assert os.path.exists(LOOPBACK), "build first: python __graft_entry__.py"
+    os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    dims, brick = (16, 12, 8), (4, 3, 2)
+    ctx = mp.get_context("spawn")
+    q, uid_q = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_asm_worker, args=(r, world, uid_q, q, dims, brick, eos)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # the global matrix and right-hand side from one rank, in natural cell numbering
+    g, lm, prim, region = make_case(dims=dims, brick=brick, eos=eos, lens=(eos == "we"))
+    sim = FlowSimulation(lm, eos=eos, device=0)
+    sim.set_regions(region)
+    sim.set_opts(pc_type="asm", asm_overlap=1, ksp_rtol=1e-12)
+    bs = sim.num_primary_variables
+    y = scaled(prim, region, eos).ravel().copy()
+    n = lm.n_owned * bs
+    dt = 2.0e4
+    assert sim.pre_eval(0.0, y) == 0
+    L, f = np.zeros(n), np.zeros(n)
+    sim.lhs(0.0, (0.0, 0.0), y, L)
+    assert sim.residual(dt, dt, y, L, f) == 0
+    assert sim.jacobian(dt, dt, y, L) == 0
+    rp, ci = sim.setup_jacobian()
+    val = sim.jacobian_values().reshape(-1, bs, bs)
+    x1 = np.zeros(n)
+    its1, reason1, _ = sim.ksp_solve(f, x1)
+    assert reason1 > 0
+    g1 = lm.owned_gid
+    N = g.n_global
+    A = sp.bsr_matrix((val, ci, rp), shape=(n, n)).tocsr()
+    perm = np.zeros(N * bs, dtype=np.int64)       # natural scalar index -> one-rank scalar index
+    for k in range(bs):
+        perm[g1 * bs + k] = np.arange(lm.n_owned) * bs + k
+    A = A[perm][:, perm].toarray()                 # natural numbering, dense (1536 cells)
+    xs = np.zeros(N * bs)
+    xs[(g1[:, None] * bs + np.arange(bs)).ravel()] = x1
+    sim.destroy()
+    blockpat = np.kron((np.abs(A.reshape(N, bs, N, bs)).sum(axis=(1, 3)) != 0) | np.eye(N, dtype=bool), np.ones((bs, bs), dtype=bool))
+    adj = (np.abs(A.reshape(N, bs, N, bs)).sum(axis=(1, 3)) != 0)
+    worst, worst_x = 0.0, 0.0
+    for rank, gid, n_owned, sub_ptr, z, x, its, reason in res:
+        assert reason > 0
+        local = {int(gc): i for i, gc in enumerate(gid)}          # the rank's local index of every cell it knows
+        rvec = np.sin(0.37 * np.repeat(np.arange(N), bs) + np.tile(np.arange(bs), N))
+        ref = np.zeros(n_owned * bs)
+        for s in range(len(sub_ptr) - 1):
+            own = gid[sub_ptr[s]:sub_ptr[s + 1]]
+            ext = set(int(v) for v in own)
+            for c in own:
+                ext |= {int(j) for j in np.nonzero(adj[c])[0] if int(j) in local}
+            ext = sorted(ext, key=lambda gc: local[gc])           # ascending local index on that rank
+            sc = (np.array(ext)[:, None] * bs + np.arange(bs)).ravel()
+            Al = A[np.ix_(sc, sc)]
+            Lf, Uf = _dense_ilu_on_pattern(Al, blockpat[np.ix_(sc, sc)])
+            zl = np.linalg.solve(Uf, np.linalg.solve(Lf, rvec[sc])).reshape(-1, bs)
+            for e, gc in enumerate(ext):
+                li = local[gc]
+                if sub_ptr[s] <= li < sub_ptr[s + 1]:
+                    ref[li * bs:(li + 1) * bs] = zl[e]
+        worst = max(worst, np.abs(z - ref).max() / np.abs(ref).max())
+        xr = xs[(gid[:n_owned, None] * bs + np.arange(bs)).ravel()]
+        worst_x = max(worst_x, np.abs(x - xr).max() / np.abs(xs).max())
+        assert abs(its - its1) <= max(3, its1 // 5), (its, its1)
+    print("asm across %d ranks (%s): application vs definition %.2e, solution vs one rank %.2e" % (world, eos, worst, worst_x))
+    assert worst < 1e-9, worst
+    assert worst_x < 1e-8, worst_x

@@ -215,3 +215,50 @@ def test_lgmres_with_a_tiny_restart_and_the_restart_cap(oracle):
     with pytest.raises(WaiError, match="restart"):
         sim.set_opts(ksp_type="gmres", gmres_restart=41)
     sim.destroy(); osim.close()
+
+
+@pytest.mark.parametrize("eos,pc,brick", [("we", "bjacobi", (4, 4, 3)), ("we", "asm", (4, 4, 2)), ("wce", "bjacobi", (4, 4, 3)),
+                                          ("w", "bjacobi", (4, 4, 3))])
+def test_iluk_sub_preconditioner(oracle, eos, pc, brick):
+    """"sub_preconditioner": {"factor": {"levels": k}} (src/timestepper.F90:1716-1718, PCFactorSetLevels :1827),
+    k = 1, 2, under block Jacobi and under PCASM: one application and whole Krylov solves against the oracle's
+    ILU(k) (itself pinned on the fill-path definition, tests/test_oracle_linalg.py); ILU(k) is not ILU(0), and
+    BiCGStab needs no more iterations with it"""
+    lm, sim, osim, J, f = system(oracle, eos, (8, 8, 6), brick, lens=(eos == "we"))
+    n = sim.num_dof
+    r = np.random.default_rng(11).normal(size=n)
+    ov = 1 if pc == "asm" else 0
+    osim.set_asm(ov)
+    sim.set_opts(pc_type=pc, asm_overlap=1, ilu_levels=0, ksp_rtol=1e-12)
+    z0 = np.zeros(n)
+    assert sim.pc_setup() == 0
+    sim.pc_apply(r, z0)
+    x = np.zeros(n)
+    its0, reason, rn = sim.ksp_solve(f, x)
+    assert reason > 0
+    prev = its0
+    for k in (1, 2):
+        sim.set_opts(ilu_levels=k)
+        osim.set_ilu_levels(k)
+        assert sim.pc_setup() == 0 and osim.pc_setup(J) == 0
+        z = np.zeros(n)
+        sim.pc_apply(r, z)
+        assert relmax(z, osim.pc_apply(r)) < 1e-10, k
+        assert relmax(z, z0) > 1e-6
+        x = np.zeros(n)
+        its, reason, rn = sim.ksp_solve(f, x)
+        oreason, xo, oits, hist = osim.ksp_solve(J, f, ksp_type=0, rtol=1e-12)
+        assert reason > 0 and oreason > 0
+        assert relmax(x, xo) < 1e-8
+        assert abs(its - oits) <= max(2, oits // 10), (k, its, oits)
+        assert its <= prev + 1, (k, its, prev)
+        prev = its
+        print(eos, pc, "ILU(%d):" % k, sim.pc_kernel_name(), "BiCGStab", its, "(oracle %d, ILU(0) %d)" % (oits, its0))
+    # back to ILU(0): the fused path again, same result as before
+    sim.set_opts(ilu_levels=0)
+    osim.set_ilu_levels(0)
+    assert sim.pc_setup() == 0
+    z = np.zeros(n)
+    sim.pc_apply(r, z)
+    assert relmax(z, z0) < 1e-14
+    sim.destroy(); osim.close()

@@ -117,8 +117,9 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
     const int* row = colidx.data() + rowptr[i];
     diag[i] = (int)(std::lower_bound(row, row + (rowptr[i + 1] - rowptr[i]), i) - row);
   }
-  std::vector<int> info(N), uoff(N, 0), levf(N), levb(N), nlev(s.nsub, 0), lfirst(N), ulast(N), tslot(N, 0);
-  s.max_rows = 0; s.max_lev = 0; s.max_ublocks = 0; s.max_nlu = 0; s.max_nl = 0;
+  std::vector<int> info(N), uoff(N, 0), uoffw(N, 0), levf(N), levb(N), nlev(s.nsub, 0), lfirst(N), ulast(N), tslot(N, 0);
+  int max_nu = 0;
+  s.max_rows = 0; s.max_lev = 0; s.max_ublocks = 0; s.max_ublocks_w = 0; s.max_nlu = 0; s.max_nl = 0;
   bool offdiag_fill = false, fast3 = true;
   int nlf_all = 0, nlb_all = 0;
   for (int sd = 0; sd < s.nsub; sd++) {
@@ -174,15 +175,19 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
       tslot[i] = pack;
       s.max_nl = std::max(s.max_nl, diag[i] - lfirst[i]);
     }
-    int ucount = 0;
+    int ucount = 0, ucountw = 0;
     for (int i = lo; i < hi; i++) {
       const int nL = diag[i] - lfirst[i], nU = ulast[i] - diag[i] - 1;
       if (nL > 3 || nU > 3 || lfirst[i] > 3 || diag[i] > 3) fast3 = false;
       s.max_nlu = std::max(s.max_nlu, std::max(nL, nU));
       uoff[i] = ucount;
       ucount += std::min(nU, 3);
+      uoffw[i] = ucountw;
+      ucountw += nU;
+      max_nu = std::max(max_nu, nU);
     }
     s.max_ublocks = std::max(s.max_ublocks, ucount);
+    s.max_ublocks_w = std::max(s.max_ublocks_w, ucountw);
     nlev[sd] = (nlf & 0xffff) | (nlb << 16);
     s.max_lev = std::max(s.max_lev, std::max(nlf, nlb));
     nlf_all = std::max(nlf_all, nlf); nlb_all = std::max(nlb_all, nlb);
@@ -233,7 +238,7 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
     if (dev_upload(c, &s.ord_f, of) || dev_upload(c, &s.ord_b, ob)) return -1;
   }
   if (dev_upload(c, &s.sub_ptr, sub) || dev_upload(c, &s.sub_nlev, nlev) || dev_upload(c, &s.row_info, info) ||
-      dev_upload(c, &s.row_uoff, uoff) || dev_upload(c, &s.row_tslot, tslot) ||
+      dev_upload(c, &s.row_uoff, uoff) || dev_upload(c, &s.row_uoffw, uoffw) || dev_upload(c, &s.row_tslot, tslot) ||
       dev_alloc(c, &s.fval, (size_t)W * np * np * N) || dev_alloc(c, &s.dinv, (size_t)np * np * N))
     return -1;
   // Kernel-selection switches are build-time (A/B builds: WAI_EXTRA_HIPCC_FLAGS="-DWAI_ILU_GENERAL" ...); the
@@ -271,6 +276,16 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
     s.rows_kernel = can && np >= 3;
 #endif
   }
+  {
+    // one wave per brick: <= 64 block rows, <= 3 lower and <= 4 upper in-brick couplings, LDS for four bricks per
+    // workgroup within 64 KB (-DWAI_PC_WAVE=0 builds without)
+    const size_t lds_w = (size_t)4 * (64 * np + (size_t)s.max_ublocks_w * np * np) * sizeof(double);
+    s.wave_kernel = s.rows_kernel && np == 3 && s.max_rows <= 64   // (4 x 4 blocks: 174 VGPRs, two waves per SIMD -- not measured, k_pc_rows keeps them)
+                    && s.max_nl <= 3 && max_nu <= 4 && lds_w <= 64 * 1024;
+#ifdef WAI_PC_WAVE
+    s.wave_kernel = s.wave_kernel && (WAI_PC_WAVE != 0);
+#endif
+  }
   if (s.rows_kernel) {
     // bricks whose long rows come first (MINC: fracture cells, then their matrix cells with 2 of 8
     // slots): k_pc_rows maps the long rows of all components to the first waves, so that a wave is
@@ -295,12 +310,12 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
 
 void free_schedule(IluSchedule& s) {
   hipFree(s.sub_ptr); hipFree(s.sub_nlev); hipFree(s.sub_split); hipFree(s.row_info); hipFree(s.fval); hipFree(s.dinv);
-  hipFree(s.row_uoff); hipFree(s.row_tslot); hipFree(s.sub_int); hipFree(s.sub_bnd); hipFree(s.ord_f); hipFree(s.ord_b);
+  hipFree(s.row_uoff); hipFree(s.row_uoffw); hipFree(s.row_tslot); hipFree(s.sub_int); hipFree(s.sub_bnd); hipFree(s.ord_f); hipFree(s.ord_b);
   s = IluSchedule();
 }
 void free_asm(AsmSystem& a) {
   free_schedule(a.sched);
-  hipFree(a.E.col); hipFree(a.E.val); hipFree(a.ext_row); hipFree(a.gmap); hipFree(a.r_ext);
+  hipFree(a.E.col); hipFree(a.E.val); hipFree(a.ext_row); hipFree(a.gmap); hipFree(a.r_ext); hipFree(a.hval); hipFree(a.r_full);
   a = AsmSystem();
 }
 
@@ -347,15 +362,89 @@ void iluk_fill(const std::vector<int>& ptr, int levels, std::vector<int>& rp, st
 // fills it from the Jacobian.  Local order inside a block = ascending row index (PETSc sorts the
 // subdomain index sets).
 // levels > 0: ILU(k) fill inside every block; overlap 0 with levels > 0 is block Jacobi + ILU(k) on the same path
+int ensure_halo_dof(wai_ctx* c, int dof) {   // halo buffers wide enough for `dof` doubles per cell
+  if (dof <= c->max_dof_buf) return 0;
+  if (c->d_sendbuf) (void)hipFree(c->d_sendbuf);
+  if (c->d_recvbuf) (void)hipFree(c->d_recvbuf);
+  c->d_sendbuf = c->d_recvbuf = nullptr;
+  c->max_dof_buf = dof;
+  if (dev_alloc(c, &c->d_sendbuf, (size_t)c->send_total * dof) || dev_alloc(c, &c->d_recvbuf, (size_t)c->mesh.n_halo * dof)) return -1;
+  return 0;
+}
+
+int halo_exchange(wai_ctx* c, double* vec, int dof);
+
+// The structure of the partition-ghost cells' matrix rows, from their owners (collective).  Every cell gets the
+// identity (owner rank, owner's local index); the identities of the ghost cells arrive by a halo exchange, and a
+// second exchange carries, for every cell a rank sends, the identities of its row's columns.  The receiver keeps
+// the columns it knows (its owned and ghost cells -- what the overlapped row sets can contain) in ascending local
+// order, with the sender's slot each came from.
+int ghost_rows(wai_ctx* c, std::vector<int>& grp, std::vector<int>& gci, std::vector<int>& gslot) {
+  const Bcsr& J = c->J;
+  const int N = J.n, H = c->mesh.n_halo, W = J.W;
+  std::vector<double> ids((size_t)N + H, -1.0);
+  const double base = (double)c->comm->rank * 4294967296.0;
+  for (int i = 0; i < N; i++) ids[i] = base + i;
+  HIPCHK(c, hipMemcpyAsync(c->w_c, ids.data(), sizeof(double) * (N + H), hipMemcpyHostToDevice, c->stream));
+  if (halo_exchange(c, c->w_c, 1)) return -1;
+  HIPCHK(c, hipMemcpyAsync(ids.data(), c->w_c, sizeof(double) * (N + H), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (ensure_halo_dof(c, W * J.bs * J.bs)) return -1;
+  std::vector<int> sidx((size_t)c->send_total);
+  HIPCHK(c, hipMemcpy(sidx.data(), c->d_send_idx, sizeof(int) * sidx.size(), hipMemcpyDeviceToHost));
+  std::vector<double> sb((size_t)c->send_total * W, -1.0), rb((size_t)H * W, -1.0);
+  for (int p = 0; p < c->send_total; p++) {
+    const int i = sidx[p];
+    for (int q = J.h_rowptr[i]; q < J.h_rowptr[i + 1]; q++) sb[(size_t)p * W + (q - J.h_rowptr[i])] = ids[J.h_colidx[q]];
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_sendbuf, sb.data(), sizeof(double) * sb.size(), hipMemcpyHostToDevice, c->stream));
+  if (comm_exchange(c->comm, c->n_nbr, c->nbr_rank.data(), c->send_ptr.data(), c->recv_ptr.data(), W, c->d_sendbuf, c->d_recvbuf,
+                    c->stream, c->err))
+    return -1;
+  HIPCHK(c, hipMemcpyAsync(rb.data(), c->d_recvbuf, sizeof(double) * rb.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<std::pair<double, int>> known((size_t)N + H);
+  for (int i = 0; i < N + H; i++) known[i] = {ids[i], i};
+  std::sort(known.begin(), known.end());
+  grp.assign((size_t)H + 1, 0);
+  gci.clear(); gslot.clear();
+  std::vector<std::pair<int, int>> row;
+  for (int h = 0; h < H; h++) {
+    row.clear();
+    for (int q = 0; q < W; q++) {
+      const double id = rb[(size_t)h * W + q];
+      if (id < 0.0) continue;
+      auto it = std::lower_bound(known.begin(), known.end(), std::make_pair(id, -1));
+      if (it != known.end() && it->first == id) row.push_back({it->second, q});
+    }
+    std::sort(row.begin(), row.end());
+    for (auto& e : row) { gci.push_back(e.first); gslot.push_back(e.second); }
+    grp[h + 1] = (int)gci.size();
+  }
+  return 0;
+}
+
 int build_asm(wai_ctx* c, int overlap, int levels) {
   AsmSystem& a = c->as;
   free_asm(a);
   const Bcsr& J = c->J;
   const int N = J.n, np = J.bs;
+  // Overlap across rank boundaries (the reference's PCASM subdomains are the ranks and MatIncreaseOverlap
+  // pulls in the neighbours' rows): the overlapped sets may contain partition-ghost cells, whose matrix rows come
+  // from their owners.  One ghost layer exists, so overlap 1 is exact; deeper overlap stops at that layer.
+  const bool cross = overlap > 0 && c->comm && c->comm->nranks > 1 && c->mesh.n_halo > 0 && c->n_nbr > 0;
+  const int H = cross ? c->mesh.n_halo : 0, NX = N + H;
+  std::vector<int> grp, gci, gslot;
+  if (cross && ghost_rows(c, grp, gci, gslot)) return -1;
+  // row i of the local matrix: owned rows are the Jacobian's, ghost rows the received ones
+  auto row_begin = [&](int i) { return i < N ? J.h_rowptr[i] : grp[i - N]; };
+  auto row_end = [&](int i) { return i < N ? J.h_rowptr[i + 1] : grp[i - N + 1]; };
+  auto row_col = [&](int i, int e) { return i < N ? J.h_colidx[e] : gci[e]; };
+  auto row_src = [&](int i, int e) { return i < N ? (e - J.h_rowptr[i]) * N + i : -(2 + gslot[e] * H + (i - N)); };
   std::vector<int> sub((size_t)c->ilu.nsub + 1);
   HIPCHK(c, hipMemcpy(sub.data(), c->ilu.sub_ptr, sizeof(int) * sub.size(), hipMemcpyDeviceToHost));
   const int nsub = c->ilu.nsub;
-  std::vector<int> ext_ptr(nsub + 1, 0), ext_rows, mark(N, -1), loc(N, 0);
+  std::vector<int> ext_ptr(nsub + 1, 0), ext_rows, mark(NX, -1), loc(NX, 0);
   ext_rows.reserve((size_t)N * 2);
   for (int sd = 0; sd < nsub; sd++) {
     const size_t start = ext_rows.size();
@@ -365,9 +454,9 @@ int build_asm(wai_ctx* c, int overlap, int levels) {
       const size_t hi = ext_rows.size();
       for (size_t q = lo; q < hi; q++) {
         const int i = ext_rows[q];
-        for (int e = J.h_rowptr[i]; e < J.h_rowptr[i + 1]; e++) {
-          const int j = J.h_colidx[e];
-          if (j >= N || mark[j] == sd) continue;
+        for (int e = row_begin(i); e < row_end(i); e++) {
+          const int j = row_col(i, e);
+          if (j >= NX || mark[j] == sd) continue;
           ext_rows.push_back(j); mark[j] = sd;
         }
       }
@@ -386,11 +475,11 @@ int build_asm(wai_ctx* c, int overlap, int levels) {
     for (int q = a0; q < b0; q++) { mark[ext_rows[q]] = sd; loc[ext_rows[q]] = q; }
     for (int q = a0; q < b0; q++) {
       const int i = ext_rows[q];
-      for (int e = J.h_rowptr[i]; e < J.h_rowptr[i + 1]; e++) {
-        const int j = J.h_colidx[e];
-        if (j >= N || mark[j] != sd) continue;
+      for (int e = row_begin(i); e < row_end(i); e++) {
+        const int j = row_col(i, e);
+        if (j >= NX || mark[j] != sd) continue;
         ecol.push_back(loc[j]);
-        esrc.push_back((e - J.h_rowptr[i]) * N + i);   // slot * n + row in J's block-ELL planes
+        esrc.push_back(row_src(i, e));   // slot * n + row in J's block-ELL planes, or the ghost rows' (<= -2)
       }
       erp[q + 1] = (int)ecol.size();
     }
@@ -421,6 +510,11 @@ int build_asm(wai_ctx* c, int overlap, int levels) {
       dev_alloc(c, &a.E.val, (size_t)W * np * np * n_ext) || dev_alloc(c, &a.r_ext, (size_t)np * n_ext + 16))
     return -1;
   if (int e = build_schedule(c, a.sched, erp, ecol, ext_ptr, n_ext, W, np, false)) return e;
+  if (cross) {
+    if (dev_alloc(c, &a.hval, (size_t)J.W * np * np * H) || dev_alloc(c, &a.r_full, (size_t)np * NX + 16)) return -1;
+    HIPCHK(c, hipMemset(a.r_full, 0, sizeof(double) * ((size_t)np * NX + 16)));
+  }
+  a.cross = cross;
   a.overlap = overlap;
   a.levels = levels;
   return 0;
@@ -916,6 +1010,15 @@ int do_pc_setup(wai_ctx* c) {
       const int ov = c->opts.pc_type == WAI_PC_ASM ? (c->opts.asm_overlap > 0 ? c->opts.asm_overlap : 1) : 0;
       const int lv = std::max(c->opts.ilu_levels, 0);
       if (c->as.overlap != ov || c->as.levels != lv || c->as.E.bs != c->J.bs) { if (int e = build_asm(c, ov, lv)) return e < 0 ? -1 : e; }
+      if (c->as.cross) {   // the ghost cells' matrix rows, from their owners
+        const int dof = c->J.W * c->J.bs * c->J.bs;
+        if (ensure_halo_dof(c, dof)) return -1;
+        launch_pack_rows(c);
+        if (comm_exchange(c->comm, c->n_nbr, c->nbr_rank.data(), c->send_ptr.data(), c->recv_ptr.data(), dof, c->d_sendbuf,
+                          c->d_recvbuf, c->stream, c->err))
+          return -1;
+        launch_unpack_rows(c);
+      }
       launch_asm_gather_matrix(c);
       if (launch_ilu_factor_on(c, c->as.E, c->as.sched)) return -1;
       c->ilu.factored = true;
@@ -981,7 +1084,11 @@ int pc_solve(wai_ctx* c, const double* r, double* z, int dot_mode, const double*
     if (launch_lu_apply(c, r, z)) return -1;
   } else if (pc_extended(c)) {
     AsmSystem& a = c->as;
-    launch_asm_gather(c, r);
+    if (a.cross) {   // the residual's ghost entries: one more halo exchange per application
+      vec_copy(c, a.r_full, r, n);
+      if (halo_exchange(c, a.r_full, c->np)) return -1;
+      launch_asm_gather(c, a.r_full);
+    } else launch_asm_gather(c, r);
     if (a.sched.big) { if (launch_big_solve(c, a.E, a.sched, a.r_ext)) return -1; }
     else if (launch_pc_on(c, a.E, a.sched, false, a.r_ext, a.r_ext, 0, nullptr)) return -1;
     launch_asm_scatter(c, z);
@@ -2895,6 +3002,7 @@ const char* wai_pc_kernel_name(wai_ctx* c) {
     return b3;
   }
   if (s.big) return "k_spmv + k_lvl_solve per level";
+  if (s.wave_kernel) { static thread_local char b4[64]; snprintf(b4, sizeof(b4), "k_pc_wave<%d,spmv>", c->J.bs); return b4; }
   if (s.rows_kernel) { static thread_local char b2[64]; snprintf(b2, sizeof(b2), "k_pc_rows<%d,spmv,%d+%d>", c->J.bs, s.max_nlu <= 3 ? 3 : 4, s.max_nlu <= 3 ? 3 : 4); return b2; }
   if (c->J.bs == 2 && s.park && s.diag_only && s.scaled && s.fast3 && s.max_rows <= 512) return "k_pc_park<spmv>";
   static thread_local char buf[96];

@@ -148,6 +148,9 @@ struct IluSchedule {
   bool fast3 = false;         // <= 3 lower and <= 3 upper in-subdomain couplings per row, offsets < 4
   int max_nlu = 0;            // most lower or upper in-subdomain couplings of any row
   bool rows_kernel = false;   // k_pc_rows (one thread per scalar row) applies and is selected
+  bool wave_kernel = false;   // k_pc_wave (one wave per brick of <= 64 block rows) applies and is selected
+  int* row_uoffw = nullptr;   // first parked upper block of a row inside its subdomain, all (<= 4) uppers counted
+  int max_ublocks_w = 0;
   bool level_sorted = false;  // every subdomain's rows are stored in dependency-level order
   bool factored = false;
   // subdomains of more than 1024 rows ("one block per rank", sub_ptr = NULL, is the reference's
@@ -175,6 +178,12 @@ struct AsmSystem {
   int* ext_row = nullptr;     // [n_ext] row of the global system, bit 31 set: owned by this block
   int* gmap = nullptr;        // [W * n_ext] plane position (slot * n + row) of the source block in J, -1: none
   double* r_ext = nullptr;    // [bs * n_ext] gathered right-hand side / solution
+  // overlap across rank boundaries: the matrix rows of the partition-ghost cells, received from
+  // their owners at every set-up (block-ELL over the n_halo cells, the sender's slot order), and the residual
+  // with its ghost entries filled by one more halo exchange per application
+  bool cross = false;
+  double* hval = nullptr;     // [W * bs * bs * n_halo]
+  double* r_full = nullptr;   // [bs * n_prim]
 };
 
 // Residual form of the time stepping method (src/timestepper.F90:345-452), by value to kernels
@@ -348,7 +357,9 @@ int launch_pc_on(wai_ctx* c, const Bcsr& M, const IluSchedule& s, bool spmv, con
                  int dot_mode, const double* aux, const int* list = nullptr, int nrun = 0, const Fin* fin = nullptr);
 // subdomains of any size: level-by-level launches, in place on z (z = r on entry)
 int launch_big_solve(wai_ctx* c, const Bcsr& M, const IluSchedule& s, double* z);
-int launch_asm_gather_matrix(wai_ctx* c);                   // E.val <- J.val
+int launch_asm_gather_matrix(wai_ctx* c);                   // E.val <- J.val (and the ghost cells' rows)
+int launch_pack_rows(wai_ctx* c);                           // d_sendbuf <- matrix rows of the cells sent to neighbours
+int launch_unpack_rows(wai_ctx* c);                         // as.hval <- d_recvbuf
 int launch_asm_gather(wai_ctx* c, const double* r);        // as.r_ext <- r
 int launch_asm_scatter(wai_ctx* c, double* z);             // z[owned] <- as.r_ext
 // up to two dot products (a1,b1) -> slot1, (a2,b2) -> slot2 (a2 null: one); partial blocks in ks.nb_pc

@@ -532,6 +532,24 @@ __device__ __forceinline__ void post_scalars(const double* scal, double* post, i
   __atomic_signal_fence(__ATOMIC_SEQ_CST);
   __hip_atomic_store(post + 16, (double)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// merged reductions (multi-rank): slots hold (S,T), (T,T), (S,S), (S,RP), (T,RP).  omega = (S,T)/(T,T) (see
+// phase 3 for (T,T) = 0); then, with R = S - omega T:  (R,RP) = (S,RP) - omega (T,RP)  and
+// (R,R) = (S,S) - 2 omega (S,T) + omega^2 (T,T) -- one all-reduce instead of two
+__device__ __forceinline__ void derive_merged(double* s) {
+  const double st = s[S_D1], tt = s[S_D2], ss = s[S_DP2], srp = s[S_RHONEW], trp = s[S_W2];
+  if (tt == 0.0) { s[S_BREAK] = 2.0; s[S_OMEGA] = 0.0; }
+  else s[S_OMEGA] = st / tt;
+  const double om = s[S_OMEGA];
+  const double rr = (ss - 2.0 * om * st) + om * om * tt;
+  s[S_DP2] = rr > 0.0 ? rr : 0.0;
+  s[S_RHONEW] = srp - om * trp;
+}
+// end of iteration: rotate rho, next beta = (rho/rhoold)*(alpha/omega)
+__device__ __forceinline__ void derive_rotate(double* s) {
+  s[S_RHOOLD] = s[S_RHO]; s[S_RHO] = s[S_RHONEW];
+  if (s[S_RHO] == 0.0 && s[S_BREAK] == 0.0) s[S_BREAK] = 3.0;  // only matters if not converged
+  s[S_BETA] = (s[S_RHO] / s[S_RHOOLD]) * (s[S_ALPHA] / s[S_OMEGA]);
+}
 __device__ __forceinline__ void derive_scalars(double* s, int phase) {
   switch (phase) {  // PETSc KSPSolve_BCGS order of operations
     case 0:  // after R = B^-1 b: DP2 = (R,R); rho = (R,RP) with RP = R
@@ -551,32 +569,16 @@ __device__ __forceinline__ void derive_scalars(double* s, int phase) {
       if (s[S_D2] == 0.0) { s[S_BREAK] = 2.0; s[S_OMEGA] = 0.0; }
       else s[S_OMEGA] = s[S_D1] / s[S_D2];
       break;
-    case 5: {  // merged reductions (multi-rank): slots hold (S,T), (T,T), (S,S), (S,RP), (T,RP).
-      // omega as in case 3; then, with R = S - omega T:  (R,RP) = (S,RP) - omega (T,RP)  and
-      // (R,R) = (S,S) - 2 omega (S,T) + omega^2 (T,T) -- one all-reduce instead of two
-      const double st = s[S_D1], tt = s[S_D2], ss = s[S_DP2], srp = s[S_RHONEW], trp = s[S_W2];
-      if (tt == 0.0) { s[S_BREAK] = 2.0; s[S_OMEGA] = 0.0; }
-      else s[S_OMEGA] = st / tt;
-      const double om = s[S_OMEGA];
-      const double rr = (ss - 2.0 * om * st) + om * om * tt;
-      s[S_DP2] = rr > 0.0 ? rr : 0.0;
-      s[S_RHONEW] = srp - om * trp;
-      break;
-    }
+    case 5: derive_merged(s); break;
     case 6:  // merged reductions, then the end-of-iteration rotation: the X / R update that runs between the
              // two in KSPSolve_BCGS reads alpha and omega only, which the rotation leaves alone
-      derive_scalars(s, 5);
-      derive_scalars(s, 4);
+      derive_merged(s);
+      derive_rotate(s);
       break;
-    case 4:  // end of iteration: rotate rho, next beta = (rho/rhoold)*(alpha/omega)
-      s[S_RHOOLD] = s[S_RHO]; s[S_RHO] = s[S_RHONEW];
-      if (s[S_RHO] == 0.0 && s[S_BREAK] == 0.0) s[S_BREAK] = 3.0;  // only matters if not converged
-      s[S_BETA] = (s[S_RHO] / s[S_RHOOLD]) * (s[S_ALPHA] / s[S_OMEGA]);
-      break;
+    case 4: derive_rotate(s); break;
     default: break;
   }
 }
-
 // Finalisation inside the producing launch (Fin, context.hpp).  A launch that carries a Fin has ONE
 // workgroup more than it has work: the extra one -- the last index, dispatched after every other -- waits
 // for the partial sums to arrive, sums them and derives the BiCGStab scalars.  The working workgroups do
@@ -1333,6 +1335,180 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
   }
 }
 
+// ---- K6+K8 fused, one WAVE per brick of <= 64 block rows (block sizes 3, 4; pivot-scaled DILU) ------
+// k_pc_rows spreads a brick over BS x R threads and pays a workgroup barrier per substitution level, with most
+// of its waves idle at every one of them.  A brick of at most 64 block rows fits ONE wave, one lane per block
+// row, and then no barrier is needed at all: the LDS executes a wave's instructions in order, so a level's
+// writes are seen by the next level's reads.  The lower blocks of a row stay in registers (3 x BS^2 doubles),
+// the upper ones are parked in LDS as the row streams in (k_pc_park's idea) and read back from there in the
+// backward sweep; four independent bricks share a 256-thread workgroup (no __syncthreads anywhere), ~13 bricks
+// are resident per CU, and the latency of one brick's sweeps hides behind the loads of the others.
+// Serves the 8 x 4 x 2 bricks of 3 x 3 blocks and the 8 x 4 x 1 (32 + 32 rows) MINC bricks.
+template <int BS, bool SPMV>
+__global__ __launch_bounds__(256) void k_pc_wave(
+    int n, int W, int nsub, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev,
+    const int* __restrict__ row_info, const int* __restrict__ row_uoffw, const int* __restrict__ col,
+    const double* __restrict__ sval, const double* __restrict__ dinv, const double* __restrict__ in,
+    double* __restrict__ z, const double* __restrict__ aux, double* partials, int nb_max, int dot,
+    const int* __restrict__ sub_list, const int* __restrict__ rowptr, int lds_per_brick, Fin fin) {
+  constexpr int BB = BS * BS, NL = 3, NU = 4;
+  extern __shared__ double lds[];
+  if (fin_block(fin, partials, nb_max)) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ngrp = (nsub + 3) >> 2;
+  const int g = xcd_remap(blockIdx.x, ngrp);
+  if (g >= ngrp) return;
+  int s = g * 4 + wave;
+  if (s >= nsub) return;          // wave-uniform: no workgroup barrier follows
+  if (sub_list) s = sub_list[s];
+  const int lo = sub_ptr[s], R = sub_ptr[s + 1] - lo;
+  const int nl = sub_nlev[s];
+  const int nlf = nl & 0xffff, nlb = nl >> 16;
+  const int i = lo + lane;
+  const bool active = lane < R;
+  double* ys = lds + (size_t)wave * lds_per_brick;   // [64 * BS] solution in block order
+  double* upark = ys + 64 * BS;                      // parked upper blocks, row-major BS x BS each
+  double Lf[NL][BB];
+  int Lc[NL], ucpack = 0, lf = -1, lb = -1, uo = 0, nU = 0;   // ucpack: local columns of the <= 4 upper couplings, 8 bits each
+#pragma unroll
+  for (int p = 0; p < NL; p++) {
+    Lc[p] = lane;
+#pragma unroll
+    for (int e = 0; e < BB; e++) Lf[p][e] = 0.0;
+  }
+  if (active) {
+    int lfirst, dslot, ulast;
+    unpack_info(row_info[i], lfirst, dslot, ulast, lf, lb);
+    uo = row_uoffw[i];
+    nU = ulast - dslot - 1;
+    const int cnt = rowptr ? rowptr[i + 1] - rowptr[i] : W;
+    int cgs[WMAX];
+#pragma unroll
+    for (int q = 0; q < WMAX; q++) {
+      cgs[q] = i;
+      if (q < cnt) cgs[q] = load_col(col, (size_t)q * n + i);
+    }
+    double acc[BS];
+#pragma unroll
+    for (int r = 0; r < BS; r++) acc[r] = 0.0;
+#pragma unroll
+    for (int q = 0; q < WMAX; q++) {
+      if (q < cnt) {
+        const int cg = cgs[q];
+        double blk[BB];
+#pragma unroll
+        for (int e = 0; e < BB; e++) blk[e] = __builtin_nontemporal_load(sval + vix<BS>(n, q, e, i));
+        if constexpr (SPMV) {
+          double xv[BS];
+          load_x<BS>(in, cg, xv);
+#pragma unroll
+          for (int r = 0; r < BS; r++)
+#pragma unroll
+            for (int k = 0; k < BS; k++) acc[r] += blk[r * BS + k] * xv[k];
+        }
+        const bool isl = (q >= lfirst) && (q < dslot), isu = (q > dslot) && (q < ulast);
+#pragma unroll
+        for (int p = 0; p < NL; p++) {
+          const bool tl = isl && (q - lfirst == p);
+          Lc[p] = tl ? cg - lo : Lc[p];
+#pragma unroll
+          for (int e = 0; e < BB; e++) Lf[p][e] = tl ? blk[e] : Lf[p][e];
+        }
+        if (isu) {
+          const int pu = q - dslot - 1;
+          ucpack |= (cg - lo) << (8 * pu);
+          double* dst = upark + (size_t)(uo + pu) * BB;
+#pragma unroll
+          for (int e = 0; e < BB; e++) dst[e] = blk[e];
+        }
+      }
+    }
+    if constexpr (!SPMV) {  // plain application to an unscaled vector: scale it by the inverted pivot
+#pragma unroll
+      for (int r = 0; r < BS; r++)
+#pragma unroll
+        for (int k = 0; k < BS; k++) acc[r] += dinv[vix<BS>(n, 0, r * BS + k, i)] * in[(size_t)i * BS + k];
+    }
+#pragma unroll
+    for (int r = 0; r < BS; r++) ys[lane * BS + r] = acc[r];
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int lev = 1; lev < nlf; lev++) {  // forward: y_i = t_i - sum A'_ik y_k
+    if (lf == lev) {
+      double a[BS];
+#pragma unroll
+      for (int r = 0; r < BS; r++) a[r] = ys[lane * BS + r];
+#pragma unroll
+      for (int p = 0; p < NL; p++) {
+        double yk[BS];
+#pragma unroll
+        for (int k = 0; k < BS; k++) yk[k] = ys[Lc[p] * BS + k];
+#pragma unroll
+        for (int r = 0; r < BS; r++)
+#pragma unroll
+          for (int k = 0; k < BS; k++) a[r] -= Lf[p][r * BS + k] * yk[k];
+      }
+#pragma unroll
+      for (int r = 0; r < BS; r++) ys[lane * BS + r] = a[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int lev = 0; lev < nlb; lev++) {  // backward: x_i = y_i - sum A'_ij x_j, upper blocks from LDS
+    if (lb == lev) {
+      double a[BS];
+#pragma unroll
+      for (int r = 0; r < BS; r++) a[r] = ys[lane * BS + r];
+#pragma unroll
+      for (int p = 0; p < NU; p++) {
+        if (p < nU) {
+          const double* ub = upark + (size_t)(uo + p) * BB;
+          double xk[BS];
+          const int uc = (ucpack >> (8 * p)) & 63;
+#pragma unroll
+          for (int k = 0; k < BS; k++) xk[k] = ys[uc * BS + k];
+#pragma unroll
+          for (int r = 0; r < BS; r++)
+#pragma unroll
+            for (int k = 0; k < BS; k++) a[r] -= ub[r * BS + k] * xk[k];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < BS; r++) ys[lane * BS + r] = a[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // block-order, lane-linear epilogue: the wave's R * BS results leave coalesced; dot products on the way
+  double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  const int tot = R * BS;
+#pragma unroll
+  for (int j = 0; j < BS; j++) {
+    const int t = lane + 64 * j;
+    if (t < tot) {
+      const size_t gi = (size_t)lo * BS + t;
+      const double out = ys[t];
+      __builtin_nontemporal_store(out, z + gi);
+      if (dot == 1) v[0] += out * __builtin_nontemporal_load(aux + gi);
+      else if (dot == 2) { const double xi = in[gi]; v[0] += xi * out; v[1] += out * out; }
+      else if (dot == 4) {
+        const double xi = in[gi], av = __builtin_nontemporal_load(aux + gi);
+        v[0] += xi * out; v[1] += out * out; v[2] += xi * xi; v[3] += xi * av; v[4] += out * av;
+      } else if (dot == 3) v[0] += out * out;
+    }
+  }
+  if (dot != 0) {
+    const int ns = dot == 4 ? 5 : (dot == 2 ? 2 : 1);
+    const int slot0 = dot == 3 ? S_DP2 : S_D1;   // S_D1 .. S_W2 are consecutive
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+      if (q < ns) {
+        double t = v[q];
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+        if (lane == 0) store_partial(partials + (size_t)(slot0 + q) * nb_max + s, t);
+      }
+    }
+  }
+}
+
 // ---- layout conversion (C ABI exchanges BCSR) -------------------------------------------------
 __global__ __launch_bounds__(TPB) void k_ell_to_bcsr(int n, int W, int bs, const int* __restrict__ rowptr,
                                                      const double* __restrict__ ell, double* __restrict__ bcsr) {
@@ -1648,17 +1824,41 @@ __global__ __launch_bounds__(TPB) void k_lvl_solve(int n, int cnt, const int* __
 
 // ---- PCASM: extended system ---------------------------------------------------------------------
 // E.val plane element <- J.val plane element (gmap = slot*n + row of the source block, -1: none)
-__global__ __launch_bounds__(TPB) void k_asm_gather_matrix(int n, int n_ext, int W_ext, int bs,
+// gmap: >= 0 slot * n + row of the source block in J; -1 none (zero block); <= -2: -(g + 2) = slot * n_halo + ghost
+// cell, a block of a partition-ghost cell's row as received from its owner (hval)
+__global__ __launch_bounds__(TPB) void k_asm_gather_matrix(int n, int n_ext, int W_ext, int bs, int n_halo,
                                                            const int* __restrict__ gmap,
-                                                           const double* __restrict__ jval, double* __restrict__ eval) {
+                                                           const double* __restrict__ jval,
+                                                           const double* __restrict__ hval, double* __restrict__ eval) {
   const size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;
   if (t >= (size_t)W_ext * n_ext) return;
   const int s = (int)(t / n_ext), q = (int)(t - (size_t)s * n_ext);
   const int g = gmap[t];
-  const int ss = g < 0 ? 0 : g / n, i = g < 0 ? 0 : g - ss * n;
+  const bool ghost = g <= -2;
+  const int gg = ghost ? -(g + 2) : g, nn = ghost ? n_halo : n;
+  const double* src = ghost ? hval : jval;
+  const int ss = g == -1 ? 0 : gg / nn, i = g == -1 ? 0 : gg - ss * nn;
   for (int r = 0; r < bs; r++)
     for (int k = 0; k < bs; k++)
-      eval[ell_ix(bs, (size_t)n_ext, s, r, k, (size_t)q)] = g < 0 ? 0.0 : jval[ell_ix(bs, (size_t)n, ss, r, k, (size_t)i)];
+      eval[ell_ix(bs, (size_t)n_ext, s, r, k, (size_t)q)] = g == -1 ? 0.0 : src[ell_ix(bs, (size_t)nn, ss, r, k, (size_t)i)];
+}
+// matrix rows of the cells a rank sends to its neighbours: buf[p][slot][r][k] (W * bs * bs doubles per cell)
+__global__ __launch_bounds__(TPB) void k_pack_rows(int n, int W, int bs, int nsend, const int* __restrict__ idx,
+                                                   const double* __restrict__ jval, double* __restrict__ buf) {
+  const size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;
+  const int bb = bs * bs, dof = W * bb;
+  if (t >= (size_t)nsend * dof) return;
+  const int p = (int)(t / dof), e = (int)(t - (size_t)p * dof), sl = e / bb, rk = e - sl * bb;
+  buf[t] = jval[ell_ix(bs, (size_t)n, sl, rk / bs, rk % bs, (size_t)idx[p])];
+}
+// ... and on the receiving side into block-ELL planes over the ghost cells (receive buffer in ghost order)
+__global__ __launch_bounds__(TPB) void k_unpack_rows(int n_halo, int W, int bs, const double* __restrict__ buf,
+                                                     double* __restrict__ hval) {
+  const size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;
+  const int bb = bs * bs, dof = W * bb;
+  if (t >= (size_t)n_halo * dof) return;
+  const int h = (int)(t / dof), e = (int)(t - (size_t)h * dof), sl = e / bb, rk = e - sl * bb;
+  hval[ell_ix(bs, (size_t)n_halo, sl, rk / bs, rk % bs, (size_t)h)] = buf[t];
 }
 __global__ __launch_bounds__(TPB) void k_asm_gather(int n_ext, int bs, const int* __restrict__ ext_row,
                                                     const double* __restrict__ r, double* __restrict__ r_ext) {
@@ -1827,6 +2027,22 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
                          nrun, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.fval,          \
                          s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, c->dbg, list, fin); \
   } while (0)
+  // one wave per brick of <= 64 block rows (block sizes 3 and 4), four bricks per workgroup
+  if (s.wave_kernel && !c->dbg) {
+    if constexpr (BS >= 3) {
+      const int ngrp = (nrun + 3) / 4, gridw = ((ngrp + 7) / 8) * 8 + (with_fin ? 1 : 0);
+      const int per = 64 * BS + s.max_ublocks_w * BS * BS;            // doubles per brick: solution + parked upper blocks
+      const size_t lds_w = (size_t)4 * per * sizeof(double);
+      const int* rp = (size_t)J.nnzb * 10 < (size_t)J.n * J.W * 9 ? J.rowptr : nullptr;   // > 10 % padding
+      if (spmv)
+        hipLaunchKernelGGL((k_pc_wave<BS, true>), gridw, 256, lds_w, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev, s.row_info,
+                           s.row_uoffw, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, list, rp, per, fin);
+      else
+        hipLaunchKernelGGL((k_pc_wave<BS, false>), gridw, 256, lds_w, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev, s.row_info,
+                           s.row_uoffw, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, list, rp, per, fin);
+      return;
+    }
+  }
   // one thread per scalar row: block sizes 3 and 4 (and 2 when asked for: WAI_PC_ROWS=1)
   if (s.rows_kernel && !c->dbg) {
     const int TR = ((s.max_rows * BS + 63) / 64) * 64;
@@ -1896,7 +2112,21 @@ int launch_asm_gather_matrix(wai_ctx* c) {
   const AsmSystem& a = c->as;
   const size_t tot = (size_t)a.E.W * a.n_ext;
   hipLaunchKernelGGL(k_asm_gather_matrix, (int)((tot + TPB - 1) / TPB), TPB, 0, c->stream, c->J.n, a.n_ext, a.E.W,
-                     a.E.bs, a.gmap, c->J.val, a.E.val);
+                     a.E.bs, c->mesh.n_halo, a.gmap, c->J.val, a.hval, a.E.val);
+  return 0;
+}
+int launch_pack_rows(wai_ctx* c) {
+  const Bcsr& J = c->J;
+  const size_t tot = (size_t)c->send_total * J.W * J.bs * J.bs;
+  if (tot) hipLaunchKernelGGL(k_pack_rows, (int)((tot + TPB - 1) / TPB), TPB, 0, c->stream, J.n, J.W, J.bs, c->send_total,
+                              c->d_send_idx, J.val, c->d_sendbuf);
+  return 0;
+}
+int launch_unpack_rows(wai_ctx* c) {
+  const Bcsr& J = c->J;
+  const size_t tot = (size_t)c->mesh.n_halo * J.W * J.bs * J.bs;
+  if (tot) hipLaunchKernelGGL(k_unpack_rows, (int)((tot + TPB - 1) / TPB), TPB, 0, c->stream, c->mesh.n_halo, J.W, J.bs,
+                              c->d_recvbuf, c->as.hval);
   return 0;
 }
 int launch_asm_gather(wai_ctx* c, const double* r) {
