@@ -339,6 +339,8 @@ def main():
     ap.add_argument("--minc", action="store_true", default=None)
     ap.add_argument("--brick", type=int, nargs=3, default=None,
                     help="preconditioner subdomain shape (cells): wide in x, y and thin in z because k_z = 0.1 k_x")
+    ap.add_argument("--brick-order", default="z", choices=["z", "x"],
+                    help="numbering of the bricks: vertical neighbour bricks adjacent in memory (z), or x fastest (rounds 1, 2)")
     ap.add_argument("--dt0", type=float, default=1.0e4)
     ap.add_argument("--lead", type=int, default=3, help="accepted time steps run before the measured window")
     ap.add_argument("--window", type=int, default=5, help="accepted time steps in the measured cycle")
@@ -419,7 +421,7 @@ def main():
     # shape of 256-512 cells tried at 216^3 needs 190-1360 iterations (18x12x2 195, 16x8x2 304, 8x8x8 1363)
     brick = tuple(a.brick) if a.brick else ((8, 4, 1) if minc else ((8, 5, 2) if eos == "wce" else (16, 16, 2)))
     grid, lm, prim, region = make_case(dims=dims, brick=brick, eos=eos, lens=not a.no_lens, minc=minc,
-                                       part=M.partition_shape(world), rank=rank)
+                                       part=M.partition_shape(world), rank=rank, brick_order=a.brick_order)
     opts = wl.default_opts(ksp_type=a.ksp, pc_type=a.pc, ilu_levels=a.ilu_levels)
     sim = FlowSimulation(lm, eos=eos, opts=opts, device=local_rank)
     sim.set_regions(region)
