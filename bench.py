@@ -339,7 +339,7 @@ def main():
     ap.add_argument("--minc", action="store_true", default=None)
     ap.add_argument("--brick", type=int, nargs=3, default=None,
                     help="preconditioner subdomain shape (cells): wide in x, y and thin in z because k_z = 0.1 k_x")
-    ap.add_argument("--brick-order", default="z", choices=["z", "x"],
+    ap.add_argument("--brick-order", default="x", choices=["z", "x"],
                     help="numbering of the bricks: vertical neighbour bricks adjacent in memory (z), or x fastest (rounds 1, 2)")
     ap.add_argument("--dt0", type=float, default=1.0e4)
     ap.add_argument("--lead", type=int, default=3, help="accepted time steps run before the measured window")

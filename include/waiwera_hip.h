@@ -182,7 +182,7 @@ int wai_set_source_controls(wai_ctx *ctx, const wai_source_control *controls);
  * The dependencies between cells that the network adds to the Jacobian (flow_simulation_modify_jacobian,
  * src/flow_simulation.F90:3023-3084; source_network_identify_source_dependencies,
  * src/source_network.F90:359-498) are kept beside the 7-point matrix: see wai_get_network_couplings.
- * All sources of the network must live on this rank.  Call after wai_set_sources / controls. */
+ * On one rank; for sources on several ranks see wai_set_source_global_index.  Call after wai_set_sources / controls. */
 int wai_set_source_network(wai_ctx *ctx, const int *rate_specified, const int *enthalpy_specified,
                            int n_groups, const int *grp_ptr, const int *grp_in_kind, const int *grp_in,
                            const int *grp_scaling, const int *grp_limit_type, const double *grp_limit,
@@ -198,6 +198,13 @@ int wai_set_source_network(wai_ctx *ctx, const int *rate_specified, const int *e
  * A alone.  n_cells = m (0: no network, switched off, or E = 0 at this state); cells (may be NULL) m local
  * cell indices, ascending; values (may be NULL) m x m blocks of bs x bs, row-major [row cell][col cell][r][k].
  * wai_set_network_couplings(ctx, 0) holds the factors instead (round 1's inexact Newton); default on. */
+/* A network whose sources live on several ranks (the reference gathers over the group's communicator,
+ * src/source_network_group.F90:494-515, 579-596, 701-709; source_network_reinjector.F90:534, 740, 772-789): every
+ * rank hands wai_set_source_network the SAME description, numbered by global source index, after telling which
+ * global index each of its own sources has.  The sources' own rates are then all-gathered before every network
+ * pass (one small all-reduce per residual evaluation) and the pass runs identically on every rank.  The Jacobian
+ * blocks through the network are not formed in that case (factors held, as wai_set_network_couplings(ctx, 0)). */
+int wai_set_source_global_index(wai_ctx *ctx, int n_global, const int *global_index);
 int wai_set_network_couplings(wai_ctx *ctx, int on);
 int wai_get_network_couplings(wai_ctx *ctx, int *n_cells, int *cells, double *values);
 /* after the last pass: groups 6 doubles each (rate, enthalpy, water_rate, water_enthalpy, steam_rate,

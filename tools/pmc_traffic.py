@@ -35,7 +35,7 @@ def main(src, tag, dst):
     dims = [int(v) for v in m.groups()]
     mb = re.search(r"\((\d+)x(\d+)x(\d+) bricks\)", bench["config"]["workload"])
     brick = [int(v) for v in mb.groups()]
-    pc = find(r"k_pc_park<true|k_pc_rows<\d, true|k_pc<\d, true")
+    pc = find(r"k_pc_park<true|k_pc_rows<\d, true|k_pc_wave<\d, true|k_pc<\d, true")
     sp = find(r"k_spmv<")
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python "
                      "bench.py --config ... --lead 1 --steps 1 --warmup 0 --no-cpu --spmv-reps 10 on 1 x MI355X; " +
@@ -46,8 +46,8 @@ def main(src, tag, dst):
            "dims": dims, "brick": brick, "k_pc_kernel": pc,
            "k_pc_hbm_bytes_per_launch": hbm(pc), "k_pc_algorithmic_bytes": roof["algorithmic_bytes_per_launch"],
            "k_pc_traffic_over_algorithmic": hbm(pc) / roof["algorithmic_bytes_per_launch"],
-           "k_spmv_hbm_bytes_per_launch": hbm(sp), "k_spmv_algorithmic_bytes": roof["spmv"]["algorithmic_bytes_per_launch"],
-           "k_spmv_traffic_over_algorithmic": hbm(sp) / roof["spmv"]["algorithmic_bytes_per_launch"]}
+           "k_spmv_hbm_bytes_per_launch": hbm(sp), "k_spmv_algorithmic_bytes": roof["spmv_algorithmic_bytes_per_launch"],
+           "k_spmv_traffic_over_algorithmic": hbm(sp) / roof["spmv_algorithmic_bytes_per_launch"]}
     for name, pat in (("k_bcgs_p", r"k_bcgs_p"), ("k_jacobian", r"k_jacobian"), ("k_residual", r"k_residual"),
                       ("k_eos_pert", r"k_eos_pert")):
         k = find(pat)

@@ -22,3 +22,7 @@ run ilu0_c2 --config c2 --steps 20 --warmup 5
 run ilu1_c2 --config c2 --steps 20 --warmup 5 --ilu-levels 1
 run ilu2_c2 --config c2 --steps 20 --warmup 5 --ilu-levels 2
 run asm_c2 --config c2 --steps 20 --warmup 5 --pc asm
+run share8_nt --rank-share 8 --steps 20 --warmup 5
+WAI_EXTRA_HIPCC_FLAGS="-DWAI_NO_NT=1" python -m waiwera_amd.build --force > /dev/null 2>&1
+run share8_nont --rank-share 8 --steps 20 --warmup 5
+python -m waiwera_amd.build --force > /dev/null 2>&1

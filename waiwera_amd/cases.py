@@ -7,7 +7,7 @@ from waiwera_amd import mesh as M
 
 
 def make_case(dims=(8, 8, 8), brick=(4, 4, 4), eos="we", lens=False, sources=True, part=(1, 1, 1),
-              rank=0, hetero=True, top_bc=True, minc=False, spacing=None, brick_order="z"):
+              rank=0, hetero=True, top_bc=True, minc=False, spacing=None, brick_order="x"):
     if spacing is None:
         # the two-phase lens sits 400..500 m deep: stretch shallow test boxes so that their bottom
         # layer falls inside it (otherwise lens=True silently means no lens)

@@ -756,33 +756,47 @@ void network_evaluate(Network& nw) {
 
 int network_update(wai_ctx* c) {
   Network& nw = c->net;
-  const int n = c->src.n;
-  if (!nw.on || n == 0) return 0;
+  const int n = c->src.n;           // local sources
+  if (!nw.on) return 0;
+  const bool span = !nw.gidx.empty();
+  const int ng = span ? nw.n_global : n;
+  if (ng == 0) return 0;
   // the sources' own (controlled) rates and flowing enthalpies on the current fluid
-  launch_source_rates(c, nw.d_raw, true);
-  HIPCHK(c, hipMemcpyAsync(nw.h_raw.data(), nw.d_raw, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (n) {
+    launch_source_rates(c, nw.d_raw, true);
+    HIPCHK(c, hipMemcpyAsync(span ? nw.h_loc.data() : nw.h_raw.data(), nw.d_raw, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  if (span) {   // all ranks' sources: every rank fills its own entries, the sum is the gather (collective)
+    std::fill(nw.h_raw.begin(), nw.h_raw.end(), 0.0);
+    for (int i = 0; i < n; i++) { nw.h_raw[nw.gidx[i]] = nw.h_loc[i]; nw.h_raw[ng + nw.gidx[i]] = nw.h_loc[n + i]; }
+    HIPCHK(c, hipMemcpyAsync(nw.d_all, nw.h_raw.data(), sizeof(double) * 2 * ng, hipMemcpyHostToDevice, c->stream));
+    if (comm_allreduce(c->comm, nw.d_all, 2 * (size_t)ng, 0, c->stream, c->err)) return -1;
+    HIPCHK(c, hipMemcpyAsync(nw.h_raw.data(), nw.d_all, sizeof(double) * 2 * ng, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   network_evaluate(nw);
+  if (!n) return 0;
   const std::vector<double>& out_rate = nw.out_rate;
-  const std::vector<double>& out_enth = nw.out_enth;
   const std::vector<char>& is_out = nw.is_out;
   // hand the result to the device: scale factors of group members, rates / enthalpies of reinjection sources
   bool enth_changed = false;
   for (int i = 0; i < n; i++) {
+    const int g = span ? nw.gidx[i] : i;
     double mode = 0.0, val = 0.0;
-    if (is_out[i]) {
-      mode = 2.0; val = out_rate[i];
-      const double e = nw.src[i].enth;
-      if (e != nw.h_enth[i]) { nw.h_enth[i] = e; enth_changed = true; }
-    } else if (nw.src[i].rate != nw.h_raw[i]) {
-      mode = 1.0; val = nw.h_raw[i] != 0.0 ? nw.src[i].rate / nw.h_raw[i] : 1.0;
+    if (is_out[g]) {
+      mode = 2.0; val = out_rate[g];
+      const double e = nw.src[g].enth;
+      if (e != nw.l_enth[i]) { nw.l_enth[i] = e; enth_changed = true; }
+    } else if (nw.src[g].rate != nw.h_raw[g]) {
+      mode = 1.0; val = nw.h_raw[g] != 0.0 ? nw.src[g].rate / nw.h_raw[g] : 1.0;
     }
-    nw.h_net[2 * i] = mode; nw.h_net[2 * i + 1] = val;
+    nw.l_net[2 * i] = mode; nw.l_net[2 * i + 1] = val;
   }
-  HIPCHK(c, hipMemcpyAsync(c->src.net, nw.h_net.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->src.net, nw.l_net.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
   if (enth_changed)
-    HIPCHK(c, hipMemcpyAsync(c->src.enth, nw.h_enth.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));   // h_net / h_enth are reused by the next pass
+    HIPCHK(c, hipMemcpyAsync(c->src.enth, nw.l_enth.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // l_net / l_enth are reused by the next pass
   return 0;
 }
 
@@ -2110,9 +2124,14 @@ int wai_update_sources(wai_ctx* c, const double* rate, const double* enthalpy) {
   if (rate) HIPCHK(c, hipMemcpyAsync(c->src.rate, rate, nb, hipMemcpyDefault, c->stream));
   if (enthalpy) HIPCHK(c, hipMemcpyAsync(c->src.enth, enthalpy, nb, hipMemcpyDefault, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (enthalpy && c->net.h_enth0.size() == (size_t)c->src.n && !is_device_ptr(enthalpy)) {
-    c->net.h_enth0.assign(enthalpy, enthalpy + c->src.n);
-    c->net.h_enth = c->net.h_enth0;
+  if (enthalpy && !is_device_ptr(enthalpy)) {   // the network's host copies of the specified injection enthalpies
+    Network& nw = c->net;
+    const bool span = !nw.gidx.empty();
+    for (int i = 0; i < c->src.n; i++) {
+      const size_t g = span ? (size_t)nw.gidx[i] : (size_t)i;
+      if (g < nw.h_enth0.size()) nw.h_enth0[g] = enthalpy[i];
+      if ((size_t)i < nw.l_enth.size()) nw.l_enth[i] = enthalpy[i];
+    }
   }
   return 0;
 }
@@ -2136,7 +2155,9 @@ int wai_set_source_controls(wai_ctx* c, const wai_source_control* controls) {
     }
   }
   if (!s.ctl) HIPCHK(c, hipMalloc(&s.ctl, sizeof(SrcCtl) * (size_t)s.n));
-  c->net.h_ctl.assign(reinterpret_cast<const SrcCtl*>(controls), reinterpret_cast<const SrcCtl*>(controls) + s.n);
+  if (c->net.gidx.empty()) c->net.h_ctl.assign(reinterpret_cast<const SrcCtl*>(controls), reinterpret_cast<const SrcCtl*>(controls) + s.n);
+  else   // a network across ranks numbers its control records globally: this rank's own entries
+    for (int i = 0; i < s.n; i++) c->net.h_ctl[c->net.gidx[i]] = reinterpret_cast<const SrcCtl*>(controls)[i];
   HIPCHK(c, hipMemcpyAsync(s.ctl, controls, sizeof(SrcCtl) * (size_t)s.n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
@@ -2214,10 +2235,8 @@ int network_build(Network& nw, int n, const int* rate_specified, const int* enth
     for (int r = 0; r < n_reinj; r++) if (!visit(r)) { err = "source network reinjectors form a cycle"; return -2; }
   }
   nw.src.assign(n, NetNode());
-  nw.h_net.assign(2 * (size_t)n, 0.0);
   nw.h_raw.assign(2 * (size_t)n, 0.0);
   if (nw.h_enth0.size() != (size_t)n) nw.h_enth0.assign(n, 0.0);
-  nw.h_enth = nw.h_enth0;
   return 0;
 }
 // the cells whose equations and unknowns the network ties together: every source a group, a reinjector input,
@@ -2258,15 +2277,66 @@ int wai_set_source_network(wai_ctx* c, const int* rate_specified, const int* ent
   nw = Network();
   nw.h_ctl = ctl; nw.h_enth0 = e0; nw.h_cell = cells; nw.coupling = coupling;
   if (n_groups <= 0 && n_reinj <= 0) return 0;
-  if (c->comm && c->comm->nranks > 1) { c->err = "source networks across ranks are not supported"; return -2; }
-  if (int e = network_build(nw, n, rate_specified, enthalpy_specified, n_groups, grp_ptr, grp_in_kind, grp_in, grp_scaling,
+  const bool span = c->comm && c->comm->nranks > 1;
+  int ng = n;
+  if (span) {
+    // the description is numbered by global source index (wai_set_source_global_index); what the pass needs of
+    // the other ranks' sources -- separator enthalpies, specified injection enthalpies -- is gathered once, here
+    if ((int)c->src_gidx.size() != n || c->src_nglobal < n) { c->err = "source network on several ranks: wai_set_source_global_index first"; return -2; }
+    ng = c->src_nglobal;
+    for (int g : c->src_gidx) if (g < 0 || g >= ng) { c->err = "global source index out of range"; return -2; }
+    nw.gidx = c->src_gidx;
+    nw.n_global = ng;
+    std::vector<double> all((size_t)9 * ng, 0.0);
+    for (int i = 0; i < n; i++) {
+      const int g = nw.gidx[i];
+      if (i < (int)ctl.size()) {
+        all[(size_t)9 * g] = ctl[i].sep_hf; all[(size_t)9 * g + 1] = ctl[i].sep_hg;
+        for (int q = 0; q < 6; q++) all[(size_t)9 * g + 2 + q] = ctl[i].sep_more[q];
+      }
+      all[(size_t)9 * g + 8] = i < (int)e0.size() ? e0[i] : 0.0;
+    }
+    double* tmp = nullptr;
+    if (dev_upload(c, &tmp, all)) return -1;
+    int rc = comm_allreduce(c->comm, tmp, all.size(), 0, c->stream, c->err);
+    if (!rc && hipMemcpyAsync(all.data(), tmp, sizeof(double) * all.size(), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = -1;
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = -1;
+    (void)hipFree(tmp);
+    if (rc) return -1;
+    nw.h_ctl.assign((size_t)ng, SrcCtl{});
+    nw.h_enth0.assign((size_t)ng, 0.0);
+    for (int g = 0; g < ng; g++) {
+      nw.h_ctl[g].sep_hf = all[(size_t)9 * g]; nw.h_ctl[g].sep_hg = all[(size_t)9 * g + 1];
+      for (int q = 0; q < 6; q++) nw.h_ctl[g].sep_more[q] = all[(size_t)9 * g + 2 + q];
+      nw.h_enth0[g] = all[(size_t)9 * g + 8];
+    }
+    // the Jacobian blocks through the network would couple cells of different ranks: the network's factors are
+    // held in the Jacobian instead (wai_set_network_couplings(ctx, 0) semantics)
+    nw.coupling = false;
+  }
+  if (int e = network_build(nw, ng, rate_specified, enthalpy_specified, n_groups, grp_ptr, grp_in_kind, grp_in, grp_scaling,
                             grp_limit_type, grp_limit, grp_sep, n_reinj, rj_in_kind, rj_in, rj_out_ptr, out_flow, out_kind,
                             out_node, out_rate, out_proportion, out_enthalpy, rj_overflow_kind, rj_overflow, c->err))
     return e;
-  if (dev_alloc(c, &nw.d_raw, 2 * (size_t)n) || dev_alloc(c, &c->src.net, 2 * (size_t)n)) return -1;
-  HIPCHK(c, hipMemset(c->src.net, 0, sizeof(double) * 2 * n));
+  if (dev_alloc(c, &nw.d_raw, 2 * (size_t)std::max(n, 1)) || dev_alloc(c, &c->src.net, 2 * (size_t)std::max(n, 1))) return -1;
+  if (span && dev_alloc(c, &nw.d_all, 2 * (size_t)ng)) return -1;
+  HIPCHK(c, hipMemset(c->src.net, 0, sizeof(double) * 2 * std::max(n, 1)));
+  nw.h_loc.assign(2 * (size_t)n, 0.0);
+  nw.l_net.assign(2 * (size_t)n, 0.0);
+  nw.l_enth.assign((size_t)n, 0.0);
+  for (int i = 0; i < n; i++) nw.l_enth[i] = span ? nw.h_enth0[nw.gidx[i]] : (i < (int)nw.h_enth0.size() ? nw.h_enth0[i] : 0.0);
   nw.on = true;
-  network_cells(nw, n);
+  if (!span) network_cells(nw, n);
+  return 0;
+}
+
+// Global index of every local source, for a source network whose sources live on several ranks: the network
+// description handed to wai_set_source_network then refers to sources by these indices (0 .. n_global - 1), the same
+// description on every rank.  After wai_set_sources, before wai_set_source_network.
+int wai_set_source_global_index(wai_ctx* c, int n_global, const int* global_index) {
+  if (!c || n_global < 0 || (c->src.n > 0 && !global_index)) return -2;
+  c->src_gidx.assign(global_index, global_index + c->src.n);
+  c->src_nglobal = n_global;
   return 0;
 }
 
@@ -2425,7 +2495,8 @@ int wai_get_source_separated(wai_ctx* c, double* out4) {
   for (int i = 0; i < n; i++) {
     NetNode nd;
     nd.rate = q[i]; nd.enth = h[i];
-    if (q[i] < 0.0 && i < (int)c->net.h_ctl.size() && c->net.h_ctl[i].sep_hg > 0.0) net_separate(c->net.h_ctl[i], q[i], h[i], nd);
+    const int g = c->net.gidx.empty() ? i : c->net.gidx[i];   // the network's control records are numbered globally
+    if (q[i] < 0.0 && g < (int)c->net.h_ctl.size() && c->net.h_ctl[g].sep_hg > 0.0) net_separate(c->net.h_ctl[g], q[i], h[i], nd);
     out4[4 * i] = nd.wrate; out4[4 * i + 1] = nd.wenth; out4[4 * i + 2] = nd.srate; out4[4 * i + 3] = nd.senth;
   }
   return 0;

@@ -83,10 +83,18 @@ struct Network {
   std::vector<int> reinj_order;                    // outputs / overflow targets before their feeders
   std::vector<int> rate_specified, enth_specified; // per source
   std::vector<NetNode> src;                        // per source, last pass
-  std::vector<double> h_net, h_enth0, h_enth, h_raw, out_rate, out_enth;
+  std::vector<double> h_enth0, h_raw, out_rate, out_enth;
   std::vector<char> is_out;                        // sources a reinjector feeds (last pass)
   std::vector<SrcCtl> h_ctl;                       // host copy of the control records (separators)
   double* d_raw = nullptr;                         // device scratch: raw rates and enthalpies, 2 n
+  // A network whose sources live on several ranks (source_network_group.F90:494-515, 579-596: gathers over the
+  // group's communicator): every rank holds the whole description, numbered by GLOBAL source index; the sources' own
+  // rates are all-gathered (an all-reduce of a vector each rank fills at its own entries) before the pass, which
+  // every rank then evaluates identically.  gidx: global index of each local source; empty: one rank, identity
+  std::vector<int> gidx;
+  int n_global = 0;
+  double* d_all = nullptr;                         // [2 n_global] all-reduce buffer
+  std::vector<double> h_loc, l_net, l_enth;        // local staging: raw rates (2 n_local), factors (2 n_local), enthalpies
   // Jacobian couplings through the network (flow_simulation_modify_jacobian, src/flow_simulation.F90:3023-3084,
   // dependencies of src/source_network.F90:359-498): blocks E[i][j] = d R(cell i) / d y(cell j) *through the
   // network pass* for the cells of the network's sources (the reference inserts the outer product of its
@@ -101,6 +109,8 @@ struct Network {
   double *d_cp_val = nullptr, *d_cp_f = nullptr, *d_cp_g = nullptr;
   void free_device() {
     if (d_raw) (void)hipFree(d_raw);
+    if (d_all) (void)hipFree(d_all);
+    d_all = nullptr;
     if (d_cp_cells) (void)hipFree(d_cp_cells);
     if (d_cp_val) (void)hipFree(d_cp_val);
     if (d_cp_f) (void)hipFree(d_cp_f);
@@ -272,6 +282,8 @@ struct wai_ctx {
   wai::DeviceMesh mesh;
   wai::Sources src;
   wai::Network net;
+  std::vector<int> src_gidx;    // wai_set_source_global_index: global index of every local source (networks across ranks)
+  int src_nglobal = 0;
   wai::Bcsr J;
   wai::IluSchedule ilu;
   wai::AsmSystem as;

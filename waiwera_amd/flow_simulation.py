@@ -101,6 +101,13 @@ class FlowSimulation:
         self._chk(LIB.wai_set_source_network(self.h, *args), "set_source_network")
         self._net_sizes = (len(g), len(r))
 
+    def set_source_global_index(self, n_global, global_index):
+        """a source network across ranks: the global index of each of this rank's sources (the description given
+        to set_source_network is then numbered globally, the same on every rank)"""
+        gi = _lib._i32(global_index)
+        self._gidx_keep = gi
+        self._chk(LIB.wai_set_source_global_index(self.h, int(n_global), gi.ctypes.data_as(_lib.pi)), "set_source_global_index")
+
     def source_network(self):
         """(groups (n, 6): rate, enthalpy, water_rate, water_enthalpy, steam_rate, steam_enthalpy;
         reinjectors (n, 8): output water / steam rate, overflow rate, enthalpy, water rate, water enthalpy, steam

@@ -122,6 +122,7 @@ def _load():
         "wai_network_cells": (i32, [i32, pi, pi, pi, i32, pi, pi, pi, pi, pi, pd, pd, i32, pi, pi, pi, pi, pi, pi, pd, pd,
                                     pd, pi, pi, pi, pi]),
         "wai_get_source_network": (i32, [vp, pd, pd]),
+        "wai_set_source_global_index": (i32, [vp, i32, pi]),
         "wai_set_network_couplings": (i32, [vp, i32]),
         "wai_get_network_couplings": (i32, [vp, pi, pi, pd]),
         "wai_separator_enthalpies": (i32, [vp, d, pd, pd]),

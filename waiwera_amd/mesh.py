@@ -109,17 +109,17 @@ class StructuredGrid:
     """Global description of an nx*ny*nz box split over px*py*pz ranks."""
 
     def __init__(self, dims, spacing=(10.0, 10.0, 10.0), part=(1, 1, 1), brick=(8, 8, 8),
-                 order="hyperplane", brick_order="z"):
+                 order="hyperplane", brick_order="x"):
         # order: numbering of the cells inside a brick.  "hyperplane" sorts them by i+j+k (ties in
         # natural order) = by dependency level of the brick's ILU(0) factors, so storage order is
         # level order and a wavefront owns whole consecutive levels; "natural" is x-fastest.
         self.order = order
-        # brick_order: which way the bricks of a rank are numbered.  "z" (default): the brick above / below follows
-        # directly.  In a flat brick (16 x 16 x 2) every cell has one vertical neighbour outside its brick, against
-        # one cell in eight for x / y: with the vertical neighbour bricks next in memory -- 94 KB of fluid records
-        # apart instead of 18 MB at 216^3 -- the assembly sweeps find those records in their XCD's L2.  The
-        # block-Jacobi bricks are independent, so the preconditioner does not depend on their order.  "x": x fastest
-        # (rounds 1 and 2).
+        # brick_order: which way the bricks of a rank are numbered: "x" x fastest (default), "z" with the brick above /
+        # below following directly.  The block-Jacobi bricks are independent, so the preconditioner does not depend on
+        # it; it only moves the out-of-brick neighbours in memory.  MEASURED at 216^3 (rocprofv3, one box, round 3): "z"
+        # k_pc_park 621 against 631 us, but k_jacobian_park 10.87 against 10.57 ms and k_residual 2.73 against 2.66 ms --
+        # the assembly sweeps' re-reads are a capacity problem (a brick's 31 field planes of own + neighbour lines, ~160 KB,
+        # against 128 KB of L2 per CU), not a distance problem; not adopted.
         if brick_order not in ("z", "x"):
             raise ValueError("brick_order 'z' or 'x'")
         self.brick_order = brick_order
