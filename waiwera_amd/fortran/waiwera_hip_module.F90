@@ -147,6 +147,20 @@ module waiwera_hip_module
        integer(c_int), intent(out) :: n_cells
        type(c_ptr), value :: cells, values   ! c_loc of integer(c_int) / real(c_double) arrays, or c_null_ptr
      end function wai_get_network_couplings
+     ! a source network whose sources live on several ranks: the global index of each local source, before
+     ! wai_set_source_network is given the globally numbered description (source_network_group.F90:494-515, 579-596)
+     integer(c_int) function wai_set_source_global_index(ctx, n_global, global_index) bind(c, name = "wai_set_source_global_index")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n_global
+       integer(c_int), intent(in) :: global_index(*)
+     end function wai_set_source_global_index
+     ! kernels launched / copies enqueued by the linear solver so far (a BiCGStab iteration: 5 kernels, no copy)
+     integer(c_int) function wai_launch_stats(ctx, kernels, copies) bind(c, name = "wai_launch_stats")
+       import :: c_int, c_ptr, c_long_long
+       type(c_ptr), value :: ctx
+       integer(c_long_long), intent(out) :: kernels, copies
+     end function wai_launch_stats
      integer(c_int) function wai_set_regions(ctx, region) bind(c, name = "wai_set_regions")
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx
@@ -340,6 +354,7 @@ module waiwera_hip_module
 
   public :: wai_set_tracers, wai_set_tracer_bc, wai_set_tracer_injection, wai_set_aux_solver
   public :: wai_set_source_network, wai_get_source_network, wai_set_network_couplings, wai_get_network_couplings
+  public :: wai_set_source_global_index, wai_launch_stats
   public :: wai_default_eos, wai_default_opts, wai_set_bc, wai_set_sources, wai_update_sources, wai_set_source_controls, wai_get_source_rates, wai_separator_enthalpies, wai_set_regions, &
        wai_get_regions, wai_jacobian_nnzb, wai_jacobian_pattern, wai_jacobian_get_values
 
