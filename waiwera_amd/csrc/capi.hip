@@ -1158,19 +1158,22 @@ int pc_amul(wai_ctx* c, double* x, double* z, int dot_mode = 0, const double* au
 // no copy, no event -- the host spins on the pinned word the device writes last
 int wait_post(wai_ctx* c, int seq) {
   Krylov& k = c->ks;
-  volatile double* post = k.h_scal + POST_OFF;
-  const double want = (double)seq;
-  for (unsigned long long spin = 1; post[16] != want; spin++) {
+  volatile double* post = k.h_scal + POST_OFF;   // {(R,R), 4 * sequence number + breakdown code}: one 16-byte device store
+  const double lo = 4.0 * (double)seq, hi = lo + 4.0;
+  double tag = post[1];
+  for (unsigned long long spin = 1; !(tag >= lo && tag < hi); spin++, tag = post[1]) {
     if ((spin & 0x3fff) == 0) {   // a stream that ran dry without posting, or a device error: do not spin forever
       const hipError_t e = hipStreamQuery(c->stream);
-      if (e != hipErrorNotReady && post[16] != want) {
+      tag = post[1];
+      if (e != hipErrorNotReady && !(tag >= lo && tag < hi)) {
         c->err = e == hipSuccess ? "scalars were not posted by the device" : std::string("stream: ") + hipGetErrorString(e);
         return -1;
       }
     }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  for (int i = 0; i < 16; i++) k.h_scal[i] = post[i];
+  k.h_scal[S_DP2] = post[0];
+  k.h_scal[S_BREAK] = tag - lo;
   return 0;
 }
 

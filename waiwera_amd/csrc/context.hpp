@@ -207,7 +207,7 @@ struct ResForm {
 // Passive tracers (src/tracer.F90:30-40) and the auxiliary linear problem's solver settings
 // (timestepper.F90:2021-2022, 2061-2064: gmres + bjacobi unless configured)
 constexpr int MAX_TRACERS = 8;
-constexpr int POST_OFF = 64;   // h_scal[POST_OFF .. POST_OFF + 16]: scalars and sequence number posted by the device
+constexpr int POST_OFF = 64;   // h_scal[POST_OFF], [POST_OFF + 1]: {(R,R), 4 * sequence number + breakdown code} posted by the device in one 16-byte store
 struct Tracers {
   int nt = 0;
   int phase[MAX_TRACERS] = {0};
@@ -235,9 +235,9 @@ struct Fin {
   int nb = 0;                  // partials per slot to sum (an earlier launch may have left some of them)
   int slot0 = 0, nslots = 0;
   int phase = -1;              // derive_scalars phase, -1: sums only
-  int seq = 0;                 // > 0: post scal[0..16) and this sequence number to `post`
+  int seq = 0;                 // > 0: post (R,R) and the breakdown code with this sequence number to `post`
   double* scal = nullptr;
-  double* post = nullptr;      // device address of the pinned host mirror: [16] scalars, [16] = seq
+  double* post = nullptr;      // device address of the pinned host mirror (16 bytes, 16-byte aligned)
 };
 
 struct Krylov {

@@ -834,15 +834,23 @@ __global__ __launch_bounds__(TPB) void k_max_scaled(const double* __restrict__ v
   }
 }
 
+// one wave: lanes scan the per-block results strided, then the same first-index tie-break across lanes (a single
+// thread walking ~1000 dependent loads took 100 us -- 6 % of a Newton step's fixed part at a rank's share of 216^3)
 __global__ void k_max_scaled_final(int nb, double* pval, int* pidx) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double best = pval[0];
-    int bi = pidx[0];
-    for (int q = 1; q < nb; q++)
-      if (pval[q] > best || (pval[q] == best && pidx[q] < bi)) { best = pval[q]; bi = pidx[q]; }
-    pval[0] = best;
-    pidx[0] = bi;
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  double best = -1.0;
+  int bi = 0x7fffffff;
+  for (int q = threadIdx.x; q < nb; q += 64) {
+    const double v = pval[q];
+    const int i = pidx[q];
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
   }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ob = __shfl_down(best, off);
+    const int oi = __shfl_down(bi, off);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (threadIdx.x == 0) { pval[0] = best; pidx[0] = bi; }
 }
 
 // ---- layout helpers --------------------------------------------------------------------------

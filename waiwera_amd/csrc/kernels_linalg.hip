@@ -523,14 +523,17 @@ __global__ __launch_bounds__(TPB) void k_scale_rows(int n, int W, const double* 
 }
 
 // ---- reductions finished inside the producing kernel ---------------------------------------------
-// The scalars the host tests after an iteration, written straight into pinned host memory: the 16 scalars,
-// then -- once those stores have completed -- the sequence number the host spins on (wait_post, capi.hip).
+// What the host tests after an iteration -- the squared residual norm and the breakdown code -- written straight
+// into pinned host memory as ONE aligned 16-byte store: {(R,R), 4 * sequence number + breakdown code}.  One PCIe
+// write carries both, so the host, spinning on the second word (wait_post, capi.hip), never sees one without the
+// other, and the posting workgroup neither issues 17 stores nor waits for their acknowledgement.
+typedef unsigned wai_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void post_scalars(const double* scal, double* post, int seq) {
-  for (int i = 0; i < 16; i++) __hip_atomic_store(post + i, scal[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __atomic_signal_fence(__ATOMIC_SEQ_CST);
-  __builtin_amdgcn_s_waitcnt(0);
-  __atomic_signal_fence(__ATOMIC_SEQ_CST);
-  __hip_atomic_store(post + 16, (double)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const double v0 = scal[S_DP2], v1 = 4.0 * (double)seq + scal[S_BREAK];
+  wai_u4 w;
+  w.x = (unsigned)__double2loint(v0); w.y = (unsigned)__double2hiint(v0);
+  w.z = (unsigned)__double2loint(v1); w.w = (unsigned)__double2hiint(v1);
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(post), "v"(w) : "memory");
 }
 // merged reductions (multi-rank): slots hold (S,T), (T,T), (S,S), (S,RP), (T,RP).  omega = (S,T)/(T,T) (see
 // phase 3 for (T,T) = 0); then, with R = S - omega T:  (R,RP) = (S,RP) - omega (T,RP)  and
@@ -594,27 +597,40 @@ __device__ __forceinline__ void derive_scalars(double* s, int phase) {
 // counters, no fence, 0.70 ms (each workgroup holds its CU slot ~2 us longer for the store acknowledgement
 // and the returning atomic).
 constexpr unsigned long long FIN_EMPTY = 0x7FF4DEADBEEF0001ull;
-__device__ __forceinline__ double fin_take(const double* p, bool wait) {
-  unsigned long long* q = reinterpret_cast<unsigned long long*>(const_cast<double*>(p));
-  unsigned long long u = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // bounded: a partial that never arrives becomes a NaN sum (KSP_DIVERGED_NANORINF), not a hung device
-  for (int spin = 0; wait && u == FIN_EMPTY && spin < (1 << 22); spin++) {
-    __builtin_amdgcn_s_sleep(8);
-    u = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __hip_atomic_store(q, FIN_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return __longlong_as_double((long long)u);   // FIN_EMPTY itself is a NaN
-}
-// sums of nslots slots -> scal, k_finalize's order, by a workgroup of any size (multiple of 64)
+// sums of nslots slots -> scal, k_finalize's order, by a workgroup of any size (multiple of 64).  A virtual
+// thread's partials are fetched eight at a time -- independent agent-scope loads in flight together; one dependent
+// round trip per entry cost 2 us each, 40 us at 21 168 partials (MEASURED: k_pc_park 603 us under rocprofv3 against
+// 583 before the reductions moved into it) -- and added in ascending order; an entry that has not arrived yet is
+// polled (bounded: a partial that never arrives becomes a NaN sum, KSP_DIVERGED_NANORINF, not a hung device).
 __device__ __forceinline__ void sum_partials(const double* partials, int nb_max, int nb, int slot0, int nslots,
                                              double* scal, bool wait) {
   __shared__ double fsm[16];
+  constexpr int CH = 8;
   const int VT = nb > 256 ? 1024 : 256;
   for (int s = 0; s < nslots; s++) {
-    const double* ps = partials + (size_t)(slot0 + s) * nb_max;
+    unsigned long long* ps = reinterpret_cast<unsigned long long*>(const_cast<double*>(partials)) + (size_t)(slot0 + s) * nb_max;
     for (int v = threadIdx.x; v < VT; v += blockDim.x) {   // whole waves: blockDim is a multiple of 64
       double t = 0.0;
-      for (int i = v; i < nb; i += VT) t += fin_take(ps + i, wait);
+      for (int i0 = v; i0 < nb; i0 += VT * CH) {
+        unsigned long long u[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+          const int i = i0 + k * VT;
+          u[k] = i < nb ? __hip_atomic_load(ps + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+          const int i = i0 + k * VT;
+          if (i < nb) {
+            for (int spin = 0; wait && u[k] == FIN_EMPTY && spin < (1 << 22); spin++) {
+              __builtin_amdgcn_s_sleep(8);
+              u[k] = __hip_atomic_load(ps + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __hip_atomic_store(ps + i, FIN_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: the slot is empty again
+            t += __longlong_as_double((long long)u[k]);   // FIN_EMPTY itself is a NaN
+          }
+        }
+      }
       for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
       if ((v & 63) == 0) fsm[v >> 6] = t;
     }
