@@ -341,6 +341,9 @@ def main():
                     help="preconditioner subdomain shape (cells): wide in x, y and thin in z because k_z = 0.1 k_x")
     ap.add_argument("--brick-order", default="x", choices=["z", "x"],
                     help="numbering of the bricks: vertical neighbour bricks adjacent in memory (z), or x fastest (rounds 1, 2)")
+    ap.add_argument("--cell-order", default=None, choices=["hyperplane", "natural"],
+                    help="numbering of the cells inside a brick: by dependency level (i + j + k) -- default for 2 x 2 blocks, "
+                         "whose fused kernel wants a level's rows in one wave -- or x fastest (default for 3 x 3 blocks)")
     ap.add_argument("--dt0", type=float, default=1.0e4)
     ap.add_argument("--lead", type=int, default=3, help="accepted time steps run before the measured window")
     ap.add_argument("--window", type=int, default=5, help="accepted time steps in the measured cycle")
@@ -419,9 +422,15 @@ def main():
     # (3 x 3 blocks there: 8x5x2 2.84 / 208 / 61.0 %, 8x4x2 2.82 / 224 / 67.2 %, 6x6x2 2.80 / 210, 4x5x2 2.58 / 227)
     # 2 x 2 blocks (k_pc_park, one thread per block row, 512 rows): 16x16x2 3.21 / 171; every other
     # shape of 256-512 cells tried at 216^3 needs 190-1360 iterations (18x12x2 195, 16x8x2 304, 8x8x8 1363)
+    # cells inside a brick: the same ILU(0) either way (the lower neighbours of a cell are (i-1, j, k), (i, j-1, k),
+    # (i, j, k-1) in both orders).  MEASURED on one box (fused launch / SpMV): c4 0.648 / 0.499 ms by level against 0.614 /
+    # 0.489 x fastest (the neighbour gathers of a wave's 64 rows fall on fewer cache lines); c3's k_pc_park 0.604 by
+    # level against 0.640 (it keeps a level's rows in one wave); c5 unchanged
+    if a.cell_order is None:
+        a.cell_order = "natural" if eos == "wce" else "hyperplane"
     brick = tuple(a.brick) if a.brick else ((8, 4, 1) if minc else ((8, 5, 2) if eos == "wce" else (16, 16, 2)))
     grid, lm, prim, region = make_case(dims=dims, brick=brick, eos=eos, lens=not a.no_lens, minc=minc,
-                                       part=M.partition_shape(world), rank=rank, brick_order=a.brick_order)
+                                       part=M.partition_shape(world), rank=rank, brick_order=a.brick_order, order=a.cell_order)
     opts = wl.default_opts(ksp_type=a.ksp, pc_type=a.pc, ilu_levels=a.ilu_levels)
     sim = FlowSimulation(lm, eos=eos, opts=opts, device=local_rank)
     sim.set_regions(region)

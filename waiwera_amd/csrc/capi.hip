@@ -199,6 +199,30 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
   for (int i = 0; i < N; i++)
     info[i] = s.big ? (lfirst[i] | (diag[i] << 8) | (ulast[i] << 16))
                     : (lfirst[i] | (diag[i] << 4) | (ulast[i] << 8) | (levf[i] << 12) | (levb[i] << 22));
+  // Launch order.  Workgroup b of a fused launch runs on XCD b % 8 and takes position (b & 7) * per + (b >> 3) of the
+  // list it is given, so each XCD works through one contiguous eighth in order.  Where bricks differ in cost (the
+  // ragged bricks at the upper ends of a rank's box: fewer rows, fewer levels) the long ones go first inside each
+  // eighth and the short ones last: a launch ends with its shortest workgroups (the tail of 2646 bricks on 768 slots
+  // at 108^3 is a fifth of the launch).  The eighths themselves stay contiguous -- an XCD's L2 keeps serving the
+  // neighbour bricks' vector entries.
+  auto brick_cost = [&](int sd) { return ((nlev[sd] & 0xffff) + (nlev[sd] >> 16)) * 4096 + (sub[sd + 1] - sub[sd]); };
+  auto lpt_order = [&](std::vector<int>& list) {
+    const int n = (int)list.size(), per = (n + 7) >> 3;
+    for (int j = 0; j < 8; j++) {
+      const int a = std::min(j * per, n), b = std::min((j + 1) * per, n);
+      std::stable_sort(list.begin() + a, list.begin() + b, [&](int x, int y) { return brick_cost(x) > brick_cost(y); });
+    }
+  };
+  if (!s.big) {
+    bool uniform = true;
+    for (int sd = 1; sd < s.nsub && uniform; sd++) uniform = brick_cost(sd) == brick_cost(0);
+    if (!uniform) {
+      std::vector<int> order(s.nsub);
+      std::iota(order.begin(), order.end(), 0);
+      lpt_order(order);
+      if (dev_upload(c, &s.sub_order, order)) return -1;
+    }
+  }
   if (ghosts) {   // subdomains without / with partition-ghost columns (for the overlapped halo exchange)
     std::vector<int> li, lb;
     for (int sd = 0; sd < s.nsub; sd++) {
@@ -221,6 +245,7 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
     }
     s.n_int = (int)li.size();
     s.n_bnd = (int)lb.size();
+    lpt_order(li); lpt_order(lb);
     if (s.n_int > 0 && s.n_bnd > 0) {
       if (dev_upload(c, &s.sub_int, li) || dev_upload(c, &s.sub_bnd, lb)) return -1;
     }
@@ -310,7 +335,7 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
 
 void free_schedule(IluSchedule& s) {
   hipFree(s.sub_ptr); hipFree(s.sub_nlev); hipFree(s.sub_split); hipFree(s.row_info); hipFree(s.fval); hipFree(s.dinv);
-  hipFree(s.row_uoff); hipFree(s.row_uoffw); hipFree(s.row_tslot); hipFree(s.sub_int); hipFree(s.sub_bnd); hipFree(s.ord_f); hipFree(s.ord_b);
+  hipFree(s.row_uoff); hipFree(s.row_uoffw); hipFree(s.row_tslot); hipFree(s.sub_order); hipFree(s.sub_int); hipFree(s.sub_bnd); hipFree(s.ord_f); hipFree(s.ord_b);
   s = IluSchedule();
 }
 void free_asm(AsmSystem& a) {

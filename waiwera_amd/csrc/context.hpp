@@ -154,6 +154,8 @@ struct IluSchedule {
   int* sub_int = nullptr;   // subdomains none of whose rows has a partition-ghost column ...
   int* sub_bnd = nullptr;   // ... and the others (device lists; null on a single rank)
   int n_int = 0, n_bnd = 0;
+  int* sub_order = nullptr; // launch order of all subdomains when they differ in cost (ragged bricks): inside each XCD's
+                            // contiguous eighth the long ones first, so the short ones make the tail; null: uniform
   int max_ublocks = 0;      // most in-subdomain upper blocks of any subdomain
   bool fast3 = false;         // <= 3 lower and <= 3 upper in-subdomain couplings per row, offsets < 4
   int max_nlu = 0;            // most lower or upper in-subdomain couplings of any row

@@ -88,11 +88,25 @@ __device__ __forceinline__ void load_block(const double* __restrict__ val, int n
   }
 }
 
+// a 16-byte pair of doubles at 8-byte alignment: gfx950 serves it with one global_load_dwordx4 (unaligned access
+// mode), so the three components of a 3 x 3 system's vector entry cost a dwordx4 + a dwordx2 instead of three
+// dwordx2 gathers through the same cache lines (-DWAI_X_SCALAR_GATHER: the three scalar gathers of rounds 1-2)
+typedef double wai_d2u __attribute__((ext_vector_type(2), aligned(8)));
 template <int BS>
 __device__ __forceinline__ void load_x(const double* __restrict__ x, int col, double* xv) {
   if constexpr (BS == 2) {
     const double2 t = *reinterpret_cast<const double2*>(x + (size_t)col * 2);
     xv[0] = t.x; xv[1] = t.y;
+#ifndef WAI_X_SCALAR_GATHER
+  } else if constexpr (BS == 3) {
+    const double* p = x + (size_t)col * 3;
+    const wai_d2u t = *reinterpret_cast<const wai_d2u*>(p);
+    xv[0] = t.x; xv[1] = t.y; xv[2] = p[2];
+  } else if constexpr (BS == 4) {
+    const double* p = x + (size_t)col * 4;
+    const wai_d2u t = *reinterpret_cast<const wai_d2u*>(p), u = *reinterpret_cast<const wai_d2u*>(p + 2);
+    xv[0] = t.x; xv[1] = t.y; xv[2] = u.x; xv[3] = u.y;
+#endif
   } else {
 #pragma unroll
     for (int k = 0; k < BS; k++) xv[k] = x[(size_t)col * BS + k];
@@ -156,6 +170,14 @@ __global__ __launch_bounds__(TPB) void k_spmv(int n, int W, int nblk, const int*
   for (int r = 0; r < BS; r++) acc[r] = 0.0;
   ell_row_mult<BS>(n, SHORT ? rowptr[i + 1] - rowptr[i] : W, i, col, val, x, acc);
   if constexpr (BS == 2) store_z2(y, (size_t)i, acc[0], acc[1]);
+#ifndef WAI_X_SCALAR_GATHER
+  else if constexpr (BS == 3) {
+    double* p = y + (size_t)i * 3;
+    wai_d2u t = {acc[0], acc[1]};
+    *reinterpret_cast<wai_d2u*>(p) = t;
+    p[2] = acc[2];
+  }
+#endif
   else {
 #pragma unroll
     for (int r = 0; r < BS; r++) y[(size_t)i * BS + r] = acc[r];
@@ -2025,7 +2047,7 @@ int launch_big_solve(wai_ctx* c, const Bcsr& J, const IluSchedule& s, double* z)
 template <int BS>
 static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool spmv, const double* in, double* z,
                          int dot_mode, const double* aux, const int* list, int nrun, const Fin* finp) {
-  if (!list) nrun = s.nsub;
+  if (!list) { nrun = s.nsub; list = s.sub_order; }   // all subdomains: in the schedule's launch order, if it has one
   const bool with_fin = finp && dot_mode != 0;
   Fin fin;
   if (finp && dot_mode != 0) { fin = *finp; fin.count = nrun; fin.nb = s.nsub; }   // all subdomains' partials are summed
