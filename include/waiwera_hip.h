@@ -126,6 +126,10 @@ int wai_set_curve_table(wai_ctx *ctx, int which, int interpolation, int n, const
 /* boundary-condition ghost cells: unscaled primaries + region per bc cell
  * (mesh_set_boundary_conditions, src/mesh.F90:1069-1264; fluid filled once :1199-1202) */
 int wai_set_bc(wai_ctx *ctx, const double *primary, const int *region);
+/* rock controls (src/rock_control.F90:49-116: permeability / porosity tables against time, applied before every try,
+ * src/flow_simulation.F90:2040-2090): one field of the rock record (0..2 permeability, 3 wet, 4 dry conductivity,
+ * 5 porosity, 6 density, 7 specific heat) on the listed local cells */
+int wai_update_rock(wai_ctx *ctx, int field, int n, const int *cells, const double *values);
 /* constant-rate sources (src/source.F90:386-480, source_network.F90:296-355) */
 int wai_set_sources(wai_ctx *ctx, int n, const int *cell, const double *rate,
                     const double *enthalpy, const int *component);

@@ -340,3 +340,38 @@ def test_reinjection_with_and_without_network_couplings():
         sim.ode.destroy()
     print("reinjection: (time steps, newton iterations) with couplings", taken[True], "without", taken[False])
     assert taken[True][0] <= taken[False][0]
+
+
+def test_rock_table_controls():
+    """rock controls (rock.types[i].permeability as rows of [time, k...], porosity as rows of [time, phi];
+    src/rock_control.F90:49-116, applied before every try, flow_simulation.F90:2040-2090) on the radial production
+    problem 2b: a table that never changes reproduces the constant-property run bit for bit; a table that raises the
+    permeability tenfold half way leaves the device with the table's final values and a smaller drawdown at the well"""
+    import json
+    from waiwera_amd.simulation import Simulation
+    base = json.load(open(os.path.join(INPUTS, "problem2b.json")))
+    k0, phi0 = 2.4e-13, 0.15
+
+    def variant(perm, por):
+        inp = json.loads(json.dumps(base))
+        inp["rock"]["types"][0]["permeability"] = perm
+        inp["rock"]["types"][0]["porosity"] = por
+        inp["mesh"]["filename"] = os.path.join(INPUTS, base["mesh"]["filename"])
+        sim = Simulation(inp, base_dir=INPUTS)
+        out = sim.run()
+        return sim, out
+    s0, o0 = variant([k0, k0], phi0)
+    s1, o1 = variant([[0.0, k0, k0], [1.0e9, k0, k0]], [[0.0, phi0], [1.0e9, phi0]])
+    assert s1._rock_controls and s0.ts.taken == s1.ts.taken
+    assert np.array_equal(o0["fluid_pressure"], o1["fluid_pressure"])
+    assert np.array_equal(o0["fluid_temperature"], o1["fluid_temperature"])
+    s2, o2 = variant([[0.0, k0], [40000.0, k0], [40001.0, 10.0 * k0], [1.0e9, 10.0 * k0]], [[0.0, phi0], [1.0e9, 0.5 * phi0 + 0.075]])
+    rock = s2.ode.mesh.rock
+    n = s2.ode.n_owned
+    assert np.allclose(rock[:n, 0], 10.0 * k0, rtol=1e-14) and np.allclose(rock[:n, 2], 10.0 * k0, rtol=1e-14)
+    phi_end = phi0 + (0.5 * phi0 + 0.075 - phi0) * 86400.0 / 1.0e9
+    assert np.allclose(rock[:n, 5], phi_end, rtol=1e-12)
+    # ten times the permeability for the second half: the well block is drawn down less
+    assert o2["fluid_pressure"].min() > o0["fluid_pressure"].min() + 1.0e4
+    for s in (s0, s1, s2):
+        s.ode.destroy()

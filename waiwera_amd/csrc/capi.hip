@@ -2145,6 +2145,26 @@ int wai_set_sources(wai_ctx* c, int n, const int* cell, const double* rate, cons
   return 0;
 }
 
+// Time-dependent rock properties (rock controls, src/rock_control.F90:49-116, applied by
+// flow_simulation_update_rock_properties before every try, src/flow_simulation.F90:2040-2090): one field of the
+// 8-double rock record (0..2 permeability, 3 wet / 4 dry conductivity, 5 porosity, 6 density, 7 specific heat) set
+// on the listed local cells.
+int wai_update_rock(wai_ctx* c, int field, int n, const int* cells, const double* values) {
+  if (!c || n < 0 || (n > 0 && (!cells || !values))) return -2;
+  if (field < 0 || field > 7) { c->err = "rock field 0..7"; return -2; }
+  const int NL = c->mesh.n_local;
+  for (int i = 0; i < n; i++) if (cells[i] < 0 || cells[i] >= NL) { c->err = "rock cell out of range"; return -2; }
+  if (!n) return 0;
+  // a rock type's cells are few thousand at most and change once per try: plane by host round trip
+  std::vector<double> plane((size_t)NL);
+  HIPCHK(c, hipMemcpyAsync(plane.data(), c->mesh.rock + (size_t)field * NL, sizeof(double) * NL, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; i++) plane[cells[i]] = values[i];
+  HIPCHK(c, hipMemcpyAsync(c->mesh.rock + (size_t)field * NL, plane.data(), sizeof(double) * NL, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 int wai_update_sources(wai_ctx* c, const double* rate, const double* enthalpy) {
   if (!c) return -2;
   const size_t nb = sizeof(double) * (size_t)c->src.n;

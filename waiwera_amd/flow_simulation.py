@@ -72,6 +72,13 @@ class FlowSimulation:
             self._chk(LIB.wai_set_halo(h, nr.size, nr.ctypes.data_as(_lib.pi), sp.ctypes.data_as(_lib.pi),
                                        si.ctypes.data_as(_lib.pi), rp.ctypes.data_as(_lib.pi)), "set_halo")
 
+    def update_rock(self, field, cells, values):
+        """rock controls: one field of the rock record (0..2 permeability, 3 wet, 4 dry conductivity, 5 porosity,
+        6 density, 7 specific heat) on the listed local cells, before a try"""
+        ci, v = _lib._i32(cells), _lib._f64(np.broadcast_to(np.asarray(values, dtype=np.float64), np.shape(cells)))
+        self._chk(LIB.wai_update_rock(self.h, int(field), ci.size, ci.ctypes.data_as(_lib.pi), v.ctypes.data_as(_lib.pd)), "update_rock")
+        self.mesh.rock[ci, field] = v
+
     def set_source_rates(self, rate=None, enthalpy=None):
         """new rates / enthalpies of the sources in force (what table controls do before a try)"""
         r = _lib._f64(rate) if rate is not None else None

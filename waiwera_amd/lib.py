@@ -114,6 +114,7 @@ def _load():
         "wai_set_curve_table": (i32, [vp, i32, i32, i32, pd]),
         "wai_set_sources": (i32, [vp, i32, pi, pd, pd, pi]),
         "wai_update_sources": (i32, [vp, pd, pd]),
+        "wai_update_rock": (i32, [vp, i32, i32, pi, pd]),
         "wai_set_source_controls": (i32, [vp, C.POINTER(SourceControl)]),
         "wai_get_source_rates": (i32, [vp, pd, pd]),
         "wai_set_source_network": (i32, [vp, pi, pi, i32, pi, pi, pi, pi, pi, pd, pd, i32, pi, pi, pi, pi, pi, pi, pd, pd, pd, pi, pi]),

@@ -27,7 +27,7 @@ src/timestepper.F90:1960-2275; src/tracer.F90:63-140; utils/input_schema.json):
   output      filename, initial, final, frequency, checkpoint {time, tolerance} (cell fields, source
               rate and enthalpy)
 
-Anything else that changes results (source groups, reinjectors, rock controls, ...) raises
+Anything else that changes results (deliverability thresholds, ...) raises
 NotImplementedError instead of being ignored.  Output: `Simulation.run` returns the final cell
 fields under the reference's HDF5 dataset names (fluid_pressure, ...) and writes "output.filename"
 in the reference's HDF5 layout (waiwera_amd/hdf5io.py, HDF5 C library through ctypes); `save`
@@ -101,8 +101,18 @@ def capillary_spec(cp):
     raise NotImplementedError("capillary pressure type %r" % t)
 
 
+def _is_table(v):
+    """a rank-2 array: rows of [time, value(s)] (rock_setup.F90:300-326: permeability of rank 2, porosity any array)"""
+    return isinstance(v, (list, tuple)) and len(v) > 0 and isinstance(v[0], (list, tuple))
+
+
 def rock_record(rt, dim):
     k = rt.get("permeability", 1.0e-13)
+    if _is_table(k):       # permeability against time: a rock control sets it before every try; start from the first row
+        k = list(k[0][1:])
+    por = rt.get("porosity", 0.1)
+    if isinstance(por, (list, tuple)):
+        rt = dict(rt, porosity=(por[0][1] if _is_table(por) else por[0]))
     k = [k] * 3 if np.isscalar(k) else list(k) + [k[-1]] * (3 - len(k))
     return np.array([k[0], k[1], k[2], rt.get("wet_conductivity", 2.5), rt.get("dry_conductivity", rt.get("wet_conductivity", 2.5)),
                      rt.get("porosity", 0.1), rt.get("density", 2200.0), rt.get("specific_heat", 1000.0)])
@@ -310,6 +320,7 @@ class Simulation:
         cen = lm.cell_geom[:n, :3]
         rock = inp.get("rock", {}) or {}
         zones = (mesh or {}).get("zones", {}) or {}
+        self._rock_controls = []     # (rock record fields, cells, Table): rock_control.F90:49-116
         for rt in rock.get("types", []) or []:
             rec = rock_record(rt, dim)
             sel = []
@@ -320,6 +331,17 @@ class Simulation:
                     sel.append(zone_cells(zones.get(z) if z in zones else (None if z == "all" else zones[z]), cen))
             for idx in sel:
                 lm.rock[idx] = rec
+            if sel and (_is_table(rt.get("permeability")) or isinstance(rt.get("porosity"), (list, tuple))):
+                cells = np.unique(np.concatenate(sel)).astype(np.int32)
+                interp = rt.get("interpolation", "linear")
+                if _is_table(rt.get("permeability")):
+                    tab = Table(rt["permeability"], interpolation=interp)
+                    if tab.dim not in (1, dim):
+                        raise ValueError("permeability table: 1 or %d values per row" % dim)
+                    self._rock_controls.append(((0, 1, 2), cells, tab))
+                if isinstance(rt.get("porosity"), (list, tuple)):
+                    por = rt["porosity"] if _is_table(rt["porosity"]) else [rt["porosity"]]
+                    self._rock_controls.append(((5,), cells, Table(por, interpolation=interp)))
         for k in range(lm.n_bc):
             lm.rock[n + k] = lm.rock[lm.face_cells[lm.n_faces - lm.n_bc + k, 0]]
         # MINC zones (setup of src/minc.F90:58-374): the zone's cells become fracture cells with
@@ -510,7 +532,8 @@ class Simulation:
 
         self._setup_source_controls(inp.get("source", []) or [], _get(inp, "time.start", 0.0))
         self._setup_network(inp)
-        if self._tables or self._ctl_tables or getattr(self, "_tracer_tables", None) or getattr(self, "_network_timed", False):
+        if (self._tables or self._ctl_tables or getattr(self, "_tracer_tables", None) or getattr(self, "_network_timed", False)
+                or self._rock_controls):
             self.ts.controls = self._update_controls
 
     # ---- source network --------------------------------------------------------------------------
@@ -636,6 +659,13 @@ class Simulation:
         """table_object_control_update (src/control.F90:263-284): each table's average over the step
         interval becomes the rate / enthalpy of its source; likewise the productivity, reference
         pressure and limit tables of the state-dependent controls"""
+        # rock controls: flow_simulation_pre_try_timestep(t) with t the time the try ends at (timestepper.F90:2333),
+        # the table's value AT that time (rock_control.F90:66, 102: interpolate, not an interval average); a scalar
+        # permeability fills all directions
+        for fields, cells, tab in self._rock_controls:
+            v = tab.interpolate(float(interval[1]))
+            for q, f in enumerate(fields):
+                self.ode.update_rock(f, cells, v[0] if tab.dim == 1 else v[min(q, tab.dim - 1)])
         if self._tables:
             rate, enth = self.mesh.src_rate.copy(), self.mesh.src_enthalpy.copy()
             for i, key, tab in self._tables:
