@@ -304,9 +304,8 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
   {
     // one wave per brick: <= 64 block rows, <= 3 lower and <= 4 upper in-brick couplings, LDS for four bricks per
     // workgroup within 64 KB (-DWAI_PC_WAVE=0 builds without)
-    const int nw = s.max_rows <= 64 ? 1 : 2;
-    const size_t lds_w = (size_t)(nw == 1 ? 4 : 1) * (64 * nw * np + (size_t)std::max(s.max_ublocks_w, 2) * np * np) * sizeof(double);
-    s.wave_kernel = s.rows_kernel && np == 3 && s.max_rows <= 128   // (4 x 4 blocks: 174 VGPRs, two waves per SIMD -- not measured, k_pc_rows keeps them)
+    const size_t lds_w = (size_t)4 * (64 * np + (size_t)s.max_ublocks_w * np * np) * sizeof(double);
+    s.wave_kernel = s.rows_kernel && np == 3 && s.max_rows <= 64   // (4 x 4 blocks: 174 VGPRs, two waves per SIMD -- not measured, k_pc_rows keeps them)
                     && s.max_nl <= 3 && max_nu <= 4 && lds_w <= 64 * 1024;
 #ifdef WAI_PC_WAVE
     s.wave_kernel = s.wave_kernel && (WAI_PC_WAVE != 0);
@@ -3122,7 +3121,7 @@ const char* wai_pc_kernel_name(wai_ctx* c) {
     return b3;
   }
   if (s.big) return "k_spmv + k_lvl_solve per level";
-  if (s.wave_kernel) { static thread_local char b4[64]; snprintf(b4, sizeof(b4), "k_pc_wave<%d,spmv,%d>", c->J.bs, s.max_rows <= 64 ? 1 : 2); return b4; }
+  if (s.wave_kernel) { static thread_local char b4[64]; snprintf(b4, sizeof(b4), "k_pc_wave<%d,spmv>", c->J.bs); return b4; }
   if (s.rows_kernel) { static thread_local char b2[64]; snprintf(b2, sizeof(b2), "k_pc_rows<%d,spmv,%d+%d>", c->J.bs, s.max_nlu <= 3 ? 3 : 4, s.max_nlu <= 3 ? 3 : 4); return b2; }
   if (c->J.bs == 2 && s.park && s.diag_only && s.scaled && s.fast3 && s.max_rows <= 512) return "k_pc_park<spmv>";
   static thread_local char buf[96];

@@ -1382,10 +1382,8 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
 // backward sweep; four independent bricks share a 256-thread workgroup (no __syncthreads anywhere), ~13 bricks
 // are resident per CU, and the latency of one brick's sweeps hides behind the loads of the others.
 // Serves the 8 x 4 x 2 bricks of 3 x 3 blocks and the 8 x 4 x 1 (32 + 32 rows) MINC bricks.
-// NW = 1: four one-wave bricks (<= 64 rows) per 256-thread workgroup, no barrier at all; NW = 2: one two-wave brick
-// (<= 128 rows) per 128-thread workgroup, a two-wave barrier per level (C4's 8 x 5 x 2 bricks)
-template <int BS, bool SPMV, int NW>
-__global__ __launch_bounds__(NW == 1 ? 256 : 128) void k_pc_wave(
+template <int BS, bool SPMV>
+__global__ __launch_bounds__(256) void k_pc_wave(
     int n, int W, int nsub, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev,
     const int* __restrict__ row_info, const int* __restrict__ row_uoffw, const int* __restrict__ col,
     const double* __restrict__ sval, const double* __restrict__ dinv, const double* __restrict__ in,
@@ -1394,22 +1392,20 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 128) void k_pc_wave(
   constexpr int BB = BS * BS, NL = 3, NU = 4;
   extern __shared__ double lds[];
   if (fin_block(fin, partials, nb_max)) return;
-  constexpr int CAP = 64 * NW;     // rows a brick may have
-  const int wave = NW == 1 ? threadIdx.x >> 6 : 0, lane = NW == 1 ? threadIdx.x & 63 : threadIdx.x;
-  const int ngrp = NW == 1 ? (nsub + 3) >> 2 : nsub;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ngrp = (nsub + 3) >> 2;
   const int g = xcd_remap(blockIdx.x, ngrp);
   if (g >= ngrp) return;
-  int s = NW == 1 ? g * 4 + wave : g;
-  if (s >= nsub) return;          // NW = 1: wave-uniform, and no workgroup barrier follows
+  int s = g * 4 + wave;
+  if (s >= nsub) return;          // wave-uniform: no workgroup barrier follows
   if (sub_list) s = sub_list[s];
-  auto level_sync = [&]() { if constexpr (NW == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads(); };
   const int lo = sub_ptr[s], R = sub_ptr[s + 1] - lo;
   const int nl = sub_nlev[s];
   const int nlf = nl & 0xffff, nlb = nl >> 16;
   const int i = lo + lane;
   const bool active = lane < R;
-  double* ys = lds + (size_t)wave * lds_per_brick;   // [CAP * BS] solution in block order
-  double* upark = ys + CAP * BS;                     // parked upper blocks, row-major BS x BS each
+  double* ys = lds + (size_t)wave * lds_per_brick;   // [64 * BS] solution in block order
+  double* upark = ys + 64 * BS;                      // parked upper blocks, row-major BS x BS each
   double Lf[NL][BB];
   int Lc[NL], ucpack = 0, lf = -1, lb = -1, uo = 0, nU = 0;   // ucpack: local columns of the <= 4 upper couplings, 8 bits each
 #pragma unroll
@@ -1474,7 +1470,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 128) void k_pc_wave(
 #pragma unroll
     for (int r = 0; r < BS; r++) ys[lane * BS + r] = acc[r];
   }
-  level_sync();
+  __builtin_amdgcn_wave_barrier();
   for (int lev = 1; lev < nlf; lev++) {  // forward: y_i = t_i - sum A'_ik y_k
     if (lf == lev) {
       double a[BS];
@@ -1493,7 +1489,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 128) void k_pc_wave(
 #pragma unroll
       for (int r = 0; r < BS; r++) ys[lane * BS + r] = a[r];
     }
-    level_sync();
+    __builtin_amdgcn_wave_barrier();
   }
   for (int lev = 0; lev < nlb; lev++) {  // backward: x_i = y_i - sum A'_ij x_j, upper blocks from LDS
     if (lb == lev) {
@@ -1505,7 +1501,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 128) void k_pc_wave(
         if (p < nU) {
           const double* ub = upark + (size_t)(uo + p) * BB;
           double xk[BS];
-          const int uc = (ucpack >> (8 * p)) & 255;
+          const int uc = (ucpack >> (8 * p)) & 63;
 #pragma unroll
           for (int k = 0; k < BS; k++) xk[k] = ys[uc * BS + k];
 #pragma unroll
@@ -1517,14 +1513,14 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 128) void k_pc_wave(
 #pragma unroll
       for (int r = 0; r < BS; r++) ys[lane * BS + r] = a[r];
     }
-    level_sync();
+    __builtin_amdgcn_wave_barrier();
   }
   // block-order, lane-linear epilogue: the wave's R * BS results leave coalesced; dot products on the way
   double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   const int tot = R * BS;
 #pragma unroll
   for (int j = 0; j < BS; j++) {
-    const int t = lane + CAP * j;
+    const int t = lane + 64 * j;
     if (t < tot) {
       const size_t gi = (size_t)lo * BS + t;
       const double out = ys[t];
@@ -1540,23 +1536,13 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 128) void k_pc_wave(
   if (dot != 0) {
     const int ns = dot == 4 ? 5 : (dot == 2 ? 2 : 1);
     const int slot0 = dot == 3 ? S_DP2 : S_D1;   // S_D1 .. S_W2 are consecutive
-    double* red = upark;   // NW = 2: the parked blocks are dead; two doubles per slot
-    if constexpr (NW > 1) __syncthreads();
 #pragma unroll
     for (int q = 0; q < 5; q++) {
       if (q < ns) {
         double t = v[q];
         for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
-        if constexpr (NW == 1) {
-          if (lane == 0) store_partial(partials + (size_t)(slot0 + q) * nb_max + s, t);
-        } else {
-          if ((lane & 63) == 0) red[q * 2 + (lane >> 6)] = t;
-        }
+        if (lane == 0) store_partial(partials + (size_t)(slot0 + q) * nb_max + s, t);
       }
-    }
-    if constexpr (NW > 1) {
-      __syncthreads();
-      if (lane < ns) store_partial(partials + (size_t)(slot0 + lane) * nb_max + s, red[lane * 2] + red[lane * 2 + 1]);
     }
   }
 }
@@ -2079,20 +2065,19 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
                          nrun, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.fval,          \
                          s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, c->dbg, list, fin); \
   } while (0)
-  // one wave per brick of <= 64 block rows, four bricks per workgroup -- or two waves per brick of <= 128 rows (3 x 3 blocks)
+  // one wave per brick of <= 64 block rows (block sizes 3 and 4), four bricks per workgroup
   if (s.wave_kernel && !c->dbg) {
-    if constexpr (BS == 3) {
+    if constexpr (BS >= 3) {
+      const int ngrp = (nrun + 3) / 4, gridw = ((ngrp + 7) / 8) * 8 + (with_fin ? 1 : 0);
+      const int per = 64 * BS + s.max_ublocks_w * BS * BS;            // doubles per brick: solution + parked upper blocks
+      const size_t lds_w = (size_t)4 * per * sizeof(double);
       const int* rp = (size_t)J.nnzb * 10 < (size_t)J.n * J.W * 9 ? J.rowptr : nullptr;   // > 10 % padding
-      const int nw = s.max_rows <= 64 ? 1 : 2, cap = 64 * nw;
-      const int per = cap * BS + std::max(s.max_ublocks_w, 2) * BS * BS;      // doubles per brick: solution + parked upper blocks
-      const int ngrp = nw == 1 ? (nrun + 3) / 4 : nrun, gridw = ((ngrp + 7) / 8) * 8 + (with_fin ? 1 : 0);
-      const size_t lds_w = (size_t)(nw == 1 ? 4 : 1) * per * sizeof(double);
-#define PCW(SP, NWV) hipLaunchKernelGGL((k_pc_wave<BS, SP, NWV>), gridw, NWV == 1 ? 256 : 128, lds_w, c->stream, J.n, J.W, nrun, s.sub_ptr, \
-                                        s.sub_nlev, s.row_info, s.row_uoffw, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials,          \
-                                        c->ks.nb_max, dot_mode, list, rp, per, fin)
-      if (nw == 1) { if (spmv) PCW(true, 1); else PCW(false, 1); }
-      else { if (spmv) PCW(true, 2); else PCW(false, 2); }
-#undef PCW
+      if (spmv)
+        hipLaunchKernelGGL((k_pc_wave<BS, true>), gridw, 256, lds_w, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev, s.row_info,
+                           s.row_uoffw, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, list, rp, per, fin);
+      else
+        hipLaunchKernelGGL((k_pc_wave<BS, false>), gridw, 256, lds_w, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev, s.row_info,
+                           s.row_uoffw, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, list, rp, per, fin);
       return;
     }
   }
