@@ -262,3 +262,24 @@ def test_iluk_sub_preconditioner(oracle, eos, pc, brick):
     sim.pc_apply(r, z)
     assert relmax(z, z0) < 1e-14
     sim.destroy(); osim.close()
+
+
+def test_bicgstab_iteration_is_five_launches_and_no_copy(oracle):
+    """one rank, fused block-Jacobi path: P update, fused A*P + ILU(0) solve (+ (V,RP), alpha), S update, fused A*S + solve
+    (+ (S,T), (T,T), omega), X / R update (+ (R,R), (R,RP), rho / beta, the posted norm) -- every reduction finished
+    inside its producer, the residual norm posted to pinned host memory: wai_launch_stats counts 5 kernels per
+    iteration (+ the speculative half iteration that is thrown away and the solve's set-up) and no copy per iteration"""
+    lm, sim, osim, J, f = system(oracle, "we", (12, 12, 8), (4, 4, 2))
+    n = sim.num_dof
+    sim.set_opts(pc_type="bjacobi", ksp_type="bcgs", ksp_rtol=1e-10)
+    assert sim.pc_setup() == 0
+    x = np.zeros(n)
+    k0, c0 = sim.launch_stats()
+    its, reason, rn = sim.ksp_solve(f, x)
+    k1, c1 = sim.launch_stats()
+    assert reason > 0 and its >= 20
+    assert 5 * its <= k1 - k0 <= 5 * its + 8, (its, k1 - k0)
+    assert c1 - c0 <= 6, (its, c1 - c0)        # set-up only: RP = R, the initial norm, the staged vectors
+    oreason, xo, oits, hist = osim.ksp_solve(J, f, ksp_type=0, rtol=1e-10)
+    assert relmax(x, xo) < 1e-7 and abs(its - oits) <= max(2, oits // 10)
+    sim.destroy(); osim.close()

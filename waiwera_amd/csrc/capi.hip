@@ -410,9 +410,10 @@ int ghost_rows(wai_ctx* c, std::vector<int>& grp, std::vector<int>& gci, std::ve
   std::vector<double> ids((size_t)N + H, -1.0);
   const double base = (double)c->comm->rank * 4294967296.0;
   for (int i = 0; i < N; i++) ids[i] = base + i;
-  HIPCHK(c, hipMemcpyAsync(c->w_c, ids.data(), sizeof(double) * (N + H), hipMemcpyHostToDevice, c->stream));
-  if (halo_exchange(c, c->w_c, 1)) return -1;
-  HIPCHK(c, hipMemcpyAsync(ids.data(), c->w_c, sizeof(double) * (N + H), hipMemcpyDeviceToHost, c->stream));
+  double* scratch = c->ks.tmp;   // a Krylov work vector (n_prim * bs + 16 doubles): idle while the preconditioner is set up
+  HIPCHK(c, hipMemcpyAsync(scratch, ids.data(), sizeof(double) * (N + H), hipMemcpyHostToDevice, c->stream));
+  if (halo_exchange(c, scratch, 1)) return -1;
+  HIPCHK(c, hipMemcpyAsync(ids.data(), scratch, sizeof(double) * (N + H), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (ensure_halo_dof(c, W * J.bs * J.bs)) return -1;
   std::vector<int> sidx((size_t)c->send_total);

@@ -347,6 +347,8 @@ class Simulation:
         # MINC zones (setup of src/minc.F90:58-374): the zone's cells become fracture cells with
         # nested matrix cells behind them
         self._order = None
+        if minc_in and self._rock_controls:
+            raise NotImplementedError("rock table controls together with MINC zones")
         if minc_in:
             from . import mesh as M
             by_name = {rt.get("name", "").strip(): rt for rt in rock.get("types", []) or []}
