@@ -164,6 +164,11 @@ typedef struct wai_source_control {
   double factor;      /* rate factor for the step interval, applied last ("factor",
                          rate_factor_table_source_control, src/source_control.F90:178-193); 0 = none */
   double sep_more[6]; /* (hf, hg) of separator stages 2..4; hg = 0 ends the list */
+  double threshold;   /* deliverability "threshold" (src/source_control.F90:99-100, :489-503): > 0: the source keeps its own
+                         rate while the pressure stays at or above it -- and the productivity index that would give
+                         exactly that rate is noted at every unperturbed residual evaluation; below it the rate is
+                         the deliverability's with that noted index, if that is the smaller production.  <= 0: off */
+  double threshold_pi; /* the noted index; < 0 in a record handed to wai_set_source_controls: keep the one in force */
 } wai_source_control;
 int wai_set_source_controls(wai_ctx *ctx, const wai_source_control *controls);
 /* Source network: groups and reinjectors (src/source_network_group.F90, source_network_reinjector.F90;

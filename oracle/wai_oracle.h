@@ -155,6 +155,8 @@ typedef struct wo_src_ctl {
   double table[16];       /* (x, pressure) pairs, linear, clamped */
   double factor;          /* rate factor applied last (src/source_control.F90:178-193); 0 = none */
   double sep_more[6];     /* (hf, hg) of separator stages 2..4, hg = 0 ends the list (src/separator.F90:212-260) */
+  double threshold;       /* deliverability threshold pressure (src/source_control.F90:99-100, 489-503); <= 0: off */
+  double threshold_pi;    /* productivity index noted while the pressure was at or above the threshold; < 0 when set: keep */
 } wo_src_ctl;
 /* steam fraction of a flow of enthalpy h through the separator of a control record */
 double wo_separator_steam_fraction(const wo_src_ctl *k, double h);

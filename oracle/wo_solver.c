@@ -254,13 +254,18 @@ void wo_sim_set_sources(wo_sim *s, int n, const int *cell, const double *rate,
   memcpy(s->src_enth, enthalpy, sizeof(double) * n);
 }
 void wo_sim_set_source_controls(wo_sim *s, const wo_src_ctl *ctl) {
-  free(s->src_ctl);
+  wo_src_ctl *old = s->src_ctl;
   s->src_ctl = NULL;
   if (ctl && s->n_src) {
     s->src_ctl = (wo_src_ctl *)xmalloc(sizeof(wo_src_ctl) * s->n_src);
     memcpy(s->src_ctl, ctl, sizeof(wo_src_ctl) * s->n_src);
+    for (int i = 0; i < s->n_src; i++)   /* threshold_pi < 0: keep the index noted so far (records are set again before every try) */
+      if (s->src_ctl[i].threshold > 0.0 && s->src_ctl[i].threshold_pi < 0.0)
+        s->src_ctl[i].threshold_pi = old ? old[i].threshold_pi : s->src_ctl[i].coef;
   }
+  free(old);
 }
+static double source_rate_c(const wo_eos *e, const double *fl, wo_src_ctl *k, double rate, int commit);
 static double source_rate(const wo_eos *e, const double *fl, const wo_src_ctl *k, double rate);
 /* rate and enthalpy every source has on the current fluid (the source_rate / source_enthalpy
  * output fields, src/source.F90:386-480): flowing enthalpy for production, given for injection */
@@ -422,6 +427,11 @@ static double ctl_table(const wo_src_ctl *k, double x) {
 
 /* rate of a controlled source on the cell's fluid fl: see wo_src_ctl in wai_oracle.h */
 static double source_rate(const wo_eos *e, const double *fl, const wo_src_ctl *k, double rate) {
+  return source_rate_c(e, fl, (wo_src_ctl *)k, rate, 0);
+}
+/* commit: an unperturbed function evaluation -- a deliverability control with a threshold then notes the
+ * productivity index that gives the source's own rate (src/source_control.F90:489-503, 407-466) */
+static double source_rate_c(const wo_eos *e, const double *fl, wo_src_ctl *k, double rate, int commit) {
   if (!k) return rate;
   int nph = e->nph, boff = 7 + e->nc - 1, pdof = 8 + e->nc - 1;
   int phases = (int)lround(fl[4]);
@@ -440,9 +450,21 @@ static double source_rate(const wo_eos *e, const double *fl, const wo_src_ctl *k
     if (k->table_coord == 1) pref = ctl_table(k, h);
     else if (k->table_coord == 2) pref = ctl_table(k, fl[0]);
     double dp = fl[0] - pref;
-    rate = 0.0;
-    for (int p = 0; p < nph; p++)
-      if (phases & (1 << p)) rate = rate - k->coef * mob[p] * dp;
+    if (k->threshold > 0.0) {
+      if (fl[0] < k->threshold) {   /* below: deliverability with the noted index, if that is the smaller production */
+        double qd = 0.0;
+        for (int p = 0; p < nph; p++)
+          if (phases & (1 << p)) qd = qd - k->threshold_pi * fl[5] * mob[p] * dp;
+        if (qd > rate) rate = qd;
+      } else if (commit) {          /* at or above: the source keeps its rate; note the index that would give it */
+        double fac = sum * dp * fl[5];
+        if (fabs(fac) > 1.0e-9) k->threshold_pi = fabs(rate) / fac;
+      }
+    } else {
+      rate = 0.0;
+      for (int p = 0; p < nph; p++)
+        if (phases & (1 << p)) rate = rate - k->coef * mob[p] * dp;
+    }
   } else if (k->kind == 2) {
     rate = -k->coef * (fl[0] - k->pressure);
   }
@@ -528,7 +550,7 @@ void wo_rhs(wo_sim *s, double *rhs) {
     if (c < 0 || c >= s->n_owned) continue;
     double flow[MAXBS];
     const double *fl = s->fluid + (size_t)c * df;
-    source_flow(&s->eos, fl, source_rate(&s->eos, fl, s->src_ctl ? s->src_ctl + i : NULL, s->src_rate[i]),
+    source_flow(&s->eos, fl, source_rate_c(&s->eos, fl, s->src_ctl ? s->src_ctl + i : NULL, s->src_rate[i], 1),
                 s->src_enth[i], s->src_comp[i], flow);
     for (int q = 0; q < np; q++) rhs[c * np + q] += flow[q] / s->cell_geom[4 * c + 3];
   }
@@ -595,7 +617,7 @@ static void cell_residual(const wo_sim *s, int c, double dt, const double *lhs_o
   for (int i = 0; i < s->n_src; i++)
     if (s->src_cell[i] == c) {
       double flow[MAXBS];
-      source_flow(e, own, source_rate(e, own, s->src_ctl ? s->src_ctl + i : NULL, s->src_rate[i]),
+      source_flow(e, own, source_rate_c(e, own, s->src_ctl ? s->src_ctl + i : NULL, s->src_rate[i], which == -1),
                   s->src_enth[i], s->src_comp[i], flow);
       for (int k = 0; k < np; k++) R[k] += flow[k] / vol;
     }

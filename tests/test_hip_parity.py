@@ -547,3 +547,33 @@ def test_flux_vector(FS, oracle, eos):
     assert (np.abs(fx - ref) / scale).max() < 1e-11
     assert np.abs(ref[:, -2:]).max() > 0        # phase fluxes present
     sim.destroy(); osim.close()
+
+
+def test_deliverability_threshold(FS, oracle):
+    """deliverability that switches on below a threshold pressure (src/source_control.F90:489-503): the index is noted
+    on the device at every unperturbed residual evaluation and survives a new set of control records; the reference's
+    scenario (source_control_test.F90:389-420: -2.25 at 6 bar, -1.125 at 4, -0.5625 at 3, then the source's own smaller
+    rate) on the device against the oracle"""
+    from tests.test_oracle_separator import _threshold_sequence
+    g, lm, prim, region = make_case(dims=(4, 4, 2), brick=(4, 4, 2), eos="w", top_bc=False)
+    sim = FS(lm, eos="w")
+    osim = ol.OracleSim(oracle, lm, 0)
+    sim.set_regions(region); osim.set_regions(region)
+    recs = [dict(kind="deliverability", coef=1.0e-12, pressure=2.0e5, threshold=5.0e5)] * lm.n_src
+    sim.set_source_controls(recs); osim.set_source_controls(recs)
+    rg = _threshold_sequence(sim, lambda p: np.full(lm.n_owned, p / 1.0e6), lm.n_src)
+    ro = _threshold_sequence(osim, lambda p: osim.yvec(np.full(lm.n_owned, p / 1.0e6)), lm.n_src)
+    for a, b in zip(rg, ro):
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), (a, b)
+    assert rg[0][0] == -2.25 and abs(rg[1][0] + 1.125) < 2e-3 * 1.125 and abs(rg[2][0] + 0.5625) < 2e-3 * 0.5625
+    # a new set of records (as before every try) keeps the noted index; a record that brings one replaces it
+    sim.set_source_rates(np.full(lm.n_src, -2.25))
+    sim.set_source_controls(recs)
+    y3 = np.full(lm.n_owned, 0.3)
+    assert sim.pre_eval(0.0, y3) == 0
+    q, _ = sim.source_rates()
+    assert abs(q[0] - rg[2][0]) <= 1e-12 * abs(q[0])
+    sim.set_source_controls([dict(r, threshold_pi=0.0) for r in recs])
+    q, _ = sim.source_rates()
+    assert q[0] == 0.0
+    sim.destroy(); osim.close()

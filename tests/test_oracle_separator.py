@@ -37,3 +37,52 @@ def test_single_stage_water_enthalpy(oracle):
     # separated water leaves the 10 bar stage at the saturated water enthalpy the reference's test holds
     hf, hg = _enthalpies(oracle, 10.0e5)
     assert abs(hf - 762682.8443354106) <= 1e-9 * hf and abs(hg - 2777119.5376846623) <= 1e-9 * hg
+
+
+def _threshold_sequence(sim, y_of_pressure, n_src):
+    """the reference's threshold scenario (test/unit/src/source_control_test.F90:389-420, its source 13: a rate of
+    -2.25 kg/s, deliverability against a 2 bar reference pressure switched on below 5 bar): rates at 6, 4, 3 bar, then at 3
+    bar after the rate has dropped to -0.0291666..."""
+    out = []
+    for p, rate in ((6.0e5, -2.25), (4.0e5, -2.25), (3.0e5, -2.25), (3.0e5, -0.0291666666667)):
+        sim.set_source_rates(np.full(n_src, rate))
+        y = y_of_pressure(p)
+        assert sim.pre_eval(y) == 0 if hasattr(sim, "yvec") else sim.pre_eval(0.0, y) == 0
+        if hasattr(sim, "yvec"):
+            sim.rhs()                                   # an unperturbed evaluation: the control notes its index
+            q, _ = sim.source_rates()
+        else:
+            R = np.zeros(sim.n_owned * sim.num_primary_variables)
+            sim.rhs(0.0, (0.0, 0.0), y, R)
+            q, _ = sim.source_rates()
+        out.append(q.copy())
+    return out
+
+
+def test_deliverability_threshold_known_answers(oracle):
+    """-2.25 at 6 bar (above the threshold the source keeps its rate), -1.125 at 4 bar, -0.5625 at 3 bar (the index
+    noted at 6 bar: 2.25 / (mobility (6 - 2) bar)), and -0.02917 once the source's own rate is the smaller production.
+    The reference's unit test holds the mobility fixed; here it is the water's at the cell's pressure (1e-4 apart
+    between 3 and 6 bar), so its figures are met to 2e-3 and the formula exactly."""
+    from tests import oracle_lib as ol
+    from tests.cases import make_case
+    g, lm, prim, region = make_case(dims=(4, 4, 2), brick=(4, 4, 2), eos="w", top_bc=False)
+    sim = ol.OracleSim(oracle, lm, 0)
+    sim.set_regions(region)
+    n_src = lm.n_src
+    sim.set_source_controls([dict(kind="deliverability", coef=1.0e-12, pressure=2.0e5, threshold=5.0e5)] * n_src)
+    rates = _threshold_sequence(sim, lambda p: sim.yvec(np.full(lm.n_owned, p / 1.0e6)), n_src)
+    for q in rates:
+        assert np.all(q == q[0])
+    r6, r4, r3, r3b = (q[0] for q in rates)
+    assert r6 == -2.25
+    assert abs(r4 + 1.125) < 2e-3 * 1.125 and abs(r3 + 0.5625) < 2e-3 * 0.5625
+    assert r3b == -0.0291666666667
+    # the formula itself: index noted at 6 bar, applied with the mobility at the lower pressure
+    def mob(p):
+        assert sim.pre_eval(sim.yvec(np.full(lm.n_owned, p / 1.0e6))) == 0
+        f = sim.fluid()[lm.src_cell[0]]
+        return f[7 + 3] * f[7] / f[7 + 1]
+    pi = 2.25 / (mob(6.0e5) * 4.0e5)
+    assert abs(r4 + pi * mob(4.0e5) * 2.0e5) < 1e-12 and abs(r3 + pi * mob(3.0e5) * 1.0e5) < 1e-12
+    sim.close()

@@ -2203,6 +2203,20 @@ int wai_set_source_controls(wai_ctx* c, const wai_source_control* controls) {
       return -1;
     }
   }
+  // threshold deliverability: the index the device noted so far survives a new set of records (they are set again
+  // before every try for their time tables) unless the record brings one (threshold_pi >= 0)
+  std::vector<SrcCtl> recs(reinterpret_cast<const SrcCtl*>(controls), reinterpret_cast<const SrcCtl*>(controls) + s.n);
+  {
+    std::vector<SrcCtl> old;
+    if (s.ctl) {
+      old.resize((size_t)s.n);
+      HIPCHK(c, hipMemcpyAsync(old.data(), s.ctl, sizeof(SrcCtl) * (size_t)s.n, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    for (int i = 0; i < s.n; i++)
+      if (recs[i].threshold > 0.0 && recs[i].threshold_pi < 0.0) recs[i].threshold_pi = old.empty() ? recs[i].coef : old[i].threshold_pi;
+  }
+  controls = reinterpret_cast<const wai_source_control*>(recs.data());
   if (!s.ctl) HIPCHK(c, hipMalloc(&s.ctl, sizeof(SrcCtl) * (size_t)s.n));
   if (c->net.gidx.empty()) c->net.h_ctl.assign(reinterpret_cast<const SrcCtl*>(controls), reinterpret_cast<const SrcCtl*>(controls) + s.n);
   else   // a network across ranks numbers its control records globally: this rank's own entries

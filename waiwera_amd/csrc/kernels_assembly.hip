@@ -127,11 +127,11 @@ __device__ __forceinline__ void slot_term(const FaceGeom& g, int side, const Cel
 
 template <int KIND>
 __device__ __forceinline__ void source_terms(const MeshView& m, int c, const CellState<KIND>& s,
-                                             double vol, double* R) {
+                                             double vol, double* R, bool commit = false) {
   using E = EosT<KIND>;
   for (int si = m.cell_src[c]; si >= 0; si = m.src_next[si]) {
     double flow[E::np];
-    source_flow<KIND>(s, source_rate<KIND>(s, m.src_ctl, si, m.src_rate[si], m.src_net), m.src_enth[si], m.src_comp[si], flow);
+    source_flow<KIND>(s, source_rate<KIND>(s, m.src_ctl, si, m.src_rate[si], m.src_net, commit), m.src_enth[si], m.src_comp[si], flow);
 #pragma unroll
     for (int k = 0; k < E::np; k++) R[k] += flow[k] / vol;
   }
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(TPB) void k_residual(MeshView m, const double* __re
 #pragma unroll
     for (int k = 0; k < E::np; k++) R[k] += term[k];
   }
-  source_terms<KIND>(m, c, own, vol, R);
+  source_terms<KIND>(m, c, own, vol, R, only == nullptr);   // a full sweep is an unperturbed evaluation (the row list: network_couplings)
 #pragma unroll
   for (int k = 0; k < E::np; k++) {
     if (lhs_out) lhs_out[(size_t)c * E::np + k] = L[k];

@@ -822,6 +822,7 @@ struct SrcCtl {
   double table[16];
   double factor;
   double sep_more[6];
+  double threshold, threshold_pi;
 };
 
 // one separator stage (separator.F90:139-166): steam fraction f of a flow of enthalpy h, hw the
@@ -868,8 +869,9 @@ __device__ inline double source_network_rate(const double* net, int si, double r
 }
 
 template <int KIND>
+// commit: an unperturbed residual evaluation -- the threshold deliverability notes its productivity index then
 __device__ inline double source_rate(const CellState<KIND>& s, const SrcCtl* ctl, int si, double rate,
-                                     const double* net = nullptr) {
+                                     const double* net = nullptr, bool commit = false) {
   using E = EosT<KIND>;
   if (!ctl) return source_network_rate(net, si, rate);
   const SrcCtl& k = ctl[si];
@@ -889,9 +891,24 @@ __device__ inline double source_rate(const CellState<KIND>& s, const SrcCtl* ctl
     if (k.table_coord == 1) pref = ctl_table(k, h);
     else if (k.table_coord == 2) pref = ctl_table(k, s.P);
     const double dp = s.P - pref;
-    rate = 0.0;
+    if (k.threshold > 0.0) {
+      // deliverability_source_control_iterator (src/source_control.F90:489-503): above the threshold pressure the
+      // source keeps its rate and the index that would give exactly that rate is noted (calculate_PI_from_rate,
+      // :407-466); below it the deliverability rate with the noted index applies if it is the smaller production
+      if (s.P < k.threshold) {
+        double qd = 0.0;
 #pragma unroll
-    for (int p = 0; p < E::nph; p++) if (phases & (1 << p)) rate = rate - k.coef * s.permfac * mob[p] * dp;
+        for (int p = 0; p < E::nph; p++) if (phases & (1 << p)) qd = qd - k.threshold_pi * s.permfac * mob[p] * dp;
+        if (qd > rate) rate = qd;
+      } else if (commit) {
+        const double fac = sum * dp * s.permfac;
+        if (fabs(fac) > 1.0e-9) const_cast<SrcCtl*>(ctl)[si].threshold_pi = fabs(rate) / fac;
+      }
+    } else {
+      rate = 0.0;
+#pragma unroll
+      for (int p = 0; p < E::nph; p++) if (phases & (1 << p)) rate = rate - k.coef * s.permfac * mob[p] * dp;
+    }
   } else if (k.kind == 2) {
     rate = -k.coef * (s.P - k.pressure);
   }

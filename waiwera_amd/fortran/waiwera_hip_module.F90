@@ -46,6 +46,8 @@ module waiwera_hip_module
      real(c_double) :: table(16) = 0._c_double
      real(c_double) :: factor = 0._c_double
      real(c_double) :: sep_more(6) = 0._c_double   !! (hf, hg) of separator stages 2..4; hg = 0 ends the list
+     real(c_double) :: threshold = 0._c_double      !! deliverability below this pressure only (source_control.F90:489-503); 0: off
+     real(c_double) :: threshold_pi = -1._c_double  !! the noted productivity index; < 0: keep the one the device holds
   end type wai_source_control
 
   type, bind(c), public :: wai_solver_opts

@@ -48,7 +48,7 @@ class SourceControl(C.Structure):
     """wai_source_control (include/waiwera_hip.h): state-dependent control of one source"""
     _fields_ = [("kind", i32), ("direction", i32), ("limiter", i32), ("table_coord", i32), ("n_table", i32),
                 ("coef", d), ("pressure", d), ("limit", d), ("sep_hf", d), ("sep_hg", d), ("table", d * 16),
-                ("factor", d), ("sep_more", d * 6)]
+                ("factor", d), ("sep_more", d * 6), ("threshold", d), ("threshold_pi", d)]
 
 
 SRC_KIND = {"rate": 0, "deliverability": 1, "recharge": 2}
@@ -67,6 +67,7 @@ def source_controls(records):
         k.coef, k.pressure = r.get("coef", 0.0), r.get("pressure", 0.0)
         k.limit, k.sep_hf, k.sep_hg = r.get("limit", 0.0), r.get("sep_hf", 0.0), r.get("sep_hg", 0.0)
         k.factor = r.get("factor", 0.0)
+        k.threshold, k.threshold_pi = r.get("threshold", 0.0), r.get("threshold_pi", -1.0)
         more = r.get("sep_more", ())      # (hf, hg) of separator stages 2..4
         if len(more) > 3:
             raise ValueError("separators have at most 4 stages")

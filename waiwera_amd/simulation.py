@@ -592,8 +592,13 @@ class Simulation:
                 if key not in s:
                     continue
                 spec = s[key] if isinstance(s[key], dict) else {}
-                if spec.get("threshold", -1.0) > 0.0:
-                    raise NotImplementedError("deliverability threshold")
+                thr = float(spec.get("threshold", -1.0) or -1.0)
+                if thr > 0.0:
+                    # deliverability that switches on below a threshold pressure (source_control.F90:99-100, 489-503;
+                    # source_setup.F90:2855-2911): the source keeps its own rate above it
+                    if kind != "deliverability":
+                        raise ValueError("threshold belongs to a deliverability control")
+                    r["threshold"] = thr
                 r["kind"] = kind
                 pr = spec.get("pressure", 1.0e5)
                 if isinstance(pr, str):
@@ -607,8 +612,10 @@ class Simulation:
                     r["table"] = [tuple(q) for q in pr[r["table_coord"]]]
                 else:
                     self._ctl_tables.append((i, "pressure", timed(pr, 1.0e5, s)))
-                if ckey in spec or kind == "recharge" or "rate" not in s:
+                if ckey in spec or kind == "recharge" or "rate" not in s or thr > 0.0:
                     self._ctl_tables.append((i, "coef", timed(spec.get(ckey), cdef, s)))
+                    if thr > 0.0:   # threshold_productivity starts as the productivity at the start time (:2906-2909)
+                        r["threshold_pi"] = float(self._ctl_tables[-1][2].interpolate(t0)[0])
                 else:
                     # productivity index from the initial rate (calculate_PI_from_rate,
                     # src/source_control.F90:407-468) on the initial fluid
@@ -651,6 +658,8 @@ class Simulation:
                 self._ctl_tables.append((i, "factor", timed(fac, 1.0, fs)))
         self._ctl = recs
         self._apply_controls((t0, t0))
+        for r in self._ctl:
+            r.pop("threshold_pi", None)     # from now on the index the device notes (wai_set_source_controls keeps it)
 
     def _apply_controls(self, interval):
         for i, key, tab in self._ctl_tables:
