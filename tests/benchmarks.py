@@ -444,3 +444,28 @@ def problem6_errors(sim, out, fx):
         h = np.array([sim.outputs[i][name][w] for i in near[ok]])
         worst["history " + k] = field_errors({k: h}, {k: np.asarray(fx["history"][k])[ok]}, [k])[k]
     return worst, int(ok.sum())
+
+
+def check_minc_datasets(sim):
+    """the MINC index datasets of the output file (flow_simulation.F90:2625-2691, mesh.F90:2728-2815): level and parent
+    per cell in the output's order -- original cells first (level 0, their own parent), then the matrix cells level by
+    level, each with the natural index of the original cell it was cut from; absent without MINC zones"""
+    import os
+    import tempfile
+    from waiwera_amd import hdf5io
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "out.h5")
+        sim.save_hdf5(path)
+        if sim._order is None:
+            assert not hdf5io.has_dataset(path, "/minc/level")
+            return
+        level = hdf5io.read_dataset(path, "/minc/level").ravel()
+        parent = hdf5io.read_dataset(path, "/minc/parent").ravel()
+    n0 = int((level == 0).sum())
+    assert level.size == sim.mesh.n_owned and n0 < level.size and np.all(level[:n0] == 0) and np.all(np.diff(level) >= 0)
+    assert np.array_equal(parent[:n0], np.arange(n0)) and parent.min() >= 0 and parent.max() < n0
+    zone = np.unique(parent[n0:])
+    for lev in range(1, int(level.max()) + 1):
+        pl = parent[level == lev]                                   # one cell per zone cell and level
+        assert np.unique(pl).size == pl.size and np.isin(pl, zone).all()
+    assert np.array_equal(np.sort(parent[level == 1]), zone)

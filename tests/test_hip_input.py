@@ -166,6 +166,7 @@ def test_minc_zones_from_input_files(name, geometry, key):
     out = sim.run()
     worst = B.field_errors(triple(out), fx, ("Pressure", "Temperature", "Vapour saturation"))
     assert max(v[0] for v in worst.values()) < 5.0e-3
+    B.check_minc_datasets(sim)
     sim.ode.destroy()
 
 

@@ -489,6 +489,7 @@ def test_minc_zones_from_input_files_against_autough2(oracle, name, geometry, ke
     worst = B.field_errors(got, fx, list(got))
     print(name, {k: "%.1e / %.1e" % v for k, v in worst.items()}, "steps", sim.ts.taken)
     assert max(v[0] for v in worst.values()) < 5.0e-3
+    B.check_minc_datasets(sim)
     sim.ode.o.close()
 
 

@@ -732,11 +732,17 @@ class Simulation:
 
     def save_hdf5(self, path):
         """the collected outputs in the reference's layout: /time, /cell_index, /cell_fields/*,
-        /source_fields/source_rate and source_enthalpy"""
+        /source_fields/source_rate and source_enthalpy, /minc/level and /minc/parent of a MINC mesh"""
         from . import hdf5io
         outs = getattr(self, "outputs", None) or [self.fields()]
         n = self.mesh.n_owned
         data = {"/time": np.array([[o["time"]] for o in outs]), "/cell_index": np.arange(n, dtype=np.int32)[:, None]}
+        if self._order is not None:
+            # flow_simulation_output_minc_data (src/flow_simulation.F90:2625-2691): per cell, in the output's cell
+            # order, its MINC level (0: fracture or single-porosity cell) and the natural index of the original cell
+            ex = self.mesh.extras
+            data["/minc/level"] = np.asarray(ex["minc_level"])[self._order].astype(np.int32)[:, None]
+            data["/minc/parent"] = np.asarray(ex["minc_parent"])[self._order].astype(np.int32)[:, None]
         for k in outs[0]:
             if k == "time":
                 continue
