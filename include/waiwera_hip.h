@@ -212,7 +212,11 @@ int wai_set_source_network(wai_ctx *ctx, const int *rate_specified, const int *e
  * rank hands wai_set_source_network the SAME description, numbered by global source index, after telling which
  * global index each of its own sources has.  The sources' own rates are then all-gathered before every network
  * pass (one small all-reduce per residual evaluation) and the pass runs identically on every rank.  The Jacobian
- * blocks through the network are not formed in that case (factors held, as wai_set_network_couplings(ctx, 0)). */
+ * blocks through the network then couple cells of different ranks: the columns of E are the network's cells of ALL
+ * ranks, ordered by (owner rank, local cell), the rows this rank's own; every rank differences its rows against every
+ * column (collective, inside wai_jacobian) and x at the network's cells is gathered for every operator application
+ * (one more small all-reduce).  wai_get_network_couplings: n_cells = m columns, cells[j] = the local cell or
+ * -1 - owner rank, values = (own rows, in column order) x m blocks. */
 int wai_set_source_global_index(wai_ctx *ctx, int n_global, const int *global_index);
 int wai_set_network_couplings(wai_ctx *ctx, int on);
 int wai_get_network_couplings(wai_ctx *ctx, int *n_cells, int *cells, double *values);

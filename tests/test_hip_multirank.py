@@ -318,7 +318,7 @@ def test_asm_overlap_reaches_across_ranks(world, eos):
 # ---- a source network whose sources live on several ranks ------------------------------------------------------
 
 def _network_spec(n_global):
-    """producers 4..7 in one group behind a separator with a total limit of 12 kg/s (they ask for 20): uniform
+    """producers 4..7 in one group behind a separator with a total limit of 12 kg/s (they would give more): uniform
     scaling; the group's separated water goes half to injector 0 and three tenths to injector 3 -- which sit on
     different ranks of the 2 x 1 x 1 partition -- the rest is not reinjected"""
     return dict(rate_specified=[1] * n_global, enthalpy_specified=[1] * 4 + [0] * 4,
@@ -327,6 +327,11 @@ def _network_spec(n_global):
                 reinjectors=[dict(input=(2, 0), overflow=(0, -1),
                                   outputs=[dict(flow=1, out=(1, 0), rate=-1.0, proportion=0.5, enthalpy=-1.0),
                                            dict(flow=1, out=(1, 3), rate=-1.0, proportion=0.3, enthalpy=-1.0)])])
+
+
+# the producers on deliverability: their rates -- and through the group's limiter each other's, and the injectors' --
+# depend on the pressures of all four producer cells: that is what the network's Jacobian blocks hold
+_NET_CONTROLS = [dict()] * 4 + [dict(kind="deliverability", coef=1.0e-11, pressure=2.0e5)] * 4
 
 
 def _net_problem(part, rank):
@@ -354,13 +359,27 @@ def _net_worker(rank, world, uid_q, q):
     sim.set_regions(region)
     sim.comm_init(rank, world, uid)
     sim.set_source_global_index(ng, gidx)
+    sim.set_source_controls([_NET_CONTROLS[g] for g in gidx])
     sim.set_source_network(_network_spec(ng))
     y = scaled(prim, region).ravel().copy()
+    cp = _initial_couplings(sim, lm, y)
     hist = _run_steps(sim, y, 2)
     rate, enth = sim.source_rates()
     G, R = sim.source_network()
-    q.put((rank, lm.owned_gid.copy(), y[: lm.n_owned * 2].copy(), hist, gidx, rate, enth, G, R))
+    q.put((rank, lm.owned_gid.copy(), y[: lm.n_owned * 2].copy(), hist, gidx, rate, enth, G, R, cp))
     sim.destroy()
+
+
+def _initial_couplings(sim, lm, y):
+    """the network's Jacobian blocks at the initial state: (global ids of this rank's rows, E (ml, m, bs, bs))"""
+    n = lm.n_owned * 2
+    L, f = np.zeros(n), np.zeros(n)
+    assert sim.pre_eval(0.0, y) == 0
+    sim.lhs(0.0, (0.0, 0.0), y, L)
+    assert sim.residual(0.0, 2.0e4, y, L, f) == 0
+    assert sim.jacobian(0.0, 2.0e4, y, L) == 0
+    cells, E = sim.network_couplings()
+    return lm.owned_gid[cells[cells >= 0]].copy(), E, cells.copy()
 
 
 @pytest.mark.timeout(900)
@@ -368,7 +387,9 @@ def test_source_network_across_ranks():
     """groups and reinjectors whose sources sit on different ranks (the reference gathers over the group's
     communicator, source_network_group.F90:494-515, 579-596): the sources' own rates are all-gathered before every
     network pass, which each rank then runs on the whole network -- same source rates, group and reinjector states
-    and the same solution as the one-rank run with the network's factors held in the Jacobian"""
+    and the same solution as the one-rank run; the network's Jacobian blocks couple cells of different ranks (each
+    rank differences its own rows against every rank's columns, x at the network's cells is gathered for every
+    operator application): the same blocks and the same Newton iteration counts as on one rank"""
     assert os.path.exists(LOOPBACK), "build first: python __graft_entry__.py"
     os.environ["WAI_RCCL_LIB"] = LOOPBACK
     from waiwera_amd.flow_simulation import FlowSimulation
@@ -386,9 +407,11 @@ def test_source_network_across_ranks():
     assert gidx == list(range(ng))
     sim = FlowSimulation(lm, eos="we", device=0)
     sim.set_regions(region)
+    sim.set_source_controls(_NET_CONTROLS)
     sim.set_source_network(_network_spec(ng))
-    sim.set_network_couplings(False)
     y = scaled(prim, region).ravel().copy()
+    gid1, E1, cells1 = _initial_couplings(sim, lm, y)
+    assert E1.shape[0] == E1.shape[1] == 6 and np.abs(E1).max() > 0       # four producers, two injectors
     hist = _run_steps(sim, y, 2)
     rate1, enth1 = sim.source_rates()
     G1, R1 = sim.source_network()
@@ -400,7 +423,17 @@ def test_source_network_across_ranks():
     assert abs(rate1[1] - 10.0) < 1e-12
     owners = set()
     ypar = np.zeros((g.n_global, 2))
-    for rank, gid, yy, h, gi, rate, enth, G, R in res:
+    res.sort(key=lambda r: r[0])
+    colgid = np.concatenate([r[9][0] for r in res])                    # columns: (owner rank, local cell) order
+    assert sorted(colgid) == sorted(gid1)
+    pos1 = {int(gc): i for i, gc in enumerate(gid1)}
+    perm = [pos1[int(gc)] for gc in colgid]
+    for rank, gid, yy, h, gi, rate, enth, G, R, cp in res:
+        rows, E, cells = cp
+        assert E.shape[:2] == (len(rows), len(colgid)) and len(rows) > 0 and (cells < 0).any()
+        assert np.all(cells[cells < 0] == -1 - (1 - rank))              # the other rank's cells name their owner
+        ref = E1[np.ix_([pos1[int(gc)] for gc in rows], perm)]
+        assert np.abs(E - ref).max() <= 1e-9 * np.abs(E1).max(), (rank, np.abs(E - ref).max(), np.abs(E1).max())
         assert all(r > 0 for r, _, _ in h) and [n for _, n, _ in h] == [n for _, n, _ in hist]
         assert len(gi) > 0
         owners.add(rank)

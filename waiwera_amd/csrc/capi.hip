@@ -842,16 +842,17 @@ __global__ void k_gather_rows(int m, int bs, const int* __restrict__ cells, cons
   out[t] = f[(size_t)cells[t / bs] * bs + t % bs];
 }
 
-// t += E x on the network's rows: thread (i, r) sums its row over the m column cells (cells are distinct: no race)
-__global__ void k_coupling_apply(int m, int bs, const int* __restrict__ cells, const double* __restrict__ val,
-                                 const double* __restrict__ x, double* __restrict__ t) {
+// t += E x on the network's rows: thread (i, r) sums its row over the mc column cells (cells are distinct: no race).
+// xg != null: x at the column cells, gathered over the ranks ([mc][bs]); else the columns are the row cells themselves
+__global__ void k_coupling_apply(int mr, int mc, int bs, const int* __restrict__ cells, const double* __restrict__ val,
+                                 const double* __restrict__ x, const double* __restrict__ xg, double* __restrict__ t) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= m * bs) return;
+  if (id >= mr * bs) return;
   const int i = id / bs, r = id % bs;
   double s = 0.0;
-  for (int j = 0; j < m; j++) {
-    const double* e = val + ((size_t)(i * m + j) * bs + r) * bs;
-    const double* xj = x + (size_t)cells[j] * bs;
+  for (int j = 0; j < mc; j++) {
+    const double* e = val + ((size_t)(i * mc + j) * bs + r) * bs;
+    const double* xj = xg ? xg + (size_t)j * bs : x + (size_t)cells[j] * bs;
     for (int k = 0; k < bs; k++) s += e[k] * xj[k];
   }
   t[(size_t)cells[i] * bs + r] += s;
@@ -860,14 +861,19 @@ __global__ void k_coupling_apply(int m, int bs, const int* __restrict__ cells, c
 int network_couplings(wai_ctx* c, double dt, double* y, const double* lhs_old) {
   Network& nw = c->net;
   nw.cp_valid = false;
-  if (!nw.on || !nw.coupling || nw.cp_cells.empty()) return 0;
-  const int m = (int)nw.cp_cells.size(), bs = c->np, mb = m * bs;
-  if (!nw.d_cp_cells) {
-    if (dev_upload(c, &nw.d_cp_cells, nw.cp_cells) || dev_alloc(c, &nw.d_cp_val, (size_t)m * m * bs * bs) ||
-        dev_alloc(c, &nw.d_cp_f, (size_t)c->mesh.n_local * bs) || dev_alloc(c, &nw.d_cp_g, (size_t)2 * mb))
+  const bool span = nw.cp_span;
+  const int ml = (int)nw.cp_cells.size(), m = span ? nw.cp_m : ml, j0 = span ? nw.cp_j0 : 0;
+  if (!nw.on || !nw.coupling || m == 0) return 0;
+  const int bs = c->np, mb = ml * bs, me = span ? c->comm->rank : 0;
+  if (!nw.d_cp_val) {
+    std::vector<int> cells = nw.cp_cells;
+    if (cells.empty()) cells.push_back(0);
+    if (dev_upload(c, &nw.d_cp_cells, cells) || dev_alloc(c, &nw.d_cp_val, (size_t)std::max(ml, 1) * m * bs * bs) ||
+        dev_alloc(c, &nw.d_cp_f, (size_t)c->mesh.n_local * bs) || dev_alloc(c, &nw.d_cp_g, (size_t)2 * std::max(mb, 1)) ||
+        dev_alloc(c, &nw.d_cp_x, (size_t)m * bs + 2))
       return -1;
   }
-  nw.h_cp_val.assign((size_t)m * m * bs * bs, 0.0);
+  nw.h_cp_val.assign((size_t)ml * m * bs * bs, 0.0);
   std::vector<double> g((size_t)2 * mb), yc((size_t)bs);
   const int grid = (mb + 63) / 64;
   auto set_y = [&](int cell, int k, double v) -> int {
@@ -876,31 +882,52 @@ int network_couplings(wai_ctx* c, double dt, double* y, const double* lhs_old) {
     launch_eos(c, y, cell, 1, false);
     return 0;
   };
+  // one double from its owner to every rank (the sum over the ranks of {value on the owner, 0 elsewhere})
+  auto from_owner = [&](double& v, bool mine) -> int {
+    if (!span) return 0;
+    const double mineval = mine ? v : 0.0;
+    HIPCHK(c, hipMemcpyAsync(nw.d_cp_x, &mineval, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (comm_allreduce(c->comm, nw.d_cp_x, 1, 0, c->stream, c->err)) return -1;
+    HIPCHK(c, hipMemcpyAsync(&v, nw.d_cp_x, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+  };
   if (network_update(c)) return -1;   // the factors A was differenced with
   bool any = false;
-  for (int j = 0; j < m; j++) {
-    const int cell = nw.cp_cells[j];
-    HIPCHK(c, hipMemcpyAsync(yc.data(), y + (size_t)cell * bs, sizeof(double) * bs, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int k = 0; k < bs; k++) {
-      double dx = yc[k];   // MatFDColoring "ds" increment, as fd_step (kernels_assembly.hip)
-      if (std::fabs(dx) < c->opts.fd_umin) dx = dx >= 0.0 ? c->opts.fd_umin : -c->opts.fd_umin;
-      const double h = dx * c->opts.fd_eps;
-      if (set_y(cell, k, yc[k] + h)) return -1;
-      launch_residual(c, dt, lhs_old, nw.d_cp_f, nullptr, nullptr, nw.d_cp_cells, m);   // factors held; the network's rows alone
-      hipLaunchKernelGGL(k_gather_rows, grid, 64, 0, c->stream, m, bs, nw.d_cp_cells, nw.d_cp_f, nw.d_cp_g);
-      if (network_update(c)) return -1;
-      launch_residual(c, dt, lhs_old, nw.d_cp_f, nullptr, nullptr, nw.d_cp_cells, m);   // network pass redone
-      hipLaunchKernelGGL(k_gather_rows, grid, 64, 0, c->stream, m, bs, nw.d_cp_cells, nw.d_cp_f, nw.d_cp_g + mb);
-      HIPCHK(c, hipMemcpyAsync(g.data(), nw.d_cp_g, sizeof(double) * 2 * mb, hipMemcpyDeviceToHost, c->stream));
+  for (int j = 0; j < m; j++) {       // every rank walks the same columns: the network passes are collective
+    const bool mine = !span || nw.cp_owner[j] == me;
+    const int cell = mine ? nw.cp_cells[j - j0] : -1;
+    if (mine) {
+      HIPCHK(c, hipMemcpyAsync(yc.data(), y + (size_t)cell * bs, sizeof(double) * bs, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
-      for (int i = 0; i < m; i++)
-        for (int r = 0; r < bs; r++) {
-          const double e = (g[(size_t)mb + i * bs + r] - g[(size_t)i * bs + r]) / h;
-          nw.h_cp_val[((size_t)(i * m + j) * bs + r) * bs + k] = e;
-          any = any || e != 0.0;
-        }
-      if (set_y(cell, k, yc[k])) return -1;   // back to the unperturbed state and its network factors
+    }
+    for (int k = 0; k < bs; k++) {
+      double h = 0.0;
+      if (mine) {
+        double dx = yc[k];   // MatFDColoring "ds" increment, as fd_step (kernels_assembly.hip)
+        if (std::fabs(dx) < c->opts.fd_umin) dx = dx >= 0.0 ? c->opts.fd_umin : -c->opts.fd_umin;
+        h = dx * c->opts.fd_eps;
+      }
+      if (from_owner(h, mine)) return -1;
+      if (mine && set_y(cell, k, yc[k] + h)) return -1;
+      if (ml) {
+        launch_residual(c, dt, lhs_old, nw.d_cp_f, nullptr, nullptr, nw.d_cp_cells, ml);   // factors held; the network's rows alone
+        hipLaunchKernelGGL(k_gather_rows, grid, 64, 0, c->stream, ml, bs, nw.d_cp_cells, nw.d_cp_f, nw.d_cp_g);
+      }
+      if (network_update(c)) return -1;
+      if (ml) {
+        launch_residual(c, dt, lhs_old, nw.d_cp_f, nullptr, nullptr, nw.d_cp_cells, ml);   // network pass redone
+        hipLaunchKernelGGL(k_gather_rows, grid, 64, 0, c->stream, ml, bs, nw.d_cp_cells, nw.d_cp_f, nw.d_cp_g + mb);
+        HIPCHK(c, hipMemcpyAsync(g.data(), nw.d_cp_g, sizeof(double) * 2 * mb, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < ml; i++)
+          for (int r = 0; r < bs; r++) {
+            const double e = (g[(size_t)mb + i * bs + r] - g[(size_t)i * bs + r]) / h;
+            nw.h_cp_val[((size_t)(i * m + j) * bs + r) * bs + k] = e;
+            any = any || e != 0.0;
+          }
+      }
+      if (mine && set_y(cell, k, yc[k])) return -1;   // back to the unperturbed state and its network factors
       if (network_update(c)) return -1;
     }
   }
@@ -911,18 +938,36 @@ int network_couplings(wai_ctx* c, double dt, double* y, const double* lhs_old) {
                              c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  nw.cp_valid = any;
+  double flag = any ? 1.0 : 0.0;   // every rank applies E (a collective gather of x) or none does
+  if (span) {
+    HIPCHK(c, hipMemcpyAsync(nw.d_cp_x, &flag, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (comm_allreduce(c->comm, nw.d_cp_x, 1, 1, c->stream, c->err)) return -1;
+    HIPCHK(c, hipMemcpyAsync(&flag, nw.d_cp_x, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  nw.cp_valid = flag != 0.0;
   return 0;
 }
 
-// t = (A + E) x: the block-ELL SpMV and, when the network couples cells, its blocks on top
-void apply_operator(wai_ctx* c, const double* x, double* t) {
+// t = (A + E) x: the block-ELL SpMV and, when the network couples cells, its blocks on top.  A network on several
+// ranks: x at the network's cells is gathered first (one all-reduce of m * bs doubles per application)
+int apply_operator(wai_ctx* c, const double* x, double* t) {
   launch_spmv(c, x, t);
   const Network& nw = c->net;
-  if (nw.cp_valid) {
-    const int m = (int)nw.cp_cells.size();
-    hipLaunchKernelGGL(k_coupling_apply, (m * c->np + 63) / 64, 64, 0, c->stream, m, c->np, nw.d_cp_cells, nw.d_cp_val, x, t);
+  if (!nw.cp_valid) return 0;
+  const int ml = (int)nw.cp_cells.size(), bs = c->np;
+  if (!nw.cp_span) {
+    hipLaunchKernelGGL(k_coupling_apply, (ml * bs + 63) / 64, 64, 0, c->stream, ml, ml, bs, nw.d_cp_cells, nw.d_cp_val, x,
+                       (const double*)nullptr, t);
+    return 0;
   }
+  const int m = nw.cp_m;
+  HIPCHK(c, hipMemsetAsync(nw.d_cp_x, 0, sizeof(double) * (size_t)m * bs, c->stream));
+  if (ml) hipLaunchKernelGGL(k_gather_rows, (ml * bs + 63) / 64, 64, 0, c->stream, ml, bs, nw.d_cp_cells, x, nw.d_cp_x + (size_t)nw.cp_j0 * bs);
+  if (comm_allreduce(c->comm, nw.d_cp_x, (size_t)m * bs, 0, c->stream, c->err)) return -1;
+  if (ml) hipLaunchKernelGGL(k_coupling_apply, (ml * bs + 63) / 64, 64, 0, c->stream, ml, m, bs, nw.d_cp_cells, nw.d_cp_val, x,
+                             (const double*)nw.d_cp_x, t);
+  return 0;
 }
 
 // ---- fluid_properties / pre_eval on device vectors -------------------------------------------
@@ -1145,7 +1190,7 @@ int pc_amul(wai_ctx* c, double* x, double* z, int dot_mode = 0, const double* au
   const IluSchedule& s = c->ilu;
   if (!pc_fused(c) || c->net.cp_valid) {   // unfused: t = A x (+ the network's blocks), then the preconditioner
     if (halo_exchange(c, x, c->np)) return -1;
-    { Prof p(c, KC_SPMV); apply_operator(c, x, c->ks.tmp); }
+    { Prof p(c, KC_SPMV); if (apply_operator(c, x, c->ks.tmp)) return -1; }
     Prof p(c, KC_PC_APPLY);
     return pc_solve(c, c->ks.tmp, z, dot_mode, x, aux, fin_phase);
   }
@@ -1319,7 +1364,7 @@ int ksp_gmres(wai_ctx* c, const double* b, double* x, int* its, int* reason, dou
     } else {
       vec_copy(c, k.P, x, n);
       if (halo_exchange(c, k.P, c->np)) return -1;
-      { Prof p(c, KC_SPMV); apply_operator(c, k.P, k.tmp); }
+      { Prof p(c, KC_SPMV); if (apply_operator(c, k.P, k.tmp)) return -1; }
       vec_waxpy(c, k.tmp, -1.0, k.tmp, b, n);
       Prof p(c, KC_PC_APPLY);
       if (pc_solve(c, k.tmp, v0, 0, nullptr, nullptr)) return -1;
@@ -1424,7 +1469,7 @@ int ksp_lgmres(wai_ctx* c, const double* b, double* x, int* its, int* reason, do
     } else {
       vec_copy(c, k.P, x, n);
       if (halo_exchange(c, k.P, c->np)) return -1;
-      { Prof p(c, KC_SPMV); apply_operator(c, k.P, k.tmp); }
+      { Prof p(c, KC_SPMV); if (apply_operator(c, k.P, k.tmp)) return -1; }
       vec_waxpy(c, k.tmp, -1.0, k.tmp, b, n);
       Prof p(c, KC_PC_APPLY);
       if (pc_solve(c, k.tmp, v0, 0, nullptr, nullptr)) return -1;
@@ -2317,6 +2362,31 @@ void network_cells(Network& nw, int n) {
   std::sort(nw.cp_cells.begin(), nw.cp_cells.end());
   nw.cp_cells.erase(std::unique(nw.cp_cells.begin(), nw.cp_cells.end()), nw.cp_cells.end());
 }
+// the same over several ranks: the network's cells of all ranks, ordered by (owner rank, local cell); this rank's own
+// are then one contiguous run of the columns and, in that order, the rows it differences and applies
+void network_cells_span(Network& nw, int ng, const std::vector<double>& id, int rank) {
+  std::vector<char> in_net((size_t)ng, 0);
+  auto mark = [&](const NetRef& r) { if (r.kind == 1 && r.index >= 0 && r.index < ng) in_net[r.index] = 1; };
+  for (const NetGroup& g : nw.groups) for (const NetRef& r : g.in) mark(r);
+  for (const NetReinjector& r : nw.reinjectors) { mark(r.in); mark(r.overflow); for (const NetOutput& o : r.out) mark(o.out); }
+  std::vector<double> u;
+  for (int g = 0; g < ng; g++) if (in_net[g]) u.push_back(id[g]);
+  std::sort(u.begin(), u.end());
+  u.erase(std::unique(u.begin(), u.end()), u.end());
+  nw.cp_span = true;
+  nw.cp_m = (int)u.size();
+  nw.cp_owner.resize(u.size());
+  nw.cp_cells.clear();
+  nw.cp_j0 = 0;
+  for (size_t j = 0; j < u.size(); j++) {
+    const int owner = (int)(u[j] / 4294967296.0);
+    nw.cp_owner[j] = owner;
+    if (owner == rank) {
+      if (nw.cp_cells.empty()) nw.cp_j0 = (int)j;
+      nw.cp_cells.push_back((int)(u[j] - (double)owner * 4294967296.0));
+    }
+  }
+}
 }  // namespace
 extern "C" {
 
@@ -2342,6 +2412,7 @@ int wai_set_source_network(wai_ctx* c, const int* rate_specified, const int* ent
   if (n_groups <= 0 && n_reinj <= 0) return 0;
   const bool span = c->comm && c->comm->nranks > 1;
   int ng = n;
+  std::vector<double> span_id;   // several ranks: every source's cell as (owner rank, local cell)
   if (span) {
     // the description is numbered by global source index (wai_set_source_global_index); what the pass needs of
     // the other ranks' sources -- separator enthalpies, specified injection enthalpies -- is gathered once, here
@@ -2350,14 +2421,16 @@ int wai_set_source_network(wai_ctx* c, const int* rate_specified, const int* ent
     for (int g : c->src_gidx) if (g < 0 || g >= ng) { c->err = "global source index out of range"; return -2; }
     nw.gidx = c->src_gidx;
     nw.n_global = ng;
-    std::vector<double> all((size_t)9 * ng, 0.0);
+    const int NG = 10;   // per source: 8 separator enthalpies, the specified enthalpy, the cell's identity (rank * 2^32 + cell)
+    std::vector<double> all((size_t)NG * ng, 0.0);
     for (int i = 0; i < n; i++) {
       const int g = nw.gidx[i];
       if (i < (int)ctl.size()) {
-        all[(size_t)9 * g] = ctl[i].sep_hf; all[(size_t)9 * g + 1] = ctl[i].sep_hg;
-        for (int q = 0; q < 6; q++) all[(size_t)9 * g + 2 + q] = ctl[i].sep_more[q];
+        all[(size_t)NG * g] = ctl[i].sep_hf; all[(size_t)NG * g + 1] = ctl[i].sep_hg;
+        for (int q = 0; q < 6; q++) all[(size_t)NG * g + 2 + q] = ctl[i].sep_more[q];
       }
-      all[(size_t)9 * g + 8] = i < (int)e0.size() ? e0[i] : 0.0;
+      all[(size_t)NG * g + 8] = i < (int)e0.size() ? e0[i] : 0.0;
+      all[(size_t)NG * g + 9] = (double)c->comm->rank * 4294967296.0 + (double)(i < (int)cells.size() ? cells[i] : 0);
     }
     double* tmp = nullptr;
     if (dev_upload(c, &tmp, all)) return -1;
@@ -2368,14 +2441,13 @@ int wai_set_source_network(wai_ctx* c, const int* rate_specified, const int* ent
     if (rc) return -1;
     nw.h_ctl.assign((size_t)ng, SrcCtl{});
     nw.h_enth0.assign((size_t)ng, 0.0);
+    span_id.assign((size_t)ng, 0.0);
     for (int g = 0; g < ng; g++) {
-      nw.h_ctl[g].sep_hf = all[(size_t)9 * g]; nw.h_ctl[g].sep_hg = all[(size_t)9 * g + 1];
-      for (int q = 0; q < 6; q++) nw.h_ctl[g].sep_more[q] = all[(size_t)9 * g + 2 + q];
-      nw.h_enth0[g] = all[(size_t)9 * g + 8];
+      nw.h_ctl[g].sep_hf = all[(size_t)NG * g]; nw.h_ctl[g].sep_hg = all[(size_t)NG * g + 1];
+      for (int q = 0; q < 6; q++) nw.h_ctl[g].sep_more[q] = all[(size_t)NG * g + 2 + q];
+      nw.h_enth0[g] = all[(size_t)NG * g + 8];
+      span_id[g] = all[(size_t)NG * g + 9];
     }
-    // the Jacobian blocks through the network would couple cells of different ranks: the network's factors are
-    // held in the Jacobian instead (wai_set_network_couplings(ctx, 0) semantics)
-    nw.coupling = false;
   }
   if (int e = network_build(nw, ng, rate_specified, enthalpy_specified, n_groups, grp_ptr, grp_in_kind, grp_in, grp_scaling,
                             grp_limit_type, grp_limit, grp_sep, n_reinj, rj_in_kind, rj_in, rj_out_ptr, out_flow, out_kind,
@@ -2390,6 +2462,7 @@ int wai_set_source_network(wai_ctx* c, const int* rate_specified, const int* ent
   for (int i = 0; i < n; i++) nw.l_enth[i] = span ? nw.h_enth0[nw.gidx[i]] : (i < (int)nw.h_enth0.size() ? nw.h_enth0[i] : 0.0);
   nw.on = true;
   if (!span) network_cells(nw, n);
+  else network_cells_span(nw, ng, span_id, c->comm->rank);
   return 0;
 }
 
@@ -2413,10 +2486,15 @@ int wai_set_network_couplings(wai_ctx* c, int on) {
 int wai_get_network_couplings(wai_ctx* c, int* n_cells, int* cells, double* values) {
   if (!c || !n_cells) return -2;
   const Network& nw = c->net;
-  const int m = (nw.on && nw.coupling && nw.cp_valid) ? (int)nw.cp_cells.size() : 0;
+  const bool on = nw.on && nw.coupling && nw.cp_valid;
+  const int ml = on ? (int)nw.cp_cells.size() : 0, m = on ? (nw.cp_span ? nw.cp_m : ml) : 0;
   *n_cells = m;
-  if (cells) for (int i = 0; i < m; i++) cells[i] = nw.cp_cells[i];
-  if (values && m) std::memcpy(values, nw.h_cp_val.data(), sizeof(double) * nw.h_cp_val.size());
+  if (cells)
+    for (int j = 0; j < m; j++) {
+      const bool mine = !nw.cp_span || (j >= nw.cp_j0 && j < nw.cp_j0 + ml);
+      cells[j] = mine ? nw.cp_cells[j - (nw.cp_span ? nw.cp_j0 : 0)] : -1 - nw.cp_owner[j];
+    }
+  if (values && ml) std::memcpy(values, nw.h_cp_val.data(), sizeof(double) * nw.h_cp_val.size());
   return 0;
 }
 // The same network pass without a context or a device (host logic only; tests): the sources' own rates
@@ -2789,7 +2867,7 @@ int wai_spmv(wai_ctx* c, const double* x, double* y) {
   if (yo.out_only(y, c->ks.n, 1)) return -1;
   {
     Prof p(c, KC_SPMV);
-    apply_operator(c, xd, yo.dev);
+    if (apply_operator(c, xd, yo.dev)) return -1;
   }
   return yo.back();
 }

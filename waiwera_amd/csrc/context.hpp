@@ -103,10 +103,16 @@ struct Network {
   std::vector<int> h_cell;                         // cell of every source
   bool coupling = true;                            // wai_set_network_couplings
   bool cp_valid = false;                           // E belongs to the Jacobian in force and has a nonzero entry
-  std::vector<int> cp_cells;                       // distinct cells of the network's sources, ascending
-  std::vector<double> h_cp_val;                    // [m][m][bs][bs] row-major, m = cp_cells.size()
+  std::vector<int> cp_cells;                       // distinct (local) cells of the network's sources, ascending
+  std::vector<double> h_cp_val;                    // [ml][m][bs][bs] row-major, ml = cp_cells.size() rows, m columns
+  // a network on several ranks: the columns are the network's cells of ALL ranks, ordered by (owner rank, local
+  // cell) -- this rank's cells are the columns cp_j0 .. cp_j0 + ml; one rank: m = ml, cp_j0 = 0
+  bool cp_span = false;
+  int cp_m = 0, cp_j0 = 0;
+  std::vector<int> cp_owner;                       // [m] owner rank of every column cell
   int* d_cp_cells = nullptr;
   double *d_cp_val = nullptr, *d_cp_f = nullptr, *d_cp_g = nullptr;
+  double* d_cp_x = nullptr;                        // [m * bs + 2] x at the column cells, gathered over the ranks
   void free_device() {
     if (d_raw) (void)hipFree(d_raw);
     if (d_all) (void)hipFree(d_all);
@@ -115,7 +121,8 @@ struct Network {
     if (d_cp_val) (void)hipFree(d_cp_val);
     if (d_cp_f) (void)hipFree(d_cp_f);
     if (d_cp_g) (void)hipFree(d_cp_g);
-    d_raw = d_cp_val = d_cp_f = d_cp_g = nullptr; d_cp_cells = nullptr;
+    if (d_cp_x) (void)hipFree(d_cp_x);
+    d_raw = d_cp_val = d_cp_f = d_cp_g = d_cp_x = nullptr; d_cp_cells = nullptr;
   }
 };
 

@@ -129,15 +129,20 @@ class FlowSimulation:
         self._chk(LIB.wai_set_network_couplings(self.h, 1 if on else 0), "set_network_couplings")
 
     def network_couplings(self):
-        """(cells (m,), E (m, m, bs, bs)): d R(cell i) / d y(cell j) through the network pass, of the last
-        wai_jacobian (wai_get_network_couplings); m = 0 without a network or when E vanishes"""
+        """(cells (m,), E (ml, m, bs, bs)): d R(cell i) / d y(cell j) through the network pass, of the last
+        wai_jacobian (wai_get_network_couplings); m = 0 without a network or when E vanishes.  One rank: ml = m.
+        A network on several ranks: the columns are the network's cells of all ranks ordered by (owner, cell), the
+        rows this rank's own (cells >= 0, in that order); another rank's cell reads -1 - owner"""
         m = C.c_int(0)
         self._chk(LIB.wai_get_network_couplings(self.h, C.byref(m), None, None), "get_network_couplings")
         bs = self.num_primary_variables
-        cells, E = np.zeros(m.value, dtype=np.int32), np.zeros((m.value, m.value, bs, bs))
-        if m.value:
-            self._chk(LIB.wai_get_network_couplings(self.h, C.byref(m), cells.ctypes.data_as(_lib.pi),
-                                                    E.ctypes.data_as(_lib.pd)), "get_network_couplings")
+        cells = np.zeros(m.value, dtype=np.int32)
+        if not m.value:
+            return cells, np.zeros((0, 0, bs, bs))
+        self._chk(LIB.wai_get_network_couplings(self.h, C.byref(m), cells.ctypes.data_as(_lib.pi), None), "get_network_couplings")
+        E = np.zeros((int((cells >= 0).sum()), m.value, bs, bs))
+        if E.size:
+            self._chk(LIB.wai_get_network_couplings(self.h, C.byref(m), None, E.ctypes.data_as(_lib.pd)), "get_network_couplings")
         return cells, E
 
     def separator_enthalpies(self, pressure):
