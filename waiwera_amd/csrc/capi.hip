@@ -24,6 +24,9 @@ using namespace wai;
     }                                                                                   \
   } while (0)
 
+#ifdef WAI_PC_PHASES
+namespace wai { void pc_phases_fetch(unsigned long long out[8], bool reset); }
+#endif
 namespace {
 
 enum { S_RHO = 0, S_RHOOLD = 1, S_ALPHA = 2, S_OMEGA = 3, S_BETA = 4, S_D1 = 5, S_D2 = 6,
@@ -3198,6 +3201,18 @@ int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
   float ms = 0.f;
   HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
   *ms_per_launch = ms / reps;
+#ifdef WAI_PC_PHASES
+  {
+    unsigned long long ph[8];
+    pc_phases_fetch(ph, true);
+    if (ph[7]) {
+      const double n = (double)ph[7], us = 0.01;   // 100 MHz ticks
+      fprintf(stderr, "pc phases (which %d, %.0f workgroups, %.4f ms per launch): load %.2f wait %.2f forward %.2f backward %.2f epilogue %.2f us per workgroup; "
+              "resident workgroups on average %.1f\n", which, n, ms / reps, ph[0] * us / n, ph[1] * us / n, ph[2] * us / n, ph[3] * us / n, ph[4] * us / n,
+              (ph[0] + ph[1] + ph[2] + ph[3] + ph[4]) * us * 1e-3 / ((reps + 5) * (double)(ms / reps)));
+    }
+  }
+#endif
   return 0;
 }
 

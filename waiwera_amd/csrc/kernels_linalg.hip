@@ -23,6 +23,33 @@
 
 namespace wai {
 
+// Phase timing of the fused preconditioner kernels (build with -DWAI_PC_PHASES; tools/pc_phases.sh): thread 0 of every
+// workgroup stamps the 100 MHz real-time counter at the phase boundaries and adds the differences to g_pc_phase
+// [0] row loads + products, [1] wait for the workgroup's slowest wave, [2] forward sweep, [3] backward sweep,
+// [4] store + reductions, [7] workgroups
+#ifdef WAI_PC_PHASES
+__device__ unsigned long long g_pc_phase[8];
+#define PH_DECL unsigned long long ph_t = wall_clock64()
+#define PH(k)                                                                                    \
+  do {                                                                                           \
+    if (threadIdx.x == 0) {                                                                      \
+      const unsigned long long t_ = wall_clock64();                                              \
+      atomicAdd(&g_pc_phase[k], t_ - ph_t);                                                      \
+      ph_t = t_;                                                                                 \
+    }                                                                                            \
+  } while (0)
+#define PH_COUNT() do { if (threadIdx.x == 0) atomicAdd(&g_pc_phase[7], 1ull); } while (0)
+void pc_phases_fetch(unsigned long long out[8], bool reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pc_phase), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pc_phase), z, sizeof(z)); }
+}
+#else
+#define PH_DECL
+#define PH(k)
+#define PH_COUNT()
+#endif
+
+
 constexpr int TPB = 256;
 #ifndef PC_MIN_WAVES
 #define PC_MIN_WAVES 4   // waves per SIMD k_pc is compiled for; 5 or 6 force spills and measured 1.2x / 3x slower (tools/ab_pc_waves.sh)
@@ -1243,6 +1270,7 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
   const int nl = sub_nlev[s];
   const int nlf = nl & 0xffff, nlb = nl >> 16;
   const int tid = threadIdx.x;
+  PH_DECL;
   // component-major over the R1 leading (long) rows, then component-major over the short ones
   const int R1 = sub_split ? sub_split[s] : R;
   const bool shortrow = tid >= R1 * BS;
@@ -1316,10 +1344,12 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
     }
     ys[il * BS + r] = acc;
   }
+  PH(0);
   // the dot product's partner (block order, tid-linear): in flight through the sweeps
   double avp = 0.0;
   if (active && (dot == 1 || dot == 4)) avp = __builtin_nontemporal_load(aux + (size_t)lo * BS + tid);
   __syncthreads();
+  PH(1);
   for (int lev = 1; lev < nlf; lev++) {  // forward: y_i = t_i - sum A'_ik y_k
     if (lf == lev) {
       double a = ys[il * BS + r];
@@ -1331,6 +1361,7 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
     }
     __syncthreads();
   }
+  PH(2);
   for (int lev = 0; lev < nlb; lev++) {  // backward: x_i = y_i - sum A'_ij x_j
     if (lb == lev) {
       double a = ys[il * BS + r];
@@ -1342,6 +1373,7 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
     }
     __syncthreads();
   }
+  PH(3);
   // block-order, tid-linear epilogue: store the result, reduce the dot products
   double out = 0.0;
   const size_t g = (size_t)lo * BS + tid;
@@ -1371,6 +1403,8 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
     else if (dot == 2) { double v2[2] = {v[0], v[1]}; wg_reduce_store<2>(v2, red, partials, nb_max, slots, s); }
     else { double v1[1] = {v[0]}; wg_reduce_store<1>(v1, red, partials, nb_max, slots, s); }
   }
+  PH(4);
+  PH_COUNT();
 }
 
 // ---- K6+K8 fused, one WAVE per brick of <= 64 block rows (block sizes 3, 4; pivot-scaled DILU) ------
@@ -1404,6 +1438,7 @@ __global__ __launch_bounds__(256) void k_pc_wave(
   const int nlf = nl & 0xffff, nlb = nl >> 16;
   const int i = lo + lane;
   const bool active = lane < R;
+  PH_DECL;
   double* ys = lds + (size_t)wave * lds_per_brick;   // [64 * BS] solution in block order
   double* upark = ys + 64 * BS;                      // parked upper blocks, row-major BS x BS each
   double Lf[NL][BB];
@@ -1470,6 +1505,7 @@ __global__ __launch_bounds__(256) void k_pc_wave(
 #pragma unroll
     for (int r = 0; r < BS; r++) ys[lane * BS + r] = acc[r];
   }
+  PH(0);
   __builtin_amdgcn_wave_barrier();
   for (int lev = 1; lev < nlf; lev++) {  // forward: y_i = t_i - sum A'_ik y_k
     if (lf == lev) {
@@ -1491,6 +1527,7 @@ __global__ __launch_bounds__(256) void k_pc_wave(
     }
     __builtin_amdgcn_wave_barrier();
   }
+  PH(2);
   for (int lev = 0; lev < nlb; lev++) {  // backward: x_i = y_i - sum A'_ij x_j, upper blocks from LDS
     if (lb == lev) {
       double a[BS];
@@ -1515,6 +1552,7 @@ __global__ __launch_bounds__(256) void k_pc_wave(
     }
     __builtin_amdgcn_wave_barrier();
   }
+  PH(3);
   // block-order, lane-linear epilogue: the wave's R * BS results leave coalesced; dot products on the way
   double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   const int tot = R * BS;
@@ -1545,6 +1583,8 @@ __global__ __launch_bounds__(256) void k_pc_wave(
       }
     }
   }
+  PH(4);
+  PH_COUNT();
 }
 
 // ---- layout conversion (C ABI exchanges BCSR) -------------------------------------------------
