@@ -122,7 +122,7 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
   }
   std::vector<int> info(N), uoff(N, 0), uoffw(N, 0), levf(N), levb(N), nlev(s.nsub, 0), lfirst(N), ulast(N), tslot(N, 0);
   int max_nu = 0;
-  s.max_rows = 0; s.max_lev = 0; s.max_ublocks = 0; s.max_ublocks_w = 0; s.max_nlu = 0; s.max_nl = 0; s.max_out = 0; s.max_out_pad = 0;
+  s.max_rows = 0; s.max_lev = 0; s.max_ublocks = 0; s.max_ublocks_w = 0; s.max_nlu = 0; s.max_nl = 0;
   bool offdiag_fill = false, fast3 = true;
   int nlf_all = 0, nlb_all = 0;
   for (int sd = 0; sd < s.nsub; sd++) {
@@ -182,8 +182,6 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
     for (int i = lo; i < hi; i++) {
       const int nL = diag[i] - lfirst[i], nU = ulast[i] - diag[i] - 1;
       if (nL > 3 || nU > 3 || lfirst[i] > 3 || diag[i] > 3) fast3 = false;
-      s.max_out = std::max(s.max_out, lfirst[i] + (rowptr[i + 1] - rowptr[i]) - ulast[i]);
-      s.max_out_pad = std::max(s.max_out_pad, W - 1 - nL - nU);   // the padding slots of a short row count: they are read
       s.max_nlu = std::max(s.max_nlu, std::max(nL, nU));
       uoff[i] = ucount;
       ucount += std::min(nU, 3);
@@ -267,53 +265,6 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
     for (int i = 0; i < N; i++) { of[pf[levf[i]]++] = i; ob[pb[levb[i]]++] = i; }
     if (dev_upload(c, &s.ord_f, of) || dev_upload(c, &s.ord_b, ob)) return -1;
   }
-  // Role descriptors for the kernels that fetch a row's blocks by role (k_pc_rows3): per subdomain the distinct
-  // columns its rows couple to outside it (the halo: their vector entries are staged in LDS behind the subdomain's own
-  // segment), per row four ints -- the local indices (10 bits each, 1023: none) of its <= 3 in-subdomain lower
-  // couplings, of its <= 3 upper ones, of its <= 3 outside ones (index = rows + position in the halo list), and the
-  // slots of the outside ones (4 bits each).  Padding slots of short rows are not couplings.
-  s.roles_ok = !s.big && W <= 8 && s.max_nlu <= 3 && s.max_out <= 3;
-  if (s.roles_ok) {
-    std::vector<int> roles((size_t)4 * N, 0), hptr(s.nsub + 1, 0), hcol;
-    s.max_halo = 0;
-    std::vector<int> hl;
-    for (int sd = 0; sd < s.nsub && s.roles_ok; sd++) {
-      const int lo = sub[sd], hi = sub[sd + 1], R = hi - lo;
-      hl.clear();
-      for (int i = lo; i < hi; i++) {
-        const int* row = colidx.data() + rowptr[i];
-        const int cnt = rowptr[i + 1] - rowptr[i];
-        for (int q = 0; q < cnt; q++) if (q < lfirst[i] || q >= ulast[i]) hl.push_back(row[q]);
-      }
-      std::sort(hl.begin(), hl.end());
-      hl.erase(std::unique(hl.begin(), hl.end()), hl.end());
-      const int H = (int)hl.size();
-      if (R + H + 1 > 1023) { s.roles_ok = false; break; }
-      s.max_halo = std::max(s.max_halo, H);
-      for (int i = lo; i < hi; i++) {
-        const int* row = colidx.data() + rowptr[i];
-        const int cnt = rowptr[i + 1] - rowptr[i];
-        int L = 0x3fffffff, U = 0x3fffffff, O = 0x3fffffff, OS = 0;
-        for (int q = lfirst[i], pp = 0; q < diag[i]; q++, pp++) L = (L & ~(1023 << (10 * pp))) | ((row[q] - lo) << (10 * pp));
-        for (int q = diag[i] + 1, pp = 0; q < ulast[i]; q++, pp++) U = (U & ~(1023 << (10 * pp))) | ((row[q] - lo) << (10 * pp));
-        int k = 0;
-        for (int q = 0; q < cnt; q++) {
-          if (q >= lfirst[i] && q < ulast[i]) continue;
-          const int h = (int)(std::lower_bound(hl.begin(), hl.end(), row[q]) - hl.begin());
-          O = (O & ~(1023 << (10 * k))) | ((R + h) << (10 * k));
-          OS |= q << (4 * k);
-          k++;
-        }
-        roles[(size_t)4 * i] = L; roles[(size_t)4 * i + 1] = U; roles[(size_t)4 * i + 2] = O; roles[(size_t)4 * i + 3] = OS | (k << 12);
-      }
-      hcol.insert(hcol.end(), hl.begin(), hl.end());
-      hptr[sd + 1] = (int)hcol.size();
-    }
-    if (s.roles_ok) {
-      if (hcol.empty()) hcol.push_back(0);
-      if (dev_upload(c, &s.row_roles, roles) || dev_upload(c, &s.halo_ptr, hptr) || dev_upload(c, &s.halo_col, hcol)) return -1;
-    }
-  }
   if (dev_upload(c, &s.sub_ptr, sub) || dev_upload(c, &s.sub_nlev, nlev) || dev_upload(c, &s.row_info, info) ||
       dev_upload(c, &s.row_uoff, uoff) || dev_upload(c, &s.row_uoffw, uoffw) || dev_upload(c, &s.row_tslot, tslot) ||
       dev_alloc(c, &s.fval, (size_t)W * np * np * N) || dev_alloc(c, &s.dinv, (size_t)np * np * N))
@@ -341,7 +292,6 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
 #ifdef WAI_PC_NOPARK
     s.park = false;        // k_pc instead of k_pc_park
 #endif
-    // blocks fetched by role: at most three couplings of a row leave its brick (bricks at least two cells thick)
   }
   {
     // one thread per scalar row: needs the pivot-scaled DILU form, <= 4 + 4 couplings and a brick whose
@@ -364,12 +314,6 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
     s.wave_kernel = s.wave_kernel && (WAI_PC_WAVE != 0);
 #endif
   }
-  // 3 x 3 blocks with role descriptors, no MINC-style short rows: the scalar-row kernel that fetches blocks by role
-  // (-DWAI_PC_ROWS3=0 builds without)
-  s.rows3_kernel = s.rows_kernel && s.roles_ok && np == 3 && (size_t)rowptr[N] * 10 >= (size_t)N * W * 9;
-#ifdef WAI_PC_ROWS3
-  s.rows3_kernel = s.rows3_kernel && (WAI_PC_ROWS3 != 0);
-#endif
   if (s.rows_kernel) {
     // bricks whose long rows come first (MINC: fracture cells, then their matrix cells with 2 of 8
     // slots): k_pc_rows maps the long rows of all components to the first waves, so that a wave is
@@ -394,7 +338,7 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
 
 void free_schedule(IluSchedule& s) {
   hipFree(s.sub_ptr); hipFree(s.sub_nlev); hipFree(s.sub_split); hipFree(s.row_info); hipFree(s.fval); hipFree(s.dinv);
-  hipFree(s.row_uoff); hipFree(s.row_uoffw); hipFree(s.row_tslot); hipFree(s.row_roles); hipFree(s.halo_ptr); hipFree(s.halo_col); hipFree(s.sub_order); hipFree(s.sub_int); hipFree(s.sub_bnd); hipFree(s.ord_f); hipFree(s.ord_b);
+  hipFree(s.row_uoff); hipFree(s.row_uoffw); hipFree(s.row_tslot); hipFree(s.sub_order); hipFree(s.sub_int); hipFree(s.sub_bnd); hipFree(s.ord_f); hipFree(s.ord_b);
   s = IluSchedule();
 }
 void free_asm(AsmSystem& a) {

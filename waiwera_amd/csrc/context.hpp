@@ -154,14 +154,6 @@ struct IluSchedule {
   bool diag_only = false;   // ILU(0) touches no off-diagonal block in any subdomain (== DILU)
   bool scaled = true;       // diag_only: rows pre-scaled by the inverted pivots (WAI_ILU_NOSCALE: off)
   bool park = true;         // k_pc_park: upper blocks parked in LDS (WAI_PC_PARK=0: off)
-  int max_out = 0;          // most couplings of one row that leave its subdomain
-  int max_out_pad = 0;      // the same with the padding slots of short rows counted
-  bool roles_ok = false;    // role descriptors exist (<= 3 + 3 in-subdomain and <= 3 outside couplings per row, rows + halo < 1023)
-  int* row_roles = nullptr; // per row 4 ints: local indices of the lower / upper / outside couplings (3 x 10 bits each), outside slots
-  int* halo_ptr = nullptr;  // per subdomain: its distinct outside columns in halo_col
-  int* halo_col = nullptr;
-  int max_halo = 0;
-  bool rows3_kernel = false; // k_pc_rows3: one thread per scalar row, blocks fetched by role (3 x 3 blocks)
   int* row_uoff = nullptr;  // first parked upper block of a row inside its subdomain
   int* row_tslot = nullptr; // per row: slot of A_ki in row k for each of its (<= 4) in-subdomain lower couplings k, 4 bits each (15: none)
   int max_nl = 0;           // most in-subdomain lower couplings of any row

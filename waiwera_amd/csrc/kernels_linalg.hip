@@ -1420,195 +1420,6 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
   PH_COUNT();
 }
 
-// ---- K6+K8 fused, one thread per scalar row, blocks fetched by ROLE (3 x 3 blocks; k_pc_rows' successor) -----------
-// k_pc_rows walks a row's slots one after the other -- block row and neighbour entry in, products, a chain of
-// selects that sorts the block row into its lower / upper position -- and every slot is a round trip to HBM: MEASURED
-// with the phase stamps (-DWAI_PC_PHASES, C4, 80-row bricks): 8.2 of a workgroup's 14.7 us are this loop, 4.6 the
-// two sweeps.  Here the symbolic phase has already said which slot plays which role (IluSchedule::row_roles) and
-// which vector entries a brick needs from outside (halo_col), so that
-//   1. the brick's segment of the input vector and its halo entries go to LDS, coalesced / through one short list,
-//   2. every in-brick block row is requested straight into the registers of its role -- <= 3 lower, the diagonal,
-//      <= 3 upper: the registers the sweeps use anyway -- in ONE round trip, with no column indices and no selects,
-//   3. the <= 3 block rows of the couplings that leave the brick follow in a second one,
-// and every product of the SpMV reads its vector entry from LDS.  A role the row does not have points at a zero
-// entry in LDS and fetches the diagonal block row once more (a line the wave has just brought in).
-__device__ __forceinline__ int role_index(int packed, int p, int none) {
-  const int v = (packed >> (10 * p)) & 1023;
-  return v == 1023 ? none : v;
-}
-template <int BS>
-__global__ __launch_bounds__(1024, (BS == 3 ? 6 : 4)) void k_pc_rows3(
-    int n, int nsub, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev, const int* __restrict__ row_info,
-    const int4* __restrict__ row_roles, const int* __restrict__ halo_ptr, const int* __restrict__ halo_col,
-    const double* __restrict__ sval, const double* __restrict__ in, double* __restrict__ z, const double* __restrict__ aux,
-    double* partials, int nb_max, int dot, const int* __restrict__ sub_list, Fin fin) {
-  constexpr int MLU = 3, NO = 3;
-  extern __shared__ double lds[];  // [(R + H + 1) * BS] segment | halo entries | zeros; the segment becomes the solution; then reduction scratch
-  if (fin_block(fin, partials, nb_max)) return;
-  int s = xcd_remap(blockIdx.x, nsub);
-  if (s >= nsub) return;
-  if (sub_list) s = sub_list[s];
-  const int lo = sub_ptr[s], R = sub_ptr[s + 1] - lo;
-  const int hp = halo_ptr[s], H = halo_ptr[s + 1] - hp;
-  const int nl = sub_nlev[s];
-  const int nlf = nl & 0xffff, nlb = nl >> 16;
-  const int tid = threadIdx.x;
-#ifdef WAI_PC_STAGGER
-  // the first generation of workgroups starts in three cohorts a third of a brick's life apart: a brick that has all its
-  // loads in flight at once is bandwidth-bound while it loads and silent while it sweeps, and workgroups that start
-  // together stay in step -- the memory system then idles through everybody's sweeps
-  if (blockIdx.x < 1536) for (int w = (blockIdx.x >> 8) % 3; w > 0; w--) __builtin_amdgcn_s_sleep(WAI_PC_STAGGER);
-#endif
-  PH_DECL;
-  const bool active = tid < R * BS;
-  const int r = active ? tid / R : 0, il = active ? tid - r * R : 0, i = lo + il;   // component-major
-  double* xs = lds;
-  const int ZI = R + H;
-  if (tid < BS) xs[ZI * BS + tid] = 0.0;
-  // round trip 1: the halo list, the row's descriptors, the segment
-  const int HB = H * BS, T = (int)blockDim.x;
-  const int t0 = tid, t1 = tid + T;
-  const int h0 = t0 < HB ? halo_col[hp + t0 / BS] : 0, h1 = t1 < HB ? halo_col[hp + t1 / BS] : 0;
-  const int info = row_info[i];
-  const int4 ro = row_roles[i];
-  double xlin = 0.0;
-  if (active) xlin = in[(size_t)lo * BS + tid];
-  int lfirst, dslot, ulast, lf, lb;
-  unpack_info(info, lfirst, dslot, ulast, lf, lb);
-  int nL = dslot - lfirst, nU = ulast - dslot - 1, nO = (ro.w >> 12) & 3;
-  if (!active) { nL = 0; nU = 0; nO = 0; lf = -1; lb = -1; }
-  // round trip 2: every in-brick block row into the registers of its role
-  double Lf[MLU][BS], Uf[MLU][BS], Df[BS];
-#pragma unroll
-  for (int p = 0; p < MLU; p++) {
-    const int q = p < nL ? lfirst + p : dslot;
-#pragma unroll
-    for (int k = 0; k < BS; k++) Lf[p][k] = __builtin_nontemporal_load(sval + ell_ix(BS, (size_t)n, q, r, k, (size_t)i));
-  }
-#pragma unroll
-  for (int k = 0; k < BS; k++) Df[k] = __builtin_nontemporal_load(sval + ell_ix(BS, (size_t)n, dslot, r, k, (size_t)i));
-#pragma unroll
-  for (int p = 0; p < MLU; p++) {
-    const int q = p < nU ? dslot + 1 + p : dslot;
-#pragma unroll
-    for (int k = 0; k < BS; k++) Uf[p][k] = __builtin_nontemporal_load(sval + ell_ix(BS, (size_t)n, q, r, k, (size_t)i));
-  }
-  // the halo entries (their list has arrived by now)
-  const double xh0 = t0 < HB ? in[(size_t)h0 * BS + t0 % BS] : 0.0, xh1 = t1 < HB ? in[(size_t)h1 * BS + t1 % BS] : 0.0;
-  if (active) xs[tid] = xlin;
-  if (t0 < HB) xs[R * BS + t0] = xh0;
-  if (t1 < HB) xs[R * BS + t1] = xh1;
-  for (int t = tid + 2 * T; t < HB; t += T) xs[R * BS + t] = in[(size_t)halo_col[hp + t / BS] * BS + t % BS];   // (long halo lists)
-  PH(0);
-  __syncthreads();   // segment and halo entries are in LDS
-  PH(1);
-  // (anchors: the sum is only used behind the next barrier, inside `if (active)`, and LLVM sinks the whole chain of
-  // products down there -- every operand then has to survive until then, 30 of them in scratch memory; an empty asm
-  // that "modifies" the sum pins each stage where it is written.  The scheduling fences keep the compiler from
-  // hoisting all LDS reads and the next round trip's loads above the products.)
-  int Lc[MLU], Uc[MLU];
-  const int own = il * BS;
-  double acc = 0.0;
-#pragma unroll
-  for (int k = 0; k < BS; k++) acc += Df[k] * xs[own + k];
-  asm volatile("" : "+v"(acc));
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int p = 0; p < MLU; p++) {
-    Lc[p] = role_index(ro.x, p, ZI) * BS;
-#pragma unroll
-    for (int k = 0; k < BS; k++) acc += Lf[p][k] * xs[Lc[p] + k];
-    asm volatile("" : "+v"(acc));
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#pragma unroll
-  for (int p = 0; p < MLU; p++) {
-    Uc[p] = role_index(ro.y, p, ZI) * BS;
-#pragma unroll
-    for (int k = 0; k < BS; k++) acc += Uf[p][k] * xs[Uc[p] + k];
-    asm volatile("" : "+v"(acc));
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  {
-    // round trip 3: the block rows of the couplings that leave the brick
-    double Of[NO][BS];
-#pragma unroll
-    for (int k = 0; k < NO; k++) {
-      const int q = k < nO ? (ro.w >> (4 * k)) & 15 : dslot;
-#pragma unroll
-      for (int e = 0; e < BS; e++) Of[k][e] = __builtin_nontemporal_load(sval + ell_ix(BS, (size_t)n, q, r, e, (size_t)i));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int k = 0; k < NO; k++) {
-      const int oc = role_index(ro.z, k, ZI) * BS;
-#pragma unroll
-      for (int e = 0; e < BS; e++) acc += Of[k][e] * xs[oc + e];
-      asm volatile("" : "+v"(acc));
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  // the dot product's partner (block order, tid-linear): in flight through the sweeps
-  double avp = 0.0;
-  if (active && (dot == 1 || dot == 4)) avp = __builtin_nontemporal_load(aux + (size_t)lo * BS + tid);
-  __syncthreads();   // every product has read the segment: it becomes the sweep vector
-  if (active) xs[il * BS + r] = acc;
-  __syncthreads();
-  PH(5);
-  for (int lev = 1; lev < nlf; lev++) {  // forward: y_i = t_i - sum A'_ik y_k
-    if (lf == lev) {
-      double a = xs[il * BS + r];
-#pragma unroll
-      for (int p = 0; p < MLU; p++)
-#pragma unroll
-        for (int k = 0; k < BS; k++) a -= Lf[p][k] * xs[Lc[p] + k];
-      xs[il * BS + r] = a;
-    }
-    __syncthreads();
-  }
-  PH(2);
-  for (int lev = 0; lev < nlb; lev++) {  // backward: x_i = y_i - sum A'_ij x_j
-    if (lb == lev) {
-      double a = xs[il * BS + r];
-#pragma unroll
-      for (int p = 0; p < MLU; p++)
-#pragma unroll
-        for (int k = 0; k < BS; k++) a -= Uf[p][k] * xs[Uc[p] + k];
-      xs[il * BS + r] = a;
-    }
-    __syncthreads();
-  }
-  PH(3);
-  // block-order, tid-linear epilogue: store the result, reduce the dot products
-  double out = 0.0;
-  if (active) {
-    out = xs[tid];
-    __builtin_nontemporal_store(out, z + (size_t)lo * BS + tid);
-  }
-  if (dot != 0) {
-    if (active && (dot == 2 || dot == 4)) xlin = in[(size_t)lo * BS + tid];   // (again: a register through the sweeps costs more)
-    double* red = xs + (size_t)(ZI + 1) * BS;
-    double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    int slots[5] = {S_D1, S_D2, S_DP2, S_RHONEW, S_W2};
-    if (dot == 1) {
-      if (active) v[0] = out * avp;
-    } else if (dot == 2) {
-      if (active) { v[0] = xlin * out; v[1] = out * out; }
-    } else if (dot == 4) {
-      if (active) { v[0] = xlin * out; v[1] = out * out; v[2] = xlin * xlin; v[3] = xlin * avp; v[4] = out * avp; }
-    } else {
-      v[0] = out * out;
-      slots[0] = S_DP2;
-    }
-    __syncthreads();
-    if (dot == 4) wg_reduce_store<5>(v, red, partials, nb_max, slots, s);
-    else if (dot == 2) { double v2[2] = {v[0], v[1]}; wg_reduce_store<2>(v2, red, partials, nb_max, slots, s); }
-    else { double v1[1] = {v[0]}; wg_reduce_store<1>(v1, red, partials, nb_max, slots, s); }
-  }
-  PH(4);
-  PH_COUNT();
-}
-
 // ---- K6+K8 fused, one WAVE per brick of <= 64 block rows (block sizes 3, 4; pivot-scaled DILU) ------
 // k_pc_rows spreads a brick over BS x R threads and pays a workgroup barrier per substitution level, with most
 // of its waves idle at every one of them.  A brick of at most 64 block rows fits ONE wave, one lane per block
@@ -2324,16 +2135,6 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
     }
   }
   // one thread per scalar row: block sizes 3 and 4 (and 2 when asked for: WAI_PC_ROWS=1)
-  if constexpr (BS == 3) {
-    if (s.rows_kernel && s.rows3_kernel && spmv && !c->dbg) {
-      const int TR = ((s.max_rows * BS + 63) / 64) * 64;
-      const size_t lds_r3 = ((size_t)(s.max_rows + s.max_halo + 1) * BS + 5 * 16 + 8) * sizeof(double);
-      hipLaunchKernelGGL((k_pc_rows3<BS>), grid, TR, lds_r3, c->stream, J.n, nrun, s.sub_ptr, s.sub_nlev, s.row_info,
-                         reinterpret_cast<const int4*>(s.row_roles), s.halo_ptr, s.halo_col, s.fval, in, z, aux, c->ks.partials,
-                         c->ks.nb_max, dot_mode, list, fin);
-      return;
-    }
-  }
   if (s.rows_kernel && !c->dbg) {
     const int TR = ((s.max_rows * BS + 63) / 64) * 64;
     const size_t lds_r = ((size_t)s.max_rows * BS + BS + 5 * 16 + 8) * sizeof(double);
