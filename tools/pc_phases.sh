@@ -1,6 +1,10 @@
 #!/bin/bash
 # Phase timing of the fused preconditioner kernels: libraries built with -DWAI_PC_PHASES (waiwera_amd/lib_phases*.so,
 # see kernels_linalg.hip PH()), kernel microbench only.  usage: bash tools/pc_phases.sh  (writes gpurun_out/pc_phases.log)
+# build first, here (the variants travel with the snapshot; they are git-ignored):
+#   cd waiwera_amd && WAI_EXTRA_HIPCC_FLAGS="-DWAI_PC_PHASES" python build.py --force && cp libwaiwera_hip.so lib_phases.so
+#   WAI_EXTRA_HIPCC_FLAGS="-DWAI_PC_PHASES -DWAI_PC_WAVE=0" python build.py --force && cp libwaiwera_hip.so lib_phases_rows.so
+#   python build.py --force
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 cp waiwera_amd/libwaiwera_hip.so /tmp/lib_keep.so
