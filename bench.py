@@ -431,7 +431,9 @@ def main():
     # round 3, cells x fastest inside the bricks, the reference's adaptive controller, one box (profiles/brick_scan_r3_c4.log):
     #   8x4x2 (64 rows: one wave per brick, k_pc_wave) 3.22 / 192 / 64.5 %   8x5x2 (k_pc_rows) 3.05-3.11 / 181 / 55 %
     #   8x5x4 2.89 / 185   8x8x2 2.74 / 178 / 47.5 %   12x6x2 2.56 / 176   16x8x2 2.45 / 181   16x4x2 2.33 / 195   10x10x2 2.05 / 177
-    brick = tuple(a.brick) if a.brick else ((8, 4, 1) if minc else ((8, 4, 2) if eos == "wce" else (16, 16, 2)))
+    # MINC, same protocol (profiles/brick_scan_r3_c5.log): 4x4x2 (32 + 32 rows) 15.84 / 101 / 55.7 %   8x4x1 15.46-15.54 / 99 / 52.5 %
+    #   4x8x1 15.33 / 101   8x2x2 14.27 / 108   8x8x1 12.48 / 94 / 36 %   16x2x1 11.88 / 113   8x4x2 9.77 / 97 / 27 %
+    brick = tuple(a.brick) if a.brick else ((4, 4, 2) if minc else ((8, 4, 2) if eos == "wce" else (16, 16, 2)))
     grid, lm, prim, region = make_case(dims=dims, brick=brick, eos=eos, lens=not a.no_lens, minc=minc,
                                        part=M.partition_shape(world), rank=rank, brick_order=a.brick_order, order=a.cell_order)
     opts = wl.default_opts(ksp_type=a.ksp, pc_type=a.pc, ilu_levels=a.ilu_levels)

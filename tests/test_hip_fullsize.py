@@ -156,7 +156,7 @@ def test_other_block_sizes_at_scale(eos, minc, dims):
 @pytest.mark.parametrize("name,dims,eos,minc,brick", [
     ("c3", (216, 216, 216), "we", False, (16, 16, 2)),       # BASELINE configs[2]: 10 077 696 cells
     ("c4", (172, 172, 170), "wce", False, (8, 4, 2)),        # configs[3]: 5 029 280 cells, 3 x 3 blocks (bench.py's bricks)
-    ("c5", (100, 100, 100), "wce", True, (8, 4, 1)),         # configs[4]: 1 M fracture + 1 M matrix cells
+    ("c5", (100, 100, 100), "wce", True, (4, 4, 2)),         # configs[4]: 1 M fracture + 1 M matrix cells
 ])
 def test_baseline_configs_at_their_stated_sizes(oracle, name, dims, eos, minc, brick):
     """bench.py's set-up (bricks, top Dirichlet boundary, wells, lens) at the sizes BASELINE.json
@@ -279,7 +279,7 @@ def _colmax_rel(a, b):
 @pytest.mark.parametrize("name,dims,eos,minc,brick", [
     ("c3", (216, 216, 216), "we", False, (16, 16, 2)),
     ("c4", (172, 172, 170), "wce", False, (8, 4, 2)),
-    ("c5", (100, 100, 100), "wce", True, (8, 4, 1)),
+    ("c5", (100, 100, 100), "wce", True, (4, 4, 2)),
 ])
 def test_elementwise_oracle_parity_at_baseline_sizes(oracle, name, dims, eos, minc, brick):
     from tests.cases import make_case
