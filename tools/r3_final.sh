@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/r3
 R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -q -s --durations=10 > gpurun_out/r3/pytest_gpu_final.log 2>&1
+if [ -z "$SKIP_TESTS" ]; then python -m pytest tests -m gpu -q -s --durations=10 > gpurun_out/r3/pytest_gpu_final.log 2>&1; fi
 echo "pytest rc $?"; tail -14 gpurun_out/r3/pytest_gpu_final.log | cut -c1-160
 for cfg in c3 c4 c5; do
   bash tools/gpu_profile.sh r3 $cfg --steps 20 --warmup 5 > gpurun_out/r3/gpu_profile_$cfg.log 2>&1
