@@ -459,7 +459,9 @@ __global__ void k_dilu_pivots(int n, int nsub, const int* __restrict__ sub_ptr,
 // [coupling][element][row], so neither the store nor the reload conflicts -- and A_ki is addressed through the
 // transposed slot the symbolic phase recorded (row_tslot), i.e. two dependent global round trips per brick
 // (column, blocks) instead of four per level.  Same products in the same order as k_dilu_pivots: identical pivots.
-template <int BS, int NPL>
+// RAIK (bricks of one wave, round 3): A_ik stays in registers (27 doubles per coupling set) and only A_ki and the inverted pivots
+// live in LDS -- 18 instead of 32 KB per 64-row brick, eight instead of five bricks per CU.  Same products, same order.
+template <int BS, int NPL, bool RAIK>
 __global__ __launch_bounds__(256) void k_dilu_pivots_lds(int n, int nsub, int cap, const int* __restrict__ sub_ptr,
                                   const int* __restrict__ sub_nlev, const int* __restrict__ row_info,
                                   const int* __restrict__ row_tslot, const int* __restrict__ col,
@@ -474,7 +476,8 @@ __global__ __launch_bounds__(256) void k_dilu_pivots_lds(int n, int nsub, int ca
   const bool active = tid < R;
   double* pinv = sm;
   double* laik = sm + (size_t)BB * cap;
-  double* laki = laik + (size_t)NPL * BB * cap;
+  double* laki = RAIK ? laik : laik + (size_t)NPL * BB * cap;
+  double raik[RAIK ? NPL : 1][BB];
   int lfirst = 0, dslot = 0, ulast = 0, lf = -1, lb = 0;
   int koff[NPL];
   double P[BB];
@@ -500,7 +503,8 @@ __global__ __launch_bounds__(256) void k_dilu_pivots_lds(int n, int nsub, int ca
         koff[p] = k - lo;
 #pragma unroll
         for (int e = 0; e < BB; e++) {
-          laik[(size_t)(p * BB + e) * cap + tid] = aval[vix<BS>(n, q, e, i)];
+          if constexpr (RAIK) raik[p][e] = aval[vix<BS>(n, q, e, i)];
+          else laik[(size_t)(p * BB + e) * cap + tid] = aval[vix<BS>(n, q, e, i)];
           laki[(size_t)(p * BB + e) * cap + tid] = r2 == 15 ? 0.0 : aval[vix<BS>(n, r2, e, k)];
         }
       }
@@ -513,7 +517,11 @@ __global__ __launch_bounds__(256) void k_dilu_pivots_lds(int n, int nsub, int ca
         if (koff[p] >= 0) {   // P -= (A_ik inv(P_k)) A_ki
           double aik[BB], pk[BB], t[BB];
 #pragma unroll
-          for (int e = 0; e < BB; e++) { aik[e] = laik[(size_t)(p * BB + e) * cap + tid]; pk[e] = pinv[(size_t)e * cap + koff[p]]; }
+          for (int e = 0; e < BB; e++) {
+            if constexpr (RAIK) aik[e] = raik[p][e];
+            else aik[e] = laik[(size_t)(p * BB + e) * cap + tid];
+            pk[e] = pinv[(size_t)e * cap + koff[p]];
+          }
 #pragma unroll
           for (int r = 0; r < BS; r++)
 #pragma unroll
@@ -2039,12 +2047,16 @@ int launch_ilu_factor_on(wai_ctx* c, const Bcsr& J, IluSchedule& s) {
         // blocks stay on the general kernel (the staged one compiles to 256 VGPRs + scratch there: not measured)
         const int npl = s.max_nl <= 3 ? 3 : 4;
         const size_t lds2 = (size_t)(1 + 2 * npl) * 9 * s.max_rows * sizeof(double);
-        if (s.max_nl <= 4 && lds2 <= 64 * 1024 && T <= 256) {
+        if (npl == 3 && T <= 64) {   // one wave per brick: A_ik in registers
+          const size_t lds3 = (size_t)(1 + npl) * 9 * s.max_rows * sizeof(double);
+          hipLaunchKernelGGL((k_dilu_pivots_lds<3, 3, true>), grid, T, lds3, c->stream, J.n, s.nsub, s.max_rows, s.sub_ptr, s.sub_nlev,
+                             s.row_info, s.row_tslot, J.col, J.val, s.dinv, c->d_flags);
+        } else if (s.max_nl <= 4 && lds2 <= 64 * 1024 && T <= 256) {
           if (npl == 3)
-            hipLaunchKernelGGL((k_dilu_pivots_lds<3, 3>), grid, T, lds2, c->stream, J.n, s.nsub, s.max_rows, s.sub_ptr, s.sub_nlev,
+            hipLaunchKernelGGL((k_dilu_pivots_lds<3, 3, false>), grid, T, lds2, c->stream, J.n, s.nsub, s.max_rows, s.sub_ptr, s.sub_nlev,
                                s.row_info, s.row_tslot, J.col, J.val, s.dinv, c->d_flags);
           else
-            hipLaunchKernelGGL((k_dilu_pivots_lds<3, 4>), grid, T, lds2, c->stream, J.n, s.nsub, s.max_rows, s.sub_ptr, s.sub_nlev,
+            hipLaunchKernelGGL((k_dilu_pivots_lds<3, 4, false>), grid, T, lds2, c->stream, J.n, s.nsub, s.max_rows, s.sub_ptr, s.sub_nlev,
                                s.row_info, s.row_tslot, J.col, J.val, s.dinv, c->d_flags);
         } else
           hipLaunchKernelGGL((k_dilu_pivots<3, false>), grid, T, lds, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.dinv, c->d_flags);
