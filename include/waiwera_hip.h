@@ -281,14 +281,6 @@ int wai_comm_unique_id(char id[128]);                       /* rank 0, then broa
 int wai_comm_init(wai_ctx *ctx, int rank, int nranks, const char id[128]);
 int wai_halo_exchange(wai_ctx *ctx, double *vec, int dof);  /* vec has dof*(n_owned+n_halo) */
 int wai_comm_size(wai_ctx *ctx);   /* ranks the RCCL communicator reports (1 without one) */
-/* collectives enqueued on this rank so far: all-reduces (Krylov inner products, flags, norms) and
- * neighbour exchanges (halos); a BiCGStab iteration costs 2 all-reduces and 2 exchanges */
-int wai_comm_stats(wai_ctx *ctx, long long *allreduces, long long *exchanges);
-/* kernels launched and copies enqueued by the linear-solver helpers so far (SpMV, preconditioner, vector
- * updates, reductions, halo pack / unpack, scalar read-backs): a BiCGStab iteration on one rank is 5 kernels
- * and no copy -- every reduction is finished by the last workgroup of its producer and the residual norm is
- * posted to pinned host memory */
-int wai_launch_stats(wai_ctx *ctx, long long *kernels, long long *copies);
 
 /* ---- ode_type surface (src/ode.F90:39-108 as overridden by src/flow_simulation.F90) ------ */
 int wai_pre_timestep(wai_ctx *ctx);                 /* flow_simulation.F90:2022-2035 */
@@ -381,21 +373,11 @@ int wai_tracer_system(wai_ctx *ctx, int tracer, int method, double dt, double ra
 int wai_tracer_solve(wai_ctx *ctx, int method, double dt, double ratio, const double *alx_last,
                      const double *alx_last2, double *X, double *alx_new, int *its, int *reason);
 
-/* ---- measurement helpers ------------------------------------------------------------------- */
-int wai_timer_start(wai_ctx *ctx);             /* hipEvent on the library's stream */
-int wai_timer_stop(wai_ctx *ctx, float *ms);
-int wai_synchronize(wai_ctx *ctx);
-/* HIP-event timed repetitions of one kernel on the library's stream (needs an assembled
- * Jacobian): which 0 block SpMV, 1 ILU(0) apply, 2 fused SpMV + ILU(0) apply + dot,
- * 3/4 timing probes of 1/2 without the substitution sweeps (generic brick kernel only), 9 / 10 the fused
- * kernel on the interior / the face bricks alone (the two launches of the overlapped halo exchange) */
-int wai_bench_kernel(wai_ctx *ctx, int which, int reps, float *ms_per_launch);
-const char *wai_pc_kernel_name(wai_ctx *ctx);   /* kernel / path of a preconditioned-operator application */
-/* accumulated HIP-event time (ms) and launch counts per kernel class since the last reset;
- * classes: 0 eos, 1 residual, 2 jacobian, 3 spmv, 4 pc_apply, 5 pc_setup, 6 vector, 7 transitions */
-int wai_profile_enable(wai_ctx *ctx, int on);
-int wai_profile_get(wai_ctx *ctx, int kclass, double *ms, long long *launches);
-int wai_profile_reset(wai_ctx *ctx);
+int wai_synchronize(wai_ctx *ctx);   /* wait for everything enqueued on the library's stream */
+const char *wai_pc_kernel_name(wai_ctx *ctx);   /* kernel / path of a preconditioned-operator application (reports) */
+
+/* measurement and test entry points (kernel micro-benchmarks, HIP-event timers, launch / collective counters):
+ * include/waiwera_hip_bench.h -- not part of the drop-in boundary */
 
 #ifdef __cplusplus
 }

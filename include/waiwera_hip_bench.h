@@ -1,0 +1,46 @@
+/* Measurement and test entry points of libwaiwera_hip.so: kernel micro-benchmarks, HIP-event timers, launch and
+ * collective counters.  NOT part of the drop-in boundary (include/waiwera_hip.h): nothing here has a counterpart in
+ * the reference; bench.py, tools/ and tests/ use them. */
+#ifndef WAIWERA_HIP_BENCH_H
+#define WAIWERA_HIP_BENCH_H
+#include "waiwera_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* collectives enqueued on this rank so far: all-reduces (Krylov inner products, flags, norms) and
+ * neighbour exchanges (halos); a BiCGStab iteration costs 2 all-reduces and 2 exchanges */
+int wai_comm_stats(wai_ctx *ctx, long long *allreduces, long long *exchanges);
+/* kernels launched and copies enqueued by the linear-solver helpers so far (SpMV, preconditioner, vector
+ * updates, reductions, halo pack / unpack, scalar read-backs): a BiCGStab iteration on one rank is 3 kernels
+ * and no copy -- every reduction is finished by the last workgroup of its producer and the residual norm is
+ * posted to pinned host memory */
+int wai_launch_stats(wai_ctx *ctx, long long *kernels, long long *copies);
+
+/* bench.py's A/B for the collectives' share of an iteration: on != 0 makes every all-reduce and neighbour exchange
+ * of this context return without calling RCCL (results are then wrong; timing probes only).  Every rank must switch
+ * together. */
+int wai_bench_mute_comm(wai_ctx *ctx, int on);
+/* bytes this rank sends per halo exchange of a dof-per-cell vector, and its number of neighbours */
+int wai_halo_size(wai_ctx *ctx, int dof, long long *bytes_sent, int *n_neighbours);
+
+/* ---- measurement helpers ------------------------------------------------------------------- */
+int wai_timer_start(wai_ctx *ctx);             /* hipEvent on the library's stream */
+int wai_timer_stop(wai_ctx *ctx, float *ms);
+/* HIP-event timed repetitions of one kernel on the library's stream (needs an assembled
+ * Jacobian): which 0 block SpMV, 1 ILU(0) apply, 2 fused SpMV + ILU(0) apply + dot,
+ * 3/4 timing probes of 1/2 without the substitution sweeps (generic brick kernel only), 5 one whole BiCGStab
+ * iteration's launches (and collectives) back to back without the host, 6 its vector updates alone, 7 the second
+ * fused launch of the three-launch iteration (operand R - alpha V, five inner products), 9 / 10 the fused
+ * kernel on the interior / the face bricks alone (the two launches of the overlapped halo exchange) */
+int wai_bench_kernel(wai_ctx *ctx, int which, int reps, float *ms_per_launch);
+/* accumulated HIP-event time (ms) and launch counts per kernel class since the last reset;
+ * classes: 0 eos, 1 residual, 2 jacobian, 3 spmv, 4 pc_apply, 5 pc_setup, 6 vector, 7 transitions */
+int wai_profile_enable(wai_ctx *ctx, int on);
+int wai_profile_get(wai_ctx *ctx, int kclass, double *ms, long long *launches);
+int wai_profile_reset(wai_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

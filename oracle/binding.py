@@ -384,14 +384,16 @@ class OracleSim:
         return r, k.value
 
 
-def jacobian_parity(Jg, Jo, rowptr, colidx, y, lhs, bs, fd_eps=1.0e-8, fd_umin=1.0e-2):
+def jacobian_parity(Jg, Jo, rowptr, colidx, y, lhs, bs, fd_eps=1.0e-8, fd_umin=1.0e-2, bar=False):
     """Two finite-difference Jacobians of the same residual function, entry by entry (BCSR values, row-major blocks).
 
     An entry J[i,r; j,k] = (f_ir(y + h_jk e_jk) - f_ir(y)) / h_jk carries the rounding of f_ir divided by the step:
     two correct evaluations of f that differ in the last bits of its accumulation term L_ir differ in the entry by a
     few eps |L_ir| / |h_jk| -- which for a small scaled primary (a gas partial-pressure fraction of 0.02 has
     h = 2e-10) is 1e-5 of the entry scale.  Returns (worst difference relative to the largest entry of the block
-    row's equation, worst difference in units of eps |L_ir| / |h_jk| among the entries above 2e-5 of that scale)."""
+    row's equation, worst difference in units of eps |L_ir| / |h_jk| among the entries above 2e-5 of that scale);
+    with bar=True a third value: the worst difference over THE bar an entry has to meet,
+    max(2e-5 x the block row's largest entry, 16 eps |L_ir| / |h_jk|) -- parity holds iff it is <= 1."""
     n = rowptr.size - 1
     Jg = np.asarray(Jg).reshape(-1, bs, bs)
     Jo = np.asarray(Jo).reshape(-1, bs, bs)
@@ -401,7 +403,7 @@ def jacobian_parity(Jg, Jo, rowptr, colidx, y, lhs, bs, fd_eps=1.0e-8, fd_umin=1
     h = np.abs(dx * fd_eps)                      # MatFDColoring "ds" increment on the scaled variables
     Lb = np.abs(np.asarray(lhs, dtype=np.float64)[: n * bs].reshape(-1, bs))
     eps = np.finfo(np.float64).eps
-    worst_rel, worst_ulp = 0.0, 0.0
+    worst_rel, worst_ulp, worst_bar = 0.0, 0.0, 0.0
     for r in range(bs):
         rowscale = np.zeros(n)
         np.maximum.at(rowscale, rows, np.abs(Jo[:, r, :]).max(axis=1))
@@ -413,4 +415,7 @@ def jacobian_parity(Jg, Jo, rowptr, colidx, y, lhs, bs, fd_eps=1.0e-8, fd_umin=1
             if big.any():
                 ulp = d[big] / (eps * np.maximum(Lb[rows[big], r], 1e-300) / h[colidx[big], k])
                 worst_ulp = max(worst_ulp, float(ulp.max()))
-    return worst_rel, worst_ulp
+            if bar:
+                allow = np.maximum(2.0e-5 * rowscale[rows], 16.0 * eps * np.maximum(Lb[rows, r], 1e-300) / h[colidx, k])
+                worst_bar = max(worst_bar, float((d / np.maximum(allow, 1e-300)).max()))
+    return (worst_rel, worst_ulp, worst_bar) if bar else (worst_rel, worst_ulp)

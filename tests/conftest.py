@@ -29,5 +29,5 @@ def oracle():
     if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")],
                               stdout=subprocess.DEVNULL)
-    from tests import oracle_lib
+    from oracle import binding as oracle_lib
     return oracle_lib.load(so)

@@ -1,4 +1,5 @@
-"""The C-ABI library loads without a GPU and exports every symbol include/waiwera_hip.h declares."""
+"""The C-ABI library loads without a GPU and exports every symbol include/*.h declares (waiwera_hip.h: the drop-in
+boundary; waiwera_hip_bench.h: measurement and test entry points)."""
 import ctypes
 import os
 import re
@@ -6,10 +7,13 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "waiwera_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(wai_[a-z_0-9]+)\s*\(", text)))
+def declared_symbols(headers=("waiwera_hip.h", "waiwera_hip_bench.h")):
+    syms = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        syms |= set(re.findall(r"\b(wai_[a-z_0-9]+)\s*\(", text))
+    return sorted(syms)
 
 
 def test_library_exports_all_declared_symbols():
@@ -25,6 +29,11 @@ def test_library_exports_all_declared_symbols():
 def test_python_binding_covers_header():
     from waiwera_amd import lib
     assert set(declared_symbols()) == set(lib.EXPORTED)
+
+
+def test_bench_entry_points_are_not_in_the_product_header():
+    product = set(declared_symbols(("waiwera_hip.h",)))
+    assert not [s for s in product if re.match(r"wai_(bench_|profile_|timer_|launch_stats|comm_stats)", s)], product
 
 
 def test_defaults_match_reference_defaults():

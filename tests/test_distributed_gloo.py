@@ -13,8 +13,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from tests import oracle_lib as ol
-from tests.cases import scaled
+from oracle import binding as ol
+from waiwera_amd.cases import scaled
 from waiwera_amd import mesh as M
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from tests import benchmarks as B
-from tests import oracle_lib as ol
+from oracle import binding as ol
 from tests.test_oracle_benchmark import OracleOde
 from waiwera_amd.timestepper import Timestepper
 

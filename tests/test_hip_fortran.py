@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from tests.cases import make_case, scaled
+from waiwera_amd.cases import make_case, scaled
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

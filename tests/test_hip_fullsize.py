@@ -17,9 +17,9 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from tests import oracle_lib as ol
+from oracle import binding as ol
 
-from tests.cases import scaled
+from waiwera_amd.cases import scaled
 from waiwera_amd import mesh as M
 
 pytestmark = pytest.mark.gpu
@@ -110,7 +110,7 @@ def test_other_block_sizes_at_scale(eos, minc, dims):
     """the generic-block-size kernels (3 x 3, 4 x 4, MINC rows) on a quarter-million-cell mesh:
     component mass conservation of the flux sweep, block SpMV against scipy's BSR product on the
     values fetched through the ABI, and a Krylov solve verified with that independent operator"""
-    from tests.cases import make_case
+    from waiwera_amd.cases import make_case
     from waiwera_amd.flow_simulation import FlowSimulation
     g, lm, prim, region = make_case(dims=dims, brick=(8, 8, 8), eos=eos, lens=False, minc=minc, top_bc=False,
                                     sources=(eos != "wsce"))
@@ -164,7 +164,7 @@ def test_baseline_configs_at_their_stated_sizes(oracle, name, dims, eos, minc, b
     sweep (closed sides: what is left is the wells and the open top), the block SpMV against scipy's BSR
     product on the values fetched through the ABI, a Krylov solve verified with that independent
     operator, and a backward-Euler step whose Newton iterations reduce the scaled residual"""
-    from tests.cases import make_case
+    from waiwera_amd.cases import make_case
     from waiwera_amd.flow_simulation import FlowSimulation
     g, lm, prim, region = make_case(dims=dims, brick=brick, eos=eos, lens=True, minc=minc)
     sim = FlowSimulation(lm, eos=eos)
@@ -282,7 +282,7 @@ def _colmax_rel(a, b):
     ("c5", (100, 100, 100), "wce", True, (4, 4, 2)),
 ])
 def test_elementwise_oracle_parity_at_baseline_sizes(oracle, name, dims, eos, minc, brick):
-    from tests.cases import make_case
+    from waiwera_amd.cases import make_case
     from waiwera_amd.flow_simulation import FlowSimulation
     gomp, nthreads = _oracle_threads()
     try:
@@ -370,7 +370,7 @@ def test_whole_time_step_at_c2_matches_the_oracle(oracle):
     """BASELINE configs[1] (100^3 eos we, bench.py's bricks, lens, wells, top boundary): one backward-Euler step
     on both paths with the Krylov solves run to 1e-10 and the Newton iteration to 1e-9 -- same Newton
     iteration count, same region map, solution to 1e-7"""
-    from tests.cases import make_case
+    from waiwera_amd.cases import make_case
     from waiwera_amd.flow_simulation import FlowSimulation
     gomp, nthreads = _oracle_threads()
     try:

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import waiwera_amd.mesh as M
-from tests import oracle_lib as ol
+from oracle import binding as ol
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch.multiprocessing as mp
 
-from tests.cases import scaled
+from waiwera_amd.cases import scaled
 from waiwera_amd import mesh as M
 
 pytestmark = pytest.mark.gpu
@@ -139,6 +139,143 @@ def test_ranks_sharing_one_gpu_match_one_rank(world, dims=DIMS, brick=BRICK, nst
     assert err.max() < 1e-7, err
 
 
+# ---- BASELINE's other shardings: C4 (eos wce, 3 x 3 blocks, 2 x 2 x 1 ranks) and C5 (MINC, 2 x 1 x 1) -------------------
+
+def _cell_keys(lm, dims):
+    """a global name for every owned cell: the fracture cell's natural index, + level x n_global for MINC matrix cells
+    (a matrix cell carries its fracture cell's ijk: it stays on its parent's rank, src/mesh.F90:3123-3156)"""
+    ijk = np.asarray(lm.owned_ijk, dtype=np.int64)
+    key = (ijk[:, 2] * dims[1] + ijk[:, 1]) * dims[0] + ijk[:, 0]
+    lev = lm.extras.get("minc_level")
+    if lev is not None:
+        key = key + np.asarray(lev, dtype=np.int64) * int(np.prod(dims))
+    return key
+
+
+def _brick_lists(lm):
+    """(bricks none of whose cells has a face to a partition-ghost cell, the others)"""
+    fc = np.asarray(lm.face_cells)
+    ghost = (fc >= lm.n_owned) & (fc < lm.n_owned + lm.n_halo)
+    touch = np.concatenate([fc[ghost[:, 1], 0], fc[ghost[:, 0], 1]])
+    touch = touch[touch < lm.n_owned]
+    sub = np.searchsorted(np.asarray(lm.sub_ptr), touch, side="right") - 1
+    nsub = len(lm.sub_ptr) - 1
+    face = np.zeros(nsub, dtype=bool)
+    face[sub] = True
+    return int((~face).sum()), int(face.sum())
+
+
+def _shape_steps(sim, y, nsteps, dt0):
+    sim.set_opts(ksp_rtol=1e-12, ftol_rel=1e-10)
+    dt, t, out = dt0, 0.0, []
+    for _ in range(nsteps):
+        reason, nits, kits = sim.timestep(t, dt, y)
+        out.append((reason, nits, kits))
+        t += dt
+        dt *= 2
+    return out
+
+
+def _shape_worker(rank, world, uid_q, q, spec):
+    os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    os.environ["WAI_HALO_OVERLAP"] = "1" if spec["overlap"] else "0"
+    from waiwera_amd import lib as wl
+    from waiwera_amd.cases import make_case
+    from waiwera_amd.flow_simulation import FlowSimulation
+    if rank == 0:
+        uid = wl.comm_unique_id()
+        for _ in range(world - 1):
+            uid_q.put(uid)
+    else:
+        uid = uid_q.get(timeout=300)
+    part = M.partition_shape(world)
+    g, lm, prim, region = make_case(dims=spec["dims"], brick=spec["brick"], eos=spec["eos"], lens=False, part=part, rank=rank,
+                                    minc=spec["minc"], order=spec["order"])
+    sim = FlowSimulation(lm, eos=spec["eos"], device=0)
+    sim.set_regions(region)
+    sim.comm_init(rank, world, uid)
+    bs = sim.num_primary_variables
+    y = scaled(prim, region, spec["eos"]).ravel().copy()
+    hist = _shape_steps(sim, y, spec["nsteps"], spec["dt0"])
+    a0, e0 = sim.comm_stats()
+    k0 = sim.launch_stats()[0]
+    n = lm.n_owned * bs
+    b, x = np.ones(n), np.zeros(n)
+    kits, kreason, _ = sim.ksp_solve(b, x)
+    a1, e1 = sim.comm_stats()
+    q.put((rank, part, _cell_keys(lm, spec["dims"]), y[:n].copy(), hist, sim.regions()[: lm.n_owned].copy(), sim.pc_kernel_name(),
+           _brick_lists(lm), (kits, kreason, a1 - a0, e1 - e0, sim.launch_stats()[0] - k0)))
+    sim.destroy()
+
+
+C4_SHAPE = dict(dims=(48, 24, 4), brick=(8, 4, 2), eos="wce", minc=False, order="natural", nsteps=2, dt0=2.0e4,
+                kernel="k_pc_wave<3,spmv>", part=(2, 2, 1), world=4)
+C5_SHAPE = dict(dims=(16, 8, 4), brick=(4, 4, 2), eos="wce", minc=True, order="natural", nsteps=2, dt0=2.0e4,
+                kernel="k_pc_wave<3,spmv>", part=(2, 1, 1), world=2)
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("shape,overlap", [("c4", False), ("c4", True), ("c5", False), ("c5", True)])
+def test_baseline_shardings_of_3x3_blocks(shape, overlap):
+    """BASELINE configs[3] and [4] as they are sharded: C4 -- eos wce, 3 x 3 blocks, 2 x 2 x 1 ranks, 8 x 4 x 2 bricks on
+    the one-wave-per-brick kernel with the interior / face brick lists -- and C5 -- eos wce with one MINC level on
+    2 x 1 x 1 ranks, a fracture cell's matrix cell in its brick and on its rank (src/mesh.F90:3123-3156) -- against the
+    one-rank run: same Newton counts, Krylov counts to all-reduce rounding, same regions, same solution; with the halo
+    exchange in order and behind the interior bricks (what bench.py --gpus N runs).  The rank boundaries fall on brick
+    boundaries of the one-rank tiling, so the preconditioner is the same operator."""
+    assert os.path.exists(LOOPBACK), "build first: python __graft_entry__.py"
+    os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    from waiwera_amd.cases import make_case
+    from waiwera_amd.flow_simulation import FlowSimulation
+    spec = dict(C4_SHAPE if shape == "c4" else C5_SHAPE, overlap=overlap)
+    world = spec["world"]
+    ctx = mp.get_context("spawn")
+    q, uid_q = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_shape_worker, args=(r, world, uid_q, q, spec)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=1500) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    eos, dims = spec["eos"], spec["dims"]
+    g, lm, prim, region = make_case(dims=dims, brick=spec["brick"], eos=eos, lens=False, minc=spec["minc"], order=spec["order"])
+    sim = FlowSimulation(lm, eos=eos, device=0)
+    sim.set_regions(region)
+    bs = sim.num_primary_variables
+    assert sim.pc_kernel_name() == spec["kernel"]
+    y = scaled(prim, region, eos).ravel().copy()
+    hist = _shape_steps(sim, y, spec["nsteps"], spec["dt0"])
+    n = lm.n_owned * bs
+    b, x = np.ones(n), np.zeros(n)
+    kits1, kreason1, _ = sim.ksp_solve(b, x)
+    assert kreason1 > 0
+    key1 = _cell_keys(lm, dims)
+    order1 = np.argsort(key1)
+    yser = y[:n].reshape(-1, bs)[order1]
+    rser = sim.regions()[: lm.n_owned][order1]
+    sim.destroy()
+    assert all(r > 0 for r, _, _ in hist)
+    keys, ys, regs = [], [], []
+    for rank, part, key, yy, h, reg, kernel, (n_int, n_bnd), (kits, kreason, n_ar, n_ex, n_launch) in res:
+        assert tuple(part) == spec["part"] and kernel == spec["kernel"]
+        assert n_int > 0 and n_bnd > 0, (rank, n_int, n_bnd)          # both brick lists of the overlapped exchange in play
+        assert kreason > 0 and abs(kits - kits1) <= max(3, kits1 // 10), (kits, kits1)
+        # two all-reduces and two exchanges per BiCGStab iteration (+ set-up and one speculative half iteration)
+        assert n_ar <= 2 * kits + 4 and n_ex <= 2 * kits + 4, (kits, n_ar, n_ex)
+        assert all(r > 0 for r, _, _ in h) and [m for _, m, _ in h] == [m for _, m, _ in hist], (h, hist)
+        for (_, _, k1), (_, _, k2) in zip(h, hist):
+            assert abs(k1 - k2) <= max(3, k2 // 10), (h, hist)
+        keys.append(key); ys.append(yy.reshape(-1, bs)); regs.append(reg)
+    keys = np.concatenate(keys)
+    assert np.array_equal(np.sort(keys), key1[order1])                 # every cell (and matrix cell) on exactly one rank
+    o = np.argsort(keys)
+    ypar, rpar = np.concatenate(ys)[o], np.concatenate(regs)[o]
+    assert np.array_equal(rpar, rser)
+    err = np.abs(ypar - yser).max(axis=0) / np.abs(yser).max(axis=0)
+    assert err.max() < 1e-7, err
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -155,7 +292,9 @@ def test_bench_as_the_driver_launches_it(world, dims, brick, part):
     (WAI_BENCH_LOOPBACK: gloo for the host-side barrier / max, device 0 for every rank).  The
     8-rank case has the default brick shape cut raggedly by 20-cell rank extents (as 108-cell
     extents are at full size) and is deep enough for the two-phase lens."""
-    env = dict(os.environ, WAI_RCCL_LIB=LOOPBACK, WAI_BENCH_LOOPBACK="1", WAI_HALO_OVERLAP="0")
+    # two ranks run the multi-rank default (halo exchange behind the interior bricks); eight processes with two streams
+    # each time-slice the one test GPU 30x slower that way, so the 8-rank launch takes the in-order exchange
+    env = dict(os.environ, WAI_RCCL_LIB=LOOPBACK, WAI_BENCH_LOOPBACK="1", WAI_HALO_OVERLAP="1" if world == 2 else "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", str(world), "--steps", "2", "--warmup", "1", "--lead", "1", "--window", "2", "--dims"] + [str(v) for v in dims] + \
@@ -168,13 +307,24 @@ def test_bench_as_the_driver_launches_it(world, dims, brick, part):
     assert out["n_gpus"] == world and out["steps"] == 2 and out["value"] > 0
     assert out["config"]["partition"] == part
     assert out["config"]["krylov_iterations_per_newton_step"] > 0
+    # the N > 1 line says what the ranks exchanged: communicator size, collectives per Krylov iteration, halo bytes, and
+    # the collectives' exposed time (iteration back to back with RCCL at work and muted)
+    c = out["comm"]
+    assert c["rccl_ranks"] == world
+    assert 2.0 <= c["allreduces_per_krylov_iteration"] < 3.5 and 2.0 <= c["exchanges_per_krylov_iteration"] < 3.5, c
+    assert c["halo_bytes_per_exchange"] > 0 and c["halo_neighbours"] == (1 if world == 2 else 3)
+    assert c["ms_per_krylov_iteration_device_only"] > 0 and c["ms_per_krylov_iteration_collectives_muted"] > 0
+    # the gate is global: the step balance summed over all ranks' cells
+    bal = out["check"]["step_balance_defect_per_equation"]
+    assert len(bal) == 2 and max(bal) < 1e-4 and "ranks" in out["check"]["step_balance_of"], out["check"]
 
 
 @pytest.mark.timeout(1200)
 def test_bench_spawns_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher, as the driver calls it: bench.py starts the two
     ranks itself (here on the loopback, both on cuda:0)"""
-    env = dict(os.environ, WAI_RCCL_LIB=LOOPBACK, WAI_BENCH_LOOPBACK="1", WAI_HALO_OVERLAP="0", MASTER_PORT=str(_free_port()))
+    env = dict(os.environ, WAI_RCCL_LIB=LOOPBACK, WAI_BENCH_LOOPBACK="1", MASTER_PORT=str(_free_port()))   # overlapped halo exchange: the default
+    env.pop("WAI_HALO_OVERLAP", None)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--lead", "1",
@@ -229,7 +379,7 @@ def _asm_worker(rank, world, uid_q, q, dims, brick, eos):
 
 
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize("world,eos", [(2, "w"), (2, "we"), (8, "we")])
+@pytest.mark.parametrize("world,eos", [(2, "w"), (2, "we"), (8, "we"), (2, "wce")])
 def test_asm_overlap_reaches_across_ranks(world, eos):
     """The reference's default preconditioner on more than one rank: PCASM overlap 1 whose overlapped row sets
     contain the neighbour ranks' cells (their matrix rows arrive from their owners at every set-up, the residual's

@@ -10,8 +10,8 @@ solves are run to.
 import numpy as np
 import pytest
 
-from tests import oracle_lib as ol
-from tests.cases import make_case, scaled
+from oracle import binding as ol
+from waiwera_amd.cases import make_case, scaled
 
 pytestmark = pytest.mark.gpu
 

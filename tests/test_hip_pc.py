@@ -5,8 +5,8 @@ oracle's restatement through the C ABI, on preconditioner applications and on wh
 import numpy as np
 import pytest
 
-from tests import oracle_lib as ol
-from tests.cases import make_case, scaled
+from oracle import binding as ol
+from waiwera_amd.cases import make_case, scaled
 
 pytestmark = pytest.mark.gpu
 
@@ -140,6 +140,47 @@ def test_bicgstab_with_merged_reductions(oracle, eos, brick, monkeypatch):
     oreason, xo, oits, hist = osim.ksp_solve(J, f, rtol=1e-12)
     assert reason > 0 and oreason > 0
     assert relmax(x, xo) < 1e-8 and abs(its - oits) <= max(2, oits // 10)
+    sim.destroy(); osim.close()
+
+
+@pytest.mark.parametrize("eos,brick,minc", [("we", (4, 4, 2), False), ("wce", (4, 4, 2), False), ("wce", (4, 4, 1), True),
+                                            ("w", (4, 4, 4), False), ("wsce", (4, 2, 2), False)])
+def test_bicgstab_three_launch_iteration(oracle, eos, brick, minc, monkeypatch):
+    """The default iteration (WAI_BCGS=fused): S = R - alpha V formed inside the second fused launch, the X / R / next-P
+    updates in one pass -- three launches.  Every expression is the one the five-launch merged form evaluates
+    (WAI_BCGS=merged), so the two must agree BIT FOR BIT: same iteration count, same residual norm, same solution; with S
+    stored by k_bcgs_s instead (WAI_BCGS_STORE_S: what preconditioners without a fused kernel run) too; and with the
+    reductions finished by separate k_finalize launches (WAI_FIN_SEPARATE).  Against the oracle's KSPBCGS: within
+    rounding.  eos w runs the generic k_pc (no composed operand: four launches), we k_pc_park, wce k_pc_wave, the MINC
+    bricks k_pc_wave with short rows, wsce k_pc_rows<4>."""
+    lm, sim, osim, J, f = system(oracle, eos, (8, 8, 6), brick, lens=(eos == "we"), **({"minc": True} if minc else {}))
+    n = sim.num_dof
+    sim.set_opts(ksp_rtol=1e-12)
+    out = {}
+    for tag, env in (("fused", {"WAI_BCGS": "fused"}), ("merged", {"WAI_BCGS": "merged"}),
+                     ("stored_s", {"WAI_BCGS": "fused", "WAI_BCGS_STORE_S": "1"}),
+                     ("fin_separate", {"WAI_BCGS": "fused", "WAI_FIN_SEPARATE": "1"}), ("petsc", {"WAI_BCGS": "petsc"})):
+        for k in ("WAI_BCGS", "WAI_BCGS_STORE_S", "WAI_FIN_SEPARATE", "WAI_BCGS_MERGED"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        x = np.zeros(n)
+        k0 = sim.launch_stats()[0]
+        its, reason, rn = sim.ksp_solve(f, x)
+        out[tag] = (its, reason, rn, x, (sim.launch_stats()[0] - k0) / max(its, 1))
+        assert reason > 0, (tag, its, reason, rn)
+    oreason, xo, oits, hist = osim.ksp_solve(J, f, rtol=1e-12)
+    assert oreason > 0
+    its, _, rn, x, per = out["fused"]
+    for tag in ("merged", "stored_s", "fin_separate"):
+        assert out[tag][0] == its and out[tag][2] == rn and np.array_equal(out[tag][3], x), (tag, out[tag][:3], its, rn)
+    # launches per iteration (the speculative half of an iteration that is then not needed and the set-up add a few)
+    kernel = sim.pc_kernel_name()
+    composed = not kernel.startswith("k_pc<")
+    assert per <= (3 if composed else 4) + 8.0 / its, (kernel, per)
+    assert out["merged"][4] >= 5 and out["fin_separate"][4] >= 5
+    for tag in ("fused", "petsc"):
+        assert relmax(out[tag][3], xo) < 1e-8 and abs(out[tag][0] - oits) <= max(2, oits // 10), (tag, out[tag][0], oits)
     sim.destroy(); osim.close()
 
 

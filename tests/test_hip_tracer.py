@@ -6,8 +6,8 @@ import math
 import numpy as np
 import pytest
 
-from tests import oracle_lib as ol
-from tests.cases import make_case, scaled
+from oracle import binding as ol
+from waiwera_amd.cases import make_case, scaled
 
 pytestmark = pytest.mark.gpu
 KIND = {"w": 0, "we": 1, "wce": 2}

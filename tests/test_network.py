@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-from tests import oracle_lib as ol
+from oracle import binding as ol
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 

@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 from tests import benchmarks as B
-from tests import oracle_lib as ol
+from oracle import binding as ol
 from waiwera_amd.timestepper import Timestepper
 
 

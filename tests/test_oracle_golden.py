@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from tests import oracle_lib as ol
+from oracle import binding as ol
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 G = json.load(open(os.path.join(HERE, "golden", "reference_unit_values.json")))

@@ -30,7 +30,7 @@ def test_gas_in_brine_henry_constants_and_energy_of_solution(oracle):
     """henrys_constant_salt / energy_solution_salt of air and CO2 (eos wsae / wsce) against the
     values of test/unit/src/ncg_{air,co2}_thermodynamics_test.F90"""
     import numpy as np
-    from tests import oracle_lib as ol
+    from oracle import binding as ol
 
     def henry(kind, t, xs):
         e = ol.Eos()

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from tests import oracle_lib as ol
+from oracle import binding as ol
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 FX = json.load(open(os.path.join(HERE, "golden", "reference_unit_values_salt.json")))

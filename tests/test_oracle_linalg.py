@@ -8,8 +8,8 @@ import pytest
 import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
-from tests import oracle_lib as ol
-from tests.cases import make_case, scaled
+from oracle import binding as ol
+from waiwera_amd.cases import make_case, scaled
 
 
 def setup(oracle, dims=(6, 5, 4), brick=(3, 3, 2), eos="we", lens=False, dt=2.0e4):

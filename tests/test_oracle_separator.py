@@ -7,7 +7,7 @@ import ctypes as C
 import pytest
 
 from waiwera_amd.lib import source_controls
-from tests.oracle_lib import Eos, dp
+from oracle.binding import Eos, dp
 import numpy as np
 
 
@@ -64,8 +64,8 @@ def test_deliverability_threshold_known_answers(oracle):
     noted at 6 bar: 2.25 / (mobility (6 - 2) bar)), and -0.02917 once the source's own rate is the smaller production.
     The reference's unit test holds the mobility fixed; here it is the water's at the cell's pressure (1e-4 apart
     between 3 and 6 bar), so its figures are met to 2e-3 and the formula exactly."""
-    from tests import oracle_lib as ol
-    from tests.cases import make_case
+    from oracle import binding as ol
+    from waiwera_amd.cases import make_case
     g, lm, prim, region = make_case(dims=(4, 4, 2), brick=(4, 4, 2), eos="w", top_bc=False)
     sim = ol.OracleSim(oracle, lm, 0)
     sim.set_regions(region)

@@ -8,8 +8,8 @@ import math
 
 import numpy as np
 
-from tests import oracle_lib as ol
-from tests.cases import make_case, scaled
+from oracle import binding as ol
+from waiwera_amd.cases import make_case, scaled
 
 DAY = 86400.0
 

@@ -12,7 +12,7 @@ code = r'''
 import sys, time, os, ctypes as C
 import numpy as np
 sys.path.insert(0, ".")
-from tests import oracle_lib as ol
+from oracle import binding as ol
 L = ol.load("oracle/liboracle.so")
 n, bs, w = 4000000, 2, 7
 rp = (np.arange(n + 1, dtype=np.int64) * w).astype(np.int32)

@@ -3,8 +3,8 @@ import os, subprocess, sys, json
 code = r'''
 import sys, time, os
 sys.path.insert(0, ".")
-from tests import oracle_lib as ol
-from tests.cases import make_case, scaled
+from oracle import binding as ol
+from waiwera_amd.cases import make_case, scaled
 L = ol.load("oracle/liboracle.so")
 g, lm, prim, region = make_case(dims=(64, 64, 64), brick=(8, 8, 8), eos="we", lens=True)
 sim = ol.OracleSim(L, lm, 1); sim.set_regions(region)

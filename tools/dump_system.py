@@ -5,8 +5,8 @@ import argparse, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tests import oracle_lib as ol
-from tests.cases import scaled
+from oracle import binding as ol
+from waiwera_amd.cases import scaled
 from waiwera_amd import mesh as M
 
 ap = argparse.ArgumentParser()

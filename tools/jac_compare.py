@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from waiwera_amd import lib as wl
 from waiwera_amd.flow_simulation import FlowSimulation
-from tests.cases import make_case, scaled
+from waiwera_amd.cases import make_case, scaled
 
 eos = sys.argv[1] if len(sys.argv) > 1 else "we"
 grid, lm, prim, region = make_case(dims=(48, 48, 48), brick=(16, 16, 2) if eos == "we" else (8, 5, 2), eos=eos, lens=True, minc=False)

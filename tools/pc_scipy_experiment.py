@@ -8,7 +8,7 @@ import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tests import oracle_lib as ol
+from oracle import binding as ol
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--sys", default="/tmp/exp/system.npz")

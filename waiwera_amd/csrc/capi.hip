@@ -12,6 +12,7 @@
 #include "comm.hpp"
 #include <functional>
 #include "context.hpp"
+#include "../../include/waiwera_hip_bench.h"
 
 using namespace wai;
 
@@ -1188,30 +1189,38 @@ int pc_solve(wai_ctx* c, const double* r, double* z, int dot_mode, const double*
   return fin_phase >= -1 ? pc_finalize(c, dot_mode, fin_phase) : 0;
 }
 
-// z = B^-1 A x  (x has halo room); optional fused dot products of the result, summed as pc_solve sums them
-int pc_amul(wai_ctx* c, double* x, double* z, int dot_mode = 0, const double* aux = nullptr, int fin_phase = -2) {
+// z = B^-1 A x  (x has halo room); optional fused dot products of the result, summed as pc_solve sums them.
+// x2 (optional; fused kernels only, pc_axpy_ok): the operand is x - alpha x2 with alpha the device scalar S_ALPHA, formed
+// inside the kernel (BiCGStab's S = R - alpha V); both vectors have halo room, the operand's ghost values are packed as
+// one vector on the sending side and arrive in x's ghost entries, x2's stay zero.
+int pc_amul(wai_ctx* c, double* x, double* z, int dot_mode = 0, const double* aux = nullptr, int fin_phase = -2,
+            const double* x2 = nullptr, bool post = false) {
   const IluSchedule& s = c->ilu;
   if (!pc_fused(c) || c->net.cp_valid) {   // unfused: t = A x (+ the network's blocks), then the preconditioner
+    if (x2) { c->err = "pc_amul: composed operand on the unfused path"; return -1; }
     if (halo_exchange(c, x, c->np)) return -1;
     { Prof p(c, KC_SPMV); if (apply_operator(c, x, c->ks.tmp)) return -1; }
     Prof p(c, KC_PC_APPLY);
-    return pc_solve(c, c->ks.tmp, z, dot_mode, x, aux, fin_phase);
+    if (int e = pc_solve(c, c->ks.tmp, z, dot_mode, x, aux, fin_phase)) return e;
+    if (post) bcgs_scalars(c, -1, true);   // the scalars k_finalize derived, posted to the host
+    return 0;
   }
   Fin fin;
   const Fin* fp = nullptr;
   if (fin_phase >= -1 && dot_mode) {
     int slot0, nslots;
     mode_slots(dot_mode, slot0, nslots);
-    fin = make_fin(c, slot0, nslots, fin_phase);
+    fin = make_fin(c, slot0, nslots, fin_phase, post);
     fp = &fin;
   }
-  if (c->comm && c->mesh.n_halo && c->comm_stream && s.n_int > 0 && s.n_bnd > 0 && !c->prof_on) {
+  const bool halo = c->comm && c->mesh.n_halo;
+  if (halo && c->np > c->max_dof_buf) { c->err = "halo dof too large"; return -1; }
+  if (halo && c->comm_stream && s.n_int > 0 && s.n_bnd > 0 && !c->prof_on) {
     // The partition-ghost values are needed only by the bricks on the rank's faces: pack on the
     // compute stream, send / receive / unpack on the communication stream while the interior bricks
     // run, then the face bricks.  (xGMI transfers and RCCL's launch latency hide behind ~90 % of
     // the kernel at 108^3 cells per rank.)
-    if (c->np > c->max_dof_buf) { c->err = "halo dof too large"; return -1; }
-    pack_halo(c, x, c->np);
+    if (x2) pack_halo_axpy(c, x, x2, c->np); else pack_halo(c, x, c->np);
     HIPCHK(c, hipEventRecord(c->ev_pack, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
     if (comm_exchange(c->comm, c->n_nbr, c->nbr_rank.data(), c->send_ptr.data(), c->recv_ptr.data(), c->np,
@@ -1219,51 +1228,144 @@ int pc_amul(wai_ctx* c, double* x, double* z, int dot_mode = 0, const double* au
       return -1;
     if (unpack_halo(c, x, c->np, c->comm_stream)) return -1;
     HIPCHK(c, hipEventRecord(c->ev_halo, c->comm_stream));
-    if (launch_pc(c, true, x, z, dot_mode, aux, s.sub_int, s.n_int)) return -1;   // its partials wait for ...
+    if (launch_pc(c, true, x, z, dot_mode, aux, s.sub_int, s.n_int, nullptr, x2)) return -1;   // its partials wait for ...
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_halo, 0));
-    return launch_pc(c, true, x, z, dot_mode, aux, s.sub_bnd, s.n_bnd, fp);        // ... the face bricks' last workgroup
+    return launch_pc(c, true, x, z, dot_mode, aux, s.sub_bnd, s.n_bnd, fp, x2);        // ... the face bricks' last workgroup
   }
-  if (halo_exchange(c, x, c->np)) return -1;
+  if (halo) {
+    if (x2) {
+      pack_halo_axpy(c, x, x2, c->np);
+      if (comm_exchange(c->comm, c->n_nbr, c->nbr_rank.data(), c->send_ptr.data(), c->recv_ptr.data(), c->np, c->d_sendbuf,
+                        c->d_recvbuf, c->stream, c->err))
+        return -1;
+      if (unpack_halo(c, x, c->np)) return -1;
+    } else if (halo_exchange(c, x, c->np)) return -1;
+  }
   Prof p(c, KC_PC_APPLY);
-  return launch_pc(c, true, x, z, dot_mode, aux, nullptr, 0, fp);
+  return launch_pc(c, true, x, z, dot_mode, aux, nullptr, 0, fp, x2);
 }
 
 // wait for the scalars a kernel posted to the host mirror with sequence number `seq` (Fin / k_bcgs_scalars):
 // no copy, no event -- the host spins on the pinned word the device writes last
 int wait_post(wai_ctx* c, int seq) {
   Krylov& k = c->ks;
-  volatile double* post = k.h_scal + POST_OFF;   // {(R,R), 4 * sequence number + breakdown code}: one 16-byte device store
-  const double lo = 4.0 * (double)seq, hi = lo + 4.0;
-  double tag = post[1];
-  for (unsigned long long spin = 1; !(tag >= lo && tag < hi); spin++, tag = post[1]) {
+  // {(R,R), 8 * sequence number + code, check}: the pair is taken only when the check word verifies it (post_scalars)
+  volatile unsigned long long* post = reinterpret_cast<volatile unsigned long long*>(k.h_scal + POST_OFF);
+  const double lo = 8.0 * (double)seq, hi = lo + 8.0;
+  auto take = [&](double& val, double& tag) -> bool {
+    const unsigned long long t = post[1];
+    std::memcpy(&tag, &t, 8);
+    if (!(tag >= lo && tag < hi)) return false;
+    const unsigned long long v = post[0], chk = post[2];
+    if ((v ^ t ^ POST_KEY) != chk) return false;    // torn or not all there yet: look again
+    std::memcpy(&val, &v, 8);
+    return true;
+  };
+  double val = 0.0, tag = 0.0;
+  for (unsigned long long spin = 1; !take(val, tag); spin++) {
     if ((spin & 0x3fff) == 0) {   // a stream that ran dry without posting, or a device error: do not spin forever
       const hipError_t e = hipStreamQuery(c->stream);
-      tag = post[1];
-      if (e != hipErrorNotReady && !(tag >= lo && tag < hi)) {
+      if (e != hipErrorNotReady && !take(val, tag)) {
         c->err = e == hipSuccess ? "scalars were not posted by the device" : std::string("stream: ") + hipGetErrorString(e);
         return -1;
       }
+      if (e != hipErrorNotReady) break;
     }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  k.h_scal[S_DP2] = post[0];
+  k.h_scal[S_DP2] = val;
   k.h_scal[S_BREAK] = tag - lo;
   return 0;
 }
 
+// How ksp_bcgs arranges an iteration (WAI_BCGS=petsc | merged | fused; WAI_BCGS_MERGED=1 is "merged"):
+//   0 petsc   the reductions where KSPSolve_BCGS has them: five launches (one rank only; several ranks run "merged")
+//   1 merged  the second half's five inner products in one reduction, (R,R) and (R,RP) derived: five launches (+ two
+//             one-thread scalar kernels behind the all-reduces on several ranks) -- round 3's multi-rank form
+//   2 fused   merged reductions, S = R - alpha V formed inside the second fused launch and the X / R / next-P updates in
+//             one pass: THREE launches and 9 vector passes beside the two matrix sweeps (default)
+int bcgs_mode(const wai_ctx* c) {
+  const bool multi = c->comm && c->comm->nranks > 1;
+  int mode = 2;
+  if (const char* e = getenv("WAI_BCGS")) {
+    if (!strcmp(e, "petsc")) mode = 0;
+    else if (!strcmp(e, "merged")) mode = 1;
+    else if (!strcmp(e, "fused")) mode = 2;
+  } else if (getenv("WAI_BCGS_MERGED")) mode = 1;
+  if (multi && mode == 0) mode = 1;
+  return mode;
+}
+// can the second fused launch form S itself?  (the fused brick kernels, no network blocks beside the matrix)
+bool pc_axpy_ok(const wai_ctx* c) { return pc_fused(c) && !c->net.cp_valid && pc_axpy_capable(c) && !getenv("WAI_BCGS_STORE_S"); }
+
+struct BcgsPlan { int mode; bool fused3, merged, axpy, multi; };
+BcgsPlan bcgs_plan(const wai_ctx* c) {
+  BcgsPlan p;
+  p.mode = bcgs_mode(c);
+  p.fused3 = p.mode == 2; p.merged = p.mode >= 1;
+  p.axpy = p.fused3 && pc_axpy_ok(c);
+  p.multi = c->comm && c->comm->nranks > 1;
+  return p;
+}
+// First half of an iteration: (P update,) V = B^-1 A P with (V,RP), alpha, (S).  It touches P, V, S and the device
+// scalars only -- not X, R -- so ksp_bcgs enqueues the NEXT iteration's first half *before* the host waits for this
+// iteration's residual norm: the device never idles through the read-back, and if the norm says "converged" the
+// speculative half is simply discarded.
+int bcgs_first_half(wai_ctx* c, const BcgsPlan& pl) {
+  Krylov& k = c->ks;
+  if (!pl.fused3) { Prof p(c, KC_VECTOR); bcgs_update_p(c); }
+  if (int e = pc_amul(c, k.P, k.V, 1, k.RP, pl.multi ? -1 : 2)) return e;
+  Prof p(c, KC_VECTOR);
+  if (pl.multi) { if (int e = allreduce_scal(c, S_D1, 1)) return e; bcgs_scalars(c, 2); }
+  if (!pl.axpy) bcgs_update_s(c);
+  return 0;
+}
+// Second half: T = B^-1 A S with its inner products, omega (and with merged reductions (R,R), rho, beta), the scalars
+// posted to the host (sequence number left in ks.seq), X / R (/ next P) updated.
+// Merged reductions (more than one rank always): the five inner products travel in ONE all-reduce -- (S,T), (T,T) for
+// omega and (S,S), (S,RP), (T,RP), from which (R,R) and (R,RP) of R = S - omega T follow -- so an iteration costs two
+// all-reduces ((V,RP); these five) instead of three, and omega, rho and beta are known before X and R are touched: the
+// host sees the norm one launch earlier, and (fused) the updates of X, R and the next P are one pass.
+int bcgs_second_half(wai_ctx* c, const BcgsPlan& pl) {
+  Krylov& k = c->ks;
+  if (pl.fused3) {
+    if (int e = pc_amul(c, pl.axpy ? k.R : k.S, k.T, 4, k.RP, pl.multi ? -1 : 6, pl.axpy ? k.V : nullptr, !pl.multi)) return e;
+    Prof p(c, KC_VECTOR);
+    if (pl.multi) { if (int e = allreduce_scal(c, S_D1, 5)) return e; bcgs_scalars(c, 6, true); }
+    bcgs_update_xrp(c);
+    return 0;
+  }
+  if (int e = pc_amul(c, k.S, k.T, pl.merged ? 4 : 2, pl.merged ? k.RP : nullptr, pl.merged ? -1 : 3)) return e;
+  Prof p(c, KC_VECTOR);
+  if (pl.merged) {
+    if (pl.multi) { if (int e = allreduce_scal(c, S_D1, 5)) return e; }
+    bcgs_scalars(c, 6, true);   // omega, (R,R), (R,RP), rotation; posted: the host sees the norm before X, R are updated
+    bcgs_update_xr(c, false);
+  } else {
+    bcgs_update_xr(c, true, 4, true);
+  }
+  return 0;
+}
+
 // KSPBCGS [PETSc], left preconditioning, preconditioned residual norm, zero initial guess.
-// Launches per iteration: P update, fused A*P + ILU solve + (V,RP), alpha, S update, fused
-// A*S + ILU solve + (S,T),(T,T), omega, fused X/R update + (R,R),(R,RP), rho/beta.
+// One rank: every reduction is finished by the last workgroup of the kernel that produces it (Fin), and the one that
+// ends an iteration's reductions posts the scalars to the pinned host mirror: no k_finalize launches, no copy, no event.
+// petsc / merged -- five launches: P update, fused A*P + ILU solve + (V,RP) + alpha, S update, fused A*S + ILU solve +
+// its inner products (+ omega), X/R update (+ (R,R),(R,RP) + rho/beta).
+// fused -- three: fused A*P + ILU solve + (V,RP) + alpha; fused A*(R - alpha V) + ILU solve + (S,T),(T,T),(S,S),(S,RP),
+// (T,RP) + omega, (R,R), rho, beta, posted; X / R / P update.  (A preconditioner that cannot take the composed operand
+// -- unfused paths, network blocks -- gets S from k_bcgs_s: four launches.)
 int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
   Krylov& k = c->ks;
   const int n = k.n;
   const double rtol = c->opts.ksp_rtol, atol = c->opts.ksp_atol;
   const int maxits = c->opts.ksp_max_its;
+  const BcgsPlan pl = bcgs_plan(c);
+  const bool multi = pl.multi;
   vec_zero(c, x, n);
   vec_zero(c, k.P, k.nl);
-  vec_zero(c, k.V, n);
+  vec_zero(c, k.V, pl.fused3 ? k.nl : n);   // fused: V's ghost entries stay zero (the composed operand's ghosts arrive in R's)
   partials_clear(c, S_D1, 5);   // S_D1 .. S_W2: whatever an aborted solve or a probe left behind
-  const bool multi = c->comm && c->comm->nranks > 1;
   {
     Prof p(c, KC_PC_APPLY);
     if (pc_solve(c, b, k.R, 3, nullptr, nullptr, multi ? -1 : 0)) return -1;  // R = B^-1 b, (R,R), first rho / beta
@@ -1272,6 +1374,7 @@ int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, doub
     Prof p(c, KC_VECTOR);
     if (multi) { if (allreduce_scal(c, S_DP2, 1)) return -1; bcgs_scalars(c, 0); }
     vec_copy(c, k.RP, k.R, n);
+    if (pl.fused3) vec_copy(c, k.P, k.R, n);   // the first P = R + beta (0 - omega 0): the later ones come out of k_bcgs_xrp
   }
   if (read_scal(c, S_DP2, 1)) return -1;
   double dp = std::sqrt(k.h_scal[S_DP2]);
@@ -1283,57 +1386,27 @@ int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, doub
   double* Xsave = k.X;
   k.X = x;  // X aliases the caller's x during the iteration
   int rc = 0;
-  // One rank: every reduction is finished by the last workgroup of the kernel that produces it (Fin), so
-  // an iteration is five launches -- P update, fused A*P + ILU solve + (V,RP) + alpha, S update, fused
-  // A*S + ILU solve + (S,T),(T,T) + omega, X/R update + (R,R),(R,RP) + rho/beta -- and the last of them
-  // posts the scalars to the pinned host mirror: no k_finalize launches, no copy, no event.
-  // first half of an iteration: P update, V = B^-1 A P with (V, RP), alpha, S.  It touches P, V, S
-  // and the device scalars only -- not X, R -- so the next iteration's first half is enqueued
-  // *before* the host waits for this iteration's residual norm: the device never idles through the
-  // read-back, and if the norm says "converged" the speculative half is simply discarded.
-  auto first_half = [&]() -> int {
-    { Prof p(c, KC_VECTOR); bcgs_update_p(c); }
-    if (int e = pc_amul(c, k.P, k.V, 1, k.RP, multi ? -1 : 2)) return e;
-    Prof p(c, KC_VECTOR);
-    if (multi) { if (int e = allreduce_scal(c, S_D1, 1)) return e; bcgs_scalars(c, 2); }
-    bcgs_update_s(c);
-    return 0;
-  };
 #ifdef WAI_BCGS_NO_SPECULATION
   const bool speculate = false;
 #else
   const bool speculate = true;
 #endif
-  // More than one rank: the second half's five inner products travel in ONE all-reduce -- (S,T), (T,T)
-  // for omega and (S,S), (S,RP), (T,RP), from which (R,R) and (R,RP) of R = S - omega T follow -- so an
-  // iteration costs two all-reduces ((V,RP); these five) instead of three.  On one rank the
-  // reductions stay where KSPSolve_BCGS has them (WAI_BCGS_MERGED=1 forces the merged form: tests).
-  const bool merged = multi || getenv("WAI_BCGS_MERGED") != nullptr;
   bool have_first_half = false;
   for (int i = 0; i < maxits && !*reason && !rc; i++) {
-    if (!have_first_half && (rc = first_half())) break;
+    if (!have_first_half && (rc = bcgs_first_half(c, pl))) break;
     have_first_half = false;
-    if ((rc = pc_amul(c, k.S, k.T, merged ? 4 : 2, merged ? k.RP : nullptr, merged ? -1 : 3))) break;
-    {
-      Prof p(c, KC_VECTOR);
-      if (merged) {
-        if (multi && (rc = allreduce_scal(c, S_D1, 5))) break;
-        bcgs_scalars(c, 6, true);   // omega, (R,R), (R,RP), rotation; posted: the host sees the norm before X, R are updated
-        bcgs_update_xr(c, false);
-      } else {
-        bcgs_update_xr(c, true, 4, true);
-      }
-    }
+    if ((rc = bcgs_second_half(c, pl))) break;
     const int seq = k.seq;
     if (speculate && i + 1 < maxits) {
-      if ((rc = first_half())) break;
+      if ((rc = bcgs_first_half(c, pl))) break;
       have_first_half = true;
     }
     if ((rc = wait_post(c, seq))) break;
     dp = std::sqrt(k.h_scal[S_DP2]);
     *its = i + 1;
     const double brk = k.h_scal[S_BREAK];
-    if (brk == 1.0) *reason = -5;                             // (R,RP) or (V,RP) vanished
+    if (brk == 4.0) { *reason = -9; c->err = "a reduction's partial sum never arrived (finaliser wait ran out)"; }
+    else if (brk == 1.0) *reason = -5;                        // (R,RP) or (V,RP) vanished
     else if (brk == 2.0) *reason = (dp == 0.0) ? 3 : -5;      // (T,T) = 0: solved exactly, or breakdown
     else if (std::isnan(dp)) *reason = -9;
     else if (dp <= ttol) *reason = (dp <= atol) ? 3 : 2;
@@ -1350,6 +1423,7 @@ int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, doub
 // KSPGMRES [PETSc]: restarted, left preconditioning, classical Gram-Schmidt without refinement
 int ksp_gmres(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
   Krylov& k = c->ks;
+  partials_clear(c, 0, NSLOTS);   // every reduction slot empty before the first producer (fin_block invariant, kernels_linalg.hip)
   const int n = k.n, m = std::min(std::max(c->opts.gmres_restart, 1), k.basis_m);
   const size_t ld = (size_t)k.nl;
   const double rtol = c->opts.ksp_rtol, atol = c->opts.ksp_atol;
@@ -1449,6 +1523,7 @@ int ksp_gmres(wai_ctx* c, const double* b, double* x, int* its, int* reason, dou
 // vector or an error approximation.
 int ksp_lgmres(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
   Krylov& k = c->ks;
+  partials_clear(c, 0, NSLOTS);   // every reduction slot empty before the first producer (fin_block invariant, kernels_linalg.hip)
   constexpr int AUG = 2;
   // restart = Krylov directions + AUG error approximations: at least one direction (wai_set_opts / wai_ctx_create
   // size the basis for restart >= AUG + 1 and refuse a restart beyond the basis cap)
@@ -1584,6 +1659,7 @@ int host_dots(wai_ctx* c, const double* a1, const double* b1, const double* a2, 
 int ksp_bcgsl(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
   constexpr int L = 2;
   Krylov& k = c->ks;
+  partials_clear(c, 0, NSLOTS);   // every reduction slot empty before the first producer (fin_block invariant, kernels_linalg.hip)
   const int n = k.n;
   const size_t nl = (size_t)k.nl;
   if (!k.bl) {
@@ -3179,12 +3255,18 @@ int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
       case 1: case 3: pc_solve(c, k.P, k.V, 0, nullptr, nullptr); break;
       case 9: if (c->ilu.n_int > 0) launch_pc(c, true, k.P, k.V, 1, k.RP, c->ilu.sub_int, c->ilu.n_int); break;   // interior bricks only
       case 10: if (c->ilu.n_bnd > 0) launch_pc(c, true, k.P, k.V, 1, k.RP, c->ilu.sub_bnd, c->ilu.n_bnd); break;  // face bricks only
-      case 5:   // the launches of one BiCGStab iteration back to back, no host in the loop: the iteration's floor
-        bcgs_update_p(c); pc_amul(c, k.P, k.V, 1, k.RP, 2); bcgs_update_s(c); pc_amul(c, k.S, k.T, 2, nullptr, 3);
-        bcgs_update_xr(c, true, 4, false);
+      case 5: {  // the launches (and, on several ranks, collectives) of one BiCGStab iteration back to back, no host in
+                 // the loop: the iteration's floor
+        const BcgsPlan pl = bcgs_plan(c);
+        bcgs_first_half(c, pl); bcgs_second_half(c, pl);
         break;
-      case 6:   // its three vector updates alone
-        bcgs_update_p(c); bcgs_update_s(c); bcgs_update_xr(c, true, 4, false);
+      }
+      case 6:   // its vector updates alone
+        if (bcgs_mode(c) == 2) { if (!pc_axpy_ok(c)) bcgs_update_s(c); bcgs_update_xrp(c); }
+        else { bcgs_update_p(c); bcgs_update_s(c); bcgs_update_xr(c, true, 4, false); }
+        break;
+      case 7:   // the second fused launch of the "fused" iteration: z = B^-1 A (R - alpha V) with the five inner products
+        pc_amul(c, k.R, k.T, 4, k.RP, -1, pc_axpy_ok(c) ? k.V : nullptr, false);
         break;
       default: pc_amul(c, k.P, k.V, 1, k.RP, 2); break;   // what a BiCGStab half-iteration runs (no halo on one rank)
     }
@@ -3242,6 +3324,17 @@ int wai_launch_stats(wai_ctx* c, long long* kernels, long long* copies) {
   if (!c) return -2;
   if (kernels) *kernels = c->ks.n_launch;
   if (copies) *copies = c->ks.n_copy;
+  return 0;
+}
+int wai_bench_mute_comm(wai_ctx* c, int on) {
+  if (!c) return -2;
+  if (c->comm) c->comm->mute = on != 0;
+  return 0;
+}
+int wai_halo_size(wai_ctx* c, int dof, long long* bytes_sent, int* n_neighbours) {
+  if (!c) return -2;
+  if (bytes_sent) *bytes_sent = (long long)c->send_total * dof * (long long)sizeof(double);
+  if (n_neighbours) *n_neighbours = c->n_nbr;
   return 0;
 }
 int wai_comm_stats(wai_ctx* c, long long* allreduces, long long* exchanges) {

@@ -110,6 +110,7 @@ void comm_destroy(Comm* c) {
 int comm_allreduce(Comm* c, double* buf, size_t count, int op, hipStream_t stream, std::string& err) {
   if (!c || c->nranks == 1) return 0;
   c->n_allreduce++;
+  if (c->mute) return 0;
   const int nccl_op = (op == 0) ? 0 : (op == 1 ? 2 : 3);  // ncclSum / ncclMax / ncclMin
   const int r = g_api.AllReduce(buf, buf, count, kFloat64, nccl_op, c->handle, stream);
   if (r) { err = g_api.GetErrorString(r); return -1; }
@@ -121,6 +122,7 @@ int comm_exchange(Comm* c, int n_nbr, const int* nbr_rank, const int* send_ptr, 
                   std::string& err) {
   if (!c || n_nbr == 0) return 0;
   c->n_exchange++;
+  if (c->mute) return 0;
   int r = g_api.GroupStart();
   for (int q = 0; q < n_nbr && !r; q++) {
     const size_t ns = (size_t)(send_ptr[q + 1] - send_ptr[q]) * dof;

@@ -11,6 +11,7 @@ struct Comm {
   void* handle = nullptr;  // ncclComm_t
   int rank = 0, nranks = 1;
   long long n_allreduce = 0, n_exchange = 0;   // collectives enqueued so far (tests, reports)
+  bool mute = false;                           // timing probe (wai_bench_mute_comm): collectives return without calling RCCL
 };
 
 int comm_unique_id(char id[128], std::string& err);

@@ -216,7 +216,8 @@ struct ResForm {
 // Passive tracers (src/tracer.F90:30-40) and the auxiliary linear problem's solver settings
 // (timestepper.F90:2021-2022, 2061-2064: gmres + bjacobi unless configured)
 constexpr int MAX_TRACERS = 8;
-constexpr int POST_OFF = 64;   // h_scal[POST_OFF], [POST_OFF + 1]: {(R,R), 4 * sequence number + breakdown code} posted by the device in one 16-byte store
+constexpr int POST_OFF = 64;   // h_scal[POST_OFF ..+2]: {(R,R), 8 * sequence number + code, check word} posted by the device (post_scalars)
+constexpr unsigned long long POST_KEY = 0x5bd1e995a5a5c3c3ull;   // check = bits((R,R)) ^ bits(tag) ^ POST_KEY: zeroed memory never verifies
 struct Tracers {
   int nt = 0;
   int phase[MAX_TRACERS] = {0};
@@ -374,8 +375,11 @@ int launch_ilu_factor(wai_ctx* c);
 // the same on any (matrix, schedule) pair: the Jacobian with the brick schedule, or the extended
 // ASM system with its own
 int launch_ilu_factor_on(wai_ctx* c, const Bcsr& M, IluSchedule& s);
+// in2 (optional, fused kernels that can: pc_axpy_capable): the input is in - alpha in2, alpha = the device scalar S_ALPHA
 int launch_pc_on(wai_ctx* c, const Bcsr& M, const IluSchedule& s, bool spmv, const double* in, double* z,
-                 int dot_mode, const double* aux, const int* list = nullptr, int nrun = 0, const Fin* fin = nullptr);
+                 int dot_mode, const double* aux, const int* list = nullptr, int nrun = 0, const Fin* fin = nullptr,
+                 const double* in2 = nullptr);
+bool pc_axpy_capable(const wai_ctx* c);
 // subdomains of any size: level-by-level launches, in place on z (z = r on entry)
 int launch_big_solve(wai_ctx* c, const Bcsr& M, const IluSchedule& s, double* z);
 int launch_asm_gather_matrix(wai_ctx* c);                   // E.val <- J.val (and the ghost cells' rows)
@@ -392,7 +396,7 @@ int vec_dots(wai_ctx* c, const double* a1, const double* b1, int slot1, const do
 // list / nrun: run only the listed subdomains (null: all)
 // fin (optional): finalise the dot products in the kernel's last workgroup instead of a k_finalize launch
 int launch_pc(wai_ctx* c, bool spmv, const double* in, double* z, int dot_mode, const double* aux,
-              const int* list = nullptr, int nrun = 0, const Fin* fin = nullptr);
+              const int* list = nullptr, int nrun = 0, const Fin* fin = nullptr, const double* in2 = nullptr);
 // finalisation descriptor for slots [slot0, slot0 + nslots) (the launcher fills in the workgroup counts);
 // post: mirror the scalars to the host with a fresh sequence number (left in ks.seq)
 Fin make_fin(wai_ctx* c, int slot0, int nslots, int phase, bool post = false);
@@ -407,10 +411,14 @@ int vec_copy(wai_ctx* c, double* dst, const double* src, size_t n);
 int vec_zero(wai_ctx* c, double* dst, size_t n);
 int vec_waxpy(wai_ctx* c, double* w, double alpha, const double* x, const double* y, int n);
 int bcgs_scalars(wai_ctx* c, int phase, bool post = false);
+int bcgs_post(wai_ctx* c, int seq);
 int bcgs_update_p(wai_ctx* c);
 int bcgs_update_s(wai_ctx* c);
 // dots: reduces (R,R), (R,RP) into S_DP2, S_RHONEW and (fin_phase >= -1) finalises them in its last workgroup
 int bcgs_update_xr(wai_ctx* c, bool dots = true, int fin_phase = -2, bool post = false);
+// S = R - alpha V re-formed; X += alpha P + omega S; R = S - omega T; P = R + beta (P - omega V): one pass, no reduction
+int bcgs_update_xrp(wai_ctx* c);
+int pack_halo_axpy(wai_ctx* c, const double* a, const double* b, int dof, hipStream_t stream = nullptr);
 int gmres_mdot(wai_ctx* c, const double* w, int k);          // scal[16+i] = (w, v_i), i<k
 int gmres_maxpy_norm(wai_ctx* c, double* w, int k);          // w -= sum h_i v_i ; scal[8] = |w|^2
 int gmres_scale_to(wai_ctx* c, double* dst, const double* src, int slot_norm2, int n);

@@ -146,6 +146,22 @@ __device__ __forceinline__ void load_x(const double* __restrict__ x, int col, do
   }
 }
 
+// The fused kernels' input composed on the fly (AX): x = in + nalpha * in2, one fused multiply-add per entry -- BiCGStab's
+// S = R - alpha V is then never written to memory: the second fused launch of an iteration gathers R and V (own row and
+// neighbours; the neighbours' lines are L2 hits either way) instead of reading an S that a separate launch had to write
+// (k_bcgs_s: R, V read, S written).  The same fma as k_bcgs_s and k_bcgs_xrp use: identical bits wherever S is formed.
+template <int BS, bool AX>
+__device__ __forceinline__ void load_xs(const double* __restrict__ in, const double* __restrict__ in2, double nalpha,
+                                        int col, double* xv) {
+  load_x<BS>(in, col, xv);
+  if constexpr (AX) {
+    double x2[BS];
+    load_x<BS>(in2, col, x2);
+#pragma unroll
+    for (int k = 0; k < BS; k++) xv[k] = __builtin_fma(nalpha, x2[k], xv[k]);
+  }
+}
+
 template <int BS>
 __device__ __forceinline__ void load_x_stream(const double* __restrict__ x, int col, double* xv) {   // read once
   if constexpr (BS == 2) {
@@ -587,16 +603,26 @@ __global__ __launch_bounds__(TPB) void k_scale_rows(int n, int W, const double* 
 
 // ---- reductions finished inside the producing kernel ---------------------------------------------
 // What the host tests after an iteration -- the squared residual norm and the breakdown code -- written straight
-// into pinned host memory as ONE aligned 16-byte store: {(R,R), 4 * sequence number + breakdown code}.  One PCIe
-// write carries both, so the host, spinning on the second word (wait_post, capi.hip), never sees one without the
-// other, and the posting workgroup neither issues 17 stores nor waits for their acknowledgement.
+// into pinned host memory: {(R,R), 8 * sequence number + code, check} with check = bits((R,R)) ^ bits(tag) ^ POST_KEY.
+// The first two words leave as ONE aligned 16-byte store (one PCIe write on gfx942 / gfx950), the check word behind
+// them; the host (wait_post, capi.hip) spins on the tag and accepts the pair only when the check word matches, so a
+// store that the fabric tears, or words that arrive in another order, can only delay the host, never pair a new
+// sequence number with an old norm.  Codes: 0 none, 1-3 BiCGStab breakdowns (derive_scalars), 4 a partial sum of a
+// reduction never arrived (sum_partials).
 typedef unsigned wai_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void post_scalars(const double* scal, double* post, int seq) {
-  const double v0 = scal[S_DP2], v1 = 4.0 * (double)seq + scal[S_BREAK];
+  const double v0 = scal[S_DP2], v1 = 8.0 * (double)seq + scal[S_BREAK];
+  const unsigned long long chk = (unsigned long long)__double_as_longlong(v0) ^ (unsigned long long)__double_as_longlong(v1) ^ POST_KEY;
+#if defined(__gfx942__) || defined(__gfx950__)
   wai_u4 w;
   w.x = (unsigned)__double2loint(v0); w.y = (unsigned)__double2hiint(v0);
   w.z = (unsigned)__double2loint(v1); w.w = (unsigned)__double2hiint(v1);
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(post), "v"(w) : "memory");
+#else
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(post), (unsigned long long)__double_as_longlong(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(post) + 1, (unsigned long long)__double_as_longlong(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(post) + 2, chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // merged reductions (multi-rank): slots hold (S,T), (T,T), (S,S), (S,RP), (T,RP).  omega = (S,T)/(T,T) (see
 // phase 3 for (T,T) = 0); then, with R = S - omega T:  (R,RP) = (S,RP) - omega (T,RP)  and
@@ -651,6 +677,13 @@ __device__ __forceinline__ void derive_scalars(double* s, int phase) {
 // nothing beyond storing their partial (agent scope: written through, coherent across the XCDs' L2s).
 // Arrival is read off the data: an empty partial slot holds FIN_EMPTY (a NaN payload no sum produces), and
 // whoever consumes a partial -- this workgroup or k_finalize -- leaves the slot empty again.
+// INVARIANT the launchers keep (launch_pc_on, vec_dots, bcgs_update_xr): every launch that stores partials into a
+// slot is followed, before the next producer of that slot, by exactly one consumer -- its own finaliser workgroup
+// or a k_finalize launch -- and every Krylov driver empties the slots it uses before its first producer
+// (partials_clear), so what an aborted solve or a probe left behind cannot pass for an arrival.  A partial that never
+// arrives (bounded wait) or a consumer without a producer gives a NaN sum AND breakdown code 4 (KSP_DIVERGED_NANORINF
+// with a message on the host).  WAI_FIN_SEPARATE=1 (run time) takes the finalisation out of the producers again --
+// one-block k_finalize launches behind them, as in rounds 1-2 -- for debuggers and serialised dispatch.
 // The sums are formed exactly as k_finalize forms them (virtual threads v < VT stride over the partials, a
 // 64-lane shuffle tree per virtual wave, the wave sums added in order): the bits do not depend on timing
 // and equal what the separate launch gave.
@@ -689,6 +722,9 @@ __device__ __forceinline__ void sum_partials(const double* partials, int nb_max,
               __builtin_amdgcn_s_sleep(8);
               u[k] = __hip_atomic_load(ps + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            // still empty: the producer never stored it (waited out above), or -- k_finalize, wait = false -- no producer
+            // ran before this consumer.  The sum is a NaN either way; say why (code 4 reaches the host with the post)
+            if (u[k] == FIN_EMPTY) scal[S_BREAK] = 4.0;
             __hip_atomic_store(ps + i, FIN_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: the slot is empty again
             t += __longlong_as_double((long long)u[k]);   // FIN_EMPTY itself is a NaN
           }
@@ -1094,11 +1130,12 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
 // three resident workgroups per CU (3 x 51 KB of the 160 KB LDS), so one more brick's loads are in
 // flight to cover the latency-bound sweeps of the others.
 // MEASURED (216^3, MI355X, same box): 0.604 ms against k_pc's 0.709 ms; 68 VGPRs, no spills.
-template <bool SPMV>
+template <bool SPMV, bool AX>
 __global__ __launch_bounds__(512, 6) void k_pc_park(
     int n, int W, int nsub, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev,
     const int* __restrict__ row_info, const int* __restrict__ row_uoff, const int* __restrict__ col,
     const double* __restrict__ sval, const double* __restrict__ dinv, const double* __restrict__ in,
+    const double* __restrict__ in2, const double* __restrict__ scal,
     double* __restrict__ z, const double* __restrict__ aux, double* partials, int nb_max, int dot,
     const int* __restrict__ sub_list, Fin fin) {
   constexpr int BS = 2, BB = 4, MLU = 3;
@@ -1114,6 +1151,7 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
   const int nlf = nl & 0xffff, nlb = nl >> 16;
   const int tid = threadIdx.x, i = lo + tid;
   const bool active = tid < R;
+  const double nalpha = AX ? -scal[S_ALPHA] : 0.0;   // input = in - alpha in2 (uniform: a scalar load)
   PH_DECL;
   double* ys = lds;
   double* upark = lds + (size_t)blockDim.x * BS + 80;
@@ -1150,7 +1188,7 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
         load_block<BS>(sval, n, q, i, blk);
         if constexpr (SPMV) {
           double xv[BS];
-          load_x<BS>(in, cg, xv);
+          load_xs<BS, AX>(in, in2, nalpha, cg, xv);
           acc[0] += blk[0] * xv[0] + blk[1] * xv[1];
           acc[1] += blk[2] * xv[0] + blk[3] * xv[1];
         }
@@ -1177,7 +1215,7 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
       acc[0] = dv[0] * r[0] + dv[1] * r[1];
       acc[1] = dv[2] * r[0] + dv[3] * r[1];
     }
-    if (dot == 2 || dot == 4) load_x<BS>(in, i, xin);
+    if (dot == 2 || dot == 4) load_xs<BS, AX>(in, in2, nalpha, i, xin);
     if (dot == 1 || dot == 4) load_x_stream<BS>(aux, i, avp);   // the dot product's partner: in flight through the sweeps
     *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(acc[0], acc[1]);
   }
@@ -1275,11 +1313,12 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
 // registers: 58 (bs 2), 69 (bs 3), 90 (bs 4) without spills -> 8 / 7 / 5 waves per SIMD; asking for 8
 // everywhere spills 150-600 registers at bs = 3, 4.  Four couplings per sweep (NL = 4: MINC inside 3-D
 // bricks) cost 12 more: 5 and 4 waves (at 7 and 5 they spilled 200 bytes per lane)
-template <int BS, bool SPMV, int NL, int NU>
+template <int BS, bool SPMV, int NL, int NU, bool AX>
 __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) : (NL <= 3 ? 5 : 4)))) void k_pc_rows(
     int n, int W, int nsub, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev,
     const int* __restrict__ row_info, const int* __restrict__ col, const double* __restrict__ sval,
-    const double* __restrict__ dinv, const double* __restrict__ in, double* __restrict__ z,
+    const double* __restrict__ dinv, const double* __restrict__ in, const double* __restrict__ in2,
+    const double* __restrict__ scal, double* __restrict__ z,
     const double* __restrict__ aux, double* partials, int nb_max, int dot, const int* __restrict__ sub_list,
     const int* __restrict__ rowptr, const int* __restrict__ sub_split, Fin fin) {
   extern __shared__ double lds[];  // [R*BS] solution in block order, [BS] zeros, then reduction scratch
@@ -1291,6 +1330,7 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
   const int nl = sub_nlev[s];
   const int nlf = nl & 0xffff, nlb = nl >> 16;
   const int tid = threadIdx.x;
+  const double nalpha = AX ? -scal[S_ALPHA] : 0.0;   // input = in - alpha in2
   PH_DECL;
   // component-major over the R1 leading (long) rows, then component-major over the short ones
   const int R1 = sub_split ? sub_split[s] : R;
@@ -1338,7 +1378,7 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
         for (int k = 0; k < BS; k++) blk[k] = __builtin_nontemporal_load(sval + ell_ix(BS, (size_t)n, q, r, k, (size_t)i));
         if constexpr (SPMV) {
           double xv[BS];
-          load_x<BS>(in, cg, xv);
+          load_xs<BS, AX>(in, in2, nalpha, cg, xv);
 #pragma unroll
           for (int k = 0; k < BS; k++) acc += blk[k] * xv[k];
         }
@@ -1409,10 +1449,10 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
     if (dot == 1) {
       if (active) v[0] = out * avp;
     } else if (dot == 2) {
-      if (active) { v[0] = in[g] * out; v[1] = out * out; }
+      if (active) { const double xi = AX ? __builtin_fma(nalpha, in2[g], in[g]) : in[g]; v[0] = xi * out; v[1] = out * out; }
     } else if (dot == 4) {
       if (active) {
-        const double xi = in[g], av = avp;
+        const double xi = AX ? __builtin_fma(nalpha, in2[g], in[g]) : in[g], av = avp;
         v[0] = xi * out; v[1] = out * out; v[2] = xi * xi; v[3] = xi * av; v[4] = out * av;
       }
     } else {
@@ -1437,12 +1477,12 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
 // backward sweep; four independent bricks share a 256-thread workgroup (no __syncthreads anywhere), ~13 bricks
 // are resident per CU, and the latency of one brick's sweeps hides behind the loads of the others.
 // Serves the 8 x 4 x 2 bricks of 3 x 3 blocks and the 8 x 4 x 1 (32 + 32 rows) MINC bricks.
-template <int BS, bool SPMV>
+template <int BS, bool SPMV, bool AX>
 __global__ __launch_bounds__(256) void k_pc_wave(
     int n, int W, int nsub, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev,
     const int* __restrict__ row_info, const int* __restrict__ row_uoffw, const int* __restrict__ col,
     const double* __restrict__ sval, const double* __restrict__ dinv, const double* __restrict__ in,
-    double* __restrict__ z, const double* __restrict__ aux, double* partials, int nb_max, int dot,
+    const double* __restrict__ in2, const double* __restrict__ scal, double* __restrict__ z, const double* __restrict__ aux, double* partials, int nb_max, int dot,
     const int* __restrict__ sub_list, const int* __restrict__ rowptr, int lds_per_brick, Fin fin) {
   constexpr int BB = BS * BS, NL = 3, NU = 4;
   extern __shared__ double lds[];
@@ -1459,6 +1499,7 @@ __global__ __launch_bounds__(256) void k_pc_wave(
   const int nlf = nl & 0xffff, nlb = nl >> 16;
   const int i = lo + lane;
   const bool active = lane < R;
+  const double nalpha = AX ? -scal[S_ALPHA] : 0.0;   // input = in - alpha in2
   PH_DECL;
   double* ys = lds + (size_t)wave * lds_per_brick;   // [64 * BS] solution in block order
   double* upark = ys + 64 * BS;                      // parked upper blocks, row-major BS x BS each
@@ -1494,7 +1535,7 @@ __global__ __launch_bounds__(256) void k_pc_wave(
         for (int e = 0; e < BB; e++) blk[e] = __builtin_nontemporal_load(sval + vix<BS>(n, q, e, i));
         if constexpr (SPMV) {
           double xv[BS];
-          load_x<BS>(in, cg, xv);
+          load_xs<BS, AX>(in, in2, nalpha, cg, xv);
 #pragma unroll
           for (int r = 0; r < BS; r++)
 #pragma unroll
@@ -1585,9 +1626,9 @@ __global__ __launch_bounds__(256) void k_pc_wave(
       const double out = ys[t];
       __builtin_nontemporal_store(out, z + gi);
       if (dot == 1) v[0] += out * __builtin_nontemporal_load(aux + gi);
-      else if (dot == 2) { const double xi = in[gi]; v[0] += xi * out; v[1] += out * out; }
+      else if (dot == 2) { const double xi = AX ? __builtin_fma(nalpha, in2[gi], in[gi]) : in[gi]; v[0] += xi * out; v[1] += out * out; }
       else if (dot == 4) {
-        const double xi = in[gi], av = __builtin_nontemporal_load(aux + gi);
+        const double xi = AX ? __builtin_fma(nalpha, in2[gi], in[gi]) : in[gi], av = __builtin_nontemporal_load(aux + gi);
         v[0] += xi * out; v[1] += out * out; v[2] += xi * xi; v[3] += xi * av; v[4] += out * av;
       } else if (dot == 3) v[0] += out * out;
     }
@@ -1700,16 +1741,15 @@ __global__ __launch_bounds__(TPB) void k_bcgs_p(double* __restrict__ P, const do
                                                 const double* __restrict__ s) {
   const double beta = s[S_BETA], ob = -s[S_OMEGA] * beta;
   for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB)
-    stv(P + i, ldv(R + i) + ob * ldv(V + i) + beta * ldv(P + i));
+    stv(P + i, __builtin_fma(beta, ldv(P + i), __builtin_fma(ob, ldv(V + i), ldv(R + i))));
 
 }
 // S = R - alpha V
 __global__ __launch_bounds__(TPB) void k_bcgs_s(double* __restrict__ S, const double* __restrict__ R,
                                                 const double* __restrict__ V, int n,
                                                 const double* __restrict__ s) {
-  const double alpha = s[S_ALPHA];
-  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) stv(S + i, ldv(R + i) - alpha * ldv(V + i));
-
+  const double nalpha = -s[S_ALPHA];
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) stv(S + i, __builtin_fma(nalpha, ldv(V + i), ldv(R + i)));
 }
 // X += alpha P + omega S ; R = S - omega T ; partial (R,R) and (R,RP) unless the caller already has
 // them from the merged reductions (DOTS = false)
@@ -1725,8 +1765,8 @@ __global__ __launch_bounds__(TPB) void k_bcgs_xr(double* __restrict__ X, double*
   double v[2] = {0.0, 0.0};
   for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += nblk * TPB) {
     const double si = ldv(S + i);
-    stv(X + i, ldv(X + i) + alpha * ldv(P + i) + omega * si);
-    const double r = si - omega * ldv(T + i);
+    stv(X + i, __builtin_fma(omega, si, __builtin_fma(alpha, ldv(P + i), ldv(X + i))));
+    const double r = __builtin_fma(-omega, ldv(T + i), si);
     stv(R + i, r);
     if constexpr (DOTS) {
       v[0] += r * r;
@@ -1737,6 +1777,58 @@ __global__ __launch_bounds__(TPB) void k_bcgs_xr(double* __restrict__ X, double*
     const int slots[2] = {S_DP2, S_RHONEW};
     block_reduce_store<2>(v, partials, nb_max, slots);
   }
+}
+
+// The iteration's vector work in ONE pass (merged reductions: omega, rho, beta are known before X and R move):
+//   S = R - alpha V (re-formed, never stored)   X += alpha P + omega S   R = S - omega T   P = R + beta (P - omega V)
+// -- k_bcgs_s, k_bcgs_xr and the next iteration's k_bcgs_p: reads X, P, R, V, T, writes X, R, P (8 vector passes where the
+// three kernels make 14), no reduction.  Every expression is the one its separate kernel evaluates: identical bits.
+__global__ __launch_bounds__(TPB) void k_bcgs_xrp(double* __restrict__ X, double* __restrict__ R, double* __restrict__ P,
+                                                  const double* __restrict__ V, const double* __restrict__ T, int n,
+                                                  const double* __restrict__ s) {
+  const double alpha = s[S_ALPHA], omega = s[S_OMEGA], beta = s[S_BETA], nalpha = -alpha, ob = -omega * beta;
+  auto one = [&](double x, double r0, double p, double v, double t, double& xo, double& ro, double& po) {
+    const double si = __builtin_fma(nalpha, v, r0);
+    xo = __builtin_fma(omega, si, __builtin_fma(alpha, p, x));
+    ro = __builtin_fma(-omega, t, si);
+    po = __builtin_fma(beta, p, __builtin_fma(ob, v, ro));
+  };
+  // no reduction here, so the lanes are free to take two entries each (16-byte accesses; with a reduction the pairing
+  // would change the order of the partial sums and with it the solver's rounding)
+  const int n2 = n >> 1;
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n2; i += gridDim.x * TPB) {
+    const wai_d2 x = __builtin_nontemporal_load(reinterpret_cast<const wai_d2*>(X) + i);
+    const wai_d2 r0 = __builtin_nontemporal_load(reinterpret_cast<const wai_d2*>(R) + i);
+    const wai_d2 p = __builtin_nontemporal_load(reinterpret_cast<const wai_d2*>(P) + i);
+    const wai_d2 v = __builtin_nontemporal_load(reinterpret_cast<const wai_d2*>(V) + i);
+    const wai_d2 t = __builtin_nontemporal_load(reinterpret_cast<const wai_d2*>(T) + i);
+    wai_d2 xo, ro, po;
+    double a, b, c2;
+    one(x.x, r0.x, p.x, v.x, t.x, a, b, c2); xo.x = a; ro.x = b; po.x = c2;
+    one(x.y, r0.y, p.y, v.y, t.y, a, b, c2); xo.y = a; ro.y = b; po.y = c2;
+    __builtin_nontemporal_store(xo, reinterpret_cast<wai_d2*>(X) + i);
+    __builtin_nontemporal_store(ro, reinterpret_cast<wai_d2*>(R) + i);
+    __builtin_nontemporal_store(po, reinterpret_cast<wai_d2*>(P) + i);
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int i = n - 1;
+    double a, b, c2;
+    one(X[i], R[i], P[i], V[i], T[i], a, b, c2);
+    X[i] = a; R[i] = b; P[i] = c2;
+  }
+}
+
+// halo pack of a composed vector: sendbuf[p*dof + k] = a[idx*dof + k] - alpha b[idx*dof + k] (the ghost values of
+// S = R - alpha V for the fused launch that forms S on the fly; the receiver unpacks them into R's ghost entries and
+// keeps V's at zero)
+__global__ __launch_bounds__(TPB) void k_pack_axpy(const double* __restrict__ a, const double* __restrict__ b,
+                                                   const double* __restrict__ s, const int* __restrict__ idx,
+                                                   int n, int dof, double* __restrict__ buf) {
+  const int t = blockIdx.x * TPB + threadIdx.x;
+  if (t >= n * dof) return;
+  const int p = t / dof, k = t - p * dof;
+  const size_t g = (size_t)idx[p] * dof + k;
+  buf[t] = __builtin_fma(-s[S_ALPHA], b[g], a[g]);
 }
 
 __global__ __launch_bounds__(TPB) void k_waxpy(double* w, double alpha, const double* x, const double* y, int n) {
@@ -2011,6 +2103,8 @@ int launch_lu_apply(wai_ctx* c, const double* r, double* z) {
   return 0;
 }
 
+static bool fin_separate() { return getenv("WAI_FIN_SEPARATE") != nullptr; }   // read per launch: tests switch it inside one process
+int bcgs_post(wai_ctx* c, int seq);
 static inline int pc_threads(const IluSchedule& s) { return ((s.max_rows + 63) / 64) * 64; }
 
 int launch_ilu_factor_on(wai_ctx* c, const Bcsr& J, IluSchedule& s) {
@@ -2109,9 +2203,20 @@ int launch_big_solve(wai_ctx* c, const Bcsr& J, const IluSchedule& s, double* z)
   return 0;
 }
 
+// which fused kernel serves (matrix, schedule): 3 k_pc_wave, 2 k_pc_rows, 1 k_pc_park, 0 the generic k_pc.  The first
+// three can form their input on the fly (in - alpha in2: launch_pc_on's in2)
+static int pc_kernel_kind(const wai_ctx* c, const Bcsr& J, const IluSchedule& s) {
+  if (c->dbg) return 0;
+  if (s.wave_kernel && J.bs >= 3) return 3;
+  if (s.rows_kernel) return 2;
+  if (J.bs == 2 && s.park && s.diag_only && s.scaled && s.fast3 && pc_threads(s) <= 512) return 1;
+  return 0;
+}
+bool pc_axpy_capable(const wai_ctx* c) { return !c->ilu.big && pc_kernel_kind(c, c->J, c->ilu) != 0; }
+
 template <int BS>
 static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool spmv, const double* in, double* z,
-                         int dot_mode, const double* aux, const int* list, int nrun, const Fin* finp) {
+                         int dot_mode, const double* aux, const int* list, int nrun, const Fin* finp, const double* in2) {
   if (!list) { nrun = s.nsub; list = s.sub_order; }   // all subdomains: in the schedule's launch order, if it has one
   const bool with_fin = finp && dot_mode != 0;
   Fin fin;
@@ -2130,48 +2235,49 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
                          nrun, s.sub_ptr, s.sub_nlev, s.row_info, J.col, J.val, s.fval,          \
                          s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, c->dbg, list, fin); \
   } while (0)
+  const int kind = pc_kernel_kind(c, J, s);
+  const double* scal = c->ks.scal;
   // one wave per brick of <= 64 block rows (block sizes 3 and 4), four bricks per workgroup
-  if (s.wave_kernel && !c->dbg) {
+  if (kind == 3) {
     if constexpr (BS >= 3) {
       const int ngrp = (nrun + 3) / 4, gridw = ((ngrp + 7) / 8) * 8 + (with_fin ? 1 : 0);
       const int per = 64 * BS + s.max_ublocks_w * BS * BS;            // doubles per brick: solution + parked upper blocks
       const size_t lds_w = (size_t)4 * per * sizeof(double);
       const int* rp = (size_t)J.nnzb * 10 < (size_t)J.n * J.W * 9 ? J.rowptr : nullptr;   // > 10 % padding
-      if (spmv)
-        hipLaunchKernelGGL((k_pc_wave<BS, true>), gridw, 256, lds_w, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev, s.row_info,
-                           s.row_uoffw, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, list, rp, per, fin);
-      else
-        hipLaunchKernelGGL((k_pc_wave<BS, false>), gridw, 256, lds_w, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev, s.row_info,
-                           s.row_uoffw, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, list, rp, per, fin);
+#define PCW(SP, AXV)                                                                                \
+      hipLaunchKernelGGL((k_pc_wave<BS, SP, AXV>), gridw, 256, lds_w, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev, s.row_info, \
+                         s.row_uoffw, J.col, s.fval, s.dinv, in, in2, scal, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, list, rp, per, fin)
+      if (spmv) { if (in2) PCW(true, true); else PCW(true, false); }
+      else PCW(false, false);
+#undef PCW
       return;
     }
   }
   // one thread per scalar row: block sizes 3 and 4 (and 2 when asked for: WAI_PC_ROWS=1)
-  if (s.rows_kernel && !c->dbg) {
+  if (kind == 2) {
     const int TR = ((s.max_rows * BS + 63) / 64) * 64;
     const size_t lds_r = ((size_t)s.max_rows * BS + BS + 5 * 16 + 8) * sizeof(double);
     const int* rp = (size_t)J.nnzb * 10 < (size_t)J.n * J.W * 9 ? J.rowptr : nullptr;   // > 10 % padding
-#define PCR(SP, NLU)                                                                               \
-    hipLaunchKernelGGL((k_pc_rows<BS, SP, NLU, NLU>), grid, TR, lds_r, c->stream, J.n, J.W, nrun, s.sub_ptr,  \
-                       s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials, c->ks.nb_max, \
+#define PCR(SP, NLU, AXV)                                                                          \
+    hipLaunchKernelGGL((k_pc_rows<BS, SP, NLU, NLU, AXV>), grid, TR, lds_r, c->stream, J.n, J.W, nrun, s.sub_ptr,  \
+                       s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, in, in2, scal, z, aux, c->ks.partials, c->ks.nb_max, \
                        dot_mode, list, rp, s.sub_split, fin)
-    if (s.max_nlu <= 3) { if (spmv) PCR(true, 3); else PCR(false, 3); }
-    else { if (spmv) PCR(true, 4); else PCR(false, 4); }
+    if (s.max_nlu <= 3) { if (spmv) { if (in2) PCR(true, 3, true); else PCR(true, 3, false); } else PCR(false, 3, false); }
+    else { if (spmv) { if (in2) PCR(true, 4, true); else PCR(true, 4, false); } else PCR(false, 4, false); }
 #undef PCR
     return;
   }
   if constexpr (BS == 2) {
     // upper blocks parked in LDS: three resident workgroups per CU
-    if (s.park && s.diag_only && s.scaled && s.fast3 && T <= 512 && !c->dbg) {
+    if (kind == 1) {
       const size_t lds_park = lds + (size_t)s.max_ublocks * 4 * sizeof(double);
-      if (spmv)
-        hipLaunchKernelGGL(k_pc_park<true>, grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,
-                           s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials,
-                           c->ks.nb_max, dot_mode, list, fin);
-      else
-        hipLaunchKernelGGL(k_pc_park<false>, grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,
-                           s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, z, aux, c->ks.partials,
-                           c->ks.nb_max, dot_mode, list, fin);
+#define PCP(SP, AXV)                                                                               \
+      hipLaunchKernelGGL((k_pc_park<SP, AXV>), grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,  \
+                         s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, in2, scal, z, aux, c->ks.partials,       \
+                         c->ks.nb_max, dot_mode, list, fin)
+      if (spmv) { if (in2) PCP(true, true); else PCP(true, false); }
+      else PCP(false, false);
+#undef PCP
       return;
     }
   }
@@ -2188,20 +2294,27 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
 }
 
 int launch_pc_on(wai_ctx* c, const Bcsr& M, const IluSchedule& s, bool spmv, const double* in, double* z,
-                 int dot_mode, const double* aux, const int* list, int nrun, const Fin* fin) {
+                 int dot_mode, const double* aux, const int* list, int nrun, const Fin* fin, const double* in2) {
+  if (in2 && (!spmv || pc_kernel_kind(c, M, s) == 0)) { c->err = "composed input asked of a kernel that cannot form it"; return -1; }
+  const Fin* fin_later = nullptr;
+  if (fin && dot_mode != 0 && fin_separate()) { fin_later = fin; fin = nullptr; }
   switch (M.bs) {
-    case 1: launch_pc_bs<1>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun, fin); break;
-    case 2: launch_pc_bs<2>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun, fin); break;
-    case 3: launch_pc_bs<3>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun, fin); break;
-    case 4: launch_pc_bs<4>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun, fin); break;
+    case 1: launch_pc_bs<1>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun, fin, in2); break;
+    case 2: launch_pc_bs<2>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun, fin, in2); break;
+    case 3: launch_pc_bs<3>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun, fin, in2); break;
+    case 4: launch_pc_bs<4>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun, fin, in2); break;
     default: return -1;
   }
   c->ks.nb_pc = s.nsub;
+  if (fin_later) {
+    vec_finalize(c, s.nsub, fin_later->slot0, fin_later->nslots, fin_later->phase);
+    if (fin_later->seq > 0) bcgs_post(c, fin_later->seq);
+  }
   return 0;
 }
 int launch_pc(wai_ctx* c, bool spmv, const double* in, double* z, int dot_mode, const double* aux,
-              const int* list, int nrun, const Fin* fin) {
-  return launch_pc_on(c, c->J, c->ilu, spmv, in, z, dot_mode, aux, list, nrun, fin);
+              const int* list, int nrun, const Fin* fin, const double* in2) {
+  return launch_pc_on(c, c->J, c->ilu, spmv, in, z, dot_mode, aux, list, nrun, fin, in2);
 }
 Fin make_fin(wai_ctx* c, int slot0, int nslots, int phase, bool post) {
   Fin f;   // count / nb: filled in by the launcher
@@ -2300,6 +2413,12 @@ int bcgs_scalars(wai_ctx* c, int phase, bool post) {
   hipLaunchKernelGGL(k_bcgs_scalars, 1, 64, 0, c->stream, c->ks.scal, phase, c->ks.d_post, post ? ++c->ks.seq : 0);
   return 0;
 }
+int bcgs_post(wai_ctx* c, int seq) {   // the device scalars as they stand, under a sequence number already handed out
+  c->ks.n_launch++;
+  hipLaunchKernelGGL(k_bcgs_scalars, 1, 64, 0, c->stream, c->ks.scal, -1, c->ks.d_post, seq);
+  return 0;
+}
+
 int bcgs_update_p(wai_ctx* c) {
   c->ks.n_launch++;
   hipLaunchKernelGGL(k_bcgs_p, vgrid(c->ks.n), TPB, 0, c->stream, c->ks.P, c->ks.R, c->ks.V, c->ks.n, c->ks.scal);
@@ -2315,6 +2434,15 @@ int bcgs_update_xr(wai_ctx* c, bool dots, int fin_phase, bool post) {
   Fin fin;
   if (dots && fin_phase >= -1) { fin = make_fin(c, S_DP2, 2, fin_phase, post); fin.count = g; fin.nb = g; }
   c->ks.n_launch++;
+  if (dots && fin.count > 0 && fin_separate()) {
+    Fin none;
+    hipLaunchKernelGGL(k_bcgs_xr<true>, g, TPB, 0, c->stream, c->ks.X, c->ks.R, c->ks.P, c->ks.S, c->ks.T,
+                       c->ks.RP, c->ks.n, c->ks.scal, c->ks.partials, c->ks.nb_max, none);
+    c->ks.nblocks = g;
+    vec_finalize(c, g, S_DP2, 2, fin_phase);
+    if (fin.seq > 0) bcgs_post(c, fin.seq);
+    return 0;
+  }
   if (dots)
     hipLaunchKernelGGL(k_bcgs_xr<true>, g + (fin.count > 0 ? 1 : 0), TPB, 0, c->stream, c->ks.X, c->ks.R, c->ks.P, c->ks.S, c->ks.T,
                        c->ks.RP, c->ks.n, c->ks.scal, c->ks.partials, c->ks.nb_max, fin);
@@ -2322,6 +2450,12 @@ int bcgs_update_xr(wai_ctx* c, bool dots, int fin_phase, bool post) {
     hipLaunchKernelGGL(k_bcgs_xr<false>, g, TPB, 0, c->stream, c->ks.X, c->ks.R, c->ks.P, c->ks.S, c->ks.T,
                        c->ks.RP, c->ks.n, c->ks.scal, c->ks.partials, c->ks.nb_max, fin);
   c->ks.nblocks = g;
+  return 0;
+}
+int bcgs_update_xrp(wai_ctx* c) {
+  c->ks.n_launch++;
+  hipLaunchKernelGGL(k_bcgs_xrp, vgrid(c->ks.n), TPB, 0, c->stream, c->ks.X, c->ks.R, c->ks.P, c->ks.V, c->ks.T, c->ks.n,
+                     c->ks.scal);
   return 0;
 }
 int gmres_mdot(wai_ctx* c, const double* w, int k) {
@@ -2357,6 +2491,14 @@ int pack_halo(wai_ctx* c, const double* vec, int dof, hipStream_t stream) {
   c->ks.n_launch++;
   hipLaunchKernelGGL(k_pack, (n * dof + TPB - 1) / TPB, TPB, 0, stream ? stream : c->stream, vec, c->d_send_idx, n,
                      dof, c->d_sendbuf);
+  return 0;
+}
+int pack_halo_axpy(wai_ctx* c, const double* a, const double* b, int dof, hipStream_t stream) {
+  const int n = c->send_total;
+  if (n <= 0) return 0;
+  c->ks.n_launch++;
+  hipLaunchKernelGGL(k_pack_axpy, (n * dof + TPB - 1) / TPB, TPB, 0, stream ? stream : c->stream, a, b, c->ks.scal,
+                     c->d_send_idx, n, dof, c->d_sendbuf);
   return 0;
 }
 int unpack_halo(wai_ctx* c, double* vec, int dof, hipStream_t stream) {

@@ -194,6 +194,16 @@ class FlowSimulation:
         LIB.wai_comm_stats(self.h, C.byref(a), C.byref(e))
         return a.value, e.value
 
+    def mute_comm(self, on):
+        """timing probe: collectives return without calling RCCL (every rank together)"""
+        self._chk(LIB.wai_bench_mute_comm(self.h, 1 if on else 0), "bench_mute_comm")
+
+    def halo_size(self, dof=None):
+        """(bytes this rank sends per halo exchange of a dof-per-cell vector, neighbours)"""
+        b, n = C.c_longlong(0), C.c_int(0)
+        LIB.wai_halo_size(self.h, self.num_primary_variables if dof is None else dof, C.byref(b), C.byref(n))
+        return b.value, n.value
+
     def launch_stats(self):
         """(kernels launched, copies enqueued) by the linear-solver helpers so far"""
         a, e = C.c_longlong(0), C.c_longlong(0)
