@@ -250,23 +250,6 @@ def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0, gpu_s
         err, J2 = osim.jacobian(y, dt, lhs_old, f, mode=1)
         t_col = time.time() - t0
         del J2
-    elif brick is not None:
-        # does not fit the budget on this mesh: the coloured / per-row cost ratio measured on the 1 M-cell mesh of
-        # the same kind (C2's size; both sweeps are linear in the cell count) carries it over
-        from waiwera_amd.cases import make_case, scaled as scaled_
-        g2, lm2, prim2, region2 = make_case(dims=(100, 100, 100), brick=brick, eos=eos, lens=True, minc=minc)
-        o2 = ol.OracleSim(L, lm2, kind)
-        o2.set_regions(region2)
-        y2 = o2.yvec(scaled_(prim2, region2, eos).ravel())
-        assert o2.pre_eval(y2) == 0
-        l2 = o2.lhs()
-        e2, f2 = o2.residual(y2, dt, l2)
-        L.wo_pre_iteration(o2.h)
-        t0 = time.time(); o2.jacobian(y2, dt, l2, f2, mode=0); t_row2 = time.time() - t0
-        t0 = time.time(); o2.jacobian(y2, dt, l2, f2, mode=1); t_col2 = time.time() - t0
-        o2.close()
-        t_col = t_jac * t_col2 / t_row2
-        col_note = " (scaled from the 100^3 mesh of the same kind: %.2f s coloured against %.2f s per-row there)" % (t_col2, t_row2)
     # thread count: the memory-bound Krylov iteration decides.  Each trial = ILU(0) set-up with one
     # subdomain per thread + a few BiCGStab iterations; the best count is then timed over K iterations
     xs = np.zeros(osim.n_prim * bs)
@@ -291,7 +274,60 @@ def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0, gpu_s
             best, best_t = ti, t
     K = 8
     t_setup, t_iter = solve(best_t, K)
+    n_big = n
     osim.close()
+    # The model's check, and the coloured sweep where it does not fit above: ONE WHOLE Newton step of the oracle
+    # (wo_newton_step: FD Jacobian, ILU(0) set-up, BiCGStab to rtol 1e-5, line search with transitions, new residual --
+    # src/timestepper.F90:587-735) on the 1 M-cell mesh of the same kind (C2's size; this mesh when it is that small),
+    # timed as a whole beside the model's sum of its pieces timed on that same mesh with the iteration count that step took
+    whole = None
+    try:
+        from waiwera_amd.cases import make_case, scaled as scaled_
+        if gomp:
+            gomp.omp_set_num_threads(int(best_t))
+        g2, lm2, prim2, region2 = make_case(dims=(100, 100, 100), brick=brick or (16, 16, 2), eos=eos, lens=True, minc=minc)
+        o2 = ol.OracleSim(L, lm2, kind)
+        o2.set_regions(region2)
+        sp2 = np.linspace(0, o2.n_owned, int(best_t) + 1).astype(np.int32)
+        L.wo_sim_set_subdomains(o2.h, int(best_t), ol.ip(sp2))
+        L.wo_sim_spread_pages(o2.h)
+        y2 = o2.yvec(scaled_(prim2, region2, eos).ravel())
+        L.wo_pre_timestep(o2.h)
+        t0 = time.time()
+        assert o2.pre_eval(y2) == 0
+        l2 = o2.lhs()
+        e2, f2 = o2.residual(y2, dt, l2)
+        t_res2 = time.time() - t0
+        L.wo_pre_iteration(o2.h)
+        t0 = time.time(); e2, J2 = o2.jacobian(y2, dt, l2, f2, mode=0); t_row2 = time.time() - t0
+        t0 = time.time(); o2.jacobian(y2, dt, l2, f2, mode=1); t_col2 = time.time() - t0
+        t0 = time.time(); assert o2.pc_setup(J2) == 0; t_set2 = time.time() - t0
+        x2 = np.zeros(o2.n_prim * bs)
+        t0 = time.time()
+        L.wo_ksp_solve(o2.h, 0, 30, ol.dp(J2), ol.dp(f2), ol.dp(x2), 1e-30, 1e-50, K, C.byref(its), C.byref(rn), None)
+        t_it2 = max(time.time() - t0 - t_set2, 1e-9) / max(its.value, 1)
+        del J2
+        opt2 = o2.opts()     # reference defaults: BiCGStab, rtol 1e-5, per-row differencing (jac_mode 0)
+        kits2, mr2 = C.c_int(0), C.c_double(0)
+        f2w = f2.copy()
+        t0 = time.time()
+        r2 = L.wo_newton_step(o2.h, C.byref(opt2), 0, dt, ol.dp(y2), ol.dp(l2), ol.dp(f2w), C.byref(kits2), C.byref(mr2))
+        t_whole = time.time() - t0
+        o2.close()
+        model2 = t_res2 + t_row2 + t_set2 + kits2.value * t_it2     # the step ends with a residual evaluation: t_res2
+        whole = {"mesh": "%dx%dx%d eos_%s%s (%d cells), dt %.3g s, initial state of the benchmark" % (tuple(int(v) for v in lm2.dims) + (eos, " + 1 MINC level" if minc else "", o2.n_owned, dt)),
+                 "seconds": t_whole, "krylov_iterations": kits2.value, "reason": int(r2),
+                 "modelled_seconds": model2, "measured_over_modelled": t_whole / model2,
+                 "pieces": {"residual": t_res2, "jacobian_per_row": t_row2, "jacobian_coloured": t_col2, "pc_setup": t_set2, "krylov_iteration": t_it2},
+                 "seconds_with_coloured_jacobian": t_whole - t_row2 + t_col2, "threads": int(best_t)}
+        log("  cpu baseline: whole oracle Newton step on %s: %.2f s measured, %.2f s modelled (%d Krylov iterations)"
+            % (whole["mesh"], t_whole, model2, kits2.value))
+        if t_col is None:
+            t_col = t_jac * t_col2 / t_row2
+            col_note = " (scaled from the 100^3 mesh of the same kind: %.2f s coloured against %.2f s per-row there)" % (t_col2, t_row2)
+    except Exception as e:   # the validation must not take the baseline down with it
+        log("  cpu baseline: whole-step validation failed: %r" % (e,))
+    n = n_big
     t_newton = t_res + t_jac + t_setup + kits_per_newton * t_iter
     model = "unknown"
     try:
@@ -315,6 +351,9 @@ def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0, gpu_s
                        "krylov_iteration": t_iter}}
     if t_col:
         out["value_with_coloured_jacobian"] = 1.0 / (t_newton - t_jac + t_col)
+    if whole:
+        out["measured_whole_step"] = whole
+        out["host"] = {"cpu": model, "hardware_threads": avail, "cpu_quota": quota, "threads_used": int(best_t)}
     if vs_oracle:
         out["vs_oracle"] = vs_oracle
     return out

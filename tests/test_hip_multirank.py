@@ -166,7 +166,7 @@ def _brick_lists(lm):
 
 
 def _shape_steps(sim, y, nsteps, dt0):
-    sim.set_opts(ksp_rtol=1e-12, ftol_rel=1e-10)
+    sim.set_opts(ksp_rtol=1e-12, ftol_rel=1e-9)
     dt, t, out = dt0, 0.0, []
     for _ in range(nsteps):
         reason, nits, kits = sim.timestep(t, dt, y)
@@ -189,7 +189,7 @@ def _shape_worker(rank, world, uid_q, q, spec):
     else:
         uid = uid_q.get(timeout=300)
     part = M.partition_shape(world)
-    g, lm, prim, region = make_case(dims=spec["dims"], brick=spec["brick"], eos=spec["eos"], lens=False, part=part, rank=rank,
+    g, lm, prim, region = make_case(dims=spec["dims"], brick=spec["brick"], eos=spec["eos"], lens=True, part=part, rank=rank,
                                     minc=spec["minc"], order=spec["order"])
     sim = FlowSimulation(lm, eos=spec["eos"], device=0)
     sim.set_regions(region)
@@ -239,7 +239,7 @@ def test_baseline_shardings_of_3x3_blocks(shape, overlap):
         p.join(timeout=60)
         assert p.exitcode == 0
     eos, dims = spec["eos"], spec["dims"]
-    g, lm, prim, region = make_case(dims=dims, brick=spec["brick"], eos=eos, lens=False, minc=spec["minc"], order=spec["order"])
+    g, lm, prim, region = make_case(dims=dims, brick=spec["brick"], eos=eos, lens=True, minc=spec["minc"], order=spec["order"])   # lens: 125 m layers
     sim = FlowSimulation(lm, eos=eos, device=0)
     sim.set_regions(region)
     bs = sim.num_primary_variables

@@ -274,7 +274,14 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
   // run-time environment only steers what the tests compare in one process (WAI_BCGS_MERGED, WAI_JAC_PARK,
   // WAI_HALO_OVERLAP) and the transport library (WAI_RCCL_LIB).
   s.diag_only = !offdiag_fill && !s.big;
-  s.level_sorted = false;
+  s.level_sorted = !s.big;
+  for (int sd = 0; sd < s.nsub && s.level_sorted; sd++)
+    for (int i = sub[sd] + 1; i < sub[sd + 1]; i++)
+      if (levf[i] < levf[i - 1] || levb[i] > levb[i - 1]) { s.level_sorted = false; break; }
+  {
+    const char* e = getenv("WAI_PC_WAVESTAGE");   // read when the schedule is built: same-process A/B of the two sweep forms
+    s.wave_staged = s.level_sorted && !(e && e[0] == '0');
+  }
   s.fast3 = fast3;
   s.scaled = true;
 #ifdef WAI_ILU_GENERAL
@@ -1282,8 +1289,15 @@ int wait_post(wai_ctx* c, int seq) {
 //   0 petsc   the reductions where KSPSolve_BCGS has them: five launches (one rank only; several ranks run "merged")
 //   1 merged  the second half's five inner products in one reduction, (R,R) and (R,RP) derived: five launches (+ two
 //             one-thread scalar kernels behind the all-reduces on several ranks) -- round 3's multi-rank form
-//   2 fused   merged reductions, S = R - alpha V formed inside the second fused launch and the X / R / next-P updates in
-//             one pass: THREE launches and 9 vector passes beside the two matrix sweeps (default)
+//   2 fused   merged reductions and the X / R / next-P updates in ONE pass (k_bcgs_xrp, which re-forms S from R and V):
+//             FOUR launches -- fused A P, S = R - alpha V, fused A S, X / R / P -- and 11 vector passes beside the two
+//             matrix sweeps where "petsc" makes 14 (default).
+//             WAI_BCGS_COMPOSE=1: S is not stored at all, the second fused launch forms R - alpha V itself (own row and
+//             neighbour gathers): THREE launches, 9 passes -- and MEASURED SLOWER at every full size: the second gather
+//             per matrix slot costs the launch 0.56 -> 0.73 ms at 216^3 (the gathers, not the matrix stream, fill the
+//             vector-cache's request slots), more than k_bcgs_s's 0.07 ms; same box, ms per iteration petsc / fused /
+//             composed: c3 1.530 / -- / 1.542, c4 1.562 / -- / 1.649, c5 0.559 / -- / 0.578; only the 108^3 rank share
+//             gains (0.245 -> 0.235).  Kept selectable; bit-identical to the stored-S form (tests/test_hip_pc.py).
 int bcgs_mode(const wai_ctx* c) {
   const bool multi = c->comm && c->comm->nranks > 1;
   int mode = 2;
@@ -1295,8 +1309,11 @@ int bcgs_mode(const wai_ctx* c) {
   if (multi && mode == 0) mode = 1;
   return mode;
 }
-// can the second fused launch form S itself?  (the fused brick kernels, no network blocks beside the matrix)
-bool pc_axpy_ok(const wai_ctx* c) { return pc_fused(c) && !c->net.cp_valid && pc_axpy_capable(c) && !getenv("WAI_BCGS_STORE_S"); }
+// does the second fused launch form S itself?  (asked for, the fused brick kernels, no network blocks beside the matrix)
+bool pc_axpy_ok(const wai_ctx* c) {
+  const char* e = getenv("WAI_BCGS_COMPOSE");
+  return e && e[0] == '1' && pc_fused(c) && !c->net.cp_valid && pc_axpy_capable(c);
+}
 
 struct BcgsPlan { int mode; bool fused3, merged, axpy, multi; };
 BcgsPlan bcgs_plan(const wai_ctx* c) {
@@ -1352,9 +1369,9 @@ int bcgs_second_half(wai_ctx* c, const BcgsPlan& pl) {
 // ends an iteration's reductions posts the scalars to the pinned host mirror: no k_finalize launches, no copy, no event.
 // petsc / merged -- five launches: P update, fused A*P + ILU solve + (V,RP) + alpha, S update, fused A*S + ILU solve +
 // its inner products (+ omega), X/R update (+ (R,R),(R,RP) + rho/beta).
-// fused -- three: fused A*P + ILU solve + (V,RP) + alpha; fused A*(R - alpha V) + ILU solve + (S,T),(T,T),(S,S),(S,RP),
-// (T,RP) + omega, (R,R), rho, beta, posted; X / R / P update.  (A preconditioner that cannot take the composed operand
-// -- unfused paths, network blocks -- gets S from k_bcgs_s: four launches.)
+// fused -- four: fused A*P + ILU solve + (V,RP) + alpha; S = R - alpha V; fused A*S + ILU solve + (S,T),(T,T),(S,S),(S,RP),
+// (T,RP) + omega, (R,R), rho, beta, posted; X / R / P update in one pass.  (WAI_BCGS_COMPOSE=1: three, S formed inside the
+// second fused launch -- measured slower, bcgs_mode.)
 int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
   Krylov& k = c->ks;
   const int n = k.n;

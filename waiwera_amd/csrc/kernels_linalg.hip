@@ -1130,7 +1130,13 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
 // three resident workgroups per CU (3 x 51 KB of the 160 KB LDS), so one more brick's loads are in
 // flight to cover the latency-bound sweeps of the others.
 // MEASURED (216^3, MI355X, same box): 0.604 ms against k_pc's 0.709 ms; 68 VGPRs, no spills.
-template <bool SPMV, bool AX>
+// WS (wave-staged sweeps; bricks whose rows are stored in dependency-level order): a wave's 64 consecutive rows then
+// span a contiguous range of levels, and a row's lower couplings lie in the same wave or an earlier one.  Inside a wave
+// no barrier is needed at all -- the LDS executes a wave's instructions in order, a level's writes are seen by the next
+// level's reads (k_pc_wave's argument) -- so the workgroup barrier is only the hand-over from one wave to the next:
+// nw barriers per sweep instead of one per level (8 instead of 32 for a 16 x 16 x 2 brick), and a level costs its LDS
+// round trip and FMA chain without the barrier's arrival / release latency on top.  Same row arithmetic: identical bits.
+template <bool SPMV, bool AX, bool WS>
 __global__ __launch_bounds__(512, 6) void k_pc_park(
     int n, int W, int nsub, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev,
     const int* __restrict__ row_info, const int* __restrict__ row_uoff, const int* __restrict__ col,
@@ -1234,6 +1240,27 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
       sum[r] = (part[0] + part[1]) + part[2];
     }
   };
+  const int wv = tid >> 6, nw = (int)(blockDim.x >> 6);
+  if constexpr (WS) {
+    // forward, wave by wave: the rows of wave wv span levels lv0 .. lv1 (level order: lf is non-decreasing in tid)
+    int lv0 = __builtin_amdgcn_readfirstlane(active ? lf : 0x7fffffff), lv1 = active ? lf : -1;
+    for (int off = 32; off > 0; off >>= 1) lv1 = max(lv1, __shfl_xor(lv1, off));
+    lv0 = min(lv0, __shfl(active ? lf : 0x7fffffff, 0));
+    for (int st = 0; st < nw; st++) {
+      if (wv == st) {
+        for (int lev = max(lv0, 1); lev <= lv1; lev++) {
+          if (lf == lev) {
+            const double2 a = *reinterpret_cast<const double2*>(ys + tid * 2);
+            double sum[BS];
+            gather3(Lc, Lf, sum);
+            *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(a.x - sum[0], a.y - sum[1]);
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      __syncthreads();
+    }
+  } else {
   for (int lev = 1; lev < nlf; lev++) {  // forward: y_i = t_i - sum A'_ik y_k
     if (lf == lev) {
       const double2 a = *reinterpret_cast<const double2*>(ys + tid * 2);
@@ -1242,6 +1269,7 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
       *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(a.x - sum[0], a.y - sum[1]);
     }
     __syncthreads();
+  }
   }
   PH(2);
   // the lower blocks are dead: their registers take the parked upper blocks
@@ -1254,6 +1282,27 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
     Lf[p][2] = have ? u1.x : 0.0; Lf[p][3] = have ? u1.y : 0.0;
   }
   double out[BS] = {0.0, 0.0};
+  if constexpr (WS) {
+    // backward, from the last wave to the first: lb is non-increasing in tid
+    int lb1 = active ? lb : -1, lb0 = active ? lb : 0x7fffffff;
+    for (int off = 32; off > 0; off >>= 1) { lb1 = max(lb1, __shfl_xor(lb1, off)); lb0 = min(lb0, __shfl_xor(lb0, off)); }
+    for (int st = nw - 1; st >= 0; st--) {
+      if (wv == st) {
+        for (int lev = lb0; lev <= lb1; lev++) {
+          if (lb == lev) {
+            const double2 a = *reinterpret_cast<const double2*>(ys + tid * 2);
+            double sum[BS];
+            gather3(Uc, Lf, sum);
+            out[0] = a.x - sum[0];
+            out[1] = a.y - sum[1];
+            *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(out[0], out[1]);
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      if (st > 0) __syncthreads();
+    }
+  } else {
   for (int lev = 0; lev < nlb; lev++) {  // backward: x_i = y_i - sum A'_ij x_j
     if (lb == lev) {
       const double2 a = *reinterpret_cast<const double2*>(ys + tid * 2);
@@ -1264,6 +1313,7 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
       *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(out[0], out[1]);
     }
     if (lev + 1 < nlb) __syncthreads();
+  }
   }
   PH(3);
   if (active) store_z2(z, (size_t)i, out[0], out[1]);
@@ -2271,12 +2321,17 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
     // upper blocks parked in LDS: three resident workgroups per CU
     if (kind == 1) {
       const size_t lds_park = lds + (size_t)s.max_ublocks * 4 * sizeof(double);
-#define PCP(SP, AXV)                                                                               \
-      hipLaunchKernelGGL((k_pc_park<SP, AXV>), grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,  \
+#define PCP(SP, AXV, WSV)                                                                          \
+      hipLaunchKernelGGL((k_pc_park<SP, AXV, WSV>), grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,  \
                          s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, in2, scal, z, aux, c->ks.partials,       \
                          c->ks.nb_max, dot_mode, list, fin)
-      if (spmv) { if (in2) PCP(true, true); else PCP(true, false); }
-      else PCP(false, false);
+      if (s.wave_staged) {
+        if (spmv) { if (in2) PCP(true, true, true); else PCP(true, false, true); }
+        else PCP(false, false, true);
+      } else {
+        if (spmv) { if (in2) PCP(true, true, false); else PCP(true, false, false); }
+        else PCP(false, false, false);
+      }
 #undef PCP
       return;
     }

@@ -157,7 +157,7 @@ module waiwera_hip_module
        integer(c_int), value :: n_global
        integer(c_int), intent(in) :: global_index(*)
      end function wai_set_source_global_index
-     ! kernels launched / copies enqueued by the linear solver so far (a BiCGStab iteration: 5 kernels, no copy)
+     ! kernels launched / copies enqueued by the linear solver so far (a BiCGStab iteration: 4 kernels, no copy)
      integer(c_int) function wai_launch_stats(ctx, kernels, copies) bind(c, name = "wai_launch_stats")
        import :: c_int, c_ptr, c_long_long
        type(c_ptr), value :: ctx
