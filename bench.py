@@ -399,7 +399,9 @@ def main():
     ap.add_argument("--rank-share", type=int, default=0,
                     help="run one rank's share of the N-GPU decomposition (dims / partition) on one GPU and report the iteration's cost")
     ap.add_argument("--ksp", default="bcgs")
-    ap.add_argument("--pc", default="bjacobi", choices=["bjacobi", "asm", "none"])
+    ap.add_argument("--pc", default="bjacobi", choices=["bjacobi", "asm", "none", "ilu"],
+                    help="ilu: ONE ILU(0) block per rank (the reference's own layout, sub_ptr = NULL: src/timestepper.F90:1668-1669) "
+                         "on the launch-per-level path")
     ap.add_argument("--ilu-levels", type=int, default=0, help="ILU(k) sub-preconditioner (factor.levels); k > 0 runs the unfused extended-system path")
     ap.add_argument("--no-lens", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
@@ -483,8 +485,13 @@ def main():
     brick = tuple(a.brick) if a.brick else ((4, 4, 2) if minc else ((8, 4, 2) if eos == "wce" else (16, 16, 2)))
     grid, lm, prim, region = make_case(dims=dims, brick=brick, eos=eos, lens=not a.no_lens, minc=minc,
                                        part=M.partition_shape(world), rank=rank, brick_order=a.brick_order, order=a.cell_order)
-    opts = wl.default_opts(ksp_type=a.ksp, pc_type=a.pc, ilu_levels=a.ilu_levels)
+    opts = wl.default_opts(ksp_type=a.ksp, pc_type="bjacobi" if a.pc == "ilu" else a.pc, ilu_levels=a.ilu_levels)
+    n_bricks = lm.sub_ptr.size - 1
+    if a.pc == "ilu":
+        lm.sub_ptr = None                      # one block per rank
     sim = FlowSimulation(lm, eos=eos, opts=opts, device=local_rank)
+    if a.pc == "ilu":
+        lm.sub_ptr = np.array([0, lm.n_owned], dtype=np.int32)
     sim.set_regions(region)
     if world > 1:
         uid = [wl.comm_unique_id() if rank == 0 else None]
@@ -679,7 +686,8 @@ def main():
 
     if rank == 0:
         ksp_name = {"bcgs": "BiCGStab", "gmres": "GMRES(30)"}.get(a.ksp, a.ksp)
-        pc_name = {"bjacobi": "block-Jacobi", "asm": "ASM overlap 1 (restricted)", "none": "no preconditioner"}[a.pc]
+        pc_name = {"bjacobi": "block-Jacobi", "asm": "ASM overlap 1 (restricted)", "none": "no preconditioner",
+                   "ilu": "one ILU(0) block per rank, launch per level; "}[a.pc]
         ilu_name = "ILU(%d)" % a.ilu_levels
         n_newton = max(a.steps, 1)
         launches = (ls1[0] - ls0[0]) / max(kits, 1)

@@ -461,7 +461,10 @@ def test_asm_overlap_reaches_across_ranks(world, eos):
     # scalar blocks: the same arithmetic, 3e-16 measured.  2 x 2 blocks: the definition here eliminates scalar by scalar
     # without pivoting, the device inverts the pivot blocks (mass and energy rows 1e6 apart) with partial pivoting --
     # equal up to the blocks' conditioning, 2.6e-10 (2 ranks) / 2.7e-9 (8 ranks) measured
-    assert worst < (1e-12 if bs == 1 else 1e-7), worst
+    # 3 x 3 blocks (eos wce): pressure, temperature and gas-fraction rows lie 1e6 .. 1e8 apart inside a pivot block, and the
+    # two eliminations round its inverse differently by that conditioning: 2.5e-6 measured, with the Krylov solutions of the
+    # two decompositions agreeing to 8.6e-13
+    assert worst < (1e-12 if bs == 1 else (1e-7 if bs == 2 else 2e-5)), worst
     assert worst_x < 1e-8, worst_x
 
 

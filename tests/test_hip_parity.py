@@ -129,6 +129,35 @@ def test_jacobian_kernels_agree_bitwise(FS, oracle, eos, monkeypatch):
     sim.destroy(); osim.close()
 
 
+@pytest.mark.parametrize("eos,dims", [("w", (12, 12, 12)), ("we", (12, 12, 12)), ("wce", (12, 12, 12)), ("wse", (12, 12, 12)),
+                                      ("we", (13, 11, 7))])
+def test_residual_kernels_agree_bitwise(FS, oracle, eos, dims, monkeypatch):
+    """k_residual_tile (the workgroup's own cells parked in LDS, in-tile neighbours read from there: the default of a
+    full sweep) and k_residual (WAI_RES_TILE=0: every neighbour gathered from memory) load the same doubles and do the
+    same arithmetic in the same order: identical lhs, rhs and residual, with the two-phase lens in the mesh; 13 x 11 x 7
+    cells leave the last workgroup's tile ragged."""
+    g, lm, sim, osim, y, region = build(FS, oracle, eos=eos, dims=dims, brick=(4, 4, 2), lens=True)
+    n = sim.n_owned * sim.num_primary_variables
+    dt = 2.0e4
+    yo = osim.yvec(y)
+    assert sim.pre_eval(0.0, y) == 0 and osim.pre_eval(yo) == 0
+    L = osim.lhs()
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("WAI_RES_TILE", flag)
+        f, lhs, rhs = np.zeros(n), np.zeros(n), np.zeros(n)
+        assert sim.residual(0.0, dt, y, L, f) == 0
+        sim.lhs(0.0, (0.0, 0.0), y, lhs)
+        sim.rhs(0.0, (0.0, dt), y, rhs)
+        out[flag] = (f, lhs, rhs)
+    assert np.abs(out["0"][0]).max() > 0.0 and np.abs(out["0"][2]).max() > 0.0
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a, b)
+    err, fo = osim.residual(yo, dt, L)
+    assert relmax(out["1"][0], fo) < 1e-11
+    sim.destroy(); osim.close()
+
+
 @pytest.mark.parametrize("eos", ["we", "w", "wce", "wsce"])
 def test_spmv_ilu_krylov(FS, oracle, eos):
     g, lm, sim, osim, y, region = build(FS, oracle, eos=eos, dims=(12, 10, 9), brick=(4, 4, 4))

@@ -278,10 +278,6 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
   for (int sd = 0; sd < s.nsub && s.level_sorted; sd++)
     for (int i = sub[sd] + 1; i < sub[sd + 1]; i++)
       if (levf[i] < levf[i - 1] || levb[i] > levb[i - 1]) { s.level_sorted = false; break; }
-  {
-    const char* e = getenv("WAI_PC_WAVESTAGE");   // read when the schedule is built: same-process A/B of the two sweep forms
-    s.wave_staged = s.level_sorted && !(e && e[0] == '0');
-  }
   s.fast3 = fast3;
   s.scaled = true;
 #ifdef WAI_ILU_GENERAL

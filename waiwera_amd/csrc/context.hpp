@@ -172,7 +172,6 @@ struct IluSchedule {
   int max_ublocks_w = 0;
   bool level_sorted = false;  // every subdomain's rows are stored in dependency-level order (forward levels non-decreasing,
                               // backward levels non-increasing with the row index)
-  bool wave_staged = false;   // k_pc_park runs its sweeps wave by wave (level_sorted; WAI_PC_WAVESTAGE=0: per-level barriers)
   bool factored = false;
   // subdomains of more than 1024 rows ("one block per rank", sub_ptr = NULL, is the reference's
   // PCBJACOBI / PCASM default): rows of equal dependency level are independent across all

@@ -151,6 +151,53 @@ __device__ __forceinline__ double res_form(const ResForm& rf, double L, double R
   return (L - l1) - rf.dt * R;
 }
 
+// ---- records parked in LDS (k_residual_tile, k_jacobian_park) ------------------------------------------
+template <int KIND> struct ParkT {
+  using E = EosT<KIND>;
+  static constexpr int nld = 4 + E::nph * (7 + (E::nc > 1 ? E::nc : 0));   // doubles load_state reads
+  static constexpr int threads = E::np <= 2 ? 128 : 64;
+  static constexpr int lds_bytes = E::np * (nld + MAXDEG) * 8 * threads;   // parked states + base terms
+  // three workgroups per CU or the plain kernel: MEASURED 13.7 -> 10.4 ms (we, 216^3), 12.5 -> 11.0 (wce,
+  // 172x172x170; 14.7 with 128 threads = one workgroup per CU); the three-phase salt EOS would hold one
+  static constexpr bool use = lds_bytes <= 54 * 1024;
+};
+template <int KIND>
+__device__ __forceinline__ void park_state(const CellState<KIND>& s, double* __restrict__ b, int st) {
+  using E = EosT<KIND>;
+  int f = 0;
+  b[(f++) * st] = s.P; b[(f++) * st] = s.T; b[(f++) * st] = s.phases; b[(f++) * st] = s.permfac;
+#pragma unroll
+  for (int p = 0; p < E::nph; p++) {
+    b[(f++) * st] = s.rho[p]; b[(f++) * st] = s.mu[p]; b[(f++) * st] = s.sat[p]; b[(f++) * st] = s.kr[p];
+    b[(f++) * st] = s.pc[p]; b[(f++) * st] = s.h[p]; b[(f++) * st] = s.u[p];
+    if constexpr (E::nc > 1) {
+#pragma unroll
+      for (int q = 0; q < E::nc; q++) b[(f++) * st] = s.x[p][q];
+    }
+  }
+}
+template <int KIND>
+__device__ __forceinline__ void unpark_state(const double* __restrict__ b, int st, CellState<KIND>& s) {
+  using E = EosT<KIND>;
+  int f = 0;
+  s.P = b[(f++) * st]; s.T = b[(f++) * st]; s.phases = b[(f++) * st]; s.permfac = b[(f++) * st];
+  s.region = 0.0;
+#pragma unroll
+  for (int q = 0; q < E::nc; q++) s.pp[q] = 0.0;
+#pragma unroll
+  for (int p = 0; p < E::nph; p++) {
+    s.rho[p] = b[(f++) * st]; s.mu[p] = b[(f++) * st]; s.sat[p] = b[(f++) * st]; s.kr[p] = b[(f++) * st];
+    s.pc[p] = b[(f++) * st]; s.h[p] = b[(f++) * st]; s.u[p] = b[(f++) * st];
+    if constexpr (E::nc == 1) {
+      s.x[p][0] = (((int)s.phases >> p) & 1) ? 1.0 : 0.0;
+    } else {
+#pragma unroll
+      for (int q = 0; q < E::nc; q++) s.x[p][q] = b[(f++) * st];
+    }
+  }
+}
+
+
 // ---- K2-K4: residual -------------------------------------------------------------------------
 template <int KIND>
 __global__ __launch_bounds__(TPB) void k_residual(MeshView m, const double* __restrict__ flu,
@@ -193,6 +240,88 @@ __global__ __launch_bounds__(TPB) void k_residual(MeshView m, const double* __re
     for (int k = 0; k < E::np; k++) R[k] += term[k];
   }
   source_terms<KIND>(m, c, own, vol, R, only == nullptr);   // a full sweep is an unperturbed evaluation (the row list: network_couplings)
+#pragma unroll
+  for (int k = 0; k < E::np; k++) {
+    if (lhs_out) lhs_out[(size_t)c * E::np + k] = L[k];
+    if (rhs_out) rhs_out[(size_t)c * E::np + k] = R[k];
+    if (f) {
+      const size_t i = (size_t)c * E::np + k;
+      f[i] = res_form(rf, L[k], R[k], rf.last[i], rf.method == WAI_METHOD_BDF2 ? rf.last2[i] : 0.0);
+    }
+  }
+}
+
+// ---- K2-K4 with the workgroup's own cells staged in LDS -----------------------------------------------
+// k_residual gathers a neighbour's record (state + rock: 26 doubles for eos we) from memory for every face, in-brick
+// neighbours included, and NONE of these gathers hits a cache: the XCD's 32 CUs stream ~14 MB of records through its
+// 4 MB L2 while a workgroup lives, so a line fetched as one wave's own record is gone when another wave asks for it as
+// a neighbour's (PMC, 216^3: 1.6 KB of L2-miss traffic per cell = every load of the kernel, 3.4 x the algorithmic
+// bytes).  Here a workgroup's T = 256 consecutive cells (half a 16 x 16 x 2 brick) park the records they have loaded
+// anyway -- state as park_state lays it out, and the rock fields the flux reads -- in LDS, field-major (a wave
+// instruction reads or writes 64 consecutive doubles of one plane: conflict-free), and a neighbour inside the tile is
+// read from there; only neighbours outside the tile (the brick above / below, the other half) are gathered from memory.
+// Same loads of the same doubles, same arithmetic in the same order: bit-identical residuals.
+template <int KIND> struct ResTile {
+  using E = EosT<KIND>;
+  static constexpr int nld = ParkT<KIND>::nld, nrk = 5;       // state record, rock: k1 k2 k3 wet dry
+  static constexpr int lds_bytes = (nld + nrk) * 8 * TPB;
+};
+template <int KIND>
+__global__ __launch_bounds__(TPB) void k_residual_tile(MeshView m, const double* __restrict__ flu,
+                                                       size_t stride, ResForm rf,
+                                                       double* __restrict__ f, double* __restrict__ lhs_out,
+                                                       double* __restrict__ rhs_out) {
+  using E = EosT<KIND>;
+  constexpr int nld = ResTile<KIND>::nld;
+  extern __shared__ double tile[];
+  const int st = (int)blockDim.x;
+  // the tile: cells c0 .. c1 - 1 (xcd_cell's block mapping)
+  const int nblk = (m.n_owned + st - 1) / st, per = (nblk + 7) >> 3;
+  const int b = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (((int)blockIdx.x >> 3) >= per || b >= nblk) return;   // padding workgroup (uniform)
+  const int c0 = b * st, c1 = min(c0 + st, m.n_owned);
+  const int c = c0 + (int)threadIdx.x;
+  const bool active = c < c1;
+  CellState<KIND> own;
+  RockState rown;
+  double* rk = tile + (size_t)nld * st + threadIdx.x;
+  if (active) {
+    load_state<KIND>(flu, stride, c, own);
+    load_rock(m.rock, m.n_local, c, rown);
+    park_state<KIND>(own, tile + threadIdx.x, st);
+    rk[0] = rown.k[0]; rk[st] = rown.k[1]; rk[2 * st] = rown.k[2]; rk[3 * st] = rown.wet; rk[4 * st] = rown.dry;
+  }
+  __syncthreads();
+  if (!active) return;
+  const double vol = m.vol[c];
+  double L[E::np], R[E::np];
+  cell_balance<KIND>(own, rown, L);
+#pragma unroll
+  for (int k = 0; k < E::np; k++) R[k] = 0.0;
+  for (int s = 0; s < m.max_deg; s++) {
+    const int fs = m.adj_face[(size_t)s * m.n_owned + c];
+    if (fs < 0) continue;
+    const int o = m.adj_other[(size_t)s * m.n_owned + c];
+    FaceGeom g;
+    load_face(m, fs >> 1, g);
+    CellState<KIND> oth;
+    RockState roth;
+    if (o >= c0 && o < c1) {   // a cell of this tile: its record is in LDS
+      const int lo = o - c0;
+      unpark_state<KIND>(tile + lo, st, oth);
+      const double* ro = tile + (size_t)nld * st + lo;
+      roth.k[0] = ro[0]; roth.k[1] = ro[st]; roth.k[2] = ro[2 * st]; roth.wet = ro[3 * st]; roth.dry = ro[4 * st];
+      roth.phi = 0.0; roth.rho = 0.0; roth.cp = 0.0;   // the flux reads permeabilities and conductivities only
+    } else {
+      load_state<KIND>(flu, stride, o, oth);
+      load_rock(m.rock, m.n_local, o, roth);
+    }
+    double term[E::np];
+    slot_term<KIND>(g, fs & 1, own, rown, oth, roth, vol, term);
+#pragma unroll
+    for (int k = 0; k < E::np; k++) R[k] += term[k];
+  }
+  source_terms<KIND>(m, c, own, vol, R, true);   // a full sweep is an unperturbed evaluation
 #pragma unroll
   for (int k = 0; k < E::np; k++) {
     if (lhs_out) lhs_out[(size_t)c * E::np + k] = L[k];
@@ -298,7 +427,7 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
 #pragma unroll
     for (int r = 0; r < np; r++) {
       const double f1 = res_form(rf, Lk[r], R[r], lold[r], lold2[r]);
-      val[ell_ix(np, nrow, dq, r, k, (size_t)c)] = (f1 - f0[r]) / h;
+      __builtin_nontemporal_store((f1 - f0[r]) / h, val + ell_ix(np, nrow, dq, r, k, (size_t)c));
     }
   }
 
@@ -334,7 +463,7 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
 #pragma unroll
       for (int r = 0; r < np; r++) {
         const double f1 = res_form(rf, L0[r], R[r] + src0[r], lold[r], lold2[r]);
-        val[ell_ix(np, nrow, blk, r, k, (size_t)c)] += (f1 - f0[r]) / h;
+        __builtin_nontemporal_store((f1 - f0[r]) / h, val + ell_ix(np, nrow, blk, r, k, (size_t)c));
       }
     }
   }
@@ -351,51 +480,6 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
 // and face record are loaded once for all of them: 21 instead of 33 state records per cell for np = 2,
 // 13 instead of 25 rock records, 12 instead of 24 face records.  Same evaluations, same summation
 // order, bit-identical blocks.
-template <int KIND> struct ParkT {
-  using E = EosT<KIND>;
-  static constexpr int nld = 4 + E::nph * (7 + (E::nc > 1 ? E::nc : 0));   // doubles load_state reads
-  static constexpr int threads = E::np <= 2 ? 128 : 64;
-  static constexpr int lds_bytes = E::np * (nld + MAXDEG) * 8 * threads;   // parked states + base terms
-  // three workgroups per CU or the plain kernel: MEASURED 13.7 -> 10.4 ms (we, 216^3), 12.5 -> 11.0 (wce,
-  // 172x172x170; 14.7 with 128 threads = one workgroup per CU); the three-phase salt EOS would hold one
-  static constexpr bool use = lds_bytes <= 54 * 1024;
-};
-template <int KIND>
-__device__ __forceinline__ void park_state(const CellState<KIND>& s, double* __restrict__ b, int st) {
-  using E = EosT<KIND>;
-  int f = 0;
-  b[(f++) * st] = s.P; b[(f++) * st] = s.T; b[(f++) * st] = s.phases; b[(f++) * st] = s.permfac;
-#pragma unroll
-  for (int p = 0; p < E::nph; p++) {
-    b[(f++) * st] = s.rho[p]; b[(f++) * st] = s.mu[p]; b[(f++) * st] = s.sat[p]; b[(f++) * st] = s.kr[p];
-    b[(f++) * st] = s.pc[p]; b[(f++) * st] = s.h[p]; b[(f++) * st] = s.u[p];
-    if constexpr (E::nc > 1) {
-#pragma unroll
-      for (int q = 0; q < E::nc; q++) b[(f++) * st] = s.x[p][q];
-    }
-  }
-}
-template <int KIND>
-__device__ __forceinline__ void unpark_state(const double* __restrict__ b, int st, CellState<KIND>& s) {
-  using E = EosT<KIND>;
-  int f = 0;
-  s.P = b[(f++) * st]; s.T = b[(f++) * st]; s.phases = b[(f++) * st]; s.permfac = b[(f++) * st];
-  s.region = 0.0;
-#pragma unroll
-  for (int q = 0; q < E::nc; q++) s.pp[q] = 0.0;
-#pragma unroll
-  for (int p = 0; p < E::nph; p++) {
-    s.rho[p] = b[(f++) * st]; s.mu[p] = b[(f++) * st]; s.sat[p] = b[(f++) * st]; s.kr[p] = b[(f++) * st];
-    s.pc[p] = b[(f++) * st]; s.h[p] = b[(f++) * st]; s.u[p] = b[(f++) * st];
-    if constexpr (E::nc == 1) {
-      s.x[p][0] = (((int)s.phases >> p) & 1) ? 1.0 : 0.0;
-    } else {
-#pragma unroll
-      for (int q = 0; q < E::nc; q++) s.x[p][q] = b[(f++) * st];
-    }
-  }
-}
-
 template <int KIND>
 __global__ __launch_bounds__(ParkT<KIND>::threads, (EosT<KIND>::np <= 2 ? 2 : 1)) void k_jacobian_park(MeshView m, const double* __restrict__ flu,
                                                   size_t stride, const double* __restrict__ flu_pert,
@@ -495,11 +579,17 @@ __global__ __launch_bounds__(ParkT<KIND>::threads, (EosT<KIND>::np <= 2 ? 2 : 1)
 #pragma unroll
     for (int r = 0; r < np; r++) {
       const double f1 = res_form(rf, Lk[k][r], Rk[k][r], lold[r], lold2[r]);
-      val[ell_ix(np, nrow, dq, r, k, (size_t)c)] = (f1 - f0[r]) / h;
+      __builtin_nontemporal_store((f1 - f0[r]) / h, val + ell_ix(np, nrow, dq, r, k, (size_t)c));
     }
   }
 
-  // off-diagonal blocks: neighbour across slot s perturbed in component k
+  // off-diagonal blocks: neighbour across slot s perturbed in component k.  SHARE (128-thread workgroups, np <= 2): a
+  // neighbour that belongs to this workgroup has its perturbed states in LDS already -- they are what its thread parked
+  // -- so they are taken from there instead of memory (MEASURED, round 3: 10.38 -> 10.05 ms at 216^3; the 64-thread
+  // workgroups of 3 x 3 blocks hold few of their own neighbours and lose to the divergent branch: 11.1 -> 12.3 ms at C4)
+  constexpr bool SHARE = np <= 2;
+  const int c0 = c - (int)threadIdx.x, c1 = min(c0 + st, m.n_owned);
+  if constexpr (SHARE) __syncthreads();   // every thread's states are parked
 #pragma unroll 1
   for (int s = 0; s < m.max_deg; s++) {
     if (!((valid >> s) & 1u)) continue;
@@ -514,7 +604,8 @@ __global__ __launch_bounds__(ParkT<KIND>::threads, (EosT<KIND>::np <= 2 ? 2 : 1)
 #pragma unroll
     for (int k = 0; k < np; k++) {
       CellState<KIND> othk;
-      load_state<KIND>(flu_pert + (size_t)k * E::df * n_prim, (size_t)n_prim, o, othk);
+      if (SHARE && o >= c0 && o < c1) unpark_state<KIND>(park + (size_t)k * nld * st + (o - c0), st, othk);   // what its thread parked
+      else load_state<KIND>(flu_pert + (size_t)k * E::df * n_prim, (size_t)n_prim, o, othk);
       double term[np], R[np];
       slot_term<KIND>(g, fs & 1, own0, rown, othk, roth, vol, term);
 #pragma unroll
@@ -530,7 +621,7 @@ __global__ __launch_bounds__(ParkT<KIND>::threads, (EosT<KIND>::np <= 2 ? 2 : 1)
 #pragma unroll
       for (int r = 0; r < np; r++) {
         const double f1 = res_form(rf, L0[r], R[r] + src0[r], lold[r], lold2[r]);
-        val[ell_ix(np, nrow, blk, r, k, (size_t)c)] += (f1 - f0[r]) / h;
+        __builtin_nontemporal_store((f1 - f0[r]) / h, val + ell_ix(np, nrow, blk, r, k, (size_t)c));
       }
     }
   }
@@ -922,6 +1013,21 @@ int launch_residual(wai_ctx* c, double dt, const double* lhs_old, double* f, dou
                     double* rhs_out, const int* only, int n_only) {
   const MeshView m = view(c);
   const size_t stride = c->mesh.n_local;
+  const char* et = getenv("WAI_RES_TILE");   // read per call: tests compare the two kernels in one process
+  if (!only && !(et && et[0] == '0')) {   // a full sweep: the workgroup's own cells staged in LDS
+    const ResForm rf = res_form_of(c, dt, lhs_old);
+    const int g = grid8_for(m.n_owned);
+#define RT(K) hipLaunchKernelGGL(k_residual_tile<K>, g, TPB, ResTile<K>::lds_bytes, c->stream, m, c->flu, stride, rf, f, lhs_out, rhs_out)
+    if (c->kind == EOS_W) RT(EOS_W);
+    else if (c->kind == EOS_WE) RT(EOS_WE);
+    else if (c->kind == EOS_WSE) RT(EOS_WSE);
+    else if (c->kind == EOS_WAE) RT(EOS_WAE);
+    else if (c->kind == EOS_WSCE) RT(EOS_WSCE);
+    else if (c->kind == EOS_WSAE) RT(EOS_WSAE);
+    else RT(EOS_WCE);
+#undef RT
+    return 0;
+  }
   WAI_BY_EOS(c, k_residual, only ? grid_for(n_only) : grid8_for(m.n_owned), m, c->flu, stride,
              res_form_of(c, dt, lhs_old), f, lhs_out, rhs_out, only, n_only);
   return 0;
@@ -931,7 +1037,10 @@ int launch_jacobian(wai_ctx* c, double dt, const double* lhs_old) {
   const MeshView m = view(c);
   if (m.max_deg > MAXDEG) { c->err = "cell with more than 8 faces not supported"; return -1; }
   const size_t stride = c->mesh.n_local;
-  hipMemsetAsync(c->J.val, 0, sizeof(double) * (size_t)c->J.W * c->np * c->np * c->J.n, c->stream);
+  // No clearing pass and no read-modify-write: two cells share at most one face (wai_ctx_create refuses duplicate
+  // connections), so every block of a row is produced by exactly one adjacency slot and is STORED; the padding slots of
+  // the block-ELL planes were zeroed once at creation and nobody writes them.  (Rounds 1-3 zeroed the 2.5 GB of a
+  // 216^3 matrix before every assembly and accumulated into it: 4.6 GB of the launch's traffic.)
   const char* ep = getenv("WAI_JAC_PARK");   // read per call: tests compare the two kernels in one process
   const bool park = !(ep && ep[0] == '0');
   if (park) {

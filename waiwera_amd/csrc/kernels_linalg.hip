@@ -693,51 +693,66 @@ __device__ __forceinline__ void derive_scalars(double* s, int phase) {
 // counters, no fence, 0.70 ms (each workgroup holds its CU slot ~2 us longer for the store acknowledgement
 // and the returning atomic).
 constexpr unsigned long long FIN_EMPTY = 0x7FF4DEADBEEF0001ull;
+constexpr int FIN_MAXS = 5;   // reduction slots summed together (the merged BiCGStab reductions: five)
 // sums of nslots slots -> scal, k_finalize's order, by a workgroup of any size (multiple of 64).  A virtual
-// thread's partials are fetched eight at a time -- independent agent-scope loads in flight together; one dependent
-// round trip per entry cost 2 us each, 40 us at 21 168 partials (MEASURED: k_pc_park 603 us under rocprofv3 against
-// 583 before the reductions moved into it) -- and added in ascending order; an entry that has not arrived yet is
-// polled (bounded: a partial that never arrives becomes a NaN sum, KSP_DIVERGED_NANORINF, not a hung device).
+// thread's partials are fetched four at a time FOR ALL (<= 5) SLOTS TOGETHER -- up to 20 independent agent-scope loads in
+// flight; one dependent round trip per entry cost 2 us each, 40 us at 21 168 partials (MEASURED: k_pc_park 603 us under
+// rocprofv3 against 583 before the reductions moved into it), and slot after slot (round 3) the five merged BiCGStab
+// reductions cost the second fused launch 0.09 ms at 216^3 (MEASURED round 4: 0.70 against 0.61 ms with two) -- and added
+// per slot in ascending order; an entry that has not arrived yet is polled (bounded: a partial that never arrives becomes
+// a NaN sum, KSP_DIVERGED_NANORINF, not a hung device).
 __device__ __forceinline__ void sum_partials(const double* partials, int nb_max, int nb, int slot0, int nslots,
                                              double* scal, bool wait) {
-  __shared__ double fsm[16];
-  constexpr int CH = 8;
+  __shared__ double fsm[FIN_MAXS][16];
+  constexpr int CH = 4;
   const int VT = nb > 256 ? 1024 : 256;
-  for (int s = 0; s < nslots; s++) {
-    unsigned long long* ps = reinterpret_cast<unsigned long long*>(const_cast<double*>(partials)) + (size_t)(slot0 + s) * nb_max;
+  unsigned long long* p0 = reinterpret_cast<unsigned long long*>(const_cast<double*>(partials)) + (size_t)slot0 * nb_max;
+  for (int sb = 0; sb < nslots; sb += FIN_MAXS) {   // up to FIN_MAXS slots together: their loads are in flight at once
+    const int ns = min(nslots - sb, FIN_MAXS);
     for (int v = threadIdx.x; v < VT; v += blockDim.x) {   // whole waves: blockDim is a multiple of 64
-      double t = 0.0;
+      double t[FIN_MAXS];
+#pragma unroll
+      for (int s = 0; s < FIN_MAXS; s++) t[s] = 0.0;
       for (int i0 = v; i0 < nb; i0 += VT * CH) {
-        unsigned long long u[CH];
+        unsigned long long u[FIN_MAXS][CH];
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
-          const int i = i0 + k * VT;
-          u[k] = i < nb ? __hip_atomic_load(ps + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        }
+        for (int s = 0; s < FIN_MAXS; s++)
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
-          const int i = i0 + k * VT;
-          if (i < nb) {
-            for (int spin = 0; wait && u[k] == FIN_EMPTY && spin < (1 << 22); spin++) {
-              __builtin_amdgcn_s_sleep(8);
-              u[k] = __hip_atomic_load(ps + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            // still empty: the producer never stored it (waited out above), or -- k_finalize, wait = false -- no producer
-            // ran before this consumer.  The sum is a NaN either way; say why (code 4 reaches the host with the post)
-            if (u[k] == FIN_EMPTY) scal[S_BREAK] = 4.0;
-            __hip_atomic_store(ps + i, FIN_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: the slot is empty again
-            t += __longlong_as_double((long long)u[k]);   // FIN_EMPTY itself is a NaN
+          for (int k = 0; k < CH; k++) {
+            const int i = i0 + k * VT;
+            u[s][k] = (s < ns && i < nb) ? __hip_atomic_load(p0 + (size_t)(sb + s) * nb_max + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
           }
-        }
+#pragma unroll
+        for (int s = 0; s < FIN_MAXS; s++)
+#pragma unroll
+          for (int k = 0; k < CH; k++) {
+            const int i = i0 + k * VT;
+            if (s < ns && i < nb) {
+              unsigned long long* ps = p0 + (size_t)(sb + s) * nb_max + i;
+              for (int spin = 0; wait && u[s][k] == FIN_EMPTY && spin < (1 << 22); spin++) {
+                __builtin_amdgcn_s_sleep(8);
+                u[s][k] = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+              // still empty: the producer never stored it (waited out above), or -- k_finalize, wait = false -- no producer
+              // ran before this consumer.  The sum is a NaN either way; say why (code 4 reaches the host with the post)
+              if (u[s][k] == FIN_EMPTY) scal[S_BREAK] = 4.0;
+              __hip_atomic_store(ps, FIN_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: the slot is empty again
+              t[s] += __longlong_as_double((long long)u[s][k]);   // FIN_EMPTY itself is a NaN
+            }
+          }
       }
-      for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
-      if ((v & 63) == 0) fsm[v >> 6] = t;
+#pragma unroll
+      for (int s = 0; s < FIN_MAXS; s++) {
+        double ts = t[s];
+        for (int off = 32; off > 0; off >>= 1) ts += __shfl_down(ts, off);
+        if ((v & 63) == 0) fsm[s][v >> 6] = ts;
+      }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if ((int)threadIdx.x < ns) {
       double tot = 0.0;
-      for (int w = 0; w < (VT >> 6); w++) tot += fsm[w];
-      scal[slot0 + s] = tot;
+      for (int w = 0; w < (VT >> 6); w++) tot += fsm[threadIdx.x][w];
+      scal[slot0 + sb + threadIdx.x] = tot;
     }
     __syncthreads();
   }
@@ -1130,13 +1145,13 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
 // three resident workgroups per CU (3 x 51 KB of the 160 KB LDS), so one more brick's loads are in
 // flight to cover the latency-bound sweeps of the others.
 // MEASURED (216^3, MI355X, same box): 0.604 ms against k_pc's 0.709 ms; 68 VGPRs, no spills.
-// WS (wave-staged sweeps; bricks whose rows are stored in dependency-level order): a wave's 64 consecutive rows then
-// span a contiguous range of levels, and a row's lower couplings lie in the same wave or an earlier one.  Inside a wave
-// no barrier is needed at all -- the LDS executes a wave's instructions in order, a level's writes are seen by the next
-// level's reads (k_pc_wave's argument) -- so the workgroup barrier is only the hand-over from one wave to the next:
-// nw barriers per sweep instead of one per level (8 instead of 32 for a 16 x 16 x 2 brick), and a level costs its LDS
-// round trip and FMA chain without the barrier's arrival / release latency on top.  Same row arithmetic: identical bits.
-template <bool SPMV, bool AX, bool WS>
+// MEASURED AND REMOVED (round 4): wave-staged sweeps.  With a brick's rows in dependency-level order a wave's 64 rows
+// span a contiguous range of levels and need no barrier among themselves (the LDS executes a wave's instructions in
+// order), so the workgroup barrier can shrink to the hand-over from one wave to the next -- 8 per sweep instead of 32.
+// Same bits, and SLOWER on every size: fused launch 0.6175 against 0.5904 ms at 216^3, 0.0960 / 0.0892 at 108^3,
+// 0.0839 / 0.0766 at 100^3 (same box, profiles/bench_r4_wavestage_ab.log): a level's cost is its LDS round trip and FMA
+// chain, not the barrier, and the per-level barriers let the two waves that share a level run it side by side.
+template <bool SPMV, bool AX>
 __global__ __launch_bounds__(512, 6) void k_pc_park(
     int n, int W, int nsub, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev,
     const int* __restrict__ row_info, const int* __restrict__ row_uoff, const int* __restrict__ col,
@@ -1240,27 +1255,6 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
       sum[r] = (part[0] + part[1]) + part[2];
     }
   };
-  const int wv = tid >> 6, nw = (int)(blockDim.x >> 6);
-  if constexpr (WS) {
-    // forward, wave by wave: the rows of wave wv span levels lv0 .. lv1 (level order: lf is non-decreasing in tid)
-    int lv0 = __builtin_amdgcn_readfirstlane(active ? lf : 0x7fffffff), lv1 = active ? lf : -1;
-    for (int off = 32; off > 0; off >>= 1) lv1 = max(lv1, __shfl_xor(lv1, off));
-    lv0 = min(lv0, __shfl(active ? lf : 0x7fffffff, 0));
-    for (int st = 0; st < nw; st++) {
-      if (wv == st) {
-        for (int lev = max(lv0, 1); lev <= lv1; lev++) {
-          if (lf == lev) {
-            const double2 a = *reinterpret_cast<const double2*>(ys + tid * 2);
-            double sum[BS];
-            gather3(Lc, Lf, sum);
-            *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(a.x - sum[0], a.y - sum[1]);
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-      __syncthreads();
-    }
-  } else {
   for (int lev = 1; lev < nlf; lev++) {  // forward: y_i = t_i - sum A'_ik y_k
     if (lf == lev) {
       const double2 a = *reinterpret_cast<const double2*>(ys + tid * 2);
@@ -1269,7 +1263,6 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
       *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(a.x - sum[0], a.y - sum[1]);
     }
     __syncthreads();
-  }
   }
   PH(2);
   // the lower blocks are dead: their registers take the parked upper blocks
@@ -1282,27 +1275,6 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
     Lf[p][2] = have ? u1.x : 0.0; Lf[p][3] = have ? u1.y : 0.0;
   }
   double out[BS] = {0.0, 0.0};
-  if constexpr (WS) {
-    // backward, from the last wave to the first: lb is non-increasing in tid
-    int lb1 = active ? lb : -1, lb0 = active ? lb : 0x7fffffff;
-    for (int off = 32; off > 0; off >>= 1) { lb1 = max(lb1, __shfl_xor(lb1, off)); lb0 = min(lb0, __shfl_xor(lb0, off)); }
-    for (int st = nw - 1; st >= 0; st--) {
-      if (wv == st) {
-        for (int lev = lb0; lev <= lb1; lev++) {
-          if (lb == lev) {
-            const double2 a = *reinterpret_cast<const double2*>(ys + tid * 2);
-            double sum[BS];
-            gather3(Uc, Lf, sum);
-            out[0] = a.x - sum[0];
-            out[1] = a.y - sum[1];
-            *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(out[0], out[1]);
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-      if (st > 0) __syncthreads();
-    }
-  } else {
   for (int lev = 0; lev < nlb; lev++) {  // backward: x_i = y_i - sum A'_ij x_j
     if (lb == lev) {
       const double2 a = *reinterpret_cast<const double2*>(ys + tid * 2);
@@ -1313,7 +1285,6 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
       *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(out[0], out[1]);
     }
     if (lev + 1 < nlb) __syncthreads();
-  }
   }
   PH(3);
   if (active) store_z2(z, (size_t)i, out[0], out[1]);
@@ -2321,17 +2292,12 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
     // upper blocks parked in LDS: three resident workgroups per CU
     if (kind == 1) {
       const size_t lds_park = lds + (size_t)s.max_ublocks * 4 * sizeof(double);
-#define PCP(SP, AXV, WSV)                                                                          \
-      hipLaunchKernelGGL((k_pc_park<SP, AXV, WSV>), grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,  \
+#define PCP(SP, AXV)                                                                               \
+      hipLaunchKernelGGL((k_pc_park<SP, AXV>), grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,  \
                          s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, in2, scal, z, aux, c->ks.partials,       \
                          c->ks.nb_max, dot_mode, list, fin)
-      if (s.wave_staged) {
-        if (spmv) { if (in2) PCP(true, true, true); else PCP(true, false, true); }
-        else PCP(false, false, true);
-      } else {
-        if (spmv) { if (in2) PCP(true, true, false); else PCP(true, false, false); }
-        else PCP(false, false, false);
-      }
+      if (spmv) { if (in2) PCP(true, true); else PCP(true, false); }
+      else PCP(false, false);
 #undef PCP
       return;
     }
