@@ -525,6 +525,11 @@ def main():
         log("micro %s [%s]: spmv %.4f ms (%.1f%% of HBM peak), pc apply %.4f ms, fused pc %.4f ms (%.1f%%)"
             % (a.config, sim.pc_kernel_name(), kb["spmv"], 100 * spmv_bytes(nnzb, lm.n_owned, bs) / kb["spmv"] / 1e6 / HBM_PEAK_GBS,
                kb["ilu_apply"], kb["fused_pc_amul"], 100 * pc_bytes(nnzb, lm.n_owned, bs) / kb["fused_pc_amul"] / 1e6 / HBM_PEAK_GBS))
+        modes = {"no reduction": 11, "(z,aux) partials only": 12, "(z,aux) + alpha in the launch": 2, "(x,z),(z,z) + omega in the launch": 13,
+                 "five merged products, partials only": 14, "five merged + scalars in the launch": 15}
+        log("micro %s fused launch by reduction mode (ms): %s" % (a.config, json.dumps({k: round(sim.bench_kernel(w, a.spmv_reps), 4) for k, w in modes.items()})))
+        log("micro %s iteration device-only %.4f ms, vector updates %.4f ms [WAI_BCGS=%s]"
+            % (a.config, sim.bench_kernel(5, 50), sim.bench_kernel(6, 50), os.environ.get("WAI_BCGS", "default")))
         return
 
     # lead-in: the first accepted time steps, outside warm-up and timing

@@ -276,6 +276,101 @@ def test_baseline_shardings_of_3x3_blocks(shape, overlap):
     assert err.max() < 1e-7, err
 
 
+# ---- the tracers' auxiliary solve on the same communicator (src/timestepper.F90:2347-2356) ------------------------------
+
+def _tracer_fields(gid, nt):
+    """per-cell test data as functions of the GLOBAL cell index, so that every decomposition sees the same problem"""
+    g = np.asarray(gid, dtype=np.float64)[:, None] + 17.0 * np.arange(nt)[None, :]
+    return 1.0e-3 * (0.5 + 0.5 * np.sin(0.37 * g)), 0.01 * np.cos(0.11 * g)      # X0, relative change of Al o X two steps back
+
+
+def _tracer_run(sim, lm, eos, y, nt=2):
+    phases = [0, 1][:nt] if eos != "w" else [0] * nt
+    bc = np.tile(np.array([2.0e-4, 5.0e-4])[:nt], (lm.n_bc, 1))
+    inj = np.where(np.asarray(lm.src_rate)[:, None] > 0, np.array([3.0e-3, 7.0e-3])[:nt][None, :], 0.0) if lm.n_src else np.zeros((0, nt))
+    sim.set_tracers(phases, [1.0e-6, 0.0][:nt], [0.0] * nt, [1.0e-6, 2.0e-6][:nt], bc=bc, injection=inj)
+    sim.set_aux_solver("gmres", 30, 1e-12, 1e-50, 10000)
+    sim.set_opts(ksp_rtol=1e-12, ftol_rel=1e-10)
+    dt = 1.0e4
+    reason, nits, kits = sim.timestep(0.0, dt, y)
+    assert reason > 0
+    n = lm.n_owned * nt
+    X0, rel = _tracer_fields(lm.owned_gid, nt)
+    Al = np.zeros(n)
+    sim.aux_lhs(0.0, None, Al)
+    alx1 = Al * X0.ravel()
+    alx2 = alx1 * (1.0 + rel.ravel())
+    out = {}
+    for method in ("beuler", "bdf2"):
+        X, new = X0.ravel().copy(), np.zeros(n)
+        r, its = sim.aux_solve(method, dt, 1.3, alx1, alx2, X, new)
+        assert r > 0, (method, r, its)
+        out[method] = (X.reshape(-1, nt).copy(), new.reshape(-1, nt).copy(), its)
+    return nits, out
+
+
+def _tracer_worker(rank, world, uid_q, q):
+    os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    os.environ.setdefault("WAI_HALO_OVERLAP", "0")
+    from waiwera_amd import lib as wl
+    from waiwera_amd.flow_simulation import FlowSimulation
+    if rank == 0:
+        uid = wl.comm_unique_id()
+        for _ in range(world - 1):
+            uid_q.put(uid)
+    else:
+        uid = uid_q.get(timeout=300)
+    g, lm, prim, region = _problem(M.partition_shape(world), rank)
+    sim = FlowSimulation(lm, eos="we", device=0)
+    sim.set_regions(region)
+    sim.comm_init(rank, world, uid)
+    y = scaled(prim, region).ravel().copy()
+    nits, out = _tracer_run(sim, lm, "we", y)
+    q.put((rank, lm.owned_gid.copy(), nits, out))
+    sim.destroy()
+
+
+@pytest.mark.timeout(900)
+def test_tracer_solve_across_ranks():
+    """The auxiliary linear problem of the tracers runs on the flow's communicator (timestepper.F90:2347-2356): the scalar
+    systems of two tracers (liquid- and vapour-phase, decay, diffusion, Dirichlet boundary, injection) assembled on the
+    converged flow state of a two-rank time step and solved by GMRES with the ghost entries exchanged -- same solutions and
+    same Al o X as the one-rank run, backward Euler and BDF2."""
+    assert os.path.exists(LOOPBACK), "build first: python __graft_entry__.py"
+    os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    from waiwera_amd.flow_simulation import FlowSimulation
+    world = 2
+    ctx = mp.get_context("spawn")
+    q, uid_q = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_tracer_worker, args=(r, world, uid_q, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=400) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g, lm, prim, region = _problem((1, 1, 1), 0)
+    sim = FlowSimulation(lm, eos="we", device=0)
+    sim.set_regions(region)
+    y = scaled(prim, region).ravel().copy()
+    nits1, out1 = _tracer_run(sim, lm, "we", y)
+    sim.destroy()
+    N, nt = g.n_global, 2
+    for method in ("beuler", "bdf2"):
+        Xs, As = np.zeros((N, nt)), np.zeros((N, nt))
+        Xs[lm.owned_gid], As[lm.owned_gid] = out1[method][0], out1[method][1]
+        Xp, Ap = np.zeros((N, nt)), np.zeros((N, nt))
+        for rank, gid, nits, out in res:
+            assert nits == nits1
+            Xp[gid], Ap[gid] = out[method][0], out[method][1]
+            assert out[method][2] > 0
+        assert np.abs(Xs).max() > 0
+        ex = np.abs(Xp - Xs).max(axis=0) / np.abs(Xs).max(axis=0)
+        ea = np.abs(Ap - As).max(axis=0) / np.abs(As).max(axis=0)
+        print("tracer solve on 2 ranks, %s: X %s, Al o X %s" % (method, ex, ea))
+        assert ex.max() < 1e-7 and ea.max() < 1e-7, (method, ex, ea)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -14,7 +14,10 @@ template <bool SLICED>
 __device__ __forceinline__ size_t vx(size_t n, int s, int e, size_t i) {
   return SLICED ? ((i >> 6) * (W * 9) + (size_t)(s * 9 + e)) * 64 + (i & 63) : (size_t)(s * 9 + e) * n + i;
 }
-template <bool SLICED, bool GATHER, bool COLS>
+// XS: doubles per cell in the vectors -- 3 (the library's packed block Vec) or 4 (padded: a cell's three components in one
+// aligned 32-byte sector, fetched as an aligned dwordx4 + dwordx2)
+typedef double d2a __attribute__((ext_vector_type(2)));
+template <bool SLICED, bool GATHER, bool COLS, int XS = 3>
 __global__ __launch_bounds__(256) void k_spmv3(int n, const int* __restrict__ col, const double* __restrict__ val,
                                                const double* __restrict__ x, double* __restrict__ y) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -26,18 +29,26 @@ __global__ __launch_bounds__(256) void k_spmv3(int n, const int* __restrict__ co
 #pragma unroll
   for (int s = 0; s < W; s++) {
     const int c = GATHER ? cs[s] : (cs[s] & 0 ) + i;
-    const double* p = x + (size_t)c * 3;
-    const d2u t = *reinterpret_cast<const d2u*>(p);
-    const double xv[3] = {t.x, t.y, p[2]};
+    const double* p = x + (size_t)c * XS;
+    double xv[3];
+    if constexpr (XS == 4) { const d2a t = *reinterpret_cast<const d2a*>(p); xv[0] = t.x; xv[1] = t.y; xv[2] = p[2]; }
+    else { const d2u t = *reinterpret_cast<const d2u*>(p); xv[0] = t.x; xv[1] = t.y; xv[2] = p[2]; }
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
       for (int k = 0; k < 3; k++) acc[r] += __builtin_nontemporal_load(val + vx<SLICED>(n, s, r * 3 + k, i)) * xv[k];
   }
-  for (int r = 0; r < 3; r++) y[(size_t)i * 3 + r] = acc[r];
+  if constexpr (XS == 4) {
+    d2a a = {acc[0], acc[1]}, b = {acc[2], 0.0};
+    *reinterpret_cast<d2a*>(y + (size_t)i * 4) = a;
+    *reinterpret_cast<d2a*>(y + (size_t)i * 4 + 2) = b;
+  } else {
+    for (int r = 0; r < 3; r++) y[(size_t)i * 3 + r] = acc[r];
+  }
 }
 int main(int argc, char** argv) {
-  const int nx = 172, ny = 172, nz = 170, bx = 8, by = 5, bz = 2;
+  const int nx = 172, ny = 172, nz = 170;
+  const int bx = argc > 3 ? atoi(argv[1]) : 8, by = argc > 3 ? atoi(argv[2]) : 4, bz = argc > 3 ? atoi(argv[3]) : 2;   // bricks (library default 8 x 4 x 2)
   const int n = nx * ny * nz, np = ((n + 63) / 64) * 64;
   // brick-major numbering
   std::vector<int> id((size_t)n);
@@ -61,9 +72,9 @@ int main(int argc, char** argv) {
   }
   const size_t nv = (size_t)np * W * 9;
   int* dcol; double *val, *x, *y;
-  hipMalloc(&dcol, col.size() * 4); hipMalloc(&val, nv * 8); hipMalloc(&x, (size_t)n * 24); hipMalloc(&y, (size_t)n * 24);
+  hipMalloc(&dcol, col.size() * 4); hipMalloc(&val, nv * 8); hipMalloc(&x, (size_t)n * 32); hipMalloc(&y, (size_t)n * 32);
   hipMemcpy(dcol, col.data(), col.size() * 4, hipMemcpyHostToDevice);
-  hipMemset(val, 0, nv * 8); hipMemset(x, 0, (size_t)n * 24);
+  hipMemset(val, 0, nv * 8); hipMemset(x, 0, (size_t)n * 32);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const double gb = ((double)n * W * 76 + 4.0 * n + 48.0 * n) / 1e9;   // the library's algorithmic bytes
   auto run = [&](const char* name, auto launch) {
@@ -77,6 +88,8 @@ int main(int argc, char** argv) {
   const int g = (n + 255) / 256;
 #define RUN(S, G, C, name) run(name, [&] { hipLaunchKernelGGL((k_spmv3<S, G, C>), g, 256, 0, 0, n, dcol, val, x, y); })
   RUN(false, true, true, "planes, gathers, columns (library)");
+  run("planes, gathers, columns, PADDED x / y (4)", [&] { hipLaunchKernelGGL((k_spmv3<false, true, true, 4>), g, 256, 0, 0, n, dcol, val, x, y); });
+  run("planes, no gathers, columns, padded x / y", [&] { hipLaunchKernelGGL((k_spmv3<false, false, true, 4>), g, 256, 0, 0, n, dcol, val, x, y); });
   RUN(true, true, true, "sliced64, gathers, columns");
   RUN(false, false, true, "planes, own-row x, columns");
   RUN(true, false, true, "sliced64, own-row x, columns");

@@ -3281,6 +3281,13 @@ int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
       case 7:   // the second fused launch of the "fused" iteration: z = B^-1 A (R - alpha V) with the five inner products
         pc_amul(c, k.R, k.T, 4, k.RP, -1, pc_axpy_ok(c) ? k.V : nullptr, false);
         break;
+      // the fused launch by reduction mode: 11 none; 12 (z,aux) left as partials; 13 (x,z),(z,z) + omega in the launch;
+      // 14 the five merged products left as partials; 15 the five + omega, (R,R), rho, beta in the launch
+      case 11: pc_amul(c, k.P, k.V, 0, nullptr, -2); break;
+      case 12: pc_amul(c, k.P, k.V, 1, k.RP, -2); break;
+      case 13: pc_amul(c, k.P, k.V, 2, nullptr, 3); break;
+      case 14: pc_amul(c, k.P, k.V, 4, k.RP, -2); break;
+      case 15: pc_amul(c, k.P, k.V, 4, k.RP, 6); break;
       default: pc_amul(c, k.P, k.V, 1, k.RP, 2); break;   // what a BiCGStab half-iteration runs (no halo on one rank)
     }
   };
