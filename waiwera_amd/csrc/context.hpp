@@ -241,9 +241,12 @@ struct TracerForm {
 // scalars -- in the order k_finalize sums them --, derives the BiCGStab scalars of `phase` and, when asked,
 // posts the scalars to the pinned host mirror.  Replaces a one-block k_finalize launch (and the 128-byte
 // copy) behind every producer.
+constexpr int FIN_MAXF = 64;   // most finaliser workgroups of a launch (second-level partials per slot)
 struct Fin {
   int count = 0;               // workgroups of this launch that store partials; 0: no finalisation here (no extra workgroup)
   int nb = 0;                  // partials per slot to sum (an earlier launch may have left some of them)
+  int nf = 1;                  // finaliser workgroups: the last nf of the grid, each sums one slice of the partials (fin_slices)
+  double* part2 = nullptr;     // [slots][FIN_MAXF] slice sums on their way to the last finaliser
   int slot0 = 0, nslots = 0;
   int phase = -1;              // derive_scalars phase, -1: sums only
   int seq = 0;                 // > 0: post (R,R) and the breakdown code with this sequence number to `post`
@@ -262,6 +265,7 @@ struct Krylov {
   double* basis = nullptr;     // GMRES: (m+1) vectors of nl
   int basis_m = 0;
   double* partials = nullptr;  // [slots][nb_max]
+  double* partials2 = nullptr; // [slots][FIN_MAXF]: slice sums of the finaliser workgroups (fin_block)
   int nb_max = 0;
   double* scal = nullptr;      // device scalars
   double* h_scal = nullptr;    // pinned host mirror

@@ -671,9 +671,9 @@ __device__ __forceinline__ void derive_scalars(double* s, int phase) {
     default: break;
   }
 }
-// Finalisation inside the producing launch (Fin, context.hpp).  A launch that carries a Fin has ONE
-// workgroup more than it has work: the extra one -- the last index, dispatched after every other -- waits
-// for the partial sums to arrive, sums them and derives the BiCGStab scalars.  The working workgroups do
+// Finalisation inside the producing launch (Fin, context.hpp).  A launch that carries a Fin has a few
+// workgroups more than it has work (fin_slices: one per ~2048 partials): the extra ones -- the last indices, dispatched
+// after every other -- wait for the partial sums to arrive and sum them; the last one derives the BiCGStab scalars.  The working workgroups do
 // nothing beyond storing their partial (agent scope: written through, coherent across the XCDs' L2s).
 // Arrival is read off the data: an empty partial slot holds FIN_EMPTY (a NaN payload no sum produces), and
 // whoever consumes a partial -- this workgroup or k_finalize -- leaves the slot empty again.
@@ -694,74 +694,144 @@ __device__ __forceinline__ void derive_scalars(double* s, int phase) {
 // and the returning atomic).
 constexpr unsigned long long FIN_EMPTY = 0x7FF4DEADBEEF0001ull;
 constexpr int FIN_MAXS = 5;   // reduction slots summed together (the merged BiCGStab reductions: five)
-// sums of nslots slots -> scal, k_finalize's order, by a workgroup of any size (multiple of 64).  A virtual
-// thread's partials are fetched four at a time FOR ALL (<= 5) SLOTS TOGETHER -- up to 20 independent agent-scope loads in
-// flight; one dependent round trip per entry cost 2 us each, 40 us at 21 168 partials (MEASURED: k_pc_park 603 us under
-// rocprofv3 against 583 before the reductions moved into it), and slot after slot (round 3) the five merged BiCGStab
-// reductions cost the second fused launch 0.09 ms at 216^3 (MEASURED round 4: 0.70 against 0.61 ms with two) -- and added
-// per slot in ascending order; an entry that has not arrived yet is polled (bounded: a partial that never arrives becomes
-// a NaN sum, KSP_DIVERGED_NANORINF, not a hung device).
-__device__ __forceinline__ void sum_partials(const double* partials, int nb_max, int nb, int slot0, int nslots,
-                                             double* scal, bool wait) {
+// Several finaliser workgroups (round 4).  ONE workgroup summing all partials is a serial tail that grows with the number
+// of bricks: its loads are agent-scope round trips of ~2 us, a few in flight per thread -- MEASURED (bench.py --micro-only,
+// fused launch with / without the in-launch finalisation): 0.015 ms of 0.563 at 216^3 (21 168 bricks of 512 rows), but
+// 0.127 of 0.690 ms at C4 (78 586 one-wave bricks), 0.047 of 0.233 at C5 -- and with the five merged reductions 0.069,
+// 0.537 (!) and 0.198 ms.  So the partials are cut into fin_slices(nb) slices of ~2048, a launch carries that many extra
+// workgroups, finaliser f sums slice f of every slot and stores the slice sums (second-level partials, same arrival
+// protocol), and the LAST finaliser adds the slice sums in slice order, derives and posts.  k_finalize (the separate
+// launch) forms the same slice sums and adds them in the same order: identical bits either way, independent of timing.
+__host__ __device__ __forceinline__ int fin_slices(int nb) { return nb <= 4096 ? 1 : (nb + 2047) / 2048 > FIN_MAXF ? FIN_MAXF : (nb + 2047) / 2048; }
+__host__ __device__ __forceinline__ void fin_slice_range(int nb, int nf, int f, int& lo, int& hi) {
+  const int per = (nb + nf - 1) / nf;
+  lo = f * per; hi = lo + per < nb ? lo + per : nb;
+  if (lo > nb) lo = nb;
+}
+// sums of the partials [lo, hi) of ns (<= FIN_MAXS) slots starting at p0 -> res[0 .. ns) (shared memory, valid for every
+// thread on return), by a workgroup of any size (multiple of 64).  A virtual thread's partials are fetched four at a time
+// FOR ALL SLOTS TOGETHER -- up to 20 independent agent-scope loads in flight (one dependent round trip per entry cost 2 us
+// each) -- and added per slot in ascending order; an entry that has not arrived yet is polled (bounded: a partial that
+// never arrives becomes a NaN sum and breakdown code 4, KSP_DIVERGED_NANORINF, not a hung device).
+__device__ __forceinline__ void sum_slice(unsigned long long* p0, int nb_max, int lo, int hi, int ns, bool wait,
+                                          double* scal, double* res) {
   __shared__ double fsm[FIN_MAXS][16];
   constexpr int CH = 4;
-  const int VT = nb > 256 ? 1024 : 256;
-  unsigned long long* p0 = reinterpret_cast<unsigned long long*>(const_cast<double*>(partials)) + (size_t)slot0 * nb_max;
-  for (int sb = 0; sb < nslots; sb += FIN_MAXS) {   // up to FIN_MAXS slots together: their loads are in flight at once
-    const int ns = min(nslots - sb, FIN_MAXS);
-    for (int v = threadIdx.x; v < VT; v += blockDim.x) {   // whole waves: blockDim is a multiple of 64
-      double t[FIN_MAXS];
+  const int len = hi - lo, VT = len > 256 ? 1024 : 256;
+  __syncthreads();   // fsm / res of an earlier call are no longer read
+  for (int v = threadIdx.x; v < VT; v += blockDim.x) {   // whole waves: blockDim is a multiple of 64
+    double t[FIN_MAXS];
 #pragma unroll
-      for (int s = 0; s < FIN_MAXS; s++) t[s] = 0.0;
-      for (int i0 = v; i0 < nb; i0 += VT * CH) {
-        unsigned long long u[FIN_MAXS][CH];
+    for (int s = 0; s < FIN_MAXS; s++) t[s] = 0.0;
+    for (int i0 = lo + v; i0 < hi; i0 += VT * CH) {
+      unsigned long long u[FIN_MAXS][CH];
 #pragma unroll
-        for (int s = 0; s < FIN_MAXS; s++)
+      for (int s = 0; s < FIN_MAXS; s++)
 #pragma unroll
-          for (int k = 0; k < CH; k++) {
-            const int i = i0 + k * VT;
-            u[s][k] = (s < ns && i < nb) ? __hip_atomic_load(p0 + (size_t)(sb + s) * nb_max + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-          }
+        for (int k = 0; k < CH; k++) {
+          const int i = i0 + k * VT;
+          u[s][k] = (s < ns && i < hi) ? __hip_atomic_load(p0 + (size_t)s * nb_max + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
 #pragma unroll
-        for (int s = 0; s < FIN_MAXS; s++)
+      for (int s = 0; s < FIN_MAXS; s++)
 #pragma unroll
-          for (int k = 0; k < CH; k++) {
-            const int i = i0 + k * VT;
-            if (s < ns && i < nb) {
-              unsigned long long* ps = p0 + (size_t)(sb + s) * nb_max + i;
-              for (int spin = 0; wait && u[s][k] == FIN_EMPTY && spin < (1 << 22); spin++) {
-                __builtin_amdgcn_s_sleep(8);
-                u[s][k] = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              }
-              // still empty: the producer never stored it (waited out above), or -- k_finalize, wait = false -- no producer
-              // ran before this consumer.  The sum is a NaN either way; say why (code 4 reaches the host with the post)
-              if (u[s][k] == FIN_EMPTY) scal[S_BREAK] = 4.0;
-              __hip_atomic_store(ps, FIN_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: the slot is empty again
-              t[s] += __longlong_as_double((long long)u[s][k]);   // FIN_EMPTY itself is a NaN
+        for (int k = 0; k < CH; k++) {
+          const int i = i0 + k * VT;
+          if (s < ns && i < hi) {
+            unsigned long long* ps = p0 + (size_t)s * nb_max + i;
+            for (int spin = 0; wait && u[s][k] == FIN_EMPTY && spin < (1 << 22); spin++) {
+              __builtin_amdgcn_s_sleep(8);
+              u[s][k] = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            // still empty: the producer never stored it (waited out above), or -- k_finalize, wait = false -- no producer
+            // ran before this consumer.  The sum is a NaN either way; say why (code 4 reaches the host with the post)
+            if (u[s][k] == FIN_EMPTY) scal[S_BREAK] = 4.0;
+            __hip_atomic_store(ps, FIN_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: the slot is empty again
+            t[s] += __longlong_as_double((long long)u[s][k]);   // FIN_EMPTY itself is a NaN
           }
-      }
+        }
+    }
 #pragma unroll
-      for (int s = 0; s < FIN_MAXS; s++) {
-        double ts = t[s];
-        for (int off = 32; off > 0; off >>= 1) ts += __shfl_down(ts, off);
-        if ((v & 63) == 0) fsm[s][v >> 6] = ts;
-      }
+    for (int s = 0; s < FIN_MAXS; s++) {
+      double ts = t[s];
+      for (int off = 32; off > 0; off >>= 1) ts += __shfl_down(ts, off);
+      if ((v & 63) == 0) fsm[s][v >> 6] = ts;
     }
-    __syncthreads();
-    if ((int)threadIdx.x < ns) {
-      double tot = 0.0;
-      for (int w = 0; w < (VT >> 6); w++) tot += fsm[threadIdx.x][w];
-      scal[slot0 + sb + threadIdx.x] = tot;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < ns) {
+    double tot = 0.0;
+    for (int w = 0; w < (VT >> 6); w++) tot += fsm[threadIdx.x][w];
+    res[threadIdx.x] = tot;
+  }
+  __syncthreads();
+}
+// k_finalize's body: every slice of every slot, the slice sums added in slice order -> scal
+__device__ __forceinline__ void sum_partials(const double* partials, int nb_max, int nb, int slot0, int nslots,
+                                             double* scal, bool wait) {
+  __shared__ double res[FIN_MAXS], tot[FIN_MAXS];
+  const int nf = fin_slices(nb);
+  for (int sb = 0; sb < nslots; sb += FIN_MAXS) {
+    const int ns = min(nslots - sb, FIN_MAXS);
+    unsigned long long* p0 = reinterpret_cast<unsigned long long*>(const_cast<double*>(partials)) + (size_t)(slot0 + sb) * nb_max;
+    if ((int)threadIdx.x < ns) tot[threadIdx.x] = 0.0;
+    for (int f = 0; f < nf; f++) {
+      int lo, hi;
+      fin_slice_range(nb, nf, f, lo, hi);
+      sum_slice(p0, nb_max, lo, hi, ns, wait, scal, res);
+      if ((int)threadIdx.x < ns) tot[threadIdx.x] = nf == 1 ? res[threadIdx.x] : tot[threadIdx.x] + res[threadIdx.x];
     }
+    if ((int)threadIdx.x < ns) scal[slot0 + sb + threadIdx.x] = tot[threadIdx.x];
     __syncthreads();
   }
 }
-// is this workgroup the launch's finaliser?  If so do the finalisation (the caller returns)
+// A workgroup's partial sum: stored at agent scope (written through to memory, coherent across the XCDs' L2s)
+// so that the workgroup that finishes a reduction can read it without any cache-wide fence
+__device__ __forceinline__ void store_partial(double* p, double t) {
+  __hip_atomic_store(p, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// is this workgroup one of the launch's finalisers (the last f.nf workgroups)?  If so do its share (the caller returns)
 __device__ __forceinline__ bool fin_block(const Fin& f, const double* partials, int nb_max) {
-  if (f.count == 0 || blockIdx.x != gridDim.x - 1) return false;
-  sum_partials(partials, nb_max, f.nb, f.slot0, f.nslots, f.scal, true);
+  if (f.count == 0 || (int)blockIdx.x < (int)gridDim.x - f.nf) return false;
+  __shared__ double res[FIN_MAXS];
+  const int me = (int)blockIdx.x - ((int)gridDim.x - f.nf);
+  const bool last = me == f.nf - 1;
+  unsigned long long* p0 = reinterpret_cast<unsigned long long*>(const_cast<double*>(partials)) + (size_t)f.slot0 * nb_max;
+  unsigned long long* q0 = reinterpret_cast<unsigned long long*>(f.part2) + (size_t)f.slot0 * FIN_MAXF;
+  int lo, hi;
+  fin_slice_range(f.nb, f.nf, me, lo, hi);
+  sum_slice(p0, nb_max, lo, hi, f.nslots, true, f.scal, res);   // nslots <= FIN_MAXS for every in-launch finalisation
+  if (f.nf == 1) {
+    if ((int)threadIdx.x < f.nslots) f.scal[f.slot0 + threadIdx.x] = res[threadIdx.x];
+  } else {
+    if ((int)threadIdx.x < f.nslots) store_partial(f.part2 + (size_t)(f.slot0 + threadIdx.x) * FIN_MAXF + me, res[threadIdx.x]);
+    if (!last) return true;
+    // the last finaliser, its first wave: lane t takes slice t's sums as they arrive (nf <= 64 = FIN_MAXF), every lane
+    // then adds them in slice order
+    if (threadIdx.x < 64) {
+      const int t = (int)threadIdx.x;
+      for (int s2 = 0; s2 < f.nslots; s2++) {
+        unsigned long long u = 0ull;
+        if (t < f.nf) {
+          unsigned long long* ps = q0 + (size_t)s2 * FIN_MAXF + t;
+          u = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int spin = 0; u == FIN_EMPTY && spin < (1 << 22); spin++) {
+            __builtin_amdgcn_s_sleep(8);
+            u = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (u == FIN_EMPTY) f.scal[S_BREAK] = 4.0;
+          __hip_atomic_store(ps, FIN_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const double v = __longlong_as_double((long long)u);
+        double tot = 0.0;
+        for (int g = 0; g < f.nf; g++) tot += __shfl(v, g);
+        if (t == 0) f.scal[f.slot0 + s2] = tot;
+      }
+    }
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
+    __threadfence_block();
     if (f.phase >= 0) derive_scalars(f.scal, f.phase);
     if (f.seq > 0) post_scalars(f.scal, f.post, f.seq);
   }
@@ -769,11 +839,6 @@ __device__ __forceinline__ bool fin_block(const Fin& f, const double* partials, 
 }
 
 // ---- K6+K8 fused: z = U^-1 L^-1 (A x)  or  z = U^-1 L^-1 r ------------------------------------
-// A workgroup's partial sum: stored at agent scope (written through to memory, coherent across the XCDs' L2s)
-// so that the workgroup that finishes a reduction (fin_tail) can read it without any cache-wide fence
-__device__ __forceinline__ void store_partial(double* p, double t) {
-  __hip_atomic_store(p, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 template <int NS>
 __device__ __forceinline__ void wg_reduce_store(double (&v)[NS], double* red, double* partials,
@@ -1729,9 +1794,10 @@ __global__ __launch_bounds__(1024) void k_finalize(const double* __restrict__ pa
 }
 
 // every partial slot of [slot0, slot0 + nslots) empty: before a solve, whatever an aborted one left
-__global__ __launch_bounds__(TPB) void k_partials_clear(double* partials, int nb_max, int slot0, int nslots) {
+__global__ __launch_bounds__(TPB) void k_partials_clear(double* partials, double* partials2, int nb_max, int slot0, int nslots) {
   const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
   if (i < (size_t)nslots * nb_max) reinterpret_cast<unsigned long long*>(partials)[(size_t)slot0 * nb_max + i] = FIN_EMPTY;
+  if (i < (size_t)nslots * FIN_MAXF) reinterpret_cast<unsigned long long*>(partials2)[(size_t)slot0 * FIN_MAXF + i] = FIN_EMPTY;
 }
 
 __global__ void k_bcgs_scalars(double* s, int phase, double* post, int seq) {
@@ -1781,7 +1847,7 @@ __global__ __launch_bounds__(TPB) void k_bcgs_xr(double* __restrict__ X, double*
                                                  int n, const double* __restrict__ s, double* partials,
                                                  int nb_max, Fin fin) {
   if (fin_block(fin, partials, nb_max)) return;
-  const int nblk = fin.count > 0 ? gridDim.x - 1 : gridDim.x;   // the finaliser is one workgroup more
+  const int nblk = fin.count > 0 ? gridDim.x - fin.nf : gridDim.x;   // the finalisers are extra workgroups
   const double alpha = s[S_ALPHA], omega = s[S_OMEGA];
   double v[2] = {0.0, 0.0};
   for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += nblk * TPB) {
@@ -2241,9 +2307,9 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
   if (!list) { nrun = s.nsub; list = s.sub_order; }   // all subdomains: in the schedule's launch order, if it has one
   const bool with_fin = finp && dot_mode != 0;
   Fin fin;
-  if (finp && dot_mode != 0) { fin = *finp; fin.count = nrun; fin.nb = s.nsub; }   // all subdomains' partials are summed
+  if (finp && dot_mode != 0) { fin = *finp; fin.count = nrun; fin.nb = s.nsub; fin.nf = fin_slices(s.nsub); }   // all subdomains' partials are summed
   c->ks.n_launch++;
-  const int grid = ((nrun + 7) / 8) * 8 + (with_fin ? 1 : 0), T = pc_threads(s);   // + the finaliser (fin_block)
+  const int grid = ((nrun + 7) / 8) * 8 + (with_fin ? fin.nf : 0), T = pc_threads(s);   // + the finalisers (fin_block)
   const size_t lds = ((size_t)T * BS + 80) * sizeof(double);
 #define PCL(SP, DI)                                                                              \
   do {                                                                                           \
@@ -2261,7 +2327,7 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
   // one wave per brick of <= 64 block rows (block sizes 3 and 4), four bricks per workgroup
   if (kind == 3) {
     if constexpr (BS >= 3) {
-      const int ngrp = (nrun + 3) / 4, gridw = ((ngrp + 7) / 8) * 8 + (with_fin ? 1 : 0);
+      const int ngrp = (nrun + 3) / 4, gridw = ((ngrp + 7) / 8) * 8 + (with_fin ? fin.nf : 0);
       const int per = 64 * BS + s.max_ublocks_w * BS * BS;            // doubles per brick: solution + parked upper blocks
       const size_t lds_w = (size_t)4 * per * sizeof(double);
       const int* rp = (size_t)J.nnzb * 10 < (size_t)J.n * J.W * 9 ? J.rowptr : nullptr;   // > 10 % padding
@@ -2340,7 +2406,7 @@ int launch_pc(wai_ctx* c, bool spmv, const double* in, double* z, int dot_mode, 
 Fin make_fin(wai_ctx* c, int slot0, int nslots, int phase, bool post) {
   Fin f;   // count / nb: filled in by the launcher
   f.slot0 = slot0; f.nslots = nslots; f.phase = phase;
-  f.scal = c->ks.scal; f.post = c->ks.d_post;
+  f.scal = c->ks.scal; f.post = c->ks.d_post; f.part2 = c->ks.partials2;
   f.seq = post ? ++c->ks.seq : 0;
   return f;
 }
@@ -2414,7 +2480,7 @@ int vec_dots(wai_ctx* c, const double* a1, const double* b1, int slot1, const do
 int partials_clear(wai_ctx* c, int slot0, int nslots) {
   const size_t tot = (size_t)nslots * c->ks.nb_max;
   c->ks.n_launch++;
-  hipLaunchKernelGGL(k_partials_clear, (int)((tot + TPB - 1) / TPB), TPB, 0, c->stream, c->ks.partials, c->ks.nb_max, slot0, nslots);
+  hipLaunchKernelGGL(k_partials_clear, (int)((tot + TPB - 1) / TPB), TPB, 0, c->stream, c->ks.partials, c->ks.partials2, c->ks.nb_max, slot0, nslots);
   return 0;
 }
 int vec_copy(wai_ctx* c, double* dst, const double* src, size_t n) {
@@ -2453,7 +2519,7 @@ int bcgs_update_s(wai_ctx* c) {
 int bcgs_update_xr(wai_ctx* c, bool dots, int fin_phase, bool post) {
   const int g = vgrid(c->ks.n);
   Fin fin;
-  if (dots && fin_phase >= -1) { fin = make_fin(c, S_DP2, 2, fin_phase, post); fin.count = g; fin.nb = g; }
+  if (dots && fin_phase >= -1) { fin = make_fin(c, S_DP2, 2, fin_phase, post); fin.count = g; fin.nb = g; fin.nf = fin_slices(g); }
   c->ks.n_launch++;
   if (dots && fin.count > 0 && fin_separate()) {
     Fin none;
@@ -2465,7 +2531,7 @@ int bcgs_update_xr(wai_ctx* c, bool dots, int fin_phase, bool post) {
     return 0;
   }
   if (dots)
-    hipLaunchKernelGGL(k_bcgs_xr<true>, g + (fin.count > 0 ? 1 : 0), TPB, 0, c->stream, c->ks.X, c->ks.R, c->ks.P, c->ks.S, c->ks.T,
+    hipLaunchKernelGGL(k_bcgs_xr<true>, g + (fin.count > 0 ? fin.nf : 0), TPB, 0, c->stream, c->ks.X, c->ks.R, c->ks.P, c->ks.S, c->ks.T,
                        c->ks.RP, c->ks.n, c->ks.scal, c->ks.partials, c->ks.nb_max, fin);
   else
     hipLaunchKernelGGL(k_bcgs_xr<false>, g, TPB, 0, c->stream, c->ks.X, c->ks.R, c->ks.P, c->ks.S, c->ks.T,
