@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwaiwera_hip.so")
-SOURCES = ["capi.hip", "kernels_assembly.hip", "kernels_linalg.hip", "comm.cpp"]
+SOURCES = ["capi.hip", "krylov.hip", "pc_setup.hip", "network.hip", "measure.hip", "kernels_assembly.hip", "kernels_linalg.hip", "comm.cpp"]
 import glob  # noqa: E402
 # every header any source could include: a stale object after a header edit is worse than a rebuild
 HEADERS = sorted(os.path.basename(h) for pat in ("*.h", "*.hpp") for h in glob.glob(os.path.join(CSRC, pat))) + \

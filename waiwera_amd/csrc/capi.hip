@@ -1,557 +1,13 @@
-// C ABI of libwaiwera_hip.so (include/waiwera_hip.h): context set-up, the ode_type hooks, the
-// device-resident Krylov solvers (PETSc KSPBCGS / KSPGMRES restated, left preconditioning) and
-// the Newton iteration of the reference's SNES callbacks (src/timestepper.F90:587-735,
-// 1898-1951).  Host code here only orders kernel launches and RCCL calls on one HIP stream and
-// reads back a handful of scalars per Krylov iteration; all vectors and matrices stay in HBM.
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <numeric>
-#include "comm.hpp"
-#include <functional>
-#include "context.hpp"
-#include "../../include/waiwera_hip_bench.h"
+// C ABI of libwaiwera_hip.so (include/waiwera_hip.h): context set-up, the ode_type hooks and the Newton iteration of
+// the reference's SNES callbacks (src/timestepper.F90:587-735, 1898-1951).  Host code here only orders kernel launches
+// and RCCL calls on one HIP stream and reads back a handful of scalars per Krylov iteration; all vectors and matrices
+// stay in HBM.  The Krylov drivers live in krylov.hip, the preconditioner set-up in pc_setup.hip, the source network in
+// network.hip, measurement entry points in measure.hip; host.hpp declares what they share.
+#include "host.hpp"
 
 using namespace wai;
 
-#define HIPCHK(c, call)                                                                 \
-  do {                                                                                  \
-    hipError_t e_ = (call);                                                             \
-    if (e_ != hipSuccess) {                                                             \
-      (c)->err = std::string(#call) + ": " + hipGetErrorString(e_);                     \
-      return -1;                                                                        \
-    }                                                                                   \
-  } while (0)
-
-#ifdef WAI_PC_PHASES
-namespace wai { void pc_phases_fetch(unsigned long long out[8], bool reset); }
-#endif
-namespace {
-
-enum { S_RHO = 0, S_RHOOLD = 1, S_ALPHA = 2, S_OMEGA = 3, S_BETA = 4, S_D1 = 5, S_D2 = 6,
-       S_DP2 = 7, S_RHONEW = 8, S_W2 = 9, S_BREAK = 15, S_H = 16 };
-constexpr int NSLOTS = 64;
-constexpr int NSCAL = 128;
-
-// GMRES / LGMRES basis: restart vectors, at least 3 (LGMRES: one Krylov direction + 2 error approximations),
-// at most MAX_RESTART (the Hessenberg column travels through the scalar / partial-sum slots S_H ..)
-constexpr int MAX_RESTART = 40;
-int basis_vectors(int restart) { return std::max(3, std::min(restart > 0 ? restart : 30, MAX_RESTART)); }
-
-template <typename T>
-int dev_alloc(wai_ctx* c, T** p, size_t n) {
-  *p = nullptr;
-  if (n == 0) n = 1;
-  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
-  return 0;
-}
-template <typename T>
-int dev_upload(wai_ctx* c, T** p, const std::vector<T>& v) {
-  if (dev_alloc(c, p, v.size())) return -1;
-  if (!v.empty()) HIPCHK(c, hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-  return 0;
-}
-
-bool is_device_ptr(const void* p) {
-  hipPointerAttribute_t a;
-  hipError_t e = hipPointerGetAttributes(&a, p);
-  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
-  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
-}
-
-// vector argument handling: device pointers pass through, host arrays are staged
-struct VecArg {
-  wai_ctx* c; double* dev = nullptr; double* host = nullptr; size_t n = 0; bool staged = false;
-  int in(const double* p, size_t n_, int slot) {
-    n = n_;
-    if (!p) { dev = nullptr; return 0; }
-    if (is_device_ptr(p)) { dev = const_cast<double*>(p); return 0; }
-    if (n > c->stage_len) { c->err = "vector longer than staging buffer"; return -1; }
-    host = const_cast<double*>(p); dev = c->stage[slot]; staged = true;
-    HIPCHK(c, hipMemcpyAsync(dev, p, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    return 0;
-  }
-  int out_only(double* p, size_t n_, int slot) {
-    n = n_;
-    if (!p) { dev = nullptr; return 0; }
-    if (is_device_ptr(p)) { dev = p; return 0; }
-    if (n > c->stage_len) { c->err = "vector longer than staging buffer"; return -1; }
-    host = p; dev = c->stage[slot]; staged = true;
-    return 0;
-  }
-  int back() {
-    if (staged && host) {
-      HIPCHK(c, hipMemcpyAsync(host, dev, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
-    return 0;
-  }
-};
-
-struct Prof {
-  wai_ctx* c; int k;
-  Prof(wai_ctx* c_, int k_) : c(c_), k(k_) {
-    if (c->prof_on) (void)hipEventRecord(c->pev0, c->stream);
-  }
-  ~Prof() {
-    if (c->prof_on) {
-      (void)hipEventRecord(c->pev1, c->stream);
-      (void)hipEventSynchronize(c->pev1);
-      float ms = 0.f;
-      (void)hipEventElapsedTime(&ms, c->pev0, c->pev1);
-      c->prof_ms[k] += ms;
-      c->prof_n[k] += 1;
-    }
-  }
-};
-
-// Symbolic phase of block-Jacobi ILU(0) on a block matrix given as host CSR (ascending columns):
-// per-row slot ranges inside the row's subdomain, dependency levels of both substitutions, whether
-// ILU(0) ever touches an off-diagonal block (if not it is DILU and the fused kernels apply), the
-// compact / parked kernel conditions -- or, for subdomains of more than 1024 rows, the level sets
-// of the launch-per-level path.  `ghosts`: rows may have columns >= n (partition ghosts).
-int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, const std::vector<int>& colidx,
-                   const std::vector<int>& sub, int N, int W, int np, bool ghosts) {
-  s.nsub = (int)sub.size() - 1;
-  if (sub.front() != 0 || sub.back() != N) { c->err = "sub_ptr must cover [0, n_owned]"; return -2; }
-  std::vector<int> diag(N);
-  for (int i = 0; i < N; i++) {
-    const int* row = colidx.data() + rowptr[i];
-    diag[i] = (int)(std::lower_bound(row, row + (rowptr[i + 1] - rowptr[i]), i) - row);
-  }
-  std::vector<int> info(N), uoff(N, 0), uoffw(N, 0), levf(N), levb(N), nlev(s.nsub, 0), lfirst(N), ulast(N), tslot(N, 0);
-  int max_nu = 0;
-  s.max_rows = 0; s.max_lev = 0; s.max_ublocks = 0; s.max_ublocks_w = 0; s.max_nlu = 0; s.max_nl = 0;
-  bool offdiag_fill = false, fast3 = true;
-  int nlf_all = 0, nlb_all = 0;
-  for (int sd = 0; sd < s.nsub; sd++) {
-    const int lo = sub[sd], hi = sub[sd + 1];
-    if (hi < lo) { c->err = "sub_ptr not monotone"; return -2; }
-    s.max_rows = std::max(s.max_rows, hi - lo);
-    int nlf = 0, nlb = 0;
-    for (int i = lo; i < hi; i++) {
-      const int* row = colidx.data() + rowptr[i];
-      const int cnt = rowptr[i + 1] - rowptr[i];
-      int ls = 0;
-      while (ls < cnt && row[ls] < lo) ls++;
-      int ue = cnt;
-      while (ue > 0 && row[ue - 1] >= hi) ue--;
-      lfirst[i] = ls; ulast[i] = ue;
-      int lv = 0;
-      for (int q = ls; q < diag[i]; q++) lv = std::max(lv, levf[row[q]] + 1);
-      levf[i] = lv;
-      nlf = std::max(nlf, lv + 1);
-    }
-    for (int i = hi - 1; i >= lo; i--) {
-      const int* row = colidx.data() + rowptr[i];
-      int lv = 0;
-      for (int q = diag[i] + 1; q < ulast[i]; q++) lv = std::max(lv, levb[row[q]] + 1);
-      levb[i] = lv;
-      nlb = std::max(nlb, lv + 1);
-    }
-    // does the IKJ elimination ever update an off-diagonal block of a row in this subdomain?
-    for (int i = lo; i < hi && !offdiag_fill; i++) {
-      const int* row = colidx.data() + rowptr[i];
-      for (int q = lfirst[i]; q < diag[i] && !offdiag_fill; q++) {
-        const int k = row[q];
-        const int* rk = colidx.data() + rowptr[k];
-        for (int r2 = diag[k] + 1; r2 < ulast[k]; r2++) {
-          const int j = rk[r2];
-          if (j == i) continue;
-          if (std::binary_search(row + q + 1, row + ulast[i], j)) { offdiag_fill = true; break; }
-        }
-      }
-    }
-    // per in-subdomain lower coupling (i, k): the slot of row k that holds A_ki (15: structurally absent), four
-    // bits each -- the pivot recurrence reads A_ki without chasing row k's descriptor and columns
-    for (int i = lo; i < hi; i++) {
-      const int* row = colidx.data() + rowptr[i];
-      int pack = 0;
-      for (int q = lfirst[i], p = 0; q < diag[i] && p < 4; q++, p++) {
-        const int k = row[q];
-        const int* rk = colidx.data() + rowptr[k];
-        const int* e = std::lower_bound(rk + diag[k] + 1, rk + ulast[k], i);
-        const int r2 = (e < rk + ulast[k] && *e == i) ? (int)(e - rk) : 15;
-        pack |= (r2 & 15) << (4 * p);
-      }
-      tslot[i] = pack;
-      s.max_nl = std::max(s.max_nl, diag[i] - lfirst[i]);
-    }
-    int ucount = 0, ucountw = 0;
-    for (int i = lo; i < hi; i++) {
-      const int nL = diag[i] - lfirst[i], nU = ulast[i] - diag[i] - 1;
-      if (nL > 3 || nU > 3 || lfirst[i] > 3 || diag[i] > 3) fast3 = false;
-      s.max_nlu = std::max(s.max_nlu, std::max(nL, nU));
-      uoff[i] = ucount;
-      ucount += std::min(nU, 3);
-      uoffw[i] = ucountw;
-      ucountw += nU;
-      max_nu = std::max(max_nu, nU);
-    }
-    s.max_ublocks = std::max(s.max_ublocks, ucount);
-    s.max_ublocks_w = std::max(s.max_ublocks_w, ucountw);
-    nlev[sd] = (nlf & 0xffff) | (nlb << 16);
-    s.max_lev = std::max(s.max_lev, std::max(nlf, nlb));
-    nlf_all = std::max(nlf_all, nlf); nlb_all = std::max(nlb_all, nlb);
-  }
-  // the brick kernels hold a row's <= 8 blocks in registers and pack slot numbers in 4 bits: wider rows (ILU(k)
-  // fill) and subdomains of more than 1024 rows take the launch-per-level path, whose descriptor has 8-bit slots
-  s.big = s.max_rows > 1024 || W > 8;
-  if (!s.big && s.max_lev > 1023) { c->err = "more than 1023 dependency levels in a subdomain"; return -2; }
-  for (int i = 0; i < N; i++)
-    info[i] = s.big ? (lfirst[i] | (diag[i] << 8) | (ulast[i] << 16))
-                    : (lfirst[i] | (diag[i] << 4) | (ulast[i] << 8) | (levf[i] << 12) | (levb[i] << 22));
-  // Launch order.  Workgroup b of a fused launch runs on XCD b % 8 and takes position (b & 7) * per + (b >> 3) of the
-  // list it is given, so each XCD works through one contiguous eighth in order.  Where bricks differ in cost (the
-  // ragged bricks at the upper ends of a rank's box: fewer rows, fewer levels) the long ones go first inside each
-  // eighth and the short ones last: a launch ends with its shortest workgroups (the tail of 2646 bricks on 768 slots
-  // at 108^3 is a fifth of the launch).  The eighths themselves stay contiguous -- an XCD's L2 keeps serving the
-  // neighbour bricks' vector entries.
-  auto brick_cost = [&](int sd) { return ((nlev[sd] & 0xffff) + (nlev[sd] >> 16)) * 4096 + (sub[sd + 1] - sub[sd]); };
-  auto lpt_order = [&](std::vector<int>& list) {
-    const int n = (int)list.size(), per = (n + 7) >> 3;
-    for (int j = 0; j < 8; j++) {
-      const int a = std::min(j * per, n), b = std::min((j + 1) * per, n);
-      std::stable_sort(list.begin() + a, list.begin() + b, [&](int x, int y) { return brick_cost(x) > brick_cost(y); });
-    }
-  };
-  if (!s.big) {
-    bool uniform = true;
-    for (int sd = 1; sd < s.nsub && uniform; sd++) uniform = brick_cost(sd) == brick_cost(0);
-    if (!uniform) {
-      std::vector<int> order(s.nsub);
-      std::iota(order.begin(), order.end(), 0);
-      lpt_order(order);
-      if (dev_upload(c, &s.sub_order, order)) return -1;
-    }
-  }
-  if (ghosts) {   // subdomains without / with partition-ghost columns (for the overlapped halo exchange)
-    std::vector<int> li, lb;
-    for (int sd = 0; sd < s.nsub; sd++) {
-      bool ghost = false;
-      for (int i = sub[sd]; i < sub[sd + 1] && !ghost; i++)
-        for (int q = rowptr[i]; q < rowptr[i + 1]; q++)
-          if (colidx[q] >= N) { ghost = true; break; }
-      (ghost ? lb : li).push_back(sd);
-    }
-    if (c->mesh.n_halo == 0 && W == 7) {
-      // one rank: for the split-kernel measurement (wai_bench_kernel 9, 10) take the bricks on the
-      // faces of the box -- rows with fewer than six neighbours -- as if every face were a partition
-      // boundary (what an interior rank of a larger decomposition sees)
-      li.clear(); lb.clear();
-      for (int sd = 0; sd < s.nsub; sd++) {
-        bool face = false;
-        for (int i = sub[sd]; i < sub[sd + 1] && !face; i++) face = rowptr[i + 1] - rowptr[i] < 7;
-        (face ? lb : li).push_back(sd);
-      }
-    }
-    s.n_int = (int)li.size();
-    s.n_bnd = (int)lb.size();
-    lpt_order(li); lpt_order(lb);
-    if (s.n_int > 0 && s.n_bnd > 0) {
-      if (dev_upload(c, &s.sub_int, li) || dev_upload(c, &s.sub_bnd, lb)) return -1;
-    }
-  }
-  if (s.big) {
-    // level sets over all subdomains: rows of one level are independent wherever they live
-    s.nlev_f = nlf_all; s.nlev_b = nlb_all;
-    std::vector<int> of(N), ob(N);
-    s.lev_f_ptr.assign(nlf_all + 1, 0); s.lev_b_ptr.assign(nlb_all + 1, 0);
-    for (int i = 0; i < N; i++) { s.lev_f_ptr[levf[i] + 1]++; s.lev_b_ptr[levb[i] + 1]++; }
-    for (int l = 0; l < nlf_all; l++) s.lev_f_ptr[l + 1] += s.lev_f_ptr[l];
-    for (int l = 0; l < nlb_all; l++) s.lev_b_ptr[l + 1] += s.lev_b_ptr[l];
-    std::vector<int> pf(s.lev_f_ptr.begin(), s.lev_f_ptr.end() - 1), pb(s.lev_b_ptr.begin(), s.lev_b_ptr.end() - 1);
-    for (int i = 0; i < N; i++) { of[pf[levf[i]]++] = i; ob[pb[levb[i]]++] = i; }
-    if (dev_upload(c, &s.ord_f, of) || dev_upload(c, &s.ord_b, ob)) return -1;
-  }
-  if (dev_upload(c, &s.sub_ptr, sub) || dev_upload(c, &s.sub_nlev, nlev) || dev_upload(c, &s.row_info, info) ||
-      dev_upload(c, &s.row_uoff, uoff) || dev_upload(c, &s.row_uoffw, uoffw) || dev_upload(c, &s.row_tslot, tslot) ||
-      dev_alloc(c, &s.fval, (size_t)W * np * np * N) || dev_alloc(c, &s.dinv, (size_t)np * np * N))
-    return -1;
-  // Kernel-selection switches are build-time (A/B builds: WAI_EXTRA_HIPCC_FLAGS="-DWAI_ILU_GENERAL" ...); the
-  // run-time environment only steers what the tests compare in one process (WAI_BCGS_MERGED, WAI_JAC_PARK,
-  // WAI_HALO_OVERLAP) and the transport library (WAI_RCCL_LIB).
-  s.diag_only = !offdiag_fill && !s.big;
-  s.level_sorted = !s.big;
-  for (int sd = 0; sd < s.nsub && s.level_sorted; sd++)
-    for (int i = sub[sd] + 1; i < sub[sd + 1]; i++)
-      if (levf[i] < levf[i - 1] || levb[i] > levb[i - 1]) { s.level_sorted = false; break; }
-  s.fast3 = fast3;
-  s.scaled = true;
-#ifdef WAI_ILU_GENERAL
-  s.diag_only = false;     // stored L / U factor everywhere
-#endif
-#ifdef WAI_ILU_NOFAST
-  s.fast3 = false;         // no compacted 3 + 3 couplings
-#endif
-#ifdef WAI_ILU_NOSCALE
-  s.scaled = false;        // DILU with the inverted pivots read per application
-#endif
-  {
-    // 160 KB of LDS per CU; a workgroup may use 64 KB
-    const size_t need = ((size_t)(((s.max_rows + 63) / 64) * 64) * np + 32 + (size_t)s.max_ublocks * 4) * sizeof(double);
-    s.park = need <= 64 * 1024;
-#ifdef WAI_PC_NOPARK
-    s.park = false;        // k_pc instead of k_pc_park
-#endif
-  }
-  {
-    // one thread per scalar row: needs the pivot-scaled DILU form, <= 4 + 4 couplings and a brick whose
-    // scalar rows fit one workgroup.  Default for block sizes 3 and 4, where a whole block row per
-    // thread does not fit the register file (-DWAI_PC_ROWS=0 / 1 forces it off / on, bs <= 2 too).
-    const bool can = s.diag_only && s.scaled && !s.big && s.max_nlu <= 4 && s.max_rows * np <= 1024 && W <= 8;
-#ifdef WAI_PC_ROWS
-    s.rows_kernel = can && (WAI_PC_ROWS != 0);
-#else
-    s.rows_kernel = can && np >= 3;
-#endif
-  }
-  {
-    // one wave per brick: <= 64 block rows, <= 3 lower and <= 4 upper in-brick couplings, LDS for four bricks per
-    // workgroup within 64 KB (-DWAI_PC_WAVE=0 builds without)
-    const size_t lds_w = (size_t)4 * (64 * np + (size_t)s.max_ublocks_w * np * np) * sizeof(double);
-    s.wave_kernel = s.rows_kernel && np == 3 && s.max_rows <= 64   // (4 x 4 blocks: 174 VGPRs, two waves per SIMD -- not measured, k_pc_rows keeps them)
-                    && s.max_nl <= 3 && max_nu <= 4 && lds_w <= 64 * 1024;
-#ifdef WAI_PC_WAVE
-    s.wave_kernel = s.wave_kernel && (WAI_PC_WAVE != 0);
-#endif
-  }
-  if (s.rows_kernel) {
-    // bricks whose long rows come first (MINC: fracture cells, then their matrix cells with 2 of 8
-    // slots): k_pc_rows maps the long rows of all components to the first waves, so that a wave is
-    // all-long or all-short and the short ones skip the slot loop instead of idling in it
-    std::vector<int> split(s.nsub);
-    bool any = false;
-    for (int sd = 0; sd < s.nsub; sd++) {
-      const int lo = sub[sd], hi = sub[sd + 1];
-      int r1 = lo;
-      while (r1 < hi && (rowptr[r1 + 1] - rowptr[r1]) * 2 > W) r1++;
-      bool sorted = true;
-      for (int i = r1; i < hi && sorted; i++) sorted = (rowptr[i + 1] - rowptr[i]) * 2 <= W;
-      split[sd] = (sorted && r1 > lo) ? r1 - lo : hi - lo;
-      any = any || split[sd] != hi - lo;
-    }
-    if (any && dev_upload(c, &s.sub_split, split)) return -1;
-  }
-  s.built = true;
-  s.factored = false;
-  return 0;
-}
-
-void free_schedule(IluSchedule& s) {
-  hipFree(s.sub_ptr); hipFree(s.sub_nlev); hipFree(s.sub_split); hipFree(s.row_info); hipFree(s.fval); hipFree(s.dinv);
-  hipFree(s.row_uoff); hipFree(s.row_uoffw); hipFree(s.row_tslot); hipFree(s.sub_order); hipFree(s.sub_int); hipFree(s.sub_bnd); hipFree(s.ord_f); hipFree(s.ord_b);
-  s = IluSchedule();
-}
-void free_asm(AsmSystem& a) {
-  free_schedule(a.sched);
-  hipFree(a.E.col); hipFree(a.E.val); hipFree(a.ext_row); hipFree(a.gmap); hipFree(a.r_ext); hipFree(a.hval); hipFree(a.r_full);
-  a = AsmSystem();
-}
-
-// ILU(k) symbolic phase on the blocks of a block matrix (host CSR, ascending columns, all columns inside the
-// row's block): level-of-fill rule of PETSc's MatILUFactorSymbolic -- an entry created while row k is
-// eliminated from row i gets lev(i,k) + lev(k,j) + 1, an entry reached twice keeps the smaller level, kept when
-// <= levels ("sub_preconditioner": {"factor": {"levels": k}}, src/timestepper.F90:1716-1718, 1827).  ILU(k)'s
-// numeric phase is ILU(0) on the filled pattern with explicit zeros, which is how it runs here.
-// src: per entry the index it is filled from (kept for original entries, -1 for fill).
-void iluk_fill(const std::vector<int>& ptr, int levels, std::vector<int>& rp, std::vector<int>& col, std::vector<int>& src) {
-  const int n = (int)rp.size() - 1;
-  std::vector<int> orp(n + 1, 0), ocol, osrc, olev, odiag(n, 0);
-  ocol.reserve(col.size() * (size_t)(1 + 2 * levels)); osrc.reserve(ocol.capacity()); olev.reserve(ocol.capacity());
-  std::vector<int> wc, wl, ws;
-  for (size_t b = 0; b + 1 < ptr.size(); b++)
-    for (int i = ptr[b]; i < ptr[b + 1]; i++) {
-      wc.assign(col.begin() + rp[i], col.begin() + rp[i + 1]);
-      ws.assign(src.begin() + rp[i], src.begin() + rp[i + 1]);
-      wl.assign(wc.size(), 0);
-      for (size_t a = 0; a < wc.size() && wc[a] < i; a++) {   // eliminate with row k = wc[a], ascending (fill included)
-        const int k = wc[a], lik = wl[a];
-        for (int r = odiag[k] + 1; r < orp[k + 1]; r++) {
-          const int j = ocol[r], lv = lik + olev[r] + 1;
-          if (lv > levels) continue;
-          const size_t pos = (size_t)(std::lower_bound(wc.begin() + a + 1, wc.end(), j) - wc.begin());
-          if (pos < wc.size() && wc[pos] == j) { wl[pos] = std::min(wl[pos], lv); continue; }
-          wc.insert(wc.begin() + pos, j); wl.insert(wl.begin() + pos, lv); ws.insert(ws.begin() + pos, -1);
-        }
-      }
-      orp[i] = (int)ocol.size();
-      odiag[i] = -1;
-      for (size_t a = 0; a < wc.size(); a++) {
-        if (wc[a] == i) odiag[i] = (int)ocol.size();
-        ocol.push_back(wc[a]); osrc.push_back(ws[a]); olev.push_back(wl[a]);
-      }
-      orp[i + 1] = (int)ocol.size();
-      if (odiag[i] < 0) odiag[i] = orp[i + 1] - 1;
-    }
-  rp.swap(orp); col.swap(ocol); src.swap(osrc);
-}
-
-// PCASM: the overlapped row set of every subdomain (MatIncreaseOverlap over the matrix graph, owned
-// rows only), the extended block-ELL matrix that holds each set as its own block, and the map that
-// fills it from the Jacobian.  Local order inside a block = ascending row index (PETSc sorts the
-// subdomain index sets).
-// levels > 0: ILU(k) fill inside every block; overlap 0 with levels > 0 is block Jacobi + ILU(k) on the same path
-int ensure_halo_dof(wai_ctx* c, int dof) {   // halo buffers wide enough for `dof` doubles per cell
-  if (dof <= c->max_dof_buf) return 0;
-  if (c->d_sendbuf) (void)hipFree(c->d_sendbuf);
-  if (c->d_recvbuf) (void)hipFree(c->d_recvbuf);
-  c->d_sendbuf = c->d_recvbuf = nullptr;
-  c->max_dof_buf = dof;
-  if (dev_alloc(c, &c->d_sendbuf, (size_t)c->send_total * dof) || dev_alloc(c, &c->d_recvbuf, (size_t)c->mesh.n_halo * dof)) return -1;
-  return 0;
-}
-
-int halo_exchange(wai_ctx* c, double* vec, int dof);
-
-// The structure of the partition-ghost cells' matrix rows, from their owners (collective).  Every cell gets the
-// identity (owner rank, owner's local index); the identities of the ghost cells arrive by a halo exchange, and a
-// second exchange carries, for every cell a rank sends, the identities of its row's columns.  The receiver keeps
-// the columns it knows (its owned and ghost cells -- what the overlapped row sets can contain) in ascending local
-// order, with the sender's slot each came from.
-int ghost_rows(wai_ctx* c, std::vector<int>& grp, std::vector<int>& gci, std::vector<int>& gslot) {
-  const Bcsr& J = c->J;
-  const int N = J.n, H = c->mesh.n_halo, W = J.W;
-  std::vector<double> ids((size_t)N + H, -1.0);
-  const double base = (double)c->comm->rank * 4294967296.0;
-  for (int i = 0; i < N; i++) ids[i] = base + i;
-  double* scratch = c->ks.tmp;   // a Krylov work vector (n_prim * bs + 16 doubles): idle while the preconditioner is set up
-  HIPCHK(c, hipMemcpyAsync(scratch, ids.data(), sizeof(double) * (N + H), hipMemcpyHostToDevice, c->stream));
-  if (halo_exchange(c, scratch, 1)) return -1;
-  HIPCHK(c, hipMemcpyAsync(ids.data(), scratch, sizeof(double) * (N + H), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (ensure_halo_dof(c, W * J.bs * J.bs)) return -1;
-  std::vector<int> sidx((size_t)c->send_total);
-  HIPCHK(c, hipMemcpy(sidx.data(), c->d_send_idx, sizeof(int) * sidx.size(), hipMemcpyDeviceToHost));
-  std::vector<double> sb((size_t)c->send_total * W, -1.0), rb((size_t)H * W, -1.0);
-  for (int p = 0; p < c->send_total; p++) {
-    const int i = sidx[p];
-    for (int q = J.h_rowptr[i]; q < J.h_rowptr[i + 1]; q++) sb[(size_t)p * W + (q - J.h_rowptr[i])] = ids[J.h_colidx[q]];
-  }
-  HIPCHK(c, hipMemcpyAsync(c->d_sendbuf, sb.data(), sizeof(double) * sb.size(), hipMemcpyHostToDevice, c->stream));
-  if (comm_exchange(c->comm, c->n_nbr, c->nbr_rank.data(), c->send_ptr.data(), c->recv_ptr.data(), W, c->d_sendbuf, c->d_recvbuf,
-                    c->stream, c->err))
-    return -1;
-  HIPCHK(c, hipMemcpyAsync(rb.data(), c->d_recvbuf, sizeof(double) * rb.size(), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  std::vector<std::pair<double, int>> known((size_t)N + H);
-  for (int i = 0; i < N + H; i++) known[i] = {ids[i], i};
-  std::sort(known.begin(), known.end());
-  grp.assign((size_t)H + 1, 0);
-  gci.clear(); gslot.clear();
-  std::vector<std::pair<int, int>> row;
-  for (int h = 0; h < H; h++) {
-    row.clear();
-    for (int q = 0; q < W; q++) {
-      const double id = rb[(size_t)h * W + q];
-      if (id < 0.0) continue;
-      auto it = std::lower_bound(known.begin(), known.end(), std::make_pair(id, -1));
-      if (it != known.end() && it->first == id) row.push_back({it->second, q});
-    }
-    std::sort(row.begin(), row.end());
-    for (auto& e : row) { gci.push_back(e.first); gslot.push_back(e.second); }
-    grp[h + 1] = (int)gci.size();
-  }
-  return 0;
-}
-
-int build_asm(wai_ctx* c, int overlap, int levels) {
-  AsmSystem& a = c->as;
-  free_asm(a);
-  const Bcsr& J = c->J;
-  const int N = J.n, np = J.bs;
-  // Overlap across rank boundaries (the reference's PCASM subdomains are the ranks and MatIncreaseOverlap
-  // pulls in the neighbours' rows): the overlapped sets may contain partition-ghost cells, whose matrix rows come
-  // from their owners.  One ghost layer exists, so overlap 1 is exact; deeper overlap stops at that layer.
-  const bool cross = overlap > 0 && c->comm && c->comm->nranks > 1 && c->mesh.n_halo > 0 && c->n_nbr > 0;
-  const int H = cross ? c->mesh.n_halo : 0, NX = N + H;
-  std::vector<int> grp, gci, gslot;
-  if (cross && ghost_rows(c, grp, gci, gslot)) return -1;
-  // row i of the local matrix: owned rows are the Jacobian's, ghost rows the received ones
-  auto row_begin = [&](int i) { return i < N ? J.h_rowptr[i] : grp[i - N]; };
-  auto row_end = [&](int i) { return i < N ? J.h_rowptr[i + 1] : grp[i - N + 1]; };
-  auto row_col = [&](int i, int e) { return i < N ? J.h_colidx[e] : gci[e]; };
-  auto row_src = [&](int i, int e) { return i < N ? (e - J.h_rowptr[i]) * N + i : -(2 + gslot[e] * H + (i - N)); };
-  std::vector<int> sub((size_t)c->ilu.nsub + 1);
-  HIPCHK(c, hipMemcpy(sub.data(), c->ilu.sub_ptr, sizeof(int) * sub.size(), hipMemcpyDeviceToHost));
-  const int nsub = c->ilu.nsub;
-  std::vector<int> ext_ptr(nsub + 1, 0), ext_rows, mark(NX, -1), loc(NX, 0);
-  ext_rows.reserve((size_t)N * 2);
-  for (int sd = 0; sd < nsub; sd++) {
-    const size_t start = ext_rows.size();
-    for (int i = sub[sd]; i < sub[sd + 1]; i++) { ext_rows.push_back(i); mark[i] = sd; }
-    size_t lo = start;
-    for (int l = 0; l < overlap; l++) {
-      const size_t hi = ext_rows.size();
-      for (size_t q = lo; q < hi; q++) {
-        const int i = ext_rows[q];
-        for (int e = row_begin(i); e < row_end(i); e++) {
-          const int j = row_col(i, e);
-          if (j >= NX || mark[j] == sd) continue;
-          ext_rows.push_back(j); mark[j] = sd;
-        }
-      }
-      lo = hi;
-    }
-    std::sort(ext_rows.begin() + start, ext_rows.end());
-    ext_ptr[sd + 1] = (int)ext_rows.size();
-  }
-  const int n_ext = (int)ext_rows.size();
-  std::fill(mark.begin(), mark.end(), -1);
-  std::vector<int> erp(n_ext + 1, 0), ecol, esrc;
-  ecol.reserve((size_t)n_ext * 7); esrc.reserve((size_t)n_ext * 7);
-  int W = 1;
-  for (int sd = 0; sd < nsub; sd++) {
-    const int a0 = ext_ptr[sd], b0 = ext_ptr[sd + 1];
-    for (int q = a0; q < b0; q++) { mark[ext_rows[q]] = sd; loc[ext_rows[q]] = q; }
-    for (int q = a0; q < b0; q++) {
-      const int i = ext_rows[q];
-      for (int e = row_begin(i); e < row_end(i); e++) {
-        const int j = row_col(i, e);
-        if (j >= NX || mark[j] != sd) continue;
-        ecol.push_back(loc[j]);
-        esrc.push_back(row_src(i, e));   // slot * n + row in J's block-ELL planes, or the ghost rows' (<= -2)
-      }
-      erp[q + 1] = (int)ecol.size();
-    }
-  }
-  // (columns are positions in the extended numbering: block b's rows are ext_ptr[b] .. ext_ptr[b + 1])
-  if (levels > 0) iluk_fill(ext_ptr, levels, erp, ecol, esrc);
-  for (int q = 0; q < n_ext; q++) W = std::max(W, erp[q + 1] - erp[q]);
-  if (W > 255) { c->err = "ILU(k): more than 255 blocks in a factor row"; return -2; }
-  std::vector<int> ell_col((size_t)W * n_ext), gmap((size_t)W * n_ext, -1), erow(n_ext);
-  for (int sd = 0; sd < nsub; sd++)
-    for (int q = ext_ptr[sd]; q < ext_ptr[sd + 1]; q++) {
-      const int i = ext_rows[q];
-      const bool own = i >= sub[sd] && i < sub[sd + 1];
-      erow[q] = own ? (int)((unsigned)i | 0x80000000u) : i;
-      const int cnt = erp[q + 1] - erp[q];
-      for (int t = 0; t < W; t++) {
-        ell_col[(size_t)t * n_ext + q] = t < cnt ? ecol[erp[q] + t] : q;
-        gmap[(size_t)t * n_ext + q] = t < cnt ? esrc[erp[q] + t] : -1;
-      }
-    }
-  // (re)build
-  IluSchedule fresh;
-  a.sched = fresh;
-  a.n_ext = n_ext;
-  a.E.n = n_ext; a.E.ncols = n_ext; a.E.bs = np; a.E.W = W; a.E.nnzb = (int)ecol.size();
-  a.E.h_rowptr = erp; a.E.h_colidx = ecol;
-  if (dev_upload(c, &a.E.col, ell_col) || dev_upload(c, &a.gmap, gmap) || dev_upload(c, &a.ext_row, erow) ||
-      dev_alloc(c, &a.E.val, (size_t)W * np * np * n_ext) || dev_alloc(c, &a.r_ext, (size_t)np * n_ext + 16))
-    return -1;
-  if (int e = build_schedule(c, a.sched, erp, ecol, ext_ptr, n_ext, W, np, false)) return e;
-  if (cross) {
-    if (dev_alloc(c, &a.hval, (size_t)J.W * np * np * H) || dev_alloc(c, &a.r_full, (size_t)np * NX + 16)) return -1;
-    HIPCHK(c, hipMemset(a.r_full, 0, sizeof(double) * ((size_t)np * NX + 16)));
-  }
-  a.cross = cross;
-  a.overlap = overlap;
-  a.levels = levels;
-  return 0;
-}
+namespace wai {
 
 // read and clear the device flags; collective over ranks
 int fetch_flags(wai_ctx* c, int out[4]) {
@@ -572,408 +28,6 @@ int fetch_flags(wai_ctx* c, int out[4]) {
   }
   const int reset[4] = {0, 0x7fffffff, 0, 0};
   HIPCHK(c, hipMemcpyAsync(c->d_flags, reset, sizeof(reset), hipMemcpyHostToDevice, c->stream));
-  return 0;
-}
-
-int halo_exchange(wai_ctx* c, double* vec, int dof) {
-  if (!c->comm || c->mesh.n_halo == 0) return 0;
-  if (dof > c->max_dof_buf) { c->err = "halo dof too large"; return -1; }
-  pack_halo(c, vec, dof);
-  if (comm_exchange(c->comm, c->n_nbr, c->nbr_rank.data(), c->send_ptr.data(), c->recv_ptr.data(),
-                    dof, c->d_sendbuf, c->d_recvbuf, c->stream, c->err))
-    return -1;
-  return unpack_halo(c, vec, dof);
-}
-
-int allreduce_scal(wai_ctx* c, int slot, int count) {
-  if (!c->comm || c->comm->nranks == 1) return 0;
-  return comm_allreduce(c->comm, c->ks.scal + slot, count, 0, c->stream, c->err);
-}
-
-int read_scal(wai_ctx* c, int first, int count) {
-  c->ks.n_copy++;
-  HIPCHK(c, hipMemcpyAsync(c->ks.h_scal + first, c->ks.scal + first, count * sizeof(double),
-                           hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return 0;
-}
-
-// ---- source network: groups and reinjectors, one pass on the host -------------------------------
-// source_network%update (src/source_network.F90:90-130) after the sources' own controls: group sums
-// (source_network_group.F90:239-287) and limiters with uniform (:479-534) or progressive (:652-763;
-// array_progressive_limit, utils.F90:607-647) scaling, reinjector capacities
-// (source_network_reinjector.F90:1014-1112) and distribution with overflow (:1115-1292, :970-1010).
-// Serial: every source of the network lives on this rank.
-void net_separate(const SrcCtl& k, double rate, double enth, NetNode& n) {   // separator.F90:139-166, 212-260
-  double q = rate, h = enth, steam_m = 0.0, steam_e = 0.0;
-  for (int st = 0; st < 4; st++) {
-    const double hf = st == 0 ? k.sep_hf : k.sep_more[2 * (st - 1)], hg = st == 0 ? k.sep_hg : k.sep_more[2 * (st - 1) + 1];
-    if (st > 0 && !(hg > 0.0)) break;
-    double f, hw, hs;
-    if (h <= hf) { f = 0.0; hw = h; hs = 0.0; }
-    else if (h <= hg) { f = (h - hf) / (hg - hf); hw = hf; hs = hg; }
-    else { f = 1.0; hw = 0.0; hs = h; }
-    const double sr = f * q;
-    steam_m += sr; steam_e += sr * hs;
-    q = (1.0 - f) * q; h = hw;
-  }
-  n.wrate = q; n.wenth = h; n.srate = steam_m;
-  n.senth = std::fabs(steam_m) > 1.e-9 ? steam_e / steam_m : 0.0;
-}
-void net_zero_separated(NetNode& n) { n.wrate = n.wenth = n.srate = n.senth = 0.0; }
-void net_source_set_rate(Network& nw, int i, double rate) {   // source_network_node_set_rate + get_separated_flows
-  NetNode& n = nw.src[i];
-  n.rate = rate;
-  if (rate < 0.0 && i < (int)nw.h_ctl.size() && nw.h_ctl[i].sep_hg > 0.0) net_separate(nw.h_ctl[i], rate, n.enth, n);
-  else net_zero_separated(n);
-}
-NetNode& net_node(Network& nw, const NetRef& r) { return r.kind == 1 ? nw.src[r.index] : nw.groups[r.index].node; }
-double net_rate_by_type(const NetNode& n, int type) { return type == 1 ? n.wrate : (type == 2 ? n.srate : n.rate); }
-void net_group_sum(Network& nw, NetGroup& g) {   // source_network_group_sum + default_separated_flows
-  double q = 0.0, qh = 0.0;
-  for (const NetRef& r : g.in) { const NetNode& n = net_node(nw, r); q += n.rate; qh += n.rate * n.enth; }
-  g.node.enth = std::fabs(q) > 1.e-9 ? qh / q : 0.0;
-  g.node.rate = q;
-  if (q < 0.0 && g.sep.sep_hg > 0.0) net_separate(g.sep, q, g.node.enth, g.node);   // the group's own separator (:375-403)
-  else if (q < 0.0) {
-    double wq = 0, wqh = 0, sq = 0, sqh = 0;
-    for (const NetRef& r : g.in) {
-      const NetNode& n = net_node(nw, r);
-      wq += n.wrate; wqh += n.wrate * n.wenth; sq += n.srate; sqh += n.srate * n.senth;
-    }
-    g.node.wrate = wq; g.node.srate = sq;
-    g.node.wenth = std::fabs(wq) > 1.e-9 ? wqh / wq : 0.0;
-    g.node.senth = std::fabs(sq) > 1.e-9 ? sqh / sq : 0.0;
-  } else net_zero_separated(g.node);
-}
-void net_scale(Network& nw, const NetRef& r, double scale) {   // scale_rate, recursive through groups
-  if (r.kind == 1) { net_source_set_rate(nw, r.index, nw.src[r.index].rate * scale); return; }
-  NetGroup& g = nw.groups[r.index];
-  for (const NetRef& q : g.in) net_scale(nw, q, scale);
-  net_group_sum(nw, g);
-}
-bool net_min_limit_scale(const NetNode& n, int nl, const int* type, const double* limit, double& scale) {
-  bool over = false;
-  scale = 1.0;
-  for (int i = 0; i < nl; i++) {
-    const double a = std::fabs(net_rate_by_type(n, type[i]));
-    if (a > limit[i]) { over = true; if (a > 1.e-6) scale = std::min(scale, limit[i] / a); }
-  }
-  return over;
-}
-void net_limit_inputs(Network& nw, const NetRef& r, int nl, const int* type, const double* limit);
-void net_limit_rate(Network& nw, const NetRef& r, int nl, const int* type, const double* limit) {
-  double scale;
-  if (r.kind == 1 || nw.groups[r.index].scaling == 0) {   // node / uniform group: one factor for everything below
-    if (net_min_limit_scale(net_node(nw, r), nl, type, limit, scale)) net_scale(nw, r, scale);
-    return;
-  }
-  bool over = false;
-  for (int i = 0; i < nl; i++) over = over || std::fabs(net_rate_by_type(nw.groups[r.index].node, type[i])) > limit[i];
-  if (over) net_limit_inputs(nw, r, nl, type, limit);
-}
-void net_limit_inputs(Network& nw, const NetRef& r, int nl, const int* type, const double* limit) {
-  if (r.kind == 1 || nw.groups[r.index].scaling == 0) { net_limit_rate(nw, r, nl, type, limit); return; }
-  NetGroup& g = nw.groups[r.index];   // progressive: inputs are limited in order until the total is met
-  const size_t m = g.in.size();
-  std::vector<double> node_limit(m * 3, 0.0);
-  for (int il = 0; il < nl; il++) {
-    double sum = 0.0;
-    for (size_t i = 0; i < m; i++) {
-      const double a = std::fabs(net_rate_by_type(net_node(nw, g.in[i]), type[il]));
-      if (sum + a > limit[il]) { node_limit[i * 3 + il] = limit[il] - sum; break; }
-      node_limit[i * 3 + il] = a;
-      sum += a;
-    }
-  }
-  for (size_t i = 0; i < m; i++) net_limit_inputs(nw, g.in[i], nl, type, &node_limit[i * 3]);
-  net_group_sum(nw, g);
-}
-void net_node_limit_rate(double node_rate, double& rate) {   // reinjector.F90:199-215
-  if (node_rate > -1.0) rate = rate > -1.0 ? std::min(rate, node_rate) : node_rate;
-}
-void net_total(double wr, double wh, double sr, double sh, double& rate, double& enth) {
-  rate = wr + sr;
-  enth = rate > 1.e-6 ? (wr * wh + sr * sh) / rate : 0.0;
-}
-
-// one pass of the network on the host: nw.h_raw (rates, then enthalpies of the sources' own controls) ->
-// node states, nw.is_out / out_rate / out_enth for the sources the reinjectors feed
-void network_evaluate(Network& nw) {
-  const int n = (int)nw.src.size();
-  for (int i = 0; i < n; i++) { nw.src[i].enth = nw.h_raw[n + i]; net_source_set_rate(nw, i, nw.h_raw[i]); }
-  for (NetGroup& g : nw.groups) net_group_sum(nw, g);
-  for (size_t gi = 0; gi < nw.groups.size(); gi++) {
-    NetGroup& g = nw.groups[gi];
-    if (!g.n_limit) continue;
-    NetRef self; self.kind = 2; self.index = (int)gi;
-    net_limit_rate(nw, self, g.n_limit, g.limit_type, g.limit);
-    for (size_t gj = gi + 1; gj < nw.groups.size(); gj++) net_group_sum(nw, nw.groups[gj]);   // sum_out
-  }
-  // what the injection sources can take: their own specified rate, -1 if none
-  auto specified = [&](int i) { return nw.rate_specified[i] ? nw.h_raw[i] : -1.0; };
-  std::vector<double>& out_rate = nw.out_rate;
-  std::vector<double>& out_enth = nw.out_enth;
-  std::vector<char>& is_out = nw.is_out;
-  out_rate.assign(n, 0.0); out_enth.assign(n, 0.0); is_out.assign(n, 0);
-  for (NetReinjector& r : nw.reinjectors) r.fed = false;
-  for (int ri : nw.reinj_order) {   // capacities, downstream first
-    NetReinjector& r = nw.reinjectors[ri];
-    double cap[3] = {0.0, 0.0, 0.0};
-    for (const NetOutput& o : r.out) {
-      double node_rate = -1.0;
-      if (o.out.kind == 1) node_rate = specified(o.out.index);
-      else if (o.out.kind == 3) node_rate = o.flow == 1 ? nw.reinjectors[o.out.index].node.wrate : nw.reinjectors[o.out.index].node.srate;
-      else continue;
-      double& cc = cap[o.flow];
-      if (node_rate > -1.0) { if (cc > -1.0) cc += node_rate; } else cc = -1.0;
-    }
-    r.node.wrate = cap[1]; r.node.srate = cap[2];
-  }
-  for (auto it = nw.reinj_order.rbegin(); it != nw.reinj_order.rend(); ++it) {   // distribution, upstream first
-    NetReinjector& r = nw.reinjectors[*it];
-    if (r.in.kind == 1 || r.in.kind == 2) {
-      const NetNode& in = net_node(nw, r.in);
-      r.in_w = std::fabs(in.wrate); r.in_wh = in.wenth; r.in_s = std::fabs(in.srate); r.in_sh = in.senth;
-    } else if (!r.fed) { r.in_w = r.in_wh = r.in_s = r.in_sh = 0.0; }
-    double wbal = r.in_w, sbal = r.in_s;
-    r.out_w = r.out_s = 0.0;
-    for (NetOutput& o : r.out) {
-      double qw = 0.0, qs = 0.0;
-      double& q = o.flow == 1 ? qw : qs;
-      if (o.rate > -1.0) q = o.rate;                                              // rate output (:463-480)
-      else if (o.proportion >= 0.0) q = o.proportion * (o.flow == 1 ? r.in_w : r.in_s);   // proportion output (:484-501)
-      else q = -1.0;                                                              // whatever is left
-      double node_rate = -1.0;
-      if (o.out.kind == 1) node_rate = specified(o.out.index);
-      else if (o.out.kind == 3) node_rate = o.flow == 1 ? nw.reinjectors[o.out.index].node.wrate : nw.reinjectors[o.out.index].node.srate;
-      if (o.out.kind) net_node_limit_rate(node_rate, q);
-      double& bal = o.flow == 1 ? wbal : sbal;
-      double& tot = o.flow == 1 ? r.out_w : r.out_s;
-      if (q < 0.0) q = bal;
-      q = std::min(q, bal);
-      bal = std::max(bal - q, 0.0);
-      tot += q;
-      // enthalpies: specified for this flow type, or the input's
-      const double wh = (o.enthalpy > 0.0 && o.flow == 1) ? o.enthalpy : (o.enthalpy > 0.0 ? 0.0 : r.in_wh);
-      const double sh = (o.enthalpy > 0.0 && o.flow == 2) ? o.enthalpy : (o.enthalpy > 0.0 ? 0.0 : r.in_sh);
-      o.node.wrate = qw; o.node.wenth = wh; o.node.srate = qs; o.node.senth = sh;
-      net_total(qw, wh, qs, sh, o.node.rate, o.node.enth);
-      if (o.out.kind == 1) {
-        const int i = o.out.index;
-        is_out[i] = 1; out_rate[i] = o.node.rate; out_enth[i] = o.node.enth;
-        nw.src[i].wrate = qw; nw.src[i].wenth = wh; nw.src[i].srate = qs; nw.src[i].senth = sh;
-      } else if (o.out.kind == 3) {
-        NetReinjector& d = nw.reinjectors[o.out.index];
-        if (!d.fed) { d.in_w = d.in_wh = d.in_s = d.in_sh = 0.0; d.fed = true; }
-        if (o.flow == 1) { d.in_w += qw; d.in_wh = wh; } else { d.in_s += qs; d.in_sh = sh; }
-      }
-    }
-    r.over.wrate = wbal; r.over.wenth = r.in_wh; r.over.srate = sbal; r.over.senth = r.in_sh;
-    net_total(wbal, r.in_wh, sbal, r.in_sh, r.over.rate, r.over.enth);
-    if (r.overflow.kind == 3) {
-      NetReinjector& d = nw.reinjectors[r.overflow.index];
-      d.in_w = wbal; d.in_wh = r.in_wh; d.in_s = sbal; d.in_sh = r.in_sh; d.fed = true;
-    } else if (r.overflow.kind == 1) {   // an overflow source takes what is left, whatever its own rate says (:1002-1006)
-      const int i = r.overflow.index;
-      is_out[i] = 1; out_rate[i] = r.over.rate; out_enth[i] = r.over.enth;
-      nw.src[i].wrate = wbal; nw.src[i].wenth = r.in_wh; nw.src[i].srate = sbal; nw.src[i].senth = r.in_sh;
-    }
-  }
-  for (int i = 0; i < n; i++)
-    if (is_out[i]) {   // reinjector_output_update (:283-320): rate always, enthalpy unless the source has its own
-      nw.src[i].rate = out_rate[i];
-      nw.src[i].enth = (nw.enth_specified[i] && i < (int)nw.h_enth0.size()) ? nw.h_enth0[i] : out_enth[i];
-    }
-}
-
-int network_update(wai_ctx* c) {
-  Network& nw = c->net;
-  const int n = c->src.n;           // local sources
-  if (!nw.on) return 0;
-  const bool span = !nw.gidx.empty();
-  const int ng = span ? nw.n_global : n;
-  if (ng == 0) return 0;
-  // the sources' own (controlled) rates and flowing enthalpies on the current fluid
-  if (n) {
-    launch_source_rates(c, nw.d_raw, true);
-    HIPCHK(c, hipMemcpyAsync(span ? nw.h_loc.data() : nw.h_raw.data(), nw.d_raw, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-  }
-  if (span) {   // all ranks' sources: every rank fills its own entries, the sum is the gather (collective)
-    std::fill(nw.h_raw.begin(), nw.h_raw.end(), 0.0);
-    for (int i = 0; i < n; i++) { nw.h_raw[nw.gidx[i]] = nw.h_loc[i]; nw.h_raw[ng + nw.gidx[i]] = nw.h_loc[n + i]; }
-    HIPCHK(c, hipMemcpyAsync(nw.d_all, nw.h_raw.data(), sizeof(double) * 2 * ng, hipMemcpyHostToDevice, c->stream));
-    if (comm_allreduce(c->comm, nw.d_all, 2 * (size_t)ng, 0, c->stream, c->err)) return -1;
-    HIPCHK(c, hipMemcpyAsync(nw.h_raw.data(), nw.d_all, sizeof(double) * 2 * ng, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-  }
-  network_evaluate(nw);
-  if (!n) return 0;
-  const std::vector<double>& out_rate = nw.out_rate;
-  const std::vector<char>& is_out = nw.is_out;
-  // hand the result to the device: scale factors of group members, rates / enthalpies of reinjection sources
-  bool enth_changed = false;
-  for (int i = 0; i < n; i++) {
-    const int g = span ? nw.gidx[i] : i;
-    double mode = 0.0, val = 0.0;
-    if (is_out[g]) {
-      mode = 2.0; val = out_rate[g];
-      const double e = nw.src[g].enth;
-      if (e != nw.l_enth[i]) { nw.l_enth[i] = e; enth_changed = true; }
-    } else if (nw.src[g].rate != nw.h_raw[g]) {
-      mode = 1.0; val = nw.h_raw[g] != 0.0 ? nw.src[g].rate / nw.h_raw[g] : 1.0;
-    }
-    nw.l_net[2 * i] = mode; nw.l_net[2 * i + 1] = val;
-  }
-  HIPCHK(c, hipMemcpyAsync(c->src.net, nw.l_net.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
-  if (enth_changed)
-    HIPCHK(c, hipMemcpyAsync(c->src.enth, nw.l_enth.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));   // l_net / l_enth are reused by the next pass
-  return 0;
-}
-
-// ---- Jacobian couplings through the source network ---------------------------------------------
-// flow_simulation_modify_jacobian (src/flow_simulation.F90:3023-3084) widens the Jacobian's pattern by the
-// network's dependencies and MatFDColoring then differences the whole residual function -- network pass
-// included -- into it.  Here the 7-point part A is differenced with the network's factors held
-// (k_jacobian), and the rest, E = dR/dy *through the network pass*, is differenced separately on the cells
-// of the network's sources: for every such cell j and primary k, with y_jk + h (the same h as A's
-// columns), E[:, j][:, k] = (R(network pass redone) - R(factors held)) / h on the rows of those cells.
-// Two residual launches on the network's rows alone (k_residual's row list: the same code path per row, so
-// the same bits as a full sweep) and three host passes per column: the cost does not grow with the mesh.
-__global__ void k_gather_rows(int m, int bs, const int* __restrict__ cells, const double* __restrict__ f,
-                              double* __restrict__ out) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= m * bs) return;
-  out[t] = f[(size_t)cells[t / bs] * bs + t % bs];
-}
-
-// t += E x on the network's rows: thread (i, r) sums its row over the mc column cells (cells are distinct: no race).
-// xg != null: x at the column cells, gathered over the ranks ([mc][bs]); else the columns are the row cells themselves
-__global__ void k_coupling_apply(int mr, int mc, int bs, const int* __restrict__ cells, const double* __restrict__ val,
-                                 const double* __restrict__ x, const double* __restrict__ xg, double* __restrict__ t) {
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= mr * bs) return;
-  const int i = id / bs, r = id % bs;
-  double s = 0.0;
-  for (int j = 0; j < mc; j++) {
-    const double* e = val + ((size_t)(i * mc + j) * bs + r) * bs;
-    const double* xj = xg ? xg + (size_t)j * bs : x + (size_t)cells[j] * bs;
-    for (int k = 0; k < bs; k++) s += e[k] * xj[k];
-  }
-  t[(size_t)cells[i] * bs + r] += s;
-}
-
-int network_couplings(wai_ctx* c, double dt, double* y, const double* lhs_old) {
-  Network& nw = c->net;
-  nw.cp_valid = false;
-  const bool span = nw.cp_span;
-  const int ml = (int)nw.cp_cells.size(), m = span ? nw.cp_m : ml, j0 = span ? nw.cp_j0 : 0;
-  if (!nw.on || !nw.coupling || m == 0) return 0;
-  const int bs = c->np, mb = ml * bs, me = span ? c->comm->rank : 0;
-  if (!nw.d_cp_val) {
-    std::vector<int> cells = nw.cp_cells;
-    if (cells.empty()) cells.push_back(0);
-    if (dev_upload(c, &nw.d_cp_cells, cells) || dev_alloc(c, &nw.d_cp_val, (size_t)std::max(ml, 1) * m * bs * bs) ||
-        dev_alloc(c, &nw.d_cp_f, (size_t)c->mesh.n_local * bs) || dev_alloc(c, &nw.d_cp_g, (size_t)2 * std::max(mb, 1)) ||
-        dev_alloc(c, &nw.d_cp_x, (size_t)m * bs + 2))
-      return -1;
-  }
-  nw.h_cp_val.assign((size_t)ml * m * bs * bs, 0.0);
-  std::vector<double> g((size_t)2 * mb), yc((size_t)bs);
-  const int grid = (mb + 63) / 64;
-  auto set_y = [&](int cell, int k, double v) -> int {
-    HIPCHK(c, hipMemcpyAsync(y + (size_t)cell * bs + k, &v, sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    launch_eos(c, y, cell, 1, false);
-    return 0;
-  };
-  // one double from its owner to every rank (the sum over the ranks of {value on the owner, 0 elsewhere})
-  auto from_owner = [&](double& v, bool mine) -> int {
-    if (!span) return 0;
-    const double mineval = mine ? v : 0.0;
-    HIPCHK(c, hipMemcpyAsync(nw.d_cp_x, &mineval, sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if (comm_allreduce(c->comm, nw.d_cp_x, 1, 0, c->stream, c->err)) return -1;
-    HIPCHK(c, hipMemcpyAsync(&v, nw.d_cp_x, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return 0;
-  };
-  if (network_update(c)) return -1;   // the factors A was differenced with
-  bool any = false;
-  for (int j = 0; j < m; j++) {       // every rank walks the same columns: the network passes are collective
-    const bool mine = !span || nw.cp_owner[j] == me;
-    const int cell = mine ? nw.cp_cells[j - j0] : -1;
-    if (mine) {
-      HIPCHK(c, hipMemcpyAsync(yc.data(), y + (size_t)cell * bs, sizeof(double) * bs, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
-    for (int k = 0; k < bs; k++) {
-      double h = 0.0;
-      if (mine) {
-        double dx = yc[k];   // MatFDColoring "ds" increment, as fd_step (kernels_assembly.hip)
-        if (std::fabs(dx) < c->opts.fd_umin) dx = dx >= 0.0 ? c->opts.fd_umin : -c->opts.fd_umin;
-        h = dx * c->opts.fd_eps;
-      }
-      if (from_owner(h, mine)) return -1;
-      if (mine && set_y(cell, k, yc[k] + h)) return -1;
-      if (ml) {
-        launch_residual(c, dt, lhs_old, nw.d_cp_f, nullptr, nullptr, nw.d_cp_cells, ml);   // factors held; the network's rows alone
-        hipLaunchKernelGGL(k_gather_rows, grid, 64, 0, c->stream, ml, bs, nw.d_cp_cells, nw.d_cp_f, nw.d_cp_g);
-      }
-      if (network_update(c)) return -1;
-      if (ml) {
-        launch_residual(c, dt, lhs_old, nw.d_cp_f, nullptr, nullptr, nw.d_cp_cells, ml);   // network pass redone
-        hipLaunchKernelGGL(k_gather_rows, grid, 64, 0, c->stream, ml, bs, nw.d_cp_cells, nw.d_cp_f, nw.d_cp_g + mb);
-        HIPCHK(c, hipMemcpyAsync(g.data(), nw.d_cp_g, sizeof(double) * 2 * mb, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (int i = 0; i < ml; i++)
-          for (int r = 0; r < bs; r++) {
-            const double e = (g[(size_t)mb + i * bs + r] - g[(size_t)i * bs + r]) / h;
-            nw.h_cp_val[((size_t)(i * m + j) * bs + r) * bs + k] = e;
-            any = any || e != 0.0;
-          }
-      }
-      if (mine && set_y(cell, k, yc[k])) return -1;   // back to the unperturbed state and its network factors
-      if (network_update(c)) return -1;
-    }
-  }
-  // a perturbed state outside the EOS's range was already reported by the perturbed-state sweep of A
-  HIPCHK(c, hipMemsetAsync(c->d_flags, 0, sizeof(int), c->stream));
-  if (any) {
-    HIPCHK(c, hipMemcpyAsync(nw.d_cp_val, nw.h_cp_val.data(), sizeof(double) * nw.h_cp_val.size(), hipMemcpyHostToDevice,
-                             c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-  }
-  double flag = any ? 1.0 : 0.0;   // every rank applies E (a collective gather of x) or none does
-  if (span) {
-    HIPCHK(c, hipMemcpyAsync(nw.d_cp_x, &flag, sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if (comm_allreduce(c->comm, nw.d_cp_x, 1, 1, c->stream, c->err)) return -1;
-    HIPCHK(c, hipMemcpyAsync(&flag, nw.d_cp_x, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-  }
-  nw.cp_valid = flag != 0.0;
-  return 0;
-}
-
-// t = (A + E) x: the block-ELL SpMV and, when the network couples cells, its blocks on top.  A network on several
-// ranks: x at the network's cells is gathered first (one all-reduce of m * bs doubles per application)
-int apply_operator(wai_ctx* c, const double* x, double* t) {
-  launch_spmv(c, x, t);
-  const Network& nw = c->net;
-  if (!nw.cp_valid) return 0;
-  const int ml = (int)nw.cp_cells.size(), bs = c->np;
-  if (!nw.cp_span) {
-    hipLaunchKernelGGL(k_coupling_apply, (ml * bs + 63) / 64, 64, 0, c->stream, ml, ml, bs, nw.d_cp_cells, nw.d_cp_val, x,
-                       (const double*)nullptr, t);
-    return 0;
-  }
-  const int m = nw.cp_m;
-  HIPCHK(c, hipMemsetAsync(nw.d_cp_x, 0, sizeof(double) * (size_t)m * bs, c->stream));
-  if (ml) hipLaunchKernelGGL(k_gather_rows, (ml * bs + 63) / 64, 64, 0, c->stream, ml, bs, nw.d_cp_cells, x, nw.d_cp_x + (size_t)nw.cp_j0 * bs);
-  if (comm_allreduce(c->comm, nw.d_cp_x, (size_t)m * bs, 0, c->stream, c->err)) return -1;
-  if (ml) hipLaunchKernelGGL(k_coupling_apply, (ml * bs + 63) / 64, 64, 0, c->stream, ml, m, bs, nw.d_cp_cells, nw.d_cp_val, x,
-                             (const double*)nw.d_cp_x, t);
   return 0;
 }
 
@@ -1015,745 +69,6 @@ int do_jacobian(wai_ctx* c, double dt, const double* y, const double* lhs_old) {
   if (launch_jacobian(c, dt, lhs_old)) return -1;
   c->ilu.factored = false;
   return network_couplings(c, dt, const_cast<double*>(y), lhs_old);   // y is perturbed and restored in place
-}
-
-// which preconditioner path is in force: the fused brick kernels (block Jacobi, every subdomain
-// <= 1024 rows) or the general one (PCASM's extended system, subdomains of any size, PCNONE)
-bool pc_fused(const wai_ctx* c) {
-  return c->opts.pc_type == WAI_PC_BJACOBI && !c->ilu.big && c->opts.ilu_levels <= 0;
-}
-// the extended-system path: PCASM's overlapped row sets and / or ILU(k)'s filled pattern
-bool pc_extended(const wai_ctx* c) {
-  return c->opts.pc_type == WAI_PC_ASM || (c->opts.pc_type == WAI_PC_BJACOBI && c->opts.ilu_levels > 0);
-}
-
-// PCLU: dense inverse of every preconditioner block (one block per rank with sub_ptr = NULL), by
-// Gauss-Jordan elimination with partial pivoting on the host.  Meant for small systems.
-int lu_setup(wai_ctx* c) {
-  const Bcsr& J = c->J;
-  const int bs = J.bs, bb = bs * bs, nsub = c->ilu.nsub;
-  std::vector<int> sub((size_t)nsub + 1);
-  HIPCHK(c, hipMemcpy(sub.data(), c->ilu.sub_ptr, sizeof(int) * sub.size(), hipMemcpyDeviceToHost));
-  LuBlocks& L = c->lu;
-  if (L.h_inv_ptr.empty()) {
-    L.h_inv_ptr.assign((size_t)nsub + 1, 0);
-    for (int s = 0; s < nsub; s++) {
-      const size_t m = (size_t)(sub[s + 1] - sub[s]) * bs;
-      if (m > 8192) { c->err = "preconditioner lu: a block has more than 8192 unknowns (dense inverses; use ilu)"; return -2; }
-      L.h_inv_ptr[s + 1] = L.h_inv_ptr[s] + m * m;
-    }
-    L.total = L.h_inv_ptr[nsub];
-    if (L.total > ((size_t)1 << 29)) { c->err = "preconditioner lu: more than 4 GB of dense block inverses"; return -2; }
-    if (dev_alloc(c, &L.inv, L.total) || dev_upload(c, &L.inv_ptr, L.h_inv_ptr)) return -1;
-  }
-  std::vector<double> val((size_t)J.nnzb * bb), inv(L.total), A;
-  {
-    double* tmp = nullptr;
-    if (dev_alloc(c, &tmp, val.size())) return -1;
-    launch_ell_to_bcsr(c, J.val, tmp);
-    HIPCHK(c, hipMemcpyAsync(val.data(), tmp, val.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(tmp);
-  }
-  for (int s = 0; s < nsub; s++) {
-    const int lo = sub[s], hi = sub[s + 1], m = (hi - lo) * bs;
-    A.assign((size_t)m * m, 0.0);
-    double* B = inv.data() + L.h_inv_ptr[s];
-    std::fill(B, B + (size_t)m * m, 0.0);
-    for (int i = 0; i < m; i++) B[(size_t)i * m + i] = 1.0;
-    for (int i = lo; i < hi; i++)
-      for (int q = J.h_rowptr[i]; q < J.h_rowptr[i + 1]; q++) {
-        const int j = J.h_colidx[q];
-        if (j < lo || j >= hi) continue;   // couplings leaving the block are dropped (block Jacobi)
-        for (int r = 0; r < bs; r++)
-          for (int k = 0; k < bs; k++) A[(size_t)((i - lo) * bs + r) * m + (j - lo) * bs + k] = val[(size_t)q * bb + r * bs + k];
-      }
-    for (int p = 0; p < m; p++) {   // Gauss-Jordan with partial pivoting on [A | B]
-      int piv = p;
-      for (int r = p + 1; r < m; r++) if (std::fabs(A[(size_t)r * m + p]) > std::fabs(A[(size_t)piv * m + p])) piv = r;
-      if (A[(size_t)piv * m + p] == 0.0) return 1;   // singular block: recoverable (KSP_DIVERGED_PC_FAILED)
-      if (piv != p)
-        for (int k = 0; k < m; k++) { std::swap(A[(size_t)p * m + k], A[(size_t)piv * m + k]); std::swap(B[(size_t)p * m + k], B[(size_t)piv * m + k]); }
-      const double d = 1.0 / A[(size_t)p * m + p];
-      for (int k = 0; k < m; k++) { A[(size_t)p * m + k] *= d; B[(size_t)p * m + k] *= d; }
-      for (int r = 0; r < m; r++) {
-        const double f = A[(size_t)r * m + p];
-        if (r == p || f == 0.0) continue;
-        for (int k = 0; k < m; k++) { A[(size_t)r * m + k] -= f * A[(size_t)p * m + k]; B[(size_t)r * m + k] -= f * B[(size_t)p * m + k]; }
-      }
-    }
-  }
-  HIPCHK(c, hipMemcpyAsync(L.inv, inv.data(), L.total * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return 0;
-}
-
-int do_pc_setup(wai_ctx* c) {
-  if (c->opts.pc_type == WAI_PC_NONE) { c->ilu.factored = true; return 0; }
-  if (c->opts.pc_type == WAI_PC_LU) {
-    Prof p(c, KC_PC_SETUP);
-    const int e = lu_setup(c);
-    if (e == 0) c->ilu.factored = true;
-    return e;
-  }
-  {
-    Prof p(c, KC_PC_SETUP);
-    if (pc_extended(c)) {
-      const int ov = c->opts.pc_type == WAI_PC_ASM ? (c->opts.asm_overlap > 0 ? c->opts.asm_overlap : 1) : 0;
-      const int lv = std::max(c->opts.ilu_levels, 0);
-      if (c->as.overlap != ov || c->as.levels != lv || c->as.E.bs != c->J.bs) { if (int e = build_asm(c, ov, lv)) return e < 0 ? -1 : e; }
-      if (c->as.cross) {   // the ghost cells' matrix rows, from their owners
-        const int dof = c->J.W * c->J.bs * c->J.bs;
-        if (ensure_halo_dof(c, dof)) return -1;
-        launch_pack_rows(c);
-        if (comm_exchange(c->comm, c->n_nbr, c->nbr_rank.data(), c->send_ptr.data(), c->recv_ptr.data(), dof, c->d_sendbuf,
-                          c->d_recvbuf, c->stream, c->err))
-          return -1;
-        launch_unpack_rows(c);
-      }
-      launch_asm_gather_matrix(c);
-      if (launch_ilu_factor_on(c, c->as.E, c->as.sched)) return -1;
-      c->ilu.factored = true;
-    } else if (launch_ilu_factor(c)) return -1;
-  }
-  int fl[4];
-  if (fetch_flags(c, fl)) return -1;
-  return fl[0] ? 1 : 0;
-}
-
-// dot products the Krylov drivers want of a preconditioner result (see launch_pc): general path
-int pc_dots(wai_ctx* c, int dot_mode, const double* x, const double* z, const double* aux) {
-  const int n = c->ks.n;
-  if (dot_mode == 1) return vec_dots(c, z, aux, S_D1, nullptr, nullptr, 0, n);
-  if (dot_mode == 2) return vec_dots(c, x, z, S_D1, z, z, S_D2, n);
-  if (dot_mode == 4) {   // merged BiCGStab reductions: (x,z), (z,z), (x,x), (x,aux), (z,aux)
-    vec_dots(c, x, z, S_D1, z, z, S_D2, n);
-    vec_dots(c, x, x, S_DP2, x, aux, S_RHONEW, n);
-    return vec_dots(c, z, aux, S_W2, nullptr, nullptr, 0, n);
-  }
-  if (dot_mode == 3) return vec_dots(c, z, z, S_DP2, nullptr, nullptr, 0, n);
-  return 0;
-}
-
-// the reduction slots a dot mode leaves partial sums in: first slot, count
-void mode_slots(int dot_mode, int& slot0, int& nslots) {
-  slot0 = dot_mode == 3 ? S_DP2 : S_D1;
-  nslots = dot_mode == 2 ? 2 : (dot_mode == 4 ? 5 : 1);
-}
-// sum the partials a preconditioner application left (general path: separate one-block launches)
-int pc_finalize(wai_ctx* c, int dot_mode, int phase) {
-  if (!dot_mode) return 0;
-  int slot0, nslots;
-  mode_slots(dot_mode, slot0, nslots);
-  if (nslots == 5) { vec_finalize(c, c->ks.nb_pc, slot0, 4, -1); return vec_finalize(c, c->ks.nb_pc, slot0 + 4, 1, phase); }
-  return vec_finalize(c, c->ks.nb_pc, slot0, nslots, phase);
-}
-
-// z = B^-1 r; dot_mode as launch_pc, with `x` the partner of mode 2.  fin_phase >= -1: the partial sums of
-// the dot products are summed into the device scalars (and the BiCGStab scalars of that phase derived) --
-// in the fused kernel's last workgroup, or by a k_finalize launch on the general path; -2: left as partials
-int pc_solve(wai_ctx* c, const double* r, double* z, int dot_mode, const double* x, const double* aux, int fin_phase = -2) {
-  if (pc_fused(c)) {
-    // the fused kernels take the partner of modes 2 and 4 from their own input vector (the x of
-    // z = B^-1 A x); here the input is r = (A + E) x, so those inner products are reduced separately
-    if (dot_mode == 2 || dot_mode == 4) {
-      if (launch_pc(c, false, r, z, 0, nullptr)) return -1;
-      if (pc_dots(c, dot_mode, x, z, aux)) return -1;
-      return fin_phase >= -1 ? pc_finalize(c, dot_mode, fin_phase) : 0;
-    }
-    if (fin_phase >= -1 && dot_mode) {
-      int slot0, nslots;
-      mode_slots(dot_mode, slot0, nslots);
-      const Fin fin = make_fin(c, slot0, nslots, fin_phase);
-      return launch_pc(c, false, r, z, dot_mode, aux, nullptr, 0, &fin);
-    }
-    return launch_pc(c, false, r, z, dot_mode, aux);
-  }
-  const size_t n = (size_t)c->ks.n;
-  if (c->opts.pc_type == WAI_PC_NONE) {
-    if (z != r) vec_copy(c, z, r, n);
-  } else if (c->opts.pc_type == WAI_PC_LU) {
-    if (launch_lu_apply(c, r, z)) return -1;
-  } else if (pc_extended(c)) {
-    AsmSystem& a = c->as;
-    if (a.cross) {   // the residual's ghost entries: one more halo exchange per application
-      vec_copy(c, a.r_full, r, n);
-      if (halo_exchange(c, a.r_full, c->np)) return -1;
-      launch_asm_gather(c, a.r_full);
-    } else launch_asm_gather(c, r);
-    if (a.sched.big) { if (launch_big_solve(c, a.E, a.sched, a.r_ext)) return -1; }
-    else if (launch_pc_on(c, a.E, a.sched, false, a.r_ext, a.r_ext, 0, nullptr)) return -1;
-    launch_asm_scatter(c, z);
-  } else {   // block Jacobi with subdomains of more than 1024 rows
-    if (z != r) vec_copy(c, z, r, n);
-    if (launch_big_solve(c, c->J, c->ilu, z)) return -1;
-  }
-  if (pc_dots(c, dot_mode, x, z, aux)) return -1;
-  return fin_phase >= -1 ? pc_finalize(c, dot_mode, fin_phase) : 0;
-}
-
-// z = B^-1 A x  (x has halo room); optional fused dot products of the result, summed as pc_solve sums them.
-// x2 (optional; fused kernels only, pc_axpy_ok): the operand is x - alpha x2 with alpha the device scalar S_ALPHA, formed
-// inside the kernel (BiCGStab's S = R - alpha V); both vectors have halo room, the operand's ghost values are packed as
-// one vector on the sending side and arrive in x's ghost entries, x2's stay zero.
-int pc_amul(wai_ctx* c, double* x, double* z, int dot_mode = 0, const double* aux = nullptr, int fin_phase = -2,
-            const double* x2 = nullptr, bool post = false) {
-  const IluSchedule& s = c->ilu;
-  if (!pc_fused(c) || c->net.cp_valid) {   // unfused: t = A x (+ the network's blocks), then the preconditioner
-    if (x2) { c->err = "pc_amul: composed operand on the unfused path"; return -1; }
-    if (halo_exchange(c, x, c->np)) return -1;
-    { Prof p(c, KC_SPMV); if (apply_operator(c, x, c->ks.tmp)) return -1; }
-    Prof p(c, KC_PC_APPLY);
-    if (int e = pc_solve(c, c->ks.tmp, z, dot_mode, x, aux, fin_phase)) return e;
-    if (post) bcgs_scalars(c, -1, true);   // the scalars k_finalize derived, posted to the host
-    return 0;
-  }
-  Fin fin;
-  const Fin* fp = nullptr;
-  if (fin_phase >= -1 && dot_mode) {
-    int slot0, nslots;
-    mode_slots(dot_mode, slot0, nslots);
-    fin = make_fin(c, slot0, nslots, fin_phase, post);
-    fp = &fin;
-  }
-  const bool halo = c->comm && c->mesh.n_halo;
-  if (halo && c->np > c->max_dof_buf) { c->err = "halo dof too large"; return -1; }
-  if (halo && c->comm_stream && s.n_int > 0 && s.n_bnd > 0 && !c->prof_on) {
-    // The partition-ghost values are needed only by the bricks on the rank's faces: pack on the
-    // compute stream, send / receive / unpack on the communication stream while the interior bricks
-    // run, then the face bricks.  (xGMI transfers and RCCL's launch latency hide behind ~90 % of
-    // the kernel at 108^3 cells per rank.)
-    if (x2) pack_halo_axpy(c, x, x2, c->np); else pack_halo(c, x, c->np);
-    HIPCHK(c, hipEventRecord(c->ev_pack, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
-    if (comm_exchange(c->comm, c->n_nbr, c->nbr_rank.data(), c->send_ptr.data(), c->recv_ptr.data(), c->np,
-                      c->d_sendbuf, c->d_recvbuf, c->comm_stream, c->err))
-      return -1;
-    if (unpack_halo(c, x, c->np, c->comm_stream)) return -1;
-    HIPCHK(c, hipEventRecord(c->ev_halo, c->comm_stream));
-    if (launch_pc(c, true, x, z, dot_mode, aux, s.sub_int, s.n_int, nullptr, x2)) return -1;   // its partials wait for ...
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_halo, 0));
-    return launch_pc(c, true, x, z, dot_mode, aux, s.sub_bnd, s.n_bnd, fp, x2);        // ... the face bricks' last workgroup
-  }
-  if (halo) {
-    if (x2) {
-      pack_halo_axpy(c, x, x2, c->np);
-      if (comm_exchange(c->comm, c->n_nbr, c->nbr_rank.data(), c->send_ptr.data(), c->recv_ptr.data(), c->np, c->d_sendbuf,
-                        c->d_recvbuf, c->stream, c->err))
-        return -1;
-      if (unpack_halo(c, x, c->np)) return -1;
-    } else if (halo_exchange(c, x, c->np)) return -1;
-  }
-  Prof p(c, KC_PC_APPLY);
-  return launch_pc(c, true, x, z, dot_mode, aux, nullptr, 0, fp, x2);
-}
-
-// wait for the scalars a kernel posted to the host mirror with sequence number `seq` (Fin / k_bcgs_scalars):
-// no copy, no event -- the host spins on the pinned word the device writes last
-int wait_post(wai_ctx* c, int seq) {
-  Krylov& k = c->ks;
-  // {(R,R), 8 * sequence number + code, check}: the pair is taken only when the check word verifies it (post_scalars)
-  volatile unsigned long long* post = reinterpret_cast<volatile unsigned long long*>(k.h_scal + POST_OFF);
-  const double lo = 8.0 * (double)seq, hi = lo + 8.0;
-  auto take = [&](double& val, double& tag) -> bool {
-    const unsigned long long t = post[1];
-    std::memcpy(&tag, &t, 8);
-    if (!(tag >= lo && tag < hi)) return false;
-    const unsigned long long v = post[0], chk = post[2];
-    if ((v ^ t ^ POST_KEY) != chk) return false;    // torn or not all there yet: look again
-    std::memcpy(&val, &v, 8);
-    return true;
-  };
-  double val = 0.0, tag = 0.0;
-  for (unsigned long long spin = 1; !take(val, tag); spin++) {
-    if ((spin & 0x3fff) == 0) {   // a stream that ran dry without posting, or a device error: do not spin forever
-      const hipError_t e = hipStreamQuery(c->stream);
-      if (e != hipErrorNotReady && !take(val, tag)) {
-        c->err = e == hipSuccess ? "scalars were not posted by the device" : std::string("stream: ") + hipGetErrorString(e);
-        return -1;
-      }
-      if (e != hipErrorNotReady) break;
-    }
-  }
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  k.h_scal[S_DP2] = val;
-  k.h_scal[S_BREAK] = tag - lo;
-  return 0;
-}
-
-// How ksp_bcgs arranges an iteration (WAI_BCGS=petsc | merged | fused; WAI_BCGS_MERGED=1 is "merged"):
-//   0 petsc   the reductions where KSPSolve_BCGS has them: five launches (one rank only; several ranks run "merged")
-//   1 merged  the second half's five inner products in one reduction, (R,R) and (R,RP) derived: five launches (+ two
-//             one-thread scalar kernels behind the all-reduces on several ranks) -- round 3's multi-rank form
-//   2 fused   merged reductions and the X / R / next-P updates in ONE pass (k_bcgs_xrp, which re-forms S from R and V):
-//             FOUR launches -- fused A P, S = R - alpha V, fused A S, X / R / P -- and 11 vector passes beside the two
-//             matrix sweeps where "petsc" makes 14 (default).
-//             WAI_BCGS_COMPOSE=1: S is not stored at all, the second fused launch forms R - alpha V itself (own row and
-//             neighbour gathers): THREE launches, 9 passes -- and MEASURED SLOWER at every full size: the second gather
-//             per matrix slot costs the launch 0.56 -> 0.73 ms at 216^3 (the gathers, not the matrix stream, fill the
-//             vector-cache's request slots), more than k_bcgs_s's 0.07 ms; same box, ms per iteration petsc / fused /
-//             composed: c3 1.530 / -- / 1.542, c4 1.562 / -- / 1.649, c5 0.559 / -- / 0.578; only the 108^3 rank share
-//             gains (0.245 -> 0.235).  Kept selectable; bit-identical to the stored-S form (tests/test_hip_pc.py).
-int bcgs_mode(const wai_ctx* c) {
-  const bool multi = c->comm && c->comm->nranks > 1;
-  int mode = 2;
-  if (const char* e = getenv("WAI_BCGS")) {
-    if (!strcmp(e, "petsc")) mode = 0;
-    else if (!strcmp(e, "merged")) mode = 1;
-    else if (!strcmp(e, "fused")) mode = 2;
-  } else if (getenv("WAI_BCGS_MERGED")) mode = 1;
-  if (multi && mode == 0) mode = 1;
-  return mode;
-}
-// does the second fused launch form S itself?  (asked for, the fused brick kernels, no network blocks beside the matrix)
-bool pc_axpy_ok(const wai_ctx* c) {
-  const char* e = getenv("WAI_BCGS_COMPOSE");
-  return e && e[0] == '1' && pc_fused(c) && !c->net.cp_valid && pc_axpy_capable(c);
-}
-
-struct BcgsPlan { int mode; bool fused3, merged, axpy, multi; };
-BcgsPlan bcgs_plan(const wai_ctx* c) {
-  BcgsPlan p;
-  p.mode = bcgs_mode(c);
-  p.fused3 = p.mode == 2; p.merged = p.mode >= 1;
-  p.axpy = p.fused3 && pc_axpy_ok(c);
-  p.multi = c->comm && c->comm->nranks > 1;
-  return p;
-}
-// First half of an iteration: (P update,) V = B^-1 A P with (V,RP), alpha, (S).  It touches P, V, S and the device
-// scalars only -- not X, R -- so ksp_bcgs enqueues the NEXT iteration's first half *before* the host waits for this
-// iteration's residual norm: the device never idles through the read-back, and if the norm says "converged" the
-// speculative half is simply discarded.
-int bcgs_first_half(wai_ctx* c, const BcgsPlan& pl) {
-  Krylov& k = c->ks;
-  if (!pl.fused3) { Prof p(c, KC_VECTOR); bcgs_update_p(c); }
-  if (int e = pc_amul(c, k.P, k.V, 1, k.RP, pl.multi ? -1 : 2)) return e;
-  Prof p(c, KC_VECTOR);
-  if (pl.multi) { if (int e = allreduce_scal(c, S_D1, 1)) return e; bcgs_scalars(c, 2); }
-  if (!pl.axpy) bcgs_update_s(c);
-  return 0;
-}
-// Second half: T = B^-1 A S with its inner products, omega (and with merged reductions (R,R), rho, beta), the scalars
-// posted to the host (sequence number left in ks.seq), X / R (/ next P) updated.
-// Merged reductions (more than one rank always): the five inner products travel in ONE all-reduce -- (S,T), (T,T) for
-// omega and (S,S), (S,RP), (T,RP), from which (R,R) and (R,RP) of R = S - omega T follow -- so an iteration costs two
-// all-reduces ((V,RP); these five) instead of three, and omega, rho and beta are known before X and R are touched: the
-// host sees the norm one launch earlier, and (fused) the updates of X, R and the next P are one pass.
-int bcgs_second_half(wai_ctx* c, const BcgsPlan& pl) {
-  Krylov& k = c->ks;
-  if (pl.fused3) {
-    if (int e = pc_amul(c, pl.axpy ? k.R : k.S, k.T, 4, k.RP, pl.multi ? -1 : 6, pl.axpy ? k.V : nullptr, !pl.multi)) return e;
-    Prof p(c, KC_VECTOR);
-    if (pl.multi) { if (int e = allreduce_scal(c, S_D1, 5)) return e; bcgs_scalars(c, 6, true); }
-    bcgs_update_xrp(c);
-    return 0;
-  }
-  if (int e = pc_amul(c, k.S, k.T, pl.merged ? 4 : 2, pl.merged ? k.RP : nullptr, pl.merged ? -1 : 3)) return e;
-  Prof p(c, KC_VECTOR);
-  if (pl.merged) {
-    if (pl.multi) { if (int e = allreduce_scal(c, S_D1, 5)) return e; }
-    bcgs_scalars(c, 6, true);   // omega, (R,R), (R,RP), rotation; posted: the host sees the norm before X, R are updated
-    bcgs_update_xr(c, false);
-  } else {
-    bcgs_update_xr(c, true, 4, true);
-  }
-  return 0;
-}
-
-// KSPBCGS [PETSc], left preconditioning, preconditioned residual norm, zero initial guess.
-// One rank: every reduction is finished by the last workgroup of the kernel that produces it (Fin), and the one that
-// ends an iteration's reductions posts the scalars to the pinned host mirror: no k_finalize launches, no copy, no event.
-// petsc / merged -- five launches: P update, fused A*P + ILU solve + (V,RP) + alpha, S update, fused A*S + ILU solve +
-// its inner products (+ omega), X/R update (+ (R,R),(R,RP) + rho/beta).
-// fused -- four: fused A*P + ILU solve + (V,RP) + alpha; S = R - alpha V; fused A*S + ILU solve + (S,T),(T,T),(S,S),(S,RP),
-// (T,RP) + omega, (R,R), rho, beta, posted; X / R / P update in one pass.  (WAI_BCGS_COMPOSE=1: three, S formed inside the
-// second fused launch -- measured slower, bcgs_mode.)
-int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
-  Krylov& k = c->ks;
-  const int n = k.n;
-  const double rtol = c->opts.ksp_rtol, atol = c->opts.ksp_atol;
-  const int maxits = c->opts.ksp_max_its;
-  const BcgsPlan pl = bcgs_plan(c);
-  const bool multi = pl.multi;
-  vec_zero(c, x, n);
-  vec_zero(c, k.P, k.nl);
-  vec_zero(c, k.V, pl.fused3 ? k.nl : n);   // fused: V's ghost entries stay zero (the composed operand's ghosts arrive in R's)
-  partials_clear(c, S_D1, 5);   // S_D1 .. S_W2: whatever an aborted solve or a probe left behind
-  {
-    Prof p(c, KC_PC_APPLY);
-    if (pc_solve(c, b, k.R, 3, nullptr, nullptr, multi ? -1 : 0)) return -1;  // R = B^-1 b, (R,R), first rho / beta
-  }
-  {
-    Prof p(c, KC_VECTOR);
-    if (multi) { if (allreduce_scal(c, S_DP2, 1)) return -1; bcgs_scalars(c, 0); }
-    vec_copy(c, k.RP, k.R, n);
-    if (pl.fused3) vec_copy(c, k.P, k.R, n);   // the first P = R + beta (0 - omega 0): the later ones come out of k_bcgs_xrp
-  }
-  if (read_scal(c, S_DP2, 1)) return -1;
-  double dp = std::sqrt(k.h_scal[S_DP2]);
-  const double dp0 = dp, ttol = std::max(rtol * dp, atol);
-  *its = 0;
-  *reason = 0;
-  if (std::isnan(dp)) *reason = -9;
-  else if (dp <= ttol) *reason = (dp <= atol) ? 3 : 2;
-  double* Xsave = k.X;
-  k.X = x;  // X aliases the caller's x during the iteration
-  int rc = 0;
-#ifdef WAI_BCGS_NO_SPECULATION
-  const bool speculate = false;
-#else
-  const bool speculate = true;
-#endif
-  bool have_first_half = false;
-  for (int i = 0; i < maxits && !*reason && !rc; i++) {
-    if (!have_first_half && (rc = bcgs_first_half(c, pl))) break;
-    have_first_half = false;
-    if ((rc = bcgs_second_half(c, pl))) break;
-    const int seq = k.seq;
-    if (speculate && i + 1 < maxits) {
-      if ((rc = bcgs_first_half(c, pl))) break;
-      have_first_half = true;
-    }
-    if ((rc = wait_post(c, seq))) break;
-    dp = std::sqrt(k.h_scal[S_DP2]);
-    *its = i + 1;
-    const double brk = k.h_scal[S_BREAK];
-    if (brk == 4.0) { *reason = -9; c->err = "a reduction's partial sum never arrived (finaliser wait ran out)"; }
-    else if (brk == 1.0) *reason = -5;                        // (R,RP) or (V,RP) vanished
-    else if (brk == 2.0) *reason = (dp == 0.0) ? 3 : -5;      // (T,T) = 0: solved exactly, or breakdown
-    else if (std::isnan(dp)) *reason = -9;
-    else if (dp <= ttol) *reason = (dp <= atol) ? 3 : 2;
-    else if (brk == 3.0) *reason = -5;                        // next rho = 0 without convergence
-    else if (dp >= 1.e4 * dp0) *reason = -4;
-  }
-  k.X = Xsave;
-  if (rc) return -1;
-  if (!*reason) *reason = -3;
-  *rnorm = dp;
-  return 0;
-}
-
-// KSPGMRES [PETSc]: restarted, left preconditioning, classical Gram-Schmidt without refinement
-int ksp_gmres(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
-  Krylov& k = c->ks;
-  partials_clear(c, 0, NSLOTS);   // every reduction slot empty before the first producer (fin_block invariant, kernels_linalg.hip)
-  const int n = k.n, m = std::min(std::max(c->opts.gmres_restart, 1), k.basis_m);
-  const size_t ld = (size_t)k.nl;
-  const double rtol = c->opts.ksp_rtol, atol = c->opts.ksp_atol;
-  const int maxits = c->opts.ksp_max_its;
-  std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), yv(m);
-  vec_zero(c, x, n);
-  int it = 0;
-  double res = 0.0, res0 = 0.0, ttol = 0.0;
-  *reason = 0;
-  while (!*reason) {
-    double* v0 = k.basis;
-    if (it == 0) {
-      Prof p(c, KC_PC_APPLY);
-      if (pc_solve(c, b, v0, 0, nullptr, nullptr)) return -1;
-    } else {
-      vec_copy(c, k.P, x, n);
-      if (halo_exchange(c, k.P, c->np)) return -1;
-      { Prof p(c, KC_SPMV); if (apply_operator(c, k.P, k.tmp)) return -1; }
-      vec_waxpy(c, k.tmp, -1.0, k.tmp, b, n);
-      Prof p(c, KC_PC_APPLY);
-      if (pc_solve(c, k.tmp, v0, 0, nullptr, nullptr)) return -1;
-    }
-    {
-      Prof p(c, KC_VECTOR);
-      vec_dot(c, v0, v0, n, S_W2);
-      if (allreduce_scal(c, S_W2, 1)) return -1;
-    }
-    if (read_scal(c, S_W2, 1)) return -1;
-    res = std::sqrt(k.h_scal[S_W2]);
-    if (it == 0) {
-      res0 = res;
-      ttol = std::max(rtol * res, atol);
-      if (std::isnan(res)) { *reason = -9; break; }
-      if (res <= ttol) { *reason = (res <= atol) ? 3 : 2; break; }
-    }
-    if (res == 0.0) { *reason = 3; break; }
-    gmres_scale_to(c, v0, v0, S_W2, n);
-    std::fill(g.begin(), g.end(), 0.0);
-    g[0] = res;
-    int j = 0;
-    for (; j < m && !*reason; j++) {
-      double* vj = k.basis + ld * j;
-      double* vn = k.basis + ld * (j + 1);
-      double* w = k.T;
-      if (pc_amul(c, vj, w)) return -1;
-      {
-        Prof p(c, KC_VECTOR);
-        gmres_mdot(c, w, j + 1);
-        if (allreduce_scal(c, S_H, j + 1)) return -1;
-        gmres_maxpy_norm(c, w, j + 1);
-        if (allreduce_scal(c, S_W2, 1)) return -1;
-        gmres_scale_to(c, vn, w, S_W2, n);
-      }
-      if (read_scal(c, S_W2, S_H + j + 1 - S_W2)) return -1;  // |w|^2 and h_0..h_j
-      for (int i = 0; i <= j; i++) H[(size_t)i * m + j] = k.h_scal[S_H + i];
-      const double hn = std::sqrt(k.h_scal[S_W2]);
-      H[(size_t)(j + 1) * m + j] = hn;
-      for (int i = 0; i < j; i++) {
-        const double a = H[(size_t)i * m + j], bq = H[(size_t)(i + 1) * m + j];
-        H[(size_t)i * m + j] = cs[i] * a + sn[i] * bq;
-        H[(size_t)(i + 1) * m + j] = -sn[i] * a + cs[i] * bq;
-      }
-      const double a = H[(size_t)j * m + j], bq = H[(size_t)(j + 1) * m + j], d = std::sqrt(a * a + bq * bq);
-      cs[j] = a / d; sn[j] = bq / d;
-      H[(size_t)j * m + j] = d; H[(size_t)(j + 1) * m + j] = 0.0;
-      g[j + 1] = -sn[j] * g[j];
-      g[j] = cs[j] * g[j];
-      res = std::fabs(g[j + 1]);
-      it++;
-      if (std::isnan(res)) *reason = -9;
-      else if (res <= ttol) *reason = (res <= atol) ? 3 : 2;
-      else if (res >= 1.e4 * res0) *reason = -4;
-      else if (it >= maxits) *reason = -3;
-      else if (hn == 0.0) *reason = 3;
-    }
-    const int kk = j;
-    for (int i = kk - 1; i >= 0; i--) {
-      double t = g[i];
-      for (int q = i + 1; q < kk; q++) t -= H[(size_t)i * m + q] * yv[q];
-      yv[i] = t / H[(size_t)i * m + i];
-    }
-    {
-      Prof p(c, KC_VECTOR);
-      gmres_update_x(c, x, yv.data(), kk);
-      HIPCHK(c, hipStreamSynchronize(c->stream));  // yv is reused by the next cycle
-    }
-  }
-  *its = it;
-  *rnorm = res;
-  return 0;
-}
-
-// KSPLGMRES [PETSc]: "loose" GMRES (Baker, Jessup & Manteuffel 2005): restarted GMRES augmented with the
-// last two error approximations z = (x_i - x_{i-1}) / |.|; PETSc's defaults: restart 30 = 28 Krylov
-// directions + 2 error approximations, classical Gram-Schmidt, left preconditioning.  "linear.type":
-// "lgmres", src/timestepper.F90:1729-1730.  Same kernels as ksp_gmres; the Arnoldi step multiplies a basis
-// vector or an error approximation.
-int ksp_lgmres(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
-  Krylov& k = c->ks;
-  partials_clear(c, 0, NSLOTS);   // every reduction slot empty before the first producer (fin_block invariant, kernels_linalg.hip)
-  constexpr int AUG = 2;
-  // restart = Krylov directions + AUG error approximations: at least one direction (wai_set_opts / wai_ctx_create
-  // size the basis for restart >= AUG + 1 and refuse a restart beyond the basis cap)
-  const int n = k.n, mt = std::max(std::min(std::max(c->opts.gmres_restart, AUG + 1), k.basis_m), AUG + 1), mk = mt - AUG, m = mt;
-  double* Z = k.basis + (size_t)(mt + 1) * k.nl;          // Z[0] most recent
-  double* dx = k.basis + (size_t)(mt + 1 + AUG) * k.nl;
-  int naug = 0;
-  const size_t ld = (size_t)k.nl;
-  const double rtol = c->opts.ksp_rtol, atol = c->opts.ksp_atol;
-  const int maxits = c->opts.ksp_max_its;
-  std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), yv(m);
-  vec_zero(c, x, n);
-  int it = 0;
-  double res = 0.0, res0 = 0.0, ttol = 0.0;
-  *reason = 0;
-  while (!*reason) {
-    double* v0 = k.basis;
-    if (it == 0) {
-      Prof p(c, KC_PC_APPLY);
-      if (pc_solve(c, b, v0, 0, nullptr, nullptr)) return -1;
-    } else {
-      vec_copy(c, k.P, x, n);
-      if (halo_exchange(c, k.P, c->np)) return -1;
-      { Prof p(c, KC_SPMV); if (apply_operator(c, k.P, k.tmp)) return -1; }
-      vec_waxpy(c, k.tmp, -1.0, k.tmp, b, n);
-      Prof p(c, KC_PC_APPLY);
-      if (pc_solve(c, k.tmp, v0, 0, nullptr, nullptr)) return -1;
-    }
-    {
-      Prof p(c, KC_VECTOR);
-      vec_dot(c, v0, v0, n, S_W2);
-      if (allreduce_scal(c, S_W2, 1)) return -1;
-    }
-    if (read_scal(c, S_W2, 1)) return -1;
-    res = std::sqrt(k.h_scal[S_W2]);
-    if (it == 0) {
-      res0 = res;
-      ttol = std::max(rtol * res, atol);
-      if (std::isnan(res)) { *reason = -9; break; }
-      if (res <= ttol) { *reason = (res <= atol) ? 3 : 2; break; }
-    }
-    if (res == 0.0) { *reason = 3; break; }
-    gmres_scale_to(c, v0, v0, S_W2, n);
-    std::fill(g.begin(), g.end(), 0.0);
-    g[0] = res;
-    int j = 0;
-    const int ms = mk + naug;
-    for (; j < ms && !*reason; j++) {
-      double* vj = j < mk ? k.basis + ld * j : Z + ld * (j - mk);   // Krylov direction, then error approximations
-      double* vn = k.basis + ld * (j + 1);
-      double* w = k.T;
-      if (pc_amul(c, vj, w)) return -1;
-      {
-        Prof p(c, KC_VECTOR);
-        gmres_mdot(c, w, j + 1);
-        if (allreduce_scal(c, S_H, j + 1)) return -1;
-        gmres_maxpy_norm(c, w, j + 1);
-        if (allreduce_scal(c, S_W2, 1)) return -1;
-        gmres_scale_to(c, vn, w, S_W2, n);
-      }
-      if (read_scal(c, S_W2, S_H + j + 1 - S_W2)) return -1;  // |w|^2 and h_0..h_j
-      for (int i = 0; i <= j; i++) H[(size_t)i * m + j] = k.h_scal[S_H + i];
-      const double hn = std::sqrt(k.h_scal[S_W2]);
-      H[(size_t)(j + 1) * m + j] = hn;
-      for (int i = 0; i < j; i++) {
-        const double a = H[(size_t)i * m + j], bq = H[(size_t)(i + 1) * m + j];
-        H[(size_t)i * m + j] = cs[i] * a + sn[i] * bq;
-        H[(size_t)(i + 1) * m + j] = -sn[i] * a + cs[i] * bq;
-      }
-      const double a = H[(size_t)j * m + j], bq = H[(size_t)(j + 1) * m + j], d = std::sqrt(a * a + bq * bq);
-      cs[j] = a / d; sn[j] = bq / d;
-      H[(size_t)j * m + j] = d; H[(size_t)(j + 1) * m + j] = 0.0;
-      g[j + 1] = -sn[j] * g[j];
-      g[j] = cs[j] * g[j];
-      res = std::fabs(g[j + 1]);
-      it++;
-      if (std::isnan(res)) *reason = -9;
-      else if (res <= ttol) *reason = (res <= atol) ? 3 : 2;
-      else if (res >= 1.e4 * res0) *reason = -4;
-      else if (it >= maxits) *reason = -3;
-      else if (hn == 0.0) *reason = 3;
-    }
-    const int kk = j;
-    for (int i = kk - 1; i >= 0; i--) {
-      double t = g[i];
-      for (int q = i + 1; q < kk; q++) t -= H[(size_t)i * m + q] * yv[q];
-      yv[i] = t / H[(size_t)i * m + i];
-    }
-    {
-      Prof p(c, KC_VECTOR);
-      vec_zero(c, dx, n);
-      gmres_update_x(c, dx, yv.data(), std::min(kk, mk));
-      HIPCHK(c, hipStreamSynchronize(c->stream));  // yv is reused by the next cycle
-      for (int i = mk; i < kk; i++) vec_waxpy(c, dx, yv[i], Z + ld * (i - mk), dx, n);
-      vec_waxpy(c, x, 1.0, dx, x, n);
-      vec_dot(c, dx, dx, n, S_W2);
-      if (allreduce_scal(c, S_W2, 1)) return -1;
-    }
-    if (read_scal(c, S_W2, 1)) return -1;
-    if (k.h_scal[S_W2] > 0.0) {   // the new error approximation goes to the front
-      for (int a = AUG - 1; a > 0; a--) vec_copy(c, Z + ld * a, Z + ld * (a - 1), n);
-      gmres_scale_to(c, Z, dx, S_W2, n);
-      if (naug < AUG) naug++;
-    }
-  }
-  *its = it;
-  *rnorm = res;
-  return 0;
-}
-
-// up to two inner products brought to the host: (a1,b1) -> out[0], (a2,b2) -> out[1] (a2 null: one);
-// one all-reduce on several ranks
-int host_dots(wai_ctx* c, const double* a1, const double* b1, const double* a2, const double* b2, double* out) {
-  Krylov& k = c->ks;
-  {
-    Prof p(c, KC_VECTOR);
-    vec_dots(c, a1, b1, S_D1, a2, b2, S_D2, k.n);
-    vec_finalize(c, k.nb_pc, S_D1, a2 ? 2 : 1, -1);
-    if (allreduce_scal(c, S_D1, a2 ? 2 : 1)) return -1;
-  }
-  if (read_scal(c, S_D1, 2)) return -1;
-  out[0] = k.h_scal[S_D1];
-  if (a2) out[1] = k.h_scal[S_D2];
-  return 0;
-}
-
-// KSPBCGSL [PETSc]: BiCGStab(L), L = 2 (PETSc's default), of Sleijpen & Fokkema; left preconditioning,
-// preconditioned residual norm tested after every sweep of L BiCG steps (counted as L iterations);
-// "linear.type": "bcgsl", src/timestepper.F90:1733-1734.  The preconditioned operator runs on the
-// fused kernels; the vector updates and inner products use the generic vector kernels with the
-// scalars formed on the host (the documented use of this solver is the occasional ill-conditioned
-// system, not the headline path).
-int ksp_bcgsl(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
-  constexpr int L = 2;
-  Krylov& k = c->ks;
-  partials_clear(c, 0, NSLOTS);   // every reduction slot empty before the first producer (fin_block invariant, kernels_linalg.hip)
-  const int n = k.n;
-  const size_t nl = (size_t)k.nl;
-  if (!k.bl) {
-    if (dev_alloc(c, &k.bl, (2 * (L + 1) + 1) * (nl + 16))) return -1;
-    HIPCHK(c, hipMemsetAsync(k.bl, 0, (2 * (L + 1) + 1) * (nl + 16) * sizeof(double), c->stream));
-  }
-  double *r[L + 1], *u[L + 1];
-  for (int j = 0; j <= L; j++) { r[j] = k.bl + (size_t)j * (nl + 16); u[j] = k.bl + (size_t)(L + 1 + j) * (nl + 16); }
-  double* rt = k.bl + (size_t)(2 * (L + 1)) * (nl + 16);
-  const double rtol = c->opts.ksp_rtol, atol = c->opts.ksp_atol;
-  const int maxits = c->opts.ksp_max_its;
-  vec_zero(c, x, n);
-  for (int j = 0; j <= L; j++) vec_zero(c, u[j], nl);
-  { Prof p(c, KC_PC_APPLY); if (pc_solve(c, b, r[0], 0, nullptr, nullptr)) return -1; }
-  vec_copy(c, rt, r[0], n);
-  double d[2];
-  if (host_dots(c, r[0], r[0], nullptr, nullptr, d)) return -1;
-  double dp = std::sqrt(d[0]);
-  const double dp0 = dp, ttol = std::max(rtol * dp, atol);
-  *its = 0; *reason = 0;
-  if (std::isnan(dp)) *reason = -9;
-  else if (dp <= ttol) *reason = (dp <= atol) ? 3 : 2;
-  double rho0 = 1.0, alpha = 0.0, omega = 1.0;
-  while (!*reason && *its < maxits) {
-    rho0 = -omega * rho0;
-    for (int j = 0; j < L && !*reason; j++) {
-      if (host_dots(c, r[j], rt, nullptr, nullptr, d)) return -1;
-      const double rho1 = d[0];
-      if (rho0 == 0.0) { *reason = -5; break; }
-      const double beta = alpha * (rho1 / rho0);
-      rho0 = rho1;
-      for (int i = 0; i <= j; i++) vec_waxpy(c, u[i], -beta, u[i], r[i], n);     // u_i = r_i - beta u_i
-      if (pc_amul(c, u[j], u[j + 1])) return -1;
-      if (host_dots(c, u[j + 1], rt, nullptr, nullptr, d)) return -1;
-      if (d[0] == 0.0) { *reason = -5; break; }
-      alpha = rho0 / d[0];
-      for (int i = 0; i <= j; i++) vec_waxpy(c, r[i], -alpha, u[i + 1], r[i], n);  // r_i -= alpha u_{i+1}
-      if (pc_amul(c, r[j], r[j + 1])) return -1;
-      vec_waxpy(c, x, alpha, u[0], x, n);
-    }
-    if (*reason) break;
-    double Z[L][L], z[L], g[L], t2[2];
-    if (host_dots(c, r[1], r[1], r[1], r[2], t2)) return -1;
-    Z[0][0] = t2[0]; Z[0][1] = Z[1][0] = t2[1];
-    if (host_dots(c, r[2], r[2], r[1], r[0], t2)) return -1;
-    Z[1][1] = t2[0]; z[0] = t2[1];
-    if (host_dots(c, r[2], r[0], nullptr, nullptr, t2)) return -1;
-    z[1] = t2[0];
-    const double det = Z[0][0] * Z[1][1] - Z[0][1] * Z[1][0];
-    if (det == 0.0) { *reason = -5; break; }
-    g[0] = (z[0] * Z[1][1] - z[1] * Z[0][1]) / det;
-    g[1] = (Z[0][0] * z[1] - Z[1][0] * z[0]) / det;
-    for (int j = 0; j < L; j++) {
-      vec_waxpy(c, x, g[j], r[j], x, n);
-      vec_waxpy(c, u[0], -g[j], u[j + 1], u[0], n);
-    }
-    for (int j = 0; j < L; j++) vec_waxpy(c, r[0], -g[j], r[j + 1], r[0], n);
-    omega = g[L - 1];
-    *its += L;
-    if (host_dots(c, r[0], r[0], nullptr, nullptr, d)) return -1;
-    dp = std::sqrt(d[0]);
-    if (std::isnan(dp)) *reason = -9;
-    else if (dp <= ttol) *reason = (dp <= atol) ? 3 : 2;
-    else if (dp >= 1.e4 * dp0) *reason = -4;
-    else if (omega == 0.0) *reason = -5;
-  }
-  if (!*reason) *reason = -3;
-  *rnorm = dp;
-  return 0;
-}
-
-int do_ksp(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
-  if (!c->ilu.factored) {
-    const int e = do_pc_setup(c);
-    if (e < 0) return -1;
-    if (e > 0) { *reason = -11; *its = 0; *rnorm = 0.0; return 0; }
-  }
-  if (c->opts.ksp_type == WAI_KSP_GMRES) return ksp_gmres(c, b, x, its, reason, rnorm);
-  if (c->opts.ksp_type == WAI_KSP_BCGSL) return ksp_bcgsl(c, b, x, its, reason, rnorm);
-  if (c->opts.ksp_type == WAI_KSP_LGMRES) return ksp_lgmres(c, b, x, its, reason, rnorm);
-  return ksp_bcgs(c, b, x, its, reason, rnorm);
 }
 
 int do_norm2(wai_ctx* c, const double* v, double* out) {
@@ -1879,7 +194,7 @@ void free_all(wai_ctx* c) {
   comm_destroy(c->comm);
 }
 
-}  // namespace
+}  // namespace wai
 
 extern "C" {
 
@@ -2365,312 +680,6 @@ int wai_set_source_controls(wai_ctx* c, const wai_source_control* controls) {
   return 0;
 }
 
-}  // extern "C"
-namespace {
-// the flat description of wai_set_source_network -> Network (no device involved)
-int network_build(Network& nw, int n, const int* rate_specified, const int* enthalpy_specified, int n_groups,
-                  const int* grp_ptr, const int* grp_in_kind, const int* grp_in, const int* grp_scaling,
-                  const int* grp_limit_type, const double* grp_limit, const double* grp_sep, int n_reinj,
-                  const int* rj_in_kind, const int* rj_in, const int* rj_out_ptr, const int* out_flow,
-                  const int* out_kind, const int* out_node, const double* out_rate, const double* out_proportion,
-                  const double* out_enthalpy, const int* rj_overflow_kind, const int* rj_overflow, std::string& err) {
-  if (!n || !rate_specified || !enthalpy_specified) { err = "source network without sources"; return -2; }
-  auto ok = [&](int kind, int idx) {
-    return kind == 0 || (kind == 1 && idx >= 0 && idx < n) || (kind == 2 && idx >= 0 && idx < n_groups) ||
-           (kind == 3 && idx >= 0 && idx < n_reinj);
-  };
-  nw.rate_specified.assign(rate_specified, rate_specified + n);
-  nw.enth_specified.assign(enthalpy_specified, enthalpy_specified + n);
-  nw.groups.assign(std::max(n_groups, 0), NetGroup());
-  for (int g = 0; g < n_groups; g++) {
-    NetGroup& G = nw.groups[g];
-    for (int q = grp_ptr[g]; q < grp_ptr[g + 1]; q++) {
-      if (!ok(grp_in_kind[q], grp_in[q]) || grp_in_kind[q] == 0 || grp_in_kind[q] == 3 || (grp_in_kind[q] == 2 && grp_in[q] >= g)) {
-        err = "source network group: inputs are sources or earlier groups"; return -2;
-      }
-      NetRef r; r.kind = grp_in_kind[q]; r.index = grp_in[q];
-      G.in.push_back(r);
-    }
-    G.scaling = grp_scaling ? grp_scaling[g] : 0;
-    for (int l = 0; l < 3; l++)
-      if (grp_limit_type && grp_limit_type[3 * g + l] >= 0) {
-        G.limit_type[G.n_limit] = grp_limit_type[3 * g + l]; G.limit[G.n_limit] = grp_limit[3 * g + l]; G.n_limit++;
-      }
-    std::memset(&G.sep, 0, sizeof(G.sep));
-    if (grp_sep) {
-      G.sep.sep_hf = grp_sep[8 * g]; G.sep.sep_hg = grp_sep[8 * g + 1];
-      for (int q = 0; q < 6; q++) G.sep.sep_more[q] = grp_sep[8 * g + 2 + q];
-    }
-  }
-  nw.reinjectors.assign(std::max(n_reinj, 0), NetReinjector());
-  for (int r = 0; r < n_reinj; r++) {
-    NetReinjector& R = nw.reinjectors[r];
-    if (!ok(rj_in_kind[r], rj_in[r]) || rj_in_kind[r] == 3 || !ok(rj_overflow_kind[r], rj_overflow[r]) || rj_overflow_kind[r] == 2) {
-      err = "source network reinjector: bad input / overflow reference"; return -2;
-    }
-    R.in.kind = rj_in_kind[r]; R.in.index = rj_in[r];
-    R.overflow.kind = rj_overflow_kind[r]; R.overflow.index = rj_overflow[r];
-    for (int q = rj_out_ptr[r]; q < rj_out_ptr[r + 1]; q++) {
-      if (!ok(out_kind[q], out_node[q]) || out_kind[q] == 2 || (out_flow[q] != 1 && out_flow[q] != 2)) {
-        err = "source network reinjector: bad output"; return -2;
-      }
-      NetOutput o;
-      o.flow = out_flow[q]; o.out.kind = out_kind[q]; o.out.index = out_node[q];
-      o.rate = out_rate[q]; o.proportion = out_proportion[q]; o.enthalpy = out_enthalpy[q];
-      R.out.push_back(o);
-    }
-  }
-  {   // order: a reinjector after every reinjector it delivers or overflows to
-    nw.reinj_order.clear();
-    std::vector<int> state(std::max(n_reinj, 0), 0);
-    std::function<bool(int)> visit = [&](int r) -> bool {
-      if (state[r] == 2) return true;
-      if (state[r] == 1) return false;
-      state[r] = 1;
-      const NetReinjector& R = nw.reinjectors[r];
-      for (const NetOutput& o : R.out) if (o.out.kind == 3 && !visit(o.out.index)) return false;
-      if (R.overflow.kind == 3 && !visit(R.overflow.index)) return false;
-      state[r] = 2;
-      nw.reinj_order.push_back(r);
-      return true;
-    };
-    for (int r = 0; r < n_reinj; r++) if (!visit(r)) { err = "source network reinjectors form a cycle"; return -2; }
-  }
-  nw.src.assign(n, NetNode());
-  nw.h_raw.assign(2 * (size_t)n, 0.0);
-  if (nw.h_enth0.size() != (size_t)n) nw.h_enth0.assign(n, 0.0);
-  return 0;
-}
-// the cells whose equations and unknowns the network ties together: every source a group, a reinjector input,
-// output or overflow names (source_network_identify_source_dependencies, source_network.F90:359-498, walks the
-// same lists: production cells of a reinjector's input x cells of the sources it -- or the reinjectors
-// it delivers or overflows to -- feeds; the members of a limited group among each other).  The coupling
-// blocks E cover all pairs of these cells, a superset of the reference's dependency list.
-void network_cells(Network& nw, int n) {
-  std::vector<char> in_net((size_t)n, 0);
-  auto mark = [&](const NetRef& r) { if (r.kind == 1 && r.index >= 0 && r.index < n) in_net[r.index] = 1; };
-  for (const NetGroup& g : nw.groups) for (const NetRef& r : g.in) mark(r);
-  for (const NetReinjector& r : nw.reinjectors) { mark(r.in); mark(r.overflow); for (const NetOutput& o : r.out) mark(o.out); }
-  nw.cp_cells.clear();
-  for (int i = 0; i < n && i < (int)nw.h_cell.size(); i++) if (in_net[i]) nw.cp_cells.push_back(nw.h_cell[i]);
-  std::sort(nw.cp_cells.begin(), nw.cp_cells.end());
-  nw.cp_cells.erase(std::unique(nw.cp_cells.begin(), nw.cp_cells.end()), nw.cp_cells.end());
-}
-// the same over several ranks: the network's cells of all ranks, ordered by (owner rank, local cell); this rank's own
-// are then one contiguous run of the columns and, in that order, the rows it differences and applies
-void network_cells_span(Network& nw, int ng, const std::vector<double>& id, int rank) {
-  std::vector<char> in_net((size_t)ng, 0);
-  auto mark = [&](const NetRef& r) { if (r.kind == 1 && r.index >= 0 && r.index < ng) in_net[r.index] = 1; };
-  for (const NetGroup& g : nw.groups) for (const NetRef& r : g.in) mark(r);
-  for (const NetReinjector& r : nw.reinjectors) { mark(r.in); mark(r.overflow); for (const NetOutput& o : r.out) mark(o.out); }
-  std::vector<double> u;
-  for (int g = 0; g < ng; g++) if (in_net[g]) u.push_back(id[g]);
-  std::sort(u.begin(), u.end());
-  u.erase(std::unique(u.begin(), u.end()), u.end());
-  nw.cp_span = true;
-  nw.cp_m = (int)u.size();
-  nw.cp_owner.resize(u.size());
-  nw.cp_cells.clear();
-  nw.cp_j0 = 0;
-  for (size_t j = 0; j < u.size(); j++) {
-    const int owner = (int)(u[j] / 4294967296.0);
-    nw.cp_owner[j] = owner;
-    if (owner == rank) {
-      if (nw.cp_cells.empty()) nw.cp_j0 = (int)j;
-      nw.cp_cells.push_back((int)(u[j] - (double)owner * 4294967296.0));
-    }
-  }
-}
-}  // namespace
-extern "C" {
-
-// Source network (src/source_network_group.F90, source_network_reinjector.F90; input "network.group",
-// "network.reinject").  Node references are (kind, index) pairs: kind 0 none, 1 source, 2 group,
-// 3 reinjector.  Groups in dependency order (a group after the groups it takes in).
-int wai_set_source_network(wai_ctx* c, const int* rate_specified, const int* enthalpy_specified, int n_groups,
-                           const int* grp_ptr, const int* grp_in_kind, const int* grp_in, const int* grp_scaling,
-                           const int* grp_limit_type, const double* grp_limit, const double* grp_sep, int n_reinj,
-                           const int* rj_in_kind, const int* rj_in, const int* rj_out_ptr, const int* out_flow,
-                           const int* out_kind, const int* out_node, const double* out_rate,
-                           const double* out_proportion, const double* out_enthalpy, const int* rj_overflow_kind,
-                           const int* rj_overflow) {
-  if (!c) return -2;
-  Network& nw = c->net;
-  const int n = c->src.n;
-  auto ctl = nw.h_ctl; auto e0 = nw.h_enth0; auto cells = nw.h_cell;
-  const bool coupling = nw.coupling;
-  nw.free_device();
-  if (c->src.net) { (void)hipFree(c->src.net); c->src.net = nullptr; }
-  nw = Network();
-  nw.h_ctl = ctl; nw.h_enth0 = e0; nw.h_cell = cells; nw.coupling = coupling;
-  if (n_groups <= 0 && n_reinj <= 0) return 0;
-  const bool span = c->comm && c->comm->nranks > 1;
-  int ng = n;
-  std::vector<double> span_id;   // several ranks: every source's cell as (owner rank, local cell)
-  if (span) {
-    // the description is numbered by global source index (wai_set_source_global_index); what the pass needs of
-    // the other ranks' sources -- separator enthalpies, specified injection enthalpies -- is gathered once, here
-    if ((int)c->src_gidx.size() != n || c->src_nglobal < n) { c->err = "source network on several ranks: wai_set_source_global_index first"; return -2; }
-    ng = c->src_nglobal;
-    for (int g : c->src_gidx) if (g < 0 || g >= ng) { c->err = "global source index out of range"; return -2; }
-    nw.gidx = c->src_gidx;
-    nw.n_global = ng;
-    const int NG = 10;   // per source: 8 separator enthalpies, the specified enthalpy, the cell's identity (rank * 2^32 + cell)
-    std::vector<double> all((size_t)NG * ng, 0.0);
-    for (int i = 0; i < n; i++) {
-      const int g = nw.gidx[i];
-      if (i < (int)ctl.size()) {
-        all[(size_t)NG * g] = ctl[i].sep_hf; all[(size_t)NG * g + 1] = ctl[i].sep_hg;
-        for (int q = 0; q < 6; q++) all[(size_t)NG * g + 2 + q] = ctl[i].sep_more[q];
-      }
-      all[(size_t)NG * g + 8] = i < (int)e0.size() ? e0[i] : 0.0;
-      all[(size_t)NG * g + 9] = (double)c->comm->rank * 4294967296.0 + (double)(i < (int)cells.size() ? cells[i] : 0);
-    }
-    double* tmp = nullptr;
-    if (dev_upload(c, &tmp, all)) return -1;
-    int rc = comm_allreduce(c->comm, tmp, all.size(), 0, c->stream, c->err);
-    if (!rc && hipMemcpyAsync(all.data(), tmp, sizeof(double) * all.size(), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = -1;
-    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = -1;
-    (void)hipFree(tmp);
-    if (rc) return -1;
-    nw.h_ctl.assign((size_t)ng, SrcCtl{});
-    nw.h_enth0.assign((size_t)ng, 0.0);
-    span_id.assign((size_t)ng, 0.0);
-    for (int g = 0; g < ng; g++) {
-      nw.h_ctl[g].sep_hf = all[(size_t)NG * g]; nw.h_ctl[g].sep_hg = all[(size_t)NG * g + 1];
-      for (int q = 0; q < 6; q++) nw.h_ctl[g].sep_more[q] = all[(size_t)NG * g + 2 + q];
-      nw.h_enth0[g] = all[(size_t)NG * g + 8];
-      span_id[g] = all[(size_t)NG * g + 9];
-    }
-  }
-  if (int e = network_build(nw, ng, rate_specified, enthalpy_specified, n_groups, grp_ptr, grp_in_kind, grp_in, grp_scaling,
-                            grp_limit_type, grp_limit, grp_sep, n_reinj, rj_in_kind, rj_in, rj_out_ptr, out_flow, out_kind,
-                            out_node, out_rate, out_proportion, out_enthalpy, rj_overflow_kind, rj_overflow, c->err))
-    return e;
-  if (dev_alloc(c, &nw.d_raw, 2 * (size_t)std::max(n, 1)) || dev_alloc(c, &c->src.net, 2 * (size_t)std::max(n, 1))) return -1;
-  if (span && dev_alloc(c, &nw.d_all, 2 * (size_t)ng)) return -1;
-  HIPCHK(c, hipMemset(c->src.net, 0, sizeof(double) * 2 * std::max(n, 1)));
-  nw.h_loc.assign(2 * (size_t)n, 0.0);
-  nw.l_net.assign(2 * (size_t)n, 0.0);
-  nw.l_enth.assign((size_t)n, 0.0);
-  for (int i = 0; i < n; i++) nw.l_enth[i] = span ? nw.h_enth0[nw.gidx[i]] : (i < (int)nw.h_enth0.size() ? nw.h_enth0[i] : 0.0);
-  nw.on = true;
-  if (!span) network_cells(nw, n);
-  else network_cells_span(nw, ng, span_id, c->comm->rank);
-  return 0;
-}
-
-// Global index of every local source, for a source network whose sources live on several ranks: the network
-// description handed to wai_set_source_network then refers to sources by these indices (0 .. n_global - 1), the same
-// description on every rank.  After wai_set_sources, before wai_set_source_network.
-int wai_set_source_global_index(wai_ctx* c, int n_global, const int* global_index) {
-  if (!c || n_global < 0 || (c->src.n > 0 && !global_index)) return -2;
-  c->src_gidx.assign(global_index, global_index + c->src.n);
-  c->src_nglobal = n_global;
-  return 0;
-}
-
-int wai_set_network_couplings(wai_ctx* c, int on) {
-  if (!c) return -2;
-  c->net.coupling = on != 0;
-  if (!on) c->net.cp_valid = false;
-  return 0;
-}
-
-int wai_get_network_couplings(wai_ctx* c, int* n_cells, int* cells, double* values) {
-  if (!c || !n_cells) return -2;
-  const Network& nw = c->net;
-  const bool on = nw.on && nw.coupling && nw.cp_valid;
-  const int ml = on ? (int)nw.cp_cells.size() : 0, m = on ? (nw.cp_span ? nw.cp_m : ml) : 0;
-  *n_cells = m;
-  if (cells)
-    for (int j = 0; j < m; j++) {
-      const bool mine = !nw.cp_span || (j >= nw.cp_j0 && j < nw.cp_j0 + ml);
-      cells[j] = mine ? nw.cp_cells[j - (nw.cp_span ? nw.cp_j0 : 0)] : -1 - nw.cp_owner[j];
-    }
-  if (values && ml) std::memcpy(values, nw.h_cp_val.data(), sizeof(double) * nw.h_cp_val.size());
-  return 0;
-}
-// The same network pass without a context or a device (host logic only; tests): the sources' own rates
-// and enthalpies and their separators (8 doubles per source: hf, hg of stage 1, then (hf, hg) of stages
-// 2..4, hg = 0: no separator / no further stage) in, node states out -- sources and groups 6 doubles each
-// (rate, enthalpy, water_rate, water_enthalpy, steam_rate, steam_enthalpy), reinjectors 8 each as
-// wai_get_source_network.
-int wai_network_evaluate(int n_sources, const double* rate, const double* enthalpy, const double* src_sep,
-                         const int* rate_specified, const int* enthalpy_specified, int n_groups,
-                         const int* grp_ptr, const int* grp_in_kind, const int* grp_in, const int* grp_scaling,
-                         const int* grp_limit_type, const double* grp_limit, const double* grp_sep, int n_reinj,
-                         const int* rj_in_kind, const int* rj_in, const int* rj_out_ptr, const int* out_flow,
-                         const int* out_kind, const int* out_node, const double* out_rate,
-                         const double* out_proportion, const double* out_enthalpy, const int* rj_overflow_kind,
-                         const int* rj_overflow, double* sources_out, double* groups_out, double* reinjectors_out) {
-  if (!rate || !enthalpy || n_sources <= 0) return -2;
-  Network nw;
-  std::string err;
-  nw.h_enth0.assign(enthalpy, enthalpy + n_sources);
-  if (int e = network_build(nw, n_sources, rate_specified, enthalpy_specified, n_groups, grp_ptr, grp_in_kind, grp_in,
-                            grp_scaling, grp_limit_type, grp_limit, grp_sep, n_reinj, rj_in_kind, rj_in, rj_out_ptr, out_flow,
-                            out_kind, out_node, out_rate, out_proportion, out_enthalpy, rj_overflow_kind, rj_overflow, err))
-    return e;
-  nw.h_ctl.assign(n_sources, SrcCtl{});
-  for (int i = 0; i < n_sources && src_sep; i++) {
-    nw.h_ctl[i].sep_hf = src_sep[8 * i]; nw.h_ctl[i].sep_hg = src_sep[8 * i + 1];
-    for (int q = 0; q < 6; q++) nw.h_ctl[i].sep_more[q] = src_sep[8 * i + 2 + q];
-  }
-  for (int i = 0; i < n_sources; i++) { nw.h_raw[i] = rate[i]; nw.h_raw[n_sources + i] = enthalpy[i]; }
-  network_evaluate(nw);
-  auto put = [](const NetNode& n, double* o) { o[0] = n.rate; o[1] = n.enth; o[2] = n.wrate; o[3] = n.wenth; o[4] = n.srate; o[5] = n.senth; };
-  for (int i = 0; sources_out && i < n_sources; i++) put(nw.src[i], sources_out + 6 * i);
-  for (size_t g = 0; groups_out && g < nw.groups.size(); g++) put(nw.groups[g].node, groups_out + 6 * g);
-  for (size_t r = 0; reinjectors_out && r < nw.reinjectors.size(); r++) {
-    const NetReinjector& R = nw.reinjectors[r];
-    const double v[8] = {R.out_w, R.out_s, R.over.rate, R.over.enth, R.over.wrate, R.over.wenth, R.over.srate, R.over.senth};
-    std::memcpy(reinjectors_out + 8 * r, v, sizeof(v));
-  }
-  return 0;
-}
-// The cells between which wai_jacobian forms the network's coupling blocks, for the given sources' cells and
-// network description -- no context, no device (tests pin it on the reference's dependency list).
-// cells: room for n_sources entries; *n_cells: how many were written (ascending, distinct)
-int wai_network_cells(int n_sources, const int* source_cell, const int* rate_specified, const int* enthalpy_specified,
-                      int n_groups, const int* grp_ptr, const int* grp_in_kind, const int* grp_in, const int* grp_scaling,
-                      const int* grp_limit_type, const double* grp_limit, const double* grp_sep, int n_reinj,
-                      const int* rj_in_kind, const int* rj_in, const int* rj_out_ptr, const int* out_flow,
-                      const int* out_kind, const int* out_node, const double* out_rate, const double* out_proportion,
-                      const double* out_enthalpy, const int* rj_overflow_kind, const int* rj_overflow, int* n_cells,
-                      int* cells) {
-  if (!source_cell || !n_cells || !cells || n_sources <= 0) return -2;
-  Network nw;
-  std::string err;
-  if (int e = network_build(nw, n_sources, rate_specified, enthalpy_specified, n_groups, grp_ptr, grp_in_kind, grp_in,
-                            grp_scaling, grp_limit_type, grp_limit, grp_sep, n_reinj, rj_in_kind, rj_in, rj_out_ptr, out_flow,
-                            out_kind, out_node, out_rate, out_proportion, out_enthalpy, rj_overflow_kind, rj_overflow, err))
-    return e;
-  nw.h_cell.assign(source_cell, source_cell + n_sources);
-  network_cells(nw, n_sources);
-  *n_cells = (int)nw.cp_cells.size();
-  for (size_t i = 0; i < nw.cp_cells.size(); i++) cells[i] = nw.cp_cells[i];
-  return 0;
-}
-// state of the network after the last pass: groups 6 doubles each (rate, enthalpy, water_rate,
-// water_enthalpy, steam_rate, steam_enthalpy); reinjectors 8 each (output water / steam rate, overflow
-// rate, enthalpy, water rate, water enthalpy, steam rate, steam enthalpy)
-int wai_get_source_network(wai_ctx* c, double* groups, double* reinjectors) {
-  if (!c) return -2;
-  const Network& nw = c->net;
-  for (size_t g = 0; groups && g < nw.groups.size(); g++) {
-    const NetNode& n = nw.groups[g].node;
-    const double v[6] = {n.rate, n.enth, n.wrate, n.wenth, n.srate, n.senth};
-    std::memcpy(groups + 6 * g, v, sizeof(v));
-  }
-  for (size_t r = 0; reinjectors && r < nw.reinjectors.size(); r++) {
-    const NetReinjector& R = nw.reinjectors[r];
-    const double v[8] = {R.out_w, R.out_s, R.over.rate, R.over.enth, R.over.wrate, R.over.wenth, R.over.srate, R.over.senth};
-    std::memcpy(reinjectors + 8 * r, v, sizeof(v));
-  }
-  return 0;
-}
-
 int wai_separator_enthalpies(wai_ctx* c, double pressure, double* hf, double* hg) {
   if (!c || !hf || !hg) return -2;
   double* tmp = nullptr;
@@ -3059,7 +1068,10 @@ int wai_tracer_lhs(wai_ctx* c, double* Al) {
   return o.back();
 }
 
-namespace {
+}  // extern "C"
+
+namespace wai {
+
 // The Krylov drivers work on c->J / c->ilu / c->ks / c->np; for the scalar tracer systems those
 // are pointed at the auxiliary matrix (same sparsity, block size 1) for the scope's lifetime.
 struct AuxScope {
@@ -3089,7 +1101,10 @@ struct AuxScope {
     c->ilu.factored = false;  // the factor buffers now hold a tracer system's factor
   }
 };
-}  // namespace
+
+}  // namespace wai
+
+extern "C" {
 
 int wai_tracer_system(wai_ctx* c, int tracer, int method, double dt, double ratio, const double* alx_last,
                       const double* alx_last2, double* val, double* b) {
@@ -3253,139 +1268,6 @@ int wai_timestep(wai_ctx* c, double t, double dt, double* y, int* newton_its, in
     c->can_reject = true;
   }
   return from_work(c, c->w_y, y);
-}
-
-// Micro-benchmark of one kernel on the library's stream, HIP-event timed: which 0 = block SpMV,
-// 1 = ILU(0) apply z = B^-1 r, 2 = fused z = B^-1 (A x) with the (z, aux) reduction finished in the kernel,
-// 3/4 = probes of 1/2 with the substitution sweeps skipped (load/compute phase split), 5 = the five launches
-// of a whole BiCGStab iteration (overwrites the Krylov work vectors), 6 = its vector updates alone,
-// 9 / 10 = the fused kernel on the interior / face bricks only.
-int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
-  if (!c || !ms_per_launch || reps <= 0) return -2;
-  if (which > 0 && !c->ilu.factored) { const int e = do_pc_setup(c); if (e) return e < 0 ? -1 : e; }
-  Krylov& k = c->ks;
-  auto run = [&]() {
-    switch (which) {
-      case 0: launch_spmv(c, k.P, k.tmp); break;
-      case 1: case 3: pc_solve(c, k.P, k.V, 0, nullptr, nullptr); break;
-      case 9: if (c->ilu.n_int > 0) launch_pc(c, true, k.P, k.V, 1, k.RP, c->ilu.sub_int, c->ilu.n_int); break;   // interior bricks only
-      case 10: if (c->ilu.n_bnd > 0) launch_pc(c, true, k.P, k.V, 1, k.RP, c->ilu.sub_bnd, c->ilu.n_bnd); break;  // face bricks only
-      case 5: {  // the launches (and, on several ranks, collectives) of one BiCGStab iteration back to back, no host in
-                 // the loop: the iteration's floor
-        const BcgsPlan pl = bcgs_plan(c);
-        bcgs_first_half(c, pl); bcgs_second_half(c, pl);
-        break;
-      }
-      case 6:   // its vector updates alone
-        if (bcgs_mode(c) == 2) { if (!pc_axpy_ok(c)) bcgs_update_s(c); bcgs_update_xrp(c); }
-        else { bcgs_update_p(c); bcgs_update_s(c); bcgs_update_xr(c, true, 4, false); }
-        break;
-      case 7:   // the second fused launch of the "fused" iteration: z = B^-1 A (R - alpha V) with the five inner products
-        pc_amul(c, k.R, k.T, 4, k.RP, -1, pc_axpy_ok(c) ? k.V : nullptr, false);
-        break;
-      // the fused launch by reduction mode: 11 none; 12 (z,aux) left as partials; 13 (x,z),(z,z) + omega in the launch;
-      // 14 the five merged products left as partials; 15 the five + omega, (R,R), rho, beta in the launch
-      case 11: pc_amul(c, k.P, k.V, 0, nullptr, -2); break;
-      case 12: pc_amul(c, k.P, k.V, 1, k.RP, -2); break;
-      case 13: pc_amul(c, k.P, k.V, 2, nullptr, 3); break;
-      case 14: pc_amul(c, k.P, k.V, 4, k.RP, -2); break;
-      case 15: pc_amul(c, k.P, k.V, 4, k.RP, 6); break;
-      default: pc_amul(c, k.P, k.V, 1, k.RP, 2); break;   // what a BiCGStab half-iteration runs (no halo on one rank)
-    }
-  };
-  c->dbg = (which == 3 || which == 4) && pc_fused(c) && !(c->J.bs == 2 && c->ilu.park) ? 1 : 0;
-  partials_clear(c, S_D1, 5);
-  for (int i = 0; i < 5; i++) run();
-  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-  for (int i = 0; i < reps; i++) run();
-  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-  HIPCHK(c, hipEventSynchronize(c->ev1));
-  c->dbg = 0;
-  partials_clear(c, S_D1, 5);   // the interior- / face-only launches leave partials nobody sums
-  float ms = 0.f;
-  HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-  *ms_per_launch = ms / reps;
-#ifdef WAI_PC_PHASES
-  {
-    unsigned long long ph[8];
-    pc_phases_fetch(ph, true);
-    if (ph[7]) {
-      const double n = (double)ph[7], us = 0.01;   // 100 MHz ticks; the last launch's workgroups
-      fprintf(stderr, "pc phases (which %d, %.0f workgroups, %.4f ms per launch): load %.2f wait %.2f forward %.2f backward %.2f epilogue %.2f us per workgroup; "
-              "resident workgroups on average %.1f\n", which, n, ms / reps, ph[0] * us / n, ph[1] * us / n, ph[2] * us / n, ph[3] * us / n, ph[4] * us / n,
-              (ph[0] + ph[1] + ph[2] + ph[3] + ph[4]) * us * 1e-3 / (double)(ms / reps));
-    }
-  }
-#endif
-  return 0;
-}
-
-// name of the kernel (or path) a preconditioned-operator application runs on, for reports
-const char* wai_pc_kernel_name(wai_ctx* c) {
-  if (!c) return "";
-  const IluSchedule& s = c->ilu;
-  if (c->opts.pc_type == WAI_PC_NONE) return "k_spmv (no preconditioner)";
-  if (c->opts.pc_type == WAI_PC_LU) return "k_spmv + k_lu_apply (dense block inverses)";
-  if (pc_extended(c)) {
-    static thread_local char b3[96];
-    snprintf(b3, sizeof(b3), "k_spmv + %s on the extended system (%s, ILU(%d))", c->as.sched.big ? "k_lvl_solve per level" : "k_pc",
-             c->opts.pc_type == WAI_PC_ASM ? "ASM" : "block Jacobi", std::max(c->opts.ilu_levels, 0));
-    return b3;
-  }
-  if (s.big) return "k_spmv + k_lvl_solve per level";
-  if (s.wave_kernel) { static thread_local char b4[64]; snprintf(b4, sizeof(b4), "k_pc_wave<%d,spmv>", c->J.bs); return b4; }
-  if (s.rows_kernel) { static thread_local char b2[64]; snprintf(b2, sizeof(b2), "k_pc_rows<%d,spmv,%d+%d>", c->J.bs, s.max_nlu <= 3 ? 3 : 4, s.max_nlu <= 3 ? 3 : 4); return b2; }
-  if (c->J.bs == 2 && s.park && s.diag_only && s.scaled && s.fast3 && s.max_rows <= 512) return "k_pc_park<spmv>";
-  static thread_local char buf[96];
-  snprintf(buf, sizeof(buf), "k_pc<%d,spmv,%s,%s>", c->J.bs, s.diag_only ? (s.scaled ? "dilu-scaled" : "dilu") : "ilu",
-           s.fast3 ? "compact3" : "generic");
-  return buf;
-}
-int wai_comm_size(wai_ctx* c) { return c ? comm_count(c->comm) : -2; }
-int wai_launch_stats(wai_ctx* c, long long* kernels, long long* copies) {
-  if (!c) return -2;
-  if (kernels) *kernels = c->ks.n_launch;
-  if (copies) *copies = c->ks.n_copy;
-  return 0;
-}
-int wai_bench_mute_comm(wai_ctx* c, int on) {
-  if (!c) return -2;
-  if (c->comm) c->comm->mute = on != 0;
-  return 0;
-}
-int wai_halo_size(wai_ctx* c, int dof, long long* bytes_sent, int* n_neighbours) {
-  if (!c) return -2;
-  if (bytes_sent) *bytes_sent = (long long)c->send_total * dof * (long long)sizeof(double);
-  if (n_neighbours) *n_neighbours = c->n_nbr;
-  return 0;
-}
-int wai_comm_stats(wai_ctx* c, long long* allreduces, long long* exchanges) {
-  if (!c) return -2;
-  if (allreduces) *allreduces = c->comm ? c->comm->n_allreduce : 0;
-  if (exchanges) *exchanges = c->comm ? c->comm->n_exchange : 0;
-  return 0;
-}
-
-int wai_timer_start(wai_ctx* c) { if (!c) return -2; HIPCHK(c, hipEventRecord(c->ev0, c->stream)); return 0; }
-int wai_timer_stop(wai_ctx* c, float* ms) {
-  if (!c || !ms) return -2;
-  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-  HIPCHK(c, hipEventSynchronize(c->ev1));
-  HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
-  return 0;
-}
-int wai_synchronize(wai_ctx* c) { if (!c) return -2; HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
-int wai_profile_enable(wai_ctx* c, int on) { if (!c) return -2; c->prof_on = on != 0; return 0; }
-int wai_profile_get(wai_ctx* c, int kclass, double* ms, long long* launches) {
-  if (!c || kclass < 0 || kclass >= KC_COUNT) return -2;
-  if (ms) *ms = c->prof_ms[kclass];
-  if (launches) *launches = c->prof_n[kclass];
-  return 0;
-}
-int wai_profile_reset(wai_ctx* c) {
-  if (!c) return -2;
-  for (int i = 0; i < KC_COUNT; i++) { c->prof_ms[i] = 0.0; c->prof_n[i] = 0; }
-  return 0;
 }
 
 }  // extern "C"

@@ -21,6 +21,10 @@ __host__ __device__ __forceinline__ size_t ell_ix(int bs, size_t n, int s, int r
 enum KClass { KC_EOS = 0, KC_RESIDUAL = 1, KC_JACOBIAN = 2, KC_SPMV = 3, KC_PC_APPLY = 4,
               KC_PC_SETUP = 5, KC_VECTOR = 6, KC_TRANSITIONS = 7, KC_COUNT = 8 };
 
+// device scalars of the Krylov solvers (Krylov::scal) and the reduction slots of the same numbers (Krylov::partials)
+enum { S_RHO = 0, S_RHOOLD = 1, S_ALPHA = 2, S_OMEGA = 3, S_BETA = 4, S_D1 = 5, S_D2 = 6,
+       S_DP2 = 7, S_RHONEW = 8, S_W2 = 9, S_BREAK = 15, S_H = 16 };
+
 struct Comm;  // RCCL state (comm.cpp)
 
 struct DeviceMesh {

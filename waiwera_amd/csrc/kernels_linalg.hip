@@ -62,8 +62,6 @@ constexpr int TPB = 256;
 #endif
 constexpr int WMAX = 8;  // block-ELL width handled in registers (7-point stencil: 7, MINC: 8)
 
-enum { S_RHO = 0, S_RHOOLD = 1, S_ALPHA = 2, S_OMEGA = 3, S_BETA = 4, S_D1 = 5, S_D2 = 6,
-       S_DP2 = 7, S_RHONEW = 8, S_W2 = 9, S_BREAK = 15, S_H = 16 };
 
 __device__ __forceinline__ int xcd_remap(int b, int n) {
   // dispatch places block b on XCD b % 8: give XCD j the contiguous range j*per .. (j+1)*per
@@ -672,7 +670,7 @@ __device__ __forceinline__ void derive_scalars(double* s, int phase) {
   }
 }
 // Finalisation inside the producing launch (Fin, context.hpp).  A launch that carries a Fin has a few
-// workgroups more than it has work (fin_slices: one per ~2048 partials): the extra ones -- the last indices, dispatched
+// workgroups more than it has work (fin_slices: one per ~1024 partials): the extra ones -- the last indices, dispatched
 // after every other -- wait for the partial sums to arrive and sum them; the last one derives the BiCGStab scalars.  The working workgroups do
 // nothing beyond storing their partial (agent scope: written through, coherent across the XCDs' L2s).
 // Arrival is read off the data: an empty partial slot holds FIN_EMPTY (a NaN payload no sum produces), and
@@ -698,11 +696,11 @@ constexpr int FIN_MAXS = 5;   // reduction slots summed together (the merged BiC
 // of bricks: its loads are agent-scope round trips of ~2 us, a few in flight per thread -- MEASURED (bench.py --micro-only,
 // fused launch with / without the in-launch finalisation): 0.015 ms of 0.563 at 216^3 (21 168 bricks of 512 rows), but
 // 0.127 of 0.690 ms at C4 (78 586 one-wave bricks), 0.047 of 0.233 at C5 -- and with the five merged reductions 0.069,
-// 0.537 (!) and 0.198 ms.  So the partials are cut into fin_slices(nb) slices of ~2048, a launch carries that many extra
+// 0.537 (!) and 0.198 ms.  So the partials are cut into fin_slices(nb) slices of ~1024 (at most 64 slices), a launch carries that many extra
 // workgroups, finaliser f sums slice f of every slot and stores the slice sums (second-level partials, same arrival
 // protocol), and the LAST finaliser adds the slice sums in slice order, derives and posts.  k_finalize (the separate
 // launch) forms the same slice sums and adds them in the same order: identical bits either way, independent of timing.
-__host__ __device__ __forceinline__ int fin_slices(int nb) { return nb <= 4096 ? 1 : (nb + 2047) / 2048 > FIN_MAXF ? FIN_MAXF : (nb + 2047) / 2048; }
+__host__ __device__ __forceinline__ int fin_slices(int nb) { return nb <= 1024 ? 1 : (nb + 1023) / 1024 > FIN_MAXF ? FIN_MAXF : (nb + 1023) / 1024; }
 __host__ __device__ __forceinline__ void fin_slice_range(int nb, int nf, int f, int& lo, int& hi) {
   const int per = (nb + nf - 1) / nf;
   lo = f * per; hi = lo + per < nb ? lo + per : nb;
@@ -715,7 +713,7 @@ __host__ __device__ __forceinline__ void fin_slice_range(int nb, int nf, int f, 
 // never arrives becomes a NaN sum and breakdown code 4, KSP_DIVERGED_NANORINF, not a hung device).
 __device__ __forceinline__ void sum_slice(unsigned long long* p0, int nb_max, int lo, int hi, int ns, bool wait,
                                           double* scal, double* res) {
-  __shared__ double fsm[FIN_MAXS][16];
+  __shared__ __attribute__((aligned(16))) double fsm[FIN_MAXS][16];
   constexpr int CH = 4;
   const int len = hi - lo, VT = len > 256 ? 1024 : 256;
   __syncthreads();   // fsm / res of an earlier call are no longer read
@@ -769,7 +767,7 @@ __device__ __forceinline__ void sum_slice(unsigned long long* p0, int nb_max, in
 // k_finalize's body: every slice of every slot, the slice sums added in slice order -> scal
 __device__ __forceinline__ void sum_partials(const double* partials, int nb_max, int nb, int slot0, int nslots,
                                              double* scal, bool wait) {
-  __shared__ double res[FIN_MAXS], tot[FIN_MAXS];
+  __shared__ __attribute__((aligned(16))) double res[8], tot[8];   // static LDS stays a multiple of 16 bytes: the kernels' dynamic arrays behind it take 16-byte accesses
   const int nf = fin_slices(nb);
   for (int sb = 0; sb < nslots; sb += FIN_MAXS) {
     const int ns = min(nslots - sb, FIN_MAXS);
@@ -793,7 +791,7 @@ __device__ __forceinline__ void store_partial(double* p, double t) {
 // is this workgroup one of the launch's finalisers (the last f.nf workgroups)?  If so do its share (the caller returns)
 __device__ __forceinline__ bool fin_block(const Fin& f, const double* partials, int nb_max) {
   if (f.count == 0 || (int)blockIdx.x < (int)gridDim.x - f.nf) return false;
-  __shared__ double res[FIN_MAXS];
+  __shared__ __attribute__((aligned(16))) double res[8];   // (a multiple of 16 bytes: see sum_partials)
   const int me = (int)blockIdx.x - ((int)gridDim.x - f.nf);
   const bool last = me == f.nf - 1;
   unsigned long long* p0 = reinterpret_cast<unsigned long long*>(const_cast<double*>(partials)) + (size_t)f.slot0 * nb_max;
@@ -881,7 +879,7 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
   // the pivots of ILU(0)(A') are identities, so neither dinv nor its two products per row are needed
   constexpr bool SC = (DILU == 2);
   const double* __restrict__ mat = SC ? fval : aval;
-  extern __shared__ double lds[];  // [T * BS] solution vector, then 80 doubles reduction scratch
+  extern __shared__ __attribute__((aligned(16))) double lds[];  // [T * BS] solution vector, then 80 doubles reduction scratch
   if (fin_block(fin, partials, nb_max)) return;
   int s = xcd_remap(blockIdx.x, nsub);
   if (s >= nsub) return;
@@ -1225,7 +1223,7 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
     double* __restrict__ z, const double* __restrict__ aux, double* partials, int nb_max, int dot,
     const int* __restrict__ sub_list, Fin fin) {
   constexpr int BS = 2, BB = 4, MLU = 3;
-  extern __shared__ double lds[];  // [T*2] solution, [80] reduction scratch, then parked U blocks
+  extern __shared__ __attribute__((aligned(16))) double lds[];  // [T*2] solution, [80] reduction scratch, then parked U blocks
   // nsub subdomains to run: all of them, or (sub_list) the listed ones -- the bricks that touch no
   // partition ghost while the halo exchange is in flight, the others after it
   if (fin_block(fin, partials, nb_max)) return;
@@ -1407,7 +1405,7 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
     const double* __restrict__ scal, double* __restrict__ z,
     const double* __restrict__ aux, double* partials, int nb_max, int dot, const int* __restrict__ sub_list,
     const int* __restrict__ rowptr, const int* __restrict__ sub_split, Fin fin) {
-  extern __shared__ double lds[];  // [R*BS] solution in block order, [BS] zeros, then reduction scratch
+  extern __shared__ __attribute__((aligned(16))) double lds[];  // [R*BS] solution in block order, [BS] zeros, then reduction scratch
   if (fin_block(fin, partials, nb_max)) return;
   int s = xcd_remap(blockIdx.x, nsub);
   if (s >= nsub) return;
@@ -1571,7 +1569,7 @@ __global__ __launch_bounds__(256) void k_pc_wave(
     const double* __restrict__ in2, const double* __restrict__ scal, double* __restrict__ z, const double* __restrict__ aux, double* partials, int nb_max, int dot,
     const int* __restrict__ sub_list, const int* __restrict__ rowptr, int lds_per_brick, Fin fin) {
   constexpr int BB = BS * BS, NL = 3, NU = 4;
-  extern __shared__ double lds[];
+  extern __shared__ __attribute__((aligned(16))) double lds[];
   if (fin_block(fin, partials, nb_max)) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ngrp = (nsub + 3) >> 2;

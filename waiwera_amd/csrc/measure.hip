@@ -1,0 +1,146 @@
+// Measurement and reporting entry points of libwaiwera_hip.so (include/waiwera_hip_bench.h; wai_pc_kernel_name and
+// wai_comm_size of include/waiwera_hip.h): kernel micro-benchmarks, HIP-event timers, launch and collective counters.
+#include "host.hpp"
+
+using namespace wai;
+
+#ifdef WAI_PC_PHASES
+namespace wai { void pc_phases_fetch(unsigned long long out[8], bool reset); }
+#endif
+
+extern "C" {
+
+// Micro-benchmark of one kernel on the library's stream, HIP-event timed: which 0 = block SpMV,
+// 1 = ILU(0) apply z = B^-1 r, 2 = fused z = B^-1 (A x) with the (z, aux) reduction finished in the kernel,
+// 3/4 = probes of 1/2 with the substitution sweeps skipped (load/compute phase split), 5 = the five launches
+// of a whole BiCGStab iteration (overwrites the Krylov work vectors), 6 = its vector updates alone,
+// 9 / 10 = the fused kernel on the interior / face bricks only.
+int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
+  if (!c || !ms_per_launch || reps <= 0) return -2;
+  if (which > 0 && !c->ilu.factored) { const int e = do_pc_setup(c); if (e) return e < 0 ? -1 : e; }
+  Krylov& k = c->ks;
+  auto run = [&]() {
+    switch (which) {
+      case 0: launch_spmv(c, k.P, k.tmp); break;
+      case 1: case 3: pc_solve(c, k.P, k.V, 0, nullptr, nullptr); break;
+      case 9: if (c->ilu.n_int > 0) launch_pc(c, true, k.P, k.V, 1, k.RP, c->ilu.sub_int, c->ilu.n_int); break;   // interior bricks only
+      case 10: if (c->ilu.n_bnd > 0) launch_pc(c, true, k.P, k.V, 1, k.RP, c->ilu.sub_bnd, c->ilu.n_bnd); break;  // face bricks only
+      case 5: {  // the launches (and, on several ranks, collectives) of one BiCGStab iteration back to back, no host in
+                 // the loop: the iteration's floor
+        const BcgsPlan pl = bcgs_plan(c);
+        bcgs_first_half(c, pl); bcgs_second_half(c, pl);
+        break;
+      }
+      case 6:   // its vector updates alone
+        if (bcgs_mode(c) == 2) { if (!pc_axpy_ok(c)) bcgs_update_s(c); bcgs_update_xrp(c); }
+        else { bcgs_update_p(c); bcgs_update_s(c); bcgs_update_xr(c, true, 4, false); }
+        break;
+      case 7:   // the second fused launch of the "fused" iteration: z = B^-1 A (R - alpha V) with the five inner products
+        pc_amul(c, k.R, k.T, 4, k.RP, -1, pc_axpy_ok(c) ? k.V : nullptr, false);
+        break;
+      // the fused launch by reduction mode: 11 none; 12 (z,aux) left as partials; 13 (x,z),(z,z) + omega in the launch;
+      // 14 the five merged products left as partials; 15 the five + omega, (R,R), rho, beta in the launch
+      case 11: pc_amul(c, k.P, k.V, 0, nullptr, -2); break;
+      case 12: pc_amul(c, k.P, k.V, 1, k.RP, -2); break;
+      case 13: pc_amul(c, k.P, k.V, 2, nullptr, 3); break;
+      case 14: pc_amul(c, k.P, k.V, 4, k.RP, -2); break;
+      case 15: pc_amul(c, k.P, k.V, 4, k.RP, 6); break;
+      default: pc_amul(c, k.P, k.V, 1, k.RP, 2); break;   // what a BiCGStab half-iteration runs (no halo on one rank)
+    }
+  };
+  c->dbg = (which == 3 || which == 4) && pc_fused(c) && !(c->J.bs == 2 && c->ilu.park) ? 1 : 0;
+  partials_clear(c, S_D1, 5);
+  for (int i = 0; i < 5; i++) run();
+  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  for (int i = 0; i < reps; i++) run();
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  HIPCHK(c, hipEventSynchronize(c->ev1));
+  c->dbg = 0;
+  partials_clear(c, S_D1, 5);   // the interior- / face-only launches leave partials nobody sums
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *ms_per_launch = ms / reps;
+#ifdef WAI_PC_PHASES
+  {
+    unsigned long long ph[8];
+    pc_phases_fetch(ph, true);
+    if (ph[7]) {
+      const double n = (double)ph[7], us = 0.01;   // 100 MHz ticks; the last launch's workgroups
+      fprintf(stderr, "pc phases (which %d, %.0f workgroups, %.4f ms per launch): load %.2f wait %.2f forward %.2f backward %.2f epilogue %.2f us per workgroup; "
+              "resident workgroups on average %.1f\n", which, n, ms / reps, ph[0] * us / n, ph[1] * us / n, ph[2] * us / n, ph[3] * us / n, ph[4] * us / n,
+              (ph[0] + ph[1] + ph[2] + ph[3] + ph[4]) * us * 1e-3 / (double)(ms / reps));
+    }
+  }
+#endif
+  return 0;
+}
+
+// name of the kernel (or path) a preconditioned-operator application runs on, for reports
+const char* wai_pc_kernel_name(wai_ctx* c) {
+  if (!c) return "";
+  const IluSchedule& s = c->ilu;
+  if (c->opts.pc_type == WAI_PC_NONE) return "k_spmv (no preconditioner)";
+  if (c->opts.pc_type == WAI_PC_LU) return "k_spmv + k_lu_apply (dense block inverses)";
+  if (pc_extended(c)) {
+    static thread_local char b3[96];
+    snprintf(b3, sizeof(b3), "k_spmv + %s on the extended system (%s, ILU(%d))", c->as.sched.big ? "k_lvl_solve per level" : "k_pc",
+             c->opts.pc_type == WAI_PC_ASM ? "ASM" : "block Jacobi", std::max(c->opts.ilu_levels, 0));
+    return b3;
+  }
+  if (s.big) return "k_spmv + k_lvl_solve per level";
+  if (s.wave_kernel) { static thread_local char b4[64]; snprintf(b4, sizeof(b4), "k_pc_wave<%d,spmv>", c->J.bs); return b4; }
+  if (s.rows_kernel) { static thread_local char b2[64]; snprintf(b2, sizeof(b2), "k_pc_rows<%d,spmv,%d+%d>", c->J.bs, s.max_nlu <= 3 ? 3 : 4, s.max_nlu <= 3 ? 3 : 4); return b2; }
+  if (c->J.bs == 2 && s.park && s.diag_only && s.scaled && s.fast3 && s.max_rows <= 512) return "k_pc_park<spmv>";
+  static thread_local char buf[96];
+  snprintf(buf, sizeof(buf), "k_pc<%d,spmv,%s,%s>", c->J.bs, s.diag_only ? (s.scaled ? "dilu-scaled" : "dilu") : "ilu",
+           s.fast3 ? "compact3" : "generic");
+  return buf;
+}
+int wai_comm_size(wai_ctx* c) { return c ? comm_count(c->comm) : -2; }
+int wai_launch_stats(wai_ctx* c, long long* kernels, long long* copies) {
+  if (!c) return -2;
+  if (kernels) *kernels = c->ks.n_launch;
+  if (copies) *copies = c->ks.n_copy;
+  return 0;
+}
+int wai_bench_mute_comm(wai_ctx* c, int on) {
+  if (!c) return -2;
+  if (c->comm) c->comm->mute = on != 0;
+  return 0;
+}
+int wai_halo_size(wai_ctx* c, int dof, long long* bytes_sent, int* n_neighbours) {
+  if (!c) return -2;
+  if (bytes_sent) *bytes_sent = (long long)c->send_total * dof * (long long)sizeof(double);
+  if (n_neighbours) *n_neighbours = c->n_nbr;
+  return 0;
+}
+int wai_comm_stats(wai_ctx* c, long long* allreduces, long long* exchanges) {
+  if (!c) return -2;
+  if (allreduces) *allreduces = c->comm ? c->comm->n_allreduce : 0;
+  if (exchanges) *exchanges = c->comm ? c->comm->n_exchange : 0;
+  return 0;
+}
+
+int wai_timer_start(wai_ctx* c) { if (!c) return -2; HIPCHK(c, hipEventRecord(c->ev0, c->stream)); return 0; }
+int wai_timer_stop(wai_ctx* c, float* ms) {
+  if (!c || !ms) return -2;
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  HIPCHK(c, hipEventSynchronize(c->ev1));
+  HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return 0;
+}
+int wai_synchronize(wai_ctx* c) { if (!c) return -2; HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+int wai_profile_enable(wai_ctx* c, int on) { if (!c) return -2; c->prof_on = on != 0; return 0; }
+int wai_profile_get(wai_ctx* c, int kclass, double* ms, long long* launches) {
+  if (!c || kclass < 0 || kclass >= KC_COUNT) return -2;
+  if (ms) *ms = c->prof_ms[kclass];
+  if (launches) *launches = c->prof_n[kclass];
+  return 0;
+}
+int wai_profile_reset(wai_ctx* c) {
+  if (!c) return -2;
+  for (int i = 0; i < KC_COUNT; i++) { c->prof_ms[i] = 0.0; c->prof_n[i] = 0; }
+  return 0;
+}
+
+}  // extern "C"
