@@ -157,6 +157,29 @@ module waiwera_hip_module
        integer(c_int), value :: n_global
        integer(c_int), intent(in) :: global_index(*)
      end function wai_set_source_global_index
+     ! rock table controls (src/rock_control.F90:49-116): new values of one rock field (0 .. 7: permeability 1-3, wet and
+     ! dry conductivity, porosity, density, specific heat) for the listed local cells, before a try
+     integer(c_int) function wai_update_rock(ctx, field, n, cells, values) bind(c, name = "wai_update_rock")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: field, n
+       integer(c_int), intent(in) :: cells(*)
+       real(c_double), intent(in) :: values(*)
+     end function wai_update_rock
+     ! the distinct cells a source network couples (no context needed): the same flat description as
+     ! wai_set_source_network plus every source's cell; cells(*) has room for n_sources entries
+     integer(c_int) function wai_network_cells(n_sources, source_cell, rate_specified, enthalpy_specified, n_groups, &
+          grp_ptr, grp_in_kind, grp_in, grp_scaling, grp_limit_type, grp_limit, grp_sep, n_reinjectors, rj_in_kind, &
+          rj_in, rj_out_ptr, out_flow, out_kind, out_node, out_rate, out_proportion, out_enthalpy, rj_overflow_kind, &
+          rj_overflow, n_cells, cells) bind(c, name = "wai_network_cells")
+       import :: c_int, c_ptr
+       integer(c_int), value :: n_sources, n_groups, n_reinjectors
+       type(c_ptr), value :: source_cell, rate_specified, enthalpy_specified, grp_ptr, grp_in_kind, grp_in, grp_scaling, &
+            grp_limit_type, grp_limit, grp_sep, rj_in_kind, rj_in, rj_out_ptr, out_flow, out_kind, out_node, &
+            out_rate, out_proportion, out_enthalpy, rj_overflow_kind, rj_overflow
+       integer(c_int), intent(out) :: n_cells
+       integer(c_int), intent(out) :: cells(*)
+     end function wai_network_cells
      ! kernels launched / copies enqueued by the linear solver so far (a BiCGStab iteration: 4 kernels, no copy)
      integer(c_int) function wai_launch_stats(ctx, kernels, copies) bind(c, name = "wai_launch_stats")
        import :: c_int, c_ptr, c_long_long
@@ -356,7 +379,7 @@ module waiwera_hip_module
 
   public :: wai_set_tracers, wai_set_tracer_bc, wai_set_tracer_injection, wai_set_aux_solver
   public :: wai_set_source_network, wai_get_source_network, wai_set_network_couplings, wai_get_network_couplings
-  public :: wai_set_source_global_index, wai_launch_stats
+  public :: wai_set_source_global_index, wai_launch_stats, wai_update_rock, wai_network_cells
   public :: wai_default_eos, wai_default_opts, wai_set_bc, wai_set_sources, wai_update_sources, wai_set_source_controls, wai_get_source_rates, wai_separator_enthalpies, wai_set_regions, &
        wai_get_regions, wai_jacobian_nnzb, wai_jacobian_pattern, wai_jacobian_get_values
 
