@@ -158,36 +158,6 @@ def test_residual_kernels_agree_bitwise(FS, oracle, eos, dims, monkeypatch):
     sim.destroy(); osim.close()
 
 
-@pytest.mark.parametrize("eos", ["wce", "we"])
-def test_assembly_with_cells_sorted_by_face_count(FS, oracle, eos, monkeypatch):
-    """MINC meshes: inside every run of 256 cells the assembly sweeps take the fracture cells (7 faces) before their
-    matrix cells (1 face), so that a wave's lanes run the same face loop (DeviceMesh::cell_order).  The cells' arithmetic
-    is untouched: residual, lhs and FD Jacobian identical to the unsorted sweeps (WAI_NO_CELL_ORDER) bit for bit, and equal
-    to the oracle's."""
-    out = {}
-    for flag in ("1", None):
-        if flag:
-            monkeypatch.setenv("WAI_NO_CELL_ORDER", flag)
-        else:
-            monkeypatch.delenv("WAI_NO_CELL_ORDER")
-        g, lm, sim, osim, y, region = build(FS, oracle, eos=eos, dims=(9, 8, 6), brick=(4, 4, 2), lens=(eos == "we"), minc=True)
-        n = sim.n_owned * sim.num_primary_variables
-        dt = 2.0e4
-        yo = osim.yvec(y)
-        assert sim.pre_eval(0.0, y) == 0 and osim.pre_eval(yo) == 0
-        L = osim.lhs()
-        f, lhs = np.zeros(n), np.zeros(n)
-        assert sim.residual(0.0, dt, y, L, f) == 0
-        sim.lhs(0.0, (0.0, 0.0), y, lhs)
-        assert sim.jacobian(0.0, dt, y, L) == 0
-        out[flag] = (f, lhs, sim.jacobian_values().copy())
-        err, fo = osim.residual(yo, dt, L)
-        assert relmax(f, fo) < 1e-11
-        sim.destroy(); osim.close()
-    for a, b in zip(out["1"], out[None]):
-        assert np.abs(a).max() > 0.0 and np.array_equal(a, b)
-
-
 @pytest.mark.parametrize("eos", ["we", "w", "wce", "wsce"])
 def test_spmv_ilu_krylov(FS, oracle, eos):
     g, lm, sim, osim, y, region = build(FS, oracle, eos=eos, dims=(12, 10, 9), brick=(4, 4, 4))

@@ -164,7 +164,7 @@ void free_all(wai_ctx* c) {
   auto F = [](void* p) { if (p) (void)hipFree(p); };
   DeviceMesh& m = c->mesh;
   F(m.rock); F(m.vol); F(m.fgeom); F(m.fdir); F(m.adj_face); F(m.adj_other); F(m.adj_blk);
-  F(m.diag_blk); F(m.cell_src); F(m.cell_order); F(m.face_cells);
+  F(m.diag_blk); F(m.cell_src); F(m.face_cells);
   F(c->src.cell); F(c->src.comp); F(c->src.next); F(c->src.rate); F(c->src.enth); F(c->src.ctl); F(c->src.net); c->net.free_device();
   F(c->J.rowptr); F(c->J.col); F(c->J.val);
   free_schedule(c->ilu);
@@ -362,25 +362,6 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
   {
     std::vector<int> fc(md->face_cells, md->face_cells + (size_t)2 * NF);
     if (dev_upload(c, &m.face_cells, fc)) return -1;
-  }
-  {
-    // Cells of very different face counts in one wave (a MINC brick: 32 fracture cells with 7 faces, then their 32
-    // matrix cells with one) leave half the lanes idle through most of the face loops of the assembly sweeps.  Inside
-    // every aligned run of 256 cells -- one workgroup of k_residual_tile, four of k_jacobian_park's 64-thread ones --
-    // the cells with more than half the widest face count go first: waves are then all-long or all-short.  Each cell's
-    // arithmetic is untouched (identical results); meshes whose cells are alike keep the identity.
-    long long shortc = 0;
-    for (int i = 0; i < N; i++) shortc += deg[i] * 2 <= m.max_deg;
-    if (shortc * 5 > N && !getenv("WAI_NO_CELL_ORDER")) {
-      std::vector<int> ord(N);
-      for (int a = 0; a < N; a += 256) {
-        const int b = std::min(a + 256, N);
-        int q = a;
-        for (int i = a; i < b; i++) if (deg[i] * 2 > m.max_deg) ord[q++] = i;
-        for (int i = a; i < b; i++) if (deg[i] * 2 <= m.max_deg) ord[q++] = i;
-      }
-      if (dev_upload(c, &m.cell_order, ord)) return -1;
-    }
   }
   if (dev_upload(c, &m.adj_face, adj_face) || dev_upload(c, &m.adj_other, adj_other) ||
       dev_upload(c, &m.adj_blk, adj_blk) || dev_upload(c, &m.diag_blk, diag) ||

@@ -39,9 +39,6 @@ struct DeviceMesh {
   int* adj_blk = nullptr;    // matrix slot of (cell, other) in the cell's block row, -1 for a bc cell
   int* diag_blk = nullptr;   // matrix slot of (cell, cell)
   int* cell_src = nullptr;   // first source in the cell or -1
-  int* cell_order = nullptr; // assembly sweeps: thread t works on cell cell_order[t] -- inside every aligned run of 256 cells the
-                             // cells with many faces first (MINC: fracture cells before their one-face matrix cells), so
-                             // that a wave's lanes run the same face loop; null: cells all alike, identity
   int* face_cells = nullptr; // [2 n_faces] (cell 1, cell 2) of every face: flux output only
 };
 

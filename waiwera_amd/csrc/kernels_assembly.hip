@@ -99,7 +99,6 @@ struct MeshView {
   const double* rock; const double* vol; const double* fgeom; const int* fdir;
   const int* adj_face; const int* adj_other; const int* adj_blk; const int* diag_blk;
   const int* cell_src;
-  const int* order;        // thread -> cell inside aligned runs of 256 (DeviceMesh::cell_order), null: identity
   const int* src_next; const int* src_comp; const double* src_rate; const double* src_enth;
   const SrcCtl* src_ctl;   // null: all rates as given
   const double* src_net;   // null: no source network (source_network_rate)
@@ -281,15 +280,15 @@ __global__ __launch_bounds__(TPB) void k_residual_tile(MeshView m, const double*
   const int b = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
   if (((int)blockIdx.x >> 3) >= per || b >= nblk) return;   // padding workgroup (uniform)
   const int c0 = b * st, c1 = min(c0 + st, m.n_owned);
-  const bool active = c0 + (int)threadIdx.x < c1;
-  const int c = !active ? c0 : (m.order ? m.order[c0 + threadIdx.x] : c0 + (int)threadIdx.x);   // a cell of this tile either way
+  const int c = c0 + (int)threadIdx.x;
+  const bool active = c < c1;
   CellState<KIND> own;
   RockState rown;
-  double* rk = tile + (size_t)nld * st + (c - c0);
+  double* rk = tile + (size_t)nld * st + threadIdx.x;
   if (active) {
     load_state<KIND>(flu, stride, c, own);
     load_rock(m.rock, m.n_local, c, rown);
-    park_state<KIND>(own, tile + (c - c0), st);
+    park_state<KIND>(own, tile + threadIdx.x, st);
     rk[0] = rown.k[0]; rk[st] = rown.k[1]; rk[2 * st] = rown.k[2]; rk[3 * st] = rown.wet; rk[4 * st] = rown.dry;
   }
   __syncthreads();
@@ -342,10 +341,8 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
                                                   ResForm rf, double* __restrict__ val) {
   using E = EosT<KIND>;
   constexpr int np = E::np, bb = E::np * E::np;
-  int c = xcd_cell(m.n_owned);
+  const int c = xcd_cell(m.n_owned);
   if (c < 0) return;
-  const int c_lin = c;
-  if (m.order) c = m.order[c];   // cells of like face counts in one wave
   CellState<KIND> own0;
   RockState rown;
   load_state<KIND>(flu, stride, c, own0);
@@ -490,10 +487,8 @@ __global__ __launch_bounds__(ParkT<KIND>::threads, (EosT<KIND>::np <= 2 ? 2 : 1)
                                                   ResForm rf, double* __restrict__ val) {
   using E = EosT<KIND>;
   constexpr int np = E::np, bb = E::np * E::np;
-  int c = xcd_cell(m.n_owned);
+  const int c = xcd_cell(m.n_owned);
   if (c < 0) return;
-  const int c_lin = c;
-  if (m.order) c = m.order[c];   // cells of like face counts in one wave
   CellState<KIND> own0;
   RockState rown;
   load_state<KIND>(flu, stride, c, own0);
@@ -592,9 +587,9 @@ __global__ __launch_bounds__(ParkT<KIND>::threads, (EosT<KIND>::np <= 2 ? 2 : 1)
   // neighbour that belongs to this workgroup has its perturbed states in LDS already -- they are what its thread parked
   // -- so they are taken from there instead of memory (MEASURED, round 3: 10.38 -> 10.05 ms at 216^3; the 64-thread
   // workgroups of 3 x 3 blocks hold few of their own neighbours and lose to the divergent branch: 11.1 -> 12.3 ms at C4)
-  const bool SHARE = np <= 2 && !m.order;
-  const int c0 = c_lin - (int)threadIdx.x, c1 = min(c0 + st, m.n_owned);
-  if (np <= 2) __syncthreads();   // every thread's states are parked
+  constexpr bool SHARE = np <= 2;
+  const int c0 = c - (int)threadIdx.x, c1 = min(c0 + st, m.n_owned);
+  if constexpr (SHARE) __syncthreads();   // every thread's states are parked
 #pragma unroll 1
   for (int s = 0; s < m.max_deg; s++) {
     if (!((valid >> s) & 1u)) continue;
@@ -967,7 +962,7 @@ static MeshView view(wai_ctx* c) {
   MeshView m;
   m.rock = c->mesh.rock; m.vol = c->mesh.vol; m.fgeom = c->mesh.fgeom; m.fdir = c->mesh.fdir;
   m.adj_face = c->mesh.adj_face; m.adj_other = c->mesh.adj_other; m.adj_blk = c->mesh.adj_blk;
-  m.diag_blk = c->mesh.diag_blk; m.cell_src = c->mesh.cell_src; m.order = c->mesh.cell_order;
+  m.diag_blk = c->mesh.diag_blk; m.cell_src = c->mesh.cell_src;
   m.src_next = c->src.next; m.src_comp = c->src.comp; m.src_rate = c->src.rate;
   m.src_enth = c->src.enth; m.src_ctl = c->src.ctl; m.src_net = c->src.net;
   m.n_owned = c->mesh.n_owned; m.n_local = c->mesh.n_local; m.n_faces = c->mesh.n_faces;
