@@ -235,6 +235,10 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
   *out = c;
   c->device = device;
   HIPCHK(c, hipSetDevice(device));
+  {
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
+  }
   HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(c, hipEventCreate(&c->ev0)); HIPCHK(c, hipEventCreate(&c->ev1));
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_scal, hipEventDisableTiming));

@@ -294,6 +294,7 @@ int launch_lu_apply(wai_ctx* c, const double* r, double* z);
 
 struct wai_ctx {
   int device = 0;
+  int n_cu = 256;               // compute units of the device (hipDeviceProp_t::multiProcessorCount)
   hipStream_t stream = nullptr;
   int kind = 0, np = 0, df = 0;
   wai::EosParams ep{};

@@ -836,6 +836,24 @@ __device__ __forceinline__ bool fin_block(const Fin& f, const double* partials, 
   return true;
 }
 
+// The first generation of a fused launch started in cohorts.  The workgroups that are resident together from the start
+// (ncu CUs x the kernel's workgroups per CU) begin in the same phase and STAY in step -- all loading (bandwidth-bound, the
+// sweeps' LDS idle), then all sweeping (the memory system idle) -- for the whole launch, 27 generations at 216^3 included:
+// the slot loop's trickle that interleaves one brick's loads with its neighbours' sweeps only works once the bricks of a
+// CU are out of phase.  So the k-th workgroup of a CU (blockIdx / ncu: dispatch hands the first ncu workgroups one to each
+// CU) waits k x `ticks` of the 100-MHz clock before it starts, a third of a brick's period for k_pc_park's three.
+// MEASURED (bench.py --micro-only, same box, profiles/stagger_r4.log): k_pc_park 0.0917 -> 0.0842 ms at 108^3, 0.0801 ->
+// 0.0752 at 100^3, 0.6012 -> 0.5464 ms at 216^3 (63.5 -> 69.9 % of HBM peak) with 6 us per cohort; 3 us gives most of it,
+// 9 us nothing.  (Round 3 tried the same on the all-loads-at-once experiment k_pc_rows3 and saw no change: there a
+// brick's loads ARE one burst.)  WAI_PC_STAGGER=<ticks> overrides, 0 switches it off.
+struct Stagger { int ticks = 0, ncu = 256, per_cu = 3; };
+__device__ __forceinline__ void stagger_start(const Stagger& st) {
+  if (st.ticks > 0 && (int)blockIdx.x < st.ncu * st.per_cu) {
+    const unsigned long long t0 = wall_clock64(), wait = (unsigned long long)((int)blockIdx.x / st.ncu) * (unsigned long long)st.ticks;
+    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
+}
+
 // ---- K6+K8 fused: z = U^-1 L^-1 (A x)  or  z = U^-1 L^-1 r ------------------------------------
 
 template <int NS>
@@ -1221,7 +1239,7 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
     const double* __restrict__ sval, const double* __restrict__ dinv, const double* __restrict__ in,
     const double* __restrict__ in2, const double* __restrict__ scal,
     double* __restrict__ z, const double* __restrict__ aux, double* partials, int nb_max, int dot,
-    const int* __restrict__ sub_list, Fin fin) {
+    const int* __restrict__ sub_list, Fin fin, Stagger stagger) {
   constexpr int BS = 2, BB = 4, MLU = 3;
   extern __shared__ __attribute__((aligned(16))) double lds[];  // [T*2] solution, [80] reduction scratch, then parked U blocks
   // nsub subdomains to run: all of them, or (sub_list) the listed ones -- the bricks that touch no
@@ -1236,6 +1254,7 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
   const int tid = threadIdx.x, i = lo + tid;
   const bool active = tid < R;
   const double nalpha = AX ? -scal[S_ALPHA] : 0.0;   // input = in - alpha in2 (uniform: a scalar load)
+  stagger_start(stagger);
   PH_DECL;
   double* ys = lds;
   double* upark = lds + (size_t)blockDim.x * BS + 80;
@@ -1567,10 +1586,11 @@ __global__ __launch_bounds__(256) void k_pc_wave(
     const int* __restrict__ row_info, const int* __restrict__ row_uoffw, const int* __restrict__ col,
     const double* __restrict__ sval, const double* __restrict__ dinv, const double* __restrict__ in,
     const double* __restrict__ in2, const double* __restrict__ scal, double* __restrict__ z, const double* __restrict__ aux, double* partials, int nb_max, int dot,
-    const int* __restrict__ sub_list, const int* __restrict__ rowptr, int lds_per_brick, Fin fin) {
+    const int* __restrict__ sub_list, const int* __restrict__ rowptr, int lds_per_brick, Fin fin, Stagger stagger) {
   constexpr int BB = BS * BS, NL = 3, NU = 4;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   if (fin_block(fin, partials, nb_max)) return;
+  stagger_start(stagger);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ngrp = (nsub + 3) >> 2;
   const int g = xcd_remap(blockIdx.x, ngrp);
@@ -2299,6 +2319,12 @@ static int pc_kernel_kind(const wai_ctx* c, const Bcsr& J, const IluSchedule& s)
 }
 bool pc_axpy_capable(const wai_ctx* c) { return !c->ilu.big && pc_kernel_kind(c, c->J, c->ilu) != 0; }
 
+// ticks of the 100-MHz clock between the cohorts of a fused launch's first generation (stagger_start); WAI_PC_STAGGER overrides
+static int stagger_ticks(int dflt) {
+  const char* es = getenv("WAI_PC_STAGGER");
+  return es ? atoi(es) : dflt;
+}
+
 template <int BS>
 static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool spmv, const double* in, double* z,
                          int dot_mode, const double* aux, const int* list, int nrun, const Fin* finp, const double* in2) {
@@ -2331,7 +2357,11 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
       const int* rp = (size_t)J.nnzb * 10 < (size_t)J.n * J.W * 9 ? J.rowptr : nullptr;   // > 10 % padding
 #define PCW(SP, AXV)                                                                                \
       hipLaunchKernelGGL((k_pc_wave<BS, SP, AXV>), gridw, 256, lds_w, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev, s.row_info, \
-                         s.row_uoffw, J.col, s.fval, s.dinv, in, in2, scal, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, list, rp, per, fin)
+                         s.row_uoffw, J.col, s.fval, s.dinv, in, in2, scal, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, list, rp, per, fin, stagger)
+      Stagger stagger;
+      stagger.ncu = c->n_cu;
+      stagger.per_cu = std::max(1, (int)((size_t)160 * 1024 / (lds_w + 704)));
+      stagger.ticks = stagger_ticks(0);
       if (spmv) { if (in2) PCW(true, true); else PCW(true, false); }
       else PCW(false, false);
 #undef PCW
@@ -2359,7 +2389,11 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
 #define PCP(SP, AXV)                                                                               \
       hipLaunchKernelGGL((k_pc_park<SP, AXV>), grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,  \
                          s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, in2, scal, z, aux, c->ks.partials,       \
-                         c->ks.nb_max, dot_mode, list, fin)
+                         c->ks.nb_max, dot_mode, list, fin, stagger)
+      Stagger stagger;
+      stagger.ncu = c->n_cu;
+      stagger.per_cu = std::max(1, std::min(3, (int)((size_t)160 * 1024 / (lds_park + 704))));
+      stagger.ticks = stagger_ticks(600);
       if (spmv) { if (in2) PCP(true, true); else PCP(true, false); }
       else PCP(false, false);
 #undef PCP
