@@ -844,8 +844,10 @@ __device__ __forceinline__ bool fin_block(const Fin& f, const double* partials, 
 // CU) waits k x `ticks` of the 100-MHz clock before it starts, a third of a brick's period for k_pc_park's three.
 // MEASURED (bench.py --micro-only, same box, profiles/stagger_r4.log): k_pc_park 0.0917 -> 0.0842 ms at 108^3, 0.0801 ->
 // 0.0752 at 100^3, 0.6012 -> 0.5464 ms at 216^3 (63.5 -> 69.9 % of HBM peak) with 6 us per cohort; 3 us gives most of it,
-// 9 us nothing.  (Round 3 tried the same on the all-loads-at-once experiment k_pc_rows3 and saw no change: there a
-// brick's loads ARE one burst.)  WAI_PC_STAGGER=<ticks> overrides, 0 switches it off.
+// 9 us nothing; a second box: 0.0899 -> 0.0840 at 108^3, 0.556-0.561 -> 0.546-0.551 at 216^3.  k_pc_wave (ten-odd one-wave
+// bricks per CU, in workgroups of four) gains 1.5 % with 4 us per cohort (C5 0.1981-0.1993 -> 0.1954-0.1959, C4's quarter
+// 0.1687-0.1695 -> 0.1661-0.1666).  (Round 3 tried the same on the all-loads-at-once experiment k_pc_rows3 and saw no
+// change: there a brick's loads ARE one burst.)  WAI_PC_STAGGER=<ticks> overrides, 0 switches it off.
 struct Stagger { int ticks = 0, ncu = 256, per_cu = 3; };
 __device__ __forceinline__ void stagger_start(const Stagger& st) {
   if (st.ticks > 0 && (int)blockIdx.x < st.ncu * st.per_cu) {
@@ -2361,7 +2363,7 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
       Stagger stagger;
       stagger.ncu = c->n_cu;
       stagger.per_cu = std::max(1, (int)((size_t)160 * 1024 / (lds_w + 704)));
-      stagger.ticks = stagger_ticks(0);
+      stagger.ticks = stagger_ticks(400);
       if (spmv) { if (in2) PCW(true, true); else PCW(true, false); }
       else PCW(false, false);
 #undef PCW
