@@ -519,10 +519,6 @@ def main():
         drv._begin()
         sim.jacobian(drv.t + drv.dt, drv.dt, y, drv.lhs_old)
         sim.pc_setup()
-        if os.environ.get("WAI_MICRO_NOFIN") == "1":   # experiment builds whose partials no finaliser can see
-            modes = {"spmv": 0, "no reduction": 11, "(z,aux) partials only": 12, "five merged products, partials only": 14}
-            log("micro %s [%s] (ms): %s" % (a.config, sim.pc_kernel_name(), json.dumps({k: round(sim.bench_kernel(w, a.spmv_reps), 4) for k, w in modes.items()})))
-            return
         names = ["spmv", "ilu_apply", "fused_pc_amul"]
         kb = {name: sim.bench_kernel(w, a.spmv_reps if w in (0, 2) else 20) for w, name in enumerate(names)}
         nnzb = wl.LIB.wai_jacobian_nnzb(sim.h)

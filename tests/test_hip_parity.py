@@ -120,13 +120,12 @@ def test_jacobian_kernels_agree_bitwise(FS, oracle, eos, monkeypatch):
     f = np.zeros(n)
     assert sim.residual(0.0, dt, y, L, f) == 0
     vals = {}
-    for flag in ("0", "1", "share_base"):
-        monkeypatch.setenv("WAI_JAC_PARK", "0" if flag == "0" else "1")
-        monkeypatch.setenv("WAI_JAC_SHARE_BASE", "1" if flag == "share_base" else "0")   # base records shared in LDS too (2 x 2 blocks)
+    for flag in ("0", "1"):
+        monkeypatch.setenv("WAI_JAC_PARK", flag)
         assert sim.jacobian(0.0, dt, y, L) == 0
         vals[flag] = sim.jacobian_values().copy()
     assert np.abs(vals["0"]).max() > 0.0
-    assert np.array_equal(vals["0"], vals["1"]) and np.array_equal(vals["0"], vals["share_base"])
+    assert np.array_equal(vals["0"], vals["1"])
     sim.destroy(); osim.close()
 
 

@@ -480,10 +480,7 @@ __global__ __launch_bounds__(TPB) void k_jacobian(MeshView m, const double* __re
 // and face record are loaded once for all of them: 21 instead of 33 state records per cell for np = 2,
 // 13 instead of 25 rock records, 12 instead of 24 face records.  Same evaluations, same summation
 // order, bit-identical blocks.
-// SB (experiment, WAI_JAC_SHARE_BASE=1; 2 x 2 blocks): the workgroup's BASE records and rock fields are parked too
-// ((nld + 5) more doubles per thread: 77 instead of 53 KB for eos we, two workgroups per CU instead of three) and an
-// in-workgroup neighbour's base state comes from there in both face loops.
-template <int KIND, bool SB>
+template <int KIND>
 __global__ __launch_bounds__(ParkT<KIND>::threads, (EosT<KIND>::np <= 2 ? 2 : 1)) void k_jacobian_park(MeshView m, const double* __restrict__ flu,
                                                   size_t stride, const double* __restrict__ flu_pert,
                                                   const double* __restrict__ hstep, int n_prim,
@@ -521,21 +518,6 @@ __global__ __launch_bounds__(ParkT<KIND>::threads, (EosT<KIND>::np <= 2 ? 2 : 1)
   // base residual, keeping every slot's contribution (in LDS too: [slot][component][thread], so that the
   // face loops need not be unrolled); the own-perturbed evaluations of the same face with it
   double* terms0 = park + (size_t)np * nld * st + threadIdx.x;
-  double* pbase = park + (size_t)np * (nld + MAXDEG) * st;     // SB: [nld][st] base states, then [5][st] rock
-  const int c0 = c - (int)threadIdx.x, c1 = min(c0 + st, m.n_owned);
-  if constexpr (SB) {
-    park_state<KIND>(own0, pbase + threadIdx.x, st);
-    double* rk = pbase + (size_t)nld * st + threadIdx.x;
-    rk[0] = rown.k[0]; rk[st] = rown.k[1]; rk[2 * st] = rown.k[2]; rk[3 * st] = rown.wet; rk[4 * st] = rown.dry;
-    __syncthreads();   // every thread's base and perturbed states are parked
-  }
-  auto neighbour_rock = [&](int o, RockState& roth) {
-    if (SB && o >= c0 && o < c1) {
-      const double* ro = pbase + (size_t)nld * st + (o - c0);
-      roth.k[0] = ro[0]; roth.k[1] = ro[st]; roth.k[2] = ro[2 * st]; roth.wet = ro[3 * st]; roth.dry = ro[4 * st];
-      roth.phi = 0.0; roth.rho = 0.0; roth.cp = 0.0;   // the flux reads permeabilities and conductivities only
-    } else load_rock(m.rock, m.n_local, o, roth);
-  };
   double L0[np], src0[np], f0[np];
   cell_balance<KIND>(own0, rown, L0);
   unsigned valid = 0u;
@@ -549,9 +531,8 @@ __global__ __launch_bounds__(ParkT<KIND>::threads, (EosT<KIND>::np <= 2 ? 2 : 1)
     load_face(m, fs >> 1, g);
     CellState<KIND> oth;
     RockState roth;
-    if (SB && o >= c0 && o < c1) unpark_state<KIND>(pbase + (o - c0), st, oth);
-    else load_state<KIND>(flu, stride, o, oth);
-    neighbour_rock(o, roth);
+    load_state<KIND>(flu, stride, o, oth);
+    load_rock(m.rock, m.n_local, o, roth);
     double t0[np];
     slot_term<KIND>(g, fs & 1, own0, rown, oth, roth, vol, t0);
 #pragma unroll
@@ -607,7 +588,8 @@ __global__ __launch_bounds__(ParkT<KIND>::threads, (EosT<KIND>::np <= 2 ? 2 : 1)
   // -- so they are taken from there instead of memory (MEASURED, round 3: 10.38 -> 10.05 ms at 216^3; the 64-thread
   // workgroups of 3 x 3 blocks hold few of their own neighbours and lose to the divergent branch: 11.1 -> 12.3 ms at C4)
   constexpr bool SHARE = np <= 2;
-  if constexpr (SHARE && !SB) __syncthreads();   // every thread's states are parked
+  const int c0 = c - (int)threadIdx.x, c1 = min(c0 + st, m.n_owned);
+  if constexpr (SHARE) __syncthreads();   // every thread's states are parked
 #pragma unroll 1
   for (int s = 0; s < m.max_deg; s++) {
     if (!((valid >> s) & 1u)) continue;
@@ -618,7 +600,7 @@ __global__ __launch_bounds__(ParkT<KIND>::threads, (EosT<KIND>::np <= 2 ? 2 : 1)
     FaceGeom g;
     load_face(m, fs >> 1, g);
     RockState roth;
-    neighbour_rock(o, roth);
+    load_rock(m.rock, m.n_local, o, roth);
 #pragma unroll
     for (int k = 0; k < np; k++) {
       CellState<KIND> othk;
@@ -1061,19 +1043,13 @@ int launch_jacobian(wai_ctx* c, double dt, const double* lhs_old) {
   // 216^3 matrix before every assembly and accumulated into it: 4.6 GB of the launch's traffic.)
   const char* ep = getenv("WAI_JAC_PARK");   // read per call: tests compare the two kernels in one process
   const bool park = !(ep && ep[0] == '0');
-  const char* esb = getenv("WAI_JAC_SHARE_BASE");
-  const bool share_base = esb && esb[0] == '1';
   if (park) {
 #define JP(K)                                                                                             \
     do {                                                                                                  \
       constexpr int T = ParkT<K>::threads;                                                                \
       const int g = (((int)((m.n_owned + T - 1) / T) + 7) / 8) * 8;                                        \
-      if (ParkT<K>::use && share_base && EosT<K>::np <= 2)                                                \
-        hipLaunchKernelGGL((k_jacobian_park<K, true>), g, T, ParkT<K>::lds_bytes + (ParkT<K>::nld + 5) * 8 * T, c->stream, \
-                           m, c->flu, stride, c->flu_pert, c->hstep, c->mesh.n_prim, res_form_of(c, dt, lhs_old), \
-                           c->J.val);                                                                     \
-      else if (ParkT<K>::use)                                                                             \
-        hipLaunchKernelGGL((k_jacobian_park<K, false>), g, T, ParkT<K>::lds_bytes, c->stream,               \
+      if (ParkT<K>::use)                                                                                  \
+        hipLaunchKernelGGL(k_jacobian_park<K>, g, T, ParkT<K>::lds_bytes, c->stream,                       \
                            m, c->flu, stride, c->flu_pert, c->hstep, c->mesh.n_prim, res_form_of(c, dt, lhs_old), \
                            c->J.val);                                                                     \
       else                                                                                                \

@@ -786,11 +786,7 @@ __device__ __forceinline__ void sum_partials(const double* partials, int nb_max,
 // A workgroup's partial sum: stored at agent scope (written through to memory, coherent across the XCDs' L2s)
 // so that the workgroup that finishes a reduction can read it without any cache-wide fence
 __device__ __forceinline__ void store_partial(double* p, double t) {
-#ifdef WAI_EXP_PLAIN_PARTIAL   // timing experiment only (no finaliser can see these): what the write-through costs the producers
-  *p = t;
-#else
   __hip_atomic_store(p, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
 }
 // is this workgroup one of the launch's finalisers (the last f.nf workgroups)?  If so do its share (the caller returns)
 __device__ __forceinline__ bool fin_block(const Fin& f, const double* partials, int nb_max) {
