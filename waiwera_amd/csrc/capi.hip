@@ -672,7 +672,8 @@ int wai_set_source_controls(wai_ctx* c, const wai_source_control* controls) {
       HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     for (int i = 0; i < s.n; i++)
-      if (recs[i].threshold > 0.0 && recs[i].threshold_pi < 0.0) recs[i].threshold_pi = old.empty() ? recs[i].coef : old[i].threshold_pi;
+      if (recs[i].threshold > 0.0 && recs[i].threshold_pi < 0.0)   // inherited only from a record that HAD a threshold and a noted index
+        recs[i].threshold_pi = (!old.empty() && old[i].threshold > 0.0 && old[i].threshold_pi >= 0.0) ? old[i].threshold_pi : recs[i].coef;
   }
   controls = reinterpret_cast<const wai_source_control*>(recs.data());
   if (!s.ctl) HIPCHK(c, hipMalloc(&s.ctl, sizeof(SrcCtl) * (size_t)s.n));

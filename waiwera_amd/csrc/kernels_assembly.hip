@@ -100,7 +100,7 @@ struct MeshView {
   const int* adj_face; const int* adj_other; const int* adj_blk; const int* diag_blk;
   const int* cell_src;
   const int* src_next; const int* src_comp; const double* src_rate; const double* src_enth;
-  const SrcCtl* src_ctl;   // null: all rates as given
+  SrcCtl* src_ctl;         // null: all rates as given (the unperturbed residual sweep notes threshold indices into the records)
   const double* src_net;   // null: no source network (source_network_rate)
   int n_owned, n_local, n_faces, max_deg;
 };

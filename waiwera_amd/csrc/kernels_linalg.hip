@@ -57,6 +57,33 @@ void pc_phases_fetch(unsigned long long out[8], bool reset) {
 
 
 constexpr int TPB = 256;
+
+// The sum of a wave's 64 doubles, in every lane, by DPP row operations (row_shr 1, 2, 4, 8 inside the rows of 16, then
+// row_bcast 15 and 31 across them) on the two halves of the double: six adds whose operands come through the VALU's
+// data-parallel-primitive path instead of six dependent ds_bpermute round trips through the LDS pipe -- which the
+// substitution sweeps of the other bricks on the CU are waiting on.  (Round 3 measured 0.6 % for the one or two sums of
+// its launches and left the shuffle tree; the merged BiCGStab reductions make five per brick.)  Lanes without a source
+// take 0.0, the identity; the order of the additions is fixed, so the sum is reproducible.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, BANK_MASK, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, BANK_MASK, false);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#ifdef WAI_SHFL_SUMS   // the shuffle tree of rounds 1-3 (A/B builds)
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  return __shfl(v, 0);
+#else
+  v = dpp_add<0x111, 0xf, 0xf>(v);   // row_shr:1
+  v = dpp_add<0x112, 0xf, 0xf>(v);   // row_shr:2
+  v = dpp_add<0x114, 0xf, 0xe>(v);   // row_shr:4, lanes 4 .. 15 of a row
+  v = dpp_add<0x118, 0xf, 0xc>(v);   // row_shr:8, lanes 8 .. 15: lane 15 holds its row's sum
+  v = dpp_add<0x142, 0xa, 0xf>(v);   // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc, 0xf>(v);   // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's sum
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+#endif
+}
 #ifndef PC_MIN_WAVES
 #define PC_MIN_WAVES 4   // waves per SIMD k_pc is compiled for; 5 or 6 force spills and measured 1.2x / 3x slower (tools/ab_pc_waves.sh)
 #endif
@@ -751,8 +778,7 @@ __device__ __forceinline__ void sum_slice(unsigned long long* p0, int nb_max, in
     }
 #pragma unroll
     for (int s = 0; s < FIN_MAXS; s++) {
-      double ts = t[s];
-      for (int off = 32; off > 0; off >>= 1) ts += __shfl_down(ts, off);
+      const double ts = wave_sum(t[s]);
       if ((v & 63) == 0) fsm[s][v >> 6] = ts;
     }
   }
@@ -865,8 +891,7 @@ __device__ __forceinline__ void wg_reduce_store(double (&v)[NS], double* red, do
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
 #pragma unroll
   for (int s = 0; s < NS; s++) {
-    double t = v[s];
-    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+    const double t = wave_sum(v[s]);
     if (lane == 0) red[s * 16 + w] = t;
   }
   __syncthreads();
@@ -1745,8 +1770,7 @@ __global__ __launch_bounds__(256) void k_pc_wave(
 #pragma unroll
     for (int q = 0; q < 5; q++) {
       if (q < ns) {
-        double t = v[q];
-        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+        const double t = wave_sum(v[q]);
         if (lane == 0) store_partial(partials + (size_t)(slot0 + q) * nb_max + s, t);
       }
     }
@@ -1782,8 +1806,7 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[NS], double* part
   __shared__ double sm[NS][TPB / 64];
 #pragma unroll
   for (int s = 0; s < NS; s++) {
-    double t = v[s];
-    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+    const double t = wave_sum(v[s]);
     if ((threadIdx.x & 63) == 0) sm[s][threadIdx.x >> 6] = t;
   }
   __syncthreads();
@@ -2200,7 +2223,7 @@ __global__ __launch_bounds__(256) void k_lu_apply(int nsub, int bs, const int* _
   for (int i = w; i < m; i += nw) {
     double t = 0.0;
     for (int j = lane; j < m; j += 64) t += A[(size_t)i * m + j] * r[lo + j];
-    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+    t = wave_sum(t);
     if (lane == 0) z[lo + i] = t;
   }
 }

@@ -870,7 +870,7 @@ __device__ inline double source_network_rate(const double* net, int si, double r
 
 template <int KIND>
 // commit: an unperturbed residual evaluation -- the threshold deliverability notes its productivity index then
-__device__ inline double source_rate(const CellState<KIND>& s, const SrcCtl* ctl, int si, double rate,
+__device__ inline double source_rate(const CellState<KIND>& s, SrcCtl* ctl, int si, double rate,
                                      const double* net = nullptr, bool commit = false) {
   using E = EosT<KIND>;
   if (!ctl) return source_network_rate(net, si, rate);
@@ -902,7 +902,7 @@ __device__ inline double source_rate(const CellState<KIND>& s, const SrcCtl* ctl
         if (qd > rate) rate = qd;
       } else if (commit) {
         const double fac = sum * dp * s.permfac;
-        if (fabs(fac) > 1.0e-9) const_cast<SrcCtl*>(ctl)[si].threshold_pi = fabs(rate) / fac;
+        if (fabs(fac) > 1.0e-9) ctl[si].threshold_pi = fabs(rate) / fac;   // the control records are the sweep's to note into (commit: unperturbed evaluations only)
       }
     } else {
       rate = 0.0;
