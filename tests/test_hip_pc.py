@@ -184,6 +184,74 @@ def test_bicgstab_fused_iteration(oracle, eos, brick, minc, monkeypatch):
     sim.destroy(); osim.close()
 
 
+@pytest.mark.parametrize("eos", ["we", "wce", "w"])
+def test_ilu0_with_off_diagonal_fill(oracle, eos):
+    """A cell graph WITH triangles: diagonal connections (i, j, k) - (i + 1, j + 1, k) added to a structured mesh make
+    (i, j), (i + 1, j), (i + 1, j + 1) pairwise adjacent, so the IKJ elimination updates off-diagonal blocks inside a
+    subdomain, ILU(0) is no longer DILU and the library takes the stored-factor kernels (k_ilu_factor, k_pc with the
+    factor read back: the path of meshes with triangles in their cell graph, which the hexahedral / MINC tests never
+    reach).  Rows have up to 9 blocks > the register-resident 8?  No: 6 + 2 diagonals + itself = 9 only in the interior of
+    3-D meshes, so the mesh here is one layer thick (4 + 2 + 1 = 7).  Application and Krylov solve against the oracle."""
+    import waiwera_amd.cases as cases
+    from waiwera_amd.flow_simulation import FlowSimulation
+    dims, brick = (10, 9, 1), (5, 3, 1)
+    g, lm, prim, region = cases.make_case(dims=dims, brick=brick, eos=eos, lens=False, top_bc=False)
+    ijk = np.asarray(lm.owned_ijk)
+    idx = {(int(a), int(b)): q for q, (a, b, c) in enumerate(ijk)}
+    fg_x = None
+    fc = np.asarray(lm.face_cells)
+    for f in range(lm.n_faces):     # a template: any x face between two owned cells
+        a, b = fc[f]
+        if a < lm.n_owned and b < lm.n_owned and abs(ijk[a][0] - ijk[b][0]) == 1:
+            fg_x = np.asarray(lm.face_geom)[f].copy()
+            break
+    extra_c, extra_g = [], []
+    for (i, j), q in idx.items():
+        if (i + 1, j + 1) in idx:
+            row = fg_x.copy()
+            row[0] *= 0.3                                   # area
+            row[1] = row[2] = 0.5 * np.hypot(10.0, 10.0)    # distances to the face
+            row[3] = row[1] + row[2]
+            extra_c.append((q, idx[(i + 1, j + 1)]))
+            extra_g.append(row)
+    lm.face_cells = np.concatenate([fc, np.array(extra_c, dtype=np.int32)]).astype(np.int32)
+    lm.face_geom = np.concatenate([np.asarray(lm.face_geom), np.array(extra_g)])
+    lm.n_faces = lm.face_cells.shape[0]
+    sim = FlowSimulation(lm, eos=eos)
+    osim = ol.OracleSim(oracle, lm, KIND[eos])
+    sim.set_regions(region); osim.set_regions(region)
+    assert sim.pc_kernel_name().startswith("k_pc<") and ",ilu," in sim.pc_kernel_name(), sim.pc_kernel_name()
+    y = scaled(prim, region, eos).ravel().copy()
+    yo = osim.yvec(y)
+    dt = 5.0e4
+    assert osim.pre_eval(yo) == 0
+    L = osim.lhs()
+    err, f = osim.residual(yo, dt, L)
+    err, J = osim.jacobian(yo, dt, L, f, mode=0)
+    assert err == 0
+    sim.set_jacobian_values(J)
+    n = sim.num_dof
+    assert sim.pc_setup() == 0 and osim.pc_setup(J) == 0
+    r = np.random.default_rng(3).normal(size=n)
+    z = np.zeros(n)
+    sim.pc_apply(r, z)
+    assert relmax(z, osim.pc_apply(r)) < 1e-10
+    sim.set_opts(ksp_rtol=1e-12)
+    x = np.zeros(n)
+    its, reason, rn = sim.ksp_solve(f, x)
+    oreason, xo, oits, hist = osim.ksp_solve(J, f, rtol=1e-12)
+    assert reason > 0 and oreason > 0
+    assert relmax(x, xo) < 1e-8 and abs(its - oits) <= max(2, oits // 10), (its, oits)
+    # the device's own FD Jacobian on this mesh equals the oracle's too (9-point rows through the assembly sweeps)
+    assert sim.pre_eval(0.0, y) == 0
+    fd = np.zeros(n)
+    assert sim.residual(0.0, dt, y, L, fd) == 0 and relmax(fd, f) < 1e-11
+    assert sim.jacobian(0.0, dt, y, L) == 0
+    Jg = sim.jacobian_values()
+    assert np.abs(Jg - J).max() <= 2e-5 * np.abs(J).max()
+    sim.destroy(); osim.close()
+
+
 @pytest.mark.parametrize("eos,pc", [("we", "bjacobi"), ("wce", "bjacobi"), ("we", "asm")])
 def test_bcgsl(oracle, eos, pc):
     """BiCGStab(2) ("linear.type": "bcgsl") against the oracle's restatement"""
