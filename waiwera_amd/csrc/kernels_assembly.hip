@@ -207,7 +207,7 @@ __global__ __launch_bounds__(TPB) void k_residual(MeshView m, const double* __re
                                                   const int* __restrict__ only, int n_only) {
   using E = EosT<KIND>;
   int c;
-  if (only) {   // the listed rows alone (the source network's cells, network_couplings in capi.hip)
+  if (only) {   // the listed rows alone (the source network's cells, network_couplings in network.hip)
     const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (t >= n_only) return;
     c = only[t];

@@ -630,7 +630,7 @@ __global__ __launch_bounds__(TPB) void k_scale_rows(int n, int W, const double* 
 // What the host tests after an iteration -- the squared residual norm and the breakdown code -- written straight
 // into pinned host memory: {(R,R), 8 * sequence number + code, check} with check = bits((R,R)) ^ bits(tag) ^ POST_KEY.
 // The first two words leave as ONE aligned 16-byte store (one PCIe write on gfx942 / gfx950), the check word behind
-// them; the host (wait_post, capi.hip) spins on the tag and accepts the pair only when the check word matches, so a
+// them; the host (wait_post, krylov.hip) spins on the tag and accepts the pair only when the check word matches, so a
 // store that the fabric tears, or words that arrive in another order, can only delay the host, never pair a new
 // sequence number with an old norm.  Codes: 0 none, 1-3 BiCGStab breakdowns (derive_scalars), 4 a partial sum of a
 // reduction never arrived (sum_partials).

@@ -857,7 +857,7 @@ __device__ inline double ctl_table(const SrcCtl& k, double x) {
   return (1.0 - xi) * k.table[2 * i + 1] + xi * k.table[2 * (i + 1) + 1];
 }
 
-// what the source network did to a source in the last network pass (host side, capi.hip): net[2 si]
+// what the source network did to a source in the last network pass (host side, network.hip): net[2 si]
 // 0 nothing, 1 its rate is scaled by net[2 si + 1] (member of a limited group), 2 its rate IS
 // net[2 si + 1] (output of a reinjector); src/source_network_group.F90, source_network_reinjector.F90
 __device__ inline double source_network_rate(const double* net, int si, double rate) {
