@@ -155,21 +155,28 @@ __device__ __forceinline__ double res_form(const ResForm& rf, double L, double R
 template <int KIND> struct ParkT {
   using E = EosT<KIND>;
   static constexpr int nld = 4 + E::nph * (7 + (E::nc > 1 ? E::nc : 0));   // doubles load_state reads
+  // what a parked record holds: what the FLUX (and the source terms) read of a state -- not the internal energies, which
+  // only the accumulation term uses, and the permeability factor only where it is not identically 1 (salt: halite)
+  static constexpr int npark = 3 + (is_salt<KIND> ? 1 : 0) + E::nph * (6 + (E::nc > 1 ? E::nc : 0));
   static constexpr int threads = E::np <= 2 ? 128 : 64;
-  static constexpr int lds_bytes = E::np * (nld + MAXDEG) * 8 * threads;   // parked states + base terms
+  // parked own-perturbed states + base terms of max_deg faces, per thread.  Round 4: the leaner record and max_deg instead
+  // of a fixed 8 slots bring a 64-thread workgroup of 3 x 3 blocks from 46 080 to 39 936 B (eos wce, 6 or 7 faces): FOUR
+  // workgroups per CU, one wave on every SIMD, where three left one SIMD idle
+  static constexpr int lds_bytes(int max_deg) { return E::np * (npark + max_deg) * 8 * threads; }
   // three workgroups per CU or the plain kernel: MEASURED 13.7 -> 10.4 ms (we, 216^3), 12.5 -> 11.0 (wce,
   // 172x172x170; 14.7 with 128 threads = one workgroup per CU); the three-phase salt EOS would hold one
-  static constexpr bool use = lds_bytes <= 54 * 1024;
+  static constexpr bool use = E::np * (npark + MAXDEG) * 8 * threads <= 54 * 1024;
 };
 template <int KIND>
 __device__ __forceinline__ void park_state(const CellState<KIND>& s, double* __restrict__ b, int st) {
   using E = EosT<KIND>;
   int f = 0;
-  b[(f++) * st] = s.P; b[(f++) * st] = s.T; b[(f++) * st] = s.phases; b[(f++) * st] = s.permfac;
+  b[(f++) * st] = s.P; b[(f++) * st] = s.T; b[(f++) * st] = s.phases;
+  if constexpr (is_salt<KIND>) b[(f++) * st] = s.permfac;
 #pragma unroll
   for (int p = 0; p < E::nph; p++) {
     b[(f++) * st] = s.rho[p]; b[(f++) * st] = s.mu[p]; b[(f++) * st] = s.sat[p]; b[(f++) * st] = s.kr[p];
-    b[(f++) * st] = s.pc[p]; b[(f++) * st] = s.h[p]; b[(f++) * st] = s.u[p];
+    b[(f++) * st] = s.pc[p]; b[(f++) * st] = s.h[p];
     if constexpr (E::nc > 1) {
 #pragma unroll
       for (int q = 0; q < E::nc; q++) b[(f++) * st] = s.x[p][q];
@@ -180,14 +187,16 @@ template <int KIND>
 __device__ __forceinline__ void unpark_state(const double* __restrict__ b, int st, CellState<KIND>& s) {
   using E = EosT<KIND>;
   int f = 0;
-  s.P = b[(f++) * st]; s.T = b[(f++) * st]; s.phases = b[(f++) * st]; s.permfac = b[(f++) * st];
+  s.P = b[(f++) * st]; s.T = b[(f++) * st]; s.phases = b[(f++) * st];
+  if constexpr (is_salt<KIND>) s.permfac = b[(f++) * st];
+  else s.permfac = 1.0;   // eos_eval leaves it at 1 where no permeability modifier exists
   s.region = 0.0;
 #pragma unroll
   for (int q = 0; q < E::nc; q++) s.pp[q] = 0.0;
 #pragma unroll
   for (int p = 0; p < E::nph; p++) {
     s.rho[p] = b[(f++) * st]; s.mu[p] = b[(f++) * st]; s.sat[p] = b[(f++) * st]; s.kr[p] = b[(f++) * st];
-    s.pc[p] = b[(f++) * st]; s.h[p] = b[(f++) * st]; s.u[p] = b[(f++) * st];
+    s.pc[p] = b[(f++) * st]; s.h[p] = b[(f++) * st]; s.u[p] = 0.0;   // (not read by the flux or the sources)
     if constexpr (E::nc == 1) {
       s.x[p][0] = (((int)s.phases >> p) & 1) ? 1.0 : 0.0;
     } else {
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(TPB) void k_residual(MeshView m, const double* __re
 // Same loads of the same doubles, same arithmetic in the same order: bit-identical residuals.
 template <int KIND> struct ResTile {
   using E = EosT<KIND>;
-  static constexpr int nld = ParkT<KIND>::nld, nrk = 5;       // state record, rock: k1 k2 k3 wet dry
+  static constexpr int nld = ParkT<KIND>::npark, nrk = 5;     // parked state record, rock: k1 k2 k3 wet dry
   static constexpr int lds_bytes = (nld + nrk) * 8 * TPB;
 };
 template <int KIND>
@@ -503,7 +512,7 @@ __global__ __launch_bounds__(ParkT<KIND>::threads, (EosT<KIND>::np <= 2 ? 2 : 1)
 
   // own-perturbed states: accumulation terms now, the states themselves into LDS (thread-private columns)
   extern __shared__ double park[];
-  constexpr int nld = ParkT<KIND>::nld;
+  constexpr int nld = ParkT<KIND>::npark;
   const int st = (int)blockDim.x;
   double Lk[np][np], Rk[np][np];
 #pragma unroll
@@ -1049,7 +1058,7 @@ int launch_jacobian(wai_ctx* c, double dt, const double* lhs_old) {
       constexpr int T = ParkT<K>::threads;                                                                \
       const int g = (((int)((m.n_owned + T - 1) / T) + 7) / 8) * 8;                                        \
       if (ParkT<K>::use)                                                                                  \
-        hipLaunchKernelGGL(k_jacobian_park<K>, g, T, ParkT<K>::lds_bytes, c->stream,                       \
+        hipLaunchKernelGGL(k_jacobian_park<K>, g, T, ParkT<K>::lds_bytes(m.max_deg), c->stream,                       \
                            m, c->flu, stride, c->flu_pert, c->hstep, c->mesh.n_prim, res_form_of(c, dt, lhs_old), \
                            c->J.val);                                                                     \
       else                                                                                                \
