@@ -563,6 +563,59 @@ def test_asm_overlap_reaches_across_ranks(world, eos):
     assert worst_x < 1e-8, worst_x
 
 
+def _asm_refuse_worker(rank, world, uid_q, q):
+    os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    os.environ.setdefault("WAI_HALO_OVERLAP", "0")
+    from waiwera_amd import lib as wl
+    from waiwera_amd.cases import make_case
+    from waiwera_amd.flow_simulation import FlowSimulation
+    if rank == 0:
+        uid = wl.comm_unique_id()
+        for _ in range(world - 1):
+            uid_q.put(uid)
+    else:
+        uid = uid_q.get(timeout=300)
+    g, lm, prim, region = make_case(dims=(16, 12, 8), brick=(4, 3, 2), eos="we", lens=True, part=M.partition_shape(world), rank=rank)
+    sim = FlowSimulation(lm, eos="we", device=0)
+    sim.set_regions(region)
+    sim.comm_init(rank, world, uid)
+    y = scaled(prim, region, "we").ravel().copy()
+    n = lm.n_owned * 2
+    assert sim.pre_eval(0.0, y) == 0
+    L, f = np.zeros(n), np.zeros(n)
+    sim.lhs(0.0, (0.0, 0.0), y, L)
+    assert sim.residual(2.0e4, 2.0e4, y, L, f) == 0 and sim.jacobian(2.0e4, 2.0e4, y, L) == 0
+    sim.set_opts(pc_type="asm", asm_overlap=2)
+    msg = ""
+    try:
+        sim.pc_setup()
+    except wl.WaiError as e:
+        msg = str(e)
+    sim.set_opts(pc_type="asm", asm_overlap=1)       # ... and the context is still good for the supported overlap
+    ok = sim.pc_setup() == 0
+    q.put((rank, msg, ok))
+    sim.destroy()
+
+
+@pytest.mark.timeout(600)
+def test_asm_overlap_two_is_refused_across_ranks():
+    """one ghost layer travels between ranks, so PCASM overlap 1 (the reference's default) is exact across a rank boundary
+    and a deeper overlap would silently stop there: refused with a message instead"""
+    assert os.path.exists(LOOPBACK), "build first: python __graft_entry__.py"
+    os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    ctx = mp.get_context("spawn")
+    q, uid_q = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_asm_refuse_worker, args=(r, 2, uid_q, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=400) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, msg, ok in res:
+        assert "overlap > 1 across ranks" in msg and ok, (rank, msg, ok)
+
+
 # ---- a source network whose sources live on several ranks ------------------------------------------------------
 
 def _network_spec(n_global):

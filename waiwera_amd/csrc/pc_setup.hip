@@ -363,8 +363,13 @@ int build_asm(wai_ctx* c, int overlap, int levels) {
   const int N = J.n, np = J.bs;
   // Overlap across rank boundaries (the reference's PCASM subdomains are the ranks and MatIncreaseOverlap
   // pulls in the neighbours' rows): the overlapped sets may contain partition-ghost cells, whose matrix rows come
-  // from their owners.  One ghost layer exists, so overlap 1 is exact; deeper overlap stops at that layer.
+  // from their owners.  One ghost layer exists, so overlap 1 -- the reference's default -- is exact; a deeper overlap would
+  // silently stop at that layer on a rank boundary and is refused instead.
   const bool cross = overlap > 0 && c->comm && c->comm->nranks > 1 && c->mesh.n_halo > 0 && c->n_nbr > 0;
+  if (cross && overlap > 1) {
+    c->err = "preconditioner asm: overlap > 1 across ranks is not supported (the partition carries one ghost layer); use overlap 1";
+    return -2;
+  }
   const int H = cross ? c->mesh.n_halo : 0, NX = N + H;
   std::vector<int> grp, gci, gslot;
   if (cross && ghost_rows(c, grp, gci, gslot)) return -1;
