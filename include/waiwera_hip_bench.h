@@ -13,7 +13,7 @@ extern "C" {
 int wai_comm_stats(wai_ctx *ctx, long long *allreduces, long long *exchanges);
 /* kernels launched and copies enqueued by the linear-solver helpers so far (SpMV, preconditioner, vector
  * updates, reductions, halo pack / unpack, scalar read-backs): a BiCGStab iteration on one rank is 4 kernels
- * and no copy -- every reduction is finished by the last workgroup of its producer and the residual norm is
+ * and no copy -- every reduction is finished by the last workgroups of its producer and the residual norm is
  * posted to pinned host memory */
 int wai_launch_stats(wai_ctx *ctx, long long *kernels, long long *copies);
 
@@ -31,8 +31,10 @@ int wai_timer_stop(wai_ctx *ctx, float *ms);
  * Jacobian): which 0 block SpMV, 1 ILU(0) apply, 2 fused SpMV + ILU(0) apply + dot,
  * 3/4 timing probes of 1/2 without the substitution sweeps (generic brick kernel only), 5 one whole BiCGStab
  * iteration's launches (and collectives) back to back without the host, 6 its vector updates alone, 7 the second
- * fused launch of the three-launch iteration (operand R - alpha V, five inner products), 9 / 10 the fused
- * kernel on the interior / the face bricks alone (the two launches of the overlapped halo exchange) */
+ * fused launch of the iteration (operand S, or R - alpha V with WAI_BCGS_COMPOSE=1; five inner products), 9 / 10 the fused
+ * kernel on the interior / the face bricks alone (the two launches of the overlapped halo exchange), 11 .. 15 the fused
+ * launch by reduction mode: 11 none, 12 (z,aux) left as partial sums, 13 (x,z),(z,z) + omega finished in the launch,
+ * 14 the five merged products left as partial sums, 15 the five + omega, (R,R), rho, beta finished in the launch */
 int wai_bench_kernel(wai_ctx *ctx, int which, int reps, float *ms_per_launch);
 /* accumulated HIP-event time (ms) and launch counts per kernel class since the last reset;
  * classes: 0 eos, 1 residual, 2 jacobian, 3 spmv, 4 pc_apply, 5 pc_setup, 6 vector, 7 transitions */
