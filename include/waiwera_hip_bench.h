@@ -21,6 +21,9 @@ int wai_launch_stats(wai_ctx *ctx, long long *kernels, long long *copies);
  * of this context return without calling RCCL (results are then wrong; timing probes only).  Every rank must switch
  * together. */
 int wai_bench_mute_comm(wai_ctx *ctx, int on);
+/* fault injection for the tests: workgroup 0 of the following launches loses its next n partial sums of a reduction --
+ * the in-launch finalisation must run into its bounded wait and the solver return KSP_DIVERGED_NANORINF (-9) */
+int wai_test_drop_partials(wai_ctx *ctx, int n);
 /* bytes this rank sends per halo exchange of a dof-per-cell vector, and its number of neighbours */
 int wai_halo_size(wai_ctx *ctx, int dof, long long *bytes_sent, int *n_neighbours);
 

@@ -373,6 +373,32 @@ def test_iluk_sub_preconditioner(oracle, eos, pc, brick):
     sim.destroy(); osim.close()
 
 
+@pytest.mark.timeout(300)
+def test_a_lost_partial_sum_ends_the_solve_not_the_device(oracle):
+    """The in-launch finalisation reads arrival off the data; a partial sum that never arrives (fault injected: workgroup 0
+    of the next fused launch loses its store) must end in the finaliser's bounded wait, breakdown code 4 posted to the
+    host and KSP_DIVERGED_NANORINF -- not in a hung device or a sum of stale data -- and the next solve, which empties the
+    reduction slots first, must be untouched by it."""
+    from waiwera_amd.lib import LIB
+    lm, sim, osim, J, f = system(oracle, "we", (12, 12, 8), (4, 4, 2))
+    n = sim.num_dof
+    sim.set_opts(pc_type="bjacobi", ksp_type="bcgs", ksp_rtol=1e-10)
+    assert sim.pc_setup() == 0
+    x = np.zeros(n)
+    its0, reason0, rn0 = sim.ksp_solve(f, x)
+    assert reason0 > 0
+    x0 = x.copy()
+    assert LIB.wai_test_drop_partials(sim.h, 1) == 0
+    x[:] = 0.0
+    its, reason, rn = sim.ksp_solve(f, x)
+    assert reason == -9, (its, reason, rn)
+    assert "partial sum never arrived" in LIB.wai_last_error(sim.h).decode()
+    x[:] = 0.0
+    its2, reason2, rn2 = sim.ksp_solve(f, x)
+    assert reason2 > 0 and its2 == its0 and np.array_equal(x, x0), (its2, its0, reason2)
+    sim.destroy(); osim.close()
+
+
 def test_bicgstab_iteration_is_four_launches_and_no_copy(oracle):
     """one rank, fused block-Jacobi path: fused A*P + ILU(0) solve (+ (V,RP), alpha), S update, fused A*S + solve (+ the
     five merged inner products, omega, (R,R), rho, beta, the posted norm), X / R / next-P update in one pass -- every

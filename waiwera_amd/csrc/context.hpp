@@ -422,6 +422,7 @@ int vec_zero(wai_ctx* c, double* dst, size_t n);
 int vec_waxpy(wai_ctx* c, double* w, double alpha, const double* x, const double* y, int n);
 int bcgs_scalars(wai_ctx* c, int phase, bool post = false);
 int bcgs_post(wai_ctx* c, int seq);
+int test_drop_partials(wai_ctx* c, int n);   // fault injection (tests): workgroup 0 loses its next n partial sums
 int bcgs_update_p(wai_ctx* c);
 int bcgs_update_s(wai_ctx* c);
 // dots: reduces (R,R), (R,RP) into S_DP2, S_RHONEW and (fin_phase >= -1) finalises them in its last workgroup

@@ -670,7 +670,8 @@ __device__ __forceinline__ void derive_rotate(double* s) {
 __device__ __forceinline__ void derive_scalars(double* s, int phase) {
   switch (phase) {  // PETSc KSPSolve_BCGS order of operations
     case 0:  // after R = B^-1 b: DP2 = (R,R); rho = (R,RP) with RP = R
-      s[S_RHO] = s[S_DP2]; s[S_RHOOLD] = 1.0; s[S_ALPHA] = 1.0; s[S_OMEGA] = 1.0; s[S_BREAK] = 0.0;
+      s[S_RHO] = s[S_DP2]; s[S_RHOOLD] = 1.0; s[S_ALPHA] = 1.0; s[S_OMEGA] = 1.0;
+      if (s[S_BREAK] != 4.0) s[S_BREAK] = 0.0;   // (4: this very reduction lost a partial sum; the driver zeroes the code before a solve)
       s[S_BETA] = (s[S_RHO] / s[S_RHOOLD]) * (s[S_ALPHA] / s[S_OMEGA]);
       if (s[S_RHO] == 0.0) s[S_BREAK] = 1.0;
       break;
@@ -744,6 +745,7 @@ __device__ __forceinline__ void sum_slice(unsigned long long* p0, int nb_max, in
   constexpr int CH = 4;
   const int len = hi - lo, VT = len > 256 ? 1024 : 256;
   __syncthreads();   // fsm / res of an earlier call are no longer read
+  bool gave_up = false;
   for (int v = threadIdx.x; v < VT; v += blockDim.x) {   // whole waves: blockDim is a multiple of 64
     double t[FIN_MAXS];
 #pragma unroll
@@ -764,10 +766,11 @@ __device__ __forceinline__ void sum_slice(unsigned long long* p0, int nb_max, in
           const int i = i0 + k * VT;
           if (s < ns && i < hi) {
             unsigned long long* ps = p0 + (size_t)s * nb_max + i;
-            for (int spin = 0; wait && u[s][k] == FIN_EMPTY && spin < (1 << 22); spin++) {
+            for (int spin = 0; wait && !gave_up && u[s][k] == FIN_EMPTY && spin < (1 << 22); spin++) {
               __builtin_amdgcn_s_sleep(8);
               u[s][k] = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (u[s][k] == FIN_EMPTY) gave_up = true;   // one bounded wait per thread: a launch that lost a partial ends in seconds
             // still empty: the producer never stored it (waited out above), or -- k_finalize, wait = false -- no producer
             // ran before this consumer.  The sum is a NaN either way; say why (code 4 reaches the host with the post)
             if (u[s][k] == FIN_EMPTY) scal[S_BREAK] = 4.0;
@@ -811,7 +814,15 @@ __device__ __forceinline__ void sum_partials(const double* partials, int nb_max,
 }
 // A workgroup's partial sum: stored at agent scope (written through to memory, coherent across the XCDs' L2s)
 // so that the workgroup that finishes a reduction can read it without any cache-wide fence
+// Fault injection for the tests (wai_test_drop_partials): while positive, workgroup 0 of a launch loses its partial sums
+// (and counts the variable down) -- the finaliser must then run into its bounded wait, report breakdown code 4, and the
+// solver must come back with KSP_DIVERGED_NANORINF instead of hanging or summing stale data.
+__device__ int g_drop_partials = 0;
 __device__ __forceinline__ void store_partial(double* p, double t) {
+  if (blockIdx.x == 0 && __hip_atomic_load(&g_drop_partials, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) {
+    atomicSub(&g_drop_partials, 1);
+    return;
+  }
   __hip_atomic_store(p, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // is this workgroup one of the launch's finalisers (the last f.nf workgroups)?  If so do its share (the caller returns)
@@ -2556,6 +2567,10 @@ int bcgs_scalars(wai_ctx* c, int phase, bool post) {
   c->ks.n_launch++;
   hipLaunchKernelGGL(k_bcgs_scalars, 1, 64, 0, c->stream, c->ks.scal, phase, c->ks.d_post, post ? ++c->ks.seq : 0);
   return 0;
+}
+int test_drop_partials(wai_ctx* c, int n) {
+  return hipMemcpyToSymbolAsync(HIP_SYMBOL(g_drop_partials), &n, sizeof(int), 0, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+         hipStreamSynchronize(c->stream) == hipSuccess ? 0 : -1;
 }
 int bcgs_post(wai_ctx* c, int seq) {   // the device scalars as they stand, under a sequence number already handed out
   c->ks.n_launch++;

@@ -287,6 +287,7 @@ int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, doub
   vec_zero(c, k.P, k.nl);
   vec_zero(c, k.V, pl.fused3 ? k.nl : n);   // fused: V's ghost entries stay zero (the composed operand's ghosts arrive in R's)
   partials_clear(c, S_D1, 5);   // S_D1 .. S_W2: whatever an aborted solve or a probe left behind
+  vec_zero(c, k.scal + S_BREAK, 1);
   {
     Prof p(c, KC_PC_APPLY);
     if (pc_solve(c, b, k.R, 3, nullptr, nullptr, multi ? -1 : 0)) return -1;  // R = B^-1 b, (R,R), first rho / beta
@@ -297,12 +298,13 @@ int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, doub
     vec_copy(c, k.RP, k.R, n);
     if (pl.fused3) vec_copy(c, k.P, k.R, n);   // the first P = R + beta (0 - omega 0): the later ones come out of k_bcgs_xrp
   }
-  if (read_scal(c, S_DP2, 1)) return -1;
+  if (read_scal(c, S_DP2, S_BREAK - S_DP2 + 1)) return -1;
   double dp = std::sqrt(k.h_scal[S_DP2]);
   const double dp0 = dp, ttol = std::max(rtol * dp, atol);
   *its = 0;
   *reason = 0;
-  if (std::isnan(dp)) *reason = -9;
+  if (k.h_scal[S_BREAK] == 4.0) { *reason = -9; c->err = "a reduction's partial sum never arrived (finaliser wait ran out)"; }
+  else if (std::isnan(dp)) *reason = -9;
   else if (dp <= ttol) *reason = (dp <= atol) ? 3 : 2;
   double* Xsave = k.X;
   k.X = x;  // X aliases the caller's x during the iteration
