@@ -203,10 +203,12 @@ int wai_set_source_network(wai_ctx *ctx, const int *rate_specified, const int *e
  * that fills the added entries, src/flow_simulation.F90:3023-3084): wai_jacobian differences the 7-point
  * matrix A with the network's factors held and then E = dR/dy through the network pass on the m distinct
  * cells of the network's sources (same increment rule; two residual evaluations per column).  Every
- * operator application of the Krylov solvers and wai_spmv is (A + E) x; the preconditioner is built from
- * A alone.  n_cells = m (0: no network, switched off, or E = 0 at this state); cells (may be NULL) m local
+ * operator application of the Krylov solvers and wai_spmv is (A + E) x, and on one rank the pairs of network cells
+ * that share a preconditioner block are entries of the factor's pattern too, as PETSc factors the widened BAIJ
+ * matrix (round 4; a network across ranks: operator only).  n_cells = m (0: no network, switched off, or E = 0 at this state); cells (may be NULL) m local
  * cell indices, ascending; values (may be NULL) m x m blocks of bs x bs, row-major [row cell][col cell][r][k].
- * wai_set_network_couplings(ctx, 0) holds the factors instead (round 1's inexact Newton); default on. */
+ * wai_set_network_couplings(ctx, 0) holds the factors instead (round 1's inexact Newton); 1: E in the operator only,
+ * the preconditioner built from A alone (rounds 2-3); 2 (default): operator and factor pattern. */
 /* A network whose sources live on several ranks (the reference gathers over the group's communicator,
  * src/source_network_group.F90:494-515, 579-596, 701-709; source_network_reinjector.F90:534, 740, 772-789): every
  * rank hands wai_set_source_network the SAME description, numbered by global source index, after telling which

@@ -320,6 +320,47 @@ def test_network_couplings_are_the_literal_fd_columns(name, geometry, steps, mon
         print(name, "bjacobi", "merged" if merged else "petsc order", "krylov its", its_b, "residual", res_b)
         assert res_b < 1e-5, (merged, res_b)
     monkeypatch.delenv("WAI_BCGS_MERGED")
+    # The network's blocks inside the factor (round 4; PETSc factors the widened BAIJ matrix): block Jacobi ILU(0) of
+    # A + E on the pattern of A widened by the pairs of network cells that share a subdomain -- one application against
+    # the dense definition, and the Krylov count with E in the factor against E in the operator only
+    def _dense_ilu_on_pattern(Ad, pt):    # IKJ elimination restricted to a pattern (tests/test_oracle_linalg.py's, row-vectorised)
+        F = Ad.copy()
+        for i in range(F.shape[0]):
+            for k in np.nonzero(pt[i, :i])[0]:
+                F[i, k] /= F[k, k]
+                mk = pt[i, k + 1:]
+                F[i, k + 1:][mk] -= F[i, k] * F[k, k + 1:][mk]
+        F[~pt] = 0.0
+        return np.tril(F, -1) + np.eye(F.shape[0]), np.triu(F)
+    sub = np.asarray(sim.mesh.sub_ptr)
+    Md = M.toarray()
+    blk = (np.abs(sp.bsr_matrix((np.ones_like(A), ci, rp), shape=(n, n)).toarray().reshape(n // bs, bs, n // bs, bs)).sum(axis=(1, 3)) != 0)
+    for r in cells:
+        for c in cells:
+            blk[r, c] = True
+    pat = np.kron(blk, np.ones((bs, bs), dtype=bool))
+    rvec = np.sin(0.37 * np.arange(n))
+    zref = np.zeros(n)
+    for s0, s1 in zip(sub[:-1], sub[1:]):
+        sl = slice(s0 * bs, s1 * bs)
+        Lf, Uf = _dense_ilu_on_pattern(Md[sl, sl], pat[sl, sl])
+        zref[sl] = np.linalg.solve(Uf, np.linalg.solve(Lf, rvec[sl]))
+    its_pc = {}
+    for in_pc in (True, False):
+        ode.set_network_couplings(True, in_preconditioner=in_pc)
+        ode.set_opts(pc_type="bjacobi", ksp_rtol=1e-8)
+        assert ode.pc_setup() == 0
+        if in_pc:
+            z = np.zeros(n)
+            assert ode.pc_apply(rvec, z) == 0
+            dz = np.abs(z - zref).max() / np.abs(zref).max()
+            print(name, "ILU(0) of A + E on the widened pattern against its dense definition:", dz, "[%s]" % ode.pc_kernel_name())
+            assert dz < 1e-6, dz
+        xs[:] = 0.0
+        its_pc[in_pc], reason, rn = ode.ksp_solve(b, xs)
+        assert reason > 0 and np.abs(M @ xs - b).max() / np.abs(b).max() < 1e-5
+    print(name, "BiCGStab iterations with the network's blocks in the factor", its_pc[True], "in the operator only", its_pc[False])
+    assert its_pc[True] <= its_pc[False] + 1, its_pc
     ode.set_opts(pc_type="asm", ksp_rtol=1e-5)
     ode.set_network_couplings(False)
     assert ode.residual(t + dt, dt, y, L, f0) == 0

@@ -596,11 +596,12 @@ int wai_set_sources(wai_ctx* c, int n, const int* cell, const double* rate, cons
   if (dev_upload(c, &s.cell, vc) || dev_upload(c, &s.comp, vk) || dev_upload(c, &s.next, next) ||
       dev_upload(c, &s.rate, vr) || dev_upload(c, &s.enth, ve))
     return -1;
-  const bool coupling = c->net.coupling;
+  const bool coupling = c->net.coupling, cp_in_pc = c->net.cp_in_pc;
   c->net = Network();   // a network refers to sources by index: set it again after the sources
   c->net.h_enth0 = ve;
   c->net.h_cell.assign(vc.begin(), vc.begin() + n);
-  c->net.coupling = coupling;
+  c->net.coupling = coupling; c->net.cp_in_pc = cp_in_pc;
+  c->as.overlap = -1;   // an extended system built for another network's cells is stale
   return 0;
 }
 

@@ -106,6 +106,7 @@ struct Network {
   // the Jacobian.  The operator is A + E; the preconditioner is built from A.
   std::vector<int> h_cell;                         // cell of every source
   bool coupling = true;                            // wai_set_network_couplings
+  bool cp_in_pc = true;                            // ... and inside the preconditioner's ILU pattern (wai_set_network_couplings 2; one rank)
   bool cp_valid = false;                           // E belongs to the Jacobian in force and has a nonzero entry
   std::vector<int> cp_cells;                       // distinct (local) cells of the network's sources, ascending
   std::vector<double> h_cp_val;                    // [ml][m][bs][bs] row-major, ml = cp_cells.size() rows, m columns
@@ -205,6 +206,13 @@ struct AsmSystem {
   // overlap across rank boundaries: the matrix rows of the partition-ghost cells, received from
   // their owners at every set-up (block-ELL over the n_halo cells, the sender's slot order), and the residual
   // with its ghost entries filled by one more halo exchange per application
+  // the source network's blocks inside the factor's pattern (src/flow_simulation.F90:3023-3084 widens the BAIJ pattern
+  // PETSc factors): E's pattern carries the pairs of network cells of one subdomain, net_pos / net_pair name where each
+  // block of the network's E goes (plane position t * n_ext + q; pair = row * m + column in the coupling array)
+  bool with_net = false;
+  int n_net = 0;
+  int* net_pos = nullptr;
+  int* net_pair = nullptr;
   bool cross = false;
   double* hval = nullptr;     // [W * bs * bs * n_halo]
   double* r_full = nullptr;   // [bs * n_prim]
@@ -392,7 +400,7 @@ int launch_pc_on(wai_ctx* c, const Bcsr& M, const IluSchedule& s, bool spmv, con
 bool pc_axpy_capable(const wai_ctx* c);
 // subdomains of any size: level-by-level launches, in place on z (z = r on entry)
 int launch_big_solve(wai_ctx* c, const Bcsr& M, const IluSchedule& s, double* z);
-int launch_asm_gather_matrix(wai_ctx* c);                   // E.val <- J.val (and the ghost cells' rows)
+int launch_asm_gather_matrix(wai_ctx* c);                   // E.val <- J.val (and the ghost cells' rows; + the network's blocks)
 int launch_pack_rows(wai_ctx* c);                           // d_sendbuf <- matrix rows of the cells sent to neighbours
 int launch_unpack_rows(wai_ctx* c);                         // as.hval <- d_recvbuf
 int launch_asm_gather(wai_ctx* c, const double* r);        // as.r_ext <- r

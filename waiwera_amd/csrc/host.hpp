@@ -101,12 +101,14 @@ struct Prof {
 
 // which preconditioner path is in force: the fused brick kernels (block Jacobi, every subdomain
 // <= 1024 rows) or the general one (PCASM's extended system, subdomains of any size, PCNONE)
+// the source network's blocks are part of the Jacobian in force AND go into the factor's pattern (one rank)
+inline bool pc_with_net(const wai_ctx* c) { return c->net.cp_valid && c->net.cp_in_pc && !c->net.cp_span; }
 inline bool pc_fused(const wai_ctx* c) {
-  return c->opts.pc_type == WAI_PC_BJACOBI && !c->ilu.big && c->opts.ilu_levels <= 0;
+  return c->opts.pc_type == WAI_PC_BJACOBI && !c->ilu.big && c->opts.ilu_levels <= 0 && !pc_with_net(c);
 }
-// the extended-system path: PCASM's overlapped row sets and / or ILU(k)'s filled pattern
+// the extended-system path: PCASM's overlapped row sets and / or ILU(k)'s filled pattern and / or the network's blocks
 inline bool pc_extended(const wai_ctx* c) {
-  return c->opts.pc_type == WAI_PC_ASM || (c->opts.pc_type == WAI_PC_BJACOBI && c->opts.ilu_levels > 0);
+  return c->opts.pc_type == WAI_PC_ASM || (c->opts.pc_type == WAI_PC_BJACOBI && (c->opts.ilu_levels > 0 || pc_with_net(c)));
 }
 
 // ---- pc_setup.hip ------------------------------------------------------------------------------------------------

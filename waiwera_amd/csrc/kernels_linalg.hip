@@ -2174,6 +2174,17 @@ __global__ __launch_bounds__(TPB) void k_asm_gather_matrix(int n, int n_ext, int
     for (int k = 0; k < bs; k++)
       eval[ell_ix(bs, (size_t)n_ext, s, r, k, (size_t)q)] = g == -1 ? 0.0 : src[ell_ix(bs, (size_t)nn, ss, r, k, (size_t)i)];
 }
+// the source network's blocks added where the extended pattern holds their pair of cells (AsmSystem::net_pos / net_pair;
+// cp: [row][column][bs][bs] row-major, m columns): thread per (entry, r, k)
+__global__ __launch_bounds__(TPB) void k_asm_add_couplings(int n_net, int n_ext, int bs, const int* __restrict__ pos,
+                                                           const int* __restrict__ pair, const double* __restrict__ cp,
+                                                           double* __restrict__ eval) {
+  const int t = blockIdx.x * TPB + threadIdx.x, bb = bs * bs;
+  if (t >= n_net * bb) return;
+  const int e = t / bb, rk = t - e * bb, r = rk / bs, k = rk - r * bs;
+  const int sl = pos[e] / n_ext, q = pos[e] - sl * n_ext;
+  eval[ell_ix(bs, (size_t)n_ext, sl, r, k, (size_t)q)] += cp[(size_t)pair[e] * bb + rk];
+}
 // matrix rows of the cells a rank sends to its neighbours: buf[p][slot][r][k] (W * bs * bs doubles per cell)
 __global__ __launch_bounds__(TPB) void k_pack_rows(int n, int W, int bs, int nsend, const int* __restrict__ idx,
                                                    const double* __restrict__ jval, double* __restrict__ buf) {
@@ -2484,6 +2495,11 @@ int launch_asm_gather_matrix(wai_ctx* c) {
   const size_t tot = (size_t)a.E.W * a.n_ext;
   hipLaunchKernelGGL(k_asm_gather_matrix, (int)((tot + TPB - 1) / TPB), TPB, 0, c->stream, c->J.n, a.n_ext, a.E.W,
                      a.E.bs, c->mesh.n_halo, a.gmap, c->J.val, a.hval, a.E.val);
+  if (a.with_net && a.n_net > 0 && c->net.cp_valid && c->net.d_cp_val) {   // + the source network's blocks of this Jacobian
+    const int nt = a.n_net * a.E.bs * a.E.bs;
+    hipLaunchKernelGGL(k_asm_add_couplings, (nt + TPB - 1) / TPB, TPB, 0, c->stream, a.n_net, a.n_ext, a.E.bs, a.net_pos,
+                       a.net_pair, c->net.d_cp_val, a.E.val);
+  }
   return 0;
 }
 int launch_pack_rows(wai_ctx* c) {

@@ -578,6 +578,7 @@ int wai_set_source_network(wai_ctx* c, const int* rate_specified, const int* ent
   nw.on = true;
   if (!span) network_cells(nw, n);
   else network_cells_span(nw, ng, span_id, c->comm->rank);
+  c->as.overlap = -1;   // the factor's pattern carries the network's cell pairs: built again at the next set-up
   return 0;
 }
 
@@ -594,6 +595,7 @@ int wai_set_source_global_index(wai_ctx* c, int n_global, const int* global_inde
 int wai_set_network_couplings(wai_ctx* c, int on) {
   if (!c) return -2;
   c->net.coupling = on != 0;
+  c->net.cp_in_pc = on != 1;      // 1: in the operator only (rounds 2-3); 2 (and any other non-zero value): in the factor's pattern too
   if (!on) c->net.cp_valid = false;
   return 0;
 }

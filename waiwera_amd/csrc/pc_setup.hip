@@ -247,6 +247,7 @@ void free_schedule(IluSchedule& s) {
   s = IluSchedule();
 }
 void free_asm(AsmSystem& a) {
+  hipFree(a.net_pos); hipFree(a.net_pair);
   free_schedule(a.sched);
   hipFree(a.E.col); hipFree(a.E.val); hipFree(a.ext_row); hipFree(a.gmap); hipFree(a.r_ext); hipFree(a.hval); hipFree(a.r_full);
   a = AsmSystem();
@@ -356,7 +357,7 @@ int ghost_rows(wai_ctx* c, std::vector<int>& grp, std::vector<int>& gci, std::ve
   return 0;
 }
 
-int build_asm(wai_ctx* c, int overlap, int levels) {
+int build_asm(wai_ctx* c, int overlap, int levels, bool with_net) {
   AsmSystem& a = c->as;
   free_asm(a);
   const Bcsr& J = c->J;
@@ -422,6 +423,38 @@ int build_asm(wai_ctx* c, int overlap, int levels) {
     }
   }
   // (columns are positions in the extended numbering: block b's rows are ext_ptr[b] .. ext_ptr[b + 1])
+  // The source network's blocks (flow_simulation_modify_jacobian, src/flow_simulation.F90:3023-3084: the reference widens
+  // the BAIJ pattern by the network's dependencies and PETSc factors what it finds there): every pair of network cells
+  // that share a subdomain's row set gets an entry (a structural zero of A where the cells are not neighbours; the
+  // values are added after the gather, k_asm_add_couplings), before the fill levels are counted.
+  const Network& nw = c->net;
+  const int mnet = with_net ? (int)nw.cp_cells.size() : 0;
+  if (mnet > 0) {
+    std::vector<int> netidx(NX, -1);
+    for (int r = 0; r < mnet; r++) netidx[nw.cp_cells[r]] = r;
+    std::vector<int> nrp(n_ext + 1, 0), ncol, nsrc;
+    ncol.reserve(ecol.size() + (size_t)mnet * mnet); nsrc.reserve(ncol.capacity());
+    for (int sd = 0; sd < nsub; sd++) {
+      std::vector<int> cells;   // ext positions of the network cells in this subdomain's row set
+      for (int q = ext_ptr[sd]; q < ext_ptr[sd + 1]; q++) if (ext_rows[q] < N && netidx[ext_rows[q]] >= 0) cells.push_back(q);
+      for (int q = ext_ptr[sd]; q < ext_ptr[sd + 1]; q++) {
+        const bool isnet = ext_rows[q] < N && netidx[ext_rows[q]] >= 0 && cells.size() > 1;
+        if (!isnet) {
+          for (int e = erp[q]; e < erp[q + 1]; e++) { ncol.push_back(ecol[e]); nsrc.push_back(esrc[e]); }
+        } else {   // merge the row's columns with the network cells' positions (both ascending)
+          size_t a2 = 0;
+          int e = erp[q];
+          while (e < erp[q + 1] || a2 < cells.size()) {
+            const int ca = e < erp[q + 1] ? ecol[e] : 0x7fffffff, cb = a2 < cells.size() ? cells[a2] : 0x7fffffff;
+            if (ca <= cb) { ncol.push_back(ca); nsrc.push_back(esrc[e]); e++; if (cb == ca) a2++; }
+            else { ncol.push_back(cb); nsrc.push_back(-1); a2++; }
+          }
+        }
+        nrp[q + 1] = (int)ncol.size();
+      }
+    }
+    erp.swap(nrp); ecol.swap(ncol); esrc.swap(nsrc);
+  }
   if (levels > 0) iluk_fill(ext_ptr, levels, erp, ecol, esrc);
   for (int q = 0; q < n_ext; q++) W = std::max(W, erp[q + 1] - erp[q]);
   if (W > 255) { c->err = "ILU(k): more than 255 blocks in a factor row"; return -2; }
@@ -447,6 +480,22 @@ int build_asm(wai_ctx* c, int overlap, int levels) {
       dev_alloc(c, &a.E.val, (size_t)W * np * np * n_ext) || dev_alloc(c, &a.r_ext, (size_t)np * n_ext + 16))
     return -1;
   if (int e = build_schedule(c, a.sched, erp, ecol, ext_ptr, n_ext, W, np, false)) return e;
+  a.with_net = with_net;
+  a.n_net = 0;
+  if (mnet > 0) {   // where the blocks of the network's E land in the extended planes
+    std::vector<int> netidx(NX, -1), pos, pair;
+    for (int r = 0; r < mnet; r++) netidx[nw.cp_cells[r]] = r;
+    for (int q = 0; q < n_ext; q++) {
+      const int i = ext_rows[q];
+      if (i >= N || netidx[i] < 0) continue;
+      for (int t = 0; t < erp[q + 1] - erp[q]; t++) {
+        const int j = ext_rows[ecol[erp[q] + t]];
+        if (j < N && netidx[j] >= 0) { pos.push_back(t * n_ext + q); pair.push_back(netidx[i] * mnet + netidx[j]); }
+      }
+    }
+    a.n_net = (int)pos.size();
+    if (a.n_net && (dev_upload(c, &a.net_pos, pos) || dev_upload(c, &a.net_pair, pair))) return -1;
+  }
   if (cross) {
     if (dev_alloc(c, &a.hval, (size_t)J.W * np * np * H) || dev_alloc(c, &a.r_full, (size_t)np * NX + 16)) return -1;
     HIPCHK(c, hipMemset(a.r_full, 0, sizeof(double) * ((size_t)np * NX + 16)));
@@ -531,7 +580,8 @@ int do_pc_setup(wai_ctx* c) {
     if (pc_extended(c)) {
       const int ov = c->opts.pc_type == WAI_PC_ASM ? (c->opts.asm_overlap > 0 ? c->opts.asm_overlap : 1) : 0;
       const int lv = std::max(c->opts.ilu_levels, 0);
-      if (c->as.overlap != ov || c->as.levels != lv || c->as.E.bs != c->J.bs) { if (int e = build_asm(c, ov, lv)) return e < 0 ? -1 : e; }
+      const bool wn = pc_with_net(c);
+      if (c->as.overlap != ov || c->as.levels != lv || c->as.E.bs != c->J.bs || c->as.with_net != wn) { if (int e = build_asm(c, ov, lv, wn)) return e < 0 ? -1 : e; }
       if (c->as.cross) {   // the ghost cells' matrix rows, from their owners
         const int dof = c->J.W * c->J.bs * c->J.bs;
         if (ensure_halo_dof(c, dof)) return -1;

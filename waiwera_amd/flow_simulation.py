@@ -124,9 +124,11 @@ class FlowSimulation:
         self._chk(LIB.wai_get_source_network(self.h, G.ctypes.data_as(_lib.pd), R.ctypes.data_as(_lib.pd)), "get_source_network")
         return G[:ng], R[:nr]
 
-    def set_network_couplings(self, on=True):
-        """the network's Jacobian blocks (flow_simulation_modify_jacobian, flow_simulation.F90:3023-3084) on / off"""
-        self._chk(LIB.wai_set_network_couplings(self.h, 1 if on else 0), "set_network_couplings")
+    def set_network_couplings(self, on=True, in_preconditioner=True):
+        """the network's Jacobian blocks (flow_simulation_modify_jacobian, flow_simulation.F90:3023-3084) on / off;
+        in_preconditioner: also inside the factor's pattern, as PETSc factors the widened matrix (default), or in the
+        operator only"""
+        self._chk(LIB.wai_set_network_couplings(self.h, (2 if in_preconditioner else 1) if on else 0), "set_network_couplings")
 
     def network_couplings(self):
         """(cells (m,), E (ml, m, bs, bs)): d R(cell i) / d y(cell j) through the network pass, of the last
