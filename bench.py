@@ -133,6 +133,26 @@ class NewtonDriver:
         return reason, kits
 
 
+def device_state(index=0):
+    """Clocks, temperature and power of the GPU as rocm-smi reports them (None when it cannot be asked): read OUTSIDE the
+    timed region, right behind it.  The boxes of the pool differ by up to 10 % on the same kernel, and one box drifts by
+    as much between a cold and a warm run; this is what a reader needs to tell the two from a code change."""
+    import subprocess
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(index), "--showclocks", "--showtemp", "--showpower", "--json"],
+                           capture_output=True, timeout=20, text=True)
+        d = json.loads(r.stdout[r.stdout.index("{"):])
+        card = d[sorted(d)[0]]
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(w in kl for w in ("sclk", "mclk", "fclk", "power", "junction", "memory) (c", "edge")):
+                keep[k] = v
+        return keep or None
+    except Exception:
+        return None
+
+
 def spmv_bytes(nnzb, n, bs):
     """Algorithmic bytes of one BCSR SpMV."""
     return nnzb * (8 * bs * bs + 4) + 4 * (n + 1) + 2 * 8 * bs * n
@@ -556,6 +576,7 @@ def main():
         drv.newton_step()
     barrier()
     el = time.perf_counter() - t0
+    dev_state = device_state(local_rank) if rank == 0 else None
     ls1 = sim.launch_stats()
     cs1 = sim.comm_stats()
     l1 = len(drv.log)
@@ -710,6 +731,7 @@ def main():
             "value_accepted_steps": (acc_n / acc_s) if acc_s > 0 else None,
             "accepted_newton_steps": acc_n,
             "check": check,
+            "device_state_after_timed_region": dev_state,
             "config": {"workload": "%s%s: %dx%dx%d structured eos_%s mesh%s (%d cells), BE time steps %d-%d, %s (cyclic), "
                                    "%s + %s(%dx%dx%d bricks)/%s, rtol 1e-5"
                                    % ((a.config, share) + dims + (eos, " + 1 MINC level" if minc else "", n_cells, a.lead,

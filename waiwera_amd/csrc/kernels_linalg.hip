@@ -728,21 +728,25 @@ constexpr int FIN_MAXS = 5;   // reduction slots summed together (the merged BiC
 // workgroups, finaliser f sums slice f of every slot and stores the slice sums (second-level partials, same arrival
 // protocol), and the LAST finaliser adds the slice sums in slice order, derives and posts.  k_finalize (the separate
 // launch) forms the same slice sums and adds them in the same order: identical bits either way, independent of timing.
-__host__ __device__ __forceinline__ int fin_slices(int nb) { return nb <= 1024 ? 1 : (nb + 1023) / 1024 > FIN_MAXF ? FIN_MAXF : (nb + 1023) / 1024; }
+#ifndef WAI_FIN_SLICE
+#define WAI_FIN_SLICE 1024
+#endif
+constexpr int FIN_SLICE = WAI_FIN_SLICE;
+__host__ __device__ __forceinline__ int fin_slices(int nb) { return nb <= FIN_SLICE ? 1 : (nb + FIN_SLICE - 1) / FIN_SLICE > FIN_MAXF ? FIN_MAXF : (nb + FIN_SLICE - 1) / FIN_SLICE; }
 __host__ __device__ __forceinline__ void fin_slice_range(int nb, int nf, int f, int& lo, int& hi) {
   const int per = (nb + nf - 1) / nf;
   lo = f * per; hi = lo + per < nb ? lo + per : nb;
   if (lo > nb) lo = nb;
 }
 // sums of the partials [lo, hi) of ns (<= FIN_MAXS) slots starting at p0 -> res[0 .. ns) (shared memory, valid for every
-// thread on return), by a workgroup of any size (multiple of 64).  A virtual thread's partials are fetched four at a time
-// FOR ALL SLOTS TOGETHER -- up to 20 independent agent-scope loads in flight (one dependent round trip per entry cost 2 us
+// thread on return), by a workgroup of any size (multiple of 64).  A virtual thread's partials are fetched two at a time
+// FOR ALL SLOTS TOGETHER -- up to 10 independent agent-scope loads in flight (one dependent round trip per entry cost 2 us
 // each) -- and added per slot in ascending order; an entry that has not arrived yet is polled (bounded: a partial that
 // never arrives becomes a NaN sum and breakdown code 4, KSP_DIVERGED_NANORINF, not a hung device).
 __device__ __forceinline__ void sum_slice(unsigned long long* p0, int nb_max, int lo, int hi, int ns, bool wait,
                                           double* scal, double* res) {
   __shared__ __attribute__((aligned(16))) double fsm[FIN_MAXS][16];
-  constexpr int CH = 4;
+  constexpr int CH = 2;
   const int len = hi - lo, VT = len > 256 ? 1024 : 256;
   __syncthreads();   // fsm / res of an earlier call are no longer read
   bool gave_up = false;
@@ -759,22 +763,36 @@ __device__ __forceinline__ void sum_slice(unsigned long long* p0, int nb_max, in
           const int i = i0 + k * VT;
           u[s][k] = (s < ns && i < hi) ? __hip_atomic_load(p0 + (size_t)s * nb_max + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         }
+      // entries that have not arrived: ALL of them asked for again together, once per round (a brick's five sums arrive
+      // together; polled one after the other each cost its own round trip)
+      for (int spin = 0; wait && !gave_up && spin < (1 << 22); spin++) {
+        bool any = false;
+#pragma unroll
+        for (int s = 0; s < FIN_MAXS; s++)
+#pragma unroll
+          for (int k = 0; k < CH; k++) any |= (s < ns && i0 + k * VT < hi && u[s][k] == FIN_EMPTY);
+        if (!any) break;
+        __builtin_amdgcn_s_sleep(8);
+#pragma unroll
+        for (int s = 0; s < FIN_MAXS; s++)
+#pragma unroll
+          for (int k = 0; k < CH; k++) {
+            const int i = i0 + k * VT;
+            if (s < ns && i < hi && u[s][k] == FIN_EMPTY)
+              u[s][k] = __hip_atomic_load(p0 + (size_t)s * nb_max + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+      }
 #pragma unroll
       for (int s = 0; s < FIN_MAXS; s++)
 #pragma unroll
         for (int k = 0; k < CH; k++) {
           const int i = i0 + k * VT;
           if (s < ns && i < hi) {
-            unsigned long long* ps = p0 + (size_t)s * nb_max + i;
-            for (int spin = 0; wait && !gave_up && u[s][k] == FIN_EMPTY && spin < (1 << 22); spin++) {
-              __builtin_amdgcn_s_sleep(8);
-              u[s][k] = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (u[s][k] == FIN_EMPTY) gave_up = true;   // one bounded wait per thread: a launch that lost a partial ends in seconds
-            // still empty: the producer never stored it (waited out above), or -- k_finalize, wait = false -- no producer
-            // ran before this consumer.  The sum is a NaN either way; say why (code 4 reaches the host with the post)
-            if (u[s][k] == FIN_EMPTY) scal[S_BREAK] = 4.0;
-            __hip_atomic_store(ps, FIN_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: the slot is empty again
+            // still empty: the producer never stored it (waited out above: one bounded wait per thread, a launch that lost
+            // a partial ends in seconds), or -- k_finalize, wait = false -- no producer ran before this consumer.  The sum
+            // is a NaN either way; say why (code 4 reaches the host with the post)
+            if (u[s][k] == FIN_EMPTY) { gave_up = true; scal[S_BREAK] = 4.0; }
+            __hip_atomic_store(p0 + (size_t)s * nb_max + i, FIN_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: the slot is empty again
             t[s] += __longlong_as_double((long long)u[s][k]);   // FIN_EMPTY itself is a NaN
           }
         }
@@ -845,22 +863,33 @@ __device__ __forceinline__ bool fin_block(const Fin& f, const double* partials, 
     // then adds them in slice order
     if (threadIdx.x < 64) {
       const int t = (int)threadIdx.x;
-      for (int s2 = 0; s2 < f.nslots; s2++) {
-        unsigned long long u = 0ull;
-        if (t < f.nf) {
-          unsigned long long* ps = q0 + (size_t)s2 * FIN_MAXF + t;
-          u = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          for (int spin = 0; u == FIN_EMPTY && spin < (1 << 22); spin++) {
-            __builtin_amdgcn_s_sleep(8);
-            u = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long u[FIN_MAXS];
+#pragma unroll
+      for (int s2 = 0; s2 < FIN_MAXS; s2++)   // the slots' loads in flight together (one after the other they cost a round trip each)
+        u[s2] = (s2 < f.nslots && t < f.nf) ? __hip_atomic_load(q0 + (size_t)s2 * FIN_MAXF + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      for (int spin = 0; spin < (1 << 22); spin++) {   // what has not arrived asked for again, all slots together
+        bool any = false;
+#pragma unroll
+        for (int s2 = 0; s2 < FIN_MAXS; s2++) any |= (s2 < f.nslots && t < f.nf && u[s2] == FIN_EMPTY);
+        if (!any) break;
+        __builtin_amdgcn_s_sleep(8);
+#pragma unroll
+        for (int s2 = 0; s2 < FIN_MAXS; s2++)
+          if (s2 < f.nslots && t < f.nf && u[s2] == FIN_EMPTY)
+            u[s2] = __hip_atomic_load(q0 + (size_t)s2 * FIN_MAXF + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < FIN_MAXS; s2++) {
+        if (s2 < f.nslots) {
+          if (t < f.nf) {
+            if (u[s2] == FIN_EMPTY) f.scal[S_BREAK] = 4.0;
+            __hip_atomic_store(q0 + (size_t)s2 * FIN_MAXF + t, FIN_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          if (u == FIN_EMPTY) f.scal[S_BREAK] = 4.0;
-          __hip_atomic_store(ps, FIN_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const double v = __longlong_as_double((long long)u[s2]);
+          double tot = 0.0;
+          for (int g = 0; g < f.nf; g++) tot += __shfl(v, g);
+          if (t == 0) f.scal[f.slot0 + s2] = tot;
         }
-        const double v = __longlong_as_double((long long)u);
-        double tot = 0.0;
-        for (int g = 0; g < f.nf; g++) tot += __shfl(v, g);
-        if (t == 0) f.scal[f.slot0 + s2] = tot;
       }
     }
   }
@@ -1617,7 +1646,20 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
 // the upper ones are parked in LDS as the row streams in (k_pc_park's idea) and read back from there in the
 // backward sweep; four independent bricks share a 256-thread workgroup (no __syncthreads anywhere), ~13 bricks
 // are resident per CU, and the latency of one brick's sweeps hides behind the loads of the others.
-// Serves the 8 x 4 x 2 bricks of 3 x 3 blocks and the 8 x 4 x 1 (32 + 32 rows) MINC bricks.
+// Serves the 8 x 4 x 2 bricks of 3 x 3 blocks and the 4 x 4 x 2 (32 + 32 rows) MINC bricks.
+// MEASURED and not kept (round 4, C5 = MINC bricks of 32 eight-block + 32 two-block rows):
+//  * the matrix rows' lanes, idle through six of the eight streaming rounds, taking over the trailing (upper / out-of-brick)
+//    slots of the fracture rows -- five full rounds instead of eight half-empty ones; the SpMV ALONE gains 10 % from full
+//    load instructions (tools/micro/spmv_minc_rows.hip: 64.3 -> 70.9 % of HBM peak; the holes the short rows leave in the
+//    value planes cost nothing), but this kernel does not: application without the product 0.169 -> 0.165 ms, with it
+//    0.171 -> 0.190 (141-147 VGPRs: three waves per SIMD).  A brick lives ~18 us -- column indices, blocks + gathers, ~20
+//    levels through LDS, epilogue: a chain of latencies -- and 16 are resident per CU: the launch is
+//    bricks / (16 x 256) generations of that, whatever the rounds hold (profiles/wave_help_ab_r4.log);
+//  * two bricks per workgroup instead of four (C4's bricks park 11.3 KB each: 7 x 2 = 14 per CU instead of 3 x 4 = 12; the
+//    registers allow 16): no difference at C4 (0.4995-0.5028 against 0.5018-0.5028 ms without a reduction), the finalisers'
+//    128 threads 1-2 % slower with one (profiles/wave_bpw_ab_r4.log) -- more resident bricks do not help either;
+//  * the epilogue's dot-product partners requested before the backward sweep: the epilogue 20 us shorter with five
+//    products, the rest of the kernel 2 % longer, nothing per iteration (profiles/wave_prefetch_ab_r4.log).
 template <int BS, bool SPMV, bool AX>
 __global__ __launch_bounds__(256) void k_pc_wave(
     int n, int W, int nsub, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev,
