@@ -31,6 +31,22 @@ def test_python_binding_covers_header():
     assert set(declared_symbols()) == set(lib.EXPORTED)
 
 
+def test_fortran_module_binds_every_product_entry_point():
+    """north_star's host is Fortran 2003 over iso_c_binding: whatever the product header declares has a bind(c) interface
+    in waiwera_amd/fortran/waiwera_hip_module.F90 (the amdflang host of tests/test_hip_fortran.py compiles it)."""
+    text = open(os.path.join(ROOT, "waiwera_amd", "fortran", "waiwera_hip_module.F90")).read()
+    bound = set(re.findall(r'bind\(c,\s*name\s*=\s*"(wai_[a-z_0-9]+)"\)', text))
+    missing = sorted(set(declared_symbols(("waiwera_hip.h",))) - bound)
+    assert not missing, missing
+    public = set(re.findall(r"\b(wai_[a-z_0-9]+)\b", " ".join(ln for ln in re.sub(r"&\s*\n", " ", text).splitlines()
+                                                               if ln.strip().startswith("public ::"))))
+    private = {"wai_ctx_create", "wai_ctx_destroy"}   # behind hip_flow_simulation_type%init / %destroy
+    hidden = sorted(b for b in bound - public - private if not re.search(r"procedure.*hip_sim", b))
+    # an interface that is neither public nor wrapped by a type-bound procedure is unreachable for a host
+    wrapped = set(re.findall(r"=\s*(wai_[a-z_0-9]+)\(", text)) | set(re.findall(r"call\s+(wai_[a-z_0-9]+)\(", text))
+    assert not [h for h in hidden if h not in wrapped], [h for h in hidden if h not in wrapped]
+
+
 def test_bench_entry_points_are_not_in_the_product_header():
     product = set(declared_symbols(("waiwera_hip.h",)))
     assert not [s for s in product if re.match(r"wai_(bench_|profile_|timer_|launch_stats|comm_stats)", s)], product

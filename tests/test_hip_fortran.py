@@ -35,4 +35,26 @@ def test_fortran_driver_matches_python_host(tmp_path):
     assert tn == sum(h[2] for h in ts.history)
     assert np.array_equal(rf, sim.regions())
     assert np.abs(yf - y[: yf.size]).max() <= 1e-12 * np.abs(y).max()
+    # the driver's surface_check: the entry points beside the callback order, through their bind(c) interfaces,
+    # on the state the four steps left -- the Python host (ctypes on the same library) must see the same
+    chk = {ln.split()[1]: ln.split()[2:] for ln in res.stdout.splitlines() if ln.startswith("check ")}
+    from waiwera_amd import lib as _lib
+    assert [int(v) for v in chk["sizes"]] == [sim.num_primary_variables, sim.fluid_dof, _lib.LIB.wai_num_flux_dof(sim.h), 1]
+    assert " ".join(chk["kernel"]) == sim.pc_kernel_name()
+    fl = sim.fluid(0)
+    assert int(chk["fluid"][0]) == 0
+    assert abs(float(chk["fluid"][1]) - fl[0, 0]) <= 1e-12 * abs(fl[0, 0])
+    assert abs(float(chk["fluid"][2]) - fl[: lm.n_owned, 0].mean()) <= 1e-12 * fl[0, 0]
+    n = lm.n_prim * lm.n_owned
+    x = 1.0 + 1.0e-3 * (np.arange(1, n + 1) % 7)
+    ax, z = np.zeros(n), np.zeros(n)
+    sim.spmv(x, ax)
+    assert int(chk["spmv"][0]) == 0 and abs(float(chk["spmv"][1]) - np.linalg.norm(ax)) <= 1e-12 * np.linalg.norm(ax)
+    sim.pc_setup()
+    sim.pc_apply(ax, z)
+    assert int(chk["pc"][0]) == 0 and abs(float(chk["pc"][1]) - np.linalg.norm(z)) <= 1e-10 * np.linalg.norm(z)
+    val, idx = sim.max_scaled(ax, np.ones(n), 0.0)
+    assert int(chk["max"][0]) == 0 and abs(float(chk["max"][1]) - val) <= 1e-13 * abs(val) and int(chk["max"][2]) == idx
+    assert int(chk["error"][0]) < 0 and "curve table" in " ".join(chk["error"][1:])   # the library's text reached Fortran
+    assert [int(v) for v in chk["comm"]] == [0, 0, 1]
     sim.destroy()

@@ -99,6 +99,7 @@ program newton_driver
      dt = dt * 2._dp
   end do
 
+  call surface_check()
   ierr = wai_get_regions(sim%ctx, region)
   open(newunit = u, file = trim(outfile), access = 'stream', form = 'unformatted', status = 'replace')
   write(u) int(total_newton, c_int), int(total_ksp, c_int)
@@ -107,5 +108,64 @@ program newton_driver
   close(u)
   write(*, '(a,i6,a,i8)') 'total newton ', total_newton, ' total krylov ', total_ksp
   call sim%destroy()
+
+contains
+
+  subroutine surface_check()
+    !! The entry points a host needs beside the callback order, through their Fortran interfaces: sizes, the
+    !! reference-layout fluid vector, the operator, the preconditioner, the error text, a one-rank communicator.
+    !! tests/test_hip_fortran.py compares every "check" line with the Python host on the same state.
+    real(c_double), allocatable :: fluid(:), x(:), ax(:), z(:), ones(:), xy(:)
+    character(kind = c_char) :: id(128)
+    real(c_double) :: val
+    integer(c_int) :: idx, rc
+    integer :: df, i
+    df = wai_num_fluid_dof(sim%ctx)
+    write(*, '(a,4i6)') 'check sizes ', wai_block_size(sim%ctx), df, wai_num_flux_dof(sim%ctx), wai_comm_size(sim%ctx)
+    write(*, '(a,a)') 'check kernel ', c_string(wai_pc_kernel_name(sim%ctx))
+    allocate(fluid(df * n_local), x(np * n_owned), ax(np * n_owned), z(np * n_owned), ones(np * n_owned))
+    rc = wai_get_fluid(sim%ctx, 0_c_int, fluid)
+    write(*, '(a,i3,2es24.16)') 'check fluid ', rc, fluid(1), sum(fluid(1:df * n_owned:df)) / n_owned   ! pressure: first field
+    do i = 1, np * n_owned
+       x(i) = 1._dp + 1.e-3_dp * mod(i, 7)
+    end do
+    ones = 1._dp
+    rc = wai_spmv(sim%ctx, x, ax)
+    write(*, '(a,i3,es24.16)') 'check spmv ', rc, sqrt(sum(ax * ax))
+    rc = wai_pc_setup(sim%ctx)
+    rc = wai_pc_apply(sim%ctx, ax, z)
+    write(*, '(a,i3,es24.16)') 'check pc ', rc, sqrt(sum(z * z))
+    rc = wai_max_scaled(sim%ctx, ax, ones, 0._c_double, val, idx)
+    write(*, '(a,i3,es24.16,i8)') 'check max ', rc, val, idx
+    rc = wai_synchronize(sim%ctx)
+    ! an argument the library refuses: more than 12 points in a curve table
+    allocate(xy(2 * 13))
+    xy = 0._dp
+    rc = wai_set_curve_table(sim%ctx, 0_c_int, 0_c_int, 13_c_int, xy)
+    write(*, '(a,i4,a,a)') 'check error ', rc, ' ', sim%last_error()
+    ! a communicator of one rank (what PETSC_COMM_WORLD's size-1 run is to the reference)
+    rc = wai_comm_unique_id(id)
+    call sim%init_comm(0, 1, id, err)
+    write(*, '(a,2i4,i6)') 'check comm ', rc, err, wai_comm_size(sim%ctx)
+  end subroutine surface_check
+
+  function c_string(p) result(str)
+    type(c_ptr), intent(in) :: p
+    character(len = :), allocatable :: str
+    character(kind = c_char), pointer :: s(:)
+    integer :: n, i
+    str = ""
+    if (.not. c_associated(p)) return
+    call c_f_pointer(p, s, [256])
+    n = 0
+    do while (n < 256)
+       if (s(n + 1) == c_null_char) exit
+       n = n + 1
+    end do
+    allocate(character(len = n) :: str)
+    do i = 1, n
+       str(i:i) = s(i)
+    end do
+  end function c_string
 
 end program newton_driver

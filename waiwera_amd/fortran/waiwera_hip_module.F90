@@ -343,6 +343,150 @@ module waiwera_hip_module
        real(c_double), intent(in out) :: y(*)
        integer(c_int), intent(out) :: newton_its, ksp_its, reason
      end function wai_timestep
+     ! ---- the rest of include/waiwera_hip.h (tests/test_abi.py keeps this list complete) ----
+     ! text of the last error of a context (a C string: hip_sim_last_error converts it)
+     type(c_ptr) function wai_last_error(ctx) bind(c, name = "wai_last_error")
+       import :: c_ptr
+       type(c_ptr), value :: ctx
+     end function wai_last_error
+     ! kernel / path of a preconditioned-operator application, for reports (a C string)
+     type(c_ptr) function wai_pc_kernel_name(ctx) bind(c, name = "wai_pc_kernel_name")
+       import :: c_ptr
+       type(c_ptr), value :: ctx
+     end function wai_pc_kernel_name
+     integer(c_int) function wai_set_opts(ctx, opts) bind(c, name = "wai_set_opts")
+       import :: c_int, c_ptr, wai_solver_opts
+       type(c_ptr), value :: ctx
+       type(wai_solver_opts), intent(in) :: opts
+     end function wai_set_opts
+     ! "table" curves (relative_permeability.F90:123-132,500-558; capillary_pressure.F90:88-96,311-358):
+     ! which 0 / 1 / 2 = liquid, vapour relative permeability, capillary pressure; xy(2, n), n <= 12
+     integer(c_int) function wai_set_curve_table(ctx, which, interpolation, n, xy) bind(c, name = "wai_set_curve_table")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: which, interpolation, n
+       real(c_double), intent(in) :: xy(*)
+     end function wai_set_curve_table
+     integer(c_int) function wai_block_size(ctx) bind(c, name = "wai_block_size")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function wai_block_size
+     integer(c_int) function wai_num_fluid_dof(ctx) bind(c, name = "wai_num_fluid_dof")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function wai_num_fluid_dof
+     integer(c_int) function wai_num_flux_dof(ctx) bind(c, name = "wai_num_flux_dof")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function wai_num_flux_dof
+     ! fluid vector in the reference's layout, wai_num_fluid_dof doubles per local cell; which 0 fluid,
+     ! 1 last_iteration_fluid, 2 last_timestep_fluid (flow_simulation.F90:53-56)
+     integer(c_int) function wai_get_fluid(ctx, which, out) bind(c, name = "wai_get_fluid")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: which
+       real(c_double), intent(out) :: out(*)
+     end function wai_get_fluid
+     ! the reference's flux vector (flow_simulation.F90:156-205): n_faces * wai_num_flux_dof doubles
+     integer(c_int) function wai_get_fluxes(ctx, out) bind(c, name = "wai_get_fluxes")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: out(*)
+     end function wai_get_fluxes
+     ! separated flows of every source: water rate, water enthalpy, steam rate, steam enthalpy (separator.F90:212-260)
+     integer(c_int) function wai_get_source_separated(ctx, out4) bind(c, name = "wai_get_source_separated")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: out4(*)
+     end function wai_get_source_separated
+     ! partition ghost exchange over RCCL (DMGlobalToLocal, dm_utils.F90:480-498): zero-based cell indices and offsets
+     integer(c_int) function wai_set_halo(ctx, n_nbr, nbr_rank, send_ptr, send_idx, recv_ptr) bind(c, name = "wai_set_halo")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n_nbr
+       integer(c_int), intent(in) :: nbr_rank(*), send_ptr(*), send_idx(*), recv_ptr(*)
+     end function wai_set_halo
+     ! rank 0 makes the id (128 bytes), the host broadcasts it (MPI_Bcast), every rank joins
+     integer(c_int) function wai_comm_unique_id(id) bind(c, name = "wai_comm_unique_id")
+       import :: c_int, c_char
+       character(kind = c_char), intent(out) :: id(128)
+     end function wai_comm_unique_id
+     integer(c_int) function wai_comm_init(ctx, rank, nranks, id) bind(c, name = "wai_comm_init")
+       import :: c_int, c_ptr, c_char
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: rank, nranks
+       character(kind = c_char), intent(in) :: id(128)
+     end function wai_comm_init
+     integer(c_int) function wai_comm_size(ctx) bind(c, name = "wai_comm_size")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function wai_comm_size
+     ! vec: dof * (n_owned + n_halo) doubles on the host; the halo part is filled
+     integer(c_int) function wai_halo_exchange(ctx, vec, dof) bind(c, name = "wai_halo_exchange")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in out) :: vec(*)
+       integer(c_int), value :: dof
+     end function wai_halo_exchange
+     integer(c_int) function wai_jacobian_set_values(ctx, val) bind(c, name = "wai_jacobian_set_values")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: val(*)
+     end function wai_jacobian_set_values
+     ! MatMult: y = J x (x haloed internally)
+     integer(c_int) function wai_spmv(ctx, x, y) bind(c, name = "wai_spmv")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: x(*)
+       real(c_double), intent(out) :: y(*)
+     end function wai_spmv
+     ! PCSetUp / PCApply (timestepper.F90:1668-1669,1745-1757,1789-1834)
+     integer(c_int) function wai_pc_setup(ctx) bind(c, name = "wai_pc_setup")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function wai_pc_setup
+     integer(c_int) function wai_pc_apply(ctx, r, z) bind(c, name = "wai_pc_apply")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: r(*)
+       real(c_double), intent(out) :: z(*)
+     end function wai_pc_apply
+     ! vec_max_pointwise_abs_scale (dm_utils.F90:644-685); idx is zero-based
+     integer(c_int) function wai_max_scaled(ctx, v, scale, tol, val, idx) bind(c, name = "wai_max_scaled")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: v(*), scale(*)
+       real(c_double), value :: tol
+       real(c_double), intent(out) :: val
+       integer(c_int), intent(out) :: idx
+     end function wai_max_scaled
+     ! the system wai_tracer_solve would solve for one tracer: scalar CSR values on wai_jacobian_pattern's pattern
+     ! (nnzb doubles) and the right-hand side (n_owned)
+     integer(c_int) function wai_tracer_system(ctx, tracer, method, dt, ratio, alx_last, alx_last2, val, b) &
+          bind(c, name = "wai_tracer_system")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: tracer, method
+       real(c_double), value :: dt, ratio
+       real(c_double), intent(in) :: alx_last(*), alx_last2(*)
+       real(c_double), intent(out) :: val(*), b(*)
+     end function wai_tracer_system
+     integer(c_int) function wai_synchronize(ctx) bind(c, name = "wai_synchronize")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function wai_synchronize
+     ! the network pass on given source rates / enthalpies, host logic only (no context, no device): the flat
+     ! description of wai_set_source_network; c_loc of the arrays, or c_null_ptr for an absent part
+     integer(c_int) function wai_network_evaluate(n_sources, rate, enthalpy, src_sep, rate_specified, enthalpy_specified, &
+          n_groups, grp_ptr, grp_in_kind, grp_in, grp_scaling, grp_limit_type, grp_limit, grp_sep, n_reinjectors, &
+          rj_in_kind, rj_in, rj_out_ptr, out_flow, out_kind, out_node, out_rate, out_proportion, out_enthalpy, &
+          rj_overflow_kind, rj_overflow, sources_out, groups_out, reinjectors_out) bind(c, name = "wai_network_evaluate")
+       import :: c_int, c_ptr
+       integer(c_int), value :: n_sources, n_groups, n_reinjectors
+       type(c_ptr), value :: rate, enthalpy, src_sep, rate_specified, enthalpy_specified, grp_ptr, grp_in_kind, grp_in, &
+            grp_scaling, grp_limit_type, grp_limit, grp_sep, rj_in_kind, rj_in, rj_out_ptr, out_flow, out_kind, out_node, &
+            out_rate, out_proportion, out_enthalpy, rj_overflow_kind, rj_overflow, sources_out, groups_out, reinjectors_out
+     end function wai_network_evaluate
   end interface
 
   integer, parameter, public :: WAI_METHOD_BEULER = 0, WAI_METHOD_BDF2 = 1, WAI_METHOD_DIRECTSS = 2
@@ -375,8 +519,14 @@ module waiwera_hip_module
      procedure, public :: ksp_solve => hip_sim_ksp_solve
      procedure, public :: newton_step => hip_sim_newton_step
      procedure, public :: timestep => hip_sim_timestep
+     procedure, public :: last_error => hip_sim_last_error
+     procedure, public :: init_comm => hip_sim_init_comm
   end type hip_flow_simulation_type
 
+  public :: wai_last_error, wai_pc_kernel_name, wai_set_opts, wai_set_curve_table, wai_block_size, wai_num_fluid_dof, &
+       wai_num_flux_dof, wai_get_fluid, wai_get_fluxes, wai_get_source_separated, wai_set_halo, wai_comm_unique_id, &
+       wai_comm_init, wai_comm_size, wai_halo_exchange, wai_jacobian_set_values, wai_spmv, wai_pc_setup, wai_pc_apply, &
+       wai_max_scaled, wai_tracer_system, wai_synchronize, wai_network_evaluate
   public :: wai_set_tracers, wai_set_tracer_bc, wai_set_tracer_injection, wai_set_aux_solver
   public :: wai_set_source_network, wai_get_source_network, wai_set_network_couplings, wai_get_network_couplings
   public :: wai_set_source_global_index, wai_launch_stats, wai_update_rock, wai_network_cells
@@ -394,15 +544,45 @@ contains
     integer, intent(out) :: err
     err = wai_ctx_create(mesh, eos, opts, int(device, c_int), self%ctx)
     self%num_cells = mesh%n_owned
-    select case (eos%kind)
-    case (WAI_EOS_W)
-       self%num_primary_variables = 1
-    case (WAI_EOS_WE)
-       self%num_primary_variables = 2
-    case default
-       self%num_primary_variables = 3
-    end select
+    if (err == 0) then
+       self%num_primary_variables = wai_block_size(self%ctx)   ! 1 (w) .. 4 (the salt EOS with a gas)
+    else
+       self%num_primary_variables = 0
+    end if
   end subroutine hip_sim_init
+
+  function hip_sim_last_error(self) result(msg)
+    !! Text of the context's last error (the library keeps it as a C string).
+    class(hip_flow_simulation_type), intent(in) :: self
+    character(len = :), allocatable :: msg
+    type(c_ptr) :: p
+    character(kind = c_char), pointer :: s(:)
+    integer :: n, i
+    msg = ""
+    if (.not. c_associated(self%ctx)) return
+    p = wai_last_error(self%ctx)
+    if (.not. c_associated(p)) return
+    call c_f_pointer(p, s, [4096])
+    n = 0
+    do while (n < 4096)
+       if (s(n + 1) == c_null_char) exit
+       n = n + 1
+    end do
+    allocate(character(len = n) :: msg)
+    do i = 1, n
+       msg(i:i) = s(i)
+    end do
+  end function hip_sim_last_error
+
+  subroutine hip_sim_init_comm(self, rank, nranks, id, err)
+    !! Joins the RCCL communicator of the run: id from wai_comm_unique_id on rank 0, broadcast by the
+    !! host's MPI (the reference's PETSC_COMM_WORLD takes that part); then wai_set_halo with the ghost lists.
+    class(hip_flow_simulation_type), intent(in out) :: self
+    integer, intent(in) :: rank, nranks
+    character(kind = c_char), intent(in) :: id(128)
+    integer, intent(out) :: err
+    err = wai_comm_init(self%ctx, int(rank, c_int), int(nranks, c_int), id)
+  end subroutine hip_sim_init_comm
 
   subroutine hip_sim_destroy(self)
     class(hip_flow_simulation_type), intent(in out) :: self
