@@ -1503,7 +1503,7 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
   const double nalpha = AX ? -scal[S_ALPHA] : 0.0;   // input = in - alpha in2
   PH_DECL;
   // component-major over the R1 leading (long) rows, then component-major over the short ones
-  const int R1 = sub_split ? sub_split[s] : R;
+  const int R1 = sub_split ? (sub_split[s] & 0xffff) : R;
   const bool shortrow = tid >= R1 * BS;
   const int tt = shortrow ? tid - R1 * BS : tid, RR = shortrow ? max(R - R1, 1) : R1;
   const int r = min(tt / RR, BS - 1), il = (shortrow ? R1 : 0) + tt - (tt / RR) * RR, i = lo + il;
@@ -1666,7 +1666,7 @@ __global__ __launch_bounds__(256) void k_pc_wave(
     const int* __restrict__ row_info, const int* __restrict__ row_uoffw, const int* __restrict__ col,
     const double* __restrict__ sval, const double* __restrict__ dinv, const double* __restrict__ in,
     const double* __restrict__ in2, const double* __restrict__ scal, double* __restrict__ z, const double* __restrict__ aux, double* partials, int nb_max, int dot,
-    const int* __restrict__ sub_list, const int* __restrict__ rowptr, int lds_per_brick, Fin fin, Stagger stagger) {
+    const int* __restrict__ sub_list, const int* __restrict__ rowptr, const int* __restrict__ sub_split, int lds_per_brick, Fin fin, Stagger stagger) {
   constexpr int BB = BS * BS, NL = 3, NU = 4;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   if (fin_block(fin, partials, nb_max)) return;
@@ -1680,6 +1680,7 @@ __global__ __launch_bounds__(256) void k_pc_wave(
   if (sub_list) s = sub_list[s];
   const int lo = sub_ptr[s], R = sub_ptr[s + 1] - lo;
   const int nl = sub_nlev[s];
+  const int spl = sub_split ? sub_split[s] : 0;   // (with the brick's other scalars: no round trip of its own)
   const int nlf = nl & 0xffff, nlb = nl >> 16;
   const int i = lo + lane;
   const bool active = lane < R;
@@ -1700,7 +1701,11 @@ __global__ __launch_bounds__(256) void k_pc_wave(
     unpack_info(row_info[i], lfirst, dslot, ulast, lf, lb);
     uo = row_uoffw[i];
     nU = ulast - dslot - 1;
-    const int cnt = rowptr ? rowptr[i + 1] - rowptr[i] : W;
+    // slots to stream: all W on uniform rows; with short rows (MINC matrix cells) the brick's record tells -- the long
+    // rows first, all W slots each (padding = a zero block on the own column), then the short ones -- unless the brick
+    // mixes them (15): then, and without a record, the row pointers do, one dependent round trip before the first block
+    int cnt = W;
+    if (rowptr) cnt = (sub_split && (spl >> 16) != 15) ? (lane < (spl & 0xffff) ? W : (spl >> 16)) : rowptr[i + 1] - rowptr[i];
     int cgs[WMAX];
 #pragma unroll
     for (int q = 0; q < WMAX; q++) {
@@ -2446,7 +2451,7 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
       const int* rp = (size_t)J.nnzb * 10 < (size_t)J.n * J.W * 9 ? J.rowptr : nullptr;   // > 10 % padding
 #define PCW(SP, AXV)                                                                                \
       hipLaunchKernelGGL((k_pc_wave<BS, SP, AXV>), gridw, 256, lds_w, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev, s.row_info, \
-                         s.row_uoffw, J.col, s.fval, s.dinv, in, in2, scal, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, list, rp, per, fin, stagger)
+                         s.row_uoffw, J.col, s.fval, s.dinv, in, in2, scal, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, list, rp, (getenv("WAI_WAVE_ROWPTR") ? nullptr : s.sub_split), per, fin, stagger)
       Stagger stagger;
       stagger.ncu = c->n_cu;
       stagger.per_cu = std::max(1, (int)((size_t)160 * 1024 / (lds_w + 704)));

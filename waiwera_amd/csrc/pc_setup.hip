@@ -233,6 +233,14 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
       for (int i = r1; i < hi && sorted; i++) sorted = (rowptr[i + 1] - rowptr[i]) * 2 <= W;
       split[sd] = (sorted && r1 > lo) ? r1 - lo : hi - lo;
       any = any || split[sd] != hi - lo;
+      // bits 16+: the most blocks a short row of the brick has, or 15 where short rows are mixed among the long ones.
+      // k_pc_wave then knows a row's slot count from the brick's record -- long rows take all W slots (a missing
+      // neighbour's padding: a zero block on the own column) -- instead of waiting for rowptr before its first block load
+      int short_cnt = 0;
+      for (int i = r1; i < hi; i++) short_cnt = std::max(short_cnt, rowptr[i + 1] - rowptr[i]);
+      bool mixed = false;
+      for (int i = lo; i < hi && !mixed; i++) mixed = (i < r1) != ((rowptr[i + 1] - rowptr[i]) * 2 > W);
+      split[sd] |= (mixed || !sorted ? 15 : short_cnt) << 16;
     }
     if (any && dev_upload(c, &s.sub_split, split)) return -1;
   }
