@@ -1658,6 +1658,15 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
 //  * two bricks per workgroup instead of four (C4's bricks park 11.3 KB each: 7 x 2 = 14 per CU instead of 3 x 4 = 12; the
 //    registers allow 16): no difference at C4 (0.4995-0.5028 against 0.5018-0.5028 ms without a reduction), the finalisers'
 //    128 threads 1-2 % slower with one (profiles/wave_bpw_ab_r4.log) -- more resident bricks do not help either;
+//  * the slots' loads overlapped.  In the slot loop below every slot sits behind its own `q < cnt` branch and the compiler
+//    ends each with s_waitcnt vmcnt(0): W dependent round trips per brick with ~11 loads in flight per lane.  A variant for
+//    rows of exactly seven slots, known at compile time (C4), has no branch between the slots; unfenced, all 77 loads of a
+//    row are requested up front: 193-233 VGPRs, two waves per SIMD, fused launch 0.574 against 0.500 ms at C4 -- but the
+//    application WITHOUT the product (151 VGPRs, three waves per SIMD = what the LDS allows anyway) 0.528 against 0.549.
+//    Holding the product variant to two or three slots in flight (the streams are read-only __restrict__ data that no
+//    compiler barrier holds back; the next request's offset made to depend on the consumed slot's sum through an empty
+//    asm does) bounds the loads but not the registers: the lower-coupling selects and the gathers are then put off to the
+//    end of the row and keep all seven blocks alive (195-251 VGPRs).  Not kept (profiles/wave_pipe_ab_r4.log);
 //  * the epilogue's dot-product partners requested before the backward sweep: the epilogue 20 us shorter with five
 //    products, the rest of the kernel 2 % longer, nothing per iteration (profiles/wave_prefetch_ab_r4.log).
 template <int BS, bool SPMV, bool AX>
