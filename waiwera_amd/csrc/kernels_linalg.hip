@@ -202,7 +202,12 @@ __device__ __forceinline__ void load_x_stream(const double* __restrict__ x, int 
   }
 }
 
-// acc += A_row(i) * x over the W slots of block row i
+// acc += A_row(i) * x over the W slots of block row i.
+// Every slot sits behind its own `s < W` branch, and the compiler ends each with s_waitcnt vmcnt(0): a row's slots are
+// streamed one after the other.  MEASURED (round 4, profiles/spmv_w7_ab_r4.log): a branch-free loop for W = 7, where all
+// of a row's blocks and gathers are requested before the first is used, is SLOWER -- 0.480-0.484 against 0.438-0.464 ms
+// at 216^3 (2 x 2 blocks), 0.565-0.575 against 0.496-0.510 at C4 (3 x 3) -- one slot's element planes at a time are 4 or
+// 9 concurrent streams through the memory channels, all seven slots' 28 or 63.
 template <int BS>
 __device__ __forceinline__ void ell_row_mult(int n, int W, int i, const int* __restrict__ col,
                                              const double* __restrict__ val,
