@@ -111,9 +111,10 @@ void wai_default_opts(wai_solver_opts *o);
 /* flow_simulation_init (src/flow_simulation.F90:882-1045) for the parts the path needs */
 int wai_ctx_create(const wai_mesh_desc *mesh, const wai_eos_desc *eos,
                    const wai_solver_opts *opts, int device, wai_ctx **out);
-int wai_ctx_destroy(wai_ctx *ctx);
-const char *wai_last_error(wai_ctx *ctx);
-int wai_set_opts(wai_ctx *ctx, const wai_solver_opts *opts);
+int wai_ctx_destroy(wai_ctx *ctx);                                 /* flow_simulation_destroy, src/flow_simulation.F90:1049-1098 */
+const char *wai_last_error(wai_ctx *ctx);                          /* text for the reference's logfile (src/logfile.F90) after a call returned < 0 */
+int wai_set_opts(wai_ctx *ctx, const wai_solver_opts *opts);       /* the "time.step.solver" block read again: timestepper_configure_linear_solver,
+                                                                      src/timestepper.F90:1645-1836; nonlinear tolerances :2002-2260 */
 
 /* "table" curves (relative_permeability_table_type, src/relative_permeability.F90:123-132,500-558;
  * capillary_pressure_table_type, src/capillary_pressure.F90:88-96,311-358): which 0 liquid relative
