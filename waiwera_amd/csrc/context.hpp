@@ -11,9 +11,29 @@ namespace wai {
 
 // Element (s, r, k) of block row i in a block-ELL value array of n block rows (layout rationale:
 // kernels_linalg.hip, "Matrix entry addressing").  WAI_ELL_ROWS builds the block-row layout for every bs.
+// The stride between the element planes of block sizes >= 3 is not n but n rounded up to 512 doubles (4 KB), and never a
+// multiple of 2 MB: how a slot's nine planes fall onto the memory channels depends on it.  MEASURED (C4's SpMV alone,
+// tools/micro/spmv3_stride.hip, nine strides x three fresh allocations on one box): stride n = 5 029 280 doubles
+// 71.8-72.3 % of HBM peak, a multiple of 2 MB 70.0-72.9 %, 4-KB multiples with 0-132 KB added 71.4-78.2 % (mean 75 %).
+// Every array indexed through ell_ix with bs >= 3 is allocated with ell_rows(bs, n) rows (-DWAI_ELL_NO_PAD: stride n).
+__host__ __device__ __forceinline__ size_t ell_ld(size_t n) {
+#ifdef WAI_ELL_NO_PAD
+  return n;
+#else
+  size_t ld = (n + 511) & ~(size_t)511;
+  if ((ld & 262143) == 0) ld += 512;
+  return ld;
+#endif
+}
+__host__ __device__ __forceinline__ size_t ell_rows(int bs, size_t n) {
+#ifndef WAI_ELL_ROWS
+  if (bs >= 3) return ell_ld(n);
+#endif
+  return n;
+}
 __host__ __device__ __forceinline__ size_t ell_ix(int bs, size_t n, int s, int r, int k, size_t i) {
 #ifndef WAI_ELL_ROWS
-  if (bs >= 3) return ((size_t)((s * bs + r) * bs + k)) * n + i;
+  if (bs >= 3) return ((size_t)((s * bs + r) * bs + k)) * ell_ld(n) + i;
 #endif
   return ((size_t)(s * bs + r) * n + i) * bs + k;
 }

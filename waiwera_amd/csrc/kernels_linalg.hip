@@ -2323,7 +2323,7 @@ static inline int pc_threads(const IluSchedule& s) { return ((s.max_rows + 63) /
 int launch_ilu_factor_on(wai_ctx* c, const Bcsr& J, IluSchedule& s) {
   if (s.big) {
     // one launch per forward level; the factor starts as a copy of the matrix
-    hipMemcpyAsync(s.fval, J.val, sizeof(double) * (size_t)J.W * J.bs * J.bs * J.n, hipMemcpyDeviceToDevice, c->stream);
+    hipMemcpyAsync(s.fval, J.val, sizeof(double) * (size_t)J.W * J.bs * J.bs * ell_rows(J.bs, J.n), hipMemcpyDeviceToDevice, c->stream);
     for (int lev = 0; lev < s.nlev_f; lev++) {
       const int a = s.lev_f_ptr[lev], cnt = s.lev_f_ptr[lev + 1] - a, g = (cnt + TPB - 1) / TPB;
       if (cnt <= 0) continue;
@@ -2373,7 +2373,7 @@ int launch_ilu_factor_on(wai_ctx* c, const Bcsr& J, IluSchedule& s) {
       default: return -1;
     }
   } else {
-    hipMemcpyAsync(s.fval, J.val, sizeof(double) * (size_t)J.W * J.bs * J.bs * J.n, hipMemcpyDeviceToDevice, c->stream);
+    hipMemcpyAsync(s.fval, J.val, sizeof(double) * (size_t)J.W * J.bs * J.bs * ell_rows(J.bs, J.n), hipMemcpyDeviceToDevice, c->stream);
     switch (J.bs) {
       case 1: hipLaunchKernelGGL(k_ilu_factor<1>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
       case 2: hipLaunchKernelGGL(k_ilu_factor<2>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
