@@ -10,14 +10,17 @@
 #include <vector>
 constexpr int W = 7;
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
-template <bool SLICED>
+//   slot-sliced val[s*9*n + ((i/64)*9 + e)*64 + i%64]             (a wave's nine element loads of ONE slot are one 4.6-KB run; seven
+//                                                                   slot streams instead of 63 plane streams; needs no slot count)
+template <int SLICED>
 __device__ __forceinline__ size_t vx(size_t n, int s, int e, size_t i) {
+  if (SLICED == 2) return (size_t)s * 9 * n + ((i >> 6) * 9 + (size_t)e) * 64 + (i & 63);
   return SLICED ? ((i >> 6) * (W * 9) + (size_t)(s * 9 + e)) * 64 + (i & 63) : (size_t)(s * 9 + e) * n + i;
 }
 // XS: doubles per cell in the vectors -- 3 (the library's packed block Vec) or 4 (padded: a cell's three components in one
 // aligned 32-byte sector, fetched as an aligned dwordx4 + dwordx2)
 typedef double d2a __attribute__((ext_vector_type(2)));
-template <bool SLICED, bool GATHER, bool COLS, int XS = 3>
+template <int SLICED, bool GATHER, bool COLS, int XS = 3>
 __global__ __launch_bounds__(256) void k_spmv3(int n, const int* __restrict__ col, const double* __restrict__ val,
                                                const double* __restrict__ x, double* __restrict__ y) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -87,13 +90,14 @@ int main(int argc, char** argv) {
   };
   const int g = (n + 255) / 256;
 #define RUN(S, G, C, name) run(name, [&] { hipLaunchKernelGGL((k_spmv3<S, G, C>), g, 256, 0, 0, n, dcol, val, x, y); })
-  RUN(false, true, true, "planes, gathers, columns (library)");
-  run("planes, gathers, columns, PADDED x / y (4)", [&] { hipLaunchKernelGGL((k_spmv3<false, true, true, 4>), g, 256, 0, 0, n, dcol, val, x, y); });
-  run("planes, no gathers, columns, padded x / y", [&] { hipLaunchKernelGGL((k_spmv3<false, false, true, 4>), g, 256, 0, 0, n, dcol, val, x, y); });
-  RUN(true, true, true, "sliced64, gathers, columns");
-  RUN(false, false, true, "planes, own-row x, columns");
-  RUN(true, false, true, "sliced64, own-row x, columns");
-  RUN(false, false, false, "planes, own-row x, no columns");
-  RUN(true, false, false, "sliced64, own-row x, no columns");
+  RUN(0, true, true, "planes, gathers, columns (library)");
+  run("planes, gathers, columns, PADDED x / y (4)", [&] { hipLaunchKernelGGL((k_spmv3<0, true, true, 4>), g, 256, 0, 0, n, dcol, val, x, y); });
+  run("planes, no gathers, columns, padded x / y", [&] { hipLaunchKernelGGL((k_spmv3<0, false, true, 4>), g, 256, 0, 0, n, dcol, val, x, y); });
+  RUN(1, true, true, "sliced64, gathers, columns");
+  RUN(2, true, true, "slot-sliced, gathers, columns");
+  RUN(0, false, true, "planes, own-row x, columns");
+  RUN(1, false, true, "sliced64, own-row x, columns");
+  RUN(0, false, false, "planes, own-row x, no columns");
+  RUN(1, false, false, "sliced64, own-row x, no columns");
   return 0;
 }

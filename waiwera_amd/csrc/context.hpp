@@ -16,6 +16,9 @@ namespace wai {
 // tools/micro/spmv3_stride.hip, nine strides x three fresh allocations on one box): stride n = 5 029 280 doubles
 // 71.8-72.3 % of HBM peak, a multiple of 2 MB 70.0-72.9 %, 4-KB multiples with 0-132 KB added 71.4-78.2 % (mean 75 %).
 // Every array indexed through ell_ix with bs >= 3 is allocated with ell_rows(bs, n) rows (-DWAI_ELL_NO_PAD: stride n).
+#if defined(WAI_ELL_NO_PAD) && !defined(WAI_ELL_PLANES)
+#define WAI_ELL_PLANES   // the 64-row groups inside a slot need a stride that is a multiple of 64
+#endif
 __host__ __device__ __forceinline__ size_t ell_ld(size_t n) {
 #ifdef WAI_ELL_NO_PAD
   return n;
@@ -31,9 +34,22 @@ __host__ __device__ __forceinline__ size_t ell_rows(int bs, size_t n) {
 #endif
   return n;
 }
+// Block sizes >= 3, inside a slot: the bs^2 elements of 64 consecutive block rows together -- element e of rows
+// 64 g .. 64 g + 63 at ((g bs^2 + e) 64 + row % 64) of the slot's bs^2 ld doubles -- so that the nine (sixteen) loads a wave
+// makes for one slot are ONE run of 4.6 (8) KB and a slot is one stream instead of nine planes 40 MB apart.  MEASURED on
+// the SpMV alone (tools/micro/spmv3_variants.hip, C4's mesh, six processes): 74.8-75.0 % of HBM peak against the planes'
+// 72.4-72.7 % (82.0 against 80.1 % in the two processes that landed well); slices over ALL slots (SELL-64: 75.9 / 83.0 %)
+// would need the slot count in here.  -DWAI_ELL_PLANES builds one plane per element.
 __host__ __device__ __forceinline__ size_t ell_ix(int bs, size_t n, int s, int r, int k, size_t i) {
 #ifndef WAI_ELL_ROWS
-  if (bs >= 3) return ((size_t)((s * bs + r) * bs + k)) * ell_ld(n) + i;
+  if (bs >= 3) {
+#ifdef WAI_ELL_PLANES
+    return ((size_t)((s * bs + r) * bs + k)) * ell_ld(n) + i;
+#else
+    const size_t bb = (size_t)(bs * bs);
+    return (size_t)s * bb * ell_ld(n) + ((i >> 6) * bb + (size_t)(r * bs + k)) * 64 + (i & 63);
+#endif
+  }
 #endif
   return ((size_t)(s * bs + r) * n + i) * bs + k;
 }

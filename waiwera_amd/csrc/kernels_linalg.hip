@@ -99,10 +99,12 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 // Matrix entry addressing (ell_ix, context.hpp).  Block sizes 1 and 2: planes are indexed by (slot,
 // row-in-block) and element i of a plane is the BS-vector holding that block row of block-row i,
 // val[((s*BS + r)*n + i)*BS + k] -- for BS = 2 a lane's access is one 16-byte double2 and a wave
-// instruction moves 1 KiB.  Block sizes >= 3: one plane per block ELEMENT, val[((s*BS + r)*BS + k)*n + i]:
-// a 24-byte block row per lane costs a dwordx4 and a dwordx2 that each touch every 128-byte line, MEASURED
-// 5.5 TB/s streaming against 6.2-6.4 TB/s for element planes (tools/micro/layout_bs3.hip), where every
-// wave instruction reads 512 contiguous bytes.
+// instruction moves 1 KiB.  Block sizes >= 3: element by element -- a 24-byte block row per lane costs a dwordx4 and a
+// dwordx2 that each touch every 128-byte line, MEASURED 5.5 TB/s streaming against 6.2-6.4 TB/s where every wave
+// instruction reads 512 contiguous bytes of ONE block element (tools/micro/layout_bs3.hip).  Rounds 2-3 kept one plane
+// per element, val[((s*BS + r)*BS + k)*n + i]; since the end of round 4 the BS^2 elements of 64 consecutive rows sit
+// together inside the slot, val[s BS^2 ld + ((i/64) BS^2 + r BS + k) 64 + i%64] with ld = ell_ld(n): the same 512-byte
+// accesses, but a slot is one stream of 4.6-KB runs instead of nine planes 40 MB apart (context.hpp).
 template <int BS>
 __device__ __forceinline__ size_t vix(int n, int s, int e, int i) {
   return ell_ix(BS, (size_t)n, s, e / BS, e % BS, (size_t)i);
