@@ -51,6 +51,9 @@ __host__ __device__ __forceinline__ size_t ell_ix(int bs, size_t n, int s, int r
 #endif
   }
 #endif
+  // (2 x 2 blocks: the two block rows of 64 rows together inside a slot, the same idea, MEASURED without effect -- C3's
+  // fused launch 0.5326 / 0.5406 / 0.5387 against 0.5409 / 0.5713 / 0.5388 ms, the 108^3 share 0.0826 against 0.0820;
+  // profiles/group2_ab_r4.log -- two planes per slot are few enough)
   return ((size_t)(s * bs + r) * n + i) * bs + k;
 }
 

@@ -134,12 +134,13 @@ __device__ __forceinline__ void store_z2(double* __restrict__ z, size_t i, doubl
 template <int BS>
 __device__ __forceinline__ void load_block(const double* __restrict__ val, int n, int s, int i, double* b) {
   if constexpr (BS == 2) {
+    const size_t i0 = ell_ix(2, (size_t)n, s, 0, 0, (size_t)i), i1 = ell_ix(2, (size_t)n, s, 1, 0, (size_t)i);
 #ifndef WAI_NO_NT
-    const wai_d2 r0 = __builtin_nontemporal_load(reinterpret_cast<const wai_d2*>(val + ((size_t)(s * 2) * n + i) * 2));
-    const wai_d2 r1 = __builtin_nontemporal_load(reinterpret_cast<const wai_d2*>(val + ((size_t)(s * 2 + 1) * n + i) * 2));
+    const wai_d2 r0 = __builtin_nontemporal_load(reinterpret_cast<const wai_d2*>(val + i0));
+    const wai_d2 r1 = __builtin_nontemporal_load(reinterpret_cast<const wai_d2*>(val + i1));
 #else
-    const double2 r0 = *reinterpret_cast<const double2*>(val + ((size_t)(s * 2) * n + i) * 2);
-    const double2 r1 = *reinterpret_cast<const double2*>(val + ((size_t)(s * 2 + 1) * n + i) * 2);
+    const double2 r0 = *reinterpret_cast<const double2*>(val + i0);
+    const double2 r1 = *reinterpret_cast<const double2*>(val + i1);
 #endif
     b[0] = r0.x; b[1] = r0.y; b[2] = r1.x; b[3] = r1.y;
   } else {
