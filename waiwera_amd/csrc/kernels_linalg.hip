@@ -1683,12 +1683,14 @@ __global__ __launch_bounds__(256) void k_pc_wave(
     const int* __restrict__ row_info, const int* __restrict__ row_uoffw, const int* __restrict__ col,
     const double* __restrict__ sval, const double* __restrict__ dinv, const double* __restrict__ in,
     const double* __restrict__ in2, const double* __restrict__ scal, double* __restrict__ z, const double* __restrict__ aux, double* partials, int nb_max, int dot,
-    const int* __restrict__ sub_list, const int* __restrict__ rowptr, const int* __restrict__ sub_split, int lds_per_brick, Fin fin, Stagger stagger) {
+    const int* __restrict__ sub_list, const int* __restrict__ rowptr, const int* __restrict__ sub_split, int lds_per_brick, int pbase, Fin fin, Stagger stagger) {
   constexpr int BB = BS * BS, NL = 3, NU = 4;
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ __attribute__((aligned(16))) double wred[FIN_MAXS][4];   // the four bricks' sums of a workgroup (160 bytes: a multiple of 16)
   if (fin_block(fin, partials, nb_max)) return;
   stagger_start(stagger);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (dot != 0 && lane < FIN_MAXS) wred[lane][wave] = 0.0;   // (a wave without a brick leaves zeros behind)
   const int ngrp = (nsub + 3) >> 2;
   const int g = xcd_remap(blockIdx.x, ngrp);
   if (g >= ngrp) return;
@@ -1840,15 +1842,24 @@ __global__ __launch_bounds__(256) void k_pc_wave(
     }
   }
   if (dot != 0) {
+    // ONE partial sum per workgroup and slot, not one per brick: what the in-launch finalisation costs over storing the
+    // partials goes with their number -- MEASURED 9 us + 0.27 us per 1000 partials of five slots (2 646 at 108^3: 9 us,
+    // 21 168 at 216^3: 15, 31 250 at C5: 20, 78 586 at C4: 30), whatever the finalisers' count, batching or polling
+    // interval (profiles/fin_jv_ab_r4.log, fin_sleep_ab_r4.log).  The workgroup's LDS is held until its last brick ends
+    // anyway, so the barrier costs no residency.  Index: the workgroup's position in the launch's list + pbase (the
+    // face bricks' launch continues where the interior bricks' ended)
     const int ns = dot == 4 ? 5 : (dot == 2 ? 2 : 1);
     const int slot0 = dot == 3 ? S_DP2 : S_D1;   // S_D1 .. S_W2 are consecutive
 #pragma unroll
     for (int q = 0; q < 5; q++) {
       if (q < ns) {
         const double t = wave_sum(v[q]);
-        if (lane == 0) store_partial(partials + (size_t)(slot0 + q) * nb_max + s, t);
+        if (lane == 0) wred[q][wave] = t;
       }
     }
+    __syncthreads();   // (waves that left without a brick do not count)
+    if (wave == 0 && lane < ns)
+      store_partial(partials + (size_t)(slot0 + lane) * nb_max + pbase + g, ((wred[lane][0] + wred[lane][1]) + wred[lane][2]) + wred[lane][3]);
   }
   PH(4);
   PH_COUNT();
@@ -2462,16 +2473,22 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
   // one wave per brick of <= 64 block rows (block sizes 3 and 4), four bricks per workgroup
   if (kind == 3) {
     if constexpr (BS >= 3) {
-      const int ngrp = (nrun + 3) / 4, gridw = ((ngrp + 7) / 8) * 8 + (with_fin ? fin.nf : 0);
+      // one partial sum per WORKGROUP (four bricks) and slot: the face bricks' launch of the overlapped halo exchange
+      // continues the interior bricks' indices, and its finalisers sum both
+      const int ngrp = (nrun + 3) / 4;
+      const int pbase = (list && list == s.sub_bnd) ? (s.n_int + 3) / 4 : 0, nb_w = pbase + ngrp;
+      if (with_fin) { fin.nb = nb_w; fin.nf = fin_slices(nb_w); }
+      c->ks.nb_pc = nb_w;
+      const int gridw = ((ngrp + 7) / 8) * 8 + (with_fin ? fin.nf : 0);
       const int per = 64 * BS + s.max_ublocks_w * BS * BS;            // doubles per brick: solution + parked upper blocks
       const size_t lds_w = (size_t)4 * per * sizeof(double);
       const int* rp = (size_t)J.nnzb * 10 < (size_t)J.n * J.W * 9 ? J.rowptr : nullptr;   // > 10 % padding
 #define PCW(SP, AXV)                                                                                \
       hipLaunchKernelGGL((k_pc_wave<BS, SP, AXV>), gridw, 256, lds_w, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev, s.row_info, \
-                         s.row_uoffw, J.col, s.fval, s.dinv, in, in2, scal, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, list, rp, (getenv("WAI_WAVE_ROWPTR") ? nullptr : s.sub_split), per, fin, stagger)
+                         s.row_uoffw, J.col, s.fval, s.dinv, in, in2, scal, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, list, rp, (getenv("WAI_WAVE_ROWPTR") ? nullptr : s.sub_split), per, pbase, fin, stagger)
       Stagger stagger;
       stagger.ncu = c->n_cu;
-      stagger.per_cu = std::max(1, (int)((size_t)160 * 1024 / (lds_w + 704)));
+      stagger.per_cu = std::max(1, (int)((size_t)160 * 1024 / (lds_w + 864)));
       stagger.ticks = stagger_ticks(400);
       if (spmv) { if (in2) PCW(true, true); else PCW(true, false); }
       else PCW(false, false);
@@ -2528,6 +2545,7 @@ int launch_pc_on(wai_ctx* c, const Bcsr& M, const IluSchedule& s, bool spmv, con
   if (in2 && (!spmv || pc_kernel_kind(c, M, s) == 0)) { c->err = "composed input asked of a kernel that cannot form it"; return -1; }
   const Fin* fin_later = nullptr;
   if (fin && dot_mode != 0 && fin_separate()) { fin_later = fin; fin = nullptr; }
+  c->ks.nb_pc = s.nsub;   // partial sums per slot this application leaves: one per brick (k_pc_wave: per workgroup, set there)
   switch (M.bs) {
     case 1: launch_pc_bs<1>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun, fin, in2); break;
     case 2: launch_pc_bs<2>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun, fin, in2); break;
@@ -2535,9 +2553,8 @@ int launch_pc_on(wai_ctx* c, const Bcsr& M, const IluSchedule& s, bool spmv, con
     case 4: launch_pc_bs<4>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun, fin, in2); break;
     default: return -1;
   }
-  c->ks.nb_pc = s.nsub;
   if (fin_later) {
-    vec_finalize(c, s.nsub, fin_later->slot0, fin_later->nslots, fin_later->phase);
+    vec_finalize(c, c->ks.nb_pc, fin_later->slot0, fin_later->nslots, fin_later->phase);
     if (fin_later->seq > 0) bcgs_post(c, fin_later->seq);
   }
   return 0;
