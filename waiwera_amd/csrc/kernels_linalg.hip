@@ -1675,7 +1675,8 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
 //    compiler barrier holds back; the next request's offset made to depend on the consumed slot's sum through an empty
 //    asm does) bounds the loads but not the registers: the lower-coupling selects and the gathers are then put off to the
 //    end of the row and keep all seven blocks alive (195-251 VGPRs).  Not kept (profiles/wave_pipe_ab_r4.log);
-//  * the epilogue's dot-product partners requested before the backward sweep: the epilogue 20 us shorter with five
+//  * (first attempt at what is now in: see pav below) the epilogue's dot-product partners requested before the backward sweep,
+//    behind per-lane conditions: the epilogue 20 us shorter with five
 //    products, the rest of the kernel 2 % longer, nothing per iteration (profiles/wave_prefetch_ab_r4.log).
 template <int BS, bool SPMV, bool AX>
 __global__ __launch_bounds__(256) void k_pc_wave(
@@ -1704,6 +1705,22 @@ __global__ __launch_bounds__(256) void k_pc_wave(
   const int i = lo + lane;
   const bool active = lane < R;
   const double nalpha = AX ? -scal[S_ALPHA] : 0.0;   // input = in - alpha in2
+  // The epilogue's dot-product partner (block order, lane-linear) is requested HERE, before anything else of the brick: at
+  // the end of the brick nothing of this wave is left to hide the round trip behind, and a brick lives only ~20-30 us.
+  // One uniform branch, inside it straight-line loads with a clamped index (per-lane conditions around the requests made
+  // the compiler wait between them: the first attempt, profiles/wave_prefetch_ab_r4.log, gained nothing).  MEASURED
+  // (profiles/wave_early_aux_ab_r4.log, alternating builds, three runs): the launch with one product 0.5686 -> 0.5475 ms at
+  // C4, 0.1889 -> 0.1826 at C5; an iteration -2.1 % / -1.9 %.  -DWAI_WAVE_LATE_AUX: in the epilogue again
+  double pav[BS];
+#pragma unroll
+  for (int j = 0; j < BS; j++) pav[j] = 0.0;
+#ifndef WAI_WAVE_LATE_AUX
+  if (dot == 1 || dot == 4) {
+    const int totp = R * BS;
+#pragma unroll
+    for (int j = 0; j < BS; j++) pav[j] = __builtin_nontemporal_load(aux + (size_t)lo * BS + min(lane + 64 * j, totp - 1));
+  }
+#endif
   PH_DECL;
   double* ys = lds + (size_t)wave * lds_per_brick;   // [64 * BS] solution in block order
   double* upark = ys + 64 * BS;                      // parked upper blocks, row-major BS x BS each
@@ -1798,6 +1815,24 @@ __global__ __launch_bounds__(256) void k_pc_wave(
     __builtin_amdgcn_wave_barrier();
   }
   PH(2);
+#ifndef WAI_WAVE_LATE_AUX
+  // ... and the operand's own entries (block order) for the merged products a backward sweep early: the lower blocks'
+  // registers are free now (requested at the start too they would cost the fourth wave per SIMD).  MEASURED on top of the
+  // partner vector (profiles/wave_early_xi_ab_r4.log): the five-product launch 0.6177 -> 0.6015 ms at C4; an iteration
+  // against everything in the epilogue 1.477 -> 1.429 ms at C4 (-3.3 %), 0.503 -> 0.496 at C5, 0.413 -> 0.399 at C4's share
+  double pxi[BS], pi2[BS];
+#pragma unroll
+  for (int j = 0; j < BS; j++) { pxi[j] = 0.0; pi2[j] = 0.0; }
+  if (dot == 2 || dot == 4) {
+    const int totp = R * BS;
+#pragma unroll
+    for (int j = 0; j < BS; j++) {
+      const size_t gp = (size_t)lo * BS + min(lane + 64 * j, totp - 1);
+      pxi[j] = in[gp];
+      if constexpr (AX) pi2[j] = in2[gp];
+    }
+  }
+#endif
   for (int lev = 0; lev < nlb; lev++) {  // backward: x_i = y_i - sum A'_ij x_j, upper blocks from LDS
     if (lb == lev) {
       double a[BS];
@@ -1833,10 +1868,22 @@ __global__ __launch_bounds__(256) void k_pc_wave(
       const size_t gi = (size_t)lo * BS + t;
       const double out = ys[t];
       __builtin_nontemporal_store(out, z + gi);
+#ifndef WAI_WAVE_LATE_AUX
+      if (dot == 1) v[0] += out * pav[j];
+#else
       if (dot == 1) v[0] += out * __builtin_nontemporal_load(aux + gi);
+#endif
+#ifndef WAI_WAVE_LATE_AUX
+      else if (dot == 2) { const double xi = AX ? __builtin_fma(nalpha, pi2[j], pxi[j]) : pxi[j]; v[0] += xi * out; v[1] += out * out; }
+#else
       else if (dot == 2) { const double xi = AX ? __builtin_fma(nalpha, in2[gi], in[gi]) : in[gi]; v[0] += xi * out; v[1] += out * out; }
+#endif
       else if (dot == 4) {
+#ifndef WAI_WAVE_LATE_AUX
+        const double xi = AX ? __builtin_fma(nalpha, pi2[j], pxi[j]) : pxi[j], av = pav[j];
+#else
         const double xi = AX ? __builtin_fma(nalpha, in2[gi], in[gi]) : in[gi], av = __builtin_nontemporal_load(aux + gi);
+#endif
         v[0] += xi * out; v[1] += out * out; v[2] += xi * xi; v[3] += xi * av; v[4] += out * av;
       } else if (dot == 3) v[0] += out * out;
     }
