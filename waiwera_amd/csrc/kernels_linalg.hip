@@ -1652,7 +1652,8 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
 // row, and then no barrier is needed at all: the LDS executes a wave's instructions in order, so a level's
 // writes are seen by the next level's reads.  The lower blocks of a row stay in registers (3 x BS^2 doubles),
 // the upper ones are parked in LDS as the row streams in (k_pc_park's idea) and read back from there in the
-// backward sweep; four independent bricks share a 256-thread workgroup (no __syncthreads anywhere), ~13 bricks
+// backward sweep; four independent bricks share a 256-thread workgroup (no barrier through the sweeps; one at the very end,
+// where the four bricks' inner-product sums become the workgroup's one partial sum per slot: round 4), ~13 bricks
 // are resident per CU, and the latency of one brick's sweeps hides behind the loads of the others.
 // Serves the 8 x 4 x 2 bricks of 3 x 3 blocks and the 4 x 4 x 2 (32 + 32 rows) MINC bricks.
 // MEASURED and not kept (round 4, C5 = MINC bricks of 32 eight-block + 32 two-block rows):
