@@ -406,6 +406,9 @@ def main():
     ap.add_argument("--minc", action="store_true", default=None)
     ap.add_argument("--brick", type=int, nargs=3, default=None,
                     help="preconditioner subdomain shape (cells): wide in x, y and thin in z because k_z = 0.1 k_x")
+    ap.add_argument("--balanced-bricks", type=int, default=0, choices=[0, 1],
+                    help="1: a rank's range cut into ceil(range / brick) bricks of nearly equal size (216 in bricks of 16: "
+                         "fourteen of 15-16) instead of full bricks and one remainder (thirteen of 16 and one of 8)")
     ap.add_argument("--brick-order", default="x", choices=["z", "x"],
                     help="numbering of the bricks: vertical neighbour bricks adjacent in memory (z), or x fastest (rounds 1, 2)")
     ap.add_argument("--cell-order", default=None, choices=["hyperplane", "natural"],
@@ -504,7 +507,8 @@ def main():
     #   4x8x1 15.33 / 101   8x2x2 14.27 / 108   8x8x1 12.48 / 94 / 36 %   16x2x1 11.88 / 113   8x4x2 9.77 / 97 / 27 %
     brick = tuple(a.brick) if a.brick else ((4, 4, 2) if minc else ((8, 4, 2) if eos == "wce" else (16, 16, 2)))
     grid, lm, prim, region = make_case(dims=dims, brick=brick, eos=eos, lens=not a.no_lens, minc=minc,
-                                       part=M.partition_shape(world), rank=rank, brick_order=a.brick_order, order=a.cell_order)
+                                       part=M.partition_shape(world), rank=rank, brick_order=a.brick_order, order=a.cell_order,
+                                       balanced_bricks=bool(a.balanced_bricks))
     opts = wl.default_opts(ksp_type=a.ksp, pc_type="bjacobi" if a.pc == "ilu" else a.pc, ilu_levels=a.ilu_levels)
     n_bricks = lm.sub_ptr.size - 1
     if a.pc == "ilu":

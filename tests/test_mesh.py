@@ -5,8 +5,8 @@ import pytest
 from waiwera_amd import mesh as M
 
 
-def build_all(dims, part, brick, order="hyperplane"):
-    g = M.StructuredGrid(dims, part=part, brick=brick, order=order)
+def build_all(dims, part, brick, order="hyperplane", balanced=False):
+    g = M.StructuredGrid(dims, part=part, brick=brick, order=order, balanced_bricks=balanced)
     return g, [g.local_mesh(r, top_bc=([1e5, 20.0], 1), sources=M.benchmark_sources(g)) for r in range(g.nranks)]
 
 
@@ -38,6 +38,41 @@ def test_partition_covers_mesh_and_halos_match(dims, part, brick):
             assert np.all(m.cell_geom[m.n_prim:, 3] == 0.0)
             assert np.all(m.face_geom[bf, 2] == 0.0) and np.all(m.face_geom[bf, 3] == m.face_geom[bf, 1])
             assert np.all(m.face_geom[bf, 7] == -M.GRAVITY)
+
+
+@pytest.mark.parametrize("dims,part,brick", [((10, 9, 7), (1, 1, 1), (4, 4, 4)), ((13, 11, 6), (2, 1, 1), (4, 4, 2)),
+                                             ((27, 14, 4), (2, 2, 1), (8, 8, 2))])
+def test_balanced_bricks_tile_the_same_mesh(dims, part, brick):
+    """balanced_bricks cuts a rank's range into ceil(range / brick) bricks of nearly equal size instead of full bricks and
+    one remainder: the same cells, faces and halos, another grouping -- no brick above the asked size, sizes along an axis
+    within one of each other, every brick contiguous in the numbering and its rows in level order."""
+    g, ms = build_all(dims, part, brick, balanced=True)
+    g0, ms0 = build_all(dims, part, brick)
+    assert np.array_equal(np.sort(np.concatenate([m.owned_gid for m in ms])), np.arange(g.n_global))
+    for a in range(3):
+        sizes = np.diff(g.ax[a].edges)
+        assert sizes.max() <= brick[a]
+        for r in range(part[a]):
+            sr = sizes[g.ax[a].bsplit[r]: g.ax[a].bsplit[r + 1]]
+            assert sr.max() - sr.min() <= 1
+            assert len(sr) == -(-(g.ax[a].rank_hi[r] - g.ax[a].rank_lo[r]) // brick[a])
+    for m, m0 in zip(ms, ms0):
+        assert m.n_owned == m0.n_owned and m.n_halo == m0.n_halo and m.n_bc == m0.n_bc
+        assert m.face_cells.shape == m0.face_cells.shape
+        assert np.array_equal(np.sort(m.owned_gid), np.sort(m0.owned_gid))
+        assert m.sub_ptr[0] == 0 and m.sub_ptr[-1] == m.n_owned and np.all(np.diff(m.sub_ptr) > 0)
+        assert np.diff(m.sub_ptr).max() <= brick[0] * brick[1] * brick[2]
+        # the faces join the same pairs of global cells
+        pg, pg0 = m.extras["prim_gid"], m0.extras["prim_gid"]
+        def pairs(mm, p):
+            f = mm.face_cells[mm.face_cells.max(axis=1) < mm.n_prim]
+            return np.unique(np.sort(p[f], axis=1), axis=0)
+        assert np.array_equal(pairs(m, pg), pairs(m0, pg0))
+        for sd in range(len(m.sub_ptr) - 1):   # a box of cells, its rows by dependency level
+            c = m.owned_ijk[m.sub_ptr[sd]: m.sub_ptr[sd + 1]].astype(int)
+            ext = c.max(axis=0) - c.min(axis=0) + 1
+            assert np.prod(ext) == len(c) and np.all(ext <= np.array(brick))
+            assert np.all(np.diff((c - c.min(axis=0)).sum(axis=1)) >= 0)
 
 
 def test_bricks_are_contiguous_and_level_sorted():

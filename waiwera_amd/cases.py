@@ -7,12 +7,14 @@ from waiwera_amd import mesh as M
 
 
 def make_case(dims=(8, 8, 8), brick=(4, 4, 4), eos="we", lens=False, sources=True, part=(1, 1, 1),
-              rank=0, hetero=True, top_bc=True, minc=False, spacing=None, brick_order="x", order="hyperplane"):
+              rank=0, hetero=True, top_bc=True, minc=False, spacing=None, brick_order="x", order="hyperplane",
+              balanced_bricks=False):
     if spacing is None:
         # the two-phase lens sits 400..500 m deep: stretch shallow test boxes so that their bottom
         # layer falls inside it (otherwise lens=True silently means no lens)
         spacing = (10.0, 10.0, 500.0 / dims[2]) if lens and dims[2] * 10.0 < 450.0 else (10.0, 10.0, 10.0)
-    g = M.StructuredGrid(dims, spacing=spacing, brick=brick, part=part, brick_order=brick_order, order=order)
+    g = M.StructuredGrid(dims, spacing=spacing, brick=brick, part=part, brick_order=brick_order, order=order,
+                         balanced_bricks=balanced_bricks)
     srcs = M.benchmark_sources(g, co2_fraction=0.05 if eos in ("wce", "wse", "wae", "wsce", "wsae") else 0.0) if sources else None   # wse: 5 % salt
     bc = None
     if top_bc:

@@ -39,7 +39,10 @@ class _Axis:
     is tiled with bricks starting at its lower end (the last brick of a rank may be ragged), so
     preconditioner bricks never straddle ranks and the load stays balanced whatever the brick."""
 
-    def __init__(self, n, parts, brick):
+    def __init__(self, n, parts, brick, balanced=False):
+        # balanced: a rank's range is cut into ceil(range / brick) bricks of (nearly) EQUAL size instead of full bricks and
+        # one remainder -- 216 cells in bricks of 16: fourteen bricks of 15 or 16 instead of thirteen of 16 and one of 8.  A
+        # half or quarter brick holds a CU slot of the fused kernel for almost as long as a full one
         self.n, self.parts = n, parts
         csplit = _splits(n, parts)                      # balanced cell ranges
         self.rank_lo = csplit[:-1].copy()
@@ -47,7 +50,11 @@ class _Axis:
         edges, bsplit = [], [0]
         for r in range(parts):
             lo, hi = int(csplit[r]), int(csplit[r + 1])
-            e = list(range(lo, hi, brick))
+            if balanced and hi > lo:
+                nb = -(-(hi - lo) // brick)
+                e = [lo + int(v) for v in _splits(hi - lo, nb)[:-1]]
+            else:
+                e = list(range(lo, hi, brick))
             edges += e
             bsplit.append(len(edges))
         edges.append(n)
@@ -109,7 +116,7 @@ class StructuredGrid:
     """Global description of an nx*ny*nz box split over px*py*pz ranks."""
 
     def __init__(self, dims, spacing=(10.0, 10.0, 10.0), part=(1, 1, 1), brick=(8, 8, 8),
-                 order="hyperplane", brick_order="x"):
+                 order="hyperplane", brick_order="x", balanced_bricks=False):
         # order: numbering of the cells inside a brick.  "hyperplane" sorts them by i+j+k (ties in
         # natural order) = by dependency level of the brick's ILU(0) factors, so storage order is
         # level order and a wavefront owns whole consecutive levels; "natural" is x-fastest.
@@ -127,7 +134,8 @@ class StructuredGrid:
         self.spacing = tuple(float(v) for v in spacing)
         self.part = tuple(int(v) for v in part)
         self.brick = tuple(int(v) for v in brick)
-        self.ax = [_Axis(self.dims[a], self.part[a], self.brick[a]) for a in range(3)]
+        self.balanced_bricks = bool(balanced_bricks)
+        self.ax = [_Axis(self.dims[a], self.part[a], self.brick[a], self.balanced_bricks) for a in range(3)]
         self.nranks = self.part[0] * self.part[1] * self.part[2]
         self.n_global = self.dims[0] * self.dims[1] * self.dims[2]
 
