@@ -24,6 +24,10 @@ int wai_bench_mute_comm(wai_ctx *ctx, int on);
 /* fault injection for the tests: workgroup 0 of the following launches loses its next n partial sums of a reduction --
  * the in-launch finalisation must run into its bounded wait and the solver return KSP_DIVERGED_NANORINF (-9) */
 int wai_test_drop_partials(wai_ctx *ctx, int n);
+/* fault injection for the tests (negative check of the overlapped halo exchange): which = 1 -- the face bricks' launch
+ * is enqueued WITHOUT waiting for the event behind the unpack on the communication stream.  Over a stream-asynchronous
+ * transport a multi-rank solve must then go wrong (tests/test_hip_multirank.py); 0 restores the product's ordering */
+int wai_test_drop_stream_wait(wai_ctx *ctx, int which);
 /* bytes this rank sends per halo exchange of a dof-per-cell vector, and its number of neighbours */
 int wai_halo_size(wai_ctx *ctx, int dof, long long *bytes_sent, int *n_neighbours);
 

@@ -28,3 +28,19 @@ def test_self_halo_exchange_and_allreduce():
         want = v[: lm.n_owned * dof].reshape(-1, dof)[lm.send_idx].ravel()
         assert np.array_equal(v[lm.n_owned * dof:], want)
     sim.destroy()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("ranks,delay_us", [(2, 0), (4, 0), (8, 0), (8, 100)])
+def test_async_transport_selftest(ranks, delay_us):
+    """the stream-asynchronous stand-in for librccl that the multi-rank tests run on (tests/loopback_rccl/async_rccl.hip),
+    by itself: N processes on this one GPU, grouped sends / receives of changing lengths (8 bytes to three mailbox
+    chunks) to both ring neighbours and sum / max / min all-reduces, filled and checked by kernels on two
+    event-ordered streams, no host synchronisation until the end; no wrong word may arrive"""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "loopback_rccl", "async_selftest")
+    assert os.path.exists(exe), "build first: python __graft_entry__.py"
+    env = dict(os.environ, WAI_ASYNC_RCCL_DELAY_US=str(delay_us), WAI_ASYNC_RCCL_TIMEOUT_S="30")
+    out = subprocess.run([exe, str(ranks), "300"], env=env, capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0 and "PASSED" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])

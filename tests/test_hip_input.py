@@ -305,6 +305,18 @@ def test_network_couplings_are_the_literal_fd_columns(name, geometry, steps, mon
     res_without_E = np.abs(sp.bsr_matrix((A, ci, rp), shape=(n, n)) @ xs - b).max() / np.abs(b).max()
     print(name, "krylov its", its, "residual of (A+E)x=b", res, "of Ax=b", res_without_E)
     assert res < 1e-3 and res_without_E > 10.0 * res
+    # the set-up belongs to the path it was made for: switching where E lives between wai_pc_setup and
+    # wai_ksp_solve (factor's pattern -> operator only -> pattern again) must set up again, not apply the
+    # other path's (stale or never factored) preconditioner
+    for in_pc in (False, True, False):
+        ode.set_network_couplings(True, in_preconditioner=in_pc)
+        xs[:] = 0.0
+        its2, reason2, _ = ode.ksp_solve(b, xs)
+        res2 = np.abs(M @ xs - b).max() / np.abs(b).max()
+        print(name, "E in the factor's pattern" if in_pc else "E in the operator only", "krylov its", its2, "residual", res2)
+        assert reason2 > 0 and res2 < 1e-3, (in_pc, its2, reason2, res2)
+        assert its2 <= (its if in_pc else 4 * its + 8)
+        assert ode.pc_setup() == 0          # ... and the other order: set up for this path, switch, solve
     # the same under block Jacobi (the C / Fortran ABI default), whose fused kernels then run behind the
     # unfused operator (A + E) x: BiCGStab's inner products must pair the result with x, not with (A + E) x --
     # with the reductions where KSPSolve_BCGS has them and in the merged (multi-rank) form

@@ -1,6 +1,7 @@
-"""The N > 1 path of the HIP library on ONE GPU: two processes, one rank each, both on cuda:0,
-with librccl replaced by the shared-memory loopback of tests/loopback_rccl (real RCCL refuses two
-ranks on one device; the test boxes have one).  Everything above the nine nccl* entry points is
+"""The N > 1 path of the HIP library on ONE GPU: N processes, one rank each, all on cuda:0,
+with librccl replaced by a stand-in of tests/loopback_rccl (real RCCL refuses two ranks on one device; the
+test boxes have one) -- by default the stream-asynchronous one (async_rccl.hip: hipIpc-shared device windows,
+every collective a kernel on the caller's stream, no host synchronisation).  Everything above the nine nccl* entry points is
 the product path: partition meshes and halo lists of waiwera_amd.mesh, pack / exchange / unpack
 kernels, the Krylov all-reduces and the collective flags of the Newton protocol.  Because
 preconditioner bricks never straddle ranks the 2-rank solve is algorithmically the 1-rank solve;
@@ -20,7 +21,19 @@ from waiwera_amd import mesh as M
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LOOPBACK = os.path.join(ROOT, "tests", "loopback_rccl", "libloopback_rccl.so")
+# Two stand-ins for librccl (tests/loopback_rccl/): "async" -- device-resident windows shared with hipIpc, every
+# nccl* call a kernel on the caller's stream, no host synchronisation (RCCL's semantics: what the product's streams
+# and events do not order IS unordered) -- and "sync", the host-staged one of rounds 2-4 that drains the stream in
+# every call.  Every test here runs on the asynchronous one unless WAI_TEST_TRANSPORT=sync.
+TRANSPORT = os.environ.get("WAI_TEST_TRANSPORT", "async")
+LOOPBACK = os.path.join(ROOT, "tests", "loopback_rccl", "libasync_rccl.so" if TRANSPORT == "async" else "libloopback_rccl.so")
+
+
+def _default_overlap():
+    """the product's default (ghost values in flight behind the interior bricks) on the asynchronous transport; the
+    host-staged one serialises everything anyway and runs the in-order exchange unless a test asks"""
+    if TRANSPORT != "async":
+        os.environ.setdefault("WAI_HALO_OVERLAP", "0")
 DIMS, BRICK = (16, 12, 8), (4, 4, 4)
 
 
@@ -45,7 +58,7 @@ def _run_steps(sim, y, nsteps=3):
 
 def _worker(rank, world, uid_q, q, dims=DIMS, brick=BRICK, nsteps=3):
     os.environ["WAI_RCCL_LIB"] = LOOPBACK
-    os.environ.setdefault("WAI_HALO_OVERLAP", "0")   # the loopback time-slices the ranks on one GPU: in-order exchange unless asked
+    _default_overlap()
     from waiwera_amd import lib as wl
     from waiwera_amd.flow_simulation import FlowSimulation
     # rank 0 makes the id in its own fresh process: the pytest process may already hold the real
@@ -79,6 +92,75 @@ def test_overlapped_halo_exchange_two_ranks(monkeypatch):
     no partition ghost run; same results as one rank"""
     monkeypatch.setenv("WAI_HALO_OVERLAP", "1")
     test_ranks_sharing_one_gpu_match_one_rank(2)
+
+
+@pytest.mark.timeout(900)
+def test_in_order_halo_exchange_two_ranks(monkeypatch):
+    """WAI_HALO_OVERLAP=0: pack, exchange, unpack and all bricks on the one compute stream"""
+    monkeypatch.setenv("WAI_HALO_OVERLAP", "0")
+    test_ranks_sharing_one_gpu_match_one_rank(2)
+
+
+def _late_halo_worker(rank, world, uid_q, q):
+    os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    os.environ["WAI_HALO_OVERLAP"] = "1"
+    os.environ["WAI_ASYNC_RCCL_DELAY_US"] = "300"    # every receive delivers 0.3 ms late: "late" is certain, not likely
+    from waiwera_amd import lib as wl
+    from waiwera_amd.flow_simulation import FlowSimulation
+    if rank == 0:
+        uid = wl.comm_unique_id()
+        for _ in range(world - 1):
+            uid_q.put(uid)
+    else:
+        uid = uid_q.get(timeout=300)
+    g, lm, prim, region = _problem(M.partition_shape(world), rank, (16, 16, 16), (2, 2, 2))
+    sim = FlowSimulation(lm, eos="we", device=0)
+    sim.set_regions(region)
+    sim.comm_init(rank, world, uid)
+    y = scaled(prim, region).ravel().copy()
+    sim.set_opts(ksp_rtol=1e-10, ksp_max_its=200)
+    assert sim.timestep(0.0, 2.0e4, y)[0] > 0          # leaves a Jacobian and its preconditioner
+    n = lm.n_owned * 2
+    b = np.random.default_rng(11 + rank).uniform(-1, 1, n)
+    out = []
+    for drop in (0, 1, 0):
+        sim.drop_stream_wait(drop)
+        x = np.zeros(n)
+        kits, kreason, _ = sim.ksp_solve(b, x)
+        out.append((kits, kreason, x.copy()))
+    q.put((rank, _brick_lists(lm), out))
+    sim.destroy()
+
+
+@pytest.mark.timeout(900)
+def test_a_missing_stream_wait_is_seen():
+    """The negative check of the overlapped exchange (csrc/krylov.hip pc_amul: pack -> event -> exchange and unpack on
+    the communication stream -> event -> face bricks): with wai_test_drop_stream_wait(1) the face bricks' launch no
+    longer waits for the event behind the unpack.  On the asynchronous transport with every receive 0.3 ms late the
+    face bricks then read the previous exchange's ghost values, and the Krylov solve must come out wrong (or fail);
+    with the wait back in place it reproduces the first solve to the bit.  (On the host-staged transport of rounds
+    2-4 this test could not fail: every call drained the stream.)"""
+    if TRANSPORT != "async":
+        pytest.skip("the host-staged transport orders everything by itself")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q, uid_q = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_late_halo_worker, args=(r, world, uid_q, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    wrong = 0
+    for rank, (n_int, n_bnd), ((k0, r0, x0), (k1, r1, x1), (k2, r2, x2)) in res:
+        assert n_int > 0 and n_bnd > 0            # the overlapped path is the one that ran
+        assert r0 > 0 and r2 > 0 and k2 == k0
+        assert np.array_equal(x0, x2)             # ordered: deterministic, however late the data
+        dev = np.abs(x1 - x0).max() / np.abs(x0).max()
+        print("rank", rank, "its ordered / unordered", k0, k1, "reason", r1, "deviation of the unordered solve", dev)
+        wrong += int(r1 <= 0 or dev > 1e-6)
+    assert wrong == world
 
 
 @pytest.mark.timeout(2400)
@@ -311,7 +393,7 @@ def _tracer_run(sim, lm, eos, y, nt=2):
 
 def _tracer_worker(rank, world, uid_q, q):
     os.environ["WAI_RCCL_LIB"] = LOOPBACK
-    os.environ.setdefault("WAI_HALO_OVERLAP", "0")
+    _default_overlap()
     from waiwera_amd import lib as wl
     from waiwera_amd.flow_simulation import FlowSimulation
     if rank == 0:
@@ -436,7 +518,7 @@ def test_bench_spawns_its_own_ranks():
 
 def _asm_worker(rank, world, uid_q, q, dims, brick, eos):
     os.environ["WAI_RCCL_LIB"] = LOOPBACK
-    os.environ.setdefault("WAI_HALO_OVERLAP", "0")
+    _default_overlap()
     from waiwera_amd import lib as wl
     from waiwera_amd.cases import make_case
     from waiwera_amd.flow_simulation import FlowSimulation
@@ -565,7 +647,7 @@ def test_asm_overlap_reaches_across_ranks(world, eos):
 
 def _asm_refuse_worker(rank, world, uid_q, q):
     os.environ["WAI_RCCL_LIB"] = LOOPBACK
-    os.environ.setdefault("WAI_HALO_OVERLAP", "0")
+    _default_overlap()
     from waiwera_amd import lib as wl
     from waiwera_amd.cases import make_case
     from waiwera_amd.flow_simulation import FlowSimulation
@@ -646,7 +728,7 @@ def _net_problem(part, rank):
 
 def _net_worker(rank, world, uid_q, q):
     os.environ["WAI_RCCL_LIB"] = LOOPBACK
-    os.environ.setdefault("WAI_HALO_OVERLAP", "0")
+    _default_overlap()
     from waiwera_amd import lib as wl
     from waiwera_amd.flow_simulation import FlowSimulation
     if rank == 0:

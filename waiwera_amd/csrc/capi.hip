@@ -803,7 +803,11 @@ int wai_comm_init(wai_ctx* c, int rank, int nranks, const char id[128]) {
   // (The tests' loopback transport time-slices all ranks on one GPU and switches it off.)
   const char* ov = getenv("WAI_HALO_OVERLAP");
   if (nranks > 1 && !c->comm_stream && !(ov && ov[0] == '0')) {
-    HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    // highest priority: the interior bricks fill every CU at full occupancy, and RCCL's send / receive kernels, the
+    // pack and the unpack must not queue behind them -- they are what the face bricks wait for
+    int prio_lo = 0, prio_hi = 0;
+    HIPCHK(c, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIPCHK(c, hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, prio_hi));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
   }

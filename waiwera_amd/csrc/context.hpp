@@ -375,6 +375,7 @@ struct wai_ctx {
   // halo exchange overlapped with the preconditioned operator on the bricks that touch no ghost
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
+  int test_drop_wait = 0;   // fault injection (wai_test_drop_stream_wait): 1 the face bricks' launch does not wait for the halo
   // halo
   int n_nbr = 0;
   std::vector<int> nbr_rank, send_ptr, recv_ptr;

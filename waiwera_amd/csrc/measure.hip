@@ -104,6 +104,7 @@ int wai_launch_stats(wai_ctx* c, long long* kernels, long long* copies) {
   return 0;
 }
 int wai_test_drop_partials(wai_ctx* c, int n) { return c ? test_drop_partials(c, n) : -2; }
+int wai_test_drop_stream_wait(wai_ctx* c, int which) { if (!c) return -2; c->test_drop_wait = which; return 0; }
 int wai_bench_mute_comm(wai_ctx* c, int on) {
   if (!c) return -2;
   if (c->comm) c->comm->mute = on != 0;

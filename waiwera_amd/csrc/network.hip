@@ -594,9 +594,16 @@ int wai_set_source_global_index(wai_ctx* c, int n_global, const int* global_inde
 
 int wai_set_network_couplings(wai_ctx* c, int on) {
   if (!c) return -2;
+  const bool was = pc_with_net(c);
   c->net.coupling = on != 0;
   c->net.cp_in_pc = on != 1;      // 1: in the operator only (rounds 2-3); 2 (and any other non-zero value): in the factor's pattern too
   if (!on) c->net.cp_valid = false;
+  // pc_fused() / pc_extended() follow pc_with_net(): a set-up made for the other path (the extended system factored and
+  // c->ilu not, or the other way round) must not be applied -- the next solve sets up again, the extended pattern included
+  if (pc_with_net(c) != was) {
+    c->ilu.factored = false;
+    c->as.overlap = -1;
+  }
   return 0;
 }
 

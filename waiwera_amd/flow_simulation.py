@@ -200,6 +200,10 @@ class FlowSimulation:
         """timing probe: collectives return without calling RCCL (every rank together)"""
         self._chk(LIB.wai_bench_mute_comm(self.h, 1 if on else 0), "bench_mute_comm")
 
+    def drop_stream_wait(self, which):
+        """fault injection (tests): 1 the face bricks' launch does not wait for the halo exchange, 0 off"""
+        self._chk(LIB.wai_test_drop_stream_wait(self.h, int(which)), "test_drop_stream_wait")
+
     def halo_size(self, dof=None):
         """(bytes this rank sends per halo exchange of a dof-per-cell vector, neighbours)"""
         b, n = C.c_longlong(0), C.c_int(0)

@@ -145,6 +145,7 @@ def _load():
         "wai_launch_stats": (i32, [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
         "wai_bench_mute_comm": (i32, [vp, i32]),
         "wai_test_drop_partials": (i32, [vp, i32]),
+        "wai_test_drop_stream_wait": (i32, [vp, i32]),
         "wai_halo_size": (i32, [vp, i32, C.POINTER(C.c_longlong), C.POINTER(i32)]),
         "wai_pc_kernel_name": (C.c_char_p, [vp]),
         "wai_pre_timestep": (i32, [vp]),
