@@ -186,7 +186,12 @@ def traffic_from_profiles(cfg, dims, brick, kernel):
     return None
 
 
-def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0, gpu_state=None, minc=False, brick=None):
+# curves of the synthetic workloads -- the reference's defaults (relative_permeability.F90:225-226,591,
+# capillary_pressure.F90:389) and "one extra run with Corey (0.3, 0.05)" (relative_permeability.F90:297-307)
+CURVES = {"linear": {}, "corey": {"relperm": ("corey", [0.3, 0.05])}}
+
+
+def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0, gpu_state=None, minc=False, brick=None, curves=None):
     """The oracle (CPU restatement of the reference's path, OpenMP) timed on the SAME mesh and the same
     state the timed window starts from -- one Newton step, piece by piece: unperturbed residual, FD
     Jacobian (per-row differencing, and the reference's coloured MatFDColoring sweep when it fits the
@@ -224,7 +229,8 @@ def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0, gpu_s
         gomp = None
     kind = {"w": 0, "we": 1, "wce": 2}[eos]
     t_all = time.time()
-    osim = ol.OracleSim(L, lm, kind)
+    curves = curves or {}
+    osim = ol.OracleSim(L, lm, kind, **curves)
     osim.set_regions(region0)
     y = osim.yvec(y0)
     n = osim.n_owned
@@ -306,7 +312,7 @@ def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0, gpu_s
         if gomp:
             gomp.omp_set_num_threads(int(best_t))
         g2, lm2, prim2, region2 = make_case(dims=(100, 100, 100), brick=brick or (16, 16, 2), eos=eos, lens=True, minc=minc)
-        o2 = ol.OracleSim(L, lm2, kind)
+        o2 = ol.OracleSim(L, lm2, kind, **curves)
         o2.set_regions(region2)
         sp2 = np.linspace(0, o2.n_owned, int(best_t) + 1).astype(np.int32)
         L.wo_sim_set_subdomains(o2.h, int(best_t), ol.ip(sp2))
@@ -426,6 +432,9 @@ def main():
                     help="ilu: ONE ILU(0) block per rank (the reference's own layout, sub_ptr = NULL: src/timestepper.F90:1668-1669) "
                          "on the launch-per-level path")
     ap.add_argument("--ilu-levels", type=int, default=0, help="ILU(k) sub-preconditioner (factor.levels); k > 0 runs the unfused extended-system path")
+    ap.add_argument("--curves", default="linear", choices=sorted(CURVES),
+                    help="relative permeability / capillary pressure: the reference's defaults (linear [0,1]/[0,1], zero) or "
+                         "SURVEY.md section 8d's second series, Corey (0.3, 0.05)")
     ap.add_argument("--no-lens", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--spmv-reps", type=int, default=200)
@@ -437,10 +446,17 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a))
 
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("WAI_BENCH_LOOPBACK") == "1" and world > 1 and os.environ.get("WAI_TEST_CU_MASK", "1") != "0":
+        # tests only (all ranks on ONE GPU): each rank on its own 256 / world compute units, so that the ranks run side by
+        # side like `world` small devices instead of time-slicing one another (read when the process first touches the device)
+        per = 256 // world
+        os.environ["HSA_CU_MASK"] = "0:%d-%d" % (rank * per, (rank + 1) * per - 1)
+        if world >= 7:
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")   # all ranks' queues mapped together: no time-slicing of queues
+    import torch
     if world != a.gpus:
         print("bench.py: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
         sys.exit(2)
@@ -513,7 +529,7 @@ def main():
     n_bricks = lm.sub_ptr.size - 1
     if a.pc == "ilu":
         lm.sub_ptr = None                      # one block per rank
-    sim = FlowSimulation(lm, eos=eos, opts=opts, device=local_rank)
+    sim = FlowSimulation(lm, eos=eos, opts=opts, device=local_rank, **CURVES[a.curves])
     if a.pc == "ilu":
         lm.sub_ptr = np.array([0, lm.n_owned], dtype=np.int32)
     sim.set_regions(region)
@@ -692,6 +708,9 @@ def main():
                 "halo_bytes_per_exchange": int(maxr(hb)), "halo_neighbours": int(maxr(nn)),
                 "halo_exchange": "behind the interior bricks (communication stream)" if os.environ.get("WAI_HALO_OVERLAP", "1") != "0" else "in order",
                 "transport": os.environ.get("WAI_RCCL_LIB", "librccl (RCCL over xGMI)")}
+        if loopback:
+            comm["note"] = ("all %d ranks on ONE GPU%s over a test transport: the multi-rank code path and its collective counts, "
+                            "not a scaling measurement" % (world, (", %d compute units each (HSA_CU_MASK)" % (256 // world)) if "HSA_CU_MASK" in os.environ else ""))
         if a.ksp == "bcgs" and a.pc == "bjacobi" and a.ilu_levels == 0:
             barrier()
             t_on = maxr(sim.bench_kernel(5, 30))
@@ -738,9 +757,9 @@ def main():
             "device_state_after_timed_region": dev_state,
             "config": {"workload": "%s%s: %dx%dx%d structured eos_%s mesh%s (%d cells), BE time steps %d-%d, %s (cyclic), "
                                    "%s + %s(%dx%dx%d bricks)/%s, rtol 1e-5"
-                                   % ((a.config, share) + dims + (eos, " + 1 MINC level" if minc else "", n_cells, a.lead,
+                                   % ((a.config, share) + dims + (eos, (" + 1 MINC level" if minc else "") + (", Corey (0.3, 0.05) k_r" if a.curves == "corey" else ""), n_cells, a.lead,
                                                                   a.lead + a.window - 1, ctl, ksp_name, pc_name) + brick + (ilu_name,)),
-                       "controller": a.controller,
+                       "controller": a.controller, "curves": a.curves,
                        "krylov_iterations_per_newton_step": kits / n_newton,
                        "krylov_iterations": kits,
                        "ms_per_krylov_iteration": 1e3 * iter_s, "ms_fixed_per_newton_step": 1e3 * fixed_s,
@@ -774,7 +793,7 @@ def main():
         if not a.no_cpu and world == 1:   # the CPU baseline is a single-GPU-run item
             try:
                 cb = cpu_baseline(lm, eos, start["y"].cpu().numpy(), start["regions"], start["dt"],
-                                  kits / max(a.steps, 1), gpu_state=gpu_state, minc=minc, brick=brick)
+                                  kits / max(a.steps, 1), gpu_state=gpu_state, minc=minc, brick=brick, curves=CURVES[a.curves])
             except Exception as e:   # the reported baseline must not take the measurement down with it
                 log("cpu baseline failed: %r" % (e,))
                 cb = None

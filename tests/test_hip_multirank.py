@@ -29,6 +29,21 @@ TRANSPORT = os.environ.get("WAI_TEST_TRANSPORT", "async")
 LOOPBACK = os.path.join(ROOT, "tests", "loopback_rccl", "libasync_rccl.so" if TRANSPORT == "async" else "libloopback_rccl.so")
 
 
+def _own_cus(rank, world):
+    """The ranks share one GPU: give each its own compute units (HSA_CU_MASK, read when the process first touches the
+    device), 256 / world each, so that they run side by side like `world` small devices instead of time-slicing one
+    another's full-width launches -- and a rank's polling transport kernels never sit on CUs a peer's work is queued for."""
+    if os.environ.get("WAI_TEST_CU_MASK", "1") != "0" and world > 1:
+        per = 256 // world
+        os.environ["HSA_CU_MASK"] = "0:%d-%d" % (rank * per, (rank + 1) * per - 1)
+        # ... and few enough hardware queues that all ranks' queues stay mapped together: HIP takes up to 4 per process and
+        # priority level, and beyond the device's ~24 queue slots the scheduler time-slices them -- a polling kernel then waits
+        # out a peer's whole quantum.  MEASURED (tests/loopback_rccl/async_selftest, 200 iterations): 4 / 5 / 6 ranks 0.80 /
+        # 0.84 / 0.81 s, 7 / 8 ranks 4.4 / 5.0 s -- and 0.65 / 0.71 s with one queue per process and priority level
+        if world >= 7:
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
+
+
 def _default_overlap():
     """the product's default (ghost values in flight behind the interior bricks) on the asynchronous transport; the
     host-staged one serialises everything anyway and runs the in-order exchange unless a test asks"""
@@ -58,6 +73,7 @@ def _run_steps(sim, y, nsteps=3):
 
 def _worker(rank, world, uid_q, q, dims=DIMS, brick=BRICK, nsteps=3):
     os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    _own_cus(rank, world)
     _default_overlap()
     from waiwera_amd import lib as wl
     from waiwera_amd.flow_simulation import FlowSimulation
@@ -103,6 +119,7 @@ def test_in_order_halo_exchange_two_ranks(monkeypatch):
 
 def _late_halo_worker(rank, world, uid_q, q):
     os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    _own_cus(rank, world)
     os.environ["WAI_HALO_OVERLAP"] = "1"
     os.environ["WAI_ASYNC_RCCL_DELAY_US"] = "300"    # every receive delivers 0.3 ms late: "late" is certain, not likely
     from waiwera_amd import lib as wl
@@ -260,6 +277,7 @@ def _shape_steps(sim, y, nsteps, dt0):
 
 def _shape_worker(rank, world, uid_q, q, spec):
     os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    _own_cus(rank, world)
     os.environ["WAI_HALO_OVERLAP"] = "1" if spec["overlap"] else "0"
     from waiwera_amd import lib as wl
     from waiwera_amd.cases import make_case
@@ -393,6 +411,7 @@ def _tracer_run(sim, lm, eos, y, nt=2):
 
 def _tracer_worker(rank, world, uid_q, q):
     os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    _own_cus(rank, world)
     _default_overlap()
     from waiwera_amd import lib as wl
     from waiwera_amd.flow_simulation import FlowSimulation
@@ -518,6 +537,7 @@ def test_bench_spawns_its_own_ranks():
 
 def _asm_worker(rank, world, uid_q, q, dims, brick, eos):
     os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    _own_cus(rank, world)
     _default_overlap()
     from waiwera_amd import lib as wl
     from waiwera_amd.cases import make_case
@@ -647,6 +667,7 @@ def test_asm_overlap_reaches_across_ranks(world, eos):
 
 def _asm_refuse_worker(rank, world, uid_q, q):
     os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    _own_cus(rank, world)
     _default_overlap()
     from waiwera_amd import lib as wl
     from waiwera_amd.cases import make_case
@@ -728,6 +749,7 @@ def _net_problem(part, rank):
 
 def _net_worker(rank, world, uid_q, q):
     os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    _own_cus(rank, world)
     _default_overlap()
     from waiwera_amd import lib as wl
     from waiwera_amd.flow_simulation import FlowSimulation

@@ -373,14 +373,18 @@ def test_iluk_sub_preconditioner(oracle, eos, pc, brick):
     sim.destroy(); osim.close()
 
 
-@pytest.mark.timeout(300)
-def test_a_lost_partial_sum_ends_the_solve_not_the_device(oracle):
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("dims,brick", [((12, 12, 8), (4, 4, 2)), ((24, 24, 16), (2, 2, 2))],
+                         ids=["one-finaliser", "two-finalisers"])
+def test_a_lost_partial_sum_ends_the_solve_not_the_device(oracle, dims, brick):
     """The in-launch finalisation reads arrival off the data; a partial sum that never arrives (fault injected: workgroup 0
     of the next fused launch loses its store) must end in the finaliser's bounded wait, breakdown code 4 posted to the
     host and KSP_DIVERGED_NANORINF -- not in a hung device or a sum of stale data -- and the next solve, which empties the
-    reduction slots first, must be untouched by it."""
+    reduction slots first, must be untouched by it.  With 1 152 bricks the partials are summed in two slices by two
+    finaliser workgroups: the one that gives up (slice 0) is not the one that posts, and the code must still arrive."""
     from waiwera_amd.lib import LIB
-    lm, sim, osim, J, f = system(oracle, "we", (12, 12, 8), (4, 4, 2))
+    lm, sim, osim, J, f = system(oracle, "we", dims, brick)
+    assert (len(lm.sub_ptr) - 1 > 1024) == (brick == (2, 2, 2))
     n = sim.num_dof
     sim.set_opts(pc_type="bjacobi", ksp_type="bcgs", ksp_rtol=1e-10)
     assert sim.pc_setup() == 0

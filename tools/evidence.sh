@@ -1,19 +1,19 @@
 #!/bin/bash
-# round-4 final GPU pass: the whole GPU suite, the evidence runs for c3 / c4 / c5 (bench line, rocprofv3 kernel stats, PMC
+# evidence pass of a round (ONE gpurun call = one box; TAG names the files: bench_${TAG}_c3.json ...): the whole GPU suite, the evidence runs for c3 / c4 / c5 (bench line, rocprofv3 kernel stats, PMC
 # traffic), the rank shares on the same box, the BASELINE shardings at full size over the loopback (comm fields)
-mkdir -p gpurun_out/r4
 R=$GRAFT_REPO_ROOT
-TAG=${TAG:-r4}   # names of the evidence files: bench_${TAG}_c3.json ... (r4c: the pass on the round's last commit)
+TAG=${TAG:-r5}
+mkdir -p gpurun_out/$TAG
 export TMPDIR=/tmp
-if [ -z "$SKIP_TESTS" ]; then python -m pytest tests -m gpu -q -s --durations=10 > gpurun_out/r4/pytest_gpu_final.log 2>&1; fi
-echo "pytest rc $?"; grep -v amdgpu gpurun_out/r4/pytest_gpu_final.log | tail -14 | cut -c1-160
+if [ -z "$SKIP_TESTS" ]; then python -m pytest tests -m gpu -q -s --durations=10 > gpurun_out/$TAG/pytest_gpu_final.log 2>&1; fi
+echo "pytest rc $?"; grep -v amdgpu gpurun_out/$TAG/pytest_gpu_final.log | tail -14 | cut -c1-160
 for cfg in ${CFGS:-c3 c4 c5}; do
-  bash tools/gpu_profile.sh $TAG $cfg --steps 20 --warmup 5 > gpurun_out/r4/gpu_profile_$cfg.log 2>&1
+  bash tools/gpu_profile.sh $TAG $cfg --steps 20 --warmup 5 > gpurun_out/$TAG/gpu_profile_$cfg.log 2>&1
   head -6 gpurun_out/rocprof_kernel_stats_${TAG}_$cfg.txt | cut -c1-140
 done
 share() { name=$1; shift
   python bench.py "$@" --steps 20 --warmup 5 --no-cpu > gpurun_out/bench_${TAG}_$name.json 2> gpurun_out/bench_${TAG}_$name.log
-  (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -o p -- python $R/bench.py "$@" --steps 20 --warmup 5 --no-cpu > /dev/null 2> $R/gpurun_out/r4/prof_$name.log)
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -o p -- python $R/bench.py "$@" --steps 20 --warmup 5 --no-cpu > /dev/null 2> $R/gpurun_out/$TAG/prof_$name.log)
   db=$(find /tmp/prof_$name -name "*.db" | head -1)
   if [ -n "$db" ]; then python tools/rocprof_summary.py "$db" gpurun_out/rocprof_kernel_stats_${TAG}_$name.txt > /dev/null; fi
 }
@@ -33,20 +33,6 @@ for n in ["c3","c4","c5","c2","c3_share8","c4_share4","c5_share2"]:
     except Exception as e: print(n, e)
 PY
 if [ -z "$SKIP_LOOPBACK" ]; then
-export WAI_RCCL_LIB=$PWD/tests/loopback_rccl/libloopback_rccl.so WAI_BENCH_LOOPBACK=1 WAI_HALO_OVERLAP=0
-lb() { cfg=$1; n=$2
-  MASTER_PORT=$((29500 + RANDOM % 500)) timeout 1200 python bench.py --config $cfg --gpus $n --lead 1 --steps 3 --warmup 0 --no-cpu --spmv-reps 3 > gpurun_out/r4/lb_${cfg}_$n.out 2> gpurun_out/r4/lb_${cfg}_$n.log
-  echo "loopback $cfg x $n rc $?"
-  grep "^{" gpurun_out/r4/lb_${cfg}_$n.out > gpurun_out/bench_${TAG}_${cfg}_loopback$n.json
-  python - <<PY
-import json
-try:
-    d=json.load(open("gpurun_out/bench_${TAG}_${cfg}_loopback$n.json")); c=d["config"]
-    print("$cfg x $n:", c["partition"], round(d["value"],4), c["krylov_iterations_per_newton_step"], d["comm"], d["check"])
-except Exception as e: print("no line", e)
-PY
-}
-lb c5 2
-lb c4 4
-lb c3 8
+# BASELINE's shardings at full size, all ranks on this one GPU over the stream-asynchronous test transport
+TAG=$TAG bash tools/loopback_lines.sh "c5 2" "c4 4" "c3 8"
 fi

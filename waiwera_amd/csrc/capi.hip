@@ -238,6 +238,8 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
   {
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
+    int lds = 0;
+    if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0) c->lds_per_block = (size_t)lds;
   }
   HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(c, hipEventCreate(&c->ev0)); HIPCHK(c, hipEventCreate(&c->ev1));
@@ -989,6 +991,7 @@ int wai_pc_setup(wai_ctx* c) { return c ? do_pc_setup(c) : -2; }
 
 int wai_pc_apply(wai_ctx* c, const double* r, double* z) {
   if (!c || !r || !z) return -2;
+  read_env(c);
   if (!c->ilu.factored) { const int e = do_pc_setup(c); if (e) return e; }
   VecArg ri{c}, zo{c};
   if (ri.in(r, c->ks.n, 0) || zo.out_only(z, c->ks.n, 1)) return -1;

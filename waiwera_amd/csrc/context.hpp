@@ -342,6 +342,7 @@ int launch_lu_apply(wai_ctx* c, const double* r, double* z);
 struct wai_ctx {
   int device = 0;
   int n_cu = 256;               // compute units of the device (hipDeviceProp_t::multiProcessorCount)
+  size_t lds_per_block = 64 * 1024;   // LDS a workgroup may ask for (hipDeviceAttributeMaxSharedMemoryPerBlock; 160 KB on gfx950)
   hipStream_t stream = nullptr;
   int kind = 0, np = 0, df = 0;
   wai::EosParams ep{};
@@ -375,6 +376,9 @@ struct wai_ctx {
   // halo exchange overlapped with the preconditioned operator on the bricks that touch no ghost
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
+  // run-time switches of the fused launches, read from the environment once per solve / set-up / probe (read_env),
+  // not per launch: WAI_FIN_SEPARATE, WAI_PC_STAGGER (-1: each kernel's default), WAI_WAVE_ROWPTR
+  struct EnvSw { bool fin_separate = false; int stagger = -1; bool wave_rowptr = false; } env;
   int test_drop_wait = 0;   // fault injection (wai_test_drop_stream_wait): 1 the face bricks' launch does not wait for the halo
   // halo
   int n_nbr = 0;
@@ -470,6 +474,7 @@ int vec_zero(wai_ctx* c, double* dst, size_t n);
 int vec_waxpy(wai_ctx* c, double* w, double alpha, const double* x, const double* y, int n);
 int bcgs_scalars(wai_ctx* c, int phase, bool post = false);
 int bcgs_post(wai_ctx* c, int seq);
+void read_env(wai_ctx* c);   // the launch switches above (kernels_linalg.hip)
 int test_drop_partials(wai_ctx* c, int n);   // fault injection (tests): workgroup 0 loses its next n partial sums
 int bcgs_update_p(wai_ctx* c);
 int bcgs_update_s(wai_ctx* c);

@@ -274,6 +274,9 @@ template <int KIND> struct ResTile {
   using E = EosT<KIND>;
   static constexpr int nld = ParkT<KIND>::npark, nrk = 5;     // parked state record, rock: k1 k2 k3 wet dry
   static constexpr int lds_bytes = (nld + nrk) * 8 * TPB;
+  // the tile needs up to 72 KB (eos wsce / wsae): fine on gfx950's 160 KB, above the 64 KB a workgroup may have on older
+  // parts -- launch_residual then falls back to k_residual (as ParkT<>::use does for the Jacobian)
+  static bool use(const wai_ctx* c) { return (size_t)lds_bytes <= c->lds_per_block; }
 };
 template <int KIND>
 __global__ __launch_bounds__(TPB) void k_residual_tile(MeshView m, const double* __restrict__ flu,
@@ -1023,7 +1026,17 @@ int launch_residual(wai_ctx* c, double dt, const double* lhs_old, double* f, dou
   const MeshView m = view(c);
   const size_t stride = c->mesh.n_local;
   const char* et = getenv("WAI_RES_TILE");   // read per call: tests compare the two kernels in one process
-  if (!only && !(et && et[0] == '0')) {   // a full sweep: the workgroup's own cells staged in LDS
+  bool tile = !only && !(et && et[0] == '0');   // a full sweep: the workgroup's own cells staged in LDS
+#define RTU(K) tile = tile && ResTile<K>::use(c)
+  if (c->kind == EOS_W) RTU(EOS_W);
+  else if (c->kind == EOS_WE) RTU(EOS_WE);
+  else if (c->kind == EOS_WSE) RTU(EOS_WSE);
+  else if (c->kind == EOS_WAE) RTU(EOS_WAE);
+  else if (c->kind == EOS_WSCE) RTU(EOS_WSCE);
+  else if (c->kind == EOS_WSAE) RTU(EOS_WSAE);
+  else RTU(EOS_WCE);
+#undef RTU
+  if (tile) {
     const ResForm rf = res_form_of(c, dt, lhs_old);
     const int g = grid8_for(m.n_owned);
 #define RT(K) hipLaunchKernelGGL(k_residual_tile<K>, g, TPB, ResTile<K>::lds_bytes, c->stream, m, c->flu, stride, rf, f, lhs_out, rhs_out)
@@ -1035,10 +1048,13 @@ int launch_residual(wai_ctx* c, double dt, const double* lhs_old, double* f, dou
     else if (c->kind == EOS_WSAE) RT(EOS_WSAE);
     else RT(EOS_WCE);
 #undef RT
+    // a refused launch must not leave f / lhs / rhs stale in silence
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) { c->err = std::string("k_residual_tile: ") + hipGetErrorString(e); return -1; }
     return 0;
   }
   WAI_BY_EOS(c, k_residual, only ? grid_for(n_only) : grid8_for(m.n_owned), m, c->flu, stride,
              res_form_of(c, dt, lhs_old), f, lhs_out, rhs_out, only, n_only);
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) { c->err = std::string("k_residual: ") + hipGetErrorString(e); return -1; }
   return 0;
 }
 

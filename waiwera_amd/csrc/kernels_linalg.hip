@@ -799,7 +799,12 @@ __device__ __forceinline__ void sum_slice(unsigned long long* p0, int nb_max, in
             // still empty: the producer never stored it (waited out above: one bounded wait per thread, a launch that lost
             // a partial ends in seconds), or -- k_finalize, wait = false -- no producer ran before this consumer.  The sum
             // is a NaN either way; say why (code 4 reaches the host with the post)
-            if (u[s][k] == FIN_EMPTY) { gave_up = true; scal[S_BREAK] = 4.0; }
+            if (u[s][k] == FIN_EMPTY) {
+              // (agent scope, released: the finaliser that posts may be another workgroup on another XCD -- fin_block reads it the same way)
+              gave_up = true;
+              __hip_atomic_store(&scal[S_BREAK], 4.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            }
             __hip_atomic_store(p0 + (size_t)s * nb_max + i, FIN_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: the slot is empty again
             t[s] += __longlong_as_double((long long)u[s][k]);   // FIN_EMPTY itself is a NaN
           }
@@ -890,7 +895,7 @@ __device__ __forceinline__ bool fin_block(const Fin& f, const double* partials, 
       for (int s2 = 0; s2 < FIN_MAXS; s2++) {
         if (s2 < f.nslots) {
           if (t < f.nf) {
-            if (u[s2] == FIN_EMPTY) f.scal[S_BREAK] = 4.0;
+            if (u[s2] == FIN_EMPTY) __hip_atomic_store(&f.scal[S_BREAK], 4.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(q0 + (size_t)s2 * FIN_MAXF + t, FIN_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           const double v = __longlong_as_double((long long)u[s2]);
@@ -904,6 +909,9 @@ __device__ __forceinline__ bool fin_block(const Fin& f, const double* partials, 
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence_block();
+    // a finaliser that gave up on a partial said so at agent scope (sum_slice); it may have been another workgroup on
+    // another XCD, so the code is fetched past this XCD's L2 before derive_scalars / post_scalars read it plainly
+    if (__hip_atomic_load(&f.scal[S_BREAK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 4.0) f.scal[S_BREAK] = 4.0;
     if (f.phase >= 0) derive_scalars(f.scal, f.phase);
     if (f.seq > 0) post_scalars(f.scal, f.post, f.seq);
   }
@@ -1697,7 +1705,10 @@ __global__ __launch_bounds__(256) void k_pc_wave(
   const int g = xcd_remap(blockIdx.x, ngrp);
   if (g >= ngrp) return;
   int s = g * 4 + wave;
-  if (s >= nsub) return;          // wave-uniform: no workgroup barrier follows
+  // wave-uniform exit of a WHOLE wave ahead of the workgroup barriers of the reduction epilogue: s_barrier counts only
+  // the waves that have not terminated (CDNA ISA, "S_BARRIER": ended waves are not waited for), which this relies on;
+  // the epilogue reads the zeros such a wave left in wred above
+  if (s >= nsub) return;
   if (sub_list) s = sub_list[s];
   const int lo = sub_ptr[s], R = sub_ptr[s + 1] - lo;
   const int nl = sub_nlev[s];
@@ -2378,7 +2389,13 @@ int launch_lu_apply(wai_ctx* c, const double* r, double* z) {
   return 0;
 }
 
-static bool fin_separate() { return getenv("WAI_FIN_SEPARATE") != nullptr; }   // read per launch: tests switch it inside one process
+// the fused launches' run-time switches: read once per solve / set-up / probe (tests switch them between solves of one process)
+void read_env(wai_ctx* c) {
+  c->env.fin_separate = getenv("WAI_FIN_SEPARATE") != nullptr;
+  const char* es = getenv("WAI_PC_STAGGER");
+  c->env.stagger = es ? atoi(es) : -1;
+  c->env.wave_rowptr = getenv("WAI_WAVE_ROWPTR") != nullptr;
+}
 int bcgs_post(wai_ctx* c, int seq);
 static inline int pc_threads(const IluSchedule& s) { return ((s.max_rows + 63) / 64) * 64; }
 
@@ -2490,10 +2507,7 @@ static int pc_kernel_kind(const wai_ctx* c, const Bcsr& J, const IluSchedule& s)
 bool pc_axpy_capable(const wai_ctx* c) { return !c->ilu.big && pc_kernel_kind(c, c->J, c->ilu) != 0; }
 
 // ticks of the 100-MHz clock between the cohorts of a fused launch's first generation (stagger_start); WAI_PC_STAGGER overrides
-static int stagger_ticks(int dflt) {
-  const char* es = getenv("WAI_PC_STAGGER");
-  return es ? atoi(es) : dflt;
-}
+static int stagger_ticks(const wai_ctx* c, int dflt) { return c->env.stagger >= 0 ? c->env.stagger : dflt; }
 
 template <int BS>
 static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool spmv, const double* in, double* z,
@@ -2533,11 +2547,11 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
       const int* rp = (size_t)J.nnzb * 10 < (size_t)J.n * J.W * 9 ? J.rowptr : nullptr;   // > 10 % padding
 #define PCW(SP, AXV)                                                                                \
       hipLaunchKernelGGL((k_pc_wave<BS, SP, AXV>), gridw, 256, lds_w, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev, s.row_info, \
-                         s.row_uoffw, J.col, s.fval, s.dinv, in, in2, scal, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, list, rp, (getenv("WAI_WAVE_ROWPTR") ? nullptr : s.sub_split), per, pbase, fin, stagger)
+                         s.row_uoffw, J.col, s.fval, s.dinv, in, in2, scal, z, aux, c->ks.partials, c->ks.nb_max, dot_mode, list, rp, (c->env.wave_rowptr ? nullptr : s.sub_split), per, pbase, fin, stagger)
       Stagger stagger;
       stagger.ncu = c->n_cu;
       stagger.per_cu = std::max(1, (int)((size_t)160 * 1024 / (lds_w + 864)));
-      stagger.ticks = stagger_ticks(400);
+      stagger.ticks = stagger_ticks(c, 400);
       if (spmv) { if (in2) PCW(true, true); else PCW(true, false); }
       else PCW(false, false);
 #undef PCW
@@ -2569,7 +2583,7 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
       Stagger stagger;
       stagger.ncu = c->n_cu;
       stagger.per_cu = std::max(1, std::min(3, (int)((size_t)160 * 1024 / (lds_park + 704))));
-      stagger.ticks = stagger_ticks(600);
+      stagger.ticks = stagger_ticks(c, 600);
       if (spmv) { if (in2) PCP(true, true); else PCP(true, false); }
       else PCP(false, false);
 #undef PCP
@@ -2592,7 +2606,7 @@ int launch_pc_on(wai_ctx* c, const Bcsr& M, const IluSchedule& s, bool spmv, con
                  int dot_mode, const double* aux, const int* list, int nrun, const Fin* fin, const double* in2) {
   if (in2 && (!spmv || pc_kernel_kind(c, M, s) == 0)) { c->err = "composed input asked of a kernel that cannot form it"; return -1; }
   const Fin* fin_later = nullptr;
-  if (fin && dot_mode != 0 && fin_separate()) { fin_later = fin; fin = nullptr; }
+  if (fin && dot_mode != 0 && c->env.fin_separate) { fin_later = fin; fin = nullptr; }
   c->ks.nb_pc = s.nsub;   // partial sums per slot this application leaves: one per brick (k_pc_wave: per workgroup, set there)
   switch (M.bs) {
     case 1: launch_pc_bs<1>(c, M, s, spmv, in, z, dot_mode, aux, list, nrun, fin, in2); break;
@@ -2691,7 +2705,7 @@ int vec_dots(wai_ctx* c, const double* a1, const double* b1, int slot1, const do
   return 0;
 }
 int partials_clear(wai_ctx* c, int slot0, int nslots) {
-  const size_t tot = (size_t)nslots * c->ks.nb_max;
+  const size_t tot = (size_t)nslots * std::max(c->ks.nb_max, (int)FIN_MAXF);   // both arrays: the slices' sums too
   c->ks.n_launch++;
   hipLaunchKernelGGL(k_partials_clear, (int)((tot + TPB - 1) / TPB), TPB, 0, c->stream, c->ks.partials, c->ks.partials2, c->ks.nb_max, slot0, nslots);
   return 0;
@@ -2738,7 +2752,7 @@ int bcgs_update_xr(wai_ctx* c, bool dots, int fin_phase, bool post) {
   Fin fin;
   if (dots && fin_phase >= -1) { fin = make_fin(c, S_DP2, 2, fin_phase, post); fin.count = g; fin.nb = g; fin.nf = fin_slices(g); }
   c->ks.n_launch++;
-  if (dots && fin.count > 0 && fin_separate()) {
+  if (dots && fin.count > 0 && c->env.fin_separate) {
     Fin none;
     hipLaunchKernelGGL(k_bcgs_xr<true>, g, TPB, 0, c->stream, c->ks.X, c->ks.R, c->ks.P, c->ks.S, c->ks.T,
                        c->ks.RP, c->ks.n, c->ks.scal, c->ks.partials, c->ks.nb_max, none);

@@ -655,6 +655,7 @@ int ksp_bcgsl(wai_ctx* c, const double* b, double* x, int* its, int* reason, dou
 }
 
 int do_ksp(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
+  read_env(c);
   if (!c->ilu.factored) {
     const int e = do_pc_setup(c);
     if (e < 0) return -1;

@@ -17,6 +17,7 @@ extern "C" {
 // 9 / 10 = the fused kernel on the interior / face bricks only.
 int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
   if (!c || !ms_per_launch || reps <= 0) return -2;
+  read_env(c);
   if (which > 0 && !c->ilu.factored) { const int e = do_pc_setup(c); if (e) return e < 0 ? -1 : e; }
   Krylov& k = c->ks;
   auto run = [&]() {

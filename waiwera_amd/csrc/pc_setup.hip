@@ -576,6 +576,7 @@ int lu_setup(wai_ctx* c) {
 }
 
 int do_pc_setup(wai_ctx* c) {
+  read_env(c);
   if (c->opts.pc_type == WAI_PC_NONE) { c->ilu.factored = true; return 0; }
   if (c->opts.pc_type == WAI_PC_LU) {
     Prof p(c, KC_PC_SETUP);
