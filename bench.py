@@ -170,7 +170,7 @@ def traffic_from_profiles(cfg, dims, brick, kernel):
     collected and corrected as MI355X_MICROARCH.md prescribes, tools/pmc_traffic.py) -- counters cannot be collected
     inside this run.  Only taken when the profile was made on THIS mesh, THESE bricks and THE kernel this run's fused
     launch is (`kernel` = sim.pc_kernel_name()); a profile of another kernel is stale and gives null."""
-    for name in ("pmc_traffic_r4_%s.json" % cfg, "pmc_traffic_r3_%s.json" % cfg, "pmc_traffic_r2_%s.json" % cfg):
+    for name in ("pmc_traffic_r5_%s.json" % cfg, "pmc_traffic_r4_%s.json" % cfg, "pmc_traffic_r3_%s.json" % cfg, "pmc_traffic_r2_%s.json" % cfg):
         p = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(p):
             continue
@@ -180,6 +180,8 @@ def traffic_from_profiles(cfg, dims, brick, kernel):
             continue
         pk = str(d.get("k_pc_kernel", ""))
         same_kernel = bool(pk) and pk.replace("void ", "").replace("wai::", "").split("<")[0] == kernel.split("<")[0]
+        if "k_pc_park" in kernel:   # the 16-bit column indices (third template argument, round 5) change the launch's bytes
+            same_kernel = same_kernel and (("col16" in kernel) == (pk.count(",") == 2 and pk.rstrip().endswith("true>")))
         if list(d.get("dims", [])) == list(dims) and list(d.get("brick", [])) == list(brick) and same_kernel:
             return d.get("k_pc_hbm_bytes_per_launch"), ("profiles/%s (separate rocprofv3 --pmc passes of this command on kernel %s; "
                                                         "not measured in this run)" % (name, pk))
@@ -191,7 +193,8 @@ def traffic_from_profiles(cfg, dims, brick, kernel):
 CURVES = {"linear": {}, "corey": {"relperm": ("corey", [0.3, 0.05])}}
 
 
-def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0, gpu_state=None, minc=False, brick=None, curves=None):
+def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0, gpu_state=None, minc=False, brick=None, curves=None,
+                 gpu_first_kits=None):
     """The oracle (CPU restatement of the reference's path, OpenMP) timed on the SAME mesh and the same
     state the timed window starts from -- one Newton step, piece by piece: unperturbed residual, FD
     Jacobian (per-row differencing, and the reference's coloured MatFDColoring sweep when it fits the
@@ -300,6 +303,23 @@ def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0, gpu_s
             best, best_t = ti, t
     K = 8
     t_setup, t_iter = solve(best_t, K)
+    # The CPU's OWN Krylov count.  Its preconditioner is not the device's: one ILU(0) subdomain per thread (what `mpiexec -np T`
+    # gives the reference's block preconditioner) against the device's thousands of bricks, so it needs fewer iterations
+    # for the same system.  This system -- the window's first Newton step -- is solved to the reference's rtol 1e-5 with that
+    # preconditioner (bounded: about 25 s of iterations), and the CPU's count per Newton step is the device's window average
+    # scaled by (CPU iterations / device iterations) on this system.
+    own = None
+    cap = int(max(20, min(600, 25.0 / max(t_iter, 1e-9))))
+    if time.time() - t_all + cap * t_iter < 1.6 * budget_s:
+        xs[:] = 0.0
+        t0 = time.time()
+        reason = L.wo_ksp_solve(osim.h, 0, 30, ol.dp(J), ol.dp(f), ol.dp(xs), 1e-5, 1e-50, cap, C.byref(its), C.byref(rn), None)
+        t_own = time.time() - t0
+        own = {"krylov_iterations_this_system": int(its.value), "converged": bool(reason > 0), "reason": int(reason),
+               "seconds": t_own, "iteration_cap": cap, "subdomains": int(best_t),
+               "device_iterations_this_system": gpu_first_kits}
+        log("  cpu baseline: BiCGStab to rtol 1e-5 with %d ILU(0) subdomains on the window's first system: %d iterations "
+            "(reason %d, %.1f s); the device's bricks took %s" % (best_t, its.value, reason, t_own, gpu_first_kits))
     n_big = n
     osim.close()
     # The model's check, and the coloured sweep where it does not fit above: ONE WHOLE Newton step of the oracle
@@ -354,7 +374,13 @@ def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0, gpu_s
     except Exception as e:   # the validation must not take the baseline down with it
         log("  cpu baseline: whole-step validation failed: %r" % (e,))
     n = n_big
-    t_newton = t_res + t_jac + t_setup + kits_per_newton * t_iter
+    t_newton_gpu_count = t_res + t_jac + t_setup + kits_per_newton * t_iter
+    kits_cpu, count_note = kits_per_newton, "the count measured on the GPU trajectory"
+    if own and own["converged"] and gpu_first_kits:
+        kits_cpu = kits_per_newton * own["krylov_iterations_this_system"] / float(gpu_first_kits)
+        count_note = ("the GPU trajectory's %.1f x %d / %d: the CPU's own count with its %d-subdomain preconditioner on the window's "
+                      "first system over the device's on the same system" % (kits_per_newton, own["krylov_iterations_this_system"], gpu_first_kits, best_t))
+    t_newton = t_res + t_jac + t_setup + kits_cpu * t_iter
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -366,15 +392,19 @@ def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0, gpu_s
     sample = ("same mesh (%d cells), same state as the timed window's first Newton step, dt %.3g s: residual %.2f s, "
               "FD Jacobian %.2f s (per-row differencing%s), ILU(0) set-up %.2f s with one subdomain per thread, "
               "BiCGStab %.3f s/iteration over %d iterations; Newton step = residual + Jacobian + set-up + %.1f "
-              "iterations (the count measured on the GPU trajectory) x s/iteration = %.1f s; %d OpenMP threads "
+              "iterations (%s) x s/iteration = %.1f s; %d OpenMP threads "
               "(best Krylov iteration of %s; the container's CPU quota is %d CPUs) on %d hardware threads, %s"
               % (n, dt, t_res, t_jac, "; reference-style coloured sweeps %.2f s%s" % (t_col, col_note) if t_col else "", t_setup,
-                 t_iter, K, kits_per_newton, t_newton, best_t, "/".join(str(t) for t in trials), quota, avail, model))
+                 t_iter, K, kits_cpu, count_note, t_newton, best_t, "/".join(str(t) for t in trials), quota, avail, model))
     # "modelled": the Newton step is put together from pieces timed on this mesh and the GPU trajectory's
     # iteration count, not run as a whole
     out = {"value": 1.0 / t_newton, "unit": "Newton steps/s", "cores": best_t, "kind": "port, modelled", "sample": sample,
            "seconds": {"residual": t_res, "jacobian_per_row": t_jac, "jacobian_coloured": t_col, "pc_setup": t_setup,
                        "krylov_iteration": t_iter}}
+    out["krylov_iterations_per_newton_step"] = kits_cpu
+    out["value_with_gpu_iteration_count"] = 1.0 / t_newton_gpu_count
+    if own:
+        out["own_krylov_count"] = own
     if t_col:
         out["value_with_coloured_jacobian"] = 1.0 / (t_newton - t_jac + t_col)
     if whole:
@@ -629,6 +659,7 @@ def main():
     A = np.array([[1.0, r[3]] for r in timed])
     b = np.array([r[6] for r in timed])
     fixed_s, iter_s = (np.linalg.lstsq(A, b, rcond=None)[0] if len(timed) > 2 and np.ptp(A[:, 1]) > 0 else (0.0, 0.0))
+    k_med = float(np.median(A[:, 1])) if len(timed) else 0.0
 
     # Correctness gate (`check` in the line).  (i) the last accepted time step's convergence measure, as
     # SNES_convergence forms it; (ii) global balance of that step's discrete equations, per equation:
@@ -670,6 +701,7 @@ def main():
         del lhs1, rhs1, dl
     # the window's first state again: residual and Jacobian the oracle is compared with, and the matrix
     # the kernel microbenchmarks run on
+    gpu_first_kits = drv.log[n_lead][3] if len(drv.log) > n_lead and drv.log[n_lead][2] == 1 else None   # the device's Krylov count on the window's first system
     drv.restore(start)
     drv._begin()
     sim.jacobian(drv.t + drv.dt, drv.dt, y, drv.lhs_old)
@@ -752,6 +784,13 @@ def main():
             # Newton iterations of accepted time steps only / their time: what the window costs without the tries
             # that are thrown away
             "value_accepted_steps": (acc_n / acc_s) if acc_s > 0 else None,
+            # `value` divides by whatever Krylov counts the window's tries happened to take, and one failed try (a thousand-odd
+            # iterations, there or not depending on the rounding of an earlier step) moves it by tens of per cent.  The stable
+            # pair is (ms_fixed_per_newton_step, ms_per_krylov_iteration) of the least-squares fit over the timed steps;
+            # value_normalised is the Newton-step rate those two give at the window's MEDIAN Krylov count -- compare that
+            # between rounds and boxes
+            "value_normalised": (1.0 / (fixed_s + k_med * iter_s)) if iter_s > 0 else None,
+            "value_normalised_at_krylov_iterations": k_med,
             "accepted_newton_steps": acc_n,
             "check": check,
             "device_state_after_timed_region": dev_state,
@@ -793,7 +832,8 @@ def main():
         if not a.no_cpu and world == 1:   # the CPU baseline is a single-GPU-run item
             try:
                 cb = cpu_baseline(lm, eos, start["y"].cpu().numpy(), start["regions"], start["dt"],
-                                  kits / max(a.steps, 1), gpu_state=gpu_state, minc=minc, brick=brick, curves=CURVES[a.curves])
+                                  kits / max(a.steps, 1), gpu_state=gpu_state, minc=minc, brick=brick, curves=CURVES[a.curves],
+                                  gpu_first_kits=gpu_first_kits)
             except Exception as e:   # the reported baseline must not take the measurement down with it
                 log("cpu baseline failed: %r" % (e,))
                 cb = None

@@ -1,0 +1,14 @@
+mkdir -p gpurun_out
+: > gpurun_out/compose_full_r5.log
+for r in 1 2; do
+for v in 0 1; do
+  for cfg in "--config c3" "--rank-share 8" "--config c2"; do
+    echo "== round $r COMPOSE=$v $cfg" >> gpurun_out/compose_full_r5.log
+    WAI_BCGS_COMPOSE=$v python bench.py $cfg --steps 12 --warmup 3 --no-cpu --spmv-reps 50 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); c = d['config']
+print('value %.3f norm %s its/step %.1f ms/it %.4f fixed %.2f dev-only %s' % (d['value'], d.get('value_normalised'), c['krylov_iterations_per_newton_step'], c['ms_per_krylov_iteration'], c['ms_fixed_per_newton_step'], c.get('ms_per_krylov_iteration_device_only')))" >> gpurun_out/compose_full_r5.log
+  done
+done
+done
+cat gpurun_out/compose_full_r5.log

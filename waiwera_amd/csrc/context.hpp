@@ -214,6 +214,12 @@ struct IluSchedule {
   bool wave_kernel = false;   // k_pc_wave (one wave per brick of <= 64 block rows) applies and is selected
   int* row_uoffw = nullptr;   // first parked upper block of a row inside its subdomain, all (<= 4) uppers counted
   int max_ublocks_w = 0;
+  // Brick-local 16-bit column indices for k_pc_park (2 x 2 blocks): entry = segment << 13 | offset, column = the brick's
+  // sub_seg[segment] + offset.  Segment 0 starts at the brick's own first row; the others cover what its rows reach in
+  // other bricks and among the ghost columns, windows of 8192 columns each (a 16 x 16 x 2 brick of a structured mesh:
+  // its six neighbour bricks).  Null when some brick would need more than 8 segments: the int32 planes serve then.
+  unsigned short* col16 = nullptr;   // [n][8]: the (<= 8) slots of a row together, 16 bytes -- one load per row instead of one per slot
+  int* sub_seg = nullptr;            // [nsub][8]
   bool level_sorted = false;  // every subdomain's rows are stored in dependency-level order (forward levels non-decreasing,
                               // backward levels non-increasing with the row index)
   bool factored = false;
@@ -377,8 +383,8 @@ struct wai_ctx {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
   // run-time switches of the fused launches, read from the environment once per solve / set-up / probe (read_env),
-  // not per launch: WAI_FIN_SEPARATE, WAI_PC_STAGGER (-1: each kernel's default), WAI_WAVE_ROWPTR
-  struct EnvSw { bool fin_separate = false; int stagger = -1; bool wave_rowptr = false; } env;
+  // not per launch: WAI_FIN_SEPARATE, WAI_PC_STAGGER (-1: each kernel's default), WAI_WAVE_ROWPTR, WAI_NO_COL16 (k_pc_park on the int32 column planes)
+  struct EnvSw { bool fin_separate = false; int stagger = -1; bool wave_rowptr = false; bool no_col16 = false; } env;
   int test_drop_wait = 0;   // fault injection (wai_test_drop_stream_wait): 1 the face bricks' launch does not wait for the halo
   // halo
   int n_nbr = 0;
@@ -442,6 +448,7 @@ int launch_pc_on(wai_ctx* c, const Bcsr& M, const IluSchedule& s, bool spmv, con
                  int dot_mode, const double* aux, const int* list = nullptr, int nrun = 0, const Fin* fin = nullptr,
                  const double* in2 = nullptr);
 bool pc_axpy_capable(const wai_ctx* c);
+bool pc_axpy_default(const wai_ctx* c);   // is the composed second launch the default for the kernel in force (k_pc_park with col16)
 // subdomains of any size: level-by-level launches, in place on z (z = r on entry)
 int launch_big_solve(wai_ctx* c, const Bcsr& M, const IluSchedule& s, double* z);
 int launch_asm_gather_matrix(wai_ctx* c);                   // E.val <- J.val (and the ghost cells' rows; + the network's blocks)

@@ -1315,10 +1315,17 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
 // Same bits, and SLOWER on every size: fused launch 0.6175 against 0.5904 ms at 216^3, 0.0960 / 0.0892 at 108^3,
 // 0.0839 / 0.0766 at 100^3 (same box, profiles/bench_r4_wavestage_ab.log): a level's cost is its LDS round trip and FMA
 // chain, not the barrier, and the per-level barriers let the two waves that share a level run it side by side.
-template <bool SPMV, bool AX>
+// C16 (round 5): the column indices come as brick-local 16-bit (segment, offset) pairs (IluSchedule::col16, sub_seg), a
+// row's eight together: ONE 16-byte load per row instead of seven 4-byte loads from seven planes (16 instead of 28 bytes,
+// and six vector-memory instructions fewer of a row's ~28); the eight segment bases of the brick are wave-uniform (scalar
+// loads) and the lane's pick among them a chain of selects.  Same columns, same order, same bits.
+// (First form, one 16-bit plane per slot: 2 bytes less per block but the same seven loads -- MEASURED no faster: fused
+// launch 0.0845 -> 0.0859 ms at 108^3, 0.584 -> 0.581 at 216^3, profiles/col16_planes_ab_r5.log.)
+template <bool SPMV, bool AX, bool C16>
 __global__ __launch_bounds__(512, 6) void k_pc_park(
     int n, int W, int nsub, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev,
     const int* __restrict__ row_info, const int* __restrict__ row_uoff, const int* __restrict__ col,
+    const unsigned short* __restrict__ col16, const int* __restrict__ sub_seg,
     const double* __restrict__ sval, const double* __restrict__ dinv, const double* __restrict__ in,
     const double* __restrict__ in2, const double* __restrict__ scal,
     double* __restrict__ z, const double* __restrict__ aux, double* partials, int nb_max, int dot,
@@ -1361,10 +1368,29 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
     // in flight, needs more than the 80 registers of 6 waves per SIMD: 188 bytes of scratch, 0.965 ms;
     // fetching the next slot's block while the current one is used (80 registers, no scratch): 0.626 against 0.614
     int cgs[WMAX];
+    if constexpr (C16) {
+      const int* sg = sub_seg + (size_t)s * 8;     // wave-uniform
+      const int g0 = sg[0], g1 = sg[1], g2 = sg[2], g3 = sg[3], g4 = sg[4], g5 = sg[5], g6 = sg[6], g7 = sg[7];
+      typedef unsigned wai_u4v __attribute__((ext_vector_type(4)));
+      const wai_u4v pk = __builtin_nontemporal_load(reinterpret_cast<const wai_u4v*>(col16) + i);   // the row's eight 16-bit entries
+      const unsigned pw[4] = {pk.x, pk.y, pk.z, pk.w};
+      unsigned cu[WMAX];
 #pragma unroll
-    for (int q = 0; q < WMAX; q++) {
-      cgs[q] = i;
-      if (q < W) cgs[q] = load_col(col, (size_t)q * n + i);
+      for (int q = 0; q < WMAX; q++) cu[q] = (pw[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+#pragma unroll
+      for (int q = 0; q < WMAX; q++) {
+        const unsigned code = cu[q] >> 13;
+        int b = g0;
+        b = code == 1 ? g1 : b; b = code == 2 ? g2 : b; b = code == 3 ? g3 : b; b = code == 4 ? g4 : b;
+        b = code == 5 ? g5 : b; b = code == 6 ? g6 : b; b = code == 7 ? g7 : b;
+        cgs[q] = q < W ? b + (int)(cu[q] & 8191u) : i;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < WMAX; q++) {
+        cgs[q] = i;
+        if (q < W) cgs[q] = load_col(col, (size_t)q * n + i);
+      }
     }
 #pragma unroll
     for (int q = 0; q < WMAX; q++) {
@@ -2395,6 +2421,7 @@ void read_env(wai_ctx* c) {
   const char* es = getenv("WAI_PC_STAGGER");
   c->env.stagger = es ? atoi(es) : -1;
   c->env.wave_rowptr = getenv("WAI_WAVE_ROWPTR") != nullptr;
+  c->env.no_col16 = getenv("WAI_NO_COL16") != nullptr;
 }
 int bcgs_post(wai_ctx* c, int seq);
 static inline int pc_threads(const IluSchedule& s) { return ((s.max_rows + 63) / 64) * 64; }
@@ -2505,6 +2532,7 @@ static int pc_kernel_kind(const wai_ctx* c, const Bcsr& J, const IluSchedule& s)
   return 0;
 }
 bool pc_axpy_capable(const wai_ctx* c) { return !c->ilu.big && pc_kernel_kind(c, c->J, c->ilu) != 0; }
+bool pc_axpy_default(const wai_ctx* c) { return !c->ilu.big && pc_kernel_kind(c, c->J, c->ilu) == 1 && c->ilu.col16 && !c->env.no_col16; }
 
 // ticks of the 100-MHz clock between the cohorts of a fused launch's first generation (stagger_start); WAI_PC_STAGGER overrides
 static int stagger_ticks(const wai_ctx* c, int dflt) { return c->env.stagger >= 0 ? c->env.stagger : dflt; }
@@ -2576,10 +2604,11 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
     // upper blocks parked in LDS: three resident workgroups per CU
     if (kind == 1) {
       const size_t lds_park = lds + (size_t)s.max_ublocks * 4 * sizeof(double);
-#define PCP(SP, AXV)                                                                               \
-      hipLaunchKernelGGL((k_pc_park<SP, AXV>), grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,  \
-                         s.row_info, s.row_uoff, J.col, s.fval, s.dinv, in, in2, scal, z, aux, c->ks.partials,       \
+#define PCP2(SP, AXV, C16V)                                                                        \
+      hipLaunchKernelGGL((k_pc_park<SP, AXV, C16V>), grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,  \
+                         s.row_info, s.row_uoff, J.col, s.col16, s.sub_seg, s.fval, s.dinv, in, in2, scal, z, aux, c->ks.partials, \
                          c->ks.nb_max, dot_mode, list, fin, stagger)
+#define PCP(SP, AXV) do { if (s.col16 && !c->env.no_col16) PCP2(SP, AXV, true); else PCP2(SP, AXV, false); } while (0)
       Stagger stagger;
       stagger.ncu = c->n_cu;
       stagger.per_cu = std::max(1, std::min(3, (int)((size_t)160 * 1024 / (lds_park + 704))));
@@ -2587,6 +2616,7 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
       if (spmv) { if (in2) PCP(true, true); else PCP(true, false); }
       else PCP(false, false);
 #undef PCP
+#undef PCP2
       return;
     }
   }

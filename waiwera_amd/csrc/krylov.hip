@@ -215,9 +215,14 @@ int bcgs_mode(const wai_ctx* c) {
   return mode;
 }
 // does the second fused launch form S itself?  (asked for, the fused brick kernels, no network blocks beside the matrix)
+// Default since round 5 for the 2 x 2 kernel (k_pc_park): with a row's column indices in ONE 16-byte load (col16) the
+// composed operand's second gather per slot no longer costs more than k_bcgs_s saves -- MEASURED end to end on one box
+// (profiles/compose_full_ab_r5.log; identical Krylov counts): ms per iteration C3 1.537 -> 1.455, the 108^3 rank
+// share 0.2192 -> 0.2127, C2 0.1946 -> 0.1897.  WAI_BCGS_COMPOSE=0 / 1 forces it off / on (3 x 3 kernels: on request).
 bool pc_axpy_ok(const wai_ctx* c) {
-  const char* e = getenv("WAI_BCGS_COMPOSE");
-  return e && e[0] == '1' && pc_fused(c) && !c->net.cp_valid && pc_axpy_capable(c);
+  if (!(pc_fused(c) && !c->net.cp_valid && pc_axpy_capable(c))) return false;
+  if (const char* e = getenv("WAI_BCGS_COMPOSE")) return e[0] == '1';
+  return pc_axpy_default(c);
 }
 
 BcgsPlan bcgs_plan(const wai_ctx* c) {

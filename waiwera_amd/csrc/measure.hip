@@ -91,7 +91,8 @@ const char* wai_pc_kernel_name(wai_ctx* c) {
   if (s.big) return "k_spmv + k_lvl_solve per level";
   if (s.wave_kernel) { static thread_local char b4[64]; snprintf(b4, sizeof(b4), "k_pc_wave<%d,spmv>", c->J.bs); return b4; }
   if (s.rows_kernel) { static thread_local char b2[64]; snprintf(b2, sizeof(b2), "k_pc_rows<%d,spmv,%d+%d>", c->J.bs, s.max_nlu <= 3 ? 3 : 4, s.max_nlu <= 3 ? 3 : 4); return b2; }
-  if (c->J.bs == 2 && s.park && s.diag_only && s.scaled && s.fast3 && s.max_rows <= 512) return "k_pc_park<spmv>";
+  if (c->J.bs == 2 && s.park && s.diag_only && s.scaled && s.fast3 && s.max_rows <= 512)
+    return s.col16 && !getenv("WAI_NO_COL16") ? "k_pc_park<spmv,col16>" : "k_pc_park<spmv>";
   static thread_local char buf[96];
   snprintf(buf, sizeof(buf), "k_pc<%d,spmv,%s,%s>", c->J.bs, s.diag_only ? (s.scaled ? "dilu-scaled" : "dilu") : "ilu",
            s.fast3 ? "compact3" : "generic");

@@ -244,12 +244,62 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
     }
     if (any && dev_upload(c, &s.sub_split, split)) return -1;
   }
+  if (np == 2 && W <= 8 && !s.big && s.park && s.diag_only && s.scaled && s.fast3 && s.max_rows <= 512) {
+    // k_pc_park will serve: its column indices as 16-bit (segment, offset) pairs -- 14 of a row's 304 bytes less per launch
+    std::vector<unsigned short> c16((size_t)8 * N, 0);      // [row][8]: a row's indices are ONE 16-byte load
+    std::vector<int> seg((size_t)s.nsub * 8, 0);
+    std::vector<int> far;
+    bool ok = true;
+    for (int sd = 0; sd < s.nsub && ok; sd++) {
+      const int lo = sub[sd], hi = sub[sd + 1];
+      far.clear();
+      for (int i = lo; i < hi; i++)
+        for (int q = rowptr[i]; q < rowptr[i + 1]; q++)
+          if (colidx[q] < lo || colidx[q] >= hi) far.push_back(colidx[q]);
+      std::sort(far.begin(), far.end());
+      far.erase(std::unique(far.begin(), far.end()), far.end());
+      int* sg = seg.data() + (size_t)sd * 8;
+      int nseg = 1;
+      sg[0] = lo;
+      for (size_t k = 0; k < far.size();) {      // windows of 8192 columns over what the brick reaches outside itself
+        if (nseg == 8) { ok = false; break; }
+        const int base = far[k];
+        sg[nseg++] = base;
+        while (k < far.size() && far[k] - base < 8192) k++;
+      }
+      for (int i = lo; i < hi && ok; i++) {
+        const int cnt = rowptr[i + 1] - rowptr[i];
+        for (int q = 0; q < W; q++) {
+          const int cg = q < cnt ? colidx[rowptr[i] + q] : i;      // padding: the own column (a zero block), as Bcsr::col has it
+          int sgi = 0;
+          if (cg < lo || cg >= hi) {
+            sgi = nseg - 1;
+            while (sgi > 0 && !(cg >= sg[sgi] && cg - sg[sgi] < 8192)) sgi--;
+            if (sgi == 0) { ok = false; break; }
+          }
+          c16[(size_t)i * 8 + q] = (unsigned short)((sgi << 13) | (cg - sg[sgi]));
+        }
+      }
+    }
+#ifdef WAI_NO_COL16
+    ok = false;            // A/B builds: the int32 planes everywhere
+#endif
+    if (ok) {
+      if (hipMalloc(reinterpret_cast<void**>(&s.col16), c16.size() * sizeof(unsigned short)) != hipSuccess ||
+          hipMemcpy(s.col16, c16.data(), c16.size() * sizeof(unsigned short), hipMemcpyHostToDevice) != hipSuccess) {
+        c->err = "hipMalloc of the 16-bit column indices failed";
+        return -1;
+      }
+      if (dev_upload(c, &s.sub_seg, seg)) return -1;
+    }
+  }
   s.built = true;
   s.factored = false;
   return 0;
 }
 
 void free_schedule(IluSchedule& s) {
+  hipFree(s.col16); hipFree(s.sub_seg);
   hipFree(s.sub_ptr); hipFree(s.sub_nlev); hipFree(s.sub_split); hipFree(s.row_info); hipFree(s.fval); hipFree(s.dinv);
   hipFree(s.row_uoff); hipFree(s.row_uoffw); hipFree(s.row_tslot); hipFree(s.sub_order); hipFree(s.sub_int); hipFree(s.sub_bnd); hipFree(s.ord_f); hipFree(s.ord_b);
   s = IluSchedule();
