@@ -372,9 +372,9 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
   if (dev_upload(c, &m.adj_face, adj_face) || dev_upload(c, &m.adj_other, adj_other) ||
       dev_upload(c, &m.adj_blk, adj_blk) || dev_upload(c, &m.diag_blk, diag) ||
       dev_upload(c, &J.rowptr, J.h_rowptr) || dev_upload(c, &J.col, ell_col) ||
-      dev_alloc(c, &J.val, (size_t)J.W * np * np * ell_rows(np, N)))
+      dev_alloc(c, &J.val, ell_size(np, N, J.W)))
     return -1;
-  HIPCHK(c, hipMemset(J.val, 0, sizeof(double) * (size_t)J.W * np * np * ell_rows(np, N)));
+  HIPCHK(c, hipMemset(J.val, 0, sizeof(double) * ell_size(np, N, J.W)));
   {
     std::vector<int> cs(N, -1);
     if (dev_upload(c, &m.cell_src, cs)) return -1;

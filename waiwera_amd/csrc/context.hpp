@@ -34,20 +34,41 @@ __host__ __device__ __forceinline__ size_t ell_rows(int bs, size_t n) {
 #endif
   return n;
 }
-// Block sizes >= 3, inside a slot: the bs^2 elements of 64 consecutive block rows together -- element e of rows
-// 64 g .. 64 g + 63 at ((g bs^2 + e) 64 + row % 64) of the slot's bs^2 ld doubles -- so that the nine (sixteen) loads a wave
-// makes for one slot are ONE run of 4.6 (8) KB and a slot is one stream instead of nine planes 40 MB apart.  MEASURED on
-// the SpMV alone (tools/micro/spmv3_variants.hip, C4's mesh, six processes): 74.8-75.0 % of HBM peak against the planes'
-// 72.4-72.7 % (82.0 against 80.1 % in the two processes that landed well); slices over ALL slots (SELL-64: 75.9 / 83.0 %)
-// would need the slot count in here.  -DWAI_ELL_PLANES builds one plane per element.
+// Block sizes >= 3: SELL-64 in slices of eight slots (round 5).  The bs^2 elements of 64 consecutive block rows of slot s
+// sit together (rounds 4's per-slot form), and the (up to) eight slots of those 64 rows follow one another: everything a
+// wave reads of its 64 rows -- 7 slots x 9 elements x 512 B = 32 KB for the 7-point stencil of 3 x 3 blocks -- is ONE
+// contiguous run (the eighth slot's 4.6 KB are a hole nobody reads), where the per-slot form had seven streams 360 MB
+// apart and the element planes of rounds 2-3 sixty-three.  What the memory channels make of many concurrent streams
+// depends on where the allocation lands: C4's k_spmv<3> ran at 64 % of HBM peak on one box and 74-76 % on others, and
+// between 72.6 and 85.5 % in eight processes on one box; SELL-64 measured 76.0 % in ten processes out of ten
+// (tools/micro/spmv3_variants.hip, profiles/spmv3_variants_r4.log).  Slot s of block row i, element e = r bs + k:
+//     (s / 8) * 8 bs^2 ld  +  (((i / 64) * 8 + s % 8) * bs^2 + e) * 64  +  i % 64,      ld = ell_ld(n)
+// so wider systems (ILU(k) fill: W > 8) take further slices of eight.  An array of ONE block per row (the inverted
+// pivots) keeps the per-slot form through ell_ix1.  Arrays indexed through ell_ix are allocated with ell_size doubles.
+// -DWAI_ELL_SLOTWISE builds round 4's per-slot form, -DWAI_ELL_PLANES one plane per element.
+__host__ __device__ __forceinline__ size_t ell_ix1(int bs, size_t n, int r, int k, size_t i) {
+#ifndef WAI_ELL_ROWS
+  if (bs >= 3) {
+#ifdef WAI_ELL_PLANES
+    return ((size_t)(r * bs + k)) * ell_ld(n) + i;
+#else
+    return ((i >> 6) * (size_t)(bs * bs) + (size_t)(r * bs + k)) * 64 + (i & 63);
+#endif
+  }
+#endif
+  return ((size_t)r * n + i) * bs + k;
+}
 __host__ __device__ __forceinline__ size_t ell_ix(int bs, size_t n, int s, int r, int k, size_t i) {
 #ifndef WAI_ELL_ROWS
   if (bs >= 3) {
 #ifdef WAI_ELL_PLANES
     return ((size_t)((s * bs + r) * bs + k)) * ell_ld(n) + i;
-#else
+#elif defined(WAI_ELL_SLOTWISE)
     const size_t bb = (size_t)(bs * bs);
     return (size_t)s * bb * ell_ld(n) + ((i >> 6) * bb + (size_t)(r * bs + k)) * 64 + (i & 63);
+#else
+    const size_t bb = (size_t)(bs * bs);
+    return (size_t)(s >> 3) * 8 * bb * ell_ld(n) + ((((i >> 6) << 3) + (size_t)(s & 7)) * bb + (size_t)(r * bs + k)) * 64 + (i & 63);
 #endif
   }
 #endif
@@ -55,6 +76,13 @@ __host__ __device__ __forceinline__ size_t ell_ix(int bs, size_t n, int s, int r
   // fused launch 0.5326 / 0.5406 / 0.5387 against 0.5409 / 0.5713 / 0.5388 ms, the 108^3 share 0.0826 against 0.0820;
   // profiles/group2_ab_r4.log -- two planes per slot are few enough)
   return ((size_t)(s * bs + r) * n + i) * bs + k;
+}
+// doubles of a W-slot array indexed through ell_ix
+__host__ __device__ __forceinline__ size_t ell_size(int bs, size_t n, int W) {
+#if !defined(WAI_ELL_ROWS) && !defined(WAI_ELL_PLANES) && !defined(WAI_ELL_SLOTWISE)
+  if (bs >= 3) return (size_t)((W + 7) / 8) * 8 * bs * bs * ell_ld(n);
+#endif
+  return (size_t)W * bs * bs * ell_rows(bs, n);
 }
 
 enum KClass { KC_EOS = 0, KC_RESIDUAL = 1, KC_JACOBIAN = 2, KC_SPMV = 3, KC_PC_APPLY = 4,

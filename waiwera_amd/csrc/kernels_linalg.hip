@@ -109,6 +109,11 @@ template <int BS>
 __device__ __forceinline__ size_t vix(int n, int s, int e, int i) {
   return ell_ix(BS, (size_t)n, s, e / BS, e % BS, (size_t)i);
 }
+// element e of block row i in an array of ONE block per row (the inverted pivots)
+template <int BS>
+__device__ __forceinline__ size_t dix(int n, int e, int i) {
+  return ell_ix1(BS, (size_t)n, e / BS, e % BS, (size_t)i);
+}
 // load the BS x BS block (slot s, block row i) into b[].  The matrix (values, column indices) is
 // read once per launch and the result vector written once: these streams carry the non-temporal
 // hint so that they do not evict the vector segments the neighbour gathers want to find in L2
@@ -146,6 +151,16 @@ __device__ __forceinline__ void load_block(const double* __restrict__ val, int n
   } else {
 #pragma unroll
     for (int e = 0; e < BS * BS; e++) b[e] = val[vix<BS>(n, s, e, i)];
+  }
+}
+
+// the block of row i in an array of one block per row (the inverted pivots: ell_ix1)
+template <int BS>
+__device__ __forceinline__ void load_pivot(const double* __restrict__ val, int n, int i, double* b) {
+  if constexpr (BS <= 2) load_block<BS>(val, n, 0, i, b);
+  else {
+#pragma unroll
+    for (int e = 0; e < BS * BS; e++) b[e] = val[dix<BS>(n, e, i)];
   }
 }
 
@@ -385,7 +400,7 @@ __global__ void k_ilu_factor(int n, int nsub, const int* __restrict__ sub_ptr,
 #pragma unroll
       for (int z = 0; z < BB; z++) {
         fval[vix<BS>(n, dslot, z, i)] = inv[z];
-        dinv[vix<BS>(n, 0, z, i)] = inv[z];
+        dinv[dix<BS>(n, z, i)] = inv[z];
       }
     }
     __threadfence_block();
@@ -495,7 +510,7 @@ __global__ void k_dilu_pivots(int n, int nsub, const int* __restrict__ sub_ptr,
 #pragma unroll
       for (int e = 0; e < BB; e++) {
         pinv[(size_t)tid * BB + e] = inv[e];
-        dinv[vix<BS>(n, 0, e, i)] = inv[e];
+        dinv[dix<BS>(n, e, i)] = inv[e];
       }
     }
     __syncthreads();
@@ -598,7 +613,7 @@ __global__ __launch_bounds__(256) void k_dilu_pivots_lds(int n, int nsub, int ca
 #pragma unroll
       for (int e = 0; e < BB; e++) {
         pinv[(size_t)e * cap + tid] = inv[e];
-        dinv[vix<BS>(n, 0, e, i)] = inv[e];
+        dinv[dix<BS>(n, e, i)] = inv[e];
       }
     }
     __syncthreads();
@@ -618,7 +633,7 @@ __global__ __launch_bounds__(TPB) void k_scale_rows(int n, int W, const double* 
   const int i = blockIdx.x * TPB + threadIdx.x;
   if (i >= n) return;
   double d[BB];
-  load_block<BS>(dinv, n, 0, i, d);
+  load_pivot<BS>(dinv, n, i, d);
   for (int q = 0; q < W; q++) {
     double a[BB];
     load_block<BS>(aval, n, q, i, a);
@@ -1066,9 +1081,9 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
       }
       if constexpr (!SPMV) load_x<BS>(in, i, acc);
       if (dot == 2 || dot == 4) load_x<BS>(in, i, xin);
-      if constexpr (!SC) load_block<BS>(dinv, n, 0, i, dv);
+      if constexpr (!SC) load_pivot<BS>(dinv, n, i, dv);
       if constexpr (SC && !SPMV) {  // plain application to an unscaled vector: scale it first
-        load_block<BS>(dinv, n, 0, i, dv);
+        load_pivot<BS>(dinv, n, i, dv);
         double w0[BS];
 #pragma unroll
         for (int r = 0; r < BS; r++) {
@@ -1423,7 +1438,7 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
     if constexpr (!SPMV) {  // plain application to an unscaled vector: scale it by the inverted pivot
       double r[BS], dv[BB];
       load_x<BS>(in, i, r);
-      load_block<BS>(dinv, n, 0, i, dv);
+      load_pivot<BS>(dinv, n, i, dv);
       acc[0] = dv[0] * r[0] + dv[1] * r[1];
       acc[1] = dv[2] * r[0] + dv[3] * r[1];
     }
@@ -1613,7 +1628,7 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? 8 : (BS == 3 ? (NL <= 3 ? 7 : 5) :
     }
     if constexpr (!SPMV) {  // plain application to an unscaled vector: scale it by the inverted pivot
 #pragma unroll
-      for (int k = 0; k < BS; k++) acc += dinv[ell_ix(BS, (size_t)n, 0, r, k, (size_t)i)] * in[(size_t)i * BS + k];
+      for (int k = 0; k < BS; k++) acc += dinv[ell_ix1(BS, (size_t)n, r, k, (size_t)i)] * in[(size_t)i * BS + k];
     }
     ys[il * BS + r] = acc;
   }
@@ -1825,7 +1840,7 @@ __global__ __launch_bounds__(256) void k_pc_wave(
 #pragma unroll
       for (int r = 0; r < BS; r++)
 #pragma unroll
-        for (int k = 0; k < BS; k++) acc[r] += dinv[vix<BS>(n, 0, r * BS + k, i)] * in[(size_t)i * BS + k];
+        for (int k = 0; k < BS; k++) acc[r] += dinv[dix<BS>(n, r * BS + k, i)] * in[(size_t)i * BS + k];
     }
 #pragma unroll
     for (int r = 0; r < BS; r++) ys[lane * BS + r] = acc[r];
@@ -2231,7 +2246,7 @@ __global__ __launch_bounds__(TPB) void k_lvl_factor(int n, int cnt, const int* _
     unpack_info_wide(row_info[k], kl, kd, ku);
     double w[BB], d[BB], tt[BB];
 #pragma unroll
-    for (int z = 0; z < BB; z++) { w[z] = fval[vix<BS>(n, q, z, i)]; d[z] = dinv[vix<BS>(n, 0, z, k)]; }
+    for (int z = 0; z < BB; z++) { w[z] = fval[vix<BS>(n, q, z, i)]; d[z] = dinv[dix<BS>(n, z, k)]; }
 #pragma unroll
     for (int r = 0; r < BS; r++)
 #pragma unroll
@@ -2268,7 +2283,7 @@ __global__ __launch_bounds__(TPB) void k_lvl_factor(int n, int cnt, const int* _
   for (int z = 0; z < BB; z++) piv[z] = fval[vix<BS>(n, dslot, z, i)];
   if (!block_inverse<BS>(piv, inv)) atomicMax(&flags[0], 1);
 #pragma unroll
-  for (int z = 0; z < BB; z++) dinv[vix<BS>(n, 0, z, i)] = inv[z];
+  for (int z = 0; z < BB; z++) dinv[dix<BS>(n, z, i)] = inv[z];
 }
 
 // forward (FWD): y_i = t_i - sum_{k < i} L_ik y_k; backward: x_i = inv(D_i) (y_i - sum_{j > i} U_ij x_j); in place
@@ -2303,7 +2318,7 @@ __global__ __launch_bounds__(TPB) void k_lvl_solve(int n, int cnt, const int* __
   } else {
     double d[BB];
 #pragma unroll
-    for (int e = 0; e < BB; e++) d[e] = dinv[vix<BS>(n, 0, e, i)];
+    for (int e = 0; e < BB; e++) d[e] = dinv[dix<BS>(n, e, i)];
 #pragma unroll
     for (int r = 0; r < BS; r++) {
       double o = 0.0;
@@ -2429,7 +2444,7 @@ static inline int pc_threads(const IluSchedule& s) { return ((s.max_rows + 63) /
 int launch_ilu_factor_on(wai_ctx* c, const Bcsr& J, IluSchedule& s) {
   if (s.big) {
     // one launch per forward level; the factor starts as a copy of the matrix
-    hipMemcpyAsync(s.fval, J.val, sizeof(double) * (size_t)J.W * J.bs * J.bs * ell_rows(J.bs, J.n), hipMemcpyDeviceToDevice, c->stream);
+    hipMemcpyAsync(s.fval, J.val, sizeof(double) * ell_size(J.bs, J.n, J.W), hipMemcpyDeviceToDevice, c->stream);
     for (int lev = 0; lev < s.nlev_f; lev++) {
       const int a = s.lev_f_ptr[lev], cnt = s.lev_f_ptr[lev + 1] - a, g = (cnt + TPB - 1) / TPB;
       if (cnt <= 0) continue;
@@ -2479,7 +2494,7 @@ int launch_ilu_factor_on(wai_ctx* c, const Bcsr& J, IluSchedule& s) {
       default: return -1;
     }
   } else {
-    hipMemcpyAsync(s.fval, J.val, sizeof(double) * (size_t)J.W * J.bs * J.bs * ell_rows(J.bs, J.n), hipMemcpyDeviceToDevice, c->stream);
+    hipMemcpyAsync(s.fval, J.val, sizeof(double) * ell_size(J.bs, J.n, J.W), hipMemcpyDeviceToDevice, c->stream);
     switch (J.bs) {
       case 1: hipLaunchKernelGGL(k_ilu_factor<1>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;
       case 2: hipLaunchKernelGGL(k_ilu_factor<2>, grid, T, 0, c->stream, J.n, s.nsub, s.sub_ptr, s.sub_nlev, s.row_info, J.col, s.fval, s.dinv, c->d_flags); break;

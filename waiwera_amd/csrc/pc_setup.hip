@@ -169,7 +169,7 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
   }
   if (dev_upload(c, &s.sub_ptr, sub) || dev_upload(c, &s.sub_nlev, nlev) || dev_upload(c, &s.row_info, info) ||
       dev_upload(c, &s.row_uoff, uoff) || dev_upload(c, &s.row_uoffw, uoffw) || dev_upload(c, &s.row_tslot, tslot) ||
-      dev_alloc(c, &s.fval, (size_t)W * np * np * ell_rows(np, N)) || dev_alloc(c, &s.dinv, (size_t)np * np * ell_rows(np, N)))
+      dev_alloc(c, &s.fval, ell_size(np, N, W)) || dev_alloc(c, &s.dinv, (size_t)np * np * ell_rows(np, N)))
     return -1;
   // Kernel-selection switches are build-time (A/B builds: WAI_EXTRA_HIPCC_FLAGS="-DWAI_ILU_GENERAL" ...); the
   // run-time environment only steers what the tests compare in one process (WAI_BCGS_MERGED, WAI_JAC_PARK,
@@ -535,7 +535,7 @@ int build_asm(wai_ctx* c, int overlap, int levels, bool with_net) {
   a.E.n = n_ext; a.E.ncols = n_ext; a.E.bs = np; a.E.W = W; a.E.nnzb = (int)ecol.size();
   a.E.h_rowptr = erp; a.E.h_colidx = ecol;
   if (dev_upload(c, &a.E.col, ell_col) || dev_upload(c, &a.gmap, gmap) || dev_upload(c, &a.ext_row, erow) ||
-      dev_alloc(c, &a.E.val, (size_t)W * np * np * ell_rows(np, n_ext)) || dev_alloc(c, &a.r_ext, (size_t)np * n_ext + 16))
+      dev_alloc(c, &a.E.val, ell_size(np, n_ext, W)) || dev_alloc(c, &a.r_ext, (size_t)np * n_ext + 16))
     return -1;
   if (int e = build_schedule(c, a.sched, erp, ecol, ext_ptr, n_ext, W, np, false)) return e;
   a.with_net = with_net;
@@ -555,7 +555,7 @@ int build_asm(wai_ctx* c, int overlap, int levels, bool with_net) {
     if (a.n_net && (dev_upload(c, &a.net_pos, pos) || dev_upload(c, &a.net_pair, pair))) return -1;
   }
   if (cross) {
-    if (dev_alloc(c, &a.hval, (size_t)J.W * np * np * ell_rows(np, H)) || dev_alloc(c, &a.r_full, (size_t)np * NX + 16)) return -1;
+    if (dev_alloc(c, &a.hval, ell_size(np, H, J.W)) || dev_alloc(c, &a.r_full, (size_t)np * NX + 16)) return -1;
     HIPCHK(c, hipMemset(a.r_full, 0, sizeof(double) * ((size_t)np * NX + 16)));
   }
   a.cross = cross;
