@@ -120,12 +120,54 @@ def test_jacobian_kernels_agree_bitwise(FS, oracle, eos, monkeypatch):
     f = np.zeros(n)
     assert sim.residual(0.0, dt, y, L, f) == 0
     vals = {}
+    monkeypatch.setenv("WAI_JAC_SYM", "0")      # the two ROW-wise kernels (the column-wise one: test_column_wise_jacobian_matches_row_wise)
     for flag in ("0", "1"):
         monkeypatch.setenv("WAI_JAC_PARK", flag)
         assert sim.jacobian(0.0, dt, y, L) == 0
         vals[flag] = sim.jacobian_values().copy()
     assert np.abs(vals["0"]).max() > 0.0
     assert np.array_equal(vals["0"], vals["1"])
+    sim.destroy(); osim.close()
+
+
+@pytest.mark.parametrize("eos,minc", [("w", False), ("we", False), ("wce", False), ("wae", False), ("we", True)])
+def test_column_wise_jacobian_matches_row_wise(FS, oracle, eos, minc, monkeypatch):
+    """k_jacobian_sym (round 5; the default for np <= 2): the thread of cell c differences every face once with its own
+    perturbed states and writes column c of the neighbouring rows -- 9 instead of 21 state records per cell.  Diagonal
+    blocks are the literal row differences, bit for bit k_jacobian_park's; an off-diagonal entry is the scaled
+    difference of the face's two flux evaluations instead of the difference of two whole residual sums: equal to the
+    row-wise kernels' up to that difference's rounding (a few eps |f| / h), far inside the oracle bar of test_jacobian."""
+    g, lm, sim, osim, y, region = build(FS, oracle, eos=eos, dims=(12, 12, 12) if not minc else (8, 6, 6),
+                                        brick=(4, 4, 2) if not minc else (4, 3, 3), lens=True, **({"minc": True} if minc else {}))
+    bs = sim.num_primary_variables
+    dt = 2.0e4
+    yo = osim.yvec(y)
+    assert sim.pre_eval(0.0, y) == 0 and osim.pre_eval(yo) == 0
+    L = osim.lhs()
+    f = np.zeros(sim.n_owned * bs)
+    assert sim.residual(0.0, dt, y, L, f) == 0
+    vals = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("WAI_JAC_SYM", flag)
+        assert sim.jacobian(0.0, dt, y, L) == 0
+        vals[flag] = sim.jacobian_values().reshape(-1, bs, bs).copy()
+    rp, ci = sim.setup_jacobian()
+    rows = np.repeat(np.arange(sim.n_owned), np.diff(rp))
+    diag = ci == rows
+    assert np.array_equal(vals["0"][diag], vals["1"][diag])
+    assert np.abs(vals["1"][~diag]).max() > 0.0
+    err, fo = osim.residual(yo, dt, L)
+    err, Jo = osim.jacobian(yo, dt, L, fo, mode=0)
+    Jo = Jo.reshape(-1, bs, bs)
+    for r in range(bs):
+        rowscale = np.zeros(sim.n_owned)
+        np.maximum.at(rowscale, rows, np.abs(vals["0"][:, r, :]).max(axis=1))
+        sc = np.maximum(rowscale[rows][:, None], 1e-300)
+        d01 = (np.abs(vals["1"][:, r, :] - vals["0"][:, r, :]) / sc).max()
+        d1o = (np.abs(vals["1"][:, r, :] - Jo[:, r, :]) / sc).max()
+        d0o = (np.abs(vals["0"][:, r, :] - Jo[:, r, :]) / sc).max()
+        print("eos %s minc %s row %d: column-wise vs row-wise %.2e, vs oracle %.2e (row-wise vs oracle %.2e)" % (eos, minc, r, d01, d1o, d0o))
+        assert d01 < 1e-5 and d1o < 2e-5
     sim.destroy(); osim.close()
 
 

@@ -163,7 +163,7 @@ int restore_step(wai_ctx* c) {
 void free_all(wai_ctx* c) {
   auto F = [](void* p) { if (p) (void)hipFree(p); };
   DeviceMesh& m = c->mesh;
-  F(m.rock); F(m.vol); F(m.fgeom); F(m.fdir); F(m.adj_face); F(m.adj_other); F(m.adj_blk);
+  F(m.rock); F(m.vol); F(m.fgeom); F(m.fdir); F(m.adj_face); F(m.adj_other); F(m.adj_blk); F(m.adj_tblk);
   F(m.diag_blk); F(m.cell_src); F(m.face_cells);
   F(c->src.cell); F(c->src.comp); F(c->src.next); F(c->src.rate); F(c->src.enth); F(c->src.ctl); F(c->src.net); c->net.free_device();
   F(c->J.rowptr); F(c->J.col); F(c->J.val);
@@ -364,6 +364,21 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
       const int* p = std::lower_bound(row, row + cnt, o);
       adj_blk[(size_t)s * N + i] = (int)(p - row);
     }
+  }
+  {
+    // the transposed slot: where column i sits in the block row of its neighbour o (an owned row), for the column-wise
+    // Jacobian sweep (k_jacobian_sym)
+    std::vector<int> adj_tblk((size_t)m.max_deg * N, -1);
+    for (int i = 0; i < N; i++)
+      for (int s = 0; s < deg[i]; s++) {
+        const int o = adj_other[(size_t)s * N + i];
+        if (o >= N) continue;
+        const int* row = J.h_colidx.data() + J.h_rowptr[o];
+        const int cnt = J.h_rowptr[o + 1] - J.h_rowptr[o];
+        const int* p = std::lower_bound(row, row + cnt, i);
+        if (p < row + cnt && *p == i) adj_tblk[(size_t)s * N + i] = (int)(p - row);
+      }
+    if (dev_upload(c, &m.adj_tblk, adj_tblk)) return -1;
   }
   {
     std::vector<int> fc(md->face_cells, md->face_cells + (size_t)2 * NF);

@@ -104,6 +104,7 @@ struct DeviceMesh {
   int* adj_face = nullptr;   // face*2 + side (side 0: cell is cell 1 of the face), -1 = empty
   int* adj_other = nullptr;  // local index of the cell across the face
   int* adj_blk = nullptr;    // matrix slot of (cell, other) in the cell's block row, -1 for a bc cell
+  int* adj_tblk = nullptr;   // matrix slot of (other, cell) in the OTHER cell's block row, -1 where the other cell is no owned row (k_jacobian_sym)
   int* diag_blk = nullptr;   // matrix slot of (cell, cell)
   int* cell_src = nullptr;   // first source in the cell or -1
   int* face_cells = nullptr; // [2 n_faces] (cell 1, cell 2) of every face: flux output only

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(TPB) void k_eos_pert(EosParams ep, const double* __
 struct MeshView {
   const double* rock; const double* vol; const double* fgeom; const int* fdir;
   const int* adj_face; const int* adj_other; const int* adj_blk; const int* diag_blk;
+  const int* adj_tblk;     // slot of THIS cell's column in the neighbour's block row (-1: the neighbour is no owned row)
   const int* cell_src;
   const int* src_next; const int* src_comp; const double* src_rate; const double* src_enth;
   SrcCtl* src_ctl;         // null: all rates as given (the unperturbed residual sweep notes threshold indices into the records)
@@ -639,6 +640,172 @@ __global__ __launch_bounds__(ParkT<KIND>::threads, (EosT<KIND>::np <= 2 ? 2 : 1)
   }
 }
 
+// ---- K5, column-wise off-diagonal blocks (round 5) ---------------------------------------------------------------
+// k_jacobian / k_jacobian_park difference every ROW: for its off-diagonal block (c, o) the thread of cell c fetches the
+// np perturbed states of neighbour o, so every cell's base + np perturbed records are read by the cell itself and by
+// its six neighbours -- 21 records of 144 B per cell for eos we, none of the re-reads hits (the working set of an XCD's
+// resident workgroups is larger than its 4-MB L2): 40 GB per launch at 216^3, 7.8 x the algorithmic bytes.
+// The face flux F(c1, c2) is ONE function of the two states for both rows it feeds (+ F A / V in one, - F A / V in the
+// other), and the evaluation with c's k-th perturbed state that row c needs for its diagonal block is the very
+// evaluation row o needs for its block (o, c).  So here the thread of cell c evaluates every face with its own base
+// and perturbed states against the neighbour's BASE state only -- 3 + 6 = 9 records per cell -- and produces its
+// diagonal block AND column c of every neighbouring row: block (o, c) = dR (term_o(pert_c^k) - term_o(base)) / h_ck,
+// term_o = -+ (F A) / V_o the neighbour's slot term (the same expression k_residual evaluates for row o, from the same
+// flux), dR = d res_form / d R (-dt for backward Euler).  Each off-diagonal block is still produced by exactly one
+// thread and STORED; blocks whose column cell has no thread on this rank (partition ghosts) are produced by the row's
+// thread from the ghost's perturbed records, by the same formula.
+// The diagonal block is the literal difference of the whole row's residual, bit for bit as before.  An off-diagonal
+// entry differs from the literal (f_o(y + h e) - f_o(y)) / h by the rounding of that difference of sums,
+// <= a few eps |f_o| / h -- inside the parity bar (tests/test_hip_parity.py::test_jacobian: 2e-5 of the block row's
+// scale; bench.py's check: max of that and 16 eps |L| / h), and by construction the MORE accurate of the two.
+template <int KIND>
+__device__ __forceinline__ void slot_flux(const FaceGeom& g, int side, const CellState<KIND>& own,
+                                          const RockState& rown, const CellState<KIND>& oth,
+                                          const RockState& roth, double* flux) {
+  if (side == 0) face_flux<KIND>(g, own, rown, oth, roth, flux);
+  else face_flux<KIND>(g, oth, roth, own, rown, flux);
+}
+__device__ __forceinline__ double res_dR(const ResForm& rf) {   // d res_form / d R
+  if (rf.method == WAI_METHOD_BDF2) return -rf.dt * (rf.ratio + 1.0);
+  if (rf.method == WAI_METHOD_DIRECTSS) return 1.0;
+  return -rf.dt;
+}
+template <int KIND>
+__global__ __launch_bounds__(ParkT<KIND>::threads, (EosT<KIND>::np <= 2 ? 2 : 1)) void k_jacobian_sym(MeshView m, const double* __restrict__ flu,
+                                                  size_t stride, const double* __restrict__ flu_pert,
+                                                  const double* __restrict__ hstep, int n_prim,
+                                                  ResForm rf, double* __restrict__ val) {
+  using E = EosT<KIND>;
+  constexpr int np = E::np;
+  const int c = xcd_cell(m.n_owned);
+  if (c < 0) return;
+  CellState<KIND> own0;
+  RockState rown;
+  load_state<KIND>(flu, stride, c, own0);
+  load_rock(m.rock, m.n_local, c, rown);
+  const double vol = m.vol[c];
+  double lold[np], lold2[np], hk[np];
+#pragma unroll
+  for (int k = 0; k < np; k++) {
+    lold[k] = rf.method == WAI_METHOD_DIRECTSS ? 0.0 : rf.last[(size_t)c * np + k];
+    lold2[k] = rf.method == WAI_METHOD_BDF2 ? rf.last2[(size_t)c * np + k] : 0.0;
+    hk[k] = hstep[(size_t)c * np + k];
+  }
+  extern __shared__ double park[];
+  constexpr int nld = ParkT<KIND>::npark;
+  const int st = (int)blockDim.x;
+  double Lk[np][np], Rk[np][np];
+#pragma unroll
+  for (int k = 0; k < np; k++) {
+    CellState<KIND> ownk;
+    load_state<KIND>(flu_pert + (size_t)k * E::df * n_prim, (size_t)n_prim, c, ownk);
+    cell_balance<KIND>(ownk, rown, Lk[k]);
+    park_state<KIND>(ownk, park + (size_t)k * nld * st + threadIdx.x, st);
+#pragma unroll
+    for (int q = 0; q < np; q++) Rk[k][q] = 0.0;
+  }
+  const size_t nrow = m.n_owned;
+  const double dR = res_dR(rf);
+  double L0[np], R0[np], f0[np];
+  cell_balance<KIND>(own0, rown, L0);
+  bool ghost_cols = false;
+#pragma unroll
+  for (int k = 0; k < np; k++) R0[k] = 0.0;
+#pragma unroll 1
+  for (int s = 0; s < m.max_deg; s++) {
+    const int fs = m.adj_face[(size_t)s * m.n_owned + c];
+    if (fs < 0) continue;
+    const int o = m.adj_other[(size_t)s * m.n_owned + c];
+    const int tb = m.adj_tblk[(size_t)s * m.n_owned + c];   // >= 0: o is an owned row and this is the slot of column c in it
+    FaceGeom g;
+    load_face(m, fs >> 1, g);
+    CellState<KIND> oth;
+    RockState roth;
+    load_state<KIND>(flu, stride, o, oth);
+    load_rock_face(m.rock, m.n_local, o, g.dir, roth);
+    const int side = fs & 1;
+    const double sign = side ? 1.0 : -1.0;
+    const double volo = tb >= 0 ? m.vol[o] : 1.0;
+    double fl0[np], to0[np];
+    slot_flux<KIND>(g, side, own0, rown, oth, roth, fl0);
+#pragma unroll
+    for (int q = 0; q < np; q++) {
+      R0[q] += sign * (fl0[q] * g.area) / vol;            // slot_term's expression, this row's side ...
+      to0[q] = -sign * (fl0[q] * g.area) / volo;          // ... and the neighbour's
+    }
+#pragma unroll
+    for (int k = 0; k < np; k++) {
+      CellState<KIND> ownk;
+      unpark_state<KIND>(park + (size_t)k * nld * st + threadIdx.x, st, ownk);
+      double fl[np];
+      slot_flux<KIND>(g, side, ownk, rown, oth, roth, fl);
+#pragma unroll
+      for (int q = 0; q < np; q++) Rk[k][q] += sign * (fl[q] * g.area) / vol;
+      if (tb >= 0) {
+#pragma unroll
+        for (int r = 0; r < np; r++) {
+          const double tok = -sign * (fl[r] * g.area) / volo;
+          val[ell_ix(np, nrow, tb, r, k, (size_t)o)] = dR * (tok - to0[r]) / hk[k];
+        }
+      }
+    }
+    ghost_cols |= (m.adj_blk[(size_t)s * m.n_owned + c] >= 0 && o >= m.n_owned);
+  }
+  // column cells without a thread on this rank (partition ghosts; none on one rank): block (c, o) from the ghost's
+  // perturbed records, in a loop of its own so that the sweep above does not carry its registers
+  if (ghost_cols) {
+#pragma unroll 1
+    for (int s = 0; s < m.max_deg; s++) {
+      const int fs = m.adj_face[(size_t)s * m.n_owned + c];
+      if (fs < 0) continue;
+      const int o = m.adj_other[(size_t)s * m.n_owned + c];
+      const int blk = m.adj_blk[(size_t)s * m.n_owned + c];
+      if (blk < 0 || o < m.n_owned) continue;
+      FaceGeom g;
+      load_face(m, fs >> 1, g);
+      CellState<KIND> oth;
+      RockState roth;
+      load_state<KIND>(flu, stride, o, oth);
+      load_rock_face(m.rock, m.n_local, o, g.dir, roth);
+      const int side = fs & 1;
+      const double sign = side ? 1.0 : -1.0;
+      double fl0[np];
+      slot_flux<KIND>(g, side, own0, rown, oth, roth, fl0);
+#pragma unroll 1
+      for (int k = 0; k < np; k++) {
+        load_state<KIND>(flu_pert + (size_t)k * E::df * n_prim, (size_t)n_prim, o, oth);
+        double fl[np];
+        slot_flux<KIND>(g, side, own0, rown, oth, roth, fl);
+        const double h = hstep[(size_t)o * np + k];
+#pragma unroll
+        for (int r = 0; r < np; r++) {
+          const double t1 = sign * (fl[r] * g.area) / vol, t0 = sign * (fl0[r] * g.area) / vol;
+          __builtin_nontemporal_store(dR * (t1 - t0) / h, val + ell_ix(np, nrow, blk, r, k, (size_t)c));
+        }
+      }
+    }
+  }
+  double src0[np];
+#pragma unroll
+  for (int k = 0; k < np; k++) src0[k] = 0.0;
+  source_terms<KIND>(m, c, own0, vol, src0);
+#pragma unroll
+  for (int k = 0; k < np; k++) { R0[k] += src0[k]; f0[k] = res_form(rf, L0[k], R0[k], lold[k], lold2[k]); }
+  // diagonal block: the literal difference of the row's residual, as k_jacobian_park forms it
+  const int dq = m.diag_blk[c];
+#pragma unroll
+  for (int k = 0; k < np; k++) {
+    CellState<KIND> ownk;
+    unpark_state<KIND>(park + (size_t)k * nld * st + threadIdx.x, st, ownk);
+    source_terms<KIND>(m, c, ownk, vol, Rk[k]);
+#pragma unroll
+    for (int r = 0; r < np; r++) {
+      const double f1 = res_form(rf, Lk[k][r], Rk[k][r], lold[r], lold2[r]);
+      __builtin_nontemporal_store((f1 - f0[r]) / hk[k], val + ell_ix(np, nrow, dq, r, k, (size_t)c));
+    }
+  }
+}
+
 // ---- tracers: the auxiliary linear problem ------------------------------------------------------
 // One scalar system per tracer on the flow Jacobian's sparsity, one thread per owned cell (row):
 // aux_lhs (flow_simulation.F90:1489-1556), aux_rhs (:1560-1833: advection with the phase flux,
@@ -974,7 +1141,7 @@ static MeshView view(wai_ctx* c) {
   MeshView m;
   m.rock = c->mesh.rock; m.vol = c->mesh.vol; m.fgeom = c->mesh.fgeom; m.fdir = c->mesh.fdir;
   m.adj_face = c->mesh.adj_face; m.adj_other = c->mesh.adj_other; m.adj_blk = c->mesh.adj_blk;
-  m.diag_blk = c->mesh.diag_blk; m.cell_src = c->mesh.cell_src;
+  m.diag_blk = c->mesh.diag_blk; m.cell_src = c->mesh.cell_src; m.adj_tblk = c->mesh.adj_tblk;
   m.src_next = c->src.next; m.src_comp = c->src.comp; m.src_rate = c->src.rate;
   m.src_enth = c->src.enth; m.src_ctl = c->src.ctl; m.src_net = c->src.net;
   m.n_owned = c->mesh.n_owned; m.n_local = c->mesh.n_local; m.n_faces = c->mesh.n_faces;
@@ -1068,6 +1235,31 @@ int launch_jacobian(wai_ctx* c, double dt, const double* lhs_old) {
   // 216^3 matrix before every assembly and accumulated into it: 4.6 GB of the launch's traffic.)
   const char* ep = getenv("WAI_JAC_PARK");   // read per call: tests compare the two kernels in one process
   const bool park = !(ep && ep[0] == '0');
+  // column-wise off-diagonal blocks (k_jacobian_sym): 3 + 6 instead of 3 + 6 (1 + np) state records per cell and 1 + np
+  // instead of 1 + 2 np flux evaluations per face.  MEASURED (profiles/asm_traffic_r5_*.log, same box): 9.59 -> 5.26 ms and
+  // 40.0 -> 26.3 GB at C3 (eos we), 7.34 -> 3.81 ms / 24.3 -> 11.7 GB at C4 (wce), 3.06 -> 1.54 ms / 5.7 -> 3.7 GB at C5.
+  // The default for every EOS; WAI_JAC_SYM=0 takes the row-wise kernels (read per call: tests compare them in one process)
+  const char* es = getenv("WAI_JAC_SYM");
+  const bool sym = park && c->mesh.adj_tblk && (es ? es[0] == '1' : true);
+  if (sym) {
+#define JS(K)                                                                                             \
+    do {                                                                                                  \
+      constexpr int T = ParkT<K>::threads;                                                                \
+      const int g = (((int)((m.n_owned + T - 1) / T) + 7) / 8) * 8;                                        \
+      hipLaunchKernelGGL(k_jacobian_sym<K>, g, T, EosT<K>::np * ParkT<K>::npark * 8 * T, c->stream,       \
+                         m, c->flu, stride, c->flu_pert, c->hstep, c->mesh.n_prim, res_form_of(c, dt, lhs_old), c->J.val); \
+    } while (0)
+    if (c->kind == EOS_W) JS(EOS_W);
+    else if (c->kind == EOS_WE) JS(EOS_WE);
+    else if (c->kind == EOS_WSE) JS(EOS_WSE);
+    else if (c->kind == EOS_WAE) JS(EOS_WAE);
+    else if (c->kind == EOS_WSCE) JS(EOS_WSCE);
+    else if (c->kind == EOS_WSAE) JS(EOS_WSAE);
+    else JS(EOS_WCE);
+#undef JS
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) { c->err = std::string("k_jacobian_sym: ") + hipGetErrorString(e); return -1; }
+    return 0;
+  }
   if (park) {
 #define JP(K)                                                                                             \
     do {                                                                                                  \

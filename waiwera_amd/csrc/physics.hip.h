@@ -708,6 +708,17 @@ __device__ __forceinline__ void load_rock(const double* __restrict__ rock, size_
   r.phi = rock[R_PHI * stride + c]; r.rho = rock[R_RHO * stride + c]; r.cp = rock[R_CP * stride + c];
 }
 
+// what face_flux reads of the OTHER cell's rock: the permeability along the face's direction and the two conductivities
+// (3 of the record's 8 doubles: 40 bytes less per neighbour)
+__device__ __forceinline__ void load_rock_face(const double* __restrict__ rock, size_t stride, size_t c, int dir,
+                                               RockState& r) {
+  const int d = dir - 1;
+  const double kd = rock[(size_t)(d == 0 ? R_K1 : (d == 1 ? R_K2 : R_K3)) * stride + c];
+  r.k[0] = kd; r.k[1] = kd; r.k[2] = kd;
+  r.wet = rock[R_WET * stride + c]; r.dry = rock[R_DRY * stride + c];
+  r.phi = 0.0; r.rho = 0.0; r.cp = 0.0;
+}
+
 // cell%balance (cell.F90:114-142)
 template <int KIND>
 __device__ __forceinline__ void cell_balance(const CellState<KIND>& s, const RockState& r, double* bal) {
