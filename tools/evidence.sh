@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 TAG=${TAG:-r5}
 mkdir -p gpurun_out/$TAG
 export TMPDIR=/tmp
-if [ -z "$SKIP_TESTS" ]; then python -m pytest tests -m gpu -q -s --durations=10 > gpurun_out/$TAG/pytest_gpu_final.log 2>&1; fi
+if [ -z "$SKIP_TESTS" ]; then python -m pytest tests -m gpu -q --durations=10 -p no:cacheprovider > gpurun_out/$TAG/pytest_gpu_final.log 2>&1; fi
 echo "pytest rc $?"; grep -v amdgpu gpurun_out/$TAG/pytest_gpu_final.log | tail -14 | cut -c1-160
 for cfg in ${CFGS:-c3 c4 c5}; do
   bash tools/gpu_profile.sh $TAG $cfg --steps 20 --warmup 5 > gpurun_out/$TAG/gpu_profile_$cfg.log 2>&1
@@ -35,4 +35,20 @@ PY
 if [ -z "$SKIP_LOOPBACK" ]; then
 # BASELINE's shardings at full size, all ranks on this one GPU over the stream-asynchronous test transport
 TAG=$TAG bash tools/loopback_lines.sh "c5 2" "c4 4" "c3 8"
+fi
+if [ -z "$SKIP_SERIES" ]; then
+# SURVEY.md section 8d's second series: Corey (0.3, 0.05) curves, and GMRES(30) beside BiCGStab, at C2 and C3
+for cfg in c2 c3; do
+  python bench.py --config $cfg --curves corey --no-cpu > gpurun_out/bench_${TAG}_${cfg}_corey.json 2> gpurun_out/$TAG/bench_${cfg}_corey.log
+  python bench.py --config $cfg --ksp gmres --no-cpu --steps 10 --warmup 3 > gpurun_out/bench_${TAG}_${cfg}_gmres.json 2> gpurun_out/$TAG/bench_${cfg}_gmres.log
+done
+TAG=$TAG python - <<'PY'
+import json, os
+TAG = os.environ["TAG"]
+for n in ["c2_corey","c3_corey","c2_gmres","c3_gmres"]:
+    try:
+        d=json.load(open("gpurun_out/bench_%s_%s.json" % (TAG, n))); c=d["config"]
+        print("%-10s value %.3f norm %s its/step %.1f ms/it %.4f fixed %.2f" % (n, d["value"], d.get("value_normalised"), c["krylov_iterations_per_newton_step"], c["ms_per_krylov_iteration"], c["ms_fixed_per_newton_step"]))
+    except Exception as e: print(n, e)
+PY
 fi
