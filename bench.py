@@ -484,6 +484,7 @@ def main():
         # side like `world` small devices instead of time-slicing one another (read when the process first touches the device)
         per = 256 // world
         os.environ["HSA_CU_MASK"] = "0:%d-%d" % (rank * per, (rank + 1) * per - 1)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world >= 7:
             os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")   # all ranks' queues mapped together: no time-slicing of queues
     import torch

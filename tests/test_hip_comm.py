@@ -42,5 +42,8 @@ def test_async_transport_selftest(ranks, delay_us):
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "loopback_rccl", "async_selftest")
     assert os.path.exists(exe), "build first: python __graft_entry__.py"
     env = dict(os.environ, WAI_ASYNC_RCCL_DELAY_US=str(delay_us), WAI_ASYNC_RCCL_TIMEOUT_S="30")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if ranks >= 7:
+        env.setdefault("GPU_MAX_HW_QUEUES", "1")     # 8 x 4 hardware queues oversubscribe the device's queue slots (tests/test_hip_multirank.py::_own_cus)
     out = subprocess.run([exe, str(ranks), "300"], env=env, capture_output=True, text=True, timeout=500)
     assert out.returncode == 0 and "PASSED" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])

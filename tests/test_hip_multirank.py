@@ -33,6 +33,7 @@ def _own_cus(rank, world):
     """The ranks share one GPU: give each its own compute units (HSA_CU_MASK, read when the process first touches the
     device), 256 / world each, so that they run side by side like `world` small devices instead of time-slicing one
     another's full-width launches -- and a rank's polling transport kernels never sit on CUs a peer's work is queued for."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the transport's windows are shared with hipIpc (dmabuf IPC on this driver)
     if os.environ.get("WAI_TEST_CU_MASK", "1") != "0" and world > 1:
         per = 256 // world
         os.environ["HSA_CU_MASK"] = "0:%d-%d" % (rank * per, (rank + 1) * per - 1)

@@ -29,6 +29,50 @@ def FS():
     return FlowSimulation
 
 
+def jacobian_against_literal_fd(sim, y, L, dt, Jg, Jo, rp, ci, bs, tol, t=0.0, most=12):
+    """Device Jacobian Jg against the oracle's literal forward differences Jo, relative to the largest entry of the block
+    row's equation: returns the worst relative difference AFTER the entries above `tol` have been examined one by one.
+
+    The column-wise sweep (k_jacobian_sym, the default since round 5) forms an off-diagonal entry from the difference of
+    the face's two flux evaluations; the literal difference of two whole residual sums -- what the oracle, the row-wise
+    kernels and MatFDColoring form -- carries the rounding of those sums divided by the step, which for a small scaled
+    primary (a gas partial-pressure fraction of 0.02: h = 2e-10) reaches 1e-3 of the row's scale.  Where the two
+    disagree by more than `tol` the ARBITER is a central difference of the device's residual with a 1000 x larger step
+    (rounding 1000 x smaller, truncation still negligible): the device's entry must agree with it to `tol` and be at
+    least 10 x closer to it than the literal difference is.  An entry that fails either test is reported as it is."""
+    n = sim.n_owned
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    worst = 0.0
+    for r in range(bs):
+        rowscale = np.zeros(n)
+        np.maximum.at(rowscale, rows, np.abs(Jo[:, r, :]).max(axis=1))
+        sc = np.maximum(rowscale[rows][:, None], 1e-300)
+        rel = np.abs(Jg[:, r, :] - Jo[:, r, :]) / sc
+        over = np.argwhere(rel > tol)
+        if len(over) > most:      # the worst ones
+            over = over[np.argsort(-rel[over[:, 0], over[:, 1]])[:most]]
+        cleared = np.zeros_like(rel, dtype=bool)
+        for b, k in over:
+            i, j = rows[b], ci[b]
+            col = j * bs + k
+            dx = y[col] if abs(y[col]) >= 1e-2 else (1e-2 if y[col] >= 0.0 else -1e-2)
+            h = dx * 1e-5
+            yp, ym = y.copy(), y.copy()
+            yp[col] += h
+            ym[col] -= h
+            fp, fm = np.zeros(n * bs), np.zeros(n * bs)
+            assert sim.residual(t, dt, yp, L, fp) == 0 and sim.residual(t, dt, ym, L, fm) == 0
+            cd = (fp[i * bs + r] - fm[i * bs + r]) / (2.0 * h)
+            dg, do = abs(Jg[b, r, k] - cd), abs(Jo[b, r, k] - cd)
+            print("   entry (%d, %d; %d, %d): device %.9e literal %.9e central x1000 %.9e" % (i, r, j, k, Jg[b, r, k], Jo[b, r, k], cd))
+            if dg / sc[b, 0] < tol and dg * 10.0 < do:
+                cleared[b, k] = True
+        if len(over) <= most:
+            rel = np.where(cleared, 0.0, rel)
+        worst = max(worst, float(rel.max()))
+    return worst
+
+
 def build(FS, oracle, eos="we", dims=(8, 8, 8), brick=(4, 4, 4), lens=False, **kw):
     if eos in ("wse", "wsce", "wsae") and not lens:
         # the shallow box with its 10 m cells and halite-bearing cells does not survive the wells'
@@ -102,7 +146,10 @@ def test_jacobian(FS, oracle, eos, lens):
         tol = 2e-5
         worst = (np.abs(Jg[:, r, :] - Jo[:, r, :]) / np.maximum(sc, 1e-300)).max()
         print("jacobian parity %s lens=%s row %d: %.3e (tol %.0e)" % (eos, lens, r, worst, tol))   # pytest -s
-        assert worst < tol
+    # ... and the entries above it (column-wise sweep: the literal difference's own rounding) against the arbiter
+    worst = jacobian_against_literal_fd(sim, y, L, dt, Jg, Jo, rp, ci, bs, 2e-5)
+    print("jacobian parity %s lens=%s after the arbiter: %.3e" % (eos, lens, worst))
+    assert worst < 2e-5
     sim.destroy(); osim.close()
 
 
@@ -409,11 +456,7 @@ def test_residual_forms(FS, oracle, eos, method):
     # r = 1.7 against 2 for backward Euler): its rounding noise, divided by the FD step, is that
     # much larger relative to the block row than in test_jacobian
     jtol = 1e-4 if method == "bdf2" else 1e-5
-    for r in range(bs):
-        rowscale = np.zeros(sim.n_owned)
-        np.maximum.at(rowscale, np.repeat(np.arange(sim.n_owned), np.diff(rp)), np.abs(Jo[:, r, :]).max(axis=1))
-        sc = np.repeat(rowscale, np.diff(rp))[:, None]
-        assert (np.abs(Jg[:, r, :] - Jo[:, r, :]) / np.maximum(sc, 1e-300)).max() < jtol
+    assert jacobian_against_literal_fd(sim, y, L, dt, Jg, Jo, rp, ci, bs, jtol) < jtol
     # back to backward Euler: the default form is untouched by the excursion
     sim.set_residual_form("beuler")
     osim.set_residual_form(0)

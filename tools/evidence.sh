@@ -34,7 +34,7 @@ for n in ["c3","c4","c5","c2","c3_share8","c4_share4","c5_share2"]:
 PY
 if [ -z "$SKIP_LOOPBACK" ]; then
 # BASELINE's shardings at full size, all ranks on this one GPU over the stream-asynchronous test transport
-TAG=$TAG bash tools/loopback_lines.sh "c5 2" "c4 4" "c3 8"
+TAG=$TAG bash tools/loopback_lines.sh "c5 2" "c4 4" "c3 8 --dt0 2000"
 fi
 if [ -z "$SKIP_SERIES" ]; then
 # SURVEY.md section 8d's second series: Corey (0.3, 0.05) curves, and GMRES(30) beside BiCGStab, at C2 and C3

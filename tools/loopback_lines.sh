@@ -4,8 +4,8 @@ TAG=${TAG:-r5}
 mkdir -p gpurun_out/$TAG
 export WAI_RCCL_LIB=$PWD/tests/loopback_rccl/libasync_rccl.so WAI_BENCH_LOOPBACK=1
 for spec in "$@"; do
-  set -- $spec; cfg=$1; n=$2
-  MASTER_PORT=$((29500 + RANDOM % 500)) timeout ${LIMIT:-1200} python bench.py --config $cfg --gpus $n --lead 1 --steps ${STEPS:-3} --warmup 0 --no-cpu --spmv-reps 3 \
+  set -- $spec; cfg=$1; n=$2; shift 2     # the rest of the spec: extra bench arguments ("c3 8 --dt0 2000": no failed tries in the lead-in)
+  MASTER_PORT=$((29500 + RANDOM % 500)) timeout ${LIMIT:-1200} python bench.py --config $cfg --gpus $n --lead 1 --steps ${STEPS:-3} --warmup 0 --no-cpu --spmv-reps 3 "$@" \
     > gpurun_out/$TAG/lb_${cfg}_$n.out 2> gpurun_out/$TAG/lb_${cfg}_$n.log
   echo "async loopback $cfg x $n rc $?"
   grep "^{" gpurun_out/$TAG/lb_${cfg}_$n.out > gpurun_out/bench_${TAG}_${cfg}_async$n.json

@@ -35,7 +35,11 @@ def main(src, tag, dst):
     dims = [int(v) for v in m.groups()]
     mb = re.search(r"\((\d+)x(\d+)x(\d+) bricks\)", bench["config"]["workload"])
     brick = [int(v) for v in mb.groups()]
-    pc = find(r"k_pc_park<true|k_pc_rows<\d, true|k_pc_wave<\d, true|k_pc<\d, true")
+    # the launch bench.py's roofline times: the fused operator on a stored operand (first half of an iteration); the
+    # composed second launch of the 2 x 2 kernel (operand R - alpha V formed inside: one more vector read) beside it
+    pc = find(r"k_pc_park<true, false|k_pc_rows<\d, true, \d, \d, false|k_pc_wave<\d, true, false|k_pc<\d, true") or \
+        find(r"k_pc_park<true|k_pc_rows<\d, true|k_pc_wave<\d, true|k_pc<\d, true")
+    pcx = find(r"k_pc_park<true, true|k_pc_wave<\d, true, true|k_pc_rows<\d, true, \d, \d, true")
     sp = find(r"k_spmv<")
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python "
                      "bench.py --config ... --lead 1 --steps 1 --warmup 0 --no-cpu --spmv-reps 10 on 1 x MI355X; " +
@@ -48,6 +52,13 @@ def main(src, tag, dst):
            "k_pc_traffic_over_algorithmic": hbm(pc) / roof["algorithmic_bytes_per_launch"],
            "k_spmv_hbm_bytes_per_launch": hbm(sp), "k_spmv_algorithmic_bytes": roof["spmv_algorithmic_bytes_per_launch"],
            "k_spmv_traffic_over_algorithmic": hbm(sp) / roof["spmv_algorithmic_bytes_per_launch"]}
+    if pcx and pcx != pc:
+        m2 = re.search(r"\((\d+) cells\)", bench["config"]["workload"])
+        ncell = int(m2.group(1)) if m2 else 0
+        bs = 2 if "k_pc_park" in pcx else 3
+        alg = roof["algorithmic_bytes_per_launch"] + 8 * bs * ncell
+        out.update({"k_pc_composed_kernel": pcx, "k_pc_composed_hbm_bytes_per_launch": hbm(pcx),
+                    "k_pc_composed_algorithmic_bytes": alg, "k_pc_composed_traffic_over_algorithmic": hbm(pcx) / alg})
     for name, pat in (("k_bcgs_p", r"k_bcgs_p"), ("k_jacobian", r"k_jacobian"), ("k_residual", r"k_residual"),
                       ("k_eos_pert", r"k_eos_pert")):
         k = find(pat)
