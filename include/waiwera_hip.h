@@ -335,7 +335,9 @@ int wai_max_scaled(wai_ctx *ctx, const double *v, const double *scale, double to
 /* one Newton iteration, device-resident (timestepper.F90:628-735,1898-1951 + PETSc newtonls):
  * pre_iteration, Jacobian, KSP solve, full-step line search with transitions, new residual,
  * convergence test.  reason: 0 iterating, 1 converged (function), 2 converged (update),
- * 3/4 PETSc default tests, <0 diverged (-3 linear solve / domain error, -5 max its, -9 dtol) */
+ * 3/4 PETSc default tests, <0 diverged (-3 linear solve / domain error, -5 max its, -9 dtol).
+ * Its pre_iteration snapshot holds what the transition sweep reads of last_iteration_fluid (temperature, region,
+ * old region); a host that wants the whole record (wai_get_fluid(ctx, 1, ..)) calls wai_pre_iteration itself */
 int wai_newton_step(wai_ctx *ctx, double t, double dt, int iter, double *y,
                     const double *lhs_old, double *f, int *ksp_its, int *reason,
                     double *max_residual);
