@@ -599,6 +599,10 @@ def main():
         modes = {"no reduction": 11, "(z,aux) partials only": 12, "(z,aux) + alpha in the launch": 2, "(x,z),(z,z) + omega in the launch": 13,
                  "five merged products, partials only": 14, "five merged + scalars in the launch": 15}
         log("micro %s fused launch by reduction mode (ms): %s" % (a.config, json.dumps({k: round(sim.bench_kernel(w, a.spmv_reps), 4) for k, w in modes.items()})))
+        if not minc and bs == 2:
+            log("micro %s overlapped-exchange launches (ms): interior bricks %.4f, face bricks %.4f, both as launched %.4f [WAI_FACE_STREAM=%s]"
+                % (a.config, sim.bench_kernel(9, a.spmv_reps), sim.bench_kernel(10, a.spmv_reps), sim.bench_kernel(16, a.spmv_reps),
+                   os.environ.get("WAI_FACE_STREAM", "default")))
         log("micro %s iteration device-only %.4f ms, vector updates %.4f ms [WAI_BCGS=%s]"
             % (a.config, sim.bench_kernel(5, 50), sim.bench_kernel(6, 50), os.environ.get("WAI_BCGS", "default")))
         return
@@ -721,6 +725,7 @@ def main():
     if world == 1 and not minc and a.pc == "bjacobi" and a.ilu_levels == 0:   # the two launches of the overlapped halo exchange, timed alone
         kb["fused_interior_bricks"] = sim.bench_kernel(9, a.spmv_reps)
         kb["fused_face_bricks"] = sim.bench_kernel(10, a.spmv_reps)
+        kb["fused_interior_and_face_bricks_as_launched"] = sim.bench_kernel(16, a.spmv_reps)
     if world == 1 and a.ksp == "bcgs" and a.pc == "bjacobi" and a.ilu_levels == 0:   # the iteration's launches back to back, and its vector updates alone
         kb["bicgstab_iteration_device_only"] = sim.bench_kernel(5, 50)
         kb["bicgstab_vector_updates"] = sim.bench_kernel(6, 50)

@@ -39,7 +39,8 @@ int wai_timer_stop(wai_ctx *ctx, float *ms);
  * 3/4 timing probes of 1/2 without the substitution sweeps (generic brick kernel only), 5 one whole BiCGStab
  * iteration's launches (and collectives) back to back without the host, 6 its vector updates alone, 7 the second
  * fused launch of the iteration (operand S, or R - alpha V with WAI_BCGS_COMPOSE=1; five inner products), 9 / 10 the fused
- * kernel on the interior / the face bricks alone (the two launches of the overlapped halo exchange), 11 .. 15 the fused
+ * kernel on the interior / the face bricks alone (the two launches of the overlapped halo exchange; 16: both as that path
+ * launches them -- behind one another on the compute stream; WAI_FACE_STREAM=1: the face bricks on their own stream), 11 .. 15 the fused
  * launch by reduction mode: 11 none, 12 (z,aux) left as partial sums, 13 (x,z),(z,z) + omega finished in the launch,
  * 14 the five merged products left as partial sums, 15 the five + omega, (R,R), rho, beta finished in the launch */
 int wai_bench_kernel(wai_ctx *ctx, int which, int reps, float *ms_per_launch);

@@ -192,6 +192,9 @@ void free_all(wai_ctx* c) {
   if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
   if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+  if (c->ev_face) (void)hipEventDestroy(c->ev_face);
+  if (c->ev_prior) (void)hipEventDestroy(c->ev_prior);
+  if (c->face_stream) (void)hipStreamDestroy(c->face_stream);
   if (c->pev0) (void)hipEventDestroy(c->pev0);
   if (c->pev1) (void)hipEventDestroy(c->pev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -831,6 +834,7 @@ int wai_comm_init(wai_ctx* c, int rank, int nranks, const char id[128]) {
     HIPCHK(c, hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, prio_hi));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
+    if (ensure_face_stream(c)) return -1;
   }
   return 0;
 }

@@ -411,9 +411,13 @@ struct wai_ctx {
   // halo exchange overlapped with the preconditioned operator on the bricks that touch no ghost
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
+  // WAI_FACE_STREAM=1: the face bricks' launch of the overlapped halo exchange on a stream of its own, ordered behind the
+  // unpack only (round 5; measured slower than behind the interior bricks on the compute stream: krylov.hip launch_pc_split)
+  hipStream_t face_stream = nullptr;
+  hipEvent_t ev_face = nullptr, ev_prior = nullptr;
   // run-time switches of the fused launches, read from the environment once per solve / set-up / probe (read_env),
   // not per launch: WAI_FIN_SEPARATE, WAI_PC_STAGGER (-1: each kernel's default), WAI_WAVE_ROWPTR, WAI_NO_COL16 (k_pc_park on the int32 column planes)
-  struct EnvSw { bool fin_separate = false; int stagger = -1; bool wave_rowptr = false; bool no_col16 = false; } env;
+  struct EnvSw { bool fin_separate = false; int stagger = -1; bool wave_rowptr = false; bool no_col16 = false; bool no_face_stream = false; } env;
   int test_drop_wait = 0;   // fault injection (wai_test_drop_stream_wait): 1 the face bricks' launch does not wait for the halo
   // halo
   int n_nbr = 0;

@@ -120,6 +120,13 @@ int ensure_halo_dof(wai_ctx* c, int dof);   // halo buffers wide enough for `dof
 int do_pc_setup(wai_ctx* c);
 // ---- krylov.hip --------------------------------------------------------------------------------------------------
 int halo_exchange(wai_ctx* c, double* vec, int dof);
+void mode_slots(int dot_mode, int& slot0, int& nslots);   // the reduction slots a fused launch's dot mode fills
+int ensure_face_stream(wai_ctx* c);   // the stream and events of the face bricks' launch (created once)
+// the two launches of the overlapped halo exchange: interior bricks on the compute stream, face bricks behind `after`
+// (null: behind what the compute stream held when called) -- on the compute stream behind them, or (WAI_FACE_STREAM=1)
+// on the face stream, concurrently with the interior bricks' tail (measured slower: krylov.hip)
+int launch_pc_split(wai_ctx* c, const double* x, double* z, int dot_mode, const double* aux, const Fin* fp, const double* x2,
+                    hipEvent_t after);
 int allreduce_scal(wai_ctx* c, int slot, int count);
 int read_scal(wai_ctx* c, int first, int count);
 // z = B^-1 r; dot_mode as launch_pc, with `x` the partner of mode 2.  fin_phase >= -1: the partial sums of the dot

@@ -2437,6 +2437,7 @@ void read_env(wai_ctx* c) {
   c->env.stagger = es ? atoi(es) : -1;
   c->env.wave_rowptr = getenv("WAI_WAVE_ROWPTR") != nullptr;
   c->env.no_col16 = getenv("WAI_NO_COL16") != nullptr;
+  { const char* e = getenv("WAI_FACE_STREAM"); c->env.no_face_stream = !(e && e[0] == '1'); }   // measured slower: off unless asked for
 }
 int bcgs_post(wai_ctx* c, int seq);
 static inline int pc_threads(const IluSchedule& s) { return ((s.max_rows + 63) / 64) * 64; }

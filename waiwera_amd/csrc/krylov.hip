@@ -18,6 +18,44 @@ int halo_exchange(wai_ctx* c, double* vec, int dof) {
   return unpack_halo(c, vec, dof);
 }
 
+int ensure_face_stream(wai_ctx* c) {
+  if (c->face_stream) return 0;
+  HIPCHK(c, hipStreamCreateWithFlags(&c->face_stream, hipStreamNonBlocking));
+  HIPCHK(c, hipEventCreateWithFlags(&c->ev_face, hipEventDisableTiming));
+  HIPCHK(c, hipEventCreateWithFlags(&c->ev_prior, hipEventDisableTiming));
+  return 0;
+}
+
+// Interior bricks, then face bricks.  On ONE stream the second launch starts when the first has drained completely: two
+// ramps and two tails.  The face bricks depend on the halo, not on the interior bricks (disjoint rows of z; the
+// reductions' finalisers read arrival off the data, whichever launch stored it), so their launch CAN go to a stream of
+// its own that waits for the unpack only (WAI_FACE_STREAM=1), the compute stream then waiting for it.
+// MEASURED (round 5, bench.py --rank-share 8 --micro-only, every face of the 108^3 box taken as a partition face: 49 % of
+// the bricks "face" bricks where a 2 x 2 x 2 rank has 28 %; profiles/facestream_ab_r5.log): unsplit launch 0.0834 ms;
+// interior 0.0500 + face 0.0468 timed alone; both on the compute stream 0.1030; face bricks on their own stream 0.1085
+// -- SLOWER: the two launches do not overlap enough to pay for the two cross-queue event hand-overs (~2.5 us each).
+// Same results either way (tests/test_hip_multirank.py ran green on both); default: one stream.
+int launch_pc_split(wai_ctx* c, const double* x, double* z, int dot_mode, const double* aux, const Fin* fp, const double* x2,
+                    hipEvent_t after) {
+  const IluSchedule& s = c->ilu;
+  const bool own = !c->env.no_face_stream && c->face_stream;
+  if (own && !after) { HIPCHK(c, hipEventRecord(c->ev_prior, c->stream)); after = c->ev_prior; }   // the operand is ready
+  if (launch_pc(c, true, x, z, dot_mode, aux, s.sub_int, s.n_int, nullptr, x2)) return -1;   // its partials wait for ...
+  if (!own) {
+    if (after) HIPCHK(c, hipStreamWaitEvent(c->stream, after, 0));
+    return launch_pc(c, true, x, z, dot_mode, aux, s.sub_bnd, s.n_bnd, fp, x2);              // ... the face bricks' last workgroup
+  }
+  HIPCHK(c, hipStreamWaitEvent(c->face_stream, after, 0));
+  hipStream_t keep = c->stream;
+  c->stream = c->face_stream;
+  const int e = launch_pc(c, true, x, z, dot_mode, aux, s.sub_bnd, s.n_bnd, fp, x2);
+  c->stream = keep;
+  if (e) return e;
+  HIPCHK(c, hipEventRecord(c->ev_face, c->face_stream));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_face, 0));
+  return 0;
+}
+
 int allreduce_scal(wai_ctx* c, int slot, int count) {
   if (!c->comm || c->comm->nranks == 1) return 0;
   return comm_allreduce(c->comm, c->ks.scal + slot, count, 0, c->stream, c->err);
@@ -140,9 +178,8 @@ int pc_amul(wai_ctx* c, double* x, double* z, int dot_mode, const double* aux, i
       return -1;
     if (unpack_halo(c, x, c->np, c->comm_stream)) return -1;
     HIPCHK(c, hipEventRecord(c->ev_halo, c->comm_stream));
-    if (launch_pc(c, true, x, z, dot_mode, aux, s.sub_int, s.n_int, nullptr, x2)) return -1;   // its partials wait for ...
-    if (!(c->test_drop_wait & 1)) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_halo, 0));
-    return launch_pc(c, true, x, z, dot_mode, aux, s.sub_bnd, s.n_bnd, fp, x2);        // ... the face bricks' last workgroup
+    // (fault injection, wai_test_drop_stream_wait: the face bricks ordered behind the pack instead of behind the unpack)
+    return launch_pc_split(c, x, z, dot_mode, aux, fp, x2, (c->test_drop_wait & 1) ? c->ev_pack : c->ev_halo);
   }
   if (halo) {
     if (x2) {

@@ -18,6 +18,7 @@ extern "C" {
 int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
   if (!c || !ms_per_launch || reps <= 0) return -2;
   read_env(c);
+  if (which == 16 && ensure_face_stream(c)) return -1;
   if (which > 0 && !c->ilu.factored) { const int e = do_pc_setup(c); if (e) return e < 0 ? -1 : e; }
   Krylov& k = c->ks;
   auto run = [&]() {
@@ -26,6 +27,14 @@ int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
       case 1: case 3: pc_solve(c, k.P, k.V, 0, nullptr, nullptr); break;
       case 9: if (c->ilu.n_int > 0) launch_pc(c, true, k.P, k.V, 1, k.RP, c->ilu.sub_int, c->ilu.n_int); break;   // interior bricks only
       case 10: if (c->ilu.n_bnd > 0) launch_pc(c, true, k.P, k.V, 1, k.RP, c->ilu.sub_bnd, c->ilu.n_bnd); break;  // face bricks only
+      case 16:  // interior + face bricks as the overlapped halo exchange launches them (no halo here): the split's cost against case 2
+        if (c->ilu.n_int > 0 && c->ilu.n_bnd > 0) {
+          int slot0, nslots;
+          mode_slots(1, slot0, nslots);
+          const Fin fin = make_fin(c, slot0, nslots, 2);
+          launch_pc_split(c, k.P, k.V, 1, k.RP, &fin, nullptr, nullptr);
+        }
+        break;
       case 5: {  // the launches (and, on several ranks, collectives) of one BiCGStab iteration back to back, no host in
                  // the loop: the iteration's floor
         const BcgsPlan pl = bcgs_plan(c);
