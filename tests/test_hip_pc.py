@@ -178,8 +178,8 @@ def test_bicgstab_fused_iteration(oracle, eos, brick, minc, monkeypatch):
     can_compose = not kernel.startswith("k_pc<")
     assert 4 <= per <= 4 + 8.0 / its, (kernel, per)
     assert (3 if can_compose else 4) <= out["composed"][4] <= (3 if can_compose else 4) + 8.0 / its, (kernel, out["composed"][4])
-    # the default: composed for k_pc_park on its 16-bit column indices (round 5: measured faster at every size), stored S elsewhere
-    dflt = 3 if "col16" in kernel else 4
+    # the default: composed for k_pc_park on its 16-bit column indices and for k_pc_wave (round 5: measured faster), stored S elsewhere
+    dflt = 3 if ("col16" in kernel or kernel.startswith("k_pc_wave")) else 4
     assert dflt <= out["default"][4] <= dflt + 8.0 / its, (kernel, out["default"][4])
     assert out["merged"][4] >= 5 and out["fin_separate"][4] >= 5 and 5 <= out["petsc"][4] <= 5 + 8.0 / its
     for tag in ("fused", "petsc"):

@@ -2548,7 +2548,11 @@ static int pc_kernel_kind(const wai_ctx* c, const Bcsr& J, const IluSchedule& s)
   return 0;
 }
 bool pc_axpy_capable(const wai_ctx* c) { return !c->ilu.big && pc_kernel_kind(c, c->J, c->ilu) != 0; }
-bool pc_axpy_default(const wai_ctx* c) { return !c->ilu.big && pc_kernel_kind(c, c->J, c->ilu) == 1 && c->ilu.col16 && !c->env.no_col16; }
+bool pc_axpy_default(const wai_ctx* c) {
+  if (c->ilu.big) return false;
+  const int kind = pc_kernel_kind(c, c->J, c->ilu);
+  return (kind == 1 && c->ilu.col16 && !c->env.no_col16) || kind == 3;   // k_pc_park on col16, k_pc_wave: measured faster end to end
+}
 
 // ticks of the 100-MHz clock between the cohorts of a fused launch's first generation (stagger_start); WAI_PC_STAGGER overrides
 static int stagger_ticks(const wai_ctx* c, int dflt) { return c->env.stagger >= 0 ? c->env.stagger : dflt; }

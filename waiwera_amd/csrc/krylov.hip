@@ -255,7 +255,9 @@ int bcgs_mode(const wai_ctx* c) {
 // Default since round 5 for the 2 x 2 kernel (k_pc_park): with a row's column indices in ONE 16-byte load (col16) the
 // composed operand's second gather per slot no longer costs more than k_bcgs_s saves -- MEASURED end to end on one box
 // (profiles/compose_full_ab_r5.log; identical Krylov counts): ms per iteration C3 1.537 -> 1.455, the 108^3 rank
-// share 0.2192 -> 0.2127, C2 0.1946 -> 0.1897.  WAI_BCGS_COMPOSE=0 / 1 forces it off / on (3 x 3 kernels: on request).
+// share 0.2192 -> 0.2127, C2 0.1946 -> 0.1897 -- and for the one-wave-per-brick kernel of 3 x 3 blocks on the SELL-64 layout
+// (profiles/compose_full_c4c5_ab_r5.log): C4 1.303 -> 1.265, C5 0.486 -> 0.467.  WAI_BCGS_COMPOSE=0 / 1 forces it off / on
+// (k_pc_rows -- 4 x 4 blocks, MINC inside 3-D bricks -- not measured: on request).
 bool pc_axpy_ok(const wai_ctx* c) {
   if (!(pc_fused(c) && !c->net.cp_valid && pc_axpy_capable(c))) return false;
   if (const char* e = getenv("WAI_BCGS_COMPOSE")) return e[0] == '1';
