@@ -47,3 +47,28 @@ def test_async_transport_selftest(ranks, delay_us):
         env.setdefault("GPU_MAX_HW_QUEUES", "1")     # 8 x 4 hardware queues oversubscribe the device's queue slots (tests/test_hip_multirank.py::_own_cus)
     out = subprocess.run([exe, str(ranks), "300"], env=env, capture_output=True, text=True, timeout=500)
     assert out.returncode == 0 and "PASSED" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+
+
+@pytest.mark.timeout(600)
+def test_toolchain_on_this_box_builds_and_runs_a_kernel(tmp_path):
+    """__graft_entry__.build() finds the shipped libraries current (source digest) and compiles nothing on a GPU box; this
+    compiles on THE BOX -- its hipcc against its own runtime -- the asynchronous transport and its stress test from their
+    sources and runs the result on two ranks, so a toolchain / runtime mismatch between the authoring container and the box
+    would show here and not first in the field"""
+    import os
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "loopback_rccl")
+    for f in ("async_rccl.hip", "async_selftest.hip"):
+        shutil.copy(os.path.join(src, f), tmp_path)
+    flags = ["-O2", "-std=c++17", "--offload-arch=gfx950"]
+    subprocess.run([hipcc] + flags + ["-fPIC", "-shared", "-o", "libasync_rccl.so", "async_rccl.hip", "-lrt"], cwd=tmp_path, check=True, timeout=300)
+    subprocess.run([hipcc] + flags + ["-o", "async_selftest", "async_selftest.hip", "-L.", "-lasync_rccl", "-Wl,-rpath,$ORIGIN", "-lrt"],
+                   cwd=tmp_path, check=True, timeout=300)
+    env = dict(os.environ, WAI_ASYNC_RCCL_TIMEOUT_S="30")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([os.path.join(tmp_path, "async_selftest"), "2", "100"], env=env, capture_output=True, text=True, timeout=200)
+    assert out.returncode == 0 and "PASSED" in out.stdout, (out.stdout[-1000:], out.stderr[-1000:])
