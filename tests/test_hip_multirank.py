@@ -181,6 +181,66 @@ def test_a_missing_stream_wait_is_seen():
     assert wrong == world
 
 
+def _folded_scalars_worker(rank, world, uid_q, q):
+    os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    _own_cus(rank, world)
+    from waiwera_amd import lib as wl
+    from waiwera_amd.flow_simulation import FlowSimulation
+    if rank == 0:
+        uid = wl.comm_unique_id()
+        for _ in range(world - 1):
+            uid_q.put(uid)
+    else:
+        uid = uid_q.get(timeout=300)
+    g, lm, prim, region = _problem(M.partition_shape(world), rank, (16, 16, 16), (2, 2, 2))
+    sim = FlowSimulation(lm, eos="we", device=0)
+    sim.set_regions(region)
+    sim.comm_init(rank, world, uid)
+    y = scaled(prim, region).ravel().copy()
+    sim.set_opts(ksp_rtol=1e-10)
+    assert sim.timestep(0.0, 2.0e4, y)[0] > 0
+    n = lm.n_owned * 2
+    b = np.random.default_rng(3 + rank).uniform(-1, 1, n)
+    out = {}
+    for tag in ("folded", "kernels"):
+        if tag == "kernels":
+            os.environ["WAI_BCGS_SCALAR_KERNELS"] = "1"
+        x = np.zeros(n)
+        k0, a0 = sim.launch_stats()[0], sim.comm_stats()[0]
+        kits, kreason, rn = sim.ksp_solve(b, x)
+        out[tag] = (kits, kreason, rn, x.copy(), sim.launch_stats()[0] - k0, sim.comm_stats()[0] - a0)
+    q.put((rank, sim.pc_kernel_name(), out))
+    sim.destroy()
+
+
+@pytest.mark.timeout(900)
+def test_scalar_kernels_folded_into_their_consumers():
+    """Several ranks, round 5: the two one-thread kernels that sat behind the two all-reduces of a BiCGStab iteration are
+    gone -- alpha = rho / (V, rP) is formed by the pack of the composed operand's ghost values (k_pack_axpy<DERIVE>), omega,
+    (R,R), rho, beta and the post to the host by the X / R / P update (k_bcgs_xrp<DERIVE>), each thread from the
+    all-reduced sums, with the expressions of derive_scalars: same iterates bit for bit as with the scalar kernels
+    (WAI_BCGS_SCALAR_KERNELS=1), two launches per iteration fewer, the same two all-reduces."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q, uid_q = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_folded_scalars_worker, args=(r, world, uid_q, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, kernel, out in res:
+        kf, rf, nf, xf, lf, af = out["folded"]
+        kk, rk, nk, xk, lk, ak = out["kernels"]
+        assert "col16" in kernel                 # the composed iteration is the one in force
+        assert rf > 0 and rk > 0 and kf == kk and nf == nk and np.array_equal(xf, xk), (rank, kf, kk, nf, nk)
+        assert af == ak and af <= 2 * kf + 4     # the same all-reduces
+        per_f, per_k = lf / kf, lk / kk
+        print("rank", rank, "launches per iteration: folded %.2f, scalar kernels %.2f" % (per_f, per_k))
+        assert 1.7 <= per_k - per_f <= 2.3, (per_f, per_k)
+
+
 @pytest.mark.timeout(2400)
 def test_overlapped_halo_exchange_eight_ranks(monkeypatch):
     """the multi-rank default (ghost values in flight behind the interior bricks) on the 2 x 2 x 2 partition:

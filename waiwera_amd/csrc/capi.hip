@@ -176,7 +176,7 @@ void free_all(wai_ctx* c) {
   free_asm(c->as_aux);
   F(c->lu.inv); F(c->lu.inv_ptr);
   Krylov& k = c->ks;
-  F(k.R); F(k.RP); F(k.P); F(k.V); F(k.S); F(k.T); F(k.tmp); F(k.X); F(k.basis); F(k.bl); F(k.partials); F(k.partials2); F(k.scal);
+  F(k.R); F(k.RP); F(k.P); F(k.V); F(k.S); F(k.T); F(k.tmp); F(k.X); F(k.basis); F(k.bl); F(k.partials); F(k.partials2); F(k.scal); F(k.started);
   if (k.h_scal) (void)hipHostFree(k.h_scal);
   F(c->flu); F(c->flu_last_iter); F(c->flu_last_step); F(c->flu_pert); F(c->hstep);
   F(c->w_y); F(c->w_yold); F(c->w_delta); F(c->w_f); F(c->w_lhs); F(c->w_lhs2); F(c->w_hist); F(c->w_hist_prev);
@@ -444,6 +444,10 @@ int wai_ctx_create(const wai_mesh_desc* md, const wai_eos_desc* ed, const wai_so
   if (dev_alloc(c, &k.partials, (size_t)NSLOTS * k.nb_max) || dev_alloc(c, &k.scal, (size_t)NSCAL) ||
       dev_alloc(c, &k.partials2, (size_t)NSLOTS * FIN_MAXF))
     return -1;
+  if (!k.started) {
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&k.started), 64));
+    HIPCHK(c, hipMemset(k.started, 0, 64));
+  }
   partials_clear(c, 0, NSLOTS);   // every reduction slot starts empty (fin_block reads arrival off the data)
   HIPCHK(c, hipMemset(k.scal, 0, NSCAL * sizeof(double)));
   // pinned, coherent, device-mapped: the kernels that finish a BiCGStab iteration write the scalars the host

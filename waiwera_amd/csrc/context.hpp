@@ -352,6 +352,8 @@ struct Krylov {
   int basis_m = 0;
   double* partials = nullptr;  // [slots][nb_max]
   double* partials2 = nullptr; // [slots][FIN_MAXF]: slice sums of the finaliser workgroups (fin_block)
+  unsigned* started = nullptr; // k_bcgs_xrp<DERIVE>: workgroups of the launch that have read their scalars (device counter, zero between launches)
+  bool alpha_pending = false;  // several ranks: alpha = rho / (V,rP) is to be derived by the next pack_halo_axpy launch (no scalar kernel)
   int nb_max = 0;
   double* scal = nullptr;      // device scalars
   double* h_scal = nullptr;    // pinned host mirror
@@ -417,7 +419,7 @@ struct wai_ctx {
   hipEvent_t ev_face = nullptr, ev_prior = nullptr;
   // run-time switches of the fused launches, read from the environment once per solve / set-up / probe (read_env),
   // not per launch: WAI_FIN_SEPARATE, WAI_PC_STAGGER (-1: each kernel's default), WAI_WAVE_ROWPTR, WAI_NO_COL16 (k_pc_park on the int32 column planes)
-  struct EnvSw { bool fin_separate = false; int stagger = -1; bool wave_rowptr = false; bool no_col16 = false; bool no_face_stream = false; } env;
+  struct EnvSw { bool fin_separate = false; int stagger = -1; bool wave_rowptr = false; bool no_col16 = false; bool no_face_stream = false; bool scalar_kernels = false; } env;
   int test_drop_wait = 0;   // fault injection (wai_test_drop_stream_wait): 1 the face bricks' launch does not wait for the halo
   // halo
   int n_nbr = 0;
@@ -513,6 +515,7 @@ int vec_copy(wai_ctx* c, double* dst, const double* src, size_t n);
 int vec_zero(wai_ctx* c, double* dst, size_t n);
 int vec_waxpy(wai_ctx* c, double* w, double alpha, const double* x, const double* y, int n);
 int bcgs_scalars(wai_ctx* c, int phase, bool post = false);
+int bcgs_update_xrp_derive(wai_ctx* c);
 int bcgs_post(wai_ctx* c, int seq);
 void read_env(wai_ctx* c);   // the launch switches above (kernels_linalg.hip)
 int test_drop_partials(wai_ctx* c, int n);   // fault injection (tests): workgroup 0 loses its next n partial sums

@@ -2099,10 +2099,50 @@ __global__ __launch_bounds__(TPB) void k_bcgs_xr(double* __restrict__ X, double*
 //   S = R - alpha V (re-formed, never stored)   X += alpha P + omega S   R = S - omega T   P = R + beta (P - omega V)
 // -- k_bcgs_s, k_bcgs_xr and the next iteration's k_bcgs_p: reads X, P, R, V, T, writes X, R, P (8 vector passes where the
 // three kernels make 14), no reduction.  Every expression is the one its separate kernel evaluates: identical bits.
+// DERIVE (several ranks, round 5): the five all-reduced products have just arrived and the one-thread scalar kernel that
+// used to sit between the all-reduce and this launch is gone.  Every thread forms omega, (R,R), rho, beta itself from the
+// sums and the scalars of the iteration (derive_merged + derive_rotate, the same expressions in the same order: same
+// bits) and uses its own copies; workgroup 0 stores them -- the rotation overwrites what the others read, so it waits
+// until every workgroup of the launch has said that it has read (a counter; the grid is at most 1 024 workgroups, all
+// resident) -- and posts the norm to the host.  The wait is bounded; the counter is left at zero for the next launch.
+template <bool DERIVE>
 __global__ __launch_bounds__(TPB) void k_bcgs_xrp(double* __restrict__ X, double* __restrict__ R, double* __restrict__ P,
                                                   const double* __restrict__ V, const double* __restrict__ T, int n,
-                                                  const double* __restrict__ s) {
-  const double alpha = s[S_ALPHA], omega = s[S_OMEGA], beta = s[S_BETA], nalpha = -alpha, ob = -omega * beta;
+                                                  double* s, unsigned* started, double* post, int seq) {
+  double alpha, omega, beta;
+  if constexpr (DERIVE) {
+    double loc[8];
+    // a private copy of the scalars derive_scalars' phase 6 reads and writes, the derivation on the copy
+    loc[0] = s[S_D1]; loc[1] = s[S_D2]; loc[2] = s[S_DP2]; loc[3] = s[S_RHONEW]; loc[4] = s[S_W2];
+    loc[5] = s[S_RHO]; loc[6] = s[S_ALPHA]; loc[7] = s[S_BREAK];
+    const double st = loc[0], tt = loc[1], ss = loc[2], srp = loc[3], trp = loc[4];
+    double brk = loc[7];
+    if (tt == 0.0) { brk = 2.0; omega = 0.0; }
+    else omega = st / tt;
+    const double rr0 = (ss - 2.0 * omega * st) + omega * omega * tt;
+    const double rr = rr0 > 0.0 ? rr0 : 0.0;
+    const double rhonew = srp - omega * trp;
+    const double rhoold = loc[5];
+    alpha = loc[6];
+    if (rhonew == 0.0 && brk == 0.0) brk = 3.0;
+    beta = (rhonew / rhoold) * (alpha / omega);
+    __syncthreads();                       // every thread of the workgroup has its copies
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(started, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (blockIdx.x == 0) {
+        for (int spin = 0; spin < (1 << 24) && __hip_atomic_load(started, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x; spin++)
+          __builtin_amdgcn_s_sleep(2);
+        s[S_OMEGA] = omega; s[S_DP2] = rr; s[S_RHONEW] = rhonew;
+        s[S_RHOOLD] = rhoold; s[S_RHO] = rhonew; s[S_BETA] = beta; s[S_BREAK] = brk;
+        __threadfence();
+        if (seq > 0) post_scalars(s, post, seq);
+        __hip_atomic_store(started, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  } else {
+    alpha = s[S_ALPHA]; omega = s[S_OMEGA]; beta = s[S_BETA];
+  }
+  const double nalpha = -alpha, ob = -omega * beta;
   auto one = [&](double x, double r0, double p, double v, double t, double& xo, double& ro, double& po) {
     const double si = __builtin_fma(nalpha, v, r0);
     xo = __builtin_fma(omega, si, __builtin_fma(alpha, p, x));
@@ -2137,14 +2177,29 @@ __global__ __launch_bounds__(TPB) void k_bcgs_xrp(double* __restrict__ X, double
 // halo pack of a composed vector: sendbuf[p*dof + k] = a[idx*dof + k] - alpha b[idx*dof + k] (the ghost values of
 // S = R - alpha V for the fused launch that forms S on the fly; the receiver unpacks them into R's ghost entries and
 // keeps V's at zero)
+// DERIVE (several ranks, round 5): alpha is not there yet -- the all-reduced (V, rP) has just arrived and the one-thread
+// scalar kernel that used to sit between the all-reduce and this launch is gone: every thread forms
+// alpha = rho / (V, rP) itself (derive_scalars' phase 2, the same division: same bits) and thread 0 stores it -- with the
+// breakdown code of (V, rP) = 0 -- for the launches behind this one, which read S_ALPHA as before.  Nobody reads S_ALPHA
+// in this launch, nobody writes S_RHO / S_D1: no hazard.
+template <bool DERIVE>
 __global__ __launch_bounds__(TPB) void k_pack_axpy(const double* __restrict__ a, const double* __restrict__ b,
-                                                   const double* __restrict__ s, const int* __restrict__ idx,
+                                                   double* s, const int* __restrict__ idx,
                                                    int n, int dof, double* __restrict__ buf) {
   const int t = blockIdx.x * TPB + threadIdx.x;
+  double alpha;
+  if constexpr (DERIVE) {
+    const double d1 = s[S_D1];
+    alpha = s[S_RHO] / d1;
+    if (t == 0) {
+      if (d1 == 0.0) s[S_BREAK] = 1.0;
+      s[S_ALPHA] = alpha;
+    }
+  } else alpha = s[S_ALPHA];
   if (t >= n * dof) return;
   const int p = t / dof, k = t - p * dof;
   const size_t g = (size_t)idx[p] * dof + k;
-  buf[t] = __builtin_fma(-s[S_ALPHA], b[g], a[g]);
+  buf[t] = __builtin_fma(-alpha, b[g], a[g]);
 }
 
 __global__ __launch_bounds__(TPB) void k_waxpy(double* w, double alpha, const double* x, const double* y, int n) {
@@ -2437,6 +2492,7 @@ void read_env(wai_ctx* c) {
   c->env.stagger = es ? atoi(es) : -1;
   c->env.wave_rowptr = getenv("WAI_WAVE_ROWPTR") != nullptr;
   c->env.no_col16 = getenv("WAI_NO_COL16") != nullptr;
+  c->env.scalar_kernels = getenv("WAI_BCGS_SCALAR_KERNELS") != nullptr;   // several ranks: the one-thread kernels behind the all-reduces (rounds 3-4)
   { const char* e = getenv("WAI_FACE_STREAM"); c->env.no_face_stream = !(e && e[0] == '1'); }   // measured slower: off unless asked for
 }
 int bcgs_post(wai_ctx* c, int seq);
@@ -2822,8 +2878,15 @@ int bcgs_update_xr(wai_ctx* c, bool dots, int fin_phase, bool post) {
 }
 int bcgs_update_xrp(wai_ctx* c) {
   c->ks.n_launch++;
-  hipLaunchKernelGGL(k_bcgs_xrp, vgrid(c->ks.n), TPB, 0, c->stream, c->ks.X, c->ks.R, c->ks.P, c->ks.V, c->ks.T, c->ks.n,
-                     c->ks.scal);
+  hipLaunchKernelGGL(k_bcgs_xrp<false>, vgrid(c->ks.n), TPB, 0, c->stream, c->ks.X, c->ks.R, c->ks.P, c->ks.V, c->ks.T, c->ks.n,
+                     c->ks.scal, nullptr, nullptr, 0);
+  return 0;
+}
+// the same launch deriving omega, (R,R), rho, beta from the all-reduced sums itself and posting the norm (several ranks)
+int bcgs_update_xrp_derive(wai_ctx* c) {
+  c->ks.n_launch++;
+  hipLaunchKernelGGL(k_bcgs_xrp<true>, vgrid(c->ks.n), TPB, 0, c->stream, c->ks.X, c->ks.R, c->ks.P, c->ks.V, c->ks.T, c->ks.n,
+                     c->ks.scal, c->ks.started, c->ks.d_post, ++c->ks.seq);
   return 0;
 }
 int gmres_mdot(wai_ctx* c, const double* w, int k) {
@@ -2865,8 +2928,13 @@ int pack_halo_axpy(wai_ctx* c, const double* a, const double* b, int dof, hipStr
   const int n = c->send_total;
   if (n <= 0) return 0;
   c->ks.n_launch++;
-  hipLaunchKernelGGL(k_pack_axpy, (n * dof + TPB - 1) / TPB, TPB, 0, stream ? stream : c->stream, a, b, c->ks.scal,
-                     c->d_send_idx, n, dof, c->d_sendbuf);
+  if (c->ks.alpha_pending)
+    hipLaunchKernelGGL(k_pack_axpy<true>, (n * dof + TPB - 1) / TPB, TPB, 0, stream ? stream : c->stream, a, b, c->ks.scal,
+                       c->d_send_idx, n, dof, c->d_sendbuf);
+  else
+    hipLaunchKernelGGL(k_pack_axpy<false>, (n * dof + TPB - 1) / TPB, TPB, 0, stream ? stream : c->stream, a, b, c->ks.scal,
+                       c->d_send_idx, n, dof, c->d_sendbuf);
+  c->ks.alpha_pending = false;
   return 0;
 }
 int unpack_halo(wai_ctx* c, double* vec, int dof, hipStream_t stream) {

@@ -281,7 +281,13 @@ int bcgs_first_half(wai_ctx* c, const BcgsPlan& pl) {
   if (!pl.fused3) { Prof p(c, KC_VECTOR); bcgs_update_p(c); }
   if (int e = pc_amul(c, k.P, k.V, 1, k.RP, pl.multi ? -1 : 2)) return e;
   Prof p(c, KC_VECTOR);
-  if (pl.multi) { if (int e = allreduce_scal(c, S_D1, 1)) return e; bcgs_scalars(c, 2); }
+  if (pl.multi) {
+    if (int e = allreduce_scal(c, S_D1, 1)) return e;
+    // alpha: by the pack of the composed operand's ghost values, the next launch on this stream (k_pack_axpy<DERIVE>) --
+    // or, where there is no such launch, by the one-thread scalar kernel
+    if (pl.axpy && c->send_total > 0 && c->mesh.n_halo > 0 && !c->env.scalar_kernels) c->ks.alpha_pending = true;
+    else bcgs_scalars(c, 2);
+  }
   if (!pl.axpy) bcgs_update_s(c);
   return 0;
 }
@@ -296,7 +302,13 @@ int bcgs_second_half(wai_ctx* c, const BcgsPlan& pl) {
   if (pl.fused3) {
     if (int e = pc_amul(c, pl.axpy ? k.R : k.S, k.T, 4, k.RP, pl.multi ? -1 : 6, pl.axpy ? k.V : nullptr, !pl.multi)) return e;
     Prof p(c, KC_VECTOR);
-    if (pl.multi) { if (int e = allreduce_scal(c, S_D1, 5)) return e; bcgs_scalars(c, 6, true); }
+    if (pl.multi) {
+      // omega, (R,R), rho, beta and the post: derived by the X / R / P update itself (k_bcgs_xrp<DERIVE>), no scalar kernel
+      if (int e = allreduce_scal(c, S_D1, 5)) return e;
+      if (c->env.scalar_kernels) { bcgs_scalars(c, 6, true); bcgs_update_xrp(c); }
+      else bcgs_update_xrp_derive(c);
+      return 0;
+    }
     bcgs_update_xrp(c);
     return 0;
   }
@@ -330,6 +342,7 @@ int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, doub
   vec_zero(c, x, n);
   vec_zero(c, k.P, k.nl);
   vec_zero(c, k.V, pl.fused3 ? k.nl : n);   // fused: V's ghost entries stay zero (the composed operand's ghosts arrive in R's)
+  k.alpha_pending = false;
   partials_clear(c, S_D1, 5);   // S_D1 .. S_W2: whatever an aborted solve or a probe left behind
   vec_zero(c, k.scal + S_BREAK, 1);
   {
