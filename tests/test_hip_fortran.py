@@ -58,3 +58,59 @@ def test_fortran_driver_matches_python_host(tmp_path):
     assert int(chk["error"][0]) < 0 and "curve table" in " ".join(chk["error"][1:])   # the library's text reached Fortran
     assert [int(v) for v in chk["comm"]] == [0, 0, 1]
     sim.destroy()
+
+
+@pytest.mark.timeout(900)
+def test_fortran_host_on_two_ranks(tmp_path):
+    """north_star's shape of the boundary: an object-oriented Fortran 2003 host per rank, calling HIP through
+    iso_c_binding, ghost-cell halo exchange and Krylov all-reduces below it.  Two newton_driver processes -- one per rank
+    of a 2 x 1 x 1 partition, each with its own case file (the rank's cells, ghost lists for wai_set_halo), the RCCL id
+    handed from rank 0 to rank 1 through a file (the host's MPI broadcast in the reference's setting) -- run four time
+    steps in the reference's SNES callback order over the stream-asynchronous test transport (both ranks on this one
+    GPU); the result must be the one-rank Python host's: same Newton count, same regions, solution to 1e-7."""
+    from waiwera_amd import fortran_io, mesh as M
+    from waiwera_amd.cases import scaled as _scaled
+    from waiwera_amd.flow_simulation import FlowSimulation
+    from waiwera_amd.timestepper import Timestepper
+    subprocess.check_call(["make", "-C", FDIR], stdout=subprocess.DEVNULL)
+    dims, brick, world = (16, 12, 8), (4, 4, 4), 2
+    lib = os.path.join(ROOT, "tests", "loopback_rccl", "libasync_rccl.so")
+    idfile = str(tmp_path / "rccl_id.bin")
+    procs, meshes = [], []
+    for rank in range(world):
+        g = M.StructuredGrid(dims, spacing=(10.0, 10.0, 500.0 / dims[2]), part=M.partition_shape(world), brick=brick)
+        lm = g.local_mesh(rank, rock_fn=M.heterogeneous_rock(g.n_global), top_bc=([1.0e5, 20.0], 1), sources=M.benchmark_sources(g))
+        prim, region = M.benchmark_initial_state(g, lm.extras["prim_ijk"], lens=True)
+        y0 = _scaled(prim, region).ravel().copy()
+        inp, out = str(tmp_path / ("case%d.bin" % rank)), str(tmp_path / ("result%d.bin" % rank))
+        fortran_io.write_case(inp, lm, "we", y0, region)
+        per = 256 // world
+        env = dict(os.environ, WAI_RCCL_LIB=lib, HSA_CU_MASK="0:%d-%d" % (rank * per, (rank + 1) * per - 1))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([os.path.join(FDIR, "newton_driver"), inp, out, "4", "1.0e4", str(rank), str(world), idfile],
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env))
+        meshes.append((lm, out))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), logs
+    # the one-rank run of the Python host
+    g1 = M.StructuredGrid(dims, spacing=(10.0, 10.0, 500.0 / dims[2]), part=(1, 1, 1), brick=brick)
+    lm1 = g1.local_mesh(0, rock_fn=M.heterogeneous_rock(g1.n_global), top_bc=([1.0e5, 20.0], 1), sources=M.benchmark_sources(g1))
+    prim1, region1 = M.benchmark_initial_state(g1, lm1.extras["prim_ijk"], lens=True)
+    sim = FlowSimulation(lm1, eos="we")
+    sim.set_regions(region1)
+    y = _scaled(prim1, region1).ravel().copy()
+    ts = Timestepper(sim, y, stepsize=1.0e4, adapt=True, adapt_min=float("inf"), adapt_max=float("inf"))
+    ts.run(4)
+    yser = np.zeros((g1.n_global, 2)); rser = np.zeros(g1.n_global, dtype=int)
+    yser[lm1.owned_gid] = y[: lm1.n_owned * 2].reshape(-1, 2)
+    rser[lm1.owned_gid] = sim.regions()[: lm1.n_owned]
+    sim.destroy()
+    ypar = np.zeros_like(yser); rpar = np.zeros_like(rser)
+    for lm, out in meshes:
+        tn, tk, yf, rf = fortran_io.read_result(out, lm.n_owned, lm.n_prim, 2)
+        assert tn == sum(h[2] for h in ts.history), (tn, ts.history)
+        ypar[lm.owned_gid] = yf.reshape(-1, 2)
+        rpar[lm.owned_gid] = rf[: lm.n_owned]
+    assert np.array_equal(rpar, rser) and (rser != 1).any()
+    err = np.abs(ypar - yser).max(axis=0) / np.abs(yser).max(axis=0)
+    assert err.max() < 1e-7, err

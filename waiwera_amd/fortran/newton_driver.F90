@@ -20,6 +20,11 @@ program newton_driver
   real(c_double), allocatable, target :: src_rate(:), src_enth(:)
   real(dp), allocatable :: y(:), lhs_old(:), f(:), y_save(:)
   integer(c_int) :: hdr(10), ierr
+  integer(c_int), allocatable, target :: nbr_rank(:), send_ptr(:), send_idx(:), recv_ptr(:)
+  integer :: n_nbr, n_send, my_rank, n_ranks
+  character(len = 512) :: idfile
+  character(kind = c_char) :: comm_id(128)
+  logical :: there
   integer :: n_owned, n_halo, n_bc, n_faces, n_sub, n_src, eos_kind, np, n_local
   integer :: num_steps, step, it, ksp_its, reason, err, tries, total_newton, total_ksp, u
   real(dp) :: t, dt, max_residual
@@ -31,11 +36,19 @@ program newton_driver
   call get_command_argument(2, outfile)
   call get_command_argument(3, arg); read(arg, *) num_steps
   call get_command_argument(4, arg); read(arg, *) dt
+  ! several ranks (one process per GPU; the reference: mpiexec + PETSC_COMM_WORLD): rank, number of ranks, and a file
+  ! through which rank 0 hands the RCCL unique id to the others (the host's MPI broadcast in the reference's setting)
+  my_rank = 0; n_ranks = 1
+  if (command_argument_count() >= 7) then
+     call get_command_argument(5, arg); read(arg, *) my_rank
+     call get_command_argument(6, arg); read(arg, *) n_ranks
+     call get_command_argument(7, idfile)
+  end if
 
   open(newunit = u, file = trim(infile), access = 'stream', form = 'unformatted', status = 'old')
   read(u) hdr
   eos_kind = hdr(1); n_owned = hdr(2); n_halo = hdr(3); n_bc = hdr(4); n_faces = hdr(5)
-  n_sub = hdr(6); n_src = hdr(7); np = hdr(8)
+  n_sub = hdr(6); n_src = hdr(7); np = hdr(8); n_nbr = hdr(9); n_send = hdr(10)
   n_local = n_owned + n_halo + n_bc
   allocate(face_cells(2 * n_faces), face_geom(12 * n_faces), cell_geom(4 * n_local), rock(8 * n_local))
   allocate(sub_ptr(n_sub + 1), region(n_owned + n_halo), y(np * n_owned))
@@ -44,6 +57,8 @@ program newton_driver
   read(u) face_cells, face_geom, cell_geom, rock, sub_ptr, region, y
   if (n_bc > 0) read(u) bc_primary(1:np * n_bc), bc_region(1:n_bc)
   if (n_src > 0) read(u) src_cell(1:n_src), src_rate(1:n_src), src_enth(1:n_src), src_comp(1:n_src)
+  allocate(nbr_rank(max(1, n_nbr)), send_ptr(n_nbr + 1), send_idx(max(1, n_send)), recv_ptr(n_nbr + 1))
+  if (n_nbr > 0) read(u) nbr_rank(1:n_nbr), send_ptr, send_idx(1:n_send), recv_ptr
   close(u)
 
   mesh%n_owned = n_owned; mesh%n_halo = n_halo; mesh%n_bc = n_bc; mesh%n_faces = n_faces
@@ -57,6 +72,29 @@ program newton_driver
   if (n_bc > 0) ierr = wai_set_bc(sim%ctx, bc_primary, bc_region)
   if (n_src > 0) ierr = wai_set_sources(sim%ctx, int(n_src, c_int), src_cell, src_rate, src_enth, src_comp)
   ierr = wai_set_regions(sim%ctx, region)
+  if (n_ranks > 1) then
+     ! the partition's ghost lists (DMGlobalToLocal, src/dm_utils.F90:480-498), then the communicator
+     ierr = wai_set_halo(sim%ctx, int(n_nbr, c_int), nbr_rank, send_ptr, send_idx, recv_ptr)
+     if (ierr /= 0) stop 'wai_set_halo failed'
+     if (my_rank == 0) then
+        ierr = wai_comm_unique_id(comm_id)
+        open(newunit = u, file = trim(idfile) // '.part', access = 'stream', form = 'unformatted', status = 'replace')
+        write(u) comm_id
+        close(u)
+        call execute_command_line('mv ' // trim(idfile) // '.part ' // trim(idfile))
+     else
+        do
+           inquire(file = trim(idfile), exist = there)
+           if (there) exit
+           call execute_command_line('sleep 0.05')
+        end do
+        open(newunit = u, file = trim(idfile), access = 'stream', form = 'unformatted', status = 'old')
+        read(u) comm_id
+        close(u)
+     end if
+     call sim%init_comm(my_rank, n_ranks, comm_id, err)
+     if (err /= 0) stop 'wai_comm_init failed'
+  end if
 
   allocate(lhs_old(np * n_owned), f(np * n_owned), y_save(np * n_owned))
   t = 0._dp
@@ -99,7 +137,7 @@ program newton_driver
      dt = dt * 2._dp
   end do
 
-  call surface_check()
+  if (n_ranks == 1) call surface_check()
   ierr = wai_get_regions(sim%ctx, region)
   open(newunit = u, file = trim(outfile), access = 'stream', form = 'unformatted', status = 'replace')
   write(u) int(total_newton, c_int), int(total_ksp, c_int)
