@@ -435,6 +435,30 @@ def test_brick_local_column_indices_same_bits(oracle, dims, brick, monkeypatch):
     sim.destroy(); osim.close()
 
 
+def test_column_indices_fall_back_to_int32_when_a_brick_reaches_too_far(oracle, monkeypatch):
+    """a brick whose rows reach more than eight 8 192-column segments (unstructured inputs) keeps the int32 column planes
+    for the whole matrix: here the limit is lowered (WAI_COL16_MAX_SEG=1: the own brick only -- on this small mesh every
+    other column falls into one window) so that the builder bails out on a structured mesh; the library must then run k_pc_park on the int32
+    planes with the stored-S iteration and give the same solution as the default build of the same system"""
+    out = {}
+    for tag, env in (("col16", None), ("int32", "1")):
+        if env:
+            monkeypatch.setenv("WAI_COL16_MAX_SEG", env)
+        lm, sim, osim, J, f = system(oracle, "we", (12, 12, 8), (4, 4, 2))
+        sim.set_opts(pc_type="bjacobi", ksp_type="bcgs", ksp_rtol=1e-10)
+        assert sim.pc_setup() == 0
+        out[tag] = [sim.pc_kernel_name()]
+        x = np.zeros(sim.num_dof)
+        k0 = sim.launch_stats()[0]
+        its, reason, rn = sim.ksp_solve(f, x)
+        out[tag] += [its, reason, rn, x.copy(), (sim.launch_stats()[0] - k0) / max(its, 1)]
+        sim.destroy(); osim.close()
+    assert out["col16"][0] == "k_pc_park<spmv,col16>" and out["int32"][0] == "k_pc_park<spmv>"
+    assert out["col16"][2] > 0 and out["int32"][2] > 0
+    assert out["col16"][1] == out["int32"][1] and out["col16"][3] == out["int32"][3] and np.array_equal(out["col16"][4], out["int32"][4])
+    assert out["col16"][5] < 3.5 and out["int32"][5] > 3.9       # composed (three launches) only on the 16-bit indices
+
+
 @pytest.mark.parametrize("compose", ["0", None])
 def test_bicgstab_iteration_is_four_launches_and_no_copy(oracle, compose, monkeypatch):
     """(three launches with the default of the 2 x 2 kernel since round 5: S = R - alpha V formed inside the second fused

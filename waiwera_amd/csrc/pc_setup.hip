@@ -250,6 +250,9 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
     std::vector<int> seg((size_t)s.nsub * 8, 0);
     std::vector<int> far;
     bool ok = true;
+    // (tests: WAI_COL16_MAX_SEG=<n> lowers the limit so that a structured mesh takes the bail-out an unstructured one would)
+    int max_seg = 8;
+    if (const char* e = getenv("WAI_COL16_MAX_SEG")) max_seg = std::max(1, std::min(8, atoi(e)));
     for (int sd = 0; sd < s.nsub && ok; sd++) {
       const int lo = sub[sd], hi = sub[sd + 1];
       far.clear();
@@ -262,7 +265,7 @@ int build_schedule(wai_ctx* c, IluSchedule& s, const std::vector<int>& rowptr, c
       int nseg = 1;
       sg[0] = lo;
       for (size_t k = 0; k < far.size();) {      // windows of 8192 columns over what the brick reaches outside itself
-        if (nseg == 8) { ok = false; break; }
+        if (nseg == max_seg) { ok = false; break; }
         const int base = far[k];
         sg[nseg++] = base;
         while (k < far.size() && far[k] - base < 8192) k++;
