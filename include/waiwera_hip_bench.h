@@ -12,7 +12,8 @@ extern "C" {
  * neighbour exchanges (halos); a BiCGStab iteration costs 2 all-reduces and 2 exchanges */
 int wai_comm_stats(wai_ctx *ctx, long long *allreduces, long long *exchanges);
 /* kernels launched and copies enqueued by the linear-solver helpers so far (SpMV, preconditioner, vector
- * updates, reductions, halo pack / unpack, scalar read-backs): a BiCGStab iteration on one rank is 4 kernels
+ * updates, reductions, halo pack / unpack, scalar read-backs): a BiCGStab iteration on one rank is 3 kernels (2 x 2 and
+ * 3 x 3 blocks: the second fused launch forms its operand itself; 4 with a stored S), on several ranks 7,
  * and no copy -- every reduction is finished by the last workgroups of its producer and the residual norm is
  * posted to pinned host memory */
 int wai_launch_stats(wai_ctx *ctx, long long *kernels, long long *copies);
