@@ -205,3 +205,42 @@ def test_minc_zones_on_part_of_a_mesh():
     assert np.allclose(chain[[0, 2], 0], v0[1:3] * geo.connection_area[0])
     assert np.allclose(chain[:, 4:8], 0.0) and np.all(chain[:, 11] == 1.0)
     assert m.sub_ptr[-1] == 8
+
+
+def test_generic_partition_is_consistent_across_ranks():
+    """waiwera_amd.partition.partition_mesh on the reference's problem-5 gmsh mesh (96 cells) and on a structured mesh with
+    Dirichlet cells: every cell owned once, every rank's ghost block from q is -- cell for cell, in order -- what q sends
+    it, faces keep their geometry, boundary cells follow their cells, sources stay with their cells"""
+    import os
+    from waiwera_amd import gmsh, unstructured, mesh as M
+    from waiwera_amd.partition import block_owner, partition_mesh
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    nodes, cells, dim = gmsh.read_msh(os.path.join(root, "tests", "golden", "inputs", "gproblem5.msh"))
+    lm_u = unstructured.build_mesh(nodes, cells, dim, thickness=100.0, boundaries=[([0, 1, 2], [-1.0, 0.0, 0.0], [3.6e6, 160.0], 1)],
+                                   sources=[dict(cell=26, rate=-5.0), dict(cell=70, rate=1.0, enthalpy=1.0e5)])
+    g = M.StructuredGrid((6, 5, 4), brick=(3, 5, 2))
+    lm_s = g.local_mesh(0, top_bc=([1.0e5, 20.0], 1), sources=M.benchmark_sources(g))
+    for lm, world in ((lm_u, 3), (lm_s, 4)):
+        owner = block_owner(lm.n_owned, world)
+        parts = [partition_mesh(lm, owner, r, chunk=8) for r in range(world)]
+        seen = np.zeros(lm.n_owned, dtype=int)
+        nsrc = 0
+        for r, (m, gid) in enumerate(parts):
+            seen[m.owned_gid] += 1
+            assert np.array_equal(gid[: m.n_owned], m.owned_gid) and gid.size == m.n_prim
+            assert m.sub_ptr[0] == 0 and m.sub_ptr[-1] == m.n_owned and (np.diff(m.sub_ptr) > 0).all() and np.diff(m.sub_ptr).max() <= 8
+            assert m.face_cells.min() >= 0 and m.face_cells.max() < m.n_local
+            # every local face has at least one owned cell, and the geometry of the one-rank face it came from
+            assert ((m.face_cells < m.n_owned).any(axis=1)).all()
+            assert np.allclose(m.cell_geom[: m.n_prim], lm.cell_geom[gid])
+            nsrc += m.n_src
+            for s in range(m.n_src):
+                assert gid[m.src_cell[s]] == lm.src_cell[m.extras["src_global_index"][s]]
+            for qi, qrank in enumerate(m.nbr_ranks):
+                mq, gq = parts[qrank]
+                back = list(mq.nbr_ranks).index(r)
+                mine_from_q = gid[m.n_owned + m.recv_ptr[qi]: m.n_owned + m.recv_ptr[qi + 1]]
+                q_sends_me = gq[mq.send_idx[mq.send_ptr[back]: mq.send_ptr[back + 1]]]
+                assert np.array_equal(mine_from_q, q_sends_me)
+        assert (seen == 1).all() and nsrc == lm.n_src
+        assert sum(m.n_bc for m, _ in parts) == lm.n_bc
