@@ -485,8 +485,10 @@ def main():
         per = 256 // world
         os.environ["HSA_CU_MASK"] = "0:%d-%d" % (rank * per, (rank + 1) * per - 1)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if world >= 7:
-            os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")   # all ranks' queues mapped together: no time-slicing of queues
+        if world >= 7 and os.environ.get("WAI_HALO_OVERLAP") == "0":
+            # (in-order exchange: one queue per process keeps all ranks' queues mapped together; the overlapped exchange, with
+            # its second priority level, measured better on HIP's four -- tests/test_hip_multirank.py::_own_cus)
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
     import torch
     if world != a.gpus:
         print("bench.py: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
