@@ -204,7 +204,10 @@ def _folded_scalars_worker(rank, world, uid_q, q):
     n = lm.n_owned * 2
     b = np.random.default_rng(3 + rank).uniform(-1, 1, n)
     out = {}
-    for tag in ("folded", "kernels"):
+    for tag in ("folded", "stored", "kernels"):
+        os.environ.pop("WAI_BCGS_COMPOSE", None)
+        if tag == "stored":       # S = R - alpha V stored by its own launch: alpha from the scalar kernel, the rest folded
+            os.environ["WAI_BCGS_COMPOSE"] = "0"
         if tag == "kernels":
             os.environ["WAI_BCGS_SCALAR_KERNELS"] = "1"
         x = np.zeros(n)
@@ -237,6 +240,8 @@ def test_scalar_kernels_folded_into_their_consumers():
         kk, rk, nk, xk, lk, ak = out["kernels"]
         assert "col16" in kernel                 # the composed iteration is the one in force
         assert rf > 0 and rk > 0 and kf == kk and nf == nk and np.array_equal(xf, xk), (rank, kf, kk, nf, nk)
+        ks, rs, ns, xs, ls, a_s = out["stored"]
+        assert rs > 0 and ks == kf and ns == nf and np.array_equal(xs, xf)      # the stored-S form with the update's scalars folded
         assert af == ak and af <= 2 * kf + 4     # the same all-reduces
         per_f, per_k = lf / kf, lk / kk
         print("rank", rank, "launches per iteration: folded %.2f, scalar kernels %.2f" % (per_f, per_k))
