@@ -2132,6 +2132,9 @@ __global__ __launch_bounds__(TPB) void k_bcgs_xrp(double* __restrict__ X, double
       if (blockIdx.x == 0) {
         for (int spin = 0; spin < (1 << 24) && __hip_atomic_load(started, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x; spin++)
           __builtin_amdgcn_s_sleep(2);
+        // (a workgroup that never reported -- it cannot happen short of a lost launch -- must not pass for a valid rotation:
+        // breakdown code 4, the solve ends with KSP_DIVERGED_NANORINF and a message, as for a lost partial sum)
+        if (__hip_atomic_load(started, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) brk = 4.0;
         s[S_OMEGA] = omega; s[S_DP2] = rr; s[S_RHONEW] = rhonew;
         s[S_RHOOLD] = rhoold; s[S_RHO] = rhonew; s[S_BETA] = beta; s[S_BREAK] = brk;
         __threadfence();
