@@ -1004,3 +1004,62 @@ def test_an_unstructured_input_mesh_distributes(world):
     yser = y[: lm.n_owned * bs].reshape(-1, bs)
     err = np.abs(ypar - yser).max(axis=0) / np.abs(yser).max(axis=0)
     assert err.max() < 1e-7, err
+
+
+def _json_worker(rank, world, uid_q, q, path):
+    os.environ["WAI_RCCL_LIB"] = LOOPBACK
+    _own_cus(rank, world)
+    _default_overlap()
+    from waiwera_amd import lib as wl
+    from waiwera_amd.simulation import Simulation
+    if rank == 0:
+        uid = wl.comm_unique_id()
+        for _ in range(world - 1):
+            uid_q.put(uid)
+    else:
+        uid = uid_q.get(timeout=300)
+    sim = Simulation.from_json(path, rank=rank, world=world, comm_id=uid)
+    out = sim.run()
+    q.put((rank, sim.owned_gid.copy(), {k: np.asarray(v).copy() for k, v in out.items() if k.startswith("fluid_")},
+           sim.ts.taken, [h[2] for h in sim.ts.history]))
+    sim.ode.destroy()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name", ["problem5a", "problem2b"])
+def test_input_files_run_on_two_ranks(name):
+    """python -m waiwera_amd.run on several ranks: the JSON front end reads the whole input on every rank, keeps the rank's
+    cells (waiwera_amd.partition) and runs the reference's step sequence -- adaptive steps, the input's sources and
+    boundaries, IFC-67 -- collectively.  Model intercomparison problems 5a (two-phase areal production) and 2b (radial
+    two-phase production) from the reference's own files on two ranks against the one-rank run: same number of time steps,
+    same regions, pressure / temperature / saturation / density to 1e-4 (the inputs' nonlinear tolerance is 1e-5)."""
+    from waiwera_amd.simulation import Simulation
+    path = os.path.join(ROOT, "tests", "golden", "inputs", name + ".json")
+    ser = Simulation.from_json(path)
+    fser = {k: np.asarray(v).copy() for k, v in ser.run().items() if k.startswith("fluid_")}
+    taken = ser.ts.taken
+    ser.ode.destroy()
+    world = 2
+    ctx = mp.get_context("spawn")
+    q, uid_q = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_json_worker, args=(r, world, uid_q, q, path)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=800) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = fser["fluid_pressure"].size
+    par = {k: np.zeros(n) for k in fser}
+    seen = np.zeros(n, dtype=int)
+    for rank, gid, f, tk, newton in res:
+        assert tk == taken, (tk, taken)
+        seen[gid] += 1
+        for k in par:
+            par[k][gid] = f[k]
+    assert (seen == 1).all()
+    assert np.array_equal(par["fluid_region"], fser["fluid_region"])
+    for k in ("fluid_pressure", "fluid_temperature", "fluid_vapour_saturation", "fluid_liquid_density"):
+        sc = max(np.abs(fser[k]).max(), 1e-300)
+        # (both runs stop Newton at the input's own function tolerance, 1e-5 relative, with different preconditioners)
+        assert np.abs(par[k] - fser[k]).max() <= 1e-4 * sc, (k, np.abs(par[k] - fser[k]).max() / sc)

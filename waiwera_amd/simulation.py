@@ -230,7 +230,14 @@ class Simulation:
     """One Waiwera input file -> mesh, flow simulation object and time stepper."""
 
     def __init__(self, inp, base_dir=".", ode_factory=None, device=0, mesh_builder=None, mesh_file=None,
-                 output_dir=None):
+                 output_dir=None, rank=0, world=1, comm_id=None, owner=None):
+        """rank / world / comm_id (wai_comm_unique_id of rank 0, handed round by the host): one process per rank, each
+        reads the whole input, keeps its own cells with one ghost layer (waiwera_amd.partition.partition_mesh; owner: rank of
+        every cell, default contiguous blocks of the input's numbering) and runs the same step sequence -- what
+        DMPlexDistribute (src/mesh.F90:143-171) does for the reference.  On several ranks: constant or tabulated sources
+        and their device-side controls; not (yet) MINC zones, source networks, tracers, rock table controls, output files
+        (fields() returns the rank's cells, self.owned_gid their index in the input's numbering)."""
+        self.rank, self.world = int(rank), int(world)
         # output files go to output_dir (default: $WAIWERA_OUTPUT_DIR, else beside the input file)
         self.output_dir = output_dir or os.environ.get("WAIWERA_OUTPUT_DIR") or base_dir
         self.output_error = None
@@ -386,6 +393,18 @@ class Simulation:
                 zlist.append(dict(cells=zc, geometry=geo, matrix_rock=mrock, fracture_rock=named("fracture")))
             lm = M.add_minc_zones(lm, zlist)
             self._order = lm.extras["waiwera_order"]
+        self.owned_gid = np.arange(lm.n_owned)
+        self._src_pick = None
+        if self.world > 1:
+            if minc_in or self._rock_controls or inp.get("tracer") or inp.get("network"):
+                raise NotImplementedError("MINC zones, rock table controls, tracers and source networks of an input file on several ranks")
+            from .partition import block_owner, partition_mesh
+            own = block_owner(lm.n_owned, self.world) if owner is None else np.asarray(owner)
+            lm, self._gid = partition_mesh(lm, own, self.rank)
+            self.owned_gid = lm.owned_gid
+            self._src_pick = lm.extras.get("src_global_index", np.zeros(0, dtype=np.int32))
+            self._tables = [(int(np.nonzero(self._src_pick == i)[0][0]), key, tab) for (i, key, tab) in self._tables
+                            if i in set(self._src_pick.tolist())]
         self.mesh = lm
         self.relperm = relperm_spec(rock.get("relative_permeability"))
         self.capillary = capillary_spec(rock.get("capillary_pressure"))
@@ -427,6 +446,8 @@ class Simulation:
             else:
                 src[:] = lm.extras["minc_parent"]
             prim, region = prim[src], region[src]
+        if self.world > 1:
+            prim, region = prim[self._gid], region[self._gid]
         self.primary, self.region = prim, region
         # the flow object
         if ode_factory is None:
@@ -440,6 +461,10 @@ class Simulation:
         else:
             self.ode = ode_factory(lm, self.eos, self.thermo, self.relperm, self.capillary, temperature)
         self.ode.set_regions(region)
+        if self.world > 1:
+            if comm_id is None:
+                raise ValueError("several ranks need the communicator id of rank 0 (waiwera_amd.lib.comm_unique_id)")
+            self.ode.comm_init(self.rank, self.world, comm_id)
         self.y = np.ascontiguousarray(self.ode.scale(prim, region).ravel())
         # solver and time stepping parameters
         step = _get(inp, "time.step", {}) or {}
@@ -532,7 +557,10 @@ class Simulation:
         if _get(inp, "output.checkpoint.repeat") not in (None, False, 1):
             raise NotImplementedError("repeated output checkpoints")
 
-        self._setup_source_controls(inp.get("source", []) or [], _get(inp, "time.start", 0.0))
+        src_in = inp.get("source", []) or []
+        if self._src_pick is not None:      # the sources of this rank's cells, in the rank's order
+            src_in = [src_in[i] for i in self._src_pick]
+        self._setup_source_controls(src_in, _get(inp, "time.start", 0.0))
         self._setup_network(inp)
         if (self._tables or self._ctl_tables or getattr(self, "_tracer_tables", None) or getattr(self, "_network_timed", False)
                 or self._rock_controls):
@@ -575,6 +603,8 @@ class Simulation:
             if fl is None:
                 assert self.ode.pre_eval(t0, self.y) == 0
                 fl = np.asarray(self.ode.fluid())
+            if self.world > 1:      # the input's cell number -> this rank's (the source is on this rank: its cell is owned)
+                cell = int(np.nonzero(self.owned_gid == cell)[0][0])
             return fl[cell]
 
         nc = {"w": 1, "we": 1, "wce": 2, "wse": 2, "wae": 2, "wsce": 3, "wsae": 3}[self.eos]
@@ -721,7 +751,7 @@ class Simulation:
         finally:
             # the reference keeps what it has written when a step aborts; a file that cannot be written
             # is reported, not swallowed (the results are still returned)
-            if oc.get("filename") and self.outputs:
+            if oc.get("filename") and self.outputs and self.world == 1:     # (several ranks: no output file yet; fields())
                 try:
                     self.save_hdf5(os.path.join(self.output_dir, oc["filename"]))
                 except Exception as e:
@@ -840,4 +870,4 @@ class Simulation:
         return out
 
     def save(self, path):
-        np.savez(path, **self.fields())
+        np.savez(path, owned_gid=self.owned_gid, **self.fields())
