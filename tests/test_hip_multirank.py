@@ -1063,3 +1063,30 @@ def test_input_files_run_on_two_ranks(name):
         sc = max(np.abs(fser[k]).max(), 1e-300)
         # (both runs stop Newton at the input's own function tolerance, 1e-5 relative, with different preconditioners)
         assert np.abs(par[k] - fser[k]).max() <= 1e-4 * sc, (k, np.abs(par[k] - fser[k]).max() / sc)
+
+
+@pytest.mark.timeout(900)
+def test_run_module_under_the_launcher(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m waiwera_amd.run input.json -o out.npz`: the RCCL id travels over
+    the launcher's process group, every rank writes its cells with their input numbers; together they are the one-rank
+    run's fields (problem 5a)"""
+    from waiwera_amd.simulation import Simulation
+    path = os.path.join(ROOT, "tests", "golden", "inputs", "problem5a.json")
+    env = dict(os.environ, WAI_RCCL_LIB=LOOPBACK, WAI_BENCH_LOOPBACK="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    out = str(tmp_path / "out.npz")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "-m", "waiwera_amd.run", path, "-o", out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "finished at t =" in r.stdout
+    ser = Simulation.from_json(path)
+    fser = ser.run()
+    ser.ode.destroy()
+    n = fser["fluid_pressure"].size
+    p, seen = np.zeros(n), np.zeros(n, dtype=int)
+    for rank in range(2):
+        d = np.load(str(tmp_path / ("out.rank%d.npz" % rank)))
+        p[d["owned_gid"]] = d["fluid_pressure"]
+        seen[d["owned_gid"]] += 1
+    assert (seen == 1).all()
+    assert np.abs(p - fser["fluid_pressure"]).max() <= 1e-4 * np.abs(fser["fluid_pressure"]).max()

@@ -30,7 +30,9 @@ def main(argv=None):
         uid = [wl.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         kw = dict(rank=rank, world=world, comm_id=uid[0])
-        a.device = int(os.environ.get("LOCAL_RANK", a.device))
+        # one rank per GPU; WAI_BENCH_LOOPBACK=1 (tests on a one-GPU box, with a stand-in for librccl): every rank on --device
+        if os.environ.get("WAI_BENCH_LOOPBACK") != "1":
+            a.device = int(os.environ.get("LOCAL_RANK", a.device))
     sim = Simulation.from_json(a.input, device=a.device, **kw)
     out = sim.run()
     if rank != 0:
