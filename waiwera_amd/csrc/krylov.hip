@@ -234,12 +234,13 @@ int wait_post(wai_ctx* c, int seq) {
 //   2 fused   merged reductions and the X / R / next-P updates in ONE pass (k_bcgs_xrp, which re-forms S from R and V):
 //             FOUR launches -- fused A P, S = R - alpha V, fused A S, X / R / P -- and 11 vector passes beside the two
 //             matrix sweeps where "petsc" makes 14 (default).
-//             WAI_BCGS_COMPOSE=1: S is not stored at all, the second fused launch forms R - alpha V itself (own row and
-//             neighbour gathers): THREE launches, 9 passes -- and MEASURED SLOWER at every full size: the second gather
-//             per matrix slot costs the launch 0.56 -> 0.73 ms at 216^3 (the gathers, not the matrix stream, fill the
-//             vector-cache's request slots), more than k_bcgs_s's 0.07 ms; same box, ms per iteration petsc / fused /
-//             composed: c3 1.530 / -- / 1.542, c4 1.562 / -- / 1.649, c5 0.559 / -- / 0.578; only the 108^3 rank share
-//             gains (0.245 -> 0.235).  Kept selectable; bit-identical to the stored-S form (tests/test_hip_pc.py).
+//             Composed (WAI_BCGS_COMPOSE=1; the DEFAULT for k_pc_park on its 16-bit column indices and for k_pc_wave since round 5:
+//             pc_axpy_ok below): S is not stored at all, the second fused launch forms R - alpha V itself (own row and
+//             neighbour gathers): THREE launches, 9 passes.  Round 4 measured it slower at every full size (the second
+//             gather per matrix slot: c3 1.530 -> 1.542 ms per iteration, c4 1.562 -> 1.649, c5 0.559 -> 0.578; only the
+//             108^3 rank share gained); with one 16-byte index load per row instead of seven 4-byte loads (2 x 2) and the
+//             SELL-64 value layout (3 x 3) it is faster everywhere (round 5's logs below).  Bit-identical to the stored-S
+//             form (tests/test_hip_pc.py).
 int bcgs_mode(const wai_ctx* c) {
   const bool multi = c->comm && c->comm->nranks > 1;
   int mode = 2;
@@ -330,8 +331,8 @@ int bcgs_second_half(wai_ctx* c, const BcgsPlan& pl) {
 // petsc / merged -- five launches: P update, fused A*P + ILU solve + (V,RP) + alpha, S update, fused A*S + ILU solve +
 // its inner products (+ omega), X/R update (+ (R,R),(R,RP) + rho/beta).
 // fused -- four: fused A*P + ILU solve + (V,RP) + alpha; S = R - alpha V; fused A*S + ILU solve + (S,T),(T,T),(S,S),(S,RP),
-// (T,RP) + omega, (R,R), rho, beta, posted; X / R / P update in one pass.  (WAI_BCGS_COMPOSE=1: three, S formed inside the
-// second fused launch -- measured slower, bcgs_mode.)
+// (T,RP) + omega, (R,R), rho, beta, posted; X / R / P update in one pass.  Composed (the default where pc_axpy_ok says so):
+// three, S formed inside the second fused launch.
 int ksp_bcgs(wai_ctx* c, const double* b, double* x, int* its, int* reason, double* rnorm) {
   Krylov& k = c->ks;
   const int n = k.n;
