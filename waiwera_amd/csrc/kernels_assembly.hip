@@ -670,8 +670,13 @@ __device__ __forceinline__ double res_dR(const ResForm& rf) {   // d res_form / 
   if (rf.method == WAI_METHOD_DIRECTSS) return 1.0;
   return -rf.dt;
 }
+// waves per SIMD the np <= 2 kernel is built for: MEASURED at 216^3 (profiles/jsym_waves_ab_r5.log) 1 (no scratch, 282 registers)
+// 6.0 ms, 2 (256 VGPRs + 104 B of scratch per lane) 5.14 ms, 3 (168 VGPRs, 428 B) 9.75 ms
+#ifndef WAI_JSYM_WAVES
+#define WAI_JSYM_WAVES 2
+#endif
 template <int KIND>
-__global__ __launch_bounds__(ParkT<KIND>::threads, (EosT<KIND>::np <= 2 ? 2 : 1)) void k_jacobian_sym(MeshView m, const double* __restrict__ flu,
+__global__ __launch_bounds__(ParkT<KIND>::threads, (EosT<KIND>::np <= 2 ? WAI_JSYM_WAVES : 1)) void k_jacobian_sym(MeshView m, const double* __restrict__ flu,
                                                   size_t stride, const double* __restrict__ flu_pert,
                                                   const double* __restrict__ hstep, int n_prim,
                                                   ResForm rf, double* __restrict__ val) {
