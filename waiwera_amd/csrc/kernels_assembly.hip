@@ -689,25 +689,23 @@ __global__ __launch_bounds__(ParkT<KIND>::threads, (EosT<KIND>::np <= 2 ? WAI_JS
   load_state<KIND>(flu, stride, c, own0);
   load_rock(m.rock, m.n_local, c, rown);
   const double vol = m.vol[c];
-  double lold[np], lold2[np], hk[np];
+  double hk[np];
 #pragma unroll
-  for (int k = 0; k < np; k++) {
-    lold[k] = rf.method == WAI_METHOD_DIRECTSS ? 0.0 : rf.last[(size_t)c * np + k];
-    lold2[k] = rf.method == WAI_METHOD_BDF2 ? rf.last2[(size_t)c * np + k] : 0.0;
-    hk[k] = hstep[(size_t)c * np + k];
-  }
+  for (int k = 0; k < np; k++) hk[k] = hstep[(size_t)c * np + k];
   extern __shared__ double park[];
   constexpr int nld = ParkT<KIND>::npark;
   const int st = (int)blockDim.x;
-  double Lk[np][np], Rk[np][np];
+  double Rk[np][np];
+  double* lpark = park + (size_t)np * nld * st + threadIdx.x;     // the perturbed states' accumulation terms wait in LDS too
 #pragma unroll
   for (int k = 0; k < np; k++) {
     CellState<KIND> ownk;
+    double Lk[np];
     load_state<KIND>(flu_pert + (size_t)k * E::df * n_prim, (size_t)n_prim, c, ownk);
-    cell_balance<KIND>(ownk, rown, Lk[k]);
+    cell_balance<KIND>(ownk, rown, Lk);
     park_state<KIND>(ownk, park + (size_t)k * nld * st + threadIdx.x, st);
 #pragma unroll
-    for (int q = 0; q < np; q++) Rk[k][q] = 0.0;
+    for (int q = 0; q < np; q++) { lpark[(size_t)(k * np + q) * st] = Lk[q]; Rk[k][q] = 0.0; }
   }
   const size_t nrow = m.n_owned;
   const double dR = res_dR(rf);
@@ -794,6 +792,13 @@ __global__ __launch_bounds__(ParkT<KIND>::threads, (EosT<KIND>::np <= 2 ? WAI_JS
 #pragma unroll
   for (int k = 0; k < np; k++) src0[k] = 0.0;
   source_terms<KIND>(m, c, own0, vol, src0);
+  // (the earlier steps' accumulation terms only enter here: loaded behind the face loop, which is short of registers)
+  double lold[np], lold2[np];
+#pragma unroll
+  for (int k = 0; k < np; k++) {
+    lold[k] = rf.method == WAI_METHOD_DIRECTSS ? 0.0 : rf.last[(size_t)c * np + k];
+    lold2[k] = rf.method == WAI_METHOD_BDF2 ? rf.last2[(size_t)c * np + k] : 0.0;
+  }
 #pragma unroll
   for (int k = 0; k < np; k++) { R0[k] += src0[k]; f0[k] = res_form(rf, L0[k], R0[k], lold[k], lold2[k]); }
   // diagonal block: the literal difference of the row's residual, as k_jacobian_park forms it
@@ -805,7 +810,7 @@ __global__ __launch_bounds__(ParkT<KIND>::threads, (EosT<KIND>::np <= 2 ? WAI_JS
     source_terms<KIND>(m, c, ownk, vol, Rk[k]);
 #pragma unroll
     for (int r = 0; r < np; r++) {
-      const double f1 = res_form(rf, Lk[k][r], Rk[k][r], lold[r], lold2[r]);
+      const double f1 = res_form(rf, lpark[(size_t)(k * np + r) * st], Rk[k][r], lold[r], lold2[r]);
       __builtin_nontemporal_store((f1 - f0[r]) / hk[k], val + ell_ix(np, nrow, dq, r, k, (size_t)c));
     }
   }
@@ -1245,13 +1250,23 @@ int launch_jacobian(wai_ctx* c, double dt, const double* lhs_old) {
   // 40.0 -> 26.3 GB at C3 (eos we), 7.34 -> 3.81 ms / 24.3 -> 11.7 GB at C4 (wce), 3.06 -> 1.54 ms / 5.7 -> 3.7 GB at C5.
   // The default for every EOS; WAI_JAC_SYM=0 takes the row-wise kernels (read per call: tests compare them in one process)
   const char* es = getenv("WAI_JAC_SYM");
-  const bool sym = park && c->mesh.adj_tblk && (es ? es[0] == '1' : true);
+  bool sym = park && c->mesh.adj_tblk && (es ? es[0] == '1' : true);
+  // its parked records must fit the LDS a workgroup may ask for (72 KB for the four-equation salt EOS: fine on gfx950)
+#define JSL(K) sym = sym && (size_t)(EosT<K>::np * (ParkT<K>::npark + EosT<K>::np) * 8 * ParkT<K>::threads) <= c->lds_per_block
+  if (c->kind == EOS_W) JSL(EOS_W);
+  else if (c->kind == EOS_WE) JSL(EOS_WE);
+  else if (c->kind == EOS_WSE) JSL(EOS_WSE);
+  else if (c->kind == EOS_WAE) JSL(EOS_WAE);
+  else if (c->kind == EOS_WSCE) JSL(EOS_WSCE);
+  else if (c->kind == EOS_WSAE) JSL(EOS_WSAE);
+  else JSL(EOS_WCE);
+#undef JSL
   if (sym) {
 #define JS(K)                                                                                             \
     do {                                                                                                  \
       constexpr int T = ParkT<K>::threads;                                                                \
       const int g = (((int)((m.n_owned + T - 1) / T) + 7) / 8) * 8;                                        \
-      hipLaunchKernelGGL(k_jacobian_sym<K>, g, T, EosT<K>::np * ParkT<K>::npark * 8 * T, c->stream,       \
+      hipLaunchKernelGGL(k_jacobian_sym<K>, g, T, EosT<K>::np * (ParkT<K>::npark + EosT<K>::np) * 8 * T, c->stream, \
                          m, c->flu, stride, c->flu_pert, c->hstep, c->mesh.n_prim, res_form_of(c, dt, lhs_old), c->J.val); \
     } while (0)
     if (c->kind == EOS_W) JS(EOS_W);
