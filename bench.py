@@ -40,6 +40,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+DEFAULT_BRICK_ORDER = "x"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 CONFIGS = {  # C2 .. C5
@@ -153,6 +154,26 @@ def device_state(index=0):
         return None
 
 
+def physical_cores():
+    """distinct (physical id, core id) pairs of /proc/cpuinfo: the host's physical cores (None when it does not say)"""
+    try:
+        seen, pid, cid = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    seen.add((pid, cid))
+                pid = cid = None
+        if pid is not None and cid is not None:
+            seen.add((pid, cid))
+        return len(seen) or None
+    except OSError:
+        return None
+
+
 def spmv_bytes(nnzb, n, bs):
     """Algorithmic bytes of one BCSR SpMV."""
     return nnzb * (8 * bs * bs + 4) + 4 * (n + 1) + 2 * 8 * bs * n
@@ -165,12 +186,12 @@ def pc_bytes(nnzb, n, bs):
     return nnzb * (8 * bs * bs + 4) + n * (4 + 3 * 8 * bs)
 
 
-def traffic_from_profiles(cfg, dims, brick, kernel):
+def traffic_from_profiles(cfg, dims, brick, kernel, composed=False):
     """(HBM bytes per fused-kernel launch, where from): read from the committed rocprofv3 PMC passes (profiles/;
     collected and corrected as MI355X_MICROARCH.md prescribes, tools/pmc_traffic.py) -- counters cannot be collected
     inside this run.  Only taken when the profile was made on THIS mesh, THESE bricks and THE kernel this run's fused
     launch is (`kernel` = sim.pc_kernel_name()); a profile of another kernel is stale and gives null."""
-    for name in ("pmc_traffic_r5_%s.json" % cfg, "pmc_traffic_r4_%s.json" % cfg, "pmc_traffic_r3_%s.json" % cfg, "pmc_traffic_r2_%s.json" % cfg):
+    for name in ("pmc_traffic_r6_%s.json" % cfg, "pmc_traffic_r5_%s.json" % cfg, "pmc_traffic_r4_%s.json" % cfg, "pmc_traffic_r3_%s.json" % cfg, "pmc_traffic_r2_%s.json" % cfg):
         p = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(p):
             continue
@@ -178,13 +199,15 @@ def traffic_from_profiles(cfg, dims, brick, kernel):
             d = json.load(open(p))
         except Exception:
             continue
-        pk = str(d.get("k_pc_kernel", ""))
+        key = "k_pc_composed" if composed else "k_pc"      # the launch with the operand formed inside / on a stored operand
+        pk = str(d.get(key + "_kernel", ""))
         same_kernel = bool(pk) and pk.replace("void ", "").replace("wai::", "").split("<")[0] == kernel.split("<")[0]
         if "k_pc_park" in kernel:   # the 16-bit column indices (third template argument, round 5) change the launch's bytes
-            same_kernel = same_kernel and (("col16" in kernel) == (pk.count(",") == 2 and pk.rstrip().endswith("true>")))
-        if list(d.get("dims", [])) == list(dims) and list(d.get("brick", [])) == list(brick) and same_kernel:
-            return d.get("k_pc_hbm_bytes_per_launch"), ("profiles/%s (separate rocprofv3 --pmc passes of this command on kernel %s; "
-                                                        "not measured in this run)" % (name, pk))
+            targs = [t.strip() for t in pk[pk.find("<") + 1: pk.rfind(">")].split(",")] if "<" in pk else []
+            same_kernel = same_kernel and (("col16" in kernel) == (len(targs) >= 3 and targs[2] == "true"))
+        if list(d.get("dims", [])) == list(dims) and list(d.get("brick", [])) == list(brick) and same_kernel and d.get(key + "_hbm_bytes_per_launch"):
+            return d.get(key + "_hbm_bytes_per_launch"), ("profiles/%s (separate rocprofv3 --pmc passes of this command on kernel %s; "
+                                                          "not measured in this run)" % (name, pk))
     return None
 
 
@@ -194,7 +217,7 @@ CURVES = {"linear": {}, "corey": {"relperm": ("corey", [0.3, 0.05])}}
 
 
 def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0, gpu_state=None, minc=False, brick=None, curves=None,
-                 gpu_first_kits=None):
+                 gpu_first_kits=None, gpu_first_step=None, whole_budget_s=150.0):
     """The oracle (CPU restatement of the reference's path, OpenMP) timed on the SAME mesh and the same
     state the timed window starts from -- one Newton step, piece by piece: unperturbed residual, FD
     Jacobian (per-row differencing, and the reference's coloured MatFDColoring sweep when it fits the
@@ -263,7 +286,8 @@ def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0, gpu_s
     # entry of their block row's equation, as tests/test_hip_parity.py compares them)
     vs_oracle = None
     if gpu_state is not None:
-        worst, worst_ulp, over_bar = ol.jacobian_parity(gpu_state["J"], J, rp, ci, y, lhs_old, bs, bar=True)
+        jaud = {}
+        worst, worst_ulp, over_bar = ol.jacobian_parity(gpu_state["J"], J, rp, ci, y, lhs_old, bs, bar=True, audit=jaud)
         fg = gpu_state["f"]
         # ONE bar per quantity.  A finite-difference entry carries the rounding of its row's accumulation term over the FD
         # step, eps |L_i| / |h_j| (h = 2e-10 for a scaled primary below the FD floor): an entry may differ by
@@ -272,7 +296,10 @@ def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0, gpu_s
         vs_oracle = {"residual_vs_oracle": float(np.abs(fg - f).max() / np.abs(f).max()), "residual_tolerance": 1e-11,
                      "jacobian_over_bar": over_bar,
                      "jacobian_bar": "per entry: max(2e-5 x largest entry of its block row's equation, 16 eps |L_i| / |h_j|)",
-                     "jacobian_worst_relative": worst, "jacobian_worst_in_ulp_steps": worst_ulp, "cells": int(n)}
+                     "jacobian_worst_relative": worst, "jacobian_worst_in_ulp_steps": worst_ulp, "cells": int(n),
+                     # how much of the matrix the second allowance is used for: entries beyond 2e-5 of their row's scale
+                     "jacobian_entries": jaud.get("entries"), "jacobian_entries_above_2e-5": jaud.get("entries_above_2e-5_of_row_scale"),
+                     "jacobian_largest_above_2e-5": jaud.get("largest_of_them")}
     t_col, col_note = None, ""
     if time.time() - t_all + 14.0 * t_jac < budget_s:   # coloured FD: 1 + ncolors x bs full sweeps
         t0 = time.time()
@@ -320,6 +347,27 @@ def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0, gpu_s
                "device_iterations_this_system": gpu_first_kits}
         log("  cpu baseline: BiCGStab to rtol 1e-5 with %d ILU(0) subdomains on the window's first system: %d iterations "
             "(reason %d, %.1f s); the device's bricks took %s" % (best_t, its.value, reason, t_own, gpu_first_kits))
+    # ONE WHOLE Newton step of the oracle, measured (not put together from pieces), on THIS mesh and state -- the window's
+    # first Newton step (wo_newton_step: FD Jacobian by per-row differencing, ILU(0) set-up with one subdomain per thread,
+    # BiCGStab to rtol 1e-5 with the CPU's own count, line search with transitions, new residual; src/timestepper.F90:587-735)
+    whole_here = None
+    est = 2.0 * t_res + t_jac + t_setup + (own["krylov_iterations_this_system"] if own and own["converged"] else cap) * t_iter
+    if est < whole_budget_s:
+        set_threads(best_t)
+        opt = osim.opts()     # reference defaults: BiCGStab, rtol 1e-5, per-row differencing (jac_mode 0)
+        kits_w, mr_w = C.c_int(0), C.c_double(0)
+        y_w, f_w = y.copy(), f.copy()
+        t0 = time.time()
+        r_w = L.wo_newton_step(osim.h, C.byref(opt), 0, dt, ol.dp(y_w), ol.dp(lhs_old), ol.dp(f_w), C.byref(kits_w), C.byref(mr_w))
+        t_w = time.time() - t0
+        whole_here = {"seconds": t_w, "krylov_iterations": int(kits_w.value), "reason": int(r_w), "threads": int(best_t),
+                      "max_scaled_residual_after": float(mr_w.value),
+                      "modelled_seconds": t_res + t_jac + t_setup + kits_w.value * t_iter,
+                      "same_newton_step_on_the_gpu": gpu_first_step}
+        log("  cpu baseline: whole oracle Newton step on THIS mesh (%d cells), the window's first Newton step: %.2f s measured "
+            "(%d Krylov iterations, reason %d), %.2f s by the sum of its pieces; the device: %s"
+            % (n, t_w, kits_w.value, r_w, whole_here["modelled_seconds"], gpu_first_step))
+        del y_w, f_w
     n_big = n
     osim.close()
     # The model's check, and the coloured sweep where it does not fit above: ONE WHOLE Newton step of the oracle
@@ -401,6 +449,24 @@ def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0, gpu_s
     out = {"value": 1.0 / t_newton, "unit": "Newton steps/s", "cores": best_t, "kind": "port, modelled", "sample": sample,
            "seconds": {"residual": t_res, "jacobian_per_row": t_jac, "jacobian_coloured": t_col, "pc_setup": t_setup,
                        "krylov_iteration": t_iter}}
+    if whole_here and whole_here["seconds"] > 0:
+        # measured: `value` is ONE whole Newton step of the oracle on this mesh and state, timed as a whole; the window-average
+        # model (pieces timed on this mesh x the CPU's own Krylov count per Newton step) stays beside it
+        out["value_modelled_window_average"] = out["value"]
+        out["value"] = 1.0 / whole_here["seconds"]
+        out["kind"] = "port, measured"
+        out["measured_whole_step_this_mesh"] = whole_here
+        if t_col:
+            whole_here["seconds_with_coloured_jacobian"] = whole_here["seconds"] - t_jac + t_col
+            out["value_with_coloured_jacobian_measured_step"] = 1.0 / whole_here["seconds_with_coloured_jacobian"]
+        out["sample"] = ("ONE whole Newton step of the oracle (wo_newton_step: FD Jacobian, ILU(0) set-up, BiCGStab to rtol 1e-5, line "
+                         "search with transitions, new residual) on the same mesh (%d cells) and the same state as the timed window's "
+                         "first Newton step, dt %.3g s, timed as a whole: %.2f s with %d Krylov iterations of the CPU's own %d-subdomain "
+                         "preconditioner (the device took %s on that step); %d OpenMP threads (container quota %d CPUs of %d hardware "
+                         "threads), %s.  Window-average model beside it (value_modelled_window_average): %s"
+                         % (n, dt, whole_here["seconds"], whole_here["krylov_iterations"], best_t,
+                            ("%d iterations, %.3f s" % (gpu_first_step["krylov"], gpu_first_step["seconds"])) if gpu_first_step else "n/a",
+                            best_t, quota, avail, model, sample))
     out["krylov_iterations_per_newton_step"] = kits_cpu
     out["value_with_gpu_iteration_count"] = 1.0 / t_newton_gpu_count
     if own:
@@ -409,7 +475,8 @@ def cpu_baseline(lm, eos, y0, region0, dt, kits_per_newton, budget_s=45.0, gpu_s
         out["value_with_coloured_jacobian"] = 1.0 / (t_newton - t_jac + t_col)
     if whole:
         out["measured_whole_step"] = whole
-        out["host"] = {"cpu": model, "hardware_threads": avail, "cpu_quota": quota, "threads_used": int(best_t)}
+    phys = physical_cores()
+    out["host"] = {"cpu": model, "hardware_threads": avail, "physical_cores": phys, "cpu_quota": quota, "threads_used": int(best_t)}
     if vs_oracle:
         out["vs_oracle"] = vs_oracle
     return out
@@ -445,8 +512,10 @@ def main():
     ap.add_argument("--balanced-bricks", type=int, default=0, choices=[0, 1],
                     help="1: a rank's range cut into ceil(range / brick) bricks of nearly equal size (216 in bricks of 16: "
                          "fourteen of 15-16) instead of full bricks and one remainder (thirteen of 16 and one of 8)")
-    ap.add_argument("--brick-order", default="x", choices=["z", "x"],
-                    help="numbering of the bricks: vertical neighbour bricks adjacent in memory (z), or x fastest (rounds 1, 2)")
+    ap.add_argument("--brick-order", default=None,
+                    help="numbering of the bricks (memory and launch order): x fastest (x; rounds 1-5), vertical neighbour bricks "
+                         "adjacent (z), or x fastest inside strips of N brick rows, then z, then the strips (tileN, tile = tile4: "
+                         "every neighbour brick but a quarter of the y links within 56 positions -- round 6)")
     ap.add_argument("--cell-order", default=None, choices=["hyperplane", "natural"],
                     help="numbering of the cells inside a brick: by dependency level (i + j + k) -- default for 2 x 2 blocks, "
                          "whose fused kernel wants a level's rows in one wave -- or x fastest (default for 3 x 3 blocks)")
@@ -554,6 +623,8 @@ def main():
     #   8x5x4 2.89 / 185   8x8x2 2.74 / 178 / 47.5 %   12x6x2 2.56 / 176   16x8x2 2.45 / 181   16x4x2 2.33 / 195   10x10x2 2.05 / 177
     # MINC, same protocol (profiles/brick_scan_r3_c5.log): 4x4x2 (32 + 32 rows) 15.84 / 101 / 55.7 %   8x4x1 15.46-15.54 / 99 / 52.5 %
     #   4x8x1 15.33 / 101   8x2x2 14.27 / 108   8x8x1 12.48 / 94 / 36 %   16x2x1 11.88 / 113   8x4x2 9.77 / 97 / 27 %
+    if a.brick_order is None:
+        a.brick_order = DEFAULT_BRICK_ORDER
     brick = tuple(a.brick) if a.brick else ((4, 4, 2) if minc else ((8, 4, 2) if eos == "wce" else (16, 16, 2)))
     grid, lm, prim, region = make_case(dims=dims, brick=brick, eos=eos, lens=not a.no_lens, minc=minc,
                                        part=M.partition_shape(world), rank=rank, brick_order=a.brick_order, order=a.cell_order,
@@ -589,9 +660,39 @@ def main():
             dist.barrier()
 
     if a.micro_only:   # no JSON line: not a bench result
+        while a.lead and drv.nstep < a.lead and os.environ.get("WAI_MICRO_LEAD") == "1":
+            drv.newton_step()     # (WAI_MICRO_LEAD=1: the micro figures on the window's first state instead of the initial one)
         drv._begin()
         sim.jacobian(drv.t + drv.dt, drv.dt, y, drv.lhs_old)
         sim.pc_setup()
+        sim.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            sim.jacobian(drv.t + drv.dt, drv.dt, y, drv.lhs_old)
+        sim.synchronize()
+        t_jac = (time.perf_counter() - t0) / 3
+        t0 = time.perf_counter()
+        for _ in range(3):
+            sim.residual(drv.t + drv.dt, drv.dt, y, drv.lhs_old, drv.f)
+        sim.synchronize()
+        t_res = (time.perf_counter() - t0) / 3
+        sim.pc_setup()
+        log("micro %s assembly (host-timed, ms per call): FD Jacobian incl. perturbed EOS %.3f, residual incl. EOS %.3f [brick order %s]"
+            % (a.config, 1e3 * t_jac, 1e3 * t_res, a.brick_order))
+        # the window's FIRST linear system (after the lead-in when --lead > 0) solved once to rtol 1e-5: the Krylov count and
+        # the time of the preconditioner in force -- what the preconditioners are compared on (the window's average count
+        # depends on which tries fail)
+        xs = torch.zeros(sim.n_prim * bs, dtype=torch.float64, device="cuda")
+        sim.synchronize()
+        t0 = time.perf_counter()
+        k_first, r_first, rn_first = sim.ksp_solve(drv.f, xs)
+        sim.synchronize()
+        t_first = time.perf_counter() - t0
+        log("micro %s first system [%s, pc %s, ilu levels %d]: %d Krylov iterations (reason %d), %.1f ms = %.4f ms per iteration"
+            % (a.config, a.ksp, a.pc, a.ilu_levels, k_first, r_first, 1e3 * t_first, 1e3 * t_first / max(k_first, 1)))
+        del xs
+        if a.pc != "bjacobi" or a.ilu_levels or a.ksp != "bcgs":
+            return
         names = ["spmv", "ilu_apply", "fused_pc_amul"]
         kb = {name: sim.bench_kernel(w, a.spmv_reps if w in (0, 2) else 20) for w, name in enumerate(names)}
         nnzb = wl.LIB.wai_jacobian_nnzb(sim.h)
@@ -607,6 +708,11 @@ def main():
                    os.environ.get("WAI_FACE_STREAM", "default")))
         log("micro %s iteration device-only %.4f ms, vector updates %.4f ms [WAI_BCGS=%s]"
             % (a.config, sim.bench_kernel(5, 50), sim.bench_kernel(6, 50), os.environ.get("WAI_BCGS", "default")))
+        log("micro %s fused launches as an iteration issues them (ms): first half %.4f, second half %.4f (composed %s) [WAI_PC_STAGE=%s]"
+            % (a.config, sim.bench_kernel(2, a.spmv_reps), sim.bench_kernel(17, a.spmv_reps), sim.bcgs_composed(), os.environ.get("WAI_PC_STAGE", "default")))
+        n_copy = (sim.n_prim * bs * sim.fluid_dof // 2) * 8
+        log("micro %s copy ceiling (GB/s, 2 x %d bytes / time): hipMemcpyDtoD %.0f, copy kernel %.0f"
+            % (a.config, n_copy, 2.0 * n_copy / sim.bench_kernel(18, 20) / 1e6, 2.0 * n_copy / sim.bench_kernel(19, 20) / 1e6))
         return
 
     # lead-in: the first accepted time steps, outside warm-up and timing
@@ -731,6 +837,15 @@ def main():
     if world == 1 and a.ksp == "bcgs" and a.pc == "bjacobi" and a.ilu_levels == 0:   # the iteration's launches back to back, and its vector updates alone
         kb["bicgstab_iteration_device_only"] = sim.bench_kernel(5, 50)
         kb["bicgstab_vector_updates"] = sim.bench_kernel(6, 50)
+        # the iteration's SECOND fused launch exactly as it is issued (composed operand R - alpha V where that is the default,
+        # five inner products, the scalars and the post in the launch): since round 5 the launch with the larger share
+        kb["fused_pc_second_half"] = sim.bench_kernel(17, a.spmv_reps)
+    # what a copy achieves on this box (2 x bytes / time): hipMemcpy device to device and the library's own copy kernel
+    n_copy = (sim.n_prim * bs * sim.fluid_dof // 2) * 8
+    kb["copy_memcpy_d2d"] = sim.bench_kernel(18, 20)
+    kb["copy_kernel"] = sim.bench_kernel(19, 20)
+    copy_gbs = {"hipMemcpyDtoD": 2.0 * n_copy / (kb["copy_memcpy_d2d"] * 1e-3) / 1e9, "copy_kernel": 2.0 * n_copy / (kb["copy_kernel"] * 1e-3) / 1e9,
+                "bytes_moved": 2 * n_copy}
     comm = None
     if world > 1:
         # what the collectives cost per BiCGStab iteration: the iteration's launches and collectives back to back without
@@ -771,7 +886,26 @@ def main():
         % (ms, achieved, 100 * achieved / HBM_PEAK_GBS, HBM_PEAK_GBS, ms_pc, achieved_pc, 100 * achieved_pc / HBM_PEAK_GBS))
     if prof:
         log("kernel-class time inside the timed region (ms, launches): " + json.dumps(prof))
-    traffic = traffic_from_profiles(a.config, dims, brick, sim.pc_kernel_name()) if world == 1 else None
+    # The dominant kernel.  A BiCGStab iteration issues the fused kernel twice: on P with one inner product (`first`), and on
+    # S = R - alpha V -- composed inside the launch where that is the default -- with the five merged products and the
+    # scalars (`second`).  Whichever launch takes longer is the line's `roofline`; the other one travels beside it.
+    composed = bool(sim.bcgs_composed()) if "fused_pc_second_half" in kb else False
+    halves = {"first": {"ms": ms_pc, "bytes": b_pc, "what": "fused BCSR SpMV + block ILU(0) apply + (z, r^)",
+                        "kernel": sim.pc_kernel_name(composed=False)}}
+    if "fused_pc_second_half" in kb:
+        b2 = b_pc + (8 * bs * lm.n_owned if composed else 0)       # composed: R and V are read where S was
+        halves["second"] = {"ms": kb["fused_pc_second_half"], "bytes": b2,
+                            "what": ("fused BCSR SpMV on S = R - alpha V formed in the launch" if composed else "fused BCSR SpMV on S")
+                                    + " + block ILU(0) apply + five inner products + scalars",
+                            "kernel": sim.pc_kernel_name(composed=composed)}
+    for h in halves.values():
+        h["gbs"] = h["bytes"] / (h["ms"] * 1e-3) / 1e9
+        h["frac"] = h["gbs"] / HBM_PEAK_GBS
+    dom = max(halves, key=lambda k: halves[k]["ms"])
+    other = [k for k in halves if k != dom]
+    traffic = None
+    if world == 1:
+        traffic = traffic_from_profiles(a.config, dims, brick, halves[dom]["kernel"], composed=(dom == "second" and composed))
 
     if rank == 0:
         ksp_name = {"bcgs": "BiCGStab", "gmres": "GMRES(30)"}.get(a.ksp, a.ksp)
@@ -814,21 +948,35 @@ def main():
                        "copies_per_krylov_iteration": (ls1[1] - ls0[1]) / max(kits, 1),
                        "timed_newton_steps": [{"time_step": r[0], "dt": r[1], "newton": r[2], "krylov": r[3],
                                                "reason": r[4], "ms": 1e3 * r[6], "accepted": r[7]} for r in timed],
-                       "partition": "x".join(str(p) for p in grid.part), "ksp": a.ksp, "pc": a.pc, "ilu_levels": a.ilu_levels},
-            "roofline": {"bound": "hbm", "kernel": sim.pc_kernel_name() + " (fused BCSR SpMV + block ILU(0) apply + dot)",
-                         "achieved": achieved_pc, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_pc / HBM_PEAK_GBS,
+                       "partition": "x".join(str(p) for p in grid.part), "ksp": a.ksp, "pc": a.pc, "ilu_levels": a.ilu_levels,
+                       "brick_order": a.brick_order},
+            "roofline": {"bound": "hbm", "kernel": "%s (%s; the iteration's %s fused launch)" % (halves[dom]["kernel"], halves[dom]["what"], dom),
+                         "dominant_half": dom,
+                         "achieved": halves[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": halves[dom]["frac"],
                          "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,
-                         "algorithmic_bytes_per_launch": b_pc, "ms_per_launch": ms_pc,
+                         "traffic_over_algorithmic": (traffic[0] / halves[dom]["bytes"]) if traffic and traffic[0] else None,
+                         "algorithmic_bytes_per_launch": halves[dom]["bytes"], "ms_per_launch": halves[dom]["ms"],
+                         # what a copy achieves on this box, measured in this run (2 x bytes / time)
+                         "copy_ceiling_gbs": max(copy_gbs["hipMemcpyDtoD"], copy_gbs["copy_kernel"]), "copy_ceiling": copy_gbs,
                          # the metric's second half, flat: BCSR SpMV achieved GB/s and fraction of HBM peak
                          "spmv_gbs": achieved, "spmv_frac": achieved / HBM_PEAK_GBS, "spmv_ms_per_launch": ms,
                          "spmv_algorithmic_bytes_per_launch": b_spmv, "spmv_kernel": "k_spmv<%d> (BCSR SpMV)" % bs},
         }
+        for k in other:   # the iteration's other fused launch
+            out["roofline"].update({"%s_half_kernel" % k: "%s (%s)" % (halves[k]["kernel"], halves[k]["what"]), "%s_half_ms_per_launch" % k: halves[k]["ms"],
+                                    "%s_half_algorithmic_bytes_per_launch" % k: halves[k]["bytes"], "%s_half_achieved" % k: halves[k]["gbs"],
+                                    "%s_half_frac" % k: halves[k]["frac"]})
         if "bicgstab_iteration_device_only" in kb:
             out["config"]["ms_per_krylov_iteration_device_only"] = kb["bicgstab_iteration_device_only"]
             out["config"]["ms_vector_updates_per_iteration"] = kb["bicgstab_vector_updates"]
-            out["config"]["ms_fused_per_iteration"] = 2.0 * ms_pc
+            out["config"]["ms_fused_per_iteration"] = sum(h["ms"] for h in halves.values())
+            # the whole iteration against the roofline: both fused launches' algorithmic bytes + the X / R / P update's
+            # eight vectors (+ S = R - alpha V's three where it is a launch of its own) over the iteration's device time
+            b_iter = sum(h["bytes"] for h in halves.values()) + (8 + (0 if composed else 3)) * 8 * bs * lm.n_owned
+            out["roofline"]["iteration_algorithmic_bytes"] = b_iter
+            out["roofline"]["iteration_frac"] = b_iter / (kb["bicgstab_iteration_device_only"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             out["config"]["bicgstab_form"] = os.environ.get("WAI_BCGS", "fused") + " (WAI_BCGS=petsc | merged | fused)"
         if comm:
             out["comm"] = comm

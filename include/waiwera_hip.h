@@ -262,7 +262,8 @@ int wai_get_source_rates(wai_ctx *ctx, double *rate, double *enthalpy);
 int wai_set_regions(wai_ctx *ctx, const int *region);
 int wai_get_regions(wai_ctx *ctx, int *region);
 /* fluid vector in the reference's AoS layout, df doubles per local cell; which: 0 fluid,
- * 1 last_iteration_fluid, 2 last_timestep_fluid (src/flow_simulation.F90:53-56) */
+ * 1 last_iteration_fluid, 2 last_timestep_fluid (src/flow_simulation.F90:53-56).  which = 1 is refused (-2, text in
+ * wai_last_error) between a wai_newton_step and the next wai_pre_iteration: that step's snapshot is partial */
 int wai_get_fluid(wai_ctx *ctx, int which, double *out);
 int wai_num_fluid_dof(wai_ctx *ctx);
 /* the reference's flux vector (src/flow_simulation.F90:156-205, filled :1436-1440): per face np

@@ -43,8 +43,14 @@ int wai_timer_stop(wai_ctx *ctx, float *ms);
  * kernel on the interior / the face bricks alone (the two launches of the overlapped halo exchange; 16: both as that path
  * launches them -- behind one another on the compute stream; WAI_FACE_STREAM=1: the face bricks on their own stream), 11 .. 15 the fused
  * launch by reduction mode: 11 none, 12 (z,aux) left as partial sums, 13 (x,z),(z,z) + omega finished in the launch,
- * 14 the five merged products left as partial sums, 15 the five + omega, (R,R), rho, beta finished in the launch */
+ * 14 the five merged products left as partial sums, 15 the five + omega, (R,R), rho, beta finished in the launch,
+ * 17 the iteration's second fused launch exactly as it is issued on one rank (composed operand where that is the default,
+ * five products, scalars and the post to the host in the launch), 18 / 19 a device-to-device copy of half the perturbed-fluid
+ * scratch onto the other half (hipMemcpyAsync / the library's copy kernel): the box's copy ceiling, 2 x bytes / time */
 int wai_bench_kernel(wai_ctx *ctx, int which, int reps, float *ms_per_launch);
+/* 1 when a BiCGStab iteration's second fused launch forms its operand S = R - alpha V itself (three launches per
+ * iteration, no stored S), 0 when S is a launch of its own -- for the reports' kernel names and byte counts */
+int wai_bcgs_composed(wai_ctx *ctx);
 /* accumulated HIP-event time (ms) and launch counts per kernel class since the last reset;
  * classes: 0 eos, 1 residual, 2 jacobian, 3 spmv, 4 pc_apply, 5 pc_setup, 6 vector, 7 transitions */
 int wai_profile_enable(wai_ctx *ctx, int on);

@@ -384,7 +384,7 @@ class OracleSim:
         return r, k.value
 
 
-def jacobian_parity(Jg, Jo, rowptr, colidx, y, lhs, bs, fd_eps=1.0e-8, fd_umin=1.0e-2, bar=False):
+def jacobian_parity(Jg, Jo, rowptr, colidx, y, lhs, bs, fd_eps=1.0e-8, fd_umin=1.0e-2, bar=False, audit=None):
     """Two finite-difference Jacobians of the same residual function, entry by entry (BCSR values, row-major blocks).
 
     An entry J[i,r; j,k] = (f_ir(y + h_jk e_jk) - f_ir(y)) / h_jk carries the rounding of f_ir divided by the step:
@@ -393,7 +393,10 @@ def jacobian_parity(Jg, Jo, rowptr, colidx, y, lhs, bs, fd_eps=1.0e-8, fd_umin=1
     h = 2e-10) is 1e-5 of the entry scale.  Returns (worst difference relative to the largest entry of the block
     row's equation, worst difference in units of eps |L_ir| / |h_jk| among the entries above 2e-5 of that scale);
     with bar=True a third value: the worst difference over THE bar an entry has to meet,
-    max(2e-5 x the block row's largest entry, 16 eps |L_ir| / |h_jk|) -- parity holds iff it is <= 1."""
+    max(2e-5 x the block row's largest entry, 16 eps |L_ir| / |h_jk|) -- parity holds iff it is <= 1.
+    `audit` (a dict, filled in): how many entries there are, how many differ by more than 2e-5 of their row's scale (the
+    ones only the ulp-step allowance admits), and the largest of those -- so that a drift from "a handful of
+    partial-pressure columns" to "most of the matrix" is seen."""
     n = rowptr.size - 1
     Jg = np.asarray(Jg).reshape(-1, bs, bs)
     Jo = np.asarray(Jo).reshape(-1, bs, bs)
@@ -404,6 +407,7 @@ def jacobian_parity(Jg, Jo, rowptr, colidx, y, lhs, bs, fd_eps=1.0e-8, fd_umin=1
     Lb = np.abs(np.asarray(lhs, dtype=np.float64)[: n * bs].reshape(-1, bs))
     eps = np.finfo(np.float64).eps
     worst_rel, worst_ulp, worst_bar = 0.0, 0.0, 0.0
+    n_above, largest_above = 0, 0.0
     for r in range(bs):
         rowscale = np.zeros(n)
         np.maximum.at(rowscale, rows, np.abs(Jo[:, r, :]).max(axis=1))
@@ -412,10 +416,15 @@ def jacobian_parity(Jg, Jo, rowptr, colidx, y, lhs, bs, fd_eps=1.0e-8, fd_umin=1
             rel = d / np.maximum(rowscale[rows], 1e-300)
             worst_rel = max(worst_rel, float(rel.max()))
             big = rel > 2.0e-5
+            n_above += int(big.sum())
             if big.any():
+                largest_above = max(largest_above, float(rel[big].max()))
                 ulp = d[big] / (eps * np.maximum(Lb[rows[big], r], 1e-300) / h[colidx[big], k])
                 worst_ulp = max(worst_ulp, float(ulp.max()))
             if bar:
                 allow = np.maximum(2.0e-5 * rowscale[rows], 16.0 * eps * np.maximum(Lb[rows, r], 1e-300) / h[colidx, k])
                 worst_bar = max(worst_bar, float((d / np.maximum(allow, 1e-300)).max()))
+    if audit is not None:
+        audit.update({"entries": int(Jg.shape[0] * bs * bs), "entries_above_2e-5_of_row_scale": n_above,
+                      "largest_of_them": largest_above})
     return (worst_rel, worst_ulp, worst_bar) if bar else (worst_rel, worst_ulp)

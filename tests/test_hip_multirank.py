@@ -277,6 +277,13 @@ def test_ranks_sharing_one_gpu_match_one_rank(world, dims=DIMS, brick=BRICK, nst
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    compare_with_one_rank(res, world, dims, brick, nsteps)
+
+
+def compare_with_one_rank(res, world, dims=DIMS, brick=BRICK, nsteps=3):
+    """the ranks' results (what _worker puts on its queue) against the one-rank run of the same problem on this process's
+    device: collective counts, Newton counts, regions, solution to 1e-7 (also used by tests/test_hip_real_rccl.py)"""
+    from waiwera_amd.flow_simulation import FlowSimulation
     g, lm, prim, region = _problem((1, 1, 1), 0, dims, brick)
     sim = FlowSimulation(lm, eos="we", device=0)
     sim.set_regions(region)
@@ -1026,6 +1033,26 @@ def _json_worker(rank, world, uid_q, q, path):
 
 
 @pytest.mark.timeout(900)
+def test_a_deliverability_source_on_one_rank_only(tmp_path):
+    """a source control that needs the INITIAL fluid state (deliverability against reference pressure "initial", and a
+    productivity index from the initial rate) sits on one rank's cell: the evaluation of that state exchanges halos, so
+    both ranks must make it -- the rank without the source included (advisor, round 5: it hung, or left every later
+    exchange off by two).  Problem 5a with its well on deliverability, two ranks against one."""
+    from waiwera_amd.simulation import Simulation
+    inp = json.load(open(os.path.join(ROOT, "tests", "golden", "inputs", "problem5a.json")))
+    inp["source"] = [dict(cell=26, rate=-5.0, deliverability=dict(pressure="initial"), direction="production")]
+    inp["time"]["stop"] = 20 * 1576800.0
+    msh = inp["mesh"]["filename"] if isinstance(inp["mesh"], dict) else inp["mesh"]
+    src = os.path.join(ROOT, "tests", "golden", "inputs", os.path.basename(msh))
+    if os.path.exists(src):
+        import shutil
+        shutil.copy(src, tmp_path / os.path.basename(msh))
+    path = str(tmp_path / "problem5a_deliv.json")
+    json.dump(inp, open(path, "w"))
+    _two_ranks_against_one(path)
+
+
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("name", ["problem5a", "problem2b"])
 def test_input_files_run_on_two_ranks(name):
     """python -m waiwera_amd.run on several ranks: the JSON front end reads the whole input on every rank, keeps the rank's
@@ -1033,8 +1060,11 @@ def test_input_files_run_on_two_ranks(name):
     boundaries, IFC-67 -- collectively.  Model intercomparison problems 5a (two-phase areal production) and 2b (radial
     two-phase production) from the reference's own files on two ranks against the one-rank run: same number of time steps,
     same regions, pressure / temperature / saturation / density to 1e-4 (the inputs' nonlinear tolerance is 1e-5)."""
+    _two_ranks_against_one(os.path.join(ROOT, "tests", "golden", "inputs", name + ".json"))
+
+
+def _two_ranks_against_one(path):
     from waiwera_amd.simulation import Simulation
-    path = os.path.join(ROOT, "tests", "golden", "inputs", name + ".json")
     ser = Simulation.from_json(path)
     fser = {k: np.asarray(v).copy() for k, v in ser.run().items() if k.startswith("fluid_")}
     taken = ser.ts.taken

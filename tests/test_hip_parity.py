@@ -29,7 +29,15 @@ def FS():
     return FlowSimulation
 
 
-def jacobian_against_literal_fd(sim, y, L, dt, Jg, Jo, rp, ci, bs, tol, t=0.0, most=400):
+# Entries of a Jacobian that the arbiter may clear, per comparison (ADVICE round 5 / VERDICT round 5 item 7: the escape
+# hatch must be auditable).  The column-wise sweep differs from the literal differences only where the literal one's own
+# rounding is visible: twice the counts observed on an MI355X (round 6, `pytest -s` prints them), and the hard bound no
+# entry may exceed whatever the arbiter says.
+ARBITER_MAX_CLEARED = {}      # (eos, lens) or ("residual_forms", method) -> entries; absent: none may be cleared
+ARBITER_HARD_BOUND = 1e-3
+
+
+def jacobian_against_literal_fd(sim, y, L, dt, Jg, Jo, rp, ci, bs, tol, t=0.0, most=400, osim=None, audit=None):
     """Device Jacobian Jg against the oracle's literal forward differences Jo, relative to the largest entry of the block
     row's equation: returns the worst relative difference AFTER the entries above `tol` have been examined one by one.
 
@@ -37,18 +45,39 @@ def jacobian_against_literal_fd(sim, y, L, dt, Jg, Jo, rp, ci, bs, tol, t=0.0, m
     the face's two flux evaluations; the literal difference of two whole residual sums -- what the oracle, the row-wise
     kernels and MatFDColoring form -- carries the rounding of those sums divided by the step, which for a small scaled
     primary (a gas partial-pressure fraction of 0.02: h = 2e-10) reaches 1e-3 of the row's scale.  Where the two
-    disagree by more than `tol` the ARBITER is a central difference of the device's residual with a 1000 x larger step
-    (rounding 1000 x smaller, truncation still negligible): the device's entry must agree with it to `tol` and be at
-    least 3 x closer to it than the literal difference is (the arbiter's own rounding is a tenth of the literal's).  An entry that fails either test is reported as it is."""
+    disagree by more than `tol` the ARBITER is a central difference with a 1000 x larger step (rounding 1000 x smaller,
+    truncation still negligible) of the ORACLE's residual when `osim` is given (round 6: a flux error shared by the
+    device's residual and its Jacobian sweep cannot clear itself), else of the device's: the device's entry must agree
+    with it to `tol` and be at least 3 x closer to it than the literal difference is (the arbiter's own rounding is a
+    tenth of the literal's).  An entry that fails either test is reported as it is.
+
+    `audit` (a dict, filled in): how many entries were above `tol`, examined and cleared, the largest cleared one and the
+    worst raw difference -- the callers bound them (ARBITER_MAX_CLEARED, ARBITER_HARD_BOUND)."""
     n = sim.n_owned
     rows = np.repeat(np.arange(n), np.diff(rp))
     worst = 0.0
+    au = {"entries": int(Jg.shape[0] * bs * bs), "above_tol": 0, "examined": 0, "cleared": 0, "largest_cleared": 0.0, "raw_worst": 0.0,
+          "arbiter": "oracle residual" if osim is not None else "device residual"}
+    yo0 = osim.yvec(y) if osim is not None else None
+
+    def resid(yy):
+        if osim is not None:
+            yo = yo0.copy()
+            yo[: yy.size] = yy
+            err, f = osim.residual(yo, dt, L)
+            assert err == 0
+            return f
+        f = np.zeros(n * bs)
+        assert sim.residual(t, dt, yy, L, f) == 0
+        return f
     for r in range(bs):
         rowscale = np.zeros(n)
         np.maximum.at(rowscale, rows, np.abs(Jo[:, r, :]).max(axis=1))
         sc = np.maximum(rowscale[rows][:, None], 1e-300)
         rel = np.abs(Jg[:, r, :] - Jo[:, r, :]) / sc
+        au["raw_worst"] = max(au["raw_worst"], float(rel.max()))
         over = np.argwhere(rel > tol)
+        au["above_tol"] += len(over)
         if len(over) > most:      # the worst ones
             over = over[np.argsort(-rel[over[:, 0], over[:, 1]])[:most]]
         cleared = np.zeros_like(rel, dtype=bool)
@@ -60,16 +89,23 @@ def jacobian_against_literal_fd(sim, y, L, dt, Jg, Jo, rp, ci, bs, tol, t=0.0, m
             yp, ym = y.copy(), y.copy()
             yp[col] += h
             ym[col] -= h
-            fp, fm = np.zeros(n * bs), np.zeros(n * bs)
-            assert sim.residual(t, dt, yp, L, fp) == 0 and sim.residual(t, dt, ym, L, fm) == 0
+            fp, fm = resid(yp), resid(ym)
             cd = (fp[i * bs + r] - fm[i * bs + r]) / (2.0 * h)
             dg, do = abs(Jg[b, r, k] - cd), abs(Jo[b, r, k] - cd)
-            print("   entry (%d, %d; %d, %d): device %.9e literal %.9e central x1000 %.9e" % (i, r, j, k, Jg[b, r, k], Jo[b, r, k], cd))
+            print("   entry (%d, %d; %d, %d): device %.9e literal %.9e central x1000 (%s) %.9e" % (i, r, j, k, Jg[b, r, k], Jo[b, r, k], au["arbiter"], cd))
+            au["examined"] += 1
             if dg / sc[b, 0] < tol and dg * 3.0 < do:
                 cleared[b, k] = True
+                au["cleared"] += 1
+                au["largest_cleared"] = max(au["largest_cleared"], float(rel[b, k]))
         if len(over) <= most:
             rel = np.where(cleared, 0.0, rel)
         worst = max(worst, float(rel.max()))
+    if osim is not None:
+        resid(y)      # the oracle's fluid state back at y
+    print("   arbiter audit: %s" % au)
+    if audit is not None:
+        audit.update(au)
     return worst
 
 
@@ -147,9 +183,13 @@ def test_jacobian(FS, oracle, eos, lens):
         worst = (np.abs(Jg[:, r, :] - Jo[:, r, :]) / np.maximum(sc, 1e-300)).max()
         print("jacobian parity %s lens=%s row %d: %.3e (tol %.0e)" % (eos, lens, r, worst, tol))   # pytest -s
     # ... and the entries above it (column-wise sweep: the literal difference's own rounding) against the arbiter
-    worst = jacobian_against_literal_fd(sim, y, L, dt, Jg, Jo, rp, ci, bs, 2e-5)
+    au = {}
+    worst = jacobian_against_literal_fd(sim, y, L, dt, Jg, Jo, rp, ci, bs, 2e-5, osim=osim, audit=au)
     print("jacobian parity %s lens=%s after the arbiter: %.3e" % (eos, lens, worst))
     assert worst < 2e-5
+    # the escape hatch, bounded: few entries, none far from the oracle's literal difference
+    assert au["cleared"] <= ARBITER_MAX_CLEARED.get((eos, lens), 0), au
+    assert au["raw_worst"] < ARBITER_HARD_BOUND, au
     sim.destroy(); osim.close()
 
 
@@ -456,7 +496,9 @@ def test_residual_forms(FS, oracle, eos, method):
     # r = 1.7 against 2 for backward Euler): its rounding noise, divided by the FD step, is that
     # much larger relative to the block row than in test_jacobian
     jtol = 1e-4 if method == "bdf2" else 1e-5
-    assert jacobian_against_literal_fd(sim, y, L, dt, Jg, Jo, rp, ci, bs, jtol) < jtol
+    au = {}
+    assert jacobian_against_literal_fd(sim, y, L, dt, Jg, Jo, rp, ci, bs, jtol, osim=osim, audit=au) < jtol
+    assert au["cleared"] <= ARBITER_MAX_CLEARED.get(("residual_forms", method), 0) and au["raw_worst"] < ARBITER_HARD_BOUND, au
     # back to backward Euler: the default form is untouched by the excursion
     sim.set_residual_form("beuler")
     osim.set_residual_form(0)

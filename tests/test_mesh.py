@@ -244,3 +244,56 @@ def test_generic_partition_is_consistent_across_ranks():
                 assert np.array_equal(mine_from_q, q_sends_me)
         assert (seen == 1).all() and nsrc == lm.n_src
         assert sum(m.n_bc for m, _ in parts) == lm.n_bc
+
+
+@pytest.mark.parametrize("brick_order", ["x", "z", "tile", "tile2", "tile3", "tile4x4", "tile2x3", "tile5x2"])
+@pytest.mark.parametrize("part", [(1, 1, 1), (2, 1, 1)])
+def test_brick_numberings_tile_the_same_mesh(brick_order, part):
+    """the numbering of a rank's bricks ("x", "z", strips of brick rows: "tileN") moves the bricks in memory and in
+    launch order, nothing else: the same boxes of cells, each contiguous and level-sorted, the same faces between the
+    same global cells, local_id in step with local_mesh; in "tileN" the bricks above / below are N x (bricks per row)
+    positions away and the strips follow one another"""
+    dims, brick = (22, 19, 9), (4, 4, 2)      # ragged in x and y; 6 x 5 x 5 bricks on one rank
+    g0 = M.StructuredGrid(dims, part=part, brick=brick, brick_order="x")
+    g = M.StructuredGrid(dims, part=part, brick=brick, brick_order=brick_order)
+    for rank in range(g.nranks):
+        m0 = g0.local_mesh(rank, sources=M.benchmark_sources(g0))
+        m = g.local_mesh(rank, sources=M.benchmark_sources(g))
+        assert (m.n_owned, m.n_halo, m.n_bc, m.n_faces) == (m0.n_owned, m0.n_halo, m0.n_bc, m0.n_faces)
+        sp = m.sub_ptr
+        assert sp[0] == 0 and sp[-1] == m.n_owned and len(sp) == len(m0.sub_ptr)
+        boxes = set()
+        first = []
+        for s in range(len(sp) - 1):
+            c = m.owned_ijk[sp[s]: sp[s + 1]].astype(int)
+            ext = c.max(axis=0) - c.min(axis=0) + 1
+            assert np.prod(ext) == len(c) and np.all(ext <= np.array(brick))
+            assert np.all(np.diff((c - c.min(axis=0)).sum(axis=1)) >= 0)
+            boxes.add((tuple(c.min(axis=0)), tuple(ext)))
+            first.append(tuple(c.min(axis=0)))
+        boxes0 = set()
+        for s in range(len(sp) - 1):
+            c = m0.owned_ijk[m0.sub_ptr[s]: m0.sub_ptr[s + 1]].astype(int)
+            boxes0.add((tuple(c.min(axis=0)), tuple(c.max(axis=0) - c.min(axis=0) + 1)))
+        assert boxes == boxes0
+        pg, pg0 = m.extras["prim_gid"], m0.extras["prim_gid"]
+
+        def pairs(mm, p):
+            f = mm.face_cells[mm.face_cells.max(axis=1) < mm.n_prim]
+            return np.unique(np.sort(p[f], axis=1), axis=0)
+        assert np.array_equal(pairs(m, pg), pairs(m0, pg0))
+        ijk = m.extras["prim_ijk"][: m.n_owned]
+        assert np.array_equal(g.local_id(rank, ijk[:, 0], ijk[:, 1], ijk[:, 2]), np.arange(m.n_owned))
+        assert sorted(int(m.owned_gid[c]) for c in m.src_cell) == sorted(int(m0.owned_gid[c]) for c in m0.src_cell)
+        if brick_order.startswith("tile"):
+            tx, _, ty = brick_order[4:].partition("x")
+            tx, ty = (int(tx), int(ty)) if ty else (10 ** 6, int(tx or 4))
+            where = {f: s for s, f in enumerate(first)}
+            xs, ys = sorted({f[0] for f in first}), sorted({f[1] for f in first})
+            for s, (x, y, z) in enumerate(first):
+                up = where.get((x, y, z + brick[2]))
+                if up is not None:      # the brick below in z: one layer of the column on
+                    ix, iy = xs.index(x), ys.index(y)
+                    rows = min(ty, len(ys) - (iy // ty) * ty)
+                    cols = min(tx, len(xs) - (ix // tx) * tx)
+                    assert up - s == rows * cols, (s, up, rows, cols)

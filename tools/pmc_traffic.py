@@ -41,6 +41,10 @@ def main(src, tag, dst):
         find(r"k_pc_park<true|k_pc_rows<\d, true|k_pc_wave<\d, true|k_pc<\d, true")
     pcx = find(r"k_pc_park<true, true|k_pc_wave<\d, true, true|k_pc_rows<\d, true, \d, \d, true")
     sp = find(r"k_spmv<")
+    # since round 6 the line's roofline is the iteration's slower fused launch; the other one's figures travel as <half>_half_*
+    dom = roof.get("dominant_half", "first")
+    alg_first = roof["algorithmic_bytes_per_launch"] if dom == "first" else roof["first_half_algorithmic_bytes_per_launch"]
+    alg_second = roof["algorithmic_bytes_per_launch"] if dom == "second" else roof.get("second_half_algorithmic_bytes_per_launch")
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python "
                      "bench.py --config ... --lead 1 --steps 1 --warmup 0 --no-cpu --spmv-reps 10 on 1 x MI355X; " +
                      bench["config"]["workload"],
@@ -48,15 +52,15 @@ def main(src, tag, dst):
                          "requests at 64 B; calibrated on k_bcgs_p: 3 vectors read -> 2*%.0f KiB; 1 vector written -> "
                          "%.0f KiB)" % (fe.get("wai::k_bcgs_p", 0.0), wr.get("wai::k_bcgs_p", 0.0)),
            "dims": dims, "brick": brick, "k_pc_kernel": pc,
-           "k_pc_hbm_bytes_per_launch": hbm(pc), "k_pc_algorithmic_bytes": roof["algorithmic_bytes_per_launch"],
-           "k_pc_traffic_over_algorithmic": hbm(pc) / roof["algorithmic_bytes_per_launch"],
+           "k_pc_hbm_bytes_per_launch": hbm(pc), "k_pc_algorithmic_bytes": alg_first,
+           "k_pc_traffic_over_algorithmic": hbm(pc) / alg_first,
            "k_spmv_hbm_bytes_per_launch": hbm(sp), "k_spmv_algorithmic_bytes": roof["spmv_algorithmic_bytes_per_launch"],
            "k_spmv_traffic_over_algorithmic": hbm(sp) / roof["spmv_algorithmic_bytes_per_launch"]}
     if pcx and pcx != pc:
         m2 = re.search(r"\((\d+) cells\)", bench["config"]["workload"])
         ncell = int(m2.group(1)) if m2 else 0
         bs = 2 if "k_pc_park" in pcx else 3
-        alg = roof["algorithmic_bytes_per_launch"] + 8 * bs * ncell
+        alg = alg_second or (alg_first + 8 * bs * ncell)
         out.update({"k_pc_composed_kernel": pcx, "k_pc_composed_hbm_bytes_per_launch": hbm(pcx),
                     "k_pc_composed_algorithmic_bytes": alg, "k_pc_composed_traffic_over_algorithmic": hbm(pcx) / alg})
     for name, pat in (("k_bcgs_p", r"k_bcgs_p"), ("k_jacobian", r"k_jacobian"), ("k_residual", r"k_residual"),

@@ -124,6 +124,7 @@ int do_newton_step(wai_ctx* c, double dt, int iter, double* y, const double* lhs
   static_assert(F_REGION == F_T + 1 && F_OLD_REGION == F_T + 2, "the transition sweep's planes are consecutive");
   HIPCHK(c, hipMemcpyAsync(c->flu_last_iter + (size_t)F_T * c->mesh.n_local, c->flu + (size_t)F_T * c->mesh.n_local,
                            sizeof(double) * (size_t)3 * c->mesh.n_local, hipMemcpyDeviceToDevice, c->stream));
+  c->last_iter_partial = true;   // wai_get_fluid(ctx, 1, ..) refuses until wai_pre_iteration makes the whole record again
   int e = do_jacobian(c, dt, y, lhs_old);
   if (e < 0) return -1;
   if (e > 0) { *reason = -3; return 0; }
@@ -782,6 +783,12 @@ int wai_get_source_separated(wai_ctx* c, double* out4) {
 
 int wai_get_fluid(wai_ctx* c, int which, double* out) {
   if (!c || !out) return -2;
+  if (which == 1 && c->last_iter_partial) {
+    // wai_newton_step snapshots only the planes its transition sweep reads: the rest of the record is stale (advisor, round 5)
+    c->err = "wai_get_fluid(1): the last-iteration record is partial after wai_newton_step (temperature, region, old region); "
+             "call wai_pre_iteration for the whole record";
+    return -2;
+  }
   const double* src = which == 0 ? c->flu : (which == 1 ? c->flu_last_iter : c->flu_last_step);
   const size_t tot = (size_t)c->df * c->mesh.n_local;
   launch_fluid_aos(c, src, c->stage[0]);
@@ -867,6 +874,7 @@ int wai_pre_iteration(wai_ctx* c) {
   if (!c) return -2;
   HIPCHK(c, hipMemcpyAsync(c->flu_last_iter, c->flu, sizeof(double) * (size_t)c->df * c->mesh.n_local,
                            hipMemcpyDeviceToDevice, c->stream));
+  c->last_iter_partial = false;
   return 0;
 }
 

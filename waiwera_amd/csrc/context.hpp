@@ -419,7 +419,7 @@ struct wai_ctx {
   hipEvent_t ev_face = nullptr, ev_prior = nullptr;
   // run-time switches of the fused launches, read from the environment once per solve / set-up / probe (read_env),
   // not per launch: WAI_FIN_SEPARATE, WAI_PC_STAGGER (-1: each kernel's default), WAI_WAVE_ROWPTR, WAI_NO_COL16 (k_pc_park on the int32 column planes)
-  struct EnvSw { bool fin_separate = false; int stagger = -1; bool wave_rowptr = false; bool no_col16 = false; bool no_face_stream = false; bool scalar_kernels = false; } env;
+  struct EnvSw { bool fin_separate = false; int stagger = -1; bool wave_rowptr = false; bool no_col16 = false; int stage = -1; bool no_face_stream = false; bool scalar_kernels = false; } env;
   int test_drop_wait = 0;   // fault injection (wai_test_drop_stream_wait): 1 the face bricks' launch does not wait for the halo
   // halo
   int n_nbr = 0;
@@ -441,6 +441,7 @@ struct wai_ctx {
   // measurement
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool prof_on = false;
+  bool last_iter_partial = false;   // flu_last_iter holds only the transition sweep's planes (do_newton_step)
   double prof_ms[wai::KC_COUNT] = {0};
   long long prof_n[wai::KC_COUNT] = {0};
   hipEvent_t pev0 = nullptr, pev1 = nullptr;

@@ -87,6 +87,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 #ifndef PC_MIN_WAVES
 #define PC_MIN_WAVES 4   // waves per SIMD k_pc is compiled for; 5 or 6 force spills and measured 1.2x / 3x slower (tools/ab_pc_waves.sh)
 #endif
+#ifndef WAI_PC_STAGE_DEFAULT
+#define WAI_PC_STAGE_DEFAULT 0
+#endif
 constexpr int WMAX = 8;  // block-ELL width handled in registers (7-point stencil: 7, MINC: 8)
 
 
@@ -1336,7 +1339,14 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
 // loads) and the lane's pick among them a chain of selects.  Same columns, same order, same bits.
 // (First form, one 16-bit plane per slot: 2 bytes less per block but the same seven loads -- MEASURED no faster: fused
 // launch 0.0845 -> 0.0859 ms at 108^3, 0.584 -> 0.581 at 216^3, profiles/col16_planes_ab_r5.log.)
-template <bool SPMV, bool AX, bool C16>
+// SL (round 6): the brick's OWN segment of the operand staged in LDS before the slot loop.  Each thread loads its row's
+// entry (coalesced; composed: R_i and V_i, S_i = fma(-alpha, V_i, R_i) formed once), stores it to the solution area and,
+// behind one barrier, the in-brick columns of a row -- slots [lfirst, ulast): the lower couplings, the diagonal, the
+// upper couplings, 79 % of a 16 x 16 x 2 brick's -- are read from there; only the off-brick columns are gathered from
+// memory (composed: two gathers each).  The solution area doubles as the stage (a stage of its own would be the 8 KB
+// that end three resident workgroups per CU), so one more barrier separates the last read of S from the store of t = A S.
+// The same fma on the same operands: identical bits.
+template <bool SPMV, bool AX, bool C16, bool SL = false>
 __global__ __launch_bounds__(512, 6) void k_pc_park(
     int n, int W, int nsub, const int* __restrict__ sub_ptr, const int* __restrict__ sub_nlev,
     const int* __restrict__ row_info, const int* __restrict__ row_uoff, const int* __restrict__ col,
@@ -1372,17 +1382,16 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
 #pragma unroll
     for (int e = 0; e < BB; e++) Lf[p][e] = 0.0;
   }
+  int lfirst = 0, dslot = 0, ulast = 0;
+  int cgs[WMAX];
   if (active) {
-    int lfirst, dslot, ulast;
     unpack_info(row_info[i], lfirst, dslot, ulast, lf, lb);
     uo = row_uoff[i];
     nU = ulast - dslot - 1;
-    double acc[BS] = {0.0, 0.0};
     // all column indices first: one round trip instead of one per slot (MEASURED at 216^3, same box:
     // 0.6196 -> 0.6018 ms).  A branch-free 7-slot loop, which lets the compiler keep every slot's loads
     // in flight, needs more than the 80 registers of 6 waves per SIMD: 188 bytes of scratch, 0.965 ms;
     // fetching the next slot's block while the current one is used (80 registers, no scratch): 0.626 against 0.614
-    int cgs[WMAX];
     if constexpr (C16) {
       const int* sg = sub_seg + (size_t)s * 8;     // wave-uniform
       const int g0 = sg[0], g1 = sg[1], g2 = sg[2], g3 = sg[3], g4 = sg[4], g5 = sg[5], g6 = sg[6], g7 = sg[7];
@@ -1407,6 +1416,14 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
         if (q < W) cgs[q] = load_col(col, (size_t)q * n + i);
       }
     }
+    if constexpr (SPMV && SL) {   // the row's own operand entry: staged for the brick's other rows
+      load_xs<BS, AX>(in, in2, nalpha, i, xin);
+      *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(xin[0], xin[1]);
+    }
+  }
+  if constexpr (SPMV && SL) __syncthreads();
+  double acc[BS] = {0.0, 0.0};
+  if (active) {
 #pragma unroll
     for (int q = 0; q < WMAX; q++) {
       if (q < W) {
@@ -1415,7 +1432,12 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
         load_block<BS>(sval, n, q, i, blk);
         if constexpr (SPMV) {
           double xv[BS];
-          load_xs<BS, AX>(in, in2, nalpha, cg, xv);
+          if constexpr (SL) {
+            if (q >= lfirst && q < ulast) {   // in the brick: lower couplings, diagonal, upper couplings
+              const double2 t = *reinterpret_cast<const double2*>(ys + (cg - lo) * 2);
+              xv[0] = t.x; xv[1] = t.y;
+            } else load_xs<BS, AX>(in, in2, nalpha, cg, xv);
+          } else load_xs<BS, AX>(in, in2, nalpha, cg, xv);
           acc[0] += blk[0] * xv[0] + blk[1] * xv[1];
           acc[1] += blk[2] * xv[0] + blk[3] * xv[1];
         }
@@ -1442,10 +1464,11 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
       acc[0] = dv[0] * r[0] + dv[1] * r[1];
       acc[1] = dv[2] * r[0] + dv[3] * r[1];
     }
-    if (dot == 2 || dot == 4) load_xs<BS, AX>(in, in2, nalpha, i, xin);
+    if constexpr (!(SPMV && SL)) { if (dot == 2 || dot == 4) load_xs<BS, AX>(in, in2, nalpha, i, xin); }
     if (dot == 1 || dot == 4) load_x_stream<BS>(aux, i, avp);   // the dot product's partner: in flight through the sweeps
-    *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(acc[0], acc[1]);
   }
+  if constexpr (SPMV && SL) __syncthreads();   // the stage's last reader is through: the area takes t = A x
+  if (active) *reinterpret_cast<double2*>(ys + tid * 2) = make_double2(acc[0], acc[1]);
   PH(0);
   __syncthreads();
   PH(1);
@@ -2495,6 +2518,7 @@ void read_env(wai_ctx* c) {
   c->env.stagger = es ? atoi(es) : -1;
   c->env.wave_rowptr = getenv("WAI_WAVE_ROWPTR") != nullptr;
   c->env.no_col16 = getenv("WAI_NO_COL16") != nullptr;
+  { const char* e = getenv("WAI_PC_STAGE"); c->env.stage = e ? atoi(e) : -1; }   // k_pc_park's operand stage: 0 off, 1 composed launch, 2 both launches; -1 default
   c->env.scalar_kernels = getenv("WAI_BCGS_SCALAR_KERNELS") != nullptr;   // several ranks: the one-thread kernels behind the all-reduces (rounds 3-4)
   { const char* e = getenv("WAI_FACE_STREAM"); c->env.no_face_stream = !(e && e[0] == '1'); }   // measured slower: off unless asked for
 }
@@ -2613,6 +2637,13 @@ bool pc_axpy_default(const wai_ctx* c) {
   return (kind == 1 && c->ilu.col16 && !c->env.no_col16) || kind == 3;   // k_pc_park on col16, k_pc_wave: measured faster end to end
 }
 
+// k_pc_park: is the brick's own operand segment staged in LDS (template SL)?  WAI_PC_STAGE = 0 never, 1 the composed
+// launch only, 2 both launches
+static bool pc_stage(const wai_ctx* c, bool composed) {
+  const int m = c->env.stage >= 0 ? c->env.stage : WAI_PC_STAGE_DEFAULT;
+  return composed ? m >= 1 : m >= 2;
+}
+
 // ticks of the 100-MHz clock between the cohorts of a fused launch's first generation (stagger_start); WAI_PC_STAGGER overrides
 static int stagger_ticks(const wai_ctx* c, int dflt) { return c->env.stagger >= 0 ? c->env.stagger : dflt; }
 
@@ -2683,10 +2714,11 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
     // upper blocks parked in LDS: three resident workgroups per CU
     if (kind == 1) {
       const size_t lds_park = lds + (size_t)s.max_ublocks * 4 * sizeof(double);
-#define PCP2(SP, AXV, C16V)                                                                        \
-      hipLaunchKernelGGL((k_pc_park<SP, AXV, C16V>), grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,  \
+#define PCP3(SP, AXV, C16V, SLV)                                                                   \
+      hipLaunchKernelGGL((k_pc_park<SP, AXV, C16V, SLV>), grid, T, lds_park, c->stream, J.n, J.W, nrun, s.sub_ptr, s.sub_nlev,  \
                          s.row_info, s.row_uoff, J.col, s.col16, s.sub_seg, s.fval, s.dinv, in, in2, scal, z, aux, c->ks.partials, \
                          c->ks.nb_max, dot_mode, list, fin, stagger)
+#define PCP2(SP, AXV, C16V) do { if (SP && pc_stage(c, AXV)) PCP3(SP, AXV, C16V, SP); else PCP3(SP, AXV, C16V, false); } while (0)
 #define PCP(SP, AXV) do { if (s.col16 && !c->env.no_col16) PCP2(SP, AXV, true); else PCP2(SP, AXV, false); } while (0)
       Stagger stagger;
       stagger.ncu = c->n_cu;
@@ -2696,6 +2728,7 @@ static void launch_pc_bs(wai_ctx* c, const Bcsr& J, const IluSchedule& s, bool s
       else PCP(false, false);
 #undef PCP
 #undef PCP2
+#undef PCP3
       return;
     }
   }

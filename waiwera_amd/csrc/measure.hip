@@ -21,6 +21,7 @@ int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
   if (which == 16 && ensure_face_stream(c)) return -1;
   if (which > 0 && !c->ilu.factored) { const int e = do_pc_setup(c); if (e) return e < 0 ? -1 : e; }
   Krylov& k = c->ks;
+  const size_t copy_n = (size_t)c->np * c->df * c->mesh.n_prim / 2;   // modes 18 / 19 (the scratch is rewritten by every Jacobian)
   auto run = [&]() {
     switch (which) {
       case 0: launch_spmv(c, k.P, k.tmp); break;
@@ -44,6 +45,18 @@ int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
       case 6:   // its vector updates alone
         if (bcgs_mode(c) == 2) { if (!pc_axpy_ok(c)) bcgs_update_s(c); bcgs_update_xrp(c); }
         else { bcgs_update_p(c); bcgs_update_s(c); bcgs_update_xr(c, true, 4, false); }
+        break;
+      case 17: {  // the second fused launch of the iteration exactly as bcgs_second_half issues it on one rank: operand S (or
+                  // R - alpha V formed in the launch), five inner products, omega / (R,R) / rho / beta + the post in the finaliser
+        const BcgsPlan pl = bcgs_plan(c);
+        pc_amul(c, pl.axpy ? k.R : k.S, k.T, 4, k.RP, 6, pl.axpy ? k.V : nullptr, true);
+        break;
+      }
+      case 18:   // what a copy achieves on this box: hipMemcpy device to device, half of the perturbed-fluid scratch onto the other
+        hipMemcpyAsync(c->flu_pert + copy_n, c->flu_pert, copy_n * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+        break;
+      case 19:   // the same bytes through the library's own copy kernel
+        vec_copy(c, c->flu_pert + copy_n, c->flu_pert, copy_n);
         break;
       case 7:   // the second fused launch of the "fused" iteration: z = B^-1 A (R - alpha V) with the five inner products
         pc_amul(c, k.R, k.T, 4, k.RP, -1, pc_axpy_ok(c) ? k.V : nullptr, false);
@@ -108,6 +121,13 @@ const char* wai_pc_kernel_name(wai_ctx* c) {
   return buf;
 }
 int wai_comm_size(wai_ctx* c) { return c ? comm_count(c->comm) : -2; }
+// does a BiCGStab iteration's second fused launch form its operand S = R - alpha V itself (three launches per iteration)?
+int wai_bcgs_composed(wai_ctx* c) {
+  if (!c) return -2;
+  read_env(c);
+  const BcgsPlan pl = bcgs_plan(c);
+  return pl.axpy ? 1 : 0;
+}
 int wai_launch_stats(wai_ctx* c, long long* kernels, long long* copies) {
   if (!c) return -2;
   if (kernels) *kernels = c->ks.n_launch;

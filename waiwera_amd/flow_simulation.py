@@ -216,8 +216,16 @@ class FlowSimulation:
         LIB.wai_launch_stats(self.h, C.byref(a), C.byref(e))
         return a.value, e.value
 
-    def pc_kernel_name(self):
-        return LIB.wai_pc_kernel_name(self.h).decode()
+    def pc_kernel_name(self, composed=False):
+        """kernel (or path) of a preconditioned-operator application; composed: its form with the operand R - alpha V
+        made inside the launch (the second fused launch of a BiCGStab iteration where bcgs_composed() says so)"""
+        name = LIB.wai_pc_kernel_name(self.h).decode()
+        if composed:
+            name = name[:-1] + ",composed>" if name.endswith(">") else name + " (composed operand)"
+        return name
+
+    def bcgs_composed(self):
+        return LIB.wai_bcgs_composed(self.h) == 1
 
     def set_regions(self, region):
         r = _lib._i32(region)

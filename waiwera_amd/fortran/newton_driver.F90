@@ -25,6 +25,7 @@ program newton_driver
   character(len = 512) :: idfile
   character(kind = c_char) :: comm_id(128)
   logical :: there
+  integer :: waited
   integer :: n_owned, n_halo, n_bc, n_faces, n_sub, n_src, eos_kind, np, n_local
   integer :: num_steps, step, it, ksp_its, reason, err, tries, total_newton, total_ksp, u
   real(dp) :: t, dt, max_residual
@@ -43,6 +44,13 @@ program newton_driver
      call get_command_argument(5, arg); read(arg, *) my_rank
      call get_command_argument(6, arg); read(arg, *) n_ranks
      call get_command_argument(7, idfile)
+     if (my_rank == 0) then      ! a leftover of an aborted run must not be taken for this run's id
+        inquire(file = trim(idfile), exist = there)
+        if (there) then
+           open(newunit = u, file = trim(idfile), status = 'old')
+           close(u, status = 'delete')
+        end if
+     end if
   end if
 
   open(newunit = u, file = trim(infile), access = 'stream', form = 'unformatted', status = 'old')
@@ -81,12 +89,18 @@ program newton_driver
         open(newunit = u, file = trim(idfile) // '.part', access = 'stream', form = 'unformatted', status = 'replace')
         write(u) comm_id
         close(u)
-        call execute_command_line('mv ' // trim(idfile) // '.part ' // trim(idfile))
+        ! (quoted: the path is the launcher's, not ours to trust with a shell)
+        call execute_command_line("mv -- '" // trim(idfile) // ".part' '" // trim(idfile) // "'")
      else
+        ! bounded: if rank 0 dies before it writes the id, the other ranks end with an error instead of waiting for ever.
+        ! The launcher gives every run its own file name (a leftover of an earlier run would be read as this run's id).
+        waited = 0
         do
            inquire(file = trim(idfile), exist = there)
            if (there) exit
            call execute_command_line('sleep 0.05')
+           waited = waited + 1
+           if (waited > 6000) stop 'no RCCL id from rank 0 within 300 s'
         end do
         open(newunit = u, file = trim(idfile), access = 'stream', form = 'unformatted', status = 'old')
         read(u) comm_id

@@ -181,6 +181,7 @@ def _load():
         "wai_timer_stop": (i32, [vp, C.POINTER(C.c_float)]),
         "wai_synchronize": (i32, [vp]),
         "wai_bench_kernel": (i32, [vp, i32, i32, C.POINTER(C.c_float)]),
+        "wai_bcgs_composed": (i32, [vp]),
         "wai_profile_enable": (i32, [vp, i32]),
         "wai_profile_get": (i32, [vp, i32, pd, C.POINTER(C.c_longlong)]),
         "wai_profile_reset": (i32, [vp]),

@@ -21,6 +21,8 @@ Local cell order on a rank:  [owned | halo (other ranks' cells, grouped by neigh
 """
 from dataclasses import dataclass, field
 
+import re
+
 import numpy as np
 
 GRAVITY = 9.8  # default 3-D gravity (0,0,-9.8): src/flow_simulation.F90:833-846
@@ -127,9 +129,27 @@ class StructuredGrid:
         # k_pc_park 621 against 631 us, but k_jacobian_park 10.87 against 10.57 ms and k_residual 2.73 against 2.66 ms --
         # the assembly sweeps' re-reads are a capacity problem (a brick's 31 field planes of own + neighbour lines, ~160 KB,
         # against 128 KB of L2 per CU), not a distance problem; not adopted.
-        if brick_order not in ("z", "x"):
-            raise ValueError("brick_order 'z' or 'x'")
-        self.brick_order = brick_order
+        # "tile" / "tileN" (round 6): x fastest, then y inside strips of N (default 4) brick rows, then z, then the strips.
+        # A fused launch keeps ~96 bricks resident per XCD (3 per CU) and works through its eighth of the numbering in
+        # order, so a neighbour brick's vector entries are L2 hits when that brick is within about a hundred positions.
+        # With 14 x 14 x 108 bricks of 16 x 16 x 2 cells (216^3) "x" puts the bricks above / below 196 positions away --
+        # and those are the expensive neighbours: with the cells of a brick in level order their 256 rows touch every
+        # line of both bricks (16 KB per gathered vector and brick, against 4 KB for each x / y face).  In strips of 4
+        # brick rows the distances are x 1, y 14, z 56, and only a quarter of the y links cross a strip.
+        # "tileAxB": columns of A x B bricks -- x fastest inside the column's A, then its B rows, then z through all layers,
+        # then the next column (x, then y): the bricks above / below are A * B positions away.  ("tileN" = all of x, N rows.)
+        m_ = re.fullmatch(r"tile(\d*)(?:x(\d+))?", brick_order) if isinstance(brick_order, str) else None
+        if brick_order not in ("z", "x") and not m_:
+            raise ValueError("brick_order 'z', 'x', 'tile[N]' or 'tileAxB'")
+        self.brick_order = "tile" if m_ else brick_order
+        if m_ and m_.group(2):
+            self.brick_tile_x, self.brick_tile_y = int(m_.group(1) or 0), int(m_.group(2))
+            if self.brick_tile_x < 1:
+                raise ValueError("brick_order tileAxB: A >= 1")
+        else:
+            self.brick_tile_x, self.brick_tile_y = 0, int(m_.group(1)) if m_ and m_.group(1) else 4   # 0: the whole row
+        if self.brick_tile_y < 1:
+            raise ValueError("brick_order tileN / tileAxB: N, B >= 1")
         self.dims = tuple(int(v) for v in dims)
         self.spacing = tuple(float(v) for v in spacing)
         self.part = tuple(int(v) for v in part)
@@ -158,16 +178,27 @@ class StructuredGrid:
             b0, b1 = ax.bsplit[rc[a]], ax.bsplit[rc[a] + 1]
             sizes.append((ax.edges[b0 + 1:b1 + 1] - ax.edges[b0:b1]))
         vol = sizes[2][:, None, None] * sizes[1][None, :, None] * sizes[0][None, None, :]
-        if self.brick_order == "z":   # numbered (bx, by, bz) with bz fastest
-            vol = np.ascontiguousarray(vol.transpose(2, 1, 0))
-        starts = np.concatenate([[0], np.cumsum(vol.ravel())])
-        return starts, vol.shape
+        nbz, nby, nbx = vol.shape
+        bz, by, bx = np.meshgrid(np.arange(nbz), np.arange(nby), np.arange(nbx), indexing="ij")
+        if self.brick_order == "z":     # numbered (bx, by, bz) with bz fastest
+            pos = (bx * nby + by) * nbz + bz
+        elif self.brick_order == "tile":   # x fastest, y inside its strip of brick rows, z, then the strips
+            ty, tx = self.brick_tile_y, (self.brick_tile_x or nbx)
+            rows_before = np.minimum((by // ty) * ty, nby)                  # brick rows in the strips before this one
+            rows_here = np.minimum(ty, nby - (by // ty) * ty)                # rows of this strip (the last one may be short)
+            cols_before = np.minimum((bx // tx) * tx, nbx)                  # inside the strip: the columns before this one
+            cols_here = np.minimum(tx, nbx - (bx // tx) * tx)
+            pos = (rows_before * nbx + rows_here * cols_before) * nbz + (bz * rows_here + by % ty) * cols_here + bx % tx
+        else:
+            pos = (bz * nby + by) * nbx + bx
+        byvol = np.empty(vol.size, dtype=np.int64)
+        byvol[pos.ravel()] = vol.ravel()
+        starts = np.concatenate([[0], np.cumsum(byvol)])
+        return starts, pos
 
-    def _brick_index(self, bz, by, bx, shape):
-        """number of brick (bx, by, bz) of a rank; shape as returned by _brick_starts"""
-        if self.brick_order == "z":
-            return (bx * shape[1] + by) * shape[2] + bz
-        return (bz * shape[1] + by) * shape[2] + bx
+    def _brick_index(self, bz, by, bx, pos):
+        """number of brick (bx, by, bz) of a rank; pos as returned by _brick_starts"""
+        return pos[bz, by, bx]
 
     def local_id(self, rank, i, j, k):
         """Local (owned) index on `rank` of global cells (i,j,k) that rank owns."""

@@ -21,7 +21,7 @@ def block_owner(n_cells, world):
     return (np.arange(n_cells, dtype=np.int64) * world) // max(n_cells, 1)
 
 
-def partition_mesh(lm, owner, rank, chunk=512):
+def partition_mesh(lm, owner, rank, chunk=512, world=None):
     """(LocalMesh of `rank`, gid) from the one-rank LocalMesh `lm` and owner[cell] in 0 .. world - 1.
 
     gid: the one-rank index of every local owned-or-ghost cell (initial states, regions and results are gathered with it;
@@ -33,7 +33,17 @@ def partition_mesh(lm, owner, rank, chunk=512):
     N, NB = lm.n_owned, lm.n_bc
     if owner.size != N:
         raise ValueError("one owner per cell")
-    world = int(owner.max()) + 1
+    # `world` = the communicator's size (advisor, round 5: inferred from the owner array alone it is wrong for an array that
+    # leaves the last ranks empty, and an empty rank fails far downstream); every rank must own a cell
+    if world is None:
+        world = int(owner.max()) + 1
+    if owner.min() < 0 or owner.max() >= world:
+        raise ValueError("owner outside 0 .. %d" % (world - 1))
+    if not 0 <= rank < world:
+        raise ValueError("rank %d of %d" % (rank, world))
+    empty = np.setdiff1d(np.arange(world), np.unique(owner))
+    if empty.size:
+        raise ValueError("rank(s) %s own no cell (%d cells on %d ranks)" % (empty[:8].tolist(), N, world))
     fc = np.asarray(lm.face_cells, dtype=np.int64).reshape(-1, 2)
     own_f = np.where(fc < N, owner[np.clip(fc, 0, N - 1)], -1)          # owner of each face cell, -1: boundary cell
     keep = (own_f == rank).any(axis=1)

@@ -13,6 +13,13 @@ import sys
 from .simulation import Simulation
 
 
+def _stem(path):
+    """the output name without its .npz suffix (only the suffix: a '.npz' elsewhere in the path stays)"""
+    import os
+    root, ext = os.path.splitext(path)
+    return root if ext == ".npz" else path
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m waiwera_amd.run")
     ap.add_argument("input")
@@ -37,13 +44,13 @@ def main(argv=None):
     out = sim.run()
     if rank != 0:
         if a.output:
-            sim.save(a.output.replace(".npz", "") + ".rank%d.npz" % rank)
+            sim.save(_stem(a.output) + ".rank%d.npz" % rank)
         return 0
     for (t, dt, nits, kits, tries) in sim.ts.history:
         print("timestep end: time %.6e size %.6e iterations %d linear %d tries %d" % (t, dt, nits, kits, tries))
     print("finished at t = %.6e s after %d steps" % (out["time"], sim.ts.taken))
     if a.output:
-        sim.save(a.output if world == 1 else a.output.replace(".npz", "") + ".rank0.npz")
+        sim.save(a.output if world == 1 else _stem(a.output) + ".rank0.npz")
     if sim.output_error is not None:
         print("error: output file not written: %s" % sim.output_error, file=sys.stderr)
         return 1

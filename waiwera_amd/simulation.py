@@ -400,7 +400,7 @@ class Simulation:
                 raise NotImplementedError("MINC zones, rock table controls, tracers and source networks of an input file on several ranks")
             from .partition import block_owner, partition_mesh
             own = block_owner(lm.n_owned, self.world) if owner is None else np.asarray(owner)
-            lm, self._gid = partition_mesh(lm, own, self.rank)
+            lm, self._gid = partition_mesh(lm, own, self.rank, world=self.world)
             self.owned_gid = lm.owned_gid
             self._src_pick = lm.extras.get("src_global_index", np.zeros(0, dtype=np.int32))
             self._tables = [(int(np.nonzero(self._src_pick == i)[0][0]), key, tab) for (i, key, tab) in self._tables
@@ -558,9 +558,14 @@ class Simulation:
             raise NotImplementedError("repeated output checkpoints")
 
         src_in = inp.get("source", []) or []
+        # On several ranks the initial fluid state some controls need (reference pressure "initial", productivity index
+        # from the initial rate) comes out of a pre_eval, and a pre_eval there exchanges halos: it is made on EVERY rank,
+        # decided on the unfiltered source list -- a rank without such a source would otherwise never issue the matching
+        # exchange (advisor, round 5)
+        need_fluid = self.world > 1 and any(k in s_ for s_ in src_in for k in ("deliverability", "recharge", "injectivity"))
         if self._src_pick is not None:      # the sources of this rank's cells, in the rank's order
             src_in = [src_in[i] for i in self._src_pick]
-        self._setup_source_controls(src_in, _get(inp, "time.start", 0.0))
+        self._setup_source_controls(src_in, _get(inp, "time.start", 0.0), collective_fluid=need_fluid)
         self._setup_network(inp)
         if (self._tables or self._ctl_tables or getattr(self, "_tracer_tables", None) or getattr(self, "_network_timed", False)
                 or self._rock_controls):
@@ -578,17 +583,20 @@ class Simulation:
             self.ode.set_source_network(spec)
 
     # ---- state-dependent source controls -------------------------------------------------------
-    def _setup_source_controls(self, sources, t0):
+    def _setup_source_controls(self, sources, t0, collective_fluid=False):
         """Deliverability, recharge, limiter, separator and direction of each source
         (setup_inline_source_controls, src/source_setup.F90:2340-2412) as the control records the
         device evaluates (include/waiwera_hip.h, wai_source_control); their time tables are kept
         here and averaged over every step interval (_update_controls)"""
         self._ctl, self._ctl_tables = None, []
+        fl = None
+        if collective_fluid:      # every rank together, whether or not it owns such a source
+            assert self.ode.pre_eval(t0, self.y) == 0
+            fl = np.asarray(self.ode.fluid())
         if not any(k in s for s in sources for k in ("deliverability", "recharge", "injectivity", "limiter",
                                                      "direction", "factor", "separator")):
             return
         recs = [dict() for _ in sources]
-        fl = None
 
         def timed(v, default, s):     # number | [[t, v], ...] | {"time": [[t, v], ...]} -> Table
             if isinstance(v, dict):
@@ -601,6 +609,8 @@ class Simulation:
         def cell_fluid(cell):
             nonlocal fl
             if fl is None:
+                if self.world > 1:
+                    raise RuntimeError("initial fluid state asked for on one rank only: the evaluation is collective")
                 assert self.ode.pre_eval(t0, self.y) == 0
                 fl = np.asarray(self.ode.fluid())
             if self.world > 1:      # the input's cell number -> this rank's (the source is on this rank: its cell is owned)
