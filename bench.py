@@ -211,6 +211,20 @@ def traffic_from_profiles(cfg, dims, brick, kernel, composed=False):
     return None
 
 
+def pc_reference_default(cfg, pc):
+    """the reference's default preconditioner against the one this run uses, from the committed comparison"""
+    p = os.path.join(ROOT, "profiles", "pc_compare_r6.json")
+    out = {"reference_default": "asm (restricted PCASM, overlap 1, sub-PC ILU(0): src/timestepper.F90:2019-2020)", "this_run": pc}
+    try:
+        d = json.load(open(p))
+        out["measured"] = d["first_system"].get(cfg)
+        out["source"] = d["source"]
+        out["why_no_fused_asm"] = d["why_no_fused_asm"]
+    except Exception:
+        out["measured"] = None
+    return out
+
+
 # SURVEY.md section 8d: curves of the synthetic workloads -- the reference's defaults (relative_permeability.F90:225-226,591,
 # capillary_pressure.F90:389) and "one extra run with Corey (0.3, 0.05)" (relative_permeability.F90:297-307)
 CURVES = {"linear": {}, "corey": {"relperm": ("corey", [0.3, 0.05])}}
@@ -815,6 +829,9 @@ def main():
     # the window's first state again: residual and Jacobian the oracle is compared with, and the matrix
     # the kernel microbenchmarks run on
     gpu_first_kits = drv.log[n_lead][3] if len(drv.log) > n_lead and drv.log[n_lead][2] == 1 else None   # the device's Krylov count on the window's first system
+    # ... and that whole Newton step on the device (warm-up's first step: outside the timed region, host-timed like the timed ones)
+    gpu_first_step = ({"krylov": int(drv.log[n_lead][3]), "seconds": float(drv.log[n_lead][6]), "reason": int(drv.log[n_lead][4])}
+                      if gpu_first_kits is not None else None)
     drv.restore(start)
     drv._begin()
     sim.jacobian(drv.t + drv.dt, drv.dt, y, drv.lhs_old)
@@ -830,6 +847,8 @@ def main():
     nnzb = wl.LIB.wai_jacobian_nnzb(sim.h)
     names = ["spmv", "ilu_apply", "fused_pc_amul"]
     kb = {name: sim.bench_kernel(w, a.spmv_reps if w in (0, 2) else 20) for w, name in enumerate(names)}
+    if a.ksp == "gmres":
+        kb["fused_pc_plain"] = sim.bench_kernel(11, a.spmv_reps)
     if world == 1 and not minc and a.pc == "bjacobi" and a.ilu_levels == 0:   # the two launches of the overlapped halo exchange, timed alone
         kb["fused_interior_bricks"] = sim.bench_kernel(9, a.spmv_reps)
         kb["fused_face_bricks"] = sim.bench_kernel(10, a.spmv_reps)
@@ -901,6 +920,22 @@ def main():
     for h in halves.values():
         h["gbs"] = h["bytes"] / (h["ms"] * 1e-3) / 1e9
         h["frac"] = h["gbs"] / HBM_PEAK_GBS
+    if a.ksp == "gmres":
+        # GMRES(m), classical Gram-Schmidt: per Krylov iteration ONE fused operator application and, averaged over a restart
+        # cycle j = 0 .. m - 1, the inner products (w, v_0 .. v_j) (k_mdot<1..8>: j + 1 basis vectors + w once per pass of eight)
+        # and the update w -= sum h_j v_j with |w|^2 (k_maxpy_norm: j + 1 basis vectors, w read and written)
+        m_r = opts.gmres_restart
+        vec = 8 * bs * lm.n_owned
+        halves = {"operator": dict(halves["first"], ms=kb["fused_pc_plain"], what="fused BCSR SpMV + block ILU(0) apply, no inner product")}
+        halves["operator"]["bytes"] = b_pc - vec      # no dot-product partner
+        halves["gram_schmidt_dots"] = {"ms": sim.bench_kernel(20, 3), "bytes": vec * sum(j + 2 for j in range(m_r)) / m_r,
+                                       "what": "GMRES(%d) inner products (w, v_0..v_j), average over a restart cycle" % m_r, "kernel": "k_mdot<8>"}
+        halves["gram_schmidt_update"] = {"ms": sim.bench_kernel(21, 3), "bytes": vec * sum(j + 3 for j in range(m_r)) / m_r,
+                                         "what": "GMRES(%d) update w -= sum h_j v_j + |w|^2, average over a restart cycle" % m_r, "kernel": "k_maxpy_norm"}
+        for h in halves.values():
+            h["gbs"] = h["bytes"] / (h["ms"] * 1e-3) / 1e9
+            h["frac"] = h["gbs"] / HBM_PEAK_GBS
+        kb.update({"gmres_dots_per_iteration": halves["gram_schmidt_dots"]["ms"], "gmres_update_per_iteration": halves["gram_schmidt_update"]["ms"]})
     dom = max(halves, key=lambda k: halves[k]["ms"])
     other = [k for k in halves if k != dom]
     traffic = None
@@ -949,9 +984,12 @@ def main():
                        "timed_newton_steps": [{"time_step": r[0], "dt": r[1], "newton": r[2], "krylov": r[3],
                                                "reason": r[4], "ms": 1e3 * r[6], "accepted": r[7]} for r in timed],
                        "partition": "x".join(str(p) for p in grid.part), "ksp": a.ksp, "pc": a.pc, "ilu_levels": a.ilu_levels,
-                       "brick_order": a.brick_order},
-            "roofline": {"bound": "hbm", "kernel": "%s (%s; the iteration's %s fused launch)" % (halves[dom]["kernel"], halves[dom]["what"], dom),
-                         "dominant_half": dom,
+                       "brick_order": a.brick_order,
+                       # the reference's default preconditioner is PCASM overlap 1 / ILU(0); this line runs `pc` -- what the
+                       # default would cost on the same systems (committed measurement, not made in this run)
+                       "pc_reference_default": pc_reference_default(a.config, a.pc)},
+            "roofline": {"bound": "hbm", "kernel": "%s (%s; %s)" % (halves[dom]["kernel"], halves[dom]["what"], ("the iteration's %s fused launch" % dom) if dom in ("first", "second") else "per Krylov iteration"),
+                         "dominant_half": dom, "ms_per_krylov_iteration_by_kernel": {k: halves[k]["ms"] for k in halves},
                          "achieved": halves[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": halves[dom]["frac"],
                          "traffic": traffic[0] if traffic else None,
@@ -964,10 +1002,11 @@ def main():
                          "spmv_gbs": achieved, "spmv_frac": achieved / HBM_PEAK_GBS, "spmv_ms_per_launch": ms,
                          "spmv_algorithmic_bytes_per_launch": b_spmv, "spmv_kernel": "k_spmv<%d> (BCSR SpMV)" % bs},
         }
-        for k in other:   # the iteration's other fused launch
-            out["roofline"].update({"%s_half_kernel" % k: "%s (%s)" % (halves[k]["kernel"], halves[k]["what"]), "%s_half_ms_per_launch" % k: halves[k]["ms"],
-                                    "%s_half_algorithmic_bytes_per_launch" % k: halves[k]["bytes"], "%s_half_achieved" % k: halves[k]["gbs"],
-                                    "%s_half_frac" % k: halves[k]["frac"]})
+        for k in other:   # the iteration's other fused launch (GMRES: its other per-iteration kernels)
+            pre = k + ("_half" if k in ("first", "second") else "")
+            out["roofline"].update({"%s_kernel" % pre: "%s (%s)" % (halves[k]["kernel"], halves[k]["what"]), "%s_ms_per_launch" % pre: halves[k]["ms"],
+                                    "%s_algorithmic_bytes_per_launch" % pre: halves[k]["bytes"], "%s_achieved" % pre: halves[k]["gbs"],
+                                    "%s_frac" % pre: halves[k]["frac"]})
         if "bicgstab_iteration_device_only" in kb:
             out["config"]["ms_per_krylov_iteration_device_only"] = kb["bicgstab_iteration_device_only"]
             out["config"]["ms_vector_updates_per_iteration"] = kb["bicgstab_vector_updates"]
@@ -989,7 +1028,7 @@ def main():
             try:
                 cb = cpu_baseline(lm, eos, start["y"].cpu().numpy(), start["regions"], start["dt"],
                                   kits / max(a.steps, 1), gpu_state=gpu_state, minc=minc, brick=brick, curves=CURVES[a.curves],
-                                  gpu_first_kits=gpu_first_kits)
+                                  gpu_first_kits=gpu_first_kits, gpu_first_step=gpu_first_step)
             except Exception as e:   # the reported baseline must not take the measurement down with it
                 log("cpu baseline failed: %r" % (e,))
                 cb = None

@@ -98,7 +98,14 @@ typedef struct wai_solver_opts {
   double utol_rel, utol_abs;   /* nonlinear.tolerance.update.{relative 1e-10, absolute 1} */
   double fd_eps, fd_umin;      /* nonlinear.jacobian.differencing.{increment 1e-8, tolerance 1e-2} */
   int min_newton_its;          /* nonlinear.minimum.iterations, default 0 (timestepper.F90:1930-1932) */
-  int pc_type;                 /* linear.preconditioner.type: WAI_PC_BJACOBI (default here) | WAI_PC_ASM | WAI_PC_NONE | WAI_PC_LU */
+  int pc_type;                 /* linear.preconditioner.type: WAI_PC_BJACOBI | WAI_PC_ASM | WAI_PC_NONE | WAI_PC_LU.
+                                  wai_default_opts sets WAI_PC_BJACOBI -- NOT the reference's default: Waiwera defaults to
+                                  PCASM, overlap 1, sub-PC ILU(0) (default_flow_pc_type_str = "asm", src/timestepper.F90:2019-2020;
+                                  one subdomain per rank, :1668-1669).  Block Jacobi over the mesh descriptor's subdomains is
+                                  the only preconditioner with a fused fast path here; WAI_PC_ASM runs the unfused
+                                  extended-system path (measured at 216^3: 74 Krylov iterations at 7.8 ms against 98 at 1.4 ms,
+                                  profiles/pc_compare_r6.log).  A host that mirrors an unmodified Waiwera input sets WAI_PC_ASM
+                                  itself (the JSON front end of waiwera_amd/simulation.py does) */
   int asm_overlap;             /* PCASM overlap, PETSc default 1; reaches one cell layer across rank boundaries (the
                                   partition-ghost cells' matrix rows come from their owners at every set-up) */
   int ilu_levels;              /* linear.sub_preconditioner.factor.levels (src/timestepper.F90:1716-1718, PCFactorSetLevels

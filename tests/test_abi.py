@@ -85,6 +85,11 @@ def test_defaults_match_reference_defaults():
     from waiwera_amd import lib
     o = lib.default_opts()
     assert (o.ksp_type, o.max_newton_its) == (0, 8)
+    # the ONE default that is not the reference's, stated in the header: brick block Jacobi (the fused path) where Waiwera
+    # defaults to PCASM overlap 1 (src/timestepper.F90:2019-2020); overlap and fill levels are PETSc's defaults
+    assert (o.pc_type, o.asm_overlap, o.ilu_levels) == (lib.PC["bjacobi"], 1, 0)
+    hdr = open(os.path.join(ROOT, "include", "waiwera_hip.h")).read()
+    assert "NOT the reference's default" in hdr and "timestepper.F90:2019-2020" in hdr
     assert (o.ftol_rel, o.ftol_abs, o.utol_rel, o.utol_abs) == (1e-5, 1.0, 1e-10, 1.0)
     assert (o.fd_eps, o.fd_umin, o.ksp_rtol) == (1e-8, 1e-2, 1e-5)
     e = lib.eos_desc("we")

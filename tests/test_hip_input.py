@@ -34,6 +34,26 @@ def test_problem5a():
     sim.ode.destroy()
 
 
+def test_preconditioner_choice_of_an_input_is_explicit():
+    """an input that names no preconditioner runs the REFERENCE's default -- restricted PCASM, overlap 1, ILU(0)
+    (src/timestepper.F90:2019-2020) -- and says so; default_pc="bjacobi" takes the library's fused path instead; both give
+    problem 5a's result (the preconditioner changes Krylov iterates, not converged steps)"""
+    from waiwera_amd.simulation import Simulation
+    path = os.path.join(INPUTS, "problem5a.json")
+    a = Simulation.from_json(path)
+    assert a.pc_choice == ("asm", "reference default") and "ASM" in a.ode.pc_kernel_name()
+    b = Simulation.from_json(path, default_pc="bjacobi")
+    assert b.pc_choice == ("bjacobi", "default_pc argument") and "ASM" not in b.ode.pc_kernel_name()
+    oa, ob = a.run(), b.run()
+    assert a.ts.taken == b.ts.taken == 200
+    for k in ("fluid_pressure", "fluid_temperature", "fluid_vapour_saturation"):
+        sc = max(np.abs(oa[k]).max(), 1e-300)
+        assert np.abs(oa[k] - ob[k]).max() <= 1e-4 * sc, k
+    a.ode.destroy(); b.ode.destroy()
+    with pytest.raises(ValueError):
+        Simulation.from_json(path, default_pc="ilu")
+
+
 def test_problem5b_rate_table():
     """5a plus an injection well driven by a step rate table (wai_update_sources before each try)"""
     sim, out = run("problem5b.json")

@@ -2232,29 +2232,70 @@ __global__ __launch_bounds__(TPB) void k_waxpy(double* w, double alpha, const do
   for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) w[i] = alpha * x[i] + y[i];
 }
 
-// GMRES: up to 8 dots (w, v_j) per pass
-__global__ __launch_bounds__(TPB) void k_mdot8(const double* __restrict__ w, const double* __restrict__ basis,
-                                               size_t ld, int j0, int cnt, int n, double* partials, int nb_max) {
-  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
-    const double wi = w[i];
+// GMRES: up to 8 dots (w, v_j) per pass.
+// Round 6: the classical Gram-Schmidt passes are 3/4 of a GMRES(30) iteration's bytes (on average 16.5 + 17.5 vectors
+// beside the operator's 19) and ran at 50-54 % of HBM peak (0.66 ms each per iteration at 216^3, bench_r6a_c3_gmres.json):
+// scalar 8-byte loads behind a per-vector `q < cnt` branch.  Now: the vector count is a template argument (straight-line
+// code: all of an element pair's CNT + 1 loads are requested together), 16-byte loads (two doubles per lane; 8-byte
+// alignment is enough on gfx950, an odd leading dimension is fine), two pairs per trip, basis vectors with the streaming
+// hint (each is read once per pass).  A thread's sums run over other elements than before: other rounding, same algorithm.
+template <int CNT>
+__global__ __launch_bounds__(TPB) void k_mdot(const double* __restrict__ w, const double* __restrict__ basis,
+                                              size_t ld, int j0, int n, double* partials, int nb_max) {
+  double v[CNT];
 #pragma unroll
-    for (int q = 0; q < 8; q++)
-      if (q < cnt) v[q] += wi * basis[(size_t)(j0 + q) * ld + i];
+  for (int q = 0; q < CNT; q++) v[q] = 0.0;
+  const size_t n2 = (size_t)n >> 1, stride = (size_t)gridDim.x * TPB;
+  const wai_d2u* w2 = reinterpret_cast<const wai_d2u*>(w);
+  auto one = [&](size_t i) {
+    const wai_d2u wi = w2[i];
+    wai_d2u b[CNT];
+#pragma unroll
+    for (int q = 0; q < CNT; q++) b[q] = __builtin_nontemporal_load(reinterpret_cast<const wai_d2u*>(basis + (size_t)(j0 + q) * ld) + i);
+#pragma unroll
+    for (int q = 0; q < CNT; q++) { v[q] += wi.x * b[q].x; v[q] += wi.y * b[q].y; }
+  };
+  size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  for (; i + stride < n2; i += 2 * stride) { one(i); one(i + stride); }
+  if (i < n2) one(i);
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < CNT; q++) v[q] += w[n - 1] * basis[(size_t)(j0 + q) * ld + n - 1];
   }
-  const int slots[8] = {S_H + j0, S_H + j0 + 1, S_H + j0 + 2, S_H + j0 + 3,
-                        S_H + j0 + 4, S_H + j0 + 5, S_H + j0 + 6, S_H + j0 + 7};
-  block_reduce_store<8>(v, partials, nb_max, slots);
+  int slots[CNT];
+#pragma unroll
+  for (int q = 0; q < CNT; q++) slots[q] = S_H + j0 + q;
+  block_reduce_store<CNT>(v, partials, nb_max, slots);
 }
-// w -= sum_j h_j v_j ; partial |w|^2
+// w -= sum_j h_j v_j ; partial |w|^2   (16-byte accesses, the basis vectors eight at a time: straight-line groups)
 __global__ __launch_bounds__(TPB) void k_maxpy_norm(double* __restrict__ w, const double* __restrict__ basis,
                                                     size_t ld, int k, int n, const double* __restrict__ s,
                                                     double* partials, int nb_max) {
   double v[1] = {0.0};
-  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
-    double wi = w[i];
-    for (int j = 0; j < k; j++) wi -= s[S_H + j] * basis[(size_t)j * ld + i];
-    w[i] = wi;
+  const size_t n2 = (size_t)n >> 1, stride = (size_t)gridDim.x * TPB;
+  wai_d2u* w2 = reinterpret_cast<wai_d2u*>(w);
+  for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n2; i += stride) {
+    wai_d2u wi = w2[i];
+    int j = 0;
+    for (; j + 8 <= k; j += 8) {
+      wai_d2u b[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) b[q] = __builtin_nontemporal_load(reinterpret_cast<const wai_d2u*>(basis + (size_t)(j + q) * ld) + i);
+#pragma unroll
+      for (int q = 0; q < 8; q++) { const double h = s[S_H + j + q]; wi.x -= h * b[q].x; wi.y -= h * b[q].y; }
+    }
+    for (; j < k; j++) {
+      const wai_d2u b = __builtin_nontemporal_load(reinterpret_cast<const wai_d2u*>(basis + (size_t)j * ld) + i);
+      const double h = s[S_H + j];
+      wi.x -= h * b.x; wi.y -= h * b.y;
+    }
+    w2[i] = wi;
+    v[0] += wi.x * wi.x; v[0] += wi.y * wi.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    double wi = w[n - 1];
+    for (int j = 0; j < k; j++) wi -= s[S_H + j] * basis[(size_t)j * ld + n - 1];
+    w[n - 1] = wi;
     v[0] += wi * wi;
   }
   const int slots[1] = {S_W2};
@@ -2929,9 +2970,12 @@ int gmres_mdot(wai_ctx* c, const double* w, int k) {
   const int g = vgrid(c->ks.n);
   for (int j0 = 0; j0 < k; j0 += 8) {
     const int cnt = (k - j0) < 8 ? (k - j0) : 8;
-    hipLaunchKernelGGL(k_mdot8, g, TPB, 0, c->stream, w, c->ks.basis, (size_t)c->ks.nl, j0, cnt, c->ks.n,
-                       c->ks.partials, c->ks.nb_max);
-    for (int q = 0; q < cnt; q += 4) vec_finalize(c, g, S_H + j0 + q, (cnt - q) < 4 ? (cnt - q) : 4, -1);
+#define MD(CNT) hipLaunchKernelGGL(k_mdot<CNT>, g, TPB, 0, c->stream, w, c->ks.basis, (size_t)c->ks.nl, j0, c->ks.n, c->ks.partials, c->ks.nb_max)
+    c->ks.n_launch++;
+    switch (cnt) { case 1: MD(1); break; case 2: MD(2); break; case 3: MD(3); break; case 4: MD(4); break;
+                   case 5: MD(5); break; case 6: MD(6); break; case 7: MD(7); break; default: MD(8); break; }
+#undef MD
+    vec_finalize(c, g, S_H + j0, cnt, -1);   // k_finalize sums any number of slots (five at a time) in one launch
   }
   return 0;
 }

@@ -19,6 +19,7 @@ int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
   if (!c || !ms_per_launch || reps <= 0) return -2;
   read_env(c);
   if (which == 16 && ensure_face_stream(c)) return -1;
+  if ((which == 20 || which == 21) && !c->ks.basis) { c->err = "wai_bench_kernel 20 / 21: no Krylov basis (ksp_type gmres)"; return -2; }
   if (which > 0 && !c->ilu.factored) { const int e = do_pc_setup(c); if (e) return e < 0 ? -1 : e; }
   Krylov& k = c->ks;
   const size_t copy_n = (size_t)c->np * c->df * c->mesh.n_prim / 2;   // modes 18 / 19 (the scratch is rewritten by every Jacobian)
@@ -58,6 +59,17 @@ int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
       case 19:   // the same bytes through the library's own copy kernel
         vec_copy(c, c->flu_pert + copy_n, c->flu_pert, copy_n);
         break;
+      case 20: {  // GMRES: the classical Gram-Schmidt inner products (w, v_0 .. v_j) of a whole restart cycle, j = 0 .. m - 1,
+                  // as ksp_gmres issues them (k_mdot passes + their finalisations); ms_per_launch = per Krylov iteration
+        const int m = std::min(std::max(c->opts.gmres_restart, 1), k.basis_m);
+        for (int j = 0; j < m; j++) gmres_mdot(c, k.T, j + 1);
+        break;
+      }
+      case 21: {  // GMRES: w -= sum h_j v_j + |w|^2 of a whole restart cycle (k_maxpy_norm + finalisation), per iteration
+        const int m = std::min(std::max(c->opts.gmres_restart, 1), k.basis_m);
+        for (int j = 0; j < m; j++) gmres_maxpy_norm(c, k.T, j + 1);
+        break;
+      }
       case 7:   // the second fused launch of the "fused" iteration: z = B^-1 A (R - alpha V) with the five inner products
         pc_amul(c, k.R, k.T, 4, k.RP, -1, pc_axpy_ok(c) ? k.V : nullptr, false);
         break;
@@ -83,6 +95,7 @@ int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
   float ms = 0.f;
   HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
   *ms_per_launch = ms / reps;
+  if (which == 20 || which == 21) *ms_per_launch /= (float)std::min(std::max(c->opts.gmres_restart, 1), k.basis_m);
 #ifdef WAI_PC_PHASES
   {
     unsigned long long ph[8];

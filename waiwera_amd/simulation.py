@@ -230,7 +230,7 @@ class Simulation:
     """One Waiwera input file -> mesh, flow simulation object and time stepper."""
 
     def __init__(self, inp, base_dir=".", ode_factory=None, device=0, mesh_builder=None, mesh_file=None,
-                 output_dir=None, rank=0, world=1, comm_id=None, owner=None):
+                 output_dir=None, rank=0, world=1, comm_id=None, owner=None, default_pc="asm"):
         """rank / world / comm_id (wai_comm_unique_id of rank 0, handed round by the host): one process per rank, each
         reads the whole input, keeps its own cells with one ghost layer (waiwera_amd.partition.partition_mesh; owner: rank of
         every cell, default contiguous blocks of the input's numbering) and runs the same step sequence -- what
@@ -238,6 +238,9 @@ class Simulation:
         and their device-side controls; not (yet) MINC zones, source networks, tracers, rock table controls, output files
         (fields() returns the rank's cells, self.owned_gid their index in the input's numbering)."""
         self.rank, self.world = int(rank), int(world)
+        if default_pc not in ("asm", "bjacobi"):
+            raise ValueError("default_pc 'asm' (the reference's default) or 'bjacobi' (the library's fused path)")
+        self.default_pc, self.pc_choice = default_pc, None
         # output files go to output_dir (default: $WAIWERA_OUTPUT_DIR, else beside the input file)
         self.output_dir = output_dir or os.environ.get("WAIWERA_OUTPUT_DIR") or base_dir
         self.output_error = None
@@ -491,9 +494,16 @@ class Simulation:
             opts["gmres_restart"] = lin["options"]["gmres"]["restart"]
         # preconditioner (src/timestepper.F90:1745-1757, default "asm"); "ilu" of a serial run is the
         # one-block case of either.  Sub-preconditioner ilu with "factor.levels" k (ILU(k), :1716-1718, 1827) or lu.
-        pct = (_get(lin, "preconditioner.type") or "asm").lower()
+        # An input that names no preconditioner gets the REFERENCE's default, restricted PCASM with overlap 1 over ILU(0)
+        # (default_flow_pc_type_str = "asm", src/timestepper.F90:2019-2020) -- not the library's own default
+        # (wai_default_opts: brick block Jacobi, the fused fast path).  Measured on the 216^3 bench system (round 6,
+        # profiles/pc_compare_r6.log): asm 74 Krylov iterations at 7.83 ms, bjacobi 98 at 1.39 ms; a host that wants the
+        # fast path for an unmodified input passes default_pc="bjacobi".  pc_choice records what was taken and why.
+        pct_in = _get(lin, "preconditioner.type")
+        pct = (pct_in or self.default_pc).lower()
         if pct not in ("asm", "bjacobi", "ilu", "lu", "none"):
             raise NotImplementedError("preconditioner type %r" % pct)
+        self.pc_choice = (pct, "input" if pct_in else ("reference default" if self.default_pc == "asm" else "default_pc argument"))
         opts["pc_type"] = {"ilu": "bjacobi"}.get(pct, pct)
         sub = _get(lin, "preconditioner.sub.preconditioner", {}) or {}
         subt = (sub.get("type") or "ilu").lower()
