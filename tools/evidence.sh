@@ -2,7 +2,7 @@
 # evidence pass of a round (ONE gpurun call = one box; TAG names the files: bench_${TAG}_c3.json ...): the whole GPU suite, the evidence runs for c3 / c4 / c5 (bench line, rocprofv3 kernel stats, PMC
 # traffic), the rank shares on the same box, the BASELINE shardings at full size over the loopback (comm fields)
 R=$GRAFT_REPO_ROOT
-TAG=${TAG:-r5}
+TAG=${TAG:-r6}
 mkdir -p gpurun_out/$TAG
 export TMPDIR=/tmp
 if [ -z "$SKIP_TESTS" ]; then python -m pytest tests -m gpu -q --durations=10 -p no:cacheprovider > gpurun_out/$TAG/pytest_gpu_final.log 2>&1; fi
@@ -34,7 +34,7 @@ for n in ["c3","c4","c5","c2","c3_share8","c4_share4","c5_share2"]:
 PY
 if [ -z "$SKIP_LOOPBACK" ]; then
 # BASELINE's shardings at full size, all ranks on this one GPU over the stream-asynchronous test transport
-TAG=$TAG bash tools/loopback_lines.sh "c5 2" "c4 4" "c3 8 --dt0 2000"
+TAG=$TAG bash tools/loopback_lines.sh "c5 2" "c4 4" "c3 2"
 fi
 if [ -z "$SKIP_SERIES" ]; then
 # SURVEY.md section 8d's second series: Corey (0.3, 0.05) curves, and GMRES(30) beside BiCGStab, at C2 and C3
