@@ -725,8 +725,9 @@ def main():
         log("micro %s fused launches as an iteration issues them (ms): first half %.4f, second half %.4f (composed %s) [WAI_PC_STAGE=%s]"
             % (a.config, sim.bench_kernel(2, a.spmv_reps), sim.bench_kernel(17, a.spmv_reps), sim.bcgs_composed(), os.environ.get("WAI_PC_STAGE", "default")))
         n_copy = (sim.n_prim * bs * sim.fluid_dof // 2) * 8
-        log("micro %s copy ceiling (GB/s, 2 x %d bytes / time): hipMemcpyDtoD %.0f, copy kernel %.0f"
-            % (a.config, n_copy, 2.0 * n_copy / sim.bench_kernel(18, 20) / 1e6, 2.0 * n_copy / sim.bench_kernel(19, 20) / 1e6))
+        log("micro %s copy ceiling (GB/s, 2 x %d bytes / time): hipMemcpyDtoD %.0f, streaming copy kernel %.0f, read-only stream %.0f"
+            % (a.config, n_copy, 2.0 * n_copy / sim.bench_kernel(18, 20) / 1e6, 2.0 * n_copy / sim.bench_kernel(19, 20) / 1e6,
+               2.0 * n_copy / sim.bench_kernel(22, 20) / 1e6))
         return
 
     # lead-in: the first accepted time steps, outside warm-up and timing
@@ -863,8 +864,9 @@ def main():
     n_copy = (sim.n_prim * bs * sim.fluid_dof // 2) * 8
     kb["copy_memcpy_d2d"] = sim.bench_kernel(18, 20)
     kb["copy_kernel"] = sim.bench_kernel(19, 20)
+    kb["read_kernel"] = sim.bench_kernel(22, 20)
     copy_gbs = {"hipMemcpyDtoD": 2.0 * n_copy / (kb["copy_memcpy_d2d"] * 1e-3) / 1e9, "copy_kernel": 2.0 * n_copy / (kb["copy_kernel"] * 1e-3) / 1e9,
-                "bytes_moved": 2 * n_copy}
+                "read_kernel": 2.0 * n_copy / (kb["read_kernel"] * 1e-3) / 1e9, "bytes_moved": 2 * n_copy}
     comm = None
     if world > 1:
         # what the collectives cost per BiCGStab iteration: the iteration's launches and collectives back to back without
@@ -997,7 +999,8 @@ def main():
                          "traffic_over_algorithmic": (traffic[0] / halves[dom]["bytes"]) if traffic and traffic[0] else None,
                          "algorithmic_bytes_per_launch": halves[dom]["bytes"], "ms_per_launch": halves[dom]["ms"],
                          # what a copy achieves on this box, measured in this run (2 x bytes / time)
-                         "copy_ceiling_gbs": max(copy_gbs["hipMemcpyDtoD"], copy_gbs["copy_kernel"]), "copy_ceiling": copy_gbs,
+                         "copy_ceiling_gbs": max(copy_gbs["hipMemcpyDtoD"], copy_gbs["copy_kernel"]), "read_ceiling_gbs": copy_gbs["read_kernel"],
+                         "copy_ceiling": copy_gbs,
                          # the metric's second half, flat: BCSR SpMV achieved GB/s and fraction of HBM peak
                          "spmv_gbs": achieved, "spmv_frac": achieved / HBM_PEAK_GBS, "spmv_ms_per_launch": ms,
                          "spmv_algorithmic_bytes_per_launch": b_spmv, "spmv_kernel": "k_spmv<%d> (BCSR SpMV)" % bs},

@@ -46,7 +46,8 @@ int wai_timer_stop(wai_ctx *ctx, float *ms);
  * 14 the five merged products left as partial sums, 15 the five + omega, (R,R), rho, beta finished in the launch,
  * 17 the iteration's second fused launch exactly as it is issued on one rank (composed operand where that is the default,
  * five products, scalars and the post to the host in the launch), 18 / 19 a device-to-device copy of half the perturbed-fluid
- * scratch onto the other half (hipMemcpyAsync / the library's copy kernel): the box's copy ceiling, 2 x bytes / time,
+ * scratch onto the other half (hipMemcpyAsync / a streaming copy kernel): the box's copy ceiling, 2 x bytes / time; 22 a
+ * read-only stream over the whole scratch: its read ceiling,
  * 20 / 21 GMRES's Gram-Schmidt inner products / its update w -= sum h_j v_j with |w|^2 over a whole restart cycle as
  * ksp_gmres issues them, reported per Krylov iteration (needs ksp_type gmres: the basis vectors) */
 int wai_bench_kernel(wai_ctx *ctx, int which, int reps, float *ms_per_launch);

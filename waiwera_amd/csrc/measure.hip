@@ -8,6 +8,33 @@ using namespace wai;
 namespace wai { void pc_phases_fetch(unsigned long long out[8], bool reset); }
 #endif
 
+namespace {
+// What the memory system gives a plain stream on this box, for the bench line's roofline.copy_ceiling / read_ceiling:
+// 16-byte streaming loads (and stores), two per thread and trip, enough workgroups to fill the chip.
+typedef double stream_d2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void k_stream_copy(const stream_d2* __restrict__ src, stream_d2* __restrict__ dst, size_t n2) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + stride < n2; i += 2 * stride) {
+    const stream_d2 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+    __builtin_nontemporal_store(a, dst + i);
+    __builtin_nontemporal_store(b, dst + i + stride);
+  }
+  if (i < n2) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+__global__ __launch_bounds__(256) void k_stream_read(const stream_d2* __restrict__ src, size_t n2, double* sink) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  double t = 0.0;
+  for (; i + stride < n2; i += 2 * stride) {
+    const stream_d2 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+    t += (a.x + a.y) + (b.x + b.y);
+  }
+  if (i < n2) { const stream_d2 a = __builtin_nontemporal_load(src + i); t += a.x + a.y; }
+  if (t == 1.2345678e300) *sink = t;   // never: keeps the loads
+}
+}  // namespace
+
 extern "C" {
 
 // Micro-benchmark of one kernel on the library's stream, HIP-event timed: which 0 = block SpMV,
@@ -56,8 +83,13 @@ int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
       case 18:   // what a copy achieves on this box: hipMemcpy device to device, half of the perturbed-fluid scratch onto the other
         hipMemcpyAsync(c->flu_pert + copy_n, c->flu_pert, copy_n * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
         break;
-      case 19:   // the same bytes through the library's own copy kernel
-        vec_copy(c, c->flu_pert + copy_n, c->flu_pert, copy_n);
+      case 19:   // the same bytes through a streaming copy kernel (16-byte non-temporal loads and stores)
+        hipLaunchKernelGGL(k_stream_copy, 8192, 256, 0, c->stream, reinterpret_cast<const stream_d2*>(c->flu_pert),
+                           reinterpret_cast<stream_d2*>(c->flu_pert + (copy_n & ~(size_t)1)), copy_n / 2);
+        break;
+      case 22:   // read-only stream over the whole scratch (2 x copy_n doubles)
+        hipLaunchKernelGGL(k_stream_read, 8192, 256, 0, c->stream, reinterpret_cast<const stream_d2*>(c->flu_pert), copy_n & ~(size_t)1,
+                           c->ks.scal + 60);
         break;
       case 20: {  // GMRES: the classical Gram-Schmidt inner products (w, v_0 .. v_j) of a whole restart cycle, j = 0 .. m - 1,
                   // as ksp_gmres issues them (k_mdot passes + their finalisations); ms_per_launch = per Krylov iteration
@@ -88,8 +120,14 @@ int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
   // Warm-up by TIME, not by count: the probes run behind host-side work (the bench's checks, a Jacobian), and the first
   // launches after such a pause run below the clocks the real iteration sees -- MEASURED (round 6, one box, same process
   // order): k_spmv 0.516 ms in the bench line's probe against 0.442 ms average over the traced run's 205 launches.  So:
-  // launches until 25 ms have gone by (at least 5, at most 2000), then the timed repetitions.
-  {
+  // launches until 25 ms have gone by (at least 5, at most twice the timed repetitions: a counter-collection pass pays
+  // tens of milliseconds of host time per dispatch and asks for few repetitions), then the timed repetitions.
+  // On several ranks the probes contain collectives: every rank must issue the same number of launches, so the count
+  // cannot depend on a rank's own clock -- five launches there, as in rounds 1-5 (the first form of this warm-up hung the
+  // multi-rank bench tests: the ranks' loop counts differed).
+  if (c->comm && c->comm->nranks > 1) {
+    for (int i = 0; i < 5; i++) run();
+  } else {
     float warm = 0.f;
     int n = 0;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -99,7 +137,7 @@ int wai_bench_kernel(wai_ctx* c, int which, int reps, float* ms_per_launch) {
       HIPCHK(c, hipEventRecord(c->ev1, c->stream));
       HIPCHK(c, hipEventSynchronize(c->ev1));
       HIPCHK(c, hipEventElapsedTime(&warm, c->ev0, c->ev1));
-    } while (warm < 25.f && n < 2000);
+    } while (warm < 25.f && n < std::max(10, 2 * reps));
   }
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   for (int i = 0; i < reps; i++) run();
