@@ -969,6 +969,9 @@ __device__ __forceinline__ void wg_reduce_store(double (&v)[NS], double* red, do
     if (lane == 0) red[s * 16 + w] = t;
   }
   __syncthreads();
+  // MEASURED AND REMOVED (round 6): one lane per slot for these NS sums (side by side instead of one after the other, same
+  // order inside each) -- the lane-indexed slot number sent the slot table to scratch memory (32 bytes per lane) and every
+  // fused launch ran 10 % slower (0.533 -> 0.586 ms at 216^3, 0.083 -> 0.089 at 108^3: profiles/exp_ab_r6_*.log).
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int s = 0; s < NS; s++) {
@@ -1484,6 +1487,9 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
       sum[r] = (part[0] + part[1]) + part[2];
     }
   };
+#ifdef WAI_PC_SETPRIO   // MEASURED (round 6, profiles/exp_ab_r6_*.log): the sweeps at raised wave priority -- 0.5333 -> 0.5345 ms first launch,
+  __builtin_amdgcn_s_setprio(3);   // 0.6663 -> 0.6741 composed at 216^3, no change at 108^3: instruction issue is 15 % busy, there is nothing to win a race for
+#endif
   for (int lev = 1; lev < nlf; lev++) {  // forward: y_i = t_i - sum A'_ik y_k
     if (lf == lev) {
       const double2 a = *reinterpret_cast<const double2*>(ys + tid * 2);
@@ -1516,6 +1522,9 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
     if (lev + 1 < nlb) __syncthreads();
   }
   PH(3);
+#ifdef WAI_PC_SETPRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
   if (active) store_z2(z, (size_t)i, out[0], out[1]);
   if (dot != 0) {
     double* red = lds + (size_t)blockDim.x * BS;
@@ -1539,7 +1548,10 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
       v[0] = out[0] * out[0] + out[1] * out[1];
       slots[0] = S_DP2;
     }
+#ifndef WAI_PC_EPI_NOBAR
     __syncthreads();
+#endif   // (-DWAI_PC_EPI_NOBAR: the reduction scratch is touched by nothing before this point, the barrier is not needed -- and
+         // not felt: 0.5704 / 0.6942 against 0.5714 / 0.6924 ms at 216^3, profiles/nobar_ab_r6_c3.log; kept as it was)
     if (dot == 4) wg_reduce_store<5>(v, red, partials, nb_max, slots, s);
     else if (dot == 2) { double v2[2] = {v[0], v[1]}; wg_reduce_store<2>(v2, red, partials, nb_max, slots, s); }
     else { double v1[1] = {v[0]}; wg_reduce_store<1>(v1, red, partials, nb_max, slots, s); }
