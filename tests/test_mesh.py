@@ -297,3 +297,29 @@ def test_brick_numberings_tile_the_same_mesh(brick_order, part):
                     rows = min(ty, len(ys) - (iy // ty) * ty)
                     cols = min(tx, len(xs) - (ix // tx) * tx)
                     assert up - s == rows * cols, (s, up, rows, cols)
+
+
+def test_partition_takes_the_communicators_size_and_refuses_empty_ranks():
+    """advisor (round 5): `world` is the communicator's, not whatever the owner array happens to reach; a rank without a
+    cell, an owner outside the communicator or a rank outside it is an error here, not a crash far downstream"""
+    from waiwera_amd.partition import block_owner, partition_mesh
+    g = M.StructuredGrid((4, 3, 2), brick=(2, 3, 2))
+    lm = g.local_mesh(0)
+    own = block_owner(lm.n_owned, 3)
+    m, gid = partition_mesh(lm, own, 1, chunk=4, world=3)
+    assert m.part == (3, 1, 1) and m.n_owned == (own == 1).sum()
+    with pytest.raises(ValueError, match="own no cell"):
+        partition_mesh(lm, own, 0, world=4)                    # ranks 0..2 own everything: rank 3 would be empty
+    with pytest.raises(ValueError, match="owner outside"):
+        partition_mesh(lm, own, 0, world=2)
+    with pytest.raises(ValueError, match="rank 3 of 3"):
+        partition_mesh(lm, own, 3, world=3)
+    with pytest.raises(ValueError, match="own no cell"):
+        partition_mesh(lm, np.where(own == 1, 2, own), 0)       # inferred world 3, nobody owns rank 1's share
+
+
+def test_run_module_strips_only_the_suffix():
+    from waiwera_amd.run import _stem
+    assert _stem("out/results.npz") == "out/results"
+    assert _stem("runs.npz.d/results.npz") == "runs.npz.d/results"      # a '.npz' elsewhere in the path stays
+    assert _stem("results") == "results" and _stem("a.npz.bak") == "a.npz.bak"
