@@ -1342,6 +1342,16 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
 // loads) and the lane's pick among them a chain of selects.  Same columns, same order, same bits.
 // (First form, one 16-bit plane per slot: 2 bytes less per block but the same seven loads -- MEASURED no faster: fused
 // launch 0.0845 -> 0.0859 ms at 108^3, 0.584 -> 0.581 at 216^3, profiles/col16_planes_ab_r5.log.)
+// MEASURED AND NOT KEPT (round 6, commit message "persistent k_pc_park" / profiles/persist_ab_r6_*.log): the launch as 768 PERSISTENT
+// workgroups (3 per CU), each walking the brick positions w, w + 768, ... of its XCD's eighth in a loop instead of giving its
+// slot back after one brick (the verdict's "no re-dispatch gap, bricks handed out by a cursor").  Same bits.  Two findings:
+// (i) the loop form alone costs registers -- 80 VGPRs and 20-36 bytes of scratch where the straight-line body has 73 and
+// none (loop-carried kernel arguments: 41-53 SGPR spills) -- 0.545 -> 0.627 ms first launch, 0.674 -> 0.769 composed at 216^3;
+// (ii) on that same code the persistent grid is SLOWER again than one workgroup per brick: 0.685 / 0.836 ms at 216^3, equal at
+// 108^3 and 100^3.  Re-dispatch is not a gap worth closing (a fresh workgroup is in its slot within the time a brick's
+// epilogue drains), and the dispatcher's hand-out -- whichever slot frees first -- decorrelates the bricks of a CU, which a
+// fixed stride never does: workgroups that started together stay in step, all loading, then all sweeping (the effect the
+// start-up cohorts were introduced against in round 4, now for the whole launch).
 // SL (round 6): the brick's OWN segment of the operand staged in LDS before the slot loop.  Each thread loads its row's
 // entry (coalesced; composed: R_i and V_i, S_i = fma(-alpha, V_i, R_i) formed once), stores it to the solution area and,
 // behind one barrier, the in-brick columns of a row -- slots [lfirst, ulast): the lower couplings, the diagonal, the
