@@ -26,16 +26,16 @@ NDEV = torch.cuda.device_count() if torch.cuda.is_available() else 0
 # WAI_REAL_RCCL_DRYRUN=1 (a one-GPU box): run THIS FILE's code -- workers, comparisons, the bench call -- with every rank on
 # device 0 over the test transport, so that a slip in the test itself is found before the first multi-GPU box runs it.
 # It proves nothing about RCCL and is not part of the suite.
-DRYRUN = os.environ.get("WAI_REAL_RCCL_DRYRUN") == "1" and NDEV == 1
+DRYRUN = os.environ.get("WAI_REAL_RCCL_DRYRUN", "") in ("1", "2", "4", "8") and NDEV == 1
 if DRYRUN:
-    NDEV = 2
+    NDEV = max(2, int(os.environ["WAI_REAL_RCCL_DRYRUN"]))      # "8": the 4- and 8-rank cases too
     from tests.test_hip_multirank import LOOPBACK, _own_cus
 needs_two = pytest.mark.skipif(NDEV < 2, reason="real RCCL needs one device per rank: %d visible" % NDEV)
 WORLDS = [w for w in (2, 4, 8) if w <= max(NDEV, 2)]
 
 
 def _real_worker(rank, world, uid_q, q, dims, brick, nsteps, overlap):
-    if os.environ.get("WAI_REAL_RCCL_DRYRUN") == "1":
+    if os.environ.get("WAI_REAL_RCCL_DRYRUN"):
         from tests.test_hip_multirank import LOOPBACK as lb, _own_cus as cus
         os.environ["WAI_RCCL_LIB"] = lb
         cus(rank, world)
@@ -54,7 +54,7 @@ def _real_worker(rank, world, uid_q, q, dims, brick, nsteps, overlap):
     else:
         uid = uid_q.get(timeout=300)
     g, lm, prim, region = _problem(M.partition_shape(world), rank, dims, brick)
-    sim = FlowSimulation(lm, eos="we", device=0 if os.environ.get("WAI_REAL_RCCL_DRYRUN") == "1" else rank)   # ONE DEVICE PER RANK
+    sim = FlowSimulation(lm, eos="we", device=0 if os.environ.get("WAI_REAL_RCCL_DRYRUN") else rank)   # ONE DEVICE PER RANK
     sim.set_regions(region)
     sim.comm_init(rank, world, uid)
     assert sim.comm_size() == world, (sim.comm_size(), world)
@@ -105,8 +105,8 @@ def test_bench_on_real_rccl(world):
     env = dict(os.environ, MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "WAI_RCCL_LIB", "WAI_BENCH_LOOPBACK", "HSA_CU_MASK", "WAI_HALO_OVERLAP"):
         env.pop(k, None)
-    if DRYRUN:
-        env.update(WAI_RCCL_LIB=LOOPBACK, WAI_BENCH_LOOPBACK="1")
+    if DRYRUN:      # (eight processes with two streams each time-slice the one GPU: in order there, as tests/test_hip_multirank.py does)
+        env.update(WAI_RCCL_LIB=LOOPBACK, WAI_BENCH_LOOPBACK="1", WAI_HALO_OVERLAP="1" if world == 2 else "0")
     dims = (64, 64, 32) if world < 8 else (64, 64, 64)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--lead", "1",
            "--window", "2", "--dims"] + [str(v) for v in dims] + ["--spmv-reps", "5", "--no-cpu"]
