@@ -969,6 +969,22 @@ __device__ __forceinline__ void wg_reduce_store(double (&v)[NS], double* red, do
     if (lane == 0) red[s * 16 + w] = t;
   }
   __syncthreads();
+#ifndef WAI_PC_EPI_ONE_LANE
+  // Round 6, one WAVE per slot: wave s's first lane adds the waves' sums of slot s (w = 0, 1, ... in order: same bits), the NS chains
+  // side by side; the callers' slot numbers are consecutive, so slot = first + wave (an indexed or selected table went to scratch).
+  // MEASURED (profiles/epiw_ab_r6_*.log, alternating same-box rounds): the composed launch with its five sums 0.6889 -> 0.6836 ms at
+  // 216^3, 0.0977 -> 0.0961 at 108^3 (three rounds each, every round the same sign); one-sum launches and k_pc_wave unchanged.
+  // (-DWAI_PC_EPI_ONE_LANE: thread 0 adds all slots, rounds 1-5.)
+  if (nw >= NS) {      // (a workgroup of fewer waves than slots: the one-lane form below)
+    if (lane == 0 && w < NS) {
+      const int slot = slots[0] + w;   // the callers' slots are consecutive (S_D1 .. S_W2, context.hpp)
+      double t = 0.0;
+      for (int q = 0; q < nw; q++) t += red[w * 16 + q];
+      store_partial(partials + (size_t)slot * nb_max + blk, t);
+    }
+    return;
+  }
+#endif
   // MEASURED AND REMOVED (round 6): one lane per slot for these NS sums (side by side instead of one after the other, same
   // order inside each) -- the lane-indexed slot number sent the slot table to scratch memory (32 bytes per lane) and every
   // fused launch ran 10 % slower (0.533 -> 0.586 ms at 216^3, 0.083 -> 0.089 at 108^3: profiles/exp_ab_r6_*.log).
