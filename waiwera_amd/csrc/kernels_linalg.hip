@@ -1417,6 +1417,10 @@ __global__ __launch_bounds__(512, 6) void k_pc_park(
     unpack_info(row_info[i], lfirst, dslot, ulast, lf, lb);
     uo = row_uoff[i];
     nU = ulast - dslot - 1;
+    // (MEASURED AND REMOVED, round 6: slot 0's block -- which needs nothing but the row number -- requested here, together with
+    // the descriptors and the index record, one dependent round trip less per brick: 77 VGPRs, no scratch, same bits, and
+    // 3 % SLOWER at 108^3 and 100^3 (first launch 0.0840 -> 0.0868, 0.0741 -> 0.0764 ms), no better at 216^3:
+    // profiles/hoist_ab_r6_*.log.  Like every earlier form that put more of a brick's loads in flight at once.)
     // all column indices first: one round trip instead of one per slot (MEASURED at 216^3, same box:
     // 0.6196 -> 0.6018 ms).  A branch-free 7-slot loop, which lets the compiler keep every slot's loads
     // in flight, needs more than the 80 registers of 6 waves per SIMD: 188 bytes of scratch, 0.965 ms;
