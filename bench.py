@@ -40,7 +40,20 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-DEFAULT_BRICK_ORDER = "x"
+# Numbering of a rank's bricks (memory and launch order).  "auto" (round 6): x fastest where the bricks above / below are then
+# within 64 positions (nbx * nby <= 64: C2, the rank shares), else columns of 4 x 4 bricks ("tile4x4": the vertical neighbours 16
+# positions away).  MEASURED (profiles/pmc_fused_border_r6_c3.txt, border_ab_r6_*.log): at 216^3 the composed fused launch reads
+# 3.53 GB from memory with "x" and 3.13 GB with "tile4x4" (compulsory: 2.98) -- at the same 0.66 ms: the launch is not bound by those
+# bytes, so this is a traffic choice, not a speed-up; the assembly sweeps read 7-10 % less and run 2-6 % faster.  At 100^3 and
+# 108^3 the tiling is 3-6 % slower per iteration (7 x 7 bricks per layer: "x" already keeps the neighbours close).
+DEFAULT_BRICK_ORDER = "auto"
+
+
+def resolve_brick_order(order, dims, part, brick):
+    if order != "auto":
+        return order
+    nb = [-(-(-(-d // p)) // b) for d, p, b in zip(dims, part, brick)]      # bricks per rank and axis
+    return "x" if nb[0] * nb[1] <= 64 else "tile4x4"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 CONFIGS = {  # C2 .. C5
@@ -186,7 +199,7 @@ def pc_bytes(nnzb, n, bs):
     return nnzb * (8 * bs * bs + 4) + n * (4 + 3 * 8 * bs)
 
 
-def traffic_from_profiles(cfg, dims, brick, kernel, composed=False):
+def traffic_from_profiles(cfg, dims, brick, kernel, composed=False, brick_order="x"):
     """(HBM bytes per fused-kernel launch, where from): read from the committed rocprofv3 PMC passes (profiles/;
     collected and corrected as MI355X_MICROARCH.md prescribes, tools/pmc_traffic.py) -- counters cannot be collected
     inside this run.  Only taken when the profile was made on THIS mesh, THESE bricks and THE kernel this run's fused
@@ -205,6 +218,8 @@ def traffic_from_profiles(cfg, dims, brick, kernel, composed=False):
         if "k_pc_park" in kernel:   # the 16-bit column indices (third template argument, round 5) change the launch's bytes
             targs = [t.strip() for t in pk[pk.find("<") + 1: pk.rfind(">")].split(",")] if "<" in pk else []
             same_kernel = same_kernel and (("col16" in kernel) == (len(targs) >= 3 and targs[2] == "true"))
+        if str(d.get("brick_order", "x")) != brick_order:       # the bricks' numbering changes what the gathers re-read
+            continue
         if list(d.get("dims", [])) == list(dims) and list(d.get("brick", [])) == list(brick) and same_kernel and d.get(key + "_hbm_bytes_per_launch"):
             return d.get(key + "_hbm_bytes_per_launch"), ("profiles/%s (separate rocprofv3 --pmc passes of this command on kernel %s; "
                                                           "not measured in this run)" % (name, pk))
@@ -640,6 +655,7 @@ def main():
     if a.brick_order is None:
         a.brick_order = DEFAULT_BRICK_ORDER
     brick = tuple(a.brick) if a.brick else ((4, 4, 2) if minc else ((8, 4, 2) if eos == "wce" else (16, 16, 2)))
+    a.brick_order = resolve_brick_order(a.brick_order, dims, M.partition_shape(world), brick)
     grid, lm, prim, region = make_case(dims=dims, brick=brick, eos=eos, lens=not a.no_lens, minc=minc,
                                        part=M.partition_shape(world), rank=rank, brick_order=a.brick_order, order=a.cell_order,
                                        balanced_bricks=bool(a.balanced_bricks))
@@ -942,7 +958,8 @@ def main():
     other = [k for k in halves if k != dom]
     traffic = None
     if world == 1:
-        traffic = traffic_from_profiles(a.config, dims, brick, halves[dom]["kernel"], composed=(dom == "second" and composed))
+        traffic = traffic_from_profiles(a.config, dims, brick, halves[dom]["kernel"], composed=(dom == "second" and composed),
+                                        brick_order=a.brick_order)
 
     if rank == 0:
         ksp_name = {"bcgs": "BiCGStab", "gmres": "GMRES(30)"}.get(a.ksp, a.ksp)

@@ -51,4 +51,10 @@ def test_byte_counts_and_host_description():
     assert b.pc_bytes(nnzb, n, bs) == nnzb * 36 + n * (4 + 48)
     p = b.physical_cores()
     assert p is None or (isinstance(p, int) and 1 <= p <= (os.cpu_count() or 1))
-    assert b.DEFAULT_BRICK_ORDER == "x"
+    # the bricks' numbering: "auto" keeps x fastest where the vertical neighbours are within 64 positions, else 4 x 4 columns
+    assert b.DEFAULT_BRICK_ORDER == "auto"
+    assert b.resolve_brick_order("auto", (216, 216, 216), (1, 1, 1), (16, 16, 2)) == "tile4x4"      # 14 x 14 bricks per layer
+    assert b.resolve_brick_order("auto", (216, 216, 216), (2, 2, 2), (16, 16, 2)) == "x"            # 7 x 7 per rank
+    assert b.resolve_brick_order("auto", (100, 100, 100), (1, 1, 1), (16, 16, 2)) == "x"
+    assert b.resolve_brick_order("auto", (172, 172, 170), (1, 1, 1), (8, 4, 2)) == "tile4x4"
+    assert b.resolve_brick_order("z", (216, 216, 216), (1, 1, 1), (16, 16, 2)) == "z"

@@ -51,7 +51,7 @@ def main(src, tag, dst):
            "correction": "HBM bytes = 2*FETCH_SIZE[KiB]*1024 + WRITE_SIZE[KiB]*1024 (gfx950: FETCH_SIZE tallies 128-B "
                          "requests at 64 B; calibrated on k_bcgs_p: 3 vectors read -> 2*%.0f KiB; 1 vector written -> "
                          "%.0f KiB)" % (fe.get("wai::k_bcgs_p", 0.0), wr.get("wai::k_bcgs_p", 0.0)),
-           "dims": dims, "brick": brick, "k_pc_kernel": pc,
+           "dims": dims, "brick": brick, "brick_order": bench["config"].get("brick_order", "x"), "k_pc_kernel": pc,
            "k_pc_hbm_bytes_per_launch": hbm(pc), "k_pc_algorithmic_bytes": alg_first,
            "k_pc_traffic_over_algorithmic": hbm(pc) / alg_first,
            "k_spmv_hbm_bytes_per_launch": hbm(sp), "k_spmv_algorithmic_bytes": roof["spmv_algorithmic_bytes_per_launch"],
