@@ -18,17 +18,21 @@ def test_traffic_is_taken_from_the_pass_of_the_launch_that_is_reported():
     """the composed second launch and the first launch have their own PMC figures; a profile of another mesh, brick shape or
     kernel gives None instead of a stale number"""
     b = _bench()
-    first = b.traffic_from_profiles("c3", (216, 216, 216), (16, 16, 2), "k_pc_park<spmv,col16>")
-    second = b.traffic_from_profiles("c3", (216, 216, 216), (16, 16, 2), "k_pc_park<spmv,col16,composed>", composed=True)
+    first = b.traffic_from_profiles("c3", (216, 216, 216), (16, 16, 2), "k_pc_park<spmv,col16>", brick_order="tile4x4")
+    second = b.traffic_from_profiles("c3", (216, 216, 216), (16, 16, 2), "k_pc_park<spmv,col16,composed>", composed=True, brick_order="tile4x4")
     assert first and second and second[0] > first[0] > 2.9e9
-    assert "k_pc_park<true, true" in second[1] and "k_pc_park<true, false" in first[1]
+    assert "k_pc_park<true, true" in second[1] and "k_pc_park<true, false" in first[1] and "r6" in second[1]
     alg2 = b.pc_bytes(70263936, 10077696, 2) + 8 * 2 * 10077696
-    assert 1.0 < second[0] / alg2 < 1.2
+    assert 1.0 < second[0] / alg2 < 1.07                 # round 5's verdict bar for the composed launch
+    # the bricks' numbering is part of the match: round 6's pass was made with 4 x 4 columns, round 5's x fastest
+    x5 = b.traffic_from_profiles("c3", (216, 216, 216), (16, 16, 2), "k_pc_park<spmv,col16,composed>", composed=True, brick_order="x")
+    assert x5 and "r5" in x5[1] and x5[0] > second[0]
     assert b.traffic_from_profiles("c3", (108, 108, 108), (16, 16, 2), "k_pc_park<spmv,col16>") is None
+    assert b.traffic_from_profiles("c3", (216, 216, 216), (16, 16, 2), "k_pc_park<spmv,col16>", brick_order="z") is None
     assert b.traffic_from_profiles("c3", (216, 216, 216), (16, 16, 2), "k_pc_rows<2,spmv,3+3>") is None
     old = b.traffic_from_profiles("c3", (216, 216, 216), (16, 16, 2), "k_pc_park<spmv>")      # int32 column planes: other bytes,
     assert old and "r4" in old[1] and old[0] > first[0]                                            # so round 4's pass of THAT kernel
-    w = b.traffic_from_profiles("c4", (172, 172, 170), (8, 4, 2), "k_pc_wave<3,spmv,composed>", composed=True)
+    w = b.traffic_from_profiles("c4", (172, 172, 170), (8, 4, 2), "k_pc_wave<3,spmv,composed>", composed=True, brick_order="tile4x4")
     assert w and "k_pc_wave<3, true, true" in w[1]
 
 
