@@ -1358,7 +1358,9 @@ __global__ __launch_bounds__(1024, (BS <= 2 ? PC_MIN_WAVES : 4)) void k_pc(int n
 // loads) and the lane's pick among them a chain of selects.  Same columns, same order, same bits.
 // (First form, one 16-bit plane per slot: 2 bytes less per block but the same seven loads -- MEASURED no faster: fused
 // launch 0.0845 -> 0.0859 ms at 108^3, 0.584 -> 0.581 at 216^3, profiles/col16_planes_ab_r5.log.)
-// MEASURED AND NOT KEPT (round 6, commit message "persistent k_pc_park" / profiles/persist_ab_r6_*.log): the launch as 768 PERSISTENT
+// MEASURED AND NOT KEPT (round 6, profiles/persist_ab_r6_*.log; the variant was never committed -- this note is its record: the body
+// below inside `for (bpos = blockIdx.x; bpos < padded count; bpos += G)`, G = gridDim.x - finalisers, a barrier at the loop's end,
+// grid = 3 x CUs rounded to a multiple of 8): the launch as 768 PERSISTENT
 // workgroups (3 per CU), each walking the brick positions w, w + 768, ... of its XCD's eighth in a loop instead of giving its
 // slot back after one brick (the verdict's "no re-dispatch gap, bricks handed out by a cursor").  Same bits.  Two findings:
 // (i) the loop form alone costs registers -- 80 VGPRs and 20-36 bytes of scratch where the straight-line body has 73 and
